@@ -1,0 +1,351 @@
+// ============================================================================
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_core.hpp header).
+// extern "C" surface of the CPU oracle, loaded with ctypes by tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Never linked into
+// or called from the product library.
+// ============================================================================
+#include "oracle_search.hpp"
+#include <atomic>
+#include <thread>
+
+using namespace orc;
+
+extern "C" {
+
+struct orc_index_desc {
+    uint64_t text_length; // n including '$'
+    const uint8_t* text;
+    uint64_t counts[5];
+    uint64_t dollar_pos_fwd;
+    const uint64_t* bv_fwd;
+    const uint64_t* cnt_fwd;
+    uint64_t dollar_pos_rev;
+    const uint64_t* bv_rev;
+    const uint64_t* cnt_rev;
+    const uint64_t* bwt_words; // EncodedText<5> words
+    const uint64_t* sa_bv;
+    const uint64_t* sa_bv_counts;
+    const uint32_t* sa_samples;
+    uint32_t sa_sparseness;
+    uint32_t switch_point;
+    uint32_t kmer_size;
+    uint32_t n_seqs;
+    const uint32_t* seq_starts;
+};
+
+struct orc_occ {
+    uint32_t begin, end, distance, strand;
+};
+
+struct OrcIndex {
+    Index idx;
+};
+
+// populateTable indexinterface.cpp:294-335 (forward direction, bidirectional)
+static void populateTable(Index& idx) {
+    const len_t w = idx.wordSize;
+    idx.kmerTable.assign(1ull << (2 * w), RangePair());
+    if (w == 0) {
+        idx.kmerTable[0] = idx.completeRange();
+        return;
+    }
+    struct Node {
+        RangePair r;
+        len_t row;
+        uint64_t key;
+    };
+    std::vector<Node> stack;
+    auto extend = [&](const RangePair& parent, len_t row, uint64_t key) {
+        for (len_t i = 1; i < 5; ++i) {
+            RangePair child;
+            if (idx.extendForward(i, parent, child))
+                stack.push_back({child, row + 1, (key << 2) | (i - 1)});
+        }
+    };
+    extend(idx.completeRange(), 0, 0);
+    while (!stack.empty()) {
+        Node cur = stack.back();
+        stack.pop_back();
+        if (cur.row == w)
+            idx.kmerTable[cur.key] = cur.r;
+        else
+            extend(cur.r, cur.row, cur.key);
+    }
+}
+
+void* orc_index_create(const orc_index_desc* d) {
+    OrcIndex* h = new OrcIndex();
+    Index& x = h->idx;
+    x.textLength = (len_t)d->text_length;
+    x.text = d->text;
+    for (int i = 0; i < 5; i++) x.counts[i] = (len_t)d->counts[i];
+    const uint64_t N = d->text_length + 1;
+    x.fwd.bv = BitvecIntl4{N, d->bv_fwd, d->cnt_fwd};
+    x.fwd.dollarPos = d->dollar_pos_fwd;
+    x.rev.bv = BitvecIntl4{N, d->bv_rev, d->cnt_rev};
+    x.rev.dollarPos = d->dollar_pos_rev;
+    x.bwt.words = d->bwt_words;
+    x.bwt.tSize = d->text_length;
+    x.saMark = Bitvec9{d->text_length, d->sa_bv, d->sa_bv_counts};
+    x.saSamples = d->sa_samples;
+    x.sparseness = d->sa_sparseness;
+    x.switchPoint = d->switch_point;
+    x.wordSize = d->kmer_size;
+    x.seqStarts.assign(d->seq_starts, d->seq_starts + d->n_seqs);
+    populateTable(x);
+    return h;
+}
+void orc_index_destroy(void* h) { delete (OrcIndex*)h; }
+
+const void* orc_index_kmer_table(void* h, uint64_t* nEntries) {
+    Index& x = ((OrcIndex*)h)->idx;
+    *nEntries = x.kmerTable.size();
+    return x.kmerTable.data(); // 4 x u32 per entry: sa.b, sa.e, rev.b, rev.e
+}
+
+// ---- builders (format restatements) ---------------------------------------
+void orc_build_bitvec_intl(const uint8_t* codes, uint64_t n, uint64_t* bv, uint64_t* counts,
+                           uint64_t* dollarPos) {
+    buildBitvecIntl4(codes, n, bv, counts, *dollarPos);
+}
+void orc_build_bitvec9_counts(const uint64_t* bv, uint64_t nWords, uint64_t* counts) {
+    buildBitvec9Counts(bv, nWords, counts);
+}
+void orc_encode_bwt(const uint8_t* codes, uint64_t n, uint64_t* out) {
+    EncodedBWT::encode(codes, n, out);
+}
+uint64_t orc_bwt_at(const uint64_t* words, uint64_t i) {
+    EncodedBWT e;
+    e.words = words;
+    return e.at(i);
+}
+
+// ---- primitive hooks --------------------------------------------------------
+// a1: rank
+void orc_rank_batch(void* h, int rev, const uint32_t* c, const uint64_t* p, uint64_t n,
+                    uint64_t* out) {
+    Index& x = ((OrcIndex*)h)->idx;
+    const BWTRepr& r = rev ? x.rev : x.fwd;
+    for (uint64_t i = 0; i < n; i++) out[i] = r.bv.rank(c[i], p[i]);
+}
+// a2: occ / cumOcc
+void orc_occ_batch(void* h, int rev, const uint32_t* c, const uint64_t* p, uint64_t n,
+                   uint64_t* occ, uint64_t* cum) {
+    Index& x = ((OrcIndex*)h)->idx;
+    const BWTRepr& r = rev ? x.rev : x.fwd;
+    for (uint64_t i = 0; i < n; i++) {
+        occ[i] = r.occ((int)c[i], p[i]);
+        cum[i] = r.cumOcc((int)c[i], p[i]);
+    }
+}
+// a3/a4: all four children of n parents.  mode: 0 forward, 1 backward, 2 uni-backward
+// in: n x {sa.b, sa.e, rev.b, rev.e}; out: n x 4 x {sa.b, sa.e, rev.b, rev.e}; ok: n x 4
+void orc_extend_batch(void* h, int mode, const uint32_t* in, uint64_t n, uint32_t* out,
+                      uint8_t* ok) {
+    Index& x = ((OrcIndex*)h)->idx;
+    for (uint64_t i = 0; i < n; i++) {
+        RangePair p(Range(in[4 * i], in[4 * i + 1]), Range(in[4 * i + 2], in[4 * i + 3]));
+        for (len_t c = 1; c < 5; c++) {
+            RangePair ch;
+            bool o = mode == 0 ? x.extendForward(c, p, ch)
+                               : (mode == 1 ? x.extendBackward(c, p, ch) : x.extendBackwardUni(c, p, ch));
+            uint32_t* q = out + (i * 4 + (c - 1)) * 4;
+            q[0] = ch.sa.b;
+            q[1] = ch.sa.e;
+            q[2] = ch.rev.b;
+            q[3] = ch.rev.e;
+            ok[i * 4 + (c - 1)] = o;
+        }
+    }
+}
+// a10: locate
+void orc_locate_batch(void* h, const uint32_t* rows, uint64_t n, uint32_t* out, uint64_t* lfSteps) {
+    Index& x = ((OrcIndex*)h)->idx;
+    Counters cnt;
+    for (uint64_t i = 0; i < n; i++) out[i] = x.findSA(rows[i], cnt);
+    if (lfSteps) *lfSteps = cnt.c[LF_STEPS];
+}
+
+// ---- strategy ---------------------------------------------------------------
+void* orc_strategy_create(int metric, int partition, uint32_t kmerCutOff) {
+    Strategy* s = new Strategy();
+    s->metric = (DistanceMetric)metric;
+    s->partition = (PartitionStrategy)partition;
+    s->useKmerCutOff = kmerCutOff;
+    return s;
+}
+void orc_strategy_destroy(void* s) { delete (Strategy*)s; }
+// add one scheme for distance k: nSearches x nParts arrays (row-major)
+int orc_strategy_add_scheme(void* sp, uint32_t k, uint32_t nSearches, uint32_t nParts,
+                            const uint32_t* pi, const uint32_t* L, const uint32_t* U) {
+    Strategy* s = (Strategy*)sp;
+    try {
+        std::vector<Search> searches;
+        for (uint32_t i = 0; i < nSearches; i++) {
+            std::vector<len_t> o(pi + i * nParts, pi + (i + 1) * nParts);
+            std::vector<len_t> l(L + i * nParts, L + (i + 1) * nParts);
+            std::vector<len_t> u(U + i * nParts, U + (i + 1) * nParts);
+            searches.push_back(Search::makeSearch(o, l, u, i));
+        }
+        if (s->schemesPerK.size() <= k) s->schemesPerK.resize(k + 1);
+        s->schemesPerK[k].emplace_back(searches, k);
+    } catch (const std::exception& e) {
+        return -1;
+    }
+    return 0;
+}
+void orc_strategy_set_partition_params(void* sp, uint32_t k, const double* seeding, uint32_t nSeed,
+                                       const uint64_t* weights, uint32_t nW, const double* begins,
+                                       uint32_t nB) {
+    Strategy* s = (Strategy*)sp;
+    if (s->seedingPositions.size() <= k) s->seedingPositions.resize(k + 1);
+    if (s->weights.size() <= k) s->weights.resize(k + 1);
+    if (s->begins.size() <= k) s->begins.resize(k + 1);
+    s->seedingPositions[k].assign(seeding, seeding + nSeed);
+    s->weights[k].assign(weights, weights + nW);
+    s->begins[k].assign(begins, begins + nB);
+}
+// search metadata for pinning against search.h (a14)
+// out: directions[n], dswitch[n], low[n], high[n], uniBackwards(idx)[n]
+void orc_search_info(const uint32_t* pi, const uint32_t* L, const uint32_t* U, uint32_t n,
+                     uint32_t* out) {
+    std::vector<len_t> o(pi, pi + n), l(L, L + n), u(U, U + n);
+    Search s = Search::makeSearch(o, l, u, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        out[i] = s.getDirection(i);
+        out[n + i] = s.getDirectionSwitch(i);
+        out[2 * n + i] = s.lowHigh[i].first;
+        out[3 * n + i] = s.lowHigh[i].second;
+        out[4 * n + i] = s.isUnidirectionalBackwards(i);
+    }
+}
+uint32_t orc_scheme_critical_part(void* sp, uint32_t k, uint32_t schemeIdx) {
+    return ((Strategy*)sp)->schemesPerK[k][schemeIdx].criticalPartIndex;
+}
+
+// ---- matrix dump for pinning against bitparallelmatrix.{h,cpp} (a5) ---------
+// X: horizontal sequence (already in the order it is accessed), Y: vertical.
+// rows_out: per computed row i (1-based, index i-1): {valid, HP, HN, D0, RAC, score,
+// at(i,lastCol) if inFinalColumn else ~0, onlyVerticalGapsLeft, firstCol, inFinalColumn}
+// returns number of rows computed (stops after the first invalid row)
+uint32_t orc_matrix_dump(const char* X, uint32_t xlen, const char* Y, uint32_t ylen,
+                         uint32_t maxED, const uint32_t* initED, uint32_t nInit,
+                         uint64_t* rows_out, uint32_t* geom /*m,n,Wv,Wh,sizeFinalCol*/) {
+    BitParallelED64 M;
+    Substring sx(X, xlen, 0, xlen, FORWARD);
+    M.setSequence(sx);
+    M.initializeMatrix(maxED, std::vector<uint32_t>(initED, initED + nInit));
+    geom[0] = M.getNumberOfRows();
+    geom[1] = M.getNumberOfCols();
+    geom[2] = M.getWv();
+    geom[3] = M.getWh();
+    geom[4] = M.getSizeOfFinalColumn();
+    uint32_t i = 0;
+    for (; i < ylen && i + 1 < M.getNumberOfRows(); i++) {
+        bool v = M.computeRow(i + 1, Y[i]);
+        uint64_t* o = rows_out + (uint64_t)i * 10;
+        const BitVectors& r = M.row(i + 1);
+        o[0] = v;
+        o[1] = r.HP;
+        o[2] = r.HN;
+        o[3] = r.D0;
+        o[4] = r.RAC;
+        o[5] = r.score;
+        o[6] = M.inFinalColumn(i + 1) ? M.at(i + 1, M.getNumberOfCols() - 1) : ~0ull;
+        o[7] = M.onlyVerticalGapsLeft(i + 1);
+        o[8] = M.getFirstColumn(i + 1);
+        o[9] = M.inFinalColumn(i + 1);
+        if (!v) {
+            i++;
+            break;
+        }
+    }
+    return i;
+}
+
+// in-text verification of one pattern against many start positions (a11)
+// returns number of occurrences written (<= cap)
+uint64_t orc_verify_batch(void* h, const char* pattern, uint32_t plen, const uint32_t* starts,
+                          uint64_t n, uint32_t maxED, uint32_t minED, int fixedStart,
+                          orc_occ* out, uint64_t cap, uint64_t* counters_out) {
+    Index& x = ((OrcIndex*)h)->idx;
+    Strategy st;
+    Matcher m(x, st);
+    std::string pat(pattern, plen);
+    Substring p(pat.data(), plen, 0, plen, FORWARD);
+    Occurrences occ;
+    std::vector<len_t> sp(starts, starts + n);
+    m.inTextVerification(sp, maxED, minED, occ, p, fixedStart != 0);
+    uint64_t k = 0;
+    for (auto& t : occ.inTextOcc) {
+        if (k < cap) out[k] = {t.range.b, t.range.e, t.distance, (uint32_t)t.strand};
+        k++;
+    }
+    if (counters_out) memcpy(counters_out, m.counters.c, sizeof(m.counters.c));
+    return k;
+}
+
+// ---- batch matching (the §8b boundary) -------------------------------------
+struct OrcResult {
+    std::vector<orc_occ> occs;
+    std::vector<uint64_t> offs; // nReads + 1
+    Counters counters;
+    std::string error;
+};
+
+void* orc_match_batch(void* h, void* sp, uint32_t k, const char* seqs, const uint64_t* offs,
+                      uint32_t nReads, uint32_t nThreads) {
+    Index& x = ((OrcIndex*)h)->idx;
+    Strategy& st = *(Strategy*)sp;
+    OrcResult* res = new OrcResult();
+    std::vector<std::vector<orc_occ>> per(nReads);
+    if (nThreads == 0) nThreads = 1;
+    std::vector<Counters> cnts(nThreads);
+    std::vector<std::string> errs(nThreads);
+    std::atomic<uint32_t> next(0);
+    auto work = [&](uint32_t tid) {
+        Matcher m(x, st);
+        try {
+            for (;;) {
+                uint32_t base = next.fetch_add(64); // processChunk granularity parallel.cpp:67
+                if (base >= nReads) break;
+                uint32_t end = std::min(nReads, base + 64);
+                for (uint32_t r = base; r < end; r++) {
+                    std::string read = Matcher::cleanRead(std::string(seqs + offs[r], offs[r + 1] - offs[r]));
+                    auto v = m.matchApproxAll(read, k);
+                    per[r].reserve(v.size());
+                    for (auto& t : v)
+                        per[r].push_back({t.range.b, t.range.e, t.distance, (uint32_t)t.strand});
+                }
+            }
+        } catch (const std::exception& e) {
+            errs[tid] = e.what();
+        }
+        cnts[tid] = m.counters;
+    };
+    std::vector<std::thread> th;
+    for (uint32_t t = 1; t < nThreads; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& t : th) t.join();
+    for (auto& e : errs)
+        if (!e.empty()) res->error = e;
+    res->offs.resize(nReads + 1, 0);
+    for (uint32_t r = 0; r < nReads; r++) res->offs[r + 1] = res->offs[r] + per[r].size();
+    res->occs.reserve(res->offs[nReads]);
+    for (uint32_t r = 0; r < nReads; r++)
+        res->occs.insert(res->occs.end(), per[r].begin(), per[r].end());
+    for (auto& c : cnts) res->counters.add(c);
+    return res;
+}
+const char* orc_result_error(void* r) { return ((OrcResult*)r)->error.c_str(); }
+uint64_t orc_result_size(void* r) { return ((OrcResult*)r)->occs.size(); }
+void orc_result_copy(void* r, orc_occ* occs, uint64_t* offs, uint64_t* counters) {
+    OrcResult* res = (OrcResult*)r;
+    if (occs && !res->occs.empty()) memcpy(occs, res->occs.data(), res->occs.size() * sizeof(orc_occ));
+    if (offs) memcpy(offs, res->offs.data(), res->offs.size() * 8);
+    if (counters) memcpy(counters, res->counters.c, sizeof(res->counters.c));
+}
+void orc_result_free(void* r) { delete (OrcResult*)r; }
+uint32_t orc_num_counters() { return COUNTER_TYPE_MAX; }
+
+} // extern "C"

@@ -1,0 +1,741 @@
+// ============================================================================
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+//
+// CPU restatement of the search-scheme FM-index hot path of biointec/columba
+// v2.0.3 (Vanilla flavour, 32-bit length_t, ALPHABET=5).  Only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this code,
+// and there only as the checker.  The product (columba_amd/csrc) never
+// includes, links or calls anything in this directory.
+//
+// Pinning status:
+//   * rank/occ/cumOcc, BitvecIntl layout, Bitvec rank9, EncodedText, the
+//     bit-parallel matrix (setSequence/initializeMatrix/computeRow/at/
+//     onlyVerticalGapsLeft/findClusterCenters/traceBack), Search::makeSearch,
+//     SearchScheme critical part: PINNED against the reference's own headers
+//     compiled unmodified into oracle/_ref (oracle/Makefile, tests/golden).
+//   * DFS / partitioning / in-text orchestration / filter
+//     (indexinterface.cpp, searchstrategy.cpp, fmindex.cpp): restated from the
+//     source; the reference translation units need parallel_hashmap, which is
+//     absent from this image, so they cannot be built without a stand-in:
+//     PARITY UNPINNED for that layer (checked by brute-force properties only).
+//
+// Every function cites the reference file:line it follows (paths relative to
+// /root/reference/src).
+// ============================================================================
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cassert>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace orc {
+
+typedef uint32_t len_t; // definitions.h:69-75 with -DTHIRTY_TWO
+
+enum Direction { FORWARD = 0, BACKWARD = 1 };   // definitions.h:103
+enum Strand { FORWARD_STRAND = 0, REVERSE_C_STRAND = 1 };
+enum PartitionStrategy { UNIFORM = 0, STATIC = 1, DYNAMIC = 2 }; // definitions.h:112
+enum DistanceMetric { HAMMING = 0, EDIT = 1 };   // definitions.h:114
+
+// ----------------------------------------------------------------------------
+// Counters (indexhelpers.h:1846-1941) + byte-model counters of SURVEY §8(d)
+// ----------------------------------------------------------------------------
+enum CounterType {
+    NODE_COUNTER = 0,
+    TOTAL_REPORTED_POSITIONS,
+    IN_TEXT_STARTED,
+    ABORTED_IN_TEXT_VERIF,
+    CIGARS_IN_TEXT_VERIFICATION,
+    IMMEDIATE_SWITCH,
+    SEARCH_STARTED,
+    // roofline byte model (not in the reference): E, L, R, T, matrix rows
+    EXPANSIONS,   // extend calls at one parent (4-symbol extendFMPos = 1, addChar = 1)
+    LF_STEPS,     // findLF calls
+    LOCATED_ROWS, // findSA calls
+    TEXT_BYTES,   // text characters read by in-text verification
+    MATRIX_ROWS,  // computeRow calls
+    COUNTER_TYPE_MAX
+};
+struct Counters {
+    uint64_t c[COUNTER_TYPE_MAX];
+    Counters() { memset(c, 0, sizeof(c)); }
+    void inc(CounterType t, uint64_t a = 1) { c[t] += a; }
+    void add(const Counters& o) {
+        for (int i = 0; i < COUNTER_TYPE_MAX; i++) c[i] += o.c[i];
+    }
+};
+
+// ----------------------------------------------------------------------------
+// Range / SARangePair (indexhelpers.h:63-127, :1117-1243)
+// ----------------------------------------------------------------------------
+struct Range {
+    len_t b = 0, e = 0;
+    Range() {}
+    Range(len_t b_, len_t e_) : b(b_), e(e_) {}
+    bool empty() const { return e <= b; }
+    len_t width() const { return empty() ? 0 : e - b; }
+    bool operator==(const Range& o) const { return b == o.b && e == o.e; }
+};
+struct RangePair {
+    Range sa, rev;
+    RangePair() {}
+    RangePair(Range a, Range r) : sa(a), rev(r) {}
+    bool empty() const { return sa.empty(); }
+    len_t width() const { return sa.width(); }
+    bool operator==(const RangePair& o) const { return sa == o.sa; } // :1226
+};
+
+// ----------------------------------------------------------------------------
+// BitvecIntl<4> (bitvec.h:234-478): S bitvectors interleaved word by word,
+// counts interleaved (L1 absolute, L2 seven 9-bit partials)
+// ----------------------------------------------------------------------------
+struct BitvecIntl4 {
+    uint64_t N = 0;
+    const uint64_t* bv = nullptr;
+    const uint64_t* counts = nullptr;
+    static uint64_t bvWords(uint64_t N) { return 4 * ((N + 63) / 64); }      // :262
+    static uint64_t cntWords(uint64_t N) { return 2 * 4 * ((N + 511) / 512); } // :273
+    // bitvec.h:356-372
+    uint64_t rank(uint64_t c, uint64_t p) const {
+        uint64_t w = (p / 64) * 4 + c;
+        uint64_t b = p % 64;
+        uint64_t q = (p / 512) * 2 * 4 + 2 * c;
+        uint64_t rv = counts[q];
+        int64_t t = (int64_t)((p / 64) % 8) - 1;
+        rv += counts[q + 1] >> (t + (t >> 60 & 8)) * 9 & 0x1FF;
+        return rv + __builtin_popcountll((bv[w] << 1) << (63 - b));
+    }
+    bool get(uint64_t c, uint64_t p) const { // :304
+        return (bv[(p / 64) * 4 + c] >> (p % 64)) & 1ull;
+    }
+};
+
+// bitvec.h:329-349 (index()) together with bwtrepr.h:56-72 (cumulative
+// encoding: bit (c-1) set for every c >= c2i(BWT[i]); '$' not encoded)
+inline void buildBitvecIntl4(const uint8_t* bwtCodes /*0..4, 0 = $*/, uint64_t n,
+                             uint64_t* bv, uint64_t* counts,
+                             uint64_t& dollarPos) {
+    const uint64_t N = n + 1; // bwtrepr.h:57
+    const uint64_t bvSize = BitvecIntl4::bvWords(N);
+    const uint64_t cSize = BitvecIntl4::cntWords(N);
+    memset(bv, 0, bvSize * 8);
+    memset(counts, 0, cSize * 8);
+    dollarPos = n;
+    for (uint64_t i = 0; i < n; i++) {
+        if (bwtCodes[i] == 0) {
+            dollarPos = i;
+            continue;
+        }
+        for (uint64_t cIdx = bwtCodes[i]; cIdx < 5; cIdx++)
+            bv[(i / 64) * 4 + (cIdx - 1)] |= 1ull << (i % 64);
+    }
+    const uint64_t S = 4;
+    for (uint64_t c = 0; c < S; c++) {
+        uint64_t countL1 = 0, countL2 = 0;
+        for (uint64_t w = c, q = 2 * c; w < bvSize; w += S) {
+            uint64_t numBits = __builtin_popcountll(bv[w]);
+            if (w % (8 * S) == c) {
+                countL1 += countL2;
+                counts[q] = countL1;
+                countL2 = numBits;
+                q += 2 * S;
+            } else {
+                uint64_t L2offs = 9 * ((w / S % 8) - 1);
+                counts[q + 1 - 2 * S] |= (countL2 << L2offs);
+                countL2 += numBits;
+            }
+        }
+    }
+}
+
+// BWTRepresentation<5> (fmindex/bwtrepr.h:80-107)
+struct BWTRepr {
+    BitvecIntl4 bv;
+    uint64_t dollarPos = 0;
+    uint64_t occ(int cIdx, uint64_t k) const {
+        if (cIdx == 0) return (k <= dollarPos) ? 0 : 1;
+        return (cIdx == 1) ? bv.rank(0, k)
+                           : bv.rank(cIdx - 1, k) - bv.rank(cIdx - 2, k);
+    }
+    uint64_t cumOcc(int cIdx, uint64_t k) const {
+        if (cIdx == 0) return 0;
+        return (cIdx == 1) ? ((k <= dollarPos) ? 0 : 1)
+                           : bv.rank(cIdx - 2, k) + ((k <= dollarPos) ? 0 : 1);
+    }
+};
+
+// ----------------------------------------------------------------------------
+// Bitvec (rank9, bitvec.h:97-224)
+// ----------------------------------------------------------------------------
+struct Bitvec9 {
+    uint64_t N = 0;
+    const uint64_t* bv = nullptr;
+    const uint64_t* counts = nullptr;
+    static uint64_t bvWords(uint64_t N) { return (N + 63) / 64; }
+    static uint64_t cntWords(uint64_t N) { return (bvWords(N) + 7) / 4; } // :135
+    bool get(uint64_t p) const { return (bv[p / 64] >> (p % 64)) & 1ull; }
+    uint64_t rank(uint64_t p) const { // :155-170
+        uint64_t w = p / 64, b = p % 64, q = (w / 8) * 2;
+        uint64_t rv = counts[q];
+        int64_t t = (int64_t)(w % 8) - 1;
+        rv += counts[q + 1] >> (t + (t >> 60 & 8)) * 9 & 0x1FF;
+        return rv + __builtin_popcountll((bv[w] << 1) << (63 - b));
+    }
+};
+inline void buildBitvec9Counts(const uint64_t* bv, uint64_t nWords,
+                               uint64_t* counts) { // :134-149
+    uint64_t cw = (nWords + 7) / 4;
+    memset(counts, 0, cw * 8);
+    uint64_t countL1 = 0, countL2 = 0;
+    for (uint64_t w = 0, q = 0; w < nWords; w++) {
+        if (w % 8 == 0) {
+            countL1 += countL2;
+            counts[q] = countL1;
+            countL2 = __builtin_popcountll(bv[w]);
+            q += 2;
+        } else {
+            counts[q - 1] |= (countL2 << (((w % 8) - 1) * 9));
+            countL2 += __builtin_popcountll(bv[w]);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// EncodedText<5> access (fmindex/encodedtext.h:233-248): 3 bits per symbol,
+// MSB first, symbols may straddle words
+// ----------------------------------------------------------------------------
+struct EncodedBWT {
+    const uint64_t* words = nullptr;
+    uint64_t tSize = 0;
+    uint64_t at(uint64_t index) const {
+        const uint64_t B = 3;
+        const uint64_t bitmask = ((1ull << B) - 1) << (64 - B);
+        uint64_t w = (index * B) / 64;
+        uint64_t b = (index * B) % 64;
+        uint64_t bits = (words[w] & (bitmask >> b)) << b;
+        bool overflow = b > 64 - B;
+        uint64_t mask = overflow ? ((-1ull) ^ (-1ull >> (B - (64 - b)))) : 0ull;
+        uint64_t bitsNext = overflow ? (words[w + 1] & mask) : 0ull;
+        uint64_t pc = __builtin_popcountll(mask);
+        return (bits >> (64 - B)) + (pc ? (bitsNext >> (64 - pc)) : 0ull);
+    }
+    static uint64_t nWords(uint64_t size) { return ((size * 3) / 64) + 1; } // :318
+    static void encode(const uint8_t* codes, uint64_t n, uint64_t* out) {
+        // encodedtext.h encodeLetter: MSB-first packing
+        uint64_t nw = nWords(n);
+        memset(out, 0, nw * 8);
+        for (uint64_t i = 0; i < n; i++) {
+            uint64_t w = (i * 3) / 64, b = (i * 3) % 64;
+            uint64_t v = codes[i];
+            if (b <= 61) {
+                out[w] |= v << (61 - b);
+            } else {
+                uint64_t over = b - 61; // bits spilling into next word
+                out[w] |= v >> over;
+                out[w + 1] |= v << (64 - over);
+            }
+        }
+    }
+};
+
+// ----------------------------------------------------------------------------
+// Index view (fmindex/fmindex.h:43-62, indexinterface.h protected members)
+// ----------------------------------------------------------------------------
+struct Index {
+    len_t textLength = 0;     // n including the final '$'
+    const uint8_t* text = 0;  // ASCII text, text[n-1] == '$'
+    len_t counts[5] = {0, 0, 0, 0, 0}; // cumulative counts ($,A,C,G,T) indexinterface.cpp:143-150
+    BWTRepr fwd, rev;         // .brt / .rev.brt
+    EncodedBWT bwt;           // .bwt
+    Bitvec9 saMark;           // .sa.bv.<s>
+    const len_t* saSamples = 0; // .sa.<s>
+    len_t sparseness = 4;
+    len_t switchPoint = 4;    // alignparameters.h:90-91
+    len_t wordSize = 10;      // k-mer table word size
+    std::vector<RangePair> kmerTable; // 4^wordSize entries, populateTable indexinterface.cpp:294
+    std::vector<len_t> seqStarts;
+
+    static int c2i(char c) { // alphabet.h:52-64 with alphabet $ACGT
+        switch (c) {
+        case '$': return 0;
+        case 'A': return 1;
+        case 'C': return 2;
+        case 'G': return 3;
+        case 'T': return 4;
+        default: return -1;
+        }
+    }
+    static char i2c(int i) { return "$ACGT"[i]; }
+
+    RangePair completeRange() const { // fmindex.h:431
+        return RangePair(Range(0, textLength), Range(0, textLength));
+    }
+
+    // fmindex.cpp:137-172
+    bool extendBackward(len_t c, const RangePair& p, RangePair& child) const {
+        const Range& t = p.sa;
+        len_t occBefore = (len_t)fwd.occ(c, t.b);
+        len_t occAfter = (len_t)fwd.occ(c, t.e);
+        len_t start = counts[c];
+        Range r1(occBefore + start, occAfter + start);
+        len_t s = p.rev.b;
+        len_t x = (len_t)fwd.cumOcc(c, t.e) - (len_t)fwd.cumOcc(c, t.b);
+        Range r2(s + x, s + x + r1.width());
+        child = RangePair(r1, r2);
+        return !child.empty();
+    }
+    // fmindex.cpp:174-211
+    bool extendForward(len_t c, const RangePair& p, RangePair& child) const {
+        const Range& t = p.rev;
+        len_t occBefore = (len_t)rev.occ(c, t.b);
+        len_t occAfter = (len_t)rev.occ(c, t.e);
+        len_t start = counts[c];
+        Range r1(occBefore + start, occAfter + start);
+        len_t s = p.sa.b;
+        len_t x = (len_t)rev.cumOcc(c, t.e) - (len_t)rev.cumOcc(c, t.b);
+        Range r2(s + x, s + x + r1.width());
+        child = RangePair(r2, r1);
+        return !child.empty();
+    }
+    // fmindex.cpp:226-243
+    bool extendBackwardUni(len_t c, const RangePair& p, RangePair& child) const {
+        const Range& t = p.sa;
+        len_t occBefore = (len_t)fwd.occ(c, t.b);
+        len_t occAfter = (len_t)fwd.occ(c, t.e);
+        len_t start = counts[c];
+        child = RangePair(Range(occBefore + start, occAfter + start), Range());
+        return !child.empty();
+    }
+    // fmindex.cpp:213-224
+    bool extendRangeBackward(len_t c, const Range& p, Range& child) const {
+        len_t occBefore = (len_t)fwd.occ(c, p.b);
+        len_t occAfter = (len_t)fwd.occ(c, p.e);
+        len_t start = counts[c];
+        child = Range(occBefore + start, occAfter + start);
+        return !child.empty();
+    }
+    // fmindex.cpp:47-51
+    len_t findLF(len_t k, Counters& cnt) const {
+        cnt.inc(LF_STEPS);
+        uint64_t pos = bwt.at(k);
+        return counts[pos] + (len_t)fwd.occ((int)pos, k);
+    }
+    // fmindex.cpp:53-60
+    len_t findSA(len_t index, Counters& cnt) const {
+        cnt.inc(LOCATED_ROWS);
+        len_t l = 0;
+        while (!saMark.get(index)) {
+            index = findLF(index, cnt);
+            l++;
+        }
+        return saSamples[saMark.rank(index)] + l;
+    }
+    // fmindex.cpp:434-445
+    RangePair rangeOfSingleChar(char c) const {
+        int i = c2i(c);
+        if (i < 0) return RangePair();
+        if (i < 4)
+            return RangePair(Range(counts[i], counts[i + 1]),
+                             Range(counts[i], counts[i + 1]));
+        return RangePair(Range(counts[i], textLength), Range(counts[i], textLength));
+    }
+    // fmindex.h:366-382
+    std::vector<len_t> getBeginPositions(const Range& r, len_t startDiff,
+                                         len_t shift, Counters& cnt) const {
+        std::vector<len_t> positions(r.width(), 0);
+        for (len_t i = r.b; i < r.e; i++) {
+            len_t sum = findSA(i, cnt) + shift;
+            positions[i - r.b] = sum >= startDiff ? sum - startDiff : 0;
+        }
+        return positions;
+    }
+    // indexinterface.h:590-594 + tkmer.h (2-bit packed k-mer key).  Entries of
+    // k-mers that do not occur are SARangePair() (never inserted, cpp:294-335).
+    RangePair lookUpInKmerTable(const char* s, len_t begin, len_t end) const {
+        // containsN over [begin,end) (substring.h containsN)
+        for (len_t i = begin; i < end; i++)
+            if (s[i] == 'N') return RangePair();
+        uint64_t key = 0;
+        for (len_t i = 0; i < wordSize; i++) {
+            int c = c2i(s[begin + i]);
+            if (c < 1) return RangePair();
+            key = (key << 2) | (uint64_t)(c - 1);
+        }
+        return kmerTable[key];
+    }
+};
+
+// ----------------------------------------------------------------------------
+// Substring (substring.h:34-306) — view with direction
+// ----------------------------------------------------------------------------
+struct Substring {
+    const char* text = nullptr;
+    len_t textSize = 0;
+    len_t startIndex = 0, endIndex = 0;
+    Direction d = FORWARD;
+    Substring() {}
+    Substring(const char* t, len_t tsize, len_t s, len_t e, Direction dir = FORWARD)
+        : text(t), textSize(tsize), startIndex(s), endIndex(e), d(dir) {
+        if (endIndex > textSize) endIndex = textSize; // check() :132
+    }
+    Substring(const Substring& s, len_t st, len_t e)
+        : Substring(s.text, s.textSize, st, e, s.d) {}
+    Substring(const Substring& s, len_t st, len_t e, Direction dir)
+        : Substring(s.text, s.textSize, st, e, dir) {}
+    char operator[](len_t i) const {
+        return d == FORWARD ? text[startIndex + i] : text[endIndex - i - 1];
+    }
+    char forwardAccessor(len_t i) const { return text[startIndex + i]; }
+    bool empty() const { return endIndex <= startIndex; }
+    len_t size() const { return empty() ? 0 : endIndex - startIndex; }
+    len_t begin() const { return startIndex; }
+    len_t end() const { return endIndex; }
+    void setDirection(Direction nd) { d = nd; }
+    void setEnd(len_t e) { endIndex = e; }
+    void setBegin(len_t b) { startIndex = b; }
+};
+
+// ----------------------------------------------------------------------------
+// BitParallelED<uint64_t> (bitparallelmatrix.h:300-750, .cpp:34-123)
+// ----------------------------------------------------------------------------
+struct BitVectors {
+    uint64_t HP, HN, D0, RAC, score;
+};
+class BitParallelED64 {
+  public:
+    static const uint32_t WORD_SIZE = 64, BLOCK_SIZE = 32;
+    static const uint32_t MATRIX_MAX_ED = (WORD_SIZE - BLOCK_SIZE - 2) / 3; // 10
+    static const uint32_t LEFT = 2 * MATRIX_MAX_ED + 1;                    // 21
+    static const uint32_t DIAG_R0 = 2 * MATRIX_MAX_ED;                     // 20
+
+    static int char2idx(char c) { // bitparallelmatrix.h:85-93
+        switch (c) {
+        case 'A': return 0;
+        case 'C': return 1;
+        case 'G': return 2;
+        case 'T': return 3;
+        case 'N': return 4;
+        default: return 5;
+        }
+    }
+    // bitparallelmatrix.cpp:34-75
+    void setSequence(const Substring& X) {
+        n = X.size() + 1;
+        m = 2 * MATRIX_MAX_ED + n;
+        mv.assign((m + BLOCK_SIZE - 1) / BLOCK_SIZE, std::array<uint64_t, 5>());
+        const uint64_t init = (1ull << LEFT) - 1ull;
+        mv[0].fill(init);
+        uint64_t bitmask = 1ull << LEFT;
+        size_t je = std::min<size_t>(X.size(), WORD_SIZE - LEFT);
+        for (size_t j = 0; j < je; j++) {
+            mv[0][char2idx(X[(len_t)j])] |= bitmask;
+            bitmask <<= 1;
+        }
+        for (size_t b = 1; b < mv.size(); b++) {
+            for (size_t i = 0; i < 5; i++) mv[b][i] = mv[b - 1][i] >> BLOCK_SIZE;
+            bitmask = 1ull << (WORD_SIZE - BLOCK_SIZE);
+            size_t jb_b = WORD_SIZE - LEFT + (b - 1) * BLOCK_SIZE;
+            size_t je_b = std::min<size_t>(X.size(), jb_b + BLOCK_SIZE);
+            for (size_t j = jb_b; j < je_b; j++) {
+                mv[b][char2idx(X[(len_t)j])] |= bitmask;
+                bitmask <<= 1;
+            }
+        }
+    }
+    // bitparallelmatrix.cpp:77-123
+    void initializeMatrix(uint32_t maxED_, const std::vector<uint32_t>& initED = {}) {
+        maxED = maxED_;
+        Wv = initED.empty() ? maxED : (uint32_t)initED.size() - 1 + maxED - initED.back();
+        m = Wv + n;
+        bv.resize(m);
+        bv[0].score = initED.empty() ? 0 : initED[0];
+        Wh = maxED - (uint32_t)bv[0].score;
+        if (Wv + Wh + 1 > m) {
+            m = Wv + Wh + 1;
+            bv.resize(m);
+        }
+        bv[0].HP = (~0ull) << LEFT;
+        bv[0].HN = ~bv[0].HP;
+        const size_t nn = std::min<size_t>(initED.size(), LEFT + 1);
+        for (uint32_t i = 1; i < nn; ++i) {
+            if (initED[i] < initED[i - 1]) {
+                bv[0].HP ^= 1ull << (LEFT - i);
+                bv[0].HN ^= 1ull << (LEFT - i);
+            } else if (initED[i] == initED[i - 1]) {
+                bv[0].HN ^= 1ull << (LEFT - i);
+            }
+        }
+        bv[0].RAC = 1ull << (DIAG_R0 + Wh);
+    }
+    // bitparallelmatrix.h:352-415
+    bool computeRow(uint32_t i, char Y) {
+        const uint32_t b = i / BLOCK_SIZE;
+        const uint32_t l = i % BLOCK_SIZE;
+        uint64_t& HP = bv[i].HP;
+        uint64_t& HN = bv[i].HN;
+        uint64_t& D0 = bv[i].D0;
+        uint64_t& RAC = bv[i].RAC;
+        const uint64_t M = mv[b][char2idx(Y)];
+        HP = bv[i - 1].HP;
+        HN = bv[i - 1].HN;
+        RAC = bv[i - 1].RAC << 1u;
+        if (i % BLOCK_SIZE == 0) {
+            HP >>= BLOCK_SIZE;
+            HN >>= BLOCK_SIZE;
+            RAC >>= BLOCK_SIZE;
+        }
+        D0 = (((M & HP) + HP) ^ HP) | M | HN;
+        uint64_t VP = HN | ~(D0 | HP);
+        uint64_t VN = D0 & HP;
+        HP = (VN << 1u) | ~(D0 | (VP << 1u));
+        HN = (D0 & (VP << 1u));
+        const uint32_t diagBit = l + DIAG_R0;
+        bv[i].score = bv[i - 1].score + ((D0 & (1ull << diagBit)) ? 0 : 1);
+        if (!(D0 & RAC)) {
+            size_t val = 1u;
+            while (val > 0) {
+                if (HP & RAC) val--;
+                if (HN & RAC) val++;
+                if (RAC == (1ull << (diagBit - Wv))) return false;
+                RAC >>= 1u;
+            }
+        }
+        return true;
+    }
+    bool inFinalColumn(uint32_t i) const { return i >= m - getSizeOfFinalColumn(); } // :437
+    // bitparallelmatrix.h:622-639
+    uint32_t at(uint32_t i, uint32_t j) const {
+        const uint32_t bit = (i % BLOCK_SIZE) + DIAG_R0;
+        uint32_t b = (i > j) ? bit - (i - j) + 1 : bit + 1;
+        uint32_t e = (i > j) ? bit + 1 : bit + (j - i) + 1;
+        uint64_t mask = ((1ull << (e - b)) - 1ull) << b;
+        int negatives = __builtin_popcountll(bv[i].HN & mask);
+        int positives = __builtin_popcountll(bv[i].HP & mask);
+        uint32_t score = (uint32_t)bv[i].score;
+        score += (i > j) ? (negatives - positives) : (positives - negatives);
+        return score;
+    }
+    // bitparallelmatrix.h:651-665
+    bool onlyVerticalGapsLeft(uint32_t i) const {
+        if (i + LEFT < n) return false;
+        const uint32_t b = i / BLOCK_SIZE;
+        const uint32_t r = i % BLOCK_SIZE;
+        uint32_t bb = DIAG_R0 - Wv + r + 1;
+        uint32_t be = DIAG_R0 + n - b * BLOCK_SIZE;
+        return (((~bv[i].HN >> bb) << bb) << (WORD_SIZE - be)) == 0ull;
+    }
+    uint32_t getFirstColumn(uint32_t i) const { return (i <= Wv) ? 0u : i - Wv; } // :670
+    uint32_t getNumberOfCols() const { return n; }
+    uint32_t getNumberOfRows() const { return m; }
+    bool sequenceSet() const { return !mv.empty(); }
+    void reset() { mv.clear(); }
+    uint32_t getSizeOfFinalColumn() const { return Wh + Wv + 1; }
+    // bitparallelmatrix.h:591-614
+    void findClusterCenters(uint32_t lastRow, std::vector<len_t>& refEnds,
+                            uint32_t maxED_, uint32_t minED_) const {
+        refEnds.clear();
+        uint32_t firstRow = (m - 1) - getSizeOfFinalColumn();
+        uint32_t col = n - 1;
+        for (uint32_t i = lastRow; i > (m - 1) - getSizeOfFinalColumn(); i--) {
+            uint32_t ED = at(i, col);
+            if (ED > maxED_ || ED < minED_) continue;
+            bool betterThanAbove = (i == firstRow) || ED <= at(i - 1, col);
+            bool betterThanBelow = (i == lastRow) || ED <= at(i + 1, col);
+            if (betterThanAbove && betterThanBelow) refEnds.emplace_back(i);
+        }
+    }
+    // bitparallelmatrix.h:531-586 (CIGAR as (op,len) pairs, forward order)
+    void traceBack(const Substring& ref, len_t refEnd, len_t& refBegin, len_t& ED,
+                   std::vector<std::pair<char, uint32_t>>* cigar) const {
+        std::vector<std::pair<char, uint32_t>> v;
+        uint32_t i = refEnd;
+        uint32_t j = n - 1;
+        ED = at(i, j);
+        char state = 0;
+        while (j > 0) {
+            const uint32_t b = i / BLOCK_SIZE;
+            const uint64_t bit = 1ull << ((j - b * BLOCK_SIZE) + DIAG_R0);
+            char op;
+            if (bv[i].HP & bit) {
+                --j;
+                op = 'I';
+            } else if ((i > 0) &&
+                       ((mv[b][char2idx(ref.forwardAccessor(i - 1))] | ~bv[i].D0) & bit)) {
+                --i;
+                --j;
+                op = 'M';
+            } else {
+                --i;
+                op = 'D';
+            }
+            if (state != op) {
+                v.emplace_back(op, 0);
+                state = op;
+            }
+            v.back().second++;
+        }
+        refBegin = i;
+        if (cigar) cigar->assign(v.rbegin(), v.rend());
+    }
+    const BitVectors& row(uint32_t i) const { return bv[i]; }
+    uint32_t getWv() const { return Wv; }
+    uint32_t getWh() const { return Wh; }
+    const std::vector<std::array<uint64_t, 5>>& matchVectors() const { return mv; }
+
+  private:
+    uint32_t maxED = 0, m = 0, n = 0, Wv = 0, Wh = 0;
+    std::vector<BitVectors> bv;
+    std::vector<std::array<uint64_t, 5>> mv;
+};
+
+// ----------------------------------------------------------------------------
+// Search / SearchScheme (search.h:55-495, :509-757)
+// ----------------------------------------------------------------------------
+struct Search {
+    std::vector<len_t> L, U, order;
+    len_t sIdx = 0;
+    std::vector<Direction> directions;
+    std::vector<bool> directionSwitch;
+    std::vector<std::pair<len_t, len_t>> lowHigh;
+    bool uniBackwards = false;
+    len_t uniBackwardsIndex = 0;
+
+    // search.h:116-194
+    static Search makeSearch(std::vector<len_t> order, std::vector<len_t> lower,
+                             std::vector<len_t> upper, len_t sIdx) {
+        if (order.size() != lower.size() || order.size() != upper.size())
+            throw std::runtime_error(
+                "Could not create search, the sizes of all vectors are not equal");
+        Search s;
+        s.order = order;
+        s.L = lower;
+        s.U = upper;
+        s.sIdx = sIdx;
+        s.directions.push_back((order[1] > order[0]) ? FORWARD : BACKWARD);
+        for (len_t i = 1; i < order.size(); i++)
+            s.directions.push_back((order[i] > order[i - 1]) ? FORWARD : BACKWARD);
+        s.directionSwitch.push_back(false);
+        s.directionSwitch.push_back(false);
+        for (len_t i = 2; i < s.directions.size(); i++)
+            s.directionSwitch.push_back(s.directions[i] != s.directions[i - 1]);
+        s.lowHigh.emplace_back(order[0], order[0]);
+        for (len_t i = 1; i < order.size(); i++) {
+            auto before = s.lowHigh.back();
+            len_t cur = order[i];
+            if (cur < before.first)
+                s.lowHigh.emplace_back(cur, before.second);
+            else
+                s.lowHigh.emplace_back(before.first, cur);
+        }
+        s.uniBackwards = (order[0] == order.size() - 1);
+        s.uniBackwardsIndex = (len_t)order.size();
+        if (order.back() != 0) {
+            s.uniBackwardsIndex = (len_t)order.size();
+        } else if (s.uniBackwards) {
+            s.uniBackwardsIndex = 0;
+        } else {
+            for (len_t idx = 0; idx < order.size(); idx++) {
+                if (order[idx] == order.size() - 1) {
+                    s.uniBackwardsIndex = idx + 1;
+                    break;
+                }
+            }
+        }
+        return s;
+    }
+    len_t getLowerBound(len_t i) const { return L[i]; }
+    len_t getUpperBound(len_t i) const { return U[i]; }
+    len_t getPart(len_t i) const { return order[i]; }
+    len_t getLowestPartProcessedBefore(len_t i) const { return lowHigh[i - 1].first; }
+    len_t getHighestPartProcessedBefore(len_t i) const { return lowHigh[i - 1].second; }
+    len_t getMaxED() const { return U.back(); }
+    len_t getMinED() const { return L.back(); }
+    Direction getDirection(len_t i) const { return directions[i]; }
+    bool getDirectionSwitch(len_t i) const { return directionSwitch[i]; }
+    len_t getNumParts() const { return (len_t)order.size(); }
+    bool isEdge(len_t i) const { return order[i] == 0 || order[i] == getNumParts() - 1; }
+    bool isEnd(len_t i) const { return i == order.size() - 1; }
+    bool isUnidirectionalBackwards(len_t i) const {
+        return uniBackwards || i >= uniBackwardsIndex;
+    }
+    // search.h:422-441
+    bool operator<(const Search& rhs) const {
+        for (len_t i = 0; i < getNumParts(); i++)
+            if (U[i] != rhs.U[i]) return U[i] > rhs.U[i];
+        for (len_t i = 0; i < getNumParts(); i++)
+            if (L[i] != rhs.L[i]) return L[i] < rhs.L[i];
+        return sIdx < rhs.sIdx;
+    }
+    // search.h:366-411
+    bool connectivitySatisfied() const {
+        len_t hi = order[0], lo = order[0];
+        for (len_t i = 1; i < order.size(); i++) {
+            if (order[i] == hi + 1) hi++;
+            else if (order[i] == lo - 1) lo--;
+            else return false;
+        }
+        return true;
+    }
+    bool validBounds() const {
+        if (L[0] > U[0]) return false;
+        for (len_t i = 1; i < order.size(); i++)
+            if (L[i] > U[i] || L[i] < L[i - 1] || U[i] < U[i - 1]) return false;
+        return true;
+    }
+    bool zeroBased() const { return *std::min_element(order.begin(), order.end()) == 0; }
+    void setDirectionsInParts(std::vector<Substring>& parts) const { // :217
+        for (len_t i = 0; i < order.size(); i++) parts[order[i]].setDirection(directions[i]);
+    }
+    Search mirrorPiStrings() const { // :488
+        std::vector<len_t> mo = order;
+        for (len_t i = 0; i < order.size(); i++) mo[i] = (len_t)order.size() - 1 - order[i];
+        return makeSearch(mo, L, U, sIdx);
+    }
+};
+
+struct SearchScheme {
+    std::vector<Search> searches;
+    unsigned k = 0;
+    uint16_t criticalPartIndex = 0;
+    SearchScheme() {}
+    SearchScheme(const std::vector<Search>& s, unsigned k_) : searches(s), k(k_) {
+        sanityCheck();
+        // search.h:525-539
+        auto it = std::min_element(searches.begin(), searches.end());
+        criticalPartIndex = (uint16_t)it->getPart(0);
+    }
+    void sanityCheck() const { // search.h:552-588
+        len_t P = searches.front().getNumParts();
+        for (const auto& s : searches) {
+            if (s.getNumParts() != P)
+                throw std::runtime_error("Not all searches for distance " +
+                                         std::to_string(k) +
+                                         " have the same number of parts");
+            if (!s.zeroBased())
+                throw std::runtime_error("Not all searches are zero based for distance " +
+                                         std::to_string(k) + "!");
+            if (!s.connectivitySatisfied())
+                throw std::runtime_error("Connectivity property not satisfied for all "
+                                         "searches with distance " +
+                                         std::to_string(k) + "!");
+            if (!s.validBounds())
+                throw std::runtime_error("Decreasing lower or upper bounds for a search "
+                                         "for K  = " +
+                                         std::to_string(k));
+        }
+    }
+    uint16_t getNumParts() const { return (uint16_t)searches.front().getNumParts(); }
+    SearchScheme mirrorPiStrings() const { // :745
+        std::vector<Search> r;
+        for (const auto& s : searches) r.push_back(s.mirrorPiStrings());
+        return SearchScheme(r, k);
+    }
+};
+
+} // namespace orc
