@@ -1,0 +1,268 @@
+// ============================================================================
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+// Line-protocol twin of ref_driver.cpp, answering the same commands from the
+// oracle's restatement (oracle_core.hpp / oracle_search.hpp).  tests/ diff its
+// output with the fixtures that ref_driver (the real reference code) produced.
+// ============================================================================
+#include "oracle_search.hpp"
+#include <iostream>
+#include <sstream>
+
+using namespace orc;
+using namespace std;
+
+static void words(ostream& os, const vector<uint64_t>& w) {
+    os << w.size();
+    for (auto v : w) os << ' ' << hex << v << dec;
+}
+static string cigarStr(const vector<pair<char, uint32_t>>& c) {
+    string s;
+    for (auto& p : c) s += to_string(p.second) + p.first;
+    return s;
+}
+
+int main() {
+    string line;
+    while (getline(cin, line)) {
+        istringstream in(line);
+        string cmd;
+        in >> cmd;
+        ostringstream os;
+        if (cmd == "bwt") {
+            string bwt;
+            in >> bwt;
+            vector<uint8_t> codes(bwt.size());
+            for (size_t i = 0; i < bwt.size(); i++) codes[i] = (uint8_t)Index::c2i(bwt[i]);
+            uint64_t N = bwt.size() + 1;
+            vector<uint64_t> bv(BitvecIntl4::bvWords(N)), cnt(BitvecIntl4::cntWords(N));
+            uint64_t dp;
+            buildBitvecIntl4(codes.data(), bwt.size(), bv.data(), cnt.data(), dp);
+            vector<uint64_t> file = {dp, N};
+            file.insert(file.end(), bv.begin(), bv.end());
+            file.insert(file.end(), cnt.begin(), cnt.end());
+            words(os, file);
+            BWTRepr r;
+            r.bv = BitvecIntl4{N, bv.data(), cnt.data()};
+            r.dollarPos = dp;
+            for (int c = 0; c < 5; c++)
+                for (size_t k = 0; k <= bwt.size(); k++) os << ' ' << r.occ(c, k) << ' ' << r.cumOcc(c, k);
+        } else if (cmd == "bitvec9") {
+            string bits;
+            in >> bits;
+            uint64_t N = bits.size();
+            vector<uint64_t> bv(Bitvec9::bvWords(N), 0), cnt(Bitvec9::cntWords(N), 0);
+            for (size_t i = 0; i < N; i++)
+                if (bits[i] == '1') bv[i / 64] |= 1ull << (i % 64);
+            buildBitvec9Counts(bv.data(), bv.size(), cnt.data());
+            vector<uint64_t> file = {N};
+            file.insert(file.end(), bv.begin(), bv.end());
+            file.insert(file.end(), cnt.begin(), cnt.end());
+            words(os, file);
+            Bitvec9 b{N, bv.data(), cnt.data()};
+            for (size_t p = 0; p < N; p++) os << ' ' << b.rank(p);
+        } else if (cmd == "enc") {
+            string txt;
+            in >> txt;
+            vector<uint8_t> codes(txt.size());
+            for (size_t i = 0; i < txt.size(); i++) codes[i] = (uint8_t)Index::c2i(txt[i]);
+            vector<uint64_t> w(EncodedBWT::nWords(txt.size()) + 1, 0);
+            EncodedBWT::encode(codes.data(), txt.size(), w.data());
+            vector<uint64_t> file = {txt.size(), EncodedBWT::nWords(txt.size())};
+            file.insert(file.end(), w.begin(), w.end() - 1);
+            words(os, file);
+            EncodedBWT e;
+            e.words = w.data();
+            e.tSize = txt.size();
+            for (size_t i = 0; i < txt.size(); i++) os << ' ' << e.at(i);
+        } else if (cmd == "matrix") {
+            string X, Y;
+            int dir;
+            uint32_t maxED, nInit;
+            in >> X >> dir >> Y >> maxED >> nInit;
+            vector<uint32_t> init(nInit);
+            for (auto& v : init) in >> v;
+            BitParallelED64 M;
+            Substring sx(X.data(), (len_t)X.size(), 0, (len_t)X.size(), dir == 0 ? FORWARD : BACKWARD);
+            M.setSequence(sx);
+            M.initializeMatrix(maxED, init);
+            os << M.getNumberOfRows() << ' ' << M.getNumberOfCols() << ' ' << M.getSizeOfFinalColumn();
+            os << ' ' << M.inFinalColumn(0);
+            uint32_t i = 0;
+            for (; i < Y.size() && i + 1 < M.getNumberOfRows(); i++) {
+                bool v = M.computeRow(i + 1, Y[i]);
+                uint32_t r = i + 1;
+                os << ' ' << v << ' ' << M.getFirstColumn(r) << ' ' << M.inFinalColumn(r) << ' '
+                   << M.onlyVerticalGapsLeft(r);
+                uint32_t fc = M.getFirstColumn(r);
+                uint32_t lc = std::min(M.getNumberOfCols() - 1, r + (maxED - (init.empty() ? 0 : init[0])));
+                os << ' ' << (lc - fc + 1);
+                for (uint32_t j = fc; j <= lc; j++) os << ' ' << M.at(r, j);
+                if (!v) break;
+            }
+        } else if (cmd == "traceback") {
+            string X, Y;
+            uint32_t maxED, minED, nZeros;
+            in >> X >> Y >> maxED >> minED >> nZeros;
+            BitParallelED64 M;
+            Substring sx(X.data(), (len_t)X.size(), 0, (len_t)X.size(), FORWARD);
+            M.setSequence(sx);
+            M.initializeMatrix(maxED, vector<uint32_t>(nZeros, 0));
+            Substring ref(Y.data(), (len_t)Y.size(), 0, (len_t)Y.size(), FORWARD);
+            uint32_t i = 0;
+            for (; i < Y.size() && i + 1 < M.getNumberOfRows(); i++)
+                if (!M.computeRow(i + 1, Y[i])) break;
+            vector<len_t> ends;
+            if (M.inFinalColumn(i)) M.findClusterCenters(i, ends, maxED, minED);
+            os << i << ' ' << ends.size();
+            for (auto e : ends) {
+                len_t b, ed;
+                vector<pair<char, uint32_t>> cig;
+                M.traceBack(ref, e, b, ed, &cig);
+                os << ' ' << e << ' ' << b << ' ' << ed << ' ' << cigarStr(cig);
+            }
+        } else if (cmd == "search") {
+            uint32_t n;
+            in >> n;
+            vector<len_t> pi(n), L(n), U(n);
+            for (auto& v : pi) in >> v;
+            for (auto& v : L) in >> v;
+            for (auto& v : U) in >> v;
+            Search s = Search::makeSearch(pi, L, U, 0);
+            for (uint32_t i = 0; i < n; i++) os << (i ? " " : "") << s.getDirection(i);
+            for (uint32_t i = 0; i < n; i++) os << ' ' << s.getDirectionSwitch(i);
+            os << " |";
+            for (uint32_t i = 1; i < n; i++)
+                os << ' ' << s.getLowestPartProcessedBefore(i) << ' ' << s.getHighestPartProcessedBefore(i);
+            os << " |";
+            for (uint32_t i = 0; i < n; i++) os << ' ' << s.isUnidirectionalBackwards(i);
+            os << " | " << s.connectivitySatisfied() << ' ' << s.validBounds() << ' ' << s.zeroBased();
+        } else if (cmd == "scheme") {
+            uint32_t k, ns, np;
+            in >> k >> ns >> np;
+            vector<Search> ss;
+            for (uint32_t i = 0; i < ns; i++) {
+                vector<len_t> pi(np), L(np), U(np);
+                for (auto& v : pi) in >> v;
+                for (auto& v : L) in >> v;
+                for (auto& v : U) in >> v;
+                ss.push_back(Search::makeSearch(pi, L, U, i));
+            }
+            try {
+                SearchScheme sch(ss, k);
+                os << "ok " << sch.criticalPartIndex << ' ' << sch.getNumParts();
+                SearchScheme mir = sch.mirrorPiStrings();
+                os << ' ' << mir.criticalPartIndex;
+            } catch (const std::exception& e) {
+                os << "error " << e.what();
+            }
+        } else if (cmd == "cluster") {
+            uint32_t size, maxED, startDepth, shift, nset;
+            in >> size >> maxED >> startDepth >> shift >> nset;
+            Cluster cl(size, maxED, startDepth, shift);
+            for (uint32_t i = 0; i < nset; i++) {
+                uint32_t idx, ed, depth, a, b, c, d;
+                char ch;
+                in >> idx >> ed >> depth >> a >> b >> c >> d >> ch;
+                cl.setValue(idx, FMPosExt(ch, RangePair(Range(a, b), Range(c, d)), depth), ed);
+            }
+            string op;
+            uint32_t arg;
+            in >> op >> arg;
+            auto pr = [&](const FMOcc& m) {
+                os << ' ' << m.isValid() << ' ' << m.getRanges().sa.b << ' ' << m.getRanges().sa.e << ' '
+                   << m.getRanges().rev.b << ' ' << m.getRanges().rev.e << ' ' << m.distance << ' '
+                   << m.getDepth() << ' ' << m.shift;
+            };
+            if (op == "centra") {
+                vector<FMPosExt> desc;
+                vector<uint16_t> ie;
+                FMOcc m = cl.getClusterCentra((uint16_t)arg, desc, ie);
+                os << "centra";
+                pr(m);
+                os << ' ' << desc.size();
+                for (auto& dn : desc) os << ' ' << dn.depth << ' ' << dn.ranges.sa.b << ' ' << dn.c;
+                os << ' ' << ie.size();
+                for (auto v : ie) os << ' ' << v;
+            } else if (op == "centers") {
+                auto v = cl.reportCentersAtEnd();
+                os << "centers " << v.size();
+                for (auto& m : v) pr(m);
+                auto v2 = cl.reportCentersAtEnd();
+                os << " again " << v2.size();
+                for (auto& m : v2) os << ' ' << m.isValid();
+            } else {
+                FMOcc m = cl.reportDeepestMinimum(arg == 0 ? FORWARD : BACKWARD);
+                os << "deepest";
+                pr(m);
+                FMOcc m2 = cl.reportDeepestMinimum(arg == 0 ? FORWARD : BACKWARD);
+                os << " again " << m2.isValid();
+            }
+        } else if (cmd == "verify") {
+            string text, pattern;
+            uint32_t maxED, minED, nZeros, noCigar, ns;
+            in >> text >> pattern >> maxED >> minED >> nZeros >> noCigar >> ns;
+            vector<len_t> starts(ns);
+            for (auto& v : starts) in >> v;
+            Index idx;
+            idx.textLength = (len_t)text.size();
+            idx.text = (const uint8_t*)text.data();
+            Strategy st;
+            Matcher m(idx, st);
+            m.noCIGAR = noCigar != 0;
+            Substring pat(pattern.data(), (len_t)pattern.size(), 0, (len_t)pattern.size(), FORWARD);
+            Occurrences occ;
+            // nZeros == 1 <=> fixedStartPos (fmindex.cpp:276)
+            if (!(nZeros == 1 || nZeros == 2 * maxED + 1)) {
+                os << "unsupported";
+            } else {
+                m.inTextVerification(starts, maxED, minED, occ, pat, nZeros == 1);
+                os << m.counters.c[IN_TEXT_STARTED] << ' ' << m.counters.c[ABORTED_IN_TEXT_VERIF] << ' '
+                   << m.counters.c[CIGARS_IN_TEXT_VERIFICATION] << ' ' << occ.inTextOcc.size();
+                for (const auto& t : occ.inTextOcc)
+                    os << ' ' << t.range.b << ' ' << t.range.e << ' ' << t.distance << ' '
+                       << (t.hasCigar() ? cigarStr(t.cigar) : string("*"));
+            }
+        } else if (cmd == "occsort") {
+            uint32_t n;
+            in >> n;
+            Occurrences occ;
+            for (uint32_t i = 0; i < n; i++) {
+                uint32_t b, e, d, hc;
+                in >> b >> e >> d >> hc;
+                TextOcc t(Range(b, e), d, FORWARD_STRAND);
+                if (hc) t.cigar = {{'M', 1}};
+                occ.inTextOcc.push_back(t);
+            }
+            occ.eraseDoublesAndSortText();
+            os << occ.inTextOcc.size();
+            for (const auto& t : occ.inTextOcc)
+                os << ' ' << t.range.b << ' ' << t.range.e << ' ' << t.distance << ' ' << t.hasCigar();
+        } else if (cmd == "fmoccsort") {
+            uint32_t n;
+            in >> n;
+            Occurrences occ;
+            for (uint32_t i = 0; i < n; i++) {
+                uint32_t a, b, d, dep, sh, st;
+                in >> a >> b >> d >> dep >> sh >> st;
+                occ.inFMOcc.push_back(FMOcc(RangePair(Range(a, b), Range(a, b)), d, dep,
+                                            st ? REVERSE_C_STRAND : FORWARD_STRAND, sh));
+            }
+            occ.eraseDoublesFM();
+            os << occ.inFMOcc.size();
+            for (const auto& f : occ.inFMOcc)
+                os << ' ' << f.getRanges().sa.b << ' ' << f.getRanges().sa.e << ' ' << f.distance << ' '
+                   << f.getDepth() << ' ' << f.shift << ' ' << (f.strand == REVERSE_C_STRAND);
+        } else if (cmd == "revcomp") {
+            string s;
+            in >> s;
+            os << Matcher::revCompl(s);
+        } else if (cmd == "consts") {
+            os << BitParallelED64::MATRIX_MAX_ED << ' ' << BitParallelED64::LEFT << ' ' << 13 << ' ' << 10
+               << ' ' << 4 << ' ' << sizeof(len_t);
+        } else {
+            os << "unknown";
+        }
+        cout << os.str() << "\n";
+    }
+    return 0;
+}

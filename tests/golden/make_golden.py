@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ref_vectors.{cmds,out}: known-answer vectors produced by the REAL
+reference code (oracle/_ref/ref_driver, built by `make -C oracle ref` from the sources under
+/root/reference — possible only in the build container).
+
+The .cmds file holds the (seeded, synthetic) inputs, the .out file what the reference's own
+functions returned for them.  Both are data; no reference source text is stored.
+Run:  python tests/golden/make_golden.py
+"""
+import os
+import random
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+
+rng = random.Random(20251003)
+ACGT = "ACGT"
+
+
+def rseq(n, alphabet=ACGT):
+    return "".join(rng.choice(alphabet) for _ in range(n))
+
+
+def mutate(s, nedits):
+    s = list(s)
+    for _ in range(nedits):
+        if not s:
+            break
+        p = rng.randrange(len(s))
+        u = rng.random()
+        if u < 0.6:
+            s[p] = rng.choice([c for c in ACGT if c != s[p]])
+        elif u < 0.8:
+            s.insert(p, rng.choice(ACGT))
+        else:
+            del s[p]
+    return "".join(s)
+
+
+def init_ed_vector(max_ed):
+    """first-column vectors as getClusterCentra produces them: neighbours differ by <= 1,
+    first and last <= maxED (bitparallelmatrix.cpp:84-86)."""
+    n = rng.randint(1, min(2 * max_ed + 1, 9))
+    while True:
+        v = [rng.randint(0, max_ed)]
+        for _ in range(n - 1):
+            v.append(max(0, v[-1] + rng.choice([-1, 0, 1, 1])))
+        if v[-1] <= max_ed and max(v) <= max_ed + 1:
+            return v
+
+
+def connected_perm(p):
+    start = rng.randrange(p)
+    lo = hi = start
+    order = [start]
+    while len(order) < p:
+        opts = []
+        if lo > 0:
+            opts.append("l")
+        if hi < p - 1:
+            opts.append("h")
+        if rng.choice(opts) == "l":
+            lo -= 1
+            order.append(lo)
+        else:
+            hi += 1
+            order.append(hi)
+    return order
+
+
+def bounds(p, k):
+    U = sorted(rng.randint(0, k) for _ in range(p))
+    U[-1] = k
+    L = sorted(rng.randint(0, u) for u in U)
+    L = [min(l, u) for l, u in zip(L, U)]
+    for i in range(1, p):
+        L[i] = max(L[i], L[i - 1])
+        L[i] = min(L[i], U[i])
+    return L, U
+
+
+cmds = ["consts"]
+
+# a1/a2: BWTRepresentation<5>
+for n in [1, 2, 5, 63, 64, 65, 127, 128, 129, 511, 512, 513, 700] + [rng.randint(3, 600) for _ in range(12)]:
+    s = list(rseq(n))
+    s[rng.randrange(n)] = "$"
+    cmds.append("bwt " + "".join(s))
+cmds.append("bwt " + "A" * 100 + "$" + "T" * 100)  # runs
+cmds.append("bwt $")
+
+# a10: rank9 Bitvec
+for n in [1, 64, 65, 511, 512, 513, 1024, 1500, 2500] + [rng.randint(2, 2000) for _ in range(8)]:
+    dens = rng.choice([0.05, 0.25, 0.5, 0.9])
+    cmds.append("bitvec9 " + "".join("1" if rng.random() < dens else "0" for _ in range(n)))
+
+# a10: EncodedText<5>
+for n in [1, 20, 21, 22, 42, 43, 64, 65, 200] + [rng.randint(2, 400) for _ in range(6)]:
+    s = list(rseq(n))
+    s[rng.randrange(n)] = "$"
+    cmds.append("enc " + "".join(s))
+
+# a5: matrix rows (in-index use: parts of 5..60 chars, both directions, initED vectors)
+for _ in range(260):
+    max_ed = rng.randint(0, 6)
+    xl = rng.randint(max(2, max_ed), 60)
+    X = rseq(xl, "ACGTN" if rng.random() < 0.1 else ACGT)
+    d = rng.randint(0, 1)
+    base = X if d == 0 else X[::-1]
+    base = base.replace("N", "A")
+    Y = mutate(base, rng.randint(0, max_ed + 2)) + rseq(12)
+    if rng.random() < 0.2:
+        Y = rseq(len(Y))
+    init = [] if rng.random() < 0.4 else init_ed_vector(max_ed)
+    if init and (init[0] > max_ed or init[-1] > max_ed):
+        init = []
+    cmds.append(f"matrix {X} {d} {Y} {max_ed} {len(init)} " + " ".join(map(str, init)))
+# long patterns crossing several 32-row blocks (full-read matrices)
+for _ in range(40):
+    max_ed = rng.randint(1, 6)
+    X = rseq(rng.choice([100, 150, 151, 250]))
+    Y = rseq(rng.randint(0, 8)) + mutate(X, rng.randint(0, max_ed + 1)) + rseq(10)
+    nz = rng.choice([1, 2 * max_ed + 1])
+    cmds.append(f"matrix {X} 0 {Y} {max_ed} {nz} " + " ".join(["0"] * nz))
+
+# a5/a11: cluster centres + traceback on full-read matrices
+for _ in range(160):
+    max_ed = rng.randint(1, 6)
+    X = rseq(rng.choice([30, 64, 100, 150]))
+    nz = rng.choice([1, 2 * max_ed + 1])
+    lead = 0 if nz == 1 else rng.randint(0, 2 * max_ed)
+    Y = rseq(lead) + mutate(X, rng.randint(0, max_ed)) + rseq(rng.randint(0, 12))
+    if rng.random() < 0.15:
+        Y = Y[:len(X) - rng.randint(1, 3)]
+    cmds.append(f"traceback {X} {Y} {max_ed} {rng.randint(0, 1)} {nz}")
+
+# a14: Search / SearchScheme
+for _ in range(120):
+    p = rng.randint(2, 8)
+    k = rng.randint(1, 7)
+    pi = connected_perm(p)
+    L, U = bounds(p, k)
+    cmds.append(f"search {p} " + " ".join(map(str, pi + L + U)))
+SCHEMES = {
+    2: ["012 011 022", "102 000 012", "210 002 012"],
+    4: ["01234 00222 02244", "12034 00000 01244", "21034 01111 01244", "34210 00003 01444",
+        "43210 01114 01444"],
+    41: ["01234 01114 01444", "10234 00003 01444", "23410 01111 02244", "32410 00000 01244",
+         "43210 00222 01244"],
+    42: ["43210 00222 02244", "32410 00000 01244", "23410 01111 01244", "10234 00003 01444",
+         "01234 01114 01444"],
+    43: ["01234 00000 02244", "43210 00000 01344", "10234 00133 01334", "01234 00133 01334",
+         "32410 00011 01244", "21034 00013 01244", "10234 00124 01244", "01234 00034 00444"],
+    44: ["01234 00000 04444", "12340 00000 04444", "23410 00000 04444", "34210 00000 04444",
+         "43210 00000 04444"],
+}
+for k, rows in SCHEMES.items():
+    kk = k if k < 10 else 4
+    np_ = len(rows[0].split()[0])
+    flat = []
+    for r in rows:
+        for part in r.split():
+            flat += list(part)
+    cmds.append(f"scheme {kk} {len(rows)} {np_} " + " ".join(flat))
+for _ in range(30):  # random schemes incl. invalid ones (error path)
+    p = rng.randint(2, 6)
+    k = rng.randint(1, 5)
+    ns = rng.randint(1, 5)
+    flat = []
+    for _ in range(ns):
+        pi = connected_perm(p) if rng.random() < 0.85 else rng.sample(range(p), p)
+        L, U = bounds(p, k)
+        flat += pi + L + U
+    cmds.append(f"scheme {k} {ns} {p} " + " ".join(map(str, flat)))
+
+# a7: MatrixMetaInfo
+for _ in range(300):
+    max_ed = rng.randint(1, 6)
+    size = rng.randint(1, 4 * max_ed + 1)
+    start_depth = rng.randint(0, 120)
+    shift = rng.randint(0, 5)
+    nset = rng.randint(1, size)
+    eds = [rng.randint(0, max_ed + 1)]
+    for _ in range(nset - 1):
+        eds.append(max(0, min(max_ed + 2, eds[-1] + rng.choice([-1, -1, 0, 1, 1]))))
+    toks = []
+    for i in range(nset):
+        a = rng.randint(0, 1000)
+        w = rng.randint(1, 50)
+        c = rng.randint(0, 1000)
+        toks += [i, eds[i], i + rng.randint(0, 30), a, a + w, c, c + w, rng.choice(ACGT)]
+    op = rng.choice(["centra", "centra", "centers", "deepest"])
+    arg = rng.randint(0, max_ed) if op == "centra" else rng.randint(0, 1)
+    cmds.append(f"cluster {size} {max_ed} {start_depth} {shift} {nset} " + " ".join(map(str, toks)) + f" {op} {arg}")
+
+# a11: InTextVerificationTask::doTask
+for _ in range(160):
+    max_ed = rng.randint(1, 6)
+    tl = rng.randint(200, 700)
+    text = rseq(tl)
+    pl = rng.choice([20, 36, 50, 100, 150])
+    pl = min(pl, tl - 30)
+    pos = rng.randint(0, tl - pl)
+    pattern = mutate(text[pos:pos + pl], rng.randint(0, max_ed + 1))
+    if rng.random() < 0.1:
+        p = rng.randrange(len(pattern))
+        pattern = pattern[:p] + "N" + pattern[p + 1:]
+    nz = rng.choice([1, 2 * max_ed + 1])
+    starts = []
+    for _ in range(rng.randint(1, 5)):
+        u = rng.random()
+        if u < 0.6:
+            starts.append(max(0, pos - (0 if nz == 1 else rng.randint(0, 2 * max_ed))))
+        elif u < 0.8:
+            starts.append(rng.randint(0, tl))
+        else:
+            starts.append(max(0, tl - rng.randint(0, pl + 10)))
+    min_ed = rng.choice([0, 0, 0, 1, 2])
+    cmds.append(f"verify {text}$ {pattern} {max_ed} {min_ed} {nz} {rng.randint(0, 1)} {len(starts)} "
+                + " ".join(map(str, starts)))
+
+# a16: TextOcc ordering + dedup, FMOcc dedup
+for _ in range(60):
+    n = rng.randint(0, 25)
+    toks = []
+    for _ in range(n):
+        b = rng.randint(0, 30)
+        toks += [b, b + rng.randint(95, 105), rng.randint(0, 4), rng.randint(0, 1)]
+    cmds.append(f"occsort {n} " + " ".join(map(str, toks)))
+for _ in range(40):
+    base = []
+    for _ in range(rng.randint(0, 12)):
+        a = rng.randint(0, 40)
+        base.append((a, a + rng.randint(1, 9), rng.randint(0, 4), rng.randint(90, 110), rng.randint(0, 3),
+                     rng.randint(0, 1)))
+    # ties under operator< must be exact duplicates (std::sort is unstable in Release builds)
+    seen = {}
+    for t in base:
+        seen.setdefault((t[0], t[2], t[1] - t[0], t[4]), t)
+    uniq = list(seen.values())
+    items = uniq + [rng.choice(uniq) for _ in range(rng.randint(0, 5)) if uniq]
+    rng.shuffle(items)
+    cmds.append(f"fmoccsort {len(items)} " + " ".join(str(x) for t in items for x in t))
+
+for _ in range(20):
+    cmds.append("revcomp " + rseq(rng.randint(1, 60), "ACGTN"))
+
+
+def main():
+    if not os.path.exists(DRIVER):
+        sys.exit("oracle/_ref/ref_driver missing: run `make -C oracle ref` in the build container")
+    inp = "\n".join(cmds) + "\n"
+    out = subprocess.run([DRIVER], input=inp, capture_output=True, text=True, check=True).stdout
+    assert out.count("\n") == len(cmds)
+    with open(os.path.join(HERE, "ref_vectors.cmds"), "w") as f:
+        f.write(inp)
+    with open(os.path.join(HERE, "ref_vectors.out"), "w") as f:
+        f.write(out)
+    print(f"{len(cmds)} vectors, {len(inp)} B in, {len(out)} B out")
+
+
+if __name__ == "__main__":
+    main()
