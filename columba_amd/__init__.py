@@ -1,0 +1,325 @@
+"""columba_amd — MI355X-native search-scheme FM-index matcher (hot path of biointec/columba).
+
+Python host layer = plumbing around the C-ABI shared library ``libcolumba_amd.so``
+(include/columba_amd.h): ctypes bindings, index container/builder for synthetic data, and the
+read-sharding helper used by bench.py.  There is NO CPU fallback: every compute entry point goes to
+the HIP library and raises if it (or a GPU) is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcolumba_amd.so")
+_SRC = os.path.join(_HERE, "csrc", "columba_amd.hip")
+
+CMB_OK = 0
+ERRORS = {-1: "CMB_ERR_INVALID", -2: "CMB_ERR_DEVICE", -3: "CMB_ERR_UNSUPPORTED", -4: "CMB_ERR_OVERFLOW",
+          -5: "CMB_ERR_INTERNAL"}
+COUNTER_NAMES = ["NODE_COUNTER", "TOTAL_REPORTED_POSITIONS", "IN_TEXT_STARTED", "ABORTED_IN_TEXT_VERIF",
+                 "CIGARS_IN_TEXT_VERIFICATION", "IMMEDIATE_SWITCH", "SEARCH_STARTED", "EXPANSIONS", "LF_STEPS",
+                 "LOCATED_ROWS", "TEXT_BYTES", "MATRIX_ROWS"]
+METRIC = {"hamming": 0, "edit": 1}
+PARTITION = {"uniform": 0, "static": 1, "dynamic": 2}
+OCC_DTYPE = np.dtype([("begin", np.uint32), ("end", np.uint32), ("distance", np.uint32), ("strand", np.uint32)])
+
+EXPORTS = [
+    "cmb_index_create", "cmb_index_destroy", "cmb_index_device_bytes", "cmb_index_kmer_table",
+    "cmb_strategy_create_named", "cmb_strategy_create_from_dir", "cmb_strategy_create",
+    "cmb_strategy_add_scheme", "cmb_strategy_set_partition_params", "cmb_strategy_destroy",
+    "cmb_strategy_describe", "cmb_match_batch", "cmb_batch_create", "cmb_batch_run",
+    "cmb_batch_result_size", "cmb_batch_results", "cmb_batch_timings", "cmb_batch_destroy",
+    "cmb_rank_batch", "cmb_extend_batch", "cmb_extend_bench", "cmb_locate_batch", "cmb_verify_batch",
+    "cmb_last_error", "cmb_version",
+]
+
+
+class CmbError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+def build_library(force: bool = False) -> str:
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "columba_amd.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-Wno-unused-variable", "-o", LIB_PATH, _SRC]
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+class _IndexDesc(C.Structure):
+    _fields_ = [
+        ("text_length", C.c_uint64), ("text", C.c_void_p), ("counts", C.c_uint64 * 5),
+        ("dollar_pos_fwd", C.c_uint64), ("bv_fwd", C.c_void_p), ("cnt_fwd", C.c_void_p),
+        ("dollar_pos_rev", C.c_uint64), ("bv_rev", C.c_void_p), ("cnt_rev", C.c_void_p),
+        ("sa_bv", C.c_void_p), ("sa_bv_counts", C.c_void_p), ("sa_samples", C.c_void_p),
+        ("n_samples", C.c_uint64), ("sa_sparseness", C.c_uint32), ("seq_starts", C.c_void_p),
+        ("n_seqs", C.c_uint32), ("kmer_size", C.c_uint32), ("in_text_switch", C.c_uint32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load libcolumba_amd.so; raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                               "g.build()'` (the product has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+        L.cmb_last_error.restype = C.c_char_p
+        L.cmb_version.restype = C.c_char_p
+        L.cmb_index_create.argtypes = [C.POINTER(_IndexDesc), i32, C.POINTER(vp)]
+        L.cmb_index_destroy.argtypes = [vp]
+        L.cmb_index_device_bytes.restype = u64
+        L.cmb_index_device_bytes.argtypes = [vp]
+        L.cmb_index_kmer_table.argtypes = [vp, vp]
+        L.cmb_strategy_create_named.argtypes = [C.c_char_p, i32, i32, C.POINTER(vp)]
+        L.cmb_strategy_create_from_dir.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
+        L.cmb_strategy_create.argtypes = [i32, i32, u32, C.POINTER(vp)]
+        L.cmb_strategy_add_scheme.argtypes = [vp, u32, u32, u32, vp, vp, vp]
+        L.cmb_strategy_set_partition_params.argtypes = [vp, u32, vp, u32, vp, u32, vp, u32]
+        L.cmb_strategy_destroy.argtypes = [vp]
+        L.cmb_strategy_describe.argtypes = [vp, u32, C.POINTER(u32), C.POINTER(u32), vp, u32]
+        L.cmb_match_batch.argtypes = [vp, vp, u32, vp, vp, u32, vp, u64, vp, vp, C.POINTER(u64)]
+        L.cmb_batch_create.argtypes = [vp, vp, u32, vp, vp, u32, C.POINTER(vp)]
+        L.cmb_batch_run.argtypes = [vp]
+        L.cmb_batch_result_size.argtypes = [vp, C.POINTER(u64)]
+        L.cmb_batch_results.argtypes = [vp, vp, u64, vp, vp]
+        L.cmb_batch_timings.argtypes = [vp, vp, vp, u32]
+        L.cmb_batch_destroy.argtypes = [vp]
+        L.cmb_rank_batch.argtypes = [vp, i32, vp, vp, u64, vp]
+        L.cmb_extend_batch.argtypes = [vp, i32, vp, u64, vp, vp]
+        L.cmb_extend_bench.argtypes = [vp, i32, vp, u64, vp, vp, u32, C.POINTER(C.c_float)]
+        L.cmb_locate_batch.argtypes = [vp, vp, u64, vp, C.POINTER(u64)]
+        L.cmb_verify_batch.argtypes = [vp, C.c_char_p, u32, vp, u64, u32, u32, i32, vp, u64, C.POINTER(u64), vp]
+        _lib = L
+    return _lib
+
+
+def _chk(rc: int):
+    if rc != CMB_OK:
+        raise CmbError(rc, lib().cmb_last_error().decode(errors="replace"))
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Index:
+    """Device-resident bidirectional FM-index (handle of ``cmb_index_create``).
+
+    Mirrors the constructor of the reference's FMIndex (src/fmindex/fmindex.h:403):
+    ``Index(arrays, in_text_switch=4, sa_sparse=arrays.sparseness, kmer_size=10)``.
+    """
+
+    def __init__(self, ix, in_text_switch: int = 4, kmer_size: int = 10, device: int = 0):
+        d = _IndexDesc()
+        d.text_length = ix.n
+        d.text = _p(ix.text)
+        for i in range(5):
+            d.counts[i] = int(ix.counts[i])
+        d.dollar_pos_fwd = ix.dollar_pos_fwd
+        d.bv_fwd = _p(ix.bv_fwd)
+        d.cnt_fwd = _p(ix.cnt_fwd)
+        d.dollar_pos_rev = ix.dollar_pos_rev
+        d.bv_rev = _p(ix.bv_rev)
+        d.cnt_rev = _p(ix.cnt_rev)
+        d.sa_bv = _p(ix.sa_bv)
+        d.sa_bv_counts = _p(ix.sa_bv_counts)
+        d.sa_samples = _p(ix.sa_samples)
+        d.n_samples = ix.sa_samples.shape[0]
+        d.sa_sparseness = ix.sparseness
+        starts = np.ascontiguousarray(ix.seq_starts, np.uint32)
+        d.seq_starts = _p(starts)
+        d.n_seqs = starts.shape[0]
+        d.kmer_size = kmer_size
+        d.in_text_switch = in_text_switch
+        self.kmer_size = kmer_size
+        self.n = ix.n
+        h = C.c_void_p()
+        _chk(lib().cmb_index_create(C.byref(d), device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.cmb_index_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def device_bytes(self) -> int:
+        return int(lib().cmb_index_device_bytes(self.h))
+
+    def kmer_table(self) -> np.ndarray:
+        out = np.zeros((4 ** self.kmer_size, 4), np.uint32)
+        _chk(lib().cmb_index_kmer_table(self.h, _p(out)))
+        return out
+
+    def rank(self, rev: int, c, p) -> np.ndarray:
+        c = np.ascontiguousarray(c, np.uint32)
+        p = np.ascontiguousarray(p, np.uint64)
+        out = np.zeros(p.shape[0], np.uint64)
+        _chk(lib().cmb_rank_batch(self.h, rev, _p(c), _p(p), p.shape[0], _p(out)))
+        return out
+
+    def extend(self, mode: int, ranges) -> Tuple[np.ndarray, np.ndarray]:
+        r = np.ascontiguousarray(ranges, np.uint32).reshape(-1, 4)
+        out = np.zeros((r.shape[0], 4, 4), np.uint32)
+        ok = np.zeros((r.shape[0], 4), np.uint8)
+        _chk(lib().cmb_extend_batch(self.h, mode, _p(r), r.shape[0], _p(out), _p(ok)))
+        return out, ok
+
+    def locate(self, rows) -> Tuple[np.ndarray, int]:
+        rows = np.ascontiguousarray(rows, np.uint32)
+        out = np.zeros(rows.shape[0], np.uint32)
+        lf = C.c_uint64()
+        _chk(lib().cmb_locate_batch(self.h, _p(rows), rows.shape[0], _p(out), C.byref(lf)))
+        return out, int(lf.value)
+
+    def verify(self, pattern: bytes, starts, max_ed: int, min_ed: int, fixed: bool):
+        starts = np.ascontiguousarray(starts, np.uint32)
+        cap = starts.shape[0] * 32 + 64
+        out = np.zeros(cap, OCC_DTYPE)
+        n = C.c_uint64()
+        cnt = np.zeros(len(COUNTER_NAMES), np.uint64)
+        _chk(lib().cmb_verify_batch(self.h, pattern, len(pattern), _p(starts), starts.shape[0], max_ed, min_ed,
+                                    int(fixed), _p(out), cap, C.byref(n), _p(cnt)))
+        return out[:n.value], dict(zip(COUNTER_NAMES, cnt.tolist()))
+
+
+class SearchStrategy:
+    """Search schemes + partitioning (handle of ``cmb_strategy_*``).
+
+    ``SearchStrategy("kuch1" | "pigeon" | "multiple_opt", metric, partition)`` mirrors
+    ``Parameters::createStrategy`` (src/parameters/alignparameters.cpp:1313-1376);
+    ``SearchStrategy.from_dir(path, multiple=True)`` the ``-d`` / ``-c`` options.
+    """
+
+    def __init__(self, name: Optional[str] = "multiple_opt", metric: str = "edit", partition: str = "dynamic",
+                 _handle=None):
+        if _handle is not None:
+            self.h = _handle
+            return
+        h = C.c_void_p()
+        _chk(lib().cmb_strategy_create_named(name.encode(), METRIC[metric], PARTITION[partition], C.byref(h)))
+        self.h = h
+
+    @classmethod
+    def from_dir(cls, path: str, multiple: bool, metric: str = "edit", partition: str = "dynamic"):
+        h = C.c_void_p()
+        _chk(lib().cmb_strategy_create_from_dir(path.encode(), int(multiple), METRIC[metric], PARTITION[partition],
+                                                C.byref(h)))
+        return cls(_handle=h)
+
+    @classmethod
+    def from_tables(cls, spec: Dict, metric: str = "edit", partition: str = "dynamic"):
+        """spec = {"kmer_cutoff": int, "schemes": {k: [[(pi, L, U), ...], ...]}, "partition_params": {...}}"""
+        h = C.c_void_p()
+        _chk(lib().cmb_strategy_create(METRIC[metric], PARTITION[partition], spec.get("kmer_cutoff", 20), C.byref(h)))
+        self = cls(_handle=h)
+        for k, schemes in spec["schemes"].items():
+            for sch in schemes:
+                pi = np.ascontiguousarray([s[0] for s in sch], np.uint32)
+                lo = np.ascontiguousarray([s[1] for s in sch], np.uint32)
+                up = np.ascontiguousarray([s[2] for s in sch], np.uint32)
+                _chk(lib().cmb_strategy_add_scheme(h, k, pi.shape[0], pi.shape[1], _p(pi), _p(lo), _p(up)))
+        for k, pp in spec.get("partition_params", {}).items():
+            seed = np.ascontiguousarray(pp.get("seeding", []), np.float64)
+            w = np.ascontiguousarray(pp.get("weights", []), np.uint64)
+            b = np.ascontiguousarray(pp.get("begins", []), np.float64)
+            _chk(lib().cmb_strategy_set_partition_params(h, k, _p(seed), seed.shape[0], _p(w), w.shape[0], _p(b),
+                                                         b.shape[0]))
+        return self
+
+    def describe(self, k: int):
+        ns, npart = C.c_uint32(), C.c_uint32()
+        crit = np.zeros(8, np.uint32)
+        _chk(lib().cmb_strategy_describe(self.h, k, C.byref(ns), C.byref(npart), _p(crit), 8))
+        return ns.value, npart.value, crit[:ns.value].tolist()
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.cmb_strategy_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+def pack_reads(reads: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
+    offs = np.zeros(len(reads) + 1, np.uint64)
+    if reads:
+        offs[1:] = np.cumsum([len(r) for r in reads])
+    buf = np.frombuffer(b"".join(reads), dtype=np.uint8).copy() if reads else np.zeros(0, np.uint8)
+    if buf.shape[0] == 0:
+        buf = np.zeros(1, np.uint8)
+    return buf, offs
+
+
+class Batch:
+    """A batch of reads resident in HBM (handle of ``cmb_batch_*``)."""
+
+    def __init__(self, index: Index, strategy: SearchStrategy, max_distance: int, reads=None, packed=None):
+        buf, offs = packed if packed is not None else pack_reads(reads)
+        self.n_reads = offs.shape[0] - 1
+        self._keep = (index, strategy)
+        h = C.c_void_p()
+        _chk(lib().cmb_batch_create(index.h, strategy.h, max_distance, _p(buf), _p(offs), self.n_reads, C.byref(h)))
+        self.h = h
+
+    def run(self):
+        _chk(lib().cmb_batch_run(self.h))
+
+    def results(self):
+        n = C.c_uint64()
+        _chk(lib().cmb_batch_result_size(self.h, C.byref(n)))
+        occs = np.zeros(max(int(n.value), 1), OCC_DTYPE)
+        offs = np.zeros(self.n_reads + 1, np.uint64)
+        cnt = np.zeros(len(COUNTER_NAMES), np.uint64)
+        _chk(lib().cmb_batch_results(self.h, _p(occs), occs.shape[0], _p(offs), _p(cnt)))
+        return occs[:n.value], offs, dict(zip(COUNTER_NAMES, cnt.tolist()))
+
+    def timings(self) -> Dict[str, float]:
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = lib().cmb_batch_timings(self.h, names, ms, 16)
+        return {names[i].decode(): float(ms[i]) for i in range(n)}
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.cmb_batch_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+def match_batch(index: Index, strategy: SearchStrategy, max_distance: int, reads: Sequence[bytes]):
+    """``SearchStrategy::matchApprox`` for a whole chunk (src/parallel.cpp:67-78): returns
+    (occurrences, per-read offsets, counters)."""
+    b = Batch(index, strategy, max_distance, reads)
+    try:
+        b.run()
+        return b.results()
+    finally:
+        b.close()
+
+
+def shard_bounds(n_reads: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous read shard of ``rank``: ceil(N/G) reads per rank."""
+    per = (n_reads + world_size - 1) // world_size
+    lo = min(n_reads, rank * per)
+    return lo, min(n_reads, lo + per)

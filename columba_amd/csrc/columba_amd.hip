@@ -1,0 +1,774 @@
+// C-ABI implementation (include/columba_amd.h) on top of the HIP kernels.  gfx950 only.
+#include "../../include/columba_amd.h"
+#include "host_schemes.hpp"
+#include "kernels.hpp"
+
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace cmb;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+template <typename T> struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        HIPCHK(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+    }
+    void upload(const T* h, size_t count) {
+        alloc(count);
+        if (count) HIPCHK(hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice));
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+// ------------------------------------------------------------------------------------ index
+struct cmb_index {
+    int device = 0;
+    DevIndex d{};
+    DevBuf<uint64_t> bvF, cntF, bvR, cntR, saBv, saCnt;
+    DevBuf<uint32_t> saSamples;
+    DevBuf<uint8_t> text;
+    DevBuf<uint4> kmer;
+    std::vector<uint32_t> seqStarts;
+    uint64_t bytes = 0;
+};
+
+extern "C" const char* cmb_last_error(void) { return g_err.c_str(); }
+extern "C" const char* cmb_version(void) { return "columba_amd 0.1 (gfx950)"; }
+
+static void useDevice(int device) { HIPCHK(hipSetDevice(device)); }
+
+extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_index** out) {
+    if (!desc || !out) return fail(CMB_ERR_INVALID, "null argument");
+    if (desc->text_length == 0 || desc->text_length >= 0xFFFFFFFFull)
+        return fail(CMB_ERR_UNSUPPORTED, "text length must fit a 32-bit length_t");
+    if (desc->kmer_size > 12) return fail(CMB_ERR_INVALID, "k-mer size > 12 not supported");
+    if (desc->sa_sparseness == 0 || (desc->sa_sparseness & (desc->sa_sparseness - 1)))
+        return fail(CMB_ERR_INVALID, "suffix array sparseness must be a power of two");
+    try {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+            return fail(CMB_ERR_DEVICE, "no HIP device available (the product path has no CPU fallback)");
+        useDevice(device);
+        std::unique_ptr<cmb_index> ix(new cmb_index());
+        ix->device = device;
+        const uint64_t n = desc->text_length, N = n + 1;
+        const uint64_t bvW = 4 * ((N + 63) / 64), cW = 8 * ((N + 511) / 512);
+        ix->bvF.upload(desc->bv_fwd, bvW);
+        ix->cntF.upload(desc->cnt_fwd, cW);
+        ix->bvR.upload(desc->bv_rev, bvW);
+        ix->cntR.upload(desc->cnt_rev, cW);
+        const uint64_t saW = (n + 63) / 64;
+        ix->saBv.upload(desc->sa_bv, saW);
+        ix->saCnt.upload(desc->sa_bv_counts, (saW + 7) / 4);
+        ix->saSamples.upload(desc->sa_samples, desc->n_samples);
+        ix->text.upload(desc->text, n);
+        ix->kmer.alloc(1ull << (2 * desc->kmer_size));
+        if (desc->seq_starts) ix->seqStarts.assign(desc->seq_starts, desc->seq_starts + desc->n_seqs);
+        DevIndex& d = ix->d;
+        d.n = (uint32_t)n;
+        for (int i = 0; i < 5; i++) d.counts[i] = (uint32_t)desc->counts[i];
+        d.fwd = DevBWT{ix->bvF.p, ix->cntF.p, (uint32_t)desc->dollar_pos_fwd};
+        d.rev = DevBWT{ix->bvR.p, ix->cntR.p, (uint32_t)desc->dollar_pos_rev};
+        d.saBv = ix->saBv.p;
+        d.saCnt = ix->saCnt.p;
+        d.saSamples = ix->saSamples.p;
+        d.text = ix->text.p;
+        d.kmer = ix->kmer.p;
+        d.kmerSize = desc->kmer_size;
+        d.switchPoint = desc->in_text_switch;
+        const uint32_t total = 1u << (2 * desc->kmer_size);
+        hipLaunchKernelGGL(k_kmer_table, dim3((total + 255) / 256), dim3(256), 0, 0, d, ix->kmer.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipDeviceSynchronize());
+        ix->bytes = ix->bvF.bytes() + ix->cntF.bytes() + ix->bvR.bytes() + ix->cntR.bytes() + ix->saBv.bytes() +
+                    ix->saCnt.bytes() + ix->saSamples.bytes() + ix->text.bytes() + ix->kmer.bytes();
+        *out = ix.release();
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}
+extern "C" void cmb_index_destroy(cmb_index* idx) {
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    delete idx;
+}
+extern "C" uint64_t cmb_index_device_bytes(const cmb_index* idx) { return idx ? idx->bytes : 0; }
+extern "C" int cmb_index_kmer_table(const cmb_index* idx, uint32_t* out) {
+    if (!idx || !out) return fail(CMB_ERR_INVALID, "null argument");
+    try {
+        useDevice(idx->device);
+        HIPCHK(hipMemcpy(out, idx->kmer.p, idx->kmer.bytes(), hipMemcpyDeviceToHost));
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}
+
+// --------------------------------------------------------------------------------- strategy
+extern "C" int cmb_strategy_create(int metric, int partition, uint32_t kmer_cutoff, cmb_strategy** out) {
+    if (!out || metric < 0 || metric > 1 || partition < 0 || partition > 2)
+        return fail(CMB_ERR_INVALID, "bad metric / partition strategy");
+    cmb_strategy* s = new cmb_strategy();
+    s->metric = metric;
+    s->partition = partition;
+    s->kmerCutOff = kmer_cutoff;
+    *out = s;
+    return CMB_OK;
+}
+extern "C" int cmb_strategy_create_named(const char* name, int metric, int partition, cmb_strategy** out) {
+    cmb_strategy* s = nullptr;
+    int rc = cmb_strategy_create(metric, partition, 20, &s);
+    if (rc) return rc;
+    try {
+        fillNamed(*s, name ? name : "");
+    } catch (const std::exception& e) {
+        delete s;
+        return fail(CMB_ERR_INVALID, e.what());
+    }
+    *out = s;
+    return CMB_OK;
+}
+extern "C" int cmb_strategy_create_from_dir(const char* dir, int multiple, int metric, int partition,
+                                            cmb_strategy** out) {
+    cmb_strategy* s = nullptr;
+    int rc = cmb_strategy_create(metric, partition, 20, &s);
+    if (rc) return rc;
+    try {
+        if (multiple) fillFromMultipleDir(*s, dir ? dir : "");
+        else fillFromCustomDir(*s, dir ? dir : "");
+    } catch (const std::exception& e) {
+        delete s;
+        return fail(CMB_ERR_INVALID, e.what());
+    }
+    *out = s;
+    return CMB_OK;
+}
+extern "C" int cmb_strategy_add_scheme(cmb_strategy* s, uint32_t k, uint32_t n_searches, uint32_t n_parts,
+                                       const uint32_t* pi, const uint32_t* L, const uint32_t* U) {
+    if (!s || !pi || !L || !U) return fail(CMB_ERR_INVALID, "null argument");
+    try {
+        HostScheme sch;
+        sch.k = k;
+        for (uint32_t i = 0; i < n_searches; i++) {
+            HostSearch h;
+            h.pi.assign(pi + i * n_parts, pi + (i + 1) * n_parts);
+            h.L.assign(L + i * n_parts, L + (i + 1) * n_parts);
+            h.U.assign(U + i * n_parts, U + (i + 1) * n_parts);
+            h.sIdx = i;
+            sch.searches.push_back(h);
+        }
+        sch.finalize();
+        for (const auto& h : sch.searches) (void)toDevSearch(h);
+        s->schemes[k].push_back(sch);
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_INVALID, e.what());
+    }
+}
+extern "C" int cmb_strategy_set_partition_params(cmb_strategy* s, uint32_t k, const double* seeding,
+                                                 uint32_t n_seeding, const uint64_t* weights, uint32_t n_weights,
+                                                 const double* begins, uint32_t n_begins) {
+    if (!s) return fail(CMB_ERR_INVALID, "null argument");
+    PartitionParams pp;
+    if (n_seeding) pp.seeding.assign(seeding, seeding + n_seeding);
+    if (n_weights) pp.weights.assign(weights, weights + n_weights);
+    if (n_begins) pp.begins.assign(begins, begins + n_begins);
+    s->params[k] = pp;
+    return CMB_OK;
+}
+extern "C" void cmb_strategy_destroy(cmb_strategy* s) { delete s; }
+extern "C" int cmb_strategy_describe(const cmb_strategy* s, uint32_t k, uint32_t* n_schemes, uint32_t* n_parts,
+                                     uint32_t* critical_parts, uint32_t cap) {
+    if (!s) return fail(CMB_ERR_INVALID, "null argument");
+    auto it = s->schemes.find(k);
+    if (it == s->schemes.end() || it->second.empty())
+        return fail(CMB_ERR_INVALID, "the search strategy does not support distance " + std::to_string(k));
+    if (n_schemes) *n_schemes = (uint32_t)it->second.size();
+    if (n_parts) *n_parts = it->second.front().numParts();
+    for (uint32_t i = 0; critical_parts && i < cap && i < it->second.size(); i++)
+        critical_parts[i] = it->second[i].critical;
+    return CMB_OK;
+}
+
+// ------------------------------------------------------------------------------------ batch
+struct KernelTime {
+    const char* name;
+    float ms;
+};
+
+struct cmb_batch {
+    cmb_index* ix = nullptr;
+    uint32_t k = 0, nReads = 0, maxLen = 0, gw = 0;
+    int metric = 1;
+    DevStrategyK hostStrat{};
+    hipStream_t stream = nullptr;
+    DevBuf<uint8_t> reads, seq;
+    DevBuf<uint64_t> offs;
+    DevBuf<uint32_t> G;
+    DevBuf<DevStrategyK> strat;
+    DevBuf<Scratch> slabs;
+    DevBuf<VScratch> vslabs;
+    DevBuf<uint4> items;
+    DevBuf<FMOccRec> fm, fmUniq;
+    DevBuf<TextOccRec> text;
+    DevBuf<uint32_t> cnt;
+    DevBuf<unsigned long long> counters;
+    uint32_t nSlots = 0, nVSlots = 0;
+    std::vector<uint64_t> hostOffs;
+    // results
+    std::vector<cmb_occ> occs;
+    std::vector<uint64_t> occOffs;
+    uint64_t cnts[CMB_CNT_MAX];
+    std::vector<KernelTime> times;
+    bool done = false;
+    ~cmb_batch() {
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+extern "C" int cmb_batch_create(cmb_index* idx, const cmb_strategy* st, uint32_t max_distance, const char* seqs,
+                                const uint64_t* offs, uint32_t n_reads, cmb_batch** out) {
+    if (!idx || !st || !offs || !out || (!seqs && n_reads)) return fail(CMB_ERR_INVALID, "null argument");
+    if (n_reads >= 0x7FFFFFFFu) return fail(CMB_ERR_INVALID, "too many reads in one batch");
+    try {
+        useDevice(idx->device);
+        std::unique_ptr<cmb_batch> b(new cmb_batch());
+        b->ix = idx;
+        b->k = max_distance;
+        b->nReads = n_reads;
+        b->metric = st->metric;
+        if (max_distance > 0) {
+            // use64Matrix (fmindex.h:240-246): nZeros + maxED = 3k+1 must fit LEFT = 21
+            if (st->metric == CMB_METRIC_EDIT && 3 * max_distance + 1 > MX_LEFT)
+                return fail(CMB_ERR_UNSUPPORTED, "k >= 7 needs the 128-bit matrix, which is not implemented");
+            try {
+                b->hostStrat = st->flatten(max_distance);
+            } catch (const std::exception& e) {
+                return fail(CMB_ERR_INVALID, e.what());
+            }
+        }
+        uint32_t maxLen = 1;
+        for (uint32_t i = 0; i < n_reads; i++) {
+            if (offs[i + 1] < offs[i]) return fail(CMB_ERR_INVALID, "read offsets must be non-decreasing");
+            maxLen = std::max<uint32_t>(maxLen, (uint32_t)(offs[i + 1] - offs[i]));
+        }
+        if (maxLen > (uint32_t)MAX_READ)
+            return fail(CMB_ERR_UNSUPPORTED, "reads longer than " + std::to_string(MAX_READ) + " are not supported");
+        b->maxLen = maxLen;
+        b->gw = gWords(maxLen);
+        b->hostOffs.assign(offs, offs + n_reads + 1);
+        HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+        b->reads.upload((const uint8_t*)seqs, offs[n_reads]);
+        b->offs.upload(offs, n_reads + 1);
+        b->seq.alloc((size_t)2 * n_reads * maxLen);
+        b->G.alloc((size_t)2 * n_reads * 8 * b->gw);
+        b->strat.upload(&b->hostStrat, 1);
+        const uint32_t tasks = 2 * n_reads;
+        b->nSlots = std::min<uint32_t>(((tasks + 255) / 256) * 256, 256u * 512u);
+        if (b->nSlots == 0) b->nSlots = 256;
+        b->slabs.alloc(b->nSlots);
+        b->items.alloc((size_t)n_reads * 64 + 4096);
+        b->fm.alloc((size_t)n_reads * 8 + 4096);
+        b->text.alloc((size_t)n_reads * 48 + 4096);
+        b->cnt.alloc(8);
+        b->counters.alloc(CMB_CNT_MAX);
+        *out = b.release();
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}
+
+namespace {
+
+struct Timer {
+    hipStream_t s;
+    hipEvent_t a, b;
+    std::vector<KernelTime>& out;
+    Timer(hipStream_t st, std::vector<KernelTime>& o) : s(st), out(o) {
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+    }
+    ~Timer() {
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+    }
+    void begin() { (void)hipEventRecord(a, s); }
+    void end(const char* name) {
+        (void)hipEventRecord(b, s);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        for (auto& t : out)
+            if (!strcmp(t.name, name)) {
+                t.ms += ms;
+                return;
+            }
+        out.push_back({name, ms});
+    }
+};
+
+struct HostOcc {
+    uint32_t begin, end, dist, strand;
+};
+
+// ordering of TextOcc (indexhelpers.h:779-795) with the strand as final, deterministic tie-break
+inline bool occLess(const HostOcc& a, const HostOcc& b) {
+    if (a.begin != b.begin) return a.begin < b.begin;
+    if (a.dist != b.dist) return a.dist < b.dist;
+    const uint32_t wa = a.end > a.begin ? a.end - a.begin : 0, wb = b.end > b.begin ? b.end - b.begin : 0;
+    if (wa != wb) return wa < wb;
+    return a.strand < b.strand;
+}
+
+} // namespace
+
+extern "C" int cmb_batch_run(cmb_batch* b) {
+    if (!b) return fail(CMB_ERR_INVALID, "null argument");
+    try {
+        cmb_index* ix = b->ix;
+        useDevice(ix->device);
+        hipStream_t s = b->stream;
+        b->times.clear();
+        b->done = false;
+        Timer tm(s, b->times);
+        const uint32_t nReads = b->nReads;
+        const uint32_t tasks = 2 * nReads;
+        uint32_t hcnt[8];
+        Queues q{};
+        q.cnt = b->cnt.p;
+        q.counters = b->counters.p;
+
+        HIPCHK(hipMemsetAsync(b->counters.p, 0, CMB_CNT_MAX * sizeof(unsigned long long), s));
+        tm.begin();
+        hipLaunchKernelGGL(k_prep, dim3((tasks + 255) / 256), dim3(256), 0, s, b->reads.p, b->offs.p, nReads,
+                           b->maxLen, b->gw, b->seq.p, b->G.p);
+        tm.end("k_prep");
+
+        // ---- search (re-run with larger queues if they overflow: nothing is truncated)
+        for (int attempt = 0;; attempt++) {
+            HIPCHK(hipMemsetAsync(b->cnt.p, 0, 8 * sizeof(uint32_t), s));
+            // counters written by k_search are reset on a retry
+            if (attempt) {
+                HIPCHK(hipMemsetAsync(b->counters.p, 0, CMB_CNT_MAX * sizeof(unsigned long long), s));
+            }
+            q.items = b->items.p;
+            q.itemCap = (uint32_t)std::min<size_t>(b->items.n, 0xFFFFFFF0u);
+            q.fm = b->fm.p;
+            q.fmCap = (uint32_t)std::min<size_t>(b->fm.n, 0xFFFFFFF0u);
+            q.text = b->text.p;
+            q.textCap = (uint32_t)std::min<size_t>(b->text.n, 0xFFFFFFF0u);
+            tm.begin();
+            hipLaunchKernelGGL(k_search, dim3(b->nSlots / 256), dim3(256), 0, s, ix->d, b->strat.p, b->offs.p, nReads,
+                               b->k, b->maxLen, b->gw, b->seq.p, b->G.p, b->slabs.p, q);
+            tm.end("k_search");
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            const uint32_t flags = hcnt[3];
+            if (flags & FLAG_UNSUPPORTED_READ)
+                return fail(CMB_ERR_UNSUPPORTED,
+                            "a read is not longer than the number of parts of the search scheme (the reference "
+                            "falls back to naive backtracking, which the device path does not provide)");
+            if (flags & FLAG_CAPACITY)
+                return fail(CMB_ERR_INTERNAL, "device search capacity exceeded (band width / descendants / stack)");
+            if (flags & (FLAG_ITEM_OVERFLOW | FLAG_FMOCC_OVERFLOW)) {
+                if (attempt >= 3) return fail(CMB_ERR_INTERNAL, "work queues keep overflowing");
+                if (hcnt[0] > q.itemCap) b->items.alloc((size_t)hcnt[0] + hcnt[0] / 8 + 1024);
+                if (hcnt[1] > q.fmCap) b->fm.alloc((size_t)hcnt[1] + hcnt[1] / 8 + 1024);
+                continue;
+            }
+            break;
+        }
+        const uint32_t nItems = hcnt[0], nFm = hcnt[1];
+
+        // ---- de-duplicate the in-index occurrences per read (Occurrences::eraseDoublesFM,
+        // indexhelpers.h:2135-2146) on the host: small
+        std::vector<FMOccRec> fm(nFm);
+        if (nFm) HIPCHK(hipMemcpy(fm.data(), b->fm.p, nFm * sizeof(FMOccRec), hipMemcpyDeviceToHost));
+        std::sort(fm.begin(), fm.end(), [](const FMOccRec& x, const FMOccRec& y) {
+            const uint32_t rx = x.rsId >> 1, ry = y.rsId >> 1;
+            if (rx != ry) return rx < ry;
+            if (x.b != y.b) return x.b < y.b;
+            if (x.dist != y.dist) return x.dist < y.dist;
+            if (x.e != y.e) return x.e < y.e;
+            if (x.shift != y.shift) return x.shift < y.shift;
+            if (x.depth != y.depth) return x.depth < y.depth;
+            return x.rsId < y.rsId;
+        });
+        fm.erase(std::unique(fm.begin(), fm.end(),
+                             [](const FMOccRec& x, const FMOccRec& y) {
+                                 return x.rsId == y.rsId && x.b == y.b && x.e == y.e && x.dist == y.dist &&
+                                        x.depth == y.depth && x.shift == y.shift;
+                             }),
+                 fm.end());
+        uint64_t fmRows = 0;
+        for (const auto& f : fm) fmRows += f.e - f.b;
+        if (!fm.empty()) b->fmUniq.upload(fm.data(), fm.size());
+
+        // ---- locate + verify; text queue retried on overflow
+        if (b->vslabs.n == 0) {
+            b->nVSlots = std::min<uint32_t>(std::max<uint32_t>(((nItems + 255) / 256) * 256, 256u), 256u * 1024u);
+            b->vslabs.alloc(b->nVSlots);
+        }
+        uint32_t textFromVerify = 0;
+        for (int attempt = 0;; attempt++) {
+            q.text = b->text.p;
+            q.textCap = (uint32_t)std::min<size_t>(b->text.n, 0xFFFFFFF0u);
+            uint32_t zero[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(b->cnt.p + 2, zero, sizeof(zero), hipMemcpyHostToDevice, s));
+            unsigned long long keep[CMB_CNT_MAX];
+            HIPCHK(hipMemcpyAsync(keep, b->counters.p, sizeof(keep), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (nItems) {
+                tm.begin();
+                hipLaunchKernelGGL(k_verify, dim3(b->nVSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->maxLen,
+                                   b->gw, b->seq.p, b->G.p, b->items.p, nItems, b->vslabs.p, q);
+                tm.end("k_verify");
+            }
+            HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            textFromVerify = hcnt[2];
+            if (!fm.empty()) {
+                tm.begin();
+                const uint32_t nb = (uint32_t)std::min<size_t>((fm.size() + 255) / 256, 4096);
+                hipLaunchKernelGGL(k_fmocc, dim3(nb), dim3(256), 0, s, ix->d, b->fmUniq.p, (uint32_t)fm.size(), q);
+                tm.end("k_fmocc");
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (hcnt[3] & FLAG_TEXT_OVERFLOW) {
+                if (attempt >= 3) return fail(CMB_ERR_INTERNAL, "text occurrence queue keeps overflowing");
+                b->text.alloc((size_t)hcnt[2] + hcnt[2] / 8 + 1024);
+                HIPCHK(hipMemcpy(b->counters.p, keep, sizeof(keep), hipMemcpyHostToDevice));
+                continue;
+            }
+            break;
+        }
+        const uint32_t nText = hcnt[2];
+
+        // ---- gather + filter on the host (getUniqueTextOccurrences / getTextOccHamming,
+        // indexinterface.cpp:1331-1491)
+        std::vector<TextOccRec> text(nText);
+        if (nText) HIPCHK(hipMemcpy(text.data(), b->text.p, nText * sizeof(TextOccRec), hipMemcpyDeviceToHost));
+        unsigned long long hc[CMB_CNT_MAX];
+        HIPCHK(hipMemcpy(hc, b->counters.p, sizeof(hc), hipMemcpyDeviceToHost));
+        for (int i = 0; i < CMB_CNT_MAX; i++) b->cnts[i] = hc[i];
+
+        std::vector<uint64_t> start(nReads + 1, 0);
+        for (const auto& t : text) start[(t.rsId >> 1) + 1]++;
+        for (uint32_t r = 0; r < nReads; r++) start[r + 1] += start[r];
+        std::vector<HostOcc> bucket(nText);
+        {
+            std::vector<uint64_t> fill(start.begin(), start.end() - 1);
+            for (const auto& t : text) bucket[fill[t.rsId >> 1]++] = HostOcc{t.begin, t.end, t.dist, t.rsId & 1u};
+        }
+        b->occs.clear();
+        b->occOffs.assign(nReads + 1, 0);
+        const uint32_t maxED = b->k;
+        for (uint32_t r = 0; r < nReads; r++) {
+            HostOcc* lo = bucket.data() + start[r];
+            HostOcc* hi = bucket.data() + start[r + 1];
+            std::sort(lo, hi, occLess);
+            if (maxED == 0) { // searchstrategy.cpp:499-510: no de-duplication for exact matches
+                for (HostOcc* o = lo; o != hi; ++o) b->occs.push_back({o->begin, o->end, o->dist, o->strand});
+            } else {
+                // eraseDoublesAndSortText: equal = same range and distance (indexhelpers.h:811)
+                HostOcc* end = std::unique(lo, hi, [](const HostOcc& x, const HostOcc& y) {
+                    return x.begin == y.begin && x.end == y.end && x.dist == y.dist;
+                });
+                if (b->metric == CMB_METRIC_HAMMING) {
+                    for (HostOcc* o = lo; o != end; ++o) b->occs.push_back({o->begin, o->end, o->dist, o->strand});
+                } else { // redundancy filter (indexinterface.cpp:1447-1485)
+                    const uint32_t maxDiff = 2 * maxED;
+                    uint32_t prevBegin = 0xFFFFFFFFu, prevDepth = 0xFFFFFFFFu, prevED = maxED + 1;
+                    const size_t base = b->occs.size();
+                    for (HostOcc* o = lo; o != end; ++o) {
+                        const uint32_t diff = o->begin > prevBegin ? o->begin - prevBegin : prevBegin - o->begin;
+                        if (diff == 0) continue;
+                        const uint32_t width = o->end > o->begin ? o->end - o->begin : 0;
+                        if (diff <= maxDiff) {
+                            if (o->dist > prevED || (o->dist == prevED && width >= prevDepth)) continue;
+                            if (b->occs.size() > base) b->occs.pop_back();
+                        }
+                        prevBegin = o->begin;
+                        prevED = o->dist;
+                        prevDepth = width;
+                        b->occs.push_back({o->begin, o->end, o->dist, o->strand});
+                    }
+                }
+            }
+            b->occOffs[r + 1] = b->occs.size();
+        }
+        // TOTAL_REPORTED_POSITIONS (indexinterface.cpp:1378,1390 / :1333,1352)
+        b->cnts[CMB_CNT_TOTAL_REPORTED] = (uint64_t)textFromVerify + fmRows;
+        b->done = true;
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}
+
+extern "C" int cmb_batch_result_size(const cmb_batch* b, uint64_t* n_occ) {
+    if (!b || !n_occ) return fail(CMB_ERR_INVALID, "null argument");
+    if (!b->done) return fail(CMB_ERR_INVALID, "batch has not been run");
+    *n_occ = b->occs.size();
+    return CMB_OK;
+}
+extern "C" int cmb_batch_results(const cmb_batch* b, cmb_occ* out, uint64_t out_cap, uint64_t* out_offs,
+                                 uint64_t* counters) {
+    if (!b) return fail(CMB_ERR_INVALID, "null argument");
+    if (!b->done) return fail(CMB_ERR_INVALID, "batch has not been run");
+    if (out_cap < b->occs.size()) return fail(CMB_ERR_OVERFLOW, "output buffer too small");
+    if (out && !b->occs.empty()) memcpy(out, b->occs.data(), b->occs.size() * sizeof(cmb_occ));
+    if (out_offs) memcpy(out_offs, b->occOffs.data(), b->occOffs.size() * sizeof(uint64_t));
+    if (counters) memcpy(counters, b->cnts, sizeof(b->cnts));
+    return CMB_OK;
+}
+extern "C" int cmb_batch_timings(const cmb_batch* b, const char** names, float* ms, uint32_t cap) {
+    if (!b) return 0;
+    uint32_t n = 0;
+    for (const auto& t : b->times) {
+        if (n >= cap) break;
+        if (names) names[n] = t.name;
+        if (ms) ms[n] = t.ms;
+        n++;
+    }
+    return (int)n;
+}
+extern "C" void cmb_batch_destroy(cmb_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ix->device);
+    delete b;
+}
+
+extern "C" int cmb_match_batch(cmb_index* idx, const cmb_strategy* st, uint32_t max_distance, const char* seqs,
+                               const uint64_t* offs, uint32_t n_reads, cmb_occ* out, uint64_t out_cap,
+                               uint64_t* out_offs, uint64_t* counters, uint64_t* needed) {
+    cmb_batch* b = nullptr;
+    int rc = cmb_batch_create(idx, st, max_distance, seqs, offs, n_reads, &b);
+    if (rc) return rc;
+    rc = cmb_batch_run(b);
+    if (rc == CMB_OK) {
+        uint64_t n = 0;
+        cmb_batch_result_size(b, &n);
+        if (needed) *needed = n;
+        rc = cmb_batch_results(b, out, out_cap, out_offs, counters);
+    }
+    cmb_batch_destroy(b);
+    return rc;
+}
+
+// ------------------------------------------------------------------------- fine-grained hooks
+extern "C" int cmb_rank_batch(cmb_index* idx, int rev, const uint32_t* c, const uint64_t* p, uint64_t n,
+                              uint64_t* out) {
+    if (!idx || (n && (!c || !p || !out))) return fail(CMB_ERR_INVALID, "null argument");
+    try {
+        useDevice(idx->device);
+        for (uint64_t i = 0; i < n; i++)
+            if (c[i] > 3 || p[i] > idx->d.n) return fail(CMB_ERR_INVALID, "rank argument out of range");
+        DevBuf<uint32_t> dc;
+        DevBuf<uint64_t> dp, dout;
+        dc.upload(c, n);
+        dp.upload(p, n);
+        dout.alloc(n);
+        if (n) hipLaunchKernelGGL(k_rank, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, idx->d, rev, dc.p, dp.p, n, dout.p);
+        HIPCHK(hipGetLastError());
+        if (n) HIPCHK(hipMemcpy(out, dout.p, n * 8, hipMemcpyDeviceToHost));
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}
+
+static int checkRanges(const cmb_index* idx, const uint32_t* in, uint64_t n) {
+    for (uint64_t i = 0; i < 4 * n; i++)
+        if (in[i] > idx->d.n) return fail(CMB_ERR_INVALID, "range bound beyond the text length");
+    return CMB_OK;
+}
+
+extern "C" int cmb_extend_batch(cmb_index* idx, int mode, const uint32_t* in, uint64_t n, uint32_t* out,
+                                uint8_t* ok) {
+    if (!idx || mode < 0 || mode > 2 || (n && (!in || !out || !ok))) return fail(CMB_ERR_INVALID, "bad argument");
+    if (checkRanges(idx, in, n)) return CMB_ERR_INVALID;
+    try {
+        useDevice(idx->device);
+        DevBuf<uint4> din, dout;
+        DevBuf<uint8_t> dok;
+        din.upload((const uint4*)in, n);
+        dout.alloc(4 * n);
+        dok.alloc(4 * n);
+        if (n) {
+            const unsigned nb = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 32);
+            hipLaunchKernelGGL(k_extend, dim3(nb), dim3(256), 0, 0, idx->d, mode, din.p, n, dout.p, dok.p);
+        }
+        HIPCHK(hipGetLastError());
+        if (n) {
+            HIPCHK(hipMemcpy(out, dout.p, n * 64, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(ok, dok.p, n * 4, hipMemcpyDeviceToHost));
+        }
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}
+
+extern "C" int cmb_extend_bench(cmb_index* idx, int mode, const void* d_in, uint64_t n, void* d_out, void* d_ok,
+                                uint32_t iters, float* avg_ms) {
+    if (!idx || mode < 0 || mode > 2 || !d_in || !d_out || !d_ok || !avg_ms || !iters)
+        return fail(CMB_ERR_INVALID, "bad argument");
+    try {
+        useDevice(idx->device);
+        hipStream_t s;
+        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&b));
+        const unsigned nb = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL(k_extend, dim3(nb), dim3(256), 0, s, idx->d, mode, (const uint4*)d_in, n, (uint4*)d_out,
+                           (uint8_t*)d_ok); // warm-up
+        HIPCHK(hipEventRecord(a, s));
+        for (uint32_t i = 0; i < iters; i++)
+            hipLaunchKernelGGL(k_extend, dim3(nb), dim3(256), 0, s, idx->d, mode, (const uint4*)d_in, n,
+                               (uint4*)d_out, (uint8_t*)d_ok);
+        HIPCHK(hipEventRecord(b, s));
+        HIPCHK(hipEventSynchronize(b));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, a, b));
+        *avg_ms = ms / iters;
+        HIPCHK(hipGetLastError());
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+        (void)hipStreamDestroy(s);
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}
+
+extern "C" int cmb_locate_batch(cmb_index* idx, const uint32_t* rows, uint64_t n, uint32_t* out,
+                                uint64_t* lf_steps) {
+    if (!idx || (n && (!rows || !out))) return fail(CMB_ERR_INVALID, "null argument");
+    for (uint64_t i = 0; i < n; i++)
+        if (rows[i] >= idx->d.n) return fail(CMB_ERR_INVALID, "suffix array row out of range");
+    try {
+        useDevice(idx->device);
+        DevBuf<uint32_t> dr, dout;
+        DevBuf<unsigned long long> dlf;
+        dr.upload(rows, n);
+        dout.alloc(n);
+        dlf.alloc(1);
+        HIPCHK(hipMemset(dlf.p, 0, 8));
+        if (n) hipLaunchKernelGGL(k_locate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, idx->d, dr.p, n, dout.p, dlf.p);
+        HIPCHK(hipGetLastError());
+        if (n) HIPCHK(hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost));
+        unsigned long long lf = 0;
+        HIPCHK(hipMemcpy(&lf, dlf.p, 8, hipMemcpyDeviceToHost));
+        if (lf_steps) *lf_steps = lf;
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}
+
+// in-text verification hook: FMIndex::inTextVerification(startPos, maxED, minED, ..., pattern,
+// fixedStartPos) (fmindex.cpp:267-310) for one pattern.  Runs the production k_prep + k_verify on a
+// one-read batch whose items carry the start positions directly (meta bit 23: nothing to locate).
+extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t plen, const uint32_t* starts,
+                                uint64_t n, uint32_t max_ed, uint32_t min_ed, int fixed_start, cmb_occ* out,
+                                uint64_t out_cap, uint64_t* n_out, uint64_t* counters) {
+    if (!idx || !pattern || (n && !starts) || !n_out) return fail(CMB_ERR_INVALID, "null argument");
+    if (plen == 0 || plen > (uint32_t)MAX_READ) return fail(CMB_ERR_UNSUPPORTED, "pattern length not supported");
+    if (3 * max_ed + 1 > MX_LEFT || min_ed > 15) return fail(CMB_ERR_UNSUPPORTED, "needs the 128-bit matrix");
+    for (uint64_t i = 0; i < n; i++)
+        if (starts[i] > idx->d.n) return fail(CMB_ERR_INVALID, "start position beyond the text");
+    try {
+        useDevice(idx->device);
+        const uint32_t gw = gWords(plen);
+        DevBuf<uint8_t> reads, seq;
+        DevBuf<uint64_t> offs;
+        DevBuf<uint32_t> G, cnt;
+        DevBuf<uint4> items;
+        DevBuf<TextOccRec> text;
+        DevBuf<VScratch> vs;
+        DevBuf<unsigned long long> ctr;
+        const uint64_t ho[2] = {0, plen};
+        reads.upload((const uint8_t*)pattern, plen);
+        offs.upload(ho, 2);
+        seq.alloc(2 * (size_t)plen);
+        G.alloc(2 * 8 * (size_t)gw);
+        std::vector<uint4> hi(n);
+        const uint32_t meta = (max_ed << 12) | (min_ed << 16) | ((fixed_start ? 1u : 0u) << 20) |
+                              ((uint32_t)ITEM_EDIT << 21) | (1u << 23);
+        for (uint64_t i = 0; i < n; i++) hi[i] = make_uint4(0, starts[i], 0, meta);
+        items.upload(hi.data(), n);
+        const size_t cap = n * 32 + 64;
+        text.alloc(cap);
+        cnt.alloc(8);
+        ctr.alloc(CMB_CNT_MAX);
+        HIPCHK(hipMemset(cnt.p, 0, 32));
+        HIPCHK(hipMemset(ctr.p, 0, CMB_CNT_MAX * 8));
+        const uint32_t slots = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(((n + 255) / 256) * 256, 256), 65536);
+        vs.alloc(slots);
+        Queues q{};
+        q.text = text.p;
+        q.textCap = (uint32_t)cap;
+        q.cnt = cnt.p;
+        q.counters = ctr.p;
+        hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, 0, reads.p, offs.p, 1u, plen, gw, seq.p, G.p);
+        if (n)
+            hipLaunchKernelGGL(k_verify, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, plen, gw, seq.p, G.p,
+                               items.p, (uint32_t)n, vs.p, q);
+        HIPCHK(hipGetLastError());
+        uint32_t hc[8];
+        HIPCHK(hipMemcpy(hc, cnt.p, 32, hipMemcpyDeviceToHost));
+        if (hc[3] & FLAG_TEXT_OVERFLOW) return fail(CMB_ERR_INTERNAL, "verification output overflow");
+        *n_out = hc[2];
+        if (hc[2] > out_cap) return fail(CMB_ERR_OVERFLOW, "output buffer too small");
+        std::vector<TextOccRec> t(hc[2]);
+        if (hc[2]) HIPCHK(hipMemcpy(t.data(), text.p, hc[2] * sizeof(TextOccRec), hipMemcpyDeviceToHost));
+        std::sort(t.begin(), t.end(), [](const TextOccRec& x, const TextOccRec& y) {
+            if (x.begin != y.begin) return x.begin < y.begin;
+            if (x.end != y.end) return x.end < y.end;
+            return x.dist < y.dist;
+        });
+        for (uint32_t i = 0; i < hc[2]; i++) out[i] = cmb_occ{t[i].begin, t[i].end, t[i].dist, 0};
+        if (counters) {
+            unsigned long long c2[CMB_CNT_MAX];
+            HIPCHK(hipMemcpy(c2, ctr.p, sizeof(c2), hipMemcpyDeviceToHost));
+            for (int i = 0; i < CMB_CNT_MAX; i++) counters[i] = c2[i];
+        }
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}

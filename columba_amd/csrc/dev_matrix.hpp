@@ -1,0 +1,141 @@
+// Device-side banded bit-parallel edit-distance matrix (64-bit words).
+//
+// Replaces BitParallelED<uint64_t> (reference src/bitparallelmatrix.h:300-750,
+// src/bitparallelmatrix.cpp:34-123): setSequence / initializeMatrix / computeRow / at /
+// inFinalColumn / onlyVerticalGapsLeft / getFirstColumn / findClusterCenters / traceBack.
+//
+// GPU formulation: the reference materialises, per part and direction, five match vectors
+// per 32-row block (setSequence).  Here each read x strand carries two bit-strings per
+// nucleotide (forward and reversed read); the 64-bit match word of ANY part, direction and
+// block is a funnel-shifted window of those bit-strings (matchWord), so nothing is
+// re-encoded per part and the same strings serve the full-read in-text matrix.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cmb {
+
+constexpr uint32_t MX_WORD = 64, MX_BLOCK = 32;
+constexpr uint32_t MX_MAX_ED = 10; // bitparallelmatrix.h:313
+constexpr uint32_t MX_LEFT = 21;   // :315
+constexpr uint32_t MX_DIAG = 20;   // :316
+
+// words per nucleotide bit-string: ceil(maxLen/32) + 3 zero words of padding
+__host__ __device__ inline uint32_t gWords(uint32_t maxLen) { return (maxLen + 31) / 32 + 3; }
+
+// bits [off, off+64) of bit-string G (off >= 0); words beyond nW read as 0 (caller pads)
+__device__ __forceinline__ uint64_t window64(const uint32_t* G, uint32_t off) {
+    const uint32_t w = off >> 5, sh = off & 31u;
+    const uint64_t lo = (uint64_t)G[w] | ((uint64_t)G[w + 1] << 32);
+    const uint64_t hi = G[w + 2];
+    return sh ? ((lo >> sh) | (hi << (64u - sh))) : lo;
+}
+
+// Match word M for block b of a matrix whose horizontal sequence X (length xLen) starts at bit
+// `xOff` of G (G = forward bit-string for FORWARD parts, reversed-read bit-string for BACKWARD
+// parts).  Bit t of block b stands for column index j = t - LEFT + 32 b of X; the LEFT low bits of
+// block 0 are forced to one (bitparallelmatrix.cpp:44-47); bits of columns >= xLen are zero.
+__device__ __forceinline__ uint64_t matchWord(const uint32_t* G, uint32_t xOff, uint32_t xLen, uint32_t b) {
+    const int lim = (int)xLen + (int)MX_LEFT - (int)(32u * b); // number of meaningful low bits
+    if (lim <= 0) return 0ull;
+    uint64_t m;
+    if (b == 0) {
+        m = (window64(G, xOff) << MX_LEFT) | ((1ull << MX_LEFT) - 1ull);
+    } else {
+        m = window64(G, xOff + 32u * b - MX_LEFT);
+    }
+    if (lim < 64) m &= (1ull << lim) - 1ull;
+    return m;
+}
+
+struct MatGeom {
+    uint32_t n, m, Wv, Wh, maxED;
+    __device__ __forceinline__ uint32_t sfc() const { return Wh + Wv + 1; } // :705
+    __device__ __forceinline__ bool inFinalColumn(uint32_t i) const { return i >= m - sfc(); } // :437
+    __device__ __forceinline__ uint32_t firstColumn(uint32_t i) const { return i <= Wv ? 0u : i - Wv; } // :670
+};
+
+// initializeMatrix (bitparallelmatrix.cpp:77-123).  initED[0..nInit) (nInit >= 1 here; the
+// reference's empty vector is only used by findCIGAR / the naive search).
+__device__ __forceinline__ void initMatrix(MatGeom& g, uint32_t xLen, uint32_t maxED, const uint32_t* initED,
+                                           uint32_t nInit, uint64_t& HP0, uint64_t& HN0, uint64_t& RAC0,
+                                           uint32_t& score0) {
+    g.n = xLen + 1;
+    g.maxED = maxED;
+    g.Wv = nInit - 1 + maxED - initED[nInit - 1];
+    g.m = g.Wv + g.n;
+    score0 = initED[0];
+    g.Wh = maxED - score0;
+    if (g.Wv + g.Wh + 1 > g.m) g.m = g.Wv + g.Wh + 1;
+    HP0 = (~0ull) << MX_LEFT;
+    HN0 = ~HP0;
+    const uint32_t nn = nInit < MX_LEFT + 1 ? nInit : MX_LEFT + 1;
+    for (uint32_t i = 1; i < nn; ++i) {
+        if (initED[i] < initED[i - 1]) {
+            HP0 ^= 1ull << (MX_LEFT - i);
+            HN0 ^= 1ull << (MX_LEFT - i);
+        } else if (initED[i] == initED[i - 1]) {
+            HN0 ^= 1ull << (MX_LEFT - i);
+        }
+    }
+    RAC0 = 1ull << (MX_DIAG + g.Wh);
+}
+
+// computeRow (bitparallelmatrix.h:352-415).  In/out: previous row state -> row i state.
+// Returns false if every cell of row i exceeds maxED.
+__device__ __forceinline__ bool computeRow(const MatGeom& g, uint32_t i, uint64_t M, uint64_t& HP, uint64_t& HN,
+                                           uint64_t& D0, uint64_t& RAC, uint32_t& score) {
+    const uint32_t l = i % MX_BLOCK;
+    RAC <<= 1u;
+    if (l == 0) {
+        HP >>= MX_BLOCK;
+        HN >>= MX_BLOCK;
+        RAC >>= MX_BLOCK;
+    }
+    D0 = (((M & HP) + HP) ^ HP) | M | HN;
+    const uint64_t VP = HN | ~(D0 | HP);
+    const uint64_t VN = D0 & HP;
+    HP = (VN << 1u) | ~(D0 | (VP << 1u));
+    HN = (D0 & (VP << 1u));
+    const uint32_t diagBit = l + MX_DIAG;
+    score += (D0 & (1ull << diagBit)) ? 0u : 1u;
+    if (!(D0 & RAC)) {
+        uint32_t val = 1u;
+        const uint64_t stop = 1ull << (diagBit - g.Wv);
+        while (val > 0) {
+            if (HP & RAC) val--;
+            if (HN & RAC) val++;
+            if (RAC == stop) return false;
+            RAC >>= 1u;
+        }
+    }
+    return true;
+}
+
+// operator()(i,j) (bitparallelmatrix.h:622-639) from the state of row i
+__device__ __forceinline__ uint32_t cellAt(uint32_t i, uint32_t j, uint64_t HP, uint64_t HN, uint32_t score) {
+    const uint32_t bit = (i % MX_BLOCK) + MX_DIAG;
+    const uint32_t b = (i > j) ? bit - (i - j) + 1 : bit + 1;
+    const uint32_t e = (i > j) ? bit + 1 : bit + (j - i) + 1;
+    const uint32_t len = e - b;
+    const uint64_t mask = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << b;
+    const int neg = __popcll(HN & mask);
+    const int pos = __popcll(HP & mask);
+    return score + (uint32_t)((i > j) ? (neg - pos) : (pos - neg));
+}
+
+// onlyVerticalGapsLeft (bitparallelmatrix.h:651-665)
+__device__ __forceinline__ bool onlyVerticalGapsLeft(const MatGeom& g, uint32_t i, uint64_t HN) {
+    if (i + MX_LEFT < g.n) return false;
+    const uint32_t b = i / MX_BLOCK;
+    const uint32_t r = i % MX_BLOCK;
+    const uint32_t bb = MX_DIAG - g.Wv + r + 1;
+    const uint32_t be = MX_DIAG + g.n - b * MX_BLOCK;
+    // Reference: (((~HN >> bb) << bb) << (WORD_SIZE - be)) == 0.  `be` can exceed 64 (up to 72)
+    // when 44 < n - 32 b < 53; the reference then shifts by a negative count, which on the
+    // x86-64 builds of Columba means "count mod 64".  Mirror that explicitly.
+    const uint64_t v = (~HN >> bb) << bb;
+    return (v << ((MX_WORD - be) & 63u)) == 0ull;
+}
+
+} // namespace cmb

@@ -1,0 +1,182 @@
+/*
+ * columba_amd.h — C-ABI of the MI355X-native search-scheme FM-index matcher.
+ *
+ * This is the drop-in boundary for ONE path of biointec/columba (v2.0.3, Vanilla
+ * flavour, 32-bit length_t): approximate matching of single-end reads in ALL mode,
+ *      SearchStrategy::matchApprox        src/searchstrategy.h:2021-2024
+ *   -> SearchStrategy::matchApproxAllMap  src/searchstrategy.cpp:495-535
+ * as called per read from processChunk    src/parallel.cpp:67-78.
+ * A batch of reads goes in, per read the post-filter occurrence list
+ * {begin,end (concatenated-text coordinates), distance, strand} comes out, exactly what
+ * `filterPtr` returns at src/searchstrategy.cpp:529 (before SAM formatting).
+ *
+ * Plain pointers and sizes only; no C++/torch types.  All functions return CMB_OK (0)
+ * or a negative error code; cmb_last_error() gives the message of the calling thread's
+ * last failure (the reference throws std::runtime_error, src/fmindex/fmindex.cpp:84,
+ * src/indexinterface.cpp:100; the C++ adapter in columba_amd/csrc/host re-throws).
+ *
+ * Threading: handles are immutable after creation; cmb_batch objects own their stream
+ * and scratch, so N host threads may run N batches on one index concurrently (the
+ * reference shares one index + strategy between workers, src/parallel.cpp:1143-1146,
+ * with all mutable state thread_local, src/indexinterface.cpp:57-71).
+ */
+#ifndef COLUMBA_AMD_H
+#define COLUMBA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMB_OK 0
+#define CMB_ERR_INVALID (-1)     /* bad argument / malformed scheme (search.h:559-586) */
+#define CMB_ERR_DEVICE (-2)      /* HIP runtime failure / no GPU */
+#define CMB_ERR_UNSUPPORTED (-3) /* needs the 128-bit matrix (k >= 7), RLC flavour, 64-bit length_t */
+#define CMB_ERR_OVERFLOW (-4)    /* caller-provided output buffer too small: nothing truncated silently */
+#define CMB_ERR_INTERNAL (-5)    /* device-side capacity exceeded for a read (reported, never silent) */
+
+typedef struct cmb_index cmb_index;       /* device-resident bidirectional FM-index */
+typedef struct cmb_strategy cmb_strategy; /* search schemes + partitioning parameters */
+typedef struct cmb_batch cmb_batch;       /* a batch of reads resident in HBM + its results */
+
+/* --- index -------------------------------------------------------------------------
+ * Host arrays in the reference's in-memory layouts (the members of FMIndex,
+ * src/fmindex/fmindex.h:46-58; file formats SURVEY.md §5).  The host keeps ownership;
+ * cmb_index_create copies (and re-lays-out) into HBM. */
+typedef struct {
+    uint64_t text_length;     /* n, including the final '$' (IndexInterface::textLength) */
+    const uint8_t* text;      /* .txt.bin payload: n bytes, upper-case ACGT + '$' */
+    uint64_t counts[5];       /* cumulative char counts for $,A,C,G,T (indexinterface.cpp:143-150) */
+    /* BWTRepresentation<5> of the text: .brt  (bwtrepr.h:113, bitvec.h:378) */
+    uint64_t dollar_pos_fwd;
+    const uint64_t* bv_fwd;   /* BitvecIntl<4>::bv,     4*ceil((n+1)/64) words (bitvec.h:262) */
+    const uint64_t* cnt_fwd;  /* BitvecIntl<4>::counts, 8*ceil((n+1)/512) words (bitvec.h:273) */
+    /* BWTRepresentation<5> of the reversed text: .rev.brt */
+    uint64_t dollar_pos_rev;
+    const uint64_t* bv_rev;
+    const uint64_t* cnt_rev;
+    /* sparse suffix array: .sa.bv.<s> (Bitvec, bitvec.h:176) and .sa.<s> (suffixArray.h:229) */
+    const uint64_t* sa_bv;        /* ceil(n/64) words */
+    const uint64_t* sa_bv_counts; /* (ceil(n/64)+7)/4 words, rank9 */
+    const uint32_t* sa_samples;   /* samples in SA-row order */
+    uint64_t n_samples;
+    uint32_t sa_sparseness;       /* power of two (FMIndex ctor, fmindex.h:403) */
+    /* sequence start offsets + final n-1 (.pos, indexinterface.cpp:162) — carried for callers */
+    const uint32_t* seq_starts;
+    uint32_t n_seqs;
+    uint32_t kmer_size;           /* word size of the k-mer table (default 10, fmindex.h:404) */
+    uint32_t in_text_switch;      /* in-text verification switch point (default 4, alignparameters.h:90) */
+} cmb_index_desc;
+
+int cmb_index_create(const cmb_index_desc* desc, int device, cmb_index** out);
+void cmb_index_destroy(cmb_index* idx);
+/* bytes of HBM held by the index */
+uint64_t cmb_index_device_bytes(const cmb_index* idx);
+/* copy the device k-mer table (4^kmer_size x {sa.b,sa.e,rev.b,rev.e}) to host: test hook for
+ * IndexInterface::populateTable (indexinterface.cpp:294-335) */
+int cmb_index_kmer_table(const cmb_index* idx, uint32_t* out /* 4 * 4^kmer_size */);
+
+/* --- strategy ----------------------------------------------------------------------
+ * Replaces Parameters::createStrategy (src/parameters/alignparameters.cpp:1313-1376). */
+#define CMB_METRIC_HAMMING 0
+#define CMB_METRIC_EDIT 1
+#define CMB_PARTITION_UNIFORM 0
+#define CMB_PARTITION_STATIC 1
+#define CMB_PARTITION_DYNAMIC 2
+
+/* built-in strategies: "kuch1" (KucherovKPlus1, searchstrategy.h:2829), "pigeon"
+ * (PigeonHoleSearchStrategy, :3221), "multiple_opt" (the schemes of
+ * search_schemes/multiple_opt with dynamic selection, MultipleSchemesStrategy :2584) */
+int cmb_strategy_create_named(const char* name, int metric, int partition, cmb_strategy** out);
+/* `-c <dir>` (CustomSearchStrategy, searchstrategy.cpp:1990; multiple = 0) or
+ * `-d <dir>` (MultipleSchemesStrategy::readSchemes, searchstrategy.h:2624; multiple = 1) */
+int cmb_strategy_create_from_dir(const char* dir, int multiple, int metric, int partition,
+                                 cmb_strategy** out);
+/* generic: start empty, then add schemes (row-major nSearches x nParts arrays of pi, L, U) */
+int cmb_strategy_create(int metric, int partition, uint32_t kmer_cutoff, cmb_strategy** out);
+int cmb_strategy_add_scheme(cmb_strategy* s, uint32_t k, uint32_t n_searches, uint32_t n_parts,
+                            const uint32_t* pi, const uint32_t* L, const uint32_t* U);
+int cmb_strategy_set_partition_params(cmb_strategy* s, uint32_t k, const double* seeding,
+                                      uint32_t n_seeding, const uint64_t* weights, uint32_t n_weights,
+                                      const double* begins, uint32_t n_begins);
+void cmb_strategy_destroy(cmb_strategy* s);
+/* introspection used by parity tests (Search::makeSearch search.h:116-194, critical part :525) */
+int cmb_strategy_describe(const cmb_strategy* s, uint32_t k, uint32_t* n_schemes, uint32_t* n_parts,
+                          uint32_t* critical_parts /* [n_schemes] */, uint32_t cap);
+
+/* --- matching ---------------------------------------------------------------------- */
+typedef struct {
+    uint32_t begin, end; /* [begin,end) in the concatenated text (TextOcc::range) */
+    uint32_t distance;   /* edit or Hamming distance */
+    uint32_t strand;     /* 0 forward, 1 reverse complement (definitions.h:125) */
+} cmb_occ;
+
+/* counters returned per batch (Counters, src/indexhelpers.h:1846-1941, + byte-model counters) */
+enum {
+    CMB_CNT_NODE = 0,               /* NODE_COUNTER */
+    CMB_CNT_TOTAL_REPORTED,         /* TOTAL_REPORTED_POSITIONS */
+    CMB_CNT_IN_TEXT_STARTED,
+    CMB_CNT_ABORTED_IN_TEXT,
+    CMB_CNT_CIGARS_IN_TEXT,         /* traced-back in-text hits */
+    CMB_CNT_IMMEDIATE_SWITCH,
+    CMB_CNT_SEARCH_STARTED,
+    CMB_CNT_EXPANSIONS,             /* E of SURVEY.md §8d: extend calls at one parent */
+    CMB_CNT_LF_STEPS,               /* L */
+    CMB_CNT_LOCATED_ROWS,           /* R */
+    CMB_CNT_TEXT_BYTES,             /* T */
+    CMB_CNT_MATRIX_ROWS,
+    CMB_CNT_MAX
+};
+
+/* One-shot host-buffer entry: the body of processChunk's loop (parallel.cpp:67-78) for a whole
+ * chunk.  seqs: concatenated read characters (any case; non-ACGT treated as N, reads.h:43-58),
+ * offs[nReads+1].  out/outOffs are caller-allocated; on CMB_ERR_OVERFLOW *needed holds the required
+ * number of cmb_occ and nothing is written. */
+int cmb_match_batch(cmb_index* idx, const cmb_strategy* st, uint32_t max_distance, const char* seqs,
+                    const uint64_t* offs, uint32_t n_reads, cmb_occ* out, uint64_t out_cap,
+                    uint64_t* out_offs /* [n_reads+1] */, uint64_t* counters /* [CMB_CNT_MAX] or NULL */,
+                    uint64_t* needed);
+
+/* Resident-batch entries (what bench.py times: reads already in HBM when the timed region starts). */
+int cmb_batch_create(cmb_index* idx, const cmb_strategy* st, uint32_t max_distance, const char* seqs,
+                     const uint64_t* offs, uint32_t n_reads, cmb_batch** out);
+int cmb_batch_run(cmb_batch* b);  /* enqueue + wait: the whole hot path on the batch's stream */
+int cmb_batch_result_size(const cmb_batch* b, uint64_t* n_occ);
+int cmb_batch_results(const cmb_batch* b, cmb_occ* out, uint64_t out_cap, uint64_t* out_offs,
+                      uint64_t* counters);
+/* per-kernel device time of the last cmb_batch_run, measured with hipEvents on the batch's own
+ * stream.  names: NUL-separated list; ms[n]. Returns number of kernels. */
+int cmb_batch_timings(const cmb_batch* b, const char** names, float* ms, uint32_t cap);
+void cmb_batch_destroy(cmb_batch* b);
+
+/* --- fine-grained hooks (parity tests + roofline microbenchmark) ------------------- */
+/* BitvecIntl<4>::rank(c,p) (bitvec.h:356), rev = 0 forward BWT / 1 reverse BWT */
+int cmb_rank_batch(cmb_index* idx, int rev, const uint32_t* c, const uint64_t* p, uint64_t n,
+                   uint64_t* out);
+/* all four children of n parents (IndexInterface::extendFMPos, indexinterface.cpp:675-697 over
+ * FMIndex::findRangesWithExtraChar{Forward,Backward,BackwardUniDirectional}, fmindex.cpp:137-243).
+ * mode 0 forward, 1 backward, 2 uni-directional backward.  in: n x {sa.b,sa.e,rev.b,rev.e};
+ * out: n x 4 x 4; ok: n x 4.  Host-buffer variant. */
+int cmb_extend_batch(cmb_index* idx, int mode, const uint32_t* in, uint64_t n, uint32_t* out,
+                     uint8_t* ok);
+/* Device-resident variant for the roofline microbenchmark: d_in/d_out/d_ok are device pointers;
+ * runs `iters` launches and returns the average kernel time in ms (hipEvents on the launch stream). */
+int cmb_extend_bench(cmb_index* idx, int mode, const void* d_in, uint64_t n, void* d_out, void* d_ok,
+                     uint32_t iters, float* avg_ms);
+/* FMIndex::findSA (fmindex.cpp:53-60) */
+int cmb_locate_batch(cmb_index* idx, const uint32_t* rows, uint64_t n, uint32_t* out,
+                     uint64_t* lf_steps);
+/* FMIndex::inTextVerification (fmindex.cpp:267-310) for one pattern and n start positions */
+int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t plen, const uint32_t* starts,
+                     uint64_t n, uint32_t max_ed, uint32_t min_ed, int fixed_start, cmb_occ* out,
+                     uint64_t out_cap, uint64_t* n_out, uint64_t* counters);
+
+const char* cmb_last_error(void);
+const char* cmb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLUMBA_AMD_H */

@@ -528,7 +528,9 @@ class BitParallelED64 {
         const uint32_t r = i % BLOCK_SIZE;
         uint32_t bb = DIAG_R0 - Wv + r + 1;
         uint32_t be = DIAG_R0 + n - b * BLOCK_SIZE;
-        return (((~bv[i].HN >> bb) << bb) << (WORD_SIZE - be)) == 0ull;
+        // `be` may exceed 64 (44 < n - 32 b < 53): the reference shifts by a negative count; on
+        // x86-64 (all Columba builds) that is "count mod 64" — made explicit here.
+        return (((~bv[i].HN >> bb) << bb) << ((WORD_SIZE - be) & 63u)) == 0ull;
     }
     uint32_t getFirstColumn(uint32_t i) const { return (i <= Wv) ? 0u : i - Wv; } // :670
     uint32_t getNumberOfCols() const { return n; }
