@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: reads/s of the search-scheme FM-index hot path (150 bp, k = 4 edit
+distance, ALL mode, multiple_opt schemes with dynamic selection and dynamic partitioning —
+BASELINE.json configs[2]) on a human-like synthetic reference, one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the whole hot path (k_prep -> k_search -> k_verify -> k_fmocc -> filter)
+over this rank's read shard, reads already resident in HBM (cmb_batch_run).  Weak scaling: every
+rank matches `--reads` reads against a full replica of the index; no collective on the data path
+(rank 0 builds the index and broadcasts it over RCCL, read shards are scattered once, both before
+the timed region).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import columba_amd as ca  # noqa: E402
+from columba_amd import indexbuild as ib  # noqa: E402
+from columba_amd import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
+INDEX_FIELDS = ["text", "counts", "bv_fwd", "cnt_fwd", "bv_rev", "cnt_rev", "bwt_words", "sa_bv",
+                "sa_bv_counts", "sa_samples", "seq_starts"]
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def broadcast_index(ix, rank, world, dev):
+    """Replicate the index arrays from rank 0 (RCCL broadcast over xGMI); returns IndexArrays."""
+    import torch.distributed as dist
+    meta = [None]
+    if rank == 0:
+        meta = [{"shapes": {f: (getattr(ix, f).shape, str(getattr(ix, f).dtype)) for f in INDEX_FIELDS},
+                 "dpf": ix.dollar_pos_fwd, "dpr": ix.dollar_pos_rev, "sparseness": ix.sparseness,
+                 "names": ix.seq_names}]
+    dist.broadcast_object_list(meta, src=0)
+    m = meta[0]
+    arrays = {}
+    for f in INDEX_FIELDS:
+        shape, dt = m["shapes"][f]
+        nbytes = int(np.prod(shape)) * np.dtype(dt).itemsize
+        if rank == 0:
+            t = torch.from_numpy(getattr(ix, f).view(np.uint8).reshape(-1)).to(dev)
+        else:
+            t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0)
+        arrays[f] = getattr(ix, f) if rank == 0 else t.cpu().numpy().view(dt).reshape(shape)
+        del t
+    if rank == 0:
+        return ix
+    return ib.IndexArrays(text=arrays["text"], counts=arrays["counts"], dollar_pos_fwd=m["dpf"],
+                          bv_fwd=arrays["bv_fwd"], cnt_fwd=arrays["cnt_fwd"], dollar_pos_rev=m["dpr"],
+                          bv_rev=arrays["bv_rev"], cnt_rev=arrays["cnt_rev"], bwt_words=arrays["bwt_words"],
+                          sa_bv=arrays["sa_bv"], sa_bv_counts=arrays["sa_bv_counts"],
+                          sa_samples=arrays["sa_samples"], sparseness=m["sparseness"],
+                          seq_starts=arrays["seq_starts"], seq_names=m["names"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("CMB_BENCH_GENOME_MBP", 1024)))
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("CMB_BENCH_READS", 1_000_000)),
+                    help="reads per GPU (weak scaling)")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--k", type=int, default=4)
+    ap.add_argument("--cpu-sample", type=int, default=100_000, help="reads timed on the CPU oracle")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ca.lib()  # fail loudly if the HIP extension is missing
+    n = int(args.genome_mbp * 1e6)
+    t0 = time.time()
+    ix = None
+    if rank == 0:
+        g, starts = synth.genome_human_like(n, seed=2025, device=dev)
+        ix = ib.build_index(g, seq_starts=starts, device=dev, with_bwt=not args.no_cpu_baseline)
+        del g
+        torch.cuda.empty_cache()
+        log(f"[bench] index for {n / 1e6:.0f} Mbp built in {time.time() - t0:.1f} s "
+            f"({ix.nbytes() / 1e9:.2f} GB host arrays)")
+    if world > 1:
+        ix = broadcast_index(ix, rank, world, dev)
+    index = ca.Index(ix, in_text_switch=4, kmer_size=10, device=local)
+    strategy = ca.SearchStrategy("multiple_opt", "edit", "dynamic")
+
+    # reads: rank 0 samples the global batch on its GPU and scatters equal shards
+    R, L = args.reads, args.read_len
+    t1 = time.time()
+    if world > 1:
+        shard = torch.empty(R * L, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            buf, _ = synth.sample_reads_fast(torch.from_numpy(ix.text[:-1]).to(dev), R * world, L, seed=3, device=dev)
+            allr = torch.from_numpy(buf).to(dev).reshape(world, R * L)
+            dist.scatter(shard, [allr[i].contiguous() for i in range(world)], src=0)
+            del allr
+        else:
+            dist.scatter(shard, None, src=0)
+        buf = shard.cpu().numpy()
+    else:
+        buf, _ = synth.sample_reads_fast(torch.from_numpy(ix.text[:-1]).to(dev), R, L, seed=3, device=dev)
+    offs = np.arange(R + 1, dtype=np.uint64) * np.uint64(L)
+    torch.cuda.empty_cache()
+    if rank == 0:
+        log(f"[bench] {R} reads/GPU sampled in {time.time() - t1:.1f} s")
+    batch = ca.Batch(index, strategy, args.k, packed=(buf, offs))
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.run()
+    sync()
+    kern = {}
+    tstart = time.perf_counter()
+    for _ in range(args.steps):
+        batch.run()
+        for kname, ms in batch.timings().items():
+            kern[kname] = kern.get(kname, 0.0) + ms
+    sync()
+    elapsed = time.perf_counter() - tstart
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    occ, occ_offs, cnt = batch.results()
+    total_occ = len(occ)
+    if dist is not None:
+        tt = torch.tensor([total_occ], dtype=torch.int64, device=dev)
+        dist.all_reduce(tt)
+        total_occ = int(tt.item())
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        value = world * R * steps / elapsed
+        avg = {k: v / steps for k, v in kern.items()}
+        dominant = max(avg, key=avg.get)
+        # algorithmic bytes per launch:
+        #   k_search: 192 B per node expansion (2 positions x (64 B counts line + 32 B bit group))
+        #   k_verify: 112 B per LF step + 28 B per located row + 1 B per text character
+        alg = {"k_search": 192.0 * cnt["EXPANSIONS"],
+               "k_verify": 112.0 * cnt["LF_STEPS"] + 28.0 * cnt["LOCATED_ROWS"] + 1.0 * cnt["TEXT_BYTES"]}
+        achieved = alg.get(dominant, 0.0) / (avg[dominant] * 1e-3) / 1e9 if avg[dominant] > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "avg_launch_ms": round(avg[dominant], 3),
+                    "kernels_ms": {k: round(v, 3) for k, v in avg.items()}}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_py as op
+            import schemes_py as sp
+            ns = min(args.cpu_sample, R)
+            oidx = op.OracleIndex(ix)
+            ost = op.OracleStrategy(sp.MULTIPLE_OPT, "edit", "dynamic")
+            cores = os.cpu_count() or 1
+            sample = [buf[i * L:(i + 1) * L].tobytes() for i in range(ns)]
+            tc = time.perf_counter()
+            o_occ, o_off, _ = op.match_batch(oidx, ost, args.k, sample, threads=cores)
+            dt = time.perf_counter() - tc
+            same = (len(o_occ) == int(occ_offs[ns]) and
+                    np.array_equal(o_occ["begin"], occ["begin"][:len(o_occ)]) and
+                    np.array_equal(o_occ["end"], occ["end"][:len(o_occ)]) and
+                    np.array_equal(o_occ["distance"], occ["distance"][:len(o_occ)]))
+            cpu = {"value": round(ns / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
+                   "sample": f"first {ns} reads of the GPU batch, oracle/ (C++ restatement) with {cores} threads, "
+                             f"{dt:.1f} s; occurrences identical to the GPU's: {bool(same)}"}
+        line = {
+            "metric": "reads/sec (150bp, k=4 edit, human ref)",
+            "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"synthetic human-like reference {n / 1e6:.0f} Mbp (GRCh38 is not available "
+                                   f"offline), {R} x {L} bp reads per GPU, k={args.k} edit distance, ALL mode, "
+                                   "multiple_opt schemes with dynamic selection, dynamic partitioning, "
+                                   "in-text switch 4, SA sparseness 4",
+                       "reads_per_gpu": R, "read_len": L, "k": args.k, "genome_bp": n,
+                       "index_bytes_hbm": index.device_bytes(), "parallelism": f"read-shard x{world}",
+                       "occurrences": total_occ},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    batch.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

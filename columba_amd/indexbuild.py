@@ -68,39 +68,40 @@ class IndexArrays:
 # suffix array by prefix doubling (torch; works on cpu and cuda)
 # --------------------------------------------------------------------------
 def suffix_array(codes: torch.Tensor) -> torch.Tensor:
-    """SA of the sequence ``codes`` (uint8/int, values 0..4), where a suffix
-    that is a proper prefix of another sorts first (end-of-string smallest).
+    """SA of the sequence ``codes`` (uint8, values 0..4), where a suffix that is a proper prefix of
+    another sorts first (end-of-string smallest).  Prefix doubling with radix sorts (torch.sort).
 
-    Returns int64 tensor of length n on ``codes.device``.
+    Returns an int64 tensor of length n on ``codes.device``.
     """
     dev = codes.device
     n = int(codes.numel())
     if n == 0:
         return torch.zeros(0, dtype=torch.int64, device=dev)
     assert (n + 2) ** 2 < 2 ** 63, "text too long for single-key prefix doubling"
-    c = codes.to(torch.int64) + 1  # 1..5, 0 = beyond the end
-    # initial key: first 20 symbols, 3 bits each
-    h = 20
-    pad = torch.zeros(h, dtype=torch.int64, device=dev)
-    cp = torch.cat([c, pad])
+    rdt = torch.int32 if n < 2 ** 31 - 2 else torch.int64
+    h = 20  # initial key: first 20 symbols, 3 bits each (values 1..5, 0 = beyond the end)
+    cp = torch.zeros(n + h, dtype=torch.uint8, device=dev)
+    cp[:n] = codes.to(torch.uint8) + 1
     key = torch.zeros(n, dtype=torch.int64, device=dev)
     for j in range(h):
-        key = (key << 3) | cp[j:j + n]
+        key <<= 3
+        key |= cp[j:j + n]
     del cp
     skey, sa = torch.sort(key)
     del key
     while True:
-        flag = torch.ones(n, dtype=torch.int64, device=dev)
-        flag[1:] = (skey[1:] != skey[:-1]).to(torch.int64)
+        flag = torch.ones(n, dtype=torch.bool, device=dev)
+        flag[1:] = skey[1:] != skey[:-1]
         del skey
-        srank = torch.cumsum(flag, 0)  # 1-based dense rank in SA order
+        srank = torch.cumsum(flag, 0, dtype=rdt)  # 1-based dense rank in SA order
         del flag
         if int(srank[-1].item()) == n:
             return sa
-        rank = torch.empty(n, dtype=torch.int64, device=dev)
+        rank = torch.empty(n, dtype=rdt, device=dev)
         rank[sa] = srank
         del srank, sa
-        key = rank * (n + 1)
+        key = rank.to(torch.int64)
+        key *= (n + 1)
         if h < n:
             key[:n - h] += rank[h:]
         del rank
@@ -109,11 +110,40 @@ def suffix_array(codes: torch.Tensor) -> torch.Tensor:
         h *= 2
 
 
+_CHUNK = 1 << 27  # positions per chunk when packing bits (bounds temporary memory)
+
+
 def _pack_bits_le(bits: torch.Tensor) -> torch.Tensor:
-    """bits: bool/uint8 tensor [W*64] -> int64 words (bit b of word w = bits[64w+b])."""
-    w = bits.reshape(-1, 64).to(torch.int64)
+    """bits: bool tensor [W*64] -> int64 words (bit b of word w = bits[64w+b])."""
     sh = torch.arange(64, dtype=torch.int64, device=bits.device)
-    return (w << sh).sum(dim=1)
+    out = []
+    for o in range(0, bits.numel(), _CHUNK):
+        w = bits[o:o + _CHUNK].reshape(-1, 64).to(torch.int64)
+        out.append((w << sh).sum(dim=1))
+    return torch.cat(out) if len(out) != 1 else out[0]
+
+
+def _popcount_words(bits: torch.Tensor) -> torch.Tensor:
+    out = []
+    for o in range(0, bits.numel(), _CHUNK):
+        out.append(bits[o:o + _CHUNK].reshape(-1, 64).sum(dim=1, dtype=torch.int64))
+    return torch.cat(out) if len(out) != 1 else out[0]
+
+
+def _rank_counts(pc: torch.Tensor, nblk: int, n_words: int):
+    """L1 (absolute) and packed L2 (seven 9-bit partial sums) per 8-word block."""
+    within = torch.cumsum(pc.reshape(nblk, 8), dim=1)
+    blocktot = within[:, 7]
+    l1 = torch.cumsum(blocktot, 0) - blocktot
+    l2 = torch.zeros(nblk, dtype=torch.int64, device=pc.device)
+    for j in range(1, 8):
+        l2 |= within[:, j - 1] << (9 * (j - 1))
+    # words past the end of the bitvector are never visited by index(): their L2 stay 0
+    # (bitvec.h:335 / :138 loop over existing words only)
+    last_words = n_words - (nblk - 1) * 8
+    if last_words < 8:
+        l2[-1] &= (1 << (9 * max(last_words - 1, 0))) - 1
+    return l1, l2
 
 
 def build_bitvec_intl(bwt_codes: torch.Tensor):
@@ -136,22 +166,9 @@ def build_bitvec_intl(bwt_codes: torch.Tensor):
     counts = torch.zeros((nblk, 4, 2), dtype=torch.int64, device=dev)
     for c in range(1, 5):
         bits = (codes != 0) & (codes <= c)
-        words = _pack_bits_le(bits)            # [nblk*8]
-        pc = bits.reshape(-1, 64).sum(dim=1).to(torch.int64)  # popcount per word
-        bv[:, c - 1] = words[:nw]
-        pcb = pc.reshape(nblk, 8)
-        within = torch.cumsum(pcb, dim=1)      # inclusive within block
-        blocktot = within[:, 7]
-        l1 = torch.cumsum(blocktot, 0) - blocktot   # exclusive prefix
-        l2 = torch.zeros(nblk, dtype=torch.int64, device=dev)
-        for j in range(1, 8):
-            l2 |= within[:, j - 1] << (9 * (j - 1))
-        # words past the end of bv are never visited by index(): their L2 stay 0
-        # (bitvec.h:335 loops w < bvSize only)
-        last_words = nw - (nblk - 1) * 8        # words present in the last block
-        if last_words < 8:
-            keep = (1 << (9 * max(last_words - 1, 0))) - 1
-            l2[-1] &= keep
+        bv[:, c - 1] = _pack_bits_le(bits)[:nw]
+        l1, l2 = _rank_counts(_popcount_words(bits), nblk, nw)
+        del bits
         counts[:, c - 1, 0] = l1
         counts[:, c - 1, 1] = l2
     bv_np = bv.reshape(-1).cpu().numpy().view(np.uint64)
@@ -169,17 +186,9 @@ def build_sparse_sa(sa: torch.Tensor, sparseness: int):
     nblk = (nw + 7) // 8
     bits = torch.zeros(nblk * 512, dtype=torch.bool, device=dev)
     bits[:n] = mark
+    del mark
     words = _pack_bits_le(bits)
-    pc = bits.reshape(-1, 64).sum(dim=1).to(torch.int64).reshape(nblk, 8)
-    within = torch.cumsum(pc, dim=1)
-    blocktot = within[:, 7]
-    l1 = torch.cumsum(blocktot, 0) - blocktot
-    l2 = torch.zeros(nblk, dtype=torch.int64, device=dev)
-    for j in range(1, 8):
-        l2 |= within[:, j - 1] << (9 * (j - 1))
-    last_words = nw - (nblk - 1) * 8
-    if last_words < 8:
-        l2[-1] &= (1 << (9 * max(last_words - 1, 0))) - 1
+    l1, l2 = _rank_counts(_popcount_words(bits), nblk, nw)
     cw = (nw + 7) // 4
     counts = np.zeros(cw, dtype=np.uint64)
     inter = torch.stack([l1, l2], dim=1).reshape(-1).cpu().numpy().view(np.uint64)
@@ -187,62 +196,87 @@ def build_sparse_sa(sa: torch.Tensor, sparseness: int):
     return words[:nw].cpu().numpy().view(np.uint64), counts, samples
 
 
-def encode_bwt(bwt_codes: np.ndarray) -> np.ndarray:
-    """EncodedText<5> (encodedtext.h:93-118): 3 bits per symbol, MSB first."""
-    n = bwt_codes.shape[0]
+def encode_bwt(bwt_codes) -> np.ndarray:
+    """EncodedText<5> (encodedtext.h:93-118): 3 bits per symbol, MSB first; 64 symbols = 3 words."""
+    t = bwt_codes if isinstance(bwt_codes, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(bwt_codes))
+    dev = t.device
+    n = int(t.numel())
     nw = (n * 3) // 64 + 1
-    out = np.zeros(nw + 1, dtype=np.uint64)
-    pos = np.arange(n, dtype=np.uint64) * np.uint64(3)
-    w = (pos // np.uint64(64)).astype(np.int64)
-    b = (pos % np.uint64(64)).astype(np.uint64)
-    v = bwt_codes.astype(np.uint64)
-    lo = b <= 61
-    np.add.at(out, w[lo], v[lo] << (np.uint64(61) - b[lo]))
-    hi = ~lo
-    if hi.any():
-        over = b[hi] - np.uint64(61)
-        np.add.at(out, w[hi], v[hi] >> over)
-        np.add.at(out, w[hi] + 1, v[hi] << (np.uint64(64) - over))
-    return out[:nw]
+    ngrp = (n + 63) // 64
+    wsh = torch.arange(63, -1, -1, dtype=torch.int64, device=dev)
+    out = []
+    grp_chunk = _CHUNK // 64
+    for g0 in range(0, ngrp, grp_chunk):
+        g1 = min(ngrp, g0 + grp_chunk)
+        sym = torch.zeros((g1 - g0) * 64, dtype=torch.uint8, device=dev)
+        seg = t[g0 * 64:min(n, g1 * 64)].to(torch.uint8)
+        sym[:seg.numel()] = seg
+        bits = torch.stack([(sym >> 2) & 1, (sym >> 1) & 1, sym & 1], dim=1)  # MSB first
+        words = (bits.reshape(-1, 3, 64).to(torch.int64) << wsh).sum(dim=2)
+        out.append(words.reshape(-1))
+    allw = torch.cat(out) if len(out) != 1 else out[0]
+    res = np.zeros(nw, dtype=np.uint64)
+    got = allw[:nw].cpu().numpy().view(np.uint64)
+    res[:got.shape[0]] = got
+    return res
 
 
-def build_index(text: bytes | np.ndarray, sparseness: int = 4,
-                seq_starts: Optional[np.ndarray] = None,
-                seq_names: Optional[List[str]] = None,
-                device: str | torch.device = "cpu") -> IndexArrays:
-    """Build all Vanilla index arrays for ``text`` (ACGT only; '$' appended if absent)."""
-    t = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.asarray(text, dtype=np.uint8)
-    if t.shape[0] == 0 or t[-1] != ord("$"):
-        t = np.concatenate([t, np.array([ord("$")], dtype=np.uint8)])
-    codes = CODE[t]
-    if (codes[:-1] == 0).any() or (codes == 255).any():
-        raise ValueError("text must consist of A,C,G,T followed by one final '$'")
-    n = t.shape[0]
+def build_index(text, sparseness: int = 4, seq_starts: Optional[np.ndarray] = None,
+                seq_names: Optional[List[str]] = None, device: str | torch.device = "cpu",
+                with_bwt: bool = True) -> IndexArrays:
+    """Build all Vanilla index arrays for ``text`` (ACGT only; '$' appended if absent).
+
+    ``text``: bytes / numpy uint8 ASCII, or a torch uint8 tensor of ASCII codes (may live on the GPU).
+    """
     dev = torch.device(device)
-    tc = torch.from_numpy(codes.copy()).to(dev)
+    if isinstance(text, torch.Tensor):
+        tt = text.to(dev)
+    else:
+        t = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.asarray(text, dtype=np.uint8)
+        tt = torch.from_numpy(np.array(t, dtype=np.uint8, copy=True)).to(dev)
+    if tt.numel() == 0 or int(tt[-1].item()) != ord("$"):
+        tt = torch.cat([tt, torch.tensor([ord("$")], dtype=torch.uint8, device=dev)])
+    lut = torch.from_numpy(CODE).to(dev)
+    tc = lut[tt.long()] if tt.numel() < (1 << 28) else torch.cat(
+        [lut[tt[o:o + (1 << 28)].long()] for o in range(0, tt.numel(), 1 << 28)])
+    if bool((tc[:-1] == 0).any()) or bool((tc == 255).any()):
+        raise ValueError("text must consist of A,C,G,T followed by one final '$'")
+    n = int(tt.numel())
     # forward
     sa = suffix_array(tc)
-    prev = torch.where(sa > 0, sa - 1, torch.full_like(sa, n - 1))
+    prev = sa - 1
+    prev[prev < 0] = n - 1
     bwt = tc[prev]
+    del prev
     bv_fwd, cnt_fwd, dpos_f = build_bitvec_intl(bwt)
     sa_bv, sa_cnt, samples = build_sparse_sa(sa, sparseness)
-    bwt_words = encode_bwt(bwt.cpu().numpy())
-    del sa, prev, bwt
+    del sa
+    bwt_words = encode_bwt(bwt) if with_bwt else np.zeros(1, np.uint64)
+    del bwt
     # reverse text (buildindex.cpp:575-585, createRevSAWithSanityCheck :750)
     rtc = torch.flip(tc, dims=[0])
     rsa = suffix_array(rtc)
-    idx = torch.where(rsa > 0, n - rsa, torch.zeros_like(rsa))
+    del rtc
+    idx = n - rsa
+    idx[rsa == 0] = 0
+    del rsa
     rbwt = tc[idx]
+    del idx
     bv_rev, cnt_rev, dpos_r = build_bitvec_intl(rbwt)
-    del rsa, idx, rbwt, rtc
-    cc = np.bincount(codes, minlength=5).astype(np.uint64)
+    del rbwt
+    cc = torch.bincount(tc.long() if n < (1 << 28) else tc[:1].long(), minlength=5) if n < (1 << 28) else None
+    if cc is None:
+        cc = torch.zeros(5, dtype=torch.int64, device=dev)
+        for o in range(0, n, 1 << 28):
+            cc += torch.bincount(tc[o:o + (1 << 28)].long(), minlength=5)
+    cc = cc.cpu().numpy().astype(np.uint64)
     counts = np.zeros(5, dtype=np.uint64)
     counts[1:] = np.cumsum(cc)[:-1]
     if seq_starts is None:
         seq_starts = np.array([0, n - 1], dtype=np.uint32)
     if seq_names is None:
         seq_names = [f"seq{i}" for i in range(len(seq_starts) - 1)]
-    return IndexArrays(text=t.copy(), counts=counts, dollar_pos_fwd=dpos_f, bv_fwd=bv_fwd,
+    return IndexArrays(text=tt.cpu().numpy(), counts=counts, dollar_pos_fwd=dpos_f, bv_fwd=bv_fwd,
                        cnt_fwd=cnt_fwd, dollar_pos_rev=dpos_r, bv_rev=bv_rev, cnt_rev=cnt_rev,
                        bwt_words=bwt_words, sa_bv=sa_bv, sa_bv_counts=sa_cnt, sa_samples=samples,
                        sparseness=sparseness, seq_starts=np.asarray(seq_starts, dtype=np.uint32),
