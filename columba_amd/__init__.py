@@ -79,6 +79,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                                "g.build()'` (the product has no CPU fallback)")
+        # torch bundles its own HIP runtime: load it first so that this process ends up with ONE
+        # libamdhip64 (loading ours first makes the second runtime see no devices)
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
         L.cmb_last_error.restype = C.c_char_p

@@ -362,6 +362,13 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
         Timer tm(s, b->times);
         const uint32_t nReads = b->nReads;
         const uint32_t tasks = 2 * nReads;
+        if (nReads == 0) {
+            b->occs.clear();
+            b->occOffs.assign(1, 0);
+            memset(b->cnts, 0, sizeof(b->cnts));
+            b->done = true;
+            return CMB_OK;
+        }
         uint32_t hcnt[8];
         Queues q{};
         q.cnt = b->cnt.p;
