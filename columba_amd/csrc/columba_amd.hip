@@ -235,6 +235,8 @@ struct cmb_batch {
     DevBuf<uint32_t> G;
     DevBuf<DevStrategyK> strat;
     DevBuf<Scratch> slabs;
+    DevBuf<PartOut> parts;
+    DevBuf<DfsTask> dfs;
     DevBuf<VScratch> vslabs;
     DevBuf<uint4> items;
     DevBuf<FMOccRec> fm, fmUniq;
@@ -291,10 +293,8 @@ extern "C" int cmb_batch_create(cmb_index* idx, const cmb_strategy* st, uint32_t
         b->seq.alloc((size_t)2 * n_reads * maxLen);
         b->G.alloc((size_t)2 * n_reads * 8 * b->gw);
         b->strat.upload(&b->hostStrat, 1);
-        const uint32_t tasks = 2 * n_reads;
-        b->nSlots = std::min<uint32_t>(((tasks + 255) / 256) * 256, 256u * 512u);
-        if (b->nSlots == 0) b->nSlots = 256;
-        b->slabs.alloc(b->nSlots);
+        b->parts.alloc((size_t)2 * n_reads);
+        b->dfs.alloc((size_t)n_reads * 2 + 4096);
         b->items.alloc((size_t)n_reads * 64 + 4096);
         b->fm.alloc((size_t)n_reads * 8 + 4096);
         b->text.alloc((size_t)n_reads * 48 + 4096);
@@ -373,6 +373,7 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
         Queues q{};
         q.cnt = b->cnt.p;
         q.counters = b->counters.p;
+        q.dbg = getenv("CMB_DEBUG") ? (uint32_t)atoi(getenv("CMB_DEBUG")) : 0u;
 
         HIPCHK(hipMemsetAsync(b->counters.p, 0, CMB_CNT_MAX * sizeof(unsigned long long), s));
         tm.begin();
@@ -380,10 +381,10 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                            b->maxLen, b->gw, b->seq.p, b->G.p);
         tm.end("k_prep");
 
-        // ---- search (re-run with larger queues if they overflow: nothing is truncated)
+        // ---- prologue + DFS (re-run with larger queues if they overflow: nothing is truncated)
+        const uint32_t pSlots = std::min<uint32_t>(((tasks + 255) / 256) * 256, 256u * 2048u);
         for (int attempt = 0;; attempt++) {
             HIPCHK(hipMemsetAsync(b->cnt.p, 0, 8 * sizeof(uint32_t), s));
-            // counters written by k_search are reset on a retry
             if (attempt) {
                 HIPCHK(hipMemsetAsync(b->counters.p, 0, CMB_CNT_MAX * sizeof(unsigned long long), s));
             }
@@ -393,24 +394,45 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
             q.fmCap = (uint32_t)std::min<size_t>(b->fm.n, 0xFFFFFFF0u);
             q.text = b->text.p;
             q.textCap = (uint32_t)std::min<size_t>(b->text.n, 0xFFFFFFF0u);
+            const uint32_t dfsCap = (uint32_t)std::min<size_t>(b->dfs.n, 0xFFFFFFF0u);
             tm.begin();
-            hipLaunchKernelGGL(k_search, dim3(b->nSlots / 256), dim3(256), 0, s, ix->d, b->strat.p, b->offs.p, nReads,
-                               b->k, b->maxLen, b->gw, b->seq.p, b->G.p, b->slabs.p, q);
-            tm.end("k_search");
+            const uint32_t pParts = b->k ? b->hostStrat.numParts : 1;
+            hipLaunchKernelGGL(k_partition, dim3(pSlots / 256), dim3(256), 5 * pParts * 256 * sizeof(uint32_t), s,
+                               ix->d, b->strat.p, b->offs.p, nReads,
+                               b->k, b->maxLen, b->seq.p, b->parts.p, b->dfs.p, dfsCap, q);
+            tm.end("k_partition");
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            const uint32_t flags = hcnt[3];
+            uint32_t flags = hcnt[3];
             if (flags & FLAG_UNSUPPORTED_READ)
                 return fail(CMB_ERR_UNSUPPORTED,
                             "a read is not longer than the number of parts of the search scheme (the reference "
                             "falls back to naive backtracking, which the device path does not provide)");
+            const uint32_t nDfs = hcnt[5];
+            if (!(flags & (FLAG_ITEM_OVERFLOW | FLAG_DFS_OVERFLOW)) && nDfs) {
+                const uint32_t want = std::min<uint32_t>(((nDfs + 255) / 256) * 256, 256u * 512u);
+                if (b->slabs.n < want) {
+                    b->slabs.alloc(want);
+                    b->nSlots = want;
+                }
+                tm.begin();
+                hipLaunchKernelGGL(k_dfs, dim3(std::min<uint32_t>(b->nSlots, want) / 256), dim3(256), 0, s, ix->d,
+                                   b->strat.p, b->offs.p, b->k, b->maxLen, b->gw, b->seq.p, b->G.p, b->parts.p,
+                                   b->dfs.p, nDfs, b->slabs.p, q);
+                tm.end("k_dfs");
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                flags = hcnt[3];
+            }
             if (flags & FLAG_CAPACITY)
                 return fail(CMB_ERR_INTERNAL, "device search capacity exceeded (band width / descendants / stack)");
-            if (flags & (FLAG_ITEM_OVERFLOW | FLAG_FMOCC_OVERFLOW)) {
-                if (attempt >= 3) return fail(CMB_ERR_INTERNAL, "work queues keep overflowing");
-                if (hcnt[0] > q.itemCap) b->items.alloc((size_t)hcnt[0] + hcnt[0] / 8 + 1024);
-                if (hcnt[1] > q.fmCap) b->fm.alloc((size_t)hcnt[1] + hcnt[1] / 8 + 1024);
+            if (flags & (FLAG_ITEM_OVERFLOW | FLAG_FMOCC_OVERFLOW | FLAG_DFS_OVERFLOW)) {
+                if (attempt >= 4) return fail(CMB_ERR_INTERNAL, "work queues keep overflowing");
+                if (hcnt[0] > q.itemCap) b->items.alloc((size_t)hcnt[0] * 2 + 1024);
+                if (hcnt[1] > q.fmCap) b->fm.alloc((size_t)hcnt[1] * 2 + 1024);
+                if (hcnt[5] > dfsCap) b->dfs.alloc((size_t)hcnt[5] + hcnt[5] / 8 + 1024);
                 continue;
             }
             break;

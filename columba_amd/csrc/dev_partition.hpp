@@ -1,0 +1,484 @@
+// Device-side per read x strand PROLOGUE as a lane-uniform state machine (k_partition).
+//
+// Everything matchWithSearches (reference src/searchstrategy.cpp:425-493) does before the
+// approximate DFS is a chain of single-character bidirectional extensions:
+//   * partitioning — uniform / static (calculateExactMatchRanges :158-190) or dynamic
+//     (seed :381-419 + greedy extension :299-379),
+//   * part-level in-text pre-verification (:464-476),
+//   * dynamic scheme selection (src/searchstrategy.h:2505-2537),
+//   * per search: the exact phases of doRecSearch (:1181-1254) and the entry decision of
+//     recApproxMatchEditEntry (src/indexinterface.cpp:1306-1325),
+//   * for k = 0: exactMatchesOutput (src/indexinterface.cpp:947-1014).
+// On the GPU that chain is the rank/extend kernel proper: every lane of a wavefront is at the SAME
+// program point (one extension per loop iteration, 12 independent 16-byte loads per lane in
+// flight), whatever logical phase its read is in; the bookkeeping between two extensions is a few
+// scalar decisions.  What needs the irregular DFS is emitted as a compact DfsTask for k_dfs; what
+// can be verified in the text is emitted as work items for k_verify.
+#pragma once
+#include "dev_search.hpp"
+
+namespace cmb {
+
+struct DfsTask {
+    uint32_t rsId;
+    uint8_t scheme, search, idx, pad; // selected scheme, search number, first approximate phase
+    RangePair r;                      // start range (after the exact phases)
+    uint32_t depth;                   // exact length matched so far
+};
+
+struct PartOut { // per read x strand: the parts, needed again by k_dfs
+    uint16_t pb[MAXP], pe[MAXP];
+};
+
+enum : int { PH_CALC = 0, PH_DYN, PH_POST, PH_SEARCH, PH_EXACT, PH_K0, PH_DONE };
+
+struct PartMachine {
+    const DevIndex& ix;
+    const DevStrategyK& st;
+    const Queues& q;
+    DfsTask* dfsQ;
+    uint32_t dfsCap;
+    // task
+    uint32_t rsId = 0, len = 0, k = 0;
+    const uint8_t* seq = nullptr;
+    // per-lane partition state lives in LDS (dynamic indexing would otherwise force it into
+    // scratch memory, i.e. a memory round trip per access): layout [field][part][lane]
+    uint32_t* lds;   // base of this block's LDS slab
+    uint32_t ltid;   // lane index inside the block
+    uint32_t lstride; // = blockDim.x
+    uint32_t lparts;  // parts per field (numParts of the strategy)
+    __device__ __forceinline__ uint32_t& L(int field, int part) const {
+        return lds[((uint32_t)field * lparts + (uint32_t)part) * lstride + ltid];
+    }
+    __device__ __forceinline__ uint32_t PB(int i) const { return L(4, i) & 0xFFFFu; }
+    __device__ __forceinline__ uint32_t PE(int i) const { return L(4, i) >> 16; }
+    __device__ __forceinline__ void setPB(int i, uint32_t v) { L(4, i) = (L(4, i) & 0xFFFF0000u) | (v & 0xFFFFu); }
+    __device__ __forceinline__ void setPE(int i, uint32_t v) { L(4, i) = (L(4, i) & 0xFFFFu) | (v << 16); }
+    __device__ __forceinline__ void setPBE(int i, uint32_t b, uint32_t e) { L(4, i) = (b & 0xFFFFu) | (e << 16); }
+    __device__ __forceinline__ RangePair EX(int i) const {
+        return RangePair{{L(0, i), L(1, i)}, {L(2, i), L(3, i)}};
+    }
+    __device__ __forceinline__ void setEX(int i, const RangePair& r) {
+        L(0, i) = r.sa.b;
+        L(1, i) = r.sa.e;
+        L(2, i) = r.rev.b;
+        L(3, i) = r.rev.e;
+    }
+    __device__ __forceinline__ uint32_t EXW(int i) const {
+        const uint32_t b = L(0, i), e = L(1, i);
+        return e <= b ? 0u : e - b;
+    }
+    // counters
+    uint32_t cNode = 0, cExp = 0, cImm = 0, cStart = 0, flags = 0;
+    // machine state
+    int phase = PH_DONE;
+    int numParts = 0;
+    int pi = 0;          // PH_CALC: current part
+    uint32_t ci = 0;     // PH_CALC / PH_EXACT: next character index inside the part
+    uint32_t cend = 0;   // PH_CALC: number of characters to match in the part
+    uint32_t cb = 0, ce = 0; // PH_CALC / PH_EXACT: sub-range of the read being matched
+    int cdir = 0;        // direction of the substring being matched
+    uint32_t j = 0;      // PH_DYN: assigned characters so far
+    int partToExtend = 0, dynDir = 0;
+    int sel = 0, si = 0, partInSearch = 0; // PH_SEARCH / PH_EXACT
+    uint32_t exactLength = 0;
+    RangePair cur;       // range being extended (PH_EXACT / PH_K0)
+    uint32_t k0i = 0;    // PH_K0
+    // pending extension request
+    bool req = false;
+    int reqMode = 0;
+    uint32_t reqCode = 0;
+    RangePair reqParent;
+
+    __device__ PartMachine(const DevIndex& i, const DevStrategyK& s, const Queues& qq, DfsTask* dq, uint32_t dc,
+                           uint32_t* ldsBase, uint32_t tid, uint32_t stride)
+        : ix(i), st(s), q(qq), dfsQ(dq), dfsCap(dc), lds(ldsBase), ltid(tid), lstride(stride),
+          lparts(s.numParts ? s.numParts : 1) {}
+
+    // ---- emission ---------------------------------------------------------------------------
+    __device__ __forceinline__ void emitItems(const Range& sa, uint32_t a, uint32_t meta) {
+        const uint32_t w = sa.width();
+        if (!w) return;
+        if (q.dbg & 2u) return;
+        const uint32_t base = atomicAdd(&q.cnt[0], w);
+        if (base + w > q.itemCap) {
+            flags |= FLAG_ITEM_OVERFLOW;
+            return;
+        }
+        for (uint32_t t = 0; t < w; t++) q.items[base + t] = make_uint4(rsId, sa.b + t, a, meta);
+    }
+    __device__ __forceinline__ void emitDfs(int idx, const RangePair& r, uint32_t depth) {
+        const uint32_t base = atomicAdd(&q.cnt[5], 1u);
+        if (base >= dfsCap) {
+            flags |= FLAG_DFS_OVERFLOW;
+            return;
+        }
+        DfsTask t;
+        t.rsId = rsId;
+        t.scheme = (uint8_t)sel;
+        t.search = (uint8_t)si;
+        t.idx = (uint8_t)idx;
+        t.pad = 0;
+        t.r = r;
+        t.depth = depth;
+        dfsQ[base] = t;
+    }
+
+    // ---- helpers ----------------------------------------------------------------------------
+    __device__ __forceinline__ uint32_t charAt(uint32_t b, uint32_t e, int d, uint32_t i) const {
+        return d == 0 ? seq[b + i] : seq[e - i - 1];
+    }
+    __device__ __forceinline__ RangePair kmer(uint32_t begin, uint32_t end) const { // indexinterface.h:590
+        for (uint32_t i = begin; i < end; i++)
+            if (seq[i] > 4) return RangePair{{0, 0}, {0, 0}};
+        uint32_t key = 0;
+        for (uint32_t i = 0; i < ix.kmerSize; i++) key = (key << 2) | (uint32_t)(seq[begin + i] - 1);
+        const uint4 v = ix.kmer[key];
+        return RangePair{{v.x, v.y}, {v.z, v.w}};
+    }
+    __device__ __forceinline__ void request(int mode, const RangePair& parent, uint32_t code) {
+        req = true;
+        reqMode = mode;
+        reqParent = parent;
+        reqCode = code;
+    }
+
+    // ---- task start -------------------------------------------------------------------------
+    __device__ void begin(uint32_t rs, uint32_t length, const uint8_t* s, uint32_t kk) {
+        rsId = rs;
+        len = length;
+        seq = s;
+        k = kk;
+        req = false;
+        partToExtend = 0;
+        dynDir = 0;
+        if (k == 0) { // exactMatchesOutput (indexinterface.cpp:947-1014)
+            if (len == 0) {
+                phase = PH_DONE;
+                return;
+            }
+            cur = RangePair{{0, ix.n}, {0, 0}};
+            k0i = len;
+            phase = PH_K0;
+            return;
+        }
+        numParts = st.numParts;
+        if (numParts >= (int)len || numParts == 1 || len > (uint32_t)MAX_READ) {
+            flags |= FLAG_UNSUPPORTED_READ; // naive fallback (searchstrategy.cpp:148-152) not on device
+            phase = PH_DONE;
+            return;
+        }
+        const uint32_t L = len;
+        if (st.partition == 0) { // partitionUniform (:194-209)
+            for (int i = 0; i < numParts; i++) {
+                const uint32_t b = (uint32_t)((i * 1.0 / numParts) * L);
+                uint32_t e = (uint32_t)(((i + 1) * 1.0 / numParts) * L);
+                setPBE(i, b, e > L ? L : e);
+            }
+            setPE(numParts - 1, L);
+            startCalcPart(0);
+            phase = PH_CALC;
+        } else if (st.partition == 1) { // setParts (:221-238)
+            const int pSize = (int)L;
+            const double* bg = st.begins;
+            setPBE(0, 0, (uint32_t)(bg[0] * pSize) & 0xFFFFu);
+            for (int i = 0; i < numParts - 2; i++)
+                setPBE(i + 1, (uint32_t)(bg[i] * pSize), (uint32_t)(bg[i + 1] * pSize) & 0xFFFFu);
+            setPBE(numParts - 1, (uint32_t)(bg[numParts - 2] * pSize), L);
+            for (int i = 0; i < numParts; i++)
+                if (PE(i) > L) setPE(i, L); // Substring::check()
+            startCalcPart(0);
+            phase = PH_CALC;
+        } else { // seed (:381-419)
+            const uint32_t ws = ix.kmerSize;
+            const bool useKmer = ((uint32_t)numParts * ws < (L * 2) / 3) && (L >= st.kmerCutOff);
+            const int wSize = useKmer ? (int)ws : 1;
+            setPBE(0, 0, (uint32_t)wSize);
+            for (int i = 1; i < numParts - 1; i++) {
+                const uint32_t b = (uint32_t)(uint16_t)(int)((st.seeding[i - 1] * L) - (wSize / 2));
+                setPBE(i, b, (b + wSize) & 0xFFFFu);
+            }
+            setPBE(numParts - 1, L - wSize, L);
+            for (int i = 0; i < numParts; i++) {
+                if (useKmer) {
+                    setEX(i, kmer(PB(i), PE(i)));
+                } else { // getRangeOfSingleChar (fmindex.cpp:434-445)
+                    const uint32_t code = seq[PB(i)];
+                    if (code < 1 || code > 4) setEX(i, RangePair{{0, 0}, {0, 0}});
+                    else {
+                        const uint32_t lo = ix.counts[code], hi = code < 4 ? ix.counts[code + 1] : ix.n;
+                        setEX(i, RangePair{{lo, hi}, {lo, hi}});
+                    }
+                }
+            }
+            j = (uint32_t)(numParts * wSize);
+            phase = PH_DYN;
+        }
+    }
+
+    // calculateExactMatchRanges (:158-190): stages 0..P-1 match EVERY part forwards (the loop at :166
+    // runs over all parts), stage P re-matches the last part backwards, uni-directionally (:178-189)
+    __device__ void startCalcPart(int stage) {
+        pi = stage;
+        const int i = stage < numParts ? stage : numParts - 1;
+        const uint32_t ws = ix.kmerSize;
+        const uint32_t b = PB(i), e = PE(i);
+        const uint32_t size = e > b ? e - b : 0;
+        const bool last = (stage == numParts);
+        if (!last) {
+            const uint32_t start = b + (size >= ws ? ws : 0);
+            setEX(i, size >= ws ? kmer(b, start) : RangePair{{0, ix.n}, {0, ix.n}});
+            cb = start;
+            ce = e;
+            cdir = 0;
+        } else {
+            const uint32_t end = size >= ws ? e - ws : e;
+            setEX(i, size >= ws ? kmer(end, e) : RangePair{{0, ix.n}, {0, ix.n}});
+            cb = b;
+            ce = end;
+            cdir = 1;
+        }
+        ci = 0;
+        cend = ce > cb ? ce - cb : 0;
+    }
+
+    // ---- one scheduling step: runs until an extension is requested or the task is finished ----
+    __device__ void advance() {
+        for (;;) {
+            switch (phase) {
+            case PH_CALC: {
+                const int part = pi < numParts ? pi : numParts - 1;
+                if (ci < cend) {
+                    const uint32_t code = charAt(cb, ce, cdir, ci);
+                    if (code >= 1 && code <= 4) {
+                        request(pi == numParts ? 2 : 0, EX(part), code);
+                        return;
+                    }
+                    setEX(part, RangePair{{0, 0}, {0, 0}}); // addChar on a non-ACGT character
+                }
+                // part finished (or failed): next stage
+                if (pi < numParts) {
+                    startCalcPart(pi + 1);
+                } else {
+                    phase = PH_POST;
+                }
+                break;
+            }
+            case PH_DYN: { // partitionDynamic loop body (:324-378)
+                if (j >= len) {
+                    phase = PH_POST;
+                    break;
+                }
+                uint64_t maxRangeWeighted = 0;
+                {
+                    uint32_t prevPE = 0, prevW = 0;
+                    uint32_t curPBE = L(4, 0), curW = EXW(0);
+                    for (int i = 0; i < numParts; i++) {
+                        const bool lastPart = (i == numParts - 1);
+                        const uint32_t nextPBE = lastPart ? 0u : L(4, i + 1);
+                        const uint32_t nextW = lastPart ? 0u : EXW(i + 1);
+                        const uint32_t b = curPBE & 0xFFFFu, e = curPBE >> 16;
+                        const bool noLeft = (i == 0) || b == prevPE;
+                        const bool noRight = lastPart || e == (nextPBE & 0xFFFFu);
+                        if (!(noLeft && noRight)) {
+                            const uint64_t wv = (uint64_t)curW * st.weights[i];
+                            if (wv > maxRangeWeighted) {
+                                maxRangeWeighted = wv;
+                                partToExtend = i;
+                                if (noLeft) dynDir = 0;
+                                else if (noRight) dynDir = 1;
+                                else dynDir = (prevW < nextW) ? 1 : 0;
+                            }
+                        }
+                        prevPE = e;
+                        prevW = curW;
+                        curPBE = nextPBE;
+                        curW = nextW;
+                    }
+                }
+                if (maxRangeWeighted == 0) { // extendParts (:283-297)
+                    for (int i = 0; i < numParts; i++) {
+                        if (i != numParts - 1 && PE(i) != PB(i + 1)) setPE(i, PB(i + 1));
+                        if (i != 0 && PB(i) != PE(i - 1)) setPB(i, PE(i - 1));
+                    }
+                    phase = PH_POST;
+                    break;
+                }
+                uint32_t code;
+                if (dynDir == 0) {
+                    const uint32_t e = PE(partToExtend) + 1;
+                    setPE(partToExtend, e);
+                    code = seq[e - 1];
+                } else {
+                    const uint32_t b = PB(partToExtend) - 1;
+                    setPB(partToExtend, b);
+                    code = seq[b];
+                }
+                j++;
+                if (code >= 1 && code <= 4) {
+                    request(partToExtend == numParts - 1 ? 2 : dynDir, EX(partToExtend), code);
+                    return;
+                }
+                setEX(partToExtend, RangePair{{0, 0}, {0, 0}});
+                break;
+            }
+            case PH_POST: { // searchstrategy.cpp:464-481
+                const uint32_t sw = ix.switchPoint;
+                for (int i = 0; i < numParts; i++) {
+                    const uint32_t width = EXW(i);
+                    if (width != 0 && width <= sw) {
+                        const uint32_t bg = PB(i);
+                        const Range sa{L(0, i), L(1, i)};
+                        if (st.metric == 1) {
+                            cImm++; // verifyExactPartialMatchInText (fmindex.cpp:253)
+                            emitItems(sa, bg == 0 ? 0 : bg + k, packMeta(0, k, 0, bg == 0, ITEM_EDIT));
+                        } else {
+                            emitItems(sa, bg, packMeta(0, k, 0, 0, ITEM_HAMMING));
+                        }
+                    }
+                }
+                sel = 0; // MultipleSchemes::createSearches (searchstrategy.h:2505-2537)
+                if (st.nSchemes > 1) {
+                    uint32_t total = 0;
+                    for (int i = 0; i < numParts; i++) total += EXW(i);
+                    if (total > (uint32_t)numParts) {
+                        uint32_t minValue = EXW(st.sch[0].critical);
+                        for (int i = 1; i < st.nSchemes; i++) {
+                            const uint32_t w = EXW(st.sch[i].critical);
+                            if (w < minValue) {
+                                minValue = w;
+                                sel = i;
+                            }
+                        }
+                    }
+                }
+                si = 0;
+                phase = PH_SEARCH;
+                break;
+            }
+            case PH_SEARCH: { // doRecSearch (searchstrategy.cpp:1181-1254)
+                const DevScheme& sch = st.sch[sel];
+                if (si >= sch.nSearches) {
+                    phase = PH_DONE;
+                    return;
+                }
+                const DevSearch& s = sch.s[si];
+                if (s.U[0] > 0) {
+                    if (st.metric == 1) cStart++; // recApproxMatchEditEntry: complete range > switch point
+                    emitDfs(0, RangePair{{0, ix.n}, {0, ix.n}}, 0);
+                    si++;
+                    break;
+                }
+                const int first = s.order[0];
+                cur = EX(first);
+                if (cur.width() <= ix.switchPoint) {
+                    si++;
+                    break;
+                }
+                partInSearch = 1;
+                exactLength = PE(first) - PB(first);
+                ci = 0;
+                phase = PH_EXACT;
+                break;
+            }
+            case PH_EXACT: {
+                const DevSearch& s = st.sch[sel].s[si];
+                if (s.U[partInSearch] == 0) {
+                    const int part = s.order[partInSearch];
+                    const uint32_t b = PB(part), e = PE(part);
+                    const uint32_t n = e > b ? e - b : 0;
+                    if (ci < n) {
+                        const uint32_t code = charAt(b, e, s.dir[partInSearch], ci);
+                        if (code >= 1 && code <= 4) {
+                            const bool uni = s.uniAll || partInSearch >= (int)s.uniIdx;
+                            request(uni ? 2 : (s.dir[partInSearch] == 0 ? 0 : 1), cur, code);
+                            return;
+                        }
+                        cur = RangePair{{0, 0}, {0, 0}};
+                    }
+                    if (cur.empty()) { // `if (startRange.empty()) return;`
+                        si++;
+                        phase = PH_SEARCH;
+                        break;
+                    }
+                    exactLength += n;
+                    partInSearch++;
+                    ci = 0;
+                    break;
+                }
+                // exact phases done: start approximate matching
+                if (st.metric == 1 && cur.width() <= ix.switchPoint) { // recApproxMatchEditEntry
+                    cImm++;
+                    const uint32_t bg = PB(s.low[partInSearch - 1]);
+                    const uint32_t maxEDs = s.U[s.n - 1], minEDs = s.L[s.n - 1];
+                    emitItems(cur.sa, bg == 0 ? 0 : bg + maxEDs, packMeta(0, maxEDs, minEDs, bg == 0, ITEM_EDIT));
+                } else {
+                    if (st.metric == 1) cStart++;
+                    emitDfs(partInSearch, cur, exactLength);
+                }
+                si++;
+                phase = PH_SEARCH;
+                break;
+            }
+            case PH_K0: {
+                if (k0i == 0) { // everything matched in the index
+                    emitItems(cur.sa, 0, packMeta(0, 0, 0, 1, ITEM_EXACT));
+                    phase = PH_DONE;
+                    return;
+                }
+                const uint32_t code = seq[k0i - 1];
+                if (code > 4) {
+                    phase = PH_DONE;
+                    return;
+                }
+                request(2, cur, code);
+                return;
+            }
+            default:
+                return;
+            }
+        }
+    }
+
+    // ---- consume the result of the requested extension ----------------------------------------
+    __device__ void resume(bool ok, const RangePair& child) {
+        cExp++;
+        if (ok) cNode++;
+        const RangePair res = ok ? child : RangePair{{0, 0}, {0, 0}};
+        switch (phase) {
+        case PH_CALC:
+            setEX(pi < numParts ? pi : numParts - 1, res);
+            if (ok) ci++;
+            else ci = cend; // matchStringBidirectionally stops at the first failure
+            break;
+        case PH_DYN:
+            setEX(partToExtend, res);
+            break;
+        case PH_EXACT:
+            cur = res;
+            if (ok) {
+                ci++;
+            } else { // range is empty: this search is over
+                si++;
+                phase = PH_SEARCH;
+            }
+            break;
+        case PH_K0:
+            if (!ok) { // no exact match possible
+                phase = PH_DONE;
+                break;
+            }
+            cur.sa = child.sa;
+            k0i--;
+            if (cur.sa.width() <= ix.switchPoint) { // switch to in-text verification with k0i chars left
+                emitItems(cur.sa, k0i, packMeta(0, 0, 0, 0, ITEM_EXACT));
+                phase = PH_DONE;
+            }
+            break;
+        default:
+            break;
+        }
+    }
+};
+
+} // namespace cmb

@@ -65,7 +65,7 @@ struct TextOccRec { // in-text occurrence before filtering
 };
 
 enum { FLAG_ITEM_OVERFLOW = 1, FLAG_FMOCC_OVERFLOW = 2, FLAG_TEXT_OVERFLOW = 4, FLAG_CAPACITY = 8,
-       FLAG_UNSUPPORTED_READ = 16 };
+       FLAG_UNSUPPORTED_READ = 16, FLAG_DFS_OVERFLOW = 32 };
 
 struct Queues {
     uint4* items;
@@ -74,8 +74,9 @@ struct Queues {
     uint32_t fmCap;
     TextOccRec* text;
     uint32_t textCap;
-    uint32_t* cnt; // [0] items, [1] fm, [2] text, [3] flags, [4] work counter
+    uint32_t* cnt; // [0] items, [1] fm, [2] text, [3] flags, [4] work counter, [5] dfs tasks, [6] dfs work counter
     unsigned long long* counters; // CMB_CNT_MAX
+    uint32_t dbg;                 // development knobs (CMB_DEBUG), 0 in production
 };
 
 struct Node { // FMPosExt (src/indexhelpers.h:1544)
@@ -104,9 +105,7 @@ struct Frame { // one activation of recApproxMatchEdit / recApproxMatchHamming
 };
 
 struct Scratch {
-    uint16_t pb[MAXP], pe[MAXP]; // parts
-    uint8_t pdir[MAXP];
-    RangePair ex[MAXP];      // exactMatchRanges
+    uint16_t pb[MAXP], pe[MAXP]; // parts (copied from k_partition's PartOut)
     uint64_t rowHP[ROWS_MAX], rowHN[ROWS_MAX], rowRAC[ROWS_MAX];
     uint16_t rowScore[ROWS_MAX];
     Node stack[STACK_MAX];
@@ -157,20 +156,6 @@ __device__ __forceinline__ void emitFMOcc(Ctx& c, const Range& sa, uint32_t dept
 }
 
 // ---- extend helpers -------------------------------------------------------------------------
-// IndexInterface::addChar (indexinterface.cpp:1034-1049); code 1..4, 5 = N
-__device__ __forceinline__ bool addChar(Ctx& c, uint32_t code, RangePair& r) {
-    if (code >= 1 && code <= 4) {
-        c.cExp++;
-        RangePair child;
-        if (extendOne(c.ix, c.mode(), r, code, child)) {
-            r = child;
-            c.cNode++;
-            return true;
-        }
-    }
-    r = RangePair{{0, 0}, {0, 0}};
-    return false;
-}
 // IndexInterface::extendFMPos (indexinterface.cpp:675-697): push the non-empty children A,C,G,T
 __device__ __forceinline__ void extendFMPos(Ctx& c, const RangePair& parent, uint32_t row, Frame& f) {
     uint32_t Rb[4], Re[4], db, de;
@@ -198,145 +183,6 @@ __device__ __forceinline__ void extendFMPos(Ctx& c, const RangePair& parent, uin
 // character of part (b,e) with direction d at index i (Substring::operator[], substring.h:42,101)
 __device__ __forceinline__ uint32_t partChar(const Ctx& c, uint32_t b, uint32_t e, int d, uint32_t i) {
     return d == 0 ? c.seq[b + i] : c.seq[e - i - 1];
-}
-
-// IndexInterface::matchStringBidirectionally (indexinterface.cpp:1016-1032)
-__device__ __forceinline__ RangePair matchString(Ctx& c, uint32_t b, uint32_t e, int d, RangePair r) {
-    const uint32_t n = e > b ? e - b : 0;
-    for (uint32_t i = 0; i < n; i++)
-        if (!addChar(c, partChar(c, b, e, d, i), r)) break;
-    return r;
-}
-
-// IndexInterface::lookUpInKmerTable (indexinterface.h:590-594)
-__device__ __forceinline__ RangePair kmerLookup(const Ctx& c, uint32_t begin, uint32_t end) {
-    uint32_t key = 0;
-    for (uint32_t i = begin; i < end; i++)
-        if (c.seq[i] > 4) return RangePair{{0, 0}, {0, 0}}; // containsN
-    for (uint32_t i = 0; i < c.ix.kmerSize; i++) key = (key << 2) | (uint32_t)(c.seq[begin + i] - 1);
-    const uint4 v = c.ix.kmer[key];
-    return RangePair{{v.x, v.y}, {v.z, v.w}};
-}
-__device__ __forceinline__ RangePair completeRange(const DevIndex& ix) {
-    return RangePair{{0, ix.n}, {0, ix.n}};
-}
-// FMIndex::getRangeOfSingleChar (fmindex.cpp:434-445)
-__device__ __forceinline__ RangePair singleCharRange(const DevIndex& ix, uint32_t code) {
-    if (code < 1 || code > 4) return RangePair{{0, 0}, {0, 0}};
-    const uint32_t lo = ix.counts[code];
-    const uint32_t hi = code < 4 ? ix.counts[code + 1] : ix.n;
-    return RangePair{{lo, hi}, {lo, hi}};
-}
-
-// ---- partitioning (searchstrategy.cpp:141-419) ----------------------------------------------
-__device__ inline void calcExactRanges(Ctx& c, int numParts) { // :158-190
-    Scratch& S = c.S;
-    c.setDirection(0, false);
-    const uint32_t ws = c.ix.kmerSize;
-    for (int i = 0; i < numParts; i++) {
-        const uint32_t b = S.pb[i], e = S.pe[i];
-        const uint32_t size = e > b ? e - b : 0;
-        const uint32_t start = b + (size >= ws ? ws : 0);
-        RangePair init = size >= ws ? kmerLookup(c, b, start) : completeRange(c.ix);
-        S.ex[i] = matchString(c, start, e, 0, init);
-    }
-    c.setDirection(1, true);
-    const int last = numParts - 1;
-    S.pdir[last] = 1;
-    const uint32_t b = S.pb[last], e = S.pe[last];
-    const uint32_t size = e > b ? e - b : 0;
-    const uint32_t end = size >= ws ? e - ws : e;
-    RangePair init = size >= ws ? kmerLookup(c, end, e) : completeRange(c.ix);
-    S.ex[last] = matchString(c, b, end, 1, init);
-}
-
-__device__ inline void partitionUniform(Ctx& c, int numParts) { // :194-209
-    Scratch& S = c.S;
-    const uint32_t L = c.len;
-    for (int i = 0; i < numParts; i++) {
-        S.pb[i] = (uint16_t)(uint32_t)((i * 1.0 / numParts) * L);
-        uint32_t e = (uint32_t)(((i + 1) * 1.0 / numParts) * L);
-        S.pe[i] = (uint16_t)(e > L ? L : e);
-        S.pdir[i] = 0;
-    }
-    S.pe[numParts - 1] = (uint16_t)L;
-    calcExactRanges(c, numParts);
-}
-__device__ inline void partitionStatic(Ctx& c, int numParts) { // :212-238
-    Scratch& S = c.S;
-    const int pSize = (int)c.len;
-    const double* bg = c.st.begins; // numParts - 1 values
-    S.pb[0] = 0;
-    S.pe[0] = (uint16_t)(uint32_t)(bg[0] * pSize);
-    for (int i = 0; i < numParts - 2; i++) {
-        S.pb[i + 1] = (uint16_t)(uint32_t)(bg[i] * pSize);
-        S.pe[i + 1] = (uint16_t)(uint32_t)(bg[i + 1] * pSize);
-    }
-    S.pb[numParts - 1] = (uint16_t)(uint32_t)(bg[numParts - 2] * pSize);
-    S.pe[numParts - 1] = (uint16_t)c.len;
-    for (int i = 0; i < numParts; i++) {
-        S.pdir[i] = 0;
-        if (S.pe[i] > c.len) S.pe[i] = (uint16_t)c.len; // Substring::check()
-    }
-    calcExactRanges(c, numParts);
-}
-__device__ inline void partitionDynamic(Ctx& c, int numParts) { // :299-419
-    Scratch& S = c.S;
-    const uint32_t pSize = c.len;
-    const uint32_t ws = c.ix.kmerSize;
-    // seed() :381-419
-    const bool useKmer = ((uint32_t)numParts * ws < (pSize * 2) / 3) && (pSize >= c.st.kmerCutOff);
-    const int wSize = useKmer ? (int)ws : 1;
-    S.pb[0] = 0;
-    for (int i = 1; i < numParts - 1; i++) {
-        const int sd = (int)((c.st.seeding[i - 1] * pSize) - (wSize / 2));
-        S.pb[i] = (uint16_t)sd;
-    }
-    for (int i = 0; i < numParts - 1; i++) {
-        S.pe[i] = (uint16_t)(S.pb[i] + wSize);
-        S.pdir[i] = 0;
-    }
-    S.pb[numParts - 1] = (uint16_t)(pSize - wSize);
-    S.pe[numParts - 1] = (uint16_t)pSize;
-    S.pdir[numParts - 1] = 0;
-    for (int i = 0; i < numParts; i++)
-        S.ex[i] = useKmer ? kmerLookup(c, S.pb[i], S.pe[i]) : singleCharRange(c.ix, c.seq[S.pb[i]]);
-    const int matchedChars = numParts * wSize;
-    int d = 0;
-    int partToExtend = 0;
-    for (uint32_t j = (uint32_t)matchedChars; j < pSize; j++) {
-        uint64_t maxRangeWeighted = 0;
-        for (int i = 0; i < numParts; i++) {
-            const bool noLeft = (i == 0) || S.pb[i] == S.pe[i - 1];
-            const bool noRight = (i == numParts - 1) || S.pe[i] == S.pb[i + 1];
-            if (noLeft && noRight) continue;
-            const uint64_t wv = (uint64_t)S.ex[i].width() * c.st.weights[i];
-            if (wv > maxRangeWeighted) {
-                maxRangeWeighted = wv;
-                partToExtend = i;
-                if (noLeft) d = 0;
-                else if (noRight) d = 1;
-                else d = (S.ex[i - 1].width() < S.ex[i + 1].width()) ? 1 : 0;
-            }
-        }
-        if (maxRangeWeighted == 0) { // extendParts :283-297
-            for (int i = 0; i < numParts; i++) {
-                if (i != numParts - 1 && S.pe[i] != S.pb[i + 1]) S.pe[i] = S.pb[i + 1];
-                if (i != 0 && S.pb[i] != S.pe[i - 1]) S.pb[i] = S.pe[i - 1];
-            }
-            return;
-        }
-        uint32_t code;
-        if (d == 0) {
-            S.pe[partToExtend]++;
-            code = c.seq[S.pe[partToExtend] - 1];
-        } else {
-            S.pb[partToExtend]--;
-            code = c.seq[S.pb[partToExtend]];
-        }
-        c.setDirection(d, partToExtend == numParts - 1);
-        addChar(c, code, S.ex[partToExtend]);
-    }
 }
 
 // ---- cluster (MatrixMetaInfo) ---------------------------------------------------------------
@@ -630,18 +476,9 @@ struct EditSearch {
     }
 
     // recApproxMatchEditEntry (indexinterface.cpp:1306-1325) + the whole recursion
+    // (the width <= switch-point branch of the entry and SEARCH_STARTED are handled by k_partition)
     __device__ void run(const OccTmp& startMatch, int idx) {
         Scratch& S = c.S;
-        if (startMatch.r.width() <= c.ix.switchPoint) {
-            // verifyExactPartialMatchInText (fmindex.cpp:245-265)
-            c.cImm++;
-            const uint32_t begin = S.pb[s.low[idx - 1]];
-            const uint32_t maxEDs = s.U[s.n - 1], minEDs = s.L[s.n - 1];
-            const uint32_t startDiff = begin == 0 ? 0 : begin + maxEDs;
-            emitItems(c, startMatch.r.sa, startDiff, packMeta(0, maxEDs, minEDs, begin == 0, ITEM_EDIT));
-            return;
-        }
-        c.cStart++;
         firstIdx = idx;
         enter(idx, startMatch, -1, -1);
         const uint32_t sw = c.ix.switchPoint;
@@ -761,131 +598,5 @@ struct HammingSearch {
         }
     }
 };
-
-// ---- per read x strand driver (matchWithSearches, searchstrategy.cpp:425-493) ---------------
-__device__ inline void doRecSearch(Ctx& c, const DevSearch& s) { // searchstrategy.cpp:1181-1254
-    Scratch& S = c.S;
-    const bool edit = c.st.metric == 1;
-    if (s.U[0] > 0) {
-        for (int i = 0; i < s.n; i++) S.pdir[s.order[i]] = s.dir[i];
-        OccTmp sm;
-        sm.r = completeRange(c.ix);
-        sm.dist = sm.depth = sm.shift = 0;
-        sm.valid = true;
-        if (edit) {
-            EditSearch es(c, s);
-            es.run(sm, 0);
-        } else {
-            HammingSearch hs(c, s);
-            hs.run(sm.r, 0, 0);
-        }
-        return;
-    }
-    const int first = s.order[0];
-    RangePair startRange = S.ex[first];
-    if (startRange.width() > c.ix.switchPoint) {
-        for (int i = 0; i < s.n; i++) S.pdir[s.order[i]] = s.dir[i];
-        int partInSearch = 1;
-        uint32_t exactLength = S.pe[first] - S.pb[first];
-        while (s.U[partInSearch] == 0) {
-            c.setDirection(s.dir[partInSearch], s.uniAll || partInSearch >= (int)s.uniIdx);
-            const int part = s.order[partInSearch];
-            startRange = matchString(c, S.pb[part], S.pe[part], S.pdir[part], startRange);
-            if (startRange.empty()) return;
-            exactLength += S.pe[part] - S.pb[part];
-            partInSearch++;
-        }
-        OccTmp sm;
-        sm.r = startRange;
-        sm.dist = 0;
-        sm.depth = exactLength;
-        sm.shift = 0;
-        sm.valid = true;
-        if (edit) {
-            EditSearch es(c, s);
-            es.run(sm, partInSearch);
-        } else {
-            HammingSearch hs(c, s);
-            hs.run(sm.r, sm.depth, partInSearch);
-        }
-    }
-}
-
-// k == 0: IndexInterface::exactMatchesOutput (indexinterface.cpp:947-1014)
-__device__ inline void exactSearch(Ctx& c) {
-    Scratch& S = c.S;
-    if (c.len == 0) return;
-    Range range{0, c.ix.n};
-    uint32_t i = c.len;
-    for (; i-- > 0;) {
-        const uint32_t code = c.seq[i];
-        if (code > 4) return;
-        c.cExp++;
-        uint32_t Rb[4], Re[4];
-        rank4(c.ix.fwd, range.b, Rb);
-        rank4(c.ix.fwd, range.e, Re);
-        Range nr{occFromR(Rb, code) + c.ix.counts[code], occFromR(Re, code) + c.ix.counts[code]};
-        range = nr;
-        if (range.empty()) return;
-        c.cNode++;
-        if (range.width() <= c.ix.switchPoint) break;
-    }
-    // i == (uint32_t)-1: everything matched in the index; else `i` characters remain
-    const uint32_t remaining = (i == 0xFFFFFFFFu) ? 0u : i;
-    emitItems(c, range, remaining, packMeta(0, 0, 0, i == 0xFFFFFFFFu ? 1u : 0u, ITEM_EXACT));
-}
-
-__device__ inline void matchStrand(Ctx& c) {
-    Scratch& S = c.S;
-    const DevStrategyK& st = c.st;
-    const uint32_t k = c.k;
-    if (k == 0) {
-        exactSearch(c);
-        return;
-    }
-    const int numParts = st.numParts;
-    if (numParts >= (int)c.len || numParts == 1 || c.len > (uint32_t)MAX_READ) {
-        // naive backtracking fallback of the reference (searchstrategy.cpp:148-152,442-459):
-        // not provided on the device — reported, never silently skipped
-        c.flags |= FLAG_UNSUPPORTED_READ;
-        return;
-    }
-    if (st.partition == 0) partitionUniform(c, numParts);
-    else if (st.partition == 1) partitionStatic(c, numParts);
-    else partitionDynamic(c, numParts);
-
-    // A) parts with few exact matches go straight to in-text verification (:464-476)
-    const uint32_t sw = c.ix.switchPoint;
-    for (int i = 0; i < numParts; i++) {
-        const uint32_t width = S.ex[i].width();
-        if (width != 0 && width <= sw) {
-            const uint32_t begin = S.pb[i];
-            if (st.metric == 1) {
-                c.cImm++; // verifyExactPartialMatchInText (fmindex.cpp:253)
-                emitItems(c, S.ex[i].sa, begin == 0 ? 0 : begin + k, packMeta(0, k, 0, begin == 0, ITEM_EDIT));
-            } else { // verifyExactPartialMatchInTextHamming (fmindex.cpp:344-356)
-                emitItems(c, S.ex[i].sa, begin, packMeta(0, k, 0, 0, ITEM_HAMMING));
-            }
-        }
-    }
-    // B) dynamic scheme selection (searchstrategy.h:2505-2537)
-    int sel = 0;
-    if (st.nSchemes > 1) {
-        uint32_t total = 0;
-        for (int i = 0; i < numParts; i++) total += S.ex[i].width();
-        if (total > (uint32_t)numParts) {
-            uint32_t minValue = S.ex[st.sch[0].critical].width();
-            for (int i = 1; i < st.nSchemes; i++) {
-                const uint32_t w = S.ex[st.sch[i].critical].width();
-                if (w < minValue) {
-                    minValue = w;
-                    sel = i;
-                }
-            }
-        }
-    }
-    const DevScheme& sch = st.sch[sel];
-    for (int si = 0; si < sch.nSearches; si++) doRecSearch(c, sch.s[si]);
-}
 
 } // namespace cmb

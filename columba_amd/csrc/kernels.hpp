@@ -10,7 +10,7 @@
 //                                                       indexhelpers.cpp:518-574, indexinterface.cpp:918-943
 //   k_fmocc       in-index occurrence -> text positions indexinterface.cpp:1385-1440, :1349-1366
 #pragma once
-#include "dev_search.hpp"
+#include "dev_partition.hpp"
 
 namespace cmb {
 
@@ -103,30 +103,100 @@ __device__ __forceinline__ void flushCounters(const Queues& q, const uint32_t* l
         if (local[i]) atomicAdd(&q.counters[which[i]], (unsigned long long)local[i]);
 }
 
-// ------------------------------------------------------------------ search
+// ------------------------------------------------------------------ prologue: the rank/extend kernel
+// One lane per read x strand.  Every loop iteration performs at most ONE bidirectional extension per
+// lane, at one common program point: 2 positions x (4 x 16 B of the 64-byte counts line + 2 x 16 B of
+// the 32-byte bit group) = 12 independent 16-byte loads per lane in flight, whatever phase of the
+// prologue the lane's read is in (dev_partition.hpp).
+__global__ void __launch_bounds__(256, 4)
+k_partition(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* __restrict__ offs, uint32_t nReads,
+            uint32_t k, uint32_t maxLen, const uint8_t* __restrict__ seq, PartOut* __restrict__ parts,
+            DfsTask* __restrict__ dfsQ, uint32_t dfsCap, Queues q) {
+    extern __shared__ uint32_t partLds[]; // 5 fields x numParts x blockDim.x words
+    PartMachine m(ix, *stp, q, dfsQ, dfsCap, partLds, threadIdx.x, blockDim.x);
+    const uint32_t total = 2 * nReads;
+    uint32_t nextRs = blockIdx.x * blockDim.x + threadIdx.x;
+    for (;;) {
+        if (m.phase == PH_DONE) {
+            uint32_t rs;
+            if (q.dbg & 1u) {
+                rs = nextRs;
+                nextRs += gridDim.x * blockDim.x;
+            } else {
+                rs = atomicAdd(&q.cnt[4], 1u);
+            }
+            if (rs >= total) break;
+            const uint32_t r = rs >> 1;
+            m.begin(rs, (uint32_t)(offs[r + 1] - offs[r]), seq + (size_t)rs * maxLen, k);
+        }
+        m.advance();
+        if (m.phase == PH_DONE && k > 0 && !(m.flags & FLAG_UNSUPPORTED_READ)) {
+            PartOut po;
+#pragma unroll
+            for (int i = 0; i < MAXP; i++) {
+                po.pb[i] = i < m.numParts ? (uint16_t)m.PB(i) : (uint16_t)0;
+                po.pe[i] = i < m.numParts ? (uint16_t)m.PE(i) : (uint16_t)0;
+            }
+            parts[m.rsId] = po;
+        }
+        if (m.req) {
+            RangePair child;
+            const bool ok = extendOne(ix, m.reqMode, m.reqParent, m.reqCode, child);
+            m.req = false;
+            m.resume(ok, child);
+        }
+    }
+    const uint32_t local[4] = {m.cNode, m.cExp, m.cImm, m.cStart};
+    const int which[4] = {0, 7, 5, 6};
+    flushCounters(q, local, which, 4);
+    if (m.flags) atomicOr(&q.cnt[3], m.flags);
+}
+
+// ------------------------------------------------------------------ approximate DFS over the scheme
+// One lane per DfsTask (a search whose exact start range is still wider than the switch point).
 __global__ void __launch_bounds__(256)
-k_search(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* __restrict__ offs, uint32_t nReads,
-         uint32_t k, uint32_t maxLen, uint32_t gw, const uint8_t* __restrict__ seq, const uint32_t* __restrict__ G,
-         Scratch* __restrict__ slabs, Queues q) {
+k_dfs(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* __restrict__ offs, uint32_t k,
+      uint32_t maxLen, uint32_t gw, const uint8_t* __restrict__ seq, const uint32_t* __restrict__ G,
+      const PartOut* __restrict__ parts, const DfsTask* __restrict__ tasks, uint32_t nTasks,
+      Scratch* __restrict__ slabs, Queues q) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     Scratch& S = slabs[slot];
     Ctx c(ix, *stp, S, q);
     c.k = k;
     c.gw = gw;
-    const uint32_t total = 2 * nReads;
     for (;;) {
-        const uint32_t rs = atomicAdd(&q.cnt[4], 1u);
-        if (rs >= total) break;
-        const uint32_t r = rs >> 1;
+        const uint32_t t = atomicAdd(&q.cnt[6], 1u);
+        if (t >= nTasks) break;
+        const DfsTask task = tasks[t];
+        const uint32_t rs = task.rsId;
         c.rsId = rs;
-        c.len = (uint32_t)(offs[r + 1] - offs[r]);
+        c.len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
         c.seq = seq + (size_t)rs * maxLen;
         c.G = G + (size_t)rs * 8 * gw;
-        matchStrand(c);
+        const PartOut po = parts[rs];
+#pragma unroll
+        for (int i = 0; i < MAXP; i++) {
+            S.pb[i] = po.pb[i];
+            S.pe[i] = po.pe[i];
+        }
+        const DevSearch& s = stp->sch[task.scheme].s[task.search];
+        if (stp->metric == 1) {
+            OccTmp sm;
+            sm.r = task.r;
+            sm.dist = 0;
+            sm.depth = task.depth;
+            sm.shift = 0;
+            sm.valid = true;
+            EditSearch es(c, s);
+            es.run(sm, task.idx);
+        } else {
+            HammingSearch hs(c, s);
+            hs.run(task.r, task.depth, task.idx);
+        }
     }
-    const uint32_t local[5] = {c.cNode, c.cExp, c.cImm, c.cStart, c.cRows};
-    const int which[5] = {0, 7, 5, 6, 11};
-    flushCounters(q, local, which, 5);
+    const uint32_t local[3] = {c.cNode, c.cExp, c.cRows};
+    const int which[3] = {0, 7, 11};
+    flushCounters(q, local, which, 3);
     if (c.flags) atomicOr(&q.cnt[3], c.flags);
 }
 

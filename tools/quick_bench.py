@@ -8,20 +8,21 @@ from columba_amd import indexbuild as ib, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
 nreads = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000
 t = time.time()
-g, starts = synth.genome_rep(seed=11, n=n, scale=1.0)
+g, starts = synth.genome_human_like(n, seed=2025, device="cuda")
 print("genome", round(time.time() - t, 2)); t = time.time()
-ix = ib.build_index(g.tobytes(), seq_starts=starts, device="cuda")
+ix = ib.build_index(g, seq_starts=starts, device="cuda", with_bwt=False)
 print("index build", round(time.time() - t, 2), "s;", ix.nbytes() / 1e6, "MB"); t = time.time()
 dev = ca.Index(ix)
 print("upload+kmer", round(time.time() - t, 2)); t = time.time()
-reads = synth.sample_reads(g, nreads, 150, seed=3)
+buf, offs = synth.sample_reads_fast(ix.text[:-1], nreads, 150, seed=3, device="cuda")
+reads = None
 print("reads", round(time.time() - t, 2))
-for spec, metric, k in (("multiple_opt", "edit", 4), ("kuch1", "hamming", 2), ("kuch1", "edit", 0)):
+for spec, metric, k in (("multiple_opt", "edit", 4), ("kuch1", "edit", 0)):
     st = ca.SearchStrategy(spec, metric, "dynamic")
-    b = ca.Batch(dev, st, k, reads)
+    b = ca.Batch(dev, st, k, packed=(buf, offs))
     for it in range(2):
         t = time.time(); b.run(); dt = time.time() - t
-    occ, offs, cnt = b.results()
+    occ, occ_offs, cnt = b.results()
     print(spec, metric, k, "reads/s", round(nreads / dt), "wall", round(dt, 3), "occ", len(occ))
     print("  timings", {k_: round(v, 2) for k_, v in b.timings().items()})
     print("  counters", cnt)
