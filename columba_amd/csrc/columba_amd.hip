@@ -88,7 +88,9 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         ix->saBv.upload(desc->sa_bv, saW);
         ix->saCnt.upload(desc->sa_bv_counts, (saW + 7) / 4);
         ix->saSamples.upload(desc->sa_samples, desc->n_samples);
-        ix->text.upload(desc->text, n);
+        ix->text.alloc(n + 64); // padded: k_verify reads aligned 16-byte chunks one chunk ahead
+        HIPCHK(hipMemset(ix->text.p, 0, n + 64));
+        HIPCHK(hipMemcpy(ix->text.p, desc->text, n, hipMemcpyHostToDevice));
         ix->kmer.alloc(1ull << (2 * desc->kmer_size));
         if (desc->seq_starts) ix->seqStarts.assign(desc->seq_starts, desc->seq_starts + desc->n_seqs);
         DevIndex& d = ix->d;
@@ -237,13 +239,14 @@ struct cmb_batch {
     DevBuf<Scratch> slabs;
     DevBuf<PartOut> parts;
     DevBuf<DfsTask> dfs;
-    DevBuf<VScratch> vslabs;
+    DevBuf<uint64_t> vHP, vD0;
+    DevBuf<uint4> tbq;
     DevBuf<uint4> items;
     DevBuf<FMOccRec> fm, fmUniq;
     DevBuf<TextOccRec> text;
     DevBuf<uint32_t> cnt;
     DevBuf<unsigned long long> counters;
-    uint32_t nSlots = 0, nVSlots = 0;
+    uint32_t nSlots = 0;
     std::vector<uint64_t> hostOffs;
     // results
     std::vector<cmb_occ> occs;
@@ -377,8 +380,13 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
 
         HIPCHK(hipMemsetAsync(b->counters.p, 0, CMB_CNT_MAX * sizeof(unsigned long long), s));
         tm.begin();
-        hipLaunchKernelGGL(k_prep, dim3((tasks + 255) / 256), dim3(256), 0, s, b->reads.p, b->offs.p, nReads,
-                           b->maxLen, b->gw, b->seq.p, b->G.p);
+        {
+            HIPCHK(hipMemsetAsync(b->G.p, 0, b->G.bytes(), s));
+            const uint32_t chunks = (b->maxLen + 31) / 32;
+            const uint64_t nthr = (uint64_t)nReads * chunks;
+            hipLaunchKernelGGL(k_prep, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, b->reads.p, b->offs.p,
+                               nReads, b->maxLen, b->gw, chunks, b->seq.p, b->G.p);
+        }
         tm.end("k_prep");
 
         // ---- prologue + DFS (re-run with larger queues if they overflow: nothing is truncated)
@@ -464,24 +472,38 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
         if (!fm.empty()) b->fmUniq.upload(fm.data(), fm.size());
 
         // ---- locate + verify; text queue retried on overflow
-        if (b->vslabs.n == 0) {
-            b->nVSlots = std::min<uint32_t>(std::max<uint32_t>(((nItems + 255) / 256) * 256, 256u), 256u * 1024u);
-            b->vslabs.alloc(b->nVSlots);
-        }
+        if (b->tbq.n < nItems) b->tbq.alloc((size_t)nItems + nItems / 8 + 256);
         uint32_t textFromVerify = 0;
         for (int attempt = 0;; attempt++) {
             q.text = b->text.p;
             q.textCap = (uint32_t)std::min<size_t>(b->text.n, 0xFFFFFFF0u);
             uint32_t zero[2] = {0, 0};
             HIPCHK(hipMemcpyAsync(b->cnt.p + 2, zero, sizeof(zero), hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(b->cnt.p + 7, zero, sizeof(uint32_t), hipMemcpyHostToDevice, s));
             unsigned long long keep[CMB_CNT_MAX];
             HIPCHK(hipMemcpyAsync(keep, b->counters.p, sizeof(keep), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             if (nItems) {
+                const uint32_t vSlots = std::min<uint32_t>(((nItems + 255) / 256) * 256, 256u * 2048u);
                 tm.begin();
-                hipLaunchKernelGGL(k_verify, dim3(b->nVSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->maxLen,
-                                   b->gw, b->seq.p, b->G.p, b->items.p, nItems, b->vslabs.p, q);
+                hipLaunchKernelGGL(k_verify, dim3(vSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->maxLen, b->gw,
+                                   b->seq.p, b->G.p, b->items.p, nItems, b->tbq.p, q);
                 tm.end("k_verify");
+                HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                const uint32_t nTb = hcnt[7];
+                if (nTb) {
+                    const uint32_t tSlots = std::min<uint32_t>(((nTb + 255) / 256) * 256, 256u * 1024u);
+                    if (b->vHP.n < (size_t)VROWS * tSlots) {
+                        b->vHP.alloc((size_t)VROWS * tSlots);
+                        b->vD0.alloc((size_t)VROWS * tSlots);
+                    }
+                    VPlanes vp{b->vHP.p, b->vD0.p, tSlots};
+                    tm.begin();
+                    hipLaunchKernelGGL(k_traceback, dim3(tSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->gw,
+                                       b->G.p, b->tbq.p, nTb, vp, q);
+                    tm.end("k_traceback");
+                }
             }
             HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
@@ -499,6 +521,10 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                 if (attempt >= 3) return fail(CMB_ERR_INTERNAL, "text occurrence queue keeps overflowing");
                 b->text.alloc((size_t)hcnt[2] + hcnt[2] / 8 + 1024);
                 HIPCHK(hipMemcpy(b->counters.p, keep, sizeof(keep), hipMemcpyHostToDevice));
+                uint32_t z = 0; // clear the overflow flag for the retry
+                uint32_t fl = hcnt[3] & ~(uint32_t)FLAG_TEXT_OVERFLOW;
+                (void)z;
+                HIPCHK(hipMemcpy(b->cnt.p + 3, &fl, sizeof(uint32_t), hipMemcpyHostToDevice));
                 continue;
             }
             break;
@@ -748,7 +774,8 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         DevBuf<uint32_t> G, cnt;
         DevBuf<uint4> items;
         DevBuf<TextOccRec> text;
-        DevBuf<VScratch> vs;
+        DevBuf<uint64_t> vHP, vD0;
+        DevBuf<uint4> tbq;
         DevBuf<unsigned long long> ctr;
         const uint64_t ho[2] = {0, plen};
         reads.upload((const uint8_t*)pattern, plen);
@@ -767,18 +794,28 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         HIPCHK(hipMemset(cnt.p, 0, 32));
         HIPCHK(hipMemset(ctr.p, 0, CMB_CNT_MAX * 8));
         const uint32_t slots = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(((n + 255) / 256) * 256, 256), 65536);
-        vs.alloc(slots);
+        vHP.alloc((size_t)VROWS * slots);
+        vD0.alloc((size_t)VROWS * slots);
+        tbq.alloc(n + 1);
+        VPlanes vp{vHP.p, vD0.p, slots};
         Queues q{};
         q.text = text.p;
         q.textCap = (uint32_t)cap;
         q.cnt = cnt.p;
         q.counters = ctr.p;
-        hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, 0, reads.p, offs.p, 1u, plen, gw, seq.p, G.p);
-        if (n)
-            hipLaunchKernelGGL(k_verify, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, plen, gw, seq.p, G.p,
-                               items.p, (uint32_t)n, vs.p, q);
-        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemset(G.p, 0, G.bytes()));
+        hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, 0, reads.p, offs.p, 1u, plen, gw, (plen + 31) / 32, seq.p,
+                           G.p);
         uint32_t hc[8];
+        if (n) {
+            hipLaunchKernelGGL(k_verify, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, plen, gw, seq.p, G.p,
+                               items.p, (uint32_t)n, tbq.p, q);
+            HIPCHK(hipMemcpy(hc, cnt.p, 32, hipMemcpyDeviceToHost));
+            if (hc[7])
+                hipLaunchKernelGGL(k_traceback, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, gw, G.p, tbq.p,
+                                   hc[7], vp, q);
+        }
+        HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy(hc, cnt.p, 32, hipMemcpyDeviceToHost));
         if (hc[3] & FLAG_TEXT_OVERFLOW) return fail(CMB_ERR_INTERNAL, "verification output overflow");
         *n_out = hc[2];

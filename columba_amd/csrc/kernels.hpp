@@ -71,30 +71,42 @@ __global__ void k_kmer_table(DevIndex ix, uint4* __restrict__ table) {
 }
 
 // ------------------------------------------------------------------ read preparation
-// one thread per read x strand
-__global__ void k_prep(const uint8_t* __restrict__ reads, const uint64_t* __restrict__ offs, uint32_t nReads,
-                       uint32_t maxLen, uint32_t gw, uint8_t* __restrict__ seq, uint32_t* __restrict__ G) {
-    const uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rs >= 2 * nReads) return;
-    const uint32_t r = rs >> 1;
-    const bool rc = rs & 1u;
+// One thread per (read, 32-character chunk): writes the codes of both strands and the chunk's word of
+// the eight match bit-strings of both strands (forward / reversed read x A,C,G,T).  G must be zeroed
+// beforehand (padding words stay zero).  Both strands need the same two byte runs of the read:
+//   A = read[32w .. 32w+32)   and   B = read[L-1-32w-t], t = 0..31
+__global__ void __launch_bounds__(256)
+k_prep(const uint8_t* __restrict__ reads, const uint64_t* __restrict__ offs, uint32_t nReads, uint32_t maxLen,
+       uint32_t gw, uint32_t chunks, uint8_t* __restrict__ seq, uint32_t* __restrict__ G) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = gid / chunks, w = gid % chunks;
+    if (r >= nReads) return;
     const uint8_t* rd = reads + offs[r];
     const uint32_t len = (uint32_t)(offs[r + 1] - offs[r]);
-    uint8_t* s = seq + (size_t)rs * maxLen;
-    uint32_t* g = G + (size_t)rs * 8 * gw;
-    for (uint32_t w = 0; w < 8 * gw; w++) g[w] = 0;
-    if (len > maxLen) return;
-    for (uint32_t i = 0; i < len; i++) {
-        uint8_t ch = rc ? rd[len - 1 - i] : rd[i];
-        ch &= 0xDF;
-        uint32_t code = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'T' ? 4 : 5;
-        if (rc && code <= 4) code = 5 - code;
-        s[i] = (uint8_t)code;
-        if (code <= 4) {
-            g[(code - 1) * gw + (i >> 5)] |= 1u << (i & 31);
-            const uint32_t ri = len - 1 - i;
-            g[(4 + code - 1) * gw + (ri >> 5)] |= 1u << (ri & 31);
-        }
+    if (len > maxLen || 32 * w >= len) return;
+    uint32_t fA[4] = {0, 0, 0, 0}, fB[4] = {0, 0, 0, 0}; // bit t set: A[t] / B[t] is that nucleotide
+    uint8_t* sF = seq + (size_t)(2 * r) * maxLen;
+    uint8_t* sR = seq + (size_t)(2 * r + 1) * maxLen;
+    const uint32_t nT = min(32u, len - 32 * w);
+    for (uint32_t t = 0; t < nT; t++) {
+        const uint32_t i = 32 * w + t;
+        // reads.h:43-58 (upper-case, non-ACGT -> N); nucleotide.h:250 (reverse complement keeps N)
+        const uint8_t a = rd[i] & 0xDF, bch = rd[len - 1 - i] & 0xDF;
+        const uint32_t ca = a == 'A' ? 1 : a == 'C' ? 2 : a == 'G' ? 3 : a == 'T' ? 4 : 5;
+        const uint32_t cb = bch == 'A' ? 1 : bch == 'C' ? 2 : bch == 'G' ? 3 : bch == 'T' ? 4 : 5;
+        sF[i] = (uint8_t)ca;
+        sR[i] = (uint8_t)(cb <= 4 ? 5 - cb : 5);
+        if (ca <= 4) fA[ca - 1] |= 1u << t;
+        if (cb <= 4) fB[cb - 1] |= 1u << t;
+    }
+    uint32_t* gF = G + (size_t)(2 * r) * 8 * gw;     // forward strand: [0..3] fwd bits, [4..7] reversed-read bits
+    uint32_t* gR = G + (size_t)(2 * r + 1) * 8 * gw; // reverse-complement strand
+#pragma unroll
+    for (int ch = 0; ch < 4; ch++) {
+        gF[ch * gw + w] = fA[ch];             // strand F, position i      : read[i]
+        gF[(4 + ch) * gw + w] = fB[ch];       // strand F reversed, pos ri : read[L-1-ri]
+        gR[ch * gw + w] = fB[3 - ch];         // strand R, position i      : comp(read[L-1-i])
+        gR[(4 + ch) * gw + w] = fA[3 - ch];   // strand R reversed, pos ri : comp(read[ri])
     }
 }
 
@@ -202,9 +214,14 @@ k_dfs(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* __restr
 
 // ------------------------------------------------------------------ locate + verification
 constexpr int VROWS = MAX_READ + 3 * 6 + 4;
-struct VScratch {
-    uint64_t HP[VROWS], HN[VROWS], D0[VROWS];
-    uint16_t score[VROWS];
+constexpr int VEMIT = 20; // max cluster centres of one candidate (size of the final column <= 3k+2)
+
+// Row storage of the traceback pass, interleaved by slot so that the lanes of a wavefront (which
+// walk rows in lock step) write whole 512-byte lines: element (row, slot) lives at [row * nSlots + slot].
+struct VPlanes {
+    uint64_t* HP;
+    uint64_t* D0;
+    uint32_t nSlots;
 };
 
 __device__ __forceinline__ void emitText(const Queues& q, uint32_t& flags, uint32_t rsId, uint32_t b, uint32_t e,
@@ -221,152 +238,343 @@ __device__ __forceinline__ uint32_t textCode(uint8_t ch) { // A,C,G,T -> 0..3; a
     return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
 }
 
-__global__ void __launch_bounds__(256)
-k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32_t gw,
-         const uint8_t* __restrict__ seq, const uint32_t* __restrict__ G, const uint4* __restrict__ items,
-         uint32_t nItems, VScratch* __restrict__ vslabs, Queues q) {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    VScratch& V = vslabs[slot];
-    uint32_t cLF = 0, cLoc = 0, cText = 0, cRows = 0, cAbort = 0, cCig = 0, cStarted = 0, flags = 0;
-    for (uint32_t it = slot; it < nItems; it += gridDim.x * blockDim.x) {
-        const uint4 item = items[it];
-        const uint32_t rs = item.x, row = item.y, a = item.z, meta = item.w;
-        const uint32_t kind = (meta >> 21) & 3u;
-        const uint32_t maxED = (meta >> 12) & 15u, minED = (meta >> 16) & 15u;
-        const uint32_t fixed = (meta >> 20) & 1u;
-        const uint32_t shift = meta & 0xFFFu;
-        const uint32_t len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
-        const uint8_t* s = seq + (size_t)rs * maxLen;
-        uint32_t pos;
-        if ((meta >> 23) & 1u) { // direct start position (cmb_verify_batch hook): nothing to locate
-            pos = row;
-        } else {
-            cLoc++;
-            pos = findSA(ix, row, &cLF);
-        }
-        if (kind == ITEM_EXACT) { // verifyInTextExact (indexinterface.cpp:918-943)
-            if (fixed) {
-                emitText(q, flags, rs, pos, pos + len, 0);
-                continue;
-            }
-            cStarted++;
-            const uint32_t remaining = a;
-            bool ok = pos >= remaining;
-            const uint32_t p0 = pos - remaining;
-            for (uint32_t j = 0; ok && j < remaining; j++) {
-                cText++;
-                if (textCode(ix.text[p0 + j]) + 1u != s[j]) ok = false;
-            }
-            if (ok) emitText(q, flags, rs, p0, p0 + len, 0);
-            else cAbort++;
-            continue;
-        }
-        if (kind == ITEM_HAMMING) { // FMIndex::inTextVerificationHamming (fmindex.cpp:370-406)
-            cStarted++;
-            const uint32_t lengthBefore = a;
-            const uint32_t Tb = pos > lengthBefore ? pos - lengthBefore : 0;
-            const uint32_t Te = Tb + len;
-            if (Te > ix.n) continue;
-            uint32_t score = 0;
-            for (uint32_t j = 0; j < len; j++) {
-                cText++;
-                const uint32_t code = textCode(ix.text[Tb + j]) + 1u; // '$' -> 5 never equals a read code... 
-                score += (code != s[j] || code > 4u);
-                if (score > maxED) break;
-            }
-            if (score <= maxED && score >= minED) emitText(q, flags, rs, Tb, Te, score);
-            continue;
-        }
-        // ---- edit distance: FMIndex::inTextVerification + InTextVerificationTask::doTask
-        cStarted++;
-        const uint32_t startDiff = a;
-        const uint32_t sum = pos + shift; // getBeginPositions (fmindex.h:374-379)
-        const uint32_t start = sum >= startDiff ? sum - startDiff : 0;
-        const uint32_t nZeros = fixed ? 1u : 2u * maxED + 1u;
-        MatGeom g;
-        g.n = len + 1;
-        g.maxED = maxED;
-        g.Wv = nZeros - 1 + maxED;
-        g.Wh = maxED;
-        g.m = g.Wv + g.n;
-        uint64_t HP = (~0ull) << MX_LEFT, HN = ~HP, D0 = 0, RAC = 1ull << (MX_DIAG + g.Wh);
-        for (uint32_t i = 1; i < nZeros; i++) HN ^= 1ull << (MX_LEFT - i);
-        uint32_t score = 0;
-        V.HP[0] = HP;
-        V.HN[0] = HN;
-        V.score[0] = 0;
-        const uint32_t maxEnd = ix.n - 1;
-        const uint32_t hEnd = min(maxEnd, start + g.m - 1);
-        const uint32_t size = hEnd > start ? hEnd - start : 0;
-        if (!g.inFinalColumn(size)) continue;
-        const uint32_t* Gf = G + (size_t)rs * 8 * gw;
-        uint32_t i;
-        uint64_t Mblk[4];
-        for (i = 0; i < size; ++i) {
+// wave-wide exclusive prefix sum (all 64 lanes must call)
+__device__ __forceinline__ uint32_t waveExclusiveScan(uint32_t v, uint32_t& total) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if ((int)lane >= d) x += y;
+    }
+    total = __shfl(x, 63);
+    return x - v;
+}
+// one atomic per wavefront: returns this lane's slot for `n` (0 or 1) records in a queue
+__device__ __forceinline__ uint32_t waveAppend(uint32_t* counter, uint32_t n, uint32_t& total) {
+    const uint32_t off = waveExclusiveScan(n, total);
+    uint32_t base = 0;
+    if (total) {
+        if ((threadIdx.x & 63u) == 0) base = atomicAdd(counter, total);
+        base = __shfl(base, 0);
+    }
+    return base + off;
+}
+
+__device__ __forceinline__ uint4 loadText16(const uint8_t* text, uint32_t chunk) {
+    return reinterpret_cast<const uint4*>(text)[chunk];
+}
+
+// forward pass of the banded matrix of one candidate over the text window [start, start+size).
+// STORE = false: verification pass (k_verify) — nothing is stored, cluster centres of the final column
+//   are detected on the fly (bitparallelmatrix.h:591-614 needs only ED(i-1), ED(i), ED(i+1)).
+// STORE = true : traceback pass (k_traceback) — HP and D0 of every row go to the interleaved planes.
+// Returns the number of valid rows `i` (indexhelpers.cpp:535-539); centreMask bit t <=> row firstRow+1+t.
+template <bool STORE>
+__device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const uint32_t* Gf, uint32_t gw, uint32_t len,
+                                                const MatGeom& g, uint32_t nZeros, uint32_t start, uint32_t size,
+                                                uint32_t maxED, uint32_t minED, uint32_t& centreMask,
+                                                uint64_t& edPack, uint64_t& edPackHi, const VPlanes& V, uint32_t slot,
+                                                uint32_t& cRows) {
+    uint64_t HP = (~0ull) << MX_LEFT, HN = ~HP, D0 = 0, RAC = 1ull << (MX_DIAG + g.Wh);
+    for (uint32_t i = 1; i < nZeros; i++) HN ^= 1ull << (MX_LEFT - i);
+    uint32_t score = 0;
+    const uint32_t sfc = g.sfc();
+    const uint32_t firstRow = (g.m - 1) - sfc;
+    const uint32_t col = g.n - 1;
+    // sliding window of final-column values: edPrev = ED(r-1), edCur = ED(r) once r >= firstRow
+    uint32_t edPrev2 = 0, edPrev = 0;
+    if (!STORE && firstRow == 0) edPrev = cellAt(0, col, HP, HN, score);
+    centreMask = 0;
+    edPack = 0; // 3 bits per final-column row above firstRow: min(ED, 7); rows 21.. go to edPackHi
+    edPackHi = 0;
+    uint32_t i = 0;
+    uint64_t Mblk[4];
+    uint32_t chunk = start >> 4;
+    uint4 cur = loadText16(ix.text, chunk);
+    uint4 nxt = loadText16(ix.text, chunk + 1); // the text allocation is padded
+    bool valid = true;
+    while (i < size && valid) {
+        const uint32_t p = start + i;
+        const uint32_t inChunk = p & 15u;
+        const uint32_t take = min(16u - inChunk, size - i);
+        for (uint32_t t = 0; t < take; t++) {
+            const uint32_t bi = inChunk + t;
+            const uint32_t wsel = bi >> 2;
+            const uint32_t wv = wsel == 0 ? cur.x : wsel == 1 ? cur.y : wsel == 2 ? cur.z : cur.w;
+            const uint32_t tc = textCode((uint8_t)(wv >> (8 * (bi & 3u))));
             const uint32_t r = i + 1;
             if ((r % MX_BLOCK) == 0 || i == 0) {
                 const uint32_t b = r / MX_BLOCK;
 #pragma unroll
                 for (int ch = 0; ch < 4; ch++) Mblk[ch] = matchWord(Gf + ch * gw, 0, len, b);
             }
-            const uint32_t tc = textCode(ix.text[start + i]);
             const uint64_t M = tc == 0 ? Mblk[0] : tc == 1 ? Mblk[1] : tc == 2 ? Mblk[2] : tc == 3 ? Mblk[3] : 0ull;
-            cText++;
             cRows++;
-            const bool valid = computeRow(g, r, M, HP, HN, D0, RAC, score);
-            V.HP[r] = HP;
-            V.HN[r] = HN;
-            V.D0[r] = D0;
-            V.score[r] = (uint16_t)score;
+            valid = computeRow(g, r, M, HP, HN, D0, RAC, score);
+            if (STORE) {
+                const size_t o = (size_t)r * V.nSlots + slot;
+                V.HP[o] = HP;
+                V.D0[o] = D0;
+            }
             if (!valid) break;
+            if (STORE && r > firstRow) {
+                const uint32_t ed = cellAt(r, col, HP, HN, score);
+                const uint32_t bi = r - firstRow - 1u;
+                if (bi < 21u) edPack |= (uint64_t)min(ed, 7u) << (3u * bi);
+                else edPackHi |= (uint64_t)min(ed, 7u) << (3u * (bi - 21u));
+            }
+            if (!STORE && r >= firstRow) {
+                const uint32_t ed = cellAt(r, col, HP, HN, score);
+                // row r-1 can now be judged (its `below` neighbour is known)
+                if (r - 1 > firstRow) {
+                    const uint32_t e1 = edPrev;
+                    if (e1 <= maxED && e1 >= minED && e1 <= edPrev2 && e1 <= ed) centreMask |= 1u << (r - 2 - firstRow);
+                }
+                edPrev2 = edPrev;
+                edPrev = ed;
+            }
+            i++;
         }
-        const uint32_t sfc = g.sfc();
-        if (i <= size - sfc) { // u32 arithmetic as in the reference (indexhelpers.cpp:542)
-            cAbort++;
-            continue;
-        }
-        // findClusterCenters (bitparallelmatrix.h:591-614)
-        const uint32_t lastRow = i;
-        const uint32_t firstRow = (g.m - 1) - sfc;
-        const uint32_t col = g.n - 1;
-        uint32_t nCenters = 0;
-        for (uint32_t ri = lastRow; ri > firstRow; ri--) {
-            const uint32_t ED = cellAt(ri, col, V.HP[ri], V.HN[ri], V.score[ri]);
-            if (ED > maxED || ED < minED) continue;
-            const bool above = (ri == firstRow) || ED <= cellAt(ri - 1, col, V.HP[ri - 1], V.HN[ri - 1], V.score[ri - 1]);
-            const bool below = (ri == lastRow) || ED <= cellAt(ri + 1, col, V.HP[ri + 1], V.HN[ri + 1], V.score[ri + 1]);
-            if (!(above && below)) continue;
-            nCenters++;
-            // traceBack (bitparallelmatrix.h:531-586): only the begin offset is needed here
-            uint32_t ti = ri, tj = col;
-            while (tj > 0) {
-                const uint32_t b = ti / MX_BLOCK;
-                const uint64_t bit = 1ull << ((tj - b * MX_BLOCK) + MX_DIAG);
-                if (V.HP[ti] & bit) {
-                    --tj;
+        chunk++;
+        cur = nxt;
+        nxt = loadText16(ix.text, chunk + 1);
+    }
+    if (!STORE && i > firstRow) { // the last valid row has no `below` neighbour (i == lastRow)
+        const uint32_t e1 = edPrev;
+        if (e1 <= maxED && e1 >= minED && e1 <= edPrev2) centreMask |= 1u << (i - 1 - firstRow);
+    }
+    return i;
+}
+
+// pass 1: locate + verify.  Exact / Hamming candidates produce text occurrences directly; edit-distance
+// candidates whose final column holds cluster centres become traceback tasks {rs, start, mask, meta}.
+__global__ void __launch_bounds__(256)
+k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32_t gw,
+         const uint8_t* __restrict__ seq, const uint32_t* __restrict__ G, const uint4* __restrict__ items,
+         uint32_t nItems, uint4* __restrict__ tbq, Queues q) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cLF = 0, cLoc = 0, cText = 0, cRows = 0, cAbort = 0, cCig = 0, cStarted = 0, flags = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t waveBase = slot & ~63u;
+    const VPlanes noPlanes{nullptr, nullptr, 0};
+    for (uint32_t base = waveBase; base < nItems; base += stride) { // wave-uniform trip count
+        const uint32_t it = base + (threadIdx.x & 63u);
+        uint32_t nOut = 0, nTb = 0;
+        uint4 outRec = make_uint4(0, 0, 0, 0), tbRec = make_uint4(0, 0, 0, 0);
+        uint32_t rs = 0;
+        if (it < nItems) {
+            const uint4 item = items[it];
+            rs = item.x;
+            const uint32_t row = item.y, a = item.z, meta = item.w;
+            const uint32_t kind = (meta >> 21) & 3u;
+            const uint32_t maxED = (meta >> 12) & 15u, minED = (meta >> 16) & 15u;
+            const uint32_t fixed = (meta >> 20) & 1u;
+            const uint32_t shift = meta & 0xFFFu;
+            const uint32_t len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
+            const uint8_t* s = seq + (size_t)rs * maxLen;
+            uint32_t pos;
+            if ((meta >> 23) & 1u) { // direct start position (cmb_verify_batch hook): nothing to locate
+                pos = row;
+            } else {
+                cLoc++;
+                pos = findSA(ix, row, &cLF);
+            }
+            if (kind == ITEM_EXACT) { // verifyInTextExact (indexinterface.cpp:918-943)
+                if (fixed) {
+                    outRec = make_uint4(pos, pos + len, 0, 0);
+                    nOut = 1;
                 } else {
-                    bool diag = false;
-                    if (ti > 0) {
-                        const uint32_t tc = textCode(ix.text[start + ti - 1]);
-                        const uint64_t M = tc < 4 ? matchWord(Gf + tc * gw, 0, len, b) : 0ull;
-                        diag = ((M | ~V.D0[ti]) & bit) != 0;
+                    cStarted++;
+                    const uint32_t remaining = a;
+                    bool ok = pos >= remaining;
+                    const uint32_t p0 = pos - remaining;
+                    for (uint32_t j = 0; ok && j < remaining; j++) {
+                        cText++;
+                        if (textCode(ix.text[p0 + j]) + 1u != s[j]) ok = false;
                     }
-                    if (diag) {
-                        --ti;
-                        --tj;
+                    if (ok) {
+                        outRec = make_uint4(p0, p0 + len, 0, 0);
+                        nOut = 1;
                     } else {
-                        --ti;
+                        cAbort++;
+                    }
+                }
+            } else if (kind == ITEM_HAMMING) { // FMIndex::inTextVerificationHamming (fmindex.cpp:370-406)
+                cStarted++;
+                const uint32_t lengthBefore = a;
+                const uint32_t Tb = pos > lengthBefore ? pos - lengthBefore : 0;
+                const uint32_t Te = Tb + len;
+                if (Te <= ix.n) {
+                    uint32_t score = 0;
+                    for (uint32_t j = 0; j < len; j++) {
+                        cText++;
+                        const uint32_t code = textCode(ix.text[Tb + j]) + 1u; // '$' -> 5: never equal
+                        score += (code != s[j] || code > 4u);
+                        if (score > maxED) break;
+                    }
+                    if (score <= maxED && score >= minED) {
+                        outRec = make_uint4(Tb, Te, score, 0);
+                        nOut = 1;
+                    }
+                }
+            } else {
+                // ---- edit distance: FMIndex::inTextVerification + InTextVerificationTask::doTask
+                cStarted++;
+                const uint32_t startDiff = a;
+                const uint32_t sum = pos + shift; // getBeginPositions (fmindex.h:374-379)
+                const uint32_t start = sum >= startDiff ? sum - startDiff : 0;
+                const uint32_t nZeros = fixed ? 1u : 2u * maxED + 1u;
+                MatGeom g;
+                g.n = len + 1;
+                g.maxED = maxED;
+                g.Wv = nZeros - 1 + maxED;
+                g.Wh = maxED;
+                g.m = g.Wv + g.n;
+                const uint32_t maxEnd = ix.n - 1;
+                const uint32_t hEnd = min(maxEnd, start + g.m - 1);
+                const uint32_t size = hEnd > start ? hEnd - start : 0;
+                if (g.inFinalColumn(size)) {
+                    uint32_t mask = 0, rows = 0;
+                    uint64_t edPack, edPackHi;
+                    const uint32_t i = forwardPass<false>(ix, G + (size_t)rs * 8 * gw, gw, len, g, nZeros, start, size,
+                                                          maxED, minED, mask, edPack, edPackHi, noPlanes, 0, rows);
+                    cRows += rows;
+                    cText += rows;
+                    if (i <= size - g.sfc() || mask == 0) { // indexhelpers.cpp:542, :550
+                        cAbort++;
+                    } else {
+                        cCig += __popc(mask);
+                        tbRec = make_uint4(rs, start, mask, maxED | (fixed << 4));
+                        nTb = 1;
                     }
                 }
             }
-            cCig++;
-            emitText(q, flags, rs, start + ti, start + ri, ED);
         }
-        if (nCenters == 0) cAbort++;
+        // ---- wave-aggregated appends (one atomic per wavefront and queue)
+        uint32_t total;
+        const uint32_t o1 = waveAppend(&q.cnt[2], nOut, total);
+        if (nOut) {
+            if (o1 >= q.textCap) flags |= FLAG_TEXT_OVERFLOW;
+            else q.text[o1] = TextOccRec{rs, outRec.x, outRec.y, outRec.z};
+        }
+        const uint32_t o2 = waveAppend(&q.cnt[7], nTb, total);
+        if (nTb) tbq[o2] = tbRec; // capacity = nItems: cannot overflow
     }
     const uint32_t local[7] = {cLF, cLoc, cText, cRows, cAbort, cCig, cStarted};
     const int which[7] = {8, 9, 10, 11, 3, 4, 2};
     flushCounters(q, local, which, 7);
+    if (flags) atomicOr(&q.cnt[3], flags);
+}
+
+// pass 2: traceback of the candidates that hold cluster centres (about a third of them): the rows are
+// recomputed, this time keeping HP and D0, and every centre is traced back to its begin row
+// (bitparallelmatrix.h:531-586).  The traceback reads rows through an 8-row window staged in LDS, so
+// the dependent chain costs one memory round trip per 8 rows instead of three per row.
+constexpr int TBW = 8;
+__global__ void __launch_bounds__(256)
+k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const uint32_t* __restrict__ G,
+            const uint4* __restrict__ tbq, uint32_t nTasks, VPlanes V, Queues q) {
+    __shared__ uint64_t wHP[TBW][256];
+    __shared__ uint64_t wD0[TBW][256];
+    __shared__ uint8_t wT[TBW][256];
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t NS = V.nSlots;
+    uint32_t flags = 0, dummyRows = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t waveBase = slot & ~63u;
+    const uint64_t HP0 = (~0ull) << MX_LEFT;
+    for (uint32_t base = waveBase; base < nTasks; base += stride) { // wave-uniform trip count
+        const uint32_t it = base + (tid & 63u);
+        uint32_t rs = 0, start = 0, m = 0, firstRow = 0, len = 0, col = 0;
+        uint64_t edPack = 0, edPackHi = 0;
+        const uint32_t* Gf = G;
+        if (it < nTasks) {
+            const uint4 t = tbq[it];
+            rs = t.x;
+            start = t.y;
+            m = t.z;
+            const uint32_t maxED = t.w & 15u, fixed = (t.w >> 4) & 1u;
+            len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
+            const uint32_t nZeros = fixed ? 1u : 2u * maxED + 1u;
+            MatGeom g;
+            g.n = len + 1;
+            g.maxED = maxED;
+            g.Wv = nZeros - 1 + maxED;
+            g.Wh = maxED;
+            g.m = g.Wv + g.n;
+            firstRow = (g.m - 1) - g.sfc();
+            col = g.n - 1;
+            const uint32_t topCentre = firstRow + 1 + (31u - (uint32_t)__clz(m));
+            Gf = G + (size_t)rs * 8 * gw;
+            uint32_t dummyMask;
+            // rows 1..topCentre (all valid: they were valid in pass 1)
+            forwardPass<true>(ix, Gf, gw, len, g, nZeros, start, topCentre, maxED, 0, dummyMask, edPack, edPackHi, V,
+                              slot, dummyRows);
+        }
+        // one centre per lane and round; the wavefront appends its results with one atomic per round
+        for (;;) {
+            const bool have = m != 0;
+            if (__ballot(have) == 0ull) break;
+            TextOccRec rec{0, 0, 0, 0};
+            if (have) {
+                const uint32_t bitIdx = 31u - (uint32_t)__clz(m);
+                m &= ~(1u << bitIdx);
+                const uint32_t ri = firstRow + 1 + bitIdx;
+                uint32_t ti = ri, tj = col;
+                uint32_t winTop = 0xFFFFFFFFu; // window slot w holds row winTop - w
+                uint32_t curB = 0xFFFFFFFFu;
+                uint64_t Mblk[4] = {0, 0, 0, 0};
+                while (tj > 0) {
+                    if (winTop == 0xFFFFFFFFu || ti + (TBW - 1) < winTop) {
+                        winTop = ti;
+#pragma unroll
+                        for (int w = 0; w < TBW; w++) {
+                            const uint32_t r = winTop >= (uint32_t)w ? winTop - w : 0u;
+                            const size_t o = (size_t)r * NS + slot;
+                            wHP[w][tid] = (r == 0) ? HP0 : V.HP[o];
+                            wD0[w][tid] = (r == 0) ? 0ull : V.D0[o];
+                            wT[w][tid] = (r == 0) ? (uint8_t)0 : ix.text[start + r - 1];
+                        }
+                    }
+                    const uint32_t ws = winTop - ti;
+                    const uint32_t b = ti / MX_BLOCK;
+                    const uint64_t bit = 1ull << ((tj - b * MX_BLOCK) + MX_DIAG);
+                    if (wHP[ws][tid] & bit) {
+                        --tj;
+                    } else {
+                        bool diag = false;
+                        if (ti > 0) {
+                            if (b != curB) { // match words of this 32-row block (bitparallelmatrix.h:559)
+                                curB = b;
+#pragma unroll
+                                for (int ch = 0; ch < 4; ch++) Mblk[ch] = matchWord(Gf + ch * gw, 0, len, b);
+                            }
+                            const uint32_t tc = textCode(wT[ws][tid]);
+                            const uint64_t M = tc == 0 ? Mblk[0] : tc == 1 ? Mblk[1] : tc == 2 ? Mblk[2] : tc == 3 ? Mblk[3] : 0ull;
+                            diag = ((M | ~wD0[ws][tid]) & bit) != 0;
+                        }
+                        if (diag) {
+                            --ti;
+                            --tj;
+                        } else {
+                            --ti;
+                        }
+                    }
+                }
+                const uint32_t ed = bitIdx < 21u ? (uint32_t)((edPack >> (3u * bitIdx)) & 7ull)
+                                                 : (uint32_t)((edPackHi >> (3u * (bitIdx - 21u))) & 7ull);
+                rec = TextOccRec{rs, start + ti, start + ri, ed};
+            }
+            uint32_t total;
+            const uint32_t o = waveAppend(&q.cnt[2], have ? 1u : 0u, total);
+            if (have) {
+                if (o >= q.textCap) flags |= FLAG_TEXT_OVERFLOW;
+                else q.text[o] = rec;
+            }
+        }
+    }
     if (flags) atomicOr(&q.cnt[3], flags);
 }
 
