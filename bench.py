@@ -171,10 +171,12 @@ def main():
         avg = {k: v / steps for k, v in kern.items()}
         dominant = max(avg, key=avg.get)
         # algorithmic bytes per launch:
-        #   k_search: 192 B per node expansion (2 positions x (64 B counts line + 32 B bit group))
+        #   k_partition / k_dfs: 192 B per node expansion (2 positions x (64 B counts line + 32 B bit group))
         #   k_verify: 112 B per LF step + 28 B per located row + 1 B per text character
-        alg = {"k_search": 192.0 * cnt["EXPANSIONS"],
-               "k_verify": 112.0 * cnt["LF_STEPS"] + 28.0 * cnt["LOCATED_ROWS"] + 1.0 * cnt["TEXT_BYTES"]}
+        alg = {"k_partition": 192.0 * (cnt["EXPANSIONS"] - cnt["DFS_EXPANSIONS"]),
+               "k_dfs": 192.0 * cnt["DFS_EXPANSIONS"],
+               "k_verify": 112.0 * cnt["LF_STEPS"] + 28.0 * cnt["LOCATED_ROWS"] + 1.0 * cnt["TEXT_BYTES"],
+               "k_traceback": 1.0 * cnt["TEXT_BYTES"]}
         achieved = alg.get(dominant, 0.0) / (avg[dominant] * 1e-3) / 1e9 if avg[dominant] > 0 else 0.0
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,

@@ -127,6 +127,7 @@ enum {
     CMB_CNT_LOCATED_ROWS,           /* R */
     CMB_CNT_TEXT_BYTES,             /* T */
     CMB_CNT_MATRIX_ROWS,
+    CMB_CNT_DFS_EXPANSIONS,         /* the part of E performed by the DFS kernel (rest: prologue kernel) */
     CMB_CNT_MAX
 };
 
