@@ -244,6 +244,10 @@ struct cmb_batch {
     DevBuf<uint4> items;
     DevBuf<FMOccRec> fm, fmUniq;
     DevBuf<TextOccRec> text;
+    DevBuf<uint4> fout;
+    DevBuf<unsigned long long> keysA, keysB;
+    DevBuf<uint32_t> fcounts, foffs;
+    DevBuf<uint8_t> sortTmp, scanTmp;
     DevBuf<uint32_t> cnt;
     DevBuf<unsigned long long> counters;
     uint32_t nSlots = 0;
@@ -531,58 +535,60 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
         }
         const uint32_t nText = hcnt[2];
 
-        // ---- gather + filter on the host (getUniqueTextOccurrences / getTextOccHamming,
-        // indexinterface.cpp:1331-1491)
-        std::vector<TextOccRec> text(nText);
-        if (nText) HIPCHK(hipMemcpy(text.data(), b->text.p, nText * sizeof(TextOccRec), hipMemcpyDeviceToHost));
+        // ---- sort + filter on the device (getUniqueTextOccurrences / getTextOccHamming,
+        // indexinterface.cpp:1331-1491): pack -> one 64-bit radix sort -> per-read scan
         unsigned long long hc[CMB_CNT_MAX];
         HIPCHK(hipMemcpy(hc, b->counters.p, sizeof(hc), hipMemcpyDeviceToHost));
         for (int i = 0; i < CMB_CNT_MAX; i++) b->cnts[i] = hc[i];
-
-        std::vector<uint64_t> start(nReads + 1, 0);
-        for (const auto& t : text) start[(t.rsId >> 1) + 1]++;
-        for (uint32_t r = 0; r < nReads; r++) start[r + 1] += start[r];
-        std::vector<HostOcc> bucket(nText);
-        {
-            std::vector<uint64_t> fill(start.begin(), start.end() - 1);
-            for (const auto& t : text) bucket[fill[t.rsId >> 1]++] = HostOcc{t.begin, t.end, t.dist, t.rsId & 1u};
-        }
+        if (nReads >= (1u << 24)) return fail(CMB_ERR_UNSUPPORTED, "more than 2^24 reads in one batch");
         b->occs.clear();
         b->occOffs.assign(nReads + 1, 0);
-        const uint32_t maxED = b->k;
-        for (uint32_t r = 0; r < nReads; r++) {
-            HostOcc* lo = bucket.data() + start[r];
-            HostOcc* hi = bucket.data() + start[r + 1];
-            std::sort(lo, hi, occLess);
-            if (maxED == 0) { // searchstrategy.cpp:499-510: no de-duplication for exact matches
-                for (HostOcc* o = lo; o != hi; ++o) b->occs.push_back({o->begin, o->end, o->dist, o->strand});
-            } else {
-                // eraseDoublesAndSortText: equal = same range and distance (indexhelpers.h:811)
-                HostOcc* end = std::unique(lo, hi, [](const HostOcc& x, const HostOcc& y) {
-                    return x.begin == y.begin && x.end == y.end && x.dist == y.dist;
-                });
-                if (b->metric == CMB_METRIC_HAMMING) {
-                    for (HostOcc* o = lo; o != end; ++o) b->occs.push_back({o->begin, o->end, o->dist, o->strand});
-                } else { // redundancy filter (indexinterface.cpp:1447-1485)
-                    const uint32_t maxDiff = 2 * maxED;
-                    uint32_t prevBegin = 0xFFFFFFFFu, prevDepth = 0xFFFFFFFFu, prevED = maxED + 1;
-                    const size_t base = b->occs.size();
-                    for (HostOcc* o = lo; o != end; ++o) {
-                        const uint32_t diff = o->begin > prevBegin ? o->begin - prevBegin : prevBegin - o->begin;
-                        if (diff == 0) continue;
-                        const uint32_t width = o->end > o->begin ? o->end - o->begin : 0;
-                        if (diff <= maxDiff) {
-                            if (o->dist > prevED || (o->dist == prevED && width >= prevDepth)) continue;
-                            if (b->occs.size() > base) b->occs.pop_back();
-                        }
-                        prevBegin = o->begin;
-                        prevED = o->dist;
-                        prevDepth = width;
-                        b->occs.push_back({o->begin, o->end, o->dist, o->strand});
-                    }
-                }
+        {
+            tm.begin();
+            if (b->keysA.n < nText) {
+                b->keysA.alloc((size_t)nText + nText / 8 + 256);
+                b->keysB.alloc((size_t)nText + nText / 8 + 256);
             }
-            b->occOffs[r + 1] = b->occs.size();
+            if (b->fcounts.n < (size_t)nReads + 1) {
+                b->fcounts.alloc((size_t)nReads + 1);
+                b->foffs.alloc((size_t)nReads + 1);
+            }
+            if (nText) {
+                hipLaunchKernelGGL(k_pack_keys, dim3((nText + 255) / 256), dim3(256), 0, s, b->text.p, nText, b->offs.p,
+                                   b->k, b->keysA.p, b->cnt.p);
+                size_t tmpBytes = 0;
+                HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, b->keysA.p, b->keysB.p, nText, 0, 64, s));
+                if (b->sortTmp.n < tmpBytes) b->sortTmp.alloc(tmpBytes + 256);
+                HIPCHK(rocprim::radix_sort_keys(b->sortTmp.p, tmpBytes, b->keysA.p, b->keysB.p, nText, 0, 64, s));
+            }
+            const int mode = b->k == 0 ? 0 : (b->metric == CMB_METRIC_HAMMING ? 1 : 2);
+            HIPCHK(hipMemsetAsync(b->fcounts.p, 0, ((size_t)nReads + 1) * sizeof(uint32_t), s));
+            hipLaunchKernelGGL(k_filter<false>, dim3((nReads + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->offs.p,
+                               nReads, b->k, mode, b->fcounts.p, (const uint32_t*)nullptr, (uint4*)nullptr);
+            size_t scanBytes = 0;
+            HIPCHK(rocprim::exclusive_scan(nullptr, scanBytes, b->fcounts.p, b->foffs.p, 0u, (size_t)nReads + 1,
+                                           rocprim::plus<uint32_t>(), s));
+            if (b->scanTmp.n < scanBytes) b->scanTmp.alloc(scanBytes + 256);
+            HIPCHK(rocprim::exclusive_scan(b->scanTmp.p, scanBytes, b->fcounts.p, b->foffs.p, 0u, (size_t)nReads + 1,
+                                           rocprim::plus<uint32_t>(), s));
+            uint32_t total = 0;
+            HIPCHK(hipMemcpyAsync(&total, b->foffs.p + nReads, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (hcnt[3] & FLAG_CAPACITY)
+                return fail(CMB_ERR_INTERNAL, "occurrence does not fit the filter key (width / distance range)");
+            if (b->fout.n < total) b->fout.alloc((size_t)total + total / 8 + 256);
+            if (total)
+                hipLaunchKernelGGL(k_filter<true>, dim3((nReads + 255) / 256), dim3(256), 0, s, b->keysB.p, nText,
+                                   b->offs.p, nReads, b->k, mode, b->fcounts.p, b->foffs.p, b->fout.p);
+            HIPCHK(hipGetLastError());
+            tm.end("k_filter");
+            b->occs.resize(total);
+            std::vector<uint32_t> o32((size_t)nReads + 1);
+            if (total) HIPCHK(hipMemcpyAsync(b->occs.data(), b->fout.p, (size_t)total * sizeof(cmb_occ), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(o32.data(), b->foffs.p, o32.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            for (uint32_t r = 0; r <= nReads; r++) b->occOffs[r] = o32[r];
         }
         // TOTAL_REPORTED_POSITIONS (indexinterface.cpp:1378,1390 / :1333,1352)
         b->cnts[CMB_CNT_TOTAL_REPORTED] = (uint64_t)textFromVerify + fmRows;

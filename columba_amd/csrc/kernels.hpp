@@ -11,6 +11,9 @@
 //   k_fmocc       in-index occurrence -> text positions indexinterface.cpp:1385-1440, :1349-1366
 #pragma once
 #include "dev_partition.hpp"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 namespace cmb {
 
@@ -591,6 +594,86 @@ k_fmocc(DevIndex ix, const FMOccRec* __restrict__ recs, uint32_t n, Queues q) {
     const int which[2] = {8, 9};
     flushCounters(q, local, which, 2);
     if (flags) atomicOr(&q.cnt[3], flags);
+}
+
+// ------------------------------------------------------------------ occurrence filter
+// IndexInterface::getUniqueTextOccurrences / getTextOccHamming post-processing (reference
+// src/indexinterface.cpp:1331-1491) on the device.  Every raw text occurrence is packed into ONE 64-bit
+// key whose natural order is the reference's TextOcc::operator< (src/indexhelpers.h:779-795) within a
+// read:   read[63:40] | begin[39:8] | distance[7:5] | (width - (len - k))[4:1] | strand[0]
+// One radix sort of the keys (rocPRIM) therefore groups the occurrences per read AND orders them;
+// k_filter then walks each read's segment once: unique (same range and distance, :811), then the
+// redundancy filter (:1447-1485).
+__global__ void __launch_bounds__(256)
+k_pack_keys(const TextOccRec* __restrict__ text, uint32_t n, const uint64_t* __restrict__ offs, uint32_t k,
+            unsigned long long* __restrict__ keys, uint32_t* __restrict__ cnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const TextOccRec t = text[i];
+    const uint32_t r = t.rsId >> 1;
+    const uint32_t len = (uint32_t)(offs[r + 1] - offs[r]);
+    const uint32_t width = t.end - t.begin;
+    const uint32_t wrel = width - (len - k); // in [0, 2k] for every occurrence of a read of length len
+    if (wrel > 15u || t.dist > 7u) atomicOr(&cnt[3], (uint32_t)FLAG_CAPACITY);
+    keys[i] = ((unsigned long long)r << 40) | ((unsigned long long)t.begin << 8) | ((unsigned long long)(t.dist & 7u) << 5) |
+              ((unsigned long long)(wrel & 15u) << 1) | (unsigned long long)(t.rsId & 1u);
+}
+
+// mode 0: k = 0 (no filtering, searchstrategy.cpp:499-510); 1: Hamming (unique only); 2: edit distance
+// WRITE = false: count the surviving occurrences of every read; true: write them at outOffs[read].
+template <bool WRITE>
+__global__ void __launch_bounds__(256)
+k_filter(const unsigned long long* __restrict__ keys, uint32_t n, const uint64_t* __restrict__ offs, uint32_t nReads,
+         uint32_t k, int mode, uint32_t* __restrict__ counts, const uint32_t* __restrict__ outOffs,
+         uint4* __restrict__ out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nReads) return;
+    // segment of read r: [lower_bound(r << 40), lower_bound((r+1) << 40))
+    const unsigned long long klo = (unsigned long long)r << 40, khi = (unsigned long long)(r + 1) << 40;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (keys[mid] < klo) lo = mid + 1;
+        else hi = mid;
+    }
+    const uint32_t segLo = lo;
+    hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (keys[mid] < khi) lo = mid + 1;
+        else hi = mid;
+    }
+    const uint32_t segHi = lo;
+    const uint32_t len = (uint32_t)(offs[r + 1] - offs[r]);
+    const uint32_t wbase = len - k;
+    uint32_t nOut = 0;
+    const uint32_t obase = WRITE ? outOffs[r] : 0u;
+    const uint32_t maxDiff = 2 * k;
+    uint32_t prevBegin = 0xFFFFFFFFu, prevDepth = 0xFFFFFFFFu, prevED = k + 1;
+    unsigned long long prevKey = ~0ull;
+    for (uint32_t i = segLo; i < segHi; i++) {
+        const unsigned long long key = keys[i];
+        const uint32_t begin = (uint32_t)(key >> 8), dist = (uint32_t)(key >> 5) & 7u;
+        const uint32_t width = wbase + ((uint32_t)(key >> 1) & 15u), strand = (uint32_t)key & 1u;
+        if (mode != 0) {
+            if ((key >> 1) == (prevKey >> 1)) continue; // same range and distance (either strand)
+            prevKey = key;
+        }
+        if (mode == 2) {
+            const uint32_t diff = begin > prevBegin ? begin - prevBegin : prevBegin - begin;
+            if (diff == 0) continue;
+            if (diff <= maxDiff) {
+                if (dist > prevED || (dist == prevED && width >= prevDepth)) continue;
+                nOut--; // the previous one was worse: replace it
+            }
+            prevBegin = begin;
+            prevED = dist;
+            prevDepth = width;
+        }
+        if (WRITE) out[obase + nOut] = make_uint4(begin, begin + width, dist, strand);
+        nOut++;
+    }
+    if (!WRITE) counts[r] = nOut;
 }
 
 } // namespace cmb
