@@ -6,7 +6,8 @@ BASELINE.json configs[2]) on a human-like synthetic reference, one process per G
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the whole hot path (k_prep -> k_search -> k_verify -> k_fmocc -> filter)
+A "step" is one pass of the whole hot path (k_prep -> k_partition -> k_dfs -> k_verify -> k_traceback ->
+k_fmocc -> k_filter, results copied back to the host)
 over this rank's read shard, reads already resident in HBM (cmb_batch_run).  Weak scaling: every
 rank matches `--reads` reads against a full replica of the index; no collective on the data path
 (rank 0 builds the index and broadcasts it over RCCL, read shards are scattered once, both before
@@ -81,7 +82,7 @@ def main():
                     help="reads per GPU (weak scaling)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--k", type=int, default=4)
-    ap.add_argument("--cpu-sample", type=int, default=100_000, help="reads timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU oracle (bounded sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
