@@ -31,45 +31,12 @@ sys.path.insert(0, ROOT)
 import columba_amd as ca  # noqa: E402
 from columba_amd import indexbuild as ib  # noqa: E402
 from columba_amd import synth  # noqa: E402
+from columba_amd.dist import broadcast_index, scatter_reads  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
-INDEX_FIELDS = ["text", "counts", "bv_fwd", "cnt_fwd", "bv_rev", "cnt_rev", "bwt_words", "sa_bv",
-                "sa_bv_counts", "sa_samples", "seq_starts"]
-
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
-
-
-def broadcast_index(ix, rank, world, dev):
-    """Replicate the index arrays from rank 0 (RCCL broadcast over xGMI); returns IndexArrays."""
-    import torch.distributed as dist
-    meta = [None]
-    if rank == 0:
-        meta = [{"shapes": {f: (getattr(ix, f).shape, str(getattr(ix, f).dtype)) for f in INDEX_FIELDS},
-                 "dpf": ix.dollar_pos_fwd, "dpr": ix.dollar_pos_rev, "sparseness": ix.sparseness,
-                 "names": ix.seq_names}]
-    dist.broadcast_object_list(meta, src=0)
-    m = meta[0]
-    arrays = {}
-    for f in INDEX_FIELDS:
-        shape, dt = m["shapes"][f]
-        nbytes = int(np.prod(shape)) * np.dtype(dt).itemsize
-        if rank == 0:
-            t = torch.from_numpy(getattr(ix, f).view(np.uint8).reshape(-1)).to(dev)
-        else:
-            t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        dist.broadcast(t, src=0)
-        arrays[f] = getattr(ix, f) if rank == 0 else t.cpu().numpy().view(dt).reshape(shape)
-        del t
-    if rank == 0:
-        return ix
-    return ib.IndexArrays(text=arrays["text"], counts=arrays["counts"], dollar_pos_fwd=m["dpf"],
-                          bv_fwd=arrays["bv_fwd"], cnt_fwd=arrays["cnt_fwd"], dollar_pos_rev=m["dpr"],
-                          bv_rev=arrays["bv_rev"], cnt_rev=arrays["cnt_rev"], bwt_words=arrays["bwt_words"],
-                          sa_bv=arrays["sa_bv"], sa_bv_counts=arrays["sa_bv_counts"],
-                          sa_samples=arrays["sa_samples"], sparseness=m["sparseness"],
-                          seq_starts=arrays["seq_starts"], seq_names=m["names"])
 
 
 def main():
@@ -113,7 +80,7 @@ def main():
         log(f"[bench] index for {n / 1e6:.0f} Mbp built in {time.time() - t0:.1f} s "
             f"({ix.nbytes() / 1e9:.2f} GB host arrays)")
     if world > 1:
-        ix = broadcast_index(ix, rank, world, dev)
+        ix = broadcast_index(ix, rank, dev)
     index = ca.Index(ix, in_text_switch=4, kmer_size=10, device=local)
     strategy = ca.SearchStrategy("multiple_opt", "edit", "dynamic")
 
@@ -121,15 +88,12 @@ def main():
     R, L = args.reads, args.read_len
     t1 = time.time()
     if world > 1:
-        shard = torch.empty(R * L, dtype=torch.uint8, device=dev)
+        allr = None
         if rank == 0:
             buf, _ = synth.sample_reads_fast(torch.from_numpy(ix.text[:-1]).to(dev), R * world, L, seed=3, device=dev)
             allr = torch.from_numpy(buf).to(dev).reshape(world, R * L)
-            dist.scatter(shard, [allr[i].contiguous() for i in range(world)], src=0)
-            del allr
-        else:
-            dist.scatter(shard, None, src=0)
-        buf = shard.cpu().numpy()
+        buf = scatter_reads(allr, R * L, rank, world, dev)
+        del allr
     else:
         buf, _ = synth.sample_reads_fast(torch.from_numpy(ix.text[:-1]).to(dev), R, L, seed=3, device=dev)
     offs = np.arange(R + 1, dtype=np.uint64) * np.uint64(L)

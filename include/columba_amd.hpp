@@ -1,0 +1,284 @@
+// columba_amd.hpp — C++ host adapter over the C-ABI (include/columba_amd.h).
+//
+// Keeps the names, argument meaning and error behaviour of the reference's host API for the hot
+// path, so that Columba-style driver code (processChunk, src/parallel.cpp:67-78) ports by changing
+// the namespace:
+//
+//   reference (src/)                                         here (namespace columba_amd)
+//   -------------------------------------------------------  -------------------------------------
+//   FMIndex(base, inTextSwitch, noCIGAR, sa_sparse,           FMIndex(base, inTextSwitch, noCIGAR,
+//           verbose, wordSize)        fmindex/fmindex.h:403           sa_sparse, verbose, wordSize)
+//   KucherovKPlus1 / PigeonHoleSearchStrategy /               same class names (thin subclasses of
+//   MultipleSchemesStrategy / CustomSearchStrategy            SearchStrategy)
+//                         searchstrategy.h:2829,3221,2584,2130
+//   SearchStrategy::matchApprox(ReadBundle&, maxED,           same signature, plus matchApproxBatch
+//           Counters&, std::vector<TextOcc>&)   :2021-2024    for a whole chunk (one GPU batch)
+//   Counters / TextOcc / Range / ReadBundle                   value types with the same accessors
+//                         indexhelpers.h:1846,289,63; reads.h:128
+//
+// Errors: every failure of the C-ABI is re-thrown as std::runtime_error, which is what the
+// reference throws from its loaders and parsers (fmindex.cpp:84, indexinterface.cpp:100,
+// search.h:559-586) and what its main() catches (parallel.cpp:1041-1044).
+#pragma once
+#include "columba_amd.h"
+
+#include <array>
+#include <cstdint>
+#include <cstdio>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace columba_amd {
+
+typedef uint32_t length_t;
+enum Strand { FORWARD_STRAND = 0, REVERSE_C_STRAND = 1 };
+enum PartitionStrategy { UNIFORM = CMB_PARTITION_UNIFORM, STATIC = CMB_PARTITION_STATIC, DYNAMIC = CMB_PARTITION_DYNAMIC };
+enum DistanceMetric { HAMMING = CMB_METRIC_HAMMING, EDIT = CMB_METRIC_EDIT };
+
+inline void check(int rc) {
+    if (rc != CMB_OK) throw std::runtime_error(cmb_last_error());
+}
+
+class Range {
+    length_t b, e;
+
+  public:
+    Range(length_t begin = 0, length_t end = 0) : b(begin), e(end) {}
+    length_t getBegin() const { return b; }
+    length_t getEnd() const { return e; }
+    length_t width() const { return e > b ? e - b : 0; }
+};
+
+class TextOcc {
+    Range range;
+    length_t distance;
+    Strand strand;
+
+  public:
+    TextOcc(Range r, length_t d, Strand s) : range(r), distance(d), strand(s) {}
+    const Range& getRange() const { return range; }
+    length_t getBegin() const { return range.getBegin(); }
+    length_t getEnd() const { return range.getEnd(); }
+    length_t getDistance() const { return distance; }
+    Strand getStrand() const { return strand; }
+    bool isRevCompl() const { return strand == REVERSE_C_STRAND; }
+};
+
+class Counters {
+  public:
+    enum CounterType {
+        NODE_COUNTER = CMB_CNT_NODE,
+        TOTAL_REPORTED_POSITIONS = CMB_CNT_TOTAL_REPORTED,
+        IN_TEXT_STARTED = CMB_CNT_IN_TEXT_STARTED,
+        ABORTED_IN_TEXT_VERIF = CMB_CNT_ABORTED_IN_TEXT,
+        CIGARS_IN_TEXT_VERIFICATION = CMB_CNT_CIGARS_IN_TEXT,
+        IMMEDIATE_SWITCH = CMB_CNT_IMMEDIATE_SWITCH,
+        SEARCH_STARTED = CMB_CNT_SEARCH_STARTED,
+        COUNTER_TYPE_MAX = CMB_CNT_MAX
+    };
+    Counters() { counters.fill(0); }
+    void resetCounters() { counters.fill(0); }
+    void inc(CounterType t, uint64_t amount = 1) { counters[t] += amount; }
+    uint64_t get(CounterType t) const { return counters[t]; }
+    void addRaw(const uint64_t* c) {
+        for (int i = 0; i < CMB_CNT_MAX; i++) counters[i] += c[i];
+    }
+
+  private:
+    std::array<uint64_t, CMB_CNT_MAX> counters;
+};
+
+class ReadBundle { // reads.h:128 (clean-up and reverse complement happen on the device)
+    std::string seqID, read;
+
+  public:
+    ReadBundle(const std::string& id, const std::string& sequence) : seqID(id), read(sequence) {}
+    const std::string& getSeqID() const { return seqID; }
+    const std::string& getRead() const { return read; }
+    size_t size() const { return read.size(); }
+};
+
+class FMIndex {
+    cmb_index* h = nullptr;
+    length_t textLength = 0, switchPoint = 0;
+    std::vector<length_t> startPos;
+    std::vector<std::string> seqNames;
+
+    template <typename T> static std::vector<T> slurp(std::ifstream& f, size_t n) {
+        std::vector<T> v(n);
+        f.read(reinterpret_cast<char*>(v.data()), (std::streamsize)(n * sizeof(T)));
+        if (!f) throw std::runtime_error("Problem reading index file (truncated)");
+        return v;
+    }
+
+  public:
+    // Loads the Vanilla index files written by columba_build (formats: SURVEY.md §5) and uploads them.
+    FMIndex(const std::string& baseFile, length_t inTextSwitch, bool /*noCIGAR*/, int sa_sparse = 1,
+            bool /*verbose*/ = true, length_t wordSize = 10, int device = 0)
+        : switchPoint(inTextSwitch) {
+        { // indexinterface.cpp:77-128
+            std::ifstream m(baseFile + ".meta");
+            if (m) {
+                length_t tag;
+                size_t sz;
+                std::string flavour;
+                m >> tag >> sz >> flavour;
+                if (sz != sizeof(length_t))
+                    throw std::runtime_error("The index was built with a compiled version that uses " +
+                                             std::to_string(sz * 8) + "-bit numbers, while the current programme was "
+                                             "compiled using 32-bit numbers. Recompile the programme with the correct "
+                                             "THIRTY_TWO flag set or rebuild the index.");
+                if (flavour != "VANILLA")
+                    throw std::runtime_error("The index was built with a different flavor of Columba.");
+            }
+        }
+        std::ifstream cct(baseFile + ".cct", std::ios::binary);
+        if (!cct) throw std::runtime_error("Cannot open file: " + baseFile + ".cct");
+        auto charCounts = slurp<length_t>(cct, 256);
+        cmb_index_desc d{};
+        uint64_t cum = 0;
+        int nsym = 0;
+        for (size_t i = 0; i < 256; i++) {
+            if (!charCounts[i]) continue;
+            if (nsym < 5) d.counts[nsym] = cum;
+            nsym++;
+            cum += charCounts[i];
+        }
+        if (nsym != 5) throw std::runtime_error("The index alphabet must be $ACGT");
+        std::ifstream txt(baseFile + ".txt.bin", std::ios::binary);
+        if (!txt) throw std::runtime_error("Error opening file for reading: " + baseFile + ".txt.bin");
+        length_t n;
+        txt.read(reinterpret_cast<char*>(&n), sizeof(n));
+        auto text = slurp<uint8_t>(txt, n);
+        textLength = n;
+        auto readBrt = [&](const std::string& fn, uint64_t& dollar, std::vector<uint64_t>& bv, std::vector<uint64_t>& cnt) {
+            std::ifstream f(fn, std::ios::binary);
+            if (!f) throw std::runtime_error("Cannot open file: " + fn);
+            uint64_t N;
+            f.read(reinterpret_cast<char*>(&dollar), 8);
+            f.read(reinterpret_cast<char*>(&N), 8);
+            bv = slurp<uint64_t>(f, 4 * ((N + 63) / 64));
+            cnt = slurp<uint64_t>(f, 8 * ((N + 511) / 512));
+        };
+        std::vector<uint64_t> bvF, cF, bvR, cR;
+        readBrt(baseFile + ".brt", d.dollar_pos_fwd, bvF, cF);
+        readBrt(baseFile + ".rev.brt", d.dollar_pos_rev, bvR, cR);
+        const std::string sfx = std::to_string(sa_sparse);
+        std::ifstream sab(baseFile + ".sa.bv." + sfx, std::ios::binary);
+        if (!sab)
+            throw std::runtime_error("Cannot open file: " + baseFile + ".sa.bv." + sfx +
+                                     ". Did you set an incorrect suffix array sparseness factor using the -s flag "
+                                     "or move your index files?");
+        uint64_t N;
+        sab.read(reinterpret_cast<char*>(&N), 8);
+        const uint64_t nw = (N + 63) / 64;
+        auto saBv = slurp<uint64_t>(sab, nw);
+        auto saCnt = slurp<uint64_t>(sab, (nw + 7) / 4);
+        std::ifstream sas(baseFile + ".sa." + sfx, std::ios::binary | std::ios::ate);
+        if (!sas) throw std::runtime_error("Problem reading file: " + baseFile + ".sa." + sfx);
+        const size_t nSamples = (size_t)sas.tellg() / sizeof(length_t);
+        sas.seekg(0);
+        auto samples = slurp<length_t>(sas, nSamples);
+        std::ifstream pos(baseFile + ".pos", std::ios::binary | std::ios::ate);
+        if (!pos) throw std::runtime_error("Cannot open file: " + baseFile + ".pos\nIs the reference index outdated?");
+        const size_t np = (size_t)pos.tellg() / sizeof(length_t);
+        pos.seekg(0);
+        startPos = slurp<length_t>(pos, np);
+        d.text_length = n;
+        d.text = text.data();
+        d.bv_fwd = bvF.data();
+        d.cnt_fwd = cF.data();
+        d.bv_rev = bvR.data();
+        d.cnt_rev = cR.data();
+        d.sa_bv = saBv.data();
+        d.sa_bv_counts = saCnt.data();
+        d.sa_samples = samples.data();
+        d.n_samples = nSamples;
+        d.sa_sparseness = (uint32_t)sa_sparse;
+        d.seq_starts = startPos.data();
+        d.n_seqs = (uint32_t)startPos.size();
+        d.kmer_size = wordSize;
+        d.in_text_switch = inTextSwitch;
+        check(cmb_index_create(&d, device, &h));
+    }
+    FMIndex(const FMIndex&) = delete;
+    FMIndex& operator=(const FMIndex&) = delete;
+    ~FMIndex() { cmb_index_destroy(h); }
+    cmb_index* handle() const { return h; }
+    length_t getSwitchPoint() const { return switchPoint; }
+    length_t getTextLength() const { return textLength; }
+    const std::vector<length_t>& getStartPositions() const { return startPos; }
+};
+
+class SearchStrategy {
+  protected:
+    FMIndex& index;
+    cmb_strategy* h = nullptr;
+    SearchStrategy(FMIndex& idx) : index(idx) {}
+
+  public:
+    SearchStrategy(const SearchStrategy&) = delete;
+    virtual ~SearchStrategy() { cmb_strategy_destroy(h); }
+
+    // the body of processChunk's loop for a whole chunk: result[i] = occurrences of reads[i]
+    void matchApproxBatch(const std::vector<ReadBundle>& reads, length_t maxED, Counters& counters,
+                          std::vector<std::vector<TextOcc>>& result) {
+        std::string seqs;
+        std::vector<uint64_t> offs(reads.size() + 1, 0);
+        for (size_t i = 0; i < reads.size(); i++) {
+            seqs += reads[i].getRead();
+            offs[i + 1] = seqs.size();
+        }
+        cmb_batch* b = nullptr;
+        check(cmb_batch_create(index.handle(), h, maxED, seqs.data(), offs.data(), (uint32_t)reads.size(), &b));
+        struct Guard {
+            cmb_batch* b;
+            ~Guard() { cmb_batch_destroy(b); }
+        } guard{b};
+        check(cmb_batch_run(b));
+        uint64_t n = 0;
+        check(cmb_batch_result_size(b, &n));
+        std::vector<cmb_occ> occ(n ? n : 1);
+        std::vector<uint64_t> oo(reads.size() + 1), cnt(CMB_CNT_MAX);
+        check(cmb_batch_results(b, occ.data(), occ.size(), oo.data(), cnt.data()));
+        counters.addRaw(cnt.data());
+        result.assign(reads.size(), {});
+        for (size_t i = 0; i < reads.size(); i++)
+            for (uint64_t j = oo[i]; j < oo[i + 1]; j++)
+                result[i].emplace_back(Range(occ[j].begin, occ[j].end), occ[j].distance, (Strand)occ[j].strand);
+    }
+    // SearchStrategy::matchApprox (searchstrategy.h:2021-2024), ALL mode, one read
+    void matchApprox(ReadBundle& bundle, length_t maxED, Counters& counters, std::vector<TextOcc>& result) {
+        std::vector<std::vector<TextOcc>> r;
+        matchApproxBatch({bundle}, maxED, counters, r);
+        result = r.empty() ? std::vector<TextOcc>() : r[0];
+    }
+};
+
+struct NamedStrategy : SearchStrategy {
+    NamedStrategy(FMIndex& idx, const char* name, PartitionStrategy p, DistanceMetric m) : SearchStrategy(idx) {
+        check(cmb_strategy_create_named(name, m, p, &h));
+    }
+};
+struct KucherovKPlus1 : NamedStrategy { // searchstrategy.h:2829
+    KucherovKPlus1(FMIndex& idx, PartitionStrategy p, DistanceMetric m) : NamedStrategy(idx, "kuch1", p, m) {}
+};
+struct PigeonHoleSearchStrategy : NamedStrategy { // searchstrategy.h:3221
+    PigeonHoleSearchStrategy(FMIndex& idx, PartitionStrategy p, DistanceMetric m) : NamedStrategy(idx, "pigeon", p, m) {}
+};
+struct MultipleSchemesStrategy : SearchStrategy { // searchstrategy.h:2584 (`-d <dir>`)
+    MultipleSchemesStrategy(FMIndex& idx, const std::string& pathToFolder, PartitionStrategy p, DistanceMetric m)
+        : SearchStrategy(idx) {
+        check(cmb_strategy_create_from_dir(pathToFolder.c_str(), 1, m, p, &h));
+    }
+};
+struct CustomSearchStrategy : SearchStrategy { // searchstrategy.h:2130 (`-c <dir>`)
+    CustomSearchStrategy(FMIndex& idx, const std::string& pathToFolder, PartitionStrategy p, DistanceMetric m)
+        : SearchStrategy(idx) {
+        check(cmb_strategy_create_from_dir(pathToFolder.c_str(), 0, m, p, &h));
+    }
+};
+
+} // namespace columba_amd

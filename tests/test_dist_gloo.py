@@ -1,0 +1,74 @@
+"""N > 1 plumbing on CPU: two gloo ranks replicate the index (broadcast), receive their read shard
+(scatter) and match it; the union of the shards equals a single-process run.  The matching itself is
+done by the CPU oracle here (there is no GPU in the CPU suite) — what is under test is the sharding."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+    import columba_amd as ca
+    from columba_amd import indexbuild as ib, synth
+    from columba_amd.dist import broadcast_index, scatter_reads
+    import oracle_py as op
+    import schemes_py as sp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    R, L = 150, 100
+    ix = None
+    allr = None
+    if rank == 0:
+        g, starts = synth.genome_rep(seed=5, n=120_000, scale=2.0)
+        ix = ib.build_index(g.tobytes(), seq_starts=starts)
+        reads = synth.sample_reads(g, R * world, L, seed=2)
+        allr = torch.from_numpy(np.frombuffer(b"".join(reads), dtype=np.uint8).copy()).reshape(world, R * L)
+    ix = broadcast_index(ix, rank, "cpu")
+    buf = scatter_reads(allr, R * L, rank, world, "cpu")
+    lo, hi = ca.shard_bounds(R * world, world, rank)
+    assert hi - lo == R
+    reads = [buf[i * L:(i + 1) * L].tobytes() for i in range(R)]
+    occ, offs, cnt = op.match_batch(op.OracleIndex(ix), op.OracleStrategy(sp.MULTIPLE_OPT), 2, reads)
+    tot = torch.tensor([len(occ), int(occ["begin"].astype(np.int64).sum())], dtype=torch.int64)
+    dist.all_reduce(tot)
+    np.save(os.path.join(tmp, f"tot{rank}.npy"), tot.numpy())
+    if rank == 0:
+        np.save(os.path.join(tmp, "reads.npy"), allr.numpy())
+        ib.save_index(ix, os.path.join(tmp, "idx"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process(tmp_path, oracle_built):
+    world = 2
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as op
+    import schemes_py as sp
+    from columba_amd import indexbuild as ib
+    ix = ib.load_index(str(tmp_path / "idx"))
+    allr = np.load(tmp_path / "reads.npy").reshape(-1)
+    reads = [allr[i * 100:(i + 1) * 100].tobytes() for i in range(300)]
+    occ, offs, _ = op.match_batch(op.OracleIndex(ix), op.OracleStrategy(sp.MULTIPLE_OPT), 2, reads)
+    t0, t1 = np.load(tmp_path / "tot0.npy"), np.load(tmp_path / "tot1.npy")
+    assert np.array_equal(t0, t1)
+    assert t0[0] == len(occ) and t0[1] == int(occ["begin"].astype(np.int64).sum()) and len(occ) > 0
+
+
+def test_shard_bounds_cover_everything():
+    import columba_amd as ca
+    for n in (0, 1, 7, 8, 9, 1000, 1001):
+        for w in (1, 2, 3, 8):
+            spans = [ca.shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
