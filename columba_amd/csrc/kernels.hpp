@@ -290,55 +290,54 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const uint32
     edPackHi = 0;
     uint32_t i = 0;
     uint64_t Mblk[4];
+    // One row per loop iteration for every lane (lock step: the plane stores of a wavefront then fall
+    // into whole lines).  The text is read in aligned 16-byte chunks, one chunk ahead of its use.
     uint32_t chunk = start >> 4;
     uint4 cur = loadText16(ix.text, chunk);
     uint4 nxt = loadText16(ix.text, chunk + 1); // the text allocation is padded
-    bool valid = true;
-    while (i < size && valid) {
+    while (i < size) {
         const uint32_t p = start + i;
-        const uint32_t inChunk = p & 15u;
-        const uint32_t take = min(16u - inChunk, size - i);
-        for (uint32_t t = 0; t < take; t++) {
-            const uint32_t bi = inChunk + t;
-            const uint32_t wsel = bi >> 2;
-            const uint32_t wv = wsel == 0 ? cur.x : wsel == 1 ? cur.y : wsel == 2 ? cur.z : cur.w;
-            const uint32_t tc = textCode((uint8_t)(wv >> (8 * (bi & 3u))));
-            const uint32_t r = i + 1;
-            if ((r % MX_BLOCK) == 0 || i == 0) {
-                const uint32_t b = r / MX_BLOCK;
-#pragma unroll
-                for (int ch = 0; ch < 4; ch++) Mblk[ch] = matchWord(Gf + ch * gw, 0, len, b);
-            }
-            const uint64_t M = tc == 0 ? Mblk[0] : tc == 1 ? Mblk[1] : tc == 2 ? Mblk[2] : tc == 3 ? Mblk[3] : 0ull;
-            cRows++;
-            valid = computeRow(g, r, M, HP, HN, D0, RAC, score);
-            if (STORE) {
-                const size_t o = (size_t)r * V.nSlots + slot;
-                V.HP[o] = HP;
-                V.D0[o] = D0;
-            }
-            if (!valid) break;
-            if (STORE && r > firstRow) {
-                const uint32_t ed = cellAt(r, col, HP, HN, score);
-                const uint32_t bi = r - firstRow - 1u;
-                if (bi < 21u) edPack |= (uint64_t)min(ed, 7u) << (3u * bi);
-                else edPackHi |= (uint64_t)min(ed, 7u) << (3u * (bi - 21u));
-            }
-            if (!STORE && r >= firstRow) {
-                const uint32_t ed = cellAt(r, col, HP, HN, score);
-                // row r-1 can now be judged (its `below` neighbour is known)
-                if (r - 1 > firstRow) {
-                    const uint32_t e1 = edPrev;
-                    if (e1 <= maxED && e1 >= minED && e1 <= edPrev2 && e1 <= ed) centreMask |= 1u << (r - 2 - firstRow);
-                }
-                edPrev2 = edPrev;
-                edPrev = ed;
-            }
-            i++;
+        if ((p >> 4) != chunk) {
+            chunk++;
+            cur = nxt;
+            nxt = loadText16(ix.text, chunk + 1);
         }
-        chunk++;
-        cur = nxt;
-        nxt = loadText16(ix.text, chunk + 1);
+        const uint32_t bi = p & 15u;
+        const uint32_t wsel = bi >> 2;
+        const uint32_t wv = wsel == 0 ? cur.x : wsel == 1 ? cur.y : wsel == 2 ? cur.z : cur.w;
+        const uint32_t tc = textCode((uint8_t)(wv >> (8 * (bi & 3u))));
+        const uint32_t r = i + 1;
+        if ((r % MX_BLOCK) == 0 || i == 0) {
+            const uint32_t b = r / MX_BLOCK;
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) Mblk[ch] = matchWord(Gf + ch * gw, 0, len, b);
+        }
+        const uint64_t M = tc == 0 ? Mblk[0] : tc == 1 ? Mblk[1] : tc == 2 ? Mblk[2] : tc == 3 ? Mblk[3] : 0ull;
+        cRows++;
+        const bool valid = computeRow(g, r, M, HP, HN, D0, RAC, score);
+        if (STORE) {
+            const size_t o = (size_t)r * V.nSlots + slot;
+            V.HP[o] = HP;
+            V.D0[o] = D0;
+        }
+        if (!valid) break;
+        if (STORE && r > firstRow) {
+            const uint32_t ed = cellAt(r, col, HP, HN, score);
+            const uint32_t bidx = r - firstRow - 1u;
+            if (bidx < 21u) edPack |= (uint64_t)min(ed, 7u) << (3u * bidx);
+            else edPackHi |= (uint64_t)min(ed, 7u) << (3u * (bidx - 21u));
+        }
+        if (!STORE && r >= firstRow) {
+            const uint32_t ed = cellAt(r, col, HP, HN, score);
+            // row r-1 can now be judged (its `below` neighbour is known)
+            if (r - 1 > firstRow) {
+                const uint32_t e1 = edPrev;
+                if (e1 <= maxED && e1 >= minED && e1 <= edPrev2 && e1 <= ed) centreMask |= 1u << (r - 2 - firstRow);
+            }
+            edPrev2 = edPrev;
+            edPrev = ed;
+        }
+        i++;
     }
     if (!STORE && i > firstRow) { // the last valid row has no `below` neighbour (i == lastRow)
         const uint32_t e1 = edPrev;
