@@ -237,6 +237,8 @@ struct cmb_batch {
     DevBuf<uint32_t> G;
     DevBuf<DevStrategyK> strat;
     DevBuf<Scratch> slabs;
+    DevBuf<Scratch2> slabs2;
+    DevBuf<uint32_t> dfsKeysA, dfsIdxA;
     DevBuf<PartOut> parts;
     DevBuf<DfsTask> dfs;
     DevBuf<uint64_t> vHP, vD0;
@@ -424,14 +426,23 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
             const uint32_t nDfs = hcnt[5];
             if (!(flags & (FLAG_ITEM_OVERFLOW | FLAG_DFS_OVERFLOW)) && nDfs) {
                 const uint32_t want = std::min<uint32_t>(((nDfs + 255) / 256) * 256, 256u * 512u);
-                if (b->slabs.n < want) {
-                    b->slabs.alloc(want);
-                    b->nSlots = want;
-                }
                 tm.begin();
-                hipLaunchKernelGGL(k_dfs, dim3(std::min<uint32_t>(b->nSlots, want) / 256), dim3(256), 0, s, ix->d,
-                                   b->strat.p, b->offs.p, b->k, b->maxLen, b->gw, b->seq.p, b->G.p, b->parts.p,
-                                   b->dfs.p, nDfs, b->slabs.p, q);
+                if (b->metric == CMB_METRIC_EDIT) {
+                    if (b->slabs2.n < want) b->slabs2.alloc(want);
+                    if (b->dfsKeysA.n < nDfs) {
+                        b->dfsKeysA.alloc((size_t)nDfs + 1024);
+                        b->dfsIdxA.alloc((size_t)nDfs + 1024);
+                    }
+                    hipLaunchKernelGGL(k_dfs_keys, dim3((nDfs + 255) / 256), dim3(256), 0, s, b->dfs.p, nDfs,
+                                       b->dfsKeysA.p, b->dfsIdxA.p);
+                    hipLaunchKernelGGL(k_dfs_edit, dim3(want / 64), dim3(64), 0, s, ix->d, b->strat.p, b->offs.p,
+                                       b->maxLen, b->gw, b->G.p, b->parts.p, b->dfs.p, b->dfsIdxA.p, nDfs, b->slabs2.p, q);
+                } else {
+                    if (b->slabs.n < want) b->slabs.alloc(want);
+                    hipLaunchKernelGGL(k_dfs_hamming, dim3(want / 256), dim3(256), 0, s, ix->d, b->strat.p, b->offs.p,
+                                       b->k, b->maxLen, b->gw, b->seq.p, b->G.p, b->parts.p, b->dfs.p, nDfs,
+                                       b->slabs.p, q);
+                }
                 tm.end("k_dfs");
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));

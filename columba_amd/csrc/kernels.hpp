@@ -10,7 +10,7 @@
 //                                                       indexhelpers.cpp:518-574, indexinterface.cpp:918-943
 //   k_fmocc       in-index occurrence -> text positions indexinterface.cpp:1385-1440, :1349-1366
 #pragma once
-#include "dev_partition.hpp"
+#include "dev_dfs_edit.hpp"
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -165,12 +165,82 @@ k_partition(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* _
 }
 
 // ------------------------------------------------------------------ approximate DFS over the scheme
-// One lane per DfsTask (a search whose exact start range is still wider than the switch point).
+// wave-wide exclusive prefix sum (all 64 lanes must call)
+__device__ __forceinline__ uint32_t waveExclusiveScan(uint32_t v, uint32_t& total) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if ((int)lane >= d) x += y;
+    }
+    total = __shfl(x, 63);
+    return x - v;
+}
+// one atomic per wavefront: returns this lane's first slot for its `n` records in a queue
+__device__ __forceinline__ uint32_t waveAppend(uint32_t* counter, uint32_t n, uint32_t& total) {
+    const uint32_t off = waveExclusiveScan(n, total);
+    uint32_t base = 0;
+    if (total) {
+        if ((threadIdx.x & 63u) == 0) base = atomicAdd(counter, total);
+        base = __shfl(base, 0);
+    }
+    return base + off;
+}
+
+// sort key of a DFS task: wide start ranges (big subtrees) first, so that the long tasks start first and
+// the 64 tasks a wavefront fetches together have similar sizes
+__global__ void k_dfs_keys(const DfsTask* __restrict__ tasks, uint32_t n, uint32_t* __restrict__ keys,
+                           uint32_t* __restrict__ idx) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = ~tasks[i].r.sa.width();
+    idx[i] = i;
+}
+
+// Edit distance: one lane per DfsTask, one wavefront per block (dev_dfs_edit.hpp).
+__global__ void __launch_bounds__(64)
+k_dfs_edit(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* __restrict__ offs, uint32_t maxLen,
+           uint32_t gw, const uint32_t* __restrict__ G, const PartOut* __restrict__ parts,
+           const DfsTask* __restrict__ tasks, const uint32_t* __restrict__ order, uint32_t nTasks,
+           Scratch2* __restrict__ slabs, Queues q) {
+    __shared__ uint8_t clEd[MAXP][CL_MAX][64];
+    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    EditDfs d(ix, *stp, slabs[slot], q, clEd, threadIdx.x);
+    d.gw = gw;
+    bool done = false;
+    for (;;) {
+        // (1) EXPAND: rank loads + children rows + pushes, for every lane with a pending parent
+        if (d.req) d.expand();
+        // (2) STEP: pop / replay one node and classify it
+        if (!done && d.pend == PEND_NONE) d.step();
+        // (3) staged in-text work items: one atomic per wavefront
+        if (__ballot(d.stN > 0) != 0ull) {
+            uint32_t total;
+            const uint32_t o = waveAppend(&q.cnt[0], d.stN, total);
+            if (d.stN) {
+                if (o + d.stN > q.itemCap) d.flags |= FLAG_ITEM_OVERFLOW;
+                else
+                    for (uint32_t j = 0; j < d.stN; j++) q.items[o + j] = make_uint4(d.rsId, d.stB + j, d.stA, d.stMeta);
+                d.stN = 0;
+            }
+        }
+        // (4) the long, rare paths (goDeeper, phase entry/exit, next task) of the lanes that need one
+        if (!done && d.pend != PEND_NONE) d.heavy(tasks, order, nTasks, parts, offs, maxLen, G, done);
+        if (__ballot(!done) == 0ull) break;
+    }
+    const uint32_t local[4] = {d.cNode, d.cExp, d.cRows, d.cExp};
+    const int which[4] = {0, 7, 11, 12};
+    flushCounters(q, local, which, 4);
+    if (d.flags) atomicOr(&q.cnt[3], d.flags);
+}
+
+// Hamming distance: one lane per DfsTask (recApproxMatchHamming, indexinterface.cpp:1211-1304)
 __global__ void __launch_bounds__(256)
-k_dfs(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* __restrict__ offs, uint32_t k,
-      uint32_t maxLen, uint32_t gw, const uint8_t* __restrict__ seq, const uint32_t* __restrict__ G,
-      const PartOut* __restrict__ parts, const DfsTask* __restrict__ tasks, uint32_t nTasks,
-      Scratch* __restrict__ slabs, Queues q) {
+k_dfs_hamming(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* __restrict__ offs, uint32_t k,
+              uint32_t maxLen, uint32_t gw, const uint8_t* __restrict__ seq, const uint32_t* __restrict__ G,
+              const PartOut* __restrict__ parts, const DfsTask* __restrict__ tasks, uint32_t nTasks,
+              Scratch* __restrict__ slabs, Queues q) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     Scratch& S = slabs[slot];
     Ctx c(ix, *stp, S, q);
@@ -192,19 +262,8 @@ k_dfs(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* __restr
             S.pe[i] = po.pe[i];
         }
         const DevSearch& s = stp->sch[task.scheme].s[task.search];
-        if (stp->metric == 1) {
-            OccTmp sm;
-            sm.r = task.r;
-            sm.dist = 0;
-            sm.depth = task.depth;
-            sm.shift = 0;
-            sm.valid = true;
-            EditSearch es(c, s);
-            es.run(sm, task.idx);
-        } else {
-            HammingSearch hs(c, s);
-            hs.run(task.r, task.depth, task.idx);
-        }
+        HammingSearch hs(c, s);
+        hs.run(task.r, task.depth, task.idx);
     }
     const uint32_t local[4] = {c.cNode, c.cExp, c.cRows, c.cExp};
     const int which[4] = {0, 7, 11, 12};
@@ -236,29 +295,6 @@ __device__ __forceinline__ void emitText(const Queues& q, uint32_t& flags, uint3
 
 __device__ __forceinline__ uint32_t textCode(uint8_t ch) { // A,C,G,T -> 0..3; anything else ('$') -> 4
     return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
-}
-
-// wave-wide exclusive prefix sum (all 64 lanes must call)
-__device__ __forceinline__ uint32_t waveExclusiveScan(uint32_t v, uint32_t& total) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d);
-        if ((int)lane >= d) x += y;
-    }
-    total = __shfl(x, 63);
-    return x - v;
-}
-// one atomic per wavefront: returns this lane's slot for `n` (0 or 1) records in a queue
-__device__ __forceinline__ uint32_t waveAppend(uint32_t* counter, uint32_t n, uint32_t& total) {
-    const uint32_t off = waveExclusiveScan(n, total);
-    uint32_t base = 0;
-    if (total) {
-        if ((threadIdx.x & 63u) == 0) base = atomicAdd(counter, total);
-        base = __shfl(base, 0);
-    }
-    return base + off;
 }
 
 __device__ __forceinline__ uint4 loadText16(const uint8_t* text, uint32_t chunk) {
