@@ -51,7 +51,8 @@ template <typename T> struct DevBuf {
 struct cmb_index {
     int device = 0;
     DevIndex d{};
-    DevBuf<uint64_t> bvF, cntF, bvR, cntR, saBv, saCnt;
+    DevBuf<uint4> blkF, blkR; // 128-byte rank blocks
+    DevBuf<uint64_t> saBv, saCnt;
     DevBuf<uint32_t> saSamples;
     DevBuf<uint8_t> text;
     DevBuf<uint4> kmer;
@@ -80,10 +81,18 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         ix->device = device;
         const uint64_t n = desc->text_length, N = n + 1;
         const uint64_t bvW = 4 * ((N + 63) / 64), cW = 8 * ((N + 511) / 512);
-        ix->bvF.upload(desc->bv_fwd, bvW);
-        ix->cntF.upload(desc->cnt_fwd, cW);
-        ix->bvR.upload(desc->bv_rev, bvW);
-        ix->cntR.upload(desc->cnt_rev, cW);
+        const uint64_t nBlocks = N / RANK_BLOCK + 1; // rank(N) must be answerable
+        for (int dir = 0; dir < 2; dir++) {        // re-pack the reference arrays, one direction at a time
+            DevBuf<uint64_t> bv, cnt;
+            bv.upload(dir ? desc->bv_rev : desc->bv_fwd, bvW);
+            cnt.upload(dir ? desc->cnt_rev : desc->cnt_fwd, cW);
+            DevBuf<uint4>& blk = dir ? ix->blkR : ix->blkF;
+            blk.alloc(nBlocks * 8);
+            hipLaunchKernelGGL(k_relayout, dim3((unsigned)((nBlocks + 255) / 256)), dim3(256), 0, 0, bv.p, cnt.p, N,
+                               nBlocks, blk.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipDeviceSynchronize());
+        }
         const uint64_t saW = (n + 63) / 64;
         ix->saBv.upload(desc->sa_bv, saW);
         ix->saCnt.upload(desc->sa_bv_counts, (saW + 7) / 4);
@@ -96,8 +105,8 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         DevIndex& d = ix->d;
         d.n = (uint32_t)n;
         for (int i = 0; i < 5; i++) d.counts[i] = (uint32_t)desc->counts[i];
-        d.fwd = DevBWT{ix->bvF.p, ix->cntF.p, (uint32_t)desc->dollar_pos_fwd};
-        d.rev = DevBWT{ix->bvR.p, ix->cntR.p, (uint32_t)desc->dollar_pos_rev};
+        d.fwd = DevBWT{ix->blkF.p, (uint32_t)desc->dollar_pos_fwd};
+        d.rev = DevBWT{ix->blkR.p, (uint32_t)desc->dollar_pos_rev};
         d.saBv = ix->saBv.p;
         d.saCnt = ix->saCnt.p;
         d.saSamples = ix->saSamples.p;
@@ -109,7 +118,7 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         hipLaunchKernelGGL(k_kmer_table, dim3((total + 255) / 256), dim3(256), 0, 0, d, ix->kmer.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipDeviceSynchronize());
-        ix->bytes = ix->bvF.bytes() + ix->cntF.bytes() + ix->bvR.bytes() + ix->cntR.bytes() + ix->saBv.bytes() +
+        ix->bytes = ix->blkF.bytes() + ix->blkR.bytes() + ix->saBv.bytes() +
                     ix->saCnt.bytes() + ix->saSamples.bytes() + ix->text.bytes() + ix->kmer.bytes();
         *out = ix.release();
         return CMB_OK;
@@ -233,6 +242,8 @@ struct cmb_batch {
     DevStrategyK hostStrat{};
     hipStream_t stream = nullptr;
     DevBuf<uint8_t> reads, seq;
+    DevBuf<uint32_t> rec; // read records for k_partition (k_prep)
+    uint32_t recW = 0;
     DevBuf<uint64_t> offs;
     DevBuf<uint32_t> G;
     DevBuf<DevStrategyK> strat;
@@ -301,6 +312,8 @@ extern "C" int cmb_batch_create(cmb_index* idx, const cmb_strategy* st, uint32_t
         b->offs.upload(offs, n_reads + 1);
         b->seq.alloc((size_t)2 * n_reads * maxLen);
         b->G.alloc((size_t)2 * n_reads * 8 * b->gw);
+        b->recW = ((1 + 2 * ((maxLen + 31) / 32)) + 3) / 4 * 4;
+        b->rec.alloc((size_t)2 * n_reads * b->recW);
         b->strat.upload(&b->hostStrat, 1);
         b->parts.alloc((size_t)2 * n_reads);
         b->dfs.alloc((size_t)n_reads * 2 + 4096);
@@ -388,10 +401,11 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
         tm.begin();
         {
             HIPCHK(hipMemsetAsync(b->G.p, 0, b->G.bytes(), s));
+            HIPCHK(hipMemsetAsync(b->rec.p, 0, b->rec.bytes(), s));
             const uint32_t chunks = (b->maxLen + 31) / 32;
             const uint64_t nthr = (uint64_t)nReads * chunks;
             hipLaunchKernelGGL(k_prep, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, b->reads.p, b->offs.p,
-                               nReads, b->maxLen, b->gw, chunks, b->seq.p, b->G.p);
+                               nReads, b->maxLen, b->gw, chunks, b->seq.p, b->G.p, b->rec.p, b->recW);
         }
         tm.end("k_prep");
 
@@ -411,9 +425,11 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
             const uint32_t dfsCap = (uint32_t)std::min<size_t>(b->dfs.n, 0xFFFFFFF0u);
             tm.begin();
             const uint32_t pParts = b->k ? b->hostStrat.numParts : 1;
-            hipLaunchKernelGGL(k_partition, dim3(pSlots / 256), dim3(256), 5 * pParts * 256 * sizeof(uint32_t), s,
-                               ix->d, b->strat.p, b->offs.p, nReads,
-                               b->k, b->maxLen, b->seq.p, b->parts.p, b->dfs.p, dfsCap, q);
+            const uint32_t pLds = (uint32_t)((sizeof(DevStrategyK) + 15) / 16 * 16) +
+                                  (5 * pParts + 2 * ((b->maxLen + 31) / 32)) * 256 * sizeof(uint32_t);
+            hipLaunchKernelGGL(k_partition, dim3(pSlots / 256), dim3(256), pLds, s, ix->d, b->strat.p, b->offs.p,
+                               nReads, b->k, b->maxLen, b->seq.p, (const uint4*)b->rec.p, b->recW / 4, b->parts.p, b->dfs.p,
+                               dfsCap, q);
             tm.end("k_partition");
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
@@ -726,11 +742,12 @@ extern "C" int cmb_extend_bench(cmb_index* idx, int mode, const void* d_in, uint
         HIPCHK(hipEventCreate(&a));
         HIPCHK(hipEventCreate(&b));
         const unsigned nb = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 32);
-        hipLaunchKernelGGL(k_extend, dim3(nb), dim3(256), 0, s, idx->d, mode, (const uint4*)d_in, n, (uint4*)d_out,
+        auto kern = k_extend;
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, s, idx->d, mode, (const uint4*)d_in, n, (uint4*)d_out,
                            (uint8_t*)d_ok); // warm-up
         HIPCHK(hipEventRecord(a, s));
         for (uint32_t i = 0; i < iters; i++)
-            hipLaunchKernelGGL(k_extend, dim3(nb), dim3(256), 0, s, idx->d, mode, (const uint4*)d_in, n,
+            hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, s, idx->d, mode, (const uint4*)d_in, n,
                                (uint4*)d_out, (uint8_t*)d_ok);
         HIPCHK(hipEventRecord(b, s));
         HIPCHK(hipEventSynchronize(b));
@@ -822,7 +839,7 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         q.counters = ctr.p;
         HIPCHK(hipMemset(G.p, 0, G.bytes()));
         hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, 0, reads.p, offs.p, 1u, plen, gw, (plen + 31) / 32, seq.p,
-                           G.p);
+                           G.p, (uint32_t*)nullptr, 0u);
         uint32_t hc[8];
         if (n) {
             hipLaunchKernelGGL(k_verify, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, plen, gw, seq.p, G.p,

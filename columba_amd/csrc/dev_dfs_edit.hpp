@@ -157,7 +157,7 @@ struct EditDfs {
     }
 
     // getClusterCentra (indexhelpers.cpp:276-382) into the cold frame's desc / init
-    __device__ OccTmp clusterCentra(uint32_t lowerBound) {
+    __device__ __forceinline__ OccTmp clusterCentra(uint32_t lowerBound) {
         ColdFrame& f = S.fr[level];
         OccTmp m;
         m.valid = false;
@@ -237,7 +237,7 @@ struct EditDfs {
 
     // ---- phase entry: recApproxMatchEdit prologue (indexinterface.cpp:377-497) ------------------
     // Called with `level` = the caller's level (or firstIdx - 1 for the first phase); suspends the caller.
-    __device__ void enter(int idx, const OccTmp& sm, int prevLvl, int notPrevLvl) {
+    __device__ __forceinline__ void enter(int idx, const OccTmp& sm, int prevLvl, int notPrevLvl) {
         uint32_t parentStackEnd = 0;
         if (idx != firstIdx) {
             S.fr[level].saved = H;
@@ -263,22 +263,20 @@ struct EditDfs {
         H.useRev = H.dir == 1 ? 1u : 0u;
         H.xOff = H.dir == 0 ? pb : len - pe;
         // first column of the band (:411-424)
-        uint32_t initED[DESC_MAX + 1];
-        uint32_t nInit;
         const ColdFrame* df = H.descLvl >= 0 ? &S.fr[H.descLvl] : nullptr;
         const uint32_t nSrc = df ? df->nInit : 0;
-        if (nSrc == 0) {
-            initED[0] = sm.dist;
-            nInit = 1;
-        } else {
+        uint32_t first = sm.dist, last = sm.dist, nInit = 1, increase = 0;
+        if (nSrc != 0) {
             uint32_t prevED = df->init[0];
             if (dsw)
                 for (uint32_t i = 1; i < nSrc; i++) prevED = min(prevED, (uint32_t)df->init[i]);
-            const uint32_t increase = sm.dist - prevED;
-            for (uint32_t i = 0; i < nSrc; i++) initED[i] = df->init[i] + increase;
+            increase = sm.dist - prevED;
+            first = df->init[0] + increase;
+            last = df->init[nSrc - 1] + increase;
             nInit = nSrc;
         }
-        initMatrix(H.g, H.xLen, H.maxED, initED, nInit, H.pHP, H.pHN, H.pRAC, H.pScore);
+        initMatrix(H.g, H.xLen, H.maxED, first, last, df ? df->init : nullptr, increase, nInit, H.pHP, H.pHN, H.pRAC,
+                   H.pScore);
         H.stackBase = parentStackEnd;
         H.stackTop = H.stackBase;
         H.replay = 0;
@@ -310,7 +308,7 @@ struct EditDfs {
     }
 
     // return from the running phase; a caller that was replaying descendants returns as well (:472-477)
-    __device__ void leave() {
+    __device__ __forceinline__ void leave() {
         for (;;) {
             level--;
             if (level < firstIdx) return;
@@ -320,8 +318,15 @@ struct EditDfs {
         mbBlock = 0xFFFFFFFFu;
     }
 
-    // goDeeper (indexinterface.cpp:563-669).  Returns true if a deeper phase was entered.
-    __device__ bool goDeeper(int remFrom) {
+    // a phase entry decided by heavy()'s branches, performed at ONE call site (enter() is large)
+    struct EnterReq {
+        bool want;
+        int idx, prevLvl, notPrevLvl;
+        OccTmp sm;
+    };
+
+    // goDeeper (indexinterface.cpp:563-669).  Returns true if a deeper phase is to be entered (er filled).
+    __device__ __forceinline__ bool goDeeper(int remFrom, EnterReq& er) {
         ColdFrame& f = S.fr[level];
         const int idx = (int)H.idx;
         const int nIdx = idx + 1;
@@ -368,7 +373,7 @@ struct EditDfs {
                 }
             }
             if (m.valid && m.dist >= lowerBound) {
-                enter(nIdx, m, -1, H.otherLvl);
+                er = EnterReq{true, nIdx, -1, H.otherLvl, m};
                 return true;
             }
             return false;
@@ -396,7 +401,7 @@ struct EditDfs {
                 nm.dist = mn;
             }
         }
-        enter(nIdx, nm, idx, H.otherLvl);
+        er = EnterReq{true, nIdx, idx, H.otherLvl, nm};
         return true;
     }
 
@@ -460,7 +465,8 @@ struct EditDfs {
                 pend = PEND_LEAVE;
                 return;
             }
-            const RangePair pair = s->dsw[H.idx] ? H.smR : lastD.r;
+            RangePair pair = lastD.r; // (no `?:` between two objects: a select of addresses would pin
+            if (s->dsw[H.idx]) pair = H.smR; //  the whole lane state in scratch memory)
             H.inReplay = 0;
             requestExpand(pair, lastD.depth, H.pHP, H.pHN, H.pRAC, H.pScore);
             return;
@@ -483,54 +489,56 @@ struct EditDfs {
     }
 
     // ---- (4) parked operations ------------------------------------------------------------------
-    __device__ void heavy(const DfsTask* tasks, const uint32_t* order, uint32_t nTasks, const PartOut* parts,
-                          const uint64_t* offs, uint32_t maxLen, const uint32_t* Gall, bool& done) {
+    __device__ __forceinline__ void heavy(const DfsTask* tasks, const uint32_t* order, uint32_t nTasks,
+                                          const PartOut* parts, const uint64_t* offs, const uint32_t* Gall, bool& done) {
+        EnterReq er;
+        er.want = false;
         if (pend == PEND_FETCH) {
+            pend = PEND_NONE;
             const uint32_t t = atomicAdd(&q.cnt[6], 1u);
             if (t >= nTasks) {
                 done = true;
-                pend = PEND_NONE;
                 level = -1;
                 firstIdx = 0;
-                return;
-            }
-            const DfsTask task = tasks[order[t]];
-            rsId = task.rsId;
-            len = (uint32_t)(offs[(rsId >> 1) + 1] - offs[rsId >> 1]);
-            G = Gall + (size_t)rsId * 8 * gw;
-            const PartOut po = parts[rsId];
+            } else {
+                const DfsTask task = tasks[order[t]];
+                rsId = task.rsId;
+                len = (uint32_t)(offs[(rsId >> 1) + 1] - offs[rsId >> 1]);
+                G = Gall + (size_t)rsId * 8 * gw;
+                const PartOut po = parts[rsId];
 #pragma unroll
-            for (int i = 0; i < MAXP; i++) {
-                S.pb[i] = po.pb[i];
-                S.pe[i] = po.pe[i];
+                for (int i = 0; i < MAXP; i++) {
+                    S.pb[i] = po.pb[i];
+                    S.pe[i] = po.pe[i];
+                }
+                s = &st.sch[task.scheme].s[task.search];
+                firstIdx = task.idx;
+                level = firstIdx - 1;
+                req = false;
+                er.want = true;
+                er.idx = firstIdx;
+                er.prevLvl = -1;
+                er.notPrevLvl = -1;
+                er.sm.r = task.r;
+                er.sm.dist = 0;
+                er.sm.depth = task.depth;
+                er.sm.shift = 0;
+                er.sm.valid = true;
             }
-            s = &st.sch[task.scheme].s[task.search];
-            firstIdx = task.idx;
-            level = firstIdx - 1;
-            req = false;
-            OccTmp sm;
-            sm.r = task.r;
-            sm.dist = 0;
-            sm.depth = task.depth;
-            sm.shift = 0;
-            sm.valid = true;
-            pend = PEND_NONE;
-            enter(firstIdx, sm, -1, -1);
-            (void)maxLen;
-            return;
+        } else {
+            if (pend == PEND_DEEPER) {
+                pend = PEND_NONE;
+                const bool wasReplay = H.inReplay;
+                const bool entered = goDeeper(pendRem, er);
+                if (!entered && wasReplay) pend = PEND_LEAVE; // branchAndBound returned true inside the replay (:472-477)
+            }
+            if (pend == PEND_LEAVE) {
+                pend = PEND_NONE;
+                leave();
+                if (level < firstIdx) pend = PEND_FETCH; // search finished: next task
+            }
         }
-        if (pend == PEND_DEEPER) {
-            pend = PEND_NONE;
-            const bool wasReplay = H.inReplay;
-            const bool entered = goDeeper(pendRem);
-            if (!entered && wasReplay) pend = PEND_LEAVE; // branchAndBound returned true inside the replay (:472-477)
-            if (pend != PEND_LEAVE) return;
-        }
-        if (pend == PEND_LEAVE) {
-            pend = PEND_NONE;
-            leave();
-            if (level < firstIdx) pend = PEND_FETCH; // search finished: next task
-        }
+        if (er.want) enter(er.idx, er.sm, er.prevLvl, er.notPrevLvl);
     }
 };
 

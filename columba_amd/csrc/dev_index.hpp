@@ -8,12 +8,17 @@
 //   FMIndex::findLF / findSA         fmindex/fmindex.cpp:47-60
 //   Bitvec::rank (rank9)             bitvec.h:155-170
 //
-// HBM layout (round 1): the rank arrays keep the reference's interleaved layout, so the
-// four cumulative bitvectors of one position share one 32-byte group and their eight
-// L1/L2 count words share one 64-byte line; both are fetched with 16-byte vector loads
-// (2 + 4 per position).  The BWT symbol needed by LF is decoded from the same 32-byte
-// group (the bitvectors are cumulative: bwtrepr.h:67-68), so the 3-bit EncodedText
-// (.bwt) is not kept on the device at all.
+// HBM layout: the reference's two arrays per BWT (interleaved bitvector words + interleaved L1/L2
+// counts, bitvec.h:209-232) are re-packed at index creation (k_relayout) into self-contained
+// 128-byte rank blocks, one per 192 positions, so that one rank4() touches exactly one 128-byte
+// line (the reference layout needs a 64-byte count line plus a 32-byte bit group in another line):
+//     chunk 0      u32 abs[4]    cumulative rank of bitvector c at the block start
+//     chunk 1+2s   u64 bits of bitvectors 0,1 for positions [64s, 64s+64) of the block (s = 0..2)
+//     chunk 2+2s   u64 bits of bitvectors 2,3
+//     chunk 7      u8 in1[4], u8 in2[4]: set bits in sub-word 0 / sub-words 0..1 (then 8 spare bytes)
+// rank = abs + in[s] + popcount(bits & lowmask): four loads (16+8+16+16 B) from one line.
+// The BWT symbol needed by LF is decoded from the same bit chunks (the bitvectors are cumulative:
+// bwtrepr.h:67-68), so the 3-bit EncodedText (.bwt) is not kept on the device at all.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,8 +26,7 @@
 namespace cmb {
 
 struct DevBWT {
-    const uint64_t* bv;  // 4 words per 64 positions
-    const uint64_t* cnt; // 8 words per 512 positions
+    const uint4* blk; // 8 x 16 B per 192 positions (see above)
     uint32_t dollarPos;
 };
 
@@ -50,44 +54,105 @@ struct RangePair {
     __host__ __device__ uint32_t width() const { return sa.width(); }
 };
 
-// ranks of the four cumulative bitvectors at position p: R[i] = #{j < p : 1 <= BWT[j] <= i+1}
-__device__ __forceinline__ void rank4(const DevBWT& t, uint32_t p, uint32_t R[4]) {
+constexpr uint32_t RANK_BLOCK = 192; // positions per rank block
+
+struct RankChunks { // what one position needs from its block
+    uint4 abs;
+    uint2 in;
+    ulonglong2 b0, b1;
+    uint32_t sub, bit;
+};
+__device__ __forceinline__ void loadRankChunks(const DevBWT& t, uint32_t p, RankChunks& k) {
     const uint32_t w = p >> 6;
-    const uint32_t b = p & 63u;
-    const ulonglong2* cl = reinterpret_cast<const ulonglong2*>(t.cnt + (size_t)(p >> 9) * 8);
-    const ulonglong2* bl = reinterpret_cast<const ulonglong2*>(t.bv + (size_t)w * 4);
-    const ulonglong2 c0 = cl[0], c1 = cl[1], c2 = cl[2], c3 = cl[3];
-    const ulonglong2 b0 = bl[0], b1 = bl[1];
-    const uint32_t sub = w & 7u; // word within the 512-position block
-    // bitvec.h:367-368: L2 partial of word `sub` (0 for the first word)
-    const uint32_t sh = (sub == 0) ? 0u : (sub - 1u) * 9u;
-    const uint64_t m = (sub == 0) ? 0ull : 0x1FFull;
-    // bitvec.h:371: bits below position b
-    const uint64_t lowmask = (b == 0) ? 0ull : (~0ull >> (64u - b));
-    R[0] = (uint32_t)(c0.x + ((c0.y >> sh) & m)) + (uint32_t)__popcll(b0.x & lowmask);
-    R[1] = (uint32_t)(c1.x + ((c1.y >> sh) & m)) + (uint32_t)__popcll(b0.y & lowmask);
-    R[2] = (uint32_t)(c2.x + ((c2.y >> sh) & m)) + (uint32_t)__popcll(b1.x & lowmask);
-    R[3] = (uint32_t)(c3.x + ((c3.y >> sh) & m)) + (uint32_t)__popcll(b1.y & lowmask);
+    const uint32_t blk = __umulhi(w, 0xAAAAAAABu) >> 1; // w / 3
+    k.sub = w - 3u * blk;
+    k.bit = p & 63u;
+    const uint4* B = t.blk + (size_t)blk * 8;
+    k.abs = B[0];
+    k.in = *reinterpret_cast<const uint2*>(B + 7);
+    const ulonglong2* bl = reinterpret_cast<const ulonglong2*>(B) + 1 + 2 * k.sub;
+    k.b0 = bl[0];
+    k.b1 = bl[1];
+}
+__device__ __forceinline__ void ranksFromChunks(const RankChunks& k, uint32_t R[4]) {
+    const uint32_t in = k.sub == 0 ? 0u : (k.sub == 1 ? k.in.x : k.in.y);
+    // bitvec.h:371: bits below position `bit`
+    const uint64_t lowmask = (k.bit == 0) ? 0ull : (~0ull >> (64u - k.bit));
+    R[0] = k.abs.x + (in & 0xFFu) + (uint32_t)__popcll(k.b0.x & lowmask);
+    R[1] = k.abs.y + ((in >> 8) & 0xFFu) + (uint32_t)__popcll(k.b0.y & lowmask);
+    R[2] = k.abs.z + ((in >> 16) & 0xFFu) + (uint32_t)__popcll(k.b1.x & lowmask);
+    R[3] = k.abs.w + (in >> 24) + (uint32_t)__popcll(k.b1.y & lowmask);
+}
+
+// the same as four raw 16-byte chunks {abs, in(+spare), bits01, bits23} (callers that share the
+// reply registers with other kinds of loads)
+__device__ __forceinline__ void loadRankChunksRaw(const DevBWT& t, uint32_t p, uint4 v[4]) {
+    const uint32_t w = p >> 6;
+    const uint32_t blk = __umulhi(w, 0xAAAAAAABu) >> 1;
+    const uint32_t sub = w - 3u * blk;
+    const uint4* B = t.blk + (size_t)blk * 8;
+    v[0] = B[0];
+    v[1] = B[7];
+    v[2] = B[1 + 2 * sub];
+    v[3] = B[2 + 2 * sub];
+}
+__device__ __forceinline__ void ranksFromRaw(const uint4 v[4], uint32_t p, uint32_t R[4]) {
+    const uint32_t w = p >> 6;
+    const uint32_t sub = w - 3u * (__umulhi(w, 0xAAAAAAABu) >> 1);
+    const uint32_t bit = p & 63u;
+    const uint32_t in = sub == 0 ? 0u : (sub == 1 ? v[1].x : v[1].y);
+    const uint64_t lowmask = (bit == 0) ? 0ull : (~0ull >> (64u - bit));
+    const uint32_t mlo = (uint32_t)lowmask, mhi = (uint32_t)(lowmask >> 32);
+    R[0] = v[0].x + (in & 0xFFu) + (uint32_t)__popc(v[2].x & mlo) + (uint32_t)__popc(v[2].y & mhi);
+    R[1] = v[0].y + ((in >> 8) & 0xFFu) + (uint32_t)__popc(v[2].z & mlo) + (uint32_t)__popc(v[2].w & mhi);
+    R[2] = v[0].z + ((in >> 16) & 0xFFu) + (uint32_t)__popc(v[3].x & mlo) + (uint32_t)__popc(v[3].y & mhi);
+    R[3] = v[0].w + (in >> 24) + (uint32_t)__popc(v[3].z & mlo) + (uint32_t)__popc(v[3].w & mhi);
+}
+
+// ranks of the four cumulative bitvectors at position p: R[i] = #{j < p : 1 <= BWT[j] <= i+1}
+// (BitvecIntl<4>::rank, bitvec.h:356-372, on the re-packed blocks)
+__device__ __forceinline__ void rank4(const DevBWT& t, uint32_t p, uint32_t R[4]) {
+    RankChunks k;
+    loadRankChunks(t, p, k);
+    ranksFromChunks(k, R);
 }
 
 // single rank(c, p) — test hook
 __device__ __forceinline__ uint64_t rank1(const DevBWT& t, uint32_t c, uint64_t p) {
-    uint64_t w = (p / 64) * 4 + c;
-    uint64_t b = p % 64;
-    uint64_t q = (p / 512) * 8 + 2 * c;
-    uint64_t rv = t.cnt[q];
-    uint64_t sub = (p / 64) % 8;
-    if (sub) rv += (t.cnt[q + 1] >> ((sub - 1) * 9)) & 0x1FF;
-    uint64_t lowmask = b ? (~0ull >> (64 - b)) : 0ull;
-    return rv + __popcll(t.bv[w] & lowmask);
+    uint32_t R[4];
+    rank4(t, (uint32_t)p, R);
+    return R[c];
+}
+
+// BitvecIntl<4>::rank on the reference's own layout (bitvec.h:356-372); used once, by k_relayout.
+// p == N (one past the last position) is answered from position N-1 so that no word past the
+// reference arrays is touched.
+__device__ __forceinline__ uint32_t rankRefLayout(const uint64_t* bv, const uint64_t* cnt, uint32_t c, uint64_t p,
+                                                  uint64_t N) {
+    uint32_t extra = 0;
+    if (p >= N) {
+        p = N - 1;
+        extra = (uint32_t)((bv[(p / 64) * 4 + c] >> (p % 64)) & 1ull);
+    }
+    const uint64_t q = (p / 512) * 8 + 2 * c;
+    uint64_t rv = cnt[q];
+    const uint64_t sub = (p / 64) % 8;
+    if (sub) rv += (cnt[q + 1] >> ((sub - 1) * 9)) & 0x1FF;
+    const uint64_t b = p % 64;
+    const uint64_t lowmask = b ? (~0ull >> (64 - b)) : 0ull;
+    return (uint32_t)rv + (uint32_t)__popcll(bv[(p / 64) * 4 + c] & lowmask) + extra;
 }
 
 // occ(c,k), cumOcc(c,k) for c = 1..4 from the four cumulative ranks (bwtrepr.h:80-107)
+// (R[] is selected, not indexed: with a run-time c an indexed private array would live in scratch)
+__device__ __forceinline__ uint32_t pickR(const uint32_t R[4], uint32_t i) {
+    return i == 0 ? R[0] : i == 1 ? R[1] : i == 2 ? R[2] : R[3];
+}
 __device__ __forceinline__ uint32_t occFromR(const uint32_t R[4], uint32_t c) {
-    return c == 1 ? R[0] : R[c - 1] - R[c - 2];
+    return c == 1 ? R[0] : pickR(R, c - 1) - pickR(R, c - 2);
 }
 __device__ __forceinline__ uint32_t cumFromR(const uint32_t R[4], uint32_t c, uint32_t dollarFlag) {
-    return (c == 1 ? 0u : R[c - 2]) + dollarFlag;
+    return (c == 1 ? 0u : pickR(R, c - 2)) + dollarFlag;
 }
 
 // Extend `p` with character index c (1..4).  mode: 0 forward, 1 backward, 2 uni-directional
@@ -124,8 +189,13 @@ __device__ __forceinline__ bool childFromRanks(const DevIndex& ix, int mode, con
 __device__ __forceinline__ void loadExtendRanks(const DevIndex& ix, int mode, const RangePair& p,
                                                 uint32_t Rb[4], uint32_t Re[4], uint32_t& db,
                                                 uint32_t& de) {
-    const DevBWT& t = (mode == 0) ? ix.rev : ix.fwd;
-    const Range& tr = (mode == 0) ? p.rev : p.sa;
+    // values, not references, are selected: a select between two addresses keeps the objects in memory
+    DevBWT t = ix.fwd;
+    Range tr = p.sa;
+    if (mode == 0) {
+        t = ix.rev;
+        tr = p.rev;
+    }
     rank4(t, tr.b, Rb);
     rank4(t, tr.e, Re);
     db = tr.b > t.dollarPos ? 1u : 0u;
@@ -161,13 +231,13 @@ __device__ __forceinline__ uint32_t findLF(const DevIndex& ix, uint32_t k) {
         // symbol '$' (index 0): counts[0] + occ(0,k) = 0 + (k <= dollarPos ? 0 : 1) = 0
         return ix.counts[0];
     }
+    RankChunks ch;
+    loadRankChunks(t, k, ch);
     uint32_t R[4];
-    rank4(t, k, R);
-    const ulonglong2* bl = reinterpret_cast<const ulonglong2*>(t.bv + (size_t)(k >> 6) * 4);
-    const ulonglong2 b0 = bl[0], b1 = bl[1];
-    const uint32_t bit = k & 63u;
+    ranksFromChunks(ch, R);
+    const uint32_t bit = ch.bit;
     // smallest c with bit (c-1) set
-    uint32_t c = ((b0.x >> bit) & 1ull) ? 1u : ((b0.y >> bit) & 1ull) ? 2u : ((b1.x >> bit) & 1ull) ? 3u : 4u;
+    const uint32_t c = ((ch.b0.x >> bit) & 1ull) ? 1u : ((ch.b0.y >> bit) & 1ull) ? 2u : ((ch.b1.x >> bit) & 1ull) ? 3u : 4u;
     return ix.counts[c] + occFromR(R, c);
 }
 

@@ -55,26 +55,30 @@ struct MatGeom {
     __device__ __forceinline__ uint32_t firstColumn(uint32_t i) const { return i <= Wv ? 0u : i - Wv; } // :670
 };
 
-// initializeMatrix (bitparallelmatrix.cpp:77-123).  initED[0..nInit) (nInit >= 1 here; the
-// reference's empty vector is only used by findCIGAR / the naive search).
-__device__ __forceinline__ void initMatrix(MatGeom& g, uint32_t xLen, uint32_t maxED, const uint32_t* initED,
-                                           uint32_t nInit, uint64_t& HP0, uint64_t& HN0, uint64_t& RAC0,
-                                           uint32_t& score0) {
+// initializeMatrix (bitparallelmatrix.cpp:77-123).  The initial edit distances are
+// initED[i] = raw[i] + increase for i in [0, nInit) (nInit >= 1 here; the reference's empty vector is
+// only used by findCIGAR / the naive search); `first` / `last` are initED[0] / initED[nInit-1].  The
+// first column is built from raw[] on the fly — no private array of initial distances is needed (it
+// would live in scratch memory).
+__device__ __forceinline__ void initMatrix(MatGeom& g, uint32_t xLen, uint32_t maxED, uint32_t first, uint32_t last,
+                                           const uint16_t* raw, uint32_t increase, uint32_t nInit, uint64_t& HP0,
+                                           uint64_t& HN0, uint64_t& RAC0, uint32_t& score0) {
     g.n = xLen + 1;
     g.maxED = maxED;
-    g.Wv = nInit - 1 + maxED - initED[nInit - 1];
+    g.Wv = nInit - 1 + maxED - last;
     g.m = g.Wv + g.n;
-    score0 = initED[0];
+    score0 = first;
     g.Wh = maxED - score0;
     if (g.Wv + g.Wh + 1 > g.m) g.m = g.Wv + g.Wh + 1;
     HP0 = (~0ull) << MX_LEFT;
     HN0 = ~HP0;
     const uint32_t nn = nInit < MX_LEFT + 1 ? nInit : MX_LEFT + 1;
     for (uint32_t i = 1; i < nn; ++i) {
-        if (initED[i] < initED[i - 1]) {
+        const uint32_t cur = raw[i] + increase, prev = raw[i - 1] + increase; // length_t arithmetic
+        if (cur < prev) {
             HP0 ^= 1ull << (MX_LEFT - i);
             HN0 ^= 1ull << (MX_LEFT - i);
-        } else if (initED[i] == initED[i - 1]) {
+        } else if (cur == prev) {
             HN0 ^= 1ull << (MX_LEFT - i);
         }
     }

@@ -30,7 +30,9 @@ struct PartOut { // per read x strand: the parts, needed again by k_dfs
     uint16_t pb[MAXP], pe[MAXP];
 };
 
-enum : int { PH_CALC = 0, PH_DYN, PH_POST, PH_SEARCH, PH_EXACT, PH_K0, PH_DONE };
+enum : int { PH_CALC = 0, PH_DYN, PH_POST, PH_SEARCH, PH_EXACT, PH_K0, PH_SEED, PH_DONE };
+// what a lane asks of the iteration's single memory step
+enum : int { RQ_NONE = 0, RQ_RANK, RQ_SEED, RQ_REC };
 
 struct PartMachine {
     const DevIndex& ix;
@@ -84,8 +86,9 @@ struct PartMachine {
     uint32_t exactLength = 0;
     RangePair cur;       // range being extended (PH_EXACT / PH_K0)
     uint32_t k0i = 0;    // PH_K0
-    // pending extension request
-    bool req = false;
+    int postI = 0;       // PH_POST: next part to pre-verify
+    // pending request for the memory step (RQ_RANK: extension of reqParent with reqCode)
+    int req = RQ_NONE;
     int reqMode = 0;
     uint32_t reqCode = 0;
     RangePair reqParent;
@@ -94,64 +97,109 @@ struct PartMachine {
                            uint32_t* ldsBase, uint32_t tid, uint32_t stride)
         : ix(i), st(s), q(qq), dfsQ(dq), dfsCap(dc), lds(ldsBase), ltid(tid), lstride(stride),
           lparts(s.numParts ? s.numParts : 1) {}
+    __device__ void setReadWords(uint32_t maxLen) { // LDS words after the 5 x lparts partition fields
+        rdBase = 5u * lparts;
+        pw1 = (maxLen + 31) / 32;
+    }
 
     // ---- emission ---------------------------------------------------------------------------
-    __device__ __forceinline__ void emitItems(const Range& sa, uint32_t a, uint32_t meta) {
+    // Work items and DFS tasks are STAGED (at most one group of each per advance()/resume()); the
+    // kernel appends the staged records of the whole wavefront with one atomic (waveAppend).
+    uint32_t stN = 0, stB = 0, stA = 0, stMeta = 0, stRs = 0;
+    bool stDfs = false;
+    DfsTask stTask;
+    __device__ __forceinline__ bool emitItems(const Range& sa, uint32_t a, uint32_t meta) {
         const uint32_t w = sa.width();
-        if (!w) return;
-        if (q.dbg & 2u) return;
-        const uint32_t base = atomicAdd(&q.cnt[0], w);
-        if (base + w > q.itemCap) {
-            flags |= FLAG_ITEM_OVERFLOW;
-            return;
-        }
-        for (uint32_t t = 0; t < w; t++) q.items[base + t] = make_uint4(rsId, sa.b + t, a, meta);
+        if (!w) return false;
+        stN = w;
+        stB = sa.b;
+        stA = a;
+        stMeta = meta;
+        stRs = rsId;
+        return true;
     }
     __device__ __forceinline__ void emitDfs(int idx, const RangePair& r, uint32_t depth) {
-        const uint32_t base = atomicAdd(&q.cnt[5], 1u);
-        if (base >= dfsCap) {
-            flags |= FLAG_DFS_OVERFLOW;
-            return;
-        }
-        DfsTask t;
-        t.rsId = rsId;
-        t.scheme = (uint8_t)sel;
-        t.search = (uint8_t)si;
-        t.idx = (uint8_t)idx;
-        t.pad = 0;
-        t.r = r;
-        t.depth = depth;
-        dfsQ[base] = t;
+        stTask.rsId = rsId;
+        stTask.scheme = (uint8_t)sel;
+        stTask.search = (uint8_t)si;
+        stTask.idx = (uint8_t)idx;
+        stTask.pad = 0;
+        stTask.r = r;
+        stTask.depth = depth;
+        stDfs = true;
     }
 
     // ---- helpers ----------------------------------------------------------------------------
+    // The read is kept in LDS as two bit-strings (low / high bit of code-1), built at begin() from the
+    // match bit-strings k_prep wrote, so that the character of an extension costs no global load.
+    // Reads with a non-ACGT character (hasN) take the byte path.
+    uint32_t rdBase = 0, pw1 = 1;
+    bool hasN = false;
+    __device__ __forceinline__ uint32_t& RD(uint32_t plane, uint32_t w) const {
+        return lds[(rdBase + plane * pw1 + w) * lstride + ltid];
+    }
+    __device__ __forceinline__ uint32_t code(uint32_t i) const {
+        if (hasN) return seq[i];
+        const uint32_t w = i >> 5, b = i & 31u;
+        return 1u + ((RD(0, w) >> b) & 1u) + 2u * ((RD(1, w) >> b) & 1u);
+    }
     __device__ __forceinline__ uint32_t charAt(uint32_t b, uint32_t e, int d, uint32_t i) const {
-        return d == 0 ? seq[b + i] : seq[e - i - 1];
+        return code(d == 0 ? b + i : e - i - 1);
+    }
+    __device__ __forceinline__ uint32_t kmerKey(uint32_t begin, uint32_t end, bool& valid) const {
+        valid = true;
+        uint32_t key = 0;
+        if (hasN) {
+            for (uint32_t i = begin; i < end; i++)
+                if (seq[i] > 4) valid = false;
+            if (!valid) return 0;
+            for (uint32_t i = 0; i < ix.kmerSize; i++) key = (key << 2) | (uint32_t)(seq[begin + i] - 1);
+            return key;
+        }
+        const uint32_t w = begin >> 5, b = begin & 31u;
+        const bool more = w + 1 < pw1;
+        const uint64_t lo = ((uint64_t)RD(0, w) | ((uint64_t)(more ? RD(0, w + 1) : 0u) << 32)) >> b;
+        const uint64_t hi = ((uint64_t)RD(1, w) | ((uint64_t)(more ? RD(1, w + 1) : 0u) << 32)) >> b;
+        for (uint32_t i = 0; i < ix.kmerSize; i++)
+            key = (key << 2) | (uint32_t)(((hi >> i) & 1ull) << 1) | (uint32_t)((lo >> i) & 1ull);
+        return key;
     }
     __device__ __forceinline__ RangePair kmer(uint32_t begin, uint32_t end) const { // indexinterface.h:590
-        for (uint32_t i = begin; i < end; i++)
-            if (seq[i] > 4) return RangePair{{0, 0}, {0, 0}};
-        uint32_t key = 0;
-        for (uint32_t i = 0; i < ix.kmerSize; i++) key = (key << 2) | (uint32_t)(seq[begin + i] - 1);
+        bool valid;
+        const uint32_t key = kmerKey(begin, end, valid);
+        if (!valid) return RangePair{{0, 0}, {0, 0}};
         const uint4 v = ix.kmer[key];
         return RangePair{{v.x, v.y}, {v.z, v.w}};
     }
     __device__ __forceinline__ void request(int mode, const RangePair& parent, uint32_t code) {
-        req = true;
+        req = RQ_RANK;
         reqMode = mode;
         reqParent = parent;
         reqCode = code;
     }
 
     // ---- task start -------------------------------------------------------------------------
-    __device__ void begin(uint32_t rs, uint32_t length, const uint8_t* s, uint32_t kk) {
+    // The read record k_prep wrote (len | hasN << 16, then (low, high) code-bit word pairs) has arrived
+    // in v[]: unpack it into LDS and start the prologue of read x strand `rs`.
+    __device__ void begin(uint32_t rs, const uint4 v[5], const uint8_t* s, uint32_t kk) {
         rsId = rs;
-        len = length;
         seq = s;
         k = kk;
-        req = false;
+        {
+            const uint32_t* vw = reinterpret_cast<const uint32_t*>(v);
+            len = vw[0] & 0xFFFFu;
+            hasN = (vw[0] >> 16) & 1u;
+#pragma unroll
+            for (uint32_t w = 0; w < 8; w++) // MAX_READ / 32 words per bit-string at most
+                if (w < pw1) { // record words: header, then (low, high) pairs
+                    RD(0, w) = vw[1 + 2 * w];
+                    RD(1, w) = vw[2 + 2 * w];
+                }
+        }
+        req = RQ_NONE;
         partToExtend = 0;
         dynDir = 0;
+        postI = 0;
         if (k == 0) { // exactMatchesOutput (indexinterface.cpp:947-1014)
             if (len == 0) {
                 phase = PH_DONE;
@@ -199,21 +247,40 @@ struct PartMachine {
                 setPBE(i, b, (b + wSize) & 0xFFFFu);
             }
             setPBE(numParts - 1, L - wSize, L);
-            for (int i = 0; i < numParts; i++) {
-                if (useKmer) {
-                    setEX(i, kmer(PB(i), PE(i)));
-                } else { // getRangeOfSingleChar (fmindex.cpp:434-445)
-                    const uint32_t code = seq[PB(i)];
-                    if (code < 1 || code > 4) setEX(i, RangePair{{0, 0}, {0, 0}});
-                    else {
-                        const uint32_t lo = ix.counts[code], hi = code < 4 ? ix.counts[code + 1] : ix.n;
-                        setEX(i, RangePair{{lo, hi}, {lo, hi}});
-                    }
+            j = (uint32_t)(numParts * wSize);
+            if (useKmer) { // the k-mer table entries of all parts are fetched together in the memory step
+                phase = PH_SEED;
+                req = RQ_SEED;
+                return;
+            }
+            for (int i = 0; i < numParts; i++) { // getRangeOfSingleChar (fmindex.cpp:434-445)
+                const uint32_t code = this->code(PB(i));
+                if (code < 1 || code > 4) setEX(i, RangePair{{0, 0}, {0, 0}});
+                else {
+                    const uint32_t lo = ix.counts[code], hi = code < 4 ? ix.counts[code + 1] : ix.n;
+                    setEX(i, RangePair{{lo, hi}, {lo, hi}});
                 }
             }
-            j = (uint32_t)(numParts * wSize);
             phase = PH_DYN;
         }
+    }
+
+    // RQ_SEED: issue the k-mer table loads of all parts (indexinterface.h:590), then take the replies
+    __device__ __forceinline__ void seedIssue(uint4 v[8]) const {
+#pragma unroll
+        for (int i = 0; i < MAXP; i++)
+            if (i < numParts) {
+                bool valid;
+                const uint32_t key = kmerKey(PB(i), PE(i), valid);
+                v[i] = make_uint4(0, 0, 0, 0);
+                if (valid) v[i] = ix.kmer[key];
+            }
+    }
+    __device__ __forceinline__ void seedTake(const uint4 v[8]) {
+#pragma unroll
+        for (int i = 0; i < MAXP; i++)
+            if (i < numParts) setEX(i, RangePair{{v[i].x, v[i].y}, {v[i].z, v[i].w}});
+        phase = PH_DYN;
     }
 
     // calculateExactMatchRanges (:158-190): stages 0..P-1 match EVERY part forwards (the loop at :166
@@ -308,11 +375,11 @@ struct PartMachine {
                 if (dynDir == 0) {
                     const uint32_t e = PE(partToExtend) + 1;
                     setPE(partToExtend, e);
-                    code = seq[e - 1];
+                    code = this->code(e - 1);
                 } else {
                     const uint32_t b = PB(partToExtend) - 1;
                     setPB(partToExtend, b);
-                    code = seq[b];
+                    code = this->code(b);
                 }
                 j++;
                 if (code >= 1 && code <= 4) {
@@ -324,7 +391,8 @@ struct PartMachine {
             }
             case PH_POST: { // searchstrategy.cpp:464-481
                 const uint32_t sw = ix.switchPoint;
-                for (int i = 0; i < numParts; i++) {
+                while (postI < numParts) {
+                    const int i = postI++;
                     const uint32_t width = EXW(i);
                     if (width != 0 && width <= sw) {
                         const uint32_t bg = PB(i);
@@ -335,6 +403,7 @@ struct PartMachine {
                         } else {
                             emitItems(sa, bg, packMeta(0, k, 0, 0, ITEM_HAMMING));
                         }
+                        return; // one staged group per scheduling step
                     }
                 }
                 sel = 0; // MultipleSchemes::createSearches (searchstrategy.h:2505-2537)
@@ -367,7 +436,7 @@ struct PartMachine {
                     if (st.metric == 1) cStart++; // recApproxMatchEditEntry: complete range > switch point
                     emitDfs(0, RangePair{{0, ix.n}, {0, ix.n}}, 0);
                     si++;
-                    break;
+                    return;
                 }
                 const int first = s.order[0];
                 cur = EX(first);
@@ -418,7 +487,7 @@ struct PartMachine {
                 }
                 si++;
                 phase = PH_SEARCH;
-                break;
+                return;
             }
             case PH_K0: {
                 if (k0i == 0) { // everything matched in the index
@@ -426,7 +495,7 @@ struct PartMachine {
                     phase = PH_DONE;
                     return;
                 }
-                const uint32_t code = seq[k0i - 1];
+                const uint32_t code = this->code(k0i - 1);
                 if (code > 4) {
                     phase = PH_DONE;
                     return;

@@ -25,6 +25,41 @@ __global__ void k_rank(DevIndex ix, int rev, const uint32_t* __restrict__ c, con
     out[i] = rank1(rev ? ix.rev : ix.fwd, c[i], p[i]);
 }
 
+// Re-pack one BWT's reference arrays into 128-byte rank blocks (dev_index.hpp); one thread per block.
+__global__ void k_relayout(const uint64_t* __restrict__ bv, const uint64_t* __restrict__ cnt, uint64_t N,
+                           uint64_t nBlocks, uint4* __restrict__ out) {
+    const uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= nBlocks) return;
+    const uint64_t nWords = (N + 63) / 64;
+    uint64_t bits[3][4];
+    for (uint32_t s = 0; s < 3; s++)
+        for (uint32_t c = 0; c < 4; c++) {
+            const uint64_t w = blk * 3 + s;
+            bits[s][c] = w < nWords ? bv[w * 4 + c] : 0ull;
+        }
+    uint4 abs;
+    abs.x = rankRefLayout(bv, cnt, 0, blk * RANK_BLOCK, N);
+    abs.y = rankRefLayout(bv, cnt, 1, blk * RANK_BLOCK, N);
+    abs.z = rankRefLayout(bv, cnt, 2, blk * RANK_BLOCK, N);
+    abs.w = rankRefLayout(bv, cnt, 3, blk * RANK_BLOCK, N);
+    uint32_t in1 = 0, in2 = 0;
+    for (uint32_t c = 0; c < 4; c++) {
+        const uint32_t p0 = (uint32_t)__popcll(bits[0][c]);
+        const uint32_t p1 = p0 + (uint32_t)__popcll(bits[1][c]);
+        in1 |= p0 << (8 * c);
+        in2 |= p1 << (8 * c);
+    }
+    uint4* B = out + blk * 8;
+    B[0] = abs;
+    for (uint32_t s = 0; s < 3; s++) {
+        B[1 + 2 * s] = make_uint4((uint32_t)bits[s][0], (uint32_t)(bits[s][0] >> 32), (uint32_t)bits[s][1],
+                                  (uint32_t)(bits[s][1] >> 32));
+        B[2 + 2 * s] = make_uint4((uint32_t)bits[s][2], (uint32_t)(bits[s][2] >> 32), (uint32_t)bits[s][3],
+                                  (uint32_t)(bits[s][3] >> 32));
+    }
+    B[7] = make_uint4(in1, in2, 0u, 0u);
+}
+
 // all four children of each parent; one thread per parent.
 __global__ void __launch_bounds__(256)
 k_extend(DevIndex ix, int mode, const uint4* __restrict__ in, uint64_t n, uint4* __restrict__ out,
@@ -80,13 +115,21 @@ __global__ void k_kmer_table(DevIndex ix, uint4* __restrict__ table) {
 //   A = read[32w .. 32w+32)   and   B = read[L-1-32w-t], t = 0..31
 __global__ void __launch_bounds__(256)
 k_prep(const uint8_t* __restrict__ reads, const uint64_t* __restrict__ offs, uint32_t nReads, uint32_t maxLen,
-       uint32_t gw, uint32_t chunks, uint8_t* __restrict__ seq, uint32_t* __restrict__ G) {
+       uint32_t gw, uint32_t chunks, uint8_t* __restrict__ seq, uint32_t* __restrict__ G, uint32_t* __restrict__ rec,
+       uint32_t recW) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t r = gid / chunks, w = gid % chunks;
     if (r >= nReads) return;
     const uint8_t* rd = reads + offs[r];
     const uint32_t len = (uint32_t)(offs[r + 1] - offs[r]);
-    if (len > maxLen || 32 * w >= len) return;
+    if (len > maxLen) return;
+    if (32 * w >= len) {
+        if (w == 0 && rec) { // empty read: header only (rec is zeroed beforehand)
+            rec[(size_t)(2 * r) * recW] = 0;
+            rec[(size_t)(2 * r + 1) * recW] = 0;
+        }
+        return;
+    }
     uint32_t fA[4] = {0, 0, 0, 0}, fB[4] = {0, 0, 0, 0}; // bit t set: A[t] / B[t] is that nucleotide
     uint8_t* sF = seq + (size_t)(2 * r) * maxLen;
     uint8_t* sR = seq + (size_t)(2 * r + 1) * maxLen;
@@ -111,6 +154,23 @@ k_prep(const uint8_t* __restrict__ reads, const uint64_t* __restrict__ offs, uin
         gR[ch * gw + w] = fB[3 - ch];         // strand R, position i      : comp(read[L-1-i])
         gR[(4 + ch) * gw + w] = fA[3 - ch];   // strand R reversed, pos ri : comp(read[ri])
     }
+    if (rec) {
+        // read record for k_partition: word 0 = len | hasN << 16 (rec zeroed beforehand, chunks OR into it),
+        // then per 32 characters the low / high bit of (code - 1): A=00 C=01 G=10 T=11
+        uint32_t* rF = rec + (size_t)(2 * r) * recW;
+        uint32_t* rR = rec + (size_t)(2 * r + 1) * recW;
+        const uint32_t valid = nT >= 32 ? 0xFFFFFFFFu : ((1u << nT) - 1u);
+        const uint32_t nA = valid & ~(fA[0] | fA[1] | fA[2] | fA[3]);
+        const uint32_t nB = valid & ~(fB[0] | fB[1] | fB[2] | fB[3]);
+        rF[1 + 2 * w] = fA[1] | fA[3];
+        rF[2 + 2 * w] = fA[2] | fA[3];
+        rR[1 + 2 * w] = fB[2] | fB[0]; // strand R position i is comp(read[L-1-i])
+        rR[2 + 2 * w] = fB[1] | fB[0];
+        const uint32_t hF = (w == 0 ? len : 0u) | (nA ? 0x10000u : 0u);
+        const uint32_t hR = (w == 0 ? len : 0u) | (nB ? 0x10000u : 0u);
+        if (hF) atomicOr(&rF[0], hF);
+        if (hR) atomicOr(&rR[0], hR);
+    }
 }
 
 __device__ __forceinline__ void flushCounters(const Queues& q, const uint32_t* local, const int* which, int n) {
@@ -118,53 +178,6 @@ __device__ __forceinline__ void flushCounters(const Queues& q, const uint32_t* l
         if (local[i]) atomicAdd(&q.counters[which[i]], (unsigned long long)local[i]);
 }
 
-// ------------------------------------------------------------------ prologue: the rank/extend kernel
-// One lane per read x strand.  Every loop iteration performs at most ONE bidirectional extension per
-// lane, at one common program point: 2 positions x (4 x 16 B of the 64-byte counts line + 2 x 16 B of
-// the 32-byte bit group) = 12 independent 16-byte loads per lane in flight, whatever phase of the
-// prologue the lane's read is in (dev_partition.hpp).
-__global__ void __launch_bounds__(256, 4)
-k_partition(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* __restrict__ offs, uint32_t nReads,
-            uint32_t k, uint32_t maxLen, const uint8_t* __restrict__ seq, PartOut* __restrict__ parts,
-            DfsTask* __restrict__ dfsQ, uint32_t dfsCap, Queues q) {
-    extern __shared__ uint32_t partLds[]; // 5 fields x numParts x blockDim.x words
-    PartMachine m(ix, *stp, q, dfsQ, dfsCap, partLds, threadIdx.x, blockDim.x);
-    const uint32_t total = 2 * nReads;
-    uint32_t nextRs = blockIdx.x * blockDim.x + threadIdx.x;
-    for (;;) {
-        if (m.phase == PH_DONE) {
-            // static round-robin assignment: the prologue of every read costs about the same, and a
-            // shared work counter would serialise on one L2 atomic unit (~90 fetches/us)
-            const uint32_t rs = nextRs;
-            nextRs += gridDim.x * blockDim.x;
-            if (rs >= total) break;
-            const uint32_t r = rs >> 1;
-            m.begin(rs, (uint32_t)(offs[r + 1] - offs[r]), seq + (size_t)rs * maxLen, k);
-        }
-        m.advance();
-        if (m.phase == PH_DONE && k > 0 && !(m.flags & FLAG_UNSUPPORTED_READ)) {
-            PartOut po;
-#pragma unroll
-            for (int i = 0; i < MAXP; i++) {
-                po.pb[i] = i < m.numParts ? (uint16_t)m.PB(i) : (uint16_t)0;
-                po.pe[i] = i < m.numParts ? (uint16_t)m.PE(i) : (uint16_t)0;
-            }
-            parts[m.rsId] = po;
-        }
-        if (m.req) {
-            RangePair child;
-            const bool ok = extendOne(ix, m.reqMode, m.reqParent, m.reqCode, child);
-            m.req = false;
-            m.resume(ok, child);
-        }
-    }
-    const uint32_t local[4] = {m.cNode, m.cExp, m.cImm, m.cStart};
-    const int which[4] = {0, 7, 5, 6};
-    flushCounters(q, local, which, 4);
-    if (m.flags) atomicOr(&q.cnt[3], m.flags);
-}
-
-// ------------------------------------------------------------------ approximate DFS over the scheme
 // wave-wide exclusive prefix sum (all 64 lanes must call)
 __device__ __forceinline__ uint32_t waveExclusiveScan(uint32_t v, uint32_t& total) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -187,6 +200,161 @@ __device__ __forceinline__ uint32_t waveAppend(uint32_t* counter, uint32_t n, ui
     }
     return base + off;
 }
+
+// Wave-aggregated reservation whose reply is consumed one loop iteration later, so that the atomic's
+// round trip overlaps the next iteration's rank loads instead of stalling the wavefront.
+struct WaveReserve {
+    uint32_t raw = 0, pre = 0;
+    bool pend = false; // wave-uniform
+    __device__ __forceinline__ void issue(uint32_t* counter, uint32_t n) { // all 64 lanes
+        uint32_t total;
+        pre = waveExclusiveScan(n, total);
+        if ((threadIdx.x & 63u) == 0) raw = atomicAdd(counter, total);
+        pend = true;
+    }
+    __device__ __forceinline__ uint32_t take() { // all 64 lanes
+        pend = false;
+        return __shfl(raw, 0) + pre;
+    }
+};
+
+// ------------------------------------------------------------------ prologue: the rank/extend kernel
+// One lane per read x strand.  Every loop iteration performs at most ONE bidirectional extension per
+// lane, at one common program point: 2 positions x (4 x 16 B of the 64-byte counts line + 2 x 16 B of
+// the 32-byte bit group) = 12 independent 16-byte loads per lane in flight, whatever phase of the
+// prologue the lane's read is in (dev_partition.hpp).
+__global__ void __launch_bounds__(256, 4)
+k_partition(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* __restrict__ offs, uint32_t nReads,
+            uint32_t k, uint32_t maxLen, const uint8_t* __restrict__ seq, const uint4* __restrict__ rec,
+            uint32_t recQ, PartOut* __restrict__ parts, DfsTask* __restrict__ dfsQ, uint32_t dfsCap, Queues q) {
+    // LDS: a copy of the strategy tables (indexed per lane by scheme / search / phase), then per lane
+    // 5 x numParts partition words and 2 x ceil(maxLen/32) read words
+    extern __shared__ uint32_t partLds[];
+    constexpr uint32_t STRAT_WORDS = (uint32_t)((sizeof(DevStrategyK) + 15) / 16 * 4);
+    for (uint32_t i = threadIdx.x; i < sizeof(DevStrategyK) / 4; i += blockDim.x)
+        partLds[i] = reinterpret_cast<const uint32_t*>(stp)[i];
+    __syncthreads();
+    const DevStrategyK& lst = *reinterpret_cast<const DevStrategyK*>(partLds);
+    PartMachine m(ix, lst, q, dfsQ, dfsCap, partLds + STRAT_WORDS, threadIdx.x, blockDim.x);
+    m.setReadWords(maxLen);
+    const uint32_t total = 2 * nReads;
+    uint32_t nextRs = blockIdx.x * blockDim.x + threadIdx.x;
+    bool done = false;
+    uint32_t flags = 0;
+    // records whose queue slots were reserved during the previous iteration
+    WaveReserve resI, resD;
+    uint32_t pN = 0, pB = 0, pA = 0, pMeta = 0, pRs = 0;
+    bool pDfs = false;
+    DfsTask pTask;
+    for (;;) {
+        // (1) an idle lane takes its next read x strand (static round-robin: the prologue of every read
+        //     costs about the same, and a shared work counter would serialise on one L2 atomic unit) and
+        //     asks for its read record
+        if (!done && m.phase == PH_DONE && m.req == RQ_NONE) {
+            m.rsId = nextRs;
+            nextRs += gridDim.x * blockDim.x;
+            if (m.rsId >= total) done = true;
+            else m.req = RQ_REC;
+        }
+        // (2) bookkeeping up to the next request
+        if (!done && m.req == RQ_NONE) {
+            m.advance();
+            if (m.phase == PH_DONE && k > 0 && !(m.flags & FLAG_UNSUPPORTED_READ)) {
+                PartOut po;
+#pragma unroll
+                for (int i = 0; i < MAXP; i++) {
+                    po.pb[i] = i < m.numParts ? (uint16_t)m.PB(i) : (uint16_t)0;
+                    po.pe[i] = i < m.numParts ? (uint16_t)m.PE(i) : (uint16_t)0;
+                }
+                parts[m.rsId] = po;
+            }
+        }
+        // (3) THE memory step: every lane issues the loads of its request (rank blocks of an extension,
+        //     k-mer table entries of the seeds, or a read record) before any reply is consumed, so the
+        //     wavefront waits for memory once per iteration
+        uint4 v[8]; // one register window for the replies of all three request kinds
+        const int rq = done ? RQ_NONE : m.req;
+        if (rq == RQ_RANK) {
+            DevBWT t = ix.fwd;
+            Range tr = m.reqParent.sa;
+            if (m.reqMode == 0) {
+                t = ix.rev;
+                tr = m.reqParent.rev;
+            }
+            loadRankChunksRaw(t, tr.b, v);
+            loadRankChunksRaw(t, tr.e, v + 4);
+        } else if (rq == RQ_SEED) {
+            m.seedIssue(v);
+        } else if (rq == RQ_REC) {
+#pragma unroll
+            for (uint32_t j = 0; j < 5; j++)
+                if (j < recQ) v[j] = rec[(size_t)m.rsId * recQ + j];
+        }
+        if (rq == RQ_RANK) {
+            DevBWT t = ix.fwd;
+            Range tr = m.reqParent.sa;
+            if (m.reqMode == 0) {
+                t = ix.rev;
+                tr = m.reqParent.rev;
+            }
+            uint32_t Rb[4], Re[4];
+            ranksFromRaw(v, tr.b, Rb);
+            ranksFromRaw(v + 4, tr.e, Re);
+            RangePair child;
+            const bool ok = childFromRanks(ix, m.reqMode, m.reqParent, m.reqCode, Rb, Re,
+                                           tr.b > t.dollarPos ? 1u : 0u, tr.e > t.dollarPos ? 1u : 0u, child);
+            m.req = RQ_NONE;
+            m.resume(ok, child);
+        } else if (rq == RQ_SEED) {
+            m.req = RQ_NONE;
+            m.seedTake(v);
+        } else if (rq == RQ_REC) {
+            m.begin(m.rsId, v, seq + (size_t)m.rsId * maxLen, k); // may leave a RQ_SEED request
+        }
+        // (4) write the records reserved one iteration ago (the reply travelled with the rank loads)
+        if (resI.pend) {
+            const uint32_t o = resI.take();
+            if (pN) {
+                if (o + pN > q.itemCap) flags |= FLAG_ITEM_OVERFLOW;
+                else
+                    for (uint32_t t = 0; t < pN; t++) q.items[o + t] = make_uint4(pRs, pB + t, pA, pMeta);
+                pN = 0;
+            }
+        }
+        if (resD.pend) {
+            const uint32_t o = resD.take();
+            if (pDfs) {
+                if (o >= dfsCap) flags |= FLAG_DFS_OVERFLOW;
+                else dfsQ[o] = pTask;
+                pDfs = false;
+            }
+        }
+        // (5) reserve queue space for what this iteration staged: one atomic per wavefront and queue
+        if (__ballot(m.stN > 0) != 0ull) {
+            resI.issue(&q.cnt[0], m.stN);
+            pN = m.stN;
+            pB = m.stB;
+            pA = m.stA;
+            pMeta = m.stMeta;
+            pRs = m.stRs;
+            m.stN = 0;
+        }
+        if (__ballot(m.stDfs) != 0ull) {
+            resD.issue(&q.cnt[5], m.stDfs ? 1u : 0u);
+            pDfs = m.stDfs;
+            pTask = m.stTask;
+            m.stDfs = false;
+        }
+        if (__ballot(!done) == 0ull && !resI.pend && !resD.pend) break;
+    }
+    m.flags |= flags;
+    const uint32_t local[4] = {m.cNode, m.cExp, m.cImm, m.cStart};
+    const int which[4] = {0, 7, 5, 6};
+    flushCounters(q, local, which, 4);
+    if (m.flags) atomicOr(&q.cnt[3], m.flags);
+}
+
+// ------------------------------------------------------------------ approximate DFS over the scheme
 
 // sort key of a DFS task: wide start ranges (big subtrees) first, so that the long tasks start first and
 // the 64 tasks a wavefront fetches together have similar sizes
@@ -226,7 +394,7 @@ k_dfs_edit(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* __
             }
         }
         // (4) the long, rare paths (goDeeper, phase entry/exit, next task) of the lanes that need one
-        if (!done && d.pend != PEND_NONE) d.heavy(tasks, order, nTasks, parts, offs, maxLen, G, done);
+        if (!done && d.pend != PEND_NONE) d.heavy(tasks, order, nTasks, parts, offs, G, done);
         if (__ballot(!done) == 0ull) break;
     }
     const uint32_t local[4] = {d.cNode, d.cExp, d.cRows, d.cExp};
