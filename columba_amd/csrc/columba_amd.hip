@@ -249,7 +249,7 @@ struct cmb_batch {
     DevBuf<DevStrategyK> strat;
     DevBuf<Scratch> slabs;
     DevBuf<Scratch2> slabs2;
-    DevBuf<uint32_t> dfsKeysA, dfsIdxA;
+    DevBuf<uint32_t> dfsKeysA, dfsKeysB, dfsIdxA, dfsIdxB;
     DevBuf<PartOut> parts;
     DevBuf<DfsTask> dfs;
     DevBuf<uint64_t> vHP, vD0;
@@ -441,18 +441,40 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                             "falls back to naive backtracking, which the device path does not provide)");
             const uint32_t nDfs = hcnt[5];
             if (!(flags & (FLAG_ITEM_OVERFLOW | FLAG_DFS_OVERFLOW)) && nDfs) {
-                const uint32_t want = std::min<uint32_t>(((nDfs + 255) / 256) * 256, 256u * 512u);
+                const uint32_t slotCap = getenv("CMB_DFS_SLOTS") ? (uint32_t)atoi(getenv("CMB_DFS_SLOTS")) : 256u * 512u;
+                const uint32_t want = std::min<uint32_t>(((nDfs + 255) / 256) * 256, slotCap);
                 tm.begin();
                 if (b->metric == CMB_METRIC_EDIT) {
                     if (b->slabs2.n < want) b->slabs2.alloc(want);
                     if (b->dfsKeysA.n < nDfs) {
                         b->dfsKeysA.alloc((size_t)nDfs + 1024);
+                        b->dfsKeysB.alloc((size_t)nDfs + 1024);
                         b->dfsIdxA.alloc((size_t)nDfs + 1024);
+                        b->dfsIdxB.alloc((size_t)nDfs + 1024);
                     }
+                    // Widest start ranges (largest subtrees) first — but spread: lane l of wavefront w starts
+                    // with the (l * W + w)-th largest task, so every wavefront gets one task of each size class
+                    // and the longest tasks all start at time zero; the rest is fetched through a counter.
                     hipLaunchKernelGGL(k_dfs_keys, dim3((nDfs + 255) / 256), dim3(256), 0, s, b->dfs.p, nDfs,
                                        b->dfsKeysA.p, b->dfsIdxA.p);
-                    hipLaunchKernelGGL(k_dfs_edit, dim3(want / 64), dim3(64), 0, s, ix->d, b->strat.p, b->offs.p,
-                                       b->maxLen, b->gw, b->G.p, b->parts.p, b->dfs.p, b->dfsIdxA.p, nDfs, b->slabs2.p, q);
+                    size_t tmpBytes = 0;
+                    HIPCHK(rocprim::radix_sort_pairs(nullptr, tmpBytes, b->dfsKeysA.p, b->dfsKeysB.p, b->dfsIdxA.p,
+                                                     b->dfsIdxB.p, nDfs, 0, 32, s));
+                    if (b->sortTmp.n < tmpBytes) b->sortTmp.alloc(tmpBytes + 256);
+                    HIPCHK(rocprim::radix_sort_pairs(b->sortTmp.p, tmpBytes, b->dfsKeysA.p, b->dfsKeysB.p, b->dfsIdxA.p,
+                                                     b->dfsIdxB.p, nDfs, 0, 32, s));
+                    DfsQueue dq;
+                    dq.tasks = b->dfs.p;
+                    dq.order = b->dfsIdxB.p;
+                    dq.live = nDfs;
+                    dq.nStatic = std::min<uint32_t>(want, nDfs);
+                    dq.tSplit = getenv("CMB_TSPLIT") ? (uint32_t)atoi(getenv("CMB_TSPLIT")) : 32u;
+                    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&b->cnt.p[6], (int)dq.nStatic, 1, s));
+                    // final-column cluster cells per phase: Wh + Wv + 1 <= 3 k + 1 (search.h bounds U by k)
+                    const uint32_t clCells = std::min<uint32_t>(CL_MAX, 3 * b->k + 2);
+                    const uint32_t dfsLds = b->hostStrat.numParts * clCells * 64;
+                    hipLaunchKernelGGL(k_dfs_edit, dim3(want / 64), dim3(64), dfsLds, s, ix->d, b->strat.p, b->offs.p,
+                                       b->maxLen, b->gw, b->G.p, b->parts.p, dq, b->slabs2.p, clCells, q);
                 } else {
                     if (b->slabs.n < want) b->slabs.alloc(want);
                     hipLaunchKernelGGL(k_dfs_hamming, dim3(want / 256), dim3(256), 0, s, ix->d, b->strat.p, b->offs.p,
@@ -503,8 +525,9 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
         if (!fm.empty()) b->fmUniq.upload(fm.data(), fm.size());
 
         // ---- locate + verify; text queue retried on overflow
-        if (b->tbq.n < nItems) b->tbq.alloc((size_t)nItems + nItems / 8 + 256);
-        uint32_t textFromVerify = 0;
+        // traceback task queue: at most one task per item + the chunk slack of every k_verify wavefront
+        const size_t tbNeed = (size_t)nItems + (size_t)(256u * 2048u / 64u + 1) * 256u;
+        if (b->tbq.n < tbNeed) b->tbq.alloc(tbNeed + nItems / 8);
         for (int attempt = 0;; attempt++) {
             q.text = b->text.p;
             q.textCap = (uint32_t)std::min<size_t>(b->text.n, 0xFFFFFFF0u);
@@ -518,7 +541,8 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                 const uint32_t vSlots = std::min<uint32_t>(((nItems + 255) / 256) * 256, 256u * 2048u);
                 tm.begin();
                 hipLaunchKernelGGL(k_verify, dim3(vSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->maxLen, b->gw,
-                                   b->seq.p, b->G.p, b->items.p, nItems, b->tbq.p, q);
+                                   b->seq.p, b->G.p, b->items.p, nItems, b->tbq.p,
+                                   (uint32_t)std::min<size_t>(b->tbq.n, 0xFFFFFFF0u), q);
                 tm.end("k_verify");
                 HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
                 HIPCHK(hipStreamSynchronize(s));
@@ -538,7 +562,6 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
             }
             HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            textFromVerify = hcnt[2];
             if (!fm.empty()) {
                 tm.begin();
                 const uint32_t nb = (uint32_t)std::min<size_t>((fm.size() + 255) / 256, 4096);
@@ -618,7 +641,8 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
             for (uint32_t r = 0; r <= nReads; r++) b->occOffs[r] = o32[r];
         }
         // TOTAL_REPORTED_POSITIONS (indexinterface.cpp:1378,1390 / :1333,1352)
-        b->cnts[CMB_CNT_TOTAL_REPORTED] = (uint64_t)textFromVerify + fmRows;
+        // (the device counter holds the records k_verify / k_traceback wrote; queue holes are not records)
+        b->cnts[CMB_CNT_TOTAL_REPORTED] += fmRows;
         b->done = true;
         return CMB_OK;
     } catch (const std::exception& e) {
@@ -821,7 +845,8 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
                               ((uint32_t)ITEM_EDIT << 21) | (1u << 23);
         for (uint64_t i = 0; i < n; i++) hi[i] = make_uint4(0, starts[i], 0, meta);
         items.upload(hi.data(), n);
-        const size_t cap = n * 32 + 64;
+        // (every wavefront of k_verify / k_traceback may leave one partly used chunk of 256 records)
+        const size_t cap = n * 32 + 64 + 2 * (std::min<uint64_t>(std::max<uint64_t>(((n + 255) / 256) * 256, 256), 65536) / 64 + 1) * 256;
         text.alloc(cap);
         cnt.alloc(8);
         ctr.alloc(CMB_CNT_MAX);
@@ -830,7 +855,7 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         const uint32_t slots = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(((n + 255) / 256) * 256, 256), 65536);
         vHP.alloc((size_t)VROWS * slots);
         vD0.alloc((size_t)VROWS * slots);
-        tbq.alloc(n + 1);
+        tbq.alloc(n + (size_t)(slots / 64 + 1) * 256);
         VPlanes vp{vHP.p, vD0.p, slots};
         Queues q{};
         q.text = text.p;
@@ -843,7 +868,7 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         uint32_t hc[8];
         if (n) {
             hipLaunchKernelGGL(k_verify, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, plen, gw, seq.p, G.p,
-                               items.p, (uint32_t)n, tbq.p, q);
+                               items.p, (uint32_t)n, tbq.p, (uint32_t)tbq.n, q);
             HIPCHK(hipMemcpy(hc, cnt.p, 32, hipMemcpyDeviceToHost));
             if (hc[7])
                 hipLaunchKernelGGL(k_traceback, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, gw, G.p, tbq.p,
@@ -852,16 +877,18 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy(hc, cnt.p, 32, hipMemcpyDeviceToHost));
         if (hc[3] & FLAG_TEXT_OVERFLOW) return fail(CMB_ERR_INTERNAL, "verification output overflow");
-        *n_out = hc[2];
-        if (hc[2] > out_cap) return fail(CMB_ERR_OVERFLOW, "output buffer too small");
         std::vector<TextOccRec> t(hc[2]);
         if (hc[2]) HIPCHK(hipMemcpy(t.data(), text.p, hc[2] * sizeof(TextOccRec), hipMemcpyDeviceToHost));
+        t.erase(std::remove_if(t.begin(), t.end(), [](const TextOccRec& x) { return x.rsId == 0xFFFFFFFFu; }),
+                t.end()); // holes of the wavefronts' queue chunks
+        *n_out = t.size();
+        if (t.size() > out_cap) return fail(CMB_ERR_OVERFLOW, "output buffer too small");
         std::sort(t.begin(), t.end(), [](const TextOccRec& x, const TextOccRec& y) {
             if (x.begin != y.begin) return x.begin < y.begin;
             if (x.end != y.end) return x.end < y.end;
             return x.dist < y.dist;
         });
-        for (uint32_t i = 0; i < hc[2]; i++) out[i] = cmb_occ{t[i].begin, t[i].end, t[i].dist, 0};
+        for (size_t i = 0; i < t.size(); i++) out[i] = cmb_occ{t[i].begin, t[i].end, t[i].dist, 0};
         if (counters) {
             unsigned long long c2[CMB_CNT_MAX];
             HIPCHK(hipMemcpy(c2, ctr.p, sizeof(c2), hipMemcpyDeviceToHost));

@@ -25,6 +25,7 @@
 namespace cmb {
 
 constexpr int STACK2_MAX = 3 * ROWS_MAX + 4 * MAXP;
+constexpr int DON_MAX = 3; // children offered to helpers per expansion (the first valid child is always kept)
 
 struct SEntry { // one DFS stack entry
     uint4 a;    // child ranges sa.b, sa.e, rev.b, rev.e
@@ -53,9 +54,29 @@ struct ColdFrame {
 };
 
 struct Scratch2 {
+    SEntry don[DON_MAX]; // children offered to helper lanes in this iteration
+    SEntry subIn;        // child this lane received
     uint16_t pb[MAXP], pe[MAXP];
     ColdFrame fr[MAXP];
     SEntry stack[STACK2_MAX];
+};
+
+// The DFS task queue.  Positions [0, live): the first nStatic are assigned statically (lane l of wavefront
+// w takes position l * W + w), the others through the counter q.cnt[6].  Positions map to tasks through
+// order[] (widest start range first), so every wavefront starts with one task of each size class.
+//
+// Sharing a big subtree inside the wavefront: once the original tasks are exhausted, a lane without work
+// becomes a helper.  A lane working on the FIRST phase of its task offers wide children (>= tSplit
+// suffix-array rows, row not yet in the final column: such a child is self-contained — ranges + row state)
+// to the helpers of its own wavefront instead of pushing them: the entries are staged in the donor's slab,
+// matched to helpers by rank at the end of the iteration (ballots + one LDS table, no global atomics), and a
+// helper then runs the first phase from that child as if it had popped it.  What no helper takes goes back
+// on the donor's stack.  So the time a wavefront needs is the sum of its tasks over 64 lanes, not its
+// largest task.
+struct DfsQueue {
+    const DfsTask* tasks;
+    const uint32_t* order;
+    uint32_t nStatic, live, tSplit;
 };
 
 enum { PEND_NONE = 0, PEND_FETCH, PEND_DEEPER, PEND_LEAVE };
@@ -65,13 +86,15 @@ struct EditDfs {
     const DevStrategyK& st;
     Scratch2& S;
     const Queues& q;
-    uint8_t (*clEd)[CL_MAX][64]; // LDS: [level][cell][lane]
+    uint8_t* clEd;                // LDS: [level][cell][lane], clCells cells per level
+    uint32_t clCells;
     const uint32_t lane;
     // task
     const DevSearch* s = nullptr;
     uint32_t rsId = 0, len = 0, gw = 0;
     const uint32_t* G = nullptr;
     int level = -1, firstIdx = 0;
+    uint32_t curTask = 0; // index of the running task (copied when a child is handed over)
     Hot H;
     // pending expansion
     bool req = false;
@@ -83,6 +106,10 @@ struct EditDfs {
     uint64_t Mblk[4];
     // parked heavy operation
     int pend = PEND_FETCH;
+    bool firstFetch = true;
+    bool origDone = false;            // the original tasks of this pass are exhausted
+    uint32_t claim = 0xFFFFFFFFu;     // task index of the subtree this lane received (entry in S.subIn)
+    uint32_t nDon = 0;                // children staged in S.don[] this iteration
     int pendRem = -1;
     // staged in-text work item
     uint32_t stN = 0, stB = 0, stA = 0, stMeta = 0;
@@ -90,12 +117,14 @@ struct EditDfs {
     uint32_t cNode = 0, cExp = 0, cRows = 0, flags = 0;
 
     __device__ EditDfs(const DevIndex& i, const DevStrategyK& t, Scratch2& sc, const Queues& qq,
-                       uint8_t (*ed)[CL_MAX][64], uint32_t ln)
-        : ix(i), st(t), S(sc), q(qq), clEd(ed), lane(ln) {}
+                       uint8_t* ed, uint32_t cells, uint32_t ln)
+        : ix(i), st(t), S(sc), q(qq), clEd(ed), clCells(cells), lane(ln) {}
 
     __device__ __forceinline__ bool uniAt(int idx) const { return s->uniAll || idx >= (int)s->uniIdx; }
     __device__ __forceinline__ int mode() const { return H.uni ? 2 : (H.dir == 0 ? 0 : 1); }
-    __device__ __forceinline__ uint8_t& ED(int lvl, int cell) { return clEd[lvl][cell][lane]; }
+    __device__ __forceinline__ uint8_t& ED(int lvl, int cell) {
+        return clEd[((uint32_t)lvl * clCells + (uint32_t)cell) * 64u + lane];
+    }
     __device__ __forceinline__ const uint32_t* gbits(uint32_t ch) const { return G + (H.useRev * 4 + ch) * gw; }
 
     __device__ __forceinline__ void requestExpand(const RangePair& parent, uint32_t row, uint64_t HP, uint64_t HN,
@@ -110,7 +139,7 @@ struct EditDfs {
     }
 
     // ---- (1) EXPAND: extendFMPos (indexinterface.cpp:675-697) + the children's rows (computeRow :536)
-    __device__ __forceinline__ void expand() {
+    __device__ __forceinline__ void expand(const DfsQueue& dq, bool helpersWaiting) {
         uint32_t Rb[4], Re[4], db, de;
         const int md = mode();
         loadExtendRanks(ix, md, reqParent, Rb, Re, db, de);
@@ -122,6 +151,8 @@ struct EditDfs {
 #pragma unroll
             for (int ch = 0; ch < 4; ch++) Mblk[ch] = matchWord(gbits(ch), H.xOff, H.xLen, blk);
         }
+        const bool canSplit = helpersWaiting && dq.tSplit != 0 && level == firstIdx && !H.g.inFinalColumn(row);
+        bool kept = false;
 #pragma unroll
         for (uint32_t ch = 1; ch <= 4; ch++) {
             RangePair child;
@@ -134,14 +165,20 @@ struct EditDfs {
                 // a child whose row already exceeds maxED outside the final column is pruned the moment it
                 // is popped (branchAndBound returns true, :560) and has no other effect: do not push it
                 if (!valid && !H.g.inFinalColumn(row)) continue;
+                SEntry e;
+                e.a = make_uint4(child.sa.b, child.sa.e, child.rev.b, child.rev.e);
+                e.b = make_uint4(row | (ch << 16) | ((valid ? 1u : 0u) << 24), score, (uint32_t)HP, (uint32_t)(HP >> 32));
+                e.c = make_uint4((uint32_t)HN, (uint32_t)(HN >> 32), (uint32_t)RAC, (uint32_t)(RAC >> 32));
+                if (canSplit && kept && child.sa.width() >= dq.tSplit) { // offer the subtree to a helper
+                    S.don[nDon++] = e;
+                    continue;
+                }
+                kept = true;
                 if (H.stackTop >= (uint32_t)STACK2_MAX) {
                     flags |= FLAG_CAPACITY;
                     break;
                 }
-                SEntry& e = S.stack[H.stackTop++];
-                e.a = make_uint4(child.sa.b, child.sa.e, child.rev.b, child.rev.e);
-                e.b = make_uint4(row | (ch << 16) | ((valid ? 1u : 0u) << 24), score, (uint32_t)HP, (uint32_t)(HP >> 32));
-                e.c = make_uint4((uint32_t)HN, (uint32_t)(HN >> 32), (uint32_t)RAC, (uint32_t)(RAC >> 32));
+                S.stack[H.stackTop++] = e;
             }
         }
         req = false;
@@ -285,7 +322,7 @@ struct EditDfs {
         H.clSize = H.g.sfc();
         f.nDesc = 0;
         f.nInit = 0;
-        if (H.g.Wv > 2 * MX_MAX_ED || H.clSize > (uint32_t)CL_MAX || H.stackBase + 3 * H.g.m + 4 > (uint32_t)STACK2_MAX) {
+        if (H.g.Wv > 2 * MX_MAX_ED || H.clSize > clCells || H.stackBase + 3 * H.g.m + 4 > (uint32_t)STACK2_MAX) {
             flags |= FLAG_CAPACITY;
             H.clSize = 0;
             return; // empty stack: the phase is left at its first step
@@ -489,19 +526,41 @@ struct EditDfs {
     }
 
     // ---- (4) parked operations ------------------------------------------------------------------
-    __device__ __forceinline__ void heavy(const DfsTask* tasks, const uint32_t* order, uint32_t nTasks,
-                                          const PartOut* parts, const uint64_t* offs, const uint32_t* Gall, bool& done) {
+    __device__ __forceinline__ void heavy(const DfsQueue& dq, const PartOut* parts, const uint64_t* offs,
+                                          const uint32_t* Gall) {
         EnterReq er;
         er.want = false;
+        bool subStart = false;
         if (pend == PEND_FETCH) {
-            pend = PEND_NONE;
-            const uint32_t t = atomicAdd(&q.cnt[6], 1u);
-            if (t >= nTasks) {
-                done = true;
-                level = -1;
-                firstIdx = 0;
+            uint32_t p = 0xFFFFFFFFu;
+            if (claim != 0xFFFFFFFFu) { // a subtree received from a lane of this wavefront
+                curTask = claim;
+                claim = 0xFFFFFFFFu;
+                subStart = true;
+                p = 0;
             } else {
-                const DfsTask task = tasks[order[t]];
+                if (firstFetch) {
+                    firstFetch = false;
+                    const uint32_t g = (threadIdx.x & 63u) * gridDim.x + blockIdx.x;
+                    if (g < dq.nStatic) p = g;
+                }
+                if (p == 0xFFFFFFFFu) p = atomicAdd(&q.cnt[6], 1u);
+                if (p >= dq.live) {
+                    p = 0xFFFFFFFFu;
+                    origDone = true; // stays PEND_FETCH: from now on the lane is a helper
+                    level = -1;
+                    firstIdx = 0;
+                } else {
+                    curTask = dq.order[p];
+                }
+            }
+            DfsTask task;
+            if (p != 0xFFFFFFFFu) {
+                task = dq.tasks[curTask];
+                if (task.rsId == 0xFFFFFFFFu) p = 0xFFFFFFFFu; // a hole of the task queue: try again
+            }
+            if (p != 0xFFFFFFFFu) {
+                pend = PEND_NONE;
                 rsId = task.rsId;
                 len = (uint32_t)(offs[(rsId >> 1) + 1] - offs[rsId >> 1]);
                 G = Gall + (size_t)rsId * 8 * gw;
@@ -538,7 +597,13 @@ struct EditDfs {
                 if (level < firstIdx) pend = PEND_FETCH; // search finished: next task
             }
         }
-        if (er.want) enter(er.idx, er.sm, er.prevLvl, er.notPrevLvl);
+        if (er.want) {
+            enter(er.idx, er.sm, er.prevLvl, er.notPrevLvl);
+            if (subStart) { // a handed-over subtree: the phase starts at that child instead of at row 0
+                req = false;
+                S.stack[H.stackTop++] = S.subIn;
+            }
+        }
     }
 };
 

@@ -201,20 +201,45 @@ __device__ __forceinline__ uint32_t waveAppend(uint32_t* counter, uint32_t n, ui
     return base + off;
 }
 
-// Wave-aggregated reservation whose reply is consumed one loop iteration later, so that the atomic's
-// round trip overlaps the next iteration's rank loads instead of stalling the wavefront.
-struct WaveReserve {
-    uint32_t raw = 0, pre = 0;
-    bool pend = false; // wave-uniform
-    __device__ __forceinline__ void issue(uint32_t* counter, uint32_t n) { // all 64 lanes
+// Queue space in per-wavefront CHUNKS.  Atomics on one address are served at ~90 per microsecond by the
+// L2 atomic unit, whichever wavefront issues them: a kernel whose wavefronts append a few records every
+// loop iteration is bound by that (2 M appends = 22 ms) and does not get faster with more wavefronts.  So a
+// wavefront reserves `chunk` slots with ONE atomic and hands them out locally (prefix sum); what is left of
+// a chunk when it is retired, or when the kernel ends, is filled with HOLES (records whose first word is
+// 0xFFFFFFFF), which the consumers skip.  All members are wave-uniform.
+struct WaveChunk {
+    uint32_t base = 0, used = 0, size = 0;
+    // slots [returned, returned + n) for this lane's n records; 0xFFFFFFFF if the queue overflowed.
+    // All 64 lanes must call; `hole(i)` writes a hole at slot i.
+    template <class Hole>
+    __device__ __forceinline__ uint32_t alloc(uint32_t* counter, uint32_t cap, uint32_t n, uint32_t chunk, bool& overflow,
+                                              Hole hole) {
         uint32_t total;
-        pre = waveExclusiveScan(n, total);
-        if ((threadIdx.x & 63u) == 0) raw = atomicAdd(counter, total);
-        pend = true;
+        const uint32_t pre = waveExclusiveScan(n, total);
+        if (total == 0) return 0xFFFFFFFFu;
+        if (used + total > size) {
+            fill(hole);
+            const uint32_t want = total > chunk ? total : chunk;
+            uint32_t b = 0;
+            if ((threadIdx.x & 63u) == 0) b = atomicAdd(counter, want);
+            b = __shfl(b, 0);
+            if (b > cap || want > cap - b) { // (the counter keeps the needed size for the retry on the host)
+                overflow = true;
+                size = used = 0;
+                return 0xFFFFFFFFu;
+            }
+            base = b;
+            size = want;
+            used = 0;
+        }
+        const uint32_t o = base + used + pre;
+        used += total;
+        return o;
     }
-    __device__ __forceinline__ uint32_t take() { // all 64 lanes
-        pend = false;
-        return __shfl(raw, 0) + pre;
+    template <class Hole>
+    __device__ __forceinline__ void fill(Hole hole) { // holes in the unused rest of the current chunk
+        for (uint32_t i = used + (threadIdx.x & 63u); i < size; i += 64u) hole(base + i);
+        used = size;
     }
 };
 
@@ -223,7 +248,7 @@ struct WaveReserve {
 // lane, at one common program point: 2 positions x (4 x 16 B of the 64-byte counts line + 2 x 16 B of
 // the 32-byte bit group) = 12 independent 16-byte loads per lane in flight, whatever phase of the
 // prologue the lane's read is in (dev_partition.hpp).
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(256, 2)
 k_partition(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* __restrict__ offs, uint32_t nReads,
             uint32_t k, uint32_t maxLen, const uint8_t* __restrict__ seq, const uint4* __restrict__ rec,
             uint32_t recQ, PartOut* __restrict__ parts, DfsTask* __restrict__ dfsQ, uint32_t dfsCap, Queues q) {
@@ -241,11 +266,10 @@ k_partition(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* _
     uint32_t nextRs = blockIdx.x * blockDim.x + threadIdx.x;
     bool done = false;
     uint32_t flags = 0;
-    // records whose queue slots were reserved during the previous iteration
-    WaveReserve resI, resD;
-    uint32_t pN = 0, pB = 0, pA = 0, pMeta = 0, pRs = 0;
-    bool pDfs = false;
-    DfsTask pTask;
+    WaveChunk chI, chD; // this wavefront's chunks of the item queue / the DFS task queue
+    bool ovI = false, ovD = false;
+    auto holeI = [&](uint32_t i) { q.items[i] = make_uint4(0xFFFFFFFFu, 0, 0, 0); };
+    auto holeD = [&](uint32_t i) { dfsQ[i].rsId = 0xFFFFFFFFu; };
     for (;;) {
         // (1) an idle lane takes its next read x strand (static round-robin: the prologue of every read
         //     costs about the same, and a shared work counter would serialise on one L2 atomic unit) and
@@ -311,42 +335,24 @@ k_partition(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* _
         } else if (rq == RQ_REC) {
             m.begin(m.rsId, v, seq + (size_t)m.rsId * maxLen, k); // may leave a RQ_SEED request
         }
-        // (4) write the records reserved one iteration ago (the reply travelled with the rank loads)
-        if (resI.pend) {
-            const uint32_t o = resI.take();
-            if (pN) {
-                if (o + pN > q.itemCap) flags |= FLAG_ITEM_OVERFLOW;
-                else
-                    for (uint32_t t = 0; t < pN; t++) q.items[o + t] = make_uint4(pRs, pB + t, pA, pMeta);
-                pN = 0;
-            }
-        }
-        if (resD.pend) {
-            const uint32_t o = resD.take();
-            if (pDfs) {
-                if (o >= dfsCap) flags |= FLAG_DFS_OVERFLOW;
-                else dfsQ[o] = pTask;
-                pDfs = false;
-            }
-        }
-        // (5) reserve queue space for what this iteration staged: one atomic per wavefront and queue
+        // (4) queue what this iteration staged (slots come from the wavefront's chunks: no atomic here)
         if (__ballot(m.stN > 0) != 0ull) {
-            resI.issue(&q.cnt[0], m.stN);
-            pN = m.stN;
-            pB = m.stB;
-            pA = m.stA;
-            pMeta = m.stMeta;
-            pRs = m.stRs;
+            const uint32_t o = chI.alloc(&q.cnt[0], q.itemCap, m.stN, 256u, ovI, holeI);
+            if (m.stN && o != 0xFFFFFFFFu)
+                for (uint32_t t = 0; t < m.stN; t++) q.items[o + t] = make_uint4(m.stRs, m.stB + t, m.stA, m.stMeta);
             m.stN = 0;
         }
         if (__ballot(m.stDfs) != 0ull) {
-            resD.issue(&q.cnt[5], m.stDfs ? 1u : 0u);
-            pDfs = m.stDfs;
-            pTask = m.stTask;
+            const uint32_t o = chD.alloc(&q.cnt[5], dfsCap, m.stDfs ? 1u : 0u, 64u, ovD, holeD);
+            if (m.stDfs && o != 0xFFFFFFFFu) dfsQ[o] = m.stTask;
             m.stDfs = false;
         }
-        if (__ballot(!done) == 0ull && !resI.pend && !resD.pend) break;
+        if (__ballot(!done) == 0ull) break;
     }
+    chI.fill(holeI);
+    chD.fill(holeD);
+    if (ovI) flags |= FLAG_ITEM_OVERFLOW;
+    if (ovD) flags |= FLAG_DFS_OVERFLOW;
     m.flags |= flags;
     const uint32_t local[4] = {m.cNode, m.cExp, m.cImm, m.cStart};
     const int which[4] = {0, 7, 5, 6};
@@ -362,41 +368,81 @@ __global__ void k_dfs_keys(const DfsTask* __restrict__ tasks, uint32_t n, uint32
                            uint32_t* __restrict__ idx) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    keys[i] = ~tasks[i].r.sa.width();
+    keys[i] = tasks[i].rsId == 0xFFFFFFFFu ? 0xFFFFFFFFu : ~tasks[i].r.sa.width(); // holes last
     idx[i] = i;
 }
 
 // Edit distance: one lane per DfsTask, one wavefront per block (dev_dfs_edit.hpp).
 __global__ void __launch_bounds__(64)
 k_dfs_edit(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* __restrict__ offs, uint32_t maxLen,
-           uint32_t gw, const uint32_t* __restrict__ G, const PartOut* __restrict__ parts,
-           const DfsTask* __restrict__ tasks, const uint32_t* __restrict__ order, uint32_t nTasks,
-           Scratch2* __restrict__ slabs, Queues q) {
-    __shared__ uint8_t clEd[MAXP][CL_MAX][64];
+           uint32_t gw, const uint32_t* __restrict__ G, const PartOut* __restrict__ parts, DfsQueue dq,
+           Scratch2* __restrict__ slabs, uint32_t clCells, Queues q) {
+    extern __shared__ uint8_t clEd[]; // [numParts][clCells][64] final-column edit distances (MatrixMetaInfo)
     const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
-    EditDfs d(ix, *stp, slabs[slot], q, clEd, threadIdx.x);
+    EditDfs d(ix, *stp, slabs[slot], q, clEd, clCells, threadIdx.x);
     d.gw = gw;
-    bool done = false;
+    const uint32_t laneId = threadIdx.x & 63u;
+    __shared__ uint8_t donMap[64 * DON_MAX]; // rank of an offered child -> donor lane << 2 | item
+    WaveChunk chI;
+    bool ovI = false;
+    auto holeI = [&](uint32_t i) { q.items[i] = make_uint4(0xFFFFFFFFu, 0, 0, 0); };
     for (;;) {
+        // helpers: lanes without work once the original tasks are exhausted
+        const bool helper = d.pend == PEND_FETCH && d.origDone && d.claim == 0xFFFFFFFFu;
+        const uint64_t helpMask = __ballot(helper);
         // (1) EXPAND: rank loads + children rows + pushes, for every lane with a pending parent
-        if (d.req) d.expand();
+        if (d.req) d.expand(dq, helpMask != 0ull);
         // (2) STEP: pop / replay one node and classify it
-        if (!done && d.pend == PEND_NONE) d.step();
-        // (3) staged in-text work items: one atomic per wavefront
+        if (d.pend == PEND_NONE) d.step();
+        // (3) staged in-text work items go to the wavefront's chunk of the item queue
         if (__ballot(d.stN > 0) != 0ull) {
-            uint32_t total;
-            const uint32_t o = waveAppend(&q.cnt[0], d.stN, total);
-            if (d.stN) {
-                if (o + d.stN > q.itemCap) d.flags |= FLAG_ITEM_OVERFLOW;
-                else
-                    for (uint32_t j = 0; j < d.stN; j++) q.items[o + j] = make_uint4(d.rsId, d.stB + j, d.stA, d.stMeta);
-                d.stN = 0;
-            }
+            const uint32_t o = chI.alloc(&q.cnt[0], q.itemCap, d.stN, 256u, ovI, holeI);
+            if (d.stN && o != 0xFFFFFFFFu)
+                for (uint32_t j = 0; j < d.stN; j++) q.items[o + j] = make_uint4(d.rsId, d.stB + j, d.stA, d.stMeta);
+            d.stN = 0;
         }
         // (4) the long, rare paths (goDeeper, phase entry/exit, next task) of the lanes that need one
-        if (!done && d.pend != PEND_NONE) d.heavy(tasks, order, nTasks, parts, offs, G, done);
-        if (__ballot(!done) == 0ull) break;
+        if (d.pend != PEND_NONE && !helper) d.heavy(dq, parts, offs, G);
+        // (5) match the children offered in this iteration to the helpers of the wavefront
+        if (__ballot(d.nDon > 0) != 0ull) {
+            // the staged entries were written by other lanes: complete the stores, drop stale L1 lines
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            uint32_t total;
+            const uint32_t off = waveExclusiveScan(d.nDon, total);
+            for (uint32_t t = 0; t < d.nDon; t++) donMap[off + t] = (uint8_t)((laneId << 2) | t);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t nHelp = (uint32_t)__popcll(helpMask);
+            if (helper) {
+                const uint32_t rank = (uint32_t)__popcll(helpMask & ((1ull << laneId) - 1ull));
+                if (rank < total) { // take child `rank`
+                    const uint32_t m = donMap[rank];
+                    d.S.subIn = slabs[blockIdx.x * 64 + (m >> 2)].don[m & 3u];
+                }
+            }
+            // the donors' task indices travel by shuffle (all lanes participate)
+            {
+                const uint32_t rank = (uint32_t)__popcll(helpMask & ((1ull << laneId) - 1ull));
+                const uint32_t m = (helper && rank < total) ? donMap[rank] : 0u;
+                const uint32_t task = __shfl(d.curTask, (int)(m >> 2));
+                if (helper && rank < total) d.claim = task;
+            }
+            // what no helper took goes back on the donor's stack
+            for (uint32_t t = 0; t < d.nDon; t++)
+                if (off + t >= nHelp) {
+                    if (d.H.stackTop >= (uint32_t)STACK2_MAX) d.flags |= FLAG_CAPACITY;
+                    else {
+                        const SEntry e = d.S.don[t];
+                        d.S.stack[d.H.stackTop++] = e;
+                    }
+                }
+            d.nDon = 0;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // every lane a helper and nothing offered: the wavefront is done
+        if (helpMask == ~0ull) break;
     }
+    chI.fill(holeI);
+    if (ovI) d.flags |= FLAG_ITEM_OVERFLOW;
     const uint32_t local[4] = {d.cNode, d.cExp, d.cRows, d.cExp};
     const int which[4] = {0, 7, 11, 12};
     flushCounters(q, local, which, 4);
@@ -419,6 +465,7 @@ k_dfs_hamming(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t*
         if (t >= nTasks) break;
         const DfsTask task = tasks[t];
         const uint32_t rs = task.rsId;
+        if (rs == 0xFFFFFFFFu) continue; // a hole of the task queue
         c.rsId = rs;
         c.len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
         c.seq = seq + (size_t)rs * maxLen;
@@ -555,9 +602,13 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const uint32
 __global__ void __launch_bounds__(256)
 k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32_t gw,
          const uint8_t* __restrict__ seq, const uint32_t* __restrict__ G, const uint4* __restrict__ items,
-         uint32_t nItems, uint4* __restrict__ tbq, Queues q) {
+         uint32_t nItems, uint4* __restrict__ tbq, uint32_t tbCap, Queues q) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t cLF = 0, cLoc = 0, cText = 0, cRows = 0, cAbort = 0, cCig = 0, cStarted = 0, flags = 0;
+    uint32_t cLF = 0, cLoc = 0, cText = 0, cRows = 0, cAbort = 0, cCig = 0, cStarted = 0, cRep = 0, flags = 0;
+    WaveChunk chT, chB; // chunks of the text-occurrence queue / the traceback task queue
+    bool ovT = false, ovB = false;
+    auto holeT = [&](uint32_t i) { q.text[i].rsId = 0xFFFFFFFFu; };
+    auto holeB = [&](uint32_t i) { tbq[i] = make_uint4(0, 0, 0, 0); }; // mask 0: nothing to trace
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t waveBase = slot & ~63u;
     const VPlanes noPlanes{nullptr, nullptr, 0};
@@ -566,8 +617,9 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
         uint32_t nOut = 0, nTb = 0;
         uint4 outRec = make_uint4(0, 0, 0, 0), tbRec = make_uint4(0, 0, 0, 0);
         uint32_t rs = 0;
-        if (it < nItems) {
-            const uint4 item = items[it];
+        uint4 item = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+        if (it < nItems) item = items[it];
+        if (item.x != 0xFFFFFFFFu) { // (holes: unused slots of a wavefront's chunk)
             rs = item.x;
             const uint32_t row = item.y, a = item.z, meta = item.w;
             const uint32_t kind = (meta >> 21) & 3u;
@@ -654,19 +706,20 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
                 }
             }
         }
-        // ---- wave-aggregated appends (one atomic per wavefront and queue)
-        uint32_t total;
-        const uint32_t o1 = waveAppend(&q.cnt[2], nOut, total);
-        if (nOut) {
-            if (o1 >= q.textCap) flags |= FLAG_TEXT_OVERFLOW;
-            else q.text[o1] = TextOccRec{rs, outRec.x, outRec.y, outRec.z};
-        }
-        const uint32_t o2 = waveAppend(&q.cnt[7], nTb, total);
-        if (nTb) tbq[o2] = tbRec; // capacity = nItems: cannot overflow
+        // ---- appends into the wavefront's chunks of the two output queues
+        cRep += nOut;
+        const uint32_t o1 = chT.alloc(&q.cnt[2], q.textCap, nOut, 256u, ovT, holeT);
+        if (nOut && o1 != 0xFFFFFFFFu) q.text[o1] = TextOccRec{rs, outRec.x, outRec.y, outRec.z};
+        const uint32_t o2 = chB.alloc(&q.cnt[7], tbCap, nTb, 256u, ovB, holeB);
+        if (nTb && o2 != 0xFFFFFFFFu) tbq[o2] = tbRec;
     }
-    const uint32_t local[7] = {cLF, cLoc, cText, cRows, cAbort, cCig, cStarted};
-    const int which[7] = {8, 9, 10, 11, 3, 4, 2};
-    flushCounters(q, local, which, 7);
+    chT.fill(holeT);
+    chB.fill(holeB);
+    if (ovT) flags |= FLAG_TEXT_OVERFLOW;
+    if (ovB) flags |= FLAG_CAPACITY; // (sized by the host for the worst case)
+    const uint32_t local[8] = {cLF, cLoc, cText, cRows, cAbort, cCig, cStarted, cRep};
+    const int which[8] = {8, 9, 10, 11, 3, 4, 2, 1};
+    flushCounters(q, local, which, 8);
     if (flags) atomicOr(&q.cnt[3], flags);
 }
 
@@ -685,6 +738,10 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const u
     const uint32_t tid = threadIdx.x;
     const uint32_t NS = V.nSlots;
     uint32_t flags = 0, dummyRows = 0;
+    WaveChunk chT; // chunk of the text-occurrence queue
+    bool ovT = false;
+    uint32_t cRep = 0;
+    auto holeT = [&](uint32_t i) { q.text[i].rsId = 0xFFFFFFFFu; };
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t waveBase = slot & ~63u;
     const uint64_t HP0 = (~0ull) << MX_LEFT;
@@ -693,8 +750,9 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const u
         uint32_t rs = 0, start = 0, m = 0, firstRow = 0, len = 0, col = 0;
         uint64_t edPack = 0, edPackHi = 0;
         const uint32_t* Gf = G;
-        if (it < nTasks) {
-            const uint4 t = tbq[it];
+        uint4 t = make_uint4(0, 0, 0, 0);
+        if (it < nTasks) t = tbq[it];
+        if (t.z != 0u) { // (mask 0: a hole of the task queue)
             rs = t.x;
             start = t.y;
             m = t.z;
@@ -770,14 +828,14 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const u
                                                  : (uint32_t)((edPackHi >> (3u * (bitIdx - 21u))) & 7ull);
                 rec = TextOccRec{rs, start + ti, start + ri, ed};
             }
-            uint32_t total;
-            const uint32_t o = waveAppend(&q.cnt[2], have ? 1u : 0u, total);
-            if (have) {
-                if (o >= q.textCap) flags |= FLAG_TEXT_OVERFLOW;
-                else q.text[o] = rec;
-            }
+            if (have) cRep++;
+            const uint32_t o = chT.alloc(&q.cnt[2], q.textCap, have ? 1u : 0u, 256u, ovT, holeT);
+            if (have && o != 0xFFFFFFFFu) q.text[o] = rec;
         }
     }
+    chT.fill(holeT);
+    if (ovT) flags |= FLAG_TEXT_OVERFLOW;
+    if (cRep) atomicAdd(&q.counters[1], (unsigned long long)cRep);
     if (flags) atomicOr(&q.cnt[3], flags);
 }
 
@@ -813,6 +871,10 @@ k_pack_keys(const TextOccRec* __restrict__ text, uint32_t n, const uint64_t* __r
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const TextOccRec t = text[i];
+    if (t.rsId == 0xFFFFFFFFu) { // a hole: sorts behind every read
+        keys[i] = ~0ull;
+        return;
+    }
     const uint32_t r = t.rsId >> 1;
     const uint32_t len = (uint32_t)(offs[r + 1] - offs[r]);
     const uint32_t width = t.end - t.begin;
