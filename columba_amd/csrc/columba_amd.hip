@@ -468,7 +468,7 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                     dq.order = b->dfsIdxB.p;
                     dq.live = nDfs;
                     dq.nStatic = std::min<uint32_t>(want, nDfs);
-                    dq.tSplit = getenv("CMB_TSPLIT") ? (uint32_t)atoi(getenv("CMB_TSPLIT")) : 32u;
+                    dq.tSplit = getenv("CMB_TSPLIT") ? (uint32_t)atoi(getenv("CMB_TSPLIT")) : 128u;
                     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&b->cnt.p[6], (int)dq.nStatic, 1, s));
                     // final-column cluster cells per phase: Wh + Wv + 1 <= 3 k + 1 (search.h bounds U by k)
                     const uint32_t clCells = std::min<uint32_t>(CL_MAX, 3 * b->k + 2);

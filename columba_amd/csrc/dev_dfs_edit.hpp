@@ -56,6 +56,8 @@ struct ColdFrame {
 struct Scratch2 {
     SEntry don[DON_MAX]; // children offered to helper lanes in this iteration
     SEntry subIn;        // child this lane received
+    Hot donHdr;          // frame header of the phase the offered children belong to
+    Hot subHdr;          // ... and of the phase of the child this lane received
     uint16_t pb[MAXP], pe[MAXP];
     ColdFrame fr[MAXP];
     SEntry stack[STACK2_MAX];
@@ -66,12 +68,15 @@ struct Scratch2 {
 // order[] (widest start range first), so every wavefront starts with one task of each size class.
 //
 // Sharing a big subtree inside the wavefront: once the original tasks are exhausted, a lane without work
-// becomes a helper.  A lane working on the FIRST phase of its task offers wide children (>= tSplit
-// suffix-array rows, row not yet in the final column: such a child is self-contained — ranges + row state)
-// to the helpers of its own wavefront instead of pushing them: the entries are staged in the donor's slab,
-// matched to helpers by rank at the end of the iteration (ballots + one LDS table, no global atomics), and a
-// helper then runs the first phase from that child as if it had popped it.  What no helper takes goes back
-// on the donor's stack.  So the time a wavefront needs is the sum of its tasks over 64 lanes, not its
+// becomes a helper.  A busy lane offers wide children (>= tSplit suffix-array rows, row not yet in the
+// final column of its phase) to the helpers of its own wavefront instead of pushing them.  Such a child is
+// self-contained given (i) its stack entry (ranges + row state), (ii) the header of its phase and (iii) the
+// descendants / initial distances of the at most two earlier phases that header refers to (they do not
+// change while the phase is alive); no cluster cell of the phase has been written on its path yet.  The
+// entries and the header are staged in the donor's slab, matched to helpers by rank at the end of the
+// iteration (ballots + one LDS table, no global atomics); the helper copies (i)-(iii) and runs the phase
+// from that child as if it had popped it, with that phase as its bottom phase.  What no helper takes goes
+// back on the donor's stack.  So the time a wavefront needs is the sum of its tasks over 64 lanes, not its
 // largest task.
 struct DfsQueue {
     const DfsTask* tasks;
@@ -151,7 +156,7 @@ struct EditDfs {
 #pragma unroll
             for (int ch = 0; ch < 4; ch++) Mblk[ch] = matchWord(gbits(ch), H.xOff, H.xLen, blk);
         }
-        const bool canSplit = helpersWaiting && dq.tSplit != 0 && level == firstIdx && !H.g.inFinalColumn(row);
+        const bool canSplit = helpersWaiting && dq.tSplit != 0 && !H.g.inFinalColumn(row);
         bool kept = false;
 #pragma unroll
         for (uint32_t ch = 1; ch <= 4; ch++) {
@@ -170,6 +175,7 @@ struct EditDfs {
                 e.b = make_uint4(row | (ch << 16) | ((valid ? 1u : 0u) << 24), score, (uint32_t)HP, (uint32_t)(HP >> 32));
                 e.c = make_uint4((uint32_t)HN, (uint32_t)(HN >> 32), (uint32_t)RAC, (uint32_t)(RAC >> 32));
                 if (canSplit && kept && child.sa.width() >= dq.tSplit) { // offer the subtree to a helper
+                    if (nDon == 0) S.donHdr = H;
                     S.don[nDon++] = e;
                     continue;
                 }
@@ -525,6 +531,27 @@ struct EditDfs {
         classify(nd, HP, HN, RAC, e.b.y, valid, -1);
     }
 
+    // helper side of a hand-over: copy the child, the header of its phase and the two earlier frames that
+    // header refers to (descendants / initial distances only) from the donor's slab
+    __device__ __forceinline__ void receive(const Scratch2& D, uint32_t item) {
+        S.subIn = D.don[item];
+        const Hot h = D.donHdr;
+        S.subHdr = h;
+        const int refs[2] = {h.descLvl, h.otherLvl};
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int lv = refs[r];
+            if (lv < 0 || (r == 1 && lv == refs[0])) continue;
+            const ColdFrame& src = D.fr[lv];
+            ColdFrame& dst = S.fr[lv];
+            const uint32_t nd = src.nDesc, ni = src.nInit;
+            dst.nDesc = (uint8_t)nd;
+            dst.nInit = (uint8_t)ni;
+            for (uint32_t i = 0; i < nd; i++) dst.desc[i] = src.desc[i];
+            for (uint32_t i = 0; i < ni; i++) dst.init[i] = src.init[i];
+        }
+    }
+
     // ---- (4) parked operations ------------------------------------------------------------------
     __device__ __forceinline__ void heavy(const DfsQueue& dq, const PartOut* parts, const uint64_t* offs,
                                           const uint32_t* Gall) {
@@ -571,18 +598,35 @@ struct EditDfs {
                     S.pe[i] = po.pe[i];
                 }
                 s = &st.sch[task.scheme].s[task.search];
-                firstIdx = task.idx;
-                level = firstIdx - 1;
                 req = false;
-                er.want = true;
-                er.idx = firstIdx;
-                er.prevLvl = -1;
-                er.notPrevLvl = -1;
-                er.sm.r = task.r;
-                er.sm.dist = 0;
-                er.sm.depth = task.depth;
-                er.sm.shift = 0;
-                er.sm.valid = true;
+                if (subStart) {
+                    // continue the donor's phase from the received child: that phase is this lane's bottom phase
+                    H = S.subHdr;
+                    level = (int)H.idx;
+                    firstIdx = level;
+                    mbBlock = 0xFFFFFFFFu;
+                    H.stackBase = 0;
+                    H.stackTop = 0;
+                    H.replay = 0;
+                    H.inReplay = 0;
+                    H.lastCell = -1;
+                    for (uint32_t i = 0; i < H.clSize; i++) ED(level, i) = (uint8_t)(H.maxED + 1);
+                    S.fr[level].nDesc = 0;
+                    S.fr[level].nInit = 0;
+                    S.stack[H.stackTop++] = S.subIn;
+                } else {
+                    firstIdx = task.idx;
+                    level = firstIdx - 1;
+                    er.want = true;
+                    er.idx = firstIdx;
+                    er.prevLvl = -1;
+                    er.notPrevLvl = -1;
+                    er.sm.r = task.r;
+                    er.sm.dist = 0;
+                    er.sm.depth = task.depth;
+                    er.sm.shift = 0;
+                    er.sm.valid = true;
+                }
             }
         } else {
             if (pend == PEND_DEEPER) {
@@ -597,13 +641,7 @@ struct EditDfs {
                 if (level < firstIdx) pend = PEND_FETCH; // search finished: next task
             }
         }
-        if (er.want) {
-            enter(er.idx, er.sm, er.prevLvl, er.notPrevLvl);
-            if (subStart) { // a handed-over subtree: the phase starts at that child instead of at row 0
-                req = false;
-                S.stack[H.stackTop++] = S.subIn;
-            }
-        }
+        if (er.want) enter(er.idx, er.sm, er.prevLvl, er.notPrevLvl);
     }
 };
 

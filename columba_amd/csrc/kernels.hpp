@@ -173,9 +173,15 @@ k_prep(const uint8_t* __restrict__ reads, const uint64_t* __restrict__ offs, uin
     }
 }
 
+// Per-lane counters are summed over the wavefront first (all 64 lanes call this, at the end of a kernel):
+// one atomic per wavefront and counter instead of one per lane.
 __device__ __forceinline__ void flushCounters(const Queues& q, const uint32_t* local, const int* which, int n) {
-    for (int i = 0; i < n; i++)
-        if (local[i]) atomicAdd(&q.counters[which[i]], (unsigned long long)local[i]);
+    for (int i = 0; i < n; i++) {
+        unsigned long long v = local[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&q.counters[which[i]], v);
+    }
 }
 
 // wave-wide exclusive prefix sum (all 64 lanes must call)
@@ -416,7 +422,7 @@ k_dfs_edit(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* __
                 const uint32_t rank = (uint32_t)__popcll(helpMask & ((1ull << laneId) - 1ull));
                 if (rank < total) { // take child `rank`
                     const uint32_t m = donMap[rank];
-                    d.S.subIn = slabs[blockIdx.x * 64 + (m >> 2)].don[m & 3u];
+                    d.receive(slabs[blockIdx.x * 64 + (m >> 2)], m & 3u);
                 }
             }
             // the donors' task indices travel by shuffle (all lanes participate)
@@ -835,7 +841,11 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const u
     }
     chT.fill(holeT);
     if (ovT) flags |= FLAG_TEXT_OVERFLOW;
-    if (cRep) atomicAdd(&q.counters[1], (unsigned long long)cRep);
+    {
+        const uint32_t local[1] = {cRep};
+        const int which[1] = {1};
+        flushCounters(q, local, which, 1);
+    }
     if (flags) atomicOr(&q.cnt[3], flags);
 }
 
