@@ -261,6 +261,8 @@ struct cmb_batch {
     DevBuf<unsigned long long> keysA, keysB;
     DevBuf<uint32_t> fcounts, foffs;
     DevBuf<uint8_t> sortTmp, scanTmp;
+    DevBuf<unsigned long long> vkeysA, vkeysB; // verification keys (k_verify) / sorted, then distinct
+    DevBuf<uint32_t> vcounts, vruns;           // multiplicities of the distinct keys / number of runs
     DevBuf<uint32_t> cnt;
     DevBuf<unsigned long long> counters;
     uint32_t nSlots = 0;
@@ -539,10 +541,43 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
             HIPCHK(hipStreamSynchronize(s));
             if (nItems) {
                 const uint32_t vSlots = std::min<uint32_t>(((nItems + 255) / 256) * 256, 256u * 2048u);
+                // Edit distance: identical verifications (same read x strand, text window and bounds — the parts of
+                // one read seeding the same alignment) are performed once: k_verify only locates and emits a key per
+                // candidate, the keys are sorted and run-length encoded, k_verify_edit verifies the distinct ones and
+                // scales the counters by the multiplicities.
+                const bool dedup = b->metric == CMB_METRIC_EDIT && b->k > 0 && b->k <= 7 && 2ull * nReads <= (1ull << 24);
+                const uint32_t tbCap = (uint32_t)std::min<size_t>(b->tbq.n, 0xFFFFFFF0u);
                 tm.begin();
+                if (dedup && b->vkeysA.n < nItems) {
+                    b->vkeysA.alloc((size_t)nItems + nItems / 8 + 256);
+                    b->vkeysB.alloc((size_t)nItems + nItems / 8 + 256);
+                    b->vcounts.alloc((size_t)nItems + nItems / 8 + 256);
+                    b->vruns.alloc(4);
+                }
                 hipLaunchKernelGGL(k_verify, dim3(vSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->maxLen, b->gw,
-                                   b->seq.p, b->G.p, b->items.p, nItems, b->tbq.p,
-                                   (uint32_t)std::min<size_t>(b->tbq.n, 0xFFFFFFF0u), q);
+                                   b->seq.p, b->G.p, b->items.p, nItems, b->tbq.p, tbCap,
+                                   dedup ? b->vkeysA.p : (unsigned long long*)nullptr, q);
+                if (dedup) {
+                    size_t tmpBytes = 0;
+                    HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, b->vkeysA.p, b->vkeysB.p, nItems, 0, 64, s));
+                    if (b->sortTmp.n < tmpBytes) b->sortTmp.alloc(tmpBytes + 256);
+                    HIPCHK(rocprim::radix_sort_keys(b->sortTmp.p, tmpBytes, b->vkeysA.p, b->vkeysB.p, nItems, 0, 64, s));
+                    size_t rleBytes = 0;
+                    HIPCHK(rocprim::run_length_encode(nullptr, rleBytes, b->vkeysB.p, nItems, b->vkeysA.p, b->vcounts.p,
+                                                      b->vruns.p, s));
+                    if (b->scanTmp.n < rleBytes) b->scanTmp.alloc(rleBytes + 256);
+                    HIPCHK(rocprim::run_length_encode(b->scanTmp.p, rleBytes, b->vkeysB.p, nItems, b->vkeysA.p,
+                                                      b->vcounts.p, b->vruns.p, s));
+                    uint32_t nRuns = 0;
+                    HIPCHK(hipMemcpyAsync(&nRuns, b->vruns.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    HIPCHK(hipStreamSynchronize(s));
+                    if (getenv("CMB_VERBOSE")) fprintf(stderr, "[verify] %u items, %u distinct keys\n", nItems, nRuns);
+                    if (nRuns) {
+                        const uint32_t eSlots = std::min<uint32_t>(((nRuns + 255) / 256) * 256, 256u * 2048u);
+                        hipLaunchKernelGGL(k_verify_edit, dim3(eSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->gw,
+                                           b->G.p, b->vkeysA.p, b->vcounts.p, nRuns, b->tbq.p, tbCap, q);
+                    }
+                }
                 tm.end("k_verify");
                 HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
                 HIPCHK(hipStreamSynchronize(s));
@@ -868,7 +903,7 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         uint32_t hc[8];
         if (n) {
             hipLaunchKernelGGL(k_verify, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, plen, gw, seq.p, G.p,
-                               items.p, (uint32_t)n, tbq.p, (uint32_t)tbq.n, q);
+                               items.p, (uint32_t)n, tbq.p, (uint32_t)tbq.n, (unsigned long long*)nullptr, q);
             HIPCHK(hipMemcpy(hc, cnt.p, 32, hipMemcpyDeviceToHost));
             if (hc[7])
                 hipLaunchKernelGGL(k_traceback, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, gw, G.p, tbq.p,

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
 
 namespace cmb {
 
@@ -603,12 +604,56 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const uint32
     return i;
 }
 
+// Key of an edit-distance verification: everything the banded matrix depends on.  The k+1 (or more) parts
+// of one read that seed the same alignment produce the same key, so equal keys are verified once and every
+// counter is scaled by the multiplicity (the reference verifies each of them, with identical results).
+__host__ __device__ __forceinline__ unsigned long long packVerifyKey(uint32_t rs, uint32_t start, uint32_t maxED,
+                                                                     uint32_t minED, uint32_t fixed) {
+    return ((unsigned long long)rs << 39) | ((unsigned long long)start << 7) | ((unsigned long long)(maxED & 7u) << 4) |
+           ((unsigned long long)(minED & 7u) << 1) | (unsigned long long)(fixed & 1u);
+}
+
+// one edit-distance verification (FMIndex::inTextVerification + InTextVerificationTask::doTask) of `mult`
+// identical candidates; returns true with a traceback task if the final column holds cluster centres
+__device__ __forceinline__ bool verifyEdit(const DevIndex& ix, const uint64_t* offs, uint32_t gw, const uint32_t* G,
+                                           uint32_t rs, uint32_t start, uint32_t maxED, uint32_t minED, uint32_t fixed,
+                                           uint32_t mult, uint32_t& cStarted, uint32_t& cRows, uint32_t& cText,
+                                           uint32_t& cAbort, uint32_t& cCig, uint4& tbRec) {
+    cStarted += mult;
+    const uint32_t len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
+    const uint32_t nZeros = fixed ? 1u : 2u * maxED + 1u;
+    MatGeom g;
+    g.n = len + 1;
+    g.maxED = maxED;
+    g.Wv = nZeros - 1 + maxED;
+    g.Wh = maxED;
+    g.m = g.Wv + g.n;
+    const uint32_t maxEnd = ix.n - 1;
+    const uint32_t hEnd = min(maxEnd, start + g.m - 1);
+    const uint32_t size = hEnd > start ? hEnd - start : 0;
+    if (!g.inFinalColumn(size)) return false;
+    uint32_t mask = 0, rows = 0;
+    uint64_t edPack, edPackHi;
+    const VPlanes noPlanes{nullptr, nullptr, 0};
+    const uint32_t i = forwardPass<false>(ix, G + (size_t)rs * 8 * gw, gw, len, g, nZeros, start, size, maxED, minED,
+                                          mask, edPack, edPackHi, noPlanes, 0, rows);
+    cRows += rows * mult;
+    cText += rows * mult;
+    if (i <= size - g.sfc() || mask == 0) { // indexhelpers.cpp:542, :550
+        cAbort += mult;
+        return false;
+    }
+    cCig += (uint32_t)__popc(mask) * mult; // = positions the traceback will report (one per centre)
+    tbRec = make_uint4(rs, start, mask, maxED | (fixed << 4));
+    return true;
+}
+
 // pass 1: locate + verify.  Exact / Hamming candidates produce text occurrences directly; edit-distance
 // candidates whose final column holds cluster centres become traceback tasks {rs, start, mask, meta}.
 __global__ void __launch_bounds__(256)
 k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32_t gw,
          const uint8_t* __restrict__ seq, const uint32_t* __restrict__ G, const uint4* __restrict__ items,
-         uint32_t nItems, uint4* __restrict__ tbq, uint32_t tbCap, Queues q) {
+         uint32_t nItems, uint4* __restrict__ tbq, uint32_t tbCap, unsigned long long* __restrict__ vkeys, Queues q) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cLF = 0, cLoc = 0, cText = 0, cRows = 0, cAbort = 0, cCig = 0, cStarted = 0, cRep = 0, flags = 0;
     WaveChunk chT, chB; // chunks of the text-occurrence queue / the traceback task queue
@@ -623,6 +668,7 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
         uint32_t nOut = 0, nTb = 0;
         uint4 outRec = make_uint4(0, 0, 0, 0), tbRec = make_uint4(0, 0, 0, 0);
         uint32_t rs = 0;
+        unsigned long long vkey = ~0ull;
         uint4 item = make_uint4(0xFFFFFFFFu, 0, 0, 0);
         if (it < nItems) item = items[it];
         if (item.x != 0xFFFFFFFFu) { // (holes: unused slots of a wavefront's chunk)
@@ -681,37 +727,18 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
                 }
             } else {
                 // ---- edit distance: FMIndex::inTextVerification + InTextVerificationTask::doTask
-                cStarted++;
                 const uint32_t startDiff = a;
                 const uint32_t sum = pos + shift; // getBeginPositions (fmindex.h:374-379)
                 const uint32_t start = sum >= startDiff ? sum - startDiff : 0;
-                const uint32_t nZeros = fixed ? 1u : 2u * maxED + 1u;
-                MatGeom g;
-                g.n = len + 1;
-                g.maxED = maxED;
-                g.Wv = nZeros - 1 + maxED;
-                g.Wh = maxED;
-                g.m = g.Wv + g.n;
-                const uint32_t maxEnd = ix.n - 1;
-                const uint32_t hEnd = min(maxEnd, start + g.m - 1);
-                const uint32_t size = hEnd > start ? hEnd - start : 0;
-                if (g.inFinalColumn(size)) {
-                    uint32_t mask = 0, rows = 0;
-                    uint64_t edPack, edPackHi;
-                    const uint32_t i = forwardPass<false>(ix, G + (size_t)rs * 8 * gw, gw, len, g, nZeros, start, size,
-                                                          maxED, minED, mask, edPack, edPackHi, noPlanes, 0, rows);
-                    cRows += rows;
-                    cText += rows;
-                    if (i <= size - g.sfc() || mask == 0) { // indexhelpers.cpp:542, :550
-                        cAbort++;
-                    } else {
-                        cCig += __popc(mask);
-                        tbRec = make_uint4(rs, start, mask, maxED | (fixed << 4));
-                        nTb = 1;
-                    }
+                if (vkeys) { // verified once per distinct key by k_verify_edit
+                    vkey = packVerifyKey(rs, start, maxED, minED, fixed);
+                } else if (verifyEdit(ix, offs, gw, G, rs, start, maxED, minED, fixed, 1u, cStarted, cRows, cText, cAbort,
+                                      cCig, tbRec)) {
+                    nTb = 1;
                 }
             }
         }
+        if (vkeys && it < nItems) vkeys[it] = vkey;
         // ---- appends into the wavefront's chunks of the two output queues
         cRep += nOut;
         const uint32_t o1 = chT.alloc(&q.cnt[2], q.textCap, nOut, 256u, ovT, holeT);
@@ -723,9 +750,44 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
     chB.fill(holeB);
     if (ovT) flags |= FLAG_TEXT_OVERFLOW;
     if (ovB) flags |= FLAG_CAPACITY; // (sized by the host for the worst case)
-    const uint32_t local[8] = {cLF, cLoc, cText, cRows, cAbort, cCig, cStarted, cRep};
+    const uint32_t local[8] = {cLF, cLoc, cText, cRows, cAbort, cCig, cStarted, cRep + cCig};
     const int which[8] = {8, 9, 10, 11, 3, 4, 2, 1};
     flushCounters(q, local, which, 8);
+    if (flags) atomicOr(&q.cnt[3], flags);
+}
+
+// pass 1b: the distinct edit-distance verifications (sorted + run-length encoded keys of k_verify)
+__global__ void __launch_bounds__(256)
+k_verify_edit(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const uint32_t* __restrict__ G,
+              const unsigned long long* __restrict__ ukeys, const uint32_t* __restrict__ counts, uint32_t nKeys,
+              uint4* __restrict__ tbq, uint32_t tbCap, Queues q) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cText = 0, cRows = 0, cAbort = 0, cCig = 0, cStarted = 0, flags = 0;
+    WaveChunk chB;
+    bool ovB = false;
+    auto holeB = [&](uint32_t i) { tbq[i] = make_uint4(0, 0, 0, 0); };
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t waveBase = slot & ~63u;
+    for (uint32_t base = waveBase; base < nKeys; base += stride) { // wave-uniform trip count
+        const uint32_t it = base + (threadIdx.x & 63u);
+        uint32_t nTb = 0;
+        uint4 tbRec = make_uint4(0, 0, 0, 0);
+        unsigned long long key = ~0ull;
+        if (it < nKeys) key = ukeys[it];
+        if (key != ~0ull) { // (~0: the run of non-edit items and holes)
+            const uint32_t mult = min(counts[it], 0xFFFFFFu);
+            if (verifyEdit(ix, offs, gw, G, (uint32_t)(key >> 39), (uint32_t)(key >> 7), (uint32_t)(key >> 4) & 7u,
+                           (uint32_t)(key >> 1) & 7u, (uint32_t)key & 1u, mult, cStarted, cRows, cText, cAbort, cCig, tbRec))
+                nTb = 1;
+        }
+        const uint32_t o2 = chB.alloc(&q.cnt[7], tbCap, nTb, 256u, ovB, holeB);
+        if (nTb && o2 != 0xFFFFFFFFu) tbq[o2] = tbRec;
+    }
+    chB.fill(holeB);
+    if (ovB) flags |= FLAG_CAPACITY;
+    const uint32_t local[6] = {cText, cRows, cAbort, cCig, cStarted, cCig};
+    const int which[6] = {10, 11, 3, 4, 2, 1}; // (every centre is reported once: TOTAL_REPORTED += CIGARS)
+    flushCounters(q, local, which, 6);
     if (flags) atomicOr(&q.cnt[3], flags);
 }
 
@@ -746,7 +808,6 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const u
     uint32_t flags = 0, dummyRows = 0;
     WaveChunk chT; // chunk of the text-occurrence queue
     bool ovT = false;
-    uint32_t cRep = 0;
     auto holeT = [&](uint32_t i) { q.text[i].rsId = 0xFFFFFFFFu; };
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t waveBase = slot & ~63u;
@@ -834,18 +895,12 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const u
                                                  : (uint32_t)((edPackHi >> (3u * (bitIdx - 21u))) & 7ull);
                 rec = TextOccRec{rs, start + ti, start + ri, ed};
             }
-            if (have) cRep++;
             const uint32_t o = chT.alloc(&q.cnt[2], q.textCap, have ? 1u : 0u, 256u, ovT, holeT);
             if (have && o != 0xFFFFFFFFu) q.text[o] = rec;
         }
     }
     chT.fill(holeT);
     if (ovT) flags |= FLAG_TEXT_OVERFLOW;
-    {
-        const uint32_t local[1] = {cRep};
-        const int which[1] = {1};
-        flushCounters(q, local, which, 1);
-    }
     if (flags) atomicOr(&q.cnt[3], flags);
 }
 
