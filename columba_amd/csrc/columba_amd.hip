@@ -242,7 +242,9 @@ struct cmb_batch {
     DevStrategyK hostStrat{};
     hipStream_t stream = nullptr;
     DevBuf<uint8_t> reads, seq;
-    DevBuf<uint32_t> rec; // read records for k_partition (k_prep)
+    DevBuf<uint32_t> rec; // read records for k_parts / k_exact (k_prep)
+    DevBuf<uint4> exr;    // exact-match range pair of every part: [part][read x strand] (k_parts -> k_exact)
+    DevBuf<uint8_t> psel; // selected scheme per read x strand (bit 7: nothing to search)
     uint32_t recW = 0;
     DevBuf<uint64_t> offs;
     DevBuf<uint32_t> G;
@@ -427,11 +429,28 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
             const uint32_t dfsCap = (uint32_t)std::min<size_t>(b->dfs.n, 0xFFFFFFF0u);
             tm.begin();
             const uint32_t pParts = b->k ? b->hostStrat.numParts : 1;
-            const uint32_t pLds = (uint32_t)((sizeof(DevStrategyK) + 15) / 16 * 16) +
-                                  (5 * pParts + 2 * ((b->maxLen + 31) / 32)) * 256 * sizeof(uint32_t);
-            hipLaunchKernelGGL(k_partition, dim3(pSlots / 256), dim3(256), pLds, s, ix->d, b->strat.p, b->offs.p,
-                               nReads, b->k, b->maxLen, b->seq.p, (const uint4*)b->rec.p, b->recW / 4, b->parts.p, b->dfs.p,
-                               dfsCap, q);
+            const uint32_t stratBytes = (uint32_t)((sizeof(DevStrategyK) + 15) / 16 * 16);
+            const uint32_t rdWords = 2 * ((b->maxLen + 31) / 32);
+            uint32_t nSlots = 1; // k = 0: one exact search per read x strand
+            if (b->k) {
+                if (b->exr.n < (size_t)pParts * tasks) {
+                    b->exr.alloc((size_t)pParts * tasks);
+                    b->psel.alloc(tasks);
+                }
+                hipLaunchKernelGGL(k_parts, dim3(pSlots / 256), dim3(256),
+                                   stratBytes + (5 * pParts + rdWords) * 256 * sizeof(uint32_t), s, ix->d, b->strat.p, nReads,
+                                   b->k, b->maxLen, b->seq.p, (const uint4*)b->rec.p, b->recW / 4, b->parts.p, b->exr.p,
+                                   b->psel.p, q);
+                uint32_t maxSearches = 0;
+                for (int i = 0; i < b->hostStrat.nSchemes; i++)
+                    maxSearches = std::max<uint32_t>(maxSearches, b->hostStrat.sch[i].nSearches);
+                nSlots = maxSearches + 1; // + the part-level pre-verification
+            }
+            const uint64_t eTasks = (uint64_t)tasks * nSlots;
+            const uint32_t eSlots = (uint32_t)std::min<uint64_t>(((eTasks + 255) / 256) * 256, 256ull * 4096ull);
+            hipLaunchKernelGGL(k_exact, dim3(eSlots / 256), dim3(256), stratBytes + (pParts + rdWords) * 256 * sizeof(uint32_t),
+                               s, ix->d, b->strat.p, nReads, b->k, b->maxLen, nSlots, b->seq.p, (const uint4*)b->rec.p,
+                               b->recW / 4, b->parts.p, b->exr.p, b->psel.p, b->dfs.p, dfsCap, q);
             tm.end("k_partition");
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));

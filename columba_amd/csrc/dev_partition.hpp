@@ -1,19 +1,18 @@
-// Device-side per read x strand PROLOGUE as a lane-uniform state machine (k_partition).
-//
-// Everything matchWithSearches (reference src/searchstrategy.cpp:425-493) does before the
-// approximate DFS is a chain of single-character bidirectional extensions:
-//   * partitioning — uniform / static (calculateExactMatchRanges :158-190) or dynamic
-//     (seed :381-419 + greedy extension :299-379),
-//   * part-level in-text pre-verification (:464-476),
-//   * dynamic scheme selection (src/searchstrategy.h:2505-2537),
-//   * per search: the exact phases of doRecSearch (:1181-1254) and the entry decision of
-//     recApproxMatchEditEntry (src/indexinterface.cpp:1306-1325),
-//   * for k = 0: exactMatchesOutput (src/indexinterface.cpp:947-1014).
-// On the GPU that chain is the rank/extend kernel proper: every lane of a wavefront is at the SAME
-// program point (one extension per loop iteration, 12 independent 16-byte loads per lane in
-// flight), whatever logical phase its read is in; the bookkeeping between two extensions is a few
-// scalar decisions.  What needs the irregular DFS is emitted as a compact DfsTask for k_dfs; what
-// can be verified in the text is emitted as work items for k_verify.
+// Device-side PROLOGUE of the search: everything matchWithSearches (reference src/searchstrategy.cpp:425-493)
+// does before the approximate DFS is a chain of single-character bidirectional extensions.  It runs as two
+// kernels whose loop bodies are small:
+//   k_parts  one lane per read x strand, PartMachine below: partitioning — uniform / static
+//            (calculateExactMatchRanges :158-190) or dynamic (seed :381-419 + greedy extension :299-379) —
+//            and the dynamic scheme selection (src/searchstrategy.h:2505-2537).  Output: the parts, the
+//            exact-match range pair of every part, the selected scheme.
+//   k_exact  one lane per (read x strand, search of the selected scheme) + one per read x strand for the
+//            part-level in-text pre-verification (:464-476): the exact phases of doRecSearch (:1181-1254) and
+//            the entry decision of recApproxMatchEditEntry (src/indexinterface.cpp:1306-1325); for k = 0
+//            one lane per read x strand runs exactMatchesOutput (src/indexinterface.cpp:947-1014).
+// Both follow the same rule: every lane of a wavefront is at the SAME program point when it touches memory
+// (one "memory step" per loop iteration: rank blocks of an extension, k-mer table entries, or a record),
+// whatever logical phase its read is in.  What needs the irregular DFS is emitted as a compact DfsTask for
+// k_dfs; what can be verified in the text is emitted as work items for k_verify.
 #pragma once
 #include "dev_search.hpp"
 
@@ -30,16 +29,13 @@ struct PartOut { // per read x strand: the parts, needed again by k_dfs
     uint16_t pb[MAXP], pe[MAXP];
 };
 
-enum : int { PH_CALC = 0, PH_DYN, PH_POST, PH_SEARCH, PH_EXACT, PH_K0, PH_SEED, PH_DONE };
+enum : int { PH_CALC = 0, PH_DYN, PH_SEED, PH_FIN, PH_DONE };
 // what a lane asks of the iteration's single memory step
 enum : int { RQ_NONE = 0, RQ_RANK, RQ_SEED, RQ_REC };
 
 struct PartMachine {
     const DevIndex& ix;
     const DevStrategyK& st;
-    const Queues& q;
-    DfsTask* dfsQ;
-    uint32_t dfsCap;
     // task
     uint32_t rsId = 0, len = 0, k = 0;
     const uint8_t* seq = nullptr;
@@ -71,62 +67,28 @@ struct PartMachine {
         return e <= b ? 0u : e - b;
     }
     // counters
-    uint32_t cNode = 0, cExp = 0, cImm = 0, cStart = 0, flags = 0;
+    uint32_t cNode = 0, cExp = 0, flags = 0;
     // machine state
     int phase = PH_DONE;
     int numParts = 0;
     int pi = 0;          // PH_CALC: current part
-    uint32_t ci = 0;     // PH_CALC / PH_EXACT: next character index inside the part
+    uint32_t ci = 0;     // PH_CALC: next character index inside the part
     uint32_t cend = 0;   // PH_CALC: number of characters to match in the part
-    uint32_t cb = 0, ce = 0; // PH_CALC / PH_EXACT: sub-range of the read being matched
+    uint32_t cb = 0, ce = 0; // PH_CALC: sub-range of the read being matched
     int cdir = 0;        // direction of the substring being matched
     uint32_t j = 0;      // PH_DYN: assigned characters so far
     int partToExtend = 0, dynDir = 0;
-    int sel = 0, si = 0, partInSearch = 0; // PH_SEARCH / PH_EXACT
-    uint32_t exactLength = 0;
-    RangePair cur;       // range being extended (PH_EXACT / PH_K0)
-    uint32_t k0i = 0;    // PH_K0
-    int postI = 0;       // PH_POST: next part to pre-verify
     // pending request for the memory step (RQ_RANK: extension of reqParent with reqCode)
     int req = RQ_NONE;
     int reqMode = 0;
     uint32_t reqCode = 0;
     RangePair reqParent;
 
-    __device__ PartMachine(const DevIndex& i, const DevStrategyK& s, const Queues& qq, DfsTask* dq, uint32_t dc,
-                           uint32_t* ldsBase, uint32_t tid, uint32_t stride)
-        : ix(i), st(s), q(qq), dfsQ(dq), dfsCap(dc), lds(ldsBase), ltid(tid), lstride(stride),
-          lparts(s.numParts ? s.numParts : 1) {}
+    __device__ PartMachine(const DevIndex& i, const DevStrategyK& s, uint32_t* ldsBase, uint32_t tid, uint32_t stride)
+        : ix(i), st(s), lds(ldsBase), ltid(tid), lstride(stride), lparts(s.numParts ? s.numParts : 1) {}
     __device__ void setReadWords(uint32_t maxLen) { // LDS words after the 5 x lparts partition fields
         rdBase = 5u * lparts;
         pw1 = (maxLen + 31) / 32;
-    }
-
-    // ---- emission ---------------------------------------------------------------------------
-    // Work items and DFS tasks are STAGED (at most one group of each per advance()/resume()); the
-    // kernel appends the staged records of the whole wavefront with one atomic (waveAppend).
-    uint32_t stN = 0, stB = 0, stA = 0, stMeta = 0, stRs = 0;
-    bool stDfs = false;
-    DfsTask stTask;
-    __device__ __forceinline__ bool emitItems(const Range& sa, uint32_t a, uint32_t meta) {
-        const uint32_t w = sa.width();
-        if (!w) return false;
-        stN = w;
-        stB = sa.b;
-        stA = a;
-        stMeta = meta;
-        stRs = rsId;
-        return true;
-    }
-    __device__ __forceinline__ void emitDfs(int idx, const RangePair& r, uint32_t depth) {
-        stTask.rsId = rsId;
-        stTask.scheme = (uint8_t)sel;
-        stTask.search = (uint8_t)si;
-        stTask.idx = (uint8_t)idx;
-        stTask.pad = 0;
-        stTask.r = r;
-        stTask.depth = depth;
-        stDfs = true;
     }
 
     // ---- helpers ----------------------------------------------------------------------------
@@ -199,17 +161,6 @@ struct PartMachine {
         req = RQ_NONE;
         partToExtend = 0;
         dynDir = 0;
-        postI = 0;
-        if (k == 0) { // exactMatchesOutput (indexinterface.cpp:947-1014)
-            if (len == 0) {
-                phase = PH_DONE;
-                return;
-            }
-            cur = RangePair{{0, ix.n}, {0, 0}};
-            k0i = len;
-            phase = PH_K0;
-            return;
-        }
         numParts = st.numParts;
         if (numParts >= (int)len || numParts == 1 || len > (uint32_t)MAX_READ) {
             flags |= FLAG_UNSUPPORTED_READ; // naive fallback (searchstrategy.cpp:148-152) not on device
@@ -327,13 +278,13 @@ struct PartMachine {
                 if (pi < numParts) {
                     startCalcPart(pi + 1);
                 } else {
-                    phase = PH_POST;
+                    phase = PH_FIN;
                 }
                 break;
             }
             case PH_DYN: { // partitionDynamic loop body (:324-378)
                 if (j >= len) {
-                    phase = PH_POST;
+                    phase = PH_FIN;
                     break;
                 }
                 uint64_t maxRangeWeighted = 0;
@@ -368,7 +319,7 @@ struct PartMachine {
                         if (i != numParts - 1 && PE(i) != PB(i + 1)) setPE(i, PB(i + 1));
                         if (i != 0 && PB(i) != PE(i - 1)) setPB(i, PE(i - 1));
                     }
-                    phase = PH_POST;
+                    phase = PH_FIN;
                     break;
                 }
                 uint32_t code;
@@ -389,121 +340,7 @@ struct PartMachine {
                 setEX(partToExtend, RangePair{{0, 0}, {0, 0}});
                 break;
             }
-            case PH_POST: { // searchstrategy.cpp:464-481
-                const uint32_t sw = ix.switchPoint;
-                while (postI < numParts) {
-                    const int i = postI++;
-                    const uint32_t width = EXW(i);
-                    if (width != 0 && width <= sw) {
-                        const uint32_t bg = PB(i);
-                        const Range sa{L(0, i), L(1, i)};
-                        if (st.metric == 1) {
-                            cImm++; // verifyExactPartialMatchInText (fmindex.cpp:253)
-                            emitItems(sa, bg == 0 ? 0 : bg + k, packMeta(0, k, 0, bg == 0, ITEM_EDIT));
-                        } else {
-                            emitItems(sa, bg, packMeta(0, k, 0, 0, ITEM_HAMMING));
-                        }
-                        return; // one staged group per scheduling step
-                    }
-                }
-                sel = 0; // MultipleSchemes::createSearches (searchstrategy.h:2505-2537)
-                if (st.nSchemes > 1) {
-                    uint32_t total = 0;
-                    for (int i = 0; i < numParts; i++) total += EXW(i);
-                    if (total > (uint32_t)numParts) {
-                        uint32_t minValue = EXW(st.sch[0].critical);
-                        for (int i = 1; i < st.nSchemes; i++) {
-                            const uint32_t w = EXW(st.sch[i].critical);
-                            if (w < minValue) {
-                                minValue = w;
-                                sel = i;
-                            }
-                        }
-                    }
-                }
-                si = 0;
-                phase = PH_SEARCH;
-                break;
-            }
-            case PH_SEARCH: { // doRecSearch (searchstrategy.cpp:1181-1254)
-                const DevScheme& sch = st.sch[sel];
-                if (si >= sch.nSearches) {
-                    phase = PH_DONE;
-                    return;
-                }
-                const DevSearch& s = sch.s[si];
-                if (s.U[0] > 0) {
-                    if (st.metric == 1) cStart++; // recApproxMatchEditEntry: complete range > switch point
-                    emitDfs(0, RangePair{{0, ix.n}, {0, ix.n}}, 0);
-                    si++;
-                    return;
-                }
-                const int first = s.order[0];
-                cur = EX(first);
-                if (cur.width() <= ix.switchPoint) {
-                    si++;
-                    break;
-                }
-                partInSearch = 1;
-                exactLength = PE(first) - PB(first);
-                ci = 0;
-                phase = PH_EXACT;
-                break;
-            }
-            case PH_EXACT: {
-                const DevSearch& s = st.sch[sel].s[si];
-                if (s.U[partInSearch] == 0) {
-                    const int part = s.order[partInSearch];
-                    const uint32_t b = PB(part), e = PE(part);
-                    const uint32_t n = e > b ? e - b : 0;
-                    if (ci < n) {
-                        const uint32_t code = charAt(b, e, s.dir[partInSearch], ci);
-                        if (code >= 1 && code <= 4) {
-                            const bool uni = s.uniAll || partInSearch >= (int)s.uniIdx;
-                            request(uni ? 2 : (s.dir[partInSearch] == 0 ? 0 : 1), cur, code);
-                            return;
-                        }
-                        cur = RangePair{{0, 0}, {0, 0}};
-                    }
-                    if (cur.empty()) { // `if (startRange.empty()) return;`
-                        si++;
-                        phase = PH_SEARCH;
-                        break;
-                    }
-                    exactLength += n;
-                    partInSearch++;
-                    ci = 0;
-                    break;
-                }
-                // exact phases done: start approximate matching
-                if (st.metric == 1 && cur.width() <= ix.switchPoint) { // recApproxMatchEditEntry
-                    cImm++;
-                    const uint32_t bg = PB(s.low[partInSearch - 1]);
-                    const uint32_t maxEDs = s.U[s.n - 1], minEDs = s.L[s.n - 1];
-                    emitItems(cur.sa, bg == 0 ? 0 : bg + maxEDs, packMeta(0, maxEDs, minEDs, bg == 0, ITEM_EDIT));
-                } else {
-                    if (st.metric == 1) cStart++;
-                    emitDfs(partInSearch, cur, exactLength);
-                }
-                si++;
-                phase = PH_SEARCH;
-                return;
-            }
-            case PH_K0: {
-                if (k0i == 0) { // everything matched in the index
-                    emitItems(cur.sa, 0, packMeta(0, 0, 0, 1, ITEM_EXACT));
-                    phase = PH_DONE;
-                    return;
-                }
-                const uint32_t code = this->code(k0i - 1);
-                if (code > 4) {
-                    phase = PH_DONE;
-                    return;
-                }
-                request(2, cur, code);
-                return;
-            }
-            default:
+            default: // PH_FIN (outputs are written by the kernel), PH_SEED, PH_DONE
                 return;
             }
         }
@@ -523,30 +360,210 @@ struct PartMachine {
         case PH_DYN:
             setEX(partToExtend, res);
             break;
-        case PH_EXACT:
-            cur = res;
-            if (ok) {
-                ci++;
-            } else { // range is empty: this search is over
-                si++;
-                phase = PH_SEARCH;
-            }
+        default:
             break;
-        case PH_K0:
+        }
+    }
+
+    // partitioning done: select the scheme (MultipleSchemes::createSearches, searchstrategy.h:2505-2537) and
+    // hand parts, exact ranges and selection to k_exact
+    __device__ void finish(PartOut* parts, uint4* exr, uint8_t* psel, uint32_t total) {
+        int sel = 0;
+        if (st.nSchemes > 1) {
+            uint32_t tot = 0;
+            for (int i = 0; i < numParts; i++) tot += EXW(i);
+            if (tot > (uint32_t)numParts) {
+                uint32_t minValue = EXW(st.sch[0].critical);
+                for (int i = 1; i < st.nSchemes; i++) {
+                    const uint32_t w = EXW(st.sch[i].critical);
+                    if (w < minValue) {
+                        minValue = w;
+                        sel = i;
+                    }
+                }
+            }
+        }
+        PartOut po;
+#pragma unroll
+        for (int i = 0; i < MAXP; i++) {
+            po.pb[i] = i < numParts ? (uint16_t)PB(i) : (uint16_t)0;
+            po.pe[i] = i < numParts ? (uint16_t)PE(i) : (uint16_t)0;
+        }
+        parts[rsId] = po;
+        for (int i = 0; i < numParts; i++) {
+            const RangePair r = EX(i);
+            exr[(size_t)i * total + rsId] = make_uint4(r.sa.b, r.sa.e, r.rev.b, r.rev.e);
+        }
+        psel[rsId] = (uint8_t)sel;
+        phase = PH_DONE;
+    }
+};
+
+// ---- k_exact: one lane per (read x strand, slot) -----------------------------------------------------
+// slot < nSlots - 1 : search `slot` of the selected scheme (exact phases, then items or a DFS task);
+// slot = nSlots - 1 : the part-level in-text pre-verification (searchstrategy.cpp:464-476);
+// k = 0            : one lane per read x strand, exactMatchesOutput (indexinterface.cpp:947-1014).
+enum : int { EX_IDLE = 0, EX_HDR, EX_LOAD, EX_RUN, EX_K0 };
+
+struct ExactLane {
+    const DevIndex& ix;
+    const DevStrategyK& st;
+    // LDS per lane: lparts words (pb | pe << 16), then 2 x pw1 read words (low / high code bits)
+    uint32_t* lds;
+    uint32_t ltid, lstride, lparts, pw1;
+    __device__ __forceinline__ uint32_t& PBE(int i) const { return lds[(uint32_t)i * lstride + ltid]; }
+    __device__ __forceinline__ uint32_t PB(int i) const { return PBE(i) & 0xFFFFu; }
+    __device__ __forceinline__ uint32_t PE(int i) const { return PBE(i) >> 16; }
+    __device__ __forceinline__ uint32_t& RD(uint32_t plane, uint32_t w) const {
+        return lds[(lparts + plane * pw1 + w) * lstride + ltid];
+    }
+    // task
+    uint32_t rsId = 0, slot = 0, len = 0;
+    const uint8_t* seq = nullptr;
+    bool hasN = false;
+    int phase = EX_IDLE;
+    int sel = 0, partInSearch = 0;
+    uint32_t ci = 0, exactLength = 0, k0i = 0;
+    RangePair cur;
+    // pending extension
+    bool req = false;
+    int reqMode = 0;
+    uint32_t reqCode = 0;
+    // staged output (at most one group / task per iteration)
+    uint32_t stN = 0, stB = 0, stA = 0, stMeta = 0;
+    bool stDfs = false;
+    uint32_t stIdx = 0, stDepth = 0;
+    RangePair stR;
+    // counters
+    uint32_t cNode = 0, cExp = 0, cImm = 0, cStart = 0;
+
+    __device__ ExactLane(const DevIndex& i, const DevStrategyK& s, uint32_t* ldsBase, uint32_t tid, uint32_t stride,
+                         uint32_t maxLen)
+        : ix(i), st(s), lds(ldsBase), ltid(tid), lstride(stride), lparts(s.numParts ? s.numParts : 1),
+          pw1((maxLen + 31) / 32) {}
+
+    __device__ __forceinline__ uint32_t code(uint32_t i) const {
+        if (hasN) return seq[i];
+        const uint32_t w = i >> 5, b = i & 31u;
+        return 1u + ((RD(0, w) >> b) & 1u) + 2u * ((RD(1, w) >> b) & 1u);
+    }
+    __device__ __forceinline__ void emitItems(const Range& sa, uint32_t a, uint32_t meta) {
+        stN = sa.width();
+        stB = sa.b;
+        stA = a;
+        stMeta = meta;
+    }
+    __device__ __forceinline__ void emitDfs(int idx, const RangePair& r, uint32_t depth) {
+        stDfs = true;
+        stIdx = (uint32_t)idx;
+        stR = r;
+        stDepth = depth;
+    }
+    // read record (k_prep): v[0].x = len | hasN << 16, then (low, high) word pairs
+    __device__ __forceinline__ void takeRecord(const uint4 v[5]) {
+        const uint32_t* vw = reinterpret_cast<const uint32_t*>(v);
+        len = vw[0] & 0xFFFFu;
+        hasN = (vw[0] >> 16) & 1u;
+#pragma unroll
+        for (uint32_t w = 0; w < 8; w++)
+            if (w < pw1) {
+                RD(0, w) = vw[1 + 2 * w];
+                RD(1, w) = vw[2 + 2 * w];
+            }
+    }
+
+    // the search starts from the exact range of its first part (doRecSearch, searchstrategy.cpp:1181-1254)
+    __device__ void startSearch(const RangePair& first) {
+        const DevSearch& s = st.sch[sel].s[slot];
+        cur = first;
+        if (cur.width() <= ix.switchPoint) { // covered by the part-level pre-verification
+            phase = EX_IDLE;
+            return;
+        }
+        const int f = s.order[0];
+        partInSearch = 1;
+        exactLength = PE(f) - PB(f);
+        ci = 0;
+        phase = EX_RUN;
+    }
+
+    // bookkeeping up to the next extension of the running search
+    __device__ void advance() {
+        const DevSearch& s = st.sch[sel].s[slot];
+        for (;;) {
+            if (s.U[partInSearch] == 0) {
+                const int part = s.order[partInSearch];
+                const uint32_t b = PB(part), e = PE(part);
+                const uint32_t n = e > b ? e - b : 0;
+                if (ci < n) {
+                    const uint32_t c = code(s.dir[partInSearch] == 0 ? b + ci : e - ci - 1);
+                    if (c >= 1 && c <= 4) {
+                        const bool uni = s.uniAll || partInSearch >= (int)s.uniIdx;
+                        req = true;
+                        reqMode = uni ? 2 : (s.dir[partInSearch] == 0 ? 0 : 1);
+                        reqCode = c;
+                        return;
+                    }
+                    cur = RangePair{{0, 0}, {0, 0}};
+                }
+                if (cur.empty()) { // `if (startRange.empty()) return;`
+                    phase = EX_IDLE;
+                    return;
+                }
+                exactLength += n;
+                partInSearch++;
+                ci = 0;
+                continue;
+            }
+            // exact phases done: start approximate matching
+            if (st.metric == 1 && cur.width() <= ix.switchPoint) { // recApproxMatchEditEntry
+                cImm++;
+                const uint32_t bg = PB(s.low[partInSearch - 1]);
+                const uint32_t maxEDs = s.U[s.n - 1], minEDs = s.L[s.n - 1];
+                emitItems(cur.sa, bg == 0 ? 0 : bg + maxEDs, packMeta(0, maxEDs, minEDs, bg == 0, ITEM_EDIT));
+            } else {
+                if (st.metric == 1) cStart++;
+                emitDfs(partInSearch, cur, exactLength);
+            }
+            phase = EX_IDLE;
+            return;
+        }
+    }
+    __device__ void resume(bool ok, const RangePair& child) {
+        cExp++;
+        if (ok) cNode++;
+        if (phase == EX_RUN) {
+            cur = ok ? child : RangePair{{0, 0}, {0, 0}};
+            if (ok) ci++;
+            else phase = EX_IDLE; // range is empty: this search is over
+        } else { // EX_K0
             if (!ok) { // no exact match possible
-                phase = PH_DONE;
-                break;
+                phase = EX_IDLE;
+                return;
             }
             cur.sa = child.sa;
             k0i--;
             if (cur.sa.width() <= ix.switchPoint) { // switch to in-text verification with k0i chars left
                 emitItems(cur.sa, k0i, packMeta(0, 0, 0, 0, ITEM_EXACT));
-                phase = PH_DONE;
+                phase = EX_IDLE;
             }
-            break;
-        default:
-            break;
         }
+    }
+    // k = 0: next step of exactMatchesOutput
+    __device__ void advanceK0() {
+        if (k0i == 0) { // everything matched in the index
+            emitItems(cur.sa, 0, packMeta(0, 0, 0, 1, ITEM_EXACT));
+            phase = EX_IDLE;
+            return;
+        }
+        const uint32_t c = code(k0i - 1);
+        if (c > 4) {
+            phase = EX_IDLE;
+            return;
+        }
+        req = true;
+        reqMode = 2;
+        reqCode = c;
     }
 };
 

@@ -250,90 +250,80 @@ struct WaveChunk {
     }
 };
 
-// ------------------------------------------------------------------ prologue: the rank/extend kernel
-// One lane per read x strand.  Every loop iteration performs at most ONE bidirectional extension per
-// lane, at one common program point: 2 positions x (4 x 16 B of the 64-byte counts line + 2 x 16 B of
-// the 32-byte bit group) = 12 independent 16-byte loads per lane in flight, whatever phase of the
-// prologue the lane's read is in (dev_partition.hpp).
-__global__ void __launch_bounds__(256, 2)
-k_partition(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* __restrict__ offs, uint32_t nReads,
-            uint32_t k, uint32_t maxLen, const uint8_t* __restrict__ seq, const uint4* __restrict__ rec,
-            uint32_t recQ, PartOut* __restrict__ parts, DfsTask* __restrict__ dfsQ, uint32_t dfsCap, Queues q) {
-    // LDS: a copy of the strategy tables (indexed per lane by scheme / search / phase), then per lane
-    // 5 x numParts partition words and 2 x ceil(maxLen/32) read words
+// ------------------------------------------------------------------ prologue: the rank/extend kernels
+// extension of `parent` by `code` from the raw chunks of its two rank blocks (loaded in the memory step)
+__device__ __forceinline__ void issueExtend(const DevIndex& ix, int mode, const RangePair& parent, uint4 v[8]) {
+    DevBWT t = ix.fwd;
+    Range tr = parent.sa;
+    if (mode == 0) {
+        t = ix.rev;
+        tr = parent.rev;
+    }
+    loadRankChunksRaw(t, tr.b, v);
+    loadRankChunksRaw(t, tr.e, v + 4);
+}
+__device__ __forceinline__ bool takeExtend(const DevIndex& ix, int mode, const RangePair& parent, uint32_t code,
+                                           const uint4 v[8], RangePair& child) {
+    DevBWT t = ix.fwd;
+    Range tr = parent.sa;
+    if (mode == 0) {
+        t = ix.rev;
+        tr = parent.rev;
+    }
+    uint32_t Rb[4], Re[4];
+    ranksFromRaw(v, tr.b, Rb);
+    ranksFromRaw(v + 4, tr.e, Re);
+    return childFromRanks(ix, mode, parent, code, Rb, Re, tr.b > t.dollarPos ? 1u : 0u, tr.e > t.dollarPos ? 1u : 0u,
+                          child);
+}
+
+// Partitioning (dev_partition.hpp: PartMachine).  One lane per read x strand, static round-robin assignment
+// (the partitioning of every read costs about the same).  Every loop iteration has ONE memory step: each lane
+// issues the loads of its request — the two rank blocks of an extension (8 x 16 B from 2 lines), the k-mer
+// table entries of its seeds, or its read record — before any reply is consumed.
+__global__ void __launch_bounds__(256, 4)
+k_parts(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint32_t k, uint32_t maxLen,
+        const uint8_t* __restrict__ seq, const uint4* __restrict__ rec, uint32_t recQ, PartOut* __restrict__ parts,
+        uint4* __restrict__ exr, uint8_t* __restrict__ psel, Queues q) {
+    // LDS: a copy of the strategy tables, then per lane 5 x numParts partition words and 2 x ceil(maxLen/32)
+    // read words
     extern __shared__ uint32_t partLds[];
     constexpr uint32_t STRAT_WORDS = (uint32_t)((sizeof(DevStrategyK) + 15) / 16 * 4);
     for (uint32_t i = threadIdx.x; i < sizeof(DevStrategyK) / 4; i += blockDim.x)
         partLds[i] = reinterpret_cast<const uint32_t*>(stp)[i];
     __syncthreads();
     const DevStrategyK& lst = *reinterpret_cast<const DevStrategyK*>(partLds);
-    PartMachine m(ix, lst, q, dfsQ, dfsCap, partLds + STRAT_WORDS, threadIdx.x, blockDim.x);
+    PartMachine m(ix, lst, partLds + STRAT_WORDS, threadIdx.x, blockDim.x);
     m.setReadWords(maxLen);
     const uint32_t total = 2 * nReads;
     uint32_t nextRs = blockIdx.x * blockDim.x + threadIdx.x;
     bool done = false;
-    uint32_t flags = 0;
-    WaveChunk chI, chD; // this wavefront's chunks of the item queue / the DFS task queue
-    bool ovI = false, ovD = false;
-    auto holeI = [&](uint32_t i) { q.items[i] = make_uint4(0xFFFFFFFFu, 0, 0, 0); };
-    auto holeD = [&](uint32_t i) { dfsQ[i].rsId = 0xFFFFFFFFu; };
     for (;;) {
-        // (1) an idle lane takes its next read x strand (static round-robin: the prologue of every read
-        //     costs about the same, and a shared work counter would serialise on one L2 atomic unit) and
-        //     asks for its read record
+        // (1) an idle lane takes its next read x strand and asks for its read record
         if (!done && m.phase == PH_DONE && m.req == RQ_NONE) {
             m.rsId = nextRs;
             nextRs += gridDim.x * blockDim.x;
             if (m.rsId >= total) done = true;
             else m.req = RQ_REC;
         }
-        // (2) bookkeeping up to the next request
+        // (2) bookkeeping up to the next request; a finished partitioning writes its outputs
         if (!done && m.req == RQ_NONE) {
             m.advance();
-            if (m.phase == PH_DONE && k > 0 && !(m.flags & FLAG_UNSUPPORTED_READ)) {
-                PartOut po;
-#pragma unroll
-                for (int i = 0; i < MAXP; i++) {
-                    po.pb[i] = i < m.numParts ? (uint16_t)m.PB(i) : (uint16_t)0;
-                    po.pe[i] = i < m.numParts ? (uint16_t)m.PE(i) : (uint16_t)0;
-                }
-                parts[m.rsId] = po;
-            }
+            if (m.phase == PH_FIN) m.finish(parts, exr, psel, total);
         }
-        // (3) THE memory step: every lane issues the loads of its request (rank blocks of an extension,
-        //     k-mer table entries of the seeds, or a read record) before any reply is consumed, so the
-        //     wavefront waits for memory once per iteration
-        uint4 v[8]; // one register window for the replies of all three request kinds
+        // (3) the memory step
+        uint4 v[8];
         const int rq = done ? RQ_NONE : m.req;
-        if (rq == RQ_RANK) {
-            DevBWT t = ix.fwd;
-            Range tr = m.reqParent.sa;
-            if (m.reqMode == 0) {
-                t = ix.rev;
-                tr = m.reqParent.rev;
-            }
-            loadRankChunksRaw(t, tr.b, v);
-            loadRankChunksRaw(t, tr.e, v + 4);
-        } else if (rq == RQ_SEED) {
-            m.seedIssue(v);
-        } else if (rq == RQ_REC) {
+        if (rq == RQ_RANK) issueExtend(ix, m.reqMode, m.reqParent, v);
+        else if (rq == RQ_SEED) m.seedIssue(v);
+        else if (rq == RQ_REC) {
 #pragma unroll
             for (uint32_t j = 0; j < 5; j++)
                 if (j < recQ) v[j] = rec[(size_t)m.rsId * recQ + j];
         }
         if (rq == RQ_RANK) {
-            DevBWT t = ix.fwd;
-            Range tr = m.reqParent.sa;
-            if (m.reqMode == 0) {
-                t = ix.rev;
-                tr = m.reqParent.rev;
-            }
-            uint32_t Rb[4], Re[4];
-            ranksFromRaw(v, tr.b, Rb);
-            ranksFromRaw(v + 4, tr.e, Re);
             RangePair child;
-            const bool ok = childFromRanks(ix, m.reqMode, m.reqParent, m.reqCode, Rb, Re,
-                                           tr.b > t.dollarPos ? 1u : 0u, tr.e > t.dollarPos ? 1u : 0u, child);
+            const bool ok = takeExtend(ix, m.reqMode, m.reqParent, m.reqCode, v, child);
             m.req = RQ_NONE;
             m.resume(ok, child);
         } else if (rq == RQ_SEED) {
@@ -341,30 +331,176 @@ k_partition(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* _
             m.seedTake(v);
         } else if (rq == RQ_REC) {
             m.begin(m.rsId, v, seq + (size_t)m.rsId * maxLen, k); // may leave a RQ_SEED request
+            if (m.phase == PH_DONE) psel[m.rsId] = 0x80u;          // unsupported read: nothing to search
         }
-        // (4) queue what this iteration staged (slots come from the wavefront's chunks: no atomic here)
+        if (__ballot(!done) == 0ull) break;
+    }
+    const uint32_t local[2] = {m.cNode, m.cExp};
+    const int which[2] = {0, 7};
+    flushCounters(q, local, which, 2);
+    if (m.flags) atomicOr(&q.cnt[3], m.flags);
+}
+
+// Exact phases of the searches + part-level pre-verification (dev_partition.hpp: ExactLane); k = 0: the whole
+// exact search.  One lane per (read x strand, slot), static round-robin; same one-memory-step loop.
+__global__ void __launch_bounds__(256, 4)
+k_exact(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint32_t k, uint32_t maxLen,
+        uint32_t nSlots, const uint8_t* __restrict__ seq, const uint4* __restrict__ rec, uint32_t recQ,
+        const PartOut* __restrict__ parts, const uint4* __restrict__ exr, const uint8_t* __restrict__ psel,
+        DfsTask* __restrict__ dfsQ, uint32_t dfsCap, Queues q) {
+    extern __shared__ uint32_t partLds[]; // strategy tables, then per lane numParts + 2 x ceil(maxLen/32) words
+    constexpr uint32_t STRAT_WORDS = (uint32_t)((sizeof(DevStrategyK) + 15) / 16 * 4);
+    for (uint32_t i = threadIdx.x; i < sizeof(DevStrategyK) / 4; i += blockDim.x)
+        partLds[i] = reinterpret_cast<const uint32_t*>(stp)[i];
+    __syncthreads();
+    const DevStrategyK& lst = *reinterpret_cast<const DevStrategyK*>(partLds);
+    ExactLane m(ix, lst, partLds + STRAT_WORDS, threadIdx.x, blockDim.x, maxLen);
+    const uint32_t total = 2 * nReads;
+    const uint64_t nTasks = (uint64_t)total * nSlots;
+    uint64_t nextT = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int numParts = lst.numParts;
+    const uint32_t sw = ix.switchPoint;
+    bool done = false, ovI = false, ovD = false;
+    WaveChunk chI, chD;
+    auto holeI = [&](uint32_t i) { q.items[i] = make_uint4(0xFFFFFFFFu, 0, 0, 0); };
+    auto holeD = [&](uint32_t i) { dfsQ[i].rsId = 0xFFFFFFFFu; };
+    for (;;) {
+        // (1) an idle lane takes its next (read x strand, slot)
+        if (!done && m.phase == EX_IDLE && !m.req) {
+            if (nextT >= nTasks) done = true;
+            else {
+                m.rsId = (uint32_t)(nextT / nSlots);
+                m.slot = (uint32_t)(nextT % nSlots);
+                m.seq = seq + (size_t)m.rsId * maxLen;
+                m.phase = k == 0 ? EX_LOAD : EX_HDR;
+                nextT += (uint64_t)gridDim.x * blockDim.x;
+            }
+        }
+        // (2) bookkeeping of running searches up to their next extension
+        if (!done && !m.req) {
+            if (m.phase == EX_RUN) m.advance();
+            else if (m.phase == EX_K0) m.advanceK0();
+        }
+        // (3) the memory step
+        uint4 v[8];
+        uint32_t hdr = 0;
+        const int ph = done ? EX_IDLE : m.phase;
+        const bool isPost = m.slot == nSlots - 1;
+        if (m.req) {
+            issueExtend(ix, m.reqMode, m.cur, v);
+        } else if (ph == EX_HDR) { // scheme selection + parts
+            hdr = psel[m.rsId];
+            const uint4* pp = reinterpret_cast<const uint4*>(parts + m.rsId);
+            v[0] = pp[0];
+            v[1] = pp[1];
+        } else if (ph == EX_LOAD) {
+            if (k == 0 || !isPost) { // read record (+ exact range of the first part of the search)
+#pragma unroll
+                for (uint32_t j = 0; j < 5; j++)
+                    if (j < recQ) v[j] = rec[(size_t)m.rsId * recQ + j];
+                if (k != 0) v[5] = exr[(size_t)lst.sch[m.sel].s[m.slot].order[0] * total + m.rsId];
+            } else { // exact ranges of all parts
+#pragma unroll
+                for (int i = 0; i < MAXP; i++)
+                    if (i < numParts) v[i] = exr[(size_t)i * total + m.rsId];
+            }
+        }
+        if (m.req) {
+            RangePair child;
+            const bool ok = takeExtend(ix, m.reqMode, m.cur, m.reqCode, v, child);
+            m.req = false;
+            m.resume(ok, child);
+        } else if (ph == EX_HDR) {
+            m.sel = (int)(hdr & 0x7Fu);
+            const uint16_t* pv = reinterpret_cast<const uint16_t*>(v);
+#pragma unroll
+            for (int i = 0; i < MAXP; i++)
+                if (i < numParts) m.PBE(i) = (uint32_t)pv[i] | ((uint32_t)pv[MAXP + i] << 16);
+            m.phase = EX_LOAD;
+            if (hdr & 0x80u) m.phase = EX_IDLE; // unsupported read (reported by k_parts)
+            else if (!isPost) {
+                const DevScheme& sch = lst.sch[m.sel];
+                if (m.slot >= sch.nSearches) m.phase = EX_IDLE;
+                else if (sch.s[m.slot].U[0] > 0) { // recApproxMatchEditEntry on the complete range
+                    if (lst.metric == 1) m.cStart++;
+                    m.emitDfs(0, RangePair{{0, ix.n}, {0, ix.n}}, 0);
+                    m.phase = EX_IDLE;
+                }
+            }
+        } else if (ph == EX_LOAD) {
+            if (k == 0) {
+                m.takeRecord(v);
+                m.cur = RangePair{{0, ix.n}, {0, 0}};
+                m.k0i = m.len;
+                m.phase = m.len == 0 ? EX_IDLE : EX_K0;
+            } else if (!isPost) {
+                m.takeRecord(v);
+                m.startSearch(RangePair{{v[5].x, v[5].y}, {v[5].z, v[5].w}});
+            } else {
+                m.phase = EX_IDLE;
+            }
+        }
+        // (4) part-level pre-verification (searchstrategy.cpp:464-476): one item group per narrow part
+        if (__ballot(ph == EX_LOAD && k != 0 && isPost) != 0ull) {
+            const bool mine = ph == EX_LOAD && k != 0 && isPost;
+#pragma unroll
+            for (int i = 0; i < MAXP; i++) {
+                if (i >= numParts) break;
+                uint32_t n = 0, a = 0, meta = 0;
+                if (mine) {
+                    const uint32_t width = v[i].y > v[i].x ? v[i].y - v[i].x : 0u;
+                    if (width != 0 && width <= sw) {
+                        n = width;
+                        const uint32_t bg = m.PB(i);
+                        if (lst.metric == 1) {
+                            m.cImm++; // verifyExactPartialMatchInText (fmindex.cpp:253)
+                            a = bg == 0 ? 0 : bg + k;
+                            meta = packMeta(0, k, 0, bg == 0, ITEM_EDIT);
+                        } else {
+                            a = bg;
+                            meta = packMeta(0, k, 0, 0, ITEM_HAMMING);
+                        }
+                    }
+                }
+                if (__ballot(n > 0) == 0ull) continue;
+                const uint32_t o = chI.alloc(&q.cnt[0], q.itemCap, n, 256u, ovI, holeI);
+                if (n && o != 0xFFFFFFFFu)
+                    for (uint32_t t = 0; t < n; t++) q.items[o + t] = make_uint4(m.rsId, v[i].x + t, a, meta);
+            }
+        }
+        // (5) queue what the searches staged
         if (__ballot(m.stN > 0) != 0ull) {
             const uint32_t o = chI.alloc(&q.cnt[0], q.itemCap, m.stN, 256u, ovI, holeI);
             if (m.stN && o != 0xFFFFFFFFu)
-                for (uint32_t t = 0; t < m.stN; t++) q.items[o + t] = make_uint4(m.stRs, m.stB + t, m.stA, m.stMeta);
+                for (uint32_t t = 0; t < m.stN; t++) q.items[o + t] = make_uint4(m.rsId, m.stB + t, m.stA, m.stMeta);
             m.stN = 0;
         }
         if (__ballot(m.stDfs) != 0ull) {
             const uint32_t o = chD.alloc(&q.cnt[5], dfsCap, m.stDfs ? 1u : 0u, 64u, ovD, holeD);
-            if (m.stDfs && o != 0xFFFFFFFFu) dfsQ[o] = m.stTask;
+            if (m.stDfs && o != 0xFFFFFFFFu) {
+                DfsTask t;
+                t.rsId = m.rsId;
+                t.scheme = (uint8_t)m.sel;
+                t.search = (uint8_t)m.slot;
+                t.idx = (uint8_t)m.stIdx;
+                t.pad = 0;
+                t.r = m.stR;
+                t.depth = m.stDepth;
+                dfsQ[o] = t;
+            }
             m.stDfs = false;
         }
         if (__ballot(!done) == 0ull) break;
     }
     chI.fill(holeI);
     chD.fill(holeD);
+    uint32_t flags = 0;
     if (ovI) flags |= FLAG_ITEM_OVERFLOW;
     if (ovD) flags |= FLAG_DFS_OVERFLOW;
-    m.flags |= flags;
     const uint32_t local[4] = {m.cNode, m.cExp, m.cImm, m.cStart};
     const int which[4] = {0, 7, 5, 6};
     flushCounters(q, local, which, 4);
-    if (m.flags) atomicOr(&q.cnt[3], m.flags);
+    if (flags) atomicOr(&q.cnt[3], flags);
 }
 
 // ------------------------------------------------------------------ approximate DFS over the scheme
