@@ -252,6 +252,11 @@ struct cmb_batch {
     DevBuf<Scratch> slabs;
     DevBuf<Scratch2> slabs2;
     DevBuf<uint32_t> dfsKeysA, dfsKeysB, dfsIdxA, dfsIdxB;
+    // frontier search (dev_bfs_edit.hpp): node / event double buffers, F records, contexts, list arena
+    DevBuf<uint4> bfsQ[2], bfsEv[2], bfsF, bfsC, bfsA;
+    DevBuf<uint32_t> bfsCnt;               // nq[passes], ne[passes], pool[4]
+    DevBuf<unsigned long long> bfsBlockCnt; // [BFS_GRID][4]
+    size_t bfsQCap = 0, bfsEvCap = 0, bfsFCap = 0, bfsCCap = 0, bfsACap = 0;
     DevBuf<PartOut> parts;
     DevBuf<DfsTask> dfs;
     DevBuf<uint64_t> vHP, vD0;
@@ -465,7 +470,92 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                 const uint32_t slotCap = getenv("CMB_DFS_SLOTS") ? (uint32_t)atoi(getenv("CMB_DFS_SLOTS")) : 256u * 512u;
                 const uint32_t want = std::min<uint32_t>(((nDfs + 255) / 256) * 256, slotCap);
                 tm.begin();
-                if (b->metric == CMB_METRIC_EDIT) {
+                if (b->metric == CMB_METRIC_EDIT && !getenv("CMB_OLD_DFS")) {
+                    // ---- frontier search: start pass, then (expand, events) per level until both queues drain
+                    const uint32_t maxPass = 2 * b->maxLen + 8 * MAXP + 64;
+                    if (!b->bfsQCap) {
+                        b->bfsQCap = (size_t)nReads * 2 + 65536;
+                        b->bfsEvCap = (size_t)nReads / 2 + 65536;
+                        b->bfsFCap = (size_t)nReads * 16 + 65536;
+                        b->bfsCCap = (size_t)nReads * 2 + 65536;
+                        b->bfsACap = (size_t)nReads * 8 + 65536;
+                    }
+                    b->bfsQCap = std::max<size_t>(b->bfsQCap, (size_t)nDfs + 1024);
+                    for (int j = 0; j < 2; j++) {
+                        if (b->bfsQ[j].n < 4 * b->bfsQCap) b->bfsQ[j].alloc(4 * b->bfsQCap);
+                        if (b->bfsEv[j].n < b->bfsEvCap) b->bfsEv[j].alloc(b->bfsEvCap);
+                    }
+                    if (b->bfsF.n < 4 * b->bfsFCap) b->bfsF.alloc(4 * b->bfsFCap);
+                    if (b->bfsC.n < CTX_U4 * b->bfsCCap) b->bfsC.alloc(CTX_U4 * b->bfsCCap);
+                    if (b->bfsA.n < b->bfsACap) b->bfsA.alloc(b->bfsACap);
+                    const size_t cntWords = 2 * ((size_t)maxPass + 2) + 4;
+                    if (b->bfsCnt.n < cntWords) b->bfsCnt.alloc(cntWords);
+                    if (b->bfsBlockCnt.n < (size_t)BFS_GRID * 4) b->bfsBlockCnt.alloc((size_t)BFS_GRID * 4);
+                    HIPCHK(hipMemsetAsync(b->bfsCnt.p, 0, cntWords * sizeof(uint32_t), s));
+                    HIPCHK(hipMemsetAsync(b->bfsBlockCnt.p, 0, (size_t)BFS_GRID * 4 * sizeof(unsigned long long), s));
+                    BfsBufs B{};
+                    for (int j = 0; j < 2; j++) {
+                        B.Q[j] = b->bfsQ[j].p;
+                        B.Ev[j] = b->bfsEv[j].p;
+                    }
+                    B.F = b->bfsF.p;
+                    B.C = b->bfsC.p;
+                    B.A = b->bfsA.p;
+                    B.qCap = (uint32_t)std::min<size_t>(b->bfsQ[0].n / 4, 0xFFFFFFF0u);
+                    B.evCap = (uint32_t)std::min<size_t>(b->bfsEv[0].n, 0xFFFFFFF0u);
+                    B.fCap = (uint32_t)std::min<size_t>(b->bfsF.n / 4, 0xFFFFFFF0u);
+                    B.cCap = (uint32_t)std::min<size_t>(b->bfsC.n / CTX_U4, 0xFFFFFFF0u);
+                    B.aCap = (uint32_t)std::min<size_t>(b->bfsA.n, 0xFFFFFFF0u);
+                    B.nq = b->bfsCnt.p;
+                    B.ne = b->bfsCnt.p + (maxPass + 2);
+                    B.pool = b->bfsCnt.p + 2 * (maxPass + 2);
+                    B.blockCnt = b->bfsBlockCnt.p;
+                    hipLaunchKernelGGL(k_bfs_heavy<true>, dim3(std::min<uint32_t>((nDfs + 255) / 256, BFS_GRID)), dim3(256), 0, s,
+                                       ix->d, b->strat.p, B, 0u, b->dfs.p, nDfs, b->offs.p, b->gw, b->G.p, b->parts.p, q);
+                    std::vector<uint32_t> hc(cntWords);
+                    const uint32_t CHECK = 16; // passes between two looks at the queue sizes
+                    uint32_t pass = 0, peakQ = 0, peakEv = 0;
+                    bool drained = false;
+                    while (!drained && pass < maxPass) {
+                        const uint32_t upTo = std::min(pass + CHECK, maxPass);
+                        for (; pass < upTo; pass++) {
+                            hipLaunchKernelGGL(k_bfs_expand, dim3(BFS_GRID), dim3(256), 0, s, ix->d, B, pass, q);
+                            hipLaunchKernelGGL(k_bfs_heavy<false>, dim3(BFS_GRID), dim3(256), 0, s, ix->d, b->strat.p, B, pass,
+                                               (const DfsTask*)nullptr, 0u, b->offs.p, b->gw, b->G.p, b->parts.p, q);
+                        }
+                        HIPCHK(hipMemcpyAsync(hc.data(), b->bfsCnt.p, cntWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                        HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
+                        HIPCHK(hipStreamSynchronize(s));
+                        if (hcnt[3] & BFS_STOP) break;
+                        drained = hc[pass] == 0 && hc[maxPass + 2 + pass] == 0;
+                    }
+                    for (uint32_t p2 = 0; p2 <= pass && p2 < maxPass + 2; p2++) {
+                        peakQ = std::max(peakQ, hc[p2]);
+                        peakEv = std::max(peakEv, hc[maxPass + 2 + p2]);
+                    }
+                    const uint32_t* pool = hc.data() + 2 * (maxPass + 2);
+                    if (getenv("CMB_VERBOSE"))
+                        fprintf(stderr, "[bfs] %u tasks, %u passes, peak frontier %u, peak events %u, F %u, contexts %u, arena %u\n",
+                                nDfs, pass, peakQ, peakEv, pool[0], pool[1], pool[2]);
+                    if (getenv("CMB_VERBOSE") && atoi(getenv("CMB_VERBOSE")) > 1)
+                        for (uint32_t p2 = 0; p2 <= pass; p2++)
+                            fprintf(stderr, "  pass %u: %u nodes, %u events\n", p2, hc[p2], hc[maxPass + 2 + p2]);
+                    hipLaunchKernelGGL(k_bfs_finish, dim3(1), dim3(256), 0, s, B, q);
+                    if (hcnt[3] & (FLAG_BFS_Q | FLAG_BFS_EV | FLAG_BFS_F | FLAG_BFS_CTX | FLAG_BFS_ARENA)) {
+                        // a pool was too small: grow what was asked for (at least x2) and run the search again
+                        if (attempt >= 6) return fail(CMB_ERR_INTERNAL, "frontier pools keep overflowing");
+                        if (hcnt[3] & FLAG_BFS_Q) b->bfsQCap = std::max<size_t>(2 * b->bfsQCap, (size_t)peakQ + peakQ / 4);
+                        if (hcnt[3] & FLAG_BFS_EV) b->bfsEvCap = std::max<size_t>(2 * b->bfsEvCap, (size_t)peakEv + peakEv / 4);
+                        if (hcnt[3] & FLAG_BFS_F) b->bfsFCap = std::max<size_t>(2 * b->bfsFCap, (size_t)pool[0] + pool[0] / 4);
+                        if (hcnt[3] & FLAG_BFS_CTX) b->bfsCCap = std::max<size_t>(2 * b->bfsCCap, (size_t)pool[1] + pool[1] / 4);
+                        if (hcnt[3] & FLAG_BFS_ARENA) b->bfsACap = std::max<size_t>(2 * b->bfsACap, (size_t)pool[2] + pool[2] / 4);
+                        HIPCHK(hipStreamSynchronize(s));
+                        tm.end("k_dfs");
+                        continue;
+                    }
+                    if (!drained && !(hcnt[3] & BFS_STOP))
+                        return fail(CMB_ERR_INTERNAL, "frontier search did not finish within its pass bound");
+                } else if (b->metric == CMB_METRIC_EDIT) {
                     if (b->slabs2.n < want) b->slabs2.alloc(want);
                     if (b->dfsKeysA.n < nDfs) {
                         b->dfsKeysA.alloc((size_t)nDfs + 1024);
@@ -525,6 +615,8 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
         // indexhelpers.h:2135-2146) on the host: small
         std::vector<FMOccRec> fm(nFm);
         if (nFm) HIPCHK(hipMemcpy(fm.data(), b->fm.p, nFm * sizeof(FMOccRec), hipMemcpyDeviceToHost));
+        fm.erase(std::remove_if(fm.begin(), fm.end(), [](const FMOccRec& x) { return x.rsId == 0xFFFFFFFFu; }),
+                 fm.end()); // holes: slots reserved for cluster centres that had been reported before
         std::sort(fm.begin(), fm.end(), [](const FMOccRec& x, const FMOccRec& y) {
             const uint32_t rx = x.rsId >> 1, ry = y.rsId >> 1;
             if (rx != ry) return rx < ry;

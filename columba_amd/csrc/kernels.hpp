@@ -250,6 +250,10 @@ struct WaveChunk {
     }
 };
 
+} // namespace cmb
+#include "dev_bfs_edit.hpp"
+namespace cmb {
+
 // ------------------------------------------------------------------ prologue: the rank/extend kernels
 // extension of `parent` by `code` from the raw chunks of its two rank blocks (loaded in the memory step)
 __device__ __forceinline__ void issueExtend(const DevIndex& ix, int mode, const RangePair& parent, uint4 v[8]) {
