@@ -510,8 +510,8 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                     B.ne = b->bfsCnt.p + (maxPass + 2);
                     B.pool = b->bfsCnt.p + 2 * (maxPass + 2);
                     B.blockCnt = b->bfsBlockCnt.p;
-                    hipLaunchKernelGGL(k_bfs_heavy<true>, dim3(std::min<uint32_t>((nDfs + 255) / 256, BFS_GRID)), dim3(256), 0, s,
-                                       ix->d, b->strat.p, B, 0u, b->dfs.p, nDfs, b->offs.p, b->gw, b->G.p, b->parts.p, q);
+                    hipLaunchKernelGGL(k_bfs_start, dim3(std::min<uint32_t>((nDfs + 255) / 256, BFS_GRID)), dim3(256), 0, s,
+                                       ix->d, b->strat.p, B, b->dfs.p, nDfs, b->offs.p, b->gw, b->G.p, b->parts.p, q);
                     std::vector<uint32_t> hc(cntWords);
                     const uint32_t CHECK = 16; // passes between two looks at the queue sizes
                     uint32_t pass = 0, peakQ = 0, peakEv = 0;
@@ -519,9 +519,8 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                     while (!drained && pass < maxPass) {
                         const uint32_t upTo = std::min(pass + CHECK, maxPass);
                         for (; pass < upTo; pass++) {
-                            hipLaunchKernelGGL(k_bfs_expand, dim3(BFS_GRID), dim3(256), 0, s, ix->d, B, pass, q);
-                            hipLaunchKernelGGL(k_bfs_heavy<false>, dim3(BFS_GRID), dim3(256), 0, s, ix->d, b->strat.p, B, pass,
-                                               (const DfsTask*)nullptr, 0u, b->offs.p, b->gw, b->G.p, b->parts.p, q);
+                            hipLaunchKernelGGL(k_bfs_pass, dim3(BFS_GRID + BFS_GRID_EV), dim3(256), 0, s, ix->d, b->strat.p, B,
+                                               pass, b->offs.p, b->gw, b->G.p, b->parts.p, q);
                         }
                         HIPCHK(hipMemcpyAsync(hc.data(), b->bfsCnt.p, cntWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                         HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));

@@ -35,7 +35,8 @@ constexpr uint32_t BFS_NONE = 0xFFFFFFFFu;
 constexpr uint32_t ED_CELLS = 24; // final-column cells per phase (5 bits each in a 128-bit pack); 3k+2 <= 24 for k <= 7
 constexpr uint32_t CTX_U4 = 24;   // uint4 per context: 8 header + 16 match words (8 row blocks x {A,C | G,T})
 constexpr uint32_t CTX_MBLK = 8;
-constexpr uint32_t BFS_GRID = 1024; // blocks of the expand / heavy kernels (grid-stride over the frontier)
+constexpr uint32_t BFS_GRID = 1024;   // blocks that expand the frontier (grid-stride)
+constexpr uint32_t BFS_GRID_EV = 512; // blocks that handle the events of the same pass
 
 enum { FLAG_BFS_Q = 64, FLAG_BFS_EV = 128, FLAG_BFS_F = 256, FLAG_BFS_CTX = 512, FLAG_BFS_ARENA = 1024 };
 // any of these set by an earlier pass: the frontier is incomplete, later passes do nothing (the host re-runs)
@@ -98,17 +99,16 @@ __device__ __forceinline__ uint32_t blockAppend(uint32_t* counter, uint32_t n, u
 //   final column, row invalid or only vertical gaps left -> event (goDeeper)
 //   narrow range (in-text switch, :516)        -> in-text verification items
 //   otherwise                                  -> node of the next frontier
-__global__ void __launch_bounds__(256)
-k_bfs_expand(DevIndex ix, BfsBufs B, uint32_t pass, Queues q) {
+__device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, uint32_t pass, const Queues& q,
+                                          uint32_t bid, uint32_t nBlocks) {
     __shared__ uint32_t sh[4][5];
-    if (q.cnt[3] & BFS_STOP) return;
     const uint32_t nIn = min(B.nq[pass], B.qCap);
     const uint4* __restrict__ Qi = B.Q[pass & 1u];
     uint4* __restrict__ Qo = B.Q[(pass + 1u) & 1u];
     uint4* __restrict__ Eo = B.Ev[(pass + 1u) & 1u];
     const uint32_t qCap = B.qCap;
     uint32_t cNode = 0, cExp = 0, cRows = 0, flags = 0;
-    for (uint32_t base = blockIdx.x * 256u; base < nIn; base += gridDim.x * 256u) { // block-uniform trip count
+    for (uint32_t base = bid * 256u; base < nIn; base += nBlocks * 256u) { // block-uniform trip count
         const uint32_t i = base + threadIdx.x;
         const bool act = i < nIn;
         // per child: 0 nothing, 1 node, 2 event, 3 in-text items
@@ -264,7 +264,7 @@ k_bfs_expand(DevIndex ix, BfsBufs B, uint32_t pass, Queues q) {
     __syncthreads();
     if (threadIdx.x < 3) {
         const unsigned long long t = shc[0][threadIdx.x] + shc[1][threadIdx.x] + shc[2][threadIdx.x] + shc[3][threadIdx.x];
-        if (t) B.blockCnt[(size_t)blockIdx.x * 4 + threadIdx.x] += t;
+        if (t) B.blockCnt[(size_t)bid * 4 + threadIdx.x] += t;
     }
     if (flags) atomicOr(&q.cnt[3], flags);
 }
@@ -300,13 +300,13 @@ struct HeavyPlan {
 };
 
 template <bool START>
-__global__ void __launch_bounds__(256)
-k_bfs_heavy(DevIndex ix, const DevStrategyK* __restrict__ stp, BfsBufs B, uint32_t pass,
-            const DfsTask* __restrict__ tasks, uint32_t nTasks, const uint64_t* __restrict__ offs, uint32_t gw,
-            const uint32_t* __restrict__ G, const PartOut* __restrict__ parts, Queues q) {
+__device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK* __restrict__ stp, const BfsBufs& B,
+                                         uint32_t pass, const DfsTask* __restrict__ tasks, uint32_t nTasks,
+                                         const uint64_t* __restrict__ offs, uint32_t gw, const uint32_t* __restrict__ G,
+                                         const PartOut* __restrict__ parts, const Queues& q, uint32_t bid,
+                                         uint32_t nBlocks) {
     __shared__ uint32_t sh[4][5];
     __shared__ uint8_t ieL[ED_CELLS + 2][256]; // initEds under construction, [entry][thread]
-    if (q.cnt[3] & BFS_STOP) return;
     const uint32_t outP = START ? 0u : pass + 1u;
     const uint32_t nIn = START ? nTasks : min(B.ne[pass], B.evCap);
     const uint4* __restrict__ Ei = B.Ev[pass & 1u];
@@ -315,7 +315,7 @@ k_bfs_heavy(DevIndex ix, const DevStrategyK* __restrict__ stp, BfsBufs B, uint32
     const uint32_t qCap = B.qCap;
     const uint32_t tid = threadIdx.x;
     uint32_t cRows = 0, flags = 0;
-    for (uint32_t base = blockIdx.x * 256u; base < nIn; base += gridDim.x * 256u) { // block-uniform trip count
+    for (uint32_t base = bid * 256u; base < nIn; base += nBlocks * 256u) { // block-uniform trip count
         const uint32_t i = base + tid;
         HeavyPlan P{};
         // the context the event belongs to (START: none)
@@ -775,6 +775,25 @@ k_bfs_heavy(DevIndex ix, const DevStrategyK* __restrict__ stp, BfsBufs B, uint32
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
     if ((tid & 63u) == 0 && v) atomicAdd(&q.counters[11], v);
     if (flags) atomicOr(&q.cnt[3], flags);
+}
+
+// first approximate phase of every task (k_exact's DfsTask queue) -> frontier of pass 0
+__global__ void __launch_bounds__(256)
+k_bfs_start(DevIndex ix, const DevStrategyK* __restrict__ stp, BfsBufs B, const DfsTask* __restrict__ tasks, uint32_t nTasks,
+            const uint64_t* __restrict__ offs, uint32_t gw, const uint32_t* __restrict__ G, const PartOut* __restrict__ parts,
+            Queues q) {
+    if (q.cnt[3] & BFS_STOP) return;
+    bfsHeavy<true>(ix, stp, B, 0u, tasks, nTasks, offs, gw, G, parts, q, blockIdx.x, gridDim.x);
+}
+
+// one level: blocks [0, BFS_GRID) expand the frontier, blocks [BFS_GRID, BFS_GRID + BFS_GRID_EV) handle the events
+// of the same pass (both only append to the queues of pass + 1, so they run side by side)
+__global__ void __launch_bounds__(256)
+k_bfs_pass(DevIndex ix, const DevStrategyK* __restrict__ stp, BfsBufs B, uint32_t pass, const uint64_t* __restrict__ offs,
+           uint32_t gw, const uint32_t* __restrict__ G, const PartOut* __restrict__ parts, Queues q) {
+    if (q.cnt[3] & BFS_STOP) return;
+    if (blockIdx.x < BFS_GRID) bfsExpand(ix, B, pass, q, blockIdx.x, BFS_GRID);
+    else bfsHeavy<false>(ix, stp, B, pass, nullptr, 0u, offs, gw, G, parts, q, blockIdx.x - BFS_GRID, BFS_GRID_EV);
 }
 
 } // namespace cmb
