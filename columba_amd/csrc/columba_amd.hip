@@ -3,6 +3,7 @@
 #include "host_schemes.hpp"
 #include "kernels.hpp"
 
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -401,6 +402,14 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
             return CMB_OK;
         }
         uint32_t hcnt[8];
+        const bool verbose = getenv("CMB_VERBOSE") != nullptr;
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!verbose) return;
+            auto t1 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[host] %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+            t0 = t1;
+        };
         Queues q{};
         q.cnt = b->cnt.p;
         q.counters = b->counters.p;
@@ -609,6 +618,7 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
             break;
         }
         const uint32_t nItems = hcnt[0], nFm = hcnt[1];
+        lap("prep + search");
 
         // ---- de-duplicate the in-index occurrences per read (Occurrences::eraseDoublesFM,
         // indexhelpers.h:2135-2146) on the host: small
@@ -635,10 +645,12 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
         uint64_t fmRows = 0;
         for (const auto& f : fm) fmRows += f.e - f.b;
         if (!fm.empty()) b->fmUniq.upload(fm.data(), fm.size());
+        lap("fm occurrences on the host");
 
         // ---- locate + verify; text queue retried on overflow
         // traceback task queue: at most one task per item + the chunk slack of every k_verify wavefront
-        const size_t tbNeed = (size_t)nItems + (size_t)(256u * 2048u / 64u + 1) * 256u;
+        // (a chunk of 256 is retired when the wavefront's next group does not fit: at most 63 holes per chunk)
+        const size_t tbNeed = (size_t)nItems + (size_t)nItems / 2 + (size_t)(256u * 2048u / 64u + 1) * 256u;
         if (b->tbq.n < tbNeed) b->tbq.alloc(tbNeed + nItems / 8);
         for (int attempt = 0;; attempt++) {
             q.text = b->text.p;
@@ -729,6 +741,7 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
             break;
         }
         const uint32_t nText = hcnt[2];
+        lap("verify + traceback + fmocc");
 
         // ---- sort + filter on the device (getUniqueTextOccurrences / getTextOccHamming,
         // indexinterface.cpp:1331-1491): pack -> one 64-bit radix sort -> per-read scan
@@ -778,12 +791,14 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                                    b->offs.p, nReads, b->k, mode, b->fcounts.p, b->foffs.p, b->fout.p);
             HIPCHK(hipGetLastError());
             tm.end("k_filter");
+            lap("filter");
             b->occs.resize(total);
             std::vector<uint32_t> o32((size_t)nReads + 1);
             if (total) HIPCHK(hipMemcpyAsync(b->occs.data(), b->fout.p, (size_t)total * sizeof(cmb_occ), hipMemcpyDeviceToHost, s));
             HIPCHK(hipMemcpyAsync(o32.data(), b->foffs.p, o32.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             for (uint32_t r = 0; r <= nReads; r++) b->occOffs[r] = o32[r];
+            lap("results to the host");
         }
         // TOTAL_REPORTED_POSITIONS (indexinterface.cpp:1378,1390 / :1333,1352)
         // (the device counter holds the records k_verify / k_traceback wrote; queue holes are not records)

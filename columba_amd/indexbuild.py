@@ -67,6 +67,48 @@ class IndexArrays:
 # --------------------------------------------------------------------------
 # suffix array by prefix doubling (torch; works on cpu and cuda)
 # --------------------------------------------------------------------------
+_SORT_LIM = (1 << 31) - 1024  # torch.sort refuses dimensions beyond INT_MAX
+_SEL_CHUNK = 1 << 29
+
+
+def _sort_big(key: torch.Tensor):
+    """(sorted keys, permutation) like torch.sort, for any length: keys beyond torch.sort's INT_MAX limit are
+    split at a sampled median into two independently sorted halves (equal keys stay on one side)."""
+    n = int(key.numel())
+    if n <= _SORT_LIM:
+        return torch.sort(key)
+    dev = key.device
+    pivot = key[torch.randint(0, n, (1 << 20,), device=dev)].median()
+    n_lo = 0
+    for o in range(0, n, _SEL_CHUNK):
+        n_lo += int((key[o:o + _SEL_CHUNK] < pivot).sum().item())
+    if n_lo == 0 or n_lo == n:
+        raise ValueError("degenerate keys: cannot split for sorting")
+    k2 = torch.empty(n, dtype=key.dtype, device=dev)
+    i2 = torch.empty(n, dtype=torch.int64, device=dev)
+    a, b = 0, n_lo
+    for o in range(0, n, _SEL_CHUNK):
+        k = key[o:o + _SEL_CHUNK]
+        m = k < pivot
+        idx = torch.arange(o, o + int(k.numel()), dtype=torch.int64, device=dev)
+        c = int(m.sum().item())
+        k2[a:a + c] = k[m]
+        i2[a:a + c] = idx[m]
+        a += c
+        c = int(k.numel()) - c
+        m = ~m
+        k2[b:b + c] = k[m]
+        i2[b:b + c] = idx[m]
+        b += c
+    del key
+    for lo, hi in ((0, n_lo), (n_lo, n)):
+        sk, p = _sort_big(k2[lo:hi].clone())
+        k2[lo:hi] = sk
+        i2[lo:hi] = i2[lo:hi][p]
+        del sk, p
+    return k2, i2
+
+
 def suffix_array(codes: torch.Tensor) -> torch.Tensor:
     """SA of the sequence ``codes`` (uint8, values 0..4), where a suffix that is a proper prefix of
     another sorts first (end-of-string smallest).  Prefix doubling with radix sorts (torch.sort).
@@ -77,7 +119,9 @@ def suffix_array(codes: torch.Tensor) -> torch.Tensor:
     n = int(codes.numel())
     if n == 0:
         return torch.zeros(0, dtype=torch.int64, device=dev)
-    assert (n + 2) ** 2 < 2 ** 63, "text too long for single-key prefix doubling"
+    # doubling key = (rank[i] - n/2) * (n+1) + rank[i+h]: centred so that texts up to 2^32 fit an int64
+    half = n // 2
+    assert (half + 2) * (n + 2) < 2 ** 63, "text too long for single-key prefix doubling"
     rdt = torch.int32 if n < 2 ** 31 - 2 else torch.int64
     h = 20  # initial key: first 20 symbols, 3 bits each (values 1..5, 0 = beyond the end)
     cp = torch.zeros(n + h, dtype=torch.uint8, device=dev)
@@ -87,7 +131,7 @@ def suffix_array(codes: torch.Tensor) -> torch.Tensor:
         key <<= 3
         key |= cp[j:j + n]
     del cp
-    skey, sa = torch.sort(key)
+    skey, sa = _sort_big(key)
     del key
     while True:
         flag = torch.ones(n, dtype=torch.bool, device=dev)
@@ -100,12 +144,13 @@ def suffix_array(codes: torch.Tensor) -> torch.Tensor:
         rank = torch.empty(n, dtype=rdt, device=dev)
         rank[sa] = srank
         del srank, sa
-        key = rank.to(torch.int64)
+        key = rank.to(torch.int64, copy=True)
+        key -= half
         key *= (n + 1)
         if h < n:
             key[:n - h] += rank[h:]
         del rank
-        skey, sa = torch.sort(key)
+        skey, sa = _sort_big(key)
         del key
         h *= 2
 
@@ -158,8 +203,12 @@ def build_bitvec_intl(bwt_codes: torch.Tensor):
     N = n + 1
     nw = (N + 63) // 64
     nblk = (N + 511) // 512
-    dollar = torch.nonzero(bwt_codes == 0).flatten()
-    dollar_pos = int(dollar[0].item()) if dollar.numel() else n
+    dollar_pos = n
+    for o in range(0, n, _SEL_CHUNK):  # (chunked: nonzero / masked selects are limited to INT_MAX elements)
+        z = torch.nonzero(bwt_codes[o:o + _SEL_CHUNK] == 0).flatten()
+        if z.numel():
+            dollar_pos = o + int(z[0].item())
+            break
     codes = torch.zeros(nblk * 512, dtype=torch.uint8, device=dev)
     codes[:n] = bwt_codes.to(torch.uint8)
     bv = torch.zeros((nw, 4), dtype=torch.int64, device=dev)
@@ -181,7 +230,8 @@ def build_sparse_sa(sa: torch.Tensor, sparseness: int):
     dev = sa.device
     n = int(sa.numel())
     mark = (sa % sparseness) == 0
-    samples = sa[mark].to(torch.int64).cpu().numpy().astype(np.uint32)
+    samples = np.concatenate([sa[o:o + _SEL_CHUNK][mark[o:o + _SEL_CHUNK]].to(torch.int64).cpu().numpy().astype(np.uint32)
+                              for o in range(0, n, _SEL_CHUNK)]) if n else np.zeros(0, np.uint32)
     nw = (n + 63) // 64
     nblk = (nw + 7) // 8
     bits = torch.zeros(nblk * 512, dtype=torch.bool, device=dev)
@@ -245,7 +295,7 @@ def build_index(text, sparseness: int = 4, seq_starts: Optional[np.ndarray] = No
     # forward
     sa = suffix_array(tc)
     prev = sa - 1
-    prev[prev < 0] = n - 1
+    prev = torch.where(prev < 0, n - 1, prev)
     bwt = tc[prev]
     del prev
     bv_fwd, cnt_fwd, dpos_f = build_bitvec_intl(bwt)
@@ -258,7 +308,7 @@ def build_index(text, sparseness: int = 4, seq_starts: Optional[np.ndarray] = No
     rsa = suffix_array(rtc)
     del rtc
     idx = n - rsa
-    idx[rsa == 0] = 0
+    idx = torch.where(rsa == 0, 0, idx)
     del rsa
     rbwt = tc[idx]
     del idx
