@@ -48,6 +48,33 @@ template <typename T> struct DevBuf {
     size_t bytes() const { return n * sizeof(T); }
 };
 
+// page-locked host memory (results are copied at PCIe speed, asynchronously)
+template <typename T> struct PinnedBuf {
+    T* p = nullptr;
+    size_t cap = 0, n = 0;
+    PinnedBuf() {}
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    void resize(size_t count) { // contents are not kept
+        if (count > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr;
+            cap = 0;
+            const size_t want = count + count / 4 + 64;
+            HIPCHK(hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault));
+            cap = want;
+        }
+        n = count;
+    }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T* data() { return p; }
+    const T* data() const { return p; }
+};
+
 // ------------------------------------------------------------------------------------ index
 struct cmb_index {
     int device = 0;
@@ -267,7 +294,10 @@ struct cmb_batch {
     DevBuf<TextOccRec> text;
     DevBuf<uint4> fout;
     DevBuf<unsigned long long> keysA, keysB;
-    DevBuf<uint32_t> fcounts, foffs;
+    DevBuf<uint32_t> fcounts;
+    DevBuf<uint64_t> foffs;
+    DevBuf<unsigned long long> fmKeysA, fmKeysB;
+    DevBuf<uint32_t> fmIdxA, fmIdxB, fmN;
     DevBuf<uint8_t> sortTmp, scanTmp;
     DevBuf<unsigned long long> vkeysA, vkeysB; // verification keys (k_verify) / sorted, then distinct
     DevBuf<uint32_t> vcounts, vruns;           // multiplicities of the distinct keys / number of runs
@@ -276,8 +306,8 @@ struct cmb_batch {
     uint32_t nSlots = 0;
     std::vector<uint64_t> hostOffs;
     // results
-    std::vector<cmb_occ> occs;
-    std::vector<uint64_t> occOffs;
+    PinnedBuf<cmb_occ> occs;
+    PinnedBuf<uint64_t> occOffs;
     uint64_t cnts[CMB_CNT_MAX];
     std::vector<KernelTime> times;
     bool done = false;
@@ -395,8 +425,9 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
         const uint32_t nReads = b->nReads;
         const uint32_t tasks = 2 * nReads;
         if (nReads == 0) {
-            b->occs.clear();
-            b->occOffs.assign(1, 0);
+            b->occs.resize(0);
+            b->occOffs.resize(1);
+            b->occOffs.p[0] = 0;
             memset(b->cnts, 0, sizeof(b->cnts));
             b->done = true;
             return CMB_OK;
@@ -620,32 +651,30 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
         const uint32_t nItems = hcnt[0], nFm = hcnt[1];
         lap("prep + search");
 
-        // ---- de-duplicate the in-index occurrences per read (Occurrences::eraseDoublesFM,
-        // indexhelpers.h:2135-2146) on the host: small
-        std::vector<FMOccRec> fm(nFm);
-        if (nFm) HIPCHK(hipMemcpy(fm.data(), b->fm.p, nFm * sizeof(FMOccRec), hipMemcpyDeviceToHost));
-        fm.erase(std::remove_if(fm.begin(), fm.end(), [](const FMOccRec& x) { return x.rsId == 0xFFFFFFFFu; }),
-                 fm.end()); // holes: slots reserved for cluster centres that had been reported before
-        std::sort(fm.begin(), fm.end(), [](const FMOccRec& x, const FMOccRec& y) {
-            const uint32_t rx = x.rsId >> 1, ry = y.rsId >> 1;
-            if (rx != ry) return rx < ry;
-            if (x.b != y.b) return x.b < y.b;
-            if (x.dist != y.dist) return x.dist < y.dist;
-            if (x.e != y.e) return x.e < y.e;
-            if (x.shift != y.shift) return x.shift < y.shift;
-            if (x.depth != y.depth) return x.depth < y.depth;
-            return x.rsId < y.rsId;
-        });
-        fm.erase(std::unique(fm.begin(), fm.end(),
-                             [](const FMOccRec& x, const FMOccRec& y) {
-                                 return x.rsId == y.rsId && x.b == y.b && x.e == y.e && x.dist == y.dist &&
-                                        x.depth == y.depth && x.shift == y.shift;
-                             }),
-                 fm.end());
-        uint64_t fmRows = 0;
-        for (const auto& f : fm) fmRows += f.e - f.b;
-        if (!fm.empty()) b->fmUniq.upload(fm.data(), fm.size());
-        lap("fm occurrences on the host");
+        // ---- de-duplicate the in-index occurrences (Occurrences::eraseDoublesFM, indexhelpers.h:2135-2146)
+        uint32_t nFmUniq = 0;
+        if (nFm) {
+            if (b->fmKeysA.n < nFm) {
+                b->fmKeysA.alloc((size_t)nFm + nFm / 4 + 256);
+                b->fmKeysB.alloc(b->fmKeysA.n);
+                b->fmIdxA.alloc(b->fmKeysA.n);
+                b->fmIdxB.alloc(b->fmKeysA.n);
+                b->fmUniq.alloc(b->fmKeysA.n);
+            }
+            if (b->fmN.n < 1) b->fmN.alloc(1);
+            HIPCHK(hipMemsetAsync(b->fmN.p, 0, sizeof(uint32_t), s));
+            hipLaunchKernelGGL(k_fm_keys, dim3((nFm + 255) / 256), dim3(256), 0, s, b->fm.p, nFm, b->fmKeysA.p, b->fmIdxA.p);
+            size_t tmpBytes = 0;
+            HIPCHK(rocprim::radix_sort_pairs(nullptr, tmpBytes, b->fmKeysA.p, b->fmKeysB.p, b->fmIdxA.p, b->fmIdxB.p, nFm, 0,
+                                             64, s));
+            if (b->sortTmp.n < tmpBytes) b->sortTmp.alloc(tmpBytes + 256);
+            HIPCHK(rocprim::radix_sort_pairs(b->sortTmp.p, tmpBytes, b->fmKeysA.p, b->fmKeysB.p, b->fmIdxA.p, b->fmIdxB.p,
+                                             nFm, 0, 64, s));
+            hipLaunchKernelGGL(k_fm_unique, dim3((nFm + 255) / 256), dim3(256), 0, s, b->fm.p, b->fmKeysB.p, b->fmIdxB.p, nFm,
+                               b->fmUniq.p, b->fmN.p, q);
+            HIPCHK(hipMemcpyAsync(&nFmUniq, b->fmN.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        }
+        lap("fm occurrences");
 
         // ---- locate + verify; text queue retried on overflow
         // traceback task queue: at most one task per item + the chunk slack of every k_verify wavefront
@@ -719,10 +748,10 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
             }
             HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            if (!fm.empty()) {
+            if (nFmUniq) {
                 tm.begin();
-                const uint32_t nb = (uint32_t)std::min<size_t>((fm.size() + 255) / 256, 4096);
-                hipLaunchKernelGGL(k_fmocc, dim3(nb), dim3(256), 0, s, ix->d, b->fmUniq.p, (uint32_t)fm.size(), q);
+                const uint32_t nb = (uint32_t)std::min<size_t>(((size_t)nFmUniq + 255) / 256, 4096);
+                hipLaunchKernelGGL(k_fmocc, dim3(nb), dim3(256), 0, s, ix->d, b->fmUniq.p, nFmUniq, q);
                 tm.end("k_fmocc");
             }
             HIPCHK(hipGetLastError());
@@ -749,8 +778,6 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
         HIPCHK(hipMemcpy(hc, b->counters.p, sizeof(hc), hipMemcpyDeviceToHost));
         for (int i = 0; i < CMB_CNT_MAX; i++) b->cnts[i] = hc[i];
         if (nReads >= (1u << 24)) return fail(CMB_ERR_UNSUPPORTED, "more than 2^24 reads in one batch");
-        b->occs.clear();
-        b->occOffs.assign(nReads + 1, 0);
         {
             tm.begin();
             if (b->keysA.n < nText) {
@@ -772,15 +799,15 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
             const int mode = b->k == 0 ? 0 : (b->metric == CMB_METRIC_HAMMING ? 1 : 2);
             HIPCHK(hipMemsetAsync(b->fcounts.p, 0, ((size_t)nReads + 1) * sizeof(uint32_t), s));
             hipLaunchKernelGGL(k_filter<false>, dim3((nReads + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->offs.p,
-                               nReads, b->k, mode, b->fcounts.p, (const uint32_t*)nullptr, (uint4*)nullptr);
+                               nReads, b->k, mode, b->fcounts.p, (const uint64_t*)nullptr, (uint4*)nullptr);
             size_t scanBytes = 0;
-            HIPCHK(rocprim::exclusive_scan(nullptr, scanBytes, b->fcounts.p, b->foffs.p, 0u, (size_t)nReads + 1,
-                                           rocprim::plus<uint32_t>(), s));
+            HIPCHK(rocprim::exclusive_scan(nullptr, scanBytes, b->fcounts.p, b->foffs.p, (uint64_t)0, (size_t)nReads + 1,
+                                           rocprim::plus<uint64_t>(), s));
             if (b->scanTmp.n < scanBytes) b->scanTmp.alloc(scanBytes + 256);
-            HIPCHK(rocprim::exclusive_scan(b->scanTmp.p, scanBytes, b->fcounts.p, b->foffs.p, 0u, (size_t)nReads + 1,
-                                           rocprim::plus<uint32_t>(), s));
-            uint32_t total = 0;
-            HIPCHK(hipMemcpyAsync(&total, b->foffs.p + nReads, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(rocprim::exclusive_scan(b->scanTmp.p, scanBytes, b->fcounts.p, b->foffs.p, (uint64_t)0, (size_t)nReads + 1,
+                                           rocprim::plus<uint64_t>(), s));
+            uint64_t total = 0;
+            HIPCHK(hipMemcpyAsync(&total, b->foffs.p + nReads, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
             HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             if (hcnt[3] & FLAG_CAPACITY)
@@ -793,16 +820,14 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
             tm.end("k_filter");
             lap("filter");
             b->occs.resize(total);
-            std::vector<uint32_t> o32((size_t)nReads + 1);
+            b->occOffs.resize((size_t)nReads + 1);
             if (total) HIPCHK(hipMemcpyAsync(b->occs.data(), b->fout.p, (size_t)total * sizeof(cmb_occ), hipMemcpyDeviceToHost, s));
-            HIPCHK(hipMemcpyAsync(o32.data(), b->foffs.p, o32.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(b->occOffs.data(), b->foffs.p, ((size_t)nReads + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            for (uint32_t r = 0; r <= nReads; r++) b->occOffs[r] = o32[r];
             lap("results to the host");
         }
         // TOTAL_REPORTED_POSITIONS (indexinterface.cpp:1378,1390 / :1333,1352)
         // (the device counter holds the records k_verify / k_traceback wrote; queue holes are not records)
-        b->cnts[CMB_CNT_TOTAL_REPORTED] += fmRows;
         b->done = true;
         return CMB_OK;
     } catch (const std::exception& e) {

@@ -1044,6 +1044,44 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const u
     if (flags) atomicOr(&q.cnt[3], flags);
 }
 
+// Occurrences::eraseDoublesFM (indexhelpers.h:2135-2146) on the device: the in-index occurrences are sorted
+// by (read, begin of the SA range) — one 64-bit radix sort — and a record is dropped if an identical one
+// (FMOcc::operator==, :1529: same strand, range, distance, depth, shift) precedes it in its (short) run of
+// equal keys.  The survivors' SA rows are what getUniqueTextOccurrences reports (:1378, :1390).
+__global__ void k_fm_keys(const FMOccRec* __restrict__ fm, uint32_t n, unsigned long long* __restrict__ keys,
+                          uint32_t* __restrict__ idx) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const FMOccRec f = fm[i];
+    keys[i] = f.rsId == 0xFFFFFFFFu ? ~0ull : (((unsigned long long)(f.rsId >> 1) << 32) | f.b); // holes last
+    idx[i] = i;
+}
+__global__ void __launch_bounds__(256)
+k_fm_unique(const FMOccRec* __restrict__ fm, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ idx,
+            uint32_t n, FMOccRec* __restrict__ out, uint32_t* __restrict__ nOut, Queues q) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    FMOccRec f{};
+    if (j < n && keys[j] != ~0ull) {
+        f = fm[idx[j]];
+        keep = true;
+        for (uint32_t t = j; t-- > 0 && keys[t] == keys[j];) {
+            const FMOccRec g = fm[idx[t]];
+            if (g.rsId == f.rsId && g.e == f.e && g.dist == f.dist && g.depth == f.depth && g.shift == f.shift) {
+                keep = false;
+                break;
+            }
+        }
+    }
+    uint32_t total;
+    const uint32_t o = waveAppend(nOut, keep ? 1u : 0u, total);
+    if (keep) out[o] = f;
+    unsigned long long rows = keep ? (unsigned long long)(f.e - f.b) : 0ull;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) rows += __shfl_xor(rows, d);
+    if ((threadIdx.x & 63u) == 0 && rows) atomicAdd(&q.counters[1], rows); // TOTAL_REPORTED_POSITIONS
+}
+
 // in-index occurrences (already de-duplicated per read) -> text occurrences
 __global__ void __launch_bounds__(256)
 k_fmocc(DevIndex ix, const FMOccRec* __restrict__ recs, uint32_t n, Queues q) {
@@ -1094,7 +1132,7 @@ k_pack_keys(const TextOccRec* __restrict__ text, uint32_t n, const uint64_t* __r
 template <bool WRITE>
 __global__ void __launch_bounds__(256)
 k_filter(const unsigned long long* __restrict__ keys, uint32_t n, const uint64_t* __restrict__ offs, uint32_t nReads,
-         uint32_t k, int mode, uint32_t* __restrict__ counts, const uint32_t* __restrict__ outOffs,
+         uint32_t k, int mode, uint32_t* __restrict__ counts, const uint64_t* __restrict__ outOffs,
          uint4* __restrict__ out) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nReads) return;
@@ -1117,7 +1155,7 @@ k_filter(const unsigned long long* __restrict__ keys, uint32_t n, const uint64_t
     const uint32_t len = (uint32_t)(offs[r + 1] - offs[r]);
     const uint32_t wbase = len - k;
     uint32_t nOut = 0;
-    const uint32_t obase = WRITE ? outOffs[r] : 0u;
+    const uint64_t obase = WRITE ? outOffs[r] : 0ull;
     const uint32_t maxDiff = 2 * k;
     uint32_t prevBegin = 0xFFFFFFFFu, prevDepth = 0xFFFFFFFFu, prevED = k + 1;
     unsigned long long prevKey = ~0ull;
