@@ -125,9 +125,11 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         ix->saBv.upload(desc->sa_bv, saW);
         ix->saCnt.upload(desc->sa_bv_counts, (saW + 7) / 4);
         ix->saSamples.upload(desc->sa_samples, desc->n_samples);
-        ix->text.alloc(n + 64); // padded: k_verify reads aligned 16-byte chunks one chunk ahead
+        ix->text.alloc(n + 64); // padded: the verification kernels read 16-byte chunks two chunks ahead
         HIPCHK(hipMemset(ix->text.p, 0, n + 64));
         HIPCHK(hipMemcpy(ix->text.p, desc->text, n, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_encode_text, dim3(4096), dim3(256), 0, 0, ix->text.p, n, n + 64); // ASCII -> codes 0..4
+        HIPCHK(hipGetLastError());
         ix->kmer.alloc(1ull << (2 * desc->kmer_size));
         if (desc->seq_starts) ix->seqStarts.assign(desc->seq_starts, desc->seq_starts + desc->n_seqs);
         DevIndex& d = ix->d;
@@ -287,7 +289,7 @@ struct cmb_batch {
     size_t bfsQCap = 0, bfsEvCap = 0, bfsFCap = 0, bfsCCap = 0, bfsACap = 0;
     DevBuf<PartOut> parts;
     DevBuf<DfsTask> dfs;
-    DevBuf<uint64_t> vHP, vD0;
+    DevBuf<uint64_t> vW; // packed trace rows [row][slot]
     DevBuf<uint4> tbq;
     DevBuf<uint4> items;
     DevBuf<FMOccRec> fm, fmUniq;
@@ -735,11 +737,8 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                 const uint32_t nTb = hcnt[7];
                 if (nTb) {
                     const uint32_t tSlots = std::min<uint32_t>(((nTb + 255) / 256) * 256, 256u * 1024u);
-                    if (b->vHP.n < (size_t)VROWS * tSlots) {
-                        b->vHP.alloc((size_t)VROWS * tSlots);
-                        b->vD0.alloc((size_t)VROWS * tSlots);
-                    }
-                    VPlanes vp{b->vHP.p, b->vD0.p, tSlots};
+                    if (b->vW.n < (size_t)VROWS * tSlots) b->vW.alloc((size_t)VROWS * tSlots);
+                    VPlanes vp{b->vW.p, tSlots};
                     tm.begin();
                     hipLaunchKernelGGL(k_traceback, dim3(tSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->gw,
                                        b->G.p, b->tbq.p, nTb, vp, q);
@@ -1017,7 +1016,7 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         DevBuf<uint32_t> G, cnt;
         DevBuf<uint4> items;
         DevBuf<TextOccRec> text;
-        DevBuf<uint64_t> vHP, vD0;
+        DevBuf<uint64_t> vW;
         DevBuf<uint4> tbq;
         DevBuf<unsigned long long> ctr;
         const uint64_t ho[2] = {0, plen};
@@ -1038,10 +1037,9 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         HIPCHK(hipMemset(cnt.p, 0, 32));
         HIPCHK(hipMemset(ctr.p, 0, CMB_CNT_MAX * 8));
         const uint32_t slots = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(((n + 255) / 256) * 256, 256), 65536);
-        vHP.alloc((size_t)VROWS * slots);
-        vD0.alloc((size_t)VROWS * slots);
+        vW.alloc((size_t)VROWS * slots);
         tbq.alloc(n + (size_t)(slots / 64 + 1) * 256);
-        VPlanes vp{vHP.p, vD0.p, slots};
+        VPlanes vp{vW.p, slots};
         Queues q{};
         q.text = text.p;
         q.textCap = (uint32_t)cap;

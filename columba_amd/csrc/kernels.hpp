@@ -639,11 +639,18 @@ constexpr int VEMIT = 20; // max cluster centres of one candidate (size of the f
 
 // Row storage of the traceback pass, interleaved by slot so that the lanes of a wavefront (which
 // walk rows in lock step) write whole 512-byte lines: element (row, slot) lives at [row * nSlots + slot].
+// What the traceback reads of row i is bit (j - 32 b) + DIAG of HP and D0 with |i - j| inside the band, i.e.
+// at most 18 (= 3 k) bits below and 6 above the row's diagonal bit: both 32-bit windows starting 18 bits below
+// the diagonal are kept in ONE 64-bit word per row (low half HP, high half D0).
 struct VPlanes {
-    uint64_t* HP;
-    uint64_t* D0;
+    uint64_t* W;
     uint32_t nSlots;
 };
+constexpr uint32_t TB_BELOW = 18;
+__device__ __forceinline__ uint64_t packTraceRow(uint32_t r, uint64_t HP, uint64_t D0) {
+    const uint32_t sh = (r % MX_BLOCK) + MX_DIAG - TB_BELOW;
+    return (uint64_t)(uint32_t)(HP >> sh) | ((uint64_t)(uint32_t)(D0 >> sh) << 32);
+}
 
 __device__ __forceinline__ void emitText(const Queues& q, uint32_t& flags, uint32_t rsId, uint32_t b, uint32_t e,
                                          uint32_t d) {
@@ -655,13 +662,25 @@ __device__ __forceinline__ void emitText(const Queues& q, uint32_t& flags, uint3
     q.text[base] = TextOccRec{rsId, b, e, d};
 }
 
-__device__ __forceinline__ uint32_t textCode(uint8_t ch) { // A,C,G,T -> 0..3; anything else ('$') -> 4
-    return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+// The device copy of the text holds CODES, one byte per character: A,C,G,T -> 0..3, anything else ('$',
+// the padding behind the text) -> 4 (k_encode_text at index creation).
+__global__ void k_encode_text(uint8_t* __restrict__ text, uint64_t n, uint64_t nPadded) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nPadded; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint8_t ch = text[i];
+        text[i] = i >= n ? 4 : ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
+    }
 }
+__device__ __forceinline__ uint32_t textCode(uint8_t code) { return code; }
 
-__device__ __forceinline__ uint4 loadText16(const uint8_t* text, uint32_t chunk) {
-    return reinterpret_cast<const uint4*>(text)[chunk];
+// 16 text codes from ANY byte offset (gfx950 serves unaligned 16-byte global loads)
+struct __attribute__((packed, aligned(1))) Unaligned16 {
+    uint32_t x, y, z, w;
+};
+__device__ __forceinline__ uint4 loadText16(const uint8_t* p) {
+    const Unaligned16 v = *reinterpret_cast<const Unaligned16*>(p);
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
+constexpr uint32_t ML_WORDS = 5 * 256; // LDS match-word table of a 256-thread block: [code 0..4][thread]
 
 // forward pass of the banded matrix of one candidate over the text window [start, start+size).
 // STORE = false: verification pass (k_verify) — nothing is stored, cluster centres of the final column
@@ -673,9 +692,8 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const uint32
                                                 const MatGeom& g, uint32_t nZeros, uint32_t start, uint32_t size,
                                                 uint32_t maxED, uint32_t minED, uint32_t& centreMask,
                                                 uint64_t& edPack, uint64_t& edPackHi, const VPlanes& V, uint32_t slot,
-                                                uint32_t& cRows) {
-    uint64_t HP = (~0ull) << MX_LEFT, HN = ~HP, D0 = 0, RAC = 1ull << (MX_DIAG + g.Wh);
-    for (uint32_t i = 1; i < nZeros; i++) HN ^= 1ull << (MX_LEFT - i);
+                                                uint32_t& cRows, uint64_t* Ml) {
+    uint64_t HP = (~0ull) << MX_LEFT, HN = (1ull << (MX_LEFT + 1u - nZeros)) - 1ull, D0 = 0, RAC = 1ull << (MX_DIAG + g.Wh);
     uint32_t score = 0;
     const uint32_t sfc = g.sfc();
     const uint32_t firstRow = (g.m - 1) - sfc;
@@ -686,56 +704,62 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const uint32
     centreMask = 0;
     edPack = 0; // 3 bits per final-column row above firstRow: min(ED, 7); rows 21.. go to edPackHi
     edPackHi = 0;
+    // All lanes of the wavefront walk their rows in lock step (row r in iteration r - 1 for everybody), so the
+    // loop counter, the byte position inside the 16-code text chunk and the moment the match words of the
+    // next 32-row block are needed are wave-uniform; only "does this lane still have rows" is per lane.
+    // The four match words of the lane's current block sit in LDS, indexed by the text code (code 4: zero).
+    const uint32_t tid = threadIdx.x;
+    Ml[4 * 256 + tid] = 0ull;
+    const uint8_t* tp = ix.text + start;
+    uint4 cur = loadText16(tp);
+    uint4 nxt = loadText16(tp + 16); // the text allocation is padded
     uint32_t i = 0;
-    uint64_t Mblk[4];
-    // One row per loop iteration for every lane (lock step: the plane stores of a wavefront then fall
-    // into whole lines).  The text is read in aligned 16-byte chunks, one chunk ahead of its use.
-    uint32_t chunk = start >> 4;
-    uint4 cur = loadText16(ix.text, chunk);
-    uint4 nxt = loadText16(ix.text, chunk + 1); // the text allocation is padded
-    while (i < size) {
-        const uint32_t p = start + i;
-        if ((p >> 4) != chunk) {
-            chunk++;
-            cur = nxt;
-            nxt = loadText16(ix.text, chunk + 1);
-        }
-        const uint32_t bi = p & 15u;
-        const uint32_t wsel = bi >> 2;
-        const uint32_t wv = wsel == 0 ? cur.x : wsel == 1 ? cur.y : wsel == 2 ? cur.z : cur.w;
-        const uint32_t tc = textCode((uint8_t)(wv >> (8 * (bi & 3u))));
-        const uint32_t r = i + 1;
-        if ((r % MX_BLOCK) == 0 || i == 0) {
-            const uint32_t b = r / MX_BLOCK;
+    bool alive = size > 0;
+    for (uint32_t c = 0; __ballot(alive) != 0ull; c++) {
 #pragma unroll
-            for (int ch = 0; ch < 4; ch++) Mblk[ch] = matchWord(Gf + ch * gw, 0, len, b);
-        }
-        const uint64_t M = tc == 0 ? Mblk[0] : tc == 1 ? Mblk[1] : tc == 2 ? Mblk[2] : tc == 3 ? Mblk[3] : 0ull;
-        cRows++;
-        const bool valid = computeRow(g, r, M, HP, HN, D0, RAC, score);
-        if (STORE) {
-            const size_t o = (size_t)r * V.nSlots + slot;
-            V.HP[o] = HP;
-            V.D0[o] = D0;
-        }
-        if (!valid) break;
-        if (STORE && r > firstRow) {
-            const uint32_t ed = cellAt(r, col, HP, HN, score);
-            const uint32_t bidx = r - firstRow - 1u;
-            if (bidx < 21u) edPack |= (uint64_t)min(ed, 7u) << (3u * bidx);
-            else edPackHi |= (uint64_t)min(ed, 7u) << (3u * (bidx - 21u));
-        }
-        if (!STORE && r >= firstRow) {
-            const uint32_t ed = cellAt(r, col, HP, HN, score);
-            // row r-1 can now be judged (its `below` neighbour is known)
-            if (r - 1 > firstRow) {
-                const uint32_t e1 = edPrev;
-                if (e1 <= maxED && e1 >= minED && e1 <= edPrev2 && e1 <= ed) centreMask |= 1u << (r - 2 - firstRow);
+        for (uint32_t t = 0; t < 16; t++) {
+            const uint32_t r = 16 * c + t + 1;
+            if ((t == 15 && (c & 1u)) || (t == 0 && c == 0)) { // r % 32 == 0, or the first row: next block's words
+                if (alive) {
+                    const uint32_t b = r / MX_BLOCK;
+#pragma unroll
+                    for (int ch = 0; ch < 4; ch++) Ml[ch * 256 + tid] = matchWord(Gf + ch * gw, 0, len, b);
+                }
             }
-            edPrev2 = edPrev;
-            edPrev = ed;
+            const uint32_t wsel = t >> 2;
+            const uint32_t wv = wsel == 0 ? cur.x : wsel == 1 ? cur.y : wsel == 2 ? cur.z : cur.w;
+            const uint32_t tc = (wv >> (8 * (t & 3u))) & 0xFFu;
+            if (alive) {
+                const uint64_t M = Ml[tc * 256 + tid];
+                cRows++;
+                const bool valid = computeRow(g, r, M, HP, HN, D0, RAC, score);
+                if (STORE) V.W[(size_t)r * V.nSlots + slot] = packTraceRow(r, HP, D0);
+                if (!valid) {
+                    alive = false;
+                } else {
+                    if (STORE && r > firstRow) {
+                        const uint32_t ed = cellAt(r, col, HP, HN, score);
+                        const uint32_t bidx = r - firstRow - 1u;
+                        if (bidx < 21u) edPack |= (uint64_t)min(ed, 7u) << (3u * bidx);
+                        else edPackHi |= (uint64_t)min(ed, 7u) << (3u * (bidx - 21u));
+                    }
+                    if (!STORE && r >= firstRow) {
+                        const uint32_t ed = cellAt(r, col, HP, HN, score);
+                        // row r-1 can now be judged (its `below` neighbour is known)
+                        if (r - 1 > firstRow) {
+                            const uint32_t e1 = edPrev;
+                            if (e1 <= maxED && e1 >= minED && e1 <= edPrev2 && e1 <= ed) centreMask |= 1u << (r - 2 - firstRow);
+                        }
+                        edPrev2 = edPrev;
+                        edPrev = ed;
+                    }
+                    i++;
+                    if (i >= size) alive = false;
+                }
+            }
         }
-        i++;
+        cur = nxt;
+        nxt = loadText16(tp + 16 * (c + 2));
     }
     if (!STORE && i > firstRow) { // the last valid row has no `below` neighbour (i == lastRow)
         const uint32_t e1 = edPrev;
@@ -758,7 +782,7 @@ __host__ __device__ __forceinline__ unsigned long long packVerifyKey(uint32_t rs
 __device__ __forceinline__ bool verifyEdit(const DevIndex& ix, const uint64_t* offs, uint32_t gw, const uint32_t* G,
                                            uint32_t rs, uint32_t start, uint32_t maxED, uint32_t minED, uint32_t fixed,
                                            uint32_t mult, uint32_t& cStarted, uint32_t& cRows, uint32_t& cText,
-                                           uint32_t& cAbort, uint32_t& cCig, uint4& tbRec) {
+                                           uint32_t& cAbort, uint32_t& cCig, uint4& tbRec, uint64_t* Ml) {
     cStarted += mult;
     const uint32_t len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
     const uint32_t nZeros = fixed ? 1u : 2u * maxED + 1u;
@@ -774,9 +798,9 @@ __device__ __forceinline__ bool verifyEdit(const DevIndex& ix, const uint64_t* o
     if (!g.inFinalColumn(size)) return false;
     uint32_t mask = 0, rows = 0;
     uint64_t edPack, edPackHi;
-    const VPlanes noPlanes{nullptr, nullptr, 0};
+    const VPlanes noPlanes{nullptr, 0};
     const uint32_t i = forwardPass<false>(ix, G + (size_t)rs * 8 * gw, gw, len, g, nZeros, start, size, maxED, minED,
-                                          mask, edPack, edPackHi, noPlanes, 0, rows);
+                                          mask, edPack, edPackHi, noPlanes, 0, rows, Ml);
     cRows += rows * mult;
     cText += rows * mult;
     if (i <= size - g.sfc() || mask == 0) { // indexhelpers.cpp:542, :550
@@ -794,6 +818,7 @@ __global__ void __launch_bounds__(256)
 k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32_t gw,
          const uint8_t* __restrict__ seq, const uint32_t* __restrict__ G, const uint4* __restrict__ items,
          uint32_t nItems, uint4* __restrict__ tbq, uint32_t tbCap, unsigned long long* __restrict__ vkeys, Queues q) {
+    __shared__ uint64_t Ml[ML_WORDS];
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cLF = 0, cLoc = 0, cText = 0, cRows = 0, cAbort = 0, cCig = 0, cStarted = 0, cRep = 0, flags = 0;
     WaveChunk chT, chB; // chunks of the text-occurrence queue / the traceback task queue
@@ -802,7 +827,7 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
     auto holeB = [&](uint32_t i) { tbq[i] = make_uint4(0, 0, 0, 0); }; // mask 0: nothing to trace
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t waveBase = slot & ~63u;
-    const VPlanes noPlanes{nullptr, nullptr, 0};
+    const VPlanes noPlanes{nullptr, 0};
     for (uint32_t base = waveBase; base < nItems; base += stride) { // wave-uniform trip count
         const uint32_t it = base + (threadIdx.x & 63u);
         uint32_t nOut = 0, nTb = 0;
@@ -873,7 +898,7 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
                 if (vkeys) { // verified once per distinct key by k_verify_edit
                     vkey = packVerifyKey(rs, start, maxED, minED, fixed);
                 } else if (verifyEdit(ix, offs, gw, G, rs, start, maxED, minED, fixed, 1u, cStarted, cRows, cText, cAbort,
-                                      cCig, tbRec)) {
+                                      cCig, tbRec, Ml)) {
                     nTb = 1;
                 }
             }
@@ -901,6 +926,7 @@ __global__ void __launch_bounds__(256)
 k_verify_edit(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const uint32_t* __restrict__ G,
               const unsigned long long* __restrict__ ukeys, const uint32_t* __restrict__ counts, uint32_t nKeys,
               uint4* __restrict__ tbq, uint32_t tbCap, Queues q) {
+    __shared__ uint64_t Ml[ML_WORDS];
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cText = 0, cRows = 0, cAbort = 0, cCig = 0, cStarted = 0, flags = 0;
     WaveChunk chB;
@@ -917,7 +943,7 @@ k_verify_edit(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const
         if (key != ~0ull) { // (~0: the run of non-edit items and holes)
             const uint32_t mult = min(counts[it], 0xFFFFFFu);
             if (verifyEdit(ix, offs, gw, G, (uint32_t)(key >> 39), (uint32_t)(key >> 7), (uint32_t)(key >> 4) & 7u,
-                           (uint32_t)(key >> 1) & 7u, (uint32_t)key & 1u, mult, cStarted, cRows, cText, cAbort, cCig, tbRec))
+                           (uint32_t)(key >> 1) & 7u, (uint32_t)key & 1u, mult, cStarted, cRows, cText, cAbort, cCig, tbRec, Ml))
                 nTb = 1;
         }
         const uint32_t o2 = chB.alloc(&q.cnt[7], tbCap, nTb, 256u, ovB, holeB);
@@ -939,8 +965,8 @@ constexpr int TBW = 8;
 __global__ void __launch_bounds__(256)
 k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const uint32_t* __restrict__ G,
             const uint4* __restrict__ tbq, uint32_t nTasks, VPlanes V, Queues q) {
-    __shared__ uint64_t wHP[TBW][256];
-    __shared__ uint64_t wD0[TBW][256];
+    __shared__ uint64_t wW[TBW][256];
+    __shared__ uint64_t Ml[ML_WORDS];
     __shared__ uint8_t wT[TBW][256];
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t tid = threadIdx.x;
@@ -979,7 +1005,7 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const u
             uint32_t dummyMask;
             // rows 1..topCentre (all valid: they were valid in pass 1)
             forwardPass<true>(ix, Gf, gw, len, g, nZeros, start, topCentre, maxED, 0, dummyMask, edPack, edPackHi, V,
-                              slot, dummyRows);
+                              slot, dummyRows, Ml);
         }
         // one centre per lane and round; the wavefront appends its results with one atomic per round
         for (;;) {
@@ -1001,15 +1027,20 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const u
                         for (int w = 0; w < TBW; w++) {
                             const uint32_t r = winTop >= (uint32_t)w ? winTop - w : 0u;
                             const size_t o = (size_t)r * NS + slot;
-                            wHP[w][tid] = (r == 0) ? HP0 : V.HP[o];
-                            wD0[w][tid] = (r == 0) ? 0ull : V.D0[o];
+                            wW[w][tid] = (r == 0) ? packTraceRow(0, HP0, 0ull) : V.W[o];
                             wT[w][tid] = (r == 0) ? (uint8_t)0 : ix.text[start + r - 1];
                         }
                     }
                     const uint32_t ws = winTop - ti;
                     const uint32_t b = ti / MX_BLOCK;
                     const uint64_t bit = 1ull << ((tj - b * MX_BLOCK) + MX_DIAG);
-                    if (wHP[ws][tid] & bit) {
+                    const uint32_t rel = tj + TB_BELOW - ti; // bit of the row's packed windows
+                    if (rel > 31u) { // outside the stored window: cannot happen inside the band (checked, not assumed)
+                        flags |= FLAG_CAPACITY;
+                        break;
+                    }
+                    const uint64_t ww = wW[ws][tid];
+                    if (((uint32_t)ww >> rel) & 1u) {
                         --tj;
                     } else {
                         bool diag = false;
@@ -1021,7 +1052,7 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const u
                             }
                             const uint32_t tc = textCode(wT[ws][tid]);
                             const uint64_t M = tc == 0 ? Mblk[0] : tc == 1 ? Mblk[1] : tc == 2 ? Mblk[2] : tc == 3 ? Mblk[3] : 0ull;
-                            diag = ((M | ~wD0[ws][tid]) & bit) != 0;
+                            diag = (M & bit) != 0 || (((uint32_t)(ww >> 32) >> rel) & 1u) == 0;
                         }
                         if (diag) {
                             --ti;
