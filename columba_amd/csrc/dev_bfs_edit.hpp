@@ -35,8 +35,10 @@ constexpr uint32_t BFS_NONE = 0xFFFFFFFFu;
 constexpr uint32_t ED_CELLS = 24; // final-column cells per phase (5 bits each in a 128-bit pack); 3k+2 <= 24 for k <= 7
 constexpr uint32_t CTX_U4 = 24;   // uint4 per context: 8 header + 16 match words (8 row blocks x {A,C | G,T})
 constexpr uint32_t CTX_MBLK = 8;
-constexpr uint32_t BFS_GRID = 1024;   // blocks that expand the frontier (grid-stride)
-constexpr uint32_t BFS_GRID_EV = 512; // blocks that handle the events of the same pass
+// (all blocks of a pass should be resident together — 3 blocks of 256 threads per CU at ~160 VGPRs — or the event
+// blocks, which come last in the grid, only start when expansion blocks have finished)
+constexpr uint32_t BFS_GRID = 576;    // blocks that expand the frontier (grid-stride)
+constexpr uint32_t BFS_GRID_EV = 192; // blocks that handle the events of the same pass
 
 enum { FLAG_BFS_Q = 64, FLAG_BFS_EV = 128, FLAG_BFS_F = 256, FLAG_BFS_CTX = 512, FLAG_BFS_ARENA = 1024 };
 // any of these set by an earlier pass: the frontier is incomplete, later passes do nothing (the host re-runs)
@@ -89,6 +91,36 @@ __device__ __forceinline__ uint32_t blockAppend(uint32_t* counter, uint32_t n, u
     if (w > 2) off += sh[2];
     __syncthreads(); // sh may be reused by the next call
     return off + pre;
+}
+
+// Four appends at once: the four wave scans first, ONE barrier, four lanes issue the four atomics side by side
+// (one atomic round trip per tile instead of four), one more barrier.  sh = 4 x 5 words.
+__device__ __forceinline__ void blockAppend4(uint32_t* c0, uint32_t* c1, uint32_t* c2, uint32_t* c3, const uint32_t n[4],
+                                             uint32_t (*sh)[5], uint32_t off[4]) {
+    uint32_t pre[4];
+    const uint32_t w = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t wTotal;
+        pre[j] = waveExclusiveScan(n[j], wTotal);
+        if ((threadIdx.x & 63u) == 0) sh[j][w] = wTotal;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        uint32_t* c = threadIdx.x == 0 ? c0 : threadIdx.x == 1 ? c1 : threadIdx.x == 2 ? c2 : c3;
+        const uint32_t t = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+        sh[threadIdx.x][4] = t ? atomicAdd(c, t) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t o = sh[j][4] + pre[j];
+        if (w > 0) o += sh[j][0];
+        if (w > 1) o += sh[j][1];
+        if (w > 2) o += sh[j][2];
+        off[j] = o;
+    }
+    __syncthreads(); // sh may be reused by the next call
 }
 
 // ------------------------------------------------------------------ expand
@@ -208,11 +240,10 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
             if (kd == 3) nIt += cr[c].y - cr[c].x;
         }
         const uint32_t nF = (uint32_t)__popc(needF);
-        uint32_t tNode, tEv, tIt, tF;
-        uint32_t oNode = blockAppend(&B.nq[pass + 1], nNode, sh[0], tNode);
-        uint32_t oEv = blockAppend(&B.ne[pass + 1], nEv, sh[1], tEv);
-        uint32_t oIt = blockAppend(&q.cnt[0], nIt, sh[2], tIt);
-        uint32_t oF = blockAppend(&B.pool[0], nF, sh[3], tF);
+        const uint32_t want[4] = {nNode, nEv, nIt, nF};
+        uint32_t got[4];
+        blockAppend4(&B.nq[pass + 1], &B.ne[pass + 1], &q.cnt[0], &B.pool[0], want, sh, got);
+        uint32_t oNode = got[0], oEv = got[1], oIt = got[2], oF = got[3];
         // (a block whose share does not fit drops it: the host sees the needed sizes and re-runs)
         bool okNode = true, okEv = true, okIt = true, okF = true;
         if (oNode + nNode > qCap) { okNode = false; flags |= FLAG_BFS_Q; }
@@ -447,11 +478,11 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
         const uint32_t wantF = P.kind >= 2 ? 1u + P.nDescSrc : 0u;
         const uint32_t wantA = P.kind == 3 ? 2u * P.nDescNew + (2u * P.ni + 15u) / 16u : 0u;
         const uint32_t wantFm = P.kind == 1 ? (uint32_t)__popc(P.centres) : 0u;
-        uint32_t t0, t1, t2, t3;
-        const uint32_t cNew = blockAppend(&B.pool[1], wantCtx, sh[0], t0);
-        uint32_t fNext = blockAppend(&B.pool[0], wantF, sh[1], t1);
-        const uint32_t aOff = blockAppend(&B.pool[2], wantA, sh[2], t2);
-        uint32_t fmNext = blockAppend(&q.cnt[1], wantFm, sh[3], t3);
+        const uint32_t want[4] = {wantCtx, wantF, wantA, wantFm};
+        uint32_t got[4];
+        blockAppend4(&B.pool[1], &B.pool[0], &B.pool[2], &q.cnt[1], want, sh, got);
+        const uint32_t cNew = got[0], aOff = got[2];
+        uint32_t fNext = got[1], fmNext = got[3];
         bool ok = true;
         if (cNew + wantCtx > B.cCap) { ok = false; flags |= FLAG_BFS_CTX; }
         if (fNext + wantF > B.fCap) { ok = false; flags |= FLAG_BFS_F; }
