@@ -300,44 +300,44 @@ k_parts(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
     PartMachine m(ix, lst, partLds + STRAT_WORDS, threadIdx.x, blockDim.x);
     m.setReadWords(maxLen);
     const uint32_t total = 2 * nReads;
-    uint32_t nextRs = blockIdx.x * blockDim.x + threadIdx.x;
-    bool done = false;
-    for (;;) {
-        // (1) an idle lane takes its next read x strand and asks for its read record
-        if (!done && m.phase == PH_DONE && m.req == RQ_NONE) {
-            m.rsId = nextRs;
-            nextRs += gridDim.x * blockDim.x;
-            if (m.rsId >= total) done = true;
-            else m.req = RQ_REC;
-        }
-        // (2) bookkeeping up to the next request; a finished partitioning writes its outputs
-        if (!done && m.req == RQ_NONE) {
-            m.advance();
-            if (m.phase == PH_FIN) m.finish(parts, exr, psel, total);
-        }
-        // (3) the memory step
+    // Lock-step batches: every lane of the wavefront takes one read x strand, all load their read records, all
+    // fetch their seeds, then all run the extension loop (one extension per iteration, the memory step in the
+    // middle) until the last one has assigned every character.  Reads of one batch need about the same number of
+    // iterations, and only ONE phase's code runs at a time (lanes in different phases of a free-running state
+    // machine made every iteration pay for all phases).
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t base = first & ~63u; base < total; base += stride) { // wave-uniform trip count
+        const uint32_t rs = base + (threadIdx.x & 63u);
         uint4 v[8];
-        const int rq = done ? RQ_NONE : m.req;
-        if (rq == RQ_RANK) issueExtend(ix, m.reqMode, m.reqParent, v);
-        else if (rq == RQ_SEED) m.seedIssue(v);
-        else if (rq == RQ_REC) {
+        m.phase = PH_DONE;
+        m.req = RQ_NONE;
+        if (rs < total) {
 #pragma unroll
             for (uint32_t j = 0; j < 5; j++)
-                if (j < recQ) v[j] = rec[(size_t)m.rsId * recQ + j];
+                if (j < recQ) v[j] = rec[(size_t)rs * recQ + j];
+            m.begin(rs, v, seq + (size_t)rs * maxLen, k); // may leave a RQ_SEED request
+            if (m.phase == PH_DONE) psel[rs] = 0x80u;      // unsupported read: nothing to search
         }
-        if (rq == RQ_RANK) {
-            RangePair child;
-            const bool ok = takeExtend(ix, m.reqMode, m.reqParent, m.reqCode, v, child);
-            m.req = RQ_NONE;
-            m.resume(ok, child);
-        } else if (rq == RQ_SEED) {
-            m.req = RQ_NONE;
-            m.seedTake(v);
-        } else if (rq == RQ_REC) {
-            m.begin(m.rsId, v, seq + (size_t)m.rsId * maxLen, k); // may leave a RQ_SEED request
-            if (m.phase == PH_DONE) psel[m.rsId] = 0x80u;          // unsupported read: nothing to search
+        if (__ballot(m.req == RQ_SEED) != 0ull) {
+            if (m.req == RQ_SEED) {
+                m.seedIssue(v);
+                m.req = RQ_NONE;
+                m.seedTake(v);
+            }
         }
-        if (__ballot(!done) == 0ull) break;
+        for (;;) {
+            if (m.req == RQ_NONE) m.advance(); // bookkeeping up to the next extension (or the end)
+            if (__ballot(m.req == RQ_RANK) == 0ull) break;
+            if (m.req == RQ_RANK) {
+                issueExtend(ix, m.reqMode, m.reqParent, v);
+                RangePair child;
+                const bool ok = takeExtend(ix, m.reqMode, m.reqParent, m.reqCode, v, child);
+                m.req = RQ_NONE;
+                m.resume(ok, child);
+            }
+        }
+        if (m.phase == PH_FIN) m.finish(parts, exr, psel, total);
     }
     const uint32_t local[2] = {m.cNode, m.cExp};
     const int which[2] = {0, 7};
