@@ -6,8 +6,8 @@ BASELINE.json configs[2]) on a human-like synthetic reference, one process per G
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the whole hot path (k_prep -> k_partition -> k_dfs -> k_verify -> k_traceback ->
-k_fmocc -> k_filter, results copied back to the host)
+A "step" is one pass of the whole hot path (k_prep -> k_parts/k_exact -> frontier search -> k_verify ->
+k_traceback -> k_fmocc -> k_filter, results copied back to the host)
 over this rank's read shard, reads already resident in HBM (cmb_batch_run).  Weak scaling: every
 rank matches `--reads` reads against a full replica of the index; no collective on the data path
 (rank 0 builds the index and broadcasts it over RCCL, read shards are scattered once, both before
@@ -39,14 +39,52 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+# kernels behind each timed group of cmb_batch_timings (rocPRIM sorts / scans between them are not attributed)
+GROUP_KERNELS = {"k_prep": ["k_prep"], "k_partition": ["k_parts", "k_exact"],
+                 "k_dfs": ["k_bfs_start", "k_bfs_pass", "k_bfs_finish", "k_dfs_hamming"],
+                 "k_verify": ["k_verify", "k_verify_edit"], "k_traceback": ["k_traceback"],
+                 "k_fmocc": ["k_fmocc"], "k_filter": ["k_pack_keys", "k_filter"]}
+
+
+def load_traffic(args, genome_bp, reads, group):
+    """HBM bytes per step of one kernel group from the PMC passes of tools/profile_round.sh (FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same command with --steps 1 --warmup 0).
+    MI355X_MICROARCH.md: both are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled."""
+    import glob
+    cands = [args.traffic_from] if args.traffic_from else sorted(
+        glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True)
+    for f in cands:
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        w = d.get("workload", {})
+        if w.get("genome_bp") != genome_bp or w.get("reads_per_gpu") != reads or w.get("k") != args.k:
+            continue
+        tot = 0.0
+        for kn in GROUP_KERNELS.get(group, [group]):
+            e = d.get("kernels", {}).get(kn)
+            if e:
+                tot += 2.0 * e.get("FETCH_SIZE_KiB", 0.0) * 1024 + e.get("WRITE_SIZE_KiB", 0.0) * 1024
+        if tot > 0:
+            return round(tot / 1e9, 3), (f"GB per step, 2 x FETCH_SIZE + WRITE_SIZE of {os.path.basename(f)} "
+                                         "(separate rocprofv3 --pmc passes; gfx950 factor for FETCH_SIZE, calibrated "
+                                         "for wide coalesced reads only)")
+    return None, "no PMC pass on record for this workload (tools/profile_round.sh writes profiles/*_pmc_traffic.json)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("CMB_BENCH_GENOME_MBP", 1024)))
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("CMB_BENCH_READS", 1_000_000)),
-                    help="reads per GPU (weak scaling)")
+    ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("CMB_BENCH_GENOME_MBP", 3000)),
+                    help="length of the synthetic human-like reference (GRCh38 scale by default)")
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("CMB_BENCH_READS", 10_000_000)),
+                    help="reads per GPU and step (weak scaling); BASELINE.json configs[2]: 10 M x 150 bp")
+    ap.add_argument("--traffic-from", default=None,
+                    help="JSON written by tools/profile_round.sh (PMC passes of this same command); default: the "
+                         "newest profiles/*_pmc_traffic.json measured on the same workload")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--k", type=int, default=4)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU oracle (bounded sample)")
@@ -135,18 +173,27 @@ def main():
         value = world * R * steps / elapsed
         avg = {k: v / steps for k, v in kern.items()}
         dominant = max(avg, key=avg.get)
-        # algorithmic bytes per launch:
-        #   k_partition / k_dfs: 192 B per node expansion (2 positions x (64 B counts line + 32 B bit group))
+        # algorithmic bytes per step of every kernel group:
+        #   k_partition (k_parts + k_exact) / k_dfs (frontier search): 192 B per node expansion
+        #       (2 positions x (64 B counts line + 32 B bit group) in the reference layout)
         #   k_verify: 112 B per LF step + 28 B per located row + 1 B per text character
+        #   k_traceback: 1 B per text character of the candidates that are traced
         alg = {"k_partition": 192.0 * (cnt["EXPANSIONS"] - cnt["DFS_EXPANSIONS"]),
                "k_dfs": 192.0 * cnt["DFS_EXPANSIONS"],
                "k_verify": 112.0 * cnt["LF_STEPS"] + 28.0 * cnt["LOCATED_ROWS"] + 1.0 * cnt["TEXT_BYTES"],
                "k_traceback": 1.0 * cnt["TEXT_BYTES"]}
-        achieved = alg.get(dominant, 0.0) / (avg[dominant] * 1e-3) / 1e9 if avg[dominant] > 0 else 0.0
+        per_kernel = {}
+        for kname, ms in avg.items():
+            gbs = alg.get(kname, 0.0) / (ms * 1e-3) / 1e9 if ms > 0 and kname in alg else None
+            per_kernel[kname] = {"ms": round(ms, 3),
+                                 "algorithmic_GBps": None if gbs is None else round(gbs, 1),
+                                 "frac_of_hbm_peak": None if gbs is None else round(gbs / HBM_PEAK_GBS, 4)}
+        achieved = per_kernel[dominant]["algorithmic_GBps"] or 0.0
+        traffic, traffic_note = load_traffic(args, n, R, dominant)
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "avg_launch_ms": round(avg[dominant], 3),
-                    "kernels_ms": {k: round(v, 3) for k, v in avg.items()}}
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_note": traffic_note, "avg_launch_ms": round(avg[dominant], 3),
+                    "per_kernel": per_kernel}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))

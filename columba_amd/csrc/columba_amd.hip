@@ -280,8 +280,6 @@ struct cmb_batch {
     DevBuf<uint32_t> G;
     DevBuf<DevStrategyK> strat;
     DevBuf<Scratch> slabs;
-    DevBuf<Scratch2> slabs2;
-    DevBuf<uint32_t> dfsKeysA, dfsKeysB, dfsIdxA, dfsIdxB;
     // frontier search (dev_bfs_edit.hpp): node / event double buffers, F records, contexts, list arena
     DevBuf<uint4> bfsQ[2], bfsEv[2], bfsF, bfsC, bfsA;
     DevBuf<uint32_t> bfsCnt;               // nq[passes], ne[passes], pool[4]
@@ -303,6 +301,8 @@ struct cmb_batch {
     DevBuf<uint8_t> sortTmp, scanTmp;
     DevBuf<unsigned long long> vkeysA, vkeysB; // verification keys (k_verify) / sorted, then distinct
     DevBuf<uint32_t> vcounts, vruns;           // multiplicities of the distinct keys / number of runs
+    DevBuf<uint4> vsA[2], vsB[2];              // staged verification: survivor lists (ping-pong)
+    DevBuf<uint32_t> vsC[2], vsN;
     DevBuf<uint32_t> cnt;
     DevBuf<unsigned long long> counters;
     uint32_t nSlots = 0;
@@ -512,7 +512,7 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                 const uint32_t slotCap = getenv("CMB_DFS_SLOTS") ? (uint32_t)atoi(getenv("CMB_DFS_SLOTS")) : 256u * 512u;
                 const uint32_t want = std::min<uint32_t>(((nDfs + 255) / 256) * 256, slotCap);
                 tm.begin();
-                if (b->metric == CMB_METRIC_EDIT && !getenv("CMB_OLD_DFS")) {
+                if (b->metric == CMB_METRIC_EDIT) {
                     // ---- frontier search: start pass, then (expand, events) per level until both queues drain
                     const uint32_t maxPass = 2 * b->maxLen + 8 * MAXP + 64;
                     if (!b->bfsQCap) {
@@ -596,37 +596,6 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                     }
                     if (!drained && !(hcnt[3] & BFS_STOP))
                         return fail(CMB_ERR_INTERNAL, "frontier search did not finish within its pass bound");
-                } else if (b->metric == CMB_METRIC_EDIT) {
-                    if (b->slabs2.n < want) b->slabs2.alloc(want);
-                    if (b->dfsKeysA.n < nDfs) {
-                        b->dfsKeysA.alloc((size_t)nDfs + 1024);
-                        b->dfsKeysB.alloc((size_t)nDfs + 1024);
-                        b->dfsIdxA.alloc((size_t)nDfs + 1024);
-                        b->dfsIdxB.alloc((size_t)nDfs + 1024);
-                    }
-                    // Widest start ranges (largest subtrees) first — but spread: lane l of wavefront w starts
-                    // with the (l * W + w)-th largest task, so every wavefront gets one task of each size class
-                    // and the longest tasks all start at time zero; the rest is fetched through a counter.
-                    hipLaunchKernelGGL(k_dfs_keys, dim3((nDfs + 255) / 256), dim3(256), 0, s, b->dfs.p, nDfs,
-                                       b->dfsKeysA.p, b->dfsIdxA.p);
-                    size_t tmpBytes = 0;
-                    HIPCHK(rocprim::radix_sort_pairs(nullptr, tmpBytes, b->dfsKeysA.p, b->dfsKeysB.p, b->dfsIdxA.p,
-                                                     b->dfsIdxB.p, nDfs, 0, 32, s));
-                    if (b->sortTmp.n < tmpBytes) b->sortTmp.alloc(tmpBytes + 256);
-                    HIPCHK(rocprim::radix_sort_pairs(b->sortTmp.p, tmpBytes, b->dfsKeysA.p, b->dfsKeysB.p, b->dfsIdxA.p,
-                                                     b->dfsIdxB.p, nDfs, 0, 32, s));
-                    DfsQueue dq;
-                    dq.tasks = b->dfs.p;
-                    dq.order = b->dfsIdxB.p;
-                    dq.live = nDfs;
-                    dq.nStatic = std::min<uint32_t>(want, nDfs);
-                    dq.tSplit = getenv("CMB_TSPLIT") ? (uint32_t)atoi(getenv("CMB_TSPLIT")) : 128u;
-                    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&b->cnt.p[6], (int)dq.nStatic, 1, s));
-                    // final-column cluster cells per phase: Wh + Wv + 1 <= 3 k + 1 (search.h bounds U by k)
-                    const uint32_t clCells = std::min<uint32_t>(CL_MAX, 3 * b->k + 2);
-                    const uint32_t dfsLds = b->hostStrat.numParts * clCells * 64;
-                    hipLaunchKernelGGL(k_dfs_edit, dim3(want / 64), dim3(64), dfsLds, s, ix->d, b->strat.p, b->offs.p,
-                                       b->maxLen, b->gw, b->G.p, b->parts.p, dq, b->slabs2.p, clCells, q);
                 } else {
                     if (b->slabs.n < want) b->slabs.alloc(want);
                     hipLaunchKernelGGL(k_dfs_hamming, dim3(want / 256), dim3(256), 0, s, ix->d, b->strat.p, b->offs.p,
@@ -698,7 +667,7 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                 // one read seeding the same alignment) are performed once: k_verify only locates and emits a key per
                 // candidate, the keys are sorted and run-length encoded, k_verify_edit verifies the distinct ones and
                 // scales the counters by the multiplicities.
-                const bool dedup = b->metric == CMB_METRIC_EDIT && b->k > 0 && b->k <= 7 && 2ull * nReads <= (1ull << 24);
+                const bool dedup = b->metric == CMB_METRIC_EDIT && b->k > 0 && b->k <= 7 && 2ull * nReads <= (1ull << 25); // 25 key bits for read x strand
                 const uint32_t tbCap = (uint32_t)std::min<size_t>(b->tbq.n, 0xFFFFFFF0u);
                 tm.begin();
                 if (dedup && b->vkeysA.n < nItems) {
@@ -726,9 +695,35 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                     HIPCHK(hipStreamSynchronize(s));
                     if (getenv("CMB_VERBOSE")) fprintf(stderr, "[verify] %u items, %u distinct keys\n", nItems, nRuns);
                     if (nRuns) {
-                        const uint32_t eSlots = std::min<uint32_t>(((nRuns + 255) / 256) * 256, 256u * 2048u);
-                        hipLaunchKernelGGL(k_verify_edit, dim3(eSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->gw,
-                                           b->G.p, b->vkeysA.p, b->vcounts.p, nRuns, b->tbq.p, tbCap, q);
+                        // staged verification (kernels.hpp: k_verify_stage): one launch per 32-row matrix block,
+                        // survivor lists ping-pong, list sizes stay on the device
+                        const uint32_t nStages = ((uint32_t)VROWS + 31u) / 32u + 1u;
+                        for (int j = 0; j < 2; j++)
+                            if (b->vsC[j].n < nRuns) {
+                                b->vsA[j].alloc((size_t)nRuns + nRuns / 8 + 256);
+                                b->vsB[j].alloc(b->vsA[j].n);
+                                b->vsC[j].alloc(b->vsA[j].n);
+                            }
+                        if (b->vsN.n < nStages + 2) b->vsN.alloc(nStages + 2);
+                        HIPCHK(hipMemsetAsync(b->vsN.p, 0, (nStages + 2) * sizeof(uint32_t), s));
+                        const uint32_t listCap = (uint32_t)std::min<size_t>(b->vsC[0].n, 0xFFFFFFF0u);
+                        const uint32_t grid = std::min<uint32_t>((nRuns + 255) / 256, 8192u);
+                        VStageList L0{b->vsA[0].p, b->vsB[0].p, b->vsC[0].p}, L1{b->vsA[1].p, b->vsB[1].p, b->vsC[1].p};
+                        hipLaunchKernelGGL(k_verify_stage<true>, dim3(grid), dim3(256), 0, s, ix->d, b->offs.p, b->gw, b->G.p,
+                                           b->vkeysA.p, b->vcounts.p, nRuns, L0, L1, b->vsN.p, listCap, 0u, b->tbq.p, tbCap, q);
+                        for (uint32_t st = 1; st < nStages; st++)
+                            hipLaunchKernelGGL(k_verify_stage<false>, dim3(grid), dim3(256), 0, s, ix->d, b->offs.p, b->gw,
+                                               b->G.p, (const unsigned long long*)nullptr, (const uint32_t*)nullptr, 0u,
+                                               (st & 1u) ? L1 : L0, (st & 1u) ? L0 : L1, b->vsN.p, listCap, st, b->tbq.p, tbCap,
+                                               q);
+                        if (verbose) {
+                            std::vector<uint32_t> hn(nStages + 2);
+                            HIPCHK(hipMemcpyAsync(hn.data(), b->vsN.p, hn.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                            HIPCHK(hipStreamSynchronize(s));
+                            fprintf(stderr, "[verify] survivors per stage:");
+                            for (uint32_t st = 1; st <= nStages; st++) fprintf(stderr, " %u", hn[st]);
+                            fprintf(stderr, "\n");
+                        }
                     }
                 }
                 tm.end("k_verify");

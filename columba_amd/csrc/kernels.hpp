@@ -10,7 +10,7 @@
 //                                                       indexhelpers.cpp:518-574, indexinterface.cpp:918-943
 //   k_fmocc       in-index occurrence -> text positions indexinterface.cpp:1385-1440, :1349-1366
 #pragma once
-#include "dev_dfs_edit.hpp"
+#include "dev_partition.hpp"
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -507,94 +507,8 @@ k_exact(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
     if (flags) atomicOr(&q.cnt[3], flags);
 }
 
-// ------------------------------------------------------------------ approximate DFS over the scheme
-
-// sort key of a DFS task: wide start ranges (big subtrees) first, so that the long tasks start first and
-// the 64 tasks a wavefront fetches together have similar sizes
-__global__ void k_dfs_keys(const DfsTask* __restrict__ tasks, uint32_t n, uint32_t* __restrict__ keys,
-                           uint32_t* __restrict__ idx) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    keys[i] = tasks[i].rsId == 0xFFFFFFFFu ? 0xFFFFFFFFu : ~tasks[i].r.sa.width(); // holes last
-    idx[i] = i;
-}
-
-// Edit distance: one lane per DfsTask, one wavefront per block (dev_dfs_edit.hpp).
-__global__ void __launch_bounds__(64)
-k_dfs_edit(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* __restrict__ offs, uint32_t maxLen,
-           uint32_t gw, const uint32_t* __restrict__ G, const PartOut* __restrict__ parts, DfsQueue dq,
-           Scratch2* __restrict__ slabs, uint32_t clCells, Queues q) {
-    extern __shared__ uint8_t clEd[]; // [numParts][clCells][64] final-column edit distances (MatrixMetaInfo)
-    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
-    EditDfs d(ix, *stp, slabs[slot], q, clEd, clCells, threadIdx.x);
-    d.gw = gw;
-    const uint32_t laneId = threadIdx.x & 63u;
-    __shared__ uint8_t donMap[64 * DON_MAX]; // rank of an offered child -> donor lane << 2 | item
-    WaveChunk chI;
-    bool ovI = false;
-    auto holeI = [&](uint32_t i) { q.items[i] = make_uint4(0xFFFFFFFFu, 0, 0, 0); };
-    for (;;) {
-        // helpers: lanes without work once the original tasks are exhausted
-        const bool helper = d.pend == PEND_FETCH && d.origDone && d.claim == 0xFFFFFFFFu;
-        const uint64_t helpMask = __ballot(helper);
-        // (1) EXPAND: rank loads + children rows + pushes, for every lane with a pending parent
-        if (d.req) d.expand(dq, helpMask != 0ull);
-        // (2) STEP: pop / replay one node and classify it
-        if (d.pend == PEND_NONE) d.step();
-        // (3) staged in-text work items go to the wavefront's chunk of the item queue
-        if (__ballot(d.stN > 0) != 0ull) {
-            const uint32_t o = chI.alloc(&q.cnt[0], q.itemCap, d.stN, 256u, ovI, holeI);
-            if (d.stN && o != 0xFFFFFFFFu)
-                for (uint32_t j = 0; j < d.stN; j++) q.items[o + j] = make_uint4(d.rsId, d.stB + j, d.stA, d.stMeta);
-            d.stN = 0;
-        }
-        // (4) the long, rare paths (goDeeper, phase entry/exit, next task) of the lanes that need one
-        if (d.pend != PEND_NONE && !helper) d.heavy(dq, parts, offs, G);
-        // (5) match the children offered in this iteration to the helpers of the wavefront
-        if (__ballot(d.nDon > 0) != 0ull) {
-            // the staged entries were written by other lanes: complete the stores, drop stale L1 lines
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-            uint32_t total;
-            const uint32_t off = waveExclusiveScan(d.nDon, total);
-            for (uint32_t t = 0; t < d.nDon; t++) donMap[off + t] = (uint8_t)((laneId << 2) | t);
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t nHelp = (uint32_t)__popcll(helpMask);
-            if (helper) {
-                const uint32_t rank = (uint32_t)__popcll(helpMask & ((1ull << laneId) - 1ull));
-                if (rank < total) { // take child `rank`
-                    const uint32_t m = donMap[rank];
-                    d.receive(slabs[blockIdx.x * 64 + (m >> 2)], m & 3u);
-                }
-            }
-            // the donors' task indices travel by shuffle (all lanes participate)
-            {
-                const uint32_t rank = (uint32_t)__popcll(helpMask & ((1ull << laneId) - 1ull));
-                const uint32_t m = (helper && rank < total) ? donMap[rank] : 0u;
-                const uint32_t task = __shfl(d.curTask, (int)(m >> 2));
-                if (helper && rank < total) d.claim = task;
-            }
-            // what no helper took goes back on the donor's stack
-            for (uint32_t t = 0; t < d.nDon; t++)
-                if (off + t >= nHelp) {
-                    if (d.H.stackTop >= (uint32_t)STACK2_MAX) d.flags |= FLAG_CAPACITY;
-                    else {
-                        const SEntry e = d.S.don[t];
-                        d.S.stack[d.H.stackTop++] = e;
-                    }
-                }
-            d.nDon = 0;
-            __builtin_amdgcn_wave_barrier();
-        }
-        // every lane a helper and nothing offered: the wavefront is done
-        if (helpMask == ~0ull) break;
-    }
-    chI.fill(holeI);
-    if (ovI) d.flags |= FLAG_ITEM_OVERFLOW;
-    const uint32_t local[4] = {d.cNode, d.cExp, d.cRows, d.cExp};
-    const int which[4] = {0, 7, 11, 12};
-    flushCounters(q, local, which, 4);
-    if (d.flags) atomicOr(&q.cnt[3], d.flags);
-}
+// ------------------------------------------------------------------ approximate search over the scheme
+// (edit distance: the frontier kernels of dev_bfs_edit.hpp, included above)
 
 // Hamming distance: one lane per DfsTask (recApproxMatchHamming, indexinterface.cpp:1211-1304)
 __global__ void __launch_bounds__(256)
@@ -921,37 +835,169 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
     if (flags) atomicOr(&q.cnt[3], flags);
 }
 
-// pass 1b: the distinct edit-distance verifications (sorted + run-length encoded keys of k_verify)
+// pass 1b: the distinct edit-distance verifications (sorted + run-length encoded keys of k_verify), in STAGES
+// of one 32-row matrix block each.  FMIndex::inTextVerification + InTextVerificationTask::doTask
+// (fmindex.cpp:267-310, indexhelpers.cpp:518-574) abandon most candidates after a few dozen rows while the true
+// locations run all len + 3k rows; with one candidate per lane from start to end, a wavefront is as slow as its
+// longest candidate (measured: 38 % of the lanes busy).  So stage s computes rows 32 s .. 32 s + 31 (stage 0:
+// rows 1 .. 31) of every candidate that is still alive, in lock step, and appends the survivors — 36 bytes of
+// row state each — to the work list of stage s + 1: every stage runs on a dense list.  A stage needs exactly two
+// 16-byte text chunks and ONE set of match words (rows 32 s .. 32 s + 31 share matrix block s), fetched up front.
+struct VStageList { // survivors entering a stage
+    uint4* a;       // {key lo, key hi, multiplicity | score << 24, centre mask}
+    uint4* b;       // {HP, HN}
+    uint32_t* c;    // len | RAC bit << 16 | edPrev << 22 | edPrev2 << 27
+};
+
+template <bool FIRST>
 __global__ void __launch_bounds__(256)
-k_verify_edit(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const uint32_t* __restrict__ G,
-              const unsigned long long* __restrict__ ukeys, const uint32_t* __restrict__ counts, uint32_t nKeys,
-              uint4* __restrict__ tbq, uint32_t tbCap, Queues q) {
+k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const uint32_t* __restrict__ G,
+               const unsigned long long* __restrict__ ukeys, const uint32_t* __restrict__ counts, uint32_t nKeys,
+               VStageList in, VStageList out, uint32_t* __restrict__ nList, uint32_t listCap, uint32_t stage,
+               uint4* __restrict__ tbq, uint32_t tbCap, Queues q) {
     __shared__ uint64_t Ml[ML_WORDS];
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t cText = 0, cRows = 0, cAbort = 0, cCig = 0, cStarted = 0, flags = 0;
-    WaveChunk chB;
-    bool ovB = false;
-    auto holeB = [&](uint32_t i) { tbq[i] = make_uint4(0, 0, 0, 0); };
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t waveBase = slot & ~63u;
-    for (uint32_t base = waveBase; base < nKeys; base += stride) { // wave-uniform trip count
-        const uint32_t it = base + (threadIdx.x & 63u);
+    __shared__ uint32_t sh[2][5];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nIn = FIRST ? nKeys : min(nList[stage], listCap);
+    uint32_t cText = 0, cAbort = 0, cCig = 0, cStarted = 0, flags = 0;
+    Ml[4 * 256 + tid] = 0ull; // text code 4 ('$', padding): matches nothing
+    const uint32_t r0 = FIRST ? 1u : 32u * stage; // first row of this stage
+    const uint32_t nRows = FIRST ? 31u : 32u;
+    for (uint32_t base = blockIdx.x * 256u; base < nIn; base += gridDim.x * 256u) { // block-uniform trip count
+        const uint32_t it = base + tid;
+        bool alive = false;
+        unsigned long long key = ~0ull;
+        uint32_t mult = 0, len = 0, score = 0, mask = 0, edPrev = 0, edPrev2 = 0;
+        uint64_t HP = 0, HN = 0, RAC = 0;
+        if (it < nIn) {
+            if (FIRST) {
+                key = ukeys[it];
+                if (key != ~0ull) { // (~0: the run of non-edit items and holes)
+                    mult = min(counts[it], 0xFFFFFFu);
+                    const uint32_t rs = (uint32_t)(key >> 39);
+                    len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
+                    cStarted += mult;
+                }
+            } else {
+                const uint4 ra = in.a[it], rb = in.b[it];
+                const uint32_t rc = in.c[it];
+                key = (unsigned long long)ra.x | ((unsigned long long)ra.y << 32);
+                mult = ra.z & 0xFFFFFFu;
+                score = ra.z >> 24;
+                mask = ra.w;
+                HP = (uint64_t)rb.x | ((uint64_t)rb.y << 32);
+                HN = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
+                len = rc & 0xFFFFu;
+                RAC = 1ull << ((rc >> 16) & 63u);
+                edPrev = (rc >> 22) & 31u;
+                edPrev2 = (rc >> 27) & 31u;
+            }
+        }
+        const uint32_t rs = (uint32_t)(key >> 39), start = (uint32_t)(key >> 7);
+        const uint32_t maxED = (uint32_t)(key >> 4) & 7u, minED = (uint32_t)(key >> 1) & 7u, fixed = (uint32_t)key & 1u;
+        const uint32_t nZeros = fixed ? 1u : 2u * maxED + 1u;
+        MatGeom g;
+        g.n = len + 1;
+        g.maxED = maxED;
+        g.Wv = nZeros - 1 + maxED;
+        g.Wh = maxED;
+        g.m = g.Wv + g.n;
+        const uint32_t sfc = g.sfc();
+        const uint32_t firstRow = (g.m - 1) - sfc;
+        const uint32_t col = g.n - 1;
+        uint32_t size = 0;
+        if (key != ~0ull) {
+            const uint32_t maxEnd = ix.n - 1;
+            const uint32_t hEnd = min(maxEnd, start + g.m - 1);
+            size = hEnd > start ? hEnd - start : 0;
+            alive = g.inFinalColumn(size); // indexhelpers.cpp:527 (candidates that cannot reach it do nothing)
+            if (FIRST && alive) {
+                HP = (~0ull) << MX_LEFT;
+                HN = (1ull << (MX_LEFT + 1u - nZeros)) - 1ull; // first column: nZeros zeros, then 1, 2, ...
+                RAC = 1ull << (MX_DIAG + g.Wh);
+                if (firstRow == 0) edPrev = cellAt(0, col, HP, HN, 0);
+            }
+        }
+        uint32_t i = r0 - 1; // rows done so far
+        uint32_t rows = 0;
+        bool ended = false;
+        uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0;
+        if (alive) {
+            const uint8_t* tp = ix.text + start + (r0 - 1); // text character of row r is text[start + r - 1]
+            t0 = loadText16(tp);
+            t1 = loadText16(tp + 16); // the text allocation is padded
+            const uint32_t* Gf = G + (size_t)rs * 8 * gw;
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) Ml[ch * 256 + tid] = matchWord(Gf + ch * gw, 0, len, stage);
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < 32; t++) {
+            if (t >= nRows) break;
+            const uint32_t r = r0 + t;
+            const uint32_t wsel = (t >> 2) & 3u;
+            const uint4 tw = t < 16 ? t0 : t1;
+            const uint32_t wv = wsel == 0 ? tw.x : wsel == 1 ? tw.y : wsel == 2 ? tw.z : tw.w;
+            const uint32_t tc = (wv >> (8 * (t & 3u))) & 0xFFu;
+            if (alive) {
+                const uint64_t M = Ml[tc * 256 + tid];
+                rows++;
+                uint64_t D0;
+                const bool valid = computeRow(g, r, M, HP, HN, D0, RAC, score);
+                if (!valid) {
+                    alive = false;
+                    ended = true;
+                } else {
+                    if (r >= firstRow) {
+                        const uint32_t ed = min(cellAt(r, col, HP, HN, score), 31u);
+                        if (r - 1 > firstRow) { // row r-1 can now be judged (its `below` neighbour is known)
+                            const uint32_t e1 = edPrev;
+                            if (e1 <= maxED && e1 >= minED && e1 <= edPrev2 && e1 <= ed) mask |= 1u << (r - 2 - firstRow);
+                        }
+                        edPrev2 = edPrev;
+                        edPrev = ed;
+                    }
+                    i++;
+                    if (i >= size) {
+                        alive = false;
+                        ended = true;
+                    }
+                }
+            }
+        }
+        cText += rows * mult;
         uint32_t nTb = 0;
         uint4 tbRec = make_uint4(0, 0, 0, 0);
-        unsigned long long key = ~0ull;
-        if (it < nKeys) key = ukeys[it];
-        if (key != ~0ull) { // (~0: the run of non-edit items and holes)
-            const uint32_t mult = min(counts[it], 0xFFFFFFu);
-            if (verifyEdit(ix, offs, gw, G, (uint32_t)(key >> 39), (uint32_t)(key >> 7), (uint32_t)(key >> 4) & 7u,
-                           (uint32_t)(key >> 1) & 7u, (uint32_t)key & 1u, mult, cStarted, cRows, cText, cAbort, cCig, tbRec, Ml))
+        if (ended) {
+            if (i > firstRow) { // the last valid row has no `below` neighbour
+                const uint32_t e1 = edPrev;
+                if (e1 <= maxED && e1 >= minED && e1 <= edPrev2) mask |= 1u << (i - 1 - firstRow);
+            }
+            if (i <= size - sfc || mask == 0) { // indexhelpers.cpp:542, :550
+                cAbort += mult;
+            } else {
+                cCig += (uint32_t)__popc(mask) * mult; // = positions the traceback will report
+                tbRec = make_uint4(rs, start, mask, maxED | (fixed << 4));
                 nTb = 1;
+            }
         }
-        const uint32_t o2 = chB.alloc(&q.cnt[7], tbCap, nTb, 256u, ovB, holeB);
-        if (nTb && o2 != 0xFFFFFFFFu) tbq[o2] = tbRec;
+        uint32_t tA, tB;
+        const uint32_t oS = blockAppend(&nList[stage + 1], alive ? 1u : 0u, sh[0], tA);
+        const uint32_t oT = blockAppend(&q.cnt[7], nTb, sh[1], tB);
+        if (alive) {
+            if (oS >= listCap) flags |= FLAG_CAPACITY; // (sized for every candidate)
+            else {
+                if (score > 255u) flags |= FLAG_CAPACITY;
+                out.a[oS] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), mult | (score << 24), mask);
+                out.b[oS] = make_uint4((uint32_t)HP, (uint32_t)(HP >> 32), (uint32_t)HN, (uint32_t)(HN >> 32));
+                out.c[oS] = len | ((uint32_t)(__ffsll((unsigned long long)RAC) - 1) << 16) | (edPrev << 22) | (edPrev2 << 27);
+            }
+        }
+        if (nTb) {
+            if (oT >= tbCap) flags |= FLAG_CAPACITY;
+            else tbq[oT] = tbRec;
+        }
     }
-    chB.fill(holeB);
-    if (ovB) flags |= FLAG_CAPACITY;
-    const uint32_t local[6] = {cText, cRows, cAbort, cCig, cStarted, cCig};
+    const uint32_t local[6] = {cText, cText, cAbort, cCig, cStarted, cCig};
     const int which[6] = {10, 11, 3, 4, 2, 1}; // (every centre is reported once: TOTAL_REPORTED += CIGARS)
     flushCounters(q, local, which, 6);
     if (flags) atomicOr(&q.cnt[3], flags);
