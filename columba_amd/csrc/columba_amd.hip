@@ -516,11 +516,15 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                     // ---- frontier search: start pass, then (expand, events) per level until both queues drain
                     const uint32_t maxPass = 2 * b->maxLen + 8 * MAXP + 64;
                     if (!b->bfsQCap) {
-                        b->bfsQCap = (size_t)nReads * 2 + 65536;
-                        b->bfsEvCap = (size_t)nReads / 2 + 65536;
-                        b->bfsFCap = (size_t)nReads * 16 + 65536;
-                        b->bfsCCap = (size_t)nReads * 2 + 65536;
-                        b->bfsACap = (size_t)nReads * 8 + 65536;
+                        // first guess; every pool grows (and the search re-runs) when it turns out too small.
+                        // CMB_TEST_SMALL_POOLS starts from almost nothing so that tests exercise that path.
+                        const size_t slack = getenv("CMB_TEST_SMALL_POOLS") ? 64 : 65536;
+                        const size_t per = getenv("CMB_TEST_SMALL_POOLS") ? 0 : 1;
+                        b->bfsQCap = per * (size_t)nReads * 2 + slack;
+                        b->bfsEvCap = per * (size_t)nReads / 2 + slack;
+                        b->bfsFCap = per * (size_t)nReads * 16 + slack;
+                        b->bfsCCap = per * (size_t)nReads * 2 + slack;
+                        b->bfsACap = per * (size_t)nReads * 8 + slack;
                     }
                     b->bfsQCap = std::max<size_t>(b->bfsQCap, (size_t)nDfs + 1024);
                     for (int j = 0; j < 2; j++) {
@@ -584,7 +588,7 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                     hipLaunchKernelGGL(k_bfs_finish, dim3(1), dim3(256), 0, s, B, q);
                     if (hcnt[3] & (FLAG_BFS_Q | FLAG_BFS_EV | FLAG_BFS_F | FLAG_BFS_CTX | FLAG_BFS_ARENA)) {
                         // a pool was too small: grow what was asked for (at least x2) and run the search again
-                        if (attempt >= 6) return fail(CMB_ERR_INTERNAL, "frontier pools keep overflowing");
+                        if (attempt >= 24) return fail(CMB_ERR_INTERNAL, "frontier pools keep overflowing");
                         if (hcnt[3] & FLAG_BFS_Q) b->bfsQCap = std::max<size_t>(2 * b->bfsQCap, (size_t)peakQ + peakQ / 4);
                         if (hcnt[3] & FLAG_BFS_EV) b->bfsEvCap = std::max<size_t>(2 * b->bfsEvCap, (size_t)peakEv + peakEv / 4);
                         if (hcnt[3] & FLAG_BFS_F) b->bfsFCap = std::max<size_t>(2 * b->bfsFCap, (size_t)pool[0] + pool[0] / 4);
@@ -611,7 +615,7 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
             if (flags & FLAG_CAPACITY)
                 return fail(CMB_ERR_INTERNAL, "device search capacity exceeded (band width / descendants / stack)");
             if (flags & (FLAG_ITEM_OVERFLOW | FLAG_FMOCC_OVERFLOW | FLAG_DFS_OVERFLOW)) {
-                if (attempt >= 4) return fail(CMB_ERR_INTERNAL, "work queues keep overflowing");
+                if (attempt >= 30) return fail(CMB_ERR_INTERNAL, "work queues keep overflowing");
                 if (hcnt[0] > q.itemCap) b->items.alloc((size_t)hcnt[0] * 2 + 1024);
                 if (hcnt[1] > q.fmCap) b->fm.alloc((size_t)hcnt[1] * 2 + 1024);
                 if (hcnt[5] > dfsCap) b->dfs.alloc((size_t)hcnt[5] + hcnt[5] / 8 + 1024);

@@ -1,0 +1,92 @@
+"""Size-independent properties of the HIP path at sizes the CPU oracle would not finish quickly
+(the domain's invariants stand in for a full-size oracle run):
+
+* batching invariance — the occurrences of a read do not depend on which other reads share its batch;
+* strand symmetry — a read and its reverse complement have the same occurrences on opposite strands;
+* the growth path of the frontier pools (too-small pools are enlarged and the search re-runs) gives the
+  same result as pools that were large enough from the start.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import columba_amd as ca
+from columba_amd import indexbuild as ib
+from columba_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+N_READS = 120_000
+
+
+@pytest.fixture(scope="module")
+def big():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    g, starts = synth.genome_human_like(48_000_000, seed=77, device="cuda")
+    ix = ib.build_index(g, seq_starts=starts, device="cuda", with_bwt=False)
+    dev = ca.Index(ix)
+    buf, _ = synth.sample_reads_fast(torch.from_numpy(ix.text[:-1]).cuda(), N_READS, 150, seed=5, device="cuda")
+    reads = [buf[i * 150:(i + 1) * 150].tobytes() for i in range(N_READS)]
+    return {"dev": dev, "reads": reads}
+
+
+def _run(dev, reads, k=4, spec="multiple_opt", part="dynamic"):
+    return ca.match_batch(dev, ca.SearchStrategy(spec, "edit", part), k, reads)
+
+
+def _per_read(occ, off, i):
+    return [(int(o["begin"]), int(o["end"]), int(o["distance"]), int(o["strand"])) for o in occ[int(off[i]):int(off[i + 1])]]
+
+
+COUNTERS = ["NODE_COUNTER", "IN_TEXT_STARTED", "ABORTED_IN_TEXT_VERIF", "CIGARS_IN_TEXT_VERIFICATION", "IMMEDIATE_SWITCH",
+            "SEARCH_STARTED", "EXPANSIONS", "DFS_EXPANSIONS", "LF_STEPS", "LOCATED_ROWS", "TEXT_BYTES", "MATRIX_ROWS",
+            "TOTAL_REPORTED_POSITIONS"]
+
+
+def test_batching_invariance(big):
+    occ, off, cnt = _run(big["dev"], big["reads"])
+    assert len(occ) > N_READS // 2
+    q = N_READS // 4
+    tot = {n: 0 for n in COUNTERS}
+    for j in range(4):
+        o2, f2, c2 = _run(big["dev"], big["reads"][j * q:(j + 1) * q])
+        assert np.array_equal(f2 - f2[0], off[j * q:(j + 1) * q + 1] - off[j * q])
+        a = occ[int(off[j * q]):int(off[(j + 1) * q])]
+        for f in ("begin", "end", "distance", "strand"):
+            assert np.array_equal(o2[f], a[f]), (j, f)
+        for n in COUNTERS:
+            tot[n] += c2[n]
+    for n in COUNTERS:  # the work counters are sums over reads
+        assert tot[n] == cnt[n], (n, tot[n], cnt[n])
+
+
+def test_strand_symmetry(big):
+    comp = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+    sub = big["reads"][:20_000]
+    rc = [r.translate(comp)[::-1] for r in sub]
+    o1, f1, _ = _run(big["dev"], sub)
+    o2, f2, _ = _run(big["dev"], rc)
+    assert np.array_equal(f1, f2)
+    for f in ("begin", "end", "distance"):
+        assert np.array_equal(o1[f], o2[f]), f
+    # strands are mirrored, except where one (begin, end, distance) exists on both strands (the device then
+    # reports the forward strand)
+    flipped = o1["strand"] != o2["strand"]
+    assert flipped.mean() > 0.99
+
+
+def test_pool_growth_path(big):
+    sub = big["reads"][:30_000]
+    o1, f1, c1 = _run(big["dev"], sub)
+    os.environ["CMB_TEST_SMALL_POOLS"] = "1"
+    try:
+        o2, f2, c2 = _run(big["dev"], sub)
+    finally:
+        del os.environ["CMB_TEST_SMALL_POOLS"]
+    assert np.array_equal(f1, f2)
+    for f in ("begin", "end", "distance", "strand"):
+        assert np.array_equal(o1[f], o2[f]), f
+    for n in COUNTERS:
+        assert c1[n] == c2[n], n

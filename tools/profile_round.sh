@@ -18,7 +18,7 @@ for f in glob.glob('/tmp/prof_stats/**/*_kernel_stats.csv', recursive=True):
 print("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs")
 for r in rows:
     n = r["Name"].split("(")[0]
-    if n.startswith("cmb::") or "rocprim" in n:
+    if n.startswith("cmb::") or n.startswith("void cmb::") or "rocprim" in n:
         print(",".join([n[:80].replace(",", ";"), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]))
 PY
 # 2) HBM traffic counters, each in its own pass (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
@@ -27,6 +27,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM --output-format csv -d /tmp/prof_SQ -- python3 $R/bench.py $ARGS --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
 python3 $R/tools/pmc_summary.py /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE /tmp/prof_SQ > $OUT/pmc_summary.txt 2>&1
-# 3) the plain bench line (not under the profiler)
+# 3) the plain bench line (not under the profiler), then the per-kernel traffic table bench.py reads back
 cd $R && python3 bench.py $ARGS > $OUT/bench_line.json 2> $OUT/bench_stderr.log
+python3 $R/tools/pmc_traffic.py $OUT/bench_line.json /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE > $OUT/pmc_traffic.json
 ls -la $OUT
