@@ -346,6 +346,9 @@ extern "C" int cmb_batch_create(cmb_index* idx, const cmb_strategy* st, uint32_t
         }
         if (maxLen > (uint32_t)MAX_READ)
             return fail(CMB_ERR_UNSUPPORTED, "reads longer than " + std::to_string(MAX_READ) + " are not supported");
+        // rows of per-read arrays are padded to a multiple of 16 bytes (16-byte stores in k_prep); the number of
+        // 32-character words per read does not change
+        maxLen = (maxLen + 15u) & ~15u;
         b->maxLen = maxLen;
         b->gw = gWords(maxLen);
         b->hostOffs.assign(offs, offs + n_reads + 1);
@@ -1009,7 +1012,8 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         if (starts[i] > idx->d.n) return fail(CMB_ERR_INVALID, "start position beyond the text");
     try {
         useDevice(idx->device);
-        const uint32_t gw = gWords(plen);
+        const uint32_t mlen = (plen + 15u) & ~15u; // row stride of the per-read arrays (k_prep stores 16 bytes)
+        const uint32_t gw = gWords(mlen);
         DevBuf<uint8_t> reads, seq;
         DevBuf<uint64_t> offs;
         DevBuf<uint32_t> G, cnt;
@@ -1021,7 +1025,7 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         const uint64_t ho[2] = {0, plen};
         reads.upload((const uint8_t*)pattern, plen);
         offs.upload(ho, 2);
-        seq.alloc(2 * (size_t)plen);
+        seq.alloc(2 * (size_t)mlen);
         G.alloc(2 * 8 * (size_t)gw);
         std::vector<uint4> hi(n);
         const uint32_t meta = (max_ed << 12) | (min_ed << 16) | ((fixed_start ? 1u : 0u) << 20) |
@@ -1045,11 +1049,11 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         q.cnt = cnt.p;
         q.counters = ctr.p;
         HIPCHK(hipMemset(G.p, 0, G.bytes()));
-        hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, 0, reads.p, offs.p, 1u, plen, gw, (plen + 31) / 32, seq.p,
+        hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, 0, reads.p, offs.p, 1u, mlen, gw, (mlen + 31) / 32, seq.p,
                            G.p, (uint32_t*)nullptr, 0u);
         uint32_t hc[8];
         if (n) {
-            hipLaunchKernelGGL(k_verify, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, plen, gw, seq.p, G.p,
+            hipLaunchKernelGGL(k_verify, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, mlen, gw, seq.p, G.p,
                                items.p, (uint32_t)n, tbq.p, (uint32_t)tbq.n, (unsigned long long*)nullptr, q);
             HIPCHK(hipMemcpy(hc, cnt.p, 32, hipMemcpyDeviceToHost));
             if (hc[7])

@@ -135,16 +135,32 @@ k_prep(const uint8_t* __restrict__ reads, const uint64_t* __restrict__ offs, uin
     uint8_t* sF = seq + (size_t)(2 * r) * maxLen;
     uint8_t* sR = seq + (size_t)(2 * r + 1) * maxLen;
     const uint32_t nT = min(32u, len - 32 * w);
-    for (uint32_t t = 0; t < nT; t++) {
-        const uint32_t i = 32 * w + t;
-        // reads.h:43-58 (upper-case, non-ACGT -> N); nucleotide.h:250 (reverse complement keeps N)
-        const uint8_t a = rd[i] & 0xDF, bch = rd[len - 1 - i] & 0xDF;
-        const uint32_t ca = a == 'A' ? 1 : a == 'C' ? 2 : a == 'G' ? 3 : a == 'T' ? 4 : 5;
-        const uint32_t cb = bch == 'A' ? 1 : bch == 'C' ? 2 : bch == 'G' ? 3 : bch == 'T' ? 4 : 5;
-        sF[i] = (uint8_t)ca;
-        sR[i] = (uint8_t)(cb <= 4 ? 5 - cb : 5);
-        if (ca <= 4) fA[ca - 1] |= 1u << t;
-        if (cb <= 4) fB[cb - 1] |= 1u << t;
+    // the 32 codes of both strands are collected in registers and written as two 16-byte stores each (maxLen
+    // is a multiple of 16): single-byte stores cost a partial-line write each
+    uint32_t cF[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cR[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t t = 0; t < 32; t++) {
+        if (t < nT) {
+            const uint32_t i = 32 * w + t;
+            // reads.h:43-58 (upper-case, non-ACGT -> N); nucleotide.h:250 (reverse complement keeps N)
+            const uint8_t a = rd[i] & 0xDF, bch = rd[len - 1 - i] & 0xDF;
+            const uint32_t ca = a == 'A' ? 1 : a == 'C' ? 2 : a == 'G' ? 3 : a == 'T' ? 4 : 5;
+            const uint32_t cb = bch == 'A' ? 1 : bch == 'C' ? 2 : bch == 'G' ? 3 : bch == 'T' ? 4 : 5;
+            cF[t >> 2] |= ca << (8 * (t & 3u));
+            cR[t >> 2] |= (cb <= 4 ? 5 - cb : 5) << (8 * (t & 3u));
+            if (ca <= 4) fA[ca - 1] |= 1u << t;
+            if (cb <= 4) fB[cb - 1] |= 1u << t;
+        }
+    }
+    {
+        uint4* dF = reinterpret_cast<uint4*>(sF + 32 * w);
+        uint4* dR = reinterpret_cast<uint4*>(sR + 32 * w);
+        dF[0] = make_uint4(cF[0], cF[1], cF[2], cF[3]);
+        dR[0] = make_uint4(cR[0], cR[1], cR[2], cR[3]);
+        if (32 * w + 16 < maxLen) { // (the row ends at maxLen)
+            dF[1] = make_uint4(cF[4], cF[5], cF[6], cF[7]);
+            dR[1] = make_uint4(cR[4], cR[5], cR[6], cR[7]);
+        }
     }
     uint32_t* gF = G + (size_t)(2 * r) * 8 * gw;     // forward strand: [0..3] fwd bits, [4..7] reversed-read bits
     uint32_t* gR = G + (size_t)(2 * r + 1) * 8 * gw; // reverse-complement strand
