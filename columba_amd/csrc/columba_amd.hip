@@ -739,8 +739,9 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                 const uint32_t nTb = hcnt[7];
                 if (nTb) {
                     const uint32_t tSlots = std::min<uint32_t>(((nTb + 255) / 256) * 256, 256u * 1024u);
-                    if (b->vW.n < (size_t)VROWS * tSlots) b->vW.alloc((size_t)VROWS * tSlots);
-                    VPlanes vp{b->vW.p, tSlots};
+                    const uint32_t tLines = ((uint32_t)VROWS + 7u) / 8u + 2u; // (a group is written whole)
+                    if (b->vW.n < (size_t)tLines * 8 * tSlots) b->vW.alloc((size_t)tLines * 8 * tSlots);
+                    VPlanes vp{b->vW.p, tSlots, tLines};
                     tm.begin();
                     hipLaunchKernelGGL(k_traceback, dim3(tSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->gw,
                                        b->G.p, b->tbq.p, nTb, vp, q);
@@ -1040,9 +1041,10 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         HIPCHK(hipMemset(cnt.p, 0, 32));
         HIPCHK(hipMemset(ctr.p, 0, CMB_CNT_MAX * 8));
         const uint32_t slots = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(((n + 255) / 256) * 256, 256), 65536);
-        vW.alloc((size_t)VROWS * slots);
+        const uint32_t tLines = ((uint32_t)VROWS + 7u) / 8u + 2u;
+        vW.alloc((size_t)tLines * 8 * slots);
         tbq.alloc(n + (size_t)(slots / 64 + 1) * 256);
-        VPlanes vp{vW.p, slots};
+        VPlanes vp{vW.p, slots, tLines};
         Queues q{};
         q.text = text.p;
         q.textCap = (uint32_t)cap;

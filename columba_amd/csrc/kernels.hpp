@@ -572,9 +572,12 @@ constexpr int VEMIT = 20; // max cluster centres of one candidate (size of the f
 // What the traceback reads of row i is bit (j - 32 b) + DIAG of HP and D0 with |i - j| inside the band, i.e.
 // at most 18 (= 3 k) bits below and 6 above the row's diagonal bit: both 32-bit windows starting 18 bits below
 // the diagonal are kept in ONE 64-bit word per row (low half HP, high half D0).
+// Layout: per lane (slot) `lines` 64-byte lines, line g = the packed rows 8 g + 1 .. 8 g + 8.  The forward pass
+// collects eight rows in registers and writes the line with four 16-byte stores; the traceback fetches a line
+// (and the eight text codes of its rows) whenever it crosses into the next group of eight rows.
 struct VPlanes {
     uint64_t* W;
-    uint32_t nSlots;
+    uint32_t nSlots, lines;
 };
 constexpr uint32_t TB_BELOW = 18;
 __device__ __forceinline__ uint64_t packTraceRow(uint32_t r, uint64_t HP, uint64_t D0) {
@@ -605,6 +608,9 @@ __device__ __forceinline__ uint32_t textCode(uint8_t code) { return code; }
 // 16 text codes from ANY byte offset (gfx950 serves unaligned 16-byte global loads)
 struct __attribute__((packed, aligned(1))) Unaligned16 {
     uint32_t x, y, z, w;
+};
+struct __attribute__((packed, aligned(1))) Unaligned8 {
+    uint32_t x, y;
 };
 __device__ __forceinline__ uint4 loadText16(const uint8_t* p) {
     const Unaligned16 v = *reinterpret_cast<const Unaligned16*>(p);
@@ -645,10 +651,13 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const uint32
     uint4 nxt = loadText16(tp + 16); // the text allocation is padded
     uint32_t i = 0;
     bool alive = size > 0;
+    uint64_t buf[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // STORE: the packed rows of the current group of eight
+    bool groupAlive = false;
     for (uint32_t c = 0; __ballot(alive) != 0ull; c++) {
 #pragma unroll
         for (uint32_t t = 0; t < 16; t++) {
             const uint32_t r = 16 * c + t + 1;
+            if (STORE && (t & 7u) == 0) groupAlive = alive;
             if ((t == 15 && (c & 1u)) || (t == 0 && c == 0)) { // r % 32 == 0, or the first row: next block's words
                 if (alive) {
                     const uint32_t b = r / MX_BLOCK;
@@ -663,7 +672,7 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const uint32
                 const uint64_t M = Ml[tc * 256 + tid];
                 cRows++;
                 const bool valid = computeRow(g, r, M, HP, HN, D0, RAC, score);
-                if (STORE) V.W[(size_t)r * V.nSlots + slot] = packTraceRow(r, HP, D0);
+                if (STORE) buf[t & 7u] = packTraceRow(r, HP, D0);
                 if (!valid) {
                     alive = false;
                 } else {
@@ -686,6 +695,13 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const uint32
                     i++;
                     if (i >= size) alive = false;
                 }
+            }
+            if (STORE && (t & 7u) == 7u && groupAlive) { // rows 16 c + t - 6 .. 16 c + t + 1 = line 2 c + t / 8
+                uint4* L = reinterpret_cast<uint4*>(V.W) + ((size_t)slot * V.lines + (2 * c + (t >> 3))) * 4;
+#pragma unroll
+                for (int h = 0; h < 4; h++)
+                    L[h] = make_uint4((uint32_t)buf[2 * h], (uint32_t)(buf[2 * h] >> 32), (uint32_t)buf[2 * h + 1],
+                                      (uint32_t)(buf[2 * h + 1] >> 32));
             }
         }
         cur = nxt;
@@ -728,7 +744,7 @@ __device__ __forceinline__ bool verifyEdit(const DevIndex& ix, const uint64_t* o
     if (!g.inFinalColumn(size)) return false;
     uint32_t mask = 0, rows = 0;
     uint64_t edPack, edPackHi;
-    const VPlanes noPlanes{nullptr, 0};
+    const VPlanes noPlanes{nullptr, 0, 0};
     const uint32_t i = forwardPass<false>(ix, G + (size_t)rs * 8 * gw, gw, len, g, nZeros, start, size, maxED, minED,
                                           mask, edPack, edPackHi, noPlanes, 0, rows, Ml);
     cRows += rows * mult;
@@ -757,7 +773,7 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
     auto holeB = [&](uint32_t i) { tbq[i] = make_uint4(0, 0, 0, 0); }; // mask 0: nothing to trace
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t waveBase = slot & ~63u;
-    const VPlanes noPlanes{nullptr, 0};
+    const VPlanes noPlanes{nullptr, 0, 0};
     for (uint32_t base = waveBase; base < nItems; base += stride) { // wave-uniform trip count
         const uint32_t it = base + (threadIdx.x & 63u);
         uint32_t nOut = 0, nTb = 0;
@@ -1029,10 +1045,8 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const u
             const uint4* __restrict__ tbq, uint32_t nTasks, VPlanes V, Queues q) {
     __shared__ uint64_t wW[TBW][256];
     __shared__ uint64_t Ml[ML_WORDS];
-    __shared__ uint8_t wT[TBW][256];
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t tid = threadIdx.x;
-    const uint32_t NS = V.nSlots;
     uint32_t flags = 0, dummyRows = 0;
     WaveChunk chT; // chunk of the text-occurrence queue
     bool ovT = false;
@@ -1079,21 +1093,31 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const u
                 m &= ~(1u << bitIdx);
                 const uint32_t ri = firstRow + 1 + bitIdx;
                 uint32_t ti = ri, tj = col;
-                uint32_t winTop = 0xFFFFFFFFu; // window slot w holds row winTop - w
+                uint32_t curG = 0xFFFFFFFFu; // the line (rows 8 g + 1 .. 8 g + 8) held in wW[.][tid]
+                uint32_t txLo = 0, txHi = 0;  // ... and the text codes of those rows
                 uint32_t curB = 0xFFFFFFFFu;
                 uint64_t Mblk[4] = {0, 0, 0, 0};
                 while (tj > 0) {
-                    if (winTop == 0xFFFFFFFFu || ti + (TBW - 1) < winTop) {
-                        winTop = ti;
+                    uint64_t ww = packTraceRow(0, HP0, 0ull); // row 0
+                    uint32_t tcRow = 4;
+                    if (ti > 0) {
+                        const uint32_t gq = (ti - 1) >> 3, jq = (ti - 1) & 7u;
+                        if (gq != curG) {
+                            curG = gq;
+                            const uint4* L = reinterpret_cast<const uint4*>(V.W) + ((size_t)slot * V.lines + gq) * 4;
 #pragma unroll
-                        for (int w = 0; w < TBW; w++) {
-                            const uint32_t r = winTop >= (uint32_t)w ? winTop - w : 0u;
-                            const size_t o = (size_t)r * NS + slot;
-                            wW[w][tid] = (r == 0) ? packTraceRow(0, HP0, 0ull) : V.W[o];
-                            wT[w][tid] = (r == 0) ? (uint8_t)0 : ix.text[start + r - 1];
+                            for (int h = 0; h < 4; h++) {
+                                const uint4 v = L[h];
+                                wW[2 * h][tid] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                                wW[2 * h + 1][tid] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+                            }
+                            const Unaligned8 tv = *reinterpret_cast<const Unaligned8*>(ix.text + start + 8 * gq);
+                            txLo = tv.x;
+                            txHi = tv.y;
                         }
+                        ww = wW[jq][tid];
+                        tcRow = ((jq < 4 ? txLo : txHi) >> (8 * (jq & 3u))) & 0xFFu;
                     }
-                    const uint32_t ws = winTop - ti;
                     const uint32_t b = ti / MX_BLOCK;
                     const uint64_t bit = 1ull << ((tj - b * MX_BLOCK) + MX_DIAG);
                     const uint32_t rel = tj + TB_BELOW - ti; // bit of the row's packed windows
@@ -1101,7 +1125,6 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const u
                         flags |= FLAG_CAPACITY;
                         break;
                     }
-                    const uint64_t ww = wW[ws][tid];
                     if (((uint32_t)ww >> rel) & 1u) {
                         --tj;
                     } else {
@@ -1112,7 +1135,7 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const u
 #pragma unroll
                                 for (int ch = 0; ch < 4; ch++) Mblk[ch] = matchWord(Gf + ch * gw, 0, len, b);
                             }
-                            const uint32_t tc = textCode(wT[ws][tid]);
+                            const uint32_t tc = tcRow;
                             const uint64_t M = tc == 0 ? Mblk[0] : tc == 1 ? Mblk[1] : tc == 2 ? Mblk[2] : tc == 3 ? Mblk[3] : 0ull;
                             diag = (M & bit) != 0 || (((uint32_t)(ww >> 32) >> rel) & 1u) == 0;
                         }
