@@ -125,10 +125,14 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         ix->saBv.upload(desc->sa_bv, saW);
         ix->saCnt.upload(desc->sa_bv_counts, (saW + 7) / 4);
         ix->saSamples.upload(desc->sa_samples, desc->n_samples);
-        ix->text.alloc(n + 64); // padded: the verification kernels read 16-byte chunks two chunks ahead
-        HIPCHK(hipMemset(ix->text.p, 0, n + 64));
+        // padded: the verification kernels read (unaligned) 16-byte chunks up to two chunks ahead, and lanes whose
+        // candidate has ended keep prefetching while their wavefront runs (at most MAX_READ + 3 k rows + 48 bytes)
+        constexpr uint64_t TEXT_PAD = 512;
+        static_assert(TEXT_PAD >= (uint64_t)VROWS + 64, "text padding must cover the longest verification window");
+        ix->text.alloc(n + TEXT_PAD);
+        HIPCHK(hipMemset(ix->text.p, 0, n + TEXT_PAD));
         HIPCHK(hipMemcpy(ix->text.p, desc->text, n, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_encode_text, dim3(4096), dim3(256), 0, 0, ix->text.p, n, n + 64); // ASCII -> codes 0..4
+        hipLaunchKernelGGL(k_encode_text, dim3(4096), dim3(256), 0, 0, ix->text.p, n, n + TEXT_PAD); // ASCII -> codes 0..4
         HIPCHK(hipGetLastError());
         ix->kmer.alloc(1ull << (2 * desc->kmer_size));
         if (desc->seq_starts) ix->seqStarts.assign(desc->seq_starts, desc->seq_starts + desc->n_seqs);
