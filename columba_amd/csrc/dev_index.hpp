@@ -96,6 +96,32 @@ __device__ __forceinline__ void loadRankChunksRaw(const DevBWT& t, uint32_t p, u
     v[2] = B[1 + 2 * sub];
     v[3] = B[2 + 2 * sub];
 }
+// both ends of a range: a narrow range usually has both ends in ONE rank block (192 positions), often in one
+// 64-bit word of it — what the begin already fetched is not requested again (the request rate of scattered
+// 16-byte loads, not the bytes, is what bounds the extension kernels)
+__device__ __forceinline__ void loadRankPairRaw(const DevBWT& t, uint32_t pb, uint32_t pe, uint4 v[8]) {
+    const uint32_t wb = pb >> 6, we = pe >> 6;
+    const uint32_t blkB = __umulhi(wb, 0xAAAAAAABu) >> 1, blkE = __umulhi(we, 0xAAAAAAABu) >> 1;
+    const uint32_t subB = wb - 3u * blkB, subE = we - 3u * blkE;
+    const uint4* B = t.blk + (size_t)blkB * 8;
+    const uint4* E = t.blk + (size_t)blkE * 8;
+    v[0] = B[0];
+    v[1] = B[7];
+    v[2] = B[1 + 2 * subB];
+    v[3] = B[2 + 2 * subB];
+    v[4] = v[0];
+    v[5] = v[1];
+    v[6] = v[2];
+    v[7] = v[3];
+    if (blkE != blkB) {
+        v[4] = E[0];
+        v[5] = E[7];
+    }
+    if (we != wb) {
+        v[6] = E[1 + 2 * subE];
+        v[7] = E[2 + 2 * subE];
+    }
+}
 __device__ __forceinline__ void ranksFromRaw(const uint4 v[4], uint32_t p, uint32_t R[4]) {
     const uint32_t w = p >> 6;
     const uint32_t sub = w - 3u * (__umulhi(w, 0xAAAAAAABu) >> 1);
@@ -196,8 +222,10 @@ __device__ __forceinline__ void loadExtendRanks(const DevIndex& ix, int mode, co
         t = ix.rev;
         tr = p.rev;
     }
-    rank4(t, tr.b, Rb);
-    rank4(t, tr.e, Re);
+    uint4 v[8];
+    loadRankPairRaw(t, tr.b, tr.e, v);
+    ranksFromRaw(v, tr.b, Rb);
+    ranksFromRaw(v + 4, tr.e, Re);
     db = tr.b > t.dollarPos ? 1u : 0u;
     de = tr.e > t.dollarPos ? 1u : 0u;
 }

@@ -279,8 +279,7 @@ __device__ __forceinline__ void issueExtend(const DevIndex& ix, int mode, const 
         t = ix.rev;
         tr = parent.rev;
     }
-    loadRankChunksRaw(t, tr.b, v);
-    loadRankChunksRaw(t, tr.e, v + 4);
+    loadRankPairRaw(t, tr.b, tr.e, v);
 }
 __device__ __forceinline__ bool takeExtend(const DevIndex& ix, int mode, const RangePair& parent, uint32_t code,
                                            const uint4 v[8], RangePair& child) {
@@ -346,9 +345,10 @@ k_parts(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
             if (m.req == RQ_NONE) m.advance(); // bookkeeping up to the next extension (or the end)
             if (__ballot(m.req == RQ_RANK) == 0ull) break;
             if (m.req == RQ_RANK) {
-                issueExtend(ix, m.reqMode, m.reqParent, v);
+                uint4 rk[8]; // (its own array: the read-record path reinterprets v[] and would pin it in scratch)
+                issueExtend(ix, m.reqMode, m.reqParent, rk);
                 RangePair child;
-                const bool ok = takeExtend(ix, m.reqMode, m.reqParent, m.reqCode, v, child);
+                const bool ok = takeExtend(ix, m.reqMode, m.reqParent, m.reqCode, rk, child);
                 m.req = RQ_NONE;
                 m.resume(ok, child);
             }
