@@ -21,11 +21,12 @@ for r in rows:
     if n.startswith("cmb::") or n.startswith("void cmb::") or "rocprim" in n:
         print(",".join([n[:80].replace(",", ";"), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]))
 PY
-# 2) HBM traffic counters, each in its own pass (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
+# 2) HBM traffic counters, each in its own pass (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass);
+#    only this library's kernels are instrumented (the harness' torch kernels on > 2^31-element tensors crashed under --pmc)
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$C -- python3 $R/bench.py $ARGS --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $C --kernel-include-regex 'cmb::' --output-format csv -d /tmp/prof_$C -- python3 $R/bench.py $ARGS --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
 done
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM --output-format csv -d /tmp/prof_SQ -- python3 $R/bench.py $ARGS --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM --kernel-include-regex 'cmb::' --output-format csv -d /tmp/prof_SQ -- python3 $R/bench.py $ARGS --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
 python3 $R/tools/pmc_summary.py /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE /tmp/prof_SQ > $OUT/pmc_summary.txt 2>&1
 # 3) the plain bench line (not under the profiler), then the per-kernel traffic table bench.py reads back
 cd $R && python3 bench.py $ARGS > $OUT/bench_line.json 2> $OUT/bench_stderr.log
