@@ -831,6 +831,11 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
             HIPCHK(hipMemcpyAsync(b->occOffs.data(), b->foffs.p, ((size_t)nReads + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             lap("results to the host");
+            if (verbose) {
+                size_t fr = 0, tot = 0;
+                (void)hipMemGetInfo(&fr, &tot);
+                fprintf(stderr, "[mem] device memory in use: %.1f GB of %.1f GB\n", (tot - fr) / 1e9, tot / 1e9);
+            }
         }
         // TOTAL_REPORTED_POSITIONS (indexinterface.cpp:1378,1390 / :1333,1352)
         // (the device counter holds the records k_verify / k_traceback wrote; queue holes are not records)
