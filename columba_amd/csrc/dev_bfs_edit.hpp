@@ -46,7 +46,8 @@ constexpr uint32_t BFS_STOP = FLAG_BFS_Q | FLAG_BFS_EV | FLAG_BFS_F | FLAG_BFS_C
                               FLAG_FMOCC_OVERFLOW | FLAG_CAPACITY;
 
 struct BfsBufs {
-    uint4* Q[2];  // frontier nodes, 4 planes of qCap: {ranges} {row | score << 16, ctx, fc, -} {HP, HN} {RAC, -}
+    uint4* Q[2];  // frontier nodes, 5 planes of qCap: {ranges} {row | score << 16, ctx, fc, -} {HP, HN} {RAC, -}
+                  // {final-column distances of the path: only for nodes in the final column}
     uint4* Ev[2]; // events {ctx, F index of the node that ended its path, remaining-descendants index | -1, cell}
     uint4* F;     // final-column records, 4 x 16 B: {ranges} {depth | c << 16, parent, reported, -} {edit distances}
     uint4* C;     // contexts, CTX_U4 x 16 B
@@ -161,27 +162,26 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
             const uint4* Cx = B.C + (size_t)ctx * CTX_U4;
             const uint32_t blk = row1 / MX_BLOCK;
             // ---- the single memory step: context (hot part), match words, F pack, rank blocks
-            const uint4 c0 = Cx[0], c1 = Cx[1];
+            const uint4 hot = Cx[5]; // everything the expansion needs of its context, in ONE 16-byte request
             const uint4 mA = Cx[8 + 2 * blk], mB = Cx[9 + 2 * blk];
             uint4 fp = make_uint4(0, 0, 0, 0);
-            if (fcP != BFS_NONE) fp = B.F[(size_t)fcP * 4 + 2];
-            const uint32_t fl = c0.w;
-            const uint32_t dir = (fl >> 4) & 1u, uni = (fl >> 5) & 1u;
+            if (fcP != BFS_NONE) fp = Qi[(size_t)4 * qCap + i]; // final-column distances of the path so far
+            const uint32_t dir = (hot.x >> 27) & 1u, uni = (hot.x >> 28) & 1u;
             const int md = uni ? 2 : (dir == 0 ? 0 : 1);
             const RangePair parent{{n0.x, n0.y}, {n0.z, n0.w}};
             uint32_t Rb[4], Re[4], db, de;
             loadExtendRanks(ix, md, parent, Rb, Re, db, de);
             cExp++;
-            rsId = c0.x;
-            itMeta = c1.y;
+            rsId = hot.x & 0x1FFFFFFu;
+            itMeta = hot.w & 0x7FFFFFu;
             MatGeom g;
-            g.n = c0.y & 0xFFFFu;
-            g.m = c0.y >> 16;
-            g.Wv = c0.z & 0xFFu;
-            g.Wh = (c0.z >> 8) & 0xFFu;
-            g.maxED = (c0.z >> 16) & 0xFFu;
-            const uint32_t clSize = c0.z >> 24;
-            const uint32_t itMode = (fl >> 7) & 3u; // 0: phase 0 (no switch), 1: start difference fixed, 2: BACKWARD
+            g.n = hot.y & 0x1FFu;
+            g.m = (hot.y >> 9) & 0x1FFu;
+            g.Wv = (hot.y >> 18) & 31u;
+            g.Wh = (hot.y >> 23) & 15u;
+            g.maxED = (hot.y >> 27) & 15u;
+            const uint32_t clSize = hot.w >> 23;
+            const uint32_t itMode = (hot.x >> 25) & 3u; // 0: phase 0 (no switch), 1: start difference fixed, 2: BACKWARD
             pack = EdPack{u64of(fp.x, fp.y), u64of(fp.z, fp.w)};
             const uint64_t pHP = u64of(n2.x, n2.y), pHN = u64of(n2.z, n2.w), pRAC = u64of(n3.x, n3.y);
             const bool inFC = g.inFinalColumn(row1);
@@ -217,7 +217,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
                     }
                 }
                 if (child.sa.width() <= ix.switchPoint && itMode != 0) { // goToInTextVerificationEdit (:340-375)
-                    uint32_t startDiff = c1.x;
+                    uint32_t startDiff = hot.z;
                     if (itMode == 2) {
                         const uint32_t col = g.firstColumn(row1);
                         startDiff -= col + cellAt(row1, col, HP, HN, sc);
@@ -272,6 +272,11 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
                     Qo[(size_t)2 * qCap + o] = make_uint4((uint32_t)cHP[c], (uint32_t)(cHP[c] >> 32), (uint32_t)cHN[c],
                                                           (uint32_t)(cHN[c] >> 32));
                     Qo[(size_t)3 * qCap + o] = make_uint4((uint32_t)cRAC[c], (uint32_t)(cRAC[c] >> 32), 0u, 0u);
+                    if (needF & (1u << c)) {
+                        EdPack p2 = pack;
+                        edPut(p2, cell, cEd[c]);
+                        Qo[(size_t)4 * qCap + o] = make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32));
+                    }
                 } else if (kd == 2) {
                     Eo[oEv++] = make_uint4(ctx, fc, 0xFFFFFFFFu, cell);
                 } else {
@@ -624,7 +629,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
 
         // ---- phase entry: recApproxMatchEdit prologue + replay of the descendants (:377-497)
         uint32_t outKind = 0; // 1: node of the next frontier, 2: event
-        uint4 oN0 = make_uint4(0, 0, 0, 0), oN1 = oN0, oN2 = oN0, oN3 = oN0, oEv = oN0;
+        uint4 oN0 = make_uint4(0, 0, 0, 0), oN1 = oN0, oN2 = oN0, oN3 = oN0, oN4 = oN0, oEv = oN0;
         if (enter) {
             if (descSelf) descRefN = cNew;
             if (otherSelf) otherRefN = cNew;
@@ -704,6 +709,10 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                                    idxN | (dirN << 4) | (uniN << 5) | (useRev << 6) | (itMode << 7) | (scheme << 12) |
                                        (search << 16));
                 Cx[1] = make_uint4(itStart, itMeta, descRefN, otherRefN);
+                if (rsId > 0x1FFFFFFu || itMeta > 0x7FFFFFu) flags |= FLAG_CAPACITY;
+                Cx[5] = make_uint4(rsId | (itMode << 25) | (dirN << 27) | (uniN << 28),
+                                   g.n | (g.m << 9) | (g.Wv << 18) | (g.Wh << 23) | (maxEDn << 27), itStart,
+                                   itMeta | (clSize << 23));
                 Cx[2] = make_uint4(smR.sa.b, smR.sa.e, smR.rev.b, smR.rev.e);
                 Cx[3] = make_uint4(smDepthN, smShiftN, smDist, xOff | (xLen << 16));
                 Cx[4] = make_uint4(descSelf || otherSelf ? aOff : 0u,
@@ -781,6 +790,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                     oN1 = make_uint4(rootRow | (score << 16), cNew, fcCur, 0u);
                     oN2 = make_uint4((uint32_t)HP, (uint32_t)(HP >> 32), (uint32_t)HN, (uint32_t)(HN >> 32));
                     oN3 = make_uint4((uint32_t)RAC, (uint32_t)(RAC >> 32), 0u, 0u);
+                    oN4 = make_uint4((uint32_t)pk.lo, (uint32_t)(pk.lo >> 32), (uint32_t)pk.hi, (uint32_t)(pk.hi >> 32));
                 }
             }
         }
@@ -795,6 +805,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                 Qo[(size_t)qCap + oN] = oN1;
                 Qo[(size_t)2 * qCap + oN] = oN2;
                 Qo[(size_t)3 * qCap + oN] = oN3;
+                Qo[(size_t)4 * qCap + oN] = oN4;
             }
         } else if (outKind == 2) {
             if (oE >= B.evCap) flags |= FLAG_BFS_EV;
