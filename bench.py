@@ -42,7 +42,7 @@ def log(*a):
 # kernels behind each timed group of cmb_batch_timings (rocPRIM sorts / scans between them are not attributed)
 GROUP_KERNELS = {"k_prep": ["k_prep"], "k_partition": ["k_parts", "k_exact"],
                  "k_dfs": ["k_bfs_start", "k_bfs_pass", "k_bfs_finish", "k_dfs_hamming"],
-                 "k_verify": ["k_verify", "k_verify_edit"], "k_traceback": ["k_traceback"],
+                 "k_verify": ["k_verify"], "k_verify_edit": ["k_verify_stage"], "k_traceback": ["k_traceback"],
                  "k_fmocc": ["k_fmocc"], "k_filter": ["k_pack_keys", "k_filter"]}
 
 
@@ -176,11 +176,13 @@ def main():
         # algorithmic bytes per step of every kernel group:
         #   k_partition (k_parts + k_exact) / k_dfs (frontier search): 192 B per node expansion
         #       (2 positions x (64 B counts line + 32 B bit group) in the reference layout)
-        #   k_verify: 112 B per LF step + 28 B per located row + 1 B per text character
-        #   k_traceback: 1 B per text character of the candidates that are traced
+        #   k_verify (locate, key sort): 112 B per LF step + 28 B per located row
+        #   k_verify_edit (matrix stages) / k_traceback: 1 B per text character
         alg = {"k_partition": 192.0 * (cnt["EXPANSIONS"] - cnt["DFS_EXPANSIONS"]),
                "k_dfs": 192.0 * cnt["DFS_EXPANSIONS"],
-               "k_verify": 112.0 * cnt["LF_STEPS"] + 28.0 * cnt["LOCATED_ROWS"] + 1.0 * cnt["TEXT_BYTES"],
+               "k_verify": 112.0 * cnt["LF_STEPS"] + 28.0 * cnt["LOCATED_ROWS"] +
+                           (0.0 if "k_verify_edit" in avg else 1.0 * cnt["TEXT_BYTES"]),
+               "k_verify_edit": 1.0 * cnt["TEXT_BYTES"],
                "k_traceback": 1.0 * cnt["TEXT_BYTES"]}
         per_kernel = {}
         for kname, ms in avg.items():

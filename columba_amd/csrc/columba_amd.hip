@@ -680,6 +680,7 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                 // scales the counters by the multiplicities.
                 const bool dedup = b->metric == CMB_METRIC_EDIT && b->k > 0 && b->k <= 7 && 2ull * nReads <= (1ull << 25); // 25 key bits for read x strand
                 const uint32_t tbCap = (uint32_t)std::min<size_t>(b->tbq.n, 0xFFFFFFF0u);
+                const char* vGroup = "k_verify";
                 tm.begin();
                 if (dedup && b->vkeysA.n < nItems) {
                     b->vkeysA.alloc((size_t)nItems + nItems / 8 + 256);
@@ -704,6 +705,9 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                     uint32_t nRuns = 0;
                     HIPCHK(hipMemcpyAsync(&nRuns, b->vruns.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                     HIPCHK(hipStreamSynchronize(s));
+                    tm.end("k_verify"); // locate + key sort + run-length encode; the matrix stages are timed apart
+                    vGroup = "k_verify_edit";
+                    tm.begin();
                     if (getenv("CMB_VERBOSE")) fprintf(stderr, "[verify] %u items, %u distinct keys\n", nItems, nRuns);
                     if (nRuns) {
                         // staged verification (kernels.hpp: k_verify_stage): one launch per 32-row matrix block,
@@ -737,7 +741,7 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                         }
                     }
                 }
-                tm.end("k_verify");
+                tm.end(vGroup);
                 HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
                 HIPCHK(hipStreamSynchronize(s));
                 const uint32_t nTb = hcnt[7];
