@@ -112,13 +112,14 @@ def main():
     ix = None
     if rank == 0:
         g, starts = synth.genome_human_like(n, seed=2025, device=dev)
-        ix = ib.build_index(g, seq_starts=starts, device=dev, with_bwt=not args.no_cpu_baseline)
+        ix = ib.build_index(g, seq_starts=starts, device=dev, with_bwt=(world == 1 and not args.no_cpu_baseline))
         del g
         torch.cuda.empty_cache()
         log(f"[bench] index for {n / 1e6:.0f} Mbp built in {time.time() - t0:.1f} s "
             f"({ix.nbytes() / 1e9:.2f} GB host arrays)")
     if world > 1:
         ix = broadcast_index(ix, rank, dev)
+        torch.cuda.empty_cache()
     index = ca.Index(ix, in_text_switch=4, kmer_size=10, device=local)
     strategy = ca.SearchStrategy("multiple_opt", "edit", "dynamic")
 
