@@ -283,7 +283,6 @@ struct cmb_batch {
     DevBuf<uint64_t> offs;
     DevBuf<uint32_t> G;
     DevBuf<DevStrategyK> strat;
-    DevBuf<Scratch> slabs;
     // frontier search (dev_bfs_edit.hpp): node / event double buffers, F records, contexts, list arena
     DevBuf<uint4> bfsQ[2], bfsEv[2], bfsF, bfsC, bfsA;
     DevBuf<uint32_t> bfsCnt;               // nq[passes], ne[passes], pool[4]
@@ -516,8 +515,6 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                             "falls back to naive backtracking, which the device path does not provide)");
             const uint32_t nDfs = hcnt[5];
             if (!(flags & (FLAG_ITEM_OVERFLOW | FLAG_DFS_OVERFLOW)) && nDfs) {
-                const uint32_t slotCap = getenv("CMB_DFS_SLOTS") ? (uint32_t)atoi(getenv("CMB_DFS_SLOTS")) : 256u * 512u;
-                const uint32_t want = std::min<uint32_t>(((nDfs + 255) / 256) * 256, slotCap);
                 tm.begin();
                 if (b->metric == CMB_METRIC_EDIT) {
                     // ---- frontier search: start pass, then (expand, events) per level until both queues drain
@@ -608,10 +605,54 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                     if (!drained && !(hcnt[3] & BFS_STOP))
                         return fail(CMB_ERR_INTERNAL, "frontier search did not finish within its pass bound");
                 } else {
-                    if (b->slabs.n < want) b->slabs.alloc(want);
-                    hipLaunchKernelGGL(k_dfs_hamming, dim3(want / 256), dim3(256), 0, s, ix->d, b->strat.p, b->offs.p,
-                                       b->k, b->maxLen, b->gw, b->seq.p, b->G.p, b->parts.p, b->dfs.p, nDfs,
-                                       b->slabs.p, q);
+                    // ---- Hamming distance: the same frontier idea without a matrix (dev_bfs_hamming.hpp)
+                    const uint32_t maxPass = b->maxLen + 2 * MAXP + 16;
+                    if (!b->bfsQCap) b->bfsQCap = (getenv("CMB_TEST_SMALL_POOLS") ? 0 : (size_t)nReads * 4) + 1024;
+                    b->bfsQCap = std::max<size_t>(b->bfsQCap, (size_t)nDfs + 1024);
+                    for (int j = 0; j < 2; j++)
+                        if (b->bfsQ[j].n < 2 * b->bfsQCap) b->bfsQ[j].alloc(2 * b->bfsQCap);
+                    const size_t cntWords = (size_t)maxPass + 2;
+                    if (b->bfsCnt.n < cntWords) b->bfsCnt.alloc(cntWords);
+                    if (b->bfsBlockCnt.n < (size_t)BFS_GRID * 4) b->bfsBlockCnt.alloc((size_t)BFS_GRID * 4);
+                    HIPCHK(hipMemsetAsync(b->bfsCnt.p, 0, cntWords * sizeof(uint32_t), s));
+                    HIPCHK(hipMemsetAsync(b->bfsBlockCnt.p, 0, (size_t)BFS_GRID * 4 * sizeof(unsigned long long), s));
+                    HbfsBufs H{};
+                    H.Q[0] = b->bfsQ[0].p;
+                    H.Q[1] = b->bfsQ[1].p;
+                    H.qCap = (uint32_t)std::min<size_t>(b->bfsQ[0].n / 2, 0xFFFFFFF0u);
+                    H.nq = b->bfsCnt.p;
+                    H.blockCnt = b->bfsBlockCnt.p;
+                    const uint32_t hLds = (uint32_t)((sizeof(DevStrategyK) + 15) / 16 * 16);
+                    hipLaunchKernelGGL(k_hbfs<true>, dim3(std::min<uint32_t>((nDfs + 255) / 256, BFS_GRID)), dim3(256), hLds, s,
+                                       ix->d, b->strat.p, H, 0u, b->dfs.p, nDfs, b->maxLen, b->seq.p, b->parts.p, q);
+                    std::vector<uint32_t> hc(cntWords);
+                    uint32_t pass = 0, peakQ = 0;
+                    bool drained = false;
+                    while (!drained && pass < maxPass) {
+                        const uint32_t upTo = std::min(pass + 16u, maxPass);
+                        for (; pass < upTo; pass++)
+                            hipLaunchKernelGGL(k_hbfs<false>, dim3(BFS_GRID), dim3(256), hLds, s, ix->d, b->strat.p, H, pass,
+                                               (const DfsTask*)nullptr, 0u, b->maxLen, b->seq.p, b->parts.p, q);
+                        HIPCHK(hipMemcpyAsync(hc.data(), b->bfsCnt.p, cntWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                        HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
+                        HIPCHK(hipStreamSynchronize(s));
+                        if (hcnt[3] & BFS_STOP) break;
+                        drained = hc[pass] == 0;
+                    }
+                    for (uint32_t p2 = 0; p2 <= pass && p2 < cntWords; p2++) peakQ = std::max(peakQ, hc[p2]);
+                    if (getenv("CMB_VERBOSE")) fprintf(stderr, "[hbfs] %u tasks, %u passes, peak frontier %u\n", nDfs, pass, peakQ);
+                    BfsBufs Bf{};
+                    Bf.blockCnt = b->bfsBlockCnt.p;
+                    hipLaunchKernelGGL(k_bfs_finish, dim3(1), dim3(256), 0, s, Bf, q);
+                    if (hcnt[3] & FLAG_BFS_Q) {
+                        if (attempt >= 24) return fail(CMB_ERR_INTERNAL, "frontier keeps overflowing");
+                        b->bfsQCap = std::max<size_t>(2 * b->bfsQCap, (size_t)peakQ + peakQ / 4);
+                        HIPCHK(hipStreamSynchronize(s));
+                        tm.end("k_dfs");
+                        continue;
+                    }
+                    if (!drained && !(hcnt[3] & BFS_STOP))
+                        return fail(CMB_ERR_INTERNAL, "frontier search did not finish within its pass bound");
                 }
                 tm.end("k_dfs");
                 HIPCHK(hipGetLastError());

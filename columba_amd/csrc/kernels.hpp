@@ -268,6 +268,7 @@ struct WaveChunk {
 
 } // namespace cmb
 #include "dev_bfs_edit.hpp"
+#include "dev_bfs_hamming.hpp"
 namespace cmb {
 
 // ------------------------------------------------------------------ prologue: the rank/extend kernels
@@ -525,43 +526,6 @@ k_exact(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
 
 // ------------------------------------------------------------------ approximate search over the scheme
 // (edit distance: the frontier kernels of dev_bfs_edit.hpp, included above)
-
-// Hamming distance: one lane per DfsTask (recApproxMatchHamming, indexinterface.cpp:1211-1304)
-__global__ void __launch_bounds__(256)
-k_dfs_hamming(DevIndex ix, const DevStrategyK* __restrict__ stp, const uint64_t* __restrict__ offs, uint32_t k,
-              uint32_t maxLen, uint32_t gw, const uint8_t* __restrict__ seq, const uint32_t* __restrict__ G,
-              const PartOut* __restrict__ parts, const DfsTask* __restrict__ tasks, uint32_t nTasks,
-              Scratch* __restrict__ slabs, Queues q) {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    Scratch& S = slabs[slot];
-    Ctx c(ix, *stp, S, q);
-    c.k = k;
-    c.gw = gw;
-    for (;;) {
-        const uint32_t t = atomicAdd(&q.cnt[6], 1u);
-        if (t >= nTasks) break;
-        const DfsTask task = tasks[t];
-        const uint32_t rs = task.rsId;
-        if (rs == 0xFFFFFFFFu) continue; // a hole of the task queue
-        c.rsId = rs;
-        c.len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
-        c.seq = seq + (size_t)rs * maxLen;
-        c.G = G + (size_t)rs * 8 * gw;
-        const PartOut po = parts[rs];
-#pragma unroll
-        for (int i = 0; i < MAXP; i++) {
-            S.pb[i] = po.pb[i];
-            S.pe[i] = po.pe[i];
-        }
-        const DevSearch& s = stp->sch[task.scheme].s[task.search];
-        HammingSearch hs(c, s);
-        hs.run(task.r, task.depth, task.idx);
-    }
-    const uint32_t local[4] = {c.cNode, c.cExp, c.cRows, c.cExp};
-    const int which[4] = {0, 7, 11, 12};
-    flushCounters(q, local, which, 4);
-    if (c.flags) atomicOr(&q.cnt[3], c.flags);
-}
 
 // ------------------------------------------------------------------ locate + verification
 constexpr int VROWS = MAX_READ + 3 * 6 + 4;
