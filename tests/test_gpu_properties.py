@@ -32,8 +32,8 @@ def big():
     return {"dev": dev, "reads": reads}
 
 
-def _run(dev, reads, k=4, spec="multiple_opt", part="dynamic"):
-    return ca.match_batch(dev, ca.SearchStrategy(spec, "edit", part), k, reads)
+def _run(dev, reads, k=4, spec="multiple_opt", part="dynamic", metric="edit"):
+    return ca.match_batch(dev, ca.SearchStrategy(spec, metric, part), k, reads)
 
 
 def _per_read(occ, off, i):
@@ -77,12 +77,14 @@ def test_strand_symmetry(big):
     assert flipped.mean() > 0.99
 
 
-def test_pool_growth_path(big):
+@pytest.mark.parametrize("cfg", [dict(), dict(k=2, spec="kuch1", part="uniform", metric="hamming")],
+                         ids=["edit-k4-multiple_opt", "hamming-k2-kuch1"])
+def test_pool_growth_path(big, cfg):
     sub = big["reads"][:30_000]
-    o1, f1, c1 = _run(big["dev"], sub)
+    o1, f1, c1 = _run(big["dev"], sub, **cfg)
     os.environ["CMB_TEST_SMALL_POOLS"] = "1"
     try:
-        o2, f2, c2 = _run(big["dev"], sub)
+        o2, f2, c2 = _run(big["dev"], sub, **cfg)
     finally:
         del os.environ["CMB_TEST_SMALL_POOLS"]
     assert np.array_equal(f1, f2)
