@@ -282,6 +282,7 @@ struct cmb_batch {
     uint32_t recW = 0;
     DevBuf<uint64_t> offs;
     DevBuf<uint32_t> G;
+    DevBuf<uint4> mfull; // match words of the full reads per 32-row block (k_match_words)
     DevBuf<DevStrategyK> strat;
     // frontier search (dev_bfs_edit.hpp): node / event double buffers, F records, contexts, list arena
     DevBuf<uint4> bfsQ[2], bfsEv[2], bfsF, bfsC, bfsA;
@@ -463,6 +464,15 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
             const uint64_t nthr = (uint64_t)nReads * chunks;
             hipLaunchKernelGGL(k_prep, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, b->reads.p, b->offs.p,
                                nReads, b->maxLen, b->gw, chunks, b->seq.p, b->G.p, b->rec.p, b->recW);
+        }
+        MFull mf{nullptr, 0};
+        if (b->metric == CMB_METRIC_EDIT && b->k > 0) {
+            mf.nBlk = mfullBlocks(b->maxLen);
+            const uint64_t nW = (uint64_t)tasks * mf.nBlk;
+            if (b->mfull.n < 2 * nW) b->mfull.alloc(2 * nW);
+            hipLaunchKernelGGL(k_match_words, dim3((unsigned)((nW + 255) / 256)), dim3(256), 0, s, b->G.p, b->gw, b->offs.p, tasks,
+                               mf.nBlk, b->mfull.p);
+            mf.p = b->mfull.p;
         }
         tm.end("k_prep");
 
@@ -730,7 +740,7 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                     b->vruns.alloc(4);
                 }
                 hipLaunchKernelGGL(k_verify, dim3(vSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->maxLen, b->gw,
-                                   b->seq.p, b->G.p, b->items.p, nItems, b->tbq.p, tbCap,
+                                   b->seq.p, mf, b->items.p, nItems, b->tbq.p, tbCap,
                                    dedup ? b->vkeysA.p : (unsigned long long*)nullptr, q);
                 if (dedup) {
                     size_t tmpBytes = 0;
@@ -765,11 +775,11 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                         const uint32_t listCap = (uint32_t)std::min<size_t>(b->vsC[0].n, 0xFFFFFFF0u);
                         const uint32_t grid = std::min<uint32_t>((nRuns + 255) / 256, 8192u);
                         VStageList L0{b->vsA[0].p, b->vsB[0].p, b->vsC[0].p}, L1{b->vsA[1].p, b->vsB[1].p, b->vsC[1].p};
-                        hipLaunchKernelGGL(k_verify_stage<true>, dim3(grid), dim3(256), 0, s, ix->d, b->offs.p, b->gw, b->G.p,
+                        hipLaunchKernelGGL(k_verify_stage<true>, dim3(grid), dim3(256), 0, s, ix->d, b->offs.p, mf,
                                            b->vkeysA.p, b->vcounts.p, nRuns, L0, L1, b->vsN.p, listCap, 0u, b->tbq.p, tbCap, q);
                         for (uint32_t st = 1; st < nStages; st++)
-                            hipLaunchKernelGGL(k_verify_stage<false>, dim3(grid), dim3(256), 0, s, ix->d, b->offs.p, b->gw,
-                                               b->G.p, (const unsigned long long*)nullptr, (const uint32_t*)nullptr, 0u,
+                            hipLaunchKernelGGL(k_verify_stage<false>, dim3(grid), dim3(256), 0, s, ix->d, b->offs.p, mf,
+                                               (const unsigned long long*)nullptr, (const uint32_t*)nullptr, 0u,
                                                (st & 1u) ? L1 : L0, (st & 1u) ? L0 : L1, b->vsN.p, listCap, st, b->tbq.p, tbCap,
                                                q);
                         if (verbose) {
@@ -792,8 +802,8 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
                     if (b->vW.n < (size_t)tLines * 8 * tSlots) b->vW.alloc((size_t)tLines * 8 * tSlots);
                     VPlanes vp{b->vW.p, tSlots, tLines};
                     tm.begin();
-                    hipLaunchKernelGGL(k_traceback, dim3(tSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->gw,
-                                       b->G.p, b->tbq.p, nTb, vp, q);
+                    hipLaunchKernelGGL(k_traceback, dim3(tSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, mf, b->tbq.p, nTb,
+                                       vp, q);
                     tm.end("k_traceback");
                 }
             }
@@ -1107,13 +1117,18 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         HIPCHK(hipMemset(G.p, 0, G.bytes()));
         hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, 0, reads.p, offs.p, 1u, mlen, gw, (mlen + 31) / 32, seq.p,
                            G.p, (uint32_t*)nullptr, 0u);
+        DevBuf<uint4> mfull;
+        MFull mf{nullptr, mfullBlocks(mlen)};
+        mfull.alloc((size_t)2 * 2 * mf.nBlk);
+        hipLaunchKernelGGL(k_match_words, dim3(1), dim3(256), 0, 0, G.p, gw, offs.p, 2u, mf.nBlk, mfull.p);
+        mf.p = mfull.p;
         uint32_t hc[8];
         if (n) {
-            hipLaunchKernelGGL(k_verify, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, mlen, gw, seq.p, G.p,
+            hipLaunchKernelGGL(k_verify, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, mlen, gw, seq.p, mf,
                                items.p, (uint32_t)n, tbq.p, (uint32_t)tbq.n, (unsigned long long*)nullptr, q);
             HIPCHK(hipMemcpy(hc, cnt.p, 32, hipMemcpyDeviceToHost));
             if (hc[7])
-                hipLaunchKernelGGL(k_traceback, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, gw, G.p, tbq.p,
+                hipLaunchKernelGGL(k_traceback, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, mf, tbq.p,
                                    hc[7], vp, q);
         }
         HIPCHK(hipGetLastError());

@@ -582,13 +582,48 @@ __device__ __forceinline__ uint4 loadText16(const uint8_t* p) {
 }
 constexpr uint32_t ML_WORDS = 5 * 256; // LDS match-word table of a 256-thread block: [code 0..4][thread]
 
+// The match words of the FULL read (the matrix of the in-text verification has the whole read as its horizontal
+// sequence): for every read x strand and 32-row block the four 64-bit words, 32 bytes, computed once per batch
+// (k_match_words) — the verification stages, the traceback's forward pass and the trace itself fetch them with
+// two 16-byte loads instead of funnel-shifting twelve scattered 4-byte words of the bit-strings each time.
+struct MFull {
+    const uint4* p; // [read x strand][block][2]
+    uint32_t nBlk;
+};
+__host__ __device__ inline uint32_t mfullBlocks(uint32_t maxLen) { return (maxLen + MX_LEFT + 31u) / 32u + 1u; }
+__global__ void k_match_words(const uint32_t* __restrict__ G, uint32_t gw, const uint64_t* __restrict__ offs, uint32_t nRs,
+                              uint32_t nBlk, uint4* __restrict__ out) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)nRs * nBlk) return;
+    const uint32_t rs = (uint32_t)(gid / nBlk), b = (uint32_t)(gid % nBlk);
+    const uint32_t len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
+    const uint32_t* Gf = G + (size_t)rs * 8 * gw;
+    uint64_t m[4];
+#pragma unroll
+    for (int ch = 0; ch < 4; ch++) m[ch] = matchWord(Gf + ch * gw, 0, len, b);
+    out[gid * 2] = make_uint4((uint32_t)m[0], (uint32_t)(m[0] >> 32), (uint32_t)m[1], (uint32_t)(m[1] >> 32));
+    out[gid * 2 + 1] = make_uint4((uint32_t)m[2], (uint32_t)(m[2] >> 32), (uint32_t)m[3], (uint32_t)(m[3] >> 32));
+}
+__device__ __forceinline__ void loadMatchWords(const MFull& mf, uint32_t rs, uint32_t b, uint64_t m[4]) {
+    uint4 a = make_uint4(0, 0, 0, 0), c = a;
+    if (b < mf.nBlk) {
+        const uint4* q = mf.p + ((size_t)rs * mf.nBlk + b) * 2;
+        a = q[0];
+        c = q[1];
+    }
+    m[0] = (uint64_t)a.x | ((uint64_t)a.y << 32);
+    m[1] = (uint64_t)a.z | ((uint64_t)a.w << 32);
+    m[2] = (uint64_t)c.x | ((uint64_t)c.y << 32);
+    m[3] = (uint64_t)c.z | ((uint64_t)c.w << 32);
+}
+
 // forward pass of the banded matrix of one candidate over the text window [start, start+size).
 // STORE = false: verification pass (k_verify) — nothing is stored, cluster centres of the final column
 //   are detected on the fly (bitparallelmatrix.h:591-614 needs only ED(i-1), ED(i), ED(i+1)).
 // STORE = true : traceback pass (k_traceback) — HP and D0 of every row go to the interleaved planes.
 // Returns the number of valid rows `i` (indexhelpers.cpp:535-539); centreMask bit t <=> row firstRow+1+t.
 template <bool STORE>
-__device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const uint32_t* Gf, uint32_t gw, uint32_t len,
+__device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull& mf, uint32_t rs,
                                                 const MatGeom& g, uint32_t nZeros, uint32_t start, uint32_t size,
                                                 uint32_t maxED, uint32_t minED, uint32_t& centreMask,
                                                 uint64_t& edPack, uint64_t& edPackHi, const VPlanes& V, uint32_t slot,
@@ -624,9 +659,10 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const uint32
             if (STORE && (t & 7u) == 0) groupAlive = alive;
             if ((t == 15 && (c & 1u)) || (t == 0 && c == 0)) { // r % 32 == 0, or the first row: next block's words
                 if (alive) {
-                    const uint32_t b = r / MX_BLOCK;
+                    uint64_t mw[4];
+                    loadMatchWords(mf, rs, r / MX_BLOCK, mw);
 #pragma unroll
-                    for (int ch = 0; ch < 4; ch++) Ml[ch * 256 + tid] = matchWord(Gf + ch * gw, 0, len, b);
+                    for (int ch = 0; ch < 4; ch++) Ml[ch * 256 + tid] = mw[ch];
                 }
             }
             const uint32_t wsel = t >> 2;
@@ -689,7 +725,7 @@ __host__ __device__ __forceinline__ unsigned long long packVerifyKey(uint32_t rs
 
 // one edit-distance verification (FMIndex::inTextVerification + InTextVerificationTask::doTask) of `mult`
 // identical candidates; returns true with a traceback task if the final column holds cluster centres
-__device__ __forceinline__ bool verifyEdit(const DevIndex& ix, const uint64_t* offs, uint32_t gw, const uint32_t* G,
+__device__ __forceinline__ bool verifyEdit(const DevIndex& ix, const uint64_t* offs, const MFull& mf,
                                            uint32_t rs, uint32_t start, uint32_t maxED, uint32_t minED, uint32_t fixed,
                                            uint32_t mult, uint32_t& cStarted, uint32_t& cRows, uint32_t& cText,
                                            uint32_t& cAbort, uint32_t& cCig, uint4& tbRec, uint64_t* Ml) {
@@ -709,7 +745,7 @@ __device__ __forceinline__ bool verifyEdit(const DevIndex& ix, const uint64_t* o
     uint32_t mask = 0, rows = 0;
     uint64_t edPack, edPackHi;
     const VPlanes noPlanes{nullptr, 0, 0};
-    const uint32_t i = forwardPass<false>(ix, G + (size_t)rs * 8 * gw, gw, len, g, nZeros, start, size, maxED, minED,
+    const uint32_t i = forwardPass<false>(ix, mf, rs, g, nZeros, start, size, maxED, minED,
                                           mask, edPack, edPackHi, noPlanes, 0, rows, Ml);
     cRows += rows * mult;
     cText += rows * mult;
@@ -726,7 +762,7 @@ __device__ __forceinline__ bool verifyEdit(const DevIndex& ix, const uint64_t* o
 // candidates whose final column holds cluster centres become traceback tasks {rs, start, mask, meta}.
 __global__ void __launch_bounds__(256)
 k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32_t gw,
-         const uint8_t* __restrict__ seq, const uint32_t* __restrict__ G, const uint4* __restrict__ items,
+         const uint8_t* __restrict__ seq, MFull mf, const uint4* __restrict__ items,
          uint32_t nItems, uint4* __restrict__ tbq, uint32_t tbCap, unsigned long long* __restrict__ vkeys, Queues q) {
     __shared__ uint64_t Ml[ML_WORDS];
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -807,7 +843,7 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
                 const uint32_t start = sum >= startDiff ? sum - startDiff : 0;
                 if (vkeys) { // verified once per distinct key by k_verify_edit
                     vkey = packVerifyKey(rs, start, maxED, minED, fixed);
-                } else if (verifyEdit(ix, offs, gw, G, rs, start, maxED, minED, fixed, 1u, cStarted, cRows, cText, cAbort,
+                } else if (verifyEdit(ix, offs, mf, rs, start, maxED, minED, fixed, 1u, cStarted, cRows, cText, cAbort,
                                       cCig, tbRec, Ml)) {
                     nTb = 1;
                 }
@@ -847,7 +883,7 @@ struct VStageList { // survivors entering a stage
 
 template <bool FIRST>
 __global__ void __launch_bounds__(256)
-k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const uint32_t* __restrict__ G,
+k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                const unsigned long long* __restrict__ ukeys, const uint32_t* __restrict__ counts, uint32_t nKeys,
                VStageList in, VStageList out, uint32_t* __restrict__ nList, uint32_t listCap, uint32_t stage,
                uint4* __restrict__ tbq, uint32_t tbCap, Queues q) {
@@ -922,9 +958,10 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, cons
             const uint8_t* tp = ix.text + start + (r0 - 1); // text character of row r is text[start + r - 1]
             t0 = loadText16(tp);
             t1 = loadText16(tp + 16); // the text allocation is padded
-            const uint32_t* Gf = G + (size_t)rs * 8 * gw;
+            uint64_t mw[4];
+            loadMatchWords(mf, rs, stage, mw);
 #pragma unroll
-            for (int ch = 0; ch < 4; ch++) Ml[ch * 256 + tid] = matchWord(Gf + ch * gw, 0, len, stage);
+            for (int ch = 0; ch < 4; ch++) Ml[ch * 256 + tid] = mw[ch];
         }
 #pragma unroll
         for (uint32_t t = 0; t < 32; t++) {
@@ -1005,7 +1042,7 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, cons
 // the dependent chain costs one memory round trip per 8 rows instead of three per row.
 constexpr int TBW = 8;
 __global__ void __launch_bounds__(256)
-k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const uint32_t* __restrict__ G,
+k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             const uint4* __restrict__ tbq, uint32_t nTasks, VPlanes V, Queues q) {
     __shared__ uint64_t wW[TBW][256];
     __shared__ uint64_t Ml[ML_WORDS];
@@ -1022,7 +1059,6 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const u
         const uint32_t it = base + (tid & 63u);
         uint32_t rs = 0, start = 0, m = 0, firstRow = 0, len = 0, col = 0;
         uint64_t edPack = 0, edPackHi = 0;
-        const uint32_t* Gf = G;
         uint4 t = make_uint4(0, 0, 0, 0);
         if (it < nTasks) t = tbq[it];
         if (t.z != 0u) { // (mask 0: a hole of the task queue)
@@ -1041,10 +1077,9 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const u
             firstRow = (g.m - 1) - g.sfc();
             col = g.n - 1;
             const uint32_t topCentre = firstRow + 1 + (31u - (uint32_t)__clz(m));
-            Gf = G + (size_t)rs * 8 * gw;
             uint32_t dummyMask;
             // rows 1..topCentre (all valid: they were valid in pass 1)
-            forwardPass<true>(ix, Gf, gw, len, g, nZeros, start, topCentre, maxED, 0, dummyMask, edPack, edPackHi, V,
+            forwardPass<true>(ix, mf, rs, g, nZeros, start, topCentre, maxED, 0, dummyMask, edPack, edPackHi, V,
                               slot, dummyRows, Ml);
         }
         // one centre per lane and round; the wavefront appends its results with one atomic per round
@@ -1096,8 +1131,7 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t gw, const u
                         if (ti > 0) {
                             if (b != curB) { // match words of this 32-row block (bitparallelmatrix.h:559)
                                 curB = b;
-#pragma unroll
-                                for (int ch = 0; ch < 4; ch++) Mblk[ch] = matchWord(Gf + ch * gw, 0, len, b);
+                                loadMatchWords(mf, rs, b, Mblk);
                             }
                             const uint32_t tc = tcRow;
                             const uint64_t M = tc == 0 ? Mblk[0] : tc == 1 ? Mblk[1] : tc == 2 ? Mblk[2] : tc == 3 ? Mblk[3] : 0ull;
