@@ -7,6 +7,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -311,6 +312,13 @@ struct cmb_batch {
     DevBuf<unsigned long long> counters;
     uint32_t nSlots = 0;
     std::vector<uint64_t> hostOffs;
+    // A large batch is a COMPOSITE of sub-batches that run concurrently, one host thread + HIP stream each: the
+    // stages of different sub-batches drift apart, so VALU-bound matrix kernels of one overlap memory-bound
+    // extension kernels of another (starting them one after the other on purpose was measured slower: the
+    // device idles at both ends).
+    std::vector<cmb_batch*> subs;
+    cmb_batch* parent = nullptr;
+    uint32_t subIndex = 0;
     // results
     PinnedBuf<cmb_occ> occs;
     PinnedBuf<uint64_t> occOffs;
@@ -318,14 +326,49 @@ struct cmb_batch {
     std::vector<KernelTime> times;
     bool done = false;
     ~cmb_batch() {
+        for (cmb_batch* c : subs) delete c;
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
+
+static int batchCreateOne(cmb_index* idx, const cmb_strategy* st, uint32_t max_distance, const char* seqs,
+                          const uint64_t* offs, uint32_t n_reads, cmb_batch** out);
 
 extern "C" int cmb_batch_create(cmb_index* idx, const cmb_strategy* st, uint32_t max_distance, const char* seqs,
                                 const uint64_t* offs, uint32_t n_reads, cmb_batch** out) {
     if (!idx || !st || !offs || !out || (!seqs && n_reads)) return fail(CMB_ERR_INVALID, "null argument");
     if (n_reads >= 0x7FFFFFFFu) return fail(CMB_ERR_INVALID, "too many reads in one batch");
+    // sub-batches: 3 from 8 M reads, 2 from 2 M (below that the fixed cost per frontier level dominates; measured
+    // on 10 M reads: 1 -> 26.4, 2 -> 30.4, 3 -> 30.6, 4 -> 29.5 M reads/s); CMB_SUBBATCHES overrides
+    uint32_t S = n_reads >= 8000000u ? 3u : n_reads >= 2000000u ? 2u : 1u;
+    if (getenv("CMB_SUBBATCHES")) S = (uint32_t)std::max(1, atoi(getenv("CMB_SUBBATCHES")));
+    S = std::min<uint32_t>(S, std::max<uint32_t>(n_reads, 1u));
+    if (S <= 1) return batchCreateOne(idx, st, max_distance, seqs, offs, n_reads, out);
+    std::unique_ptr<cmb_batch> parent(new cmb_batch());
+    parent->ix = idx;
+    parent->k = max_distance;
+    parent->nReads = n_reads;
+    parent->metric = st->metric;
+    for (uint32_t j = 0; j < S; j++) {
+        const uint32_t lo = (uint32_t)((uint64_t)n_reads * j / S), hi = (uint32_t)((uint64_t)n_reads * (j + 1) / S);
+        std::vector<uint64_t> o(hi - lo + 1);
+        for (uint32_t i = lo; i <= hi; i++) {
+            if (i > lo && offs[i] < offs[i - 1]) return fail(CMB_ERR_INVALID, "read offsets must be non-decreasing");
+            o[i - lo] = offs[i] - offs[lo];
+        }
+        cmb_batch* c = nullptr;
+        const int rc = batchCreateOne(idx, st, max_distance, seqs + offs[lo], o.data(), hi - lo, &c);
+        if (rc != CMB_OK) return rc;
+        c->parent = parent.get();
+        c->subIndex = j;
+        parent->subs.push_back(c);
+    }
+    *out = parent.release();
+    return CMB_OK;
+}
+
+static int batchCreateOne(cmb_index* idx, const cmb_strategy* st, uint32_t max_distance, const char* seqs,
+                          const uint64_t* offs, uint32_t n_reads, cmb_batch** out) {
     try {
         useDevice(idx->device);
         std::unique_ptr<cmb_batch> b(new cmb_batch());
@@ -422,8 +465,49 @@ inline bool occLess(const HostOcc& a, const HostOcc& b) {
 
 } // namespace
 
+static int batchRunOne(cmb_batch* b);
+
 extern "C" int cmb_batch_run(cmb_batch* b) {
     if (!b) return fail(CMB_ERR_INVALID, "null argument");
+    if (b->subs.empty()) return batchRunOne(b);
+    b->done = false;
+    std::vector<int> rc(b->subs.size(), CMB_OK);
+    std::vector<std::string> err(b->subs.size());
+    // CMB_SERIAL_SUBBATCHES: one sub-batch after the other — every kernel has the device to itself, which is what
+    // per-kernel timings and counters want (bench.py times its throughput steps concurrently and takes the
+    // kernel table from one extra serial step)
+    const bool serial = getenv("CMB_SERIAL_SUBBATCHES") != nullptr;
+    std::vector<std::thread> th;
+    for (size_t j = 0; j < b->subs.size(); j++) {
+        th.emplace_back([&, j] {
+            rc[j] = batchRunOne(b->subs[j]);
+            if (rc[j] != CMB_OK) err[j] = cmb_last_error(); // (the message lives in the worker's thread-local storage)
+        });
+        if (serial) th.back().join();
+    }
+    for (auto& t : th)
+        if (t.joinable()) t.join();
+    for (size_t j = 0; j < rc.size(); j++)
+        if (rc[j] != CMB_OK) return fail(rc[j], err[j]);
+    memset(b->cnts, 0, sizeof(b->cnts));
+    b->times.clear();
+    for (cmb_batch* c : b->subs) {
+        for (int i = 0; i < CMB_CNT_MAX; i++) b->cnts[i] += c->cnts[i];
+        for (const auto& t : c->times) { // busy time per kernel group, summed over the concurrent sub-batches
+            bool found = false;
+            for (auto& u : b->times)
+                if (!strcmp(u.name, t.name)) {
+                    u.ms += t.ms;
+                    found = true;
+                }
+            if (!found) b->times.push_back(t);
+        }
+    }
+    b->done = true;
+    return CMB_OK;
+}
+
+static int batchRunOne(cmb_batch* b) {
     try {
         cmb_index* ix = b->ix;
         useDevice(ix->device);
@@ -904,13 +988,31 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
 extern "C" int cmb_batch_result_size(const cmb_batch* b, uint64_t* n_occ) {
     if (!b || !n_occ) return fail(CMB_ERR_INVALID, "null argument");
     if (!b->done) return fail(CMB_ERR_INVALID, "batch has not been run");
-    *n_occ = b->occs.size();
+    uint64_t n = b->occs.size();
+    for (const cmb_batch* c : b->subs) n += c->occs.size();
+    *n_occ = n;
     return CMB_OK;
 }
 extern "C" int cmb_batch_results(const cmb_batch* b, cmb_occ* out, uint64_t out_cap, uint64_t* out_offs,
                                  uint64_t* counters) {
     if (!b) return fail(CMB_ERR_INVALID, "null argument");
     if (!b->done) return fail(CMB_ERR_INVALID, "batch has not been run");
+    if (!b->subs.empty()) { // composite: the sub-batches' lists one after the other, offsets rebased
+        uint64_t total = 0;
+        for (const cmb_batch* c : b->subs) total += c->occs.size();
+        if (out_cap < total) return fail(CMB_ERR_OVERFLOW, "output buffer too small");
+        uint64_t base = 0, read = 0;
+        for (const cmb_batch* c : b->subs) {
+            if (out && !c->occs.empty()) memcpy(out + base, c->occs.data(), c->occs.size() * sizeof(cmb_occ));
+            if (out_offs)
+                for (uint32_t i = 0; i < c->nReads; i++) out_offs[read + i] = base + c->occOffs.data()[i];
+            read += c->nReads;
+            base += c->occs.size();
+        }
+        if (out_offs) out_offs[read] = base;
+        if (counters) memcpy(counters, b->cnts, sizeof(b->cnts));
+        return CMB_OK;
+    }
     if (out_cap < b->occs.size()) return fail(CMB_ERR_OVERFLOW, "output buffer too small");
     if (out && !b->occs.empty()) memcpy(out, b->occs.data(), b->occs.size() * sizeof(cmb_occ));
     if (out_offs) memcpy(out_offs, b->occOffs.data(), b->occOffs.size() * sizeof(uint64_t));

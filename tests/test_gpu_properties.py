@@ -92,3 +92,20 @@ def test_pool_growth_path(big, cfg):
         assert np.array_equal(o1[f], o2[f]), f
     for n in COUNTERS:
         assert c1[n] == c2[n], n
+
+
+def test_composite_batch(big):
+    """A batch split into concurrent sub-batches (CMB_SUBBATCHES; automatic from 10^6 reads) returns the same
+    per-read lists and the same counters as the same batch run in one piece."""
+    sub = big["reads"][:50_001]
+    o1, f1, c1 = _run(big["dev"], sub)
+    os.environ["CMB_SUBBATCHES"] = "3"
+    try:
+        o2, f2, c2 = _run(big["dev"], sub)
+    finally:
+        del os.environ["CMB_SUBBATCHES"]
+    assert np.array_equal(f1, f2)
+    for f in ("begin", "end", "distance", "strand"):
+        assert np.array_equal(o1[f], o2[f]), f
+    for n in COUNTERS:
+        assert c1[n] == c2[n], n

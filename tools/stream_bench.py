@@ -7,8 +7,11 @@ from columba_amd import indexbuild as ib, synth
 n = int(sys.argv[1]); nreads = int(sys.argv[2])
 g, starts = synth.genome_human_like(n, seed=2025, device="cuda")
 ix = ib.build_index(g, seq_starts=starts, device="cuda", with_bwt=False)
+del g
+torch.cuda.empty_cache()
 dev = ca.Index(ix)
 buf, offs = synth.sample_reads_fast(ix.text[:-1], nreads, 150, seed=3, device="cuda")
+torch.cuda.empty_cache()
 st = ca.SearchStrategy("multiple_opt", "edit", "dynamic")
 for S in [int(x) for x in sys.argv[3:]]:
     per = nreads // S
