@@ -1,15 +1,18 @@
 """Per-kernel HBM traffic of ONE bench step from the rocprofv3 --pmc passes of tools/profile_round.sh.
 
-    python tools/pmc_traffic.py <bench_line.json> <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass>  > *_pmc_traffic.json
+    python tools/pmc_traffic.py <bench_line.json> <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> [steps run]  > *_pmc_traffic.json
 
 FETCH_SIZE / WRITE_SIZE are collected in separate passes (they do not fit one pass, MI355X_MICROARCH.md) of
-`bench.py --steps 1 --warmup 0`, so the sums over all dispatches of a kernel are per step.  Units: KiB.
+`bench.py --steps 1 --warmup 0`, which runs the hot path TWICE (one timed step + the serial step its kernel table
+comes from): the sums over all dispatches of a kernel are divided by the number of steps run.  Units: KiB.
 bench.py (load_traffic) applies the gfx950 correction (FETCH_SIZE x 2) when it reports `roofline.traffic`."""
 import collections, csv, glob, json, sys
 
 line = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+steps_run = float(sys.argv[4]) if len(sys.argv) > 4 else 2.0
 out = {"workload": {k: line["config"][k] for k in ("genome_bp", "reads_per_gpu", "read_len", "k")},
-       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one pass each, bench.py --steps 1 --warmup 0",
+       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one pass each, bench.py --steps 1 --warmup 0 "
+                 "(sub-batches one after the other); per step",
        "kernels": collections.defaultdict(dict)}
 for d, name in ((sys.argv[2], "FETCH_SIZE"), (sys.argv[3], "WRITE_SIZE")):
     for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
@@ -24,6 +27,6 @@ for d, name in ((sys.argv[2], "FETCH_SIZE"), (sys.argv[3], "WRITE_SIZE")):
             agg[k] += float(r["Counter_Value"])
             calls[k] += 1
         for k, v in agg.items():
-            out["kernels"][k][name + "_KiB"] = round(v, 1)
-            out["kernels"][k]["dispatches"] = calls[k]
+            out["kernels"][k][name + "_KiB"] = round(v / steps_run, 1)
+            out["kernels"][k]["dispatches_per_step"] = calls[k] / steps_run
 print(json.dumps(out, indent=1))
