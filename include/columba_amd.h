@@ -140,7 +140,12 @@ int cmb_match_batch(cmb_index* idx, const cmb_strategy* st, uint32_t max_distanc
                     uint64_t* out_offs /* [n_reads+1] */, uint64_t* counters /* [CMB_CNT_MAX] or NULL */,
                     uint64_t* needed);
 
-/* Resident-batch entries (what bench.py times: reads already in HBM when the timed region starts). */
+/* Resident-batch entries (what bench.py times: reads already in HBM when the timed region starts).
+ * A batch of 2 M reads or more is held as 2-3 sub-batches that cmb_batch_run processes concurrently (own HIP
+ * stream and host thread each; environment CMB_SUBBATCHES=n overrides the number, CMB_SERIAL_SUBBATCHES runs
+ * them one after the other); results and counters are those of the whole batch, in read order.
+ * cmb_batch_timings: device time per kernel group of the last run (HIP events on the batch's streams; summed
+ * over the sub-batches). */
 int cmb_batch_create(cmb_index* idx, const cmb_strategy* st, uint32_t max_distance, const char* seqs,
                      const uint64_t* offs, uint32_t n_reads, cmb_batch** out);
 int cmb_batch_run(cmb_batch* b);  /* enqueue + wait: the whole hot path on the batch's stream */
