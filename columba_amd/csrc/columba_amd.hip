@@ -299,7 +299,7 @@ struct cmb_batch {
     DevBuf<TextOccRec> text;
     DevBuf<uint4> fout;
     DevBuf<unsigned long long> keysA, keysB;
-    DevBuf<uint32_t> fcounts;
+    DevBuf<uint32_t> fcounts, fsegB, fsegE;
     DevBuf<uint64_t> foffs;
     DevBuf<unsigned long long> fmKeysA, fmKeysB;
     DevBuf<uint32_t> fmIdxA, fmIdxB, fmN;
@@ -932,6 +932,8 @@ static int batchRunOne(cmb_batch* b) {
             if (b->fcounts.n < (size_t)nReads + 1) {
                 b->fcounts.alloc((size_t)nReads + 1);
                 b->foffs.alloc((size_t)nReads + 1);
+                b->fsegB.alloc((size_t)nReads + 1);
+                b->fsegE.alloc((size_t)nReads + 1);
             }
             if (nText) {
                 hipLaunchKernelGGL(k_pack_keys, dim3((nText + 255) / 256), dim3(256), 0, s, b->text.p, nText, b->offs.p,
@@ -943,8 +945,13 @@ static int batchRunOne(cmb_batch* b) {
             }
             const int mode = b->k == 0 ? 0 : (b->metric == CMB_METRIC_HAMMING ? 1 : 2);
             HIPCHK(hipMemsetAsync(b->fcounts.p, 0, ((size_t)nReads + 1) * sizeof(uint32_t), s));
+            HIPCHK(hipMemsetAsync(b->fsegB.p, 0xFF, ((size_t)nReads + 1) * sizeof(uint32_t), s));
+            if (nText)
+                hipLaunchKernelGGL(k_filter_segments, dim3((nText + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->fsegB.p,
+                                   b->fsegE.p);
             hipLaunchKernelGGL(k_filter<false>, dim3((nReads + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->offs.p,
-                               nReads, b->k, mode, b->fcounts.p, (const uint64_t*)nullptr, (uint4*)nullptr);
+                               nReads, b->k, mode, b->fcounts.p, (const uint64_t*)nullptr, (uint4*)nullptr, b->fsegB.p,
+                               b->fsegE.p);
             size_t scanBytes = 0;
             HIPCHK(rocprim::exclusive_scan(nullptr, scanBytes, b->fcounts.p, b->foffs.p, (uint64_t)0, (size_t)nReads + 1,
                                            rocprim::plus<uint64_t>(), s));
@@ -960,7 +967,7 @@ static int batchRunOne(cmb_batch* b) {
             if (b->fout.n < total) b->fout.alloc((size_t)total + total / 8 + 256);
             if (total)
                 hipLaunchKernelGGL(k_filter<true>, dim3((nReads + 255) / 256), dim3(256), 0, s, b->keysB.p, nText,
-                                   b->offs.p, nReads, b->k, mode, b->fcounts.p, b->foffs.p, b->fout.p);
+                                   b->offs.p, nReads, b->k, mode, b->fcounts.p, b->foffs.p, b->fout.p, b->fsegB.p, b->fsegE.p);
             HIPCHK(hipGetLastError());
             tm.end("k_filter");
             lap("filter");

@@ -1241,31 +1241,34 @@ k_pack_keys(const TextOccRec* __restrict__ text, uint32_t n, const uint64_t* __r
               ((unsigned long long)(wrel & 15u) << 1) | (unsigned long long)(t.rsId & 1u);
 }
 
+// segment of every read in the sorted keys: segBeg[r] = first key of read r (one coalesced pass; reads without
+// occurrences keep the 0xFFFFFFFF the array was filled with and are skipped by k_filter)
+__global__ void k_filter_segments(const unsigned long long* __restrict__ keys, uint32_t n, uint32_t* __restrict__ segBeg,
+                                  uint32_t* __restrict__ segEnd) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = keys[i];
+    if (key == ~0ull) return; // holes sort behind every read
+    const uint32_t r = (uint32_t)(key >> 40);
+    if (i == 0 || (uint32_t)(keys[i - 1] >> 40) != r) segBeg[r] = i;
+    if (i + 1 == n || keys[i + 1] == ~0ull || (uint32_t)(keys[i + 1] >> 40) != r) segEnd[r] = i + 1;
+}
+
 // mode 0: k = 0 (no filtering, searchstrategy.cpp:499-510); 1: Hamming (unique only); 2: edit distance
 // WRITE = false: count the surviving occurrences of every read; true: write them at outOffs[read].
 template <bool WRITE>
 __global__ void __launch_bounds__(256)
 k_filter(const unsigned long long* __restrict__ keys, uint32_t n, const uint64_t* __restrict__ offs, uint32_t nReads,
          uint32_t k, int mode, uint32_t* __restrict__ counts, const uint64_t* __restrict__ outOffs,
-         uint4* __restrict__ out) {
+         uint4* __restrict__ out, const uint32_t* __restrict__ segBeg, const uint32_t* __restrict__ segEnd) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nReads) return;
-    // segment of read r: [lower_bound(r << 40), lower_bound((r+1) << 40))
-    const unsigned long long klo = (unsigned long long)r << 40, khi = (unsigned long long)(r + 1) << 40;
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (keys[mid] < klo) lo = mid + 1;
-        else hi = mid;
+    const uint32_t segLo = segBeg[r];
+    if (segLo == 0xFFFFFFFFu) { // no occurrence of this read
+        if (!WRITE) counts[r] = 0;
+        return;
     }
-    const uint32_t segLo = lo;
-    hi = n;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (keys[mid] < khi) lo = mid + 1;
-        else hi = mid;
-    }
-    const uint32_t segHi = lo;
+    const uint32_t segHi = segEnd[r];
     const uint32_t len = (uint32_t)(offs[r + 1] - offs[r]);
     const uint32_t wbase = len - k;
     uint32_t nOut = 0;
