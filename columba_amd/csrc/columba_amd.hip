@@ -537,7 +537,6 @@ static int batchRunOne(cmb_batch* b) {
         Queues q{};
         q.cnt = b->cnt.p;
         q.counters = b->counters.p;
-        q.dbg = getenv("CMB_DEBUG") ? (uint32_t)atoi(getenv("CMB_DEBUG")) : 0u;
 
         HIPCHK(hipMemsetAsync(b->counters.p, 0, CMB_CNT_MAX * sizeof(unsigned long long), s));
         tm.begin();

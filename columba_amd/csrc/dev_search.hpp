@@ -70,9 +70,8 @@ struct Queues {
     uint32_t fmCap;
     TextOccRec* text;
     uint32_t textCap;
-    uint32_t* cnt; // [0] items, [1] fm, [2] text, [3] flags, [4] work counter, [5] dfs tasks, [6] dfs work counter
+    uint32_t* cnt; // [0] items, [1] fm, [2] text, [3] flags, [5] search tasks, [7] traceback tasks
     unsigned long long* counters; // CMB_CNT_MAX
-    uint32_t dbg;                 // development knobs (CMB_DEBUG), 0 in production
 };
 
 } // namespace cmb
