@@ -625,7 +625,7 @@ static int batchRunOne(cmb_batch* b) {
                     }
                     b->bfsQCap = std::max<size_t>(b->bfsQCap, (size_t)nDfs + 1024);
                     for (int j = 0; j < 2; j++) {
-                        if (b->bfsQ[j].n < 5 * b->bfsQCap) b->bfsQ[j].alloc(5 * b->bfsQCap);
+                        if (b->bfsQ[j].n < 4 * b->bfsQCap) b->bfsQ[j].alloc(4 * b->bfsQCap);
                         if (b->bfsEv[j].n < b->bfsEvCap) b->bfsEv[j].alloc(b->bfsEvCap);
                     }
                     if (b->bfsF.n < 4 * b->bfsFCap) b->bfsF.alloc(4 * b->bfsFCap);
@@ -644,7 +644,7 @@ static int batchRunOne(cmb_batch* b) {
                     B.F = b->bfsF.p;
                     B.C = b->bfsC.p;
                     B.A = b->bfsA.p;
-                    B.qCap = (uint32_t)std::min<size_t>(b->bfsQ[0].n / 5, 0xFFFFFFF0u);
+                    B.qCap = (uint32_t)std::min<size_t>(b->bfsQ[0].n / 4, 0xFFFFFFF0u);
                     B.evCap = (uint32_t)std::min<size_t>(b->bfsEv[0].n, 0xFFFFFFF0u);
                     B.fCap = (uint32_t)std::min<size_t>(b->bfsF.n / 4, 0xFFFFFFF0u);
                     B.cCap = (uint32_t)std::min<size_t>(b->bfsC.n / CTX_U4, 0xFFFFFFF0u);

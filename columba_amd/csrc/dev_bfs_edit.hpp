@@ -46,8 +46,8 @@ constexpr uint32_t BFS_STOP = FLAG_BFS_Q | FLAG_BFS_EV | FLAG_BFS_F | FLAG_BFS_C
                               FLAG_FMOCC_OVERFLOW | FLAG_CAPACITY;
 
 struct BfsBufs {
-    uint4* Q[2];  // frontier nodes, 5 planes of qCap: {ranges} {row | score << 16, ctx, fc, -} {HP, HN} {RAC, -}
-                  // {final-column distances of the path: only for nodes in the final column}
+    uint4* Q[2];  // frontier nodes, 4 planes of qCap: {ranges} {row | score << 16, ctx, fc, RAC bit} {HP, HN}
+                  // {final-column distances of the path: only touched for nodes in the final column}
     uint4* Ev[2]; // events {ctx, F index of the node that ended its path, remaining-descendants index | -1, cell}
     uint4* F;     // final-column records, 4 x 16 B: {ranges} {depth | c << 16, parent, reported, -} {edit distances}
     uint4* C;     // contexts, CTX_U4 x 16 B
@@ -154,7 +154,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
         uint32_t row1 = 0, ctx = 0, fcP = BFS_NONE, rsId = 0, itMeta = 0, cell = 0;
         EdPack pack{0, 0};
         if (act) {
-            const uint4 n0 = Qi[i], n1 = Qi[(size_t)qCap + i], n2 = Qi[(size_t)2 * qCap + i], n3 = Qi[(size_t)3 * qCap + i];
+            const uint4 n0 = Qi[i], n1 = Qi[(size_t)qCap + i], n2 = Qi[(size_t)2 * qCap + i];
             ctx = n1.y;
             fcP = n1.z;
             const uint32_t row = n1.x & 0xFFFFu, score = n1.x >> 16;
@@ -165,7 +165,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
             const uint4 hot = Cx[5]; // everything the expansion needs of its context, in ONE 16-byte request
             const uint4 mA = Cx[8 + 2 * blk], mB = Cx[9 + 2 * blk];
             uint4 fp = make_uint4(0, 0, 0, 0);
-            if (fcP != BFS_NONE) fp = Qi[(size_t)4 * qCap + i]; // final-column distances of the path so far
+            if (fcP != BFS_NONE) fp = Qi[(size_t)3 * qCap + i]; // final-column distances of the path so far
             const uint32_t dir = (hot.x >> 27) & 1u, uni = (hot.x >> 28) & 1u;
             const int md = uni ? 2 : (dir == 0 ? 0 : 1);
             const RangePair parent{{n0.x, n0.y}, {n0.z, n0.w}};
@@ -183,7 +183,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
             const uint32_t clSize = hot.w >> 23;
             const uint32_t itMode = (hot.x >> 25) & 3u; // 0: phase 0 (no switch), 1: start difference fixed, 2: BACKWARD
             pack = EdPack{u64of(fp.x, fp.y), u64of(fp.z, fp.w)};
-            const uint64_t pHP = u64of(n2.x, n2.y), pHN = u64of(n2.z, n2.w), pRAC = u64of(n3.x, n3.y);
+            const uint64_t pHP = u64of(n2.x, n2.y), pHN = u64of(n2.z, n2.w), pRAC = 1ull << (n1.w & 63u); // (RAC is always a single bit)
             const bool inFC = g.inFinalColumn(row1);
             cell = clSize + row1 - g.m;
             if (inFC && cell >= ED_CELLS) { // (a row beyond the matrix: cannot happen for a well-formed phase)
@@ -268,14 +268,13 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
                 if (kd == 1) {
                     const uint32_t o = oNode++;
                     Qo[o] = cr[c];
-                    Qo[(size_t)qCap + o] = make_uint4(row1 | (cw[c] << 16), ctx, fc, 0u);
+                    Qo[(size_t)qCap + o] = make_uint4(row1 | (cw[c] << 16), ctx, fc, (uint32_t)__ffsll((unsigned long long)cRAC[c]) - 1u);
                     Qo[(size_t)2 * qCap + o] = make_uint4((uint32_t)cHP[c], (uint32_t)(cHP[c] >> 32), (uint32_t)cHN[c],
                                                           (uint32_t)(cHN[c] >> 32));
-                    Qo[(size_t)3 * qCap + o] = make_uint4((uint32_t)cRAC[c], (uint32_t)(cRAC[c] >> 32), 0u, 0u);
                     if (needF & (1u << c)) {
                         EdPack p2 = pack;
                         edPut(p2, cell, cEd[c]);
-                        Qo[(size_t)4 * qCap + o] = make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32));
+                        Qo[(size_t)3 * qCap + o] = make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32));
                     }
                 } else if (kd == 2) {
                     Eo[oEv++] = make_uint4(ctx, fc, 0xFFFFFFFFu, cell);
@@ -629,7 +628,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
 
         // ---- phase entry: recApproxMatchEdit prologue + replay of the descendants (:377-497)
         uint32_t outKind = 0; // 1: node of the next frontier, 2: event
-        uint4 oN0 = make_uint4(0, 0, 0, 0), oN1 = oN0, oN2 = oN0, oN3 = oN0, oN4 = oN0, oEv = oN0;
+        uint4 oN0 = make_uint4(0, 0, 0, 0), oN1 = oN0, oN2 = oN0, oN4 = oN0, oEv = oN0;
         if (enter) {
             if (descSelf) descRefN = cNew;
             if (otherSelf) otherRefN = cNew;
@@ -787,9 +786,8 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                 if (live) {
                     outKind = 1;
                     oN0 = make_uint4(root.sa.b, root.sa.e, root.rev.b, root.rev.e);
-                    oN1 = make_uint4(rootRow | (score << 16), cNew, fcCur, 0u);
+                    oN1 = make_uint4(rootRow | (score << 16), cNew, fcCur, (uint32_t)__ffsll((unsigned long long)RAC) - 1u);
                     oN2 = make_uint4((uint32_t)HP, (uint32_t)(HP >> 32), (uint32_t)HN, (uint32_t)(HN >> 32));
-                    oN3 = make_uint4((uint32_t)RAC, (uint32_t)(RAC >> 32), 0u, 0u);
                     oN4 = make_uint4((uint32_t)pk.lo, (uint32_t)(pk.lo >> 32), (uint32_t)pk.hi, (uint32_t)(pk.hi >> 32));
                 }
             }
@@ -804,8 +802,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                 Qo[oN] = oN0;
                 Qo[(size_t)qCap + oN] = oN1;
                 Qo[(size_t)2 * qCap + oN] = oN2;
-                Qo[(size_t)3 * qCap + oN] = oN3;
-                Qo[(size_t)4 * qCap + oN] = oN4;
+                Qo[(size_t)3 * qCap + oN] = oN4;
             }
         } else if (outKind == 2) {
             if (oE >= B.evCap) flags |= FLAG_BFS_EV;
