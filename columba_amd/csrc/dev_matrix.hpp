@@ -104,14 +104,37 @@ __device__ __forceinline__ bool computeRow(const MatGeom& g, uint32_t i, uint64_
     const uint32_t diagBit = l + MX_DIAG;
     score += (D0 & (1ull << diagBit)) ? 0u : 1u;
     if (!(D0 & RAC)) {
-        uint32_t val = 1u;
-        const uint64_t stop = 1ull << (diagBit - g.Wv);
-        while (val > 0) {
-            if (HP & RAC) val--;
-            if (HN & RAC) val++;
-            if (RAC == stop) return false;
-            RAC >>= 1u;
+        // The reference walks left from the RAC column, one column per iteration, until the running value
+        // (1, -1 per HP bit, +1 per HN bit) reaches zero, and gives up at column diagBit - Wv (:400-412).  The walk
+        // spans at most Wh + Wv <= 30 columns: it is done on 32-bit windows of HP / HN whose bit 31 is the RAC
+        // column.  Almost always the first HP bit ends it (no HN bit before it): that case needs no loop.
+        const uint32_t q = (uint32_t)__ffsll((unsigned long long)RAC) - 1u;
+        const uint32_t maxSteps = q - (diagBit - g.Wv); // the walk fails if it is still running at this step
+        uint32_t hp, hn;
+        if (q >= 31u) {
+            hp = (uint32_t)(HP >> (q - 31u));
+            hn = (uint32_t)(HN >> (q - 31u));
+        } else {
+            hp = (uint32_t)HP << (31u - q);
+            hn = (uint32_t)HN << (31u - q);
         }
+        const uint32_t p1 = hp ? (uint32_t)__clz(hp) : 32u; // steps before the first HP bit
+        if (p1 >= maxSteps) return false;                    // (the value cannot reach zero before the stop column)
+        uint32_t k = p1;
+        if (p1 != 0u && (hn >> (32u - p1)) != 0u) { // HN bits before it: the general walk
+            uint32_t val = 1u;
+            k = 0;
+            for (;;) {
+                val += (hn >> 31) - (hp >> 31);
+                if (val == 0u) break;
+                if (k == maxSteps) return false;
+                hp <<= 1;
+                hn <<= 1;
+                k++;
+            }
+            if (k >= maxSteps) return false; // (zero reached AT the stop column still fails, :408)
+        }
+        RAC = 1ull << (q - k - 1u);
     }
     return true;
 }
