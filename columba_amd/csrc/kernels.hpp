@@ -544,9 +544,11 @@ struct VPlanes {
     uint32_t nSlots, lines;
 };
 constexpr uint32_t TB_BELOW = 18;
-__device__ __forceinline__ uint64_t packTraceRow(uint32_t r, uint64_t HP, uint64_t D0) {
+// low half: HP; high half: M | ~D0 — "the diagonal step is allowed" (bitparallelmatrix.h:559-562), folded in by the
+// forward pass, which has the row's match word at hand: the trace then needs neither the text nor match words.
+__device__ __forceinline__ uint64_t packTraceRow(uint32_t r, uint64_t HP, uint64_t diagOk) {
     const uint32_t sh = (r % MX_BLOCK) + MX_DIAG - TB_BELOW;
-    return (uint64_t)(uint32_t)(HP >> sh) | ((uint64_t)(uint32_t)(D0 >> sh) << 32);
+    return (uint64_t)(uint32_t)(HP >> sh) | ((uint64_t)(uint32_t)(diagOk >> sh) << 32);
 }
 
 __device__ __forceinline__ void emitText(const Queues& q, uint32_t& flags, uint32_t rsId, uint32_t b, uint32_t e,
@@ -672,7 +674,7 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
                 const uint64_t M = Ml[tc * 256 + tid];
                 cRows++;
                 const bool valid = computeRow(g, r, M, HP, HN, D0, RAC, score);
-                if (STORE) buf[t & 7u] = packTraceRow(r, HP, D0);
+                if (STORE) buf[t & 7u] = packTraceRow(r, HP, M | ~D0);
                 if (!valid) {
                     alive = false;
                 } else {
@@ -1093,12 +1095,8 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                 const uint32_t ri = firstRow + 1 + bitIdx;
                 uint32_t ti = ri, tj = col;
                 uint32_t curG = 0xFFFFFFFFu; // the line (rows 8 g + 1 .. 8 g + 8) held in wW[.][tid]
-                uint32_t txLo = 0, txHi = 0;  // ... and the text codes of those rows
-                uint32_t curB = 0xFFFFFFFFu;
-                uint64_t Mblk[4] = {0, 0, 0, 0};
                 while (tj > 0) {
-                    uint64_t ww = packTraceRow(0, HP0, 0ull); // row 0
-                    uint32_t tcRow = 4;
+                    uint64_t ww = packTraceRow(0, HP0, 0ull); // row 0 (never steps diagonally: ti > 0 below)
                     if (ti > 0) {
                         const uint32_t gq = (ti - 1) >> 3, jq = (ti - 1) & 7u;
                         if (gq != curG) {
@@ -1110,39 +1108,19 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                                 wW[2 * h][tid] = (uint64_t)v.x | ((uint64_t)v.y << 32);
                                 wW[2 * h + 1][tid] = (uint64_t)v.z | ((uint64_t)v.w << 32);
                             }
-                            const Unaligned8 tv = *reinterpret_cast<const Unaligned8*>(ix.text + start + 8 * gq);
-                            txLo = tv.x;
-                            txHi = tv.y;
                         }
                         ww = wW[jq][tid];
-                        tcRow = ((jq < 4 ? txLo : txHi) >> (8 * (jq & 3u))) & 0xFFu;
                     }
-                    const uint32_t b = ti / MX_BLOCK;
-                    const uint64_t bit = 1ull << ((tj - b * MX_BLOCK) + MX_DIAG);
                     const uint32_t rel = tj + TB_BELOW - ti; // bit of the row's packed windows
                     if (rel > 31u) { // outside the stored window: cannot happen inside the band (checked, not assumed)
                         flags |= FLAG_CAPACITY;
                         break;
                     }
-                    if (((uint32_t)ww >> rel) & 1u) {
+                    if (((uint32_t)ww >> rel) & 1u) { // gap in horizontal (:553)
                         --tj;
                     } else {
-                        bool diag = false;
-                        if (ti > 0) {
-                            if (b != curB) { // match words of this 32-row block (bitparallelmatrix.h:559)
-                                curB = b;
-                                loadMatchWords(mf, rs, b, Mblk);
-                            }
-                            const uint32_t tc = tcRow;
-                            const uint64_t M = tc == 0 ? Mblk[0] : tc == 1 ? Mblk[1] : tc == 2 ? Mblk[2] : tc == 3 ? Mblk[3] : 0ull;
-                            diag = (M & bit) != 0 || (((uint32_t)(ww >> 32) >> rel) & 1u) == 0;
-                        }
-                        if (diag) {
-                            --ti;
-                            --tj;
-                        } else {
-                            --ti;
-                        }
+                        if (ti > 0 && (((uint32_t)(ww >> 32) >> rel) & 1u)) --tj; // diagonal (:559); else vertical
+                        --ti;
                     }
                 }
                 const uint32_t ed = bitIdx < 21u ? (uint32_t)((edPack >> (3u * bitIdx)) & 7ull)
