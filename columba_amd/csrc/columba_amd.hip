@@ -583,10 +583,13 @@ static int batchRunOne(cmb_batch* b) {
                     b->exr.alloc((size_t)pParts * tasks);
                     b->psel.alloc(tasks);
                 }
-                hipLaunchKernelGGL(k_parts, dim3(pSlots / 256), dim3(256),
+                {
+                    auto kp = b->hostStrat.partition == 0 ? k_parts<0> : b->hostStrat.partition == 1 ? k_parts<1> : k_parts<2>;
+                    hipLaunchKernelGGL(kp, dim3(pSlots / 256), dim3(256),
                                    stratBytes + (5 * pParts + rdWords) * 256 * sizeof(uint32_t), s, ix->d, b->strat.p, nReads,
                                    b->k, b->maxLen, b->seq.p, (const uint4*)b->rec.p, b->recW / 4, b->parts.p, b->exr.p,
                                    b->psel.p, q);
+                }
                 uint32_t maxSearches = 0;
                 for (int i = 0; i < b->hostStrat.nSchemes; i++)
                     maxSearches = std::max<uint32_t>(maxSearches, b->hostStrat.sch[i].nSearches);

@@ -33,6 +33,10 @@ enum : int { PH_CALC = 0, PH_DYN, PH_SEED, PH_FIN, PH_DONE };
 // what a lane asks of the iteration's single memory step
 enum : int { RQ_NONE = 0, RQ_RANK, RQ_SEED, RQ_REC };
 
+// PARTITION: 0 uniform, 1 static, 2 dynamic (searchstrategy.h PartitionStrategy) — a template parameter, so that
+// each k_parts instance only carries the phases of its own mode (the extension loop of the dynamic mode is a
+// third of the instructions of the generic one).
+template <int PARTITION>
 struct PartMachine {
     const DevIndex& ix;
     const DevStrategyK& st;
@@ -168,7 +172,7 @@ struct PartMachine {
             return;
         }
         const uint32_t L = len;
-        if (st.partition == 0) { // partitionUniform (:194-209)
+        if (PARTITION == 0) { // partitionUniform (:194-209)
             for (int i = 0; i < numParts; i++) {
                 const uint32_t b = (uint32_t)((i * 1.0 / numParts) * L);
                 uint32_t e = (uint32_t)(((i + 1) * 1.0 / numParts) * L);
@@ -177,7 +181,7 @@ struct PartMachine {
             setPE(numParts - 1, L);
             startCalcPart(0);
             phase = PH_CALC;
-        } else if (st.partition == 1) { // setParts (:221-238)
+        } else if (PARTITION == 1) { // setParts (:221-238)
             const int pSize = (int)L;
             const double* bg = st.begins;
             setPBE(0, 0, (uint32_t)(bg[0] * pSize) & 0xFFFFu);
@@ -263,8 +267,7 @@ struct PartMachine {
     // ---- one scheduling step: runs until an extension is requested or the task is finished ----
     __device__ void advance() {
         for (;;) {
-            switch (phase) {
-            case PH_CALC: {
+            if (PARTITION != 2 && phase == PH_CALC) {
                 const int part = pi < numParts ? pi : numParts - 1;
                 if (ci < cend) {
                     const uint32_t code = charAt(cb, ce, cdir, ci);
@@ -280,12 +283,12 @@ struct PartMachine {
                 } else {
                     phase = PH_FIN;
                 }
-                break;
+                continue;
             }
-            case PH_DYN: { // partitionDynamic loop body (:324-378)
+            if (PARTITION == 2 && phase == PH_DYN) { // partitionDynamic loop body (:324-378)
                 if (j >= len) {
                     phase = PH_FIN;
-                    break;
+                    continue;
                 }
                 uint64_t maxRangeWeighted = 0;
                 {
@@ -320,7 +323,7 @@ struct PartMachine {
                         if (i != 0 && PB(i) != PE(i - 1)) setPB(i, PE(i - 1));
                     }
                     phase = PH_FIN;
-                    break;
+                    continue;
                 }
                 uint32_t code;
                 if (dynDir == 0) {
@@ -338,11 +341,9 @@ struct PartMachine {
                     return;
                 }
                 setEX(partToExtend, RangePair{{0, 0}, {0, 0}});
-                break;
+                continue;
             }
-            default: // PH_FIN (outputs are written by the kernel), PH_SEED, PH_DONE
-                return;
-            }
+            return; // PH_FIN (outputs are written by the kernel), PH_SEED, PH_DONE
         }
     }
 

@@ -301,6 +301,7 @@ __device__ __forceinline__ bool takeExtend(const DevIndex& ix, int mode, const R
 // (the partitioning of every read costs about the same).  Every loop iteration has ONE memory step: each lane
 // issues the loads of its request — the two rank blocks of an extension (8 x 16 B from 2 lines), the k-mer
 // table entries of its seeds, or its read record — before any reply is consumed.
+template <int PARTITION>
 __global__ void __launch_bounds__(256, 4)
 k_parts(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint32_t k, uint32_t maxLen,
         const uint8_t* __restrict__ seq, const uint4* __restrict__ rec, uint32_t recQ, PartOut* __restrict__ parts,
@@ -313,7 +314,7 @@ k_parts(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
         partLds[i] = reinterpret_cast<const uint32_t*>(stp)[i];
     __syncthreads();
     const DevStrategyK& lst = *reinterpret_cast<const DevStrategyK*>(partLds);
-    PartMachine m(ix, lst, partLds + STRAT_WORDS, threadIdx.x, blockDim.x);
+    PartMachine<PARTITION> m(ix, lst, partLds + STRAT_WORDS, threadIdx.x, blockDim.x);
     m.setReadWords(maxLen);
     const uint32_t total = 2 * nReads;
     // Lock-step batches: every lane of the wavefront takes one read x strand, all load their read records, all
