@@ -825,7 +825,8 @@ static int batchRunOne(cmb_batch* b) {
                     b->vcounts.alloc((size_t)nItems + nItems / 8 + 256);
                     b->vruns.alloc(4);
                 }
-                hipLaunchKernelGGL(k_verify, dim3(vSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->maxLen, b->gw,
+                auto kv = dedup ? k_verify<true> : k_verify<false>;
+                hipLaunchKernelGGL(kv, dim3(vSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->maxLen, b->gw,
                                    b->seq.p, mf, b->items.p, nItems, b->tbq.p, tbCap,
                                    dedup ? b->vkeysA.p : (unsigned long long*)nullptr, q);
                 if (dedup) {
@@ -1235,7 +1236,7 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         mf.p = mfull.p;
         uint32_t hc[8];
         if (n) {
-            hipLaunchKernelGGL(k_verify, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, mlen, gw, seq.p, mf,
+            hipLaunchKernelGGL(k_verify<false>, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, mlen, gw, seq.p, mf,
                                items.p, (uint32_t)n, tbq.p, (uint32_t)tbq.n, (unsigned long long*)nullptr, q);
             HIPCHK(hipMemcpy(hc, cnt.p, 32, hipMemcpyDeviceToHost));
             if (hc[7])

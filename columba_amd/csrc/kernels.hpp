@@ -763,6 +763,9 @@ __device__ __forceinline__ bool verifyEdit(const DevIndex& ix, const uint64_t* o
 
 // pass 1: locate + verify.  Exact / Hamming candidates produce text occurrences directly; edit-distance
 // candidates whose final column holds cluster centres become traceback tasks {rs, start, mask, meta}.
+// KEYS: edit-distance candidates only get their verification key (the batch path; the matrix runs in
+// k_verify_stage) — that instance carries no matrix code and keeps twice the wavefronts in flight for the locate.
+template <bool KEYS>
 __global__ void __launch_bounds__(256)
 k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32_t gw,
          const uint8_t* __restrict__ seq, MFull mf, const uint4* __restrict__ items,
@@ -844,7 +847,7 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
                 const uint32_t startDiff = a;
                 const uint32_t sum = pos + shift; // getBeginPositions (fmindex.h:374-379)
                 const uint32_t start = sum >= startDiff ? sum - startDiff : 0;
-                if (vkeys) { // verified once per distinct key by k_verify_edit
+                if (KEYS) { // verified once per distinct key by k_verify_stage
                     vkey = packVerifyKey(rs, start, maxED, minED, fixed);
                 } else if (verifyEdit(ix, offs, mf, rs, start, maxED, minED, fixed, 1u, cStarted, cRows, cText, cAbort,
                                       cCig, tbRec, Ml)) {
@@ -852,7 +855,7 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
                 }
             }
         }
-        if (vkeys && it < nItems) vkeys[it] = vkey;
+        if (KEYS && it < nItems) vkeys[it] = vkey;
         // ---- appends into the wavefront's chunks of the two output queues
         cRep += nOut;
         const uint32_t o1 = chT.alloc(&q.cnt[2], q.textCap, nOut, 256u, ovT, holeT);
