@@ -299,7 +299,7 @@ struct cmb_batch {
     DevBuf<TextOccRec> text;
     DevBuf<uint4> fout;
     DevBuf<unsigned long long> keysA, keysB;
-    DevBuf<uint32_t> fcounts, fsegB, fsegE;
+    DevBuf<uint32_t> fcounts, fsegB, fsegE, frank;
     DevBuf<uint64_t> foffs;
     DevBuf<unsigned long long> fmKeysA, fmKeysB;
     DevBuf<uint32_t> fmIdxA, fmIdxB, fmN;
@@ -952,9 +952,10 @@ static int batchRunOne(cmb_batch* b) {
             if (nText)
                 hipLaunchKernelGGL(k_filter_segments, dim3((nText + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->fsegB.p,
                                    b->fsegE.p);
-            hipLaunchKernelGGL(k_filter<false>, dim3((nReads + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->offs.p,
-                               nReads, b->k, mode, b->fcounts.p, (const uint64_t*)nullptr, (uint4*)nullptr, b->fsegB.p,
-                               b->fsegE.p);
+            if (b->frank.n < nText) b->frank.alloc((size_t)nText + nText / 8 + 256);
+            if (nText) HIPCHK(hipMemsetAsync(b->frank.p, 0xFF, (size_t)nText * sizeof(uint32_t), s));
+            hipLaunchKernelGGL(k_filter_mark, dim3((nReads + 255) / 256), dim3(256), 0, s, b->keysB.p, nReads, b->k, mode,
+                               b->fcounts.p, b->frank.p, b->fsegB.p, b->fsegE.p);
             size_t scanBytes = 0;
             HIPCHK(rocprim::exclusive_scan(nullptr, scanBytes, b->fcounts.p, b->foffs.p, (uint64_t)0, (size_t)nReads + 1,
                                            rocprim::plus<uint64_t>(), s));
@@ -969,8 +970,8 @@ static int batchRunOne(cmb_batch* b) {
                 return fail(CMB_ERR_INTERNAL, "occurrence does not fit the filter key (width / distance range)");
             if (b->fout.n < total) b->fout.alloc((size_t)total + total / 8 + 256);
             if (total)
-                hipLaunchKernelGGL(k_filter<true>, dim3((nReads + 255) / 256), dim3(256), 0, s, b->keysB.p, nText,
-                                   b->offs.p, nReads, b->k, mode, b->fcounts.p, b->foffs.p, b->fout.p, b->fsegB.p, b->fsegE.p);
+                hipLaunchKernelGGL(k_filter_write, dim3((nText + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->offs.p,
+                                   b->k, b->frank.p, b->foffs.p, b->fout.p);
             HIPCHK(hipGetLastError());
             tm.end("k_filter");
             lap("filter");

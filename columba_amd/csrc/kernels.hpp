@@ -1237,50 +1237,80 @@ __global__ void k_filter_segments(const unsigned long long* __restrict__ keys, u
 }
 
 // mode 0: k = 0 (no filtering, searchstrategy.cpp:499-510); 1: Hamming (unique only); 2: edit distance
-// WRITE = false: count the surviving occurrences of every read; true: write them at outOffs[read].
-template <bool WRITE>
+// k_filter_mark: one lane per read walks the read's (short) segment of the sorted keys — the redundancy filter
+// (:1447-1485) is sequential in the last occurrence it kept — and gives every key of the segment its rank among
+// the read's surviving occurrences, or NONE.  The first eight keys of the segment are fetched together.
+// k_filter_write: one lane per KEY (coalesced) writes the survivors at offset(read) + rank.
+constexpr uint32_t FILTER_NONE = 0xFFFFFFFFu;
 __global__ void __launch_bounds__(256)
-k_filter(const unsigned long long* __restrict__ keys, uint32_t n, const uint64_t* __restrict__ offs, uint32_t nReads,
-         uint32_t k, int mode, uint32_t* __restrict__ counts, const uint64_t* __restrict__ outOffs,
-         uint4* __restrict__ out, const uint32_t* __restrict__ segBeg, const uint32_t* __restrict__ segEnd) {
+k_filter_mark(const unsigned long long* __restrict__ keys, uint32_t nReads, uint32_t k, int mode,
+              uint32_t* __restrict__ counts, uint32_t* __restrict__ rank, const uint32_t* __restrict__ segBeg,
+              const uint32_t* __restrict__ segEnd) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nReads) return;
     const uint32_t segLo = segBeg[r];
     if (segLo == 0xFFFFFFFFu) { // no occurrence of this read
-        if (!WRITE) counts[r] = 0;
+        counts[r] = 0;
         return;
     }
-    const uint32_t segHi = segEnd[r];
-    const uint32_t len = (uint32_t)(offs[r + 1] - offs[r]);
-    const uint32_t wbase = len - k;
-    uint32_t nOut = 0;
-    const uint64_t obase = WRITE ? outOffs[r] : 0ull;
+    const uint32_t nSeg = segEnd[r] - segLo;
+    unsigned long long first[8];
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) first[j] = j < nSeg ? keys[segLo + j] : 0ull;
+    uint32_t nOut = 0, lastKept = 0;
     const uint32_t maxDiff = 2 * k;
     uint32_t prevBegin = 0xFFFFFFFFu, prevDepth = 0xFFFFFFFFu, prevED = k + 1;
     unsigned long long prevKey = ~0ull;
-    for (uint32_t i = segLo; i < segHi; i++) {
-        const unsigned long long key = keys[i];
+    auto step = [&](uint32_t i, unsigned long long key) {
         const uint32_t begin = (uint32_t)(key >> 8), dist = (uint32_t)(key >> 5) & 7u;
-        const uint32_t width = wbase + ((uint32_t)(key >> 1) & 15u), strand = (uint32_t)key & 1u;
+        const uint32_t width = (uint32_t)(key >> 1) & 15u; // relative to len - k: the same for all keys of a read
+        uint32_t mine = FILTER_NONE;
+        bool keep = true;
         if (mode != 0) {
-            if ((key >> 1) == (prevKey >> 1)) continue; // same range and distance (either strand)
-            prevKey = key;
+            if ((key >> 1) == (prevKey >> 1)) keep = false; // same range and distance (either strand)
+            else prevKey = key;
         }
-        if (mode == 2) {
+        if (keep && mode == 2) {
             const uint32_t diff = begin > prevBegin ? begin - prevBegin : prevBegin - begin;
-            if (diff == 0) continue;
-            if (diff <= maxDiff) {
-                if (dist > prevED || (dist == prevED && width >= prevDepth)) continue;
-                nOut--; // the previous one was worse: replace it
+            if (diff == 0) keep = false;
+            else if (diff <= maxDiff) {
+                if (dist > prevED || (dist == prevED && width >= prevDepth)) keep = false;
+                else {
+                    nOut--; // the previous one was worse: replace it
+                    rank[segLo + lastKept] = FILTER_NONE;
+                }
             }
-            prevBegin = begin;
-            prevED = dist;
-            prevDepth = width;
+            if (keep) {
+                prevBegin = begin;
+                prevED = dist;
+                prevDepth = width;
+            }
         }
-        if (WRITE) out[obase + nOut] = make_uint4(begin, begin + width, dist, strand);
-        nOut++;
-    }
-    if (!WRITE) counts[r] = nOut;
+        if (keep) {
+            mine = nOut++;
+            lastKept = i;
+        }
+        rank[segLo + i] = mine;
+    };
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++)
+        if (j < nSeg) step(j, first[j]);
+    for (uint32_t i = 8; i < nSeg; i++) step(i, keys[segLo + i]);
+    counts[r] = nOut;
+}
+__global__ void __launch_bounds__(256)
+k_filter_write(const unsigned long long* __restrict__ keys, uint32_t n, const uint64_t* __restrict__ offs, uint32_t k,
+               const uint32_t* __restrict__ rank, const uint64_t* __restrict__ outOffs, uint4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t rk = rank[i];
+    if (rk == FILTER_NONE) return;
+    const unsigned long long key = keys[i];
+    const uint32_t r = (uint32_t)(key >> 40);
+    const uint32_t len = (uint32_t)(offs[r + 1] - offs[r]);
+    const uint32_t begin = (uint32_t)(key >> 8), dist = (uint32_t)(key >> 5) & 7u;
+    const uint32_t width = len - k + ((uint32_t)(key >> 1) & 15u), strand = (uint32_t)key & 1u;
+    out[outOffs[r] + rk] = make_uint4(begin, begin + width, dist, strand);
 }
 
 } // namespace cmb
