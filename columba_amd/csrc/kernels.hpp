@@ -552,16 +552,6 @@ __device__ __forceinline__ uint64_t packTraceRow(uint32_t r, uint64_t HP, uint64
     return (uint64_t)(uint32_t)(HP >> sh) | ((uint64_t)(uint32_t)(diagOk >> sh) << 32);
 }
 
-__device__ __forceinline__ void emitText(const Queues& q, uint32_t& flags, uint32_t rsId, uint32_t b, uint32_t e,
-                                         uint32_t d) {
-    const uint32_t base = atomicAdd(&q.cnt[2], 1u);
-    if (base >= q.textCap) {
-        flags |= FLAG_TEXT_OVERFLOW;
-        return;
-    }
-    q.text[base] = TextOccRec{rsId, b, e, d};
-}
-
 // The device copy of the text holds CODES, one byte per character: A,C,G,T -> 0..3, anything else ('$',
 // the padding behind the text) -> 4 (k_encode_text at index creation).
 __global__ void k_encode_text(uint8_t* __restrict__ text, uint64_t n, uint64_t nPadded) {
@@ -1178,16 +1168,31 @@ k_fm_unique(const FMOccRec* __restrict__ fm, const unsigned long long* __restric
     if ((threadIdx.x & 63u) == 0 && rows) atomicAdd(&q.counters[1], rows); // TOTAL_REPORTED_POSITIONS
 }
 
-// in-index occurrences (already de-duplicated per read) -> text occurrences
+// in-index occurrences (already de-duplicated per read) -> text occurrences.  A wavefront reserves the slots of
+// all the SA rows of its 64 occurrences with ONE atomic (prefix sum over the range widths).
 __global__ void __launch_bounds__(256)
 k_fmocc(DevIndex ix, const FMOccRec* __restrict__ recs, uint32_t n, Queues q) {
     uint32_t cLF = 0, cLoc = 0, flags = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const FMOccRec f = recs[i];
-        for (uint32_t row = f.b; row < f.e; row++) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t base = first & ~63u; base < n; base += stride) { // wave-uniform trip count
+        const uint32_t i = base + (threadIdx.x & 63u);
+        FMOccRec f{};
+        uint32_t w = 0;
+        if (i < n) {
+            f = recs[i];
+            w = f.e - f.b;
+        }
+        uint32_t total;
+        const uint32_t o = waveAppend(&q.cnt[2], w, total);
+        if (o + w > q.textCap) {
+            if (w) flags |= FLAG_TEXT_OVERFLOW;
+            continue;
+        }
+        for (uint32_t t = 0; t < w; t++) {
             cLoc++;
-            const uint32_t p = findSA(ix, row, &cLF) + f.shift;
-            emitText(q, flags, f.rsId, p, p + f.depth, f.dist);
+            const uint32_t p = findSA(ix, f.b + t, &cLF) + f.shift;
+            q.text[o + t] = TextOccRec{f.rsId, p, p + f.depth, f.dist};
         }
     }
     const uint32_t local[2] = {cLF, cLoc};
