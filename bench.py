@@ -40,10 +40,10 @@ def log(*a):
 
 
 # kernels behind each timed group of cmb_batch_timings (rocPRIM sorts / scans between them are not attributed)
-GROUP_KERNELS = {"k_prep": ["k_prep"], "k_partition": ["k_parts", "k_exact"],
-                 "k_dfs": ["k_bfs_start", "k_bfs_pass", "k_bfs_finish", "k_dfs_hamming"],
+GROUP_KERNELS = {"k_prep": ["k_prep", "k_match_words"], "k_partition": ["k_parts", "k_exact"],
+                 "k_dfs": ["k_bfs_start", "k_bfs_pass", "k_bfs_finish", "k_hbfs"],
                  "k_verify": ["k_verify"], "k_verify_edit": ["k_verify_stage"], "k_traceback": ["k_traceback"],
-                 "k_fmocc": ["k_fmocc"], "k_filter": ["k_pack_keys", "k_filter"]}
+                 "k_fmocc": ["k_fm_keys", "k_fm_unique", "k_fmocc"], "k_filter": ["k_pack_keys", "k_filter_segments", "k_filter_mark", "k_filter_write"]}
 
 
 def load_traffic(args, genome_bp, reads, group):
