@@ -242,15 +242,18 @@ __device__ __forceinline__ bool extendOne(const DevIndex& ix, int mode, const Ra
 __device__ __forceinline__ bool saMarked(const DevIndex& ix, uint32_t i) {
     return (ix.saBv[i >> 6] >> (i & 63u)) & 1ull;
 }
-__device__ __forceinline__ uint32_t saRank(const DevIndex& ix, uint32_t p) {
+// rank with the bitvector word of position p already at hand (`word` = saBv[p >> 6]); the two interleaved
+// count words of the 512-position block are one aligned 16-byte load
+__device__ __forceinline__ uint32_t saRankW(const DevIndex& ix, uint32_t p, uint64_t word) {
     const uint32_t w = p >> 6, b = p & 63u;
-    const uint32_t q = (w >> 3) * 2;
-    uint64_t rv = ix.saCnt[q];
+    const ulonglong2 c = reinterpret_cast<const ulonglong2*>(ix.saCnt)[w >> 3];
+    uint64_t rv = c.x;
     const uint32_t sub = w & 7u;
-    if (sub) rv += (ix.saCnt[q + 1] >> ((sub - 1u) * 9u)) & 0x1FFull;
+    if (sub) rv += (c.y >> ((sub - 1u) * 9u)) & 0x1FFull;
     const uint64_t lowmask = b ? (~0ull >> (64u - b)) : 0ull;
-    return (uint32_t)rv + (uint32_t)__popcll(ix.saBv[w] & lowmask);
+    return (uint32_t)rv + (uint32_t)__popcll(word & lowmask);
 }
+__device__ __forceinline__ uint32_t saRank(const DevIndex& ix, uint32_t p) { return saRankW(ix, p, ix.saBv[p >> 6]); }
 
 // findLF (fmindex.cpp:47-51): BWT symbol decoded from the cumulative bitvectors
 __device__ __forceinline__ uint32_t findLF(const DevIndex& ix, uint32_t k) {
@@ -272,12 +275,14 @@ __device__ __forceinline__ uint32_t findLF(const DevIndex& ix, uint32_t k) {
 // findSA (fmindex.cpp:53-60); *lf accumulates the number of LF steps
 __device__ __forceinline__ uint32_t findSA(const DevIndex& ix, uint32_t row, uint32_t* lf) {
     uint32_t l = 0;
-    while (!saMarked(ix, row)) {
+    uint64_t word = ix.saBv[row >> 6];
+    while (!((word >> (row & 63u)) & 1ull)) { // not a sampled row
         row = findLF(ix, row);
+        word = ix.saBv[row >> 6];
         l++;
     }
     if (lf) *lf += l;
-    return ix.saSamples[saRank(ix, row)] + l;
+    return ix.saSamples[saRankW(ix, row, word)] + l;
 }
 
 } // namespace cmb
