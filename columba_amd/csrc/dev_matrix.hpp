@@ -110,14 +110,8 @@ __device__ __forceinline__ bool computeRow(const MatGeom& g, uint32_t i, uint64_
         // column.  Almost always the first HP bit ends it (no HN bit before it): that case needs no loop.
         const uint32_t q = (uint32_t)__ffsll((unsigned long long)RAC) - 1u;
         const uint32_t maxSteps = q - (diagBit - g.Wv); // the walk fails if it is still running at this step
-        uint32_t hp, hn;
-        if (q >= 31u) {
-            hp = (uint32_t)(HP >> (q - 31u));
-            hn = (uint32_t)(HN >> (q - 31u));
-        } else {
-            hp = (uint32_t)HP << (31u - q);
-            hn = (uint32_t)HN << (31u - q);
-        }
+        uint32_t hp = (uint32_t)((HP << (63u - q)) >> 32); // bit 31 <- bit q (no branch on q)
+        uint32_t hn = (uint32_t)((HN << (63u - q)) >> 32);
         const uint32_t p1 = hp ? (uint32_t)__clz(hp) : 32u; // steps before the first HP bit
         if (p1 >= maxSteps) return false;                    // (the value cannot reach zero before the stop column)
         uint32_t k = p1;
