@@ -753,6 +753,27 @@ __device__ __forceinline__ bool verifyEdit(const DevIndex& ix, const uint64_t* o
 
 // pass 1: locate + verify.  Exact / Hamming candidates produce text occurrences directly; edit-distance
 // candidates whose final column holds cluster centres become traceback tasks {rs, start, mask, meta}.
+// Four text codes (0..4) against four read codes (1..5, 5 = N): bit 8 b of the result is set iff character b
+// differs — a text code 4 ('$', padding) never matches (verifyInTextExact / inTextVerificationHamming compare
+// characters; '$' is not a read character).
+__device__ __forceinline__ uint32_t mismatch4(uint32_t tw, uint32_t sw) {
+    const uint32_t x = (tw + 0x01010101u) ^ sw;
+    return ((x | (x >> 1) | (x >> 2)) | (tw >> 2)) & 0x01010101u;
+}
+// the same for a chunk of nC <= 16 characters: m[w] = flags of word w (bytes beyond nC cleared); returns the count
+__device__ __forceinline__ uint32_t mismatch16(const uint4& t, const uint4& r, uint32_t nC, uint32_t m[4]) {
+    const uint32_t tw[4] = {t.x, t.y, t.z, t.w}, sw[4] = {r.x, r.y, r.z, r.w};
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) {
+        const uint32_t nb = nC > 4 * w ? min(4u, nC - 4 * w) : 0u;
+        const uint32_t valid = nb >= 4u ? 0x01010101u : (0x01010101u & ((1u << (8u * nb)) - 1u));
+        m[w] = mismatch4(tw[w], sw[w]) & valid;
+        cnt += (uint32_t)__popc(m[w]);
+    }
+    return cnt;
+}
+
 // KEYS: edit-distance candidates only get their verification key (the batch path; the matrix runs in
 // k_verify_stage) — that instance carries no matrix code and keeps twice the wavefronts in flight for the locate.
 template <bool KEYS>
@@ -803,9 +824,20 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
                     const uint32_t remaining = a;
                     bool ok = pos >= remaining;
                     const uint32_t p0 = pos - remaining;
-                    for (uint32_t j = 0; ok && j < remaining; j++) {
-                        cText++;
-                        if (textCode(ix.text[p0 + j]) + 1u != s[j]) ok = false;
+                    // 16 characters per step (the read codes sit in 16-byte aligned rows); the reference stops at the
+                    // first mismatch: cText counts the characters up to and including it
+                    for (uint32_t j = 0; ok && j < remaining; j += 16) {
+                        const uint32_t nC = min(16u, remaining - j);
+                        uint32_t m[4];
+                        const uint32_t cnt = mismatch16(loadText16(ix.text + p0 + j), *reinterpret_cast<const uint4*>(s + j), nC, m);
+                        if (cnt == 0) {
+                            cText += nC;
+                        } else {
+                            const uint32_t w = m[0] ? 0u : m[1] ? 1u : m[2] ? 2u : 3u;
+                            const uint32_t mw = w == 0 ? m[0] : w == 1 ? m[1] : w == 2 ? m[2] : m[3];
+                            cText += 4 * w + (((uint32_t)__ffs(mw) - 1u) >> 3) + 1u;
+                            ok = false;
+                        }
                     }
                     if (ok) {
                         outRec = make_uint4(p0, p0 + len, 0, 0);
@@ -821,11 +853,23 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
                 const uint32_t Te = Tb + len;
                 if (Te <= ix.n) {
                     uint32_t score = 0;
-                    for (uint32_t j = 0; j < len; j++) {
-                        cText++;
-                        const uint32_t code = textCode(ix.text[Tb + j]) + 1u; // '$' -> 5: never equal
-                        score += (code != s[j] || code > 4u);
-                        if (score > maxED) break;
+                    for (uint32_t j = 0; j < len; j += 16) { // 16 characters per step
+                        const uint32_t nC = min(16u, len - j);
+                        uint32_t m[4];
+                        const uint32_t cnt = mismatch16(loadText16(ix.text + Tb + j), *reinterpret_cast<const uint4*>(s + j), nC, m);
+                        if (score + cnt <= maxED) {
+                            score += cnt;
+                            cText += nC;
+                            continue;
+                        }
+                        // the reference breaks at the mismatch that exceeds maxED: find it (cText counts up to it)
+                        for (uint32_t t = 0; t < nC; t++) {
+                            const uint32_t mw = (t >> 2) == 0 ? m[0] : (t >> 2) == 1 ? m[1] : (t >> 2) == 2 ? m[2] : m[3];
+                            cText++;
+                            score += (mw >> (8u * (t & 3u))) & 1u;
+                            if (score > maxED) break;
+                        }
+                        break;
                     }
                     if (score <= maxED && score >= minED) {
                         outRec = make_uint4(Tb, Te, score, 0);
