@@ -629,9 +629,9 @@ static int batchRunOne(cmb_batch* b) {
                     b->bfsQCap = std::max<size_t>(b->bfsQCap, (size_t)nDfs + 1024);
                     for (int j = 0; j < 2; j++) {
                         if (b->bfsQ[j].n < 4 * b->bfsQCap) b->bfsQ[j].alloc(4 * b->bfsQCap);
-                        if (b->bfsEv[j].n < b->bfsEvCap) b->bfsEv[j].alloc(b->bfsEvCap);
+                        if (b->bfsEv[j].n < 2 * b->bfsEvCap) b->bfsEv[j].alloc(2 * b->bfsEvCap);
                     }
-                    if (b->bfsF.n < 4 * b->bfsFCap) b->bfsF.alloc(4 * b->bfsFCap);
+                    if (b->bfsF.n < F_U4 * b->bfsFCap) b->bfsF.alloc(F_U4 * b->bfsFCap);
                     if (b->bfsC.n < CTX_U4 * b->bfsCCap) b->bfsC.alloc(CTX_U4 * b->bfsCCap);
                     if (b->bfsA.n < b->bfsACap) b->bfsA.alloc(b->bfsACap);
                     const size_t cntWords = 2 * ((size_t)maxPass + 2) + 4;
@@ -648,8 +648,8 @@ static int batchRunOne(cmb_batch* b) {
                     B.C = b->bfsC.p;
                     B.A = b->bfsA.p;
                     B.qCap = (uint32_t)std::min<size_t>(b->bfsQ[0].n / 4, 0xFFFFFFF0u);
-                    B.evCap = (uint32_t)std::min<size_t>(b->bfsEv[0].n, 0xFFFFFFF0u);
-                    B.fCap = (uint32_t)std::min<size_t>(b->bfsF.n / 4, 0xFFFFFFF0u);
+                    B.evCap = (uint32_t)std::min<size_t>(b->bfsEv[0].n / 2, 0xFFFFFFF0u);
+                    B.fCap = (uint32_t)std::min<size_t>(b->bfsF.n / F_U4, 0xFFFFFFF0u);
                     B.cCap = (uint32_t)std::min<size_t>(b->bfsC.n / CTX_U4, 0xFFFFFFF0u);
                     B.aCap = (uint32_t)std::min<size_t>(b->bfsA.n, 0xFFFFFFF0u);
                     B.nq = b->bfsCnt.p;

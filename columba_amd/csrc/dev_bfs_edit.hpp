@@ -21,10 +21,10 @@
 //   context  (384 B)  one activation of recApproxMatchEdit: band geometry, start match, in-text switch
 //                     parameters, the match words of the part (8 blocks x 4 nucleotides) and references to
 //                     the contexts that hold the `descendants` / `descOther` lists it was entered with;
-//   F record (64 B)   a node in the final column of its phase: ranges, depth, character, link to the
-//                     final-column node above it on its path, and the edit distances of the final-column
-//                     cells of the path so far (5 bits per cell).  The chain of F records of a path IS its
-//                     MatrixMetaInfo; only the event handler ever walks it.
+//   F record (32 B)   a node in the final column of its phase: ranges, depth, character, link to the
+//                     final-column node above it on its path.  The chain of F records of a path, with the
+//                     edit distances of its final-column cells (5 bits per cell, carried by the node and
+//                     handed to the event), IS its MatrixMetaInfo; only the event handler ever walks it.
 #pragma once
 // (included by kernels.hpp after its wave helpers: waveExclusiveScan)
 #include "dev_partition.hpp"
@@ -35,6 +35,7 @@ constexpr uint32_t BFS_NONE = 0xFFFFFFFFu;
 constexpr uint32_t ED_CELLS = 24; // final-column cells per phase (5 bits each in a 128-bit pack); 3k+2 <= 24 for k <= 7
 constexpr uint32_t CTX_U4 = 24;   // uint4 per context: 8 header + 16 match words (8 row blocks x {A,C | G,T})
 constexpr uint32_t CTX_MBLK = 8;
+constexpr uint32_t F_U4 = 2;      // uint4 per F record: {ranges} {depth | c << 16, parent, reported, -}
 // (all blocks of a pass should be resident together — 3 blocks of 256 threads per CU at ~160 VGPRs — or the event
 // blocks, which come last in the grid, only start when expansion blocks have finished)
 constexpr uint32_t BFS_GRID = 576;    // blocks that expand the frontier (grid-stride)
@@ -48,8 +49,9 @@ constexpr uint32_t BFS_STOP = FLAG_BFS_Q | FLAG_BFS_EV | FLAG_BFS_F | FLAG_BFS_C
 struct BfsBufs {
     uint4* Q[2];  // frontier nodes, 4 planes of qCap: {ranges} {row | score << 16, ctx, fc, RAC bit} {HP, HN}
                   // {final-column distances of the path: only touched for nodes in the final column}
-    uint4* Ev[2]; // events {ctx, F index of the node that ended its path, remaining-descendants index | -1, cell}
-    uint4* F;     // final-column records, 4 x 16 B: {ranges} {depth | c << 16, parent, reported, -} {edit distances}
+    uint4* Ev[2]; // events, 2 x 16 B: {ctx, F index of the node that ended its path, remaining-descendants index | -1,
+                  // cell} {final-column distances of the path}
+    uint4* F;     // final-column records, 2 x 16 B: {ranges} {depth | c << 16, parent, reported, -}
     uint4* C;     // contexts, CTX_U4 x 16 B
     uint4* A;     // list arena: descendants (2 x 16 B each: ranges, {depth | c << 16}) and initial distances (u16)
     uint32_t qCap, evCap, fCap, cCap, aCap;
@@ -260,10 +262,9 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
                     fc = oF++;
                     EdPack p2 = pack;
                     edPut(p2, cell, cEd[c]);
-                    uint4* Fr = B.F + (size_t)fc * 4;
+                    uint4* Fr = B.F + (size_t)fc * F_U4;
                     Fr[0] = cr[c];
                     Fr[1] = make_uint4(row1 | ((uint32_t)(c + 1) << 16), fcP, 0u, 0u);
-                    Fr[2] = make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32));
                 }
                 if (kd == 1) {
                     const uint32_t o = oNode++;
@@ -277,7 +278,13 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
                         Qo[(size_t)3 * qCap + o] = make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32));
                     }
                 } else if (kd == 2) {
-                    Eo[oEv++] = make_uint4(ctx, fc, 0xFFFFFFFFu, cell);
+                    {
+                        EdPack p2 = pack;
+                        edPut(p2, cell, cEd[c]);
+                        Eo[(size_t)2 * oEv] = make_uint4(ctx, fc, 0xFFFFFFFFu, cell);
+                        Eo[(size_t)2 * oEv + 1] = make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32));
+                        oEv++;
+                    }
                 } else {
                     const uint32_t w = cr[c].y - cr[c].x;
                     for (uint32_t t = 0; t < w; t++) q.items[oIt + t] = make_uint4(rsId, cr[c].x + t, cEd[c], itMeta);
@@ -375,14 +382,14 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                     s = &stp->sch[scheme].s[search];
                 }
             } else {
-                const uint4 ev = Ei[i];
+                const uint4 ev = Ei[(size_t)2 * i];
                 c0i = ev.x;
                 fcE = ev.y;
                 remFrom = (int)ev.z;
                 last = ev.w;
                 const uint4* Cx = B.C + (size_t)c0i * CTX_U4;
                 const uint4 c0 = Cx[0], c1 = Cx[1], c3 = Cx[3];
-                const uint4 fp = B.F[(size_t)fcE * 4 + 2];
+                const uint4 fp = Ei[(size_t)2 * i + 1]; // final-column distances of the path (travel with the event)
                 pack = EdPack{u64of(fp.x, fp.y), u64of(fp.z, fp.w)};
                 rsId = c0.x;
                 maxED = (c0.z >> 16) & 0xFFu;
@@ -509,11 +516,11 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
             uint32_t cur = fcE;
             const uint32_t lowest = (uint32_t)__ffs(P.centres) - 1u;
             for (uint32_t c = last;; c--) {
-                const uint4 f1 = B.F[(size_t)cur * 4 + 1];
+                const uint4 f1 = B.F[(size_t)cur * F_U4 + 1];
                 if ((P.centres >> c) & 1u) {
-                    const uint32_t old = atomicExch(&reinterpret_cast<uint32_t*>(B.F + (size_t)cur * 4 + 1)[2], 1u);
+                    const uint32_t old = atomicExch(&reinterpret_cast<uint32_t*>(B.F + (size_t)cur * F_U4 + 1)[2], 1u);
                     if (!old) { // FMPosExt::report (indexhelpers.h:1586-1601): once per node
-                        const uint4 r = B.F[(size_t)cur * 4];
+                        const uint4 r = B.F[(size_t)cur * F_U4];
                         const uint32_t e = edGet(pack, c);
                         if (r.y > r.x && e >= lowerBound)
                             q.fm[fmNext++] = FMOccRec{rsId, r.x, r.y, (f1.x & 0xFFFFu) + smDepth, e, smShift};
@@ -525,11 +532,11 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
             for (; fmNext < fmEnd; fmNext++) q.fm[fmNext].rsId = 0xFFFFFFFFu; // holes
         } else if (P.kind == 2) {
             uint32_t cur = fcE;
-            for (uint32_t c = last; c > P.ci; c--) cur = B.F[(size_t)cur * 4 + 1].y;
-            const uint32_t old = atomicExch(&reinterpret_cast<uint32_t*>(B.F + (size_t)cur * 4 + 1)[2], 1u);
+            for (uint32_t c = last; c > P.ci; c--) cur = B.F[(size_t)cur * F_U4 + 1].y;
+            const uint32_t old = atomicExch(&reinterpret_cast<uint32_t*>(B.F + (size_t)cur * F_U4 + 1)[2], 1u);
             if (!old) {
-                const uint4 r = B.F[(size_t)cur * 4];
-                const uint4 f1 = B.F[(size_t)cur * 4 + 1];
+                const uint4 r = B.F[(size_t)cur * F_U4];
+                const uint4 f1 = B.F[(size_t)cur * F_U4 + 1];
                 const uint32_t up = P.ci - P.hi;
                 smR = RangePair{{r.x, r.y}, {r.z, r.w}};
                 smDist = P.ed;
@@ -543,15 +550,15 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
             uint4* dl = B.A + aOff;
             uint32_t cur = fcE;
             for (uint32_t c = last; c > P.ci; c--) {
-                const uint4 r = B.F[(size_t)cur * 4];
-                const uint4 f1 = B.F[(size_t)cur * 4 + 1];
+                const uint4 r = B.F[(size_t)cur * F_U4];
+                const uint4 f1 = B.F[(size_t)cur * F_U4 + 1];
                 const uint32_t j = c - P.ci - 1;
                 dl[2 * j] = r;
                 dl[2 * j + 1] = make_uint4((j + 1) | (f1.x & 0xFF0000u), 0u, 0u, 0u);
                 cur = f1.y;
             }
-            const uint4 r = B.F[(size_t)cur * 4];
-            const uint4 f1 = B.F[(size_t)cur * 4 + 1];
+            const uint4 r = B.F[(size_t)cur * F_U4];
+            const uint4 f1 = B.F[(size_t)cur * F_U4 + 1];
             smR = RangePair{{r.x, r.y}, {r.z, r.w}};
             smDist = P.ed;
             smDepthN = (f1.x & 0xFFFFu) + smDepth;
@@ -628,7 +635,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
 
         // ---- phase entry: recApproxMatchEdit prologue + replay of the descendants (:377-497)
         uint32_t outKind = 0; // 1: node of the next frontier, 2: event
-        uint4 oN0 = make_uint4(0, 0, 0, 0), oN1 = oN0, oN2 = oN0, oN4 = oN0, oEv = oN0;
+        uint4 oN0 = make_uint4(0, 0, 0, 0), oN1 = oN0, oN2 = oN0, oN4 = oN0, oEv = oN0, oEv1 = oN0;
         if (enter) {
             if (descSelf) descRefN = cNew;
             if (otherSelf) otherRefN = cNew;
@@ -730,10 +737,9 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                     const uint32_t e0 = cellAt(0, xLen, HP, HN, score);
                     if (e0 > 31u) flags |= FLAG_CAPACITY;
                     edPut(pk, 0, min(e0, 31u));
-                    uint4* Fr = B.F + (size_t)fNext * 4;
+                    uint4* Fr = B.F + (size_t)fNext * F_U4;
                     Fr[0] = make_uint4(smR.sa.b, smR.sa.e, smR.rev.b, smR.rev.e);
                     Fr[1] = make_uint4(0u, BFS_NONE, 0u, 0u);
-                    Fr[2] = make_uint4((uint32_t)pk.lo, (uint32_t)(pk.lo >> 32), (uint32_t)pk.hi, (uint32_t)(pk.hi >> 32));
                     fcCur = fNext++;
                 }
                 bool live = true;
@@ -754,14 +760,14 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                             const uint32_t e = cellAt(depth, g.n - 1, HP, HN, score);
                             if (e > 31u) flags |= FLAG_CAPACITY;
                             edPut(pk, cellJ, min(e, 31u));
-                            uint4* Fr = B.F + (size_t)fNext * 4;
+                            uint4* Fr = B.F + (size_t)fNext * F_U4;
                             Fr[0] = dl[2 * j];
                             Fr[1] = make_uint4(depth | (ch << 16), fcCur, 0u, 0u);
-                            Fr[2] = make_uint4((uint32_t)pk.lo, (uint32_t)(pk.lo >> 32), (uint32_t)pk.hi, (uint32_t)(pk.hi >> 32));
                             fcCur = fNext++;
                             if (!valid || onlyVerticalGapsLeft(g, depth, HN)) { // goDeeper, then `return` (:472-477)
                                 outKind = 2;
                                 oEv = make_uint4(cNew, fcCur, j + 1, cellJ);
+                                oEv1 = make_uint4((uint32_t)pk.lo, (uint32_t)(pk.lo >> 32), (uint32_t)pk.hi, (uint32_t)(pk.hi >> 32));
                                 live = false;
                                 break;
                             }
@@ -806,7 +812,10 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
             }
         } else if (outKind == 2) {
             if (oE >= B.evCap) flags |= FLAG_BFS_EV;
-            else Eo[oE] = oEv;
+            else {
+                Eo[(size_t)2 * oE] = oEv;
+                Eo[(size_t)2 * oE + 1] = oEv1;
+            }
         }
     }
     unsigned long long v = cRows;
