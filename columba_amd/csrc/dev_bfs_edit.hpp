@@ -33,8 +33,13 @@ namespace cmb {
 
 constexpr uint32_t BFS_NONE = 0xFFFFFFFFu;
 constexpr uint32_t ED_CELLS = 24; // final-column cells per phase (5 bits each in a 128-bit pack); 3k+2 <= 24 for k <= 7
-constexpr uint32_t CTX_U4 = 24;   // uint4 per context: 8 header + 16 match words (8 row blocks x {A,C | G,T})
-constexpr uint32_t CTX_MBLK = 8;
+// A context is three 128-byte lines: line 0 the cold header (C0..C4), line 1 the hot word and the match words of
+// row blocks 0..2 — what an expansion reads of its context is ONE line for the first 96 rows of a phase (with the
+// hot word in line 0 the kernel took 72 instead of 66 ms) —, line 2 the match words of row blocks 3..6.
+constexpr uint32_t CTX_U4 = 24;
+constexpr uint32_t CTX_HOT = 8;   // uint4 index of the hot word
+constexpr uint32_t CTX_M = 10;    // uint4 index of the match words of row block 0 ({A,C}, {G,T} per block)
+constexpr uint32_t CTX_MBLK = 7;  // row blocks with cached match words (rows < 224)
 constexpr uint32_t F_U4 = 2;      // uint4 per F record: {ranges} {depth | c << 16, parent, reported, -}
 // (all blocks of a pass should be resident together — 3 blocks of 256 threads per CU at ~160 VGPRs — or the event
 // blocks, which come last in the grid, only start when expansion blocks have finished)
@@ -164,8 +169,8 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
             const uint4* Cx = B.C + (size_t)ctx * CTX_U4;
             const uint32_t blk = row1 / MX_BLOCK;
             // ---- the single memory step: context (hot part), match words, F pack, rank blocks
-            const uint4 hot = Cx[5]; // everything the expansion needs of its context, in ONE 16-byte request
-            const uint4 mA = Cx[8 + 2 * blk], mB = Cx[9 + 2 * blk];
+            const uint4 hot = Cx[CTX_HOT]; // everything the expansion needs of its context, in ONE 16-byte request
+            const uint4 mA = Cx[CTX_M + 2 * blk], mB = Cx[CTX_M + 1 + 2 * blk];
             uint4 fp = make_uint4(0, 0, 0, 0);
             if (fcP != BFS_NONE) fp = Qi[(size_t)3 * qCap + i]; // final-column distances of the path so far
             const uint32_t dir = (hot.x >> 27) & 1u, uni = (hot.x >> 28) & 1u;
@@ -716,7 +721,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                                        (search << 16));
                 Cx[1] = make_uint4(itStart, itMeta, descRefN, otherRefN);
                 if (rsId > 0x1FFFFFFu || itMeta > 0x7FFFFFu) flags |= FLAG_CAPACITY;
-                Cx[5] = make_uint4(rsId | (itMode << 25) | (dirN << 27) | (uniN << 28),
+                Cx[CTX_HOT] = make_uint4(rsId | (itMode << 25) | (dirN << 27) | (uniN << 28),
                                    g.n | (g.m << 9) | (g.Wv << 18) | (g.Wh << 23) | (maxEDn << 27), itStart,
                                    itMeta | (clSize << 23));
                 Cx[2] = make_uint4(smR.sa.b, smR.sa.e, smR.rev.b, smR.rev.e);
@@ -727,8 +732,8 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                 for (uint32_t b = 0; b < nBlk; b++) {
                     const uint64_t a = matchWord(Gr, xOff, xLen, b), c = matchWord(Gr + gw, xOff, xLen, b);
                     const uint64_t gg = matchWord(Gr + 2 * gw, xOff, xLen, b), t = matchWord(Gr + 3 * gw, xOff, xLen, b);
-                    Cx[8 + 2 * b] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)c, (uint32_t)(c >> 32));
-                    Cx[9 + 2 * b] = make_uint4((uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)t, (uint32_t)(t >> 32));
+                    Cx[CTX_M + 2 * b] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)c, (uint32_t)(c >> 32));
+                    Cx[CTX_M + 1 + 2 * b] = make_uint4((uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)t, (uint32_t)(t >> 32));
                 }
                 // first cell of the cluster (:452-461)
                 EdPack pk{0, 0};
