@@ -815,7 +815,7 @@ static int batchRunOne(cmb_batch* b) {
                 // one read seeding the same alignment) are performed once: k_verify only locates and emits a key per
                 // candidate, the keys are sorted and run-length encoded, k_verify_edit verifies the distinct ones and
                 // scales the counters by the multiplicities.
-                const bool dedup = b->metric == CMB_METRIC_EDIT && b->k > 0 && b->k <= 7 && 2ull * nReads <= (1ull << 25); // 25 key bits for read x strand
+                const bool dedup = b->metric == CMB_METRIC_EDIT && b->k > 0 && b->k <= 7 && 2ull * nReads < (1ull << 25); // 25 key bits for read x strand
                 const uint32_t tbCap = (uint32_t)std::min<size_t>(b->tbq.n, 0xFFFFFFF0u);
                 const char* vGroup = "k_verify";
                 tm.begin();
@@ -831,9 +831,14 @@ static int batchRunOne(cmb_batch* b) {
                                    dedup ? b->vkeysA.p : (unsigned long long*)nullptr, q);
                 if (dedup) {
                     size_t tmpBytes = 0;
-                    HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, b->vkeysA.p, b->vkeysB.p, nItems, 0, 64, s));
+                    // sorted bits: low VK_LOW bits of the start, the bounds, read x strand (2 nReads < 2^rsBits, so
+                    // that the all-ones key of the other items sorts behind every real key) — see packVerifyKey
+                    uint32_t rsBits = 1;
+                    while ((1ull << rsBits) <= 2ull * nReads) rsBits++;
+                    const uint32_t bit0 = 32u - VK_LOW, bit1 = 39u + rsBits;
+                    HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, b->vkeysA.p, b->vkeysB.p, nItems, bit0, bit1, s));
                     if (b->sortTmp.n < tmpBytes) b->sortTmp.alloc(tmpBytes + 256);
-                    HIPCHK(rocprim::radix_sort_keys(b->sortTmp.p, tmpBytes, b->vkeysA.p, b->vkeysB.p, nItems, 0, 64, s));
+                    HIPCHK(rocprim::radix_sort_keys(b->sortTmp.p, tmpBytes, b->vkeysA.p, b->vkeysB.p, nItems, bit0, bit1, s));
                     size_t rleBytes = 0;
                     HIPCHK(rocprim::run_length_encode(nullptr, rleBytes, b->vkeysB.p, nItems, b->vkeysA.p, b->vcounts.p,
                                                       b->vruns.p, s));
@@ -885,11 +890,13 @@ static int batchRunOne(cmb_batch* b) {
                 const uint32_t nTb = hcnt[7];
                 if (nTb) {
                     const uint32_t tSlots = std::min<uint32_t>(((nTb + 255) / 256) * 256, 256u * 1024u);
-                    const uint32_t tLines = ((uint32_t)VROWS + 7u) / 8u + 2u; // (a group is written whole)
+                    // 64-byte lines of 16 narrow (k <= 4) or 8 wide trace rows (a group is written whole)
+                    const bool narrow = b->k <= TBN_MAX_ED && !getenv("CMB_TRACE_WIDE");
+                    const uint32_t tLines = narrow ? ((uint32_t)VROWS + 15u) / 16u + 2u : ((uint32_t)VROWS + 7u) / 8u + 2u;
                     if (b->vW.n < (size_t)tLines * 8 * tSlots) b->vW.alloc((size_t)tLines * 8 * tSlots);
                     VPlanes vp{b->vW.p, tSlots, tLines};
                     tm.begin();
-                    hipLaunchKernelGGL(k_traceback, dim3(tSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, mf, b->tbq.p, nTb,
+                    hipLaunchKernelGGL(narrow ? k_traceback<true> : k_traceback<false>, dim3(tSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, mf, b->tbq.p, nTb,
                                        vp, q);
                     tm.end("k_traceback");
                 }
@@ -966,8 +973,10 @@ static int batchRunOne(cmb_batch* b) {
             HIPCHK(hipMemcpyAsync(&total, b->foffs.p + nReads, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
             HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
+            if (hcnt[3] & FLAG_TRACE_RULE)
+                return fail(CMB_ERR_INTERNAL, "a traceback read a band-edge bit the narrow trace rows take as implied");
             if (hcnt[3] & FLAG_CAPACITY)
-                return fail(CMB_ERR_INTERNAL, "occurrence does not fit the filter key (width / distance range)");
+                return fail(CMB_ERR_INTERNAL, "occurrence does not fit the filter key (width / distance range) or a traceback left the band");
             if (b->fout.n < total) b->fout.alloc((size_t)total + total / 8 + 256);
             if (total)
                 hipLaunchKernelGGL(k_filter_write, dim3((nText + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->offs.p,
@@ -1218,7 +1227,8 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         HIPCHK(hipMemset(cnt.p, 0, 32));
         HIPCHK(hipMemset(ctr.p, 0, CMB_CNT_MAX * 8));
         const uint32_t slots = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(((n + 255) / 256) * 256, 256), 65536);
-        const uint32_t tLines = ((uint32_t)VROWS + 7u) / 8u + 2u;
+        const bool narrow = max_ed <= TBN_MAX_ED && !getenv("CMB_TRACE_WIDE");
+        const uint32_t tLines = narrow ? ((uint32_t)VROWS + 15u) / 16u + 2u : ((uint32_t)VROWS + 7u) / 8u + 2u;
         vW.alloc((size_t)tLines * 8 * slots);
         tbq.alloc(n + (size_t)(slots / 64 + 1) * 256);
         VPlanes vp{vW.p, slots, tLines};
@@ -1241,12 +1251,13 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
                                items.p, (uint32_t)n, tbq.p, (uint32_t)tbq.n, (unsigned long long*)nullptr, q);
             HIPCHK(hipMemcpy(hc, cnt.p, 32, hipMemcpyDeviceToHost));
             if (hc[7])
-                hipLaunchKernelGGL(k_traceback, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, mf, tbq.p,
-                                   hc[7], vp, q);
+                hipLaunchKernelGGL(narrow ? k_traceback<true> : k_traceback<false>, dim3(slots / 256), dim3(256), 0, 0,
+                                   idx->d, offs.p, mf, tbq.p, hc[7], vp, q);
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy(hc, cnt.p, 32, hipMemcpyDeviceToHost));
         if (hc[3] & FLAG_TEXT_OVERFLOW) return fail(CMB_ERR_INTERNAL, "verification output overflow");
+        if (hc[3] & (FLAG_CAPACITY | FLAG_TRACE_RULE)) return fail(CMB_ERR_INTERNAL, "a traceback left the band");
         std::vector<TextOccRec> t(hc[2]);
         if (hc[2]) HIPCHK(hipMemcpy(t.data(), text.p, hc[2] * sizeof(TextOccRec), hipMemcpyDeviceToHost));
         t.erase(std::remove_if(t.begin(), t.end(), [](const TextOccRec& x) { return x.rsId == 0xFFFFFFFFu; }),

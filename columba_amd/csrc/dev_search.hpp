@@ -61,7 +61,7 @@ struct TextOccRec { // in-text occurrence before filtering
 };
 
 enum { FLAG_ITEM_OVERFLOW = 1, FLAG_FMOCC_OVERFLOW = 2, FLAG_TEXT_OVERFLOW = 4, FLAG_CAPACITY = 8,
-       FLAG_UNSUPPORTED_READ = 16, FLAG_DFS_OVERFLOW = 32 };
+       FLAG_UNSUPPORTED_READ = 16, FLAG_DFS_OVERFLOW = 32, FLAG_TRACE_RULE = 64 };
 
 struct Queues {
     uint4* items;

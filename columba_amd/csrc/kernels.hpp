@@ -551,6 +551,20 @@ __device__ __forceinline__ uint64_t packTraceRow(uint32_t r, uint64_t HP, uint64
     const uint32_t sh = (r % MX_BLOCK) + MX_DIAG - TB_BELOW;
     return (uint64_t)(uint32_t)(HP >> sh) | ((uint64_t)(uint32_t)(diagOk >> sh) << 32);
 }
+// NARROW rows (maxED <= 4): 16 + 16 bits per row, sixteen rows per 64-byte line — half the trace traffic.
+// A trace only visits cells whose value is at most maxED, i.e. cells of the band j - i in [-3 maxED, maxED]
+// (4 maxED + 1 <= 17 window bits, rel = j - i + TB_BELOW in [6, 22]); two of the 34 bits are never open:
+//  * HP at the band's left edge (rel = 6): "horizontal" would come from a cell outside the band, whose value
+//    exceeds maxED, so the bit is 0 wherever a trace reads it;
+//  * "diagonal allowed" at the band's right edge (rel = 22): the alternative, a vertical step, would come from a
+//    cell outside the band, so the bit is 1 wherever a trace (having read HP = 0) reads it.
+// Kept: HP for rel 7..22 (low half), diagonal for rel 6..21 (high half).  The wide kernel CHECKS both rules on
+// every step it takes (FLAG_CAPACITY if one is ever violated; CMB_TRACE_WIDE=1 selects it for any k).
+constexpr uint32_t TBN_HP_LO = 7, TBN_DG_LO = 6, TBN_REL_LO = 6, TBN_REL_HI = 22, TBN_MAX_ED = 4;
+__device__ __forceinline__ uint32_t packTraceRowNarrow(uint32_t r, uint64_t HP, uint64_t diagOk) {
+    const uint32_t sh = (r % MX_BLOCK) + MX_DIAG - TB_BELOW;
+    return ((uint32_t)(HP >> (sh + TBN_HP_LO)) & 0xFFFFu) | ((uint32_t)(diagOk >> (sh + TBN_DG_LO)) << 16);
+}
 
 // The device copy of the text holds CODES, one byte per character: A,C,G,T -> 0..3, anything else ('$',
 // the padding behind the text) -> 4 (k_encode_text at index creation).
@@ -615,7 +629,7 @@ __device__ __forceinline__ void loadMatchWords(const MFull& mf, uint32_t rs, uin
 //   are detected on the fly (bitparallelmatrix.h:591-614 needs only ED(i-1), ED(i), ED(i+1)).
 // STORE = true : traceback pass (k_traceback) — HP and D0 of every row go to the interleaved planes.
 // Returns the number of valid rows `i` (indexhelpers.cpp:535-539); centreMask bit t <=> row firstRow+1+t.
-template <bool STORE>
+template <bool STORE, bool NARROW = false>
 __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull& mf, uint32_t rs,
                                                 const MatGeom& g, uint32_t nZeros, uint32_t start, uint32_t size,
                                                 uint32_t maxED, uint32_t minED, uint32_t& centreMask,
@@ -644,12 +658,13 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
     uint32_t i = 0;
     bool alive = size > 0;
     uint64_t buf[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // STORE: the packed rows of the current group of eight
+    uint32_t bufN[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // NARROW: of the current group of sixteen
     bool groupAlive = false;
     for (uint32_t c = 0; __ballot(alive) != 0ull; c++) {
 #pragma unroll
         for (uint32_t t = 0; t < 16; t++) {
             const uint32_t r = 16 * c + t + 1;
-            if (STORE && (t & 7u) == 0) groupAlive = alive;
+            if (STORE && (t & (NARROW ? 15u : 7u)) == 0) groupAlive = alive;
             if ((t == 15 && (c & 1u)) || (t == 0 && c == 0)) { // r % 32 == 0, or the first row: next block's words
                 if (alive) {
                     uint64_t mw[4];
@@ -665,7 +680,8 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
                 const uint64_t M = Ml[tc * 256 + tid];
                 cRows++;
                 const bool valid = computeRow(g, r, M, HP, HN, D0, RAC, score);
-                if (STORE) buf[t & 7u] = packTraceRow(r, HP, M | ~D0);
+                if (STORE && !NARROW) buf[t & 7u] = packTraceRow(r, HP, M | ~D0);
+                if (STORE && NARROW) bufN[t] = packTraceRowNarrow(r, HP, M | ~D0);
                 if (!valid) {
                     alive = false;
                 } else {
@@ -689,7 +705,12 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
                     if (i >= size) alive = false;
                 }
             }
-            if (STORE && (t & 7u) == 7u && groupAlive) { // rows 16 c + t - 6 .. 16 c + t + 1 = line 2 c + t / 8
+            if (STORE && NARROW && t == 15u && groupAlive) { // rows 16 c + 1 .. 16 c + 16 = line c
+                uint4* L = reinterpret_cast<uint4*>(V.W) + ((size_t)slot * V.lines + c) * 4;
+#pragma unroll
+                for (int h = 0; h < 4; h++) L[h] = make_uint4(bufN[4 * h], bufN[4 * h + 1], bufN[4 * h + 2], bufN[4 * h + 3]);
+            }
+            if (STORE && !NARROW && (t & 7u) == 7u && groupAlive) { // rows 16 c + t - 6 .. 16 c + t + 1 = line 2 c + t / 8
                 uint4* L = reinterpret_cast<uint4*>(V.W) + ((size_t)slot * V.lines + (2 * c + (t >> 3))) * 4;
 #pragma unroll
                 for (int h = 0; h < 4; h++)
@@ -710,10 +731,19 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
 // Key of an edit-distance verification: everything the banded matrix depends on.  The k+1 (or more) parts
 // of one read that seed the same alignment produce the same key, so equal keys are verified once and every
 // counter is scaled by the multiplicity (the reference verifies each of them, with identical results).
+// Layout: read x strand (25 bits) | maxED | minED | fixed | start rotated right by VK_LOW.  Equal keys only have to
+// end up NEXT TO each other (a missed merge costs a repeated verification, never a different result: the counters
+// are scaled by the multiplicities), so the radix sort only covers the bits from the low VK_LOW bits of the start
+// upwards — five 8-bit passes for a sub-batch of 2^22 reads instead of eight.
+constexpr uint32_t VK_LOW = 10;
 __host__ __device__ __forceinline__ unsigned long long packVerifyKey(uint32_t rs, uint32_t start, uint32_t maxED,
                                                                      uint32_t minED, uint32_t fixed) {
-    return ((unsigned long long)rs << 39) | ((unsigned long long)start << 7) | ((unsigned long long)(maxED & 7u) << 4) |
-           ((unsigned long long)(minED & 7u) << 1) | (unsigned long long)(fixed & 1u);
+    return ((unsigned long long)rs << 39) | ((unsigned long long)(maxED & 7u) << 36) | ((unsigned long long)(minED & 7u) << 33) |
+           ((unsigned long long)(fixed & 1u) << 32) | (unsigned long long)((start >> VK_LOW) | (start << (32u - VK_LOW)));
+}
+__host__ __device__ __forceinline__ uint32_t verifyKeyStart(unsigned long long key) {
+    const uint32_t v = (uint32_t)key;
+    return (v << VK_LOW) | (v >> (32u - VK_LOW));
 }
 
 // one edit-distance verification (FMIndex::inTextVerification + InTextVerificationTask::doTask) of `mult`
@@ -965,8 +995,8 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                 edPrev2 = (rc >> 27) & 31u;
             }
         }
-        const uint32_t rs = (uint32_t)(key >> 39), start = (uint32_t)(key >> 7);
-        const uint32_t maxED = (uint32_t)(key >> 4) & 7u, minED = (uint32_t)(key >> 1) & 7u, fixed = (uint32_t)key & 1u;
+        const uint32_t rs = (uint32_t)(key >> 39), start = verifyKeyStart(key);
+        const uint32_t maxED = (uint32_t)(key >> 36) & 7u, minED = (uint32_t)(key >> 33) & 7u, fixed = (uint32_t)(key >> 32) & 1u;
         const uint32_t nZeros = fixed ? 1u : 2u * maxED + 1u;
         MatGeom g;
         g.n = len + 1;
@@ -1081,10 +1111,12 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
 // (bitparallelmatrix.h:531-586).  The traceback reads rows through an 8-row window staged in LDS, so
 // the dependent chain costs one memory round trip per 8 rows instead of three per row.
 constexpr int TBW = 8;
+template <bool NARROW>
 __global__ void __launch_bounds__(256)
 k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             const uint4* __restrict__ tbq, uint32_t nTasks, VPlanes V, Queues q) {
-    __shared__ uint64_t wW[TBW][256];
+    __shared__ uint64_t wW[NARROW ? 1 : TBW][256];
+    __shared__ uint32_t wN[NARROW ? 16 : 1][256];
     __shared__ uint64_t Ml[ML_WORDS];
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t tid = threadIdx.x;
@@ -1098,6 +1130,7 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
     for (uint32_t base = waveBase; base < nTasks; base += stride) { // wave-uniform trip count
         const uint32_t it = base + (tid & 63u);
         uint32_t rs = 0, start = 0, m = 0, firstRow = 0, len = 0, col = 0;
+        uint32_t relLeft = 0, relRight = 0; // the band's edges in window bits
         uint64_t edPack = 0, edPackHi = 0;
         uint4 t = make_uint4(0, 0, 0, 0);
         if (it < nTasks) t = tbq[it];
@@ -1116,11 +1149,17 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             g.m = g.Wv + g.n;
             firstRow = (g.m - 1) - g.sfc();
             col = g.n - 1;
+            relLeft = TB_BELOW - g.Wv;
+            relRight = TB_BELOW + g.Wh;
+            if (NARROW && maxED > TBN_MAX_ED) { // (the host picks the wide kernel for k > 4)
+                flags |= FLAG_CAPACITY;
+                m = 0;
+            }
             const uint32_t topCentre = firstRow + 1 + (31u - (uint32_t)__clz(m));
             uint32_t dummyMask;
             // rows 1..topCentre (all valid: they were valid in pass 1)
-            forwardPass<true>(ix, mf, rs, g, nZeros, start, topCentre, maxED, 0, dummyMask, edPack, edPackHi, V,
-                              slot, dummyRows, Ml);
+            forwardPass<true, NARROW>(ix, mf, rs, g, nZeros, start, topCentre, maxED, 0, dummyMask, edPack, edPackHi, V,
+                                      slot, dummyRows, Ml);
         }
         // one centre per lane and round; the wavefront appends its results with one atomic per round
         for (;;) {
@@ -1134,30 +1173,63 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                 uint32_t ti = ri, tj = col;
                 uint32_t curG = 0xFFFFFFFFu; // the line (rows 8 g + 1 .. 8 g + 8) held in wW[.][tid]
                 while (tj > 0) {
-                    uint64_t ww = packTraceRow(0, HP0, 0ull); // row 0 (never steps diagonally: ti > 0 below)
-                    if (ti > 0) {
-                        const uint32_t gq = (ti - 1) >> 3, jq = (ti - 1) & 7u;
-                        if (gq != curG) {
-                            curG = gq;
-                            const uint4* L = reinterpret_cast<const uint4*>(V.W) + ((size_t)slot * V.lines + gq) * 4;
+                    const uint32_t rel = tj + TB_BELOW - ti; // bit of the row's windows
+                    bool hpBit, dgBit;
+                    if (NARROW) {
+                        uint32_t wn = packTraceRowNarrow(0, HP0, 0ull); // row 0 (never steps diagonally: ti > 0 below)
+                        if (ti > 0) {
+                            const uint32_t gq = (ti - 1) >> 4, jq = (ti - 1) & 15u;
+                            if (gq != curG) {
+                                curG = gq;
+                                const uint4* L = reinterpret_cast<const uint4*>(V.W) + ((size_t)slot * V.lines + gq) * 4;
 #pragma unroll
-                            for (int h = 0; h < 4; h++) {
-                                const uint4 v = L[h];
-                                wW[2 * h][tid] = (uint64_t)v.x | ((uint64_t)v.y << 32);
-                                wW[2 * h + 1][tid] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+                                for (int h = 0; h < 4; h++) {
+                                    const uint4 v = L[h];
+                                    wN[4 * h][tid] = v.x;
+                                    wN[4 * h + 1][tid] = v.y;
+                                    wN[4 * h + 2][tid] = v.z;
+                                    wN[4 * h + 3][tid] = v.w;
+                                }
                             }
+                            wn = wN[jq][tid];
                         }
-                        ww = wW[jq][tid];
+                        if (rel < TBN_REL_LO || rel > TBN_REL_HI) { // outside the band (checked, not assumed)
+                            flags |= FLAG_CAPACITY;
+                            break;
+                        }
+                        hpBit = rel >= TBN_HP_LO && ((wn >> (rel - TBN_HP_LO)) & 1u);
+                        dgBit = rel == TBN_REL_HI || ((wn >> (16u + rel - TBN_DG_LO)) & 1u);
+                    } else {
+                        uint64_t ww = packTraceRow(0, HP0, 0ull); // row 0 (never steps diagonally: ti > 0 below)
+                        if (ti > 0) {
+                            const uint32_t gq = (ti - 1) >> 3, jq = (ti - 1) & 7u;
+                            if (gq != curG) {
+                                curG = gq;
+                                const uint4* L = reinterpret_cast<const uint4*>(V.W) + ((size_t)slot * V.lines + gq) * 4;
+#pragma unroll
+                                for (int h = 0; h < 4; h++) {
+                                    const uint4 v = L[h];
+                                    wW[2 * h][tid] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                                    wW[2 * h + 1][tid] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+                                }
+                            }
+                            ww = wW[jq][tid];
+                        }
+                        if (rel > 31u) { // outside the stored window: cannot happen inside the band (checked, not assumed)
+                            flags |= FLAG_CAPACITY;
+                            break;
+                        }
+                        hpBit = ((uint32_t)ww >> rel) & 1u;
+                        dgBit = ((uint32_t)(ww >> 32) >> rel) & 1u;
+                        // the two rules the narrow rows rely on (see packTraceRowNarrow), checked on every step
+                        if (rel < relLeft || rel > relRight || (rel == relLeft && hpBit) ||
+                            (rel == relRight && ti > 0 && !hpBit && !dgBit))
+                            flags |= FLAG_TRACE_RULE;
                     }
-                    const uint32_t rel = tj + TB_BELOW - ti; // bit of the row's packed windows
-                    if (rel > 31u) { // outside the stored window: cannot happen inside the band (checked, not assumed)
-                        flags |= FLAG_CAPACITY;
-                        break;
-                    }
-                    if (((uint32_t)ww >> rel) & 1u) { // gap in horizontal (:553)
+                    if (hpBit) { // gap in horizontal (:553)
                         --tj;
                     } else {
-                        if (ti > 0 && (((uint32_t)(ww >> 32) >> rel) & 1u)) --tj; // diagonal (:559); else vertical
+                        if (ti > 0 && dgBit) --tj; // diagonal (:559); else vertical
                         --ti;
                     }
                 }
