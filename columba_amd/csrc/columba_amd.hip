@@ -867,10 +867,17 @@ static int batchRunOne(cmb_batch* b) {
                         const uint32_t listCap = (uint32_t)std::min<size_t>(b->vsC[0].n, 0xFFFFFFF0u);
                         const uint32_t grid = std::min<uint32_t>((nRuns + 255) / 256, 8192u);
                         VStageList L0{b->vsA[0].p, b->vsB[0].p, b->vsC[0].p}, L1{b->vsA[1].p, b->vsB[1].p, b->vsC[1].p};
-                        hipLaunchKernelGGL(k_verify_stage<true>, dim3(grid), dim3(256), 0, s, ix->d, b->offs.p, mf,
+                        // k <= 4: the matrix on 32-bit words (dev_matrix.hpp); CMB_MATRIX_WIDE=1 keeps the 64-bit words
+                        const bool w32 = b->k <= MX32_MAX_ED && !getenv("CMB_MATRIX_WIDE");
+                        auto stageFirst = k_verify_stage<true, false>, stageNext = k_verify_stage<false, false>;
+                        if (w32) {
+                            stageFirst = k_verify_stage<true, true>;
+                            stageNext = k_verify_stage<false, true>;
+                        }
+                        hipLaunchKernelGGL(stageFirst, dim3(grid), dim3(256), 0, s, ix->d, b->offs.p, mf,
                                            b->vkeysA.p, b->vcounts.p, nRuns, L0, L1, b->vsN.p, listCap, 0u, b->tbq.p, tbCap, q);
                         for (uint32_t st = 1; st < nStages; st++)
-                            hipLaunchKernelGGL(k_verify_stage<false>, dim3(grid), dim3(256), 0, s, ix->d, b->offs.p, mf,
+                            hipLaunchKernelGGL(stageNext, dim3(grid), dim3(256), 0, s, ix->d, b->offs.p, mf,
                                                (const unsigned long long*)nullptr, (const uint32_t*)nullptr, 0u,
                                                (st & 1u) ? L1 : L0, (st & 1u) ? L0 : L1, b->vsN.p, listCap, st, b->tbq.p, tbCap,
                                                q);

@@ -145,6 +145,76 @@ __device__ __forceinline__ uint32_t cellAt(uint32_t i, uint32_t j, uint64_t HP, 
     return score + (uint32_t)((i > j) ? (neg - pos) : (pos - neg));
 }
 
+// ---- the same matrix on 32-bit words and 8-row blocks (in-text verification, maxED <= MX32_MAX_ED) ----
+// computeRow / cellAt below are the reference's algorithm with WORD 32, BLOCK 8, DIAG 13, LEFT 14 instead of
+// 64 / 32 / 20 / 21: half the VALU work per row.  Why the results (valid rows, RAC, every cell value <= maxED,
+// and every "is this cell > maxED") are those of the 64-bit matrix: a cell of value <= maxED has |i - j| inside the
+// band [-Wh, Wv] with Wv <= 3 maxED, and so has every cell of an optimal path to it; both windows contain the band
+// in every row (here: bit 0 is at least 13 columns left of the diagonal, bit 31 at least 11 right of it).  What a
+// window assumes about the cells outside (left: the cell keeps the value it had when its column left the window;
+// right: new columns continue flat) only ever yields values above maxED — the left cell's value is at least
+// 13 - (nZeros - 1) >= maxED + 1 exactly when maxED <= 4, the right one's at least 11 — and values only grow along
+// paths, so in both windows: cells whose true value is <= maxED are exact, all others are > maxED.  Values above
+// maxED may differ numerically between the windows; nothing reported depends on them (centres, distances and
+// traceback only involve cells <= maxED and comparisons against them).  tests/test_gpu_parity.py compares counters
+// (MATRIX_ROWS, ABORTED, CIGARS) and occurrences with the oracle's 64-bit matrix.
+constexpr uint32_t MX32_BLOCK = 8, MX32_DIAG = 13, MX32_LEFT = 14, MX32_MAX_ED = 4;
+// the 32-bit match word of row i from the 64-bit word of the row's 32-row block (bit p' = bit p' + 8 s + 7)
+__device__ __forceinline__ uint32_t matchWord32(uint64_t M64, uint32_t i) {
+    return (uint32_t)(M64 >> (((i % MX_BLOCK) / MX32_BLOCK) * MX32_BLOCK + (MX_LEFT - MX32_LEFT)));
+}
+__device__ __forceinline__ bool computeRow(const MatGeom& g, uint32_t i, uint32_t M, uint32_t& HP, uint32_t& HN,
+                                           uint32_t& D0, uint32_t& RAC, uint32_t& score) {
+    const uint32_t l = i % MX32_BLOCK;
+    RAC <<= 1u;
+    if (l == 0) {
+        HP >>= MX32_BLOCK;
+        HN >>= MX32_BLOCK;
+        RAC >>= MX32_BLOCK;
+    }
+    D0 = (((M & HP) + HP) ^ HP) | M | HN;
+    const uint32_t VP = HN | ~(D0 | HP);
+    const uint32_t VN = D0 & HP;
+    HP = (VN << 1u) | ~(D0 | (VP << 1u));
+    HN = (D0 & (VP << 1u));
+    const uint32_t diagBit = l + MX32_DIAG;
+    score += (D0 >> diagBit) & 1u ? 0u : 1u;
+    if (!(D0 & RAC)) { // the RAC walk, as in the 64-bit version
+        const uint32_t q = (uint32_t)__ffs((int)RAC) - 1u;
+        const uint32_t maxSteps = q - (diagBit - g.Wv);
+        uint32_t hp = HP << (31u - q);
+        uint32_t hn = HN << (31u - q);
+        const uint32_t p1 = hp ? (uint32_t)__clz(hp) : 32u;
+        if (p1 >= maxSteps) return false;
+        uint32_t k = p1;
+        if (p1 != 0u && (hn >> (32u - p1)) != 0u) {
+            uint32_t val = 1u;
+            k = 0;
+            for (;;) {
+                val += (hn >> 31) - (hp >> 31);
+                if (val == 0u) break;
+                if (k == maxSteps) return false;
+                hp <<= 1;
+                hn <<= 1;
+                k++;
+            }
+            if (k >= maxSteps) return false;
+        }
+        RAC = 1u << (q - k - 1u);
+    }
+    return true;
+}
+__device__ __forceinline__ uint32_t cellAt(uint32_t i, uint32_t j, uint32_t HP, uint32_t HN, uint32_t score) {
+    const uint32_t bit = (i % MX32_BLOCK) + MX32_DIAG;
+    const uint32_t b = (i > j) ? bit - (i - j) + 1 : bit + 1;
+    const uint32_t e = (i > j) ? bit + 1 : bit + (j - i) + 1;
+    const uint32_t len = e - b;
+    const uint32_t mask = (len >= 32 ? ~0u : ((1u << len) - 1u)) << b;
+    const int neg = __popc(HN & mask);
+    const int pos = __popc(HP & mask);
+    return score + (uint32_t)((i > j) ? (neg - pos) : (pos - neg));
+}
+
 // onlyVerticalGapsLeft (bitparallelmatrix.h:651-665)
 __device__ __forceinline__ bool onlyVerticalGapsLeft(const MatGeom& g, uint32_t i, uint64_t HN) {
     if (i + MX_LEFT < g.n) return false;

@@ -951,7 +951,8 @@ struct VStageList { // survivors entering a stage
     uint32_t* c;    // len | RAC bit << 16 | edPrev << 22 | edPrev2 << 27
 };
 
-template <bool FIRST>
+// W32: the matrix on 32-bit words / 8-row blocks (dev_matrix.hpp; k <= 4) — half the VALU work of a row.
+template <bool FIRST, bool W32>
 __global__ void __launch_bounds__(256)
 k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                const unsigned long long* __restrict__ ukeys, const uint32_t* __restrict__ counts, uint32_t nKeys,
@@ -970,7 +971,9 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
         bool alive = false;
         unsigned long long key = ~0ull;
         uint32_t mult = 0, len = 0, score = 0, mask = 0, edPrev = 0, edPrev2 = 0;
-        uint64_t HP = 0, HN = 0, RAC = 0;
+        using W = typename std::conditional<W32, uint32_t, uint64_t>::type;
+        constexpr uint32_t LEFT = W32 ? MX32_LEFT : MX_LEFT, DIAG = W32 ? MX32_DIAG : MX_DIAG;
+        W HP = 0, HN = 0, RAC = 0;
         if (it < nIn) {
             if (FIRST) {
                 key = ukeys[it];
@@ -987,10 +990,10 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                 mult = ra.z & 0xFFFFFFu;
                 score = ra.z >> 24;
                 mask = ra.w;
-                HP = (uint64_t)rb.x | ((uint64_t)rb.y << 32);
-                HN = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
+                HP = W32 ? (W)rb.x : (W)((uint64_t)rb.x | ((uint64_t)rb.y << 32));
+                HN = W32 ? (W)rb.z : (W)((uint64_t)rb.z | ((uint64_t)rb.w << 32));
                 len = rc & 0xFFFFu;
-                RAC = 1ull << ((rc >> 16) & 63u);
+                RAC = (W)1 << ((rc >> 16) & 63u);
                 edPrev = (rc >> 22) & 31u;
                 edPrev2 = (rc >> 27) & 31u;
             }
@@ -1014,9 +1017,9 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             size = hEnd > start ? hEnd - start : 0;
             alive = g.inFinalColumn(size); // indexhelpers.cpp:527 (candidates that cannot reach it do nothing)
             if (FIRST && alive) {
-                HP = (~0ull) << MX_LEFT;
-                HN = (1ull << (MX_LEFT + 1u - nZeros)) - 1ull; // first column: nZeros zeros, then 1, 2, ...
-                RAC = 1ull << (MX_DIAG + g.Wh);
+                HP = (W)(~(W)0) << LEFT;
+                HN = ((W)1 << (LEFT + 1u - nZeros)) - (W)1; // first column: nZeros zeros, then 1, 2, ...
+                RAC = (W)1 << (DIAG + g.Wh);
                 if (firstRow == 0) edPrev = cellAt(0, col, HP, HN, 0);
             }
         }
@@ -1042,9 +1045,10 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             const uint32_t wv = wsel == 0 ? tw.x : wsel == 1 ? tw.y : wsel == 2 ? tw.z : tw.w;
             const uint32_t tc = (wv >> (8 * (t & 3u))) & 0xFFu;
             if (alive) {
-                const uint64_t M = Ml[tc * 256 + tid];
+                const uint64_t M64 = Ml[tc * 256 + tid];
+                const W M = W32 ? (W)matchWord32(M64, r) : (W)M64;
                 rows++;
-                uint64_t D0;
+                W D0;
                 const bool valid = computeRow(g, r, M, HP, HN, D0, RAC, score);
                 if (!valid) {
                     alive = false;
@@ -1091,7 +1095,7 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             else {
                 if (score > 255u) flags |= FLAG_CAPACITY;
                 out.a[oS] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), mult | (score << 24), mask);
-                out.b[oS] = make_uint4((uint32_t)HP, (uint32_t)(HP >> 32), (uint32_t)HN, (uint32_t)(HN >> 32));
+                out.b[oS] = make_uint4((uint32_t)HP, (uint32_t)((uint64_t)HP >> 32), (uint32_t)HN, (uint32_t)((uint64_t)HN >> 32));
                 out.c[oS] = len | ((uint32_t)(__ffsll((unsigned long long)RAC) - 1) << 16) | (edPrev << 22) | (edPrev2 << 27);
             }
         }

@@ -156,6 +156,39 @@ def test_ragged_and_odd_reads(world):
     _compare(world, "kuch1", "hamming", "dynamic", 3, reads)
 
 
+def _edge_reads(g, n, k, seed):
+    """Reads whose k edits are all indels packed at one end: their alignments run along the edges of the
+    verification band (the cells the narrow trace rows of `k_traceback` do not store)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        pos = int(rng.integers(1000, len(g) - 1000))
+        seg = g[pos:pos + 150 + k].tobytes()
+        at = int(rng.integers(0, 6)) if i % 2 == 0 else 150 - k - int(rng.integers(0, 6))
+        kind = (i // 2) % 3
+        nd = k if kind == 0 else 0 if kind == 1 else k // 2      # deletions, the rest are insertions
+        ni = k - nd
+        ins = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), ni).tolist())
+        r = seg[:at] + ins + seg[at + nd:]
+        out.append(r[:150])
+    return out
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 6])
+def test_band_edge_alignments(world, k):
+    import os
+    reads = _edge_reads(world["genome"], 1500, k, seed=40 + k)
+    spec = "multiple_opt" if k % 2 == 0 else "kuch1"
+    _compare(world, spec, "edit", "dynamic", k, reads)
+    if k <= 4:
+        # the wide rows (used for k > 4) check, on every traceback step, the two rules the narrow rows rely on
+        os.environ["CMB_TRACE_WIDE"] = "1"
+        try:
+            _compare(world, spec, "edit", "dynamic", k, reads)
+        finally:
+            del os.environ["CMB_TRACE_WIDE"]
+
+
 def test_errors_are_loud(world):
     st = ca.SearchStrategy("multiple_opt")
     with pytest.raises(ca.CmbError) as e:   # read not longer than the number of parts

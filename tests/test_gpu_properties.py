@@ -109,3 +109,25 @@ def test_composite_batch(big):
         assert np.array_equal(o1[f], o2[f]), f
     for n in COUNTERS:
         assert c1[n] == c2[n], n
+
+
+@pytest.mark.parametrize("env", ["CMB_TRACE_WIDE", "CMB_MATRIX_WIDE"])
+@pytest.mark.parametrize("k", [2, 4])
+def test_narrow_and_wide_matrix_formats(big, k, env):
+    """For k <= 4 the in-text verification runs the banded matrix on 32-bit words / 8-row blocks
+    (CMB_MATRIX_WIDE=1: the reference's 64-bit words / 32-row blocks, used for k > 4), and `k_traceback` keeps
+    16 + 16 bits per matrix row (two band-edge bits are implied; CMB_TRACE_WIDE=1: 32 + 32 bits, whose kernel also
+    checks the implied-bit rules on every step — a violation fails the batch).  Results and counters must agree."""
+    sub = big["reads"][:60_000]
+    spec = "multiple_opt" if k == 4 else "kuch1"
+    o1, f1, c1 = _run(big["dev"], sub, k=k, spec=spec)
+    os.environ[env] = "1"
+    try:
+        o2, f2, c2 = _run(big["dev"], sub, k=k, spec=spec)
+    finally:
+        del os.environ[env]
+    assert np.array_equal(f1, f2)
+    for f in ("begin", "end", "distance", "strand"):
+        assert np.array_equal(o1[f], o2[f]), f
+    for n in COUNTERS:
+        assert c1[n] == c2[n], n
