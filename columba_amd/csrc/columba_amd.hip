@@ -855,7 +855,11 @@ static int batchRunOne(cmb_batch* b) {
                     if (nRuns) {
                         // staged verification (kernels.hpp: k_verify_stage): one launch per 32-row matrix block,
                         // survivor lists ping-pong, list sizes stay on the device
-                        const uint32_t nStages = ((uint32_t)VROWS + 31u) / 32u + 1u;
+                        // nb 32-row blocks per stage: fewer stages re-fetch fewer text lines and move fewer survivor
+                        // records, more blocks leave more lanes idle behind candidates that ended (CMB_STAGE_BLOCKS)
+                        const char* nbEnv = getenv("CMB_STAGE_BLOCKS");
+                        const uint32_t nb = nbEnv ? std::min(8u, std::max(1u, (uint32_t)atoi(nbEnv))) : 2u;
+                        const uint32_t nStages = ((uint32_t)VROWS + 32u * nb - 1u) / (32u * nb) + 1u;
                         for (int j = 0; j < 2; j++)
                             if (b->vsC[j].n < nRuns) {
                                 b->vsA[j].alloc((size_t)nRuns + nRuns / 8 + 256);
@@ -875,11 +879,11 @@ static int batchRunOne(cmb_batch* b) {
                             stageNext = k_verify_stage<false, true>;
                         }
                         hipLaunchKernelGGL(stageFirst, dim3(grid), dim3(256), 0, s, ix->d, b->offs.p, mf,
-                                           b->vkeysA.p, b->vcounts.p, nRuns, L0, L1, b->vsN.p, listCap, 0u, b->tbq.p, tbCap, q);
+                                           b->vkeysA.p, b->vcounts.p, nRuns, L0, L1, b->vsN.p, listCap, 0u, nb, b->tbq.p, tbCap, q);
                         for (uint32_t st = 1; st < nStages; st++)
                             hipLaunchKernelGGL(stageNext, dim3(grid), dim3(256), 0, s, ix->d, b->offs.p, mf,
                                                (const unsigned long long*)nullptr, (const uint32_t*)nullptr, 0u,
-                                               (st & 1u) ? L1 : L0, (st & 1u) ? L0 : L1, b->vsN.p, listCap, st, b->tbq.p, tbCap,
+                                               (st & 1u) ? L1 : L0, (st & 1u) ? L0 : L1, b->vsN.p, listCap, st, nb, b->tbq.p, tbCap,
                                                q);
                         if (verbose) {
                             std::vector<uint32_t> hn(nStages + 2);

@@ -957,15 +957,14 @@ __global__ void __launch_bounds__(256)
 k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                const unsigned long long* __restrict__ ukeys, const uint32_t* __restrict__ counts, uint32_t nKeys,
                VStageList in, VStageList out, uint32_t* __restrict__ nList, uint32_t listCap, uint32_t stage,
-               uint4* __restrict__ tbq, uint32_t tbCap, Queues q) {
+               uint32_t nb, uint4* __restrict__ tbq, uint32_t tbCap, Queues q) {
     __shared__ uint64_t Ml[ML_WORDS];
     __shared__ uint32_t sh[2][5];
     const uint32_t tid = threadIdx.x;
     const uint32_t nIn = FIRST ? nKeys : min(nList[stage], listCap);
     uint32_t cText = 0, cAbort = 0, cCig = 0, cStarted = 0, flags = 0;
     Ml[4 * 256 + tid] = 0ull; // text code 4 ('$', padding): matches nothing
-    const uint32_t r0 = FIRST ? 1u : 32u * stage; // first row of this stage
-    const uint32_t nRows = FIRST ? 31u : 32u;
+    const uint32_t rFirst = FIRST ? 1u : 32u * nb * stage; // first row of this stage (nb 32-row blocks per stage)
     for (uint32_t base = blockIdx.x * 256u; base < nIn; base += gridDim.x * 256u) { // block-uniform trip count
         const uint32_t it = base + tid;
         bool alive = false;
@@ -1023,28 +1022,32 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                 if (firstRow == 0) edPrev = cellAt(0, col, HP, HN, 0);
             }
         }
-        uint32_t i = r0 - 1; // rows done so far
+        uint32_t i = rFirst - 1; // rows done so far
         uint32_t rows = 0;
         bool ended = false;
+        for (uint32_t h = 0; h < nb; h++) {
+        if (__ballot(alive) == 0ull) break; // (wave-uniform)
+        const uint32_t blk = nb * stage + h;
+        const bool head = FIRST && h == 0; // rows 1..31 of the matrix
+        const uint32_t r0 = head ? 1u : 32u * blk;
         uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0;
         if (alive) {
             const uint8_t* tp = ix.text + start + (r0 - 1); // text character of row r is text[start + r - 1]
             t0 = loadText16(tp);
             t1 = loadText16(tp + 16); // the text allocation is padded
             uint64_t mw[4];
-            loadMatchWords(mf, rs, stage, mw);
+            loadMatchWords(mf, rs, blk, mw);
 #pragma unroll
             for (int ch = 0; ch < 4; ch++) Ml[ch * 256 + tid] = mw[ch];
         }
 #pragma unroll
         for (uint32_t t = 0; t < 32; t++) {
-            if (t >= nRows) break;
             const uint32_t r = r0 + t;
             const uint32_t wsel = (t >> 2) & 3u;
             const uint4 tw = t < 16 ? t0 : t1;
             const uint32_t wv = wsel == 0 ? tw.x : wsel == 1 ? tw.y : wsel == 2 ? tw.z : tw.w;
             const uint32_t tc = (wv >> (8 * (t & 3u))) & 0xFFu;
-            if (alive) {
+            if (alive && !(t == 31 && head)) { // (the head block has 31 rows)
                 const uint64_t M64 = Ml[tc * 256 + tid];
                 const W M = W32 ? (W)matchWord32(M64, r) : (W)M64;
                 rows++;
@@ -1070,6 +1073,7 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                     }
                 }
             }
+        }
         }
         cText += rows * mult;
         uint32_t nTb = 0;
