@@ -561,9 +561,10 @@ __device__ __forceinline__ uint64_t packTraceRow(uint32_t r, uint64_t HP, uint64
 // Kept: HP for rel 7..22 (low half), diagonal for rel 6..21 (high half).  The wide kernel CHECKS both rules on
 // every step it takes (FLAG_CAPACITY if one is ever violated; CMB_TRACE_WIDE=1 selects it for any k).
 constexpr uint32_t TBN_HP_LO = 7, TBN_DG_LO = 6, TBN_REL_LO = 6, TBN_REL_HI = 22, TBN_MAX_ED = 4;
-__device__ __forceinline__ uint32_t packTraceRowNarrow(uint32_t r, uint64_t HP, uint64_t diagOk) {
-    const uint32_t sh = (r % MX_BLOCK) + MX_DIAG - TB_BELOW;
-    return ((uint32_t)(HP >> (sh + TBN_HP_LO)) & 0xFFFFu) | ((uint32_t)(diagOk >> (sh + TBN_DG_LO)) << 16);
+// (HP and "diagonal allowed" of the 32-bit matrix: the diagonal of row r is bit r % 8 + MX32_DIAG)
+__device__ __forceinline__ uint32_t packTraceRowNarrow(uint32_t r, uint32_t HP, uint32_t diagOk) {
+    const uint32_t d = (r % MX32_BLOCK) + MX32_DIAG - TB_BELOW + 32u; // (+32: d itself would be negative)
+    return ((HP >> (d + TBN_HP_LO - 32u)) & 0xFFFFu) | ((diagOk >> (d + TBN_DG_LO - 32u)) << 16);
 }
 
 // The device copy of the text holds CODES, one byte per character: A,C,G,T -> 0..3, anything else ('$',
@@ -635,7 +636,10 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
                                                 uint32_t maxED, uint32_t minED, uint32_t& centreMask,
                                                 uint64_t& edPack, uint64_t& edPackHi, const VPlanes& V, uint32_t slot,
                                                 uint32_t& cRows, uint64_t* Ml) {
-    uint64_t HP = (~0ull) << MX_LEFT, HN = (1ull << (MX_LEFT + 1u - nZeros)) - 1ull, D0 = 0, RAC = 1ull << (MX_DIAG + g.Wh);
+    // NARROW (k <= 4) also means the matrix on 32-bit words / 8-row blocks (dev_matrix.hpp)
+    using W = typename std::conditional<NARROW, uint32_t, uint64_t>::type;
+    constexpr uint32_t LEFT = NARROW ? MX32_LEFT : MX_LEFT, DIAG = NARROW ? MX32_DIAG : MX_DIAG;
+    W HP = (W)(~(W)0) << LEFT, HN = ((W)1 << (LEFT + 1u - nZeros)) - (W)1, D0 = 0, RAC = (W)1 << (DIAG + g.Wh);
     uint32_t score = 0;
     const uint32_t sfc = g.sfc();
     const uint32_t firstRow = (g.m - 1) - sfc;
@@ -677,11 +681,12 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
             const uint32_t wv = wsel == 0 ? cur.x : wsel == 1 ? cur.y : wsel == 2 ? cur.z : cur.w;
             const uint32_t tc = (wv >> (8 * (t & 3u))) & 0xFFu;
             if (alive) {
-                const uint64_t M = Ml[tc * 256 + tid];
+                const uint64_t M64 = Ml[tc * 256 + tid];
+                const W M = NARROW ? (W)matchWord32(M64, r) : (W)M64;
                 cRows++;
                 const bool valid = computeRow(g, r, M, HP, HN, D0, RAC, score);
-                if (STORE && !NARROW) buf[t & 7u] = packTraceRow(r, HP, M | ~D0);
-                if (STORE && NARROW) bufN[t] = packTraceRowNarrow(r, HP, M | ~D0);
+                if (STORE && !NARROW) buf[t & 7u] = packTraceRow(r, (uint64_t)HP, (uint64_t)(M | ~D0));
+                if (STORE && NARROW) bufN[t] = packTraceRowNarrow(r, (uint32_t)HP, (uint32_t)(M | ~D0));
                 if (!valid) {
                     alive = false;
                 } else {
@@ -1184,7 +1189,7 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                     const uint32_t rel = tj + TB_BELOW - ti; // bit of the row's windows
                     bool hpBit, dgBit;
                     if (NARROW) {
-                        uint32_t wn = packTraceRowNarrow(0, HP0, 0ull); // row 0 (never steps diagonally: ti > 0 below)
+                        uint32_t wn = packTraceRowNarrow(0, (~0u) << MX32_LEFT, 0u); // row 0 (never steps diagonally: ti > 0 below)
                         if (ti > 0) {
                             const uint32_t gq = (ti - 1) >> 4, jq = (ti - 1) & 15u;
                             if (gq != curG) {

@@ -16,13 +16,13 @@ dev = ca.Index(ix)
 buf, offs = synth.sample_reads_fast(ix.text[:-1], nreads, 150, seed=3, device="cuda")
 torch.cuda.empty_cache()
 st = ca.SearchStrategy("multiple_opt", "edit", "dynamic")
-b = ca.Batch(dev, st, 4, packed=(buf, offs))
-b.run()
 ref = None
 for rnd in range(2):
     for sset in settings:
         kv = [x.split("=") for x in sset.split()] if sset != "-" else []
         for k_, v in kv: os.environ[k_] = v
+        b = ca.Batch(dev, st, 4, packed=(buf, offs))  # (some knobs are read when the batch is created)
+        b.run()
         ts = []
         for it in range(3):
             t = time.time(); b.run(); ts.append(time.time() - t)
@@ -31,4 +31,5 @@ for rnd in range(2):
         if ref is None: ref = sig
         print(f"{sset:40s} ms {[round(1000 * x, 1) for x in ts]} same={sig == ref}",
               {k_: round(v, 1) for k_, v in b.timings().items()}, flush=True)
+        b.close()
         for k_, v in kv: del os.environ[k_]
