@@ -1429,7 +1429,16 @@ k_filter_mark(const unsigned long long* __restrict__ keys, uint32_t nReads, uint
 #pragma unroll
     for (uint32_t j = 0; j < 8; j++)
         if (j < nSeg) step(j, first[j]);
-    for (uint32_t i = 8; i < nSeg; i++) step(i, keys[segLo + i]);
+    // long segments (reads inside repeats: thousands of occurrences): sixteen keys per round trip — the lane with
+    // the longest segment sets the duration of the whole kernel
+    for (uint32_t i0 = 8; i0 < nSeg; i0 += 16) {
+        unsigned long long nxt[16];
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) nxt[j] = i0 + j < nSeg ? keys[segLo + i0 + j] : 0ull;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++)
+            if (i0 + j < nSeg) step(i0 + j, nxt[j]);
+    }
     counts[r] = nOut;
 }
 __global__ void __launch_bounds__(256)
