@@ -1373,24 +1373,22 @@ __global__ void k_filter_segments(const unsigned long long* __restrict__ keys, u
 // mode 0: k = 0 (no filtering, searchstrategy.cpp:499-510); 1: Hamming (unique only); 2: edit distance
 // k_filter_mark: one lane per read walks the read's (short) segment of the sorted keys — the redundancy filter
 // (:1447-1485) is sequential in the last occurrence it kept — and gives every key of the segment its rank among
-// the read's surviving occurrences, or NONE.  The first eight keys of the segment are fetched together.
+// the read's surviving occurrences, or NONE.  Segments of up to FILTER_SHORT keys are fetched in one go by their
+// lane; the few long ones (reads inside repeats: thousands of occurrences — one lane walking them alone set the
+// duration of the whole kernel) are walked by their lane while the WAVEFRONT fetches them, 64 keys per load.
 // k_filter_write: one lane per KEY (coalesced) writes the survivors at offset(read) + rank.
 constexpr uint32_t FILTER_NONE = 0xFFFFFFFFu;
+constexpr uint32_t FILTER_SHORT = 24;
 __global__ void __launch_bounds__(256)
 k_filter_mark(const unsigned long long* __restrict__ keys, uint32_t nReads, uint32_t k, int mode,
               uint32_t* __restrict__ counts, uint32_t* __restrict__ rank, const uint32_t* __restrict__ segBeg,
               const uint32_t* __restrict__ segEnd) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nReads) return;
-    const uint32_t segLo = segBeg[r];
-    if (segLo == 0xFFFFFFFFu) { // no occurrence of this read
-        counts[r] = 0;
-        return;
-    }
-    const uint32_t nSeg = segEnd[r] - segLo;
-    unsigned long long first[8];
-#pragma unroll
-    for (uint32_t j = 0; j < 8; j++) first[j] = j < nSeg ? keys[segLo + j] : 0ull;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t segLo = 0xFFFFFFFFu;
+    if (r < nReads) segLo = segBeg[r];
+    const bool has = segLo != 0xFFFFFFFFu; // (no occurrence of this read otherwise)
+    const uint32_t nSeg = has ? segEnd[r] - segLo : 0u;
     uint32_t nOut = 0, lastKept = 0;
     const uint32_t maxDiff = 2 * k;
     uint32_t prevBegin = 0xFFFFFFFFu, prevDepth = 0xFFFFFFFFu, prevED = k + 1;
@@ -1426,20 +1424,39 @@ k_filter_mark(const unsigned long long* __restrict__ keys, uint32_t nReads, uint
         }
         rank[segLo + i] = mine;
     };
+    const bool isShort = nSeg <= FILTER_SHORT;
+    if (has && isShort) {
+        unsigned long long first[8];
 #pragma unroll
-    for (uint32_t j = 0; j < 8; j++)
-        if (j < nSeg) step(j, first[j]);
-    // long segments (reads inside repeats: thousands of occurrences): sixteen keys per round trip — the lane with
-    // the longest segment sets the duration of the whole kernel
-    for (uint32_t i0 = 8; i0 < nSeg; i0 += 16) {
-        unsigned long long nxt[16];
+        for (uint32_t j = 0; j < 8; j++) first[j] = j < nSeg ? keys[segLo + j] : 0ull;
 #pragma unroll
-        for (uint32_t j = 0; j < 16; j++) nxt[j] = i0 + j < nSeg ? keys[segLo + i0 + j] : 0ull;
+        for (uint32_t j = 0; j < 8; j++)
+            if (j < nSeg) step(j, first[j]);
+        if (nSeg > 8u) {
+            unsigned long long nxt[FILTER_SHORT - 8];
 #pragma unroll
-        for (uint32_t j = 0; j < 16; j++)
-            if (i0 + j < nSeg) step(i0 + j, nxt[j]);
+            for (uint32_t j = 0; j < FILTER_SHORT - 8; j++) nxt[j] = 8u + j < nSeg ? keys[segLo + 8u + j] : 0ull;
+#pragma unroll
+            for (uint32_t j = 0; j < FILTER_SHORT - 8; j++)
+                if (8u + j < nSeg) step(8u + j, nxt[j]);
+        }
     }
-    counts[r] = nOut;
+    unsigned long long todo = __ballot(has && !isShort);
+    while (todo) { // wave-uniform
+        const int owner = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const uint32_t oLo = (uint32_t)__shfl((int)segLo, owner), oN = (uint32_t)__shfl((int)nSeg, owner);
+        for (uint32_t base = 0; base < oN; base += 64u) {
+            const unsigned long long mineKey = base + lane < oN ? keys[oLo + base + lane] : 0ull;
+            const uint32_t cnt = min(64u, oN - base);
+            for (uint32_t j = 0; j < cnt; j++) {
+                const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mineKey, (int)j);
+                const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(mineKey >> 32), (int)j);
+                if (lane == (uint32_t)owner) step(base + j, (unsigned long long)lo | ((unsigned long long)hi << 32));
+            }
+        }
+    }
+    if (r < nReads) counts[r] = nOut;
 }
 __global__ void __launch_bounds__(256)
 k_filter_write(const unsigned long long* __restrict__ keys, uint32_t n, const uint64_t* __restrict__ offs, uint32_t k,

@@ -189,6 +189,31 @@ def test_band_edge_alignments(world, k):
             del os.environ["CMB_TRACE_WIDE"]
 
 
+def test_high_copy_repeat(oracle_built):
+    """Reads from a 400-copy element: hundreds of occurrences per read — the long-segment path of the occurrence
+    filter (`k_filter_mark`: segments of more than 24 / more than 64 keys) and wide SA ranges in `k_fmocc`."""
+    import oracle_py as op
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    elem = rng.choice(acgt, 400)
+    parts = []
+    for c in range(400):
+        parts.append(rng.choice(acgt, int(rng.integers(200, 900))))
+        e = elem.copy()
+        mut = rng.random(400) < 0.01
+        e[mut] = rng.choice(acgt, int(mut.sum()))
+        parts.append(e)
+    g = np.concatenate(parts + [rng.choice(acgt, 1000)])
+    ix = ib.build_index(g.tobytes(), device="cuda")
+    w = {"genome": g, "ix": ix, "dev": ca.Index(ix), "orc": op.OracleIndex(ix), "op": op}
+    reads = [elem[o:o + 150].tobytes() for o in range(0, 250, 5)]
+    reads += synth.sample_reads(g, 200, 150, seed=3, edit_choices=(0, 1, 2))
+    cnt = _compare(w, "multiple_opt", "edit", "dynamic", 4, reads)
+    assert cnt["TOTAL_REPORTED_POSITIONS"] > 100 * 50
+    _compare(w, "kuch1", "hamming", "dynamic", 2, reads)
+    _compare(w, "kuch1", "edit", "dynamic", 0, reads)
+
+
 def test_errors_are_loud(world):
     st = ca.SearchStrategy("multiple_opt")
     with pytest.raises(ca.CmbError) as e:   # read not longer than the number of parts

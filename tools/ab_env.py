@@ -28,7 +28,11 @@ for rnd in range(2):
             t = time.time(); b.run(); ts.append(time.time() - t)
         occ, occ_offs, cnt = b.results()
         sig = (len(occ), int(occ["begin"].astype(np.uint64).sum()), cnt["MATRIX_ROWS"], cnt["NODE_COUNTER"])
-        if ref is None: ref = sig
+        if ref is None:
+            ref = sig
+            d = np.diff(occ_offs.astype(np.int64))
+            print("occurrences per read after the filter: max", int(d.max()), "reads with > 24:", int((d > 24).sum()),
+                  "> 1000:", int((d > 1000).sum()), flush=True)
         print(f"{sset:40s} ms {[round(1000 * x, 1) for x in ts]} same={sig == ref}",
               {k_: round(v, 1) for k_, v in b.timings().items()}, flush=True)
         b.close()
