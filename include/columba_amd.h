@@ -144,6 +144,9 @@ int cmb_match_batch(cmb_index* idx, const cmb_strategy* st, uint32_t max_distanc
  * A batch of 2 M reads or more is held as 2-3 sub-batches that cmb_batch_run processes concurrently (own HIP
  * stream and host thread each; environment CMB_SUBBATCHES=n overrides the number, CMB_SERIAL_SUBBATCHES runs
  * them one after the other); results and counters are those of the whole batch, in read order.
+ * Diagnostic knobs, read per run, none of which changes a result: CMB_MATRIX_WIDE=1 (in-text matrices on 64-bit
+ * words also for k <= 4), CMB_TRACE_WIDE=1 (8-byte traceback rows also for k <= 4; that kernel checks the rules the
+ * 4-byte rows rely on), CMB_STAGE_BLOCKS=n (32-row blocks per verification launch), CMB_VERBOSE=1.
  * cmb_batch_timings: device time per kernel group of the last run (HIP events on the batch's streams; summed
  * over the sub-batches). */
 int cmb_batch_create(cmb_index* idx, const cmb_strategy* st, uint32_t max_distance, const char* seqs,
