@@ -84,6 +84,7 @@ struct cmb_index {
     DevBuf<uint64_t> saBv, saCnt;
     DevBuf<uint32_t> saSamples;
     DevBuf<uint8_t> text;
+    DevBuf<uint32_t> text2;
     DevBuf<uint4> kmer;
     std::vector<uint32_t> seqStarts;
     uint64_t bytes = 0;
@@ -135,6 +136,21 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         HIPCHK(hipMemcpy(ix->text.p, desc->text, n, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_encode_text, dim3(4096), dim3(256), 0, 0, ix->text.p, n, n + TEXT_PAD); // ASCII -> codes 0..4
         HIPCHK(hipGetLastError());
+        bool packedOk = false;
+        { // 2-bit copy for the matrix kernels (k_pack_text); the words past the text's padding are never used
+            const uint64_t nWords = (n + TEXT_PAD) / 16;
+            ix->text2.alloc(nWords + 16);
+            HIPCHK(hipMemset(ix->text2.p, 0, (nWords + 16) * sizeof(uint32_t)));
+            DevBuf<uint32_t> bad;
+            bad.alloc(1);
+            HIPCHK(hipMemset(bad.p, 0, sizeof(uint32_t)));
+            hipLaunchKernelGGL(k_pack_text, dim3(4096), dim3(256), 0, 0, ix->text.p, n, nWords, ix->text2.p, bad.p);
+            HIPCHK(hipGetLastError());
+            uint32_t hb = 0;
+            HIPCHK(hipMemcpy(&hb, bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            packedOk = hb == 0 && !getenv("CMB_TEXT_BYTES");
+            if (!packedOk) ix->text2.release();
+        }
         ix->kmer.alloc(1ull << (2 * desc->kmer_size));
         if (desc->seq_starts) ix->seqStarts.assign(desc->seq_starts, desc->seq_starts + desc->n_seqs);
         DevIndex& d = ix->d;
@@ -146,6 +162,7 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         d.saCnt = ix->saCnt.p;
         d.saSamples = ix->saSamples.p;
         d.text = ix->text.p;
+        d.text2 = packedOk ? ix->text2.p : nullptr;
         d.kmer = ix->kmer.p;
         d.kmerSize = desc->kmer_size;
         d.switchPoint = desc->in_text_switch;
@@ -154,7 +171,7 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         HIPCHK(hipGetLastError());
         HIPCHK(hipDeviceSynchronize());
         ix->bytes = ix->blkF.bytes() + ix->blkR.bytes() + ix->saBv.bytes() +
-                    ix->saCnt.bytes() + ix->saSamples.bytes() + ix->text.bytes() + ix->kmer.bytes();
+                    ix->saCnt.bytes() + ix->saSamples.bytes() + ix->text.bytes() + ix->text2.bytes() + ix->kmer.bytes();
         *out = ix.release();
         return CMB_OK;
     } catch (const std::exception& e) {
@@ -873,10 +890,17 @@ static int batchRunOne(cmb_batch* b) {
                         VStageList L0{b->vsA[0].p, b->vsB[0].p, b->vsC[0].p}, L1{b->vsA[1].p, b->vsB[1].p, b->vsC[1].p};
                         // k <= 4: the matrix on 32-bit words (dev_matrix.hpp); CMB_MATRIX_WIDE=1 keeps the 64-bit words
                         const bool w32 = b->k <= MX32_MAX_ED && !getenv("CMB_MATRIX_WIDE");
-                        auto stageFirst = k_verify_stage<true, false>, stageNext = k_verify_stage<false, false>;
-                        if (w32) {
-                            stageFirst = k_verify_stage<true, true>;
-                            stageNext = k_verify_stage<false, true>;
+                        const bool packed = ix->d.text2 != nullptr; // 2-bit text (cmb_index_create)
+                        auto stageFirst = k_verify_stage<true, false, false>, stageNext = k_verify_stage<false, false, false>;
+                        if (w32 && packed) {
+                            stageFirst = k_verify_stage<true, true, true>;
+                            stageNext = k_verify_stage<false, true, true>;
+                        } else if (w32) {
+                            stageFirst = k_verify_stage<true, true, false>;
+                            stageNext = k_verify_stage<false, true, false>;
+                        } else if (packed) {
+                            stageFirst = k_verify_stage<true, false, true>;
+                            stageNext = k_verify_stage<false, false, true>;
                         }
                         hipLaunchKernelGGL(stageFirst, dim3(grid), dim3(256), 0, s, ix->d, b->offs.p, mf,
                                            b->vkeysA.p, b->vcounts.p, nRuns, L0, L1, b->vsN.p, listCap, 0u, nb, b->tbq.p, tbCap, q);
@@ -907,7 +931,9 @@ static int batchRunOne(cmb_batch* b) {
                     if (b->vW.n < (size_t)tLines * 8 * tSlots) b->vW.alloc((size_t)tLines * 8 * tSlots);
                     VPlanes vp{b->vW.p, tSlots, tLines};
                     tm.begin();
-                    hipLaunchKernelGGL(narrow ? k_traceback<true> : k_traceback<false>, dim3(tSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, mf, b->tbq.p, nTb,
+                    auto kTrace = k_traceback<false, false>;
+                    if (narrow) kTrace = ix->d.text2 ? k_traceback<true, true> : k_traceback<true, false>;
+                    hipLaunchKernelGGL(kTrace, dim3(tSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, mf, b->tbq.p, nTb,
                                        vp, q);
                     tm.end("k_traceback");
                 }
@@ -1261,9 +1287,12 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
             hipLaunchKernelGGL(k_verify<false>, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, mlen, gw, seq.p, mf,
                                items.p, (uint32_t)n, tbq.p, (uint32_t)tbq.n, (unsigned long long*)nullptr, q);
             HIPCHK(hipMemcpy(hc, cnt.p, 32, hipMemcpyDeviceToHost));
-            if (hc[7])
-                hipLaunchKernelGGL(narrow ? k_traceback<true> : k_traceback<false>, dim3(slots / 256), dim3(256), 0, 0,
+            if (hc[7]) {
+                auto kTrace = k_traceback<false, false>;
+                if (narrow) kTrace = idx->d.text2 ? k_traceback<true, true> : k_traceback<true, false>;
+                hipLaunchKernelGGL(kTrace, dim3(slots / 256), dim3(256), 0, 0,
                                    idx->d, offs.p, mf, tbq.p, hc[7], vp, q);
+            }
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy(hc, cnt.p, 32, hipMemcpyDeviceToHost));

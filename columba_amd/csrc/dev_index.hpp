@@ -38,6 +38,7 @@ struct DevIndex {
     const uint64_t* saCnt;
     const uint32_t* saSamples;
     const uint8_t* text;
+    const uint32_t* text2; // 2 bits per character, 16 per word (nullptr if the text holds non-ACGT characters before '$')
     const uint4* kmer; // 4^kmerSize entries {sa.b, sa.e, rev.b, rev.e}
     uint32_t kmerSize;
     uint32_t switchPoint;

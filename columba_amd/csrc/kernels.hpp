@@ -576,6 +576,33 @@ __global__ void k_encode_text(uint8_t* __restrict__ text, uint64_t n, uint64_t n
     }
 }
 __device__ __forceinline__ uint32_t textCode(uint8_t code) { return code; }
+// The 2-bit copy of the text for the matrix kernels (a verification fetches 16 bytes per 64 rows instead of 64:
+// one memory sector instead of two or three).  The rows a verification computes never reach the '$' (the window
+// ends at n - 1, indexhelpers.cpp:527), so the copy is exact wherever it is used, PROVIDED the text has no other
+// non-ACGT character: `bad` counts them and cmb_index_create then leaves DevIndex::text2 null (byte path).
+__global__ void k_pack_text(const uint8_t* __restrict__ text, uint64_t n, uint64_t nWords, uint32_t* __restrict__ text2,
+                            uint32_t* __restrict__ bad) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nWords; w += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 v = reinterpret_cast<const uint4*>(text)[w];
+        const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+        uint32_t out = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) {
+            const uint32_t c = (in[j >> 2] >> (8 * (j & 3u))) & 0xFFu;
+            out |= (c & 3u) << (2 * j);
+            if (c > 3u && 16 * w + j + 1 < n) atomicAdd(bad, 1u); // (position n - 1 is the '$')
+        }
+        text2[w] = out;
+    }
+}
+// 32 characters from character position `pos` of the packed text: lo = characters 0..15, hi = 16..31
+__device__ __forceinline__ void loadText2x32(const uint32_t* __restrict__ text2, uint32_t pos, uint32_t& lo, uint32_t& hi) {
+    const uint32_t* p = text2 + (pos >> 4);
+    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+    const uint32_t sh = (pos & 15u) * 2u;
+    lo = __funnelshift_r(w0, w1, sh);
+    hi = __funnelshift_r(w1, w2, sh);
+}
 
 // 16 text codes from ANY byte offset (gfx950 serves unaligned 16-byte global loads)
 struct __attribute__((packed, aligned(1))) Unaligned16 {
@@ -630,7 +657,7 @@ __device__ __forceinline__ void loadMatchWords(const MFull& mf, uint32_t rs, uin
 //   are detected on the fly (bitparallelmatrix.h:591-614 needs only ED(i-1), ED(i), ED(i+1)).
 // STORE = true : traceback pass (k_traceback) — HP and D0 of every row go to the interleaved planes.
 // Returns the number of valid rows `i` (indexhelpers.cpp:535-539); centreMask bit t <=> row firstRow+1+t.
-template <bool STORE, bool NARROW = false>
+template <bool STORE, bool NARROW = false, bool PACKED = false>
 __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull& mf, uint32_t rs,
                                                 const MatGeom& g, uint32_t nZeros, uint32_t start, uint32_t size,
                                                 uint32_t maxED, uint32_t minED, uint32_t& centreMask,
@@ -657,14 +684,26 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
     const uint32_t tid = threadIdx.x;
     Ml[4 * 256 + tid] = 0ull;
     const uint8_t* tp = ix.text + start;
-    uint4 cur = loadText16(tp);
-    uint4 nxt = loadText16(tp + 16); // the text allocation is padded
+    uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
+    // PACKED: the 16 characters of chunk c are a funnel shift of words c, c + 1 of the packed text from `start`
+    const uint32_t* tp2 = PACKED ? ix.text2 + (start >> 4) : nullptr;
+    const uint32_t sh2 = (start & 15u) * 2u;
+    uint32_t pw0 = 0, pw1 = 0, pw2 = 0;
+    if (PACKED) {
+        pw0 = tp2[0];
+        pw1 = tp2[1];
+        pw2 = tp2[2];
+    } else {
+        cur = loadText16(tp);
+        nxt = loadText16(tp + 16); // the text allocation is padded
+    }
     uint32_t i = 0;
     bool alive = size > 0;
     uint64_t buf[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // STORE: the packed rows of the current group of eight
     uint32_t bufN[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // NARROW: of the current group of sixteen
     bool groupAlive = false;
     for (uint32_t c = 0; __ballot(alive) != 0ull; c++) {
+        const uint32_t pcur = PACKED ? __funnelshift_r(pw0, pw1, sh2) : 0u;
 #pragma unroll
         for (uint32_t t = 0; t < 16; t++) {
             const uint32_t r = 16 * c + t + 1;
@@ -679,7 +718,7 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
             }
             const uint32_t wsel = t >> 2;
             const uint32_t wv = wsel == 0 ? cur.x : wsel == 1 ? cur.y : wsel == 2 ? cur.z : cur.w;
-            const uint32_t tc = (wv >> (8 * (t & 3u))) & 0xFFu;
+            const uint32_t tc = PACKED ? (pcur >> (2 * t)) & 3u : (wv >> (8 * (t & 3u))) & 0xFFu;
             if (alive) {
                 const uint64_t M64 = Ml[tc * 256 + tid];
                 const W M = NARROW ? (W)matchWord32(M64, r) : (W)M64;
@@ -723,8 +762,14 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
                                       (uint32_t)(buf[2 * h + 1] >> 32));
             }
         }
-        cur = nxt;
-        nxt = loadText16(tp + 16 * (c + 2));
+        if (PACKED) {
+            pw0 = pw1;
+            pw1 = pw2;
+            pw2 = tp2[c + 3];
+        } else {
+            cur = nxt;
+            nxt = loadText16(tp + 16 * (c + 2));
+        }
     }
     if (!STORE && i > firstRow) { // the last valid row has no `below` neighbour (i == lastRow)
         const uint32_t e1 = edPrev;
@@ -957,7 +1002,7 @@ struct VStageList { // survivors entering a stage
 };
 
 // W32: the matrix on 32-bit words / 8-row blocks (dev_matrix.hpp; k <= 4) — half the VALU work of a row.
-template <bool FIRST, bool W32>
+template <bool FIRST, bool W32, bool PACKED>
 __global__ void __launch_bounds__(256)
 k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                const unsigned long long* __restrict__ ukeys, const uint32_t* __restrict__ counts, uint32_t nKeys,
@@ -1036,10 +1081,15 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
         const bool head = FIRST && h == 0; // rows 1..31 of the matrix
         const uint32_t r0 = head ? 1u : 32u * blk;
         uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0;
+        uint32_t pLo = 0, pHi = 0;
         if (alive) {
-            const uint8_t* tp = ix.text + start + (r0 - 1); // text character of row r is text[start + r - 1]
-            t0 = loadText16(tp);
-            t1 = loadText16(tp + 16); // the text allocation is padded
+            if (PACKED) {
+                loadText2x32(ix.text2, start + (r0 - 1), pLo, pHi);
+            } else {
+                const uint8_t* tp = ix.text + start + (r0 - 1); // text character of row r is text[start + r - 1]
+                t0 = loadText16(tp);
+                t1 = loadText16(tp + 16); // the text allocation is padded
+            }
             uint64_t mw[4];
             loadMatchWords(mf, rs, blk, mw);
 #pragma unroll
@@ -1051,7 +1101,7 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             const uint32_t wsel = (t >> 2) & 3u;
             const uint4 tw = t < 16 ? t0 : t1;
             const uint32_t wv = wsel == 0 ? tw.x : wsel == 1 ? tw.y : wsel == 2 ? tw.z : tw.w;
-            const uint32_t tc = (wv >> (8 * (t & 3u))) & 0xFFu;
+            const uint32_t tc = PACKED ? ((t < 16 ? pLo : pHi) >> (2 * (t & 15u))) & 3u : (wv >> (8 * (t & 3u))) & 0xFFu;
             if (alive && !(t == 31 && head)) { // (the head block has 31 rows)
                 const uint64_t M64 = Ml[tc * 256 + tid];
                 const W M = W32 ? (W)matchWord32(M64, r) : (W)M64;
@@ -1124,7 +1174,7 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
 // (bitparallelmatrix.h:531-586).  The traceback reads rows through an 8-row window staged in LDS, so
 // the dependent chain costs one memory round trip per 8 rows instead of three per row.
 constexpr int TBW = 8;
-template <bool NARROW>
+template <bool NARROW, bool PACKED>
 __global__ void __launch_bounds__(256)
 k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             const uint4* __restrict__ tbq, uint32_t nTasks, VPlanes V, Queues q) {
@@ -1171,7 +1221,7 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             const uint32_t topCentre = firstRow + 1 + (31u - (uint32_t)__clz(m));
             uint32_t dummyMask;
             // rows 1..topCentre (all valid: they were valid in pass 1)
-            forwardPass<true, NARROW>(ix, mf, rs, g, nZeros, start, topCentre, maxED, 0, dummyMask, edPack, edPackHi, V,
+            forwardPass<true, NARROW, PACKED>(ix, mf, rs, g, nZeros, start, topCentre, maxED, 0, dummyMask, edPack, edPackHi, V,
                                       slot, dummyRows, Ml);
         }
         // one centre per lane and round; the wavefront appends its results with one atomic per round

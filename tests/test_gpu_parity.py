@@ -214,6 +214,24 @@ def test_high_copy_repeat(oracle_built):
     _compare(w, "kuch1", "edit", "dynamic", 0, reads)
 
 
+def test_byte_text_path(world):
+    """The matrix kernels read a 2-bit copy of the text; an index whose text holds other characters than ACGT
+    before the '$' keeps the one-byte codes (forced here with CMB_TEXT_BYTES=1 at index creation)."""
+    import os
+    os.environ["CMB_TEXT_BYTES"] = "1"
+    try:
+        dev2 = ca.Index(world["ix"])
+    finally:
+        del os.environ["CMB_TEXT_BYTES"]
+    reads = synth.sample_reads(world["genome"], 3000, 150, seed=104, n_frac=0.02)
+    for spec, k in (("multiple_opt", 4), ("multiple_opt", 6)):
+        st = ca.SearchStrategy(spec, "edit", "dynamic")
+        o1, f1, c1 = ca.match_batch(world["dev"], st, k, reads)
+        o2, f2, c2 = ca.match_batch(dev2, st, k, reads)
+        assert np.array_equal(f1, f2) and np.array_equal(o1, o2)
+        assert c1 == c2
+
+
 def test_errors_are_loud(world):
     st = ca.SearchStrategy("multiple_opt")
     with pytest.raises(ca.CmbError) as e:   # read not longer than the number of parts
