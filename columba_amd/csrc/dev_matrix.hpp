@@ -163,14 +163,15 @@ constexpr uint32_t MX32_BLOCK = 8, MX32_DIAG = 13, MX32_LEFT = 14, MX32_MAX_ED =
 __device__ __forceinline__ uint32_t matchWord32(uint64_t M64, uint32_t i) {
     return (uint32_t)(M64 >> (((i % MX_BLOCK) / MX32_BLOCK) * MX32_BLOCK + (MX_LEFT - MX32_LEFT)));
 }
+// (the rightmost active column is kept as a bit INDEX `rac` here, not as a one-bit mask: racInit / racIndex)
 __device__ __forceinline__ bool computeRow(const MatGeom& g, uint32_t i, uint32_t M, uint32_t& HP, uint32_t& HN,
-                                           uint32_t& D0, uint32_t& RAC, uint32_t& score) {
+                                           uint32_t& D0, uint32_t& rac, uint32_t& score) {
     const uint32_t l = i % MX32_BLOCK;
-    RAC <<= 1u;
+    rac += 1u;
     if (l == 0) {
         HP >>= MX32_BLOCK;
         HN >>= MX32_BLOCK;
-        RAC >>= MX32_BLOCK;
+        rac -= MX32_BLOCK;
     }
     D0 = (((M & HP) + HP) ^ HP) | M | HN;
     const uint32_t VP = HN | ~(D0 | HP);
@@ -179,8 +180,8 @@ __device__ __forceinline__ bool computeRow(const MatGeom& g, uint32_t i, uint32_
     HN = (D0 & (VP << 1u));
     const uint32_t diagBit = l + MX32_DIAG;
     score += (D0 >> diagBit) & 1u ? 0u : 1u;
-    if (!(D0 & RAC)) { // the RAC walk, as in the 64-bit version
-        const uint32_t q = (uint32_t)__ffs((int)RAC) - 1u;
+    if (!((D0 >> rac) & 1u)) { // the RAC walk, as in the 64-bit version
+        const uint32_t q = rac;
         const uint32_t maxSteps = q - (diagBit - g.Wv);
         uint32_t hp = HP << (31u - q);
         uint32_t hn = HN << (31u - q);
@@ -200,10 +201,15 @@ __device__ __forceinline__ bool computeRow(const MatGeom& g, uint32_t i, uint32_
             }
             if (k >= maxSteps) return false;
         }
-        RAC = 1u << (q - k - 1u);
+        rac = q - k - 1u;
     }
     return true;
 }
+// the RAC state of a matrix word type: one-bit mask (64-bit matrix) or bit index (32-bit matrix)
+__device__ __forceinline__ uint64_t racInit(uint64_t, uint32_t bit) { return 1ull << bit; }
+__device__ __forceinline__ uint32_t racInit(uint32_t, uint32_t bit) { return bit; }
+__device__ __forceinline__ uint32_t racIndex(uint64_t rac) { return (uint32_t)__ffsll((unsigned long long)rac) - 1u; }
+__device__ __forceinline__ uint32_t racIndex(uint32_t rac) { return rac; }
 __device__ __forceinline__ uint32_t cellAt(uint32_t i, uint32_t j, uint32_t HP, uint32_t HN, uint32_t score) {
     const uint32_t bit = (i % MX32_BLOCK) + MX32_DIAG;
     const uint32_t b = (i > j) ? bit - (i - j) + 1 : bit + 1;

@@ -666,7 +666,7 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
     // NARROW (k <= 4) also means the matrix on 32-bit words / 8-row blocks (dev_matrix.hpp)
     using W = typename std::conditional<NARROW, uint32_t, uint64_t>::type;
     constexpr uint32_t LEFT = NARROW ? MX32_LEFT : MX_LEFT, DIAG = NARROW ? MX32_DIAG : MX_DIAG;
-    W HP = (W)(~(W)0) << LEFT, HN = ((W)1 << (LEFT + 1u - nZeros)) - (W)1, D0 = 0, RAC = (W)1 << (DIAG + g.Wh);
+    W HP = (W)(~(W)0) << LEFT, HN = ((W)1 << (LEFT + 1u - nZeros)) - (W)1, D0 = 0, RAC = racInit((W)0, DIAG + g.Wh);
     uint32_t score = 0;
     const uint32_t sfc = g.sfc();
     const uint32_t firstRow = (g.m - 1) - sfc;
@@ -1042,7 +1042,7 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                 HP = W32 ? (W)rb.x : (W)((uint64_t)rb.x | ((uint64_t)rb.y << 32));
                 HN = W32 ? (W)rb.z : (W)((uint64_t)rb.z | ((uint64_t)rb.w << 32));
                 len = rc & 0xFFFFu;
-                RAC = (W)1 << ((rc >> 16) & 63u);
+                RAC = racInit((W)0, (rc >> 16) & 63u);
                 edPrev = (rc >> 22) & 31u;
                 edPrev2 = (rc >> 27) & 31u;
             }
@@ -1068,7 +1068,7 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             if (FIRST && alive) {
                 HP = (W)(~(W)0) << LEFT;
                 HN = ((W)1 << (LEFT + 1u - nZeros)) - (W)1; // first column: nZeros zeros, then 1, 2, ...
-                RAC = (W)1 << (DIAG + g.Wh);
+                RAC = racInit((W)0, DIAG + g.Wh);
                 if (firstRow == 0) edPrev = cellAt(0, col, HP, HN, 0);
             }
         }
@@ -1155,7 +1155,7 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                 if (score > 255u) flags |= FLAG_CAPACITY;
                 out.a[oS] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), mult | (score << 24), mask);
                 out.b[oS] = make_uint4((uint32_t)HP, (uint32_t)((uint64_t)HP >> 32), (uint32_t)HN, (uint32_t)((uint64_t)HN >> 32));
-                out.c[oS] = len | ((uint32_t)(__ffsll((unsigned long long)RAC) - 1) << 16) | (edPrev << 22) | (edPrev2 << 27);
+                out.c[oS] = len | (racIndex(RAC) << 16) | (edPrev << 22) | (edPrev2 << 27);
             }
         }
         if (nTb) {
