@@ -81,7 +81,7 @@ struct cmb_index {
     int device = 0;
     DevIndex d{};
     DevBuf<uint4> blkF, blkR; // 128-byte rank blocks
-    DevBuf<uint64_t> saBv, saCnt;
+    DevBuf<uint64_t> saBlk;
     DevBuf<uint32_t> saSamples;
     DevBuf<uint8_t> text;
     DevBuf<uint32_t> text2;
@@ -124,8 +124,17 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
             HIPCHK(hipDeviceSynchronize());
         }
         const uint64_t saW = (n + 63) / 64;
-        ix->saBv.upload(desc->sa_bv, saW);
-        ix->saCnt.upload(desc->sa_bv_counts, (saW + 7) / 4);
+        { // sampled-row bitvector + rank9 counts -> 64-byte records (k_relayout_sa); the originals are dropped
+            DevBuf<uint64_t> bv, cnt;
+            bv.upload(desc->sa_bv, saW);
+            cnt.upload(desc->sa_bv_counts, (saW + 7) / 4);
+            const uint64_t nSaBlocks = n / SA_BLOCK + 2;
+            ix->saBlk.alloc(nSaBlocks * 8);
+            hipLaunchKernelGGL(k_relayout_sa, dim3((unsigned)((nSaBlocks + 255) / 256)), dim3(256), 0, 0, bv.p, cnt.p, saW,
+                               nSaBlocks, ix->saBlk.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipDeviceSynchronize());
+        }
         ix->saSamples.upload(desc->sa_samples, desc->n_samples);
         // padded: the verification kernels read (unaligned) 16-byte chunks up to two chunks ahead, and lanes whose
         // candidate has ended keep prefetching while their wavefront runs (at most MAX_READ + 3 k rows + 48 bytes)
@@ -158,8 +167,7 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         for (int i = 0; i < 5; i++) d.counts[i] = (uint32_t)desc->counts[i];
         d.fwd = DevBWT{ix->blkF.p, (uint32_t)desc->dollar_pos_fwd};
         d.rev = DevBWT{ix->blkR.p, (uint32_t)desc->dollar_pos_rev};
-        d.saBv = ix->saBv.p;
-        d.saCnt = ix->saCnt.p;
+        d.saBlk = ix->saBlk.p;
         d.saSamples = ix->saSamples.p;
         d.text = ix->text.p;
         d.text2 = packedOk ? ix->text2.p : nullptr;
@@ -170,8 +178,7 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         hipLaunchKernelGGL(k_kmer_table, dim3((total + 255) / 256), dim3(256), 0, 0, d, ix->kmer.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipDeviceSynchronize());
-        ix->bytes = ix->blkF.bytes() + ix->blkR.bytes() + ix->saBv.bytes() +
-                    ix->saCnt.bytes() + ix->saSamples.bytes() + ix->text.bytes() + ix->text2.bytes() + ix->kmer.bytes();
+        ix->bytes = ix->blkF.bytes() + ix->blkR.bytes() + ix->saBlk.bytes() + ix->saSamples.bytes() + ix->text.bytes() + ix->text2.bytes() + ix->kmer.bytes();
         *out = ix.release();
         return CMB_OK;
     } catch (const std::exception& e) {

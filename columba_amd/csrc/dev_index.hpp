@@ -34,8 +34,7 @@ struct DevIndex {
     uint32_t n; // text length including '$'
     uint32_t counts[5];
     DevBWT fwd, rev;
-    const uint64_t* saBv;
-    const uint64_t* saCnt;
+    const uint64_t* saBlk; // sampled-row bitvector with its ranks, 64-byte records of 384 rows (k_relayout_sa)
     const uint32_t* saSamples;
     const uint8_t* text;
     const uint32_t* text2; // 2 bits per character, 16 per word (nullptr if the text holds non-ACGT characters before '$')
@@ -239,22 +238,35 @@ __device__ __forceinline__ bool extendOne(const DevIndex& ix, int mode, const Ra
     return childFromRanks(ix, mode, p, c, Rb, Re, db, de, child);
 }
 
-// rank9 Bitvec (bitvec.h:155-170)
-__device__ __forceinline__ bool saMarked(const DevIndex& ix, uint32_t i) {
-    return (ix.saBv[i >> 6] >> (i & 63u)) & 1ull;
+// rank9 Bitvec (bitvec.h:155-170) of the sampled suffix-array rows, re-packed (k_relayout_sa) so that "is this row
+// sampled" and "its rank" come from ONE 64-byte record: six 64-bit words of bits (384 rows), the number of set
+// bits before the record, and the five 9-bit counts of set bits before words 1..5 of the record.
+constexpr uint32_t SA_BLOCK = 384;
+struct SaPos {
+    uint32_t blk, off; // record, row inside the record
+};
+__device__ __forceinline__ SaPos saPos(uint32_t row) {
+    const uint32_t blk = row / SA_BLOCK;
+    return SaPos{blk, row - blk * SA_BLOCK};
 }
-// rank with the bitvector word of position p already at hand (`word` = saBv[p >> 6]); the two interleaved
-// count words of the 512-position block are one aligned 16-byte load
-__device__ __forceinline__ uint32_t saRankW(const DevIndex& ix, uint32_t p, uint64_t word) {
-    const uint32_t w = p >> 6, b = p & 63u;
-    const ulonglong2 c = reinterpret_cast<const ulonglong2*>(ix.saCnt)[w >> 3];
+__device__ __forceinline__ uint64_t saWord(const DevIndex& ix, SaPos p) { return ix.saBlk[(size_t)p.blk * 8 + (p.off >> 6)]; }
+__device__ __forceinline__ bool saMarked(const DevIndex& ix, uint32_t i) {
+    const SaPos p = saPos(i);
+    return (saWord(ix, p) >> (p.off & 63u)) & 1ull;
+}
+// rank with the bitvector word of the row already at hand
+__device__ __forceinline__ uint32_t saRankW(const DevIndex& ix, SaPos p, uint64_t word) {
+    const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(ix.saBlk + (size_t)p.blk * 8 + 6);
     uint64_t rv = c.x;
-    const uint32_t sub = w & 7u;
+    const uint32_t sub = p.off >> 6, b = p.off & 63u;
     if (sub) rv += (c.y >> ((sub - 1u) * 9u)) & 0x1FFull;
     const uint64_t lowmask = b ? (~0ull >> (64u - b)) : 0ull;
     return (uint32_t)rv + (uint32_t)__popcll(word & lowmask);
 }
-__device__ __forceinline__ uint32_t saRank(const DevIndex& ix, uint32_t p) { return saRankW(ix, p, ix.saBv[p >> 6]); }
+__device__ __forceinline__ uint32_t saRank(const DevIndex& ix, uint32_t row) {
+    const SaPos p = saPos(row);
+    return saRankW(ix, p, saWord(ix, p));
+}
 
 // findLF (fmindex.cpp:47-51): BWT symbol decoded from the cumulative bitvectors
 __device__ __forceinline__ uint32_t findLF(const DevIndex& ix, uint32_t k) {
@@ -276,14 +288,16 @@ __device__ __forceinline__ uint32_t findLF(const DevIndex& ix, uint32_t k) {
 // findSA (fmindex.cpp:53-60); *lf accumulates the number of LF steps
 __device__ __forceinline__ uint32_t findSA(const DevIndex& ix, uint32_t row, uint32_t* lf) {
     uint32_t l = 0;
-    uint64_t word = ix.saBv[row >> 6];
-    while (!((word >> (row & 63u)) & 1ull)) { // not a sampled row
+    SaPos p = saPos(row);
+    uint64_t word = saWord(ix, p);
+    while (!((word >> (p.off & 63u)) & 1ull)) { // not a sampled row
         row = findLF(ix, row);
-        word = ix.saBv[row >> 6];
+        p = saPos(row);
+        word = saWord(ix, p);
         l++;
     }
     if (lf) *lf += l;
-    return ix.saSamples[saRankW(ix, row, word)] + l;
+    return ix.saSamples[saRankW(ix, p, word)] + l;
 }
 
 } // namespace cmb

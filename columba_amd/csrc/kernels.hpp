@@ -92,6 +92,37 @@ __global__ void k_locate(DevIndex ix, const uint32_t* __restrict__ rows, uint64_
     if (lf) atomicAdd(lfTotal, (unsigned long long)lf);
 }
 
+// Re-packs the sampled-row bitvector and its rank9 counts (bitvec.h:155-170: per 512 rows the count before the block
+// and seven 9-bit in-block counts) into the 64-byte records of dev_index.hpp (SA_BLOCK rows each).
+__global__ void k_relayout_sa(const uint64_t* __restrict__ bv, const uint64_t* __restrict__ cnt, uint64_t nWords,
+                              uint64_t nBlocks, uint64_t* __restrict__ out) {
+    const uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= nBlocks) return;
+    const uint64_t w0 = blk * (SA_BLOCK / 64);
+    // set bits before word w0 (rank9 of the original arrays)
+    uint64_t before = 0;
+    if (w0 < nWords) {
+        before = cnt[(w0 >> 3) * 2];
+        const uint32_t sub = (uint32_t)(w0 & 7u);
+        if (sub) before += (cnt[(w0 >> 3) * 2 + 1] >> ((sub - 1u) * 9u)) & 0x1FFull;
+    } else if (nWords) { // past the end: everything
+        const uint64_t wl = nWords - 1;
+        before = cnt[(wl >> 3) * 2];
+        const uint32_t sub = (uint32_t)(wl & 7u);
+        if (sub) before += (cnt[(wl >> 3) * 2 + 1] >> ((sub - 1u) * 9u)) & 0x1FFull;
+        before += (uint64_t)__popcll((unsigned long long)bv[wl]);
+    }
+    uint64_t subs = 0, run = 0;
+    for (uint32_t j = 0; j < SA_BLOCK / 64; j++) {
+        const uint64_t word = w0 + j < nWords ? bv[w0 + j] : 0ull;
+        out[blk * 8 + j] = word;
+        if (j) subs |= run << ((j - 1u) * 9u);
+        run += (uint64_t)__popcll((unsigned long long)word);
+    }
+    out[blk * 8 + 6] = before;
+    out[blk * 8 + 7] = subs;
+}
+
 // k-mer table: entry `key` = ranges of the k-mer after `kmerSize` forward extensions from the
 // complete range; k-mers that do not occur keep SARangePair() = zeros (never inserted, :330).
 __global__ void k_kmer_table(DevIndex ix, uint4* __restrict__ table) {
