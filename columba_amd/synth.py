@@ -127,7 +127,7 @@ def genome_human_like(n: int, seed: int = 2025, device="cpu"):
       * L1-like: 6 kb consensus, truncated copies covering ~8 %, 5 % divergence
       * segmental duplications: 20 kb segments copied at 1 % divergence (~2 %)
       * tandem repeats: 2-30 bp units x 5-40 copies
-    Returns (uint8 ASCII torch tensor on `device`, seq_starts numpy).  Deterministic in `seed`.
+    Returns (uint8 ASCII torch tensor on `device`, seq_starts numpy).  Deterministic in (`seed`, device type).
     """
     import torch
     dev = torch.device(device)
@@ -143,6 +143,16 @@ def genome_human_like(n: int, seed: int = 2025, device="cpu"):
         m = min(1 << 28, n - o)
         g[o:o + m] = rnd((m,))
 
+    def put(idx, vals):
+        # overlapping copies write some positions twice: on the GPU a plain indexed store lets either value win,
+        # differently from run to run; the deterministic kernel (sorted indices) makes the genome reproducible
+        prev = torch.are_deterministic_algorithms_enabled()
+        torch.use_deterministic_algorithms(True)
+        try:
+            g.index_put_((idx,), vals)
+        finally:
+            torch.use_deterministic_algorithms(prev)
+
     def inject(consensus, copies, div, min_len=None):
         ln = consensus.numel()
         chunk = max(1, (1 << 26) // ln)
@@ -156,9 +166,9 @@ def genome_human_like(n: int, seed: int = 2025, device="cpu"):
             if min_len is not None:  # truncated copies: keep a random suffix
                 keep = torch.randint(min_len, ln + 1, (c,), generator=gen, device=dev)
                 mask = torch.arange(ln, device=dev)[None, :] >= (ln - keep)[:, None]
-                g[idx[mask]] = vals[mask]
+                put(idx[mask], vals[mask])
             else:
-                g[idx.reshape(-1)] = vals.reshape(-1)
+                put(idx.reshape(-1), vals.reshape(-1))
 
     if n >= 100_000:
         inject(rnd((300,)), n // 3000, 0.12)
@@ -178,7 +188,7 @@ def genome_human_like(n: int, seed: int = 2025, device="cpu"):
         tr = torch.gather(unit_seq, 1, (ar % units[:, None]).long())
         mask = ar < (units * copies)[:, None]
         idx = pos[:, None] + ar
-        g[idx[mask]] = tr[mask]
+        put(idx[mask], tr[mask])
     text = acgt[g.long()] if n < (1 << 28) else torch.cat([acgt[g[o:o + (1 << 28)].long()] for o in range(0, n, 1 << 28)])
     starts = np.linspace(0, n, 25).astype(np.uint32)  # 24 "chromosomes"
     return text, starts
