@@ -32,7 +32,8 @@ def broadcast_index(ix: Optional[ib.IndexArrays], rank: int, dev) -> ib.IndexArr
             t = torch.from_numpy(np.ascontiguousarray(getattr(ix, f)).view(np.uint8).reshape(-1).copy()).to(dev)
         else:
             t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        dist.broadcast(t, src=0)
+        if nbytes:  # (an absent array, e.g. the BWT words the device does not need, has no elements)
+            dist.broadcast(t, src=0)
         arrays[f] = getattr(ix, f) if rank == 0 else t.cpu().numpy().view(dt).reshape(shape)
         del t
     if rank == 0:
