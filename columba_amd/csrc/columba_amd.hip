@@ -501,16 +501,22 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
     // per-kernel timings and counters want (bench.py times its throughput steps concurrently and takes the
     // kernel table from one extra serial step)
     const bool serial = getenv("CMB_SERIAL_SUBBATCHES") != nullptr;
+    // workers take the sub-batches in order; CMB_MAX_CONCURRENT=m: at most m at a time (default: all of them)
+    const char* mcEnv = getenv("CMB_MAX_CONCURRENT");
+    size_t nWorkers = serial ? 1 : b->subs.size();
+    if (mcEnv && !serial) nWorkers = std::min<size_t>(b->subs.size(), std::max(1, atoi(mcEnv)));
+    std::atomic<size_t> next{0};
     std::vector<std::thread> th;
-    for (size_t j = 0; j < b->subs.size(); j++) {
-        th.emplace_back([&, j] {
-            rc[j] = batchRunOne(b->subs[j]);
-            if (rc[j] != CMB_OK) err[j] = cmb_last_error(); // (the message lives in the worker's thread-local storage)
+    for (size_t w = 0; w < nWorkers; w++)
+        th.emplace_back([&] {
+            for (;;) {
+                const size_t j = next.fetch_add(1);
+                if (j >= b->subs.size()) break;
+                rc[j] = batchRunOne(b->subs[j]);
+                if (rc[j] != CMB_OK) err[j] = cmb_last_error(); // (the message lives in the worker's thread-local storage)
+            }
         });
-        if (serial) th.back().join();
-    }
-    for (auto& t : th)
-        if (t.joinable()) t.join();
+    for (auto& t : th) t.join();
     for (size_t j = 0; j < rc.size(); j++)
         if (rc[j] != CMB_OK) return fail(rc[j], err[j]);
     memset(b->cnts, 0, sizeof(b->cnts));
