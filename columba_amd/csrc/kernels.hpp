@@ -1470,39 +1470,51 @@ k_filter_mark(const unsigned long long* __restrict__ keys, uint32_t nReads, uint
     if (r < nReads) segLo = segBeg[r];
     const bool has = segLo != 0xFFFFFFFFu; // (no occurrence of this read otherwise)
     const uint32_t nSeg = has ? segEnd[r] - segLo : 0u;
-    uint32_t nOut = 0, lastKept = 0;
     const uint32_t maxDiff = 2 * k;
-    uint32_t prevBegin = 0xFFFFFFFFu, prevDepth = 0xFFFFFFFFu, prevED = k + 1;
-    unsigned long long prevKey = ~0ull;
-    auto step = [&](uint32_t i, unsigned long long key) {
+    // the filter's state and one step of it: returns the key's rank among the survivors (or NONE) and, in
+    // `replaced`, the index of the previously kept key if this one takes its place (else NONE)
+    struct State {
+        uint32_t nOut = 0, lastKept = 0, prevBegin = 0xFFFFFFFFu, prevDepth = 0xFFFFFFFFu, prevED;
+        unsigned long long prevKey = ~0ull;
+    };
+    auto stepCore = [&](State& st, uint32_t i, unsigned long long key, uint32_t& replaced) -> uint32_t {
         const uint32_t begin = (uint32_t)(key >> 8), dist = (uint32_t)(key >> 5) & 7u;
         const uint32_t width = (uint32_t)(key >> 1) & 15u; // relative to len - k: the same for all keys of a read
-        uint32_t mine = FILTER_NONE;
+        replaced = FILTER_NONE;
         bool keep = true;
         if (mode != 0) {
-            if ((key >> 1) == (prevKey >> 1)) keep = false; // same range and distance (either strand)
-            else prevKey = key;
+            if ((key >> 1) == (st.prevKey >> 1)) keep = false; // same range and distance (either strand)
+            else st.prevKey = key;
         }
         if (keep && mode == 2) {
-            const uint32_t diff = begin > prevBegin ? begin - prevBegin : prevBegin - begin;
+            const uint32_t diff = begin > st.prevBegin ? begin - st.prevBegin : st.prevBegin - begin;
             if (diff == 0) keep = false;
             else if (diff <= maxDiff) {
-                if (dist > prevED || (dist == prevED && width >= prevDepth)) keep = false;
+                if (dist > st.prevED || (dist == st.prevED && width >= st.prevDepth)) keep = false;
                 else {
-                    nOut--; // the previous one was worse: replace it
-                    rank[segLo + lastKept] = FILTER_NONE;
+                    st.nOut--; // the previous one was worse: replace it
+                    replaced = st.lastKept;
                 }
             }
             if (keep) {
-                prevBegin = begin;
-                prevED = dist;
-                prevDepth = width;
+                st.prevBegin = begin;
+                st.prevED = dist;
+                st.prevDepth = width;
             }
         }
+        uint32_t mine = FILTER_NONE;
         if (keep) {
-            mine = nOut++;
-            lastKept = i;
+            mine = st.nOut++;
+            st.lastKept = i;
         }
+        return mine;
+    };
+    State mySt;
+    mySt.prevED = k + 1;
+    auto step = [&](uint32_t i, unsigned long long key) { // a lane walking its own short segment
+        uint32_t replaced;
+        const uint32_t mine = stepCore(mySt, i, key, replaced);
+        if (replaced != FILTER_NONE) rank[segLo + replaced] = FILTER_NONE;
         rank[segLo + i] = mine;
     };
     const bool isShort = nSeg <= FILTER_SHORT;
@@ -1522,21 +1534,42 @@ k_filter_mark(const unsigned long long* __restrict__ keys, uint32_t nReads, uint
                 if (8u + j < nSeg) step(8u + j, nxt[j]);
         }
     }
+    // Long segments: the wavefront fetches 64 keys per load (the next 64 are on their way meanwhile) and ALL lanes
+    // run the filter on them with the same, wave-uniform state (scalar code: the key of step j comes from lane j by
+    // v_readlane); lane j keeps the rank of key j and the 64 ranks leave in one coalesced store.
     unsigned long long todo = __ballot(has && !isShort);
     while (todo) { // wave-uniform
         const int owner = __ffsll((long long)todo) - 1;
         todo &= todo - 1ull;
-        const uint32_t oLo = (uint32_t)__shfl((int)segLo, owner), oN = (uint32_t)__shfl((int)nSeg, owner);
+        const uint32_t oLo = (uint32_t)__builtin_amdgcn_readlane((int)segLo, owner);
+        const uint32_t oN = (uint32_t)__builtin_amdgcn_readlane((int)nSeg, owner);
+        State u;
+        u.prevED = k + 1;
+        unsigned long long nextKey = lane < oN ? keys[oLo + lane] : 0ull;
         for (uint32_t base = 0; base < oN; base += 64u) {
-            const unsigned long long mineKey = base + lane < oN ? keys[oLo + base + lane] : 0ull;
+            const unsigned long long mineKey = nextKey;
+            if (base + 64u < oN) nextKey = base + 64u + lane < oN ? keys[oLo + base + 64u + lane] : 0ull; // prefetch
             const uint32_t cnt = min(64u, oN - base);
+            uint32_t myRank = FILTER_NONE;
             for (uint32_t j = 0; j < cnt; j++) {
-                const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mineKey, (int)j);
-                const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(mineKey >> 32), (int)j);
-                if (lane == (uint32_t)owner) step(base + j, (unsigned long long)lo | ((unsigned long long)hi << 32));
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mineKey, (int)j);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mineKey >> 32), (int)j);
+                uint32_t replaced;
+                const uint32_t mine = stepCore(u, base + j, (unsigned long long)lo | ((unsigned long long)hi << 32), replaced);
+                if (replaced != FILTER_NONE) {
+                    if (replaced >= base) { // still in this chunk's registers
+                        if (lane == replaced - base) myRank = FILTER_NONE;
+                    } else if (lane == (replaced & 63u)) { // already stored with the previous chunk, by this lane
+                        rank[oLo + replaced] = FILTER_NONE;
+                    }
+                }
+                if (lane == j) myRank = mine;
             }
+            if (lane < cnt) rank[oLo + base + lane] = myRank;
         }
+        if (lane == (uint32_t)owner) mySt.nOut = u.nOut;
     }
+    const uint32_t nOut = mySt.nOut;
     if (r < nReads) counts[r] = nOut;
 }
 __global__ void __launch_bounds__(256)
