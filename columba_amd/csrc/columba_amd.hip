@@ -427,7 +427,7 @@ static int batchCreateOne(cmb_index* idx, const cmb_strategy* st, uint32_t max_d
         b->reads.upload((const uint8_t*)seqs, offs[n_reads]);
         b->offs.upload(offs, n_reads + 1);
         b->seq.alloc((size_t)2 * n_reads * maxLen);
-        b->G.alloc((size_t)2 * n_reads * 8 * b->gw);
+        b->G.alloc((size_t)n_reads * 8 * b->gw); // eight bit-strings per read (both strands use them: gString)
         b->recW = ((1 + 2 * ((maxLen + 31) / 32)) + 3) / 4 * 4;
         b->rec.alloc((size_t)2 * n_reads * b->recW);
         b->strat.upload(&b->hostStrat, 1);
@@ -1263,7 +1263,7 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         reads.upload((const uint8_t*)pattern, plen);
         offs.upload(ho, 2);
         seq.alloc(2 * (size_t)mlen);
-        G.alloc(2 * 8 * (size_t)gw);
+        G.alloc(8 * (size_t)gw);
         std::vector<uint4> hi(n);
         const uint32_t meta = (max_ed << 12) | (min_ed << 16) | ((fixed_start ? 1u : 0u) << 20) |
                               ((uint32_t)ITEM_EDIT << 21) | (1u << 23);

@@ -728,10 +728,11 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                 Cx[3] = make_uint4(smDepthN, smShiftN, smDist, xOff | (xLen << 16));
                 Cx[4] = make_uint4(descSelf || otherSelf ? aOff : 0u,
                                    descSelf || otherSelf ? (P.nDescNew | (nInitNew << 8)) : 0u, 0u, 0u);
-                const uint32_t* Gr = G + (size_t)rsId * 8 * gw + (size_t)(useRev * 4) * gw;
+                const uint32_t* Gs[4]; // the bit-strings of A, C, G, T for this read x strand and direction
+                for (uint32_t c4 = 0; c4 < 4; c4++) Gs[c4] = gString(G, gw, rsId, (uint32_t)useRev, c4);
                 for (uint32_t b = 0; b < nBlk; b++) {
-                    const uint64_t a = matchWord(Gr, xOff, xLen, b), c = matchWord(Gr + gw, xOff, xLen, b);
-                    const uint64_t gg = matchWord(Gr + 2 * gw, xOff, xLen, b), t = matchWord(Gr + 3 * gw, xOff, xLen, b);
+                    const uint64_t a = matchWord(Gs[0], xOff, xLen, b), c = matchWord(Gs[1], xOff, xLen, b);
+                    const uint64_t gg = matchWord(Gs[2], xOff, xLen, b), t = matchWord(Gs[3], xOff, xLen, b);
                     Cx[CTX_M + 2 * b] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)c, (uint32_t)(c >> 32));
                     Cx[CTX_M + 1 + 2 * b] = make_uint4((uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)t, (uint32_t)(t >> 32));
                 }
@@ -756,7 +757,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                         const uint32_t meta = dl[2 * j + 1].x;
                         const uint32_t depth = meta & 0xFFFFu, ch = (meta >> 16) & 0xFFu;
                         if (depth > maxRow) break;
-                        const uint64_t M = matchWord(Gr + (size_t)(ch - 1) * gw, xOff, xLen, depth / MX_BLOCK);
+                        const uint64_t M = matchWord(gString(G, gw, rsId, (uint32_t)useRev, ch - 1u), xOff, xLen, depth / MX_BLOCK);
                         uint64_t D0;
                         const bool valid = computeRow(g, depth, M, HP, HN, D0, RAC, score);
                         cRows++;

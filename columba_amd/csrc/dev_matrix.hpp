@@ -31,6 +31,16 @@ __device__ __forceinline__ uint64_t window64(const uint32_t* G, uint32_t off) {
     return sh ? ((lo >> sh) | (hi << (64u - sh))) : lo;
 }
 
+// Bit-string of nucleotide ch (0..3) of read x strand `rs`, of the sequence itself (reversed = 0) or of the reversed
+// sequence (reversed = 1), in the per-READ layout k_prep writes (eight strings of gw words: [0..3] the read, [4..7]
+// the reversed read).  The reverse-complement strand reads the other half with complemented nucleotide.
+__device__ __forceinline__ const uint32_t* gString(const uint32_t* G, uint32_t gw, uint32_t rs, uint32_t reversed,
+                                                   uint32_t ch) {
+    const uint32_t strand = rs & 1u;
+    const uint32_t s = 4u * ((reversed ^ strand) & 1u) + (strand ? 3u - ch : ch);
+    return G + ((size_t)(rs >> 1) * 8 + s) * gw;
+}
+
 // Match word M for block b of a matrix whose horizontal sequence X (length xLen) starts at bit
 // `xOff` of G (G = forward bit-string for FORWARD parts, reversed-read bit-string for BACKWARD
 // parts).  Bit t of block b stands for column index j = t - LEFT + 32 b of X; the LEFT low bits of

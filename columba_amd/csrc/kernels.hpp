@@ -193,14 +193,14 @@ k_prep(const uint8_t* __restrict__ reads, const uint64_t* __restrict__ offs, uin
             dR[1] = make_uint4(cR[4], cR[5], cR[6], cR[7]);
         }
     }
-    uint32_t* gF = G + (size_t)(2 * r) * 8 * gw;     // forward strand: [0..3] fwd bits, [4..7] reversed-read bits
-    uint32_t* gR = G + (size_t)(2 * r + 1) * 8 * gw; // reverse-complement strand
+    // Eight bit-strings per READ: [0..3] the read's A,C,G,T bits, [4..7] those of the reversed read.  The
+    // reverse-complement strand needs no strings of its own (gString): its position i is comp(read[L-1-i]), i.e.
+    // string 4 + (3 - ch), and its reversed sequence is comp(read[ri]), i.e. string 3 - ch.
+    uint32_t* gF = G + (size_t)r * 8 * gw;
 #pragma unroll
     for (int ch = 0; ch < 4; ch++) {
-        gF[ch * gw + w] = fA[ch];             // strand F, position i      : read[i]
-        gF[(4 + ch) * gw + w] = fB[ch];       // strand F reversed, pos ri : read[L-1-ri]
-        gR[ch * gw + w] = fB[3 - ch];         // strand R, position i      : comp(read[L-1-i])
-        gR[(4 + ch) * gw + w] = fA[3 - ch];   // strand R reversed, pos ri : comp(read[ri])
+        gF[ch * gw + w] = fA[ch];       // position i : read[i]
+        gF[(4 + ch) * gw + w] = fB[ch]; // position ri: read[L-1-ri]
     }
     if (rec) {
         // read record for k_partition: word 0 = len | hasN << 16 (rec zeroed beforehand, chunks OR into it),
@@ -663,10 +663,9 @@ __global__ void k_match_words(const uint32_t* __restrict__ G, uint32_t gw, const
     if (gid >= (uint64_t)nRs * nBlk) return;
     const uint32_t rs = (uint32_t)(gid / nBlk), b = (uint32_t)(gid % nBlk);
     const uint32_t len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
-    const uint32_t* Gf = G + (size_t)rs * 8 * gw;
     uint64_t m[4];
 #pragma unroll
-    for (int ch = 0; ch < 4; ch++) m[ch] = matchWord(Gf + ch * gw, 0, len, b);
+    for (int ch = 0; ch < 4; ch++) m[ch] = matchWord(gString(G, gw, rs, 0u, (uint32_t)ch), 0, len, b);
     out[gid * 2] = make_uint4((uint32_t)m[0], (uint32_t)(m[0] >> 32), (uint32_t)m[1], (uint32_t)(m[1] >> 32));
     out[gid * 2 + 1] = make_uint4((uint32_t)m[2], (uint32_t)(m[2] >> 32), (uint32_t)m[3], (uint32_t)(m[3] >> 32));
 }
