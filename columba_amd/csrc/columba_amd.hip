@@ -883,7 +883,7 @@ static int batchRunOne(cmb_batch* b) {
                     tm.begin();
                     if (getenv("CMB_VERBOSE")) fprintf(stderr, "[verify] %u items, %u distinct keys\n", nItems, nRuns);
                     if (nRuns) {
-                        // staged verification (kernels.hpp: k_verify_stage): one launch per 32-row matrix block,
+                        // staged verification (kernels.hpp: k_verify_stage): one launch per nb 32-row matrix blocks,
                         // survivor lists ping-pong, list sizes stay on the device
                         // nb 32-row blocks per stage: fewer stages re-fetch fewer text lines and move fewer survivor
                         // records, more blocks leave more lanes idle behind candidates that ended (CMB_STAGE_BLOCKS)

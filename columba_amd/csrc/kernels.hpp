@@ -1018,7 +1018,7 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
 }
 
 // pass 1b: the distinct edit-distance verifications (sorted + run-length encoded keys of k_verify), in STAGES
-// of one 32-row matrix block each.  FMIndex::inTextVerification + InTextVerificationTask::doTask
+// of nb 32-row matrix blocks each (nb = 2; the text below describes nb = 1).  FMIndex::inTextVerification + InTextVerificationTask::doTask
 // (fmindex.cpp:267-310, indexhelpers.cpp:518-574) abandon most candidates after a few dozen rows while the true
 // locations run all len + 3k rows; with one candidate per lane from start to end, a wavefront is as slow as its
 // longest candidate (measured: 38 % of the lanes busy).  So stage s computes rows 32 s .. 32 s + 31 (stage 0:
