@@ -373,8 +373,32 @@ extern "C" int cmb_batch_create(cmb_index* idx, const cmb_strategy* st, uint32_t
     parent->k = max_distance;
     parent->nReads = n_reads;
     parent->metric = st->metric;
+    // slice bounds: equal shares, or CMB_SUBBATCH_SPLIT="w0,w1,..." (relative weights; unequal sub-batches reach
+    // their stages at different times)
+    std::vector<double> wts(S, 1.0);
+    if (const char* sp = getenv("CMB_SUBBATCH_SPLIT")) {
+        std::vector<double> w;
+        for (const char* q = sp; *q;) {
+            char* e = nullptr;
+            const double v = strtod(q, &e);
+            if (e == q) break;
+            if (v > 0) w.push_back(v);
+            q = *e == ',' ? e + 1 : e;
+        }
+        if (w.size() == S) wts = w;
+    }
+    double wsum = 0;
+    for (double v : wts) wsum += v;
+    std::vector<uint32_t> bound(S + 1, 0);
+    {
+        double acc = 0;
+        for (uint32_t j = 0; j < S; j++) {
+            acc += wts[j];
+            bound[j + 1] = j + 1 == S ? n_reads : (uint32_t)((double)n_reads * (acc / wsum));
+        }
+    }
     for (uint32_t j = 0; j < S; j++) {
-        const uint32_t lo = (uint32_t)((uint64_t)n_reads * j / S), hi = (uint32_t)((uint64_t)n_reads * (j + 1) / S);
+        const uint32_t lo = bound[j], hi = std::max(bound[j + 1], bound[j]);
         std::vector<uint64_t> o(hi - lo + 1);
         for (uint32_t i = lo; i <= hi; i++) {
             if (i > lo && offs[i] < offs[i - 1]) return fail(CMB_ERR_INVALID, "read offsets must be non-decreasing");
