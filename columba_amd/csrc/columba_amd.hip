@@ -923,7 +923,8 @@ static int batchRunOne(cmb_batch* b) {
                         if (b->vsN.n < nStages + 2) b->vsN.alloc(nStages + 2);
                         HIPCHK(hipMemsetAsync(b->vsN.p, 0, (nStages + 2) * sizeof(uint32_t), s));
                         const uint32_t listCap = (uint32_t)std::min<size_t>(b->vsC[0].n, 0xFFFFFFF0u);
-                        const uint32_t grid = std::min<uint32_t>((nRuns + 255) / 256, 8192u);
+                        const uint32_t gridCap = getenv("CMB_STAGE_GRID") ? (uint32_t)std::max(256, atoi(getenv("CMB_STAGE_GRID"))) : 8192u;
+                        const uint32_t grid = std::min<uint32_t>((nRuns + 255) / 256, gridCap);
                         VStageList L0{b->vsA[0].p, b->vsB[0].p, b->vsC[0].p}, L1{b->vsA[1].p, b->vsB[1].p, b->vsC[1].p};
                         // k <= 4: the matrix on 32-bit words (dev_matrix.hpp); CMB_MATRIX_WIDE=1 keeps the 64-bit words
                         const bool w32 = b->k <= MX32_MAX_ED && !getenv("CMB_MATRIX_WIDE");
@@ -961,7 +962,8 @@ static int batchRunOne(cmb_batch* b) {
                 HIPCHK(hipStreamSynchronize(s));
                 const uint32_t nTb = hcnt[7];
                 if (nTb) {
-                    const uint32_t tSlots = std::min<uint32_t>(((nTb + 255) / 256) * 256, 256u * 1024u);
+                    const uint32_t slotCap = getenv("CMB_TB_SLOTS") ? (uint32_t)std::max(256, atoi(getenv("CMB_TB_SLOTS"))) / 256u * 256u : 512u * 1024u; // (measured 64 k … 2 M slots: 84 / 49 / 34.4 / 32.8 / 31 / 29 ms alone; 512 k best beside other sub-batches)
+                    const uint32_t tSlots = std::min<uint32_t>(((nTb + 255) / 256) * 256, slotCap);
                     // 64-byte lines of 16 narrow (k <= 4) or 8 wide trace rows (a group is written whole)
                     const bool narrow = b->k <= TBN_MAX_ED && !getenv("CMB_TRACE_WIDE");
                     const uint32_t tLines = narrow ? ((uint32_t)VROWS + 15u) / 16u + 2u : ((uint32_t)VROWS + 7u) / 8u + 2u;
