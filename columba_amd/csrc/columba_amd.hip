@@ -614,7 +614,9 @@ static int batchRunOne(cmb_batch* b) {
         tm.end("k_prep");
 
         // ---- prologue + DFS (re-run with larger queues if they overflow: nothing is truncated)
-        const uint32_t pSlots = std::min<uint32_t>(((tasks + 255) / 256) * 256, 256u * 2048u);
+        const uint32_t pCap = getenv("CMB_P_SLOTS") ? (uint32_t)std::max(256, atoi(getenv("CMB_P_SLOTS"))) / 256u * 256u : 256u * 32768u; // (one lane per read x strand
+        // up to 8 M: k_parts 65.7 ms with 512 k lanes looping over the tasks, 65.0 / 62.1 / 62.5 ms with 1 M / 4 M / 8 M)
+        const uint32_t pSlots = std::min<uint32_t>(((tasks + 255) / 256) * 256, pCap);
         for (int attempt = 0;; attempt++) {
             HIPCHK(hipMemsetAsync(b->cnt.p, 0, 8 * sizeof(uint32_t), s));
             if (attempt) {
@@ -864,7 +866,8 @@ static int batchRunOne(cmb_batch* b) {
             HIPCHK(hipMemcpyAsync(keep, b->counters.p, sizeof(keep), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             if (nItems) {
-                const uint32_t vSlots = std::min<uint32_t>(((nItems + 255) / 256) * 256, 256u * 2048u);
+                const uint32_t vCap = getenv("CMB_V_SLOTS") ? (uint32_t)std::min(256 * 2048, std::max(256, atoi(getenv("CMB_V_SLOTS")))) / 256u * 256u : 256u * 2048u;
+                const uint32_t vSlots = std::min<uint32_t>(((nItems + 255) / 256) * 256, vCap);
                 // Edit distance: identical verifications (same read x strand, text window and bounds — the parts of
                 // one read seeding the same alignment) are performed once: k_verify only locates and emits a key per
                 // candidate, the keys are sorted and run-length encoded, k_verify_edit verifies the distinct ones and
