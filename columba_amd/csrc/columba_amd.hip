@@ -357,6 +357,7 @@ struct cmb_batch {
 
 static int batchCreateOne(cmb_index* idx, const cmb_strategy* st, uint32_t max_distance, const char* seqs,
                           const uint64_t* offs, uint32_t n_reads, cmb_batch** out);
+constexpr uint32_t MAX_SUB_READS = 1u << 23; // reads per sub-batch (keys: kernels.hpp k_pack_keys, packVerifyKey)
 
 extern "C" int cmb_batch_create(cmb_index* idx, const cmb_strategy* st, uint32_t max_distance, const char* seqs,
                                 const uint64_t* offs, uint32_t n_reads, cmb_batch** out) {
@@ -366,6 +367,9 @@ extern "C" int cmb_batch_create(cmb_index* idx, const cmb_strategy* st, uint32_t
     // on 10 M reads: 1 -> 26.4, 2 -> 30.4, 3 -> 30.6, 4 -> 29.5 M reads/s); CMB_SUBBATCHES overrides
     uint32_t S = n_reads >= 8000000u ? 3u : n_reads >= 2000000u ? 2u : 1u;
     if (getenv("CMB_SUBBATCHES")) S = (uint32_t)std::max(1, atoi(getenv("CMB_SUBBATCHES")));
+    // a sub-batch holds fewer than 2^24 reads (24-bit read number of the filter key, 25 bits of read x strand in the
+    // verification key): larger batches are cut into more sub-batches up front, never refused after the work is done
+    S = std::max<uint32_t>(S, (uint32_t)(((uint64_t)n_reads + MAX_SUB_READS - 1) / MAX_SUB_READS));
     S = std::min<uint32_t>(S, std::max<uint32_t>(n_reads, 1u));
     if (S <= 1) return batchCreateOne(idx, st, max_distance, seqs, offs, n_reads, out);
     std::unique_ptr<cmb_batch> parent(new cmb_batch());
@@ -424,6 +428,8 @@ static int batchCreateOne(cmb_index* idx, const cmb_strategy* st, uint32_t max_d
         b->k = max_distance;
         b->nReads = n_reads;
         b->metric = st->metric;
+        if (n_reads >= (1u << 24)) // (only reachable through CMB_SUBBATCH_SPLIT weights: checked before any work)
+            return fail(CMB_ERR_UNSUPPORTED, "more than 2^24 reads in one sub-batch");
         if (max_distance > 0) {
             // use64Matrix (fmindex.h:240-246): nZeros + maxED = 3k+1 must fit LEFT = 21
             if (st->metric == CMB_METRIC_EDIT && 3 * max_distance + 1 > MX_LEFT)

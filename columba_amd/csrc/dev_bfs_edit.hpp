@@ -46,10 +46,20 @@ constexpr uint32_t F_U4 = 2;      // uint4 per F record: {ranges} {depth | c << 
 constexpr uint32_t BFS_GRID = 576;    // blocks that expand the frontier (grid-stride)
 constexpr uint32_t BFS_GRID_EV = 192; // blocks that handle the events of the same pass
 
-enum { FLAG_BFS_Q = 64, FLAG_BFS_EV = 128, FLAG_BFS_F = 256, FLAG_BFS_CTX = 512, FLAG_BFS_ARENA = 1024 };
+// (the FLAG_BFS_* bits live in dev_search.hpp with all other bits of the flag word)
 // any of these set by an earlier pass: the frontier is incomplete, later passes do nothing (the host re-runs)
 constexpr uint32_t BFS_STOP = FLAG_BFS_Q | FLAG_BFS_EV | FLAG_BFS_F | FLAG_BFS_CTX | FLAG_BFS_ARENA | FLAG_ITEM_OVERFLOW |
                               FLAG_FMOCC_OVERFLOW | FLAG_CAPACITY;
+
+// "has an earlier pass stopped the search?" as ONE answer per block: other blocks of the same launch may set the
+// flag word while this one starts, so thread 0 reads it once and the block branches on the LDS copy (a per-thread
+// read could let some wavefronts leave before a barrier the others wait at).
+__device__ __forceinline__ bool blockStopped(const Queues& q) {
+    __shared__ uint32_t stopWord;
+    if (threadIdx.x == 0) stopWord = __hip_atomic_load(&q.cnt[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & BFS_STOP;
+    __syncthreads();
+    return stopWord != 0u;
+}
 
 struct BfsBufs {
     uint4* Q[2];  // frontier nodes, 4 planes of qCap: {ranges} {row | score << 16, ctx, fc, RAC bit} {HP, HN}
@@ -836,7 +846,7 @@ __global__ void __launch_bounds__(256)
 k_bfs_start(DevIndex ix, const DevStrategyK* __restrict__ stp, BfsBufs B, const DfsTask* __restrict__ tasks, uint32_t nTasks,
             const uint64_t* __restrict__ offs, uint32_t gw, const uint32_t* __restrict__ G, const PartOut* __restrict__ parts,
             Queues q) {
-    if (q.cnt[3] & BFS_STOP) return;
+    if (blockStopped(q)) return;
     bfsHeavy<true>(ix, stp, B, 0u, tasks, nTasks, offs, gw, G, parts, q, blockIdx.x, gridDim.x);
 }
 
@@ -845,7 +855,7 @@ k_bfs_start(DevIndex ix, const DevStrategyK* __restrict__ stp, BfsBufs B, const 
 __global__ void __launch_bounds__(256)
 k_bfs_pass(DevIndex ix, const DevStrategyK* __restrict__ stp, BfsBufs B, uint32_t pass, const uint64_t* __restrict__ offs,
            uint32_t gw, const uint32_t* __restrict__ G, const PartOut* __restrict__ parts, Queues q) {
-    if (q.cnt[3] & BFS_STOP) return;
+    if (blockStopped(q)) return;
     if (blockIdx.x < BFS_GRID) bfsExpand(ix, B, pass, q, blockIdx.x, BFS_GRID);
     else bfsHeavy<false>(ix, stp, B, pass, nullptr, 0u, offs, gw, G, parts, q, blockIdx.x - BFS_GRID, BFS_GRID_EV);
 }

@@ -33,7 +33,7 @@ k_hbfs(DevIndex ix, const DevStrategyK* __restrict__ stp, HbfsBufs B, uint32_t p
        uint32_t nTasks, uint32_t maxLen, const uint8_t* __restrict__ seq, const PartOut* __restrict__ parts, Queues q) {
     __shared__ uint32_t sh[4][5];
     extern __shared__ uint32_t stratLds[];
-    if (q.cnt[3] & BFS_STOP) return;
+    if (blockStopped(q)) return;
     for (uint32_t i = threadIdx.x; i < sizeof(DevStrategyK) / 4; i += blockDim.x)
         stratLds[i] = reinterpret_cast<const uint32_t*>(stp)[i];
     __syncthreads();

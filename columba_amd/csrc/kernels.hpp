@@ -5,7 +5,8 @@
 //   k_prep        read clean-up + reverse complement + match bit-strings
 //                                                       src/reads.h:43-58, nucleotide.h:250,
 //                                                       bitparallelmatrix.cpp:34-75
-//   k_search      partition + search-scheme DFS         dev_search.hpp
+//   k_parts / k_exact   partitioning, scheme selection, exact phases   dev_partition.hpp
+//   k_bfs_start / k_bfs_pass / k_hbfs   the approximate search as a frontier   dev_bfs_edit.hpp, dev_bfs_hamming.hpp
 //   k_verify      locate + in-text verification         fmindex.cpp:267-310, :358-407,
 //                                                       indexhelpers.cpp:518-574, indexinterface.cpp:918-943
 //   k_fmocc       in-index occurrence -> text positions indexinterface.cpp:1385-1440, :1349-1366
