@@ -32,7 +32,7 @@ EXPORTS = [
     "cmb_index_create", "cmb_index_destroy", "cmb_index_device_bytes", "cmb_index_kmer_table",
     "cmb_strategy_create_named", "cmb_strategy_create_from_dir", "cmb_strategy_create",
     "cmb_strategy_add_scheme", "cmb_strategy_set_partition_params", "cmb_strategy_destroy",
-    "cmb_strategy_describe", "cmb_match_batch", "cmb_batch_create", "cmb_batch_run",
+    "cmb_strategy_describe", "cmb_strategy_export_scheme", "cmb_strategy_export_partition", "cmb_match_batch", "cmb_batch_create", "cmb_batch_run",
     "cmb_batch_result_size", "cmb_batch_results", "cmb_batch_timings", "cmb_batch_destroy",
     "cmb_rank_batch", "cmb_extend_batch", "cmb_extend_bench", "cmb_locate_batch", "cmb_verify_batch",
     "cmb_last_error", "cmb_version",
@@ -98,6 +98,8 @@ def lib():
         L.cmb_strategy_set_partition_params.argtypes = [vp, u32, vp, u32, vp, u32, vp, u32]
         L.cmb_strategy_destroy.argtypes = [vp]
         L.cmb_strategy_describe.argtypes = [vp, u32, C.POINTER(u32), C.POINTER(u32), vp, u32]
+        L.cmb_strategy_export_scheme.argtypes = [vp, u32, u32, vp, vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]
+        L.cmb_strategy_export_partition.argtypes = [vp, u32, vp, vp, vp, u32, C.POINTER(u32)]
         L.cmb_match_batch.argtypes = [vp, vp, u32, vp, vp, u32, vp, u64, vp, vp, C.POINTER(u64)]
         L.cmb_batch_create.argtypes = [vp, vp, u32, vp, vp, u32, C.POINTER(vp)]
         L.cmb_batch_run.argtypes = [vp]
@@ -208,10 +210,12 @@ class Index:
 class SearchStrategy:
     """Search schemes + partitioning (handle of ``cmb_strategy_*``).
 
-    ``SearchStrategy("kuch1" | "pigeon" | "multiple_opt", metric, partition)`` mirrors
-    ``Parameters::createStrategy`` (src/parameters/alignparameters.cpp:1313-1376);
-    ``SearchStrategy.from_dir(path, multiple=True)`` the ``-d`` / ``-c`` options.
+    ``SearchStrategy("kuch1" | "kuch2" | "kianfar" | "01*0" | "pigeon" | "minU" | "columba" | "multiple_opt",
+    metric, partition)`` mirrors ``Parameters::createStrategy`` (src/parameters/alignparameters.cpp:1313-1376);
+    ``SearchStrategy.from_dir(path, mode)`` the ``-d`` (mode "multiple"), ``-c -nD`` ("custom") and ``-c``
+    ("custom_dynamic") options.
     """
+    DIR_MODES = {"custom": 0, "multiple": 1, "custom_dynamic": 2, False: 0, True: 1}
 
     def __init__(self, name: Optional[str] = "multiple_opt", metric: str = "edit", partition: str = "dynamic",
                  _handle=None):
@@ -223,10 +227,10 @@ class SearchStrategy:
         self.h = h
 
     @classmethod
-    def from_dir(cls, path: str, multiple: bool, metric: str = "edit", partition: str = "dynamic"):
+    def from_dir(cls, path: str, multiple="multiple", metric: str = "edit", partition: str = "dynamic"):
         h = C.c_void_p()
-        _chk(lib().cmb_strategy_create_from_dir(path.encode(), int(multiple), METRIC[metric], PARTITION[partition],
-                                                C.byref(h)))
+        _chk(lib().cmb_strategy_create_from_dir(path.encode(), cls.DIR_MODES[multiple], METRIC[metric],
+                                                PARTITION[partition], C.byref(h)))
         return cls(_handle=h)
 
     @classmethod
@@ -254,6 +258,28 @@ class SearchStrategy:
         crit = np.zeros(8, np.uint32)
         _chk(lib().cmb_strategy_describe(self.h, k, C.byref(ns), C.byref(npart), _p(crit), 8))
         return ns.value, npart.value, crit[:ns.value].tolist()
+
+    def scheme(self, k: int, idx: int):
+        """searches of alternative ``idx`` for distance k as a list of (pi, L, U) (host-only, no GPU needed)"""
+        ns, npart = C.c_uint32(), C.c_uint32()
+        cap = 32 * 32
+        pi, lo, up = (np.zeros(cap, np.uint32) for _ in range(3))
+        _chk(lib().cmb_strategy_export_scheme(self.h, k, idx, _p(pi), _p(lo), _p(up), cap, C.byref(ns), C.byref(npart)))
+        n, p = ns.value, npart.value
+        return [(pi[i * p:(i + 1) * p].tolist(), lo[i * p:(i + 1) * p].tolist(), up[i * p:(i + 1) * p].tolist())
+                for i in range(n)]
+
+    def partition_params(self, k: int):
+        """(seeding positions, weights, begin positions, k-mer cut-off) in force for distance k"""
+        _, p, _ = self.describe(k)
+        seed, w, b = np.zeros(32, np.float64), np.zeros(32, np.uint64), np.zeros(32, np.float64)
+        cut = C.c_uint32()
+        _chk(lib().cmb_strategy_export_partition(self.h, k, _p(seed), _p(w), _p(b), 32, C.byref(cut)))
+        return seed[:max(p - 2, 0)].tolist(), w[:p].tolist(), b[:p - 1].tolist(), cut.value
+
+    def supports(self, k: int) -> bool:
+        ns = C.c_uint32()
+        return lib().cmb_strategy_describe(self.h, k, C.byref(ns), None, None, 0) == CMB_OK
 
     def close(self):
         if getattr(self, "h", None) and _lib is not None:

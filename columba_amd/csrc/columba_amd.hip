@@ -226,14 +226,15 @@ extern "C" int cmb_strategy_create_named(const char* name, int metric, int parti
     *out = s;
     return CMB_OK;
 }
-extern "C" int cmb_strategy_create_from_dir(const char* dir, int multiple, int metric, int partition,
+extern "C" int cmb_strategy_create_from_dir(const char* dir, int mode, int metric, int partition,
                                             cmb_strategy** out) {
+    if (mode < CMB_DIR_CUSTOM || mode > CMB_DIR_CUSTOM_DYNAMIC) return fail(CMB_ERR_INVALID, "bad scheme directory mode");
     cmb_strategy* s = nullptr;
     int rc = cmb_strategy_create(metric, partition, 20, &s);
     if (rc) return rc;
     try {
-        if (multiple) fillFromMultipleDir(*s, dir ? dir : "");
-        else fillFromCustomDir(*s, dir ? dir : "");
+        if (mode == CMB_DIR_MULTIPLE) fillFromMultipleDir(*s, dir ? dir : "");
+        else fillFromCustomDir(*s, dir ? dir : "", mode == CMB_DIR_CUSTOM_DYNAMIC);
     } catch (const std::exception& e) {
         delete s;
         return fail(CMB_ERR_INVALID, e.what());
@@ -286,6 +287,41 @@ extern "C" int cmb_strategy_describe(const cmb_strategy* s, uint32_t k, uint32_t
     for (uint32_t i = 0; critical_parts && i < cap && i < it->second.size(); i++)
         critical_parts[i] = it->second[i].critical;
     return CMB_OK;
+}
+extern "C" int cmb_strategy_export_scheme(const cmb_strategy* s, uint32_t k, uint32_t scheme, uint32_t* pi, uint32_t* L,
+                                          uint32_t* U, uint32_t cap, uint32_t* n_searches, uint32_t* n_parts) {
+    if (!s) return fail(CMB_ERR_INVALID, "null argument");
+    auto it = s->schemes.find(k);
+    if (it == s->schemes.end() || scheme >= it->second.size())
+        return fail(CMB_ERR_INVALID, "the search strategy has no such scheme for distance " + std::to_string(k));
+    const HostScheme& h = it->second[scheme];
+    const uint32_t ns = (uint32_t)h.searches.size(), np = h.numParts();
+    if (n_searches) *n_searches = ns;
+    if (n_parts) *n_parts = np;
+    if ((uint64_t)ns * np > cap) return fail(CMB_ERR_OVERFLOW, "output arrays too small");
+    for (uint32_t i = 0; i < ns; i++)
+        for (uint32_t j = 0; j < np; j++) {
+            if (pi) pi[i * np + j] = h.searches[i].pi[j];
+            if (L) L[i * np + j] = h.searches[i].L[j];
+            if (U) U[i * np + j] = h.searches[i].U[j];
+        }
+    return CMB_OK;
+}
+extern "C" int cmb_strategy_export_partition(const cmb_strategy* s, uint32_t k, double* seeding, uint64_t* weights,
+                                             double* begins, uint32_t cap, uint32_t* kmer_cutoff) {
+    if (!s) return fail(CMB_ERR_INVALID, "null argument");
+    try {
+        const DevStrategyK d = s->flatten(k);
+        const uint32_t P = d.numParts;
+        if (P > cap) return fail(CMB_ERR_OVERFLOW, "output arrays too small");
+        for (uint32_t i = 0; i + 2 < P && seeding; i++) seeding[i] = d.seeding[i];
+        for (uint32_t i = 0; i < P && weights; i++) weights[i] = d.weights[i];
+        for (uint32_t i = 0; i + 1 < P && begins; i++) begins[i] = d.begins[i];
+        if (kmer_cutoff) *kmer_cutoff = d.kmerCutOff;
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_INVALID, e.what());
+    }
 }
 
 // ------------------------------------------------------------------------------------ batch

@@ -134,14 +134,20 @@ inline HostScheme readSchemeFile(const std::string& path, uint32_t k) {
         std::vector<std::string> toks;
         std::string t;
         while (ss >> t) toks.push_back(t);
-        if (toks.empty()) continue;
-        if (toks.size() != 3)
-            throw std::runtime_error("Something went wrong with processing line: " + line + "\nin file: " + path +
-                                     "\nA search should have 3 vectors: order, lower bound and upper bound!");
+        if (line.empty()) continue; // (search.h:694)
         HostSearch s;
-        s.pi = parseBraces(toks[0]);
-        s.L = parseBraces(toks[1]);
-        s.U = parseBraces(toks[2]);
+        try { // search.h:599-621 + Search::makeSearch :116-124, wrapped per line as in readScheme (:697-703)
+            if (toks.size() != 3)
+                throw std::runtime_error("A search should have 3 vectors: order, lower bound and upper bound!");
+            s.pi = parseBraces(toks[0]);
+            s.L = parseBraces(toks[1]);
+            s.U = parseBraces(toks[2]);
+            if (s.pi.size() != s.L.size() || s.pi.size() != s.U.size())
+                throw std::runtime_error("Could not create search, the sizes of all vectors are not equal");
+        } catch (const std::runtime_error& e) {
+            throw std::runtime_error("Something went wrong with processing line: " + line + "\nin file: " + path + "\n" +
+                                     e.what());
+        }
         s.sIdx = idx++;
         sch.searches.push_back(s);
     }
@@ -235,6 +241,43 @@ inline HostScheme schemeFromRows(uint32_t k, std::initializer_list<const char*> 
     return sch;
 }
 
+// SearchScheme::mirrorPiStrings (search.h:488-493, :745-753): part i becomes part P - 1 - i in every search
+inline HostScheme mirrored(const HostScheme& in) {
+    HostScheme out;
+    out.k = in.k;
+    for (const HostSearch& h : in.searches) {
+        HostSearch m = h;
+        for (auto& p : m.pi) p = (uint32_t)h.pi.size() - 1 - p;
+        out.searches.push_back(m);
+    }
+    out.finalize();
+    return out;
+}
+
+// MinUSearchStrategy (searchstrategy.h:3284-3389), k = 1..7
+inline HostScheme minU(uint32_t k) {
+    switch (k) {
+    case 1: return schemeFromRows(1, {"01 00 01", "10 00 01"});
+    case 2: return schemeFromRows(2, {"012 011 022", "102 000 012", "210 002 012"});
+    case 3: return schemeFromRows(3, {"0123 0000 0133", "1023 0111 0133", "2310 0002 0133", "3210 0113 0133"});
+    case 4:
+        return schemeFromRows(4, {"01234 00222 02244", "12034 00000 01244", "21034 01111 01244", "34210 00003 01444",
+                                  "43210 01114 01444"});
+    case 5:
+        return schemeFromRows(5, {"012345 000222 013555", "102345 011333 013555", "231045 000000 013355",
+                                  "321045 011111 013355", "453210 000004 013555", "543210 011115 013555"});
+    case 6:
+        return schemeFromRows(6, {"0123456 0022226 0226666", "1203456 0111115 0126666", "2103456 0000004 0126666",
+                                  "3456210 0000000 0133666", "4356210 0111111 0133666", "5643210 0002222 0133666",
+                                  "6543210 0113333 0133666"});
+    case 7:
+        return schemeFromRows(7, {"01234567 00000000 01337777", "10234567 01111111 01337777", "23104567 00022222 01337777",
+                                  "32104567 01133333 01337777", "45673210 00000004 01337777", "54673210 01111115 01337777",
+                                  "67543210 00022226 01337777", "76543210 01133337 01337777"});
+    default: throw std::runtime_error("minU schemes exist for 1 to 7 errors");
+    }
+}
+
 inline void fillNamed(cmb_strategy& st, const std::string& name) {
     if (name == "kuch1") { // KucherovKPlus1 (searchstrategy.h:2829-2913)
         st.kmerCutOff = 100;
@@ -279,6 +322,61 @@ inline void fillNamed(cmb_strategy& st, const std::string& name) {
             schemeFromRows(6, {"6543210 0022226 0226666", "5463210 0111115 0126666", "4563210 0000004 0126666",
                                "3210456 0000000 0133666", "2310456 0111111 0133666", "1023456 0002222 0133666",
                                "0123456 0113333 0133666"})};
+    } else if (name == "kuch2") { // KucherovKPlus2 (searchstrategy.h:2918-3021)
+        st.kmerCutOff = 100;
+        st.schemes[1] = {schemeFromRows(1, {"012 000 011", "120 000 001"})};
+        st.schemes[2] = {schemeFromRows(2, {"0123 0000 0112", "3210 0000 0122", "1230 0001 0012", "0123 0002 0022"})};
+        st.schemes[3] = {schemeFromRows(3, {"01234 00000 01233", "12340 00000 01223", "23410 00001 01133", "34210 00012 00333"})};
+        st.schemes[4] = {schemeFromRows(4, {"012345 000000 012344", "123450 000000 012344", "543210 000001 012244",
+                                            "345210 000012 011344", "234510 000023 011244", "453210 000133 003344",
+                                            "012345 000333 003344", "012345 000044 002444", "231045 000124 002244",
+                                            "453210 000044 001444"})};
+        st.params[1] = PartitionParams{{0.94}, {0.47, 0.94}, {11, 10, 1}};
+        st.params[2] = PartitionParams{{0.48, 0.55}, {0.35, 0.50, 0.65}, {400, 4, 1, 800}};
+        st.params[3] = PartitionParams{{0.4, 0.63, 0.9}, {0.22, 0.44, 0.66, 0.88}, {6, 3, 2, 1, 1}};
+        st.params[4] = PartitionParams{{0.34, 0.5, 0.65, 0.7}, {0.18, 0.37, 0.53, 0.69, 0.83}, {52, 42, 16, 14, 1, 800}};
+    } else if (name == "kianfar") { // OptimalKianfar (searchstrategy.h:3026-3103)
+        st.kmerCutOff = 100;
+        st.schemes[1] = {schemeFromRows(1, {"01 00 01", "10 01 01"})};
+        st.schemes[2] = {schemeFromRows(2, {"012 002 012", "210 000 022", "120 011 012"})};
+        st.schemes[3] = {schemeFromRows(3, {"0123 0003 0233", "1230 0000 1233", "2310 0022 0033"})};
+        st.schemes[4] = {schemeFromRows(4, {"01234 00004 03344", "12340 00000 22334", "43210 00033 00444"})};
+        st.params[1] = PartitionParams{{}, {0.5}, {1, 1}};
+        st.params[2] = PartitionParams{{0.50}, {0.30, 0.60}, {10, 1, 5}};
+        st.params[3] = PartitionParams{{0.34, 0.66}, {0.17, 0.69, 0.96}, {1, 1, 1, 1}};
+        st.params[4] = PartitionParams{{0.42, 0.56, 0.67}, {0.2, 0.5, 0.6, 0.8}, {7, 2, 1, 3, 5}};
+    } else if (name == "01*0") { // O1StarSearchStrategy (searchstrategy.h:3115-3206)
+        st.kmerCutOff = 100;
+        st.schemes[1] = {schemeFromRows(1, {"012 000 011", "120 000 001"})};
+        st.schemes[2] = {schemeFromRows(2, {"0123 0000 0122", "1230 0000 0122", "2310 0000 0022"})};
+        st.schemes[3] = {schemeFromRows(3, {"01234 00000 01333", "12340 00000 01333", "23410 00000 01333", "34210 00000 00333"})};
+        st.schemes[4] = {schemeFromRows(4, {"012345 000000 014444", "123450 000000 014444", "234510 000000 014444",
+                                            "345210 000000 014444", "453210 000000 004444"})};
+        st.params[1] = PartitionParams{{0.94}, {0.50, 0.96}, {11, 10, 1}};
+        st.params[2] = PartitionParams{{0.51, 0.93}, {0.26, 0.64, 0.83}, {20, 11, 11, 10}};
+        st.params[3] = PartitionParams{{0.34, 0.64, 0.88}, {0.22, 0.46, 0.67, 0.95}, {3, 2, 2, 1, 1}};
+        st.params[4] = PartitionParams{{0.28, 0.48, 0.63, 0.94}, {0.19, 0.37, 0.57, 0.74, 0.96}, {1, 2, 2, 1, 2, 1}};
+    } else if (name == "minU") { // MinUSearchStrategy (searchstrategy.h:3284-3389): base-class partition defaults
+        st.kmerCutOff = 20;
+        for (uint32_t k = 1; k <= 7; k++) st.schemes[k] = {minU(k)};
+    } else if (name == "columba") {
+        // `-S columba`, the CLI default: DynamicColumbaStrategy (searchstrategy.h:3666-3736) = for every k the scheme of
+        // ColumbaSearchStrategy (minU up to 7 errors; the greedy schemes for 8..13 errors need more parts than the
+        // device tables hold and are not built in) and its mirror image (MultipleSchemes ctor, :2468-2477), then the
+        // "middle" schemes for k = 2, 4, 6 (+ the mirror of the k = 6 one); base-class partition defaults.
+        st.kmerCutOff = 20;
+        for (uint32_t k = 1; k <= 7; k++) {
+            const HostScheme m = minU(k);
+            st.schemes[k] = {m, mirrored(m)};
+        }
+        st.schemes[2].push_back(schemeFromRows(2, {"210 011 022", "120 000 012", "012 002 012"}));
+        st.schemes[4].push_back(schemeFromRows(4, {"01234 01114 01444", "10234 00003 01444", "23410 01111 02244",
+                                                   "32410 00000 01244", "43210 00222 01244"}));
+        const HostScheme mid6 = schemeFromRows(6, {"0123456 0111115 0126666", "1023456 0000004 0126666", "2103456 0022226 0226666",
+                                                   "3456210 0002222 0133666", "4356210 0113333 0133666", "5643210 0000000 0133666",
+                                                   "6543210 0111111 0133666"});
+        st.schemes[6].push_back(mid6);
+        st.schemes[6].push_back(mirrored(mid6));
     } else {
         throw std::runtime_error(name + " is not an option as search scheme");
     }
@@ -308,9 +406,12 @@ inline void fillFromMultipleDir(cmb_strategy& st, std::string dir) {
     }
 }
 
-// `-c <dir>` without dynamic selection: <dir>/<k>/searches.txt (+ optional static_partitioning.txt,
-// dynamic_partitioning.txt); k-mer cut-off 50 (searchstrategy.h:2308)
-inline void fillFromCustomDir(cmb_strategy& st, std::string dir) {
+// `-c <dir>`: <dir>/<k>/searches.txt (+ optional static_partitioning.txt, dynamic_partitioning.txt); k-mer cut-off
+// 50 (searchstrategy.h:2308).  dynamicSelection = false is `-c <dir> -nD` (CustomSearchStrategy); true is the CLI's
+// default for `-c` (DynamicCustomStrategy, searchstrategy.h:3744-3776): every scheme plus its mirror image with
+// dynamic selection — that strategy object is a COPY of the base class (MultipleSchemesStrategy(SearchStrategy*),
+// :2689), so the partitioning files of the directory no longer apply (base-class defaults), the cut-off stays 50.
+inline void fillFromCustomDir(cmb_strategy& st, std::string dir, bool dynamicSelection = false) {
     if (!dir.empty() && dir.back() != '/') dir += '/';
     if (!fileExists(dir + "name.txt"))
         throw std::runtime_error("Problem reading: " + dir +
@@ -320,23 +421,61 @@ inline void fillFromCustomDir(cmb_strategy& st, std::string dir) {
         const std::string base = dir + std::to_string(k) + "/";
         if (!fileExists(base + "searches.txt")) continue;
         st.schemes[k] = {readSchemeFile(base + "searches.txt", k)};
+        if (dynamicSelection) {
+            st.schemes[k].push_back(mirrored(st.schemes[k].front()));
+            continue;
+        }
         PartitionParams pp;
+        const uint32_t P = st.schemes[k].front().numParts();
+        auto tokensOfLine = [](std::ifstream& f) {
+            std::string line, t;
+            std::getline(f, line);
+            std::stringstream ss(line);
+            std::vector<std::string> v;
+            while (ss >> t) v.push_back(t);
+            return v;
+        };
+        // first line of static_partitioning.txt: P - 1 begin positions (searchstrategy.cpp:2033-2063, :2166-2183)
         {
             std::ifstream f(base + "static_partitioning.txt");
-            double v;
-            while (f >> v) pp.begins.push_back(v);
+            if (f) {
+                const auto toks = tokensOfLine(f);
+                if (toks.size() != P - 1)
+                    throw std::runtime_error("Not enough static positions provided in " + base +
+                                             "static_partitioning.txt\nExpected: " + std::to_string(P - 1) +
+                                             " parts\nProvided: " + std::to_string(toks.size()) + " parts");
+                for (const auto& t : toks) pp.begins.push_back(std::stod(t));
+                for (size_t i = 0; i < pp.begins.size(); i++) {
+                    if (pp.begins[i] <= 0 || pp.begins[i] >= 1)
+                        throw std::runtime_error("One of the provided static positions for " + std::to_string(k) +
+                                                 " is not between 0 and 1 (exclusive)");
+                    if (i + 1 < pp.begins.size() && pp.begins[i] - pp.begins[i + 1] >= 0)
+                        throw std::runtime_error("Provided static positions for " + std::to_string(k) +
+                                                 " are not strictly increasing");
+                }
+            }
         }
+        // dynamic_partitioning.txt: P - 2 seeding positions, then P weights (searchstrategy.cpp:2066-2117, :2184-2203)
         {
             std::ifstream f(base + "dynamic_partitioning.txt");
-            std::string l1, l2;
             if (f) {
-                std::getline(f, l1);
-                std::getline(f, l2);
-                std::stringstream a(l1), b(l2);
-                double v;
-                while (a >> v) pp.seeding.push_back(v);
-                uint64_t w;
-                while (b >> w) pp.weights.push_back(w);
+                const auto toks = tokensOfLine(f);
+                if (toks.size() != P - 2)
+                    throw std::runtime_error("Not enough seeding positions provided in " + base +
+                                             "dynamic_partitioning.txt\nExpected: " + std::to_string(P - 1) +
+                                             " seeds\nProvided: " + std::to_string(toks.size()) + " seeds");
+                for (const auto& t : toks) pp.seeding.push_back(std::stod(t));
+                for (size_t i = 0; i < pp.seeding.size(); i++) {
+                    if (pp.seeding[i] <= 0 || pp.seeding[i] >= 1)
+                        throw std::runtime_error("One of the provided static positions for " + std::to_string(k) +
+                                                 " is not between 0 and 1 (exclusive)!");
+                    if (i + 1 < pp.seeding.size() && pp.seeding[i] - pp.seeding[i + 1] >= 0)
+                        throw std::runtime_error("Provided seeding positions for " + std::to_string(k) +
+                                                 " are not strictly increasing");
+                }
+                for (const auto& t : tokensOfLine(f)) pp.weights.push_back((uint64_t)std::stoi(t));
+                if (pp.weights.size() != P)
+                    throw std::runtime_error("Not enough weights provided for max score " + std::to_string(k));
             }
         }
         st.params[k] = pp;

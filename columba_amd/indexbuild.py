@@ -371,6 +371,24 @@ def save_index(ix: IndexArrays, base: str) -> None:
     np.zeros(1, dtype=np.uint32).tofile(base + ".fsid")
 
 
+def read_sparse_sa(base: str, sparseness: int):
+    """``SparseSuffixArray(basename, sparseness)`` (suffixArray.h:176-207): the rank9 Bitvec of the sampled rows
+    (bitvec.h:187: N, words, counts) and the raw 32-bit samples.  Returns (N, words, counts, samples)."""
+    name = f"{base}.sa.bv.{sparseness}"
+    if not os.path.exists(name):
+        raise RuntimeError("Cannot open file: " + name + ". Did you set an incorrect suffix array sparseness "
+                           "factor using the -s flag or move your index files?")
+    with open(name, "rb") as f:
+        N = struct.unpack("<Q", f.read(8))[0]
+        nw = (N + 63) // 64
+        sa_bv = np.frombuffer(f.read(nw * 8), dtype=np.uint64).copy()
+        sa_cnt = np.frombuffer(f.read(((nw + 7) // 4) * 8), dtype=np.uint64).copy()
+    if not os.path.exists(f"{base}.sa.{sparseness}"):
+        raise RuntimeError(f"Problem reading file: {base}.sa.{sparseness}")
+    samples = np.fromfile(f"{base}.sa.{sparseness}", dtype=np.uint32)
+    return N, sa_bv, sa_cnt, samples
+
+
 def load_index(base: str, sparseness: int = 4) -> IndexArrays:
     """Load a Vanilla index written by ``columba_build`` (32-bit length_t) or ``save_index``.
 
@@ -409,12 +427,7 @@ def load_index(base: str, sparseness: int = 4) -> IndexArrays:
 
     dpf, bvf, cf = rd_brt(base + ".brt")
     dpr, bvr, cr = rd_brt(base + ".rev.brt")
-    with open(f"{base}.sa.bv.{sparseness}", "rb") as f:
-        N = struct.unpack("<Q", f.read(8))[0]
-        nw = (N + 63) // 64
-        sa_bv = np.frombuffer(f.read(nw * 8), dtype=np.uint64).copy()
-        sa_cnt = np.frombuffer(f.read(((nw + 7) // 4) * 8), dtype=np.uint64).copy()
-    samples = np.fromfile(f"{base}.sa.{sparseness}", dtype=np.uint32)
+    _, sa_bv, sa_cnt, samples = read_sparse_sa(base, sparseness)
     pos = np.fromfile(base + ".pos", dtype=np.uint32)
     names = []
     if os.path.exists(base + ".sna"):

@@ -86,13 +86,21 @@ int cmb_index_kmer_table(const cmb_index* idx, uint32_t* out /* 4 * 4^kmer_size 
 #define CMB_PARTITION_STATIC 1
 #define CMB_PARTITION_DYNAMIC 2
 
-/* built-in strategies: "kuch1" (KucherovKPlus1, searchstrategy.h:2829), "pigeon"
- * (PigeonHoleSearchStrategy, :3221), "multiple_opt" (the schemes of
- * search_schemes/multiple_opt with dynamic selection, MultipleSchemesStrategy :2584) */
+/* built-in strategies, the `-S` option (alignparameters.cpp:1341-1372): "kuch1" (KucherovKPlus1,
+ * searchstrategy.h:2829), "kuch2" (KucherovKPlus2, :2918), "kianfar" (OptimalKianfar, :3026), "01*0"
+ * (O1StarSearchStrategy, :3115), "pigeon" (PigeonHoleSearchStrategy, :3221), "minU" (MinUSearchStrategy, :3284),
+ * "columba" (the CLI default: DynamicColumbaStrategy, :3666 — minU schemes, their mirror images and the "middle"
+ * schemes with dynamic selection; up to 7 errors here, the greedy schemes for 8..13 errors are not built in);
+ * plus "multiple_opt" (the schemes of search_schemes/multiple_opt with dynamic selection, as `-d` loads them) */
 int cmb_strategy_create_named(const char* name, int metric, int partition, cmb_strategy** out);
-/* `-c <dir>` (CustomSearchStrategy, searchstrategy.cpp:1990; multiple = 0) or
- * `-d <dir>` (MultipleSchemesStrategy::readSchemes, searchstrategy.h:2624; multiple = 1) */
-int cmb_strategy_create_from_dir(const char* dir, int multiple, int metric, int partition,
+/* scheme directories: mode CMB_DIR_CUSTOM = `-c <dir> -nD` (CustomSearchStrategy, searchstrategy.cpp:1990),
+ * CMB_DIR_MULTIPLE = `-d <dir>` (MultipleSchemesStrategy::readSchemes, searchstrategy.h:2624),
+ * CMB_DIR_CUSTOM_DYNAMIC = `-c <dir>` (DynamicCustomStrategy, searchstrategy.h:3744: every scheme and its mirror
+ * image with dynamic selection) */
+#define CMB_DIR_CUSTOM 0
+#define CMB_DIR_MULTIPLE 1
+#define CMB_DIR_CUSTOM_DYNAMIC 2
+int cmb_strategy_create_from_dir(const char* dir, int mode, int metric, int partition,
                                  cmb_strategy** out);
 /* generic: start empty, then add schemes (row-major nSearches x nParts arrays of pi, L, U) */
 int cmb_strategy_create(int metric, int partition, uint32_t kmer_cutoff, cmb_strategy** out);
@@ -105,6 +113,16 @@ void cmb_strategy_destroy(cmb_strategy* s);
 /* introspection used by parity tests (Search::makeSearch search.h:116-194, critical part :525) */
 int cmb_strategy_describe(const cmb_strategy* s, uint32_t k, uint32_t* n_schemes, uint32_t* n_parts,
                           uint32_t* critical_parts /* [n_schemes] */, uint32_t cap);
+/* the searches of alternative `scheme` for distance k as row-major n_searches x n_parts arrays (what
+ * SearchStrategy::createSearches would hand out, searchstrategy.h:2005); cap = capacity of each array in elements.
+ * Host-only: needs no GPU. */
+int cmb_strategy_export_scheme(const cmb_strategy* s, uint32_t k, uint32_t scheme, uint32_t* pi, uint32_t* L,
+                               uint32_t* U, uint32_t cap, uint32_t* n_searches, uint32_t* n_parts);
+/* the partitioning parameters in force for distance k (getSeedingPositions / getWeights / getBegins,
+ * searchstrategy.h:1825, :283, :245, or the strategy's overrides) and the k-mer cut-off (:206): seeding[n_parts-2],
+ * weights[n_parts], begins[n_parts-1].  Host-only. */
+int cmb_strategy_export_partition(const cmb_strategy* s, uint32_t k, double* seeding, uint64_t* weights,
+                                  double* begins, uint32_t cap, uint32_t* kmer_cutoff);
 
 /* --- matching ---------------------------------------------------------------------- */
 typedef struct {

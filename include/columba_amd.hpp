@@ -268,16 +268,37 @@ struct KucherovKPlus1 : NamedStrategy { // searchstrategy.h:2829
 struct PigeonHoleSearchStrategy : NamedStrategy { // searchstrategy.h:3221
     PigeonHoleSearchStrategy(FMIndex& idx, PartitionStrategy p, DistanceMetric m) : NamedStrategy(idx, "pigeon", p, m) {}
 };
+struct KucherovKPlus2 : NamedStrategy { // searchstrategy.h:2918
+    KucherovKPlus2(FMIndex& idx, PartitionStrategy p, DistanceMetric m) : NamedStrategy(idx, "kuch2", p, m) {}
+};
+struct OptimalKianfar : NamedStrategy { // searchstrategy.h:3026
+    OptimalKianfar(FMIndex& idx, PartitionStrategy p, DistanceMetric m) : NamedStrategy(idx, "kianfar", p, m) {}
+};
+struct O1StarSearchStrategy : NamedStrategy { // searchstrategy.h:3115
+    O1StarSearchStrategy(FMIndex& idx, PartitionStrategy p, DistanceMetric m) : NamedStrategy(idx, "01*0", p, m) {}
+};
+struct MinUSearchStrategy : NamedStrategy { // searchstrategy.h:3284
+    MinUSearchStrategy(FMIndex& idx, PartitionStrategy p, DistanceMetric m) : NamedStrategy(idx, "minU", p, m) {}
+};
+struct DynamicColumbaStrategy : NamedStrategy { // searchstrategy.h:3666 (`-S columba`, the CLI default)
+    DynamicColumbaStrategy(FMIndex& idx, PartitionStrategy p, DistanceMetric m) : NamedStrategy(idx, "columba", p, m) {}
+};
 struct MultipleSchemesStrategy : SearchStrategy { // searchstrategy.h:2584 (`-d <dir>`)
     MultipleSchemesStrategy(FMIndex& idx, const std::string& pathToFolder, PartitionStrategy p, DistanceMetric m)
         : SearchStrategy(idx) {
-        check(cmb_strategy_create_from_dir(pathToFolder.c_str(), 1, m, p, &h));
+        check(cmb_strategy_create_from_dir(pathToFolder.c_str(), CMB_DIR_MULTIPLE, m, p, &h));
     }
 };
-struct CustomSearchStrategy : SearchStrategy { // searchstrategy.h:2130 (`-c <dir>`)
+struct CustomSearchStrategy : SearchStrategy { // searchstrategy.h:2130 (`-c <dir> -nD`)
     CustomSearchStrategy(FMIndex& idx, const std::string& pathToFolder, PartitionStrategy p, DistanceMetric m)
         : SearchStrategy(idx) {
-        check(cmb_strategy_create_from_dir(pathToFolder.c_str(), 0, m, p, &h));
+        check(cmb_strategy_create_from_dir(pathToFolder.c_str(), CMB_DIR_CUSTOM, m, p, &h));
+    }
+};
+struct DynamicCustomStrategy : SearchStrategy { // searchstrategy.h:3744 (`-c <dir>`)
+    DynamicCustomStrategy(FMIndex& idx, const std::string& pathToFolder, PartitionStrategy p, DistanceMetric m)
+        : SearchStrategy(idx) {
+        check(cmb_strategy_create_from_dir(pathToFolder.c_str(), CMB_DIR_CUSTOM_DYNAMIC, m, p, &h));
     }
 };
 

@@ -30,6 +30,7 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -399,7 +400,73 @@ struct Substring {
     void setDirection(Direction nd) { d = nd; }
     void setEnd(len_t e) { endIndex = e; }
     void setBegin(len_t b) { startIndex = b; }
+    bool containsN() const { // substring.h:275-282
+        for (len_t i = startIndex; i < endIndex; i++)
+            if (text[i] == 'N') return true;
+        return false;
+    }
+    std::string tostring() const { // :246-251
+        return empty() ? std::string() : std::string(text + startIndex, text + endIndex);
+    }
 };
+
+// ----------------------------------------------------------------------------
+// Kmer (tkmer.h:51, :386-417; nucleotide.h:56-58, nucleotide.cpp:28-30): the key of the
+// k-mer table.  A character is packed as lookup[(c >> 1) & 3] with lookup = {0, 1, 3, 2}
+// (A 0, C 1, G 2, T 3; any other character lands on one of the four as well, which is why
+// lookUpInKmerTable checks containsN, indexinterface.h:590-594); two keys are equal iff
+// their packed characters are.
+// ----------------------------------------------------------------------------
+inline std::string kmerKeyString(const std::string& s, size_t offset, size_t wordSize) {
+    static const int lookup[4] = {0, 1, 3, 2};
+    std::string r(wordSize, 'A');
+    for (size_t i = 0; i < wordSize; i++) r[i] = "ACGT"[lookup[(s[offset + i] >> 1) & 3]];
+    return r;
+}
+
+// ----------------------------------------------------------------------------
+// Read / ReadBundle clean-up (reads.h:43-58, :97-101): the sequence identifier loses its
+// first character (@ or >) and everything from the first space on; the read is upper-cased
+// and every non-ACGT character becomes N.
+// ----------------------------------------------------------------------------
+inline std::string cleanSeqID(std::string id) {
+    const size_t sp = id.find(' ');
+    if (sp != std::string::npos) id.erase(sp);
+    return id.substr(1);
+}
+inline std::string cleanReadSeq(const std::string& s) {
+    std::string r = s;
+    for (auto& c : r) {
+        c = (char)toupper((unsigned char)c);
+        if (c != 'A' && c != 'C' && c != 'G' && c != 'T') c = 'N';
+    }
+    return r;
+}
+
+// ----------------------------------------------------------------------------
+// SparseSuffixArray (fmindex/suffixArray.h:160-243): rows whose suffix-array value is a
+// multiple of the sparseness factor are marked in a rank9 Bitvec (.sa.bv.<s>: N, words,
+// counts — bitvec.h:176-185) and their values stored in row order (.sa.<s>, raw length_t).
+// ----------------------------------------------------------------------------
+struct SparseSAFiles {
+    std::vector<uint64_t> bvFile; // N, bv words, counts
+    std::vector<len_t> samples;
+};
+inline SparseSAFiles buildSparseSA(const std::vector<len_t>& sa, len_t factor) {
+    SparseSAFiles f;
+    const uint64_t N = sa.size();
+    std::vector<uint64_t> bv(Bitvec9::bvWords(N), 0), cnt(Bitvec9::cntWords(N), 0);
+    for (uint64_t i = 0; i < N; i++)
+        if (sa[i] % factor == 0) {
+            f.samples.push_back(sa[i]);
+            bv[i / 64] |= 1ull << (i % 64);
+        }
+    buildBitvec9Counts(bv.data(), bv.size(), cnt.data());
+    f.bvFile.push_back(N);
+    f.bvFile.insert(f.bvFile.end(), bv.begin(), bv.end());
+    f.bvFile.insert(f.bvFile.end(), cnt.begin(), cnt.end());
+    return f;
+}
 
 // ----------------------------------------------------------------------------
 // BitParallelED<uint64_t> (bitparallelmatrix.h:300-750, .cpp:34-123)
@@ -733,6 +800,43 @@ struct SearchScheme {
         }
     }
     uint16_t getNumParts() const { return (uint16_t)searches.front().getNumParts(); }
+    // search.h:599-650: "{pi} {L} {U}" per line
+    static void getVector(const std::string& tok, std::vector<len_t>& v) {
+        if (tok.size() < 2) throw std::runtime_error(tok + " is not a valid vector for a search");
+        std::stringstream ss(tok.substr(1, tok.size() - 2));
+        std::string item;
+        while (std::getline(ss, item, ',')) v.push_back((len_t)std::stoull(item));
+    }
+    static Search searchFromLine(const std::string& line, len_t idx) {
+        std::stringstream ss(line);
+        std::vector<std::string> tokens;
+        std::string t;
+        while (ss >> t) tokens.push_back(t);
+        if (tokens.size() != 3)
+            throw std::runtime_error("A search should have 3 vectors: order, lower bound and upper bound!");
+        std::vector<len_t> o, l, u;
+        getVector(tokens[0], o);
+        getVector(tokens[1], l);
+        getVector(tokens[2], u);
+        return Search::makeSearch(o, l, u, idx);
+    }
+    // search.h:684-711
+    static SearchScheme readScheme(std::istream& in, const std::string& fileName, unsigned k) {
+        std::vector<Search> r;
+        std::string line;
+        len_t sIdx = 0;
+        while (std::getline(in, line)) {
+            if (line.empty()) continue;
+            try {
+                r.push_back(searchFromLine(line, sIdx++));
+            } catch (const std::runtime_error& e) {
+                throw std::runtime_error("Something went wrong with processing line: " + line + "\nin file: " +
+                                         fileName + "\n" + e.what());
+            }
+        }
+        if (r.empty()) throw std::runtime_error("Empty scheme in: " + fileName);
+        return SearchScheme(r, k);
+    }
     SearchScheme mirrorPiStrings() const { // :745
         std::vector<Search> r;
         for (const auto& s : searches) r.push_back(s.mirrorPiStrings());

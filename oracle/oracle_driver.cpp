@@ -5,6 +5,8 @@
 // output with the fixtures that ref_driver (the real reference code) produced.
 // ============================================================================
 #include "oracle_search.hpp"
+#include <algorithm>
+#include <fstream>
 #include <iostream>
 #include <sstream>
 
@@ -256,6 +258,82 @@ int main() {
             string s;
             in >> s;
             os << Matcher::revCompl(s);
+        } else if (cmd == "ssa") {
+            uint32_t sp, n;
+            in >> sp >> n;
+            vector<len_t> sa(n);
+            for (auto& v : sa) in >> v;
+            const SparseSAFiles f = buildSparseSA(sa, sp);
+            words(os, f.bvFile);
+            os << " | " << f.samples.size();
+            for (auto v : f.samples) os << ' ' << v;
+            os << " |";
+            // read back: the Bitvec of the file + the samples (suffixArray.h:131-148)
+            const uint64_t N = f.bvFile[0];
+            Bitvec9 b{N, f.bvFile.data() + 1, f.bvFile.data() + 1 + Bitvec9::bvWords(N)};
+            for (uint32_t i = 0; i < n; i++) {
+                os << ' ' << b.get(i);
+                if (b.get(i)) os << ':' << f.samples[b.rank(i)];
+            }
+            os << " | " << sp;
+        } else if (cmd == "read") {
+            string id, rd, ql;
+            in >> id >> rd >> ql;
+            for (auto& c : id)
+                if (c == '_') c = ' ';
+            const string r = cleanReadSeq(rd), rc = Matcher::revCompl(r);
+            string rq = ql;
+            std::reverse(rq.begin(), rq.end());
+            os << cleanSeqID(id) << ' ' << r << ' ' << rc << ' ' << rq << ' ' << r.size() << ' ' << r << ' ' << rc;
+        } else if (cmd == "kmer") {
+            size_t ws, oa, ob;
+            string a, b;
+            in >> ws >> a >> oa >> b >> ob;
+            const string ka = kmerKeyString(a, oa, ws), kb = kmerKeyString(b, ob, ws);
+            os << ka << ' ' << kb << ' ' << (ka == kb) << ' ' << 1 << ' '
+               << Substring(a.data(), (len_t)a.size(), (len_t)oa, (len_t)(oa + ws)).containsN() << ' '
+               << Substring(b.data(), (len_t)b.size(), (len_t)ob, (len_t)(ob + ws)).containsN();
+        } else if (cmd == "substr") {
+            string t;
+            uint32_t b, e;
+            int d;
+            in >> t >> b >> e >> d;
+            Substring sub(t.data(), (len_t)t.size(), b, e, d == 0 ? FORWARD : BACKWARD);
+            os << sub.size() << ' ' << sub.begin() << ' ' << sub.end() << ' ' << sub.empty() << ' ' << sub.containsN() << ' '
+               << '[' << sub.tostring() << "] [";
+            for (len_t i = 0; i < sub.size(); i++) os << sub[i];
+            os << ']';
+            sub.setDirection(d == 0 ? BACKWARD : FORWARD);
+            os << " [";
+            for (len_t i = 0; i < sub.size(); i++) os << sub[i];
+            os << ']';
+        } else if (cmd == "readscheme") {
+            string path;
+            unsigned k;
+            in >> path >> k;
+            try {
+                ifstream ifs(path);
+                if (!ifs) throw std::runtime_error("cannot open");
+                SearchScheme sch = SearchScheme::readScheme(ifs, path, k);
+                SearchScheme mir = sch.mirrorPiStrings();
+                os << "ok " << sch.searches.size() << ' ' << sch.getNumParts() << ' ' << sch.criticalPartIndex << ' '
+                   << mir.criticalPartIndex;
+                for (const auto* sc : {&sch, &mir})
+                    for (const Search& se : sc->searches) {
+                        os << " |";
+                        for (len_t i = 0; i < se.getNumParts(); i++) os << ' ' << se.getPart(i);
+                        for (len_t i = 0; i < se.getNumParts(); i++) os << ' ' << se.getLowerBound(i);
+                        for (len_t i = 0; i < se.getNumParts(); i++) os << ' ' << se.getUpperBound(i);
+                        for (len_t i = 0; i < se.getNumParts(); i++) os << ' ' << se.getDirection(i);
+                        for (len_t i = 0; i < se.getNumParts(); i++) os << ' ' << se.getDirectionSwitch(i);
+                        for (len_t i = 0; i < se.getNumParts(); i++) os << ' ' << se.isUnidirectionalBackwards(i);
+                    }
+            } catch (const std::exception& e) {
+                string m = e.what();
+                for (auto& c : m)
+                    if (c == '\n') c = '~';
+                os << "error " << m;
+            }
         } else if (cmd == "consts") {
             os << BitParallelED64::MATRIX_MAX_ED << ' ' << BitParallelED64::LEFT << ' ' << 13 << ' ' << 10
                << ' ' << 4 << ' ' << sizeof(len_t);

@@ -21,9 +21,13 @@
 #include "bitvec.h"
 #include "fmindex/bwtrepr.h"
 #include "fmindex/encodedtext.h"
+#include "fmindex/suffixArray.h"
 #include "indexhelpers.h"
 #include "nucleotide.h"
+#include "reads.h"
 #include "search.h"
+#include "substring.h"
+#include "tkmer.h"
 
 #include <cstdio>
 #include <fstream>
@@ -39,6 +43,16 @@ static string tmpName() {
     if (fd >= 0) close(fd);
     return string(buf);
 }
+static void dumpFileWords32(const string& fn, ostream& os) {
+    ifstream ifs(fn, ios::binary);
+    vector<char> data((istreambuf_iterator<char>(ifs)), istreambuf_iterator<char>());
+    os << data.size() / 4;
+    for (size_t i = 0; i + 4 <= data.size(); i += 4) {
+        uint32_t w;
+        memcpy(&w, &data[i], 4);
+        os << ' ' << w;
+    }
+}
 static void dumpFileWords(const string& fn, ostream& os) {
     ifstream ifs(fn, ios::binary);
     vector<char> data((istreambuf_iterator<char>(ifs)), istreambuf_iterator<char>());
@@ -52,6 +66,7 @@ static void dumpFileWords(const string& fn, ostream& os) {
 
 int main() {
     logger.setVerbose(false);
+    logger.setLogFile("/dev/null"); // the file loaders log to the logger's stream (std::cout by default)
     string line;
     while (getline(cin, line)) {
         istringstream in(line);
@@ -294,6 +309,93 @@ int main() {
             string s;
             in >> s;
             os << Nucleotide::getRevComplWithN(s);
+        } else if (cmd == "ssa") { // s n sa[0..n): SparseSuffixArray written by its own writer, read back by the
+                                    // file constructor (mmap) — suffixArray.h:160-243, :131-148
+            uint32_t sp, n;
+            in >> sp >> n;
+            vector<length_t> sa(n);
+            for (auto& v : sa) in >> v;
+            string base = tmpName();
+            {
+                SparseSuffixArray w(sa, sp);
+                w.write(base);
+            }
+            const string fbv = base + ".sa.bv." + to_string(sp), fsa = base + ".sa." + to_string(sp);
+            dumpFileWords(fbv, os);
+            os << " |";
+            os << ' ';
+            dumpFileWords32(fsa, os);
+            os << " |";
+            {
+                SparseSuffixArray r(base, sp);
+                for (uint32_t i = 0; i < n; i++) {
+                    os << ' ' << r[i];
+                    if (r[i]) os << ':' << r.get(i);
+                }
+                os << " | " << r.getFactor();
+            }
+            unlink(fbv.c_str());
+            unlink(fsa.c_str());
+            unlink(base.c_str());
+        } else if (cmd == "read") { // seqID(with @ or >, '_' for spaces) read qual: Read + ReadBundle (reads.h:43-58, :97-160)
+            string id, rd, ql;
+            in >> id >> rd >> ql;
+            for (auto& c : id)
+                if (c == '_') c = ' ';
+            Read r(id, rd, ql);
+            ReadBundle b(r);
+            os << r.getSeqID() << ' ' << r.getRead() << ' ' << b.getRevComp() << ' ' << b.getRevQuality() << ' ' << b.size()
+               << ' ' << b.getSequence(FORWARD_STRAND) << ' ' << b.getSequence(REVERSE_C_STRAND);
+        } else if (cmd == "kmer") { // wordSize strA offA strB offB: Kmer keys of the k-mer table (tkmer.h, indexinterface.h:590)
+            size_t ws, oa, ob;
+            string a, b;
+            in >> ws >> a >> oa >> b >> ob;
+            Kmer::setWordSize(ws);
+            Kmer ka(a, oa), kb(b, ob);
+            os << ka.str() << ' ' << kb.str() << ' ' << (ka == kb) << ' ' << (!(ka == kb) || KmerHash()(ka) == KmerHash()(kb)) << ' '
+               << Substring(&a, (length_t)oa, (length_t)(oa + ws)).containsN() << ' '
+               << Substring(&b, (length_t)ob, (length_t)(ob + ws)).containsN();
+        } else if (cmd == "substr") { // text begin end dir: Substring accessors (substring.h)
+            string t;
+            uint32_t b, e;
+            int d;
+            in >> t >> b >> e >> d;
+            Substring sub(&t, b, e, d == 0 ? FORWARD : BACKWARD);
+            os << sub.size() << ' ' << sub.begin() << ' ' << sub.end() << ' ' << sub.empty() << ' ' << sub.containsN() << ' '
+               << '[' << sub.tostring() << "] [";
+            for (size_t i = 0; i < sub.size(); i++) os << sub[i];
+            os << ']';
+            sub.setDirection(d == 0 ? BACKWARD : FORWARD);
+            os << " [";
+            for (size_t i = 0; i < sub.size(); i++) os << sub[i];
+            os << ']';
+        } else if (cmd == "readscheme") { // path k: SearchScheme::readScheme (search.h:684-711) on a scheme file
+            string path;
+            unsigned k;
+            in >> path >> k;
+            try {
+                ifstream ifs(path);
+                if (!ifs) throw std::runtime_error("cannot open");
+                SearchScheme sch = SearchScheme::readScheme(ifs, path, k);
+                SearchScheme mir = sch.mirrorPiStrings();
+                os << "ok " << sch.getSearches().size() << ' ' << sch.getNumParts() << ' ' << sch.getCriticalPartIndex()
+                   << ' ' << mir.getCriticalPartIndex();
+                for (const auto* sc : {&sch, &mir})
+                    for (const Search& se : sc->getSearches()) {
+                        os << " |";
+                        for (length_t i = 0; i < se.getNumParts(); i++) os << ' ' << se.getPart(i);
+                        for (length_t i = 0; i < se.getNumParts(); i++) os << ' ' << se.getLowerBound(i);
+                        for (length_t i = 0; i < se.getNumParts(); i++) os << ' ' << se.getUpperBound(i);
+                        for (length_t i = 0; i < se.getNumParts(); i++) os << ' ' << se.getDirection(i);
+                        for (length_t i = 0; i < se.getNumParts(); i++) os << ' ' << se.getDirectionSwitch(i);
+                        for (length_t i = 0; i < se.getNumParts(); i++) os << ' ' << se.isUnidirectionalBackwards(i);
+                    }
+            } catch (const std::exception& e) {
+                string m = e.what();
+                for (auto& c : m)
+                    if (c == '\n') c = '~';
+                os << "error " << m;
+            }
         } else if (cmd == "consts") {
             os << BitParallelED64::getMatrixMaxED() << ' ' << BitParallelED64::getMaxFirstColRows() << ' '
                << MAX_K << ' ' << CIGAR_THRESHOLD << ' ' << DEFAULT_SPARSENESS << ' ' << sizeof(length_t);

@@ -1,87 +1,130 @@
 """ORACLE — TEST INFRASTRUCTURE ONLY.
 
-Search-scheme tables used to drive the oracle (data, not code).  Each search is
-(pi, L, U) written as digit strings.  Sources in the reference:
+Search-scheme tables that drive the oracle.  They are READ FROM THE REFERENCE'S OWN DATA: tests/golden/search_schemes/
+is a verbatim copy of /root/reference/search_schemes (data, not code; tests/test_oracle_golden.py checks the copy
+byte for byte where the reference is present, and every file in it is parsed by the reference's own
+SearchScheme::readScheme in the golden vectors).  Only what exists nowhere as data is written out here, each with
+the reference lines it restates:
 
-* ``multiple_opt``: search_schemes/multiple_opt/{2,4,6}/scheme<i>.txt (the ``-d`` option,
-  MultipleSchemesStrategy, src/searchstrategy.h:2584; base-class partition defaults,
-  k-mer cut-off 20)
-* ``kuch1``: KucherovKPlus1, src/searchstrategy.h:2829-2913 (seeding positions, weights,
-  static positions, k-mer cut-off 100)
-* ``pigeon``: PigeonHoleSearchStrategy, src/searchstrategy.h:3221-3274
+* the two k = 1 tables where a hard-coded class differs from the data directory of the same name
+  (OptimalKianfar, src/searchstrategy.h:3028-3030; MinUSearchStrategy, :3286-3288),
+* the k-mer cut-offs of the hard-coded classes (src/searchstrategy.h:2907, :3009, :3091, :3193: 100; base class 20,
+  :222; CustomSearchStrategy 50, :2308),
+* how `-S columba` (DynamicColumbaStrategy, :3666-3736) and `-c <dir>` (DynamicCustomStrategy, :3744-3776) assemble
+  their alternatives: scheme, mirror image (MultipleSchemes ctor :2468-2477), then the "middle" schemes.
 
-The product library carries its own, independently written tables
-(columba_amd/csrc/host/schemes.cpp); tests cross-check the two.
+The product library carries its own, independently typed tables (columba_amd/csrc/host_schemes.hpp);
+tests/test_strategy_tables.py compares the two through the C-ABI.
 """
+import os
+
+SCHEME_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                          "search_schemes")
 
 
-def _s(*rows):
+def _vec(tok):
+    return [int(x) for x in tok[1:-1].split(",")]
+
+
+def read_scheme_file(path):
+    """SearchScheme::readScheme (src/search.h:684-711): one search "{pi} {L} {U}" per non-empty line"""
     out = []
-    for r in rows:
-        pi, lo, up = r.split()
-        out.append(([int(c) for c in pi], [int(c) for c in lo], [int(c) for c in up]))
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if not t:
+                continue
+            assert len(t) == 3, (path, line)
+            out.append((_vec(t[0]), _vec(t[1]), _vec(t[2])))
     return out
 
 
-MULTIPLE_OPT = {
-    "kmer_cutoff": 20,
-    "schemes": {
-        2: [
-            _s("012 011 022", "102 000 012", "210 002 012"),
-            _s("210 011 022", "120 000 012", "012 002 012"),
-        ],
-        4: [
-            _s("01234 00222 02244", "12034 00000 01244", "21034 01111 01244",
-               "34210 00003 01444", "43210 01114 01444"),
-            _s("01234 01114 01444", "10234 00003 01444", "23410 01111 02244",
-               "32410 00000 01244", "43210 00222 01244"),
-            _s("43210 00222 02244", "32410 00000 01244", "23410 01111 01244",
-               "10234 00003 01444", "01234 01114 01444"),
-        ],
-        6: [
-            _s("0123456 0022226 0226666", "1203456 0111115 0126666", "2103456 0000004 0126666",
-               "3456210 0000000 0133666", "4356210 0111111 0133666", "5643210 0002222 0133666",
-               "6543210 0113333 0133666"),
-            _s("0123456 0111115 0126666", "1023456 0000004 0126666", "2103456 0022226 0226666",
-               "3456210 0002222 0133666", "4356210 0113333 0133666", "5643210 0000000 0133666",
-               "6543210 0111111 0133666"),
-            _s("6543210 0111115 0126666", "5643210 0000004 0126666", "4563210 0022226 0226666",
-               "3210456 0002222 0133666", "2310456 0113333 0133666", "1023456 0000000 0133666",
-               "0123456 0111111 0133666"),
-            _s("6543210 0022226 0226666", "5463210 0111115 0126666", "4563210 0000004 0126666",
-               "3210456 0000000 0133666", "2310456 0111111 0133666", "1023456 0002222 0133666",
-               "0123456 0113333 0133666"),
-        ],
-    },
-}
+def mirror(scheme):
+    """SearchScheme::mirrorPiStrings (src/search.h:488-493, :745-753)"""
+    return [([len(pi) - 1 - p for p in pi], lo, up) for pi, lo, up in scheme]
 
-KUCH1 = {
-    "kmer_cutoff": 100,
-    "schemes": {
-        1: [_s("01 01 01", "10 00 01")],
-        2: [_s("012 000 022", "210 000 012", "102 001 012")],
-        3: [_s("0123 0000 0133", "1023 0011 0133", "2310 0000 0133", "3210 0011 0133")],
-        4: [_s("01234 00000 02244", "43210 00000 01344", "10234 00133 01334", "01234 00133 01334",
-               "32410 00011 01244", "21034 00013 01244", "10234 00124 01244", "01234 00034 00444")],
-    },
-    "partition_params": {
-        1: {"seeding": [], "weights": [1, 1], "begins": [0.5]},
-        2: {"seeding": [0.57], "weights": [39, 10, 40], "begins": [0.41, 0.7]},
-        3: {"seeding": [0.38, 0.65], "weights": [400, 4, 5, 400], "begins": [0.25, 0.50, 0.75]},
-        4: {"seeding": [0.38, 0.55, 0.73], "weights": [100, 5, 1, 6, 105],
-            "begins": [0.27, 0.47, 0.62, 0.81]},
-    },
-}
 
-PIGEON = {
-    "kmer_cutoff": 20,
-    "schemes": {
-        1: [_s("01 00 01", "10 00 01")],
-        2: [_s("012 000 022", "120 000 022", "210 000 022")],
-        3: [_s("0123 0000 0333", "1023 0000 0333", "2310 0000 0333", "3210 0000 0333")],
-        4: [_s("01234 00000 04444", "12340 00000 04444", "23410 00000 04444", "34210 00000 04444",
-               "43210 00000 04444")],
-    },
-}
+def load_custom_dir(name, kmer_cutoff=50, dynamic=False, max_k=13):
+    """`-c <dir> -nD` (CustomSearchStrategy::getSearchSchemeFromFolder, src/searchstrategy.cpp:1990-2117) or, with
+    dynamic=True, `-c <dir>` (DynamicCustomStrategy: scheme + mirror image, base-class partitioning)."""
+    base = name if os.path.isabs(name) else os.path.join(SCHEME_DIR, name)
+    spec = {"kmer_cutoff": kmer_cutoff, "schemes": {}, "partition_params": {}}
+    for k in range(1, max_k + 1):
+        p = os.path.join(base, str(k), "searches.txt")
+        if not os.path.exists(p):
+            continue
+        sch = read_scheme_file(p)
+        spec["schemes"][k] = [sch, mirror(sch)] if dynamic else [sch]
+        if dynamic:
+            continue
+        pp = {}
+        ps = os.path.join(base, str(k), "static_partitioning.txt")
+        if os.path.exists(ps):
+            pp["begins"] = [float(x) for x in open(ps).readline().split()]
+        pd = os.path.join(base, str(k), "dynamic_partitioning.txt")
+        if os.path.exists(pd):
+            with open(pd) as f:
+                pp["seeding"] = [float(x) for x in f.readline().split()]
+                pp["weights"] = [int(x) for x in f.readline().split()]
+        if pp:
+            spec["partition_params"][k] = pp
+    if not spec["partition_params"]:
+        del spec["partition_params"]
+    return spec
 
-BY_NAME = {"multiple_opt": MULTIPLE_OPT, "kuch1": KUCH1, "pigeon": PIGEON}
+
+def load_multiple_dir(name, max_k=13):
+    """`-d <dir>` (MultipleSchemesStrategy::readSchemes, src/searchstrategy.h:2624-2660): <k>/scheme<i>.txt"""
+    base = name if os.path.isabs(name) else os.path.join(SCHEME_DIR, name)
+    spec = {"kmer_cutoff": 20, "schemes": {}}
+    for k in range(1, max_k + 1):
+        alts = []
+        i = 1
+        while os.path.exists(os.path.join(base, str(k), f"scheme{i}.txt")):
+            alts.append(read_scheme_file(os.path.join(base, str(k), f"scheme{i}.txt")))
+            i += 1
+        if alts:
+            spec["schemes"][k] = alts
+    return spec
+
+
+def _restrict(spec, ks):
+    out = dict(spec)
+    out["schemes"] = {k: v for k, v in spec["schemes"].items() if k in ks}
+    if "partition_params" in spec:
+        out["partition_params"] = {k: v for k, v in spec["partition_params"].items() if k in ks}
+    return out
+
+
+MULTIPLE_OPT = load_multiple_dir("multiple_opt")
+# the hard-coded classes support 1..4 errors (getMaxSupportedDistance) with cut-off 100
+KUCH1 = _restrict(load_custom_dir("kuch_k+1", 100), range(1, 5))
+KUCH2 = _restrict(load_custom_dir("kuch_k+2", 100), range(1, 5))
+KIANFAR = _restrict(load_custom_dir("kianfar", 100), range(1, 5))
+KIANFAR["schemes"][1] = [[([0, 1], [0, 0], [0, 1]), ([1, 0], [0, 1], [0, 1])]]  # searchstrategy.h:3028-3030
+O1STAR = _restrict(load_custom_dir("01star0", 100), range(1, 5))
+# PigeonHoleSearchStrategy (searchstrategy.h:3221-3274): 1..4 errors, base-class partitioning and cut-off
+PIGEON = {"kmer_cutoff": 20, "schemes": _restrict(load_custom_dir("pigeon"), range(1, 5))["schemes"]}
+# MinUSearchStrategy (searchstrategy.h:3284-3389) = search_schemes/multiple_opt/individual_schemes/scheme1 except k = 1
+MINU = {"kmer_cutoff": 20,
+        "schemes": load_custom_dir(os.path.join("multiple_opt", "individual_schemes", "scheme1"))["schemes"]}
+MINU["schemes"][1] = [[([0, 1], [0, 0], [0, 1]), ([1, 0], [0, 0], [0, 1])]]  # searchstrategy.h:3286-3288
+
+
+def _columba():
+    # DynamicColumbaStrategy::createDynamicColumbaStrategy (searchstrategy.h:3720-3735); minU part only (k <= 7)
+    spec = {"kmer_cutoff": 20, "schemes": {}}
+    for k, (sch,) in MINU["schemes"].items():
+        spec["schemes"][k] = [sch, mirror(sch)]
+    mid = {2: MULTIPLE_OPT["schemes"][2][1], 4: MULTIPLE_OPT["schemes"][4][1], 6: MULTIPLE_OPT["schemes"][6][1]}
+    # getMidSearch2 / 4 / 6 (searchstrategy.h:3669-3706) — checked against these data files in the tests
+    spec["schemes"][2].append(mid[2])
+    spec["schemes"][4].append(mid[4])
+    spec["schemes"][6] += [mid[6], mirror(mid[6])]
+    return spec
+
+
+COLUMBA = _columba()
+
+BY_NAME = {"multiple_opt": MULTIPLE_OPT, "kuch1": KUCH1, "kuch2": KUCH2, "kianfar": KIANFAR, "01*0": O1STAR,
+           "pigeon": PIGEON, "minU": MINU, "columba": COLUMBA}

@@ -248,12 +248,77 @@ for _ in range(40):
 for _ in range(20):
     cmds.append("revcomp " + rseq(rng.randint(1, 60), "ACGTN"))
 
+# ---- round 2: more reference units that compile without parallel_hashmap -----------------------------------
+# (appended with their own generator so that the vectors above stay what they were)
+rng2 = random.Random(20261004)
+
+
+def rseq2(n, alphabet=ACGT):
+    return "".join(rng2.choice(alphabet) for _ in range(n))
+
+
+# a10: SparseSuffixArray — written by the reference's writer, read back by its mmap reader (suffixArray.h)
+for n in [1, 2, 63, 64, 65, 127, 128, 129, 511, 512, 513, 520, 1023, 1025, 1600] + [rng2.randint(3, 900) for _ in range(10)]:
+    t = rseq2(n - 1) + "$" if n > 1 else "$"
+    sa = sorted(range(n), key=lambda i: t[i:])
+    for sp in ([1, 4, 32] if n in (1, 64, 513) else [rng2.choice([1, 2, 4, 8, 16, 32, 64, 128])]):
+        cmds.append(f"ssa {sp} {n} " + " ".join(map(str, sa)))
+
+# a17 / App. A 15: Read + ReadBundle clean-up (reads.h)
+IUPAC = "ACGTNacgtnRYKMSWBDHVryu.-*"
+for _ in range(60):
+    rid = rng2.choice("@>") + "".join(rng2.choice("abcXYZ019:/#") for _ in range(rng2.randint(1, 12)))
+    for _ in range(rng2.randint(0, 2)):
+        rid += "_" + "".join(rng2.choice("descr=12") for _ in range(rng2.randint(0, 6)))  # '_' stands for a space
+    ln = rng2.randint(1, 80)
+    rd = rseq2(ln, IUPAC if rng2.random() < 0.6 else "ACGTacgt")
+    ql = "".join(chr(rng2.randint(33, 73)) for _ in range(ln))
+    cmds.append(f"read {rid} {rd} {ql}")
+
+# a15: Kmer keys of the k-mer table (tkmer.h) + Substring::containsN
+for _ in range(80):
+    ws = rng2.choice([1, 3, 4, 5, 8, 10, 10, 10, 11, 12, 15])
+    a = rseq2(ws + rng2.randint(0, 6), "ACGTN" if rng2.random() < 0.3 else ACGT)
+    oa = rng2.randint(0, len(a) - ws)
+    u = rng2.random()
+    if u < 0.4:
+        b, ob = a, oa
+    elif u < 0.7:
+        pos = rng2.randrange(ws)
+        b = list(a[oa:oa + ws])
+        b[pos] = rng2.choice([c for c in "ACGTN" if c != b[pos]])
+        b, ob = rseq2(2) + "".join(b), 2
+    else:
+        b = rseq2(ws + 3, "ACGTN")
+        ob = rng2.randint(0, 3)
+    cmds.append(f"kmer {ws} {a} {oa} {b} {ob}")
+
+# a17: Substring accessors in both directions
+for _ in range(60):
+    t = rseq2(rng2.randint(1, 40), "ACGTN")
+    b = rng2.randint(0, len(t))
+    e = rng2.randint(0, len(t) + 5)
+    cmds.append(f"substr {t} {b} {e} {rng2.randint(0, 1)}")
+
+# a14: SearchScheme::readScheme on every scheme file of the reference's search_schemes/ (copied verbatim — data —
+# to tests/golden/search_schemes/; the driver runs with tests/golden/ as working directory) and on malformed files
+SCHEME_DIR = os.path.join(HERE, "search_schemes")
+for root, _dirs, files in sorted(os.walk(SCHEME_DIR)):
+    for fn in sorted(files):
+        if fn == "searches.txt" or (fn.startswith("scheme") and fn.endswith(".txt")):
+            rel = os.path.relpath(os.path.join(root, fn), HERE)
+            k = int(os.path.basename(root))
+            cmds.append(f"readscheme {rel} {k}")
+for fn in sorted(os.listdir(os.path.join(HERE, "bad_schemes"))):
+    cmds.append(f"readscheme bad_schemes/{fn} 2")
+cmds.append("readscheme bad_schemes/does_not_exist.txt 2")
+
 
 def main():
     if not os.path.exists(DRIVER):
         sys.exit("oracle/_ref/ref_driver missing: run `make -C oracle ref` in the build container")
     inp = "\n".join(cmds) + "\n"
-    out = subprocess.run([DRIVER], input=inp, capture_output=True, text=True, check=True).stdout
+    out = subprocess.run([DRIVER], input=inp, capture_output=True, text=True, check=True, cwd=HERE).stdout
     assert out.count("\n") == len(cmds)
     with open(os.path.join(HERE, "ref_vectors.cmds"), "w") as f:
         f.write(inp)

@@ -132,12 +132,70 @@ def test_in_text_verification_hook(world):
     ("pigeon", "hamming", "uniform", 1),
     ("multiple_opt", "hamming", "dynamic", 4),
     ("kuch1", "edit", "dynamic", 0),
+    # round 2: the remaining `-S` strategies (alignparameters.cpp:1341-1372)
+    ("kuch2", "edit", "dynamic", 3),
+    ("kuch2", "edit", "static", 4),
+    ("kuch2", "hamming", "dynamic", 2),
+    ("kianfar", "edit", "dynamic", 4),     # searches whose FIRST part already allows errors (U[0] > 0)
+    ("kianfar", "edit", "static", 3),
+    ("kianfar", "hamming", "uniform", 4),
+    ("01*0", "edit", "dynamic", 2),
+    ("01*0", "edit", "uniform", 4),
+    ("minU", "edit", "dynamic", 5),
+    ("minU", "edit", "uniform", 3),
+    ("minU", "hamming", "dynamic", 6),
+    ("columba", "edit", "dynamic", 4),     # the CLI's default strategy
+    ("columba", "edit", "dynamic", 6),
+    ("columba", "edit", "dynamic", 1),
+    ("columba", "edit", "uniform", 5),
+    ("columba", "hamming", "dynamic", 3),
 ])
 def test_match_batch_parity(world, spec, metric, partition, k):
     reads = synth.sample_reads(world["genome"], 3000, 150, seed=100 + k, n_frac=0.02)
     cnt = _compare(world, spec, metric, partition, k, reads)
     if k >= 2 and metric == "edit":
         assert cnt["SEARCH_STARTED"] > 0 and cnt["IN_TEXT_STARTED"] > 0  # both regimes exercised
+
+
+@pytest.mark.parametrize("name,dirname,mode,metric,partition,k", [
+    ("kuch1", "kuch_k+1", "custom", "edit", "dynamic", 4),
+    ("kuch1", "kuch_k+1", "custom", "edit", "static", 3),
+    ("kuch2", "kuch_k+2", "custom", "hamming", "dynamic", 2),
+    ("01*0", "01star0", "custom", "edit", "static", 3),
+    ("kianfar", "kianfar", "custom", "edit", "dynamic", 4),
+    ("multiple_opt", "multiple_opt", "multiple", "edit", "dynamic", 4),
+    ("multiple_opt", "multiple_opt", "multiple", "edit", "uniform", 6),
+])
+def test_scheme_directories_equal_builtin_strategies(world, name, dirname, mode, metric, partition, k):
+    """`-c <dir>` / `-d <dir>` on the reference's own search_schemes/ data (tests/golden/search_schemes) give the
+    results AND counters of the hard-coded strategy of the same name (150 bp reads are beyond every k-mer cut-off:
+    100 hard-coded, 50 custom, 20 multiple)."""
+    import os
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "search_schemes", dirname)
+    reads = synth.sample_reads(world["genome"], 2000, 150, seed=300 + k, n_frac=0.02)
+    o1, f1, c1 = ca.match_batch(world["dev"], ca.SearchStrategy(name, metric, partition), k, reads)
+    o2, f2, c2 = ca.match_batch(world["dev"], ca.SearchStrategy.from_dir(d, mode, metric, partition), k, reads)
+    assert len(o1) > 0 and np.array_equal(f1, f2) and np.array_equal(o1, o2)
+    assert c1 == c2
+
+
+def test_custom_directory_with_dynamic_selection(world):
+    """`-c <dir>` as the CLI runs it (DynamicCustomStrategy: scheme + mirror image, dynamic selection) against the
+    oracle driven by the same tables"""
+    import os
+    import schemes_py as sp
+    op = world["op"]
+    reads = synth.sample_reads(world["genome"], 2000, 150, seed=321, n_frac=0.02)
+    for dirname, k in (("kuch_k+1", 4), ("kuch_k+2", 3), ("pigeon", 5)):
+        d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "search_schemes", dirname)
+        spec = sp.load_custom_dir(dirname, dynamic=True)
+        o_occ, o_off, o_cnt = op.match_batch(world["orc"], op.OracleStrategy(spec, "edit", "dynamic"), k, reads, threads=8)
+        d_occ, d_off, d_cnt = ca.match_batch(world["dev"], ca.SearchStrategy.from_dir(d, "custom_dynamic"), k, reads)
+        assert np.array_equal(o_off, d_off)
+        for f in ("begin", "end", "distance"):
+            assert np.array_equal(o_occ[f], d_occ[f]), (dirname, f)
+        for n in ("NODE_COUNTER", "IN_TEXT_STARTED", "SEARCH_STARTED", "EXPANSIONS", "MATRIX_ROWS", "TOTAL_REPORTED_POSITIONS"):
+            assert o_cnt[n] == d_cnt[n], (dirname, n)
 
 
 def test_ragged_and_odd_reads(world):

@@ -3,8 +3,9 @@
 tests/golden/ref_vectors.out was written by oracle/_ref/ref_driver, which is the reference's
 own bitvec.h / bwtrepr.h / encodedtext.h / bitparallelmatrix.{h,cpp} / indexhelpers.{h,cpp} /
 search.{h,cpp} / nucleotide.h compiled unmodified (oracle/Makefile, tests/golden/make_golden.py).
-These tests pin rows a1, a2, a5, a7, a10 (bit structures), a11 (doTask), a14, a16 (orderings),
-a17 of SURVEY.md §8.
+These tests pin rows a1, a2, a5, a7, a10 (bit structures, sparse suffix array files), a11 (doTask), a14
+(makeSearch, critical part, readScheme on every file of search_schemes/), a15 (k-mer keys), a16 (orderings),
+a17 (value types, Read / ReadBundle clean-up, Substring) of SURVEY.md §8.
 """
 import os
 import subprocess
@@ -26,7 +27,7 @@ def _load():
 def test_oracle_matches_reference_vectors(oracle_built):
     cmds, outs = _load()
     res = subprocess.run([os.path.join(oracle_built, "oracle_driver")], input="\n".join(cmds) + "\n",
-                         capture_output=True, text=True, check=True).stdout.splitlines()
+                         capture_output=True, text=True, check=True, cwd=GOLD).stdout.splitlines()
     assert len(res) == len(outs)
     bad = Counter()
     for c, r, o in zip(cmds, res, outs):
@@ -39,8 +40,12 @@ def test_vectors_are_not_vacuous():
     cmds, outs = _load()
     kinds = Counter(c.split(" ")[0] for c in cmds)
     for k in ("bwt", "bitvec9", "enc", "matrix", "traceback", "search", "scheme", "cluster", "verify",
-              "occsort", "revcomp"):
+              "occsort", "revcomp", "ssa", "read", "kmer", "substr", "readscheme"):
         assert kinds[k] >= 10, k
+    # every scheme file of the reference's search_schemes/ is read by the reference's own reader
+    ok = sum(1 for c, o in zip(cmds, outs) if c.startswith("readscheme search_schemes/") and o.startswith("ok "))
+    assert ok >= 100
+    assert sum(1 for c, o in zip(cmds, outs) if c.startswith("readscheme bad_schemes/") and o.startswith("error ")) >= 8
     # in-text verification vectors must contain real hits and real aborts
     hits = aborts = 0
     for c, o in zip(cmds, outs):
@@ -62,5 +67,61 @@ def test_fixture_is_what_the_reference_prints_today():
     cmds, outs = _load()
     drv = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "ref_driver")
     res = subprocess.run([drv], input="\n".join(cmds) + "\n", capture_output=True, text=True,
-                         check=True).stdout.splitlines()
+                         check=True, cwd=GOLD).stdout.splitlines()
     assert res == outs
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/search_schemes"), reason="build container only")
+def test_scheme_fixtures_are_the_reference_data():
+    """tests/golden/search_schemes/ is a verbatim copy of the reference's data directory."""
+    import filecmp
+    ref = "/root/reference/search_schemes"
+    n = 0
+    for root, _d, files in os.walk(ref):
+        for fn in files:
+            a = os.path.join(root, fn)
+            b = os.path.join(GOLD, "search_schemes", os.path.relpath(a, ref))
+            assert os.path.exists(b), b
+            assert filecmp.cmp(a, b, shallow=False), b
+            n += 1
+    assert n > 150
+
+
+def test_sparse_sa_files_of_the_reference_load(tmp_path):
+    """Index files written by the reference's own SparseSuffixArray::write (suffixArray.h:229-243) are read by
+    columba_amd.indexbuild (the loader in front of cmb_index_create), and the harness' builder writes the same
+    bytes for the same suffix array."""
+    import struct
+    import numpy as np
+    import torch
+    from columba_amd import indexbuild as ib
+    cmds, outs = _load()
+    seen = 0
+    for c, o in zip(cmds, outs):
+        if not c.startswith("ssa "):
+            continue
+        t = c.split()
+        sp, n = int(t[1]), int(t[2])
+        sa = np.array(t[3:3 + n], dtype=np.int64)
+        f_bv, f_sa, marks, _ = [x.split() for x in o.split("|")]
+        words = np.array([int(x, 16) for x in f_bv[1:]], dtype=np.uint64)
+        samples = np.array(f_sa[1:], dtype=np.uint32)
+        assert int(f_bv[0]) == len(words) and int(f_sa[0]) == len(samples)
+        base = str(tmp_path / f"x{seen}")
+        words.tofile(f"{base}.sa.bv.{sp}")
+        samples.tofile(f"{base}.sa.{sp}")
+        N, bv, cnt, smp = ib.read_sparse_sa(base, sp)
+        assert N == n and np.array_equal(smp, samples)
+        # what the reference's reader answered per row: "0" or "1:<SA value>"
+        rank = 0
+        for i, m in enumerate(marks):
+            bit = (int(bv[i // 64]) >> (i % 64)) & 1
+            assert bit == int(m[0])
+            if bit:
+                assert int(m.split(":")[1]) == int(smp[rank]) == int(sa[i])
+                rank += 1
+        w2, c2, s2 = ib.build_sparse_sa(torch.from_numpy(sa), sp)
+        mine = np.concatenate([np.array([n], np.uint64), w2, c2])
+        assert np.array_equal(mine, words) and np.array_equal(s2, samples)
+        seen += 1
+    assert seen >= 20

@@ -1,0 +1,215 @@
+"""Strategy tables and scheme-directory loaders of the product library (host-only C-ABI calls: no GPU needed)
+against the reference's own data (tests/golden/search_schemes, a verbatim copy of /root/reference/search_schemes)
+and against what the reference's SearchScheme::readScheme / mirrorPiStrings printed for every one of those files
+(tests/golden/ref_vectors.*, `readscheme` vectors).  Pins SURVEY.md §8 row a14 at the table level."""
+import os
+import shutil
+
+import pytest
+
+import columba_amd as ca
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+SCHEMES = os.path.join(GOLD, "search_schemes")
+
+
+def _golden_readscheme():
+    """path -> parsed output of the reference's reader: (n_searches, n_parts, critical, critical of the mirror,
+    searches, mirrored searches) or the error text"""
+    cmds = open(os.path.join(GOLD, "ref_vectors.cmds")).read().splitlines()
+    outs = open(os.path.join(GOLD, "ref_vectors.out")).read().splitlines()
+    res = {}
+    for c, o in zip(cmds, outs):
+        if not c.startswith("readscheme "):
+            continue
+        path = c.split()[1]
+        if not o.startswith("ok "):
+            res[path] = o
+            continue
+        blocks = o.split(" | ")
+        ns, np_, crit, mcrit = map(int, blocks[0].split()[1:])
+        searches = []
+        for b in blocks[1:]:
+            v = list(map(int, b.replace("|", " ").split()))
+            searches.append((v[0:np_], v[np_:2 * np_], v[2 * np_:3 * np_]))
+        assert len(searches) == 2 * ns
+        res[path] = (ns, np_, crit, mcrit, searches[:ns], searches[ns:])
+    return res
+
+
+GOLDEN = _golden_readscheme()
+
+
+def _file_key(*parts):
+    return os.path.join("search_schemes", *parts)
+
+
+# (name of the built-in strategy, data directory, distances, k for which the hard-coded class differs from the data)
+BUILTIN = [("kuch1", "kuch_k+1", [1, 2, 3, 4], {}),
+           ("kuch2", "kuch_k+2", [1, 2, 3, 4], {}),
+           ("kianfar", "kianfar", [1, 2, 3, 4],
+            {1: [([0, 1], [0, 0], [0, 1]), ([1, 0], [0, 1], [0, 1])]}),   # searchstrategy.h:3028-3030
+           ("01*0", "01star0", [1, 2, 3, 4], {}),
+           ("pigeon", "pigeon", [1, 2, 3, 4], {}),
+           ("minU", os.path.join("multiple_opt", "individual_schemes", "scheme1"), [1, 2, 3, 4, 5, 6, 7],
+            {1: [([0, 1], [0, 0], [0, 1]), ([1, 0], [0, 0], [0, 1])]})]  # searchstrategy.h:3286-3288
+
+
+@pytest.mark.parametrize("name,dirname,ks,class_only", BUILTIN)
+def test_builtin_tables_equal_the_reference_data(name, dirname, ks, class_only):
+    built = ca.SearchStrategy(name)
+    loaded = ca.SearchStrategy.from_dir(os.path.join(SCHEMES, dirname), "custom")
+    for k in ks:
+        ns, np_, crit, _m, searches, _ms = GOLDEN[_file_key(dirname, str(k), "searches.txt")]
+        # the loader reads the file exactly as the reference's reader did
+        assert loaded.scheme(k, 0) == searches
+        assert loaded.describe(k) == (1, np_, [crit])
+        if k in class_only:
+            assert built.scheme(k, 0) == class_only[k]
+        else:
+            assert built.scheme(k, 0) == searches
+            assert built.describe(k) == (1, np_, [crit])
+        if name not in ("pigeon", "minU"):  # (these two use the base-class partitioning; the data dirs hold tuned files)
+            assert built.partition_params(k)[:3] == loaded.partition_params(k)[:3]
+    assert not built.supports(ks[-1] + 1)
+    cut = {"pigeon": 20, "minU": 20}.get(name, 100)
+    assert built.partition_params(ks[0])[3] == cut and loaded.partition_params(ks[0])[3] == 50
+
+
+def test_base_class_partition_defaults():
+    # searchstrategy.h:245 (begins i/P), :283 (weights 2,1,..,1,2), :1825 (seeding i/(P-1))
+    st = ca.SearchStrategy("minU")
+    seed, w, b, cut = st.partition_params(4)
+    assert w == [2, 1, 1, 1, 2] and cut == 20
+    assert b == [i * (1.0 / 5) for i in range(1, 5)]
+    assert seed == [i * (1.0 / 4) for i in range(1, 4)]
+
+
+def test_multiple_opt_builtin_equals_the_d_option_loader():
+    built = ca.SearchStrategy("multiple_opt")
+    loaded = ca.SearchStrategy.from_dir(os.path.join(SCHEMES, "multiple_opt"), "multiple")
+    for k, n in ((2, 2), (4, 3), (6, 4)):
+        assert built.describe(k) == loaded.describe(k)
+        assert built.describe(k)[0] == n
+        for i in range(n):
+            ns, np_, crit, _m, searches, _ms = GOLDEN[_file_key("multiple_opt", str(k), f"scheme{i + 1}.txt")]
+            assert built.scheme(k, i) == searches == loaded.scheme(k, i)
+            assert built.describe(k)[2][i] == crit
+    for k in (1, 3, 5, 7):
+        assert not loaded.supports(k) and not built.supports(k)
+
+
+def test_columba_default_strategy_assembly():
+    """`-S columba` = DynamicColumbaStrategy (searchstrategy.h:3666-3736): minU, its mirror image (as the
+    reference's mirrorPiStrings printed it), then the middle schemes — which are search_schemes/multiple_opt's
+    second schemes."""
+    st = ca.SearchStrategy("columba")
+    minu = ca.SearchStrategy("minU")
+    for k in range(1, 8):
+        n = {2: 3, 4: 3, 6: 4}.get(k, 2)
+        ns, np_, crits = st.describe(k)
+        assert ns == n and np_ == k + 1
+        assert st.scheme(k, 0) == minu.scheme(k, 0)
+        if k > 1:
+            g = GOLDEN[_file_key("multiple_opt", "individual_schemes", "scheme1", str(k), "searches.txt")]
+            assert st.scheme(k, 1) == g[5]          # the mirror image, computed by the reference
+            assert crits[:2] == [g[2], g[3]]
+        else:
+            assert st.scheme(1, 1) == [([1, 0], [0, 0], [0, 1]), ([0, 1], [0, 0], [0, 1])]
+    for k in (2, 4, 6):
+        g = GOLDEN[_file_key("multiple_opt", str(k), "scheme2.txt")]
+        assert st.scheme(k, 2) == g[4] and st.describe(k)[2][2] == g[2]
+    g6 = GOLDEN[_file_key("multiple_opt", "6", "scheme2.txt")]
+    assert st.scheme(6, 3) == g6[5] and st.describe(6)[2][3] == g6[3]
+
+
+def test_custom_dir_with_dynamic_selection():
+    """`-c <dir>` (DynamicCustomStrategy): scheme + mirror image; the strategy object is a copy of the BASE class
+    (searchstrategy.h:2689), so the directory's partitioning files do not apply, the k-mer cut-off stays 50."""
+    d = os.path.join(SCHEMES, "kuch_k+1")
+    st = ca.SearchStrategy.from_dir(d, "custom_dynamic")
+    for k in (1, 2, 3, 4):
+        g = GOLDEN[_file_key("kuch_k+1", str(k), "searches.txt")]
+        assert st.describe(k) == (2, g[1], [g[2], g[3]])
+        assert st.scheme(k, 0) == g[4] and st.scheme(k, 1) == g[5]
+    seed, w, b, cut = st.partition_params(4)
+    assert cut == 50 and w == [2, 1, 1, 1, 2] and b == [i * (1.0 / 5) for i in range(1, 5)]
+    # without dynamic selection the tuned files apply (values of search_schemes/kuch_k+1/4/)
+    plain = ca.SearchStrategy.from_dir(d, "custom")
+    assert plain.partition_params(4) == ([0.38, 0.55, 0.73], [100, 5, 1, 6, 105], [0.27, 0.47, 0.62, 0.81], 50)
+
+
+def test_every_reference_scheme_file_loads_like_the_reference(tmp_path):
+    """every <k>/searches.txt and scheme<i>.txt of search_schemes/: searches and critical part as the reference's
+    reader reports them (device-table limits are checked when a distance is used, not at load time)"""
+    n = 0
+    for path, g in GOLDEN.items():
+        if not path.startswith("search_schemes/") or isinstance(g, str):
+            continue
+        k = int(os.path.basename(os.path.dirname(path)))
+        if k > 13:  # MAX_K (definitions.h:50): the reference's directory loaders stop there too
+            continue
+        d = tmp_path / f"d{n}"
+        (d / str(k)).mkdir(parents=True)
+        (d / "name.txt").write_text("x\n")
+        shutil.copy(os.path.join(GOLD, path), d / str(k) / "searches.txt")
+        st = ca.SearchStrategy.from_dir(str(d), "custom")
+        assert st.scheme(k, 0) == g[4]
+        assert st.describe(k) == (1, g[1], [g[2]])
+        n += 1
+    assert n > 100
+
+
+def test_loader_errors_are_the_reference_errors(tmp_path):
+    """malformed scheme files: the message of the C-ABI is the one the reference's reader throws (same text, the
+    path being whatever the caller passed)"""
+    with pytest.raises(ca.CmbError, match="name.txt\nDid you provide a directory to a search scheme without a name file"):
+        ca.SearchStrategy.from_dir(str(tmp_path / "nothing"), "custom")
+    with pytest.raises(ca.CmbError, match="name.txt"):
+        ca.SearchStrategy.from_dir(str(tmp_path / "nothing"), "multiple")
+    n = 0
+    for path, g in GOLDEN.items():
+        if not path.startswith("bad_schemes/") or not isinstance(g, str) or not os.path.exists(os.path.join(GOLD, path)):
+            continue
+        d = tmp_path / f"b{n}"
+        (d / "2").mkdir(parents=True)
+        (d / "name.txt").write_text("x\n")
+        shutil.copy(os.path.join(GOLD, path), d / "2" / "searches.txt")
+        with pytest.raises(ca.CmbError) as ei:
+            ca.SearchStrategy.from_dir(str(d), "custom")
+        want = g[len("error "):].replace("~", "\n").replace(path, str(d / "2" / "searches.txt"))
+        assert str(ei.value) == "CMB_ERR_INVALID: " + want
+        n += 1
+    assert n >= 8
+    # partitioning files are validated as CustomSearchStrategy does (searchstrategy.cpp:2033-2117, :2166-2203)
+    d = tmp_path / "p"
+    shutil.copytree(os.path.join(SCHEMES, "kuch_k+1"), d)
+    (d / "2" / "static_partitioning.txt").write_text("0.5\n")
+    with pytest.raises(ca.CmbError, match="Not enough static positions provided"):
+        ca.SearchStrategy.from_dir(str(d), "custom")
+    (d / "2" / "static_partitioning.txt").write_text("0.7 0.4\n")
+    with pytest.raises(ca.CmbError, match="are not strictly increasing"):
+        ca.SearchStrategy.from_dir(str(d), "custom")
+    (d / "2" / "static_partitioning.txt").write_text("0.41 0.7\n")
+    (d / "2" / "dynamic_partitioning.txt").write_text("0.57\n39 10\n")
+    with pytest.raises(ca.CmbError, match="Not enough weights provided for max score 2"):
+        ca.SearchStrategy.from_dir(str(d), "custom")
+
+
+def test_oracle_tables_are_the_same_tables():
+    """the oracle is driven by tables read from the reference data (oracle/schemes_py.py); the product's compiled-in
+    tables must be the same ones"""
+    import schemes_py as sp
+    for name, spec in sp.BY_NAME.items():
+        st = ca.SearchStrategy(name)
+        for k, alts in spec["schemes"].items():
+            assert st.describe(k)[0] == len(alts), (name, k)
+            for i, sch in enumerate(alts):
+                assert st.scheme(k, i) == [(list(a), list(b), list(c)) for a, b, c in sch], (name, k, i)
+            seed, w, b, cut = st.partition_params(k)
+            assert cut == spec["kmer_cutoff"]
+            pp = spec.get("partition_params", {}).get(k)
+            if pp:
+                assert (seed, w, b) == (pp["seeding"], pp["weights"], pp["begins"])
+        assert not st.supports(max(spec["schemes"]) + 1)
