@@ -3,15 +3,16 @@
 distance, ALL mode, multiple_opt schemes with dynamic selection and dynamic partitioning —
 BASELINE.json configs[2]) on a human-like synthetic reference, one process per GPU.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts N ranks by itself, see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the whole hot path (k_prep -> k_parts/k_exact -> frontier search -> k_verify ->
 k_traceback -> k_fmocc -> k_filter, results copied back to the host)
 over this rank's read shard, reads already resident in HBM (cmb_batch_run).  Weak scaling: every
 rank matches `--reads` reads against a full replica of the index; no collective on the data path
-(rank 0 builds the index and broadcasts it over RCCL, read shards are scattered once, both before
-the timed region).  Rank 0 prints ONE JSON line.
+(rank 0 builds the index and broadcasts its DEVICE layout over RCCL, read shards are scattered once, both
+before the timed region; after it the occurrence lists are gathered on rank 0 and the counters all-reduced,
+timed apart as `result_gather_ms`).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -23,7 +24,7 @@ import sys
 import time
 
 import numpy as np
-import torch
+import torch   # (importing torch does not touch the GPU; nothing below does before launch_ranks has had its say)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -31,7 +32,8 @@ sys.path.insert(0, ROOT)
 import columba_amd as ca  # noqa: E402
 from columba_amd import indexbuild as ib  # noqa: E402
 from columba_amd import synth  # noqa: E402
-from columba_amd.dist import broadcast_index, scatter_reads  # noqa: E402
+from columba_amd.dist import (allreduce_counters, broadcast_device_index, gather_occurrences,  # noqa: E402
+                              scatter_reads)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
 
@@ -44,6 +46,36 @@ GROUP_KERNELS = {"k_prep": ["k_prep", "k_match_words"], "k_partition": ["k_parts
                  "k_dfs": ["k_bfs_start", "k_bfs_pass", "k_bfs_finish", "k_hbfs"],
                  "k_verify": ["k_verify"], "k_verify_edit": ["k_verify_stage"], "k_traceback": ["k_traceback"],
                  "k_fmocc": ["k_fm_keys", "k_fm_unique", "k_fmocc"], "k_filter": ["k_pack_keys", "k_filter_segments", "k_filter_mark", "k_filter_write"]}
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside a launcher: start N ranks (one process per GPU, RCCL rendezvous on
+    127.0.0.1) as a CHILD torch.distributed.run of this same command line and wait for it.  Called before
+    anything in this process has touched the GPU; the parent only waits and passes the exit code on (rank 0 of
+    the child prints the JSON line to the shared stdout)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    log(f"[bench] starting {n} ranks: {' '.join(cmd)}")
+    return subprocess.call(cmd, env=env)
+
+
+def source_digest() -> str:
+    """what a committed PMC profile must have been measured on: the kernel sources of this tree"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "columba_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        with open(os.path.join(d, fn), "rb") as f:
+            h.update(fn.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def load_traffic(args, genome_bp, reads, group):
@@ -61,16 +93,20 @@ def load_traffic(args, genome_bp, reads, group):
         w = d.get("workload", {})
         if w.get("genome_bp") != genome_bp or w.get("reads_per_gpu") != reads or w.get("k") != args.k:
             continue
+        if d.get("kernel_src_sha") != source_digest() and not args.traffic_from:
+            continue  # measured on other kernels than the ones being timed
         tot = 0.0
         for kn in GROUP_KERNELS.get(group, [group]):
             e = d.get("kernels", {}).get(kn)
             if e:
                 tot += 2.0 * e.get("FETCH_SIZE_KiB", 0.0) * 1024 + e.get("WRITE_SIZE_KiB", 0.0) * 1024
         if tot > 0:
-            return round(tot / 1e9, 3), (f"GB per step, 2 x FETCH_SIZE + WRITE_SIZE of {os.path.basename(f)} "
-                                         "(separate rocprofv3 --pmc passes; gfx950 factor for FETCH_SIZE, calibrated "
-                                         "for wide coalesced reads only)")
-    return None, "no PMC pass on record for this workload (tools/profile_round.sh writes profiles/*_pmc_traffic.json)"
+            return round(tot / 1e9, 3), os.path.relpath(f, ROOT), (
+                f"GB per step, 2 x FETCH_SIZE + WRITE_SIZE of {os.path.basename(f)} (separate rocprofv3 --pmc passes "
+                "of this command on these kernel sources; gfx950 factor for FETCH_SIZE, see profiles/README.md for its "
+                "calibration on scattered 16-byte loads)")
+    return None, None, ("no PMC pass on record for this workload AND these kernel sources "
+                        "(tools/profile_round.sh writes profiles/*_pmc_traffic.json with kernel_src_sha)")
 
 
 def main():
@@ -89,13 +125,16 @@ def main():
     ap.add_argument("--k", type=int, default=4)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU oracle (bounded sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the (untimed) gather of the results on rank 0")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))  # (before any GPU call in this process)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local)
@@ -117,10 +156,14 @@ def main():
         torch.cuda.empty_cache()
         log(f"[bench] index for {n / 1e6:.0f} Mbp built in {time.time() - t0:.1f} s "
             f"({ix.nbytes() / 1e9:.2f} GB host arrays)")
+    index = ca.Index(ix, in_text_switch=4, kmer_size=10, device=local) if rank == 0 else None
     if world > 1:
-        ix = broadcast_index(ix, rank, dev)
-        torch.cuda.empty_cache()
-    index = ca.Index(ix, in_text_switch=4, kmer_size=10, device=local)
+        tb = time.time()
+        index = broadcast_device_index(index, rank, local)  # the device layout itself, one collective per array
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f"[bench] device index ({index.device_bytes() / 1e9:.2f} GB) broadcast to {world - 1} peers in "
+                f"{time.time() - tb:.2f} s")
     strategy = ca.SearchStrategy("multiple_opt", "edit", "dynamic")
 
     # reads: rank 0 samples the global batch on its GPU and scatters equal shards
@@ -174,10 +217,26 @@ def main():
     kern_serial = dict(batch.timings())
     occ, occ_offs, cnt = batch.results()
     total_occ = len(occ)
+    gather_ms = None
     if dist is not None:
         tt = torch.tensor([total_occ], dtype=torch.int64, device=dev)
         dist.all_reduce(tt)
         total_occ = int(tt.item())
+        if not args.no_gather:
+            # result path of the sharded job: gatherv of the occurrence lists on rank 0 + all-reduce of the counters
+            # (SURVEY.md §8e).  Not part of a step: one rank's host link would carry every rank's results.
+            sync()
+            tg = time.perf_counter()
+            g_occ, g_offs = gather_occurrences(occ, occ_offs, rank, world, dev)
+            cnt_all = allreduce_counters(cnt, dev)
+            sync()
+            gather_ms = (time.perf_counter() - tg) * 1e3
+            if rank == 0:
+                assert len(g_occ) == total_occ and len(g_offs) == world * R + 1 and int(g_offs[-1]) == total_occ
+                assert np.array_equal(g_occ[:len(occ)], occ)
+                log(f"[bench] gathered {len(g_occ)} occurrences of {world * R} reads on rank 0 in {gather_ms:.1f} ms; "
+                    f"NODE_COUNTER of the job {cnt_all['NODE_COUNTER']}")
+                del g_occ, g_offs
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -203,9 +262,10 @@ def main():
                                  "algorithmic_GBps": None if gbs is None else round(gbs, 1),
                                  "frac_of_hbm_peak": None if gbs is None else round(gbs / HBM_PEAK_GBS, 4)}
         achieved = per_kernel[dominant]["algorithmic_GBps"] or 0.0
-        traffic, traffic_note = load_traffic(args, n, R, dominant)
+        traffic, traffic_source, traffic_note = load_traffic(args, n, R, dominant)
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_source": traffic_source, "kernel_src_sha": source_digest(),
                     "traffic_note": traffic_note, "avg_launch_ms": round(avg[dominant], 3),
                     "timing_note": "kernel times (HIP events on the batch's streams) are from one extra step with the "
                                    "batch's sub-batches run one after the other; in the timed steps the sub-batches "
@@ -243,7 +303,7 @@ def main():
                                    "in-text switch 4, SA sparseness 4",
                        "reads_per_gpu": R, "read_len": L, "k": args.k, "genome_bp": n,
                        "index_bytes_hbm": index.device_bytes(), "parallelism": f"read-shard x{world}",
-                       "occurrences": total_occ},
+                       "occurrences": total_occ, "result_gather_ms": None if gather_ms is None else round(gather_ms, 1)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

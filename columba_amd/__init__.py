@@ -30,6 +30,7 @@ OCC_DTYPE = np.dtype([("begin", np.uint32), ("end", np.uint32), ("distance", np.
 
 EXPORTS = [
     "cmb_index_create", "cmb_index_destroy", "cmb_index_device_bytes", "cmb_index_kmer_table",
+    "cmb_index_layout_of", "cmb_index_seq_starts", "cmb_index_create_empty", "cmb_index_device_arrays",
     "cmb_strategy_create_named", "cmb_strategy_create_from_dir", "cmb_strategy_create",
     "cmb_strategy_add_scheme", "cmb_strategy_set_partition_params", "cmb_strategy_destroy",
     "cmb_strategy_describe", "cmb_strategy_export_scheme", "cmb_strategy_export_partition", "cmb_match_batch", "cmb_batch_create", "cmb_batch_run",
@@ -69,6 +70,27 @@ class _IndexDesc(C.Structure):
     ]
 
 
+DEV_ARRAYS = 7
+
+
+class IndexLayout(C.Structure):
+    """cmb_index_layout (include/columba_amd.h): everything but the array contents of a device index"""
+    _fields_ = [
+        ("text_length", C.c_uint64), ("counts", C.c_uint64 * 5), ("dollar_pos_fwd", C.c_uint64),
+        ("dollar_pos_rev", C.c_uint64), ("n_samples", C.c_uint64), ("sa_sparseness", C.c_uint32),
+        ("kmer_size", C.c_uint32), ("in_text_switch", C.c_uint32), ("n_seqs", C.c_uint32),
+        ("bytes", C.c_uint64 * DEV_ARRAYS),
+    ]
+
+
+class _DevArray:
+    """a raw device allocation seen through __cuda_array_interface__ (torch.as_tensor wraps it without a copy)"""
+
+    def __init__(self, ptr: int, nbytes: int, owner):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+        self._owner = owner
+
+
 _lib = None
 
 
@@ -91,6 +113,10 @@ def lib():
         L.cmb_index_device_bytes.restype = u64
         L.cmb_index_device_bytes.argtypes = [vp]
         L.cmb_index_kmer_table.argtypes = [vp, vp]
+        L.cmb_index_layout_of.argtypes = [vp, C.POINTER(IndexLayout)]
+        L.cmb_index_seq_starts.argtypes = [vp, vp]
+        L.cmb_index_create_empty.argtypes = [C.POINTER(IndexLayout), vp, i32, C.POINTER(vp)]
+        L.cmb_index_device_arrays.argtypes = [vp, C.POINTER(vp * DEV_ARRAYS), C.POINTER(u64 * DEV_ARRAYS)]
         L.cmb_strategy_create_named.argtypes = [C.c_char_p, i32, i32, C.POINTER(vp)]
         L.cmb_strategy_create_from_dir.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
         L.cmb_strategy_create.argtypes = [i32, i32, u32, C.POINTER(vp)]
@@ -132,7 +158,11 @@ class Index:
     ``Index(arrays, in_text_switch=4, sa_sparse=arrays.sparseness, kmer_size=10)``.
     """
 
-    def __init__(self, ix, in_text_switch: int = 4, kmer_size: int = 10, device: int = 0):
+    def __init__(self, ix, in_text_switch: int = 4, kmer_size: int = 10, device: int = 0, _handle=None):
+        self.device = device
+        if _handle is not None:  # (Index.empty_like)
+            self.h, self.kmer_size, self.n = _handle, kmer_size, ix
+            return
         d = _IndexDesc()
         d.text_length = ix.n
         d.text = _p(ix.text)
@@ -169,6 +199,38 @@ class Index:
 
     def device_bytes(self) -> int:
         return int(lib().cmb_index_device_bytes(self.h))
+
+    # ---- replication on other GPUs (columba_amd/dist.py: broadcast_device_index)
+    def layout(self) -> IndexLayout:
+        lay = IndexLayout()
+        _chk(lib().cmb_index_layout_of(self.h, C.byref(lay)))
+        return lay
+
+    def seq_starts(self) -> np.ndarray:
+        out = np.zeros(max(int(self.layout().n_seqs), 1), np.uint32)
+        _chk(lib().cmb_index_seq_starts(self.h, _p(out)))
+        return out[:int(self.layout().n_seqs)]
+
+    @classmethod
+    def empty_like(cls, layout: IndexLayout, seq_starts: np.ndarray, device: int = 0) -> "Index":
+        """an index with the arrays of `layout` allocated but not filled (the receiving side of a broadcast)"""
+        starts = np.ascontiguousarray(seq_starts, np.uint32)
+        h = C.c_void_p()
+        _chk(lib().cmb_index_create_empty(C.byref(layout), _p(starts), device, C.byref(h)))
+        return cls(int(layout.text_length), kmer_size=int(layout.kmer_size), device=device, _handle=h)
+
+    def device_tensors(self):
+        """the device arrays of the index as flat uint8 torch tensors sharing the library's memory (no copy)"""
+        import torch
+        ptrs, nbytes = (C.c_void_p * DEV_ARRAYS)(), (C.c_uint64 * DEV_ARRAYS)()
+        _chk(lib().cmb_index_device_arrays(self.h, C.byref(ptrs), C.byref(nbytes)))
+        out = []
+        for i in range(DEV_ARRAYS):
+            if not nbytes[i]:
+                out.append(None)
+                continue
+            out.append(torch.as_tensor(_DevArray(int(ptrs[i]), int(nbytes[i]), self), device=torch.device("cuda", self.device)))
+        return out
 
     def kmer_table(self) -> np.ndarray:
         out = np.zeros((4 ** self.kmer_size, 4), np.uint32)

@@ -79,6 +79,7 @@ template <typename T> struct PinnedBuf {
 // ------------------------------------------------------------------------------------ index
 struct cmb_index {
     int device = 0;
+    uint32_t saSparseness = 0;
     DevIndex d{};
     DevBuf<uint4> blkF, blkR; // 128-byte rank blocks
     DevBuf<uint64_t> saBlk;
@@ -109,6 +110,7 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         useDevice(device);
         std::unique_ptr<cmb_index> ix(new cmb_index());
         ix->device = device;
+        ix->saSparseness = desc->sa_sparseness;
         const uint64_t n = desc->text_length, N = n + 1;
         const uint64_t bvW = 4 * ((N + 63) / 64), cW = 8 * ((N + 511) / 512);
         const uint64_t nBlocks = N / RANK_BLOCK + 1; // rank(N) must be answerable
@@ -185,6 +187,108 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         return fail(CMB_ERR_DEVICE, e.what());
     }
 }
+// ---- replication: layout description, empty twin, raw device arrays (include/columba_amd.h)
+namespace {
+struct ArrayRef {
+    void** p;
+    size_t* n;
+    size_t elem;
+};
+// the seven device arrays of an index in the order of cmb_index_layout::bytes
+inline void indexArrays(cmb_index* ix, ArrayRef out[CMB_DEV_ARRAYS]) {
+    out[0] = {(void**)&ix->blkF.p, &ix->blkF.n, sizeof(uint4)};
+    out[1] = {(void**)&ix->blkR.p, &ix->blkR.n, sizeof(uint4)};
+    out[2] = {(void**)&ix->saBlk.p, &ix->saBlk.n, sizeof(uint64_t)};
+    out[3] = {(void**)&ix->saSamples.p, &ix->saSamples.n, sizeof(uint32_t)};
+    out[4] = {(void**)&ix->text.p, &ix->text.n, sizeof(uint8_t)};
+    out[5] = {(void**)&ix->text2.p, &ix->text2.n, sizeof(uint32_t)};
+    out[6] = {(void**)&ix->kmer.p, &ix->kmer.n, sizeof(uint4)};
+}
+inline void bindDevIndex(cmb_index* ix) { // DevIndex pointers from the owning buffers
+    DevIndex& d = ix->d;
+    d.fwd.blk = ix->blkF.p;
+    d.rev.blk = ix->blkR.p;
+    d.saBlk = ix->saBlk.p;
+    d.saSamples = ix->saSamples.p;
+    d.text = ix->text.p;
+    d.text2 = ix->text2.n ? ix->text2.p : nullptr;
+    d.kmer = ix->kmer.p;
+}
+} // namespace
+
+extern "C" int cmb_index_layout_of(const cmb_index* idx, cmb_index_layout* out) {
+    if (!idx || !out) return fail(CMB_ERR_INVALID, "null argument");
+    memset(out, 0, sizeof(*out));
+    out->text_length = idx->d.n;
+    for (int i = 0; i < 5; i++) out->counts[i] = idx->d.counts[i];
+    out->dollar_pos_fwd = idx->d.fwd.dollarPos;
+    out->dollar_pos_rev = idx->d.rev.dollarPos;
+    out->n_samples = idx->saSamples.n;
+    out->sa_sparseness = idx->saSparseness;
+    out->kmer_size = idx->d.kmerSize;
+    out->in_text_switch = idx->d.switchPoint;
+    out->n_seqs = (uint32_t)idx->seqStarts.size();
+    ArrayRef a[CMB_DEV_ARRAYS];
+    indexArrays(const_cast<cmb_index*>(idx), a);
+    for (int i = 0; i < CMB_DEV_ARRAYS; i++) out->bytes[i] = *a[i].p ? (uint64_t)(*a[i].n * a[i].elem) : 0;
+    return CMB_OK;
+}
+extern "C" int cmb_index_seq_starts(const cmb_index* idx, uint32_t* out) {
+    if (!idx || (!out && !idx->seqStarts.empty())) return fail(CMB_ERR_INVALID, "null argument");
+    if (!idx->seqStarts.empty()) memcpy(out, idx->seqStarts.data(), idx->seqStarts.size() * sizeof(uint32_t));
+    return CMB_OK;
+}
+extern "C" int cmb_index_create_empty(const cmb_index_layout* L, const uint32_t* seq_starts, int device, cmb_index** out) {
+    if (!L || !out) return fail(CMB_ERR_INVALID, "null argument");
+    if (L->text_length == 0 || L->text_length >= 0xFFFFFFFFull || L->kmer_size > 12)
+        return fail(CMB_ERR_INVALID, "index layout out of range");
+    try {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+            return fail(CMB_ERR_DEVICE, "no HIP device available (the product path has no CPU fallback)");
+        useDevice(device);
+        std::unique_ptr<cmb_index> ix(new cmb_index());
+        ix->device = device;
+        ix->saSparseness = L->sa_sparseness;
+        ArrayRef a[CMB_DEV_ARRAYS];
+        indexArrays(ix.get(), a);
+        uint64_t total = 0;
+        for (int i = 0; i < CMB_DEV_ARRAYS; i++) {
+            if (L->bytes[i] % a[i].elem) return fail(CMB_ERR_INVALID, "index layout: array size is not a whole number of elements");
+            if (L->bytes[i] == 0) continue; // absent (2-bit text)
+            HIPCHK(hipMalloc(a[i].p, L->bytes[i]));
+            *a[i].n = L->bytes[i] / a[i].elem;
+            total += L->bytes[i];
+        }
+        if (!ix->blkF.p || !ix->blkR.p || !ix->saBlk.p || !ix->text.p || !ix->kmer.p)
+            return fail(CMB_ERR_INVALID, "index layout: a required array is missing");
+        DevIndex& d = ix->d;
+        d.n = (uint32_t)L->text_length;
+        for (int i = 0; i < 5; i++) d.counts[i] = (uint32_t)L->counts[i];
+        d.fwd.dollarPos = (uint32_t)L->dollar_pos_fwd;
+        d.rev.dollarPos = (uint32_t)L->dollar_pos_rev;
+        d.kmerSize = L->kmer_size;
+        d.switchPoint = L->in_text_switch;
+        bindDevIndex(ix.get());
+        if (seq_starts && L->n_seqs) ix->seqStarts.assign(seq_starts, seq_starts + L->n_seqs);
+        ix->bytes = total;
+        *out = ix.release();
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}
+extern "C" int cmb_index_device_arrays(cmb_index* idx, void** ptrs, uint64_t* bytes) {
+    if (!idx || !ptrs || !bytes) return fail(CMB_ERR_INVALID, "null argument");
+    ArrayRef a[CMB_DEV_ARRAYS];
+    indexArrays(idx, a);
+    for (int i = 0; i < CMB_DEV_ARRAYS; i++) {
+        ptrs[i] = *a[i].p;
+        bytes[i] = *a[i].p ? (uint64_t)(*a[i].n * a[i].elem) : 0;
+    }
+    return CMB_OK;
+}
+
 extern "C" void cmb_index_destroy(cmb_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
@@ -707,6 +811,11 @@ static int batchRunOne(cmb_batch* b) {
                 return fail(CMB_ERR_UNSUPPORTED,
                             "a read is not longer than the number of parts of the search scheme (the reference "
                             "falls back to naive backtracking, which the device path does not provide)");
+            if (flags & FLAG_SEED_OVERLAP)
+                return fail(CMB_ERR_INVALID,
+                            "dynamic partitioning: the seeds of a read overlap — the k-mer size of the index is too large "
+                            "for the seeding positions of this search strategy at this read length (the reference caps "
+                            "the k-mer size, e.g. at 4 for kuch2 and 01*0: alignparameters.cpp:1070-1114, :1275-1278)");
             const uint32_t nDfs = hcnt[5];
             if (!(flags & (FLAG_ITEM_OVERFLOW | FLAG_DFS_OVERFLOW)) && nDfs) {
                 tm.begin();

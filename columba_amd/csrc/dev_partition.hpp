@@ -202,6 +202,12 @@ struct PartMachine {
                 setPBE(i, b, (b + wSize) & 0xFFFFu);
             }
             setPBE(numParts - 1, L - wSize, L);
+            for (int i = 0; i + 1 < numParts; i++)
+                if (PE(i) > PB(i + 1)) { // `assert(parts[i].end() <= parts[i + 1].begin())` (:404-407)
+                    flags |= FLAG_SEED_OVERLAP;
+                    phase = PH_DONE;
+                    return;
+                }
             j = (uint32_t)(numParts * wSize);
             if (useKmer) { // the k-mer table entries of all parts are fetched together in the memory step
                 phase = PH_SEED;

@@ -46,6 +46,85 @@ def broadcast_index(ix: Optional[ib.IndexArrays], rank: int, dev) -> ib.IndexArr
                           seq_starts=arrays["seq_starts"], seq_names=m["names"])
 
 
+def broadcast_device_index(index, rank: int, device: int = 0):
+    """Replicate the DEVICE layout of rank 0's index on every rank: the 128-byte rank blocks, sampled-row records,
+    samples, text codes, 2-bit text and k-mer table are broadcast straight into the arrays of an empty twin index
+    (one collective per array, 10.5 GB for a 3 Gbp reference; per-link bound on xGMI) — no host round trip and no
+    second re-layout.  `index` is a columba_amd.Index on rank 0 and ignored elsewhere."""
+    import ctypes as C
+    import torch.distributed as dist
+    from . import Index, IndexLayout
+    meta = [None]
+    if rank == 0:
+        meta = [(bytes(index.layout()), index.seq_starts())]
+    dist.broadcast_object_list(meta, src=0)
+    raw, starts = meta[0]
+    if rank != 0:
+        lay = IndexLayout.from_buffer_copy(raw)
+        index = Index.empty_like(lay, starts, device)
+    for t in index.device_tensors():
+        if t is not None:
+            dist.broadcast(t, src=0)
+    return index
+
+
+def allreduce_counters(cnt: dict, dev) -> dict:
+    """Counters of the whole job = sum over the ranks (the reference's writer thread merges the per-chunk Counters
+    the same way, src/fastq.cpp:643)."""
+    import torch.distributed as dist
+    names = sorted(cnt)
+    t = torch.tensor([int(cnt[n]) for n in names], dtype=torch.int64, device=dev)
+    dist.all_reduce(t)
+    return dict(zip(names, t.cpu().tolist()))
+
+
+def gather_occurrences(occ: np.ndarray, offs: np.ndarray, rank: int, world: int, dev):
+    """gatherv of the per-rank occurrence lists on rank 0: every rank announces its sizes
+    (all-gather), then sends its records and per-read counts point-to-point; rank 0 receives every shard into its
+    slice of one buffer.  Shards are contiguous slices of the global read batch in rank order (shard_bounds), so the
+    result is the occurrence list of the whole batch in read order with rebased offsets.
+    Returns (occurrences, offsets) on rank 0 and (None, None) elsewhere."""
+    import torch.distributed as dist
+    from . import OCC_DTYPE
+    n_occ, n_reads = int(occ.shape[0]), int(offs.shape[0]) - 1
+    sizes = torch.tensor([n_occ, n_reads], dtype=torch.int64, device=dev)
+    allsz = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(allsz, sizes)
+    allsz = [tuple(int(x) for x in t.cpu().tolist()) for t in allsz]
+    rec = OCC_DTYPE.itemsize
+    mine_occ = torch.from_numpy(np.ascontiguousarray(occ).view(np.uint8).reshape(-1).copy()).to(dev)
+    counts = np.diff(offs.astype(np.int64)).astype(np.int64)
+    mine_cnt = torch.from_numpy(counts).to(dev)
+    if rank != 0:
+        ops = []
+        if n_occ:
+            ops.append(dist.P2POp(dist.isend, mine_occ, 0))
+        if n_reads:
+            ops.append(dist.P2POp(dist.isend, mine_cnt, 0))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return None, None
+    tot_occ, tot_reads = sum(a for a, _ in allsz), sum(b for _, b in allsz)
+    all_occ = torch.empty(tot_occ * rec, dtype=torch.uint8, device=dev)
+    all_cnt = torch.empty(tot_reads, dtype=torch.int64, device=dev)
+    all_occ[:n_occ * rec] = mine_occ
+    all_cnt[:n_reads] = mine_cnt
+    ops, o, r = [], n_occ, n_reads
+    for src in range(1, world):
+        a, b = allsz[src]
+        if a:
+            ops.append(dist.P2POp(dist.irecv, all_occ[o * rec:(o + a) * rec], src))
+        if b:
+            ops.append(dist.P2POp(dist.irecv, all_cnt[r:r + b], src))
+        o += a
+        r += b
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    out_offs = np.zeros(tot_reads + 1, np.uint64)
+    out_offs[1:] = np.cumsum(all_cnt.cpu().numpy()).astype(np.uint64)
+    return all_occ.cpu().numpy().view(OCC_DTYPE), out_offs
+
+
 def scatter_reads(all_reads: Optional[torch.Tensor], per_rank_bytes: int, rank: int, world: int, dev) -> np.ndarray:
     """Rank 0 holds `world` equal shards ([world, per_rank_bytes] uint8); every rank gets its own."""
     import torch.distributed as dist

@@ -74,6 +74,25 @@ int cmb_index_create(const cmb_index_desc* desc, int device, cmb_index** out);
 void cmb_index_destroy(cmb_index* idx);
 /* bytes of HBM held by the index */
 uint64_t cmb_index_device_bytes(const cmb_index* idx);
+/* --- replication of a built index on other GPUs (the index is read-only and replicated, reads are
+ * sharded; the reference's worker threads share one index the same way, src/parallel.cpp:1143-1146).
+ * The DEVICE layout is what travels: rank 0 describes its arrays (cmb_index_layout_of), every other rank creates
+ * an index with empty arrays of the same sizes (cmb_index_create_empty), all ranks hand the raw device pointers
+ * (cmb_index_device_arrays) to the collective library — one broadcast per array straight into the index, no host
+ * round trip, no second re-layout. */
+#define CMB_DEV_ARRAYS 7 /* rank blocks fwd, rank blocks rev, sampled-row records, SA samples, text codes, 2-bit text, k-mer table */
+typedef struct {
+    uint64_t text_length;
+    uint64_t counts[5];
+    uint64_t dollar_pos_fwd, dollar_pos_rev;
+    uint64_t n_samples;
+    uint32_t sa_sparseness, kmer_size, in_text_switch, n_seqs;
+    uint64_t bytes[CMB_DEV_ARRAYS]; /* size of every device array (0: absent, e.g. no 2-bit text) */
+} cmb_index_layout;
+int cmb_index_layout_of(const cmb_index* idx, cmb_index_layout* out);
+int cmb_index_seq_starts(const cmb_index* idx, uint32_t* out /* [n_seqs] */);
+int cmb_index_create_empty(const cmb_index_layout* layout, const uint32_t* seq_starts, int device, cmb_index** out);
+int cmb_index_device_arrays(cmb_index* idx, void** ptrs /* [CMB_DEV_ARRAYS] */, uint64_t* bytes /* [CMB_DEV_ARRAYS] */);
 /* copy the device k-mer table (4^kmer_size x {sa.b,sa.e,rev.b,rev.e}) to host: test hook for
  * IndexInterface::populateTable (indexinterface.cpp:294-335) */
 int cmb_index_kmer_table(const cmb_index* idx, uint32_t* out /* 4 * 4^kmer_size */);

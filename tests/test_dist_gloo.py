@@ -18,7 +18,7 @@ def _worker(rank, world, port, tmp):
     import torch.distributed as dist
     import columba_amd as ca
     from columba_amd import indexbuild as ib, synth
-    from columba_amd.dist import broadcast_index, scatter_reads
+    from columba_amd.dist import allreduce_counters, broadcast_index, gather_occurrences, scatter_reads
     import oracle_py as op
     import schemes_py as sp
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -41,6 +41,18 @@ def _worker(rank, world, port, tmp):
     tot = torch.tensor([len(occ), int(occ["begin"].astype(np.int64).sum())], dtype=torch.int64)
     dist.all_reduce(tot)
     np.save(os.path.join(tmp, f"tot{rank}.npy"), tot.numpy())
+    # result path of the sharded job: gatherv of the occurrence lists on rank 0, all-reduce of the counters
+    occ2 = np.zeros(len(occ), ca.OCC_DTYPE)
+    for f in ("begin", "end", "distance", "strand"):
+        occ2[f] = occ[f]
+    g_occ, g_offs = gather_occurrences(occ2, offs, rank, world, "cpu")
+    g_cnt = allreduce_counters(cnt, "cpu")
+    if rank == 0:
+        np.save(os.path.join(tmp, "g_occ.npy"), g_occ)
+        np.save(os.path.join(tmp, "g_offs.npy"), g_offs)
+        np.save(os.path.join(tmp, "g_cnt.npy"), np.array([g_cnt["NODE_COUNTER"], g_cnt["EXPANSIONS"], g_cnt["TOTAL_REPORTED_POSITIONS"]]))
+    else:
+        assert g_occ is None and g_offs is None
     if rank == 0:
         np.save(os.path.join(tmp, "reads.npy"), allr.numpy())
         ib.save_index(ix, os.path.join(tmp, "idx"))
@@ -59,10 +71,16 @@ def test_two_rank_sharding_matches_single_process(tmp_path, oracle_built):
     ix = ib.load_index(str(tmp_path / "idx"))
     allr = np.load(tmp_path / "reads.npy").reshape(-1)
     reads = [allr[i * 100:(i + 1) * 100].tobytes() for i in range(300)]
-    occ, offs, _ = op.match_batch(op.OracleIndex(ix), op.OracleStrategy(sp.MULTIPLE_OPT), 2, reads)
+    occ, offs, cnt = op.match_batch(op.OracleIndex(ix), op.OracleStrategy(sp.MULTIPLE_OPT), 2, reads)
     t0, t1 = np.load(tmp_path / "tot0.npy"), np.load(tmp_path / "tot1.npy")
     assert np.array_equal(t0, t1)
     assert t0[0] == len(occ) and t0[1] == int(occ["begin"].astype(np.int64).sum()) and len(occ) > 0
+    # the gathered list IS the single-process list: same records in read order, same offsets, summed counters
+    g_occ, g_offs = np.load(tmp_path / "g_occ.npy"), np.load(tmp_path / "g_offs.npy")
+    assert np.array_equal(g_offs, offs)
+    for f in ("begin", "end", "distance", "strand"):
+        assert np.array_equal(g_occ[f], occ[f]), f
+    assert np.load(tmp_path / "g_cnt.npy").tolist() == [cnt["NODE_COUNTER"], cnt["EXPANSIONS"], cnt["TOTAL_REPORTED_POSITIONS"]]
 
 
 def test_shard_bounds_cover_everything():

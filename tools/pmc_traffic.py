@@ -6,11 +6,23 @@ FETCH_SIZE / WRITE_SIZE are collected in separate passes (they do not fit one pa
 `bench.py --steps 1 --warmup 0`, which runs the hot path TWICE (one timed step + the serial step its kernel table
 comes from): the sums over all dispatches of a kernel are divided by the number of steps run.  Units: KiB.
 bench.py (load_traffic) applies the gfx950 correction (FETCH_SIZE x 2) when it reports `roofline.traffic`."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, hashlib, json, os, sys
+
+
+def source_digest():  # the same digest bench.py computes: a profile only speaks for the kernels it was measured on
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    d = os.path.join(root, "columba_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        with open(os.path.join(d, fn), "rb") as f:
+            h.update(fn.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
 
 line = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 steps_run = float(sys.argv[4]) if len(sys.argv) > 4 else 2.0
 out = {"workload": {k: line["config"][k] for k in ("genome_bp", "reads_per_gpu", "read_len", "k")},
+       "kernel_src_sha": source_digest(),
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one pass each, bench.py --steps 1 --warmup 0 "
                  "(sub-batches one after the other); per step",
        "kernels": collections.defaultdict(dict)}
