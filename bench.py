@@ -137,13 +137,21 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # CMB_BENCH_SHARE_GPU=1 + CMB_DIST_BACKEND=gloo: all ranks on cuda:0 — a rehearsal of the N > 1 code path on a
+    # one-GPU box (RCCL refuses two ranks on one device); numbers from such a run mean nothing
+    if os.environ.get("CMB_BENCH_SHARE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("CMB_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     ca.lib()  # fail loudly if the HIP extension is missing
     n = int(args.genome_mbp * 1e6)
@@ -202,7 +210,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - tstart
     if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     # kernel table: one extra step with the sub-batches of the batch run one after the other, so that every kernel
@@ -219,7 +227,7 @@ def main():
     total_occ = len(occ)
     gather_ms = None
     if dist is not None:
-        tt = torch.tensor([total_occ], dtype=torch.int64, device=dev)
+        tt = torch.tensor([total_occ], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(tt)
         total_occ = int(tt.item())
         if not args.no_gather:

@@ -68,11 +68,19 @@ def broadcast_device_index(index, rank: int, device: int = 0):
     return index
 
 
+def _wire(dev):
+    """the device collectives / point-to-point transfers run on: the GPU with RCCL ("nccl"); host memory with gloo,
+    which serves scatter and send/recv for CPU tensors only (CPU tests, single-GPU rehearsals of the N > 1 path)"""
+    import torch.distributed as dist
+    return "cpu" if dist.get_backend() == "gloo" else dev
+
+
 def allreduce_counters(cnt: dict, dev) -> dict:
     """Counters of the whole job = sum over the ranks (the reference's writer thread merges the per-chunk Counters
     the same way, src/fastq.cpp:643)."""
     import torch.distributed as dist
     names = sorted(cnt)
+    dev = _wire(dev)
     t = torch.tensor([int(cnt[n]) for n in names], dtype=torch.int64, device=dev)
     dist.all_reduce(t)
     return dict(zip(names, t.cpu().tolist()))
@@ -86,6 +94,7 @@ def gather_occurrences(occ: np.ndarray, offs: np.ndarray, rank: int, world: int,
     Returns (occurrences, offsets) on rank 0 and (None, None) elsewhere."""
     import torch.distributed as dist
     from . import OCC_DTYPE
+    dev = _wire(dev)
     n_occ, n_reads = int(occ.shape[0]), int(offs.shape[0]) - 1
     sizes = torch.tensor([n_occ, n_reads], dtype=torch.int64, device=dev)
     allsz = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
@@ -128,9 +137,10 @@ def gather_occurrences(occ: np.ndarray, offs: np.ndarray, rank: int, world: int,
 def scatter_reads(all_reads: Optional[torch.Tensor], per_rank_bytes: int, rank: int, world: int, dev) -> np.ndarray:
     """Rank 0 holds `world` equal shards ([world, per_rank_bytes] uint8); every rank gets its own."""
     import torch.distributed as dist
+    dev = _wire(dev)
     shard = torch.empty(per_rank_bytes, dtype=torch.uint8, device=dev)
     if rank == 0:
-        dist.scatter(shard, [all_reads[i].contiguous() for i in range(world)], src=0)
+        dist.scatter(shard, [all_reads[i].contiguous().to(dev) for i in range(world)], src=0)
     else:
         dist.scatter(shard, None, src=0)
     return shard.cpu().numpy()

@@ -61,6 +61,13 @@ enum CounterType {
     LOCATED_ROWS, // findSA calls
     TEXT_BYTES,   // text characters read by in-text verification
     MATRIX_ROWS,  // computeRow calls
+    // Occurrences::eraseDoublesFM (indexhelpers.h:2135-2146) sorts with operator< (begin, distance, width, shift) and
+    // removes ADJACENT elements equal under operator== (which also looks at depth and strand): equal elements that
+    // the (unstable) sort leaves apart survive and are located again.  Whether that happens depends on the sort
+    // implementation, not on the input alone; these two counters say how much of LOCATED_ROWS / TOTAL_REPORTED /
+    // LF_STEPS is such repeated work (the device removes every duplicate).
+    SURVIVING_DUP_ROWS,
+    SURVIVING_DUP_LF,
     COUNTER_TYPE_MAX
 };
 struct Counters {

@@ -21,6 +21,7 @@ COUNTER_NAMES = [
     "NODE_COUNTER", "TOTAL_REPORTED_POSITIONS", "IN_TEXT_STARTED", "ABORTED_IN_TEXT_VERIF",
     "CIGARS_IN_TEXT_VERIFICATION", "IMMEDIATE_SWITCH", "SEARCH_STARTED",
     "EXPANSIONS", "LF_STEPS", "LOCATED_ROWS", "TEXT_BYTES", "MATRIX_ROWS",
+    "SURVIVING_DUP_ROWS", "SURVIVING_DUP_LF",
 ]
 
 

@@ -1022,30 +1022,46 @@ class Matcher {
         counters.inc(TOTAL_REPORTED_POSITIONS, occ.inTextOcc.size());
         occ.eraseDoublesFM();
         len_t size = occ.inFMOcc.empty() ? 0 : occ.inFMOcc[0].getDepth();
-        for (const auto& f : occ.inFMOcc) {
+        for (size_t fi = 0; fi < occ.inFMOcc.size(); fi++) {
+            const auto& f = occ.inFMOcc[fi];
             const Range& saRange = f.getRanges().sa;
             counters.inc(TOTAL_REPORTED_POSITIONS, saRange.width());
+            const uint64_t lf0 = counters.c[LF_STEPS];
             for (len_t i = saRange.b; i < saRange.e; i++) {
                 len_t p = index.findSA(i, counters);
                 occ.inTextOcc.emplace_back(Range(p, p + size), f.distance, f.strand);
             }
+            noteSurvivingDuplicate(occ, fi, lf0);
         }
         occ.eraseDoublesAndSortText();
         return std::move(occ.inTextOcc);
     }
 
+    // (not in the reference: accounting of the repeated work described at SURVIVING_DUP_ROWS, oracle_core.hpp)
+    void noteSurvivingDuplicate(const Occurrences& occ, size_t fi, uint64_t lfBefore) {
+        for (size_t j = 0; j < fi; j++)
+            if (occ.inFMOcc[j] == occ.inFMOcc[fi]) {
+                counters.inc(SURVIVING_DUP_ROWS, occ.inFMOcc[fi].getRanges().sa.width());
+                counters.inc(SURVIVING_DUP_LF, counters.c[LF_STEPS] - lfBefore);
+                return;
+            }
+    }
+
     std::vector<TextOcc> getUniqueTextOccurrences(Occurrences& occ, len_t maxED) {
         counters.inc(TOTAL_REPORTED_POSITIONS, occ.inTextOcc.size());
         occ.eraseDoublesFM();
-        for (const auto& f : occ.inFMOcc) {
+        for (size_t fi = 0; fi < occ.inFMOcc.size(); fi++) {
+            const auto& f = occ.inFMOcc[fi];
             const Range& saRange = f.getRanges().sa;
             counters.inc(TOTAL_REPORTED_POSITIONS, saRange.width());
             len_t depth = f.getDepth(), distance = f.distance, shift = f.shift;
+            const uint64_t lf0 = counters.c[LF_STEPS];
             for (len_t i = saRange.b; i < saRange.e; i++) {
                 len_t p = index.findSA(i, counters);
                 len_t startPos = p + shift;
                 occ.inTextOcc.emplace_back(Range(startPos, startPos + depth), distance, f.strand);
             }
+            noteSurvivingDuplicate(occ, fi, lf0);
         }
         occ.eraseDoublesAndSortText();
         std::vector<TextOcc> nonRedundantOcc;

@@ -63,8 +63,14 @@ def _compare(world, spec_name, metric, partition, k, reads, counters=True):
             names += ["ABORTED_IN_TEXT_VERIF", "TOTAL_REPORTED_POSITIONS"]
         if k > 0 and metric == "edit":
             names.append("CIGARS_IN_TEXT_VERIFICATION")
+        # in-index occurrences that the reference's sort + adjacent-unique leaves in twice are located twice there
+        # (Occurrences::eraseDoublesFM, indexhelpers.h:2135-2146: operator< ignores depth and strand, operator== does
+        # not, std::sort is unstable); the device removes every duplicate.  The oracle counts that repeated work.
+        surplus = {"LF_STEPS": o_cnt["SURVIVING_DUP_LF"], "LOCATED_ROWS": o_cnt["SURVIVING_DUP_ROWS"],
+                   "TOTAL_REPORTED_POSITIONS": o_cnt["SURVIVING_DUP_ROWS"]}
         for n in names:
-            assert o_cnt[n] == d_cnt[n], (n, o_cnt[n], d_cnt[n])
+            assert o_cnt[n] - surplus.get(n, 0) == d_cnt[n], (n, o_cnt[n], surplus.get(n, 0), d_cnt[n])
+        assert o_cnt["SURVIVING_DUP_ROWS"] * 200 <= max(o_cnt["LOCATED_ROWS"], 1)  # (rare: well below 1 %)
     return o_cnt
 
 
