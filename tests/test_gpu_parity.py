@@ -206,8 +206,10 @@ def test_custom_directory_with_dynamic_selection(world):
         assert np.array_equal(o_off, d_off)
         for f in ("begin", "end", "distance"):
             assert np.array_equal(o_occ[f], d_occ[f]), (dirname, f)
-        for n in ("NODE_COUNTER", "IN_TEXT_STARTED", "SEARCH_STARTED", "EXPANSIONS", "MATRIX_ROWS", "TOTAL_REPORTED_POSITIONS"):
+        for n in ("NODE_COUNTER", "IN_TEXT_STARTED", "SEARCH_STARTED", "EXPANSIONS", "MATRIX_ROWS"):
             assert o_cnt[n] == d_cnt[n], (dirname, n)
+        # (net of the duplicates the reference's unstable sort lets through, see _compare)
+        assert o_cnt["TOTAL_REPORTED_POSITIONS"] - o_cnt["SURVIVING_DUP_ROWS"] == d_cnt["TOTAL_REPORTED_POSITIONS"], dirname
 
 
 def test_ragged_and_odd_reads(world):
