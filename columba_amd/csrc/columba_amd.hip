@@ -91,6 +91,16 @@ struct cmb_index {
     uint64_t bytes = 0;
 };
 
+#ifdef CMB_BFS_STATS
+extern "C" int cmb_debug_bfs_stats(unsigned long long* out, int reset) { // diagnostic build only
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(cmb::g_bfsStats), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(cmb::g_bfsStats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 extern "C" const char* cmb_last_error(void) { return g_err.c_str(); }
 extern "C" const char* cmb_version(void) { return "columba_amd 0.1 (gfx950)"; }
 
@@ -859,6 +869,9 @@ static int batchRunOne(cmb_batch* b) {
                     B.fCap = (uint32_t)std::min<size_t>(b->bfsF.n / F_U4, 0xFFFFFFF0u);
                     B.cCap = (uint32_t)std::min<size_t>(b->bfsC.n / CTX_U4, 0xFFFFFFF0u);
                     B.aCap = (uint32_t)std::min<size_t>(b->bfsA.n, 0xFFFFFFF0u);
+                    B.chain = getenv("CMB_BFS_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("CMB_BFS_CHAIN"))) : BFS_CHAIN;
+                    B.gridX = getenv("CMB_BFS_GRID") ? (uint32_t)std::min<int>(BFS_GRID, std::max(1, atoi(getenv("CMB_BFS_GRID")))) : BFS_GRID_X;
+                    B.gridEv = getenv("CMB_BFS_GRID_EV") ? (uint32_t)std::max(1, atoi(getenv("CMB_BFS_GRID_EV"))) : BFS_GRID_EV;
                     B.nq = b->bfsCnt.p;
                     B.ne = b->bfsCnt.p + (maxPass + 2);
                     B.pool = b->bfsCnt.p + 2 * (maxPass + 2);
@@ -872,7 +885,7 @@ static int batchRunOne(cmb_batch* b) {
                     while (!drained && pass < maxPass) {
                         const uint32_t upTo = std::min(pass + CHECK, maxPass);
                         for (; pass < upTo; pass++) {
-                            hipLaunchKernelGGL(k_bfs_pass, dim3(BFS_GRID + BFS_GRID_EV), dim3(256), 0, s, ix->d, b->strat.p, B,
+                            hipLaunchKernelGGL(k_bfs_pass, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->strat.p, B,
                                                pass, b->offs.p, b->gw, b->G.p, b->parts.p, q);
                         }
                         HIPCHK(hipMemcpyAsync(hc.data(), b->bfsCnt.p, cntWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));

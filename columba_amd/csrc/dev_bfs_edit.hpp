@@ -43,8 +43,10 @@ constexpr uint32_t CTX_MBLK = 7;  // row blocks with cached match words (rows < 
 constexpr uint32_t F_U4 = 2;      // uint4 per F record: {ranges} {depth | c << 16, parent, reported, -}
 // (all blocks of a pass should be resident together — 3 blocks of 256 threads per CU at ~160 VGPRs — or the event
 // blocks, which come last in the grid, only start when expansion blocks have finished)
-constexpr uint32_t BFS_GRID = 576;    // blocks that expand the frontier (grid-stride)
-constexpr uint32_t BFS_GRID_EV = 192; // blocks that handle the events of the same pass
+constexpr uint32_t BFS_CHAIN = 4;     // expansions a lane makes in a row while each yields exactly one plain node
+constexpr uint32_t BFS_GRID = 1024;   // MOST blocks that expand the frontier (grid-stride); sizes the per-block counters
+constexpr uint32_t BFS_GRID_X = 896;  // default: expanding blocks (k_bfs_pass runs four 256-thread blocks per CU) ...
+constexpr uint32_t BFS_GRID_EV = 128; // ... and blocks that handle the events of the same pass
 
 // (the FLAG_BFS_* bits live in dev_search.hpp with all other bits of the flag word)
 // any of these set by an earlier pass: the frontier is incomplete, later passes do nothing (the host re-runs)
@@ -62,7 +64,7 @@ __device__ __forceinline__ bool blockStopped(const Queues& q) {
 }
 
 struct BfsBufs {
-    uint4* Q[2];  // frontier nodes, 4 planes of qCap: {ranges} {row | score << 16, ctx, fc, RAC bit} {HP, HN}
+    uint4* Q[2];  // frontier nodes, 4 planes of qCap: {ranges} {row | score << 16, ctx, fc, RAC bit | mode << 8} {HP, HN}
                   // {final-column distances of the path: only touched for nodes in the final column}
     uint4* Ev[2]; // events, 2 x 16 B: {ctx, F index of the node that ended its path, remaining-descendants index | -1,
                   // cell} {final-column distances of the path}
@@ -70,11 +72,20 @@ struct BfsBufs {
     uint4* C;     // contexts, CTX_U4 x 16 B
     uint4* A;     // list arena: descendants (2 x 16 B each: ranges, {depth | c << 16}) and initial distances (u16)
     uint32_t qCap, evCap, fCap, cCap, aCap;
+    uint32_t chain;  // expansions a lane makes in a row while each yields exactly one plain node (BFS_CHAIN)
+    uint32_t gridX, gridEv; // blocks of k_bfs_pass that expand / that handle events
     uint32_t* nq;    // [pass] number of frontier nodes consumed by pass `pass`
     uint32_t* ne;    // [pass] number of events consumed by pass `pass`
     uint32_t* pool;  // [0] F records, [1] contexts, [2] arena units handed out
     unsigned long long* blockCnt; // [BFS_GRID][4] per-block counters: nodes, expansions, rows, -
 };
+
+#ifdef CMB_BFS_STATS
+// diagnostic build only (tools/bfs_stats.sh): what an expansion produces — [0] nothing, [1] exactly one node outside the
+// final column and nothing else, [2] exactly one node in the final column and nothing else, [3] anything else,
+// [4] of [1]: the child's row stays in the parent's 32-row matrix block, [5] expansions whose two ends share a rank block
+__device__ unsigned long long g_bfsStats[8];
+#endif
 
 struct EdPack { // final-column edit distances of one path, cell i at bits [5i, 5i+5)
     uint64_t lo, hi;
@@ -141,6 +152,26 @@ __device__ __forceinline__ void blockAppend4(uint32_t* c0, uint32_t* c1, uint32_
     __syncthreads(); // sh may be reused by the next call
 }
 
+// the two rank blocks an extension of `p` in `mode` needs: request (raw 16-byte chunks) and use
+__device__ __forceinline__ void issueRanks(const DevIndex& ix, int mode, const RangePair& p, uint4 v[8]) {
+    DevBWT t = ix.fwd; // values, not references, are selected
+    Range tr = p.sa;
+    if (mode == 0) {
+        t = ix.rev;
+        tr = p.rev;
+    }
+    loadRankPairRaw(t, tr.b, tr.e, v);
+}
+__device__ __forceinline__ void takeRanks(const DevIndex& ix, int mode, const RangePair& p, const uint4 v[8], uint32_t Rb[4],
+                                          uint32_t Re[4], uint32_t& db, uint32_t& de) {
+    const uint32_t dollar = mode == 0 ? ix.rev.dollarPos : ix.fwd.dollarPos;
+    const uint32_t b = mode == 0 ? p.rev.b : p.sa.b, e = mode == 0 ? p.rev.e : p.sa.e;
+    ranksFromRaw(v, b, Rb);
+    ranksFromRaw(v + 4, e, Re);
+    db = b > dollar ? 1u : 0u;
+    de = e > dollar ? 1u : 0u;
+}
+
 // ------------------------------------------------------------------ expand
 // One lane per frontier node.  Children (extendFMPos, indexinterface.cpp:675-697) get their matrix row at
 // once (computeRow; the reference computes it when the child is popped — every pushed child is popped) and
@@ -149,114 +180,222 @@ __device__ __forceinline__ void blockAppend4(uint32_t* c0, uint32_t* c1, uint32_
 //   final column, row invalid or only vertical gaps left -> event (goDeeper)
 //   narrow range (in-text switch, :516)        -> in-text verification items
 //   otherwise                                  -> node of the next frontier
+//
+// The kernel waits for scattered memory, so what it can keep in flight is set by its registers (measured: 2 / 3
+// wavefronts per SIMD = 99 / 71 ms per step).  Hence a lane never HOLDS the four children: it classifies them
+// (evalChild<false>: 4 bits per child), the block allocates the queue slots, and the children that leave are
+// computed again (evalChild<true>, ~50 VALU instructions each) straight into their records.
+enum : uint32_t { KIND_NONE = 0, KIND_NODE = 1, KIND_EVENT = 2, KIND_ITEMS = 3 };
+struct ExpandCtx { // what the expansions of one phase share (from the context's hot word)
+    MatGeom g;
+    uint32_t clSize, itMode, itStart, switchPoint;
+};
+struct ChildState {
+    RangePair r;
+    uint64_t HP, HN, RAC;
+    uint32_t sc, aux; // aux: final-column distance of the child (needF) or in-text start difference (KIND_ITEMS)
+};
+// kind of child `ch` of `parent` at row `row1` | needF << 2 | capacity problem << 3; FULL: also its state
+template <bool FULL>
+__device__ __forceinline__ uint32_t evalChild(const DevIndex& ix, int md, const RangePair& parent, uint32_t ch,
+                                              const uint32_t Rb[4], const uint32_t Re[4], uint32_t db, uint32_t de,
+                                              const ExpandCtx& e, uint32_t row1, bool inFC, uint64_t M, uint64_t pHP,
+                                              uint64_t pHN, uint64_t pRAC, uint32_t score, bool& nonEmpty, ChildState& out) {
+    RangePair child;
+    nonEmpty = childFromRanks(ix, md, parent, ch, Rb, Re, db, de, child);
+    if (!nonEmpty) return KIND_NONE;
+    uint64_t HP = pHP, HN = pHN, RAC = pRAC, D0;
+    uint32_t sc = score;
+    const bool valid = computeRow(e.g, row1, M, HP, HN, D0, RAC, sc);
+    if (!valid && !inFC) return KIND_NONE; // pruned when popped (branchAndBound returns true, :560)
+    uint32_t res = KIND_NODE, aux = 0;
+    if (inFC) {
+        const uint32_t ed = cellAt(row1, e.g.n - 1, HP, HN, sc);
+        aux = min(ed, 31u);
+        res |= 4u;
+        if (ed > 31u) res |= 8u;
+        if (!valid || onlyVerticalGapsLeft(e.g, row1, HN)) res = (res & ~3u) | KIND_EVENT;
+    }
+    if ((res & 3u) == KIND_NODE && child.sa.width() <= e.switchPoint && e.itMode != 0) { // goToInTextVerificationEdit (:340-375)
+        uint32_t startDiff = e.itStart;
+        if (e.itMode == 2) {
+            const uint32_t col = e.g.firstColumn(row1);
+            startDiff -= col + cellAt(row1, col, HP, HN, sc);
+        }
+        aux = startDiff;
+        res = (res & 8u) | KIND_ITEMS; // (a child that leaves the index needs no F record)
+    }
+    if (FULL) {
+        out.r = child;
+        out.HP = HP;
+        out.HN = HN;
+        out.RAC = RAC;
+        out.sc = sc;
+        out.aux = aux;
+    }
+    return res;
+}
+
 __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, uint32_t pass, const Queues& q,
                                           uint32_t bid, uint32_t nBlocks) {
     __shared__ uint32_t sh[4][5];
+    // per-lane state that is touched once or twice per expansion lives in LDS, [field][lane], not in registers: the
+    // four match words of the row block, the eight ranks of the pending expansion, the node's final-column pack
+    __shared__ uint64_t ldsM[4][256];
+    __shared__ uint32_t ldsR[8][256];
+    __shared__ uint32_t ldsCnt[2][256]; // per-lane counters: children (= matrix rows), expansions
+    const uint32_t tid = threadIdx.x;
+    ldsCnt[0][tid] = 0;
+    ldsCnt[1][tid] = 0;
     const uint32_t nIn = min(B.nq[pass], B.qCap);
     const uint4* __restrict__ Qi = B.Q[pass & 1u];
     uint4* __restrict__ Qo = B.Q[(pass + 1u) & 1u];
     uint4* __restrict__ Eo = B.Ev[(pass + 1u) & 1u];
     const uint32_t qCap = B.qCap;
-    uint32_t cNode = 0, cExp = 0, cRows = 0, flags = 0;
+    uint32_t flags = 0;
     for (uint32_t base = bid * 256u; base < nIn; base += nBlocks * 256u) { // block-uniform trip count
         const uint32_t i = base + threadIdx.x;
         const bool act = i < nIn;
-        // per child: 0 nothing, 1 node, 2 event, 3 in-text items
-        uint32_t kinds = 0; // 4 bits per child
-        uint4 cr[4];                       // child ranges
-        uint32_t cw[4];                    // child: score
-        uint64_t cHP[4], cHN[4], cRAC[4];  // child row state
-        uint32_t cEd[4];                   // child: final-column edit distance (needF) / in-text start difference
-        uint32_t needF = 0;                // bit ch: the child is in the final column and gets an F record
-        uint32_t row1 = 0, ctx = 0, fcP = BFS_NONE, rsId = 0, itMeta = 0, cell = 0;
-        EdPack pack{0, 0};
+        uint32_t kinds = 0; // 4 bits per child: kind | needF << 2
+        uint32_t row1 = 0, ctx = 0, fcP = BFS_NONE, nIt = 0;
+        // ---- the node and what the expansions of its phase need of its context: one memory step
+        RangePair parent{{0, 0}, {0, 0}};
+        uint32_t row = 0, score = 0, blk = 0;
+        int md = 0;
+        uint64_t pHP = 0, pHN = 0;
+        uint32_t pRac = 0; // (RAC is always a single bit: kept as its index)
+        ExpandCtx e{};
+        e.switchPoint = ix.switchPoint;
+        uint32_t db = 0, de = 0;
+        bool walking = act;
         if (act) {
             const uint4 n0 = Qi[i], n1 = Qi[(size_t)qCap + i], n2 = Qi[(size_t)2 * qCap + i];
             ctx = n1.y;
             fcP = n1.z;
-            const uint32_t row = n1.x & 0xFFFFu, score = n1.x >> 16;
-            row1 = row + 1;
+            row = n1.x & 0xFFFFu;
+            score = n1.x >> 16;
+            // the node carries the extension mode of its phase, so that the rank blocks of its first expansion are
+            // requested together with the context words (one round trip less than fetching the mode from the context)
+            md = (int)((n1.w >> 8) & 3u);
+            parent = RangePair{{n0.x, n0.y}, {n0.z, n0.w}};
+            uint4 rk[8];
+            issueRanks(ix, md, parent, rk);
             const uint4* Cx = B.C + (size_t)ctx * CTX_U4;
-            const uint32_t blk = row1 / MX_BLOCK;
-            // ---- the single memory step: context (hot part), match words, F pack, rank blocks
+            blk = (row + 1) / MX_BLOCK;
             const uint4 hot = Cx[CTX_HOT]; // everything the expansion needs of its context, in ONE 16-byte request
             const uint4 mA = Cx[CTX_M + 2 * blk], mB = Cx[CTX_M + 1 + 2 * blk];
-            uint4 fp = make_uint4(0, 0, 0, 0);
-            if (fcP != BFS_NONE) fp = Qi[(size_t)3 * qCap + i]; // final-column distances of the path so far
-            const uint32_t dir = (hot.x >> 27) & 1u, uni = (hot.x >> 28) & 1u;
-            const int md = uni ? 2 : (dir == 0 ? 0 : 1);
-            const RangePair parent{{n0.x, n0.y}, {n0.z, n0.w}};
-            uint32_t Rb[4], Re[4], db, de;
-            loadExtendRanks(ix, md, parent, Rb, Re, db, de);
-            cExp++;
-            rsId = hot.x & 0x1FFFFFFu;
-            itMeta = hot.w & 0x7FFFFFu;
-            MatGeom g;
-            g.n = hot.y & 0x1FFu;
-            g.m = (hot.y >> 9) & 0x1FFu;
-            g.Wv = (hot.y >> 18) & 31u;
-            g.Wh = (hot.y >> 23) & 15u;
-            g.maxED = (hot.y >> 27) & 15u;
-            const uint32_t clSize = hot.w >> 23;
-            const uint32_t itMode = (hot.x >> 25) & 3u; // 0: phase 0 (no switch), 1: start difference fixed, 2: BACKWARD
-            pack = EdPack{u64of(fp.x, fp.y), u64of(fp.z, fp.w)};
-            const uint64_t pHP = u64of(n2.x, n2.y), pHN = u64of(n2.z, n2.w), pRAC = 1ull << (n1.w & 63u); // (RAC is always a single bit)
-            const bool inFC = g.inFinalColumn(row1);
-            cell = clSize + row1 - g.m;
-            if (inFC && cell >= ED_CELLS) { // (a row beyond the matrix: cannot happen for a well-formed phase)
-                flags |= FLAG_CAPACITY;
-                cell = ED_CELLS - 1;
-            }
-            const uint64_t Mw[4] = {u64of(mA.x, mA.y), u64of(mA.z, mA.w), u64of(mB.x, mB.y), u64of(mB.z, mB.w)};
+            {
+                uint32_t Rb[4], Re[4];
+                takeRanks(ix, md, parent, rk, Rb, Re, db, de);
 #pragma unroll
-            for (uint32_t ch = 1; ch <= 4; ch++) {
-                RangePair child;
-                if (!childFromRanks(ix, md, parent, ch, Rb, Re, db, de, child)) continue;
-                cNode++;
-                cRows++;
-                uint64_t HP = pHP, HN = pHN, RAC = pRAC, D0;
-                uint32_t sc = score;
-                const bool valid = computeRow(g, row1, Mw[ch - 1], HP, HN, D0, RAC, sc);
-                if (!valid && !inFC) continue; // pruned when popped (branchAndBound returns true, :560)
-                cr[ch - 1] = make_uint4(child.sa.b, child.sa.e, child.rev.b, child.rev.e);
-                cw[ch - 1] = sc;
-                cHP[ch - 1] = HP;
-                cHN[ch - 1] = HN;
-                cRAC[ch - 1] = RAC;
-                if (inFC) {
-                    const uint32_t ed = cellAt(row1, g.n - 1, HP, HN, sc);
-                    cEd[ch - 1] = min(ed, 31u);
-                    if (ed > 31u) flags |= FLAG_CAPACITY;
-                    if (!valid || onlyVerticalGapsLeft(g, row1, HN)) {
-                        kinds |= 2u << (4 * (ch - 1));
-                        needF |= 1u << (ch - 1);
-                        continue;
-                    }
+                for (int c = 0; c < 4; c++) {
+                    ldsR[c][tid] = Rb[c];
+                    ldsR[4 + c][tid] = Re[c];
                 }
-                if (child.sa.width() <= ix.switchPoint && itMode != 0) { // goToInTextVerificationEdit (:340-375)
-                    uint32_t startDiff = hot.z;
-                    if (itMode == 2) {
-                        const uint32_t col = g.firstColumn(row1);
-                        startDiff -= col + cellAt(row1, col, HP, HN, sc);
-                    }
-                    cEd[ch - 1] = startDiff; // (a child that leaves the index needs no F record)
-                    kinds |= 3u << (4 * (ch - 1));
-                    continue;
-                }
-                kinds |= 1u << (4 * (ch - 1));
-                if (inFC) needF |= 1u << (ch - 1);
             }
+            e.itStart = hot.z;
+            e.g.n = hot.y & 0x1FFu;
+            e.g.m = (hot.y >> 9) & 0x1FFu;
+            e.g.Wv = (hot.y >> 18) & 31u;
+            e.g.Wh = (hot.y >> 23) & 15u;
+            e.g.maxED = (hot.y >> 27) & 15u;
+            e.clSize = hot.w >> 23;
+            e.itMode = (hot.x >> 25) & 3u; // 0: phase 0 (no switch), 1: start difference fixed, 2: BACKWARD
+            pHP = u64of(n2.x, n2.y);
+            pHN = u64of(n2.z, n2.w);
+            pRac = n1.w & 63u;
+            ldsM[0][tid] = u64of(mA.x, mA.y);
+            ldsM[1][tid] = u64of(mA.z, mA.w);
+            ldsM[2][tid] = u64of(mB.x, mB.y);
+            ldsM[3][tid] = u64of(mB.z, mB.w);
+        }
+        // ---- walk: three expansions in four produce exactly one plain node and nothing else (measured, DESIGN.md
+        // §4.2).  Such a child is expanded at once by the same lane — no node record written and read back, no queue
+        // slot, no context fetch — for up to B.chain rows inside one 32-row matrix block; the lane stops at the
+        // first expansion that produces anything else and keeps its PARENT state: the children are computed again
+        // after the queue slots have been handed out.
+        for (uint32_t step = 0; step < B.chain; step++) { // (wave-uniform exit below)
+            if (walking) {
+                if (step) {
+                    uint4 rk[8];
+                    issueRanks(ix, md, parent, rk); // the memory step of an expansion: two rank blocks
+                    uint32_t Rb[4], Re[4];
+                    takeRanks(ix, md, parent, rk, Rb, Re, db, de);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        ldsR[c][tid] = Rb[c];
+                        ldsR[4 + c][tid] = Re[c];
+                    }
+                }
+                uint32_t Rb[4], Re[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    Rb[c] = ldsR[c][tid];
+                    Re[c] = ldsR[4 + c][tid];
+                }
+                row1 = row + 1;
+                ldsCnt[1][tid] += 1u;
+                const bool inFC = e.g.inFinalColumn(row1);
+                if (inFC && e.clSize + row1 - e.g.m >= ED_CELLS) flags |= FLAG_CAPACITY; // (a row beyond the matrix)
+                kinds = 0;
+                nIt = 0;
+                uint32_t nOut = 0, nChildren = 0;
+#pragma unroll
+                for (uint32_t ch = 1; ch <= 4; ch++) {
+                    bool nonEmpty;
+                    ChildState cs;
+                    const uint32_t k4 = evalChild<false>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, ldsM[ch - 1][tid], pHP,
+                                                         pHN, 1ull << pRac, score, nonEmpty, cs);
+                    nChildren += nonEmpty ? 1u : 0u;
+                    if (k4 & 8u) flags |= FLAG_CAPACITY;
+                    if ((k4 & 3u) == KIND_NONE) continue;
+                    kinds |= (k4 & 7u) << (4 * (ch - 1));
+                    nOut++;
+                    if ((k4 & 3u) == KIND_ITEMS) { // (its width: the child's range again, a few instructions)
+                        RangePair child;
+                        (void)childFromRanks(ix, md, parent, ch, Rb, Re, db, de, child);
+                        nIt += child.sa.e - child.sa.b;
+                    }
+                }
+                ldsCnt[0][tid] += nChildren;
+                // exactly one child, a plain node, with rows left in this matrix block: keep walking
+                const bool single = nOut == 1u && (kinds == 0x1u || kinds == 0x10u || kinds == 0x100u || kinds == 0x1000u);
+                if (single && step + 1u < B.chain && (row1 + 1u) / MX_BLOCK == blk) {
+                    const uint32_t ch = ((31u - (uint32_t)__clz(kinds)) >> 2) + 1u;
+                    const uint64_t M = ch == 1 ? ldsM[0][tid] : ch == 2 ? ldsM[1][tid] : ch == 3 ? ldsM[2][tid] : ldsM[3][tid];
+                    bool nonEmpty;
+                    ChildState one;
+                    (void)evalChild<true>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, M, pHP, pHN, 1ull << pRac, score,
+                                          nonEmpty, one);
+                    parent = one.r;
+                    score = one.sc;
+                    pHP = one.HP;
+                    pHN = one.HN;
+                    pRac = (uint32_t)__ffsll((unsigned long long)one.RAC) - 1u;
+                    row = row1;
+                    kinds = 0; // (nothing of this expansion is left to append)
+                } else {
+                    walking = false;
+                }
+            }
+            if (__ballot(walking) == 0ull) break;
         }
         // ---- block-wide allocation in the four output queues
-        uint32_t nNode = 0, nEv = 0, nIt = 0;
+        uint32_t nNode = 0, nEv = 0, nF = 0;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const uint32_t kd = (kinds >> (4 * c)) & 15u;
-            nNode += kd == 1;
-            nEv += kd == 2;
-            if (kd == 3) nIt += cr[c].y - cr[c].x;
+            const uint32_t kd = (kinds >> (4 * c)) & 3u;
+            nNode += kd == KIND_NODE;
+            nEv += kd == KIND_EVENT;
+            nF += (kinds >> (4 * c + 2)) & 1u;
         }
-        const uint32_t nF = (uint32_t)__popc(needF);
+#ifdef CMB_BFS_STATS
+        if (act) {
+            const uint32_t outs = nNode + nEv + (nIt ? 1u : 0u);
+            const int cat = outs == 0 ? 0 : (outs == 1 && nNode == 1 && nF == 0) ? 1 : (outs == 1 && nNode == 1) ? 2 : 3;
+            atomicAdd(&g_bfsStats[cat], 1ull);
+        }
+#endif
         const uint32_t want[4] = {nNode, nEv, nIt, nF};
         uint32_t got[4];
         blockAppend4(&B.nq[pass + 1], &B.ne[pass + 1], &q.cnt[0], &B.pool[0], want, sh, got);
@@ -267,49 +406,73 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
         if (oEv + nEv > B.evCap) { okEv = false; flags |= FLAG_BFS_EV; }
         if (oIt + nIt > q.itemCap) { okIt = false; flags |= FLAG_ITEM_OVERFLOW; }
         if (oF + nF > B.fCap) { okF = false; flags |= FLAG_BFS_F; }
-        if (act && okF && okNode && okEv && okIt) {
+        if (kinds != 0u && okF && okNode && okEv && okIt) {
+            const bool inFC = e.g.inFinalColumn(row1);
+            const uint32_t cell = min(e.clSize + row1 - e.g.m, ED_CELLS - 1u);
+            // what only the records need is fetched again now: the final-column distances of the path so far (nodes in
+            // the final column: one in thirty), read number and item word of the context (in-text items)
+            EdPack pack{0, 0};
+            if (fcP != BFS_NONE && (kinds & 0x4444u)) {
+                const uint4 fp = Qi[(size_t)3 * qCap + i];
+                pack = EdPack{u64of(fp.x, fp.y), u64of(fp.z, fp.w)};
+            }
+            uint32_t rsId = 0, itMeta = 0;
+            if (nIt) {
+                const uint4 hot = B.C[(size_t)ctx * CTX_U4 + CTX_HOT];
+                rsId = hot.x & 0x1FFFFFFu;
+                itMeta = hot.w & 0x7FFFFFu;
+            }
+            uint32_t Rb[4], Re[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                const uint32_t kd = (kinds >> (4 * c)) & 15u;
-                if (kd == 0) continue;
+                Rb[c] = ldsR[c][tid];
+                Re[c] = ldsR[4 + c][tid];
+            }
+#pragma unroll
+            for (uint32_t ch = 1; ch <= 4; ch++) {
+                const uint32_t kd = (kinds >> (4 * (ch - 1))) & 3u;
+                if (kd == KIND_NONE) continue;
+                bool nonEmpty;
+                ChildState cs;
+                (void)evalChild<true>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, ldsM[ch - 1][tid], pHP, pHN, 1ull << pRac,
+                                      score, nonEmpty, cs);
+                const bool wantF = (kinds >> (4 * (ch - 1) + 2)) & 1u;
+                const uint4 cr = make_uint4(cs.r.sa.b, cs.r.sa.e, cs.r.rev.b, cs.r.rev.e);
                 uint32_t fc = BFS_NONE;
-                if (needF & (1u << c)) {
+                if (wantF) {
                     fc = oF++;
-                    EdPack p2 = pack;
-                    edPut(p2, cell, cEd[c]);
                     uint4* Fr = B.F + (size_t)fc * F_U4;
-                    Fr[0] = cr[c];
-                    Fr[1] = make_uint4(row1 | ((uint32_t)(c + 1) << 16), fcP, 0u, 0u);
+                    Fr[0] = cr;
+                    Fr[1] = make_uint4(row1 | (ch << 16), fcP, 0u, 0u);
                 }
-                if (kd == 1) {
+                if (kd == KIND_NODE) {
                     const uint32_t o = oNode++;
-                    Qo[o] = cr[c];
-                    Qo[(size_t)qCap + o] = make_uint4(row1 | (cw[c] << 16), ctx, fc, (uint32_t)__ffsll((unsigned long long)cRAC[c]) - 1u);
-                    Qo[(size_t)2 * qCap + o] = make_uint4((uint32_t)cHP[c], (uint32_t)(cHP[c] >> 32), (uint32_t)cHN[c],
-                                                          (uint32_t)(cHN[c] >> 32));
-                    if (needF & (1u << c)) {
+                    Qo[o] = cr;
+                    Qo[(size_t)qCap + o] = make_uint4(row1 | (cs.sc << 16), ctx, fc,
+                                                      ((uint32_t)__ffsll((unsigned long long)cs.RAC) - 1u) | ((uint32_t)md << 8));
+                    Qo[(size_t)2 * qCap + o] = make_uint4((uint32_t)cs.HP, (uint32_t)(cs.HP >> 32), (uint32_t)cs.HN,
+                                                          (uint32_t)(cs.HN >> 32));
+                    if (wantF) {
                         EdPack p2 = pack;
-                        edPut(p2, cell, cEd[c]);
+                        edPut(p2, cell, cs.aux);
                         Qo[(size_t)3 * qCap + o] = make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32));
                     }
-                } else if (kd == 2) {
-                    {
-                        EdPack p2 = pack;
-                        edPut(p2, cell, cEd[c]);
-                        Eo[(size_t)2 * oEv] = make_uint4(ctx, fc, 0xFFFFFFFFu, cell);
-                        Eo[(size_t)2 * oEv + 1] = make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32));
-                        oEv++;
-                    }
+                } else if (kd == KIND_EVENT) {
+                    EdPack p2 = pack;
+                    edPut(p2, cell, cs.aux);
+                    Eo[(size_t)2 * oEv] = make_uint4(ctx, fc, 0xFFFFFFFFu, cell);
+                    Eo[(size_t)2 * oEv + 1] = make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32));
+                    oEv++;
                 } else {
-                    const uint32_t w = cr[c].y - cr[c].x;
-                    for (uint32_t t = 0; t < w; t++) q.items[oIt + t] = make_uint4(rsId, cr[c].x + t, cEd[c], itMeta);
+                    const uint32_t w = cs.r.sa.e - cs.r.sa.b;
+                    for (uint32_t t = 0; t < w; t++) q.items[oIt + t] = make_uint4(rsId, cs.r.sa.b + t, cs.aux, itMeta);
                     oIt += w;
                 }
             }
         }
     }
     // per-block counters (summed by k_bfs_finish): one writer per slot and launch, launches are ordered
-    unsigned long long v[3] = {cNode, cExp, cRows};
+    unsigned long long v[3] = {ldsCnt[0][tid], ldsCnt[1][tid], ldsCnt[0][tid]}; // (every child gets its matrix row)
 #pragma unroll
     for (int j = 0; j < 3; j++) {
 #pragma unroll
@@ -808,7 +971,8 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                 if (live) {
                     outKind = 1;
                     oN0 = make_uint4(root.sa.b, root.sa.e, root.rev.b, root.rev.e);
-                    oN1 = make_uint4(rootRow | (score << 16), cNew, fcCur, (uint32_t)__ffsll((unsigned long long)RAC) - 1u);
+                    oN1 = make_uint4(rootRow | (score << 16), cNew, fcCur,
+                                     ((uint32_t)__ffsll((unsigned long long)RAC) - 1u) | ((uniN ? 2u : (dirN == 0 ? 0u : 1u)) << 8));
                     oN2 = make_uint4((uint32_t)HP, (uint32_t)(HP >> 32), (uint32_t)HN, (uint32_t)(HN >> 32));
                     oN4 = make_uint4((uint32_t)pk.lo, (uint32_t)(pk.lo >> 32), (uint32_t)pk.hi, (uint32_t)(pk.hi >> 32));
                 }
@@ -852,12 +1016,15 @@ k_bfs_start(DevIndex ix, const DevStrategyK* __restrict__ stp, BfsBufs B, const 
 
 // one level: blocks [0, BFS_GRID) expand the frontier, blocks [BFS_GRID, BFS_GRID + BFS_GRID_EV) handle the events
 // of the same pass (both only append to the queues of pass + 1, so they run side by side)
-__global__ void __launch_bounds__(256)
+#ifndef CMB_BFS_WAVES
+#define CMB_BFS_WAVES 4 // wavefronts per SIMD the register allocation of k_bfs_pass is held to (128 VGPRs)
+#endif
+__global__ void __launch_bounds__(256, CMB_BFS_WAVES)
 k_bfs_pass(DevIndex ix, const DevStrategyK* __restrict__ stp, BfsBufs B, uint32_t pass, const uint64_t* __restrict__ offs,
            uint32_t gw, const uint32_t* __restrict__ G, const PartOut* __restrict__ parts, Queues q) {
     if (blockStopped(q)) return;
-    if (blockIdx.x < BFS_GRID) bfsExpand(ix, B, pass, q, blockIdx.x, BFS_GRID);
-    else bfsHeavy<false>(ix, stp, B, pass, nullptr, 0u, offs, gw, G, parts, q, blockIdx.x - BFS_GRID, BFS_GRID_EV);
+    if (blockIdx.x < B.gridX) bfsExpand(ix, B, pass, q, blockIdx.x, B.gridX);
+    else bfsHeavy<false>(ix, stp, B, pass, nullptr, 0u, offs, gw, G, parts, q, blockIdx.x - B.gridX, B.gridEv);
 }
 
 } // namespace cmb

@@ -29,6 +29,4 @@ for name in ("wide", "narrow"):
         rc = ca.lib().cmb_extend_bench(dev.h, mode, din.data_ptr(), N, dout.data_ptr(), dok.data_ptr(), 10, C.byref(ms))
         assert rc == 0, ca.lib().cmb_last_error()
         torch.cuda.synchronize()
-        if mode < 16 and mode == 1: ref = (dout.clone(), dok.clone())
-        if mode == 17: print("  coop == plain:", bool(torch.equal(ref[0], dout) and torch.equal(ref[1], dok)))
         print(name, "mode", mode, "ms", round(ms.value, 3), "parents/s %.3g" % (N / ms.value * 1e3), flush=True)
