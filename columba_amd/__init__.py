@@ -35,7 +35,7 @@ EXPORTS = [
     "cmb_strategy_add_scheme", "cmb_strategy_set_partition_params", "cmb_strategy_destroy",
     "cmb_strategy_describe", "cmb_strategy_export_scheme", "cmb_strategy_export_partition", "cmb_match_batch", "cmb_batch_create", "cmb_batch_run",
     "cmb_batch_result_size", "cmb_batch_results", "cmb_batch_timings", "cmb_batch_destroy",
-    "cmb_rank_batch", "cmb_extend_batch", "cmb_extend_bench", "cmb_locate_batch", "cmb_verify_batch",
+    "cmb_rank_batch", "cmb_extend_batch", "cmb_extend_bench", "cmb_locate_batch", "cmb_verify_batch", "cmb_verify_batch_staged",
     "cmb_last_error", "cmb_version",
 ]
 
@@ -138,6 +138,7 @@ def lib():
         L.cmb_extend_bench.argtypes = [vp, i32, vp, u64, vp, vp, u32, C.POINTER(C.c_float)]
         L.cmb_locate_batch.argtypes = [vp, vp, u64, vp, C.POINTER(u64)]
         L.cmb_verify_batch.argtypes = [vp, C.c_char_p, u32, vp, u64, u32, u32, i32, vp, u64, C.POINTER(u64), vp]
+        L.cmb_verify_batch_staged.argtypes = L.cmb_verify_batch.argtypes
         _lib = L
     return _lib
 
@@ -258,13 +259,15 @@ class Index:
         _chk(lib().cmb_locate_batch(self.h, _p(rows), rows.shape[0], _p(out), C.byref(lf)))
         return out, int(lf.value)
 
-    def verify(self, pattern: bytes, starts, max_ed: int, min_ed: int, fixed: bool):
+    def verify(self, pattern: bytes, starts, max_ed: int, min_ed: int, fixed: bool, staged: bool = False):
+        """FMIndex::inTextVerification for one pattern; staged=True: through the production edit-distance path"""
         starts = np.ascontiguousarray(starts, np.uint32)
         cap = starts.shape[0] * 32 + 64
         out = np.zeros(cap, OCC_DTYPE)
         n = C.c_uint64()
         cnt = np.zeros(len(COUNTER_NAMES), np.uint64)
-        _chk(lib().cmb_verify_batch(self.h, pattern, len(pattern), _p(starts), starts.shape[0], max_ed, min_ed,
+        fn = lib().cmb_verify_batch_staged if staged else lib().cmb_verify_batch
+        _chk(fn(self.h, pattern, len(pattern), _p(starts), starts.shape[0], max_ed, min_ed,
                                     int(fixed), _p(out), cap, C.byref(n), _p(cnt)))
         return out[:n.value], dict(zip(COUNTER_NAMES, cnt.tolist()))
 

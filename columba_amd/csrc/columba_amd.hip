@@ -486,6 +486,10 @@ struct cmb_batch {
     DevBuf<unsigned long long> counters;
     uint32_t nSlots = 0;
     std::vector<uint64_t> hostOffs;
+    // cmb_verify_batch_staged: candidates given by the caller take the place of the search's in-text items, and the
+    // raw text occurrences (before the filter) are what is handed back
+    std::vector<uint4> presetItems;
+    std::vector<TextOccRec> presetOut;
     // A large batch is a COMPOSITE of sub-batches that run concurrently, one host thread + HIP stream each: the
     // stages of different sub-batches drift apart, so VALU-bound matrix kernels of one overlap memory-bound
     // extension kernels of another (starting them one after the other on purpose was measured slower: the
@@ -773,7 +777,18 @@ static int batchRunOne(cmb_batch* b) {
         const uint32_t pCap = getenv("CMB_P_SLOTS") ? (uint32_t)std::max(256, atoi(getenv("CMB_P_SLOTS"))) / 256u * 256u : 256u * 32768u; // (one lane per read x strand
         // up to 8 M: k_parts 65.7 ms with 512 k lanes looping over the tasks, 65.0 / 62.1 / 62.5 ms with 1 M / 4 M / 8 M)
         const uint32_t pSlots = std::min<uint32_t>(((tasks + 255) / 256) * 256, pCap);
-        for (int attempt = 0;; attempt++) {
+        const bool preset = !b->presetItems.empty();
+        if (preset) { // (no search: the candidates come from the caller)
+            if (b->items.n < b->presetItems.size()) b->items.alloc(b->presetItems.size() + 1024);
+            HIPCHK(hipMemsetAsync(b->cnt.p, 0, 8 * sizeof(uint32_t), s));
+            HIPCHK(hipMemcpyAsync(b->items.p, b->presetItems.data(), b->presetItems.size() * sizeof(uint4), hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+            memset(hcnt, 0, sizeof(hcnt));
+            hcnt[0] = (uint32_t)b->presetItems.size();
+            q.items = b->items.p;
+            q.itemCap = (uint32_t)std::min<size_t>(b->items.n, 0xFFFFFFF0u);
+        }
+        for (int attempt = 0; !preset; attempt++) {
             HIPCHK(hipMemsetAsync(b->cnt.p, 0, 8 * sizeof(uint32_t), s));
             if (attempt) {
                 HIPCHK(hipMemsetAsync(b->counters.p, 0, CMB_CNT_MAX * sizeof(unsigned long long), s));
@@ -1169,6 +1184,16 @@ static int batchRunOne(cmb_batch* b) {
         }
         const uint32_t nText = hcnt[2];
         lap("verify + traceback + fmocc");
+        if (preset) { // the raw text occurrences and the counters are the result
+            if (hcnt[3] & (FLAG_CAPACITY | FLAG_TRACE_RULE)) return fail(CMB_ERR_INTERNAL, "a traceback left the band");
+            b->presetOut.resize(nText);
+            if (nText) HIPCHK(hipMemcpy(b->presetOut.data(), b->text.p, (size_t)nText * sizeof(TextOccRec), hipMemcpyDeviceToHost));
+            unsigned long long hc2[CMB_CNT_MAX];
+            HIPCHK(hipMemcpy(hc2, b->counters.p, sizeof(hc2), hipMemcpyDeviceToHost));
+            for (int i = 0; i < CMB_CNT_MAX; i++) b->cnts[i] = hc2[i];
+            b->done = true;
+            return CMB_OK;
+        }
 
         // ---- sort + filter on the device (getUniqueTextOccurrences / getTextOccHamming,
         // indexinterface.cpp:1331-1491): pack -> one 64-bit radix sort -> per-read scan
@@ -1427,6 +1452,54 @@ extern "C" int cmb_locate_batch(cmb_index* idx, const uint32_t* rows, uint64_t n
     } catch (const std::exception& e) {
         return fail(CMB_ERR_DEVICE, e.what());
     }
+}
+
+// The PRODUCTION edit-distance verification path for one pattern and n start positions: k_verify<KEYS> (one key per
+// candidate) -> radix sort + run-length encode (identical candidates are verified once, counters scaled by the
+// multiplicity) -> k_verify_stage x stages -> k_traceback, exactly as cmb_batch_run runs it (it IS cmb_batch_run on a
+// one-read batch whose in-text items are given).  Same contract as cmb_verify_batch, incl. duplicates in `starts`.
+extern "C" int cmb_verify_batch_staged(cmb_index* idx, const char* pattern, uint32_t plen, const uint32_t* starts,
+                                       uint64_t n, uint32_t max_ed, uint32_t min_ed, int fixed_start, cmb_occ* out,
+                                       uint64_t out_cap, uint64_t* n_out, uint64_t* counters) {
+    if (!idx || !pattern || (n && !starts) || !n_out) return fail(CMB_ERR_INVALID, "null argument");
+    if (plen == 0 || plen > (uint32_t)MAX_READ) return fail(CMB_ERR_UNSUPPORTED, "pattern length not supported");
+    if (max_ed == 0 || max_ed > 7 || 3 * max_ed + 1 > MX_LEFT || min_ed > 7) return fail(CMB_ERR_UNSUPPORTED, "needs the 128-bit matrix");
+    if (n >= (1ull << 31)) return fail(CMB_ERR_INVALID, "too many start positions");
+    for (uint64_t i = 0; i < n; i++)
+        if (starts[i] > idx->d.n) return fail(CMB_ERR_INVALID, "start position beyond the text");
+    *n_out = 0;
+    if (n == 0) {
+        if (counters) memset(counters, 0, CMB_CNT_MAX * sizeof(uint64_t));
+        return CMB_OK;
+    }
+    cmb_strategy* st = nullptr;
+    int rc = cmb_strategy_create_named("columba", CMB_METRIC_EDIT, CMB_PARTITION_UNIFORM, &st); // (schemes for 1..7 errors; unused)
+    if (rc) return rc;
+    cmb_batch* b = nullptr;
+    const uint64_t ho[2] = {0, plen};
+    rc = batchCreateOne(idx, st, max_ed, pattern, ho, 1, &b);
+    cmb_strategy_destroy(st);
+    if (rc) return rc;
+    const uint32_t meta = (max_ed << 12) | (min_ed << 16) | ((fixed_start ? 1u : 0u) << 20) | ((uint32_t)ITEM_EDIT << 21) | (1u << 23);
+    b->presetItems.resize(n);
+    for (uint64_t i = 0; i < n; i++) b->presetItems[i] = make_uint4(0, starts[i], 0, meta); // (bit 23: nothing to locate)
+    rc = batchRunOne(b);
+    if (rc == CMB_OK) {
+        std::vector<TextOccRec> t = b->presetOut;
+        t.erase(std::remove_if(t.begin(), t.end(), [](const TextOccRec& x) { return x.rsId == 0xFFFFFFFFu; }), t.end());
+        std::sort(t.begin(), t.end(), [](const TextOccRec& x, const TextOccRec& y) {
+            if (x.begin != y.begin) return x.begin < y.begin;
+            if (x.end != y.end) return x.end < y.end;
+            return x.dist < y.dist;
+        });
+        *n_out = t.size();
+        if (t.size() > out_cap) rc = fail(CMB_ERR_OVERFLOW, "output buffer too small");
+        else
+            for (size_t i = 0; i < t.size(); i++) out[i] = cmb_occ{t[i].begin, t[i].end, t[i].dist, 0};
+        if (counters) memcpy(counters, b->cnts, sizeof(b->cnts));
+    }
+    cmb_batch_destroy(b);
+    return rc;
 }
 
 // in-text verification hook: FMIndex::inTextVerification(startPos, maxED, minED, ..., pattern,

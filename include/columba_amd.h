@@ -219,6 +219,13 @@ int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t plen, const u
                      uint64_t n, uint32_t max_ed, uint32_t min_ed, int fixed_start, cmb_occ* out,
                      uint64_t out_cap, uint64_t* n_out, uint64_t* counters);
 
+/* the same through the PRODUCTION edit-distance path (keys, de-duplication of identical candidates with counters
+ * scaled by their multiplicity, staged matrix blocks, traceback): what cmb_batch_run does with the in-text candidates
+ * of a search; cmb_verify_batch runs the one-candidate-per-lane kernel used for Hamming / exact candidates */
+int cmb_verify_batch_staged(cmb_index* idx, const char* pattern, uint32_t plen, const uint32_t* starts,
+                            uint64_t n, uint32_t max_ed, uint32_t min_ed, int fixed_start, cmb_occ* out,
+                            uint64_t out_cap, uint64_t* n_out, uint64_t* counters);
+
 const char* cmb_last_error(void);
 const char* cmb_version(void);
 

@@ -128,6 +128,42 @@ def test_in_text_verification_hook(world):
             assert dc[n] == oc[n], (trial, n)
 
 
+def test_production_edit_verification_path(world):
+    """The path cmb_batch_run takes for edit-distance candidates — k_verify<keys> -> radix sort + run-length encode ->
+    k_verify_stage x stages -> k_traceback — at function level (cmb_verify_batch_staged), WITH duplicate candidates:
+    identical candidates are verified once and every counter is scaled by the multiplicity, which must give exactly
+    the counters of the reference verifying each of them (FMIndex::inTextVerification, fmindex.cpp:267-310)."""
+    g = world["genome"]
+    rng = np.random.default_rng(18)
+    dup_total = 0
+    for trial in range(24):
+        k = int(rng.integers(1, 7))
+        pos = int(rng.integers(100, len(g) - 400))
+        pat = synth.sample_reads(g[pos:pos + 400], 1, int(rng.choice([50, 100, 150, 250])), seed=1000 + trial,
+                                 edit_choices=(0, 1, 2, k), rc_frac=0.0)[0]
+        fixed = bool(trial % 2)
+        base = np.concatenate([rng.integers(0, len(g), 20), np.arange(max(0, pos - 30), pos + 60, 3),
+                               [len(g) - 5, len(g), 0]]).astype(np.uint32)
+        # every candidate 1..5 times, shuffled (the parts of a read seeding the same alignment look like this)
+        mult = rng.integers(1, 6, base.shape[0])
+        starts = np.repeat(base, mult)
+        rng.shuffle(starts)
+        dup_total += int(starts.shape[0] - base.shape[0])
+        min_ed = int(trial % 3 == 0)
+        d, dc = world["dev"].verify(pat, starts, k, min_ed, fixed, staged=True)
+        o, oc = world["orc"].verify(pat, starts, k, min_ed, fixed)
+        key = lambda a: sorted(set((int(x["begin"]), int(x["end"]), int(x["distance"])) for x in a))
+        assert key(d) == key(o), trial
+        # the direct kernel (one candidate per lane, no de-duplication) must agree as well, duplicates included
+        d1, dc1 = world["dev"].verify(pat, starts, k, min_ed, fixed)
+        assert sorted((int(x["begin"]), int(x["end"]), int(x["distance"])) for x in d1) == \
+            sorted((int(x["begin"]), int(x["end"]), int(x["distance"])) for x in o), trial
+        for n in ("IN_TEXT_STARTED", "ABORTED_IN_TEXT_VERIF", "CIGARS_IN_TEXT_VERIFICATION", "MATRIX_ROWS", "TEXT_BYTES"):
+            assert dc[n] == oc[n], (trial, n, dc[n], oc[n])
+            assert dc1[n] == oc[n], (trial, n, dc1[n], oc[n])
+    assert dup_total > 1000
+
+
 @pytest.mark.parametrize("spec,metric,partition,k", [
     ("multiple_opt", "edit", "dynamic", 4),
     ("multiple_opt", "edit", "dynamic", 2),

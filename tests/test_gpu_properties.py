@@ -131,3 +131,53 @@ def test_narrow_and_wide_matrix_formats(big, k, env):
         assert np.array_equal(o1[f], o2[f]), f
     for n in COUNTERS:
         assert c1[n] == c2[n], n
+
+
+def test_one_index_many_host_threads(big):
+    """SURVEY.md §8b / include/columba_amd.h: cmb_match_batch is re-entrant — N host threads share ONE index and ONE
+    strategy handle (as the reference's workers share index + strategy, parallel.cpp:1143-1146; every batch owns its
+    stream and scratch).  Four threads match four different chunks at the same time, twice; results and counters
+    must be those of the same chunks matched one after the other."""
+    import threading
+    st = ca.SearchStrategy("multiple_opt", "edit", "dynamic")
+    world = {"dev": big["dev"]}
+    chunks = [big["reads"][20000 * t:20000 * t + 15000 + 1000 * t] for t in range(4)]
+    serial = [ca.match_batch(world["dev"], st, 4, c) for c in chunks]
+    for _round in range(2):
+        out, errs = [None] * 4, []
+
+        def work(t):
+            try:
+                out[t] = ca.match_batch(world["dev"], st, 4, chunks[t])
+            except Exception as e:  # noqa: BLE001
+                errs.append((t, repr(e)))
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errs, errs
+        for t in range(4):
+            assert np.array_equal(out[t][1], serial[t][1]) and np.array_equal(out[t][0], serial[t][0]), t
+            assert out[t][2] == serial[t][2], t
+    # mixed: Hamming and exact batches beside an edit-distance batch on the same handle
+    mixed = [("edit", 4, "multiple_opt"), ("hamming", 2, "kuch1"), ("edit", 0, "kuch1"), ("edit", 2, "columba")]
+    ser = [ca.match_batch(world["dev"], ca.SearchStrategy(n, m, "dynamic"), k, chunks[0]) for m, k, n in mixed]
+    out, errs = [None] * 4, []
+
+    def work2(t):
+        try:
+            m, k, n = mixed[t]
+            out[t] = ca.match_batch(world["dev"], ca.SearchStrategy(n, m, "dynamic"), k, chunks[0])
+        except Exception as e:  # noqa: BLE001
+            errs.append((t, repr(e)))
+
+    th = [threading.Thread(target=work2, args=(t,)) for t in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    for t in range(4):
+        assert np.array_equal(out[t][0], ser[t][0]) and out[t][2] == ser[t][2], t
