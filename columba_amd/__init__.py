@@ -27,6 +27,13 @@ COUNTER_NAMES = ["NODE_COUNTER", "TOTAL_REPORTED_POSITIONS", "IN_TEXT_STARTED", 
 METRIC = {"hamming": 0, "edit": 1}
 PARTITION = {"uniform": 0, "static": 1, "dynamic": 2}
 OCC_DTYPE = np.dtype([("begin", np.uint32), ("end", np.uint32), ("distance", np.uint32), ("strand", np.uint32)])
+ALN_DTYPE = np.dtype([("seq_id", np.uint32), ("seq_begin", np.uint32), ("cigar_off", np.uint64), ("cigar_len", np.uint16),
+                      ("spans", np.uint16), ("reserved", np.uint32)])
+
+
+def cigar_string(ops) -> str:
+    """run-length operations (length << 2 | op) -> "57M1I92M" """
+    return "".join(f"{int(o) >> 2}{'MID'[int(o) & 3]}" for o in ops)
 
 EXPORTS = [
     "cmb_index_create", "cmb_index_destroy", "cmb_index_device_bytes", "cmb_index_kmer_table",
@@ -35,7 +42,9 @@ EXPORTS = [
     "cmb_strategy_add_scheme", "cmb_strategy_set_partition_params", "cmb_strategy_destroy",
     "cmb_strategy_describe", "cmb_strategy_export_scheme", "cmb_strategy_export_partition", "cmb_match_batch", "cmb_batch_create", "cmb_batch_run",
     "cmb_batch_result_size", "cmb_batch_results", "cmb_batch_timings", "cmb_batch_destroy",
-    "cmb_rank_batch", "cmb_extend_batch", "cmb_extend_bench", "cmb_locate_batch", "cmb_verify_batch", "cmb_verify_batch_staged",
+    "cmb_rank_batch", "cmb_extend_batch", "cmb_extend_bench", "cmb_locate_batch", "cmb_verify_batch", "cmb_verify_batch_staged", "cmb_verify_window",
+    "cmb_batch_want_alignments", "cmb_batch_alignments", "cmb_sam_se", "cmb_sam_se_xa", "cmb_sam_unmapped_se",
+    "cmb_read_prepare",
     "cmb_last_error", "cmb_version",
 ]
 
@@ -91,6 +100,12 @@ class _DevArray:
         self._owner = owner
 
 
+class SamHit(C.Structure):
+    """cmb_sam_hit"""
+    _fields_ = [("seq_name", C.c_char_p), ("pos0", C.c_uint32), ("distance", C.c_uint32), ("revcomp", C.c_uint32),
+                ("cigar_ops", C.c_void_p), ("n_ops", C.c_uint32)]
+
+
 _lib = None
 
 
@@ -139,6 +154,16 @@ def lib():
         L.cmb_locate_batch.argtypes = [vp, vp, u64, vp, C.POINTER(u64)]
         L.cmb_verify_batch.argtypes = [vp, C.c_char_p, u32, vp, u64, u32, u32, i32, vp, u64, C.POINTER(u64), vp]
         L.cmb_verify_batch_staged.argtypes = L.cmb_verify_batch.argtypes
+        L.cmb_verify_window.argtypes = [vp, C.c_char_p, u32, u32, u32, u32, u32, vp, u64, C.POINTER(u64), vp]
+        L.cmb_sam_se.restype = C.c_int64
+        L.cmb_sam_se.argtypes = [C.c_char_p, C.POINTER(SamHit), i32, u32, u32, C.c_char_p, C.c_char_p, vp, u64]
+        L.cmb_sam_se_xa.restype = C.c_int64
+        L.cmb_sam_se_xa.argtypes = [C.c_char_p, C.POINTER(SamHit), u32, u32, C.c_char_p, C.c_char_p, vp, u64]
+        L.cmb_sam_unmapped_se.restype = C.c_int64
+        L.cmb_sam_unmapped_se.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, vp, u64]
+        L.cmb_read_prepare.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, vp, vp, vp, vp]
+        L.cmb_batch_want_alignments.argtypes = [vp, i32]
+        L.cmb_batch_alignments.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
         _lib = L
     return _lib
 
@@ -259,6 +284,14 @@ class Index:
         _chk(lib().cmb_locate_batch(self.h, _p(rows), rows.shape[0], _p(out), C.byref(lf)))
         return out, int(lf.value)
 
+    def verify_window(self, pattern: bytes, start: int, end: int, max_ed: int, min_ed: int = 0):
+        """FMIndex::inTextVerificationOneString: the pattern against text[start, end), fixed start"""
+        out = np.zeros(64, OCC_DTYPE)
+        n = C.c_uint64()
+        cnt = np.zeros(len(COUNTER_NAMES), np.uint64)
+        _chk(lib().cmb_verify_window(self.h, pattern, len(pattern), start, end, max_ed, min_ed, _p(out), 64, C.byref(n), _p(cnt)))
+        return out[:n.value], dict(zip(COUNTER_NAMES, cnt.tolist()))
+
     def verify(self, pattern: bytes, starts, max_ed: int, min_ed: int, fixed: bool, staged: bool = False):
         """FMIndex::inTextVerification for one pattern; staged=True: through the production edit-distance path"""
         starts = np.ascontiguousarray(starts, np.uint32)
@@ -354,6 +387,51 @@ class SearchStrategy:
     __del__ = close
 
 
+def parse_cigar(cigar: str) -> np.ndarray:
+    """"57M1I92M" -> run-length operations (length << 2 | op)"""
+    import re
+    return np.array([(int(n) << 2) | "MID".index(o) for n, o in re.findall(r"(\d+)([MID])", cigar)], np.uint16)
+
+
+def _sam_hit(seq_name: bytes, pos0: int, distance: int, revcomp: bool, ops: np.ndarray):
+    ops = np.ascontiguousarray(ops, np.uint16)
+    h = SamHit(seq_name, pos0, distance, int(revcomp), ops.ctypes.data if ops.size else None, ops.shape[0])
+    h._keep = (seq_name, ops)
+    return h
+
+
+def _sam_call(fn, *args) -> str:
+    n = fn(*args, None, 0)
+    if n < 0:
+        raise CmbError(int(n), lib().cmb_last_error().decode(errors="replace"))
+    buf = C.create_string_buffer(int(n) + 1)
+    fn(*args, buf, int(n) + 1)
+    return buf.value.decode()
+
+
+def sam_se(read_id: str, hit, primary: bool, n_hits: int, min_score: int, seq: str, qual: str) -> str:
+    """one SAM line (TextOcc::generateSAMSingleEnd); hit = (seq_name, pos0, distance, revcomp, cigar ops)"""
+    h = _sam_hit(hit[0].encode(), *hit[1:])
+    return _sam_call(lib().cmb_sam_se, read_id.encode(), C.byref(h), int(primary), n_hits, min_score, seq.encode(), qual.encode())
+
+
+def sam_se_xa(read_id: str, hits, n_hits: int, seq: str, qual: str) -> str:
+    hs = [_sam_hit(h[0].encode(), *h[1:]) for h in hits]
+    arr = (SamHit * len(hs))(*hs)
+    return _sam_call(lib().cmb_sam_se_xa, read_id.encode(), arr, len(hs), n_hits, seq.encode(), qual.encode())
+
+
+def sam_unmapped_se(read_id: str, seq: str, qual: str) -> str:
+    return _sam_call(lib().cmb_sam_unmapped_se, read_id.encode(), seq.encode(), qual.encode())
+
+
+def read_prepare(read_id: str, seq: str, qual: str = ""):
+    """(identifier, cleaned read, reverse complement, reversed quality) as Read / ReadBundle hold them (reads.h)"""
+    bufs = [C.create_string_buffer(len(x.encode()) + 2) for x in (read_id, seq, seq, qual)]
+    _chk(lib().cmb_read_prepare(read_id.encode(), seq.encode(), qual.encode(), *bufs))
+    return tuple(b.value.decode() for b in bufs)
+
+
 def pack_reads(reads: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
     offs = np.zeros(len(reads) + 1, np.uint64)
     if reads:
@@ -386,6 +464,20 @@ class Batch:
         cnt = np.zeros(len(COUNTER_NAMES), np.uint64)
         _chk(lib().cmb_batch_results(self.h, _p(occs), occs.shape[0], _p(offs), _p(cnt)))
         return occs[:n.value], offs, dict(zip(COUNTER_NAMES, cnt.tolist()))
+
+    def want_alignments(self, on: bool = True):
+        _chk(lib().cmb_batch_want_alignments(self.h, int(on)))
+
+    def alignments(self):
+        """(cmb_aln records parallel to the occurrences, pool of CIGAR run-length operations)"""
+        n = C.c_uint64()
+        _chk(lib().cmb_batch_result_size(self.h, C.byref(n)))
+        aln = np.zeros(max(int(n.value), 1), ALN_DTYPE)
+        nops = C.c_uint64()
+        rc = lib().cmb_batch_alignments(self.h, _p(aln), 0, None, 0, C.byref(nops))  # (sizes first)
+        ops = np.zeros(max(int(nops.value), 1), np.uint16)
+        _chk(lib().cmb_batch_alignments(self.h, _p(aln), aln.shape[0], _p(ops), ops.shape[0], C.byref(nops)))
+        return aln[:n.value], ops[:nops.value]
 
     def timings(self) -> Dict[str, float]:
         names = (C.c_char_p * 16)()

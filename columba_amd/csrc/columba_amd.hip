@@ -1,5 +1,6 @@
 // C-ABI implementation (include/columba_amd.h) on top of the HIP kernels.  gfx950 only.
 #include "../../include/columba_amd.h"
+#include "host_sam.hpp"
 #include "host_schemes.hpp"
 #include "kernels.hpp"
 
@@ -88,7 +89,15 @@ struct cmb_index {
     DevBuf<uint32_t> text2;
     DevBuf<uint4> kmer;
     std::vector<uint32_t> seqStarts;
+    DevBuf<uint32_t> seqStartsDev; // the same on the device (k_cigar: sequence assignment); [0, n - 1] if none were given
+    uint32_t nSeqsDev = 0;
     uint64_t bytes = 0;
+    void uploadSeqStarts() {
+        std::vector<uint32_t> v = seqStarts;
+        if (v.size() < 2) v = {0u, d.n ? d.n - 1u : 0u};
+        seqStartsDev.upload(v.data(), v.size());
+        nSeqsDev = (uint32_t)v.size() - 1u;
+    }
 };
 
 #ifdef CMB_BFS_STATS
@@ -191,6 +200,7 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         HIPCHK(hipGetLastError());
         HIPCHK(hipDeviceSynchronize());
         ix->bytes = ix->blkF.bytes() + ix->blkR.bytes() + ix->saBlk.bytes() + ix->saSamples.bytes() + ix->text.bytes() + ix->text2.bytes() + ix->kmer.bytes();
+        ix->uploadSeqStarts();
         *out = ix.release();
         return CMB_OK;
     } catch (const std::exception& e) {
@@ -281,6 +291,7 @@ extern "C" int cmb_index_create_empty(const cmb_index_layout* L, const uint32_t*
         d.switchPoint = L->in_text_switch;
         bindDevIndex(ix.get());
         if (seq_starts && L->n_seqs) ix->seqStarts.assign(seq_starts, seq_starts + L->n_seqs);
+        ix->uploadSeqStarts();
         ix->bytes = total;
         *out = ix.release();
         return CMB_OK;
@@ -486,6 +497,14 @@ struct cmb_batch {
     DevBuf<unsigned long long> counters;
     uint32_t nSlots = 0;
     std::vector<uint64_t> hostOffs;
+    // alignments of the final occurrences (cmb_batch_want_alignments): CIGAR runs + sequence assignment
+    bool wantAln = false;
+    DevBuf<uint32_t> foutRead;
+    DevBuf<uint16_t> alnOps;
+    DevBuf<AlnRec> alnRec;
+    uint32_t alnStride = 0;
+    PinnedBuf<uint16_t> hAlnOps;
+    PinnedBuf<AlnRec> hAlnRec;
     // cmb_verify_batch_staged: candidates given by the caller take the place of the search's in-text items, and the
     // raw text occurrences (before the filter) are what is handed back
     std::vector<uint4> presetItems;
@@ -1246,17 +1265,56 @@ static int batchRunOne(cmb_batch* b) {
             if (hcnt[3] & FLAG_CAPACITY)
                 return fail(CMB_ERR_INTERNAL, "occurrence does not fit the filter key (width / distance range) or a traceback left the band");
             if (b->fout.n < total) b->fout.alloc((size_t)total + total / 8 + 256);
+            if (b->wantAln && b->foutRead.n < total) b->foutRead.alloc((size_t)total + total / 8 + 256);
             if (total)
                 hipLaunchKernelGGL(k_filter_write, dim3((nText + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->offs.p,
-                                   b->k, b->frank.p, b->foffs.p, b->fout.p);
+                                   b->k, b->frank.p, b->foffs.p, b->fout.p, b->wantAln ? b->foutRead.p : (uint32_t*)nullptr);
             HIPCHK(hipGetLastError());
             tm.end("k_filter");
             lap("filter");
+            if (b->wantAln) { // CIGAR + sequence of every final occurrence (k_cigar)
+                tm.begin();
+                b->alnStride = 2u * b->k + 3u;
+                if (b->alnRec.n < total) {
+                    b->alnRec.alloc((size_t)total + total / 8 + 256);
+                    b->alnOps.alloc(b->alnRec.n * (2u * 7u + 3u));
+                }
+                if (total) {
+                    const uint32_t cSlots = (uint32_t)std::min<uint64_t>(((total + 255) / 256) * 256, 512u * 1024u);
+                    const bool narrow = b->k <= TBN_MAX_ED && !getenv("CMB_TRACE_WIDE");
+                    const uint32_t tLines = narrow ? ((uint32_t)VROWS + 15u) / 16u + 2u : ((uint32_t)VROWS + 7u) / 8u + 2u;
+                    if (b->vW.n < (size_t)tLines * 8 * cSlots) b->vW.alloc((size_t)tLines * 8 * cSlots);
+                    VPlanes vp{b->vW.p, cSlots, tLines};
+                    MFull mfc = mf;
+                    if (!mfc.p) { // (Hamming / exact batches have no match words: every CIGAR is len x M, nothing is traced)
+                        mfc.nBlk = 0;
+                    }
+                    auto kc = k_cigar<false, false>;
+                    if (narrow) kc = ix->d.text2 ? k_cigar<true, true> : k_cigar<true, false>;
+                    else if (ix->d.text2) kc = k_cigar<false, true>;
+                    hipLaunchKernelGGL(kc, dim3(cSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, mfc, b->fout.p, b->foutRead.p,
+                                       (uint64_t)total, vp, ix->seqStartsDev.p, ix->nSeqsDev, b->alnOps.p, b->alnStride, b->alnRec.p,
+                                       b->cnt.p + 3, (b->metric != CMB_METRIC_EDIT || b->k == 0) ? 1u : 0u);
+                }
+                tm.end("k_cigar");
+                HIPCHK(hipGetLastError());
+            }
             b->occs.resize(total);
             b->occOffs.resize((size_t)nReads + 1);
             if (total) HIPCHK(hipMemcpyAsync(b->occs.data(), b->fout.p, (size_t)total * sizeof(cmb_occ), hipMemcpyDeviceToHost, s));
+            if (b->wantAln) {
+                b->hAlnRec.resize(total);
+                b->hAlnOps.resize((size_t)total * b->alnStride);
+                if (total) {
+                    HIPCHK(hipMemcpyAsync(b->hAlnRec.data(), b->alnRec.p, (size_t)total * sizeof(AlnRec), hipMemcpyDeviceToHost, s));
+                    HIPCHK(hipMemcpyAsync(b->hAlnOps.data(), b->alnOps.p, (size_t)total * b->alnStride * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+                }
+                HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
+            }
             HIPCHK(hipMemcpyAsync(b->occOffs.data(), b->foffs.p, ((size_t)nReads + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
+            if (b->wantAln && (hcnt[3] & FLAG_CAPACITY))
+                return fail(CMB_ERR_INTERNAL, "a CIGAR traceback left the band or an occurrence is not an alignment within its distance");
             lap("results to the host");
             if (verbose) {
                 size_t fr = 0, tot = 0;
@@ -1307,6 +1365,41 @@ extern "C" int cmb_batch_results(const cmb_batch* b, cmb_occ* out, uint64_t out_
     if (counters) memcpy(counters, b->cnts, sizeof(b->cnts));
     return CMB_OK;
 }
+extern "C" int cmb_batch_want_alignments(cmb_batch* b, int on) {
+    if (!b) return fail(CMB_ERR_INVALID, "null argument");
+    b->wantAln = on != 0;
+    for (cmb_batch* c : b->subs) c->wantAln = on != 0;
+    b->done = false;
+    return CMB_OK;
+}
+extern "C" int cmb_batch_alignments(const cmb_batch* b, cmb_aln* out, uint64_t cap, uint16_t* cigar_ops, uint64_t ops_cap,
+                                    uint64_t* n_ops) {
+    if (!b) return fail(CMB_ERR_INVALID, "null argument");
+    if (!b->done) return fail(CMB_ERR_INVALID, "batch has not been run");
+    if (!b->wantAln) return fail(CMB_ERR_INVALID, "alignments were not requested (cmb_batch_want_alignments)");
+    std::vector<const cmb_batch*> parts;
+    if (b->subs.empty()) parts.push_back(b);
+    else
+        for (const cmb_batch* c : b->subs) parts.push_back(c);
+    uint64_t total = 0, ops = 0;
+    for (const cmb_batch* c : parts) {
+        total += c->hAlnRec.size();
+        for (size_t i = 0; i < c->hAlnRec.size(); i++) ops += c->hAlnRec.data()[i].nOps;
+    }
+    if (n_ops) *n_ops = ops;
+    if (cap < total || ops_cap < ops) return fail(CMB_ERR_OVERFLOW, "output buffer too small");
+    uint64_t o = 0, po = 0;
+    for (const cmb_batch* c : parts)
+        for (size_t i = 0; i < c->hAlnRec.size(); i++) {
+            const AlnRec& r = c->hAlnRec.data()[i];
+            out[o] = cmb_aln{r.seqId, r.seqBegin, po, (uint16_t)r.nOps, (uint16_t)r.spans};
+            const uint16_t* src = c->hAlnOps.data() + i * c->alnStride;
+            for (uint32_t j = 0; j < r.nOps; j++) cigar_ops[po + j] = src[r.nOps - 1 - j]; // (stored end to begin)
+            po += r.nOps;
+            o++;
+        }
+    return CMB_OK;
+}
 extern "C" int cmb_batch_timings(const cmb_batch* b, const char** names, float* ms, uint32_t cap) {
     if (!b) return 0;
     uint32_t n = 0;
@@ -1339,6 +1432,49 @@ extern "C" int cmb_match_batch(cmb_index* idx, const cmb_strategy* st, uint32_t 
     }
     cmb_batch_destroy(b);
     return rc;
+}
+
+// ------------------------------------------------------------------------- output records (host-only)
+static int64_t putString(const std::string& s, char* out, uint64_t cap) {
+    if (out && cap > s.size()) memcpy(out, s.c_str(), s.size() + 1);
+    return (int64_t)s.size();
+}
+static SamHit toHit(const cmb_sam_hit& h) {
+    SamHit r;
+    r.seqName = h.seq_name ? h.seq_name : "*";
+    r.cigar = cigarString(h.cigar_ops, h.n_ops);
+    r.pos0 = h.pos0;
+    r.distance = h.distance;
+    r.revCompl = h.revcomp != 0;
+    return r;
+}
+extern "C" int64_t cmb_sam_se(const char* read_id, const cmb_sam_hit* hit, int primary, uint32_t n_hits, uint32_t min_score,
+                              const char* print_seq, const char* print_qual, char* out, uint64_t cap) {
+    if (!read_id || !hit || !print_seq || !print_qual) return fail(CMB_ERR_INVALID, "null argument");
+    return putString(samLineSE(read_id, toHit(*hit), primary != 0, n_hits, min_score, print_seq, print_qual), out, cap);
+}
+extern "C" int64_t cmb_sam_se_xa(const char* read_id, const cmb_sam_hit* hits, uint32_t n, uint32_t n_hits, const char* print_seq,
+                                 const char* print_qual, char* out, uint64_t cap) {
+    if (!read_id || !hits || n == 0 || !print_seq || !print_qual) return fail(CMB_ERR_INVALID, "null argument");
+    std::vector<SamHit> v;
+    for (uint32_t i = 0; i < n; i++) v.push_back(toHit(hits[i]));
+    return putString(samLineSEWithXA(read_id, v, n_hits, print_seq, print_qual), out, cap);
+}
+extern "C" int64_t cmb_sam_unmapped_se(const char* read_id, const char* seq, const char* qual, char* out, uint64_t cap) {
+    if (!read_id || !seq || !qual) return fail(CMB_ERR_INVALID, "null argument");
+    return putString(samLineUnmappedSE(read_id, seq, qual), out, cap);
+}
+extern "C" int cmb_read_prepare(const char* id, const char* seq, const char* qual, char* id_out, char* seq_out, char* revcomp_out,
+                                char* revqual_out) {
+    if (!id || !seq) return fail(CMB_ERR_INVALID, "null argument");
+    const std::string cid = cleanSeqID(id), cs = cleanReadSeq(seq), rc = revComplWithN(cs);
+    std::string rq = qual ? qual : "";
+    std::reverse(rq.begin(), rq.end());
+    if (id_out) memcpy(id_out, cid.c_str(), cid.size() + 1);
+    if (seq_out) memcpy(seq_out, cs.c_str(), cs.size() + 1);
+    if (revcomp_out) memcpy(revcomp_out, rc.c_str(), rc.size() + 1);
+    if (revqual_out) memcpy(revqual_out, rq.c_str(), rq.size() + 1);
+    return CMB_OK;
 }
 
 // ------------------------------------------------------------------------- fine-grained hooks
@@ -1505,9 +1641,26 @@ extern "C" int cmb_verify_batch_staged(cmb_index* idx, const char* pattern, uint
 // in-text verification hook: FMIndex::inTextVerification(startPos, maxED, minED, ..., pattern,
 // fixedStartPos) (fmindex.cpp:267-310) for one pattern.  Runs the production k_prep + k_verify on a
 // one-read batch whose items carry the start positions directly (meta bit 23: nothing to locate).
+static int verifyDirect(cmb_index* idx, const char* pattern, uint32_t plen, const uint32_t* starts, const uint32_t* ends,
+                        uint64_t n, uint32_t max_ed, uint32_t min_ed, int fixed_start, cmb_occ* out, uint64_t out_cap,
+                        uint64_t* n_out, uint64_t* counters);
 extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t plen, const uint32_t* starts,
                                 uint64_t n, uint32_t max_ed, uint32_t min_ed, int fixed_start, cmb_occ* out,
                                 uint64_t out_cap, uint64_t* n_out, uint64_t* counters) {
+    return verifyDirect(idx, pattern, plen, starts, nullptr, n, max_ed, min_ed, fixed_start, out, out_cap, n_out, counters);
+}
+// FMIndex::inTextVerificationOneString (fmindex.cpp:312-342): the pattern against ONE text window [start, end) with a
+// fixed start (one zero in the first column) — what IndexInterface::findSeqName runs on an occurrence it has trimmed
+// to the sequence it lies in (indexinterface.cpp:850-866)
+extern "C" int cmb_verify_window(cmb_index* idx, const char* pattern, uint32_t plen, uint32_t start, uint32_t end,
+                                 uint32_t max_ed, uint32_t min_ed, cmb_occ* out, uint64_t out_cap, uint64_t* n_out,
+                                 uint64_t* counters) {
+    if (end <= start) return fail(CMB_ERR_INVALID, "empty text window");
+    return verifyDirect(idx, pattern, plen, &start, &end, 1, max_ed, min_ed, 1, out, out_cap, n_out, counters);
+}
+static int verifyDirect(cmb_index* idx, const char* pattern, uint32_t plen, const uint32_t* starts, const uint32_t* ends,
+                        uint64_t n, uint32_t max_ed, uint32_t min_ed, int fixed_start, cmb_occ* out, uint64_t out_cap,
+                        uint64_t* n_out, uint64_t* counters) {
     if (!idx || !pattern || (n && !starts) || !n_out) return fail(CMB_ERR_INVALID, "null argument");
     if (plen == 0 || plen > (uint32_t)MAX_READ) return fail(CMB_ERR_UNSUPPORTED, "pattern length not supported");
     if (3 * max_ed + 1 > MX_LEFT || min_ed > 15) return fail(CMB_ERR_UNSUPPORTED, "needs the 128-bit matrix");
@@ -1533,7 +1686,7 @@ extern "C" int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t pl
         std::vector<uint4> hi(n);
         const uint32_t meta = (max_ed << 12) | (min_ed << 16) | ((fixed_start ? 1u : 0u) << 20) |
                               ((uint32_t)ITEM_EDIT << 21) | (1u << 23);
-        for (uint64_t i = 0; i < n; i++) hi[i] = make_uint4(0, starts[i], 0, meta);
+        for (uint64_t i = 0; i < n; i++) hi[i] = make_uint4(0, starts[i], ends ? ends[i] : 0u, meta);
         items.upload(hi.data(), n);
         // (every wavefront of k_verify / k_traceback may leave one partly used chunk of 256 records)
         const size_t cap = n * 32 + 64 + 2 * (std::min<uint64_t>(std::max<uint64_t>(((n + 255) / 256) * 256, 256), 65536) / 64 + 1) * 256;

@@ -832,7 +832,8 @@ __host__ __device__ __forceinline__ uint32_t verifyKeyStart(unsigned long long k
 __device__ __forceinline__ bool verifyEdit(const DevIndex& ix, const uint64_t* offs, const MFull& mf,
                                            uint32_t rs, uint32_t start, uint32_t maxED, uint32_t minED, uint32_t fixed,
                                            uint32_t mult, uint32_t& cStarted, uint32_t& cRows, uint32_t& cText,
-                                           uint32_t& cAbort, uint32_t& cCig, uint4& tbRec, uint64_t* Ml) {
+                                           uint32_t& cAbort, uint32_t& cCig, uint4& tbRec, uint64_t* Ml,
+                                           uint32_t limitEnd = 0 /* explicit end of the text window (inTextVerificationOneString) */) {
     cStarted += mult;
     const uint32_t len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
     const uint32_t nZeros = fixed ? 1u : 2u * maxED + 1u;
@@ -843,7 +844,7 @@ __device__ __forceinline__ bool verifyEdit(const DevIndex& ix, const uint64_t* o
     g.Wh = maxED;
     g.m = g.Wv + g.n;
     const uint32_t maxEnd = ix.n - 1;
-    const uint32_t hEnd = min(maxEnd, start + g.m - 1);
+    const uint32_t hEnd = limitEnd ? min(maxEnd, limitEnd) : min(maxEnd, start + g.m - 1);
     const uint32_t size = hEnd > start ? hEnd - start : 0;
     if (!g.inFinalColumn(size)) return false;
     uint32_t mask = 0, rows = 0;
@@ -989,13 +990,14 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
                 }
             } else {
                 // ---- edit distance: FMIndex::inTextVerification + InTextVerificationTask::doTask
-                const uint32_t startDiff = a;
+                const bool direct = (meta >> 23) & 1u; // (hooks: `a` is the explicit end of the window, or 0)
+                const uint32_t startDiff = direct ? 0u : a;
                 const uint32_t sum = pos + shift; // getBeginPositions (fmindex.h:374-379)
                 const uint32_t start = sum >= startDiff ? sum - startDiff : 0;
                 if (KEYS) { // verified once per distinct key by k_verify_stage
                     vkey = packVerifyKey(rs, start, maxED, minED, fixed);
                 } else if (verifyEdit(ix, offs, mf, rs, start, maxED, minED, fixed, 1u, cStarted, cRows, cText, cAbort,
-                                      cCig, tbRec, Ml)) {
+                                      cCig, tbRec, Ml, direct ? a : 0u)) {
                     nTb = 1;
                 }
             }
@@ -1574,7 +1576,8 @@ k_filter_mark(const unsigned long long* __restrict__ keys, uint32_t nReads, uint
 }
 __global__ void __launch_bounds__(256)
 k_filter_write(const unsigned long long* __restrict__ keys, uint32_t n, const uint64_t* __restrict__ offs, uint32_t k,
-               const uint32_t* __restrict__ rank, const uint64_t* __restrict__ outOffs, uint4* __restrict__ out) {
+               const uint32_t* __restrict__ rank, const uint64_t* __restrict__ outOffs, uint4* __restrict__ out,
+               uint32_t* __restrict__ outRead /* read of every occurrence, or null */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t rk = rank[i];
@@ -1585,6 +1588,176 @@ k_filter_write(const unsigned long long* __restrict__ keys, uint32_t n, const ui
     const uint32_t begin = (uint32_t)(key >> 8), dist = (uint32_t)(key >> 5) & 7u;
     const uint32_t width = len - k + ((uint32_t)(key >> 1) & 15u), strand = (uint32_t)key & 1u;
     out[outOffs[r] + rk] = make_uint4(begin, begin + width, dist, strand);
+    if (outRead) outRead[outOffs[r] + rk] = r;
+}
+
+// ------------------------------------------------------------------ alignments of the final occurrences (§8f rank 1)
+// CIGAR of every occurrence that left the filter = IBitParallelED::findCIGAR (bitparallelmatrix.h:460-527): the read
+// is aligned with text[begin, end) on a fresh matrix (maxED = the occurrence's distance, first column 0, 1, 2, ...:
+// exactly an in-text verification with a fixed start) and traced back from the last cell — horizontal (I) before
+// diagonal (M) before vertical (D).  The reference gives in-text occurrences the CIGAR of their verification's
+// traceBack (:531-586) instead; that is the same string: along the traced path both matrices hold the same values
+// and take the same decisions (tests/test_oracle_golden.py checks it on the reference's own traceback vectors).
+// Output per occurrence: n runs of (length << 2 | op), op 0 M / 1 I / 2 D, stored END to BEGIN at ops[occ * stride + j].
+// Sequence assignment (IndexInterface::findSeqName, indexinterface.cpp:799-832): seq = the sequence `begin` lies in;
+// spans = the occurrence runs over its end (the host trims or drops those, :833-899).
+struct AlnRec {
+    uint32_t seqId, seqBegin, nOps, spans;
+};
+constexpr uint32_t CIG_M = 0, CIG_I = 1, CIG_D = 2;
+template <bool NARROW, bool PACKED>
+__global__ void __launch_bounds__(256)
+k_cigar(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf, const uint4* __restrict__ occs,
+        const uint32_t* __restrict__ occRead, uint64_t nOcc, VPlanes V, const uint32_t* __restrict__ seqStarts, uint32_t nSeqs,
+        uint16_t* __restrict__ ops, uint32_t stride, AlnRec* __restrict__ aln, uint32_t* __restrict__ flagWord,
+        uint32_t gapless /* Hamming distance / exact matches: every CIGAR is <len>M (fmindex.cpp:367, indexinterface.cpp:988) */) {
+    __shared__ uint64_t wW[NARROW ? 1 : TBW][256];
+    __shared__ uint32_t wN[NARROW ? 16 : 1][256];
+    __shared__ uint64_t Ml[ML_WORDS];
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    uint32_t flags = 0, dummyRows = 0;
+    const uint64_t strideT = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t HP0 = (~0ull) << MX_LEFT;
+    for (uint64_t base = slot & ~63u; base < nOcc; base += strideT) { // wave-uniform trip count
+        const uint64_t it = base + (tid & 63u);
+        uint4 o = make_uint4(0, 0, 0, 0);
+        uint32_t rs = 0, len = 0, size = 0, col = 0;
+        bool have = false;
+        if (it < nOcc) {
+            o = occs[it];
+            rs = 2u * occRead[it] + (o.w & 1u);
+            len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
+            size = o.y - o.x;
+            have = true;
+            // sequence of the occurrence: last start position <= begin (upper_bound - 1)
+            uint32_t lo = 0, hi = nSeqs; // seqStarts[0] == 0; seqStarts[nSeqs] = end of the last sequence
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (seqStarts[mid] <= o.x) lo = mid;
+                else hi = mid;
+            }
+            aln[it].seqId = lo;
+            aln[it].seqBegin = o.x - seqStarts[lo];
+            aln[it].spans = o.y > seqStarts[lo + 1] ? 1u : 0u;
+        }
+        const uint32_t maxED = o.z;
+        MatGeom g;
+        g.n = len + 1;
+        g.maxED = maxED;
+        g.Wv = maxED;
+        g.Wh = maxED;
+        g.m = g.Wv + g.n;
+        col = len;
+        bool trace = have && maxED > 0 && size > 0 && !gapless;
+        if (trace && NARROW && maxED > TBN_MAX_ED) { // (the host picks the wide kernel for k > 4)
+            flags |= FLAG_CAPACITY;
+            trace = false;
+        }
+        uint32_t dummyMask;
+        uint64_t ep, eph;
+        // rows 1..size of the fresh matrix (all valid: an alignment within maxED exists), trace rows to the lane's slab
+        const uint32_t rowsDone = forwardPass<true, NARROW, PACKED>(ix, mf, rs, g, 1u, o.x, trace ? size : 0u, maxED, 0, dummyMask,
+                                                                    ep, eph, V, slot, dummyRows, Ml);
+        if (trace && rowsDone < size) { // (a row without a cell <= maxED: the occurrence is not an alignment within its distance)
+            flags |= FLAG_CAPACITY;
+            trace = false;
+        }
+        uint32_t nOps = 0;
+        uint16_t* myOps = ops + it * stride;
+        if (have && !trace) { // distance 0 (or an empty range): len x M
+            if (len) myOps[nOps++] = (uint16_t)((len << 2) | CIG_M);
+        }
+        if (trace) {
+            uint32_t ti = size, tj = col;
+            uint32_t curG = 0xFFFFFFFFu, state = 3u, run = 0;
+            auto emit = [&](uint32_t op) {
+                if (op != state) {
+                    if (run) {
+                        if (nOps < stride) myOps[nOps] = (uint16_t)((run << 2) | state);
+                        nOps++;
+                    }
+                    state = op;
+                    run = 0;
+                }
+                run++;
+            };
+            while (tj > 0) {
+                const uint32_t rel = tj + TB_BELOW - ti;
+                bool hpBit, dgBit;
+                if (NARROW) {
+                    uint32_t wn = packTraceRowNarrow(0, (~0u) << MX32_LEFT, 0u);
+                    if (ti > 0) {
+                        const uint32_t gq = (ti - 1) >> 4, jq = (ti - 1) & 15u;
+                        if (gq != curG) {
+                            curG = gq;
+                            const uint4* L = reinterpret_cast<const uint4*>(V.W) + ((size_t)slot * V.lines + gq) * 4;
+#pragma unroll
+                            for (int h = 0; h < 4; h++) {
+                                const uint4 v = L[h];
+                                wN[4 * h][tid] = v.x;
+                                wN[4 * h + 1][tid] = v.y;
+                                wN[4 * h + 2][tid] = v.z;
+                                wN[4 * h + 3][tid] = v.w;
+                            }
+                        }
+                        wn = wN[jq][tid];
+                    }
+                    if (rel < TBN_REL_LO || rel > TBN_REL_HI) {
+                        flags |= FLAG_CAPACITY;
+                        break;
+                    }
+                    hpBit = rel >= TBN_HP_LO && ((wn >> (rel - TBN_HP_LO)) & 1u);
+                    dgBit = rel == TBN_REL_HI || ((wn >> (16u + rel - TBN_DG_LO)) & 1u);
+                } else {
+                    uint64_t ww = packTraceRow(0, HP0, 0ull);
+                    if (ti > 0) {
+                        const uint32_t gq = (ti - 1) >> 3, jq = (ti - 1) & 7u;
+                        if (gq != curG) {
+                            curG = gq;
+                            const uint4* L = reinterpret_cast<const uint4*>(V.W) + ((size_t)slot * V.lines + gq) * 4;
+#pragma unroll
+                            for (int h = 0; h < 4; h++) {
+                                const uint4 v = L[h];
+                                wW[2 * h][tid] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                                wW[2 * h + 1][tid] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+                            }
+                        }
+                        ww = wW[jq][tid];
+                    }
+                    if (rel > 31u) {
+                        flags |= FLAG_CAPACITY;
+                        break;
+                    }
+                    hpBit = ((uint32_t)ww >> rel) & 1u;
+                    dgBit = ((uint32_t)(ww >> 32) >> rel) & 1u;
+                }
+                if (hpBit) { // gap in horizontal direction: insertion (:488-494)
+                    --tj;
+                    emit(CIG_I);
+                } else if (ti > 0 && dgBit) { // diagonal (:496-506)
+                    --tj;
+                    --ti;
+                    emit(CIG_M);
+                } else { // gap in vertical direction (:508-514)
+                    if (ti == 0) { // (cannot happen: row 0 only has horizontal steps)
+                        flags |= FLAG_CAPACITY;
+                        break;
+                    }
+                    --ti;
+                    emit(CIG_D);
+                }
+            }
+            for (; ti > 0; --ti) emit(CIG_D); // findCIGAR walks on to (0, 0): leading deletions
+            if (run) {
+                if (nOps < stride) myOps[nOps] = (uint16_t)((run << 2) | state);
+                nOps++;
+            }
+            if (nOps > stride) flags |= FLAG_CAPACITY;
+        }
+        if (have) aln[it].nOps = nOps;
+    }
+    if (flags) atomicOr(flagWord, flags);
 }
 
 } // namespace cmb

@@ -192,10 +192,52 @@ int cmb_batch_run(cmb_batch* b);  /* enqueue + wait: the whole hot path on the b
 int cmb_batch_result_size(const cmb_batch* b, uint64_t* n_occ);
 int cmb_batch_results(const cmb_batch* b, cmb_occ* out, uint64_t out_cap, uint64_t* out_offs,
                       uint64_t* counters);
+/* Alignments of the final occurrences: before cmb_batch_run, ask for them; after it,
+ * cmb_batch_alignments gives, parallel to the cmb_occ list, for every occurrence
+ *  - its CIGAR as run-length operations (IBitParallelED::findCIGAR, bitparallelmatrix.h:460-527 — for in-text
+ *    occurrences the same string as their verification's traceBack, :531-586): cigar_len values of
+ *    (length << 2 | op), op 0 = M, 1 = I, 2 = D, from the begin of the alignment, at cigar_ops[cigar_off ...];
+ *  - the reference sequence it lies in and its 0-based begin inside it (IndexInterface::findSeqName,
+ *    indexinterface.cpp:799-832); spans != 0: the occurrence runs past the end of that sequence (the reference then
+ *    trims and re-verifies, or drops it: :833-899 — the C++ adapter does that with cmb_verify_window). */
+typedef struct {
+    uint32_t seq_id, seq_begin;
+    uint64_t cigar_off;
+    uint16_t cigar_len, spans;
+    uint32_t reserved;
+} cmb_aln;
+int cmb_batch_want_alignments(cmb_batch* b, int on);
+int cmb_batch_alignments(const cmb_batch* b, cmb_aln* out, uint64_t cap, uint16_t* cigar_ops, uint64_t ops_cap,
+                         uint64_t* n_ops);
 /* per-kernel device time of the last cmb_batch_run, measured with hipEvents on the batch's own
  * stream.  names: NUL-separated list; ms[n]. Returns number of kernels. */
 int cmb_batch_timings(const cmb_batch* b, const char** names, float* ms, uint32_t cap);
 void cmb_batch_destroy(cmb_batch* b);
+
+/* --- output records (host-only; no GPU needed) -----------------------------------------
+ * SAM lines of single-end reads as the reference formats them (TextOcc::generateSAMSingleEnd / ...XA /
+ * createUnmappedSAMOccurrenceSE, src/indexhelpers.cpp:56-120, :177-200; flags, mapping quality and XA entries:
+ * src/indexhelpers.h:321-331, :378-388, :416-421).  Every function returns the length of the line (without the
+ * terminating NUL) and writes it, NUL-terminated, if cap is larger than that. */
+typedef struct {
+    const char* seq_name;       /* reference sequence the occurrence lies in */
+    uint32_t pos0;              /* 0-based begin inside that sequence (cmb_aln.seq_begin) */
+    uint32_t distance;
+    uint32_t revcomp;           /* cmb_occ.strand */
+    const uint16_t* cigar_ops;  /* run-length operations of cmb_batch_alignments */
+    uint32_t n_ops;
+} cmb_sam_hit;
+int64_t cmb_sam_se(const char* read_id, const cmb_sam_hit* hit, int primary, uint32_t n_hits, uint32_t min_score,
+                   const char* print_seq, const char* print_qual, char* out, uint64_t cap);
+/* the first hit as the record, the others in its XA tag (generateSE_SAM_XATag, src/searchstrategy.h:1612-1622) */
+int64_t cmb_sam_se_xa(const char* read_id, const cmb_sam_hit* hits, uint32_t n, uint32_t n_hits, const char* print_seq,
+                      const char* print_qual, char* out, uint64_t cap);
+int64_t cmb_sam_unmapped_se(const char* read_id, const char* seq, const char* qual, char* out, uint64_t cap);
+/* Read::cleanUpRecord + ReadBundle (src/reads.h:43-58, :97-160): identifier without its first character and without
+ * anything from the first space on; upper-case sequence with every non-ACGT character replaced by N; its reverse
+ * complement; the reversed quality string.  Output buffers hold strlen(input) + 1 bytes each (any may be NULL). */
+int cmb_read_prepare(const char* id, const char* seq, const char* qual, char* id_out, char* seq_out, char* revcomp_out,
+                     char* revqual_out);
 
 /* --- fine-grained hooks (parity tests + roofline microbenchmark) ------------------- */
 /* BitvecIntl<4>::rank(c,p) (bitvec.h:356), rev = 0 forward BWT / 1 reverse BWT */
@@ -219,6 +261,10 @@ int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t plen, const u
                      uint64_t n, uint32_t max_ed, uint32_t min_ed, int fixed_start, cmb_occ* out,
                      uint64_t out_cap, uint64_t* n_out, uint64_t* counters);
 
+/* FMIndex::inTextVerificationOneString (fmindex.cpp:312-342): one text window [start, end), fixed start */
+int cmb_verify_window(cmb_index* idx, const char* pattern, uint32_t plen, uint32_t start, uint32_t end,
+                      uint32_t max_ed, uint32_t min_ed, cmb_occ* out, uint64_t out_cap, uint64_t* n_out,
+                      uint64_t* counters);
 /* the same through the PRODUCTION edit-distance path (keys, de-duplication of identical candidates with counters
  * scaled by their multiplicity, staged matrix blocks, traceback): what cmb_batch_run does with the in-text candidates
  * of a search; cmb_verify_batch runs the one-candidate-per-lane kernel used for Hamming / exact candidates */

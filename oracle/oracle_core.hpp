@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <array>
 #include <cassert>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -451,6 +452,46 @@ inline std::string cleanReadSeq(const std::string& s) {
 }
 
 // ----------------------------------------------------------------------------
+// SAM records of single-end reads (indexhelpers.cpp:56-120, :177-200; indexhelpers.h:321-331, :378-388, :416-421)
+// ----------------------------------------------------------------------------
+struct SamOcc {
+    std::string seqName, cigar;
+    len_t begin = 0, distance = 0; // begin: 0-based inside the assigned sequence
+    bool revCompl = false;
+};
+inline int samMapQ(len_t distance, len_t nHits, len_t minScore) {
+    if (distance != minScore) return 0;
+    if (nHits == 1) return 60; // MAX_MAPQ, definitions.h:49
+    return (int)std::round(-10.0 * std::log10(1 - 1.0 / nHits));
+}
+inline std::string samSingleEnd(const std::string& seqID, const SamOcc& t, const std::string& printSeq,
+                                const std::string& printQual, len_t nHits, len_t minScore, bool primary) {
+    std::ostringstream o;
+    const unsigned flags = ((unsigned)t.revCompl << 4) | ((unsigned)!primary << 8);
+    o << seqID << '\t' << flags << '\t' << t.seqName << '\t' << (t.begin + 1) << '\t' << samMapQ(t.distance, nHits, minScore)
+      << '\t' << t.cigar << "\t*\t0\t0\t" << printSeq << '\t' << printQual << "\tAS:i:" << t.distance << "\tNM:i:"
+      << t.distance << "\tPG:Z:Columba\n";
+    return o.str();
+}
+inline std::string samSingleEndXA(const std::string& seqID, const std::vector<SamOcc>& occs, const std::string& printSeq,
+                                  std::string printQual, len_t nHits) {
+    if (printQual.empty()) printQual = "*";
+    std::string line = samSingleEnd(seqID, occs[0], printSeq, printQual, nHits, occs[0].distance, true);
+    line.pop_back();
+    const len_t x0 = nHits - 1, x1 = (len_t)(occs.size() - 1) - x0;
+    std::ostringstream o;
+    o << line << "\tX0:i:" << x0 << "\tX1:i:" << x1 << "\tXA:Z:";
+    for (size_t i = 1; i < occs.size(); i++)
+        o << occs[i].seqName << ',' << (occs[i].revCompl ? '-' : '+') << (occs[i].begin + 1) << ',' << occs[i].cigar << ','
+          << occs[i].distance << ';';
+    o << "\n";
+    return o.str();
+}
+inline std::string samUnmappedSE(const std::string& seqID, const std::string& read, const std::string& qual) {
+    return seqID + "\t4\t*\t0\t0\t*\t*\t0\t0\t" + read + "\t" + qual + "\tPG:Z:Columba\n";
+}
+
+// ----------------------------------------------------------------------------
 // SparseSuffixArray (fmindex/suffixArray.h:160-243): rows whose suffix-array value is a
 // multiple of the sparseness factor are marked in a rank9 Bitvec (.sa.bv.<s>: N, words,
 // counts — bitvec.h:176-185) and their values stored in row order (.sa.<s>, raw length_t).
@@ -658,6 +699,37 @@ class BitParallelED64 {
         }
         refBegin = i;
         if (cigar) cigar->assign(v.rbegin(), v.rend());
+    }
+    // bitparallelmatrix.h:460-527: align the sequence with `ref` on a fresh matrix (maxED = score) and trace back from the
+    // last cell to (0, 0); CIGAR as (op, len) pairs in forward order
+    void findCIGAR(const Substring& ref, uint32_t score, std::vector<std::pair<char, uint32_t>>& cigar) {
+        initializeMatrix(score);
+        for (uint32_t i = 0; i < ref.size(); i++) computeRow(i + 1, ref.forwardAccessor(i));
+        uint32_t i = ref.size(), j = n - 1;
+        std::vector<std::pair<char, uint32_t>> v;
+        char state = 0;
+        while (j > 0 || i > 0) {
+            const uint32_t b = i / BLOCK_SIZE;
+            const uint64_t bit = 1ull << ((j - b * BLOCK_SIZE) + DIAG_R0);
+            char op;
+            if ((j > 0) && (bv[i].HP & bit)) {
+                --j;
+                op = 'I';
+            } else if (i > 0 && j > 0 && ((mv[b][char2idx(ref.forwardAccessor(i - 1))] | ~bv[i].D0) & bit)) {
+                --i;
+                --j;
+                op = 'M';
+            } else {
+                --i;
+                op = 'D';
+            }
+            if (state != op) {
+                v.emplace_back(op, 0);
+                state = op;
+            }
+            v.back().second++;
+        }
+        cigar.assign(v.rbegin(), v.rend());
     }
     const BitVectors& row(uint32_t i) const { return bv[i]; }
     uint32_t getWv() const { return Wv; }

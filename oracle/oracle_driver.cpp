@@ -334,6 +334,56 @@ int main() {
                     if (c == '\n') c = '~';
                 os << "error " << m;
             }
+        } else if (cmd == "findcigar") {
+            string X, Y;
+            uint32_t score;
+            in >> X >> Y >> score;
+            BitParallelED64 M;
+            M.setSequence(Substring(X.data(), (len_t)X.size(), 0, (len_t)X.size(), FORWARD));
+            Substring ref(Y.data(), (len_t)Y.size(), 0, (len_t)Y.size(), FORWARD);
+            vector<pair<char, uint32_t>> cig;
+            M.findCIGAR(ref, score, cig);
+            os << (cig.empty() ? string("*") : cigarStr(cig));
+        } else if (cmd == "sam1" || cmd == "samxa" || cmd == "samun") {
+            const vector<string> seqNames = {"chr1", "chr2_alt", "seqC"};
+            string id, rd, ql;
+            in >> id >> rd >> ql;
+            if (ql == "-") ql = "";
+            const string sid = cleanSeqID(id), read = cleanReadSeq(rd), rc = Matcher::revCompl(read);
+            string rq = ql;
+            std::reverse(rq.begin(), rq.end());
+            auto readOcc = [&]() {
+                uint32_t b, e, d, st, sq;
+                string cg;
+                in >> b >> e >> d >> cg >> st >> sq;
+                SamOcc t;
+                t.seqName = seqNames[sq];
+                t.cigar = cg;
+                t.begin = b;
+                t.distance = d;
+                t.revCompl = st != 0;
+                return t;
+            };
+            string line;
+            if (cmd == "samun") {
+                line = samUnmappedSE(sid, read, ql);
+            } else if (cmd == "sam1") {
+                uint32_t nHits, minScore, primary;
+                in >> nHits >> minScore >> primary;
+                SamOcc t = readOcc();
+                line = primary ? samSingleEnd(sid, t, t.revCompl ? rc : read, t.revCompl ? rq : ql, nHits, minScore, true)
+                               : samSingleEnd(sid, t, "*", "*", nHits, minScore, false);
+            } else {
+                uint32_t nHits, n;
+                in >> nHits >> n;
+                vector<SamOcc> occs;
+                for (uint32_t i = 0; i < n; i++) occs.push_back(readOcc());
+                line = samSingleEndXA(sid, occs, occs[0].revCompl ? rc : read, occs[0].revCompl ? rq : ql, nHits);
+            }
+            for (auto& c : line)
+                if (c == '\t') c = '|';
+                else if (c == '\n') c = '~';
+            os << line;
         } else if (cmd == "consts") {
             os << BitParallelED64::MATRIX_MAX_ED << ' ' << BitParallelED64::LEFT << ' ' << 13 << ' ' << 10
                << ' ' << 4 << ' ' << sizeof(len_t);

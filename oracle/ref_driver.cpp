@@ -396,6 +396,56 @@ int main() {
                     if (c == '\n') c = '~';
                 os << "error " << m;
             }
+        } else if (cmd == "findcigar") { // X Y score: IBitParallelED::findCIGAR (bitparallelmatrix.h:460-527), Y = text[begin, end)
+            string X, Y;
+            uint32_t score;
+            in >> X >> Y >> score;
+            BitParallelED64 M;
+            Substring sx(X, FORWARD);
+            M.setSequence(sx);
+            Substring ref(Y, FORWARD);
+            string cig;
+            M.findCIGAR(ref, score, cig);
+            os << (cig.empty() ? "*" : cig);
+        } else if (cmd == "sam1" || cmd == "samxa" || cmd == "samun") {
+            // SAM records of single-end reads (indexhelpers.cpp:56-120, :177-200; indexhelpers.h:321-331, :378-388, :416-421,
+            // :625-680): tabs are printed as '|'
+            const vector<string> seqNames = {"chr1", "chr2_alt", "seqC"};
+            string id, rd, ql;
+            in >> id >> rd >> ql;
+            if (ql == "-") ql = "";
+            Read r(id, rd, ql);
+            ReadBundle bundle(r);
+            auto readOcc = [&]() {
+                uint32_t b, e, d, st, sq;
+                string cg;
+                in >> b >> e >> d >> cg >> st >> sq;
+                TextOcc t(Range(b, e), d, cg, st ? REVERSE_C_STRAND : FORWARD_STRAND, FIRST_IN_PAIR);
+                t.setAssignedSequence(FOUND, sq);
+                return t;
+            };
+            string line;
+            if (cmd == "samun") {
+                line = TextOcc::createUnmappedSAMOccurrenceSE(bundle).getOutputLine();
+            } else if (cmd == "sam1") {
+                uint32_t nHits, minScore, primary;
+                in >> nHits >> minScore >> primary;
+                TextOcc t = readOcc();
+                if (primary) t.generateSAMSingleEndFirst(bundle, nHits, minScore, seqNames);
+                else t.generateSAMSingleEndNotFirst(bundle.getSeqID(), nHits, minScore, seqNames);
+                line = t.getOutputLine();
+            } else {
+                uint32_t nHits, n;
+                in >> nHits >> n;
+                vector<TextOcc> occs;
+                for (uint32_t i = 0; i < n; i++) occs.emplace_back(readOcc());
+                occs.front().generateSAMSingleEndXA(bundle, nHits, occs.front().getDistance(), occs.begin() + 1, occs.end(), seqNames);
+                line = occs.front().getOutputLine();
+            }
+            for (auto& c : line)
+                if (c == '\t') c = '|';
+                else if (c == '\n') c = '~';
+            os << line;
         } else if (cmd == "consts") {
             os << BitParallelED64::getMatrixMaxED() << ' ' << BitParallelED64::getMaxFirstColRows() << ' '
                << MAX_K << ' ' << CIGAR_THRESHOLD << ' ' << DEFAULT_SPARSENESS << ' ' << sizeof(length_t);

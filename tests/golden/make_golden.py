@@ -313,6 +313,74 @@ for fn in sorted(os.listdir(os.path.join(HERE, "bad_schemes"))):
     cmds.append(f"readscheme bad_schemes/{fn} 2")
 cmds.append("readscheme bad_schemes/does_not_exist.txt 2")
 
+# f1: findCIGAR (the CIGAR of in-index occurrences and of every occurrence without one) on alignments of 0..6 edits,
+# incl. indels at both ends; SAM records of single-end reads
+rng3 = random.Random(20261005)
+
+
+def mutate3(s, nedits):
+    s = list(s)
+    for _ in range(nedits):
+        p = rng3.randrange(len(s))
+        u = rng3.random()
+        if u < 0.5:
+            s[p] = rng3.choice([c for c in ACGT if c != s[p]])
+        elif u < 0.75:
+            s.insert(p, rng3.choice(ACGT))
+        elif len(s) > 2:
+            del s[p]
+    return "".join(s)
+
+
+for _ in range(200):
+    X = "".join(rng3.choice(ACGT) for _ in range(rng3.choice([20, 36, 50, 100, 150, 250])))
+    k = rng3.randint(0, 6)
+    Y = mutate3(X, k)
+    if rng3.random() < 0.2 and k:   # edits packed at an end
+        cut = rng3.randint(1, k)
+        Y = (Y[cut:] if rng3.random() < 0.5 else Y[:-cut]) if len(Y) > cut + 5 else Y
+    # the score the occurrence carries: its true distance or (in-index occurrences, see findCIGAR's comment) a bit more
+    import itertools
+
+    def ed(a, b):
+        prev = list(range(len(b) + 1))
+        for i, ca in enumerate(a, 1):
+            cur = [i]
+            for j, cb in enumerate(b, 1):
+                cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+            prev = cur
+        return prev[-1]
+    d = ed(X, Y)
+    if d > 6:
+        continue
+    score = d + (rng3.randint(0, 2) if rng3.random() < 0.2 else 0)
+    if "N" not in X and rng3.random() < 0.1:
+        p = rng3.randrange(len(X))
+        X = X[:p] + "N" + X[p + 1:]
+        score = min(score + 1, 8)
+    cmds.append(f"findcigar {X} {Y} {min(score, 8)}")
+
+CIGS = ["100M", "57M1I42M", "3M1D97M", "1I99M", "99M1D", "20M2I30M1D48M", "150M", "36M"]
+for _ in range(60):
+    rid = rng3.choice("@>") + "".join(rng3.choice("readXY019:/") for _ in range(rng3.randint(1, 10)))
+    ln = rng3.randint(4, 40)
+    rd = "".join(rng3.choice("ACGTNacgt") for _ in range(ln))
+    ql = "".join(chr(rng3.randint(33, 73)) for _ in range(ln)) if rng3.random() < 0.85 else "-"
+
+    def occ():
+        b = rng3.randint(0, 100000)
+        return f"{b} {b + ln} {rng3.randint(0, 6)} {rng3.choice(CIGS)} {rng3.randint(0, 1)} {rng3.randint(0, 2)}"
+    u = rng3.random()
+    if u < 0.5:
+        d = rng3.randint(0, 6)
+        cmds.append(f"sam1 {rid} {rd} {ql} {rng3.randint(1, 40)} {rng3.choice([d, d, max(0, d - 1)])} {rng3.randint(0, 1)} "
+                    + occ().replace(f" {d} ", f" {d} ", 1))
+    elif u < 0.9:
+        n = rng3.randint(1, 6)
+        cmds.append(f"samxa {rid} {rd} {ql} {rng3.randint(1, n)} {n} " + " ".join(occ() for _ in range(n)))
+    else:
+        cmds.append(f"samun {rid} {rd} {ql if ql != '-' else '*'}")
+
 
 def main():
     if not os.path.exists(DRIVER):

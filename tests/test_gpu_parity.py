@@ -357,3 +357,61 @@ def test_errors_are_loud(world):
     # empty batch is fine
     occ, offs, _ = ca.match_batch(world["dev"], st, 4, [])
     assert len(occ) == 0 and offs.tolist() == [0]
+
+
+@pytest.mark.parametrize("spec,metric,k", [("multiple_opt", "edit", 4), ("columba", "edit", 6), ("kuch1", "edit", 2),
+                                           ("kuch1", "hamming", 3), ("kuch1", "edit", 0)])
+def test_alignments_cigar_and_sequence(world, oracle_built, spec, metric, k):
+    """SURVEY.md §8f rank 1 on the device: the CIGAR of every final occurrence (k_cigar) is what the reference's
+    findCIGAR gives for (read on its strand, text[begin, end), distance) — asked of the oracle's restatement, which is
+    pinned to the reference's findCIGAR by the golden vectors — and the sequence assignment is findSeqName's."""
+    import os
+    import subprocess
+    g = world["genome"]
+    reads = synth.sample_reads(g, 1500, 150, seed=700 + k, n_frac=0.01)
+    # reads across sequence boundaries and with edits at their very ends
+    starts = np.asarray(world["ix"].seq_starts, dtype=np.int64)
+    for s in starts[1:-1][:20]:
+        reads.append(g[int(s) - 70:int(s) + 80].tobytes())
+    reads += _edge_reads(g, 200, max(k, 1), seed=71)
+    b = ca.Batch(world["dev"], ca.SearchStrategy(spec, metric, "dynamic"), k, reads)
+    b.want_alignments()
+    b.run()
+    occ, offs, _ = b.results()
+    aln, ops = b.alignments()
+    assert len(aln) == len(occ) > (1000 if k else 300)
+    text = g.tobytes()
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    cmds, who = [], []
+    for i, r in enumerate(reads):
+        fw = bytes(c if c in b"ACGT" else ord("N") for c in r.upper())
+        rc = fw.translate(comp)[::-1]
+        for j in range(int(offs[i]), int(offs[i + 1])):
+            o = occ[j]
+            seq = rc if o["strand"] else fw
+            if metric == "edit" and k > 0:
+                cmds.append(f"findcigar {seq.decode()} {text[int(o['begin']):int(o['end'])].decode()} {int(o['distance'])}")
+                who.append(j)
+            else:   # Hamming / exact occurrences: no gaps
+                assert ca.cigar_string(ops[int(aln[j]['cigar_off']):int(aln[j]['cigar_off']) + int(aln[j]['cigar_len'])]) == f"{len(r)}M"
+    if cmds:
+        res = subprocess.run([os.path.join(oracle_built, "oracle_driver")], input="\n".join(cmds) + "\n", capture_output=True,
+                             text=True, check=True).stdout.splitlines()
+        assert len(res) == len(cmds)
+        gaps = 0
+        for j, want in zip(who, res):
+            a = aln[j]
+            got = ca.cigar_string(ops[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])])
+            assert got == want, (j, occ[j], got, want)
+            gaps += ("I" in got) or ("D" in got)
+        assert gaps > 20 or k < 2
+    # IndexInterface::findSeqName (indexinterface.cpp:799-832)
+    idx = np.searchsorted(starts, occ["begin"].astype(np.int64), side="right") - 1
+    assert np.array_equal(aln["seq_id"], idx.astype(np.uint32))
+    assert np.array_equal(aln["seq_begin"], (occ["begin"].astype(np.int64) - starts[idx]).astype(np.uint32))
+    assert np.array_equal(aln["spans"] != 0, occ["end"].astype(np.int64) > starts[idx + 1])
+    assert (aln["spans"] != 0).sum() > 0 or k == 0
+    # the occurrences themselves are what a run without alignments gives
+    o2, f2, _ = ca.match_batch(world["dev"], ca.SearchStrategy(spec, metric, "dynamic"), k, reads)
+    assert np.array_equal(o2, occ) and np.array_equal(f2, offs)
+    b.close()
