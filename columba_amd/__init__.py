@@ -42,9 +42,10 @@ EXPORTS = [
     "cmb_strategy_add_scheme", "cmb_strategy_set_partition_params", "cmb_strategy_destroy",
     "cmb_strategy_describe", "cmb_strategy_export_scheme", "cmb_strategy_export_partition", "cmb_match_batch", "cmb_batch_create", "cmb_batch_run",
     "cmb_batch_result_size", "cmb_batch_results", "cmb_batch_timings", "cmb_batch_destroy",
-    "cmb_rank_batch", "cmb_extend_batch", "cmb_extend_bench", "cmb_locate_batch", "cmb_verify_batch", "cmb_verify_batch_staged", "cmb_verify_window",
+    "cmb_rank_batch", "cmb_extend_batch", "cmb_extend_bench", "cmb_locate_batch", "cmb_verify_batch", "cmb_verify_batch_staged", "cmb_verify_window", "cmb_cigar_windows",
     "cmb_batch_want_alignments", "cmb_batch_alignments", "cmb_sam_se", "cmb_sam_se_xa", "cmb_sam_unmapped_se",
-    "cmb_read_prepare",
+    "cmb_read_prepare", "cmb_batch_filter_per_strand", "cmb_match_best", "cmb_best_sizes", "cmb_best_results",
+    "cmb_best_destroy",
     "cmb_last_error", "cmb_version",
 ]
 
@@ -154,6 +155,7 @@ def lib():
         L.cmb_locate_batch.argtypes = [vp, vp, u64, vp, C.POINTER(u64)]
         L.cmb_verify_batch.argtypes = [vp, C.c_char_p, u32, vp, u64, u32, u32, i32, vp, u64, C.POINTER(u64), vp]
         L.cmb_verify_batch_staged.argtypes = L.cmb_verify_batch.argtypes
+        L.cmb_cigar_windows.argtypes = [vp, C.c_char_p, u32, vp, vp, vp, u64, vp, u32, vp]
         L.cmb_verify_window.argtypes = [vp, C.c_char_p, u32, u32, u32, u32, u32, vp, u64, C.POINTER(u64), vp]
         L.cmb_sam_se.restype = C.c_int64
         L.cmb_sam_se.argtypes = [C.c_char_p, C.POINTER(SamHit), i32, u32, u32, C.c_char_p, C.c_char_p, vp, u64]
@@ -162,6 +164,11 @@ def lib():
         L.cmb_sam_unmapped_se.restype = C.c_int64
         L.cmb_sam_unmapped_se.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, vp, u64]
         L.cmb_read_prepare.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, vp, vp, vp, vp]
+        L.cmb_batch_filter_per_strand.argtypes = [vp, i32]
+        L.cmb_match_best.argtypes = [vp, vp, u32, u32, vp, vp, u32, C.POINTER(vp)]
+        L.cmb_best_sizes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+        L.cmb_best_results.argtypes = [vp, vp, vp, u64, vp, u64, vp, vp, vp, vp]
+        L.cmb_best_destroy.argtypes = [vp]
         L.cmb_batch_want_alignments.argtypes = [vp, i32]
         L.cmb_batch_alignments.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
         _lib = L
@@ -502,6 +509,29 @@ def match_batch(index: Index, strategy: SearchStrategy, max_distance: int, reads
         return b.results()
     finally:
         b.close()
+
+
+def match_best(index: Index, strategy: SearchStrategy, reads: Sequence[bytes], x: int = 0, min_identity: int = 95):
+    """``SearchStrategy::matchApproxBestPlusX`` for a whole chunk (the reference's default mode): returns
+    (occurrences, alignments, CIGAR operations, per-read offsets, best distance per read, hits at that distance, counters)"""
+    buf, offs = pack_reads(reads)
+    h = C.c_void_p()
+    _chk(lib().cmb_match_best(index.h, strategy.h, x, min_identity, _p(buf), _p(offs), len(reads), C.byref(h)))
+    try:
+        n, nops = C.c_uint64(), C.c_uint64()
+        _chk(lib().cmb_best_sizes(h, C.byref(n), C.byref(nops)))
+        occ = np.zeros(max(int(n.value), 1), OCC_DTYPE)
+        aln = np.zeros(max(int(n.value), 1), ALN_DTYPE)
+        ops = np.zeros(max(int(nops.value), 1), np.uint16)
+        o = np.zeros(len(reads) + 1, np.uint64)
+        best = np.zeros(max(len(reads), 1), np.uint32)
+        hits = np.zeros(max(len(reads), 1), np.uint32)
+        cnt = np.zeros(len(COUNTER_NAMES), np.uint64)
+        _chk(lib().cmb_best_results(h, _p(occ), _p(aln), occ.shape[0], _p(ops), ops.shape[0], _p(o), _p(best), _p(hits), _p(cnt)))
+        return (occ[:n.value], aln[:n.value], ops[:nops.value], o, best[:len(reads)], hits[:len(reads)],
+                dict(zip(COUNTER_NAMES, cnt.tolist())))
+    finally:
+        lib().cmb_best_destroy(h)
 
 
 def shard_bounds(n_reads: int, world_size: int, rank: int) -> Tuple[int, int]:

@@ -497,6 +497,7 @@ struct cmb_batch {
     DevBuf<unsigned long long> counters;
     uint32_t nSlots = 0;
     std::vector<uint64_t> hostOffs;
+    bool perStrand = false; // every strand filtered by itself (BEST mode: mapRead, searchstrategy.h:490-523)
     // alignments of the final occurrences (cmb_batch_want_alignments): CIGAR runs + sequence assignment
     bool wantAln = false;
     DevBuf<uint32_t> foutRead;
@@ -1219,45 +1220,47 @@ static int batchRunOne(cmb_batch* b) {
         unsigned long long hc[CMB_CNT_MAX];
         HIPCHK(hipMemcpy(hc, b->counters.p, sizeof(hc), hipMemcpyDeviceToHost));
         for (int i = 0; i < CMB_CNT_MAX; i++) b->cnts[i] = hc[i];
-        if (nReads >= (1u << 24)) return fail(CMB_ERR_UNSUPPORTED, "more than 2^24 reads in one batch");
+        // groups of the filter: reads, or read x strand when every strand is filtered by itself
+        const uint32_t nGroups = b->perStrand ? 2u * nReads : nReads;
+        if (nGroups >= (1u << 24)) return fail(CMB_ERR_UNSUPPORTED, "more than 2^24 filter groups in one sub-batch");
         {
             tm.begin();
             if (b->keysA.n < nText) {
                 b->keysA.alloc((size_t)nText + nText / 8 + 256);
                 b->keysB.alloc((size_t)nText + nText / 8 + 256);
             }
-            if (b->fcounts.n < (size_t)nReads + 1) {
-                b->fcounts.alloc((size_t)nReads + 1);
-                b->foffs.alloc((size_t)nReads + 1);
-                b->fsegB.alloc((size_t)nReads + 1);
-                b->fsegE.alloc((size_t)nReads + 1);
+            if (b->fcounts.n < (size_t)nGroups + 1) {
+                b->fcounts.alloc((size_t)nGroups + 1);
+                b->foffs.alloc((size_t)nGroups + 1);
+                b->fsegB.alloc((size_t)nGroups + 1);
+                b->fsegE.alloc((size_t)nGroups + 1);
             }
             if (nText) {
                 hipLaunchKernelGGL(k_pack_keys, dim3((nText + 255) / 256), dim3(256), 0, s, b->text.p, nText, b->offs.p,
-                                   b->k, b->keysA.p, b->cnt.p);
+                                   b->k, b->keysA.p, b->cnt.p, b->perStrand ? 1u : 0u);
                 size_t tmpBytes = 0;
                 HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, b->keysA.p, b->keysB.p, nText, 0, 64, s));
                 if (b->sortTmp.n < tmpBytes) b->sortTmp.alloc(tmpBytes + 256);
                 HIPCHK(rocprim::radix_sort_keys(b->sortTmp.p, tmpBytes, b->keysA.p, b->keysB.p, nText, 0, 64, s));
             }
             const int mode = b->k == 0 ? 0 : (b->metric == CMB_METRIC_HAMMING ? 1 : 2);
-            HIPCHK(hipMemsetAsync(b->fcounts.p, 0, ((size_t)nReads + 1) * sizeof(uint32_t), s));
-            HIPCHK(hipMemsetAsync(b->fsegB.p, 0xFF, ((size_t)nReads + 1) * sizeof(uint32_t), s));
+            HIPCHK(hipMemsetAsync(b->fcounts.p, 0, ((size_t)nGroups + 1) * sizeof(uint32_t), s));
+            HIPCHK(hipMemsetAsync(b->fsegB.p, 0xFF, ((size_t)nGroups + 1) * sizeof(uint32_t), s));
             if (nText)
                 hipLaunchKernelGGL(k_filter_segments, dim3((nText + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->fsegB.p,
                                    b->fsegE.p);
             if (b->frank.n < nText) b->frank.alloc((size_t)nText + nText / 8 + 256);
             if (nText) HIPCHK(hipMemsetAsync(b->frank.p, 0xFF, (size_t)nText * sizeof(uint32_t), s));
-            hipLaunchKernelGGL(k_filter_mark, dim3((nReads + 255) / 256), dim3(256), 0, s, b->keysB.p, nReads, b->k, mode,
+            hipLaunchKernelGGL(k_filter_mark, dim3((nGroups + 255) / 256), dim3(256), 0, s, b->keysB.p, nGroups, b->k, mode,
                                b->fcounts.p, b->frank.p, b->fsegB.p, b->fsegE.p);
             size_t scanBytes = 0;
-            HIPCHK(rocprim::exclusive_scan(nullptr, scanBytes, b->fcounts.p, b->foffs.p, (uint64_t)0, (size_t)nReads + 1,
+            HIPCHK(rocprim::exclusive_scan(nullptr, scanBytes, b->fcounts.p, b->foffs.p, (uint64_t)0, (size_t)nGroups + 1,
                                            rocprim::plus<uint64_t>(), s));
             if (b->scanTmp.n < scanBytes) b->scanTmp.alloc(scanBytes + 256);
-            HIPCHK(rocprim::exclusive_scan(b->scanTmp.p, scanBytes, b->fcounts.p, b->foffs.p, (uint64_t)0, (size_t)nReads + 1,
+            HIPCHK(rocprim::exclusive_scan(b->scanTmp.p, scanBytes, b->fcounts.p, b->foffs.p, (uint64_t)0, (size_t)nGroups + 1,
                                            rocprim::plus<uint64_t>(), s));
             uint64_t total = 0;
-            HIPCHK(hipMemcpyAsync(&total, b->foffs.p + nReads, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(&total, b->foffs.p + nGroups, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
             HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             if (hcnt[3] & FLAG_TRACE_RULE)
@@ -1268,7 +1271,8 @@ static int batchRunOne(cmb_batch* b) {
             if (b->wantAln && b->foutRead.n < total) b->foutRead.alloc((size_t)total + total / 8 + 256);
             if (total)
                 hipLaunchKernelGGL(k_filter_write, dim3((nText + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->offs.p,
-                                   b->k, b->frank.p, b->foffs.p, b->fout.p, b->wantAln ? b->foutRead.p : (uint32_t*)nullptr);
+                                   b->k, b->frank.p, b->foffs.p, b->fout.p, b->wantAln ? b->foutRead.p : (uint32_t*)nullptr,
+                                   b->perStrand ? 1u : 0u);
             HIPCHK(hipGetLastError());
             tm.end("k_filter");
             lap("filter");
@@ -1300,7 +1304,7 @@ static int batchRunOne(cmb_batch* b) {
                 HIPCHK(hipGetLastError());
             }
             b->occs.resize(total);
-            b->occOffs.resize((size_t)nReads + 1);
+            b->occOffs.resize((size_t)nGroups + 1);
             if (total) HIPCHK(hipMemcpyAsync(b->occs.data(), b->fout.p, (size_t)total * sizeof(cmb_occ), hipMemcpyDeviceToHost, s));
             if (b->wantAln) {
                 b->hAlnRec.resize(total);
@@ -1311,7 +1315,7 @@ static int batchRunOne(cmb_batch* b) {
                 }
                 HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
             }
-            HIPCHK(hipMemcpyAsync(b->occOffs.data(), b->foffs.p, ((size_t)nReads + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(b->occOffs.data(), b->foffs.p, ((size_t)nGroups + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             if (b->wantAln && (hcnt[3] & FLAG_CAPACITY))
                 return fail(CMB_ERR_INTERNAL, "a CIGAR traceback left the band or an occurrence is not an alignment within its distance");
@@ -1351,7 +1355,7 @@ extern "C" int cmb_batch_results(const cmb_batch* b, cmb_occ* out, uint64_t out_
         for (const cmb_batch* c : b->subs) {
             if (out && !c->occs.empty()) memcpy(out + base, c->occs.data(), c->occs.size() * sizeof(cmb_occ));
             if (out_offs)
-                for (uint32_t i = 0; i < c->nReads; i++) out_offs[read + i] = base + c->occOffs.data()[i];
+                for (uint32_t i = 0; i < c->nReads; i++) out_offs[read + i] = base + c->occOffs.data()[c->perStrand ? 2 * (size_t)i : i];
             read += c->nReads;
             base += c->occs.size();
         }
@@ -1361,8 +1365,19 @@ extern "C" int cmb_batch_results(const cmb_batch* b, cmb_occ* out, uint64_t out_
     }
     if (out_cap < b->occs.size()) return fail(CMB_ERR_OVERFLOW, "output buffer too small");
     if (out && !b->occs.empty()) memcpy(out, b->occs.data(), b->occs.size() * sizeof(cmb_occ));
-    if (out_offs) memcpy(out_offs, b->occOffs.data(), b->occOffs.size() * sizeof(uint64_t));
+    if (out_offs) {
+        if (b->perStrand)
+            for (uint32_t i = 0; i <= b->nReads; i++) out_offs[i] = b->occOffs.data()[2 * (size_t)i];
+        else memcpy(out_offs, b->occOffs.data(), b->occOffs.size() * sizeof(uint64_t));
+    }
     if (counters) memcpy(counters, b->cnts, sizeof(b->cnts));
+    return CMB_OK;
+}
+extern "C" int cmb_batch_filter_per_strand(cmb_batch* b, int on) {
+    if (!b) return fail(CMB_ERR_INVALID, "null argument");
+    b->perStrand = on != 0;
+    for (cmb_batch* c : b->subs) c->perStrand = on != 0;
+    b->done = false;
     return CMB_OK;
 }
 extern "C" int cmb_batch_want_alignments(cmb_batch* b, int on) {
@@ -1752,3 +1767,400 @@ static int verifyDirect(cmb_index* idx, const char* pattern, uint32_t plen, cons
         return fail(CMB_ERR_DEVICE, e.what());
     }
 }
+
+// CIGAR of one pattern against n text windows [begin, end) with given distances (IBitParallelED::findCIGAR,
+// bitparallelmatrix.h:460-527) on the device: k_cigar over a one-read batch.  ops_out: n x stride run-length
+// operations (length << 2 | op) from the begin of the alignment, n_ops_out[i] of them for window i.
+extern "C" int cmb_cigar_windows(cmb_index* idx, const char* pattern, uint32_t plen, const uint32_t* begins,
+                                 const uint32_t* ends, const uint32_t* distances, uint64_t n, uint16_t* ops_out,
+                                 uint32_t stride, uint32_t* n_ops_out) {
+    if (!idx || !pattern || (n && (!begins || !ends || !distances || !ops_out || !n_ops_out))) return fail(CMB_ERR_INVALID, "null argument");
+    if (plen == 0 || plen > (uint32_t)MAX_READ) return fail(CMB_ERR_UNSUPPORTED, "pattern length not supported");
+    uint32_t maxD = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (ends[i] < begins[i] || ends[i] > idx->d.n) return fail(CMB_ERR_INVALID, "text window out of range");
+        if (ends[i] - begins[i] > plen + distances[i]) return fail(CMB_ERR_INVALID, "text window longer than an alignment within the distance");
+        maxD = std::max(maxD, distances[i]);
+    }
+    if (3 * maxD + 1 > MX_LEFT) return fail(CMB_ERR_UNSUPPORTED, "needs the 128-bit matrix");
+    if (stride < 2 * maxD + 3) return fail(CMB_ERR_INVALID, "stride must be at least 2 * distance + 3");
+    if (n == 0) return CMB_OK;
+    try {
+        useDevice(idx->device);
+        const uint32_t mlen = (plen + 15u) & ~15u, gw = gWords(mlen);
+        DevBuf<uint8_t> reads, seq;
+        DevBuf<uint64_t> offs, vW;
+        DevBuf<uint32_t> G, occRead, flag;
+        DevBuf<uint4> occs, mfull;
+        DevBuf<uint16_t> ops;
+        DevBuf<AlnRec> aln;
+        const uint64_t ho[2] = {0, plen};
+        reads.upload((const uint8_t*)pattern, plen);
+        offs.upload(ho, 2);
+        seq.alloc(2 * (size_t)mlen);
+        G.alloc(8 * (size_t)gw);
+        HIPCHK(hipMemset(G.p, 0, G.bytes()));
+        hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, 0, reads.p, offs.p, 1u, mlen, gw, (mlen + 31) / 32, seq.p, G.p,
+                           (uint32_t*)nullptr, 0u);
+        MFull mf{nullptr, mfullBlocks(mlen)};
+        mfull.alloc((size_t)2 * 2 * mf.nBlk);
+        hipLaunchKernelGGL(k_match_words, dim3(1), dim3(256), 0, 0, G.p, gw, offs.p, 2u, mf.nBlk, mfull.p);
+        mf.p = mfull.p;
+        std::vector<uint4> ho4(n);
+        for (uint64_t i = 0; i < n; i++) ho4[i] = make_uint4(begins[i], ends[i], distances[i], 0u);
+        occs.upload(ho4.data(), n);
+        std::vector<uint32_t> zeros(n, 0u);
+        occRead.upload(zeros.data(), n);
+        flag.alloc(1);
+        HIPCHK(hipMemset(flag.p, 0, sizeof(uint32_t)));
+        const uint32_t slots = (uint32_t)std::min<uint64_t>(((n + 255) / 256) * 256, 65536);
+        const bool narrow = maxD <= TBN_MAX_ED;
+        const uint32_t tLines = narrow ? ((uint32_t)VROWS + 15u) / 16u + 2u : ((uint32_t)VROWS + 7u) / 8u + 2u;
+        vW.alloc((size_t)tLines * 8 * slots);
+        ops.alloc(n * stride);
+        aln.alloc(n);
+        VPlanes vp{vW.p, slots, tLines};
+        auto kc = k_cigar<false, false>;
+        if (narrow) kc = idx->d.text2 ? k_cigar<true, true> : k_cigar<true, false>;
+        else if (idx->d.text2) kc = k_cigar<false, true>;
+        hipLaunchKernelGGL(kc, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, mf, occs.p, occRead.p, n, vp, idx->seqStartsDev.p,
+                           idx->nSeqsDev, ops.p, stride, aln.p, flag.p, 0u);
+        HIPCHK(hipGetLastError());
+        uint32_t hf = 0;
+        HIPCHK(hipMemcpy(&hf, flag.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (hf) return fail(CMB_ERR_INTERNAL, "a CIGAR traceback left the band or a window is not an alignment within its distance");
+        std::vector<AlnRec> ha(n);
+        std::vector<uint16_t> hops(n * stride);
+        HIPCHK(hipMemcpy(ha.data(), aln.p, n * sizeof(AlnRec), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hops.data(), ops.p, n * stride * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; i++) {
+            n_ops_out[i] = ha[i].nOps;
+            for (uint32_t j = 0; j < ha[i].nOps; j++) ops_out[i * stride + j] = hops[i * stride + ha[i].nOps - 1 - j];
+        }
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}
+
+// ------------------------------------------------------------------------- BEST (+x strata) mode
+// SearchStrategy::matchApproxBestPlusX / findBestAlignments / processSeq / mapRead / checkAlignments /
+// combineOccVectors (reference src/searchstrategy.cpp:623-760, :791-812, :536-620; src/searchstrategy.h:490-523).
+// The reference walks every read through its strata on its own: exact matches, then k = 1, 3, 5, 9, 13 (k + x + 2 below
+// 5, + 4 above) up to the identity cut-off, until a stratum holds an alignment; every stratum is one ALL-mode search
+// of ONE strand (mapRead) whose occurrences below the first unprocessed distance are dropped.  Here a stratum is one
+// device batch over all reads that are still looking at that distance: both strands at once, each strand filtered
+// by itself (cmb_batch_filter_per_strand), CIGARs and sequence assignment from the device (k_cigar); the per-read
+// bookkeeping below is the reference's.
+namespace {
+
+struct BestOcc {
+    cmb_occ occ;
+    cmb_aln aln;
+    std::vector<uint16_t> ops;
+};
+struct BestRead {
+    uint32_t len = 0, cutOff = 0, best = 0, k = 0, prevK = 0, maxED = 0;
+    bool bestFound = false, finished = false;
+    std::vector<std::vector<BestOcc>> ov[2];  // [strand][distance]
+    std::vector<uint8_t> processed[2];        // [strand][distance]
+};
+
+// IndexInterface::findSeqName for an occurrence that runs over the end of its sequence (indexinterface.cpp:833-899):
+// trim to the sequence it mostly lies in and verify again inside that window (edit distance only)
+static bool trimOccurrence(cmb_index* idx, const std::string& seq, uint32_t largestStratum, int metric, BestOcc& o,
+                           uint64_t* counters) {
+    if (metric == CMB_METRIC_HAMMING) return false;
+    const std::vector<uint32_t>& sp = idx->seqStarts;
+    const uint32_t index = o.aln.seq_id;
+    if (sp.size() < 2 || index + 1 >= sp.size()) return false;
+    uint32_t b = o.occ.begin, e = o.occ.end, seqId = index;
+    if (sp[index + 1] - b <= largestStratum) { // option 1: begin is just before the end of the sequence
+        seqId = index + 1;
+        if (seqId + 1 >= sp.size()) return false;
+        b = sp[seqId];
+        e = std::min(e, sp[seqId + 1]);
+    } else if (e - sp[index + 1] <= largestStratum) { // option 2: end is just over the start of the next sequence
+        e = sp[index + 1];
+    } else {
+        return false;
+    }
+    if (e <= b) return false;
+    cmb_occ res[64];
+    uint64_t n = 0, cnt[CMB_CNT_MAX];
+    if (cmb_verify_window(idx, seq.data(), (uint32_t)seq.size(), b, e, largestStratum, 0, res, 64, &n, cnt) != CMB_OK) return false;
+    for (int i = 0; counters && i < CMB_CNT_MAX; i++) counters[i] += cnt[i];
+    if (n == 0) return false;
+    // the minimal occurrence under TextOcc::operator< (begin, distance, width; indexhelpers.h:779-795)
+    const cmb_occ* bestO = &res[0];
+    for (uint64_t i = 1; i < n; i++) {
+        const cmb_occ& c = res[i];
+        const uint32_t wc = c.end - c.begin, wb = bestO->end - bestO->begin;
+        if (c.begin != bestO->begin ? c.begin < bestO->begin
+                                    : c.distance != bestO->distance ? c.distance < bestO->distance : wc < wb)
+            bestO = &c;
+    }
+    o.occ.begin = bestO->begin;
+    o.occ.end = bestO->end;
+    o.occ.distance = bestO->distance;
+    o.aln.seq_id = seqId;
+    o.aln.seq_begin = bestO->begin - sp[seqId];
+    o.aln.spans = 2; // found with trimming
+    uint16_t opsBuf[2 * 7 + 3];
+    uint32_t nOps = 0;
+    o.ops.clear();
+    if (cmb_cigar_windows(idx, seq.data(), (uint32_t)seq.size(), &o.occ.begin, &o.occ.end, &o.occ.distance, 1, opsBuf, 2 * 7 + 3,
+                          &nOps) != CMB_OK)
+        return false;
+    o.ops.assign(opsBuf, opsBuf + nOps);
+    return true;
+}
+
+} // namespace
+
+struct cmb_best {
+    std::vector<cmb_occ> occ;
+    std::vector<cmb_aln> aln;
+    std::vector<uint16_t> ops;
+    std::vector<uint64_t> offs;
+    std::vector<uint32_t> best, nHits;
+    uint64_t cnts[CMB_CNT_MAX];
+};
+
+extern "C" int cmb_match_best(cmb_index* idx, const cmb_strategy* st, uint32_t x, uint32_t min_identity, const char* seqs,
+                              const uint64_t* offs, uint32_t n_reads, cmb_best** out) {
+    if (!idx || !st || !offs || !out || (!seqs && n_reads)) return fail(CMB_ERR_INVALID, "null argument");
+    if (min_identity < 50 || min_identity > 100) return fail(CMB_ERR_INVALID, "the minimal identity lies between 50 and 100");
+    try {
+        // getMaxSupportedDistanceForBestMapping (searchstrategy.h:1864, :2744): the largest k such that 1..k all have a
+        // scheme — and, on this device, a matrix (edit distance: 6, the 128-bit matrix is not built)
+        uint32_t maxSupported = 0;
+        while (st->schemes.count(maxSupported + 1) && !st->schemes.at(maxSupported + 1).empty()) maxSupported++;
+        if (st->metric == CMB_METRIC_EDIT) maxSupported = std::min<uint32_t>(maxSupported, (MX_LEFT - 1) / 3);
+        maxSupported = std::min<uint32_t>(maxSupported, 7u); // (3-bit distance of the filter key)
+        std::unique_ptr<cmb_best> R(new cmb_best());
+        memset(R->cnts, 0, sizeof(R->cnts));
+        std::vector<BestRead> rd(n_reads);
+        std::vector<std::string> fw(n_reads), rc(n_reads);
+        for (uint32_t i = 0; i < n_reads; i++) {
+            BestRead& r = rd[i];
+            r.len = (uint32_t)(offs[i + 1] - offs[i]);
+            fw[i] = cleanReadSeq(std::string(seqs + offs[i], seqs + offs[i + 1]));
+            rc[i] = revComplWithN(fw[i]);
+            r.cutOff = std::min<uint32_t>(std::min<uint32_t>(13u, maxSupported), (r.len * (100 - min_identity)) / 100); // getMaxED (:1797)
+            r.best = r.cutOff + 1;
+            for (int s2 = 0; s2 < 2; s2++) {
+                r.ov[s2].assign(r.cutOff + 1, {});
+                r.processed[s2].assign(r.cutOff + 1, 0);
+            }
+        }
+        // one stratum for a set of reads: ALL-mode search of both strands at distance k, every strand filtered by itself
+        auto runStratum = [&](const std::vector<uint32_t>& ids, uint32_t k) -> int {
+            std::string cat;
+            std::vector<uint64_t> o(ids.size() + 1, 0);
+            for (size_t j = 0; j < ids.size(); j++) {
+                cat.append(seqs + offs[ids[j]], seqs + offs[ids[j] + 1]);
+                o[j + 1] = cat.size();
+            }
+            cmb_batch* b = nullptr;
+            int rcode = cmb_batch_create(idx, st, k, cat.data(), o.data(), (uint32_t)ids.size(), &b);
+            if (rcode) return rcode;
+            struct Guard {
+                cmb_batch* b;
+                ~Guard() { cmb_batch_destroy(b); }
+            } guard{b};
+            cmb_batch_filter_per_strand(b, 1);
+            cmb_batch_want_alignments(b, 1);
+            if ((rcode = cmb_batch_run(b))) return rcode;
+            uint64_t n = 0, nOps = 0;
+            cmb_batch_result_size(b, &n);
+            std::vector<cmb_occ> oc(n ? n : 1);
+            std::vector<cmb_aln> al(n ? n : 1);
+            std::vector<uint64_t> oo(ids.size() + 1), cnt(CMB_CNT_MAX);
+            if ((rcode = cmb_batch_results(b, oc.data(), oc.size(), oo.data(), cnt.data()))) return rcode;
+            (void)cmb_batch_alignments(b, al.data(), 0, nullptr, 0, &nOps);
+            std::vector<uint16_t> ops(nOps ? nOps : 1);
+            if ((rcode = cmb_batch_alignments(b, al.data(), al.size(), ops.data(), ops.size(), &nOps))) return rcode;
+            for (int i = 0; i < CMB_CNT_MAX; i++) R->cnts[i] += cnt[i];
+            for (size_t j = 0; j < ids.size(); j++) {
+                BestRead& r = rd[ids[j]];
+                for (int s2 = 0; s2 < 2; s2++) {
+                    if (r.processed[s2][k]) continue; // (hasUpdate: this distance was looked at before)
+                    // processSeq (:791-812): minD = the first distance not processed yet
+                    uint32_t minD = 0;
+                    while (minD < k && r.processed[s2][minD]) minD++;
+                    for (uint64_t q2 = oo[j]; q2 < oo[j + 1]; q2++) {
+                        if ((int)oc[q2].strand != s2 || oc[q2].distance < minD) continue;
+                        BestOcc bo;
+                        bo.occ = oc[q2];
+                        bo.aln = al[q2];
+                        bo.ops.assign(ops.begin() + al[q2].cigar_off, ops.begin() + al[q2].cigar_off + al[q2].cigar_len);
+                        r.ov[s2][oc[q2].distance].push_back(std::move(bo));
+                    }
+                    for (uint32_t d = minD; d <= k; d++) r.processed[s2][d] = 1;
+                }
+            }
+            return CMB_OK;
+        };
+        // checkAlignments (:536-571): keep what lies inside one sequence; trimmed occurrences move to their new distance
+        auto checkAlignments = [&](uint32_t i, int s2, uint32_t l, uint32_t cutOffTrim) {
+            BestRead& r = rd[i];
+            if (l >= r.ov[s2].size()) return;
+            std::vector<BestOcc> assigned, trimmed;
+            for (BestOcc& o : r.ov[s2][l]) {
+                if (o.aln.spans == 0 || o.aln.spans == 3) { // FOUND (3: checked before)
+                    o.aln.spans = 3;
+                    assigned.push_back(std::move(o));
+                    if (l < r.best) r.best = l;
+                } else if (o.aln.spans == 1) {
+                    if (trimOccurrence(idx, s2 ? rc[i] : fw[i], cutOffTrim, st->metric, o, R->cnts) && o.occ.distance > l &&
+                        o.occ.distance < r.ov[s2].size())
+                        trimmed.push_back(std::move(o));
+                }
+            }
+            r.ov[s2][l] = std::move(assigned);
+            for (BestOcc& o : trimmed) {
+                o.aln.spans = 3; // (removeTrimmingLabel: it is an ordinary assigned occurrence of its new stratum)
+                const uint32_t d = o.occ.distance;
+                r.ov[s2][d].push_back(std::move(o));
+            }
+        };
+        // ---- exact matches first (x == 0), then the strata
+        std::vector<uint32_t> all(n_reads);
+        for (uint32_t i = 0; i < n_reads; i++) all[i] = i;
+        if (x == 0 && n_reads) {
+            int rcode = runStratum(all, 0);
+            if (rcode) return rcode;
+            for (uint32_t i = 0; i < n_reads; i++) {
+                BestRead& r = rd[i];
+                if (!r.ov[0][0].empty() || !r.ov[1][0].empty()) {
+                    checkAlignments(i, 0, 0, r.cutOff);
+                    checkAlignments(i, 1, 0, r.cutOff);
+                    if (r.best == 0) r.bestFound = true;
+                }
+            }
+        }
+        for (uint32_t i = 0; i < n_reads; i++) {
+            BestRead& r = rd[i];
+            r.maxED = r.best == 0 ? x : r.cutOff;
+            r.prevK = 0;
+            r.k = std::max(x, 1u);
+            r.finished = r.k > r.maxED;
+        }
+        std::vector<uint8_t> isFresh(n_reads, 0);
+        for (;;) {
+            // the reads that look at a stratum now, grouped by its distance
+            std::map<uint32_t, std::vector<uint32_t>> byK;
+            for (uint32_t i = 0; i < n_reads; i++)
+                if (!rd[i].finished) byK[rd[i].k].push_back(i);
+            if (byK.empty()) break;
+            for (auto& kv : byK) {
+                const uint32_t k = kv.first;
+                std::vector<uint32_t> need; // (a stratum both strands have been through needs no new search)
+                for (uint32_t i : kv.second)
+                    if (!rd[i].processed[0][k] || !rd[i].processed[1][k]) need.push_back(i);
+                std::fill(isFresh.begin(), isFresh.end(), 0);
+                for (uint32_t i : need) isFresh[i] = 1;
+                if (!need.empty()) {
+                    int rcode = runStratum(need, k);
+                    if (rcode) return rcode;
+                }
+                for (uint32_t i : kv.second) {
+                    BestRead& r = rd[i];
+                    // hasUpdate (:674-681): a stratum looked at before answers with ITS occurrences only; a new one
+                    // (processSeq) with any occurrence at distance 0..k
+                    bool update = false;
+                    for (int s2 = 0; s2 < 2; s2++) {
+                        const bool fresh = isFresh[i] != 0;
+                        if (!fresh) update |= !r.ov[s2][k].empty();
+                        else
+                            for (uint32_t d = 0; d <= k; d++) update |= !r.ov[s2][d].empty();
+                    }
+                    if (update)
+                        for (uint32_t l = r.prevK + 1; l <= std::min(k, r.best + x); l++) {
+                            checkAlignments(i, 0, l, r.maxED);
+                            checkAlignments(i, 1, l, r.maxED);
+                        }
+                    if (r.bestFound) {
+                        r.finished = true; // this was the last iteration
+                        continue;
+                    }
+                    if (update && r.best < r.cutOff + 1) {
+                        r.bestFound = true;
+                        if (x == 0) {
+                            r.finished = true;
+                            continue;
+                        }
+                        r.prevK = k;
+                        r.k = std::min(r.best + x, r.maxED); // check the final x strata
+                    } else {
+                        if (k == r.maxED) {
+                            r.finished = true;
+                            continue;
+                        }
+                        const uint32_t step = k < 5 ? 2 : 4;
+                        r.prevK = k;
+                        r.k = std::min(k + x + step, r.maxED);
+                    }
+                }
+            }
+        }
+        // ---- results: combineOccVectors (:573-620) per read
+        R->offs.assign(n_reads + 1, 0);
+        R->best.assign(n_reads, 0xFFFFFFFFu);
+        R->nHits.assign(n_reads, 0);
+        // occurrences found with trimming still need their CIGAR: one more (small) pass through the device
+        for (uint32_t i = 0; i < n_reads; i++) {
+            BestRead& r = rd[i];
+            R->offs[i] = R->occ.size();
+            if (!r.bestFound) continue;
+            R->best[i] = r.best;
+            R->nHits[i] = (uint32_t)(r.ov[0][r.best].size() + r.ov[1][r.best].size());
+            const uint32_t hi = std::min(r.best + x, r.cutOff);
+            for (uint32_t d = r.best; d <= hi; d++)
+                for (int s2 = 0; s2 < 2; s2++) {
+                    std::vector<BestOcc>& v = r.ov[s2][d];
+                    std::stable_sort(v.begin(), v.end(), [](const BestOcc& a, const BestOcc& b2) {
+                        return a.aln.seq_id < b2.aln.seq_id || (a.aln.seq_id == b2.aln.seq_id && a.aln.seq_begin < b2.aln.seq_begin);
+                    });
+                    v.erase(std::unique(v.begin(), v.end(), [](const BestOcc& a, const BestOcc& b2) {
+                                return a.aln.seq_id == b2.aln.seq_id && a.aln.seq_begin == b2.aln.seq_begin;
+                            }), v.end());
+                    for (BestOcc& o : v) {
+                        cmb_aln a = o.aln;
+                        a.cigar_off = R->ops.size();
+                        a.cigar_len = (uint16_t)o.ops.size();
+                        a.spans = o.aln.spans == 2 ? 2 : 0;
+                        R->ops.insert(R->ops.end(), o.ops.begin(), o.ops.end());
+                        R->occ.push_back(o.occ);
+                        R->aln.push_back(a);
+                    }
+                }
+        }
+        R->offs[n_reads] = R->occ.size();
+        *out = R.release();
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}
+extern "C" int cmb_best_sizes(const cmb_best* r, uint64_t* n_occ, uint64_t* n_ops) {
+    if (!r) return fail(CMB_ERR_INVALID, "null argument");
+    if (n_occ) *n_occ = r->occ.size();
+    if (n_ops) *n_ops = r->ops.size();
+    return CMB_OK;
+}
+extern "C" int cmb_best_results(const cmb_best* r, cmb_occ* occ, cmb_aln* aln, uint64_t cap, uint16_t* cigar_ops, uint64_t ops_cap,
+                                uint64_t* offs, uint32_t* best, uint32_t* n_hits, uint64_t* counters) {
+    if (!r) return fail(CMB_ERR_INVALID, "null argument");
+    if (cap < r->occ.size() || ops_cap < r->ops.size()) return fail(CMB_ERR_OVERFLOW, "output buffer too small");
+    if (occ && !r->occ.empty()) memcpy(occ, r->occ.data(), r->occ.size() * sizeof(cmb_occ));
+    if (aln && !r->aln.empty()) memcpy(aln, r->aln.data(), r->aln.size() * sizeof(cmb_aln));
+    if (cigar_ops && !r->ops.empty()) memcpy(cigar_ops, r->ops.data(), r->ops.size() * sizeof(uint16_t));
+    if (offs) memcpy(offs, r->offs.data(), r->offs.size() * sizeof(uint64_t));
+    if (best) memcpy(best, r->best.data(), r->best.size() * sizeof(uint32_t));
+    if (n_hits) memcpy(n_hits, r->nHits.data(), r->nHits.size() * sizeof(uint32_t));
+    if (counters) memcpy(counters, r->cnts, sizeof(r->cnts));
+    return CMB_OK;
+}
+extern "C" void cmb_best_destroy(cmb_best* r) { delete r; }

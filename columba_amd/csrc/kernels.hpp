@@ -1423,7 +1423,9 @@ k_fmocc(DevIndex ix, const FMOccRec* __restrict__ recs, uint32_t n, Queues q) {
 // redundancy filter (:1447-1485).
 __global__ void __launch_bounds__(256)
 k_pack_keys(const TextOccRec* __restrict__ text, uint32_t n, const uint64_t* __restrict__ offs, uint32_t k,
-            unsigned long long* __restrict__ keys, uint32_t* __restrict__ cnt) {
+            unsigned long long* __restrict__ keys, uint32_t* __restrict__ cnt,
+            uint32_t perStrand /* BEST mode filters every strand by itself (mapRead, searchstrategy.h:490-523): the group of a
+                                  key is then read x strand, not the read */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const TextOccRec t = text[i];
@@ -1436,8 +1438,9 @@ k_pack_keys(const TextOccRec* __restrict__ text, uint32_t n, const uint64_t* __r
     const uint32_t width = t.end - t.begin;
     const uint32_t wrel = width - (len - k); // in [0, 2k] for every occurrence of a read of length len
     if (wrel > 15u || t.dist > 7u) atomicOr(&cnt[3], (uint32_t)FLAG_CAPACITY);
-    keys[i] = ((unsigned long long)r << 40) | ((unsigned long long)t.begin << 8) | ((unsigned long long)(t.dist & 7u) << 5) |
-              ((unsigned long long)(wrel & 15u) << 1) | (unsigned long long)(t.rsId & 1u);
+    const uint32_t grp = perStrand ? t.rsId : r;
+    keys[i] = ((unsigned long long)grp << 40) | ((unsigned long long)t.begin << 8) | ((unsigned long long)(t.dist & 7u) << 5) |
+              ((unsigned long long)(wrel & 15u) << 1) | (unsigned long long)(perStrand ? 0u : (t.rsId & 1u));
 }
 
 // segment of every read in the sorted keys: segBeg[r] = first key of read r (one coalesced pass; reads without
@@ -1577,18 +1580,19 @@ k_filter_mark(const unsigned long long* __restrict__ keys, uint32_t nReads, uint
 __global__ void __launch_bounds__(256)
 k_filter_write(const unsigned long long* __restrict__ keys, uint32_t n, const uint64_t* __restrict__ offs, uint32_t k,
                const uint32_t* __restrict__ rank, const uint64_t* __restrict__ outOffs, uint4* __restrict__ out,
-               uint32_t* __restrict__ outRead /* read of every occurrence, or null */) {
+               uint32_t* __restrict__ outRead /* read of every occurrence, or null */, uint32_t perStrand) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t rk = rank[i];
     if (rk == FILTER_NONE) return;
     const unsigned long long key = keys[i];
-    const uint32_t r = (uint32_t)(key >> 40);
+    const uint32_t grp = (uint32_t)(key >> 40);
+    const uint32_t r = perStrand ? grp >> 1 : grp;
     const uint32_t len = (uint32_t)(offs[r + 1] - offs[r]);
     const uint32_t begin = (uint32_t)(key >> 8), dist = (uint32_t)(key >> 5) & 7u;
-    const uint32_t width = len - k + ((uint32_t)(key >> 1) & 15u), strand = (uint32_t)key & 1u;
-    out[outOffs[r] + rk] = make_uint4(begin, begin + width, dist, strand);
-    if (outRead) outRead[outOffs[r] + rk] = r;
+    const uint32_t width = len - k + ((uint32_t)(key >> 1) & 15u), strand = perStrand ? (grp & 1u) : ((uint32_t)key & 1u);
+    out[outOffs[grp] + rk] = make_uint4(begin, begin + width, dist, strand);
+    if (outRead) outRead[outOffs[grp] + rk] = r;
 }
 
 // ------------------------------------------------------------------ alignments of the final occurrences (§8f rank 1)

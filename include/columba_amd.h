@@ -209,10 +209,30 @@ typedef struct {
 int cmb_batch_want_alignments(cmb_batch* b, int on);
 int cmb_batch_alignments(const cmb_batch* b, cmb_aln* out, uint64_t cap, uint16_t* cigar_ops, uint64_t ops_cap,
                          uint64_t* n_ops);
+/* every strand filtered by itself instead of the two strands of a read together (what one stratum of BEST mode needs:
+ * mapRead works on one strand, src/searchstrategy.h:490-523); the result list of a read then holds the forward
+ * strand's occurrences followed by the reverse-complement strand's */
+int cmb_batch_filter_per_strand(cmb_batch* b, int on);
 /* per-kernel device time of the last cmb_batch_run, measured with hipEvents on the batch's own
  * stream.  names: NUL-separated list; ms[n]. Returns number of kernels. */
 int cmb_batch_timings(const cmb_batch* b, const char** names, float* ms, uint32_t cap);
 void cmb_batch_destroy(cmb_batch* b);
+
+/* --- BEST (+x strata) mode: the reference's default mapping mode (`-a best`, SearchStrategy::matchApproxBestPlusX,
+ * src/searchstrategy.cpp:714-746 over findBestAlignments :623-712) for a whole chunk of single-end reads.
+ * Every read is walked through its strata — exact matches, then 1, 3, 5, 9, 13 errors up to the cut-off
+ * min(13, largest distance the strategy and the device support, len * (100 - min_identity) / 100) — until one holds an
+ * alignment that lies inside one reference sequence; the alignments of the best stratum and of the x strata above
+ * it are reported, per stratum the forward strand's (ordered by sequence and begin) before the reverse complement's
+ * (combineOccVectors :573-620).  A stratum is one device batch over the reads still looking at that distance.
+ * best[i] = best distance of read i (0xFFFFFFFF: unmapped), n_hits[i] = occurrences at that distance. */
+typedef struct cmb_best cmb_best;
+int cmb_match_best(cmb_index* idx, const cmb_strategy* st, uint32_t x, uint32_t min_identity, const char* seqs,
+                   const uint64_t* offs, uint32_t n_reads, cmb_best** out);
+int cmb_best_sizes(const cmb_best* r, uint64_t* n_occ, uint64_t* n_ops);
+int cmb_best_results(const cmb_best* r, cmb_occ* occ, cmb_aln* aln, uint64_t cap, uint16_t* cigar_ops, uint64_t ops_cap,
+                     uint64_t* offs /* [n_reads+1] */, uint32_t* best, uint32_t* n_hits, uint64_t* counters);
+void cmb_best_destroy(cmb_best* r);
 
 /* --- output records (host-only; no GPU needed) -----------------------------------------
  * SAM lines of single-end reads as the reference formats them (TextOcc::generateSAMSingleEnd / ...XA /
@@ -265,6 +285,11 @@ int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t plen, const u
 int cmb_verify_window(cmb_index* idx, const char* pattern, uint32_t plen, uint32_t start, uint32_t end,
                       uint32_t max_ed, uint32_t min_ed, cmb_occ* out, uint64_t out_cap, uint64_t* n_out,
                       uint64_t* counters);
+/* IBitParallelED::findCIGAR (bitparallelmatrix.h:460-527) of one pattern against n text windows [begin, end) with given
+ * distances: ops_out holds n x stride run-length operations (length << 2 | op, from the begin of the alignment),
+ * n_ops_out[i] of them for window i; stride >= 2 * largest distance + 3 */
+int cmb_cigar_windows(cmb_index* idx, const char* pattern, uint32_t plen, const uint32_t* begins, const uint32_t* ends,
+                      const uint32_t* distances, uint64_t n, uint16_t* ops_out, uint32_t stride, uint32_t* n_ops_out);
 /* the same through the PRODUCTION edit-distance path (keys, de-duplication of identical candidates with counters
  * scaled by their multiplicity, staged matrix blocks, traceback): what cmb_batch_run does with the in-text candidates
  * of a search; cmb_verify_batch runs the one-candidate-per-lane kernel used for Hamming / exact candidates */

@@ -337,6 +337,92 @@ void* orc_match_batch(void* h, void* sp, uint32_t k, const char* seqs, const uin
     for (auto& c : cnts) res->counters.add(c);
     return res;
 }
+// ---- BEST (+x strata) mode for a chunk of reads: occurrences (concatenated-text coordinates) + assignment + CIGAR
+struct OrcBest {
+    std::vector<orc_occ> occs;
+    std::vector<uint32_t> seqId, seqBegin, trimmed;
+    std::vector<std::string> cigars;
+    std::vector<uint64_t> offs;
+    std::vector<uint32_t> best, nHits;
+    Counters counters;
+    std::string error;
+};
+void* orc_match_best(void* h, void* sp, uint32_t x, uint32_t minIdentity, uint32_t maxSupported, const char* seqs,
+                     const uint64_t* offs, uint32_t nReads, uint32_t nThreads) {
+    Index& ix = ((OrcIndex*)h)->idx;
+    Strategy& st = *(Strategy*)sp;
+    OrcBest* res = new OrcBest();
+    std::vector<std::vector<Matcher::BestOcc>> per(nReads);
+    res->best.assign(nReads, 0xFFFFFFFFu);
+    res->nHits.assign(nReads, 0);
+    if (nThreads == 0) nThreads = 1;
+    std::vector<Counters> cnts(nThreads);
+    std::vector<std::string> errs(nThreads);
+    std::atomic<uint32_t> next(0);
+    auto work = [&](uint32_t tid) {
+        Matcher m(ix, st);
+        try {
+            for (;;) {
+                uint32_t base = next.fetch_add(64);
+                if (base >= nReads) break;
+                uint32_t end = std::min(nReads, base + 64);
+                for (uint32_t r = base; r < end; r++) {
+                    std::string read = Matcher::cleanRead(std::string(seqs + offs[r], offs[r + 1] - offs[r]));
+                    uint32_t best = 0, nHits = 0;
+                    bool found = false;
+                    per[r] = m.matchApproxBestPlusX(read, x, minIdentity, maxSupported, best, nHits, found);
+                    if (found) {
+                        res->best[r] = best;
+                        res->nHits[r] = nHits;
+                    }
+                }
+            }
+        } catch (const std::exception& e) {
+            errs[tid] = e.what();
+        }
+        cnts[tid] = m.counters;
+    };
+    std::vector<std::thread> th;
+    for (uint32_t t = 1; t < nThreads; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& t : th) t.join();
+    for (auto& e : errs)
+        if (!e.empty()) res->error = e;
+    res->offs.resize(nReads + 1, 0);
+    for (uint32_t r = 0; r < nReads; r++) {
+        res->offs[r + 1] = res->offs[r] + per[r].size();
+        for (auto& o : per[r]) {
+            res->occs.push_back({o.t.range.b, o.t.range.e, o.t.distance, (uint32_t)o.t.strand});
+            res->seqId.push_back(o.seqID);
+            res->seqBegin.push_back(o.seqBegin);
+            std::string c;
+            for (auto& p : o.t.cigar) c += std::to_string(p.second) + p.first;
+            res->cigars.push_back(c);
+        }
+    }
+    for (auto& c : cnts) res->counters.add(c);
+    return res;
+}
+const char* orc_best_error(void* r) { return ((OrcBest*)r)->error.c_str(); }
+uint64_t orc_best_size(void* r) { return ((OrcBest*)r)->occs.size(); }
+void orc_best_copy(void* r, orc_occ* occs, uint32_t* seqId, uint32_t* seqBegin, uint64_t* offs, uint32_t* best,
+                   uint32_t* nHits, uint64_t* counters) {
+    OrcBest* res = (OrcBest*)r;
+    if (!res->occs.empty()) {
+        memcpy(occs, res->occs.data(), res->occs.size() * sizeof(orc_occ));
+        memcpy(seqId, res->seqId.data(), res->seqId.size() * 4);
+        memcpy(seqBegin, res->seqBegin.data(), res->seqBegin.size() * 4);
+    }
+    memcpy(offs, res->offs.data(), res->offs.size() * 8);
+    if (!res->best.empty()) {
+        memcpy(best, res->best.data(), res->best.size() * 4);
+        memcpy(nHits, res->nHits.data(), res->nHits.size() * 4);
+    }
+    if (counters) memcpy(counters, res->counters.c, sizeof(res->counters.c));
+}
+const char* orc_best_cigar(void* r, uint64_t i) { return ((OrcBest*)r)->cigars[i].c_str(); }
+void orc_best_free(void* r) { delete (OrcBest*)r; }
+
 const char* orc_result_error(void* r) { return ((OrcResult*)r)->error.c_str(); }
 uint64_t orc_result_size(void* r) { return ((OrcResult*)r)->occs.size(); }
 void orc_result_copy(void* r, orc_occ* occs, uint64_t* offs, uint64_t* counters) {

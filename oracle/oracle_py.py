@@ -220,6 +220,40 @@ class OracleStrategy:
             self.h = None
 
 
+def match_best(index: "OracleIndex", strat: "OracleStrategy", reads: Sequence[bytes], x: int = 0, min_identity: int = 95,
+               max_supported: int = 6, threads: int = 1):
+    """BEST (+x strata) mode of the oracle: (occs, seq ids, begins inside the sequence, CIGAR strings, offsets, best distance
+    per read (0xFFFFFFFF: unmapped), hits at it, counters)"""
+    L = lib()
+    L.orc_match_best.restype = C.c_void_p
+    L.orc_match_best.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    L.orc_best_error.restype = C.c_char_p
+    L.orc_best_error.argtypes = [C.c_void_p]
+    L.orc_best_size.restype = C.c_uint64
+    L.orc_best_size.argtypes = [C.c_void_p]
+    L.orc_best_copy.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+    L.orc_best_cigar.restype = C.c_char_p
+    L.orc_best_cigar.argtypes = [C.c_void_p, C.c_uint64]
+    L.orc_best_free.argtypes = [C.c_void_p]
+    buf, offs = pack_reads(reads)
+    r = L.orc_match_best(index.h, strat.h, x, min_identity, max_supported, _p(buf), _p(offs), len(reads), threads)
+    try:
+        err = L.orc_best_error(r)
+        if err:
+            raise RuntimeError(err.decode())
+        n = int(L.orc_best_size(r))
+        occs = np.zeros(max(n, 1), OCC_DTYPE)
+        sid, sb = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32)
+        ro = np.zeros(len(reads) + 1, np.uint64)
+        best, hits = np.zeros(max(len(reads), 1), np.uint32), np.zeros(max(len(reads), 1), np.uint32)
+        cnt = np.zeros(len(COUNTER_NAMES), np.uint64)
+        L.orc_best_copy(r, _p(occs), _p(sid), _p(sb), _p(ro), _p(best), _p(hits), _p(cnt))
+        cig = [L.orc_best_cigar(r, i).decode() for i in range(n)]
+        return occs[:n], sid[:n], sb[:n], cig, ro, best[:len(reads)], hits[:len(reads)], dict(zip(COUNTER_NAMES, cnt.tolist()))
+    finally:
+        L.orc_best_free(r)
+
+
 def pack_reads(reads: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
     offs = np.zeros(len(reads) + 1, np.uint64)
     offs[1:] = np.cumsum([len(r) for r in reads])

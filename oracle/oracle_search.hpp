@@ -314,6 +314,241 @@ class Matcher {
         return getTextOccHamming(occ);
     }
 
+    // ======================================================================================================
+    // BEST (+x strata) mode: SearchStrategy::matchApproxBestPlusX (searchstrategy.cpp:714-746)
+    // ======================================================================================================
+    struct BestOcc {
+        TextOcc t;            // range in concatenated-text coordinates
+        len_t seqID = 0;      // assigned sequence
+        len_t seqBegin = 0;   // begin inside it
+        int found = -1;       // -1 not checked, 0 FOUND, 1 FOUND_WITH_TRIMMING, 2 NOT_FOUND
+    };
+    typedef std::vector<std::pair<bool, std::vector<BestOcc>>> OccVector;
+
+    // fmindex.cpp:312-342 (+ InTextVerificationTask::doTask): one window, one zero in the first column
+    void inTextVerificationOneString(len_t startPos, len_t endPos, len_t maxED, len_t minED, Occurrences& occ,
+                                     const std::string& pattern) {
+        BitParallelED64& matrix = fullReadMatrix();
+        Substring pat(pattern.data(), (len_t)pattern.size(), 0, (len_t)pattern.size(), FORWARD);
+        if (!matrix.sequenceSet()) matrix.setSequence(pat);
+        matrix.initializeMatrix(maxED, std::vector<uint32_t>(1, 0u));
+        counters.inc(IN_TEXT_STARTED);
+        Substring ref((const char*)index.text, index.textLength, startPos, endPos);
+        const len_t size = ref.size();
+        if (!matrix.inFinalColumn(size)) return;
+        len_t i;
+        for (i = 0; i < size; ++i) {
+            counters.inc(MATRIX_ROWS);
+            counters.inc(TEXT_BYTES);
+            if (!matrix.computeRow(i + 1, ref.forwardAccessor(i))) break;
+        }
+        if (i <= size - matrix.getSizeOfFinalColumn()) {
+            counters.inc(ABORTED_IN_TEXT_VERIF);
+            return;
+        }
+        std::vector<len_t> refEnds;
+        matrix.findClusterCenters(i, refEnds, maxED, minED);
+        if (refEnds.empty()) {
+            counters.inc(ABORTED_IN_TEXT_VERIF);
+            return;
+        }
+        for (len_t refEnd : refEnds) {
+            len_t bestScore = maxED + 1, bestBegin = 0;
+            std::vector<std::pair<char, uint32_t>> cigar;
+            matrix.traceBack(ref, refEnd, bestBegin, bestScore, &cigar);
+            counters.inc(CIGARS_IN_TEXT_VERIFICATION);
+            TextOcc t(Range(startPos + bestBegin, startPos + refEnd), bestScore, strand);
+            t.cigar = cigar;
+            occ.inTextOcc.emplace_back(std::move(t));
+        }
+    }
+    // IndexInterface::generateCIGAR: findCIGAR of the occurrence's text range (bitparallelmatrix.h:460-527)
+    void generateCIGAR(TextOcc& t, const std::string& seq) {
+        if (strat.metric != EDIT || t.distance == 0) {
+            t.cigar = {{'M', (uint32_t)seq.size()}};
+            return;
+        }
+        BitParallelED64 M;
+        M.setSequence(Substring(seq.data(), (len_t)seq.size(), 0, (len_t)seq.size(), FORWARD));
+        Substring ref((const char*)index.text, index.textLength, t.range.b, t.range.e);
+        M.findCIGAR(ref, t.distance, t.cigar);
+    }
+    // IndexInterface::findSeqName (indexinterface.cpp:799-899); returns 0 FOUND, 1 FOUND_WITH_TRIMMING, 2 NOT_FOUND
+    int findSeqName(BestOcc& o, len_t largestStratum, const std::string& pattern) {
+        const std::vector<len_t>& startPos = index.seqStarts;
+        const len_t begin = o.t.range.b, end = o.t.range.e;
+        len_t idx = (len_t)(std::upper_bound(startPos.begin(), startPos.end(), begin) - startPos.begin()) - 1;
+        if (end <= startPos[idx + 1]) {
+            o.seqID = idx;
+            o.seqBegin = begin - startPos[idx];
+            return 0;
+        }
+        if (strat.metric == HAMMING) return 2;
+        Range range = o.t.range;
+        if ((startPos[idx + 1] - begin) <= largestStratum) {
+            idx++;
+            if (idx + 1 >= startPos.size()) return 2; // (the reference would read past its vector here)
+            range = Range(startPos[idx], std::min(end, startPos[idx + 1]));
+        } else if ((end - startPos[idx + 1]) <= largestStratum) {
+            range = Range(begin, startPos[idx + 1]);
+        } else {
+            return 2;
+        }
+        Occurrences occ;
+        inTextVerificationOneString(range.b, range.e, largestStratum, 0, occ, pattern);
+        if (occ.inTextOcc.empty()) return 2;
+        o.t = *std::min_element(occ.inTextOcc.begin(), occ.inTextOcc.end());
+        o.seqID = idx;
+        o.seqBegin = o.t.range.b - startPos[idx];
+        return 1;
+    }
+    // searchstrategy.h:490-523: one strand
+    std::vector<TextOcc> mapRead(const std::string& read, len_t maxED, Strand st, len_t minD) {
+        strand = st;
+        if (maxED == 0) {
+            std::vector<TextOcc> exact;
+            exactMatchesOutput(read, exact);
+            std::stable_sort(exact.begin(), exact.end());
+            return exact;
+        }
+        Occurrences occ;
+        matchWithSearches(read, maxED, occ);
+        std::vector<TextOcc> v = strat.metric == EDIT ? getUniqueTextOccurrences(occ, maxED) : getTextOccHamming(occ);
+        v.erase(std::remove_if(v.begin(), v.end(), [minD](const TextOcc& e) { return e.distance < minD; }), v.end());
+        return v;
+    }
+    // searchstrategy.cpp:791-812
+    bool processSeq(const std::string& seq, Strand st, len_t maxDist, OccVector& vec) {
+        if (!vec[maxDist].first) {
+            len_t minD = 0;
+            while (minD < vec.size() && vec[minD].first) minD++;
+            minD = std::min(minD, maxDist);
+            for (auto& t : mapRead(seq, maxDist, st, minD)) {
+                BestOcc b;
+                b.t = t;
+                vec[t.distance].second.emplace_back(std::move(b));
+            }
+            for (len_t i = minD; i <= maxDist; i++) vec[i].first = true;
+        }
+        for (len_t i = 0; i <= maxDist; i++)
+            if (!vec[i].second.empty()) return true;
+        return false;
+    }
+    // searchstrategy.cpp:536-571
+    void checkAlignments(OccVector& ov, uint32_t& best, uint32_t l, uint32_t cutOff, const std::string& seq, Strand st) {
+        strand = st;
+        std::vector<BestOcc> trimmed, assigned;
+        for (auto& o : ov[l].second) {
+            if (!o.t.hasCigar()) generateCIGAR(o.t, seq);
+            if (o.found < 0) o.found = findSeqName(o, cutOff, seq); // assignSequence (searchstrategy.h:1575-1593)
+            if (o.found != 0) {
+                if (o.found == 1 && o.t.distance > l) trimmed.emplace_back(std::move(o));
+            } else {
+                assigned.emplace_back(std::move(o));
+                if (l < best) best = l;
+            }
+        }
+        ov[l].second = std::move(assigned);
+        for (auto& o : trimmed) {
+            o.found = 0; // removeTrimmingLabel
+            if (o.t.distance < ov.size()) ov[o.t.distance].second.emplace_back(std::move(o));
+        }
+    }
+    // searchstrategy.cpp:623-712
+    bool findBestAlignments(const std::string& read, const std::string& revC, OccVector& ovFW, OccVector& ovRC,
+                            uint32_t x, uint32_t& best) {
+        const len_t cutOff = (len_t)ovFW.size() - 1;
+        best = cutOff + 1;
+        bool bestFound = false;
+        if (x == 0) {
+            if (!ovFW[0].first) {
+                strand = FORWARD_STRAND;
+                std::vector<TextOcc> v;
+                exactMatchesOutput(read, v);
+                for (auto& t : v) {
+                    BestOcc b;
+                    b.t = t;
+                    ovFW[0].second.emplace_back(b);
+                }
+                ovFW[0].first = true;
+            }
+            if (!ovRC[0].first) {
+                strand = REVERSE_C_STRAND;
+                std::vector<TextOcc> v;
+                exactMatchesOutput(revC, v);
+                for (auto& t : v) {
+                    BestOcc b;
+                    b.t = t;
+                    ovRC[0].second.emplace_back(b);
+                }
+                ovRC[0].first = true;
+            }
+            if (!ovFW[0].second.empty() || !ovRC[0].second.empty()) {
+                checkAlignments(ovFW, best, 0, cutOff, read, FORWARD_STRAND);
+                checkAlignments(ovRC, best, 0, cutOff, revC, REVERSE_C_STRAND);
+                if (best == 0) bestFound = true;
+            }
+        }
+        uint32_t maxED = (best == 0) ? x : cutOff;
+        uint32_t prevK = 0;
+        auto hasUpdate = [&](const std::string& seq, Strand st, uint32_t k, OccVector& vec) {
+            if (vec[k].first) return !vec[k].second.empty();
+            return processSeq(seq, st, k, vec);
+        };
+        for (uint32_t k = std::max(x, (uint32_t)1); k <= maxED;) {
+            bool update = false;
+            update |= hasUpdate(read, FORWARD_STRAND, k, ovFW);
+            update |= hasUpdate(revC, REVERSE_C_STRAND, k, ovRC);
+            if (update) {
+                for (len_t l = prevK + 1; l <= std::min(k, best + x); l++) {
+                    checkAlignments(ovFW, best, l, maxED, read, FORWARD_STRAND);
+                    checkAlignments(ovRC, best, l, maxED, revC, REVERSE_C_STRAND);
+                }
+            }
+            if (bestFound) break;
+            if (update && best < cutOff + 1) {
+                bestFound = true;
+                if (x == 0) break;
+                prevK = k, k = std::min(best + x, maxED);
+            } else {
+                if (k == maxED) break;
+                uint32_t step = (k < 5) ? 2 : 4;
+                prevK = k;
+                k = std::min(k + x + step, maxED);
+            }
+        }
+        return bestFound;
+    }
+    // searchstrategy.cpp:714-746 (+ combineOccVectors :573-620, stable sort as DEVELOPER_MODE builds do); maxSupported =
+    // getMaxSupportedDistanceForBestMapping of the strategy (capped by the caller where the device has no matrix)
+    std::vector<BestOcc> matchApproxBestPlusX(const std::string& read, uint32_t x, uint32_t minIdentity, uint32_t maxSupported,
+                                              uint32_t& best, uint32_t& nHits, bool& found) {
+        fullReadMatrices[0].reset();
+        fullReadMatrices[1].reset();
+        noCIGAR = false;
+        const std::string revC = revCompl(read);
+        const len_t cutOff = std::min<len_t>(std::min<len_t>(13, maxSupported), ((len_t)read.size() * (100 - minIdentity)) / 100);
+        OccVector ovFW(cutOff + 1), ovRC(cutOff + 1);
+        found = findBestAlignments(read, revC, ovFW, ovRC, x, best);
+        std::vector<BestOcc> matches;
+        nHits = 0;
+        if (!found) return matches;
+        nHits = (uint32_t)(ovFW[best].second.size() + ovRC[best].second.size());
+        auto compare = [](const BestOcc& a, const BestOcc& b) {
+            return a.seqID < b.seqID || (a.seqID == b.seqID && a.seqBegin < b.seqBegin);
+        };
+        auto equal = [](const BestOcc& a, const BestOcc& b) { return a.seqID == b.seqID && a.seqBegin == b.seqBegin; };
+        for (len_t i = best; i <= std::min<len_t>(best + x, cutOff); i++) {
+            for (OccVector* ov : {&ovFW, &ovRC}) {
+                auto& v = (*ov)[i].second;
+                std::stable_sort(v.begin(), v.end(), compare);
+                v.erase(std::unique(v.begin(), v.end(), equal), v.end());
+                matches.insert(matches.end(), v.begin(), v.end());
+            }
+        }
+        return matches;
+    }
+
     // nucleotide.h getRevComplWithN: complement ACGT, everything else N
     static std::string revCompl(const std::string& s) {
         std::string r(s.size(), 'N');

@@ -415,3 +415,50 @@ def test_alignments_cigar_and_sequence(world, oracle_built, spec, metric, k):
     o2, f2, _ = ca.match_batch(world["dev"], ca.SearchStrategy(spec, metric, "dynamic"), k, reads)
     assert np.array_equal(o2, occ) and np.array_equal(f2, offs)
     b.close()
+
+
+@pytest.mark.parametrize("spec,metric,x,min_identity", [("columba", "edit", 0, 96), ("columba", "edit", 1, 96),
+                                                        ("multiple_opt", "edit", 0, 97), ("kuch1", "hamming", 0, 98),
+                                                        ("minU", "edit", 2, 97), ("columba", "edit", 0, 95)])
+def test_best_mode(world, spec, metric, x, min_identity):
+    """BEST (+x strata) mode — the reference's default (`-a best`, SearchStrategy::matchApproxBestPlusX,
+    searchstrategy.cpp:623-746): per read the best distance, the number of hits at it, and the alignments of the best
+    x + 1 strata in the reference's order, with sequence assignment and CIGAR, against the oracle's restatement.
+    (Cut-off: min(13, what strategy and device support, len * (100 - identity) / 100); the device supports 6 errors,
+    the oracle is given the same limit.)"""
+    import schemes_py as sp
+    op = world["op"]
+    g = world["genome"]
+    reads = synth.sample_reads(g, 2500, 150, seed=800 + x, n_frac=0.01, edit_choices=(0, 0, 1, 2, 3, 5, 6, 9))
+    starts = np.asarray(world["ix"].seq_starts, dtype=np.int64)
+    for s in starts[1:-1][:12]:   # reads across sequence boundaries: trimmed or dropped (findSeqName)
+        reads.append(g[int(s) - 75:int(s) + 75].tobytes())
+        reads.append(g[int(s) - 3:int(s) + 147].tobytes())
+        reads.append(g[int(s) - 147:int(s) + 3].tobytes())
+    reads += [b"ACGT" * 37 + b"AC", b"N" * 150]
+    spec_tables = sp.BY_NAME[spec]
+    max_sup = 0
+    while (max_sup + 1) in spec_tables["schemes"]:
+        max_sup += 1
+    max_sup = min(max_sup, 6 if metric == "edit" else 7)
+    o_occ, o_sid, o_sb, o_cig, o_off, o_best, o_hits, o_cnt = op.match_best(
+        world["orc"], op.OracleStrategy(spec_tables, metric, "dynamic"), reads, x=x, min_identity=min_identity,
+        max_supported=max_sup, threads=8)
+    d_occ, d_aln, d_ops, d_off, d_best, d_hits, d_cnt = ca.match_best(
+        world["dev"], ca.SearchStrategy(spec, metric, "dynamic"), reads, x=x, min_identity=min_identity)
+    assert np.array_equal(o_best, d_best)
+    # (multiple_opt has no scheme for 1 error: its best mode stops at exact matches, searchstrategy.h:2744-2750)
+    # (with x > 0 the reference never looks at stratum 0 — its loop over the strata to check starts at prevK + 1 = 1,
+    # searchstrategy.cpp:688 — so reads that only match exactly stay unmapped there; Hamming cut-off 3 at 98 %)
+    assert (o_best != 0xFFFFFFFF).sum() > (1500 if (spec, x) == ("columba", 0) else 300) and (o_best == 0xFFFFFFFF).sum() > 0
+    assert np.array_equal(o_hits, d_hits)
+    assert np.array_equal(o_off, d_off)
+    for f in ("begin", "end", "distance", "strand"):
+        assert np.array_equal(o_occ[f], d_occ[f]), f
+    assert np.array_equal(o_sid, d_aln["seq_id"]) and np.array_equal(o_sb, d_aln["seq_begin"])
+    for j in range(len(d_occ)):
+        a = d_aln[j]
+        got = ca.cigar_string(d_ops[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])])
+        assert got == o_cig[j], (j, d_occ[j], got, o_cig[j])
+    for n in ("NODE_COUNTER", "IN_TEXT_STARTED", "SEARCH_STARTED", "EXPANSIONS", "IMMEDIATE_SWITCH"):
+        assert o_cnt[n] == d_cnt[n], (n, o_cnt[n], d_cnt[n])
