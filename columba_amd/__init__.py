@@ -44,7 +44,7 @@ EXPORTS = [
     "cmb_batch_result_size", "cmb_batch_results", "cmb_batch_timings", "cmb_batch_destroy",
     "cmb_rank_batch", "cmb_extend_batch", "cmb_extend_bench", "cmb_locate_batch", "cmb_verify_batch", "cmb_verify_batch_staged", "cmb_verify_window", "cmb_cigar_windows",
     "cmb_batch_want_alignments", "cmb_batch_alignments", "cmb_sam_se", "cmb_sam_se_xa", "cmb_sam_unmapped_se",
-    "cmb_read_prepare", "cmb_batch_filter_per_strand", "cmb_match_best", "cmb_best_sizes", "cmb_best_results",
+    "cmb_read_prepare", "cmb_batch_sam", "cmb_batch_filter_per_strand", "cmb_match_best", "cmb_best_sizes", "cmb_best_results",
     "cmb_best_destroy",
     "cmb_last_error", "cmb_version",
 ]
@@ -164,6 +164,8 @@ def lib():
         L.cmb_sam_unmapped_se.restype = C.c_int64
         L.cmb_sam_unmapped_se.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, vp, u64]
         L.cmb_read_prepare.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, vp, vp, vp, vp]
+        L.cmb_batch_sam.restype = C.c_int64
+        L.cmb_batch_sam.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, u64]
         L.cmb_batch_filter_per_strand.argtypes = [vp, i32]
         L.cmb_match_best.argtypes = [vp, vp, u32, u32, vp, vp, u32, C.POINTER(vp)]
         L.cmb_best_sizes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
@@ -456,6 +458,7 @@ class Batch:
         buf, offs = packed if packed is not None else pack_reads(reads)
         self.n_reads = offs.shape[0] - 1
         self._keep = (index, strategy)
+        self._packed = (buf, offs)
         h = C.c_void_p()
         _chk(lib().cmb_batch_create(index.h, strategy.h, max_distance, _p(buf), _p(offs), self.n_reads, C.byref(h)))
         self.h = h
@@ -485,6 +488,20 @@ class Batch:
         ops = np.zeros(max(int(nops.value), 1), np.uint16)
         _chk(lib().cmb_batch_alignments(self.h, _p(aln), aln.shape[0], _p(ops), ops.shape[0], C.byref(nops)))
         return aln[:n.value], ops[:nops.value]
+
+    def sam(self, ids, quals, seq_names, unmapped: bool = True, xa: bool = False) -> str:
+        """SAM text of the chunk (SearchStrategy::generateOutputSingleEnd); needs want_alignments() before run()"""
+        def arr(strs):
+            a = (C.c_char_p * len(strs))(*[s.encode() for s in strs])
+            return a
+        ai, aq, an = arr(ids), arr(quals), arr(seq_names)
+        buf = self._packed[0]
+        n = lib().cmb_batch_sam(self.h, _p(buf), ai, aq, an, int(unmapped), int(xa), None, 0)
+        if n < 0:
+            raise CmbError(int(n), lib().cmb_last_error().decode(errors="replace"))
+        out = C.create_string_buffer(int(n) + 1)
+        lib().cmb_batch_sam(self.h, _p(buf), ai, aq, an, int(unmapped), int(xa), out, int(n) + 1)
+        return out.value.decode()
 
     def timings(self) -> Dict[str, float]:
         names = (C.c_char_p * 16)()

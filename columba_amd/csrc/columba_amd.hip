@@ -1843,15 +1843,6 @@ extern "C" int cmb_cigar_windows(cmb_index* idx, const char* pattern, uint32_t p
     }
 }
 
-// ------------------------------------------------------------------------- BEST (+x strata) mode
-// SearchStrategy::matchApproxBestPlusX / findBestAlignments / processSeq / mapRead / checkAlignments /
-// combineOccVectors (reference src/searchstrategy.cpp:623-760, :791-812, :536-620; src/searchstrategy.h:490-523).
-// The reference walks every read through its strata on its own: exact matches, then k = 1, 3, 5, 9, 13 (k + x + 2 below
-// 5, + 4 above) up to the identity cut-off, until a stratum holds an alignment; every stratum is one ALL-mode search
-// of ONE strand (mapRead) whose occurrences below the first unprocessed distance are dropped.  Here a stratum is one
-// device batch over all reads that are still looking at that distance: both strands at once, each strand filtered
-// by itself (cmb_batch_filter_per_strand), CIGARs and sequence assignment from the device (k_cigar); the per-read
-// bookkeeping below is the reference's.
 namespace {
 
 struct BestOcc {
@@ -1917,6 +1908,93 @@ static bool trimOccurrence(cmb_index* idx, const std::string& seq, uint32_t larg
 }
 
 } // namespace
+
+// SAM text of a whole chunk in ALL mode: matchApproxAllMap D) -> SearchStrategy::generateOutputSingleEnd
+// (searchstrategy.cpp:530-533, :1824-1902) -> generateSE_SAM / generateSE_SAM_XATag (searchstrategy.h:1612-1641), from the
+// occurrences, CIGARs and sequence assignments the device produced (cmb_batch_want_alignments before cmb_batch_run).
+// Occurrences that run over the end of their sequence are trimmed and verified again (findSeqName,
+// indexinterface.cpp:833-899) through the device hooks.
+extern "C" int64_t cmb_batch_sam(const cmb_batch* b, const char* seqs, const char* const* read_ids, const char* const* quals,
+                                 const char* const* seq_names, int unmapped_records, int xa_tag, char* out, uint64_t cap) {
+    if (!b || !seqs || !read_ids || !seq_names) return fail(CMB_ERR_INVALID, "null argument");
+    if (!b->done) return fail(CMB_ERR_INVALID, "batch has not been run");
+    if (!b->wantAln) return fail(CMB_ERR_INVALID, "alignments were not requested (cmb_batch_want_alignments)");
+    try {
+        std::vector<const cmb_batch*> parts;
+        if (b->subs.empty()) parts.push_back(b);
+        else
+            for (const cmb_batch* c : b->subs) parts.push_back(c);
+        cmb_index* idx = b->ix;
+        std::string text;
+        uint64_t readBase = 0, charBase = 0;
+        for (const cmb_batch* c : parts) {
+            for (uint32_t i = 0; i < c->nReads; i++) {
+                const uint64_t gi = readBase + i;
+                const uint64_t o0 = charBase + c->hostOffs[i], o1 = charBase + c->hostOffs[i + 1];
+                const std::string read = cleanReadSeq(std::string(seqs + o0, seqs + o1)), revC = revComplWithN(read);
+                const std::string sid = cleanSeqID(read_ids[gi]);
+                const std::string qual = quals && quals[gi] ? quals[gi] : "*";
+                std::string revQ = qual;
+                std::reverse(revQ.begin(), revQ.end());
+                struct Hit {
+                    SamHit h;
+                };
+                std::vector<SamHit> hits;
+                const uint64_t q0 = c->occOffs.data()[c->perStrand ? 2 * (size_t)i : i], q1 = c->occOffs.data()[c->perStrand ? 2 * (size_t)i + 2 : i + 1];
+                for (uint64_t q2 = q0; q2 < q1; q2++) {
+                    BestOcc o;
+                    o.occ = c->occs.data()[q2];
+                    const AlnRec& ar = c->hAlnRec.data()[q2];
+                    o.aln = cmb_aln{ar.seqId, ar.seqBegin, 0, (uint16_t)ar.nOps, (uint16_t)ar.spans, 0};
+                    const uint16_t* src = c->hAlnOps.data() + q2 * c->alnStride;
+                    for (uint32_t j = 0; j < ar.nOps; j++) o.ops.push_back(src[ar.nOps - 1 - j]);
+                    if (o.aln.spans == 1 && !trimOccurrence(idx, o.occ.strand ? revC : read, c->k, c->metric, o, nullptr)) continue; // NOT_FOUND
+                    SamHit h;
+                    h.seqName = seq_names[o.aln.seq_id];
+                    h.cigar = cigarString(o.ops.data(), (uint32_t)o.ops.size());
+                    h.pos0 = o.aln.seq_begin;
+                    h.distance = o.occ.distance;
+                    h.revCompl = o.occ.strand != 0;
+                    hits.push_back(h);
+                }
+                if (hits.empty()) {
+                    if (unmapped_records) text += samLineUnmappedSE(sid, read, qual);
+                    continue;
+                }
+                // primary = the first occurrence of minimal distance, swapped to the front (:1883-1899)
+                size_t mi = 0;
+                for (size_t j = 1; j < hits.size(); j++)
+                    if (hits[j].distance < hits[mi].distance) mi = j;
+                const uint32_t minScore = hits[mi].distance;
+                uint32_t nHits = 0;
+                for (const SamHit& h : hits) nHits += h.distance == minScore;
+                if (mi != 0) std::swap(hits[0], hits[mi]);
+                const bool rcFirst = hits[0].revCompl;
+                if (xa_tag) {
+                    text += samLineSEWithXA(sid, hits, nHits, rcFirst ? revC : read, rcFirst ? revQ : qual);
+                } else {
+                    text += samLineSE(sid, hits[0], true, nHits, minScore, rcFirst ? revC : read, rcFirst ? revQ : qual);
+                    for (size_t j = 1; j < hits.size(); j++) text += samLineSE(sid, hits[j], false, nHits, minScore, "*", "*");
+                }
+            }
+            readBase += c->nReads;
+            charBase += c->hostOffs[c->nReads];
+        }
+        return putString(text, out, cap);
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}
+
+// ------------------------------------------------------------------------- BEST (+x strata) mode
+// SearchStrategy::matchApproxBestPlusX / findBestAlignments / processSeq / mapRead / checkAlignments /
+// combineOccVectors (reference src/searchstrategy.cpp:623-760, :791-812, :536-620; src/searchstrategy.h:490-523).
+// The reference walks every read through its strata on its own: exact matches, then k = 1, 3, 5, 9, 13 (k + x + 2 below
+// 5, + 4 above) up to the identity cut-off, until a stratum holds an alignment; every stratum is one ALL-mode search
+// of ONE strand (mapRead) whose occurrences below the first unprocessed distance are dropped.  Here a stratum is one
+// device batch over all reads that are still looking at that distance: both strands at once, each strand filtered
+// by itself (cmb_batch_filter_per_strand), CIGARs and sequence assignment from the device (k_cigar); the per-read
+// bookkeeping below is the reference's.
 
 struct cmb_best {
     std::vector<cmb_occ> occ;

@@ -253,6 +253,14 @@ int64_t cmb_sam_se(const char* read_id, const cmb_sam_hit* hit, int primary, uin
 int64_t cmb_sam_se_xa(const char* read_id, const cmb_sam_hit* hits, uint32_t n, uint32_t n_hits, const char* print_seq,
                       const char* print_qual, char* out, uint64_t cap);
 int64_t cmb_sam_unmapped_se(const char* read_id, const char* seq, const char* qual, char* out, uint64_t cap);
+/* SAM text of a whole chunk matched in ALL mode (SearchStrategy::generateOutputSingleEnd, src/searchstrategy.cpp:1824-1902:
+ * sequence assignment incl. trimming at sequence ends, primary = first occurrence of minimal distance, the others as
+ * secondary lines or, with xa_tag, in the primary's XA tag; unmapped_records: a flag-4 record for reads without any).
+ * Needs cmb_batch_want_alignments before cmb_batch_run; seqs = the read characters given to cmb_batch_create,
+ * read_ids / quals = per read the FASTQ identifier line and quality (quals or an entry may be NULL: "*"),
+ * seq_names = names of the reference sequences.  Returns the length of the text (written if cap is larger). */
+int64_t cmb_batch_sam(const cmb_batch* b, const char* seqs, const char* const* read_ids, const char* const* quals,
+                      const char* const* seq_names, int unmapped_records, int xa_tag, char* out, uint64_t cap);
 /* Read::cleanUpRecord + ReadBundle (src/reads.h:43-58, :97-160): identifier without its first character and without
  * anything from the first space on; upper-case sequence with every non-ACGT character replaced by N; its reverse
  * complement; the reversed quality string.  Output buffers hold strlen(input) + 1 bytes each (any may be NULL). */

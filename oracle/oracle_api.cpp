@@ -423,6 +423,42 @@ void orc_best_copy(void* r, orc_occ* occs, uint32_t* seqId, uint32_t* seqBegin, 
 const char* orc_best_cigar(void* r, uint64_t i) { return ((OrcBest*)r)->cigars[i].c_str(); }
 void orc_best_free(void* r) { delete (OrcBest*)r; }
 
+// ---- SAM text of a chunk of reads in ALL mode (ids: "\n"-joined read identifiers as they stand in the FASTQ, quals likewise)
+struct OrcText {
+    std::string text, error;
+};
+void* orc_match_batch_sam(void* h, void* sp, uint32_t k, const char* seqs, const uint64_t* offs, uint32_t nReads,
+                          const char* ids, const char* quals, const char* seqNames, int unmapped, int xa) {
+    Index& ix = ((OrcIndex*)h)->idx;
+    Strategy& st = *(Strategy*)sp;
+    OrcText* res = new OrcText();
+    auto split = [](const char* s2) {
+        std::vector<std::string> v;
+        std::string cur;
+        for (const char* p = s2; *p; p++)
+            if (*p == '\n') {
+                v.push_back(cur);
+                cur.clear();
+            } else cur += *p;
+        v.push_back(cur);
+        return v;
+    };
+    const std::vector<std::string> vid = split(ids), vq = split(quals), names = split(seqNames);
+    try {
+        Matcher m(ix, st);
+        for (uint32_t r = 0; r < nReads; r++) {
+            std::string read = Matcher::cleanRead(std::string(seqs + offs[r], offs[r + 1] - offs[r]));
+            res->text += m.samRecordsAll(read, k, cleanSeqID(vid[r]), vq[r], names, unmapped != 0, xa != 0);
+        }
+    } catch (const std::exception& e) {
+        res->error = e.what();
+    }
+    return res;
+}
+const char* orc_text_get(void* r) { return ((OrcText*)r)->text.c_str(); }
+const char* orc_text_error(void* r) { return ((OrcText*)r)->error.c_str(); }
+void orc_text_free(void* r) { delete (OrcText*)r; }
+
 const char* orc_result_error(void* r) { return ((OrcResult*)r)->error.c_str(); }
 uint64_t orc_result_size(void* r) { return ((OrcResult*)r)->occs.size(); }
 void orc_result_copy(void* r, orc_occ* occs, uint64_t* offs, uint64_t* counters) {

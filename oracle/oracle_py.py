@@ -254,6 +254,30 @@ def match_best(index: "OracleIndex", strat: "OracleStrategy", reads: Sequence[by
         L.orc_best_free(r)
 
 
+def match_batch_sam(index: "OracleIndex", strat: "OracleStrategy", k: int, reads: Sequence[bytes], ids, quals, seq_names,
+                    unmapped: bool = True, xa: bool = False) -> str:
+    """SAM text of a chunk of reads in ALL mode (generateOutputSingleEnd, searchstrategy.cpp:1824-1902)"""
+    L = lib()
+    L.orc_match_batch_sam.restype = C.c_void_p
+    L.orc_match_batch_sam.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p,
+                                      C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    L.orc_text_get.restype = C.c_char_p
+    L.orc_text_get.argtypes = [C.c_void_p]
+    L.orc_text_error.restype = C.c_char_p
+    L.orc_text_error.argtypes = [C.c_void_p]
+    L.orc_text_free.argtypes = [C.c_void_p]
+    buf, offs = pack_reads(reads)
+    r = L.orc_match_batch_sam(index.h, strat.h, k, _p(buf), _p(offs), len(reads), "\n".join(ids).encode(),
+                              "\n".join(quals).encode(), "\n".join(seq_names).encode(), int(unmapped), int(xa))
+    try:
+        err = L.orc_text_error(r)
+        if err:
+            raise RuntimeError(err.decode())
+        return L.orc_text_get(r).decode()
+    finally:
+        L.orc_text_free(r)
+
+
 def pack_reads(reads: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
     offs = np.zeros(len(reads) + 1, np.uint64)
     offs[1:] = np.cumsum([len(r) for r in reads])

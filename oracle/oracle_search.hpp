@@ -549,6 +549,55 @@ class Matcher {
         return matches;
     }
 
+    // ======================================================================================================
+    // SAM records of one read in ALL mode: matchApproxAllMap D) (searchstrategy.cpp:530-533) ->
+    // generateOutputSingleEnd (:1824-1902) -> generateSE_SAM / generateSE_SAM_XATag (searchstrategy.h:1612-1641)
+    // ======================================================================================================
+    std::string samRecordsAll(const std::string& read, len_t maxED, const std::string& seqID, const std::string& qual,
+                              const std::vector<std::string>& seqNames, bool unmappedSAM, bool xaTag) {
+        const std::string revC = revCompl(read);
+        std::string revQ = qual;
+        std::reverse(revQ.begin(), revQ.end());
+        noCIGAR = true;
+        std::vector<TextOcc> result = matchApproxAll(read, maxED);
+        std::vector<BestOcc> occs;
+        for (auto& t : result) { // CIGARs (filterEditWithCIGARCalculation) and sequence assignment
+            BestOcc o;
+            o.t = t;
+            strand = t.strand;
+            const std::string& seq = t.strand == FORWARD_STRAND ? read : revC;
+            generateCIGAR(o.t, seq);
+            o.found = findSeqName(o, maxED, seq);
+            if (o.found == 1 && !o.t.hasCigar()) generateCIGAR(o.t, seq);
+            if (o.found != 2) occs.emplace_back(std::move(o));
+        }
+        if (occs.empty()) return unmappedSAM ? samUnmappedSE(seqID, read, qual) : std::string();
+        auto minIt = std::min_element(occs.begin(), occs.end(),
+                                      [](const BestOcc& a, const BestOcc& b) { return a.t.distance < b.t.distance; });
+        const len_t minScore = minIt->t.distance;
+        const len_t nHits = (len_t)std::count_if(occs.begin(), occs.end(), [&](const BestOcc& e) { return e.t.distance == minScore; });
+        if (minIt != occs.begin()) std::iter_swap(occs.begin(), minIt);
+        auto toSam = [&](const BestOcc& o) {
+            SamOcc s2;
+            s2.seqName = seqNames[o.seqID];
+            s2.begin = o.seqBegin;
+            s2.distance = o.t.distance;
+            s2.revCompl = o.t.strand == REVERSE_C_STRAND;
+            for (auto& p : o.t.cigar) s2.cigar += std::to_string(p.second) + p.first;
+            return s2;
+        };
+        const bool rcFirst = occs[0].t.strand == REVERSE_C_STRAND;
+        std::string out;
+        if (xaTag) {
+            std::vector<SamOcc> v;
+            for (auto& o : occs) v.push_back(toSam(o));
+            return samSingleEndXA(seqID, v, rcFirst ? revC : read, rcFirst ? revQ : qual, nHits);
+        }
+        out += samSingleEnd(seqID, toSam(occs[0]), rcFirst ? revC : read, rcFirst ? revQ : qual, nHits, minScore, true);
+        for (size_t i = 1; i < occs.size(); i++) out += samSingleEnd(seqID, toSam(occs[i]), "*", "*", nHits, minScore, false);
+        return out;
+    }
+
     // nucleotide.h getRevComplWithN: complement ACGT, everything else N
     static std::string revCompl(const std::string& s) {
         std::string r(s.size(), 'N');
