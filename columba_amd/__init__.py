@@ -40,7 +40,7 @@ EXPORTS = [
     "cmb_index_layout_of", "cmb_index_seq_starts", "cmb_index_create_empty", "cmb_index_device_arrays",
     "cmb_strategy_create_named", "cmb_strategy_create_from_dir", "cmb_strategy_create",
     "cmb_strategy_add_scheme", "cmb_strategy_set_partition_params", "cmb_strategy_destroy",
-    "cmb_strategy_describe", "cmb_strategy_export_scheme", "cmb_strategy_export_partition", "cmb_match_batch", "cmb_batch_create", "cmb_batch_run",
+    "cmb_strategy_describe", "cmb_strategy_export_scheme", "cmb_strategy_export_partition", "cmb_match_batch", "cmb_batch_create", "cmb_batch_run", "cmb_batch_stage_reads",
     "cmb_batch_result_size", "cmb_batch_results", "cmb_batch_timings", "cmb_batch_destroy",
     "cmb_rank_batch", "cmb_extend_batch", "cmb_extend_bench", "cmb_locate_batch", "cmb_verify_batch", "cmb_verify_batch_staged", "cmb_verify_window", "cmb_cigar_windows",
     "cmb_batch_want_alignments", "cmb_batch_alignments", "cmb_sam_se", "cmb_sam_se_xa", "cmb_sam_unmapped_se",
@@ -145,6 +145,7 @@ def lib():
         L.cmb_match_batch.argtypes = [vp, vp, u32, vp, vp, u32, vp, u64, vp, vp, C.POINTER(u64)]
         L.cmb_batch_create.argtypes = [vp, vp, u32, vp, vp, u32, C.POINTER(vp)]
         L.cmb_batch_run.argtypes = [vp]
+        L.cmb_batch_stage_reads.argtypes = [vp, vp, vp, u32]
         L.cmb_batch_result_size.argtypes = [vp, C.POINTER(u64)]
         L.cmb_batch_results.argtypes = [vp, vp, u64, vp, vp]
         L.cmb_batch_timings.argtypes = [vp, vp, vp, u32]
@@ -466,11 +467,25 @@ class Batch:
     def run(self):
         _chk(lib().cmb_batch_run(self.h))
 
-    def results(self):
+    def stage(self, packed):
+        """copy the next chunk (buf, offs: same number of reads) to the device while the current one is matched"""
+        buf, offs = packed
+        self._staged = (buf, offs)  # (kept alive until the next run has taken them)
+        _chk(lib().cmb_batch_stage_reads(self.h, _p(buf), _p(offs), offs.shape[0] - 1))
+
+    def results(self, reuse: bool = False):
+        """(occurrences, per-read offsets, counters); reuse=True hands out views of buffers the Batch keeps between
+        calls (a streaming caller consumes a chunk's results before the next run)"""
         n = C.c_uint64()
         _chk(lib().cmb_batch_result_size(self.h, C.byref(n)))
-        occs = np.zeros(max(int(n.value), 1), OCC_DTYPE)
-        offs = np.zeros(self.n_reads + 1, np.uint64)
+        need = max(int(n.value), 1)
+        if reuse and getattr(self, "_res", None) is not None and self._res[0].shape[0] >= need:
+            occs, offs = self._res
+        else:
+            occs = np.zeros(need + (need // 8 if reuse else 0), OCC_DTYPE)
+            offs = np.zeros(self.n_reads + 1, np.uint64)
+            if reuse:
+                self._res = (occs, offs)
         cnt = np.zeros(len(COUNTER_NAMES), np.uint64)
         _chk(lib().cmb_batch_results(self.h, _p(occs), occs.shape[0], _p(offs), _p(cnt)))
         return occs[:n.value], offs, dict(zip(COUNTER_NAMES, cnt.tolist()))

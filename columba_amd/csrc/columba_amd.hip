@@ -515,6 +515,17 @@ struct cmb_batch {
     // extension kernels of another (starting them one after the other on purpose was measured slower: the
     // device idles at both ends).
     std::vector<cmb_batch*> subs;
+    std::vector<uint32_t> subBound; // composite: first read of every sub-batch (+ total)
+    // the NEXT chunk of reads, uploaded on a stream of its own while this one is being matched (cmb_batch_stage_reads);
+    // cmb_batch_run swaps it in
+    DevBuf<uint8_t> readsStage;
+    DevBuf<uint64_t> offsStage;
+    std::vector<uint64_t> hostOffsStage, hostOffsActive;
+    hipStream_t copyStream = nullptr;
+    hipEvent_t copyDone = nullptr;
+    bool staged = false;                 // readsStage / offsStage hold an uploaded chunk (or its upload is in flight)
+    const char* pendingSeqs = nullptr;   // a registered chunk whose upload the next run starts
+    bool pending = false;
     cmb_batch* parent = nullptr;
     uint32_t subIndex = 0;
     // results
@@ -525,6 +536,8 @@ struct cmb_batch {
     bool done = false;
     ~cmb_batch() {
         for (cmb_batch* c : subs) delete c;
+        if (copyDone) (void)hipEventDestroy(copyDone);
+        if (copyStream) (void)hipStreamDestroy(copyStream);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -589,6 +602,7 @@ extern "C" int cmb_batch_create(cmb_index* idx, const cmb_strategy* st, uint32_t
         c->subIndex = j;
         parent->subs.push_back(c);
     }
+    parent->subBound = bound;
     *out = parent.release();
     return CMB_OK;
 }
@@ -741,11 +755,70 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
     return CMB_OK;
 }
 
+// Streaming: the reads of the NEXT chunk (same number of reads, none longer than the batch was created for) are copied
+// to the device on a stream of their own while the current chunk is matched; the next cmb_batch_run takes them.  The
+// host memory must stay valid until that run has started (page-locked memory makes the copy asynchronous and fast).
+extern "C" int cmb_batch_stage_reads(cmb_batch* b, const char* seqs, const uint64_t* offs, uint32_t n_reads) {
+    if (!b || !offs || (!seqs && n_reads)) return fail(CMB_ERR_INVALID, "null argument");
+    if (n_reads != b->nReads) return fail(CMB_ERR_INVALID, "a staged chunk must hold as many reads as the batch was created with");
+    if (!b->subs.empty()) {
+        for (size_t j = 0; j < b->subs.size(); j++) {
+            const uint32_t lo = b->subBound[j], hi = b->subBound[j + 1];
+            std::vector<uint64_t> o(hi - lo + 1);
+            for (uint32_t i = lo; i <= hi; i++) o[i - lo] = offs[i] - offs[lo];
+            const int rc = cmb_batch_stage_reads(b->subs[j], seqs + offs[lo], o.data(), hi - lo);
+            if (rc != CMB_OK) return rc;
+        }
+        return CMB_OK;
+    }
+    uint32_t maxLen = 1;
+    for (uint32_t i = 0; i < n_reads; i++) {
+        if (offs[i + 1] < offs[i]) return fail(CMB_ERR_INVALID, "read offsets must be non-decreasing");
+        maxLen = std::max<uint32_t>(maxLen, (uint32_t)(offs[i + 1] - offs[i]));
+    }
+    if (maxLen > b->maxLen) return fail(CMB_ERR_INVALID, "a staged read is longer than the batch was created for");
+    if (b->pending) return fail(CMB_ERR_INVALID, "a chunk is already registered for the next run");
+    b->hostOffsStage.assign(offs, offs + n_reads + 1);
+    b->pendingSeqs = seqs;
+    b->pending = true;
+    return CMB_OK;
+}
+// start the upload of the registered chunk on the copy stream (called by a run, right after its own reads are in place)
+static void startStagedUpload(cmb_batch* b) {
+    if (!b->copyStream) {
+        HIPCHK(hipStreamCreateWithFlags(&b->copyStream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&b->copyDone, hipEventDisableTiming));
+    }
+    const uint32_t n = b->nReads;
+    const size_t nChars = b->hostOffsStage[n];
+    if (b->readsStage.n < nChars) b->readsStage.alloc(nChars + nChars / 16 + 256);
+    if (b->offsStage.n < (size_t)n + 1) b->offsStage.alloc((size_t)n + 1);
+    if (nChars) HIPCHK(hipMemcpyAsync(b->readsStage.p, b->pendingSeqs, nChars, hipMemcpyHostToDevice, b->copyStream));
+    HIPCHK(hipMemcpyAsync(b->offsStage.p, b->hostOffsStage.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice,
+                          b->copyStream));
+    HIPCHK(hipEventRecord(b->copyDone, b->copyStream));
+    b->pending = false;
+    b->staged = true;
+}
+
 static int batchRunOne(cmb_batch* b) {
     try {
         cmb_index* ix = b->ix;
         useDevice(ix->device);
         hipStream_t s = b->stream;
+        if (b->staged) { // the chunk uploaded during the previous run becomes the batch's reads
+            HIPCHK(hipEventSynchronize(b->copyDone));
+            std::swap(b->reads.p, b->readsStage.p);
+            std::swap(b->reads.n, b->readsStage.n);
+            std::swap(b->offs.p, b->offsStage.p);
+            std::swap(b->offs.n, b->offsStage.n);
+            b->hostOffs.swap(b->hostOffsActive);
+            b->staged = false;
+        }
+        if (b->pending) { // the chunk registered since travels to the device while this run's kernels execute
+            b->hostOffsActive = b->hostOffsStage; // (offsets of the chunk in flight: the batch's from the next run on)
+            startStagedUpload(b);
+        }
         b->times.clear();
         b->done = false;
         Timer tm(s, b->times);

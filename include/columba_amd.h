@@ -189,6 +189,13 @@ int cmb_match_batch(cmb_index* idx, const cmb_strategy* st, uint32_t max_distanc
 int cmb_batch_create(cmb_index* idx, const cmb_strategy* st, uint32_t max_distance, const char* seqs,
                      const uint64_t* offs, uint32_t n_reads, cmb_batch** out);
 int cmb_batch_run(cmb_batch* b);  /* enqueue + wait: the whole hot path on the batch's stream */
+/* Streaming (the reference's reader thread hands chunk after chunk to the workers, src/fastq.cpp:283-395): register the
+ * NEXT chunk of reads — as many reads as the batch was created with, none longer.  The next cmb_batch_run copies it to
+ * the device on a stream of its own WHILE it matches the chunk the batch holds, and the run after that matches it,
+ * with all scratch memory of the batch reused:
+ *     create(A); stage(B); run() -> A   [B travels]; stage(C); run() -> B   [C travels]; run() -> C
+ * seqs must stay valid until the run that uploads it has returned; page-locked host memory makes the copy asynchronous. */
+int cmb_batch_stage_reads(cmb_batch* b, const char* seqs, const uint64_t* offs, uint32_t n_reads);
 int cmb_batch_result_size(const cmb_batch* b, uint64_t* n_occ);
 int cmb_batch_results(const cmb_batch* b, cmb_occ* out, uint64_t out_cap, uint64_t* out_offs,
                       uint64_t* counters);

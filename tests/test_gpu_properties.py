@@ -181,3 +181,28 @@ def test_one_index_many_host_threads(big):
     assert not errs, errs
     for t in range(4):
         assert np.array_equal(out[t][0], ser[t][0]) and out[t][2] == ser[t][2], t
+
+
+def test_staged_chunks_stream_through_one_batch(big):
+    """cmb_batch_stage_reads: create(A); stage(B); run() -> A while B travels; stage(C); run() -> B; run() -> C —
+    results are those of fresh batches on those chunks, for a plain and for a composite batch (sub-batches)."""
+    st = ca.SearchStrategy("multiple_opt", "edit", "dynamic")
+    for sub in (None, "3"):
+        if sub:
+            os.environ["CMB_SUBBATCHES"] = sub
+        try:
+            a, b_, c = (big["reads"][i * 20000:(i + 1) * 20000] for i in range(3))
+            want = [ca.match_batch(big["dev"], st, 4, x) for x in (a, b_, c)]
+            chunks = [ca.pack_reads(x) for x in (a, b_, c)]
+            batch = ca.Batch(big["dev"], st, 4, packed=chunks[0])
+            got = []
+            for i in range(3):
+                if i + 1 < 3:
+                    batch.stage(chunks[i + 1])
+                batch.run()
+                got.append(batch.results())
+            batch.close()
+        finally:
+            os.environ.pop("CMB_SUBBATCHES", None)
+        for w, g in zip(want, got):
+            assert np.array_equal(w[0], g[0]) and np.array_equal(w[1], g[1]) and w[2] == g[2]
