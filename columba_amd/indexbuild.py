@@ -369,6 +369,9 @@ def save_index(ix: IndexArrays, base: str) -> None:
             f.write(struct.pack("<Q", len(b)))
             f.write(b)
     np.zeros(1, dtype=np.uint32).tofile(base + ".fsid")
+    with open(base + ".headerSN.bin", "wb") as f:               # buildindex.cpp:341-353
+        for i, name in enumerate(ix.seq_names):
+            f.write(f"@SQ\tSN:{name}\tLN:{int(ix.seq_starts[i + 1]) - int(ix.seq_starts[i])}\n".encode())
 
 
 def read_sparse_sa(base: str, sparseness: int):

@@ -1,0 +1,92 @@
+// A Columba-style single-end aligner over the C-ABI (the counterpart of `columba` for the hot path this library
+// accelerates: reference src/parallel.cpp main / threadEntrySingleEnd / processChunk):
+//   columba_align -r <index base> -f <reads.fq|fa> -o <out.sam> [-e <max distance>] [-a all|best] [-x <strata>]
+//                 [-I <min identity>] [-S <strategy>] [-m edit|hamming] [-p uniform|static|dynamic]
+//                 [-s <SA sparseness>] [-K <k-mer size>] [-b <reads per chunk>] [-XA] [-nU]
+// FASTQ / FASTA in, SAM out (header of <base>.headerSN.bin, records in input order).
+#include "columba_amd.hpp"
+#include "columba_amd_io.hpp"
+
+#include <cstring>
+#include <iostream>
+
+using namespace columba_amd;
+
+int main(int argc, char** argv) {
+    std::string base, readsFile, outFile, strategyName = "columba", mode = "best", metric = "edit", part = "dynamic", cmdline;
+    int k = 0, x = 0, identity = 95, sparse = 4, kmer = 10;
+    size_t chunkReads = 1000000;
+    bool xa = false, unmapped = true;
+    for (int i = 0; i < argc; i++) cmdline += std::string(i ? " " : "") + argv[i];
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto val = [&]() -> std::string {
+            if (i + 1 >= argc) throw std::runtime_error("missing value for " + a);
+            return argv[++i];
+        };
+        try {
+            if (a == "-r") base = val();
+            else if (a == "-f") readsFile = val();
+            else if (a == "-o") outFile = val();
+            else if (a == "-e") k = std::stoi(val());
+            else if (a == "-a") mode = val();
+            else if (a == "-x") x = std::stoi(val());
+            else if (a == "-I") identity = std::stoi(val());
+            else if (a == "-S") strategyName = val();
+            else if (a == "-m") metric = val();
+            else if (a == "-p") part = val();
+            else if (a == "-s") sparse = std::stoi(val());
+            else if (a == "-K") kmer = std::stoi(val());
+            else if (a == "-b") chunkReads = (size_t)std::stoul(val());
+            else if (a == "-XA") xa = true;
+            else if (a == "-nU") unmapped = false;
+            else throw std::runtime_error("unknown option " + a);
+        } catch (const std::exception& e) {
+            std::cerr << "Fatal error: " << e.what() << "\n";
+            return 2;
+        }
+    }
+    if (base.empty() || readsFile.empty() || outFile.empty()) {
+        std::cerr << "usage: " << argv[0] << " -r <index base> -f <reads> -o <out.sam> [-e k] [-a all|best] [-x strata] [-I identity] "
+                     "[-S strategy] [-m edit|hamming] [-p uniform|static|dynamic] [-s sparseness] [-K kmer] [-b chunk] [-XA] [-nU]\n";
+        return 2;
+    }
+    try {
+        FMIndex index(base, 4, false, sparse, false, (length_t)kmer);
+        const PartitionStrategy ps = part == "uniform" ? UNIFORM : part == "static" ? STATIC : DYNAMIC;
+        const DistanceMetric dm = metric == "hamming" ? HAMMING : EDIT;
+        NamedStrategy strategy(index, strategyName.c_str(), ps, dm);
+        const std::vector<std::string> seqNames = readSequenceNames(base);
+        std::vector<const char*> seqNamePtrs;
+        for (const auto& s : seqNames) seqNamePtrs.push_back(s.c_str());
+        Reader reader(readsFile);
+        OutputWriter writer(outFile, base + ".headerSN.bin", cmdline);
+        std::vector<SequenceRecord> chunk;
+        size_t chunkID = 0, nReads = 0, nMapped = 0;
+        while (reader.getNextChunk(chunk, chunkReads)) {
+            std::string seqs;
+            std::vector<uint64_t> offs(chunk.size() + 1, 0);
+            std::vector<const char*> ids, quals;
+            for (size_t i = 0; i < chunk.size(); i++) {
+                seqs += chunk[i].read;
+                offs[i + 1] = seqs.size();
+                ids.push_back(chunk[i].seqID.c_str());
+                quals.push_back(chunk[i].qual.c_str());
+            }
+            std::string text;
+            if (mode == "all") {
+                text = strategy.samOfChunkAll(seqs, offs, ids, quals, seqNamePtrs, (length_t)k, unmapped, xa);
+            } else {
+                text = strategy.samOfChunkBest(seqs, offs, chunk, seqNames, (uint32_t)x, (uint32_t)identity, unmapped, xa, nMapped);
+            }
+            nReads += chunk.size();
+            writer.commitChunk(chunkID++, std::move(text));
+        }
+        writer.flush();
+        std::cerr << "aligned " << nReads << " reads in " << chunkID << " chunk(s)\n";
+    } catch (const std::exception& e) {
+        std::cerr << "Fatal error: " << e.what() << "\n";
+        return 1;
+    }
+    return 0;
+}

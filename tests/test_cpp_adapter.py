@@ -43,3 +43,71 @@ def test_adapter_example_matches_python_binding(tmp_path):
     exp = sorted((i, int(o["begin"]), int(o["end"]), int(o["distance"]), int(o["strand"]))
                  for i in range(len(reads)) for o in occ[int(offs[i]):int(offs[i + 1])])
     assert got == exp and len(exp) > 0
+
+
+def _build_align(tmp):
+    ca.build_library()
+    exe = os.path.join(tmp, "columba_align")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "columba_align.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "columba_amd"), "-lcolumba_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "columba_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_align_driver_compiles_and_checks_its_arguments(tmp_path):
+    exe = _build_align(str(tmp_path))
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+    (tmp_path / "r.fq").write_text("@r1\nACGT\n+\nIIII\n")
+    r = subprocess.run([exe, "-r", str(tmp_path / "nope"), "-f", str(tmp_path / "r.fq"), "-o", str(tmp_path / "o.sam")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "Cannot open file" in r.stderr
+
+
+@pytest.mark.gpu
+def test_align_driver_fastq_to_sam(tmp_path, oracle_built):
+    """FASTQ in, SAM out through the C++ host layer (Reader / OutputWriter of include/columba_amd_io.hpp, chunks of 400
+    reads): the records of ALL mode equal the oracle's SAM text for the same reads; BEST mode (the default) gives
+    one primary record per mapped read whose position the oracle's BEST mode agrees with."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as op
+    import schemes_py as sp
+    from columba_amd import indexbuild as ib, synth
+    exe = _build_align(str(tmp_path))
+    g, starts = synth.genome_rep(seed=2, n=300_000, scale=2.0)
+    ix = ib.build_index(g.tobytes(), seq_starts=starts, device="cuda")
+    ib.save_index(ix, str(tmp_path / "idx"))
+    reads = synth.sample_reads(g, 1000, 120, seed=9, n_frac=0.01)
+    rng = np.random.default_rng(3)
+    ids = [f"@read{i} len=120" for i in range(len(reads))]
+    quals = ["".join(chr(33 + int(q)) for q in rng.integers(0, 41, 120)) for _ in reads]
+    with open(tmp_path / "reads.fq", "w") as f:
+        for i, r in enumerate(reads):
+            f.write(f"{ids[i]}\n{r.decode()}\n+\n{quals[i]}\n")
+    names = ix.seq_names
+    out = tmp_path / "all.sam"
+    subprocess.run([exe, "-r", str(tmp_path / "idx"), "-f", str(tmp_path / "reads.fq"), "-o", str(out), "-a", "all", "-e", "4",
+                    "-S", "columba", "-b", "400"], check=True, capture_output=True, text=True)
+    lines = out.read_text().splitlines()
+    header = [x for x in lines if x.startswith("@")]
+    assert header[0] == "@HD\tVN:1.6\tSO:queryname" and sum(x.startswith("@SQ") for x in header) == len(names)
+    want = op.match_batch_sam(op.OracleIndex(ix), op.OracleStrategy(sp.COLUMBA, "edit", "dynamic"), 4, reads, ids, quals, names,
+                              unmapped=True, xa=False).splitlines()
+    assert [x for x in lines if not x.startswith("@")] == want and len(want) > 1000
+    # BEST mode (the reference's default): one primary record per read, in input order
+    outb = tmp_path / "best.sam"
+    subprocess.run([exe, "-r", str(tmp_path / "idx"), "-f", str(tmp_path / "reads.fq"), "-o", str(outb), "-I", "95"], check=True,
+                   capture_output=True, text=True)
+    recs = [x.split("\t") for x in outb.read_text().splitlines() if not x.startswith("@")]
+    prim = [f for f in recs if not int(f[1]) & 256]
+    assert [f[0] for f in prim] == [i[1:].split(" ")[0] for i in ids]
+    o_occ, o_sid, o_sb, o_cig, o_off, o_best, o_hits, _ = op.match_best(op.OracleIndex(ix), op.OracleStrategy(sp.COLUMBA, "edit", "dynamic"),
+                                                                        reads, x=0, min_identity=95, max_supported=6, threads=8)
+    for i, f in enumerate(prim):
+        if o_best[i] == 0xFFFFFFFF:
+            assert f[1] == "4"
+        else:
+            j = int(o_off[i])
+            assert (f[2], int(f[3]), f[5], f[11]) == (names[int(o_sid[j])], int(o_sb[j]) + 1, o_cig[j], f"AS:i:{int(o_best[i])}")
