@@ -458,6 +458,8 @@ struct KernelTime {
 struct cmb_batch {
     cmb_index* ix = nullptr;
     uint32_t k = 0, nReads = 0, maxLen = 0, gw = 0;
+    uint32_t minLen = 0; // shortest read of the batch and of every chunk staged since (picks the verification stages
+                         // that carry final-column code)
     int metric = 1;
     DevStrategyK hostStrat{};
     hipStream_t stream = nullptr;
@@ -628,11 +630,13 @@ static int batchCreateOne(cmb_index* idx, const cmb_strategy* st, uint32_t max_d
                 return fail(CMB_ERR_INVALID, e.what());
             }
         }
-        uint32_t maxLen = 1;
+        uint32_t maxLen = 1, minLen = ~0u;
         for (uint32_t i = 0; i < n_reads; i++) {
             if (offs[i + 1] < offs[i]) return fail(CMB_ERR_INVALID, "read offsets must be non-decreasing");
             maxLen = std::max<uint32_t>(maxLen, (uint32_t)(offs[i + 1] - offs[i]));
+            minLen = std::min<uint32_t>(minLen, (uint32_t)(offs[i + 1] - offs[i]));
         }
+        b->minLen = n_reads ? minLen : 0u;
         if (maxLen > (uint32_t)MAX_READ)
             return fail(CMB_ERR_UNSUPPORTED, "reads longer than " + std::to_string(MAX_READ) + " are not supported");
         // rows of per-read arrays are padded to a multiple of 16 bytes (16-byte stores in k_prep); the number of
@@ -771,11 +775,13 @@ extern "C" int cmb_batch_stage_reads(cmb_batch* b, const char* seqs, const uint6
         }
         return CMB_OK;
     }
-    uint32_t maxLen = 1;
+    uint32_t maxLen = 1, minLen = ~0u;
     for (uint32_t i = 0; i < n_reads; i++) {
         if (offs[i + 1] < offs[i]) return fail(CMB_ERR_INVALID, "read offsets must be non-decreasing");
         maxLen = std::max<uint32_t>(maxLen, (uint32_t)(offs[i + 1] - offs[i]));
+        minLen = std::min<uint32_t>(minLen, (uint32_t)(offs[i + 1] - offs[i]));
     }
+    b->minLen = std::min(b->minLen, n_reads ? minLen : 0u);
     if (maxLen > b->maxLen) return fail(CMB_ERR_INVALID, "a staged read is longer than the batch was created for");
     if (b->pending) return fail(CMB_ERR_INVALID, "a chunk is already registered for the next run");
     b->hostOffsStage.assign(offs, offs + n_reads + 1);
@@ -1204,21 +1210,34 @@ static int batchRunOne(cmb_batch* b) {
                         // k <= 4: the matrix on 32-bit words (dev_matrix.hpp); CMB_MATRIX_WIDE=1 keeps the 64-bit words
                         const bool w32 = b->k <= MX32_MAX_ED && !getenv("CMB_MATRIX_WIDE");
                         const bool packed = ix->d.text2 != nullptr; // 2-bit text (cmb_index_create)
-                        auto stageFirst = k_verify_stage<true, false, false>, stageNext = k_verify_stage<false, false, false>;
-                        if (w32 && packed) {
-                            stageFirst = k_verify_stage<true, true, true>;
-                            stageNext = k_verify_stage<false, true, true>;
-                        } else if (w32) {
-                            stageFirst = k_verify_stage<true, true, false>;
-                            stageNext = k_verify_stage<false, true, false>;
-                        } else if (packed) {
-                            stageFirst = k_verify_stage<true, false, true>;
-                            stageNext = k_verify_stage<false, false, true>;
-                        }
-                        hipLaunchKernelGGL(stageFirst, dim3(grid), dim3(256), 0, s, ix->d, b->offs.p, mf,
+                        // stages no read of the batch can reach its final-column rows in (row >= len - maxED - 1,
+                        // maxED <= 7) run the instance without final-column code
+                        auto needsFinal = [&](uint32_t st) { return 32u * nb * (st + 1u) - 1u + 8u >= b->minLen; };
+                        auto stageKernel = [&](bool first, bool fin) {
+                            const int sel = (first ? 8 : 0) | (w32 ? 4 : 0) | (packed ? 2 : 0) | (fin ? 1 : 0);
+                            switch (sel) {
+                            case 0: return k_verify_stage<false, false, false, false>;
+                            case 1: return k_verify_stage<false, false, false, true>;
+                            case 2: return k_verify_stage<false, false, true, false>;
+                            case 3: return k_verify_stage<false, false, true, true>;
+                            case 4: return k_verify_stage<false, true, false, false>;
+                            case 5: return k_verify_stage<false, true, false, true>;
+                            case 6: return k_verify_stage<false, true, true, false>;
+                            case 7: return k_verify_stage<false, true, true, true>;
+                            case 8: return k_verify_stage<true, false, false, false>;
+                            case 9: return k_verify_stage<true, false, false, true>;
+                            case 10: return k_verify_stage<true, false, true, false>;
+                            case 11: return k_verify_stage<true, false, true, true>;
+                            case 12: return k_verify_stage<true, true, false, false>;
+                            case 13: return k_verify_stage<true, true, false, true>;
+                            case 14: return k_verify_stage<true, true, true, false>;
+                            default: return k_verify_stage<true, true, true, true>;
+                            }
+                        };
+                        hipLaunchKernelGGL(stageKernel(true, needsFinal(0)), dim3(grid), dim3(256), 0, s, ix->d, b->offs.p, mf,
                                            b->vkeysA.p, b->vcounts.p, nRuns, L0, L1, b->vsN.p, listCap, 0u, nb, b->tbq.p, tbCap, q);
                         for (uint32_t st = 1; st < nStages; st++)
-                            hipLaunchKernelGGL(stageNext, dim3(grid), dim3(256), 0, s, ix->d, b->offs.p, mf,
+                            hipLaunchKernelGGL(stageKernel(false, needsFinal(st)), dim3(grid), dim3(256), 0, s, ix->d, b->offs.p, mf,
                                                (const unsigned long long*)nullptr, (const uint32_t*)nullptr, 0u,
                                                (st & 1u) ? L1 : L0, (st & 1u) ? L0 : L1, b->vsN.p, listCap, st, nb, b->tbq.p, tbCap,
                                                q);
@@ -1247,8 +1266,10 @@ static int batchRunOne(cmb_batch* b) {
                     tm.begin();
                     auto kTrace = k_traceback<false, false>;
                     if (narrow) kTrace = ix->d.text2 ? k_traceback<true, true> : k_traceback<true, false>;
+                    // no final-column row (> len - maxED - 1, maxED <= 7) at or before this row, for any read of the batch
+                    const uint32_t rowMin = (b->minLen > 8u ? b->minLen - 8u : 0u) | (getenv("CMB_DEBUG_NOWALK") ? 0x80000000u : 0u);
                     hipLaunchKernelGGL(kTrace, dim3(tSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, mf, b->tbq.p, nTb,
-                                       vp, q);
+                                       vp, q, rowMin);
                     tm.end("k_traceback");
                 }
             }
@@ -1811,7 +1832,7 @@ static int verifyDirect(cmb_index* idx, const char* pattern, uint32_t plen, cons
                 auto kTrace = k_traceback<false, false>;
                 if (narrow) kTrace = idx->d.text2 ? k_traceback<true, true> : k_traceback<true, false>;
                 hipLaunchKernelGGL(kTrace, dim3(slots / 256), dim3(256), 0, 0,
-                                   idx->d, offs.p, mf, tbq.p, hc[7], vp, q);
+                                   idx->d, offs.p, mf, tbq.p, hc[7], vp, q, 0u);
             }
         }
         HIPCHK(hipGetLastError());

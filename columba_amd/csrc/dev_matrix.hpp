@@ -215,6 +215,30 @@ __device__ __forceinline__ bool computeRow(const MatGeom& g, uint32_t i, uint32_
     }
     return true;
 }
+// computeRow without the rightmost-active-column bookkeeping and the score (rows known to be valid: the traceback's
+// forward pass): the Hyyro recurrence only
+__device__ __forceinline__ void computeRowCore(uint32_t i, uint64_t M, uint64_t& HP, uint64_t& HN, uint64_t& D0) {
+    if (i % MX_BLOCK == 0) {
+        HP >>= MX_BLOCK;
+        HN >>= MX_BLOCK;
+    }
+    D0 = (((M & HP) + HP) ^ HP) | M | HN;
+    const uint64_t VP = HN | ~(D0 | HP);
+    const uint64_t VN = D0 & HP;
+    HP = (VN << 1u) | ~(D0 | (VP << 1u));
+    HN = (D0 & (VP << 1u));
+}
+__device__ __forceinline__ void computeRowCore(uint32_t i, uint32_t M, uint32_t& HP, uint32_t& HN, uint32_t& D0) {
+    if (i % MX32_BLOCK == 0) {
+        HP >>= MX32_BLOCK;
+        HN >>= MX32_BLOCK;
+    }
+    D0 = (((M & HP) + HP) ^ HP) | M | HN;
+    const uint32_t VP = HN | ~(D0 | HP);
+    const uint32_t VN = D0 & HP;
+    HP = (VN << 1u) | ~(D0 | (VP << 1u));
+    HN = (D0 & (VP << 1u));
+}
 // the RAC state of a matrix word type: one-bit mask (64-bit matrix) or bit index (32-bit matrix)
 __device__ __forceinline__ uint64_t racInit(uint64_t, uint32_t bit) { return 1ull << bit; }
 __device__ __forceinline__ uint32_t racInit(uint32_t, uint32_t bit) { return bit; }

@@ -688,12 +688,15 @@ __device__ __forceinline__ void loadMatchWords(const MFull& mf, uint32_t rs, uin
 //   are detected on the fly (bitparallelmatrix.h:591-614 needs only ED(i-1), ED(i), ED(i+1)).
 // STORE = true : traceback pass (k_traceback) — HP and D0 of every row go to the interleaved planes.
 // Returns the number of valid rows `i` (indexhelpers.cpp:535-539); centreMask bit t <=> row firstRow+1+t.
-template <bool STORE, bool NARROW = false, bool PACKED = false>
+// CHECK = false (k_traceback: every row is known to be valid from pass 1): no rightmost-active-column walk, the
+//   score comes from the row number and the count of diagonal matches; returns min(size, rows).
+// rowMin: no lane has final-column rows (r > firstRow) at rows <= rowMin (wave-uniform skip of that code).
+template <bool STORE, bool NARROW = false, bool PACKED = false, bool CHECK = true>
 __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull& mf, uint32_t rs,
                                                 const MatGeom& g, uint32_t nZeros, uint32_t start, uint32_t size,
                                                 uint32_t maxED, uint32_t minED, uint32_t& centreMask,
                                                 uint64_t& edPack, uint64_t& edPackHi, const VPlanes& V, uint32_t slot,
-                                                uint32_t& cRows, uint64_t* Ml) {
+                                                uint32_t& cRows, uint64_t* Ml, uint32_t rowMin = 0) {
     // NARROW (k <= 4) also means the matrix on 32-bit words / 8-row blocks (dev_matrix.hpp)
     using W = typename std::conditional<NARROW, uint32_t, uint64_t>::type;
     constexpr uint32_t LEFT = NARROW ? MX32_LEFT : MX_LEFT, DIAG = NARROW ? MX32_DIAG : MX_DIAG;
@@ -728,7 +731,7 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
         cur = loadText16(tp);
         nxt = loadText16(tp + 16); // the text allocation is padded
     }
-    uint32_t i = 0;
+    uint32_t i = 0, dm = 0;
     bool alive = size > 0;
     uint64_t buf[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // STORE: the packed rows of the current group of eight
     uint32_t bufN[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // NARROW: of the current group of sixteen
@@ -753,12 +756,27 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
             if (alive) {
                 const uint64_t M64 = Ml[tc * 256 + tid];
                 const W M = NARROW ? (W)matchWord32(M64, r) : (W)M64;
-                cRows++;
-                const bool valid = computeRow(g, r, M, HP, HN, D0, RAC, score);
+                bool valid = true;
+                if (CHECK) {
+                    cRows++;
+                    valid = computeRow(g, r, M, HP, HN, D0, RAC, score);
+                } else {
+                    computeRowCore(r, M, HP, HN, D0);
+                    dm += (uint32_t)(D0 >> ((r % (NARROW ? MX32_BLOCK : MX_BLOCK)) + DIAG)) & 1u;
+                }
                 if (STORE && !NARROW) buf[t & 7u] = packTraceRow(r, (uint64_t)HP, (uint64_t)(M | ~D0));
                 if (STORE && NARROW) bufN[t] = packTraceRowNarrow(r, (uint32_t)HP, (uint32_t)(M | ~D0));
                 if (!valid) {
                     alive = false;
+                } else if (!CHECK) {
+                    if (STORE && r > rowMin && r > firstRow) {
+                        const uint32_t ed = cellAt(r, col, HP, HN, r - dm);
+                        const uint32_t bidx = r - firstRow - 1u;
+                        if (bidx < 21u) edPack |= (uint64_t)min(ed, 7u) << (3u * bidx);
+                        else edPackHi |= (uint64_t)min(ed, 7u) << (3u * (bidx - 21u));
+                    }
+                    i = r;
+                    alive = r < size;
                 } else {
                     if (STORE && r > firstRow) {
                         const uint32_t ed = cellAt(r, col, HP, HN, score);
@@ -1035,7 +1053,13 @@ struct VStageList { // survivors entering a stage
 };
 
 // W32: the matrix on 32-bit words / 8-row blocks (dev_matrix.hpp; k <= 4) — half the VALU work of a row.
-template <bool FIRST, bool W32, bool PACKED>
+// FINALCOL: rows of this stage may lie in the final-column range of some candidate (row >= len - maxED - 1); the
+// host clears it for the stages no read of the batch can reach that far in, and those instances carry no
+// final-column / cluster-centre code (a third fewer instructions per row).
+// Per row and alive lane the loop keeps no row counter: a lane that is alive has done every row up to the
+// (wave-uniform) current one, so rows done, MATRIX_ROWS and the score (rows - matches on the diagonal) are derived
+// from the row number; only the diagonal matches are counted.
+template <bool FIRST, bool W32, bool PACKED, bool FINALCOL>
 __global__ void __launch_bounds__(256)
 k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                const unsigned long long* __restrict__ ukeys, const uint32_t* __restrict__ counts, uint32_t nKeys,
@@ -1048,13 +1072,15 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
     uint32_t cText = 0, cAbort = 0, cCig = 0, cStarted = 0, flags = 0;
     Ml[4 * 256 + tid] = 0ull; // text code 4 ('$', padding): matches nothing
     const uint32_t rFirst = FIRST ? 1u : 32u * nb * stage; // first row of this stage (nb 32-row blocks per stage)
+    const uint32_t rLast = 32u * nb * (stage + 1u) - 1u;   // last row of this stage
     for (uint32_t base = blockIdx.x * 256u; base < nIn; base += gridDim.x * 256u) { // block-uniform trip count
         const uint32_t it = base + tid;
         bool alive = false;
         unsigned long long key = ~0ull;
-        uint32_t mult = 0, len = 0, score = 0, mask = 0, edPrev = 0, edPrev2 = 0;
+        uint32_t mult = 0, len = 0, score0 = 0, mask = 0, edPrev = 0, edPrev2 = 0;
         using W = typename std::conditional<W32, uint32_t, uint64_t>::type;
         constexpr uint32_t LEFT = W32 ? MX32_LEFT : MX_LEFT, DIAG = W32 ? MX32_DIAG : MX_DIAG;
+        constexpr uint32_t BLOCK = W32 ? MX32_BLOCK : MX_BLOCK;
         W HP = 0, HN = 0, RAC = 0;
         if (it < nIn) {
             if (FIRST) {
@@ -1070,7 +1096,7 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                 const uint32_t rc = in.c[it];
                 key = (unsigned long long)ra.x | ((unsigned long long)ra.y << 32);
                 mult = ra.z & 0xFFFFFFu;
-                score = ra.z >> 24;
+                score0 = ra.z >> 24;
                 mask = ra.w;
                 HP = W32 ? (W)rb.x : (W)((uint64_t)rb.x | ((uint64_t)rb.y << 32));
                 HN = W32 ? (W)rb.z : (W)((uint64_t)rb.z | ((uint64_t)rb.w << 32));
@@ -1102,12 +1128,17 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                 HP = (W)(~(W)0) << LEFT;
                 HN = ((W)1 << (LEFT + 1u - nZeros)) - (W)1; // first column: nZeros zeros, then 1, 2, ...
                 RAC = racInit((W)0, DIAG + g.Wh);
-                if (firstRow == 0) edPrev = cellAt(0, col, HP, HN, 0);
+                if (firstRow == 0) {
+                    if (FINALCOL) edPrev = cellAt(0, col, HP, HN, 0);
+                    else flags |= FLAG_CAPACITY; // (the host launches the final-column instance for such reads)
+                }
             }
         }
-        uint32_t i = rFirst - 1; // rows done so far
-        uint32_t rows = 0;
-        bool ended = false;
+        if (!FINALCOL && alive && rLast >= firstRow) flags |= FLAG_CAPACITY; // (host: stageNeedsFinalColumn)
+        const bool alive0 = alive;
+        uint32_t iDead = max(size, rFirst); // rows done when the candidate ended: all `size` of them, or up to the invalid row
+        uint32_t inval = 0;    // ended by a row without a cell <= maxED (that row was computed: it counts)
+        uint32_t dm = 0;       // rows of this stage whose diagonal cell matched (score = rows - dm)
         for (uint32_t h = 0; h < nb; h++) {
         if (__ballot(alive) == 0ull) break; // (wave-uniform)
         const uint32_t blk = nb * stage + h;
@@ -1138,14 +1169,17 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             if (alive && !(t == 31 && head)) { // (the head block has 31 rows)
                 const uint64_t M64 = Ml[tc * 256 + tid];
                 const W M = W32 ? (W)matchWord32(M64, r) : (W)M64;
-                rows++;
                 W D0;
-                const bool valid = computeRow(g, r, M, HP, HN, D0, RAC, score);
+                uint32_t unusedScore = 0;
+                const bool valid = computeRow(g, r, M, HP, HN, D0, RAC, unusedScore);
+                dm += (uint32_t)(D0 >> ((r % BLOCK) + DIAG)) & 1u;
                 if (!valid) {
                     alive = false;
-                    ended = true;
+                    inval = 1;
+                    iDead = r - 1;
                 } else {
-                    if (r >= firstRow) {
+                    if (FINALCOL && r >= firstRow) {
+                        const uint32_t score = score0 + (r - (rFirst - 1u)) - dm;
                         const uint32_t ed = min(cellAt(r, col, HP, HN, score), 31u);
                         if (r - 1 > firstRow) { // row r-1 can now be judged (its `below` neighbour is known)
                             const uint32_t e1 = edPrev;
@@ -1154,20 +1188,20 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                         edPrev2 = edPrev;
                         edPrev = ed;
                     }
-                    i++;
-                    if (i >= size) {
-                        alive = false;
-                        ended = true;
-                    }
+                    alive = r < size; // (rows done = r)
                 }
             }
         }
         }
+        const bool ended = alive0 && !alive;
+        const uint32_t i = ended ? iDead : rLast; // rows done so far
+        const uint32_t rows = alive0 ? i - (rFirst - 1u) + inval : 0u;
+        const uint32_t score = score0 + rows - dm;
         cText += rows * mult;
         uint32_t nTb = 0;
         uint4 tbRec = make_uint4(0, 0, 0, 0);
         if (ended) {
-            if (i > firstRow) { // the last valid row has no `below` neighbour
+            if (FINALCOL && i > firstRow) { // the last valid row has no `below` neighbour
                 const uint32_t e1 = edPrev;
                 if (e1 <= maxED && e1 >= minED && e1 <= edPrev2) mask |= 1u << (i - 1 - firstRow);
             }
@@ -1210,9 +1244,8 @@ constexpr int TBW = 8;
 template <bool NARROW, bool PACKED>
 __global__ void __launch_bounds__(256)
 k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
-            const uint4* __restrict__ tbq, uint32_t nTasks, VPlanes V, Queues q) {
+            const uint4* __restrict__ tbq, uint32_t nTasks, VPlanes V, Queues q, uint32_t rowMin) {
     __shared__ uint64_t wW[NARROW ? 1 : TBW][256];
-    __shared__ uint32_t wN[NARROW ? 16 : 1][256];
     __shared__ uint64_t Ml[ML_WORDS];
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t tid = threadIdx.x;
@@ -1254,74 +1287,110 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             const uint32_t topCentre = firstRow + 1 + (31u - (uint32_t)__clz(m));
             uint32_t dummyMask;
             // rows 1..topCentre (all valid: they were valid in pass 1)
-            forwardPass<true, NARROW, PACKED>(ix, mf, rs, g, nZeros, start, topCentre, maxED, 0, dummyMask, edPack, edPackHi, V,
-                                      slot, dummyRows, Ml);
+            forwardPass<true, NARROW, PACKED, false>(ix, mf, rs, g, nZeros, start, topCentre, maxED, 0, dummyMask, edPack,
+                                                     edPackHi, V, slot, dummyRows, Ml, rowMin & 0x7FFFFFFFu);
         }
+        if (rowMin >> 31) m = 0; // DEBUG-SPLIT
         // one centre per lane and round; the wavefront appends its results with one atomic per round
         for (;;) {
             const bool have = m != 0;
             if (__ballot(have) == 0ull) break;
             TextOccRec rec{0, 0, 0, 0};
+            uint32_t bitIdx = 0, ri = 0, ti = 0, tj = 0;
             if (have) {
-                const uint32_t bitIdx = 31u - (uint32_t)__clz(m);
+                bitIdx = 31u - (uint32_t)__clz(m);
                 m &= ~(1u << bitIdx);
-                const uint32_t ri = firstRow + 1 + bitIdx;
-                uint32_t ti = ri, tj = col;
+                ri = firstRow + 1 + bitIdx;
+                ti = ri;
+                tj = col;
+            }
+            if (NARROW) {
+                // The wavefront walks its traces ROW by row, downwards and in lock step (line g = rows 16 g + 1 ..
+                // 16 g + 16 sits in sixteen registers, row j of it is handled by every lane whose trace is in that
+                // row): per row, the run of horizontal steps is the run of HP bits below the current column (one
+                // count-leading-ones), then one diagonal or vertical step — no loop over steps, no LDS.
+                bool done = !have;
+                uint32_t rel = tj + TB_BELOW - ti; // bit of the row's windows
+                uint32_t gTop = have ? (ti - 1u) >> 4 : 0u;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) gTop = max(gTop, (uint32_t)__shfl_xor((int)gTop, d));
+                const uint4* Lb = reinterpret_cast<const uint4*>(V.W) + (size_t)slot * V.lines * 4;
+                for (int gq = (int)gTop; gq >= 0; gq--) { // (wave-uniform)
+                    if (__ballot(!done) == 0ull) break;
+                    uint32_t w[16];
+#pragma unroll
+                    for (int h = 0; h < 16; h++) w[h] = 0;
+                    if (!done && ((ti - 1u) >> 4) == (uint32_t)gq) { // (a trace that has reached row 0 loads nothing)
+#pragma unroll
+                        for (int h = 0; h < 4; h++) {
+                            const uint4 v = Lb[(size_t)gq * 4 + h];
+                            w[4 * h] = v.x;
+                            w[4 * h + 1] = v.y;
+                            w[4 * h + 2] = v.z;
+                            w[4 * h + 3] = v.w;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 15; j >= 0; j--) {
+                        if (!done && ti == 16u * (uint32_t)gq + (uint32_t)j + 1u) {
+                            const uint32_t wn = w[j];
+                            if (rel - TBN_REL_LO > TBN_REL_HI - TBN_REL_LO) { // outside the band (checked, not assumed)
+                                flags |= FLAG_CAPACITY;
+                                done = true;
+                            } else {
+                                // HP of column rel is bit rel - TBN_HP_LO of the low half: move it to bit 31 and count the ones
+                                const uint32_t y = (wn << 16) << (TBN_REL_HI - rel);
+                                const uint32_t run = min((uint32_t)__clz(~y), tj); // gaps in horizontal (:553)
+                                tj -= run;
+                                rel -= run;
+                                if (tj == 0) {
+                                    done = true;
+                                } else {
+                                    // "diagonal allowed" of column rel is bit 16 + rel - TBN_DG_LO; always at the band's right edge
+                                    const uint32_t z = __funnelshift_r(wn, 1u, rel - TBN_DG_LO);
+                                    const uint32_t dg = (z >> 16) & 1u; // diagonal (:559); else vertical
+                                    tj -= dg;
+                                    rel += 1u - dg;
+                                    ti -= 1u;
+                                    if (tj == 0) done = true;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (!done) { // row 0: gaps in horizontal down to column 0
+                    if (rel > TBN_REL_HI) flags |= FLAG_CAPACITY;
+                    tj = 0;
+                }
+            } else if (have) {
                 uint32_t curG = 0xFFFFFFFFu; // the line (rows 8 g + 1 .. 8 g + 8) held in wW[.][tid]
                 while (tj > 0) {
                     const uint32_t rel = tj + TB_BELOW - ti; // bit of the row's windows
-                    bool hpBit, dgBit;
-                    if (NARROW) {
-                        uint32_t wn = packTraceRowNarrow(0, (~0u) << MX32_LEFT, 0u); // row 0 (never steps diagonally: ti > 0 below)
-                        if (ti > 0) {
-                            const uint32_t gq = (ti - 1) >> 4, jq = (ti - 1) & 15u;
-                            if (gq != curG) {
-                                curG = gq;
-                                const uint4* L = reinterpret_cast<const uint4*>(V.W) + ((size_t)slot * V.lines + gq) * 4;
+                    uint64_t ww = packTraceRow(0, HP0, 0ull); // row 0 (never steps diagonally: ti > 0 below)
+                    if (ti > 0) {
+                        const uint32_t gq = (ti - 1) >> 3, jq = (ti - 1) & 7u;
+                        if (gq != curG) {
+                            curG = gq;
+                            const uint4* L = reinterpret_cast<const uint4*>(V.W) + ((size_t)slot * V.lines + gq) * 4;
 #pragma unroll
-                                for (int h = 0; h < 4; h++) {
-                                    const uint4 v = L[h];
-                                    wN[4 * h][tid] = v.x;
-                                    wN[4 * h + 1][tid] = v.y;
-                                    wN[4 * h + 2][tid] = v.z;
-                                    wN[4 * h + 3][tid] = v.w;
-                                }
+                            for (int h = 0; h < 4; h++) {
+                                const uint4 v = L[h];
+                                wW[2 * h][tid] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                                wW[2 * h + 1][tid] = (uint64_t)v.z | ((uint64_t)v.w << 32);
                             }
-                            wn = wN[jq][tid];
                         }
-                        if (rel < TBN_REL_LO || rel > TBN_REL_HI) { // outside the band (checked, not assumed)
-                            flags |= FLAG_CAPACITY;
-                            break;
-                        }
-                        hpBit = rel >= TBN_HP_LO && ((wn >> (rel - TBN_HP_LO)) & 1u);
-                        dgBit = rel == TBN_REL_HI || ((wn >> (16u + rel - TBN_DG_LO)) & 1u);
-                    } else {
-                        uint64_t ww = packTraceRow(0, HP0, 0ull); // row 0 (never steps diagonally: ti > 0 below)
-                        if (ti > 0) {
-                            const uint32_t gq = (ti - 1) >> 3, jq = (ti - 1) & 7u;
-                            if (gq != curG) {
-                                curG = gq;
-                                const uint4* L = reinterpret_cast<const uint4*>(V.W) + ((size_t)slot * V.lines + gq) * 4;
-#pragma unroll
-                                for (int h = 0; h < 4; h++) {
-                                    const uint4 v = L[h];
-                                    wW[2 * h][tid] = (uint64_t)v.x | ((uint64_t)v.y << 32);
-                                    wW[2 * h + 1][tid] = (uint64_t)v.z | ((uint64_t)v.w << 32);
-                                }
-                            }
-                            ww = wW[jq][tid];
-                        }
-                        if (rel > 31u) { // outside the stored window: cannot happen inside the band (checked, not assumed)
-                            flags |= FLAG_CAPACITY;
-                            break;
-                        }
-                        hpBit = ((uint32_t)ww >> rel) & 1u;
-                        dgBit = ((uint32_t)(ww >> 32) >> rel) & 1u;
-                        // the two rules the narrow rows rely on (see packTraceRowNarrow), checked on every step
-                        if (rel < relLeft || rel > relRight || (rel == relLeft && hpBit) ||
-                            (rel == relRight && ti > 0 && !hpBit && !dgBit))
-                            flags |= FLAG_TRACE_RULE;
+                        ww = wW[jq][tid];
                     }
+                    if (rel > 31u) { // outside the stored window: cannot happen inside the band (checked, not assumed)
+                        flags |= FLAG_CAPACITY;
+                        break;
+                    }
+                    const bool hpBit = ((uint32_t)ww >> rel) & 1u;
+                    const bool dgBit = ((uint32_t)(ww >> 32) >> rel) & 1u;
+                    // the two rules the narrow rows rely on (see packTraceRowNarrow), checked on every step
+                    if (rel < relLeft || rel > relRight || (rel == relLeft && hpBit) ||
+                        (rel == relRight && ti > 0 && !hpBit && !dgBit))
+                        flags |= FLAG_TRACE_RULE;
                     if (hpBit) { // gap in horizontal (:553)
                         --tj;
                     } else {
@@ -1329,6 +1398,8 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                         --ti;
                     }
                 }
+            }
+            if (have) {
                 const uint32_t ed = bitIdx < 21u ? (uint32_t)((edPack >> (3u * bitIdx)) & 7ull)
                                                  : (uint32_t)((edPackHi >> (3u * (bitIdx - 21u))) & 7ull);
                 rec = TextOccRec{rs, start + ti, start + ri, ed};
