@@ -110,6 +110,16 @@ extern "C" int cmb_debug_bfs_stats(unsigned long long* out, int reset) { // diag
     return 0;
 }
 #endif
+#ifdef CMB_STAGE_STATS
+extern "C" int cmb_debug_stage_stats(unsigned long long* out, int reset) { // diagnostic build only
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(cmb::g_stageStats), 24 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[24] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(cmb::g_stageStats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 extern "C" const char* cmb_last_error(void) { return g_err.c_str(); }
 extern "C" const char* cmb_version(void) { return "columba_amd 0.1 (gfx950)"; }
 

@@ -97,49 +97,61 @@ __device__ __forceinline__ void initMatrix(MatGeom& g, uint32_t xLen, uint32_t m
 
 // computeRow (bitparallelmatrix.h:352-415).  In/out: previous row state -> row i state.
 // Returns false if every cell of row i exceeds maxED.
-__device__ __forceinline__ bool computeRow(const MatGeom& g, uint32_t i, uint64_t M, uint64_t& HP, uint64_t& HN,
-                                           uint64_t& D0, uint64_t& RAC, uint32_t& score) {
-    const uint32_t l = i % MX_BLOCK;
+// The rightmost active column of the row just computed (bitparallelmatrix.h:400-412): called when D0 has no bit
+// at the RAC column.  Returns false if every cell of the row exceeds maxED.
+__device__ __forceinline__ bool racWalk(const MatGeom& g, uint32_t i, uint64_t HP, uint64_t HN, uint64_t& RAC) {
+    // The reference walks left from the RAC column, one column per iteration, until the running value
+    // (1, -1 per HP bit, +1 per HN bit) reaches zero, and gives up at column diagBit - Wv (:400-412).  The walk
+    // spans at most Wh + Wv <= 30 columns: it is done on 32-bit windows of HP / HN whose bit 31 is the RAC
+    // column.  Almost always the first HP bit ends it (no HN bit before it): that case needs no loop.
+    const uint32_t diagBit = i % MX_BLOCK + MX_DIAG;
+    const uint32_t q = (uint32_t)__ffsll((unsigned long long)RAC) - 1u;
+    const uint32_t maxSteps = q - (diagBit - g.Wv); // the walk fails if it is still running at this step
+    uint32_t hp = (uint32_t)((HP << (63u - q)) >> 32); // bit 31 <- bit q (no branch on q)
+    uint32_t hn = (uint32_t)((HN << (63u - q)) >> 32);
+    const uint32_t p1 = hp ? (uint32_t)__clz(hp) : 32u; // steps before the first HP bit
+    if (p1 >= maxSteps) return false;                    // (the value cannot reach zero before the stop column)
+    uint32_t k = p1;
+    if (p1 != 0u && (hn >> (32u - p1)) != 0u) { // HN bits before it: the general walk
+        uint32_t val = 1u;
+        k = 0;
+        for (;;) {
+            val += (hn >> 31) - (hp >> 31);
+            if (val == 0u) break;
+            if (k == maxSteps) return false;
+            hp <<= 1;
+            hn <<= 1;
+            k++;
+        }
+        if (k >= maxSteps) return false; // (zero reached AT the stop column still fails, :408)
+    }
+    RAC = 1ull << (q - k - 1u);
+    return true;
+}
+// the RAC column moves with the window: one to the left per row, back by a block when the words are realigned
+__device__ __forceinline__ void racAdvance(uint32_t i, uint64_t& RAC) {
     RAC <<= 1u;
-    if (l == 0) {
+    if (i % MX_BLOCK == 0) RAC >>= MX_BLOCK;
+}
+__device__ __forceinline__ bool racHit(uint64_t D0, uint64_t RAC) { return (D0 & RAC) != 0ull; }
+// the Hyyro recurrence of one row (bitparallelmatrix.h:352-398): no RAC, no score
+__device__ __forceinline__ void computeRowCore(uint32_t i, uint64_t M, uint64_t& HP, uint64_t& HN, uint64_t& D0) {
+    if (i % MX_BLOCK == 0) {
         HP >>= MX_BLOCK;
         HN >>= MX_BLOCK;
-        RAC >>= MX_BLOCK;
     }
     D0 = (((M & HP) + HP) ^ HP) | M | HN;
     const uint64_t VP = HN | ~(D0 | HP);
     const uint64_t VN = D0 & HP;
     HP = (VN << 1u) | ~(D0 | (VP << 1u));
     HN = (D0 & (VP << 1u));
-    const uint32_t diagBit = l + MX_DIAG;
-    score += (D0 & (1ull << diagBit)) ? 0u : 1u;
-    if (!(D0 & RAC)) {
-        // The reference walks left from the RAC column, one column per iteration, until the running value
-        // (1, -1 per HP bit, +1 per HN bit) reaches zero, and gives up at column diagBit - Wv (:400-412).  The walk
-        // spans at most Wh + Wv <= 30 columns: it is done on 32-bit windows of HP / HN whose bit 31 is the RAC
-        // column.  Almost always the first HP bit ends it (no HN bit before it): that case needs no loop.
-        const uint32_t q = (uint32_t)__ffsll((unsigned long long)RAC) - 1u;
-        const uint32_t maxSteps = q - (diagBit - g.Wv); // the walk fails if it is still running at this step
-        uint32_t hp = (uint32_t)((HP << (63u - q)) >> 32); // bit 31 <- bit q (no branch on q)
-        uint32_t hn = (uint32_t)((HN << (63u - q)) >> 32);
-        const uint32_t p1 = hp ? (uint32_t)__clz(hp) : 32u; // steps before the first HP bit
-        if (p1 >= maxSteps) return false;                    // (the value cannot reach zero before the stop column)
-        uint32_t k = p1;
-        if (p1 != 0u && (hn >> (32u - p1)) != 0u) { // HN bits before it: the general walk
-            uint32_t val = 1u;
-            k = 0;
-            for (;;) {
-                val += (hn >> 31) - (hp >> 31);
-                if (val == 0u) break;
-                if (k == maxSteps) return false;
-                hp <<= 1;
-                hn <<= 1;
-                k++;
-            }
-            if (k >= maxSteps) return false; // (zero reached AT the stop column still fails, :408)
-        }
-        RAC = 1ull << (q - k - 1u);
-    }
+}
+__device__ __forceinline__ bool computeRow(const MatGeom& g, uint32_t i, uint64_t M, uint64_t& HP, uint64_t& HN,
+                                           uint64_t& D0, uint64_t& RAC, uint32_t& score) {
+    racAdvance(i, RAC);
+    computeRowCore(i, M, HP, HN, D0);
+    score += (D0 & (1ull << (i % MX_BLOCK + MX_DIAG))) ? 0u : 1u;
+    if (!racHit(D0, RAC)) return racWalk(g, i, HP, HN, RAC);
     return true;
 }
 
@@ -174,60 +186,36 @@ __device__ __forceinline__ uint32_t matchWord32(uint64_t M64, uint32_t i) {
     return (uint32_t)(M64 >> (((i % MX_BLOCK) / MX32_BLOCK) * MX32_BLOCK + (MX_LEFT - MX32_LEFT)));
 }
 // (the rightmost active column is kept as a bit INDEX `rac` here, not as a one-bit mask: racInit / racIndex)
-__device__ __forceinline__ bool computeRow(const MatGeom& g, uint32_t i, uint32_t M, uint32_t& HP, uint32_t& HN,
-                                           uint32_t& D0, uint32_t& rac, uint32_t& score) {
-    const uint32_t l = i % MX32_BLOCK;
-    rac += 1u;
-    if (l == 0) {
-        HP >>= MX32_BLOCK;
-        HN >>= MX32_BLOCK;
-        rac -= MX32_BLOCK;
-    }
-    D0 = (((M & HP) + HP) ^ HP) | M | HN;
-    const uint32_t VP = HN | ~(D0 | HP);
-    const uint32_t VN = D0 & HP;
-    HP = (VN << 1u) | ~(D0 | (VP << 1u));
-    HN = (D0 & (VP << 1u));
-    const uint32_t diagBit = l + MX32_DIAG;
-    score += (D0 >> diagBit) & 1u ? 0u : 1u;
-    if (!((D0 >> rac) & 1u)) { // the RAC walk, as in the 64-bit version
-        const uint32_t q = rac;
-        const uint32_t maxSteps = q - (diagBit - g.Wv);
-        uint32_t hp = HP << (31u - q);
-        uint32_t hn = HN << (31u - q);
-        const uint32_t p1 = hp ? (uint32_t)__clz(hp) : 32u;
-        if (p1 >= maxSteps) return false;
-        uint32_t k = p1;
-        if (p1 != 0u && (hn >> (32u - p1)) != 0u) {
-            uint32_t val = 1u;
-            k = 0;
-            for (;;) {
-                val += (hn >> 31) - (hp >> 31);
-                if (val == 0u) break;
-                if (k == maxSteps) return false;
-                hp <<= 1;
-                hn <<= 1;
-                k++;
-            }
-            if (k >= maxSteps) return false;
+__device__ __forceinline__ bool racWalk(const MatGeom& g, uint32_t i, uint32_t HP, uint32_t HN, uint32_t& rac) {
+    const uint32_t diagBit = i % MX32_BLOCK + MX32_DIAG;
+    const uint32_t q = rac;
+    const uint32_t maxSteps = q - (diagBit - g.Wv);
+    uint32_t hp = HP << (31u - q);
+    uint32_t hn = HN << (31u - q);
+    const uint32_t p1 = hp ? (uint32_t)__clz(hp) : 32u;
+    if (p1 >= maxSteps) return false;
+    uint32_t k = p1;
+    if (p1 != 0u && (hn >> (32u - p1)) != 0u) {
+        uint32_t val = 1u;
+        k = 0;
+        for (;;) {
+            val += (hn >> 31) - (hp >> 31);
+            if (val == 0u) break;
+            if (k == maxSteps) return false;
+            hp <<= 1;
+            hn <<= 1;
+            k++;
         }
-        rac = q - k - 1u;
+        if (k >= maxSteps) return false;
     }
+    rac = q - k - 1u;
     return true;
 }
-// computeRow without the rightmost-active-column bookkeeping and the score (rows known to be valid: the traceback's
-// forward pass): the Hyyro recurrence only
-__device__ __forceinline__ void computeRowCore(uint32_t i, uint64_t M, uint64_t& HP, uint64_t& HN, uint64_t& D0) {
-    if (i % MX_BLOCK == 0) {
-        HP >>= MX_BLOCK;
-        HN >>= MX_BLOCK;
-    }
-    D0 = (((M & HP) + HP) ^ HP) | M | HN;
-    const uint64_t VP = HN | ~(D0 | HP);
-    const uint64_t VN = D0 & HP;
-    HP = (VN << 1u) | ~(D0 | (VP << 1u));
-    HN = (D0 & (VP << 1u));
+__device__ __forceinline__ void racAdvance(uint32_t i, uint32_t& rac) {
+    rac += 1u;
+    if (i % MX32_BLOCK == 0) rac -= MX32_BLOCK;
 }
+__device__ __forceinline__ bool racHit(uint32_t D0, uint32_t rac) { return ((D0 >> rac) & 1u) != 0u; }
 __device__ __forceinline__ void computeRowCore(uint32_t i, uint32_t M, uint32_t& HP, uint32_t& HN, uint32_t& D0) {
     if (i % MX32_BLOCK == 0) {
         HP >>= MX32_BLOCK;
@@ -238,6 +226,14 @@ __device__ __forceinline__ void computeRowCore(uint32_t i, uint32_t M, uint32_t&
     const uint32_t VN = D0 & HP;
     HP = (VN << 1u) | ~(D0 | (VP << 1u));
     HN = (D0 & (VP << 1u));
+}
+__device__ __forceinline__ bool computeRow(const MatGeom& g, uint32_t i, uint32_t M, uint32_t& HP, uint32_t& HN,
+                                           uint32_t& D0, uint32_t& rac, uint32_t& score) {
+    racAdvance(i, rac);
+    computeRowCore(i, M, HP, HN, D0);
+    score += (D0 >> (i % MX32_BLOCK + MX32_DIAG)) & 1u ? 0u : 1u;
+    if (!racHit(D0, rac)) return racWalk(g, i, HP, HN, rac);
+    return true;
 }
 // the RAC state of a matrix word type: one-bit mask (64-bit matrix) or bit index (32-bit matrix)
 __device__ __forceinline__ uint64_t racInit(uint64_t, uint32_t bit) { return 1ull << bit; }

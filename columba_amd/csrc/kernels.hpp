@@ -569,13 +569,18 @@ constexpr int VEMIT = 20; // max cluster centres of one candidate (size of the f
 // What the traceback reads of row i is bit (j - 32 b) + DIAG of HP and D0 with |i - j| inside the band, i.e.
 // at most 18 (= 3 k) bits below and 6 above the row's diagonal bit: both 32-bit windows starting 18 bits below
 // the diagonal are kept in ONE 64-bit word per row (low half HP, high half D0).
-// Layout: per lane (slot) `lines` 64-byte lines, line g = the packed rows 8 g + 1 .. 8 g + 8.  The forward pass
+// Layout: `lines` 64-byte lines per lane (slot), line-major (traceLine); line g = the packed rows 8 g + 1 .. 8 g + 8.  The forward pass
 // collects eight rows in registers and writes the line with four 16-byte stores; the traceback fetches a line
 // (and the eight text codes of its rows) whenever it crosses into the next group of eight rows.
 struct VPlanes {
     uint64_t* W;
     uint32_t nSlots, lines;
 };
+// line g of a lane's trace rows.  Line-major: the 64 lines a wavefront writes (or reads) for one group of rows are
+// 4 KB of consecutive memory instead of 64 lines `lines` x 64 bytes apart.
+__device__ __forceinline__ uint4* traceLine(const VPlanes& V, uint32_t slot, uint32_t line) {
+    return reinterpret_cast<uint4*>(V.W) + ((size_t)line * V.nSlots + slot) * 4;
+}
 constexpr uint32_t TB_BELOW = 18;
 // low half: HP; high half: M | ~D0 — "the diagonal step is allowed" (bitparallelmatrix.h:559-562), folded in by the
 // forward pass, which has the row's match word at hand: the trace then needs neither the text nor match words.
@@ -732,6 +737,7 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
         nxt = loadText16(tp + 16); // the text allocation is padded
     }
     uint32_t i = 0, dm = 0;
+    W dAcc = 0; // CHECK = false: diagonal matches so far (dm) and of the current block of rows (one bit each)
     bool alive = size > 0;
     uint64_t buf[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // STORE: the packed rows of the current group of eight
     uint32_t bufN[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // NARROW: of the current group of sixteen
@@ -762,7 +768,12 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
                     valid = computeRow(g, r, M, HP, HN, D0, RAC, score);
                 } else {
                     computeRowCore(r, M, HP, HN, D0);
-                    dm += (uint32_t)(D0 >> ((r % (NARROW ? MX32_BLOCK : MX_BLOCK)) + DIAG)) & 1u;
+                    constexpr uint32_t BLOCK = NARROW ? MX32_BLOCK : MX_BLOCK;
+                    dAcc |= D0 & ((W)1 << ((r % BLOCK) + DIAG)); // the diagonal cell matched (the bit moves with the row)
+                    if ((r % BLOCK) == BLOCK - 1u) {
+                        dm += NARROW ? (uint32_t)__popc((uint32_t)dAcc) : (uint32_t)__popcll((uint64_t)dAcc);
+                        dAcc = 0;
+                    }
                 }
                 if (STORE && !NARROW) buf[t & 7u] = packTraceRow(r, (uint64_t)HP, (uint64_t)(M | ~D0));
                 if (STORE && NARROW) bufN[t] = packTraceRowNarrow(r, (uint32_t)HP, (uint32_t)(M | ~D0));
@@ -770,7 +781,8 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
                     alive = false;
                 } else if (!CHECK) {
                     if (STORE && r > rowMin && r > firstRow) {
-                        const uint32_t ed = cellAt(r, col, HP, HN, r - dm);
+                        const uint32_t pend = NARROW ? (uint32_t)__popc((uint32_t)dAcc) : (uint32_t)__popcll((uint64_t)dAcc);
+                        const uint32_t ed = cellAt(r, col, HP, HN, r - dm - pend);
                         const uint32_t bidx = r - firstRow - 1u;
                         if (bidx < 21u) edPack |= (uint64_t)min(ed, 7u) << (3u * bidx);
                         else edPackHi |= (uint64_t)min(ed, 7u) << (3u * (bidx - 21u));
@@ -799,12 +811,12 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
                 }
             }
             if (STORE && NARROW && t == 15u && groupAlive) { // rows 16 c + 1 .. 16 c + 16 = line c
-                uint4* L = reinterpret_cast<uint4*>(V.W) + ((size_t)slot * V.lines + c) * 4;
+                uint4* L = traceLine(V, slot, c);
 #pragma unroll
                 for (int h = 0; h < 4; h++) L[h] = make_uint4(bufN[4 * h], bufN[4 * h + 1], bufN[4 * h + 2], bufN[4 * h + 3]);
             }
             if (STORE && !NARROW && (t & 7u) == 7u && groupAlive) { // rows 16 c + t - 6 .. 16 c + t + 1 = line 2 c + t / 8
-                uint4* L = reinterpret_cast<uint4*>(V.W) + ((size_t)slot * V.lines + (2 * c + (t >> 3))) * 4;
+                uint4* L = traceLine(V, slot, 2 * c + (t >> 3));
 #pragma unroll
                 for (int h = 0; h < 4; h++)
                     L[h] = make_uint4((uint32_t)buf[2 * h], (uint32_t)(buf[2 * h] >> 32), (uint32_t)buf[2 * h + 1],
@@ -1053,6 +1065,9 @@ struct VStageList { // survivors entering a stage
 };
 
 // W32: the matrix on 32-bit words / 8-row blocks (dev_matrix.hpp; k <= 4) — half the VALU work of a row.
+#ifdef CMB_STAGE_STATS
+__device__ unsigned long long g_stageStats[24];
+#endif
 // FINALCOL: rows of this stage may lie in the final-column range of some candidate (row >= len - maxED - 1); the
 // host clears it for the stages no read of the batch can reach that far in, and those instances carry no
 // final-column / cluster-centre code (a third fewer instructions per row).
@@ -1136,9 +1151,9 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
         }
         if (!FINALCOL && alive && rLast >= firstRow) flags |= FLAG_CAPACITY; // (host: stageNeedsFinalColumn)
         const bool alive0 = alive;
-        uint32_t iDead = max(size, rFirst); // rows done when the candidate ended: all `size` of them, or up to the invalid row
-        uint32_t inval = 0;    // ended by a row without a cell <= maxED (that row was computed: it counts)
+        uint32_t deadRow = 0;  // the row without a cell <= maxED that ended the candidate (it was computed: it counts)
         uint32_t dm = 0;       // rows of this stage whose diagonal cell matched (score = rows - dm)
+        W dAcc = 0;            // ... of the current block of rows, one bit each
         for (uint32_t h = 0; h < nb; h++) {
         if (__ballot(alive) == 0ull) break; // (wave-uniform)
         const uint32_t blk = nb * stage + h;
@@ -1170,32 +1185,54 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                 const uint64_t M64 = Ml[tc * 256 + tid];
                 const W M = W32 ? (W)matchWord32(M64, r) : (W)M64;
                 W D0;
-                uint32_t unusedScore = 0;
-                const bool valid = computeRow(g, r, M, HP, HN, D0, RAC, unusedScore);
-                dm += (uint32_t)(D0 >> ((r % BLOCK) + DIAG)) & 1u;
-                if (!valid) {
-                    alive = false;
-                    inval = 1;
-                    iDead = r - 1;
-                } else {
-                    if (FINALCOL && r >= firstRow) {
-                        const uint32_t score = score0 + (r - (rFirst - 1u)) - dm;
-                        const uint32_t ed = min(cellAt(r, col, HP, HN, score), 31u);
-                        if (r - 1 > firstRow) { // row r-1 can now be judged (its `below` neighbour is known)
-                            const uint32_t e1 = edPrev;
-                            if (e1 <= maxED && e1 >= minED && e1 <= edPrev2 && e1 <= ed) mask |= 1u << (r - 2 - firstRow);
-                        }
-                        edPrev2 = edPrev;
-                        edPrev = ed;
+                racAdvance(r, RAC);
+                computeRowCore(r, M, HP, HN, D0);
+                bool valid = true;
+#ifdef CMB_STAGE_STATS
+                if (W32) { // what do the rows of a stage do?  [stage-class][wave rows, lane rows, any miss, lane misses, any slow, lane slow]
+                    const bool miss = !racHit(D0, RAC), slow = miss && !(((uint32_t)HP >> (uint32_t)RAC) & 1u);
+                    const uint64_t am = __ballot(true), mm = __ballot(miss), sm = __ballot(slow);
+                    if ((tid & 63u) == (uint32_t)__ffsll((unsigned long long)am) - 1u) {
+                        unsigned long long* st = g_stageStats + 8 * (FIRST ? 0 : FINALCOL ? 2 : 1);
+                        atomicAdd(&st[0], 1ull);
+                        atomicAdd(&st[1], (unsigned long long)__popcll(am));
+                        atomicAdd(&st[2], mm ? 1ull : 0ull);
+                        atomicAdd(&st[3], (unsigned long long)__popcll(mm));
+                        atomicAdd(&st[4], sm ? 1ull : 0ull);
+                        atomicAdd(&st[5], (unsigned long long)__popcll(sm));
                     }
-                    alive = r < size; // (rows done = r)
                 }
+#endif
+                if (!racHit(D0, RAC)) { // (rare: what an end needs is recorded here, off the common path)
+                    valid = racWalk(g, r, HP, HN, RAC);
+                    if (!valid) deadRow = r;
+                }
+                dAcc |= D0 & ((W)1 << ((r % BLOCK) + DIAG)); // the diagonal cell matched (the bit moves with the row)
+                if ((r % BLOCK) == BLOCK - 1u) {
+                    dm += W32 ? (uint32_t)__popc((uint32_t)dAcc) : (uint32_t)__popcll((uint64_t)dAcc);
+                    dAcc = 0;
+                }
+                if (FINALCOL && valid && r >= firstRow) {
+                    const uint32_t pend = W32 ? (uint32_t)__popc((uint32_t)dAcc) : (uint32_t)__popcll((uint64_t)dAcc);
+                    const uint32_t score = score0 + (r - (rFirst - 1u)) - dm - pend;
+                    const uint32_t ed = min(cellAt(r, col, HP, HN, score), 31u);
+                    if (r - 1 > firstRow) { // row r-1 can now be judged (its `below` neighbour is known)
+                        const uint32_t e1 = edPrev;
+                        if (e1 <= maxED && e1 >= minED && e1 <= edPrev2 && e1 <= ed) mask |= 1u << (r - 2 - firstRow);
+                    }
+                    edPrev2 = edPrev;
+                    edPrev = ed;
+                }
+                // rows done = r; the window ends in the final-column range (size >= m - sfc > firstRow: inFinalColumn above)
+                alive = FINALCOL ? valid && r < size : valid;
             }
         }
         }
+        dm += W32 ? (uint32_t)__popc((uint32_t)dAcc) : (uint32_t)__popcll((uint64_t)dAcc);
         const bool ended = alive0 && !alive;
-        const uint32_t i = ended ? iDead : rLast; // rows done so far
-        const uint32_t rows = alive0 ? i - (rFirst - 1u) + inval : 0u;
+        // rows done so far: the stage's, all `size` of them, or those before the invalid row
+        const uint32_t i = !ended ? rLast : deadRow ? deadRow - 1u : max(size, rFirst);
+        const uint32_t rows = alive0 ? i - (rFirst - 1u) + (deadRow ? 1u : 0u) : 0u;
         const uint32_t score = score0 + rows - dm;
         cText += rows * mult;
         uint32_t nTb = 0;
@@ -1314,7 +1351,6 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                 uint32_t gTop = have ? (ti - 1u) >> 4 : 0u;
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) gTop = max(gTop, (uint32_t)__shfl_xor((int)gTop, d));
-                const uint4* Lb = reinterpret_cast<const uint4*>(V.W) + (size_t)slot * V.lines * 4;
                 for (int gq = (int)gTop; gq >= 0; gq--) { // (wave-uniform)
                     if (__ballot(!done) == 0ull) break;
                     uint32_t w[16];
@@ -1323,7 +1359,7 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                     if (!done && ((ti - 1u) >> 4) == (uint32_t)gq) { // (a trace that has reached row 0 loads nothing)
 #pragma unroll
                         for (int h = 0; h < 4; h++) {
-                            const uint4 v = Lb[(size_t)gq * 4 + h];
+                            const uint4 v = traceLine(V, slot, (uint32_t)gq)[h];
                             w[4 * h] = v.x;
                             w[4 * h + 1] = v.y;
                             w[4 * h + 2] = v.z;
@@ -1371,7 +1407,7 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                         const uint32_t gq = (ti - 1) >> 3, jq = (ti - 1) & 7u;
                         if (gq != curG) {
                             curG = gq;
-                            const uint4* L = reinterpret_cast<const uint4*>(V.W) + ((size_t)slot * V.lines + gq) * 4;
+                            const uint4* L = traceLine(V, slot, gq);
 #pragma unroll
                             for (int h = 0; h < 4; h++) {
                                 const uint4 v = L[h];
@@ -1766,7 +1802,7 @@ k_cigar(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf, const uint4* _
                         const uint32_t gq = (ti - 1) >> 4, jq = (ti - 1) & 15u;
                         if (gq != curG) {
                             curG = gq;
-                            const uint4* L = reinterpret_cast<const uint4*>(V.W) + ((size_t)slot * V.lines + gq) * 4;
+                            const uint4* L = traceLine(V, slot, gq);
 #pragma unroll
                             for (int h = 0; h < 4; h++) {
                                 const uint4 v = L[h];
@@ -1790,7 +1826,7 @@ k_cigar(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf, const uint4* _
                         const uint32_t gq = (ti - 1) >> 3, jq = (ti - 1) & 7u;
                         if (gq != curG) {
                             curG = gq;
-                            const uint4* L = reinterpret_cast<const uint4*>(V.W) + ((size_t)slot * V.lines + gq) * 4;
+                            const uint4* L = traceLine(V, slot, gq);
 #pragma unroll
                             for (int h = 0; h < 4; h++) {
                                 const uint4 v = L[h];
