@@ -1175,6 +1175,7 @@ static int batchRunOne(cmb_batch* b) {
                                    b->seq.p, mf, b->items.p, nItems, b->tbq.p, tbCap,
                                    dedup ? b->vkeysA.p : (unsigned long long*)nullptr, q);
                 if (dedup) {
+                    uint32_t nRuns = 0;
                     size_t tmpBytes = 0;
                     // sorted bits: low VK_LOW bits of the start, the bounds, read x strand (2 nReads < 2^rsBits, so
                     // that the all-ones key of the other items sorts behind every real key) — see packVerifyKey
@@ -1190,7 +1191,6 @@ static int batchRunOne(cmb_batch* b) {
                     if (b->scanTmp.n < rleBytes) b->scanTmp.alloc(rleBytes + 256);
                     HIPCHK(rocprim::run_length_encode(b->scanTmp.p, rleBytes, b->vkeysB.p, nItems, b->vkeysA.p,
                                                       b->vcounts.p, b->vruns.p, s));
-                    uint32_t nRuns = 0;
                     HIPCHK(hipMemcpyAsync(&nRuns, b->vruns.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                     HIPCHK(hipStreamSynchronize(s));
                     tm.end("k_verify"); // locate + key sort + run-length encode; the matrix stages are timed apart
@@ -1277,7 +1277,7 @@ static int batchRunOne(cmb_batch* b) {
                     auto kTrace = k_traceback<false, false>;
                     if (narrow) kTrace = ix->d.text2 ? k_traceback<true, true> : k_traceback<true, false>;
                     // no final-column row (> len - maxED - 1, maxED <= 7) at or before this row, for any read of the batch
-                    const uint32_t rowMin = (b->minLen > 8u ? b->minLen - 8u : 0u) | (getenv("CMB_DEBUG_NOWALK") ? 0x80000000u : 0u);
+                    const uint32_t rowMin = b->minLen > 8u ? b->minLen - 8u : 0u;
                     hipLaunchKernelGGL(kTrace, dim3(tSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, mf, b->tbq.p, nTb,
                                        vp, q, rowMin);
                     tm.end("k_traceback");

@@ -185,37 +185,45 @@ constexpr uint32_t MX32_BLOCK = 8, MX32_DIAG = 13, MX32_LEFT = 14, MX32_MAX_ED =
 __device__ __forceinline__ uint32_t matchWord32(uint64_t M64, uint32_t i) {
     return (uint32_t)(M64 >> (((i % MX_BLOCK) / MX32_BLOCK) * MX32_BLOCK + (MX_LEFT - MX32_LEFT)));
 }
-// (the rightmost active column is kept as a bit INDEX `rac` here, not as a one-bit mask: racInit / racIndex)
+// The rightmost active column of the 32-bit matrix: a one-bit mask, as in the 64-bit matrix.  The walk
+// (bitparallelmatrix.h:400-412) without its loop in all but rare cases: among the columns from the RAC column to the
+// left, x = the HP bits, y = the HN bits.  If no HN bit lies above the highest HP bit (y <= x; the two never share a
+// bit), the running value first reaches zero AT that HP bit: the new RAC column is the one left of it, and the walk
+// fails iff that bit is not above the stop column diagBit - Wv (this includes x = 0).  Otherwise the general walk.
 __device__ __forceinline__ bool racWalk(const MatGeom& g, uint32_t i, uint32_t HP, uint32_t HN, uint32_t& rac) {
-    const uint32_t diagBit = i % MX32_BLOCK + MX32_DIAG;
-    const uint32_t q = rac;
+    const uint32_t l = i % MX32_BLOCK;
+    const uint32_t below = (rac << 1u) - 1u; // the RAC column and everything left of it
+    const uint32_t x = HP & below, y = HN & below;
+    // the value cannot reach zero before the stop column unless an HP bit lies above it (this ends most candidates:
+    // decided here, without walking): highest bit of x above column l + MX32_DIAG - Wv  <=>  x >> (l + 1) >= 2^(MX32_DIAG - Wv)
+    if ((x >> (l + 1u)) < (1u << (MX32_DIAG - g.Wv))) return false;
+    if (y <= x) {
+        rac = 0x40000000u >> (uint32_t)__builtin_clz(x); // (x != 0 here)
+        return true;
+    }
+    const uint32_t diagBit = l + MX32_DIAG;
+    const uint32_t q = 31u - (uint32_t)__clz((int)rac);
     const uint32_t maxSteps = q - (diagBit - g.Wv);
     uint32_t hp = HP << (31u - q);
     uint32_t hn = HN << (31u - q);
-    const uint32_t p1 = hp ? (uint32_t)__clz(hp) : 32u;
-    if (p1 >= maxSteps) return false;
-    uint32_t k = p1;
-    if (p1 != 0u && (hn >> (32u - p1)) != 0u) {
-        uint32_t val = 1u;
-        k = 0;
-        for (;;) {
-            val += (hn >> 31) - (hp >> 31);
-            if (val == 0u) break;
-            if (k == maxSteps) return false;
-            hp <<= 1;
-            hn <<= 1;
-            k++;
-        }
-        if (k >= maxSteps) return false;
+    uint32_t val = 1u, k = 0;
+    for (;;) {
+        val += (hn >> 31) - (hp >> 31);
+        if (val == 0u) break;
+        if (k == maxSteps) return false;
+        hp <<= 1;
+        hn <<= 1;
+        k++;
     }
-    rac = q - k - 1u;
+    if (k >= maxSteps) return false;
+    rac = 1u << (q - k - 1u);
     return true;
 }
 __device__ __forceinline__ void racAdvance(uint32_t i, uint32_t& rac) {
-    rac += 1u;
-    if (i % MX32_BLOCK == 0) rac -= MX32_BLOCK;
+    rac <<= 1u;
+    if (i % MX32_BLOCK == 0) rac >>= MX32_BLOCK;
 }
-__device__ __forceinline__ bool racHit(uint32_t D0, uint32_t rac) { return ((D0 >> rac) & 1u) != 0u; }
+__device__ __forceinline__ bool racHit(uint32_t D0, uint32_t rac) { return (D0 & rac) != 0u; }
 __device__ __forceinline__ void computeRowCore(uint32_t i, uint32_t M, uint32_t& HP, uint32_t& HN, uint32_t& D0) {
     if (i % MX32_BLOCK == 0) {
         HP >>= MX32_BLOCK;
@@ -235,11 +243,11 @@ __device__ __forceinline__ bool computeRow(const MatGeom& g, uint32_t i, uint32_
     if (!racHit(D0, rac)) return racWalk(g, i, HP, HN, rac);
     return true;
 }
-// the RAC state of a matrix word type: one-bit mask (64-bit matrix) or bit index (32-bit matrix)
+// the RAC state of a matrix word type: a one-bit mask
 __device__ __forceinline__ uint64_t racInit(uint64_t, uint32_t bit) { return 1ull << bit; }
-__device__ __forceinline__ uint32_t racInit(uint32_t, uint32_t bit) { return bit; }
+__device__ __forceinline__ uint32_t racInit(uint32_t, uint32_t bit) { return 1u << bit; }
 __device__ __forceinline__ uint32_t racIndex(uint64_t rac) { return (uint32_t)__ffsll((unsigned long long)rac) - 1u; }
-__device__ __forceinline__ uint32_t racIndex(uint32_t rac) { return rac; }
+__device__ __forceinline__ uint32_t racIndex(uint32_t rac) { return 31u - (uint32_t)__clz((int)rac); }
 __device__ __forceinline__ uint32_t cellAt(uint32_t i, uint32_t j, uint32_t HP, uint32_t HN, uint32_t score) {
     const uint32_t bit = (i % MX32_BLOCK) + MX32_DIAG;
     const uint32_t b = (i > j) ? bit - (i - j) + 1 : bit + 1;

@@ -1157,17 +1157,31 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
         for (uint32_t h = 0; h < nb; h++) {
         if (__ballot(alive) == 0ull) break; // (wave-uniform)
         const uint32_t blk = nb * stage + h;
-        const bool head = FIRST && h == 0; // rows 1..31 of the matrix
-        const uint32_t r0 = head ? 1u : 32u * blk;
+        const bool head = FIRST && h == 0; // rows 1..31 of the matrix (there is no row 0 to compute)
+        // rows r0 .. r0 + 31: t is the row's position in its 32-row (and 8-row) block in every block, so the shifts
+        // of the block boundaries are compile-time decisions of the unrolled loop
+        const uint32_t r0 = 32u * blk;
         uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0;
         uint32_t pLo = 0, pHi = 0;
         if (alive) {
+            // the text character of row r is text[start + r - 1]; the head block loads from `start` and moves the
+            // characters up by one (position start - 1 need not exist)
             if (PACKED) {
-                loadText2x32(ix.text2, start + (r0 - 1), pLo, pHi);
+                loadText2x32(ix.text2, head ? start : start + (r0 - 1), pLo, pHi);
+                if (head) {
+                    pHi = (pHi << 2) | (pLo >> 30);
+                    pLo <<= 2;
+                }
             } else {
-                const uint8_t* tp = ix.text + start + (r0 - 1); // text character of row r is text[start + r - 1]
+                const uint8_t* tp = head ? ix.text + start : ix.text + start + (r0 - 1);
                 t0 = loadText16(tp);
                 t1 = loadText16(tp + 16); // the text allocation is padded
+                if (head) {
+                    t1 = make_uint4(__funnelshift_l(t0.w, t1.x, 8), __funnelshift_l(t1.x, t1.y, 8), __funnelshift_l(t1.y, t1.z, 8),
+                                    __funnelshift_l(t1.z, t1.w, 8));
+                    t0 = make_uint4(t0.x << 8, __funnelshift_l(t0.x, t0.y, 8), __funnelshift_l(t0.y, t0.z, 8),
+                                    __funnelshift_l(t0.z, t0.w, 8));
+                }
             }
             uint64_t mw[4];
             loadMatchWords(mf, rs, blk, mw);
@@ -1181,7 +1195,7 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             const uint4 tw = t < 16 ? t0 : t1;
             const uint32_t wv = wsel == 0 ? tw.x : wsel == 1 ? tw.y : wsel == 2 ? tw.z : tw.w;
             const uint32_t tc = PACKED ? ((t < 16 ? pLo : pHi) >> (2 * (t & 15u))) & 3u : (wv >> (8 * (t & 3u))) & 0xFFu;
-            if (alive && !(t == 31 && head)) { // (the head block has 31 rows)
+            if (alive && !(t == 0 && head)) { // (the head block has 31 rows)
                 const uint64_t M64 = Ml[tc * 256 + tid];
                 const W M = W32 ? (W)matchWord32(M64, r) : (W)M64;
                 W D0;
@@ -1191,7 +1205,10 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
 #ifdef CMB_STAGE_STATS
                 if (W32) { // what do the rows of a stage do?  [stage-class][wave rows, lane rows, any miss, lane misses, any slow, lane slow]
                     const bool miss = !racHit(D0, RAC), slow = miss && !(((uint32_t)HP >> (uint32_t)RAC) & 1u);
-                    const uint64_t am = __ballot(true), mm = __ballot(miss), sm = __ballot(slow);
+                    // rows whose diagonal cell exceeds maxED (only these need the RAC to know whether the row is valid)
+                    const uint32_t scoreNow = score0 + (r - (rFirst - 1u)) - dm - (uint32_t)__popc((uint32_t)dAcc) -
+                                              (uint32_t)(((uint32_t)D0 >> ((r % BLOCK) + DIAG)) & 1u);
+                    const uint64_t am = __ballot(true), mm = __ballot(miss), sm = __ballot(slow), bm = __ballot(scoreNow > maxED);
                     if ((tid & 63u) == (uint32_t)__ffsll((unsigned long long)am) - 1u) {
                         unsigned long long* st = g_stageStats + 8 * (FIRST ? 0 : FINALCOL ? 2 : 1);
                         atomicAdd(&st[0], 1ull);
@@ -1200,6 +1217,8 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                         atomicAdd(&st[3], (unsigned long long)__popcll(mm));
                         atomicAdd(&st[4], sm ? 1ull : 0ull);
                         atomicAdd(&st[5], (unsigned long long)__popcll(sm));
+                        atomicAdd(&st[6], (unsigned long long)__popcll(bm));
+                        atomicAdd(&st[7], bm ? 1ull : 0ull);
                     }
                 }
 #endif
@@ -1325,9 +1344,8 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             uint32_t dummyMask;
             // rows 1..topCentre (all valid: they were valid in pass 1)
             forwardPass<true, NARROW, PACKED, false>(ix, mf, rs, g, nZeros, start, topCentre, maxED, 0, dummyMask, edPack,
-                                                     edPackHi, V, slot, dummyRows, Ml, rowMin & 0x7FFFFFFFu);
+                                                     edPackHi, V, slot, dummyRows, Ml, rowMin);
         }
-        if (rowMin >> 31) m = 0; // DEBUG-SPLIT
         // one centre per lane and round; the wavefront appends its results with one atomic per round
         for (;;) {
             const bool have = m != 0;

@@ -27,9 +27,10 @@ ca.lib().cmb_debug_stage_stats(st, 1)
 b.run()
 ca.lib().cmb_debug_stage_stats(st, 1)
 for i, name in enumerate(("first stage", "middle stages", "final-column stages")):
-    w, l, am, lm, asl, ls = [st[8 * i + j] for j in range(6)]
+    w, l, am, lm, asl, ls, lb, ab = [st[8 * i + j] for j in range(8)]
     w = w or 1
     print(f"{name}: wave rows {w}, lanes/row {l / w:.1f}, rows with a RAC miss {am / w:.3f} ({lm / w:.1f} lanes), "
-          f"rows with a miss beyond the first HP bit {asl / w:.3f} ({ls / w:.2f} lanes)", flush=True)
+          f"rows with a miss beyond the first HP bit {asl / w:.3f} ({ls / w:.2f} lanes), "
+          f"rows with a diagonal cell > maxED {ab / w:.3f} ({lb / w:.2f} lanes)", flush=True)
 b.close()
 PY
