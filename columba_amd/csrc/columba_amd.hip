@@ -82,7 +82,7 @@ struct cmb_index {
     int device = 0;
     uint32_t saSparseness = 0;
     DevIndex d{};
-    DevBuf<uint4> blkF, blkR; // 128-byte rank blocks
+    DevBuf<uint4> blkF, blkR; // 32-byte rank blocks
     DevBuf<uint64_t> saBlk;
     DevBuf<uint32_t> saSamples;
     DevBuf<uint8_t> text;
@@ -148,7 +148,7 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
             bv.upload(dir ? desc->bv_rev : desc->bv_fwd, bvW);
             cnt.upload(dir ? desc->cnt_rev : desc->cnt_fwd, cW);
             DevBuf<uint4>& blk = dir ? ix->blkR : ix->blkF;
-            blk.alloc(nBlocks * 8);
+            blk.alloc(nBlocks * 2);
             hipLaunchKernelGGL(k_relayout, dim3((unsigned)((nBlocks + 255) / 256)), dim3(256), 0, 0, bv.p, cnt.p, N,
                                nBlocks, blk.p);
             HIPCHK(hipGetLastError());

@@ -153,7 +153,7 @@ __device__ __forceinline__ void blockAppend4(uint32_t* c0, uint32_t* c1, uint32_
 }
 
 // the two rank blocks an extension of `p` in `mode` needs: request (raw 16-byte chunks) and use
-__device__ __forceinline__ void issueRanks(const DevIndex& ix, int mode, const RangePair& p, uint4 v[8]) {
+__device__ __forceinline__ void issueRanks(const DevIndex& ix, int mode, const RangePair& p, uint4 v[4]) {
     DevBWT t = ix.fwd; // values, not references, are selected
     Range tr = p.sa;
     if (mode == 0) {
@@ -162,12 +162,12 @@ __device__ __forceinline__ void issueRanks(const DevIndex& ix, int mode, const R
     }
     loadRankPairRaw(t, tr.b, tr.e, v);
 }
-__device__ __forceinline__ void takeRanks(const DevIndex& ix, int mode, const RangePair& p, const uint4 v[8], uint32_t Rb[4],
+__device__ __forceinline__ void takeRanks(const DevIndex& ix, int mode, const RangePair& p, const uint4 v[4], uint32_t Rb[4],
                                           uint32_t Re[4], uint32_t& db, uint32_t& de) {
     const uint32_t dollar = mode == 0 ? ix.rev.dollarPos : ix.fwd.dollarPos;
     const uint32_t b = mode == 0 ? p.rev.b : p.sa.b, e = mode == 0 ? p.rev.e : p.sa.e;
     ranksFromRaw(v, b, Rb);
-    ranksFromRaw(v + 4, e, Re);
+    ranksFromRaw(v + 2, e, Re);
     db = b > dollar ? 1u : 0u;
     de = e > dollar ? 1u : 0u;
 }
@@ -278,7 +278,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
             // requested together with the context words (one round trip less than fetching the mode from the context)
             md = (int)((n1.w >> 8) & 3u);
             parent = RangePair{{n0.x, n0.y}, {n0.z, n0.w}};
-            uint4 rk[8];
+            uint4 rk[4];
             issueRanks(ix, md, parent, rk);
             const uint4* Cx = B.C + (size_t)ctx * CTX_U4;
             blk = (row + 1) / MX_BLOCK;
@@ -317,7 +317,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
         for (uint32_t step = 0; step < B.chain; step++) { // (wave-uniform exit below)
             if (walking) {
                 if (step) {
-                    uint4 rk[8];
+                    uint4 rk[4];
                     issueRanks(ix, md, parent, rk); // the memory step of an expansion: two rank blocks
                     uint32_t Rb[4], Re[4];
                     takeRanks(ix, md, parent, rk, Rb, Re, db, de);

@@ -10,14 +10,15 @@
 //
 // HBM layout: the reference's two arrays per BWT (interleaved bitvector words + interleaved L1/L2
 // counts, bitvec.h:209-232) are re-packed at index creation (k_relayout) into self-contained
-// 128-byte rank blocks, one per 192 positions, so that one rank4() touches exactly one 128-byte
-// line (the reference layout needs a 64-byte count line plus a 32-byte bit group in another line):
+// 32-byte rank blocks, one per 32 positions:
 //     chunk 0      u32 abs[4]    cumulative rank of bitvector c at the block start
-//     chunk 1+2s   u64 bits of bitvectors 0,1 for positions [64s, 64s+64) of the block (s = 0..2)
-//     chunk 2+2s   u64 bits of bitvectors 2,3
-//     chunk 7      u8 in1[4], u8 in2[4]: set bits in sub-word 0 / sub-words 0..1 (then 8 spare bytes)
-// rank = abs + in[s] + popcount(bits & lowmask): four loads (16+8+16+16 B) from one line.
-// The BWT symbol needed by LF is decoded from the same bit chunks (the bitvectors are cumulative:
+//     chunk 1      u32 bits[4]   the 32 bits of bitvectors 0..3 for the block's positions
+// rank = abs + popcount(bits & lowmask): TWO 16-byte loads from one 32-byte sector (the reference layout
+// needs a 64-byte count line plus a 32-byte bit group in another line).  One byte per position and
+// direction — 1.5 x the 128-byte blocks of 192 positions used before, which needed four loads per rank:
+// the extension kernels are bound by the NUMBER of scattered loads, and memory is not
+// what an MI355X lacks.
+// The BWT symbol needed by LF is decoded from the same bits (the bitvectors are cumulative:
 // bwtrepr.h:67-68), so the 3-bit EncodedText (.bwt) is not kept on the device at all.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -26,7 +27,7 @@
 namespace cmb {
 
 struct DevBWT {
-    const uint4* blk; // 8 x 16 B per 192 positions (see above)
+    const uint4* blk; // 2 x 16 B per 32 positions (see above)
     uint32_t dollarPos;
 };
 
@@ -54,85 +55,53 @@ struct RangePair {
     __host__ __device__ uint32_t width() const { return sa.width(); }
 };
 
-constexpr uint32_t RANK_BLOCK = 192; // positions per rank block
+constexpr uint32_t RANK_BLOCK = 32; // positions per rank block
 
 struct RankChunks { // what one position needs from its block
-    uint4 abs;
-    uint2 in;
-    ulonglong2 b0, b1;
-    uint32_t sub, bit;
+    uint4 abs, bits;
+    uint32_t bit;
 };
 __device__ __forceinline__ void loadRankChunks(const DevBWT& t, uint32_t p, RankChunks& k) {
-    const uint32_t w = p >> 6;
-    const uint32_t blk = __umulhi(w, 0xAAAAAAABu) >> 1; // w / 3
-    k.sub = w - 3u * blk;
-    k.bit = p & 63u;
-    const uint4* B = t.blk + (size_t)blk * 8;
+    const uint4* B = t.blk + (size_t)(p >> 5) * 2;
+    k.bit = p & 31u;
     k.abs = B[0];
-    k.in = *reinterpret_cast<const uint2*>(B + 7);
-    const ulonglong2* bl = reinterpret_cast<const ulonglong2*>(B) + 1 + 2 * k.sub;
-    k.b0 = bl[0];
-    k.b1 = bl[1];
+    k.bits = B[1];
 }
 __device__ __forceinline__ void ranksFromChunks(const RankChunks& k, uint32_t R[4]) {
-    const uint32_t in = k.sub == 0 ? 0u : (k.sub == 1 ? k.in.x : k.in.y);
-    // bitvec.h:371: bits below position `bit`
-    const uint64_t lowmask = (k.bit == 0) ? 0ull : (~0ull >> (64u - k.bit));
-    R[0] = k.abs.x + (in & 0xFFu) + (uint32_t)__popcll(k.b0.x & lowmask);
-    R[1] = k.abs.y + ((in >> 8) & 0xFFu) + (uint32_t)__popcll(k.b0.y & lowmask);
-    R[2] = k.abs.z + ((in >> 16) & 0xFFu) + (uint32_t)__popcll(k.b1.x & lowmask);
-    R[3] = k.abs.w + (in >> 24) + (uint32_t)__popcll(k.b1.y & lowmask);
+    const uint32_t lowmask = (1u << k.bit) - 1u; // bitvec.h:371: bits below position `bit`
+    R[0] = k.abs.x + (uint32_t)__popc(k.bits.x & lowmask);
+    R[1] = k.abs.y + (uint32_t)__popc(k.bits.y & lowmask);
+    R[2] = k.abs.z + (uint32_t)__popc(k.bits.z & lowmask);
+    R[3] = k.abs.w + (uint32_t)__popc(k.bits.w & lowmask);
 }
 
-// the same as four raw 16-byte chunks {abs, in(+spare), bits01, bits23} (callers that share the
-// reply registers with other kinds of loads)
-__device__ __forceinline__ void loadRankChunksRaw(const DevBWT& t, uint32_t p, uint4 v[4]) {
-    const uint32_t w = p >> 6;
-    const uint32_t blk = __umulhi(w, 0xAAAAAAABu) >> 1;
-    const uint32_t sub = w - 3u * blk;
-    const uint4* B = t.blk + (size_t)blk * 8;
+// the same as two raw 16-byte chunks {abs, bits} (callers that share the reply registers with other kinds of loads)
+__device__ __forceinline__ void loadRankChunksRaw(const DevBWT& t, uint32_t p, uint4 v[2]) {
+    const uint4* B = t.blk + (size_t)(p >> 5) * 2;
     v[0] = B[0];
-    v[1] = B[7];
-    v[2] = B[1 + 2 * sub];
-    v[3] = B[2 + 2 * sub];
+    v[1] = B[1];
 }
-// both ends of a range: a narrow range usually has both ends in ONE rank block (192 positions), often in one
-// 64-bit word of it — what the begin already fetched is not requested again (the request rate of scattered
-// 16-byte loads, not the bytes, is what bounds the extension kernels)
-__device__ __forceinline__ void loadRankPairRaw(const DevBWT& t, uint32_t pb, uint32_t pe, uint4 v[8]) {
-    const uint32_t wb = pb >> 6, we = pe >> 6;
-    const uint32_t blkB = __umulhi(wb, 0xAAAAAAABu) >> 1, blkE = __umulhi(we, 0xAAAAAAABu) >> 1;
-    const uint32_t subB = wb - 3u * blkB, subE = we - 3u * blkE;
-    const uint4* B = t.blk + (size_t)blkB * 8;
-    const uint4* E = t.blk + (size_t)blkE * 8;
+// both ends of a range: a narrow range often has both ends in ONE rank block — what the begin already fetched is
+// not requested again (the request rate of scattered 16-byte loads, not the bytes, bounds the extension kernels)
+__device__ __forceinline__ void loadRankPairRaw(const DevBWT& t, uint32_t pb, uint32_t pe, uint4 v[4]) {
+    const uint32_t blkB = pb >> 5, blkE = pe >> 5;
+    const uint4* B = t.blk + (size_t)blkB * 2;
+    const uint4* E = t.blk + (size_t)blkE * 2;
     v[0] = B[0];
-    v[1] = B[7];
-    v[2] = B[1 + 2 * subB];
-    v[3] = B[2 + 2 * subB];
-    v[4] = v[0];
-    v[5] = v[1];
-    v[6] = v[2];
-    v[7] = v[3];
+    v[1] = B[1];
+    v[2] = v[0];
+    v[3] = v[1];
     if (blkE != blkB) {
-        v[4] = E[0];
-        v[5] = E[7];
-    }
-    if (we != wb) {
-        v[6] = E[1 + 2 * subE];
-        v[7] = E[2 + 2 * subE];
+        v[2] = E[0];
+        v[3] = E[1];
     }
 }
-__device__ __forceinline__ void ranksFromRaw(const uint4 v[4], uint32_t p, uint32_t R[4]) {
-    const uint32_t w = p >> 6;
-    const uint32_t sub = w - 3u * (__umulhi(w, 0xAAAAAAABu) >> 1);
-    const uint32_t bit = p & 63u;
-    const uint32_t in = sub == 0 ? 0u : (sub == 1 ? v[1].x : v[1].y);
-    const uint64_t lowmask = (bit == 0) ? 0ull : (~0ull >> (64u - bit));
-    const uint32_t mlo = (uint32_t)lowmask, mhi = (uint32_t)(lowmask >> 32);
-    R[0] = v[0].x + (in & 0xFFu) + (uint32_t)__popc(v[2].x & mlo) + (uint32_t)__popc(v[2].y & mhi);
-    R[1] = v[0].y + ((in >> 8) & 0xFFu) + (uint32_t)__popc(v[2].z & mlo) + (uint32_t)__popc(v[2].w & mhi);
-    R[2] = v[0].z + ((in >> 16) & 0xFFu) + (uint32_t)__popc(v[3].x & mlo) + (uint32_t)__popc(v[3].y & mhi);
-    R[3] = v[0].w + (in >> 24) + (uint32_t)__popc(v[3].z & mlo) + (uint32_t)__popc(v[3].w & mhi);
+__device__ __forceinline__ void ranksFromRaw(const uint4 v[2], uint32_t p, uint32_t R[4]) {
+    const uint32_t lowmask = (1u << (p & 31u)) - 1u;
+    R[0] = v[0].x + (uint32_t)__popc(v[1].x & lowmask);
+    R[1] = v[0].y + (uint32_t)__popc(v[1].y & lowmask);
+    R[2] = v[0].z + (uint32_t)__popc(v[1].z & lowmask);
+    R[3] = v[0].w + (uint32_t)__popc(v[1].w & lowmask);
 }
 
 // ranks of the four cumulative bitvectors at position p: R[i] = #{j < p : 1 <= BWT[j] <= i+1}
@@ -222,10 +191,10 @@ __device__ __forceinline__ void loadExtendRanks(const DevIndex& ix, int mode, co
         t = ix.rev;
         tr = p.rev;
     }
-    uint4 v[8];
+    uint4 v[4];
     loadRankPairRaw(t, tr.b, tr.e, v);
     ranksFromRaw(v, tr.b, Rb);
-    ranksFromRaw(v + 4, tr.e, Re);
+    ranksFromRaw(v + 2, tr.e, Re);
     db = tr.b > t.dollarPos ? 1u : 0u;
     de = tr.e > t.dollarPos ? 1u : 0u;
 }
@@ -281,7 +250,7 @@ __device__ __forceinline__ uint32_t findLF(const DevIndex& ix, uint32_t k) {
     ranksFromChunks(ch, R);
     const uint32_t bit = ch.bit;
     // smallest c with bit (c-1) set
-    const uint32_t c = ((ch.b0.x >> bit) & 1ull) ? 1u : ((ch.b0.y >> bit) & 1ull) ? 2u : ((ch.b1.x >> bit) & 1ull) ? 3u : 4u;
+    const uint32_t c = ((ch.bits.x >> bit) & 1u) ? 1u : ((ch.bits.y >> bit) & 1u) ? 2u : ((ch.bits.z >> bit) & 1u) ? 3u : 4u;
     return ix.counts[c] + occFromR(R, c);
 }
 

@@ -27,39 +27,23 @@ __global__ void k_rank(DevIndex ix, int rev, const uint32_t* __restrict__ c, con
     out[i] = rank1(rev ? ix.rev : ix.fwd, c[i], p[i]);
 }
 
-// Re-pack one BWT's reference arrays into 128-byte rank blocks (dev_index.hpp); one thread per block.
+// Re-pack one BWT's reference arrays into 32-byte rank blocks (dev_index.hpp); one thread per block.
 __global__ void k_relayout(const uint64_t* __restrict__ bv, const uint64_t* __restrict__ cnt, uint64_t N,
                            uint64_t nBlocks, uint4* __restrict__ out) {
     const uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (blk >= nBlocks) return;
     const uint64_t nWords = (N + 63) / 64;
-    uint64_t bits[3][4];
-    for (uint32_t s = 0; s < 3; s++)
-        for (uint32_t c = 0; c < 4; c++) {
-            const uint64_t w = blk * 3 + s;
-            bits[s][c] = w < nWords ? bv[w * 4 + c] : 0ull;
-        }
+    const uint64_t w = blk >> 1;
+    const uint32_t sh = (uint32_t)(blk & 1u) * 32u;
+    uint32_t bits[4];
+    for (uint32_t c = 0; c < 4; c++) bits[c] = w < nWords ? (uint32_t)(bv[w * 4 + c] >> sh) : 0u;
     uint4 abs;
     abs.x = rankRefLayout(bv, cnt, 0, blk * RANK_BLOCK, N);
     abs.y = rankRefLayout(bv, cnt, 1, blk * RANK_BLOCK, N);
     abs.z = rankRefLayout(bv, cnt, 2, blk * RANK_BLOCK, N);
     abs.w = rankRefLayout(bv, cnt, 3, blk * RANK_BLOCK, N);
-    uint32_t in1 = 0, in2 = 0;
-    for (uint32_t c = 0; c < 4; c++) {
-        const uint32_t p0 = (uint32_t)__popcll(bits[0][c]);
-        const uint32_t p1 = p0 + (uint32_t)__popcll(bits[1][c]);
-        in1 |= p0 << (8 * c);
-        in2 |= p1 << (8 * c);
-    }
-    uint4* B = out + blk * 8;
-    B[0] = abs;
-    for (uint32_t s = 0; s < 3; s++) {
-        B[1 + 2 * s] = make_uint4((uint32_t)bits[s][0], (uint32_t)(bits[s][0] >> 32), (uint32_t)bits[s][1],
-                                  (uint32_t)(bits[s][1] >> 32));
-        B[2 + 2 * s] = make_uint4((uint32_t)bits[s][2], (uint32_t)(bits[s][2] >> 32), (uint32_t)bits[s][3],
-                                  (uint32_t)(bits[s][3] >> 32));
-    }
-    B[7] = make_uint4(in1, in2, 0u, 0u);
+    out[blk * 2] = abs;
+    out[blk * 2 + 1] = make_uint4(bits[0], bits[1], bits[2], bits[3]);
 }
 
 // all four children of each parent; one thread per parent.
@@ -305,7 +289,7 @@ namespace cmb {
 
 // ------------------------------------------------------------------ prologue: the rank/extend kernels
 // extension of `parent` by `code` from the raw chunks of its two rank blocks (loaded in the memory step)
-__device__ __forceinline__ void issueExtend(const DevIndex& ix, int mode, const RangePair& parent, uint4 v[8]) {
+__device__ __forceinline__ void issueExtend(const DevIndex& ix, int mode, const RangePair& parent, uint4 v[4]) {
     DevBWT t = ix.fwd;
     Range tr = parent.sa;
     if (mode == 0) {
@@ -315,7 +299,7 @@ __device__ __forceinline__ void issueExtend(const DevIndex& ix, int mode, const 
     loadRankPairRaw(t, tr.b, tr.e, v);
 }
 __device__ __forceinline__ bool takeExtend(const DevIndex& ix, int mode, const RangePair& parent, uint32_t code,
-                                           const uint4 v[8], RangePair& child) {
+                                           const uint4 v[4], RangePair& child) {
     DevBWT t = ix.fwd;
     Range tr = parent.sa;
     if (mode == 0) {
@@ -324,7 +308,7 @@ __device__ __forceinline__ bool takeExtend(const DevIndex& ix, int mode, const R
     }
     uint32_t Rb[4], Re[4];
     ranksFromRaw(v, tr.b, Rb);
-    ranksFromRaw(v + 4, tr.e, Re);
+    ranksFromRaw(v + 2, tr.e, Re);
     return childFromRanks(ix, mode, parent, code, Rb, Re, tr.b > t.dollarPos ? 1u : 0u, tr.e > t.dollarPos ? 1u : 0u,
                           child);
 }
@@ -379,7 +363,7 @@ k_parts(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
             if (m.req == RQ_NONE) m.advance(); // bookkeeping up to the next extension (or the end)
             if (__ballot(m.req == RQ_RANK) == 0ull) break;
             if (m.req == RQ_RANK) {
-                uint4 rk[8]; // (its own array: the read-record path reinterprets v[] and would pin it in scratch)
+                uint4 rk[4]; // (its own array: the read-record path reinterprets v[] and would pin it in scratch)
                 issueExtend(ix, m.reqMode, m.reqParent, rk);
                 RangePair child;
                 const bool ok = takeExtend(ix, m.reqMode, m.reqParent, m.reqCode, rk, child);
