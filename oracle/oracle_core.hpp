@@ -517,17 +517,24 @@ inline SparseSAFiles buildSparseSA(const std::vector<len_t>& sa, len_t factor) {
 }
 
 // ----------------------------------------------------------------------------
-// BitParallelED<uint64_t> (bitparallelmatrix.h:300-750, .cpp:34-123)
+// BitParallelED<WordType> (bitparallelmatrix.h:300-750, .cpp:34-123): uint64_t (BitParallelED64) and, for the in-text
+// verification beyond 64 bits (fmindex.h:240-246), a 128-bit word (BitParallelED128; the reference's UInt128,
+// largeinteger.h, here the compiler's unsigned __int128)
 // ----------------------------------------------------------------------------
-struct BitVectors {
-    uint64_t HP, HN, D0, RAC, score;
+template <typename W>
+struct BitVectorsT {
+    W HP, HN, D0, RAC;
+    uint64_t score;
 };
-class BitParallelED64 {
+typedef BitVectorsT<uint64_t> BitVectors;
+template <typename W>
+class BitParallelEDT {
   public:
-    static const uint32_t WORD_SIZE = 64, BLOCK_SIZE = 32;
-    static const uint32_t MATRIX_MAX_ED = (WORD_SIZE - BLOCK_SIZE - 2) / 3; // 10
-    static const uint32_t LEFT = 2 * MATRIX_MAX_ED + 1;                    // 21
-    static const uint32_t DIAG_R0 = 2 * MATRIX_MAX_ED;                     // 20
+    static const uint32_t WORD_SIZE = sizeof(W) * 8, BLOCK_SIZE = WORD_SIZE / 2;
+    static int popcountW(W x) { return __builtin_popcountll((uint64_t)x) + (sizeof(W) > 8 ? __builtin_popcountll((uint64_t)(x >> (WORD_SIZE / 2))) : 0); }
+    static const uint32_t MATRIX_MAX_ED = (WORD_SIZE - BLOCK_SIZE - 2) / 3; // 10 (20)
+    static const uint32_t LEFT = 2 * MATRIX_MAX_ED + 1;                    // 21 (41)
+    static const uint32_t DIAG_R0 = 2 * MATRIX_MAX_ED;                     // 20 (40)
 
     static int char2idx(char c) { // bitparallelmatrix.h:85-93
         switch (c) {
@@ -543,10 +550,10 @@ class BitParallelED64 {
     void setSequence(const Substring& X) {
         n = X.size() + 1;
         m = 2 * MATRIX_MAX_ED + n;
-        mv.assign((m + BLOCK_SIZE - 1) / BLOCK_SIZE, std::array<uint64_t, 5>());
-        const uint64_t init = (1ull << LEFT) - 1ull;
+        mv.assign((m + BLOCK_SIZE - 1) / BLOCK_SIZE, std::array<W, 5>());
+        const W init = ((W)1 << LEFT) - (W)1;
         mv[0].fill(init);
-        uint64_t bitmask = 1ull << LEFT;
+        W bitmask = (W)1 << LEFT;
         size_t je = std::min<size_t>(X.size(), WORD_SIZE - LEFT);
         for (size_t j = 0; j < je; j++) {
             mv[0][char2idx(X[(len_t)j])] |= bitmask;
@@ -554,7 +561,7 @@ class BitParallelED64 {
         }
         for (size_t b = 1; b < mv.size(); b++) {
             for (size_t i = 0; i < 5; i++) mv[b][i] = mv[b - 1][i] >> BLOCK_SIZE;
-            bitmask = 1ull << (WORD_SIZE - BLOCK_SIZE);
+            bitmask = (W)1 << (WORD_SIZE - BLOCK_SIZE);
             size_t jb_b = WORD_SIZE - LEFT + (b - 1) * BLOCK_SIZE;
             size_t je_b = std::min<size_t>(X.size(), jb_b + BLOCK_SIZE);
             for (size_t j = jb_b; j < je_b; j++) {
@@ -575,28 +582,28 @@ class BitParallelED64 {
             m = Wv + Wh + 1;
             bv.resize(m);
         }
-        bv[0].HP = (~0ull) << LEFT;
+        bv[0].HP = (~(W)0) << LEFT;
         bv[0].HN = ~bv[0].HP;
         const size_t nn = std::min<size_t>(initED.size(), LEFT + 1);
         for (uint32_t i = 1; i < nn; ++i) {
             if (initED[i] < initED[i - 1]) {
-                bv[0].HP ^= 1ull << (LEFT - i);
-                bv[0].HN ^= 1ull << (LEFT - i);
+                bv[0].HP ^= (W)1 << (LEFT - i);
+                bv[0].HN ^= (W)1 << (LEFT - i);
             } else if (initED[i] == initED[i - 1]) {
-                bv[0].HN ^= 1ull << (LEFT - i);
+                bv[0].HN ^= (W)1 << (LEFT - i);
             }
         }
-        bv[0].RAC = 1ull << (DIAG_R0 + Wh);
+        bv[0].RAC = (W)1 << (DIAG_R0 + Wh);
     }
     // bitparallelmatrix.h:352-415
     bool computeRow(uint32_t i, char Y) {
         const uint32_t b = i / BLOCK_SIZE;
         const uint32_t l = i % BLOCK_SIZE;
-        uint64_t& HP = bv[i].HP;
-        uint64_t& HN = bv[i].HN;
-        uint64_t& D0 = bv[i].D0;
-        uint64_t& RAC = bv[i].RAC;
-        const uint64_t M = mv[b][char2idx(Y)];
+        W& HP = bv[i].HP;
+        W& HN = bv[i].HN;
+        W& D0 = bv[i].D0;
+        W& RAC = bv[i].RAC;
+        const W M = mv[b][char2idx(Y)];
         HP = bv[i - 1].HP;
         HN = bv[i - 1].HN;
         RAC = bv[i - 1].RAC << 1u;
@@ -606,18 +613,18 @@ class BitParallelED64 {
             RAC >>= BLOCK_SIZE;
         }
         D0 = (((M & HP) + HP) ^ HP) | M | HN;
-        uint64_t VP = HN | ~(D0 | HP);
-        uint64_t VN = D0 & HP;
+        W VP = HN | ~(D0 | HP);
+        W VN = D0 & HP;
         HP = (VN << 1u) | ~(D0 | (VP << 1u));
         HN = (D0 & (VP << 1u));
         const uint32_t diagBit = l + DIAG_R0;
-        bv[i].score = bv[i - 1].score + ((D0 & (1ull << diagBit)) ? 0 : 1);
+        bv[i].score = bv[i - 1].score + ((D0 & ((W)1 << diagBit)) ? 0 : 1);
         if (!(D0 & RAC)) {
             size_t val = 1u;
             while (val > 0) {
                 if (HP & RAC) val--;
                 if (HN & RAC) val++;
-                if (RAC == (1ull << (diagBit - Wv))) return false;
+                if (RAC == ((W)1 << (diagBit - Wv))) return false;
                 RAC >>= 1u;
             }
         }
@@ -629,9 +636,9 @@ class BitParallelED64 {
         const uint32_t bit = (i % BLOCK_SIZE) + DIAG_R0;
         uint32_t b = (i > j) ? bit - (i - j) + 1 : bit + 1;
         uint32_t e = (i > j) ? bit + 1 : bit + (j - i) + 1;
-        uint64_t mask = ((1ull << (e - b)) - 1ull) << b;
-        int negatives = __builtin_popcountll(bv[i].HN & mask);
-        int positives = __builtin_popcountll(bv[i].HP & mask);
+        W mask = (((W)1 << (e - b)) - (W)1) << b;
+        int negatives = popcountW(bv[i].HN & mask);
+        int positives = popcountW(bv[i].HP & mask);
         uint32_t score = (uint32_t)bv[i].score;
         score += (i > j) ? (negatives - positives) : (positives - negatives);
         return score;
@@ -644,8 +651,9 @@ class BitParallelED64 {
         uint32_t bb = DIAG_R0 - Wv + r + 1;
         uint32_t be = DIAG_R0 + n - b * BLOCK_SIZE;
         // `be` may exceed 64 (44 < n - 32 b < 53): the reference shifts by a negative count; on
-        // x86-64 (all Columba builds) that is "count mod 64" — made explicit here.
-        return (((~bv[i].HN >> bb) << bb) << ((WORD_SIZE - be) & 63u)) == 0ull;
+        // x86-64 (all Columba builds) that is "count mod 64" — made explicit here.  (Only the 64-bit matrix is ever
+        // asked: the matrices of the in-index search are 64-bit up to maxED = 10, indexinterface.cpp:391-398.)
+        return (((~bv[i].HN >> bb) << bb) << ((WORD_SIZE - be) & (WORD_SIZE - 1u))) == (W)0;
     }
     uint32_t getFirstColumn(uint32_t i) const { return (i <= Wv) ? 0u : i - Wv; } // :670
     uint32_t getNumberOfCols() const { return n; }
@@ -677,7 +685,7 @@ class BitParallelED64 {
         char state = 0;
         while (j > 0) {
             const uint32_t b = i / BLOCK_SIZE;
-            const uint64_t bit = 1ull << ((j - b * BLOCK_SIZE) + DIAG_R0);
+            const W bit = (W)1 << ((j - b * BLOCK_SIZE) + DIAG_R0);
             char op;
             if (bv[i].HP & bit) {
                 --j;
@@ -710,7 +718,7 @@ class BitParallelED64 {
         char state = 0;
         while (j > 0 || i > 0) {
             const uint32_t b = i / BLOCK_SIZE;
-            const uint64_t bit = 1ull << ((j - b * BLOCK_SIZE) + DIAG_R0);
+            const W bit = (W)1 << ((j - b * BLOCK_SIZE) + DIAG_R0);
             char op;
             if ((j > 0) && (bv[i].HP & bit)) {
                 --j;
@@ -731,16 +739,18 @@ class BitParallelED64 {
         }
         cigar.assign(v.rbegin(), v.rend());
     }
-    const BitVectors& row(uint32_t i) const { return bv[i]; }
+    const BitVectorsT<W>& row(uint32_t i) const { return bv[i]; }
     uint32_t getWv() const { return Wv; }
     uint32_t getWh() const { return Wh; }
-    const std::vector<std::array<uint64_t, 5>>& matchVectors() const { return mv; }
+    const std::vector<std::array<W, 5>>& matchVectors() const { return mv; }
 
   private:
     uint32_t maxED = 0, m = 0, n = 0, Wv = 0, Wh = 0;
-    std::vector<BitVectors> bv;
-    std::vector<std::array<uint64_t, 5>> mv;
+    std::vector<BitVectorsT<W>> bv;
+    std::vector<std::array<W, 5>> mv;
 };
+typedef BitParallelEDT<uint64_t> BitParallelED64;
+typedef BitParallelEDT<unsigned __int128> BitParallelED128;
 
 // ----------------------------------------------------------------------------
 // Search / SearchScheme (search.h:55-495, :509-757)

@@ -122,6 +122,46 @@ int main() {
                 M.traceBack(ref, e, b, ed, &cig);
                 os << ' ' << e << ' ' << b << ' ' << ed << ' ' << cigarStr(cig);
             }
+        } else if (cmd == "traceback128") {
+            string X, Y;
+            uint32_t maxED, minED, nZeros;
+            in >> X >> Y >> maxED >> minED >> nZeros;
+            BitParallelED128 M;
+            Substring sx(X.data(), (len_t)X.size(), 0, (len_t)X.size(), FORWARD);
+            M.setSequence(sx);
+            M.initializeMatrix(maxED, vector<uint32_t>(nZeros, 0));
+            Substring ref(Y.data(), (len_t)Y.size(), 0, (len_t)Y.size(), FORWARD);
+            uint32_t i = 0;
+            for (; i < Y.size() && i + 1 < M.getNumberOfRows(); i++)
+                if (!M.computeRow(i + 1, Y[i])) break;
+            vector<len_t> ends;
+            if (M.inFinalColumn(i)) M.findClusterCenters(i, ends, maxED, minED);
+            os << i << ' ' << ends.size();
+            for (auto e : ends) {
+                len_t b, ed;
+                vector<pair<char, uint32_t>> cig;
+                M.traceBack(ref, e, b, ed, &cig);
+                os << ' ' << e << ' ' << b << ' ' << ed << ' ' << cigarStr(cig);
+            }
+        } else if (cmd == "matrix128") {
+            string X, Y;
+            uint32_t maxED, nZeros;
+            in >> X >> Y >> maxED >> nZeros;
+            BitParallelED128 M;
+            Substring sx(X.data(), (len_t)X.size(), 0, (len_t)X.size(), FORWARD);
+            M.setSequence(sx);
+            M.initializeMatrix(maxED, vector<uint32_t>(nZeros, 0));
+            os << M.getNumberOfRows() << ' ' << M.getNumberOfCols() << ' ' << M.getSizeOfFinalColumn();
+            for (uint32_t i = 0; i < Y.size() && i + 1 < M.getNumberOfRows(); i++) {
+                bool v = M.computeRow(i + 1, Y[i]);
+                uint32_t r = i + 1;
+                os << ' ' << v << ' ' << M.getFirstColumn(r) << ' ' << M.inFinalColumn(r);
+                uint32_t fc = M.getFirstColumn(r);
+                uint32_t lc = std::min(M.getNumberOfCols() - 1, r + maxED);
+                os << ' ' << (lc - fc + 1);
+                for (uint32_t j = fc; j <= lc; j++) os << ' ' << M.at(r, j);
+                if (!v) break;
+            }
         } else if (cmd == "search") {
             uint32_t n;
             in >> n;

@@ -306,6 +306,8 @@ class Matcher {
         Occurrences occ;
         fullReadMatrices[0].reset();
         fullReadMatrices[1].reset();
+        fullReadMatrices128[0].reset();
+        fullReadMatrices128[1].reset();
         strand = FORWARD_STRAND;
         matchWithSearches(read, maxED, occ);
         strand = REVERSE_C_STRAND;
@@ -525,6 +527,8 @@ class Matcher {
                                               uint32_t& best, uint32_t& nHits, bool& found) {
         fullReadMatrices[0].reset();
         fullReadMatrices[1].reset();
+        fullReadMatrices128[0].reset();
+        fullReadMatrices128[1].reset();
         noCIGAR = false;
         const std::string revC = revCompl(read);
         const len_t cutOff = std::min<len_t>(std::min<len_t>(13, maxSupported), ((len_t)read.size() * (100 - minIdentity)) / 100);
@@ -631,6 +635,7 @@ class Matcher {
     std::vector<std::vector<FMPosExt>> stacks;
     std::vector<BitParallelED64> matrices;
     BitParallelED64 fullReadMatrices[2];
+    BitParallelED128 fullReadMatrices128[2]; // in-text verification beyond the 64-bit matrix (fmindex.h:240-246)
 
     void setDirection(Direction d, bool uni) { // indexinterface.h:771-779
         dir = d;
@@ -731,10 +736,15 @@ class Matcher {
     void inTextVerification(const std::vector<len_t>& startPos, len_t maxED, len_t minED,
                             Occurrences& occ, const Substring& pattern, bool fixedStartPos) {
         len_t nZeros = fixedStartPos ? 1 : 2 * maxED + 1;
-        // use64Matrix fmindex.h:240-246
-        if (!(BitParallelED64::LEFT >= nZeros + maxED && BitParallelED64::MATRIX_MAX_ED >= maxED))
-            throw std::runtime_error("oracle: 128-bit matrix path (k >= 7) not restated");
-        BitParallelED64& matrix = fullReadMatrix();
+        // use64Matrix fmindex.h:240-246; else the 128-bit matrix (fmindex.cpp:276-283, :306-307)
+        if (BitParallelED64::LEFT >= nZeros + maxED && BitParallelED64::MATRIX_MAX_ED >= maxED)
+            inTextVerificationOn(fullReadMatrix(), startPos, maxED, minED, occ, pattern, nZeros);
+        else
+            inTextVerificationOn(fullReadMatrices128[strand], startPos, maxED, minED, occ, pattern, nZeros);
+    }
+    template <class Matrix>
+    void inTextVerificationOn(Matrix& matrix, const std::vector<len_t>& startPos, len_t maxED, len_t minED,
+                              Occurrences& occ, const Substring& pattern, len_t nZeros) {
         if (!matrix.sequenceSet()) matrix.setSequence(pattern);
         matrix.initializeMatrix(maxED, std::vector<uint32_t>(nZeros, 0u));
         len_t nRows = matrix.getNumberOfRows();

@@ -381,6 +381,34 @@ for _ in range(60):
     else:
         cmds.append(f"samun {rid} {rd} {ql if ql != '-' else '*'}")
 
+# a5/a11 beyond the 64-bit matrix (fmindex.h:240-246: in-text verification with 2k+1 zeros needs BitParallelED128 from
+# k = 7): band cells of every row, cluster centres and tracebacks of the reference's 128-bit matrix
+rng4 = random.Random(20260207)
+for _ in range(60):
+    max_ed = rng4.randint(7, 12)
+    X = "".join(rng4.choice(ACGT) for _ in range(rng4.choice([64, 100, 150, 151, 250])))
+    nz = rng4.choice([1, 2 * max_ed + 1, 2 * max_ed + 1])
+    lead = 0 if nz == 1 else rng4.randint(0, 2 * max_ed)
+    def mut4(seq, n):
+        seq = list(seq)
+        for _ in range(n):
+            pos = rng4.randrange(len(seq))
+            op = rng4.randint(0, 2)
+            if op == 0:
+                seq[pos] = rng4.choice(ACGT)
+            elif op == 1:
+                seq.insert(pos, rng4.choice(ACGT))
+            elif len(seq) > 1:
+                del seq[pos]
+        return "".join(seq)
+    Y = "".join(rng4.choice(ACGT) for _ in range(lead)) + mut4(X, rng4.randint(0, max_ed + 1)) + \
+        "".join(rng4.choice(ACGT) for _ in range(rng4.randint(0, 12)))
+    if rng4.random() < 0.15:
+        Y = Y[:len(X) - rng4.randint(1, 3)]
+    cmds.append(f"traceback128 {X} {Y} {max_ed} {rng4.randint(0, 2)} {nz}")
+    if rng4.random() < 0.5:
+        cmds.append(f"matrix128 {X} {Y} {max_ed} {nz}")
+
 
 def main():
     if not os.path.exists(DRIVER):
