@@ -631,9 +631,10 @@ static int batchCreateOne(cmb_index* idx, const cmb_strategy* st, uint32_t max_d
         if (n_reads >= (1u << 24)) // (only reachable through CMB_SUBBATCH_SPLIT weights: checked before any work)
             return fail(CMB_ERR_UNSUPPORTED, "more than 2^24 reads in one sub-batch");
         if (max_distance > 0) {
-            // use64Matrix (fmindex.h:240-246): nZeros + maxED = 3k+1 must fit LEFT = 21
-            if (st->metric == CMB_METRIC_EDIT && 3 * max_distance + 1 > MX_LEFT)
-                return fail(CMB_ERR_UNSUPPORTED, "k >= 7 needs the 128-bit matrix, which is not implemented");
+            // in-text verification: nZeros + maxED = 3k+1 must fit the first column of the in-text matrix (the reference
+            // switches to its 128-bit matrix at k = 7, fmindex.h:240-246; here: 64-bit words / 16-row blocks, LEFT = 22)
+            if (st->metric == CMB_METRIC_EDIT && 3 * max_distance + 1 > MXW_LEFT)
+                return fail(CMB_ERR_UNSUPPORTED, "k >= 8 needs a wider in-text matrix, which is not implemented");
             try {
                 b->hostStrat = st->flatten(max_distance);
             } catch (const std::exception& e) {
@@ -1718,7 +1719,7 @@ extern "C" int cmb_verify_batch_staged(cmb_index* idx, const char* pattern, uint
                                        uint64_t out_cap, uint64_t* n_out, uint64_t* counters) {
     if (!idx || !pattern || (n && !starts) || !n_out) return fail(CMB_ERR_INVALID, "null argument");
     if (plen == 0 || plen > (uint32_t)MAX_READ) return fail(CMB_ERR_UNSUPPORTED, "pattern length not supported");
-    if (max_ed == 0 || max_ed > 7 || 3 * max_ed + 1 > MX_LEFT || min_ed > 7) return fail(CMB_ERR_UNSUPPORTED, "needs the 128-bit matrix");
+    if (max_ed == 0 || max_ed > 7 || 3 * max_ed + 1 > MXW_LEFT || min_ed > 7) return fail(CMB_ERR_UNSUPPORTED, "needs a wider in-text matrix");
     if (n >= (1ull << 31)) return fail(CMB_ERR_INVALID, "too many start positions");
     for (uint64_t i = 0; i < n; i++)
         if (starts[i] > idx->d.n) return fail(CMB_ERR_INVALID, "start position beyond the text");
@@ -1782,7 +1783,7 @@ static int verifyDirect(cmb_index* idx, const char* pattern, uint32_t plen, cons
                         uint64_t* n_out, uint64_t* counters) {
     if (!idx || !pattern || (n && !starts) || !n_out) return fail(CMB_ERR_INVALID, "null argument");
     if (plen == 0 || plen > (uint32_t)MAX_READ) return fail(CMB_ERR_UNSUPPORTED, "pattern length not supported");
-    if (3 * max_ed + 1 > MX_LEFT || min_ed > 15) return fail(CMB_ERR_UNSUPPORTED, "needs the 128-bit matrix");
+    if (3 * max_ed + 1 > MXW_LEFT || min_ed > 15) return fail(CMB_ERR_UNSUPPORTED, "needs a wider in-text matrix");
     for (uint64_t i = 0; i < n; i++)
         if (starts[i] > idx->d.n) return fail(CMB_ERR_INVALID, "start position beyond the text");
     try {
@@ -1886,7 +1887,7 @@ extern "C" int cmb_cigar_windows(cmb_index* idx, const char* pattern, uint32_t p
         if (ends[i] - begins[i] > plen + distances[i]) return fail(CMB_ERR_INVALID, "text window longer than an alignment within the distance");
         maxD = std::max(maxD, distances[i]);
     }
-    if (3 * maxD + 1 > MX_LEFT) return fail(CMB_ERR_UNSUPPORTED, "needs the 128-bit matrix");
+    if (3 * maxD + 1 > MXW_LEFT) return fail(CMB_ERR_UNSUPPORTED, "needs a wider in-text matrix");
     if (stride < 2 * maxD + 3) return fail(CMB_ERR_INVALID, "stride must be at least 2 * distance + 3");
     if (n == 0) return CMB_OK;
     try {
@@ -2115,10 +2116,10 @@ extern "C" int cmb_match_best(cmb_index* idx, const cmb_strategy* st, uint32_t x
     if (min_identity < 50 || min_identity > 100) return fail(CMB_ERR_INVALID, "the minimal identity lies between 50 and 100");
     try {
         // getMaxSupportedDistanceForBestMapping (searchstrategy.h:1864, :2744): the largest k such that 1..k all have a
-        // scheme — and, on this device, a matrix (edit distance: 6, the 128-bit matrix is not built)
+        // scheme — and, on this device, an in-text matrix (edit distance: 7, dev_matrix.hpp: MXW_*)
         uint32_t maxSupported = 0;
         while (st->schemes.count(maxSupported + 1) && !st->schemes.at(maxSupported + 1).empty()) maxSupported++;
-        if (st->metric == CMB_METRIC_EDIT) maxSupported = std::min<uint32_t>(maxSupported, (MX_LEFT - 1) / 3);
+        if (st->metric == CMB_METRIC_EDIT) maxSupported = std::min<uint32_t>(maxSupported, (MXW_LEFT - 1) / 3);
         maxSupported = std::min<uint32_t>(maxSupported, 7u); // (3-bit distance of the filter key)
         std::unique_ptr<cmb_best> R(new cmb_best());
         memset(R->cnts, 0, sizeof(R->cnts));

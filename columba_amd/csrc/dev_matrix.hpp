@@ -45,14 +45,15 @@ __device__ __forceinline__ const uint32_t* gString(const uint32_t* G, uint32_t g
 // `xOff` of G (G = forward bit-string for FORWARD parts, reversed-read bit-string for BACKWARD
 // parts).  Bit t of block b stands for column index j = t - LEFT + 32 b of X; the LEFT low bits of
 // block 0 are forced to one (bitparallelmatrix.cpp:44-47); bits of columns >= xLen are zero.
+template <uint32_t LEFT = MX_LEFT>
 __device__ __forceinline__ uint64_t matchWord(const uint32_t* G, uint32_t xOff, uint32_t xLen, uint32_t b) {
-    const int lim = (int)xLen + (int)MX_LEFT - (int)(32u * b); // number of meaningful low bits
+    const int lim = (int)xLen + (int)LEFT - (int)(32u * b); // number of meaningful low bits
     if (lim <= 0) return 0ull;
     uint64_t m;
     if (b == 0) {
-        m = (window64(G, xOff) << MX_LEFT) | ((1ull << MX_LEFT) - 1ull);
+        m = (window64(G, xOff) << LEFT) | ((1ull << LEFT) - 1ull);
     } else {
-        m = window64(G, xOff + 32u * b - MX_LEFT);
+        m = window64(G, xOff + 32u * b - LEFT);
     }
     if (lim < 64) m &= (1ull << lim) - 1ull;
     return m;
@@ -99,12 +100,13 @@ __device__ __forceinline__ void initMatrix(MatGeom& g, uint32_t xLen, uint32_t m
 // Returns false if every cell of row i exceeds maxED.
 // The rightmost active column of the row just computed (bitparallelmatrix.h:400-412): called when D0 has no bit
 // at the RAC column.  Returns false if every cell of the row exceeds maxED.
+template <uint32_t BLOCK = MX_BLOCK, uint32_t DIAG = MX_DIAG>
 __device__ __forceinline__ bool racWalk(const MatGeom& g, uint32_t i, uint64_t HP, uint64_t HN, uint64_t& RAC) {
     // The reference walks left from the RAC column, one column per iteration, until the running value
     // (1, -1 per HP bit, +1 per HN bit) reaches zero, and gives up at column diagBit - Wv (:400-412).  The walk
     // spans at most Wh + Wv <= 30 columns: it is done on 32-bit windows of HP / HN whose bit 31 is the RAC
     // column.  Almost always the first HP bit ends it (no HN bit before it): that case needs no loop.
-    const uint32_t diagBit = i % MX_BLOCK + MX_DIAG;
+    const uint32_t diagBit = i % BLOCK + DIAG;
     const uint32_t q = (uint32_t)__ffsll((unsigned long long)RAC) - 1u;
     const uint32_t maxSteps = q - (diagBit - g.Wv); // the walk fails if it is still running at this step
     uint32_t hp = (uint32_t)((HP << (63u - q)) >> 32); // bit 31 <- bit q (no branch on q)
@@ -129,16 +131,18 @@ __device__ __forceinline__ bool racWalk(const MatGeom& g, uint32_t i, uint64_t H
     return true;
 }
 // the RAC column moves with the window: one to the left per row, back by a block when the words are realigned
+template <uint32_t BLOCK = MX_BLOCK>
 __device__ __forceinline__ void racAdvance(uint32_t i, uint64_t& RAC) {
     RAC <<= 1u;
-    if (i % MX_BLOCK == 0) RAC >>= MX_BLOCK;
+    if (i % BLOCK == 0) RAC >>= BLOCK;
 }
 __device__ __forceinline__ bool racHit(uint64_t D0, uint64_t RAC) { return (D0 & RAC) != 0ull; }
 // the Hyyro recurrence of one row (bitparallelmatrix.h:352-398): no RAC, no score
+template <uint32_t BLOCK = MX_BLOCK>
 __device__ __forceinline__ void computeRowCore(uint32_t i, uint64_t M, uint64_t& HP, uint64_t& HN, uint64_t& D0) {
-    if (i % MX_BLOCK == 0) {
-        HP >>= MX_BLOCK;
-        HN >>= MX_BLOCK;
+    if (i % BLOCK == 0) {
+        HP >>= BLOCK;
+        HN >>= BLOCK;
     }
     D0 = (((M & HP) + HP) ^ HP) | M | HN;
     const uint64_t VP = HN | ~(D0 | HP);
@@ -146,18 +150,20 @@ __device__ __forceinline__ void computeRowCore(uint32_t i, uint64_t M, uint64_t&
     HP = (VN << 1u) | ~(D0 | (VP << 1u));
     HN = (D0 & (VP << 1u));
 }
+template <uint32_t BLOCK = MX_BLOCK, uint32_t DIAG = MX_DIAG>
 __device__ __forceinline__ bool computeRow(const MatGeom& g, uint32_t i, uint64_t M, uint64_t& HP, uint64_t& HN,
                                            uint64_t& D0, uint64_t& RAC, uint32_t& score) {
-    racAdvance(i, RAC);
-    computeRowCore(i, M, HP, HN, D0);
-    score += (D0 & (1ull << (i % MX_BLOCK + MX_DIAG))) ? 0u : 1u;
-    if (!racHit(D0, RAC)) return racWalk(g, i, HP, HN, RAC);
+    racAdvance<BLOCK>(i, RAC);
+    computeRowCore<BLOCK>(i, M, HP, HN, D0);
+    score += (D0 & (1ull << (i % BLOCK + DIAG))) ? 0u : 1u;
+    if (!racHit(D0, RAC)) return racWalk<BLOCK, DIAG>(g, i, HP, HN, RAC);
     return true;
 }
 
 // operator()(i,j) (bitparallelmatrix.h:622-639) from the state of row i
+template <uint32_t BLOCK = MX_BLOCK, uint32_t DIAG = MX_DIAG>
 __device__ __forceinline__ uint32_t cellAt(uint32_t i, uint32_t j, uint64_t HP, uint64_t HN, uint32_t score) {
-    const uint32_t bit = (i % MX_BLOCK) + MX_DIAG;
+    const uint32_t bit = (i % BLOCK) + DIAG;
     const uint32_t b = (i > j) ? bit - (i - j) + 1 : bit + 1;
     const uint32_t e = (i > j) ? bit + 1 : bit + (j - i) + 1;
     const uint32_t len = e - b;
@@ -181,9 +187,25 @@ __device__ __forceinline__ uint32_t cellAt(uint32_t i, uint32_t j, uint64_t HP, 
 // traceback only involve cells <= maxED and comparisons against them).  tests/test_gpu_parity.py compares counters
 // (MATRIX_ROWS, ABORTED, CIGARS) and occurrences with the oracle's 64-bit matrix.
 constexpr uint32_t MX32_BLOCK = 8, MX32_DIAG = 13, MX32_LEFT = 14, MX32_MAX_ED = 4;
+// ---- ... and on 64-bit words and 16-row blocks (in-text verification, maxED 5 .. 7) ----
+// BitParallelED<uint64_t> supports a first column of nZeros + maxED <= LEFT = 21 values: the in-text matrix of a
+// candidate whose start is not fixed (nZeros = 2 k + 1) fits up to k = 6, and the reference switches to its 128-bit
+// word at k = 7 (fmindex.h:240-246).  The same algorithm with WORD 64, BLOCK 16, DIAG 21, LEFT 22 holds the band of
+// k = 7 (Wv = 3 k = 21 columns left of the diagonal, Wh = k right of it: bits 0 .. 44): same band, same values in the
+// band, hence the same valid rows, centres and traces as the 128-bit matrix (pinned by the golden vectors of the
+// reference's BitParallelED128 through the oracle; tests/test_gpu_parity.py compares at k = 5, 6, 7).
+constexpr uint32_t MXW_BLOCK = 16, MXW_DIAG = 21, MXW_LEFT = 22, MXW_MAX_ED = 7;
+// The match words of the full read (k_match_words: per 32-row block, bit t = character t - MXF_LEFT + 32 b) serve
+// both in-text matrices: a row's word is a shift of its block's word.
+// (23, not 22: with 22 the 32-bit matrix's shifts are whole bytes and the compiler turns the 64-bit LDS read of the
+// block's word into an UNALIGNED 32-bit read — k_verify_edit 33.6 -> 43.5 ms)
+constexpr uint32_t MXF_LEFT = 23;
+__device__ __forceinline__ uint64_t matchWordW(uint64_t M64, uint32_t i) {
+    return M64 >> (((i % MX_BLOCK) / MXW_BLOCK) * MXW_BLOCK + (MXF_LEFT - MXW_LEFT));
+}
 // the 32-bit match word of row i from the 64-bit word of the row's 32-row block (bit p' = bit p' + 8 s + 7)
 __device__ __forceinline__ uint32_t matchWord32(uint64_t M64, uint32_t i) {
-    return (uint32_t)(M64 >> (((i % MX_BLOCK) / MX32_BLOCK) * MX32_BLOCK + (MX_LEFT - MX32_LEFT)));
+    return (uint32_t)(M64 >> (((i % MX_BLOCK) / MX32_BLOCK) * MX32_BLOCK + (MXF_LEFT - MX32_LEFT)));
 }
 // The rightmost active column of the 32-bit matrix: a one-bit mask, as in the 64-bit matrix.  The walk
 // (bitparallelmatrix.h:400-412) without its loop in all but rare cases: among the columns from the RAC column to the
@@ -272,5 +294,38 @@ __device__ __forceinline__ bool onlyVerticalGapsLeft(const MatGeom& g, uint32_t 
     const uint64_t v = (~HN >> bb) << bb;
     return (v << ((MX_WORD - be) & 63u)) == 0ull;
 }
+
+
+// The two in-text matrices behind one set of names (k_verify_stage, forwardPass)
+template <bool W32>
+struct InTextMx;
+template <>
+struct InTextMx<true> {
+    typedef uint32_t W;
+    static constexpr uint32_t BLOCK = MX32_BLOCK, DIAG = MX32_DIAG, LEFT = MX32_LEFT;
+    static __device__ __forceinline__ W matchWordOf(uint64_t M64, uint32_t i) { return matchWord32(M64, i); }
+    static __device__ __forceinline__ void core(uint32_t i, W M, W& HP, W& HN, W& D0) { computeRowCore(i, M, HP, HN, D0); }
+    static __device__ __forceinline__ void advance(uint32_t i, W& rac) { racAdvance(i, rac); }
+    static __device__ __forceinline__ bool walk(const MatGeom& g, uint32_t i, W HP, W HN, W& rac) { return racWalk(g, i, HP, HN, rac); }
+    static __device__ __forceinline__ bool row(const MatGeom& g, uint32_t i, W M, W& HP, W& HN, W& D0, W& rac, uint32_t& score) {
+        return computeRow(g, i, M, HP, HN, D0, rac, score);
+    }
+    static __device__ __forceinline__ uint32_t cell(uint32_t i, uint32_t j, W HP, W HN, uint32_t score) { return cellAt(i, j, HP, HN, score); }
+    static __device__ __forceinline__ uint32_t popc(W x) { return (uint32_t)__popc(x); }
+};
+template <>
+struct InTextMx<false> {
+    typedef uint64_t W;
+    static constexpr uint32_t BLOCK = MXW_BLOCK, DIAG = MXW_DIAG, LEFT = MXW_LEFT;
+    static __device__ __forceinline__ W matchWordOf(uint64_t M64, uint32_t i) { return matchWordW(M64, i); }
+    static __device__ __forceinline__ void core(uint32_t i, W M, W& HP, W& HN, W& D0) { computeRowCore<BLOCK>(i, M, HP, HN, D0); }
+    static __device__ __forceinline__ void advance(uint32_t i, W& rac) { racAdvance<BLOCK>(i, rac); }
+    static __device__ __forceinline__ bool walk(const MatGeom& g, uint32_t i, W HP, W HN, W& rac) { return racWalk<BLOCK, DIAG>(g, i, HP, HN, rac); }
+    static __device__ __forceinline__ bool row(const MatGeom& g, uint32_t i, W M, W& HP, W& HN, W& D0, W& rac, uint32_t& score) {
+        return computeRow<BLOCK, DIAG>(g, i, M, HP, HN, D0, rac, score);
+    }
+    static __device__ __forceinline__ uint32_t cell(uint32_t i, uint32_t j, W HP, W HN, uint32_t score) { return cellAt<BLOCK, DIAG>(i, j, HP, HN, score); }
+    static __device__ __forceinline__ uint32_t popc(W x) { return (uint32_t)__popcll(x); }
+};
 
 } // namespace cmb

@@ -565,11 +565,12 @@ struct VPlanes {
 __device__ __forceinline__ uint4* traceLine(const VPlanes& V, uint32_t slot, uint32_t line) {
     return reinterpret_cast<uint4*>(V.W) + ((size_t)line * V.nSlots + slot) * 4;
 }
-constexpr uint32_t TB_BELOW = 18;
+constexpr uint32_t TB_BELOW = 18;  // narrow rows (32-bit matrix, maxED <= 4)
+constexpr uint32_t TBW_BELOW = 21; // wide rows (64-bit / 16-row-block matrix, maxED <= 7: Wv = 3 maxED <= 21, Wh <= 7)
 // low half: HP; high half: M | ~D0 — "the diagonal step is allowed" (bitparallelmatrix.h:559-562), folded in by the
 // forward pass, which has the row's match word at hand: the trace then needs neither the text nor match words.
 __device__ __forceinline__ uint64_t packTraceRow(uint32_t r, uint64_t HP, uint64_t diagOk) {
-    const uint32_t sh = (r % MX_BLOCK) + MX_DIAG - TB_BELOW;
+    const uint32_t sh = (r % MXW_BLOCK) + MXW_DIAG - TBW_BELOW;
     return (uint64_t)(uint32_t)(HP >> sh) | ((uint64_t)(uint32_t)(diagOk >> sh) << 32);
 }
 // NARROW rows (maxED <= 4): 16 + 16 bits per row, sixteen rows per 64-byte line — half the trace traffic.
@@ -646,7 +647,7 @@ struct MFull {
     const uint4* p; // [read x strand][block][2]
     uint32_t nBlk;
 };
-__host__ __device__ inline uint32_t mfullBlocks(uint32_t maxLen) { return (maxLen + MX_LEFT + 31u) / 32u + 1u; }
+__host__ __device__ inline uint32_t mfullBlocks(uint32_t maxLen) { return (maxLen + MXF_LEFT + 31u) / 32u + 1u; }
 __global__ void k_match_words(const uint32_t* __restrict__ G, uint32_t gw, const uint64_t* __restrict__ offs, uint32_t nRs,
                               uint32_t nBlk, uint4* __restrict__ out) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -655,7 +656,7 @@ __global__ void k_match_words(const uint32_t* __restrict__ G, uint32_t gw, const
     const uint32_t len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
     uint64_t m[4];
 #pragma unroll
-    for (int ch = 0; ch < 4; ch++) m[ch] = matchWord(gString(G, gw, rs, 0u, (uint32_t)ch), 0, len, b);
+    for (int ch = 0; ch < 4; ch++) m[ch] = matchWord<MXF_LEFT>(gString(G, gw, rs, 0u, (uint32_t)ch), 0, len, b);
     out[gid * 2] = make_uint4((uint32_t)m[0], (uint32_t)(m[0] >> 32), (uint32_t)m[1], (uint32_t)(m[1] >> 32));
     out[gid * 2 + 1] = make_uint4((uint32_t)m[2], (uint32_t)(m[2] >> 32), (uint32_t)m[3], (uint32_t)(m[3] >> 32));
 }
@@ -687,8 +688,9 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
                                                 uint64_t& edPack, uint64_t& edPackHi, const VPlanes& V, uint32_t slot,
                                                 uint32_t& cRows, uint64_t* Ml, uint32_t rowMin = 0) {
     // NARROW (k <= 4) also means the matrix on 32-bit words / 8-row blocks (dev_matrix.hpp)
-    using W = typename std::conditional<NARROW, uint32_t, uint64_t>::type;
-    constexpr uint32_t LEFT = NARROW ? MX32_LEFT : MX_LEFT, DIAG = NARROW ? MX32_DIAG : MX_DIAG;
+    typedef InTextMx<NARROW> MX; // NARROW: 32-bit words / 8-row blocks; else 64-bit words / 16-row blocks (dev_matrix.hpp)
+    using W = typename MX::W;
+    constexpr uint32_t LEFT = MX::LEFT, DIAG = MX::DIAG;
     W HP = (W)(~(W)0) << LEFT, HN = ((W)1 << (LEFT + 1u - nZeros)) - (W)1, D0 = 0, RAC = racInit((W)0, DIAG + g.Wh);
     uint32_t score = 0;
     const uint32_t sfc = g.sfc();
@@ -696,7 +698,7 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
     const uint32_t col = g.n - 1;
     // sliding window of final-column values: edPrev = ED(r-1), edCur = ED(r) once r >= firstRow
     uint32_t edPrev2 = 0, edPrev = 0;
-    if (!STORE && firstRow == 0) edPrev = cellAt(0, col, HP, HN, score);
+    if (!STORE && firstRow == 0) edPrev = MX::cell(0, col, HP, HN, score);
     centreMask = 0;
     edPack = 0; // 3 bits per final-column row above firstRow: min(ED, 7); rows 21.. go to edPackHi
     edPackHi = 0;
@@ -745,17 +747,17 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
             const uint32_t tc = PACKED ? (pcur >> (2 * t)) & 3u : (wv >> (8 * (t & 3u))) & 0xFFu;
             if (alive) {
                 const uint64_t M64 = Ml[tc * 256 + tid];
-                const W M = NARROW ? (W)matchWord32(M64, r) : (W)M64;
+                const W M = MX::matchWordOf(M64, r);
                 bool valid = true;
                 if (CHECK) {
                     cRows++;
-                    valid = computeRow(g, r, M, HP, HN, D0, RAC, score);
+                    valid = MX::row(g, r, M, HP, HN, D0, RAC, score);
                 } else {
-                    computeRowCore(r, M, HP, HN, D0);
-                    constexpr uint32_t BLOCK = NARROW ? MX32_BLOCK : MX_BLOCK;
+                    MX::core(r, M, HP, HN, D0);
+                    constexpr uint32_t BLOCK = MX::BLOCK;
                     dAcc |= D0 & ((W)1 << ((r % BLOCK) + DIAG)); // the diagonal cell matched (the bit moves with the row)
                     if ((r % BLOCK) == BLOCK - 1u) {
-                        dm += NARROW ? (uint32_t)__popc((uint32_t)dAcc) : (uint32_t)__popcll((uint64_t)dAcc);
+                        dm += MX::popc(dAcc);
                         dAcc = 0;
                     }
                 }
@@ -765,8 +767,7 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
                     alive = false;
                 } else if (!CHECK) {
                     if (STORE && r > rowMin && r > firstRow) {
-                        const uint32_t pend = NARROW ? (uint32_t)__popc((uint32_t)dAcc) : (uint32_t)__popcll((uint64_t)dAcc);
-                        const uint32_t ed = cellAt(r, col, HP, HN, r - dm - pend);
+                        const uint32_t ed = MX::cell(r, col, HP, HN, r - dm - MX::popc(dAcc));
                         const uint32_t bidx = r - firstRow - 1u;
                         if (bidx < 21u) edPack |= (uint64_t)min(ed, 7u) << (3u * bidx);
                         else edPackHi |= (uint64_t)min(ed, 7u) << (3u * (bidx - 21u));
@@ -775,13 +776,13 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
                     alive = r < size;
                 } else {
                     if (STORE && r > firstRow) {
-                        const uint32_t ed = cellAt(r, col, HP, HN, score);
+                        const uint32_t ed = MX::cell(r, col, HP, HN, score);
                         const uint32_t bidx = r - firstRow - 1u;
                         if (bidx < 21u) edPack |= (uint64_t)min(ed, 7u) << (3u * bidx);
                         else edPackHi |= (uint64_t)min(ed, 7u) << (3u * (bidx - 21u));
                     }
                     if (!STORE && r >= firstRow) {
-                        const uint32_t ed = cellAt(r, col, HP, HN, score);
+                        const uint32_t ed = MX::cell(r, col, HP, HN, score);
                         // row r-1 can now be judged (its `below` neighbour is known)
                         if (r - 1 > firstRow) {
                             const uint32_t e1 = edPrev;
@@ -1077,9 +1078,9 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
         bool alive = false;
         unsigned long long key = ~0ull;
         uint32_t mult = 0, len = 0, score0 = 0, mask = 0, edPrev = 0, edPrev2 = 0;
-        using W = typename std::conditional<W32, uint32_t, uint64_t>::type;
-        constexpr uint32_t LEFT = W32 ? MX32_LEFT : MX_LEFT, DIAG = W32 ? MX32_DIAG : MX_DIAG;
-        constexpr uint32_t BLOCK = W32 ? MX32_BLOCK : MX_BLOCK;
+        typedef InTextMx<W32> MX;
+        using W = typename MX::W;
+        constexpr uint32_t LEFT = MX::LEFT, DIAG = MX::DIAG, BLOCK = MX::BLOCK;
         W HP = 0, HN = 0, RAC = 0;
         if (it < nIn) {
             if (FIRST) {
@@ -1127,8 +1128,9 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                 HP = (W)(~(W)0) << LEFT;
                 HN = ((W)1 << (LEFT + 1u - nZeros)) - (W)1; // first column: nZeros zeros, then 1, 2, ...
                 RAC = racInit((W)0, DIAG + g.Wh);
+                if (g.Wv > DIAG) flags |= FLAG_CAPACITY; // (the band must fit the matrix words: the host picks the kernel)
                 if (firstRow == 0) {
-                    if (FINALCOL) edPrev = cellAt(0, col, HP, HN, 0);
+                    if (FINALCOL) edPrev = MX::cell(0, col, HP, HN, 0);
                     else flags |= FLAG_CAPACITY; // (the host launches the final-column instance for such reads)
                 }
             }
@@ -1181,10 +1183,10 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             const uint32_t tc = PACKED ? ((t < 16 ? pLo : pHi) >> (2 * (t & 15u))) & 3u : (wv >> (8 * (t & 3u))) & 0xFFu;
             if (alive && !(t == 0 && head)) { // (the head block has 31 rows)
                 const uint64_t M64 = Ml[tc * 256 + tid];
-                const W M = W32 ? (W)matchWord32(M64, r) : (W)M64;
+                const W M = MX::matchWordOf(M64, r);
                 W D0;
-                racAdvance(r, RAC);
-                computeRowCore(r, M, HP, HN, D0);
+                MX::advance(r, RAC);
+                MX::core(r, M, HP, HN, D0);
                 bool valid = true;
 #ifdef CMB_STAGE_STATS
                 if (W32) { // what do the rows of a stage do?  [stage-class][wave rows, lane rows, any miss, lane misses, any slow, lane slow]
@@ -1207,18 +1209,17 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
                 }
 #endif
                 if (!racHit(D0, RAC)) { // (rare: what an end needs is recorded here, off the common path)
-                    valid = racWalk(g, r, HP, HN, RAC);
+                    valid = MX::walk(g, r, HP, HN, RAC);
                     if (!valid) deadRow = r;
                 }
                 dAcc |= D0 & ((W)1 << ((r % BLOCK) + DIAG)); // the diagonal cell matched (the bit moves with the row)
                 if ((r % BLOCK) == BLOCK - 1u) {
-                    dm += W32 ? (uint32_t)__popc((uint32_t)dAcc) : (uint32_t)__popcll((uint64_t)dAcc);
+                    dm += MX::popc(dAcc);
                     dAcc = 0;
                 }
                 if (FINALCOL && valid && r >= firstRow) {
-                    const uint32_t pend = W32 ? (uint32_t)__popc((uint32_t)dAcc) : (uint32_t)__popcll((uint64_t)dAcc);
-                    const uint32_t score = score0 + (r - (rFirst - 1u)) - dm - pend;
-                    const uint32_t ed = min(cellAt(r, col, HP, HN, score), 31u);
+                    const uint32_t score = score0 + (r - (rFirst - 1u)) - dm - MX::popc(dAcc);
+                    const uint32_t ed = min(MX::cell(r, col, HP, HN, score), 31u);
                     if (r - 1 > firstRow) { // row r-1 can now be judged (its `below` neighbour is known)
                         const uint32_t e1 = edPrev;
                         if (e1 <= maxED && e1 >= minED && e1 <= edPrev2 && e1 <= ed) mask |= 1u << (r - 2 - firstRow);
@@ -1231,7 +1232,7 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             }
         }
         }
-        dm += W32 ? (uint32_t)__popc((uint32_t)dAcc) : (uint32_t)__popcll((uint64_t)dAcc);
+        dm += MX::popc(dAcc);
         const bool ended = alive0 && !alive;
         // rows done so far: the stage's, all `size` of them, or those before the invalid row
         const uint32_t i = !ended ? rLast : deadRow ? deadRow - 1u : max(size, rFirst);
@@ -1295,7 +1296,7 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
     auto holeT = [&](uint32_t i) { q.text[i].rsId = 0xFFFFFFFFu; };
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t waveBase = slot & ~63u;
-    const uint64_t HP0 = (~0ull) << MX_LEFT;
+    const uint64_t HP0 = (~0ull) << MXW_LEFT;
     for (uint32_t base = waveBase; base < nTasks; base += stride) { // wave-uniform trip count
         const uint32_t it = base + (tid & 63u);
         uint32_t rs = 0, start = 0, m = 0, firstRow = 0, len = 0, col = 0;
@@ -1318,8 +1319,12 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             g.m = g.Wv + g.n;
             firstRow = (g.m - 1) - g.sfc();
             col = g.n - 1;
-            relLeft = TB_BELOW - g.Wv;
-            relRight = TB_BELOW + g.Wh;
+            relLeft = TBW_BELOW - g.Wv; // (the wide rows' window; used by the wide walk only)
+            relRight = TBW_BELOW + g.Wh;
+            if (!NARROW && (g.Wv > MXW_DIAG || maxED > MXW_MAX_ED)) { // the band must fit the 64-bit / 16-row-block matrix
+                flags |= FLAG_CAPACITY;
+                m = 0;
+            }
             if (NARROW && maxED > TBN_MAX_ED) { // (the host picks the wide kernel for k > 4)
                 flags |= FLAG_CAPACITY;
                 m = 0;
@@ -1403,7 +1408,7 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             } else if (have) {
                 uint32_t curG = 0xFFFFFFFFu; // the line (rows 8 g + 1 .. 8 g + 8) held in wW[.][tid]
                 while (tj > 0) {
-                    const uint32_t rel = tj + TB_BELOW - ti; // bit of the row's windows
+                    const uint32_t rel = tj + TBW_BELOW - ti; // bit of the row's windows
                     uint64_t ww = packTraceRow(0, HP0, 0ull); // row 0 (never steps diagonally: ti > 0 below)
                     if (ti > 0) {
                         const uint32_t gq = (ti - 1) >> 3, jq = (ti - 1) & 7u;
@@ -1731,7 +1736,7 @@ k_cigar(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf, const uint4* _
     const uint32_t tid = threadIdx.x;
     uint32_t flags = 0, dummyRows = 0;
     const uint64_t strideT = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t HP0 = (~0ull) << MX_LEFT;
+    const uint64_t HP0 = (~0ull) << MXW_LEFT;
     for (uint64_t base = slot & ~63u; base < nOcc; base += strideT) { // wave-uniform trip count
         const uint64_t it = base + (tid & 63u);
         uint4 o = make_uint4(0, 0, 0, 0);
@@ -1796,7 +1801,7 @@ k_cigar(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf, const uint4* _
                 run++;
             };
             while (tj > 0) {
-                const uint32_t rel = tj + TB_BELOW - ti;
+                const uint32_t rel = tj + (NARROW ? TB_BELOW : TBW_BELOW) - ti;
                 bool hpBit, dgBit;
                 if (NARROW) {
                     uint32_t wn = packTraceRowNarrow(0, (~0u) << MX32_LEFT, 0u);

@@ -113,7 +113,7 @@ def test_in_text_verification_hook(world):
     g = world["genome"]
     rng = np.random.default_rng(8)
     for trial in range(30):
-        k = int(rng.integers(1, 7))
+        k = int(rng.integers(1, 8))   # (k = 7 with a free start: the reference's 128-bit matrix)
         pos = int(rng.integers(100, len(g) - 400))
         pat = synth.sample_reads(g[pos:pos + 400], 1, int(rng.choice([50, 100, 150, 250])), seed=trial,
                                  edit_choices=(0, 1, 2, k), rc_frac=0.0)[0]
@@ -137,7 +137,7 @@ def test_production_edit_verification_path(world):
     rng = np.random.default_rng(18)
     dup_total = 0
     for trial in range(24):
-        k = int(rng.integers(1, 7))
+        k = int(rng.integers(1, 8))   # (k = 7 with a free start: the reference's 128-bit matrix)
         pos = int(rng.integers(100, len(g) - 400))
         pat = synth.sample_reads(g[pos:pos + 400], 1, int(rng.choice([50, 100, 150, 250])), seed=1000 + trial,
                                  edit_choices=(0, 1, 2, k), rc_frac=0.0)[0]
@@ -192,6 +192,8 @@ def test_production_edit_verification_path(world):
     ("minU", "hamming", "dynamic", 6),
     ("columba", "edit", "dynamic", 4),     # the CLI's default strategy
     ("columba", "edit", "dynamic", 6),
+    ("columba", "edit", "dynamic", 7),     # in-text verification beyond the reference's 64-bit matrix
+    ("minU", "edit", "dynamic", 7),
     ("columba", "edit", "dynamic", 1),
     ("columba", "edit", "uniform", 5),
     ("columba", "hamming", "dynamic", 3),
@@ -282,11 +284,11 @@ def _edge_reads(g, n, k, seed):
     return out
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 4, 6])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 6, 7])
 def test_band_edge_alignments(world, k):
     import os
-    reads = _edge_reads(world["genome"], 1500, k, seed=40 + k)
-    spec = "multiple_opt" if k % 2 == 0 else "kuch1"
+    reads = _edge_reads(world["genome"], 1500 if k < 7 else 600, k, seed=40 + k)
+    spec = "columba" if k == 7 else "multiple_opt" if k % 2 == 0 else "kuch1"
     _compare(world, spec, "edit", "dynamic", k, reads)
     if k <= 4:
         # the wide rows (used for k > 4) check, on every traceback step, the two rules the narrow rows rely on
@@ -347,8 +349,8 @@ def test_errors_are_loud(world):
     assert e.value.code == -3
     with pytest.raises(ca.CmbError) as e:   # distance without scheme
         ca.match_batch(world["dev"], st, 3, [b"ACGT" * 30])
-    with pytest.raises(ca.CmbError) as e:   # 128-bit matrix territory
-        ca.match_batch(world["dev"], ca.SearchStrategy("pigeon"), 7, [b"ACGT" * 30])
+    with pytest.raises(ca.CmbError) as e:   # beyond the in-text matrix of the device (k <= 7) / without a scheme
+        ca.match_batch(world["dev"], ca.SearchStrategy("pigeon"), 8, [b"ACGT" * 30])
     with pytest.raises(ca.CmbError):
         ca.match_batch(world["dev"], st, 4, [b"A" * 300])
     with pytest.raises(ca.CmbError) as e:   # seeds placed for 4-mers on an index with a 10-mer table
@@ -424,8 +426,8 @@ def test_best_mode(world, spec, metric, x, min_identity):
     """BEST (+x strata) mode — the reference's default (`-a best`, SearchStrategy::matchApproxBestPlusX,
     searchstrategy.cpp:623-746): per read the best distance, the number of hits at it, and the alignments of the best
     x + 1 strata in the reference's order, with sequence assignment and CIGAR, against the oracle's restatement.
-    (Cut-off: min(13, what strategy and device support, len * (100 - identity) / 100); the device supports 6 errors,
-    the oracle is given the same limit.)"""
+    (Cut-off: min(13, what strategy and device support, len * (100 - identity) / 100); the device supports 7 errors —
+    all the columba strategy has schemes for — and the oracle is given the same limit.)"""
     import schemes_py as sp
     op = world["op"]
     g = world["genome"]
@@ -440,7 +442,7 @@ def test_best_mode(world, spec, metric, x, min_identity):
     max_sup = 0
     while (max_sup + 1) in spec_tables["schemes"]:
         max_sup += 1
-    max_sup = min(max_sup, 6 if metric == "edit" else 7)
+    max_sup = min(max_sup, 7)
     o_occ, o_sid, o_sb, o_cig, o_off, o_best, o_hits, o_cnt = op.match_best(
         world["orc"], op.OracleStrategy(spec_tables, metric, "dynamic"), reads, x=x, min_identity=min_identity,
         max_supported=max_sup, threads=8)
