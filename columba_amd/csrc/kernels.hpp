@@ -545,8 +545,7 @@ k_exact(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
 // (edit distance: the frontier kernels of dev_bfs_edit.hpp, included above)
 
 // ------------------------------------------------------------------ locate + verification
-constexpr int VROWS = MAX_READ + 3 * 6 + 4;
-constexpr int VEMIT = 20; // max cluster centres of one candidate (size of the final column <= 3k+2)
+constexpr int VROWS = MAX_READ + 3 * 7 + 4; // rows of the longest in-text matrix (len + Wv, Wv = 3 k, k <= 7)
 
 // Row storage of the traceback pass, interleaved by slot so that the lanes of a wavefront (which
 // walk rows in lock step) write whole 512-byte lines: element (row, slot) lives at [row * nSlots + slot].

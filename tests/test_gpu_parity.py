@@ -264,6 +264,11 @@ def test_ragged_and_odd_reads(world):
     reads.append(g[0:150].tobytes())             # begins at text position 0
     _compare(world, "multiple_opt", "edit", "dynamic", 4, reads)
     _compare(world, "kuch1", "hamming", "dynamic", 3, reads)
+    # the longest in-text matrices the device holds: 256 characters at k = 7 (277 rows, band of 29 columns)
+    long_reads = [r for r in reads if len(r) >= 100]
+    for ln in (250, 256):
+        long_reads += synth.sample_reads(g, 60, ln, seed=1000 + ln, edit_choices=(0, 3, 5, 7))
+    _compare(world, "columba", "edit", "dynamic", 7, long_reads)
 
 
 def _edge_reads(g, n, k, seed):
