@@ -47,6 +47,11 @@ template <typename T> struct DevBuf {
         alloc(count);
         if (count) HIPCHK(hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice));
     }
+    void uploadPadded(const T* h, size_t count, size_t pad) { // `pad` zeroed elements behind the data (k_prep reads 16-byte chunks)
+        alloc(count + pad);
+        if (count) HIPCHK(hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(p + count, 0, pad * sizeof(T)));
+    }
     size_t bytes() const { return n * sizeof(T); }
 };
 
@@ -657,7 +662,7 @@ static int batchCreateOne(cmb_index* idx, const cmb_strategy* st, uint32_t max_d
         b->gw = gWords(maxLen);
         b->hostOffs.assign(offs, offs + n_reads + 1);
         HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-        b->reads.upload((const uint8_t*)seqs, offs[n_reads]);
+        b->reads.uploadPadded((const uint8_t*)seqs, offs[n_reads], 64);
         b->offs.upload(offs, n_reads + 1);
         b->seq.alloc((size_t)2 * n_reads * maxLen);
         b->G.alloc((size_t)n_reads * 8 * b->gw); // eight bit-strings per read (both strands use them: gString)
@@ -1799,7 +1804,7 @@ static int verifyDirect(cmb_index* idx, const char* pattern, uint32_t plen, cons
         DevBuf<uint4> tbq;
         DevBuf<unsigned long long> ctr;
         const uint64_t ho[2] = {0, plen};
-        reads.upload((const uint8_t*)pattern, plen);
+        reads.uploadPadded((const uint8_t*)pattern, plen, 64);
         offs.upload(ho, 2);
         seq.alloc(2 * (size_t)mlen);
         G.alloc(8 * (size_t)gw);
@@ -1900,7 +1905,7 @@ extern "C" int cmb_cigar_windows(cmb_index* idx, const char* pattern, uint32_t p
         DevBuf<uint16_t> ops;
         DevBuf<AlnRec> aln;
         const uint64_t ho[2] = {0, plen};
-        reads.upload((const uint8_t*)pattern, plen);
+        reads.uploadPadded((const uint8_t*)pattern, plen, 64);
         offs.upload(ho, 2);
         seq.alloc(2 * (size_t)mlen);
         G.alloc(8 * (size_t)gw);

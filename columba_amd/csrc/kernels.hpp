@@ -125,6 +125,17 @@ __global__ void k_kmer_table(DevIndex ix, uint4* __restrict__ table) {
     table[key] = ok ? make_uint4(r.sa.b, r.sa.e, r.rev.b, r.rev.e) : make_uint4(0, 0, 0, 0);
 }
 
+// 16 text codes from ANY byte offset (gfx950 serves unaligned 16-byte global loads)
+struct __attribute__((packed, aligned(1))) Unaligned16 {
+    uint32_t x, y, z, w;
+};
+struct __attribute__((packed, aligned(1))) Unaligned8 {
+    uint32_t x, y;
+};
+__device__ __forceinline__ uint4 loadText16(const uint8_t* p) {
+    const Unaligned16 v = *reinterpret_cast<const Unaligned16*>(p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 // ------------------------------------------------------------------ read preparation
 // One thread per (read, 32-character chunk): writes the codes of both strands and the chunk's word of
 // the eight match bit-strings of both strands (forward / reversed read x A,C,G,T).  G must be zeroed
@@ -154,12 +165,32 @@ k_prep(const uint8_t* __restrict__ reads, const uint64_t* __restrict__ offs, uin
     // the 32 codes of both strands are collected in registers and written as two 16-byte stores each (maxLen
     // is a multiple of 16): single-byte stores cost a partial-line write each
     uint32_t cF[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cR[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // the two byte runs, 32 bytes each, as four (unaligned) 16-byte loads instead of 64 byte loads: A forwards from
+    // rd + 32 w (the buffer is padded behind its last read), B as the 32 bytes that END at rd + len - 32 w (B[t] is
+    // byte 31 - t of them; they may begin in the previous read — only the first bytes of the buffer have nothing
+    // in front of them: byte loads there)
+    uint32_t wa[8], wb[8];
+    {
+        const uint4 x = loadText16(rd + 32 * w), y = loadText16(rd + 32 * w + 16);
+        wa[0] = x.x, wa[1] = x.y, wa[2] = x.z, wa[3] = x.w, wa[4] = y.x, wa[5] = y.y, wa[6] = y.z, wa[7] = y.w;
+    }
+    if (offs[r] + len >= 32ull * w + 32ull) {
+        const uint8_t* pb = rd + len - 32 * w - 32; // (pointer arithmetic inside the reads buffer)
+        const uint4 x = loadText16(pb), y = loadText16(pb + 16);
+        wb[0] = x.x, wb[1] = x.y, wb[2] = x.z, wb[3] = x.w, wb[4] = y.x, wb[5] = y.y, wb[6] = y.z, wb[7] = y.w;
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) wb[j] = 0;
+#pragma unroll
+        for (uint32_t t = 0; t < 32; t++)
+            if (t < nT) wb[(31u - t) >> 2] |= (uint32_t)rd[len - 1 - 32 * w - t] << (8u * ((31u - t) & 3u));
+    }
 #pragma unroll
     for (uint32_t t = 0; t < 32; t++) {
         if (t < nT) {
-            const uint32_t i = 32 * w + t;
             // reads.h:43-58 (upper-case, non-ACGT -> N); nucleotide.h:250 (reverse complement keeps N)
-            const uint8_t a = rd[i] & 0xDF, bch = rd[len - 1 - i] & 0xDF;
+            const uint8_t a = (uint8_t)(wa[t >> 2] >> (8u * (t & 3u))) & 0xDF;
+            const uint8_t bch = (uint8_t)(wb[(31u - t) >> 2] >> (8u * ((31u - t) & 3u))) & 0xDF;
             const uint32_t ca = a == 'A' ? 1 : a == 'C' ? 2 : a == 'G' ? 3 : a == 'T' ? 4 : 5;
             const uint32_t cb = bch == 'A' ? 1 : bch == 'C' ? 2 : bch == 'G' ? 3 : bch == 'T' ? 4 : 5;
             cF[t >> 2] |= ca << (8 * (t & 3u));
@@ -625,17 +656,6 @@ __device__ __forceinline__ void loadText2x32(const uint32_t* __restrict__ text2,
     hi = __funnelshift_r(w1, w2, sh);
 }
 
-// 16 text codes from ANY byte offset (gfx950 serves unaligned 16-byte global loads)
-struct __attribute__((packed, aligned(1))) Unaligned16 {
-    uint32_t x, y, z, w;
-};
-struct __attribute__((packed, aligned(1))) Unaligned8 {
-    uint32_t x, y;
-};
-__device__ __forceinline__ uint4 loadText16(const uint8_t* p) {
-    const Unaligned16 v = *reinterpret_cast<const Unaligned16*>(p);
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
 constexpr uint32_t ML_WORDS = 5 * 256; // LDS match-word table of a 256-thread block: [code 0..4][thread]
 
 // The match words of the FULL read (the matrix of the in-text verification has the whole read as its horizontal
