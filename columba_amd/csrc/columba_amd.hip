@@ -115,6 +115,11 @@ extern "C" int cmb_debug_bfs_stats(unsigned long long* out, int reset) { // diag
     return 0;
 }
 #endif
+#ifdef CMB_BOUNDS
+extern "C" int cmb_debug_oob(unsigned long long* out) { // diagnostic build only (tools/bounds_check.sh)
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(cmb::g_oob), 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef CMB_STAGE_STATS
 extern "C" int cmb_debug_stage_stats(unsigned long long* out, int reset) { // diagnostic build only
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(cmb::g_stageStats), 24 * sizeof(unsigned long long)) != hipSuccess) return -1;

@@ -80,6 +80,27 @@ struct BfsBufs {
     unsigned long long* blockCnt; // [BFS_GRID][4] per-block counters: nodes, expansions, rows, -
 };
 
+#ifdef CMB_BOUNDS
+// diagnostic build only (tools/bounds_check.sh): the data-dependent indices of the frontier kernels are checked; the
+// first violation is recorded ([0] site, [1] index, [2] capacity) and the index replaced by 0 instead of faulting
+__device__ unsigned long long g_oob[4];
+__device__ __forceinline__ uint32_t boundsChecked(uint32_t idx, uint32_t cap, uint32_t site) {
+    if (idx >= cap) {
+        if (atomicCAS(&g_oob[0], 0ull, (unsigned long long)site) == 0ull) {
+            g_oob[1] = idx;
+            g_oob[2] = cap;
+        }
+        return 0u;
+    }
+    return idx;
+}
+#define CMB_IDX(idx, cap, site) boundsChecked((idx), (cap), (site))
+#else
+// production: an index read from a record that lies outside its pool stops the search with CMB_ERR_INTERNAL (the
+// enclosing function's `flags`) instead of faulting
+#define CMB_IDX(idx, cap, site) ((idx) < (cap) ? (idx) : (flags |= FLAG_CAPACITY, 0u))
+#endif
+
 #ifdef CMB_BFS_STATS
 // diagnostic build only (tools/bfs_stats.sh): what an expansion produces — [0] nothing, [1] exactly one node outside the
 // final column and nothing else, [2] exactly one node in the final column and nothing else, [3] anything else,
@@ -160,6 +181,10 @@ __device__ __forceinline__ void issueRanks(const DevIndex& ix, int mode, const R
         t = ix.rev;
         tr = p.rev;
     }
+#ifdef CMB_BOUNDS
+    tr.b = CMB_IDX(tr.b, ix.n + 2u, 200);
+    tr.e = CMB_IDX(tr.e, ix.n + 2u, 201);
+#endif
     loadRankPairRaw(t, tr.b, tr.e, v);
 }
 __device__ __forceinline__ void takeRanks(const DevIndex& ix, int mode, const RangePair& p, const uint4 v[4], uint32_t Rb[4],
@@ -280,7 +305,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
             parent = RangePair{{n0.x, n0.y}, {n0.z, n0.w}};
             uint4 rk[4];
             issueRanks(ix, md, parent, rk);
-            const uint4* Cx = B.C + (size_t)ctx * CTX_U4;
+            const uint4* Cx = B.C + (size_t)CMB_IDX(ctx, B.cCap, 1) * CTX_U4;
             blk = (row + 1) / MX_BLOCK;
             const uint4 hot = Cx[CTX_HOT]; // everything the expansion needs of its context, in ONE 16-byte request
             const uint4 mA = Cx[CTX_M + 2 * blk], mB = Cx[CTX_M + 1 + 2 * blk];
@@ -418,7 +443,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
             }
             uint32_t rsId = 0, itMeta = 0;
             if (nIt) {
-                const uint4 hot = B.C[(size_t)ctx * CTX_U4 + CTX_HOT];
+                const uint4 hot = B.C[(size_t)CMB_IDX(ctx, B.cCap, 2) * CTX_U4 + CTX_HOT];
                 rsId = hot.x & 0x1FFFFFFu;
                 itMeta = hot.w & 0x7FFFFFu;
             }
@@ -441,7 +466,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
                 uint32_t fc = BFS_NONE;
                 if (wantF) {
                     fc = oF++;
-                    uint4* Fr = B.F + (size_t)fc * F_U4;
+                    uint4* Fr = B.F + (size_t)CMB_IDX(fc, B.fCap, 9) * F_U4;
                     Fr[0] = cr;
                     Fr[1] = make_uint4(row1 | (ch << 16), fcP, 0u, 0u);
                 }
@@ -565,7 +590,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                 fcE = ev.y;
                 remFrom = (int)ev.z;
                 last = ev.w;
-                const uint4* Cx = B.C + (size_t)c0i * CTX_U4;
+                const uint4* Cx = B.C + (size_t)CMB_IDX(c0i, B.cCap, 3) * CTX_U4;
                 const uint4 c0 = Cx[0], c1 = Cx[1], c3 = Cx[3];
                 const uint4 fp = Ei[(size_t)2 * i + 1]; // final-column distances of the path (travel with the event)
                 pack = EdPack{u64of(fp.x, fp.y), u64of(fp.z, fp.w)};
@@ -627,7 +652,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                         const uint32_t nd0 = last - P.ci;
                         P.ni = nd0 + 1;
                         if (remFrom >= 0) { // :625 (descRef0 is valid: the event came out of a replay)
-                            const uint32_t dn = B.C[(size_t)descRef0 * CTX_U4 + 4].y & 0xFFu;
+                            const uint32_t dn = B.C[(size_t)CMB_IDX(descRef0, B.cCap, 4) * CTX_U4 + 4].y & 0xFFu;
                             P.nRem = dn > (uint32_t)remFrom ? dn - (uint32_t)remFrom : 0u;
                         }
                         P.nDescNew = nd0 + P.nRem;
@@ -658,7 +683,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
             }
             if (descSelf) P.nDescSrc = P.nDescNew;
             else if (descRefN != BFS_NONE) {
-                dC4 = B.C[(size_t)descRefN * CTX_U4 + 4];
+                dC4 = B.C[(size_t)CMB_IDX(descRefN, B.cCap, 5) * CTX_U4 + 4];
                 P.nDescSrc = dC4.y & 0xFFu;
             }
         }
@@ -694,11 +719,11 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
             uint32_t cur = fcE;
             const uint32_t lowest = (uint32_t)__ffs(P.centres) - 1u;
             for (uint32_t c = last;; c--) {
-                const uint4 f1 = B.F[(size_t)cur * F_U4 + 1];
+                const uint4 f1 = B.F[(size_t)CMB_IDX(cur, B.fCap, 10) * F_U4 + 1];
                 if ((P.centres >> c) & 1u) {
-                    const uint32_t old = atomicExch(&reinterpret_cast<uint32_t*>(B.F + (size_t)cur * F_U4 + 1)[2], 1u);
+                    const uint32_t old = atomicExch(&reinterpret_cast<uint32_t*>(B.F + (size_t)CMB_IDX(cur, B.fCap, 11) * F_U4 + 1)[2], 1u);
                     if (!old) { // FMPosExt::report (indexhelpers.h:1586-1601): once per node
-                        const uint4 r = B.F[(size_t)cur * F_U4];
+                        const uint4 r = B.F[(size_t)CMB_IDX(cur, B.fCap, 12) * F_U4];
                         const uint32_t e = edGet(pack, c);
                         if (r.y > r.x && e >= lowerBound)
                             q.fm[fmNext++] = FMOccRec{rsId, r.x, r.y, (f1.x & 0xFFFFu) + smDepth, e, smShift};
@@ -710,11 +735,11 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
             for (; fmNext < fmEnd; fmNext++) q.fm[fmNext].rsId = 0xFFFFFFFFu; // holes
         } else if (P.kind == 2) {
             uint32_t cur = fcE;
-            for (uint32_t c = last; c > P.ci; c--) cur = B.F[(size_t)cur * F_U4 + 1].y;
-            const uint32_t old = atomicExch(&reinterpret_cast<uint32_t*>(B.F + (size_t)cur * F_U4 + 1)[2], 1u);
+            for (uint32_t c = last; c > P.ci; c--) cur = B.F[(size_t)CMB_IDX(cur, B.fCap, 13) * F_U4 + 1].y;
+            const uint32_t old = atomicExch(&reinterpret_cast<uint32_t*>(B.F + (size_t)CMB_IDX(cur, B.fCap, 14) * F_U4 + 1)[2], 1u);
             if (!old) {
-                const uint4 r = B.F[(size_t)cur * F_U4];
-                const uint4 f1 = B.F[(size_t)cur * F_U4 + 1];
+                const uint4 r = B.F[(size_t)CMB_IDX(cur, B.fCap, 15) * F_U4];
+                const uint4 f1 = B.F[(size_t)CMB_IDX(cur, B.fCap, 16) * F_U4 + 1];
                 const uint32_t up = P.ci - P.hi;
                 smR = RangePair{{r.x, r.y}, {r.z, r.w}};
                 smDist = P.ed;
@@ -725,18 +750,18 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
         } else if (P.kind == 3) {
             // descendants = the final-column nodes below the centre (walked bottom-up), then the rest of the
             // interrupted replay; depths renumbered 1.. (:627-630)
-            uint4* dl = B.A + aOff;
+            uint4* dl = B.A + CMB_IDX(aOff, B.aCap, 101);
             uint32_t cur = fcE;
             for (uint32_t c = last; c > P.ci; c--) {
-                const uint4 r = B.F[(size_t)cur * F_U4];
-                const uint4 f1 = B.F[(size_t)cur * F_U4 + 1];
+                const uint4 r = B.F[(size_t)CMB_IDX(cur, B.fCap, 17) * F_U4];
+                const uint4 f1 = B.F[(size_t)CMB_IDX(cur, B.fCap, 18) * F_U4 + 1];
                 const uint32_t j = c - P.ci - 1;
                 dl[2 * j] = r;
                 dl[2 * j + 1] = make_uint4((j + 1) | (f1.x & 0xFF0000u), 0u, 0u, 0u);
                 cur = f1.y;
             }
-            const uint4 r = B.F[(size_t)cur * F_U4];
-            const uint4 f1 = B.F[(size_t)cur * F_U4 + 1];
+            const uint4 r = B.F[(size_t)CMB_IDX(cur, B.fCap, 19) * F_U4];
+            const uint4 f1 = B.F[(size_t)CMB_IDX(cur, B.fCap, 20) * F_U4 + 1];
             smR = RangePair{{r.x, r.y}, {r.z, r.w}};
             smDist = P.ed;
             smDepthN = (f1.x & 0xFFFFu) + smDepth;
@@ -745,8 +770,8 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
             if (enter) {
                 const uint32_t nd0 = last - P.ci;
                 if (P.nRem) {
-                    const uint4 sC4 = B.C[(size_t)descRef0 * CTX_U4 + 4];
-                    const uint4* sl = B.A + sC4.x;
+                    const uint4 sC4 = B.C[(size_t)CMB_IDX(descRef0, B.cCap, 6) * CTX_U4 + 4];
+                    const uint4* sl = B.A + CMB_IDX(sC4.x, B.aCap, 102);
                     for (uint32_t t = 0; t < P.nRem; t++) {
                         const uint32_t j = nd0 + t;
                         dl[2 * j] = sl[2 * ((uint32_t)remFrom + t)];
@@ -813,7 +838,8 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
 
         // ---- phase entry: recApproxMatchEdit prologue + replay of the descendants (:377-497)
         uint32_t outKind = 0; // 1: node of the next frontier, 2: event
-        uint4 oN0 = make_uint4(0, 0, 0, 0), oN1 = oN0, oN2 = oN0, oN4 = oN0, oEv = oN0, oEv1 = oN0;
+        uint32_t evRem = 0, evCell = 0, fLast = BFS_NONE; // event of an interrupted replay: descendants left, cell, its F record
+        uint4 oN0 = make_uint4(0, 0, 0, 0), oN1 = oN0, oN2 = oN0, oN4 = oN0, oEv1 = oN0;
         if (enter) {
             if (descSelf) descRefN = cNew;
             if (otherSelf) otherRefN = cNew;
@@ -839,7 +865,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                 nSrcDesc = dC4.y & 0xFFu;
                 nSrcInit = (dC4.y >> 8) & 0xFFu;
             }
-            const uint4* dl = B.A + dListOff;
+            const uint4* dl = B.A + CMB_IDX(dListOff, B.aCap, 103);
             const uint16_t* il = reinterpret_cast<const uint16_t*>(dl + 2 * nSrcDesc);
             uint32_t first = smDist, lastI = smDist, nInit = 1, increase = 0;
             if (nSrcInit != 0) { // :411-424
@@ -876,19 +902,19 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                             oDesc = P.nDescNew;
                             oInit = nInitNew;
                         } else {
-                            const uint4 oC4 = B.C[(size_t)otherRefN * CTX_U4 + 4];
+                            const uint4 oC4 = B.C[(size_t)CMB_IDX(otherRefN, B.cCap, 7) * CTX_U4 + 4];
                             oOff = oC4.x;
                             oDesc = oC4.y & 0xFFu;
                             oInit = (oC4.y >> 8) & 0xFFu;
                         }
                         if (oDesc > 0) {
-                            const uint16_t* oi = reinterpret_cast<const uint16_t*>(B.A + oOff + 2 * oDesc);
+                            const uint16_t* oi = reinterpret_cast<const uint16_t*>(B.A + CMB_IDX(oOff + 2 * oDesc, B.aCap, 104));
                             itStart -= oDesc - oInit + (uint32_t)oi[oInit - 1];
                         }
                     }
                     itMeta = packMeta(smShiftN, maxEDs, minEDs, stt == 0, ITEM_EDIT);
                 }
-                uint4* Cx = B.C + (size_t)cNew * CTX_U4;
+                uint4* Cx = B.C + (size_t)CMB_IDX(cNew, B.cCap, 8) * CTX_U4;
                 Cx[0] = make_uint4(rsId, g.n | (g.m << 16), g.Wv | (g.Wh << 8) | (maxEDn << 16) | (clSize << 24),
                                    idxN | (dirN << 4) | (uniN << 5) | (useRev << 6) | (itMode << 7) | (scheme << 12) |
                                        (search << 16));
@@ -916,7 +942,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                     const uint32_t e0 = cellAt(0, xLen, HP, HN, score);
                     if (e0 > 31u) flags |= FLAG_CAPACITY;
                     edPut(pk, 0, min(e0, 31u));
-                    uint4* Fr = B.F + (size_t)fNext * F_U4;
+                    uint4* Fr = B.F + (size_t)CMB_IDX(fNext, B.fCap, 21) * F_U4;
                     Fr[0] = make_uint4(smR.sa.b, smR.sa.e, smR.rev.b, smR.rev.e);
                     Fr[1] = make_uint4(0u, BFS_NONE, 0u, 0u);
                     fcCur = fNext++;
@@ -926,7 +952,12 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                 uint32_t rootRow = 0;
                 if (nSrcDesc > 0) { // replay (:463-492)
                     const uint32_t maxRow = g.m - 1;
-                    for (uint32_t j = 0; j < nSrcDesc; j++) {
+                    // (what the event of an interrupted replay carries is derived AFTER the loop from the loop counter and
+                    // the allocation counter — values assigned inside this divergent loop and read long after it came
+                    // back wrong for reads of 40 ... 100 characters: a record {0, 0, j + 1, cell})
+                    uint32_t j = 0;
+                    bool interrupted = false;
+                    for (; j < nSrcDesc; j++) {
                         const uint32_t meta = dl[2 * j + 1].x;
                         const uint32_t depth = meta & 0xFFFFu, ch = (meta >> 16) & 0xFFu;
                         if (depth > maxRow) break;
@@ -939,14 +970,12 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                             const uint32_t e = cellAt(depth, g.n - 1, HP, HN, score);
                             if (e > 31u) flags |= FLAG_CAPACITY;
                             edPut(pk, cellJ, min(e, 31u));
-                            uint4* Fr = B.F + (size_t)fNext * F_U4;
+                            uint4* Fr = B.F + (size_t)CMB_IDX(fNext, B.fCap, 22) * F_U4;
                             Fr[0] = dl[2 * j];
                             Fr[1] = make_uint4(depth | (ch << 16), fcCur, 0u, 0u);
                             fcCur = fNext++;
                             if (!valid || onlyVerticalGapsLeft(g, depth, HN)) { // goDeeper, then `return` (:472-477)
-                                outKind = 2;
-                                oEv = make_uint4(cNew, fcCur, j + 1, cellJ);
-                                oEv1 = make_uint4((uint32_t)pk.lo, (uint32_t)(pk.lo >> 32), (uint32_t)pk.hi, (uint32_t)(pk.hi >> 32));
+                                interrupted = true;
                                 live = false;
                                 break;
                             }
@@ -955,6 +984,13 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                             live = false;
                             break;
                         }
+                    }
+                    if (interrupted) {
+                        outKind = 2;
+                        evRem = j + 1;
+                        evCell = clSize + (dl[2 * j + 1].x & 0xFFFFu) - g.m;
+                        fLast = fNext - 1u; // (the F record of that row was the last one handed out)
+                        oEv1 = make_uint4((uint32_t)pk.lo, (uint32_t)(pk.lo >> 32), (uint32_t)pk.hi, (uint32_t)(pk.hi >> 32));
                     }
                     if (live) {
                         const uint32_t lastDepth = dl[2 * (nSrcDesc - 1) + 1].x & 0xFFFFu;
@@ -993,7 +1029,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
         } else if (outKind == 2) {
             if (oE >= B.evCap) flags |= FLAG_BFS_EV;
             else {
-                Eo[(size_t)2 * oE] = oEv;
+                Eo[(size_t)2 * oE] = make_uint4(cNew, fLast, evRem, evCell);
                 Eo[(size_t)2 * oE + 1] = oEv1;
             }
         }

@@ -271,6 +271,18 @@ def test_ragged_and_odd_reads(world):
     _compare(world, "columba", "edit", "dynamic", 7, long_reads)
 
 
+@pytest.mark.parametrize("spec,k", [("columba", 7), ("columba", 5), ("multiple_opt", 6)])
+def test_short_reads_with_many_errors(world, spec, k):
+    """Reads of 40 ... 100 characters at 5 ... 7 errors: short parts, replays of long descendant lists that are interrupted
+    in the final column (the events of those replays once carried a wrong context: lost alignments, and an out-of-range
+    context index on larger references — found by tools/soak_parity.py, localised by tools/bounds_check.sh)."""
+    g = world["genome"]
+    reads = []
+    for ln in (40, 48, 60, 75, 100):
+        reads += synth.sample_reads(g, 1500, ln, seed=7000 + ln + k, n_frac=0.02, edit_choices=(0, 1, 2, 3, k - 1, k, k, k + 1))
+    _compare(world, spec, "edit", "dynamic", k, reads)
+
+
 def _edge_reads(g, n, k, seed):
     """Reads whose k edits are all indels packed at one end: their alignments run along the edges of the
     verification band (the cells the narrow trace rows of `k_traceback` do not store)."""

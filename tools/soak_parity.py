@@ -1,0 +1,37 @@
+"""Soak run (GPU box, not part of the test suite): device vs oracle on larger random inputs than tests/ use.
+   python3 tools/soak_parity.py [reads per configuration]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import columba_amd as ca
+from columba_amd import indexbuild as ib, synth
+import oracle_py as op, schemes_py as sp
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+g, starts = synth.genome_rep(seed=77, n=6_000_000, scale=1.5)
+ix = ib.build_index(g.tobytes(), seq_starts=starts, device="cuda")
+dev, orc = ca.Index(ix), op.OracleIndex(ix)
+rng = np.random.default_rng(5)
+bad = 0
+for spec, metric, part, k in (("columba", "edit", "dynamic", 7), ("minU", "edit", "dynamic", 7), ("columba", "edit", "dynamic", 5),
+                              ("multiple_opt", "edit", "dynamic", 6), ("columba", "edit", "uniform", 7), ("minU", "edit", "static", 6),
+                              ("multiple_opt", "edit", "dynamic", 4), ("pigeon", "edit", "dynamic", 4), ("kuch1", "hamming", "dynamic", 4)):
+    reads = []
+    for ln in (40, 60, 100, 150, 151, 200, 256):
+        reads += synth.sample_reads(g, N // 7, ln, seed=int(rng.integers(1 << 30)), n_frac=0.02,
+                                    edit_choices=(0, 1, 2, 3, k - 1, k, k, k + 1))
+    t = time.time()
+    o_occ, o_off, o_cnt = op.match_batch(orc, op.OracleStrategy(sp.BY_NAME[spec], metric, part), k, reads, threads=64)
+    t1 = time.time()
+    d_occ, d_off, d_cnt = ca.match_batch(dev, ca.SearchStrategy(spec, metric, part), k, reads)
+    t2 = time.time()
+    same_off = np.array_equal(o_off, d_off)
+    same = same_off and all(np.array_equal(o_occ[f], d_occ[f]) for f in ("begin", "end", "distance"))
+    cn = [n for n in ("NODE_COUNTER", "IN_TEXT_STARTED", "MATRIX_ROWS", "ABORTED_IN_TEXT_VERIF", "CIGARS_IN_TEXT_VERIFICATION",
+                      "EXPANSIONS", "SEARCH_STARTED") if o_cnt[n] != d_cnt[n]]
+    print(f"{spec} {metric} {part} k={k}: {len(reads)} reads, {len(o_occ)} occurrences, oracle {t1 - t:.1f}s device {t2 - t1:.2f}s, "
+          f"occurrences {'identical' if same else 'DIFFER'}, counters {'identical' if not cn else 'DIFFER ' + str(cn)}", flush=True)
+    bad += (not same) + bool(cn)
+print("soak:", "OK" if not bad else f"{bad} mismatches")
+sys.exit(1 if bad else 0)
