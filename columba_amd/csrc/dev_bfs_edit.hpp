@@ -33,13 +33,15 @@ namespace cmb {
 
 constexpr uint32_t BFS_NONE = 0xFFFFFFFFu;
 constexpr uint32_t ED_CELLS = 24; // final-column cells per phase (5 bits each in a 128-bit pack); 3k+2 <= 24 for k <= 7
-// A context is three 128-byte lines: line 0 the cold header (C0..C4), line 1 the hot word and the match words of
+// A context is four 128-byte lines: line 0 the cold header (C0..C4), line 1 the hot word and the match words of
 // row blocks 0..2 — what an expansion reads of its context is ONE line for the first 96 rows of a phase (with the
-// hot word in line 0 the kernel took 72 instead of 66 ms) —, line 2 the match words of row blocks 3..6.
-constexpr uint32_t CTX_U4 = 24;
+// hot word in line 0 the kernel took 72 instead of 66 ms) —, lines 2 and 3 the match words of row blocks 3..10
+// (a part of a 256-character read can span all of it: 256 + 20 rows; with three lines a part beyond 223 rows — one
+// of the two parts of a long read at k = 1 — stopped the whole batch with CMB_ERR_INTERNAL).
+constexpr uint32_t CTX_U4 = 32;
 constexpr uint32_t CTX_HOT = 8;   // uint4 index of the hot word
 constexpr uint32_t CTX_M = 10;    // uint4 index of the match words of row block 0 ({A,C}, {G,T} per block)
-constexpr uint32_t CTX_MBLK = 7;  // row blocks with cached match words (rows < 224)
+constexpr uint32_t CTX_MBLK = 11; // row blocks with cached match words (rows < 352)
 constexpr uint32_t F_U4 = 2;      // uint4 per F record: {ranges} {depth | c << 16, parent, reported, -}
 // (all blocks of a pass should be resident together — 3 blocks of 256 threads per CU at ~160 VGPRs — or the event
 // blocks, which come last in the grid, only start when expansion blocks have finished)
