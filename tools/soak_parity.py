@@ -46,5 +46,26 @@ for spec, metric, part, k in CONFIGS:
     print(f"{spec} {metric} {part} k={k}: {len(reads)} reads, {len(o_occ)} occurrences, oracle {t1 - t:.1f}s device {t2 - t1:.2f}s, "
           f"occurrences {'identical' if same else 'DIFFER'}, counters {'identical' if not cn else 'DIFFER ' + str(cn)}", flush=True)
     bad += (not same) + bool(cn)
+# second data set: human-like repeats (the benchmark's generator), the headline configuration and its neighbours at scale
+import torch
+g2, starts2 = synth.genome_human_like(40_000_000, seed=2025, device="cuda")
+ix2 = ib.build_index(g2, seq_starts=starts2, device="cuda")
+dev2, orc2 = ca.Index(ix2), op.OracleIndex(ix2)
+g2h = g2.cpu().numpy() if hasattr(g2, "cpu") else g2
+for spec, metric, part, k, n, ln in (("multiple_opt", "edit", "dynamic", 4, 200000, 150), ("columba", "edit", "dynamic", 7, 30000, 150),
+                                     ("multiple_opt", "edit", "dynamic", 6, 60000, 250), ("columba", "edit", "dynamic", 4, 100000, 100),
+                                     ("kuch1", "hamming", "dynamic", 3, 200000, 150), ("minU", "edit", "static", 5, 60000, 76)):
+    reads = synth.sample_reads(g2h, n, ln, seed=int(rng.integers(1 << 30)), n_frac=0.01, edit_choices=(0, 0, 1, 2, 3, k, k + 1))
+    t = time.time()
+    o_occ, o_off, o_cnt = op.match_batch(orc2, op.OracleStrategy(sp.BY_NAME[spec], metric, part), k, reads, threads=128)
+    t1 = time.time()
+    d_occ, d_off, d_cnt = ca.match_batch(dev2, ca.SearchStrategy(spec, metric, part), k, reads)
+    t2 = time.time()
+    same = np.array_equal(o_off, d_off) and all(np.array_equal(o_occ[f], d_occ[f]) for f in ("begin", "end", "distance"))
+    cn = [c for c in ("NODE_COUNTER", "IN_TEXT_STARTED", "MATRIX_ROWS", "ABORTED_IN_TEXT_VERIF", "CIGARS_IN_TEXT_VERIFICATION",
+                      "EXPANSIONS", "SEARCH_STARTED") if o_cnt[c] != d_cnt[c]]
+    print(f"human-like 40 Mbp, {spec} {metric} {part} k={k}: {n} x {ln} bp, {len(o_occ)} occurrences, oracle {t1 - t:.1f}s device {t2 - t1:.2f}s, "
+          f"occurrences {'identical' if same else 'DIFFER'}, counters {'identical' if not cn else 'DIFFER ' + str(cn)}", flush=True)
+    bad += (not same) + bool(cn)
 print("soak:", "OK" if not bad else f"{bad} mismatches")
 sys.exit(1 if bad else 0)
