@@ -1215,7 +1215,7 @@ static int batchRunOne(cmb_batch* b) {
                         // records, more blocks leave more lanes idle behind candidates that ended (CMB_STAGE_BLOCKS)
                         const char* nbEnv = getenv("CMB_STAGE_BLOCKS");
                         const uint32_t nb = nbEnv ? std::min(8u, std::max(1u, (uint32_t)atoi(nbEnv))) : 2u;
-                        const uint32_t nStages = ((uint32_t)VROWS + 32u * nb - 1u) / (32u * nb) + 1u;
+                        const uint32_t nStages = (vRows(b->maxLen) + 32u * nb - 1u) / (32u * nb) + 1u;
                         for (int j = 0; j < 2; j++)
                             if (b->vsC[j].n < nRuns) {
                                 b->vsA[j].alloc((size_t)nRuns + nRuns / 8 + 256);
@@ -1281,7 +1281,7 @@ static int batchRunOne(cmb_batch* b) {
                     const uint32_t tSlots = std::min<uint32_t>(((nTb + 255) / 256) * 256, slotCap);
                     // 64-byte lines of 16 narrow (k <= 4) or 8 wide trace rows (a group is written whole)
                     const bool narrow = b->k <= TBN_MAX_ED && !getenv("CMB_TRACE_WIDE");
-                    const uint32_t tLines = narrow ? ((uint32_t)VROWS + 15u) / 16u + 2u : ((uint32_t)VROWS + 7u) / 8u + 2u;
+                    const uint32_t tLines = narrow ? (vRows(b->maxLen) + 15u) / 16u + 2u : (vRows(b->maxLen) + 7u) / 8u + 2u;
                     if (b->vW.n < (size_t)tLines * 8 * tSlots) b->vW.alloc((size_t)tLines * 8 * tSlots);
                     VPlanes vp{b->vW.p, tSlots, tLines};
                     tm.begin();
@@ -1401,7 +1401,7 @@ static int batchRunOne(cmb_batch* b) {
                 if (total) {
                     const uint32_t cSlots = (uint32_t)std::min<uint64_t>(((total + 255) / 256) * 256, 512u * 1024u);
                     const bool narrow = b->k <= TBN_MAX_ED && !getenv("CMB_TRACE_WIDE");
-                    const uint32_t tLines = narrow ? ((uint32_t)VROWS + 15u) / 16u + 2u : ((uint32_t)VROWS + 7u) / 8u + 2u;
+                    const uint32_t tLines = narrow ? (vRows(b->maxLen) + 15u) / 16u + 2u : (vRows(b->maxLen) + 7u) / 8u + 2u;
                     if (b->vW.n < (size_t)tLines * 8 * cSlots) b->vW.alloc((size_t)tLines * 8 * cSlots);
                     VPlanes vp{b->vW.p, cSlots, tLines};
                     MFull mfc = mf;

@@ -147,7 +147,7 @@ struct PartMachine {
     // ---- task start -------------------------------------------------------------------------
     // The read record k_prep wrote (len | hasN << 16, then (low, high) code-bit word pairs) has arrived
     // in v[]: unpack it into LDS and start the prologue of read x strand `rs`.
-    __device__ void begin(uint32_t rs, const uint4 v[5], const uint8_t* s, uint32_t kk) {
+    __device__ void begin(uint32_t rs, const uint4 v[5], const uint32_t* recWords, const uint8_t* s, uint32_t kk) {
         rsId = rs;
         seq = s;
         k = kk;
@@ -156,11 +156,15 @@ struct PartMachine {
             len = vw[0] & 0xFFFFu;
             hasN = (vw[0] >> 16) & 1u;
 #pragma unroll
-            for (uint32_t w = 0; w < 8; w++) // MAX_READ / 32 words per bit-string at most
+            for (uint32_t w = 0; w < 8; w++) // the words of the first 256 characters arrive in registers
                 if (w < pw1) { // record words: header, then (low, high) pairs
                     RD(0, w) = vw[1 + 2 * w];
                     RD(1, w) = vw[2 + 2 * w];
                 }
+            for (uint32_t w = 8; w < pw1; w++) { // longer reads (up to MAX_READ): the rest straight from the record
+                RD(0, w) = recWords[1 + 2 * w];
+                RD(1, w) = recWords[2 + 2 * w];
+            }
         }
         req = RQ_NONE;
         partToExtend = 0;
@@ -467,7 +471,7 @@ struct ExactLane {
         stDepth = depth;
     }
     // read record (k_prep): v[0].x = len | hasN << 16, then (low, high) word pairs
-    __device__ __forceinline__ void takeRecord(const uint4 v[5]) {
+    __device__ __forceinline__ void takeRecord(const uint4 v[5], const uint32_t* recWords) {
         const uint32_t* vw = reinterpret_cast<const uint32_t*>(v);
         len = vw[0] & 0xFFFFu;
         hasN = (vw[0] >> 16) & 1u;
@@ -477,6 +481,10 @@ struct ExactLane {
                 RD(0, w) = vw[1 + 2 * w];
                 RD(1, w) = vw[2 + 2 * w];
             }
+        for (uint32_t w = 8; w < pw1; w++) { // reads beyond 256 characters: the rest straight from the record
+            RD(0, w) = recWords[1 + 2 * w];
+            RD(1, w) = recWords[2 + 2 * w];
+        }
     }
 
     // the search starts from the exact range of its first part (doRecSearch, searchstrategy.cpp:1181-1254)

@@ -22,7 +22,7 @@ namespace cmb {
 constexpr int MAXP = 8;      // max parts (k <= 6 -> 7 parts in multiple_opt)
 constexpr int MAXS = 16;     // max searches per scheme
 constexpr int MAXSCH = 4;    // max alternative schemes per k (dynamic selection)
-constexpr int MAX_READ = 256;
+constexpr int MAX_READ = 320; // (contexts cache the match words of 352 rows, dev_bfs_edit.hpp: CTX_MBLK; 2 x 300 bp reads fit)
 constexpr int DESC_MAX = 56; // descendants handed to the next phase
 
 // ---- strategy tables (built on the host by host/schemes.cpp) -------------------------------

@@ -380,7 +380,7 @@ k_parts(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
 #pragma unroll
             for (uint32_t j = 0; j < 5; j++)
                 if (j < recQ) v[j] = rec[(size_t)rs * recQ + j];
-            m.begin(rs, v, seq + (size_t)rs * maxLen, k); // may leave a RQ_SEED request
+            m.begin(rs, v, reinterpret_cast<const uint32_t*>(rec + (size_t)rs * recQ), seq + (size_t)rs * maxLen, k); // may leave a RQ_SEED request
             if (m.phase == PH_DONE) psel[rs] = 0x80u;      // unsupported read: nothing to search
         }
         if (__ballot(m.req == RQ_SEED) != 0ull) {
@@ -498,12 +498,12 @@ k_exact(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
             }
         } else if (ph == EX_LOAD) {
             if (k == 0) {
-                m.takeRecord(v);
+                m.takeRecord(v, reinterpret_cast<const uint32_t*>(rec + (size_t)m.rsId * recQ));
                 m.cur = RangePair{{0, ix.n}, {0, 0}};
                 m.k0i = m.len;
                 m.phase = m.len == 0 ? EX_IDLE : EX_K0;
             } else if (!isPost) {
-                m.takeRecord(v);
+                m.takeRecord(v, reinterpret_cast<const uint32_t*>(rec + (size_t)m.rsId * recQ));
                 m.startSearch(RangePair{{v[5].x, v[5].y}, {v[5].z, v[5].w}});
             } else {
                 m.phase = EX_IDLE;
@@ -577,6 +577,7 @@ k_exact(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
 
 // ------------------------------------------------------------------ locate + verification
 constexpr int VROWS = MAX_READ + 3 * 7 + 4; // rows of the longest in-text matrix (len + Wv, Wv = 3 k, k <= 7)
+__host__ __device__ inline uint32_t vRows(uint32_t maxLen) { return maxLen + 3u * 7u + 4u; } // ... of a batch
 
 // Row storage of the traceback pass, interleaved by slot so that the lanes of a wavefront (which
 // walk rows in lock step) write whole 512-byte lines: element (row, slot) lives at [row * nSlots + slot].

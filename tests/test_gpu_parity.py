@@ -264,11 +264,13 @@ def test_ragged_and_odd_reads(world):
     reads.append(g[0:150].tobytes())             # begins at text position 0
     _compare(world, "multiple_opt", "edit", "dynamic", 4, reads)
     _compare(world, "kuch1", "hamming", "dynamic", 3, reads)
-    # the longest in-text matrices the device holds: 256 characters at k = 7 (277 rows, band of 29 columns)
+    # the longest in-text matrices the device holds: 320 characters at k = 7 (341 rows, band of 29 columns)
     long_reads = [r for r in reads if len(r) >= 100]
-    for ln in (250, 256):
+    for ln in (250, 256, 257, 300, 320):
         long_reads += synth.sample_reads(g, 60, ln, seed=1000 + ln, edit_choices=(0, 3, 5, 7))
     _compare(world, "columba", "edit", "dynamic", 7, long_reads)
+    _compare(world, "columba", "edit", "dynamic", 1, long_reads)   # two parts: phases of up to 300 rows
+    _compare(world, "multiple_opt", "edit", "dynamic", 4, long_reads)
 
 
 @pytest.mark.parametrize("spec,k", [("columba", 7), ("columba", 5), ("multiple_opt", 6)])
@@ -369,7 +371,7 @@ def test_errors_are_loud(world):
     with pytest.raises(ca.CmbError) as e:   # beyond the in-text matrix of the device (k <= 7) / without a scheme
         ca.match_batch(world["dev"], ca.SearchStrategy("pigeon"), 8, [b"ACGT" * 30])
     with pytest.raises(ca.CmbError):
-        ca.match_batch(world["dev"], st, 4, [b"A" * 300])
+        ca.match_batch(world["dev"], st, 4, [b"A" * 321])   # (reads of up to 320 characters are supported)
     with pytest.raises(ca.CmbError) as e:   # seeds placed for 4-mers on an index with a 10-mer table
         ca.match_batch(world["dev"], ca.SearchStrategy("01*0", "edit", "dynamic"), 2, [b"ACGT" * 37 + b"AC"])
     assert e.value.code == -1 and "seeds of a read overlap" in str(e.value)
