@@ -931,7 +931,9 @@ static int batchRunOne(cmb_batch* b) {
                     b->psel.alloc(tasks);
                 }
                 {
-                    auto kp = b->hostStrat.partition == 0 ? k_parts<0> : b->hostStrat.partition == 1 ? k_parts<1> : k_parts<2>;
+                    const bool longReads = b->maxLen > 256;
+                    auto kp = longReads ? (b->hostStrat.partition == 0 ? k_parts<0, true> : b->hostStrat.partition == 1 ? k_parts<1, true> : k_parts<2, true>)
+                                        : (b->hostStrat.partition == 0 ? k_parts<0, false> : b->hostStrat.partition == 1 ? k_parts<1, false> : k_parts<2, false>);
                     hipLaunchKernelGGL(kp, dim3(pSlots / 256), dim3(256),
                                    stratBytes + (5 * pParts + rdWords) * 256 * sizeof(uint32_t), s, ix->d, b->strat.p, nReads,
                                    b->k, b->maxLen, b->seq.p, (const uint4*)b->rec.p, b->recW / 4, b->parts.p, b->exr.p,
@@ -944,7 +946,7 @@ static int batchRunOne(cmb_batch* b) {
             }
             const uint64_t eTasks = (uint64_t)tasks * nSlots;
             const uint32_t eSlots = (uint32_t)std::min<uint64_t>(((eTasks + 255) / 256) * 256, 256ull * 4096ull);
-            hipLaunchKernelGGL(k_exact, dim3(eSlots / 256), dim3(256), stratBytes + (pParts + rdWords) * 256 * sizeof(uint32_t),
+            hipLaunchKernelGGL(b->maxLen > 256 ? k_exact<true> : k_exact<false>, dim3(eSlots / 256), dim3(256), stratBytes + (pParts + rdWords) * 256 * sizeof(uint32_t),
                                s, ix->d, b->strat.p, nReads, b->k, b->maxLen, nSlots, b->seq.p, (const uint4*)b->rec.p,
                                b->recW / 4, b->parts.p, b->exr.p, b->psel.p, b->dfs.p, dfsCap, q);
             tm.end("k_partition");

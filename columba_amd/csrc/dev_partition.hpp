@@ -147,7 +147,8 @@ struct PartMachine {
     // ---- task start -------------------------------------------------------------------------
     // The read record k_prep wrote (len | hasN << 16, then (low, high) code-bit word pairs) has arrived
     // in v[]: unpack it into LDS and start the prologue of read x strand `rs`.
-    __device__ void begin(uint32_t rs, const uint4 v[5], const uint32_t* recWords, const uint8_t* s, uint32_t kk) {
+    template <bool LONG> // LONG: reads beyond 256 characters (a kernel instance of its own: the common one carries no code for them)
+    __device__ void begin(uint32_t rs, const uint4 v[5], const uint4* recBase, uint32_t recQ, const uint8_t* s, uint32_t kk) {
         rsId = rs;
         seq = s;
         k = kk;
@@ -161,9 +162,12 @@ struct PartMachine {
                     RD(0, w) = vw[1 + 2 * w];
                     RD(1, w) = vw[2 + 2 * w];
                 }
-            for (uint32_t w = 8; w < pw1; w++) { // longer reads (up to MAX_READ): the rest straight from the record
-                RD(0, w) = recWords[1 + 2 * w];
-                RD(1, w) = recWords[2 + 2 * w];
+            if (LONG && pw1 > 8) { // longer reads (up to MAX_READ): the rest straight from the record
+                const uint32_t* recWords = reinterpret_cast<const uint32_t*>(recBase + (size_t)rs * recQ);
+                for (uint32_t w = 8; w < pw1; w++) {
+                    RD(0, w) = recWords[1 + 2 * w];
+                    RD(1, w) = recWords[2 + 2 * w];
+                }
             }
         }
         req = RQ_NONE;
@@ -471,7 +475,8 @@ struct ExactLane {
         stDepth = depth;
     }
     // read record (k_prep): v[0].x = len | hasN << 16, then (low, high) word pairs
-    __device__ __forceinline__ void takeRecord(const uint4 v[5], const uint32_t* recWords) {
+    template <bool LONG>
+    __device__ __forceinline__ void takeRecord(const uint4 v[5], const uint4* recBase, uint32_t recQ) {
         const uint32_t* vw = reinterpret_cast<const uint32_t*>(v);
         len = vw[0] & 0xFFFFu;
         hasN = (vw[0] >> 16) & 1u;
@@ -481,9 +486,12 @@ struct ExactLane {
                 RD(0, w) = vw[1 + 2 * w];
                 RD(1, w) = vw[2 + 2 * w];
             }
-        for (uint32_t w = 8; w < pw1; w++) { // reads beyond 256 characters: the rest straight from the record
-            RD(0, w) = recWords[1 + 2 * w];
-            RD(1, w) = recWords[2 + 2 * w];
+        if (LONG && pw1 > 8) { // reads beyond 256 characters: the rest straight from the record
+            const uint32_t* recWords = reinterpret_cast<const uint32_t*>(recBase + (size_t)rsId * recQ);
+            for (uint32_t w = 8; w < pw1; w++) {
+                RD(0, w) = recWords[1 + 2 * w];
+                RD(1, w) = recWords[2 + 2 * w];
+            }
         }
     }
 

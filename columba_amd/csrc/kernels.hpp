@@ -348,7 +348,7 @@ __device__ __forceinline__ bool takeExtend(const DevIndex& ix, int mode, const R
 // (the partitioning of every read costs about the same).  Every loop iteration has ONE memory step: each lane
 // issues the loads of its request — the two rank blocks of an extension (8 x 16 B from 2 lines), the k-mer
 // table entries of its seeds, or its read record — before any reply is consumed.
-template <int PARTITION>
+template <int PARTITION, bool LONG>
 __global__ void __launch_bounds__(256, 4)
 k_parts(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint32_t k, uint32_t maxLen,
         const uint8_t* __restrict__ seq, const uint4* __restrict__ rec, uint32_t recQ, PartOut* __restrict__ parts,
@@ -380,7 +380,7 @@ k_parts(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
 #pragma unroll
             for (uint32_t j = 0; j < 5; j++)
                 if (j < recQ) v[j] = rec[(size_t)rs * recQ + j];
-            m.begin(rs, v, reinterpret_cast<const uint32_t*>(rec + (size_t)rs * recQ), seq + (size_t)rs * maxLen, k); // may leave a RQ_SEED request
+            m.template begin<LONG>(rs, v, rec, recQ, seq + (size_t)rs * maxLen, k); // may leave a RQ_SEED request
             if (m.phase == PH_DONE) psel[rs] = 0x80u;      // unsupported read: nothing to search
         }
         if (__ballot(m.req == RQ_SEED) != 0ull) {
@@ -412,6 +412,7 @@ k_parts(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
 
 // Exact phases of the searches + part-level pre-verification (dev_partition.hpp: ExactLane); k = 0: the whole
 // exact search.  One lane per (read x strand, slot), static round-robin; same one-memory-step loop.
+template <bool LONG>
 __global__ void __launch_bounds__(256, 4)
 k_exact(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint32_t k, uint32_t maxLen,
         uint32_t nSlots, const uint8_t* __restrict__ seq, const uint4* __restrict__ rec, uint32_t recQ,
@@ -498,12 +499,12 @@ k_exact(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
             }
         } else if (ph == EX_LOAD) {
             if (k == 0) {
-                m.takeRecord(v, reinterpret_cast<const uint32_t*>(rec + (size_t)m.rsId * recQ));
+                m.template takeRecord<LONG>(v, rec, recQ);
                 m.cur = RangePair{{0, ix.n}, {0, 0}};
                 m.k0i = m.len;
                 m.phase = m.len == 0 ? EX_IDLE : EX_K0;
             } else if (!isPost) {
-                m.takeRecord(v, reinterpret_cast<const uint32_t*>(rec + (size_t)m.rsId * recQ));
+                m.template takeRecord<LONG>(v, rec, recQ);
                 m.startSearch(RangePair{{v[5].x, v[5].y}, {v[5].z, v[5].w}});
             } else {
                 m.phase = EX_IDLE;
