@@ -47,9 +47,9 @@ def broadcast_index(ix: Optional[ib.IndexArrays], rank: int, dev) -> ib.IndexArr
 
 
 def broadcast_device_index(index, rank: int, device: int = 0):
-    """Replicate the DEVICE layout of rank 0's index on every rank: the 128-byte rank blocks, sampled-row records,
+    """Replicate the DEVICE layout of rank 0's index on every rank: the 32-byte rank blocks, sampled-row records,
     samples, text codes, 2-bit text and k-mer table are broadcast straight into the arrays of an empty twin index
-    (one collective per array, 10.5 GB for a 3 Gbp reference; per-link bound on xGMI) — no host round trip and no
+    (one collective per array, 12.5 GB for a 3 Gbp reference; per-link bound on xGMI) — no host round trip and no
     second re-layout.  `index` is a columba_amd.Index on rank 0 and ignored elsewhere."""
     import ctypes as C
     import torch.distributed as dist
