@@ -15,7 +15,7 @@ from typing import Dict, Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcolumba_amd.so")
+LIB_PATH = os.environ.get("CMB_LIB") or os.path.join(_HERE, "libcolumba_amd.so")  # (CMB_LIB: a variant build, for A/B runs)
 _SRC = os.path.join(_HERE, "csrc", "columba_amd.hip")
 
 CMB_OK = 0
