@@ -954,10 +954,25 @@ static int batchRunOne(cmb_batch* b) {
             HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             uint32_t flags = hcnt[3];
-            if (flags & FLAG_UNSUPPORTED_READ)
+            if (flags & FLAG_UNSUPPORTED_READ) {
+                // name the read: the caller has to drop it (k_parts marks such reads in psel)
+                std::string which;
+                if (b->psel.p && tasks) {
+                    std::vector<uint8_t> hp(tasks);
+                    HIPCHK(hipMemcpy(hp.data(), b->psel.p, tasks, hipMemcpyDeviceToHost));
+                    for (uint32_t t = 0; t < tasks; t++)
+                        if (hp[t] & 0x80u) {
+                            const uint32_t r = t >> 1;
+                            const uint64_t global = (b->parent ? b->parent->subBound[b->subIndex] : 0u) + (uint64_t)r;
+                            which = " (first: read " + std::to_string(global) + " of the batch, " +
+                                    std::to_string(b->hostOffs[r + 1] - b->hostOffs[r]) + " characters)";
+                            break;
+                        }
+                }
                 return fail(CMB_ERR_UNSUPPORTED,
                             "a read is not longer than the number of parts of the search scheme (the reference "
-                            "falls back to naive backtracking, which the device path does not provide)");
+                            "falls back to naive backtracking, which the device path does not provide)" + which);
+            }
             if (flags & FLAG_SEED_OVERLAP)
                 return fail(CMB_ERR_INVALID,
                             "dynamic partitioning: the seeds of a read overlap — the k-mer size of the index is too large "

@@ -346,7 +346,7 @@ __device__ __forceinline__ bool takeExtend(const DevIndex& ix, int mode, const R
 
 // Partitioning (dev_partition.hpp: PartMachine).  One lane per read x strand, static round-robin assignment
 // (the partitioning of every read costs about the same).  Every loop iteration has ONE memory step: each lane
-// issues the loads of its request — the two rank blocks of an extension (8 x 16 B from 2 lines), the k-mer
+// issues the loads of its request — the two rank blocks of an extension (4 x 16 B from 2 sectors), the k-mer
 // table entries of its seeds, or its read record — before any reply is consumed.
 template <int PARTITION, bool LONG>
 __global__ void __launch_bounds__(256, 4)
