@@ -54,3 +54,19 @@ def test_strategy_tables_host_side(built_lib):
     # invalid scheme: connectivity violated
     with pytest.raises(ca.CmbError):
         ca.SearchStrategy.from_tables({"schemes": {2: [[([0, 2, 1], [0, 0, 0], [0, 1, 2])]]}})
+
+
+def test_header_is_plain_c():
+    """include/columba_amd.h is the C-ABI: it must compile as C99 on its own (no C++ or torch types in the signatures),
+    and the adapters on top of it as C++17."""
+    import shutil
+    import subprocess
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c",
+                           os.path.join(inc, "columba_amd.h")])
+    for h in ("columba_amd.hpp", "columba_amd_io.hpp"):
+        src = f'#include "{h}"\nint main() {{ return 0; }}\n'
+        subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-fsyntax-only", "-x", "c++", "-I", inc, "-"], input=src,
+                       text=True, check=True)
