@@ -114,18 +114,26 @@ __device__ __forceinline__ bool racWalk(const MatGeom& g, uint32_t i, uint64_t H
     const uint32_t p1 = hp ? (uint32_t)__clz(hp) : 32u; // steps before the first HP bit
     if (p1 >= maxSteps) return false;                    // (the value cannot reach zero before the stop column)
     uint32_t k = p1;
-    if (p1 != 0u && (hn >> (32u - p1)) != 0u) { // HN bits before it: the general walk
-        uint32_t val = 1u;
-        k = 0;
+    if (p1 != 0u && (hn >> (32u - p1)) != 0u) {
+        // HN bits before it: the general walk.  The value can only reach zero AT an HP bit, so the walk goes per HP bit,
+        // not per column: the HN bits passed since the previous HP bit are counted, and it ends at the first HP bit at
+        // which as many HP as HN bits (plus one) have been seen — before step maxSteps (zero reached AT the stop column
+        // still fails, :408), or not at all.
+        const uint32_t xs = maxSteps >= 32u ? hp : hp & ~(0xFFFFFFFFu >> maxSteps);
+        uint32_t top = 0xFFFFFFFFu; // columns not yet passed
+        int need = 1;               // HP bits still needed (rises with every HN bit passed)
         for (;;) {
-            val += (hn >> 31) - (hp >> 31);
-            if (val == 0u) break;
-            if (k == maxSteps) return false;
-            hp <<= 1;
-            hn <<= 1;
-            k++;
+            const uint32_t xm = xs & top;
+            if (xm == 0u) return false;
+            const uint32_t fh = (uint32_t)__builtin_clz(xm);
+            const uint32_t hb = 0x80000000u >> fh;
+            need += (int)__popc(hn & top & ~((hb << 1u) - 1u)) - 1;
+            if (need == 0) {
+                k = fh;
+                break;
+            }
+            top = hb - 1u;
         }
-        if (k >= maxSteps) return false; // (zero reached AT the stop column still fails, :408)
     }
     RAC = 1ull << (q - k - 1u);
     return true;
@@ -208,38 +216,37 @@ __device__ __forceinline__ uint32_t matchWord32(uint64_t M64, uint32_t i) {
     return (uint32_t)(M64 >> (((i % MX_BLOCK) / MX32_BLOCK) * MX32_BLOCK + (MXF_LEFT - MX32_LEFT)));
 }
 // The rightmost active column of the 32-bit matrix: a one-bit mask, as in the 64-bit matrix.  The walk
-// (bitparallelmatrix.h:400-412) without its loop in all but rare cases: among the columns from the RAC column to the
-// left, x = the HP bits, y = the HN bits.  If no HN bit lies above the highest HP bit (y <= x; the two never share a
-// bit), the running value first reaches zero AT that HP bit: the new RAC column is the one left of it, and the walk
-// fails iff that bit is not above the stop column diagBit - Wv (this includes x = 0).  Otherwise the general walk.
+// (bitparallelmatrix.h:400-412) goes left from the RAC column, one column per iteration, with a running value that
+// starts at 1, falls at an HP bit and rises at an HN bit, until the value is zero; it fails if that has not happened
+// above the stop column diagBit - Wv.  With x / y = the HP / HN bits from the RAC column leftwards (the two never share
+// a bit): the walk fails iff x has no bit above the stop column (decided first: this is how most candidates end), ends
+// at the highest bit of x when no HN bit lies above it (y <= x), and otherwise — the value can only reach zero AT an HP
+// bit — is walked per HP bit, not per column: the HN bits passed since the previous HP bit are counted, and the walk
+// ends at the first HP bit at which as many HP as HN bits (plus one) have been seen.
 __device__ __forceinline__ bool racWalk(const MatGeom& g, uint32_t i, uint32_t HP, uint32_t HN, uint32_t& rac) {
     const uint32_t l = i % MX32_BLOCK;
     const uint32_t below = (rac << 1u) - 1u; // the RAC column and everything left of it
     const uint32_t x = HP & below, y = HN & below;
-    // the value cannot reach zero before the stop column unless an HP bit lies above it (this ends most candidates:
-    // decided here, without walking): highest bit of x above column l + MX32_DIAG - Wv  <=>  x >> (l + 1) >= 2^(MX32_DIAG - Wv)
+    // highest bit of x above column l + MX32_DIAG - Wv  <=>  x >> (l + 1) >= 2^(MX32_DIAG - Wv)
     if ((x >> (l + 1u)) < (1u << (MX32_DIAG - g.Wv))) return false;
     if (y <= x) {
         rac = 0x40000000u >> (uint32_t)__builtin_clz(x); // (x != 0 here)
         return true;
     }
-    const uint32_t diagBit = l + MX32_DIAG;
-    const uint32_t q = 31u - (uint32_t)__clz((int)rac);
-    const uint32_t maxSteps = q - (diagBit - g.Wv);
-    uint32_t hp = HP << (31u - q);
-    uint32_t hn = HN << (31u - q);
-    uint32_t val = 1u, k = 0;
+    const uint32_t xs = x & ~((2u << (l + MX32_DIAG - g.Wv)) - 1u); // zero reached AT the stop column still fails (:408)
+    uint32_t top = below; // columns not yet passed
+    int need = 1;         // HP bits still needed (rises with every HN bit passed)
     for (;;) {
-        val += (hn >> 31) - (hp >> 31);
-        if (val == 0u) break;
-        if (k == maxSteps) return false;
-        hp <<= 1;
-        hn <<= 1;
-        k++;
+        const uint32_t xm = xs & top;
+        if (xm == 0u) return false;
+        const uint32_t hb = 0x80000000u >> (uint32_t)__builtin_clz(xm);
+        need += (int)__popc(y & top & ~((hb << 1u) - 1u)) - 1; // HN bits between the previous HP bit and this one
+        if (need == 0) {
+            rac = hb >> 1u;
+            return true;
+        }
+        top = hb - 1u;
     }
-    if (k >= maxSteps) return false;
-    rac = 1u << (q - k - 1u);
-    return true;
 }
 __device__ __forceinline__ void racAdvance(uint32_t i, uint32_t& rac) {
     rac <<= 1u;
