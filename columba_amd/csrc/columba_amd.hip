@@ -219,6 +219,21 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         hipLaunchKernelGGL(k_kmer_table, dim3((total + 255) / 256), dim3(256), 0, 0, d, ix->kmer.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipDeviceSynchronize());
+        { // the arrays must belong together, or findSA would never end (k_check_index)
+            DevBuf<uint32_t> bad;
+            bad.alloc(1);
+            HIPCHK(hipMemset(bad.p, 0, sizeof(uint32_t)));
+            const uint32_t nProbe = (uint32_t)std::min<uint64_t>(n, 1u << 20);
+            hipLaunchKernelGGL(k_check_index, dim3((nProbe + 255) / 256), dim3(256), 0, 0, d, desc->sa_sparseness, nProbe, bad.p);
+            HIPCHK(hipGetLastError());
+            uint32_t hb = 0;
+            HIPCHK(hipMemcpy(&hb, bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            if (hb)
+                return fail(CMB_ERR_INVALID, "the index arrays do not belong together: " + std::to_string(hb) + " of " +
+                                                 std::to_string(nProbe) + " probed suffix-array rows do not reach a sampled row within " +
+                                                 std::to_string(desc->sa_sparseness) + " LF steps (wrong sparseness, or bit vectors / "
+                                                 "samples / BWT of different texts)");
+        }
         ix->bytes = ix->blkF.bytes() + ix->blkR.bytes() + ix->saBlk.bytes() + ix->saSamples.bytes() + ix->text.bytes() + ix->text2.bytes() + ix->kmer.bytes();
         ix->uploadSeqStarts();
         *out = ix.release();

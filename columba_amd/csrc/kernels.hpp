@@ -77,6 +77,28 @@ __global__ void k_locate(DevIndex ix, const uint32_t* __restrict__ rows, uint64_
     if (lf) atomicAdd(lfTotal, (unsigned long long)lf);
 }
 
+// Consistency probe at index creation: findSA terminates because every LF walk reaches a sampled row within
+// `sparseness` steps — IF the sampled-row bitvector, the samples and the BWT belong together.  With arrays that do not
+// (a sparse suffix array of another sparseness or of another text) the walk of findSA would not end.  nProbe rows spread
+// over the suffix array are walked with that bound; `bad` counts the rows that break it or leave the text.
+__global__ void k_check_index(DevIndex ix, uint32_t maxSteps, uint32_t nProbe, uint32_t* __restrict__ bad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nProbe) return;
+    uint32_t row = (uint32_t)(((uint64_t)i * ix.n) / nProbe);
+    for (uint32_t l = 0;; l++) {
+        if (row >= ix.n) break;
+        const SaPos p = saPos(row);
+        const uint64_t word = saWord(ix, p);
+        if ((word >> (p.off & 63u)) & 1ull) {
+            if ((uint64_t)ix.saSamples[saRankW(ix, p, word)] + l < ix.n) return; // a position of the text: fine
+            break;
+        }
+        if (l == maxSteps) break;
+        row = findLF(ix, row);
+    }
+    atomicAdd(bad, 1u);
+}
+
 // Re-packs the sampled-row bitvector and its rank9 counts (bitvec.h:155-170: per 512 rows the count before the block
 // and seven 9-bit in-block counts) into the 64-byte records of dev_index.hpp (SA_BLOCK rows each).
 __global__ void k_relayout_sa(const uint64_t* __restrict__ bv, const uint64_t* __restrict__ cnt, uint64_t nWords,

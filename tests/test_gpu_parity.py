@@ -361,6 +361,18 @@ def test_byte_text_path(world):
         assert c1 == c2
 
 
+def test_inconsistent_index_arrays_are_refused(world):
+    """Arrays that do not belong together (here: a sparse suffix array of sparseness 8 declared as 4) would make the LF
+    walk of the locate endless; cmb_index_create probes for it and refuses."""
+    import dataclasses
+    g = world["genome"][:300_000]
+    ix8 = ib.build_index(g.tobytes(), sparseness=8, device="cuda")
+    ca.Index(ix8).close()   # (consistent: accepted)
+    with pytest.raises(ca.CmbError) as e:
+        ca.Index(dataclasses.replace(ix8, sparseness=4))
+    assert e.value.code == -1 and "do not belong together" in str(e.value)
+
+
 def test_errors_are_loud(world):
     st = ca.SearchStrategy("multiple_opt")
     with pytest.raises(ca.CmbError) as e:   # read not longer than the number of parts: refused, and named
