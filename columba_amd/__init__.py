@@ -37,7 +37,7 @@ def cigar_string(ops) -> str:
 
 EXPORTS = [
     "cmb_index_create", "cmb_index_destroy", "cmb_index_device_bytes", "cmb_index_kmer_table",
-    "cmb_index_layout_of", "cmb_index_seq_starts", "cmb_index_create_empty", "cmb_index_device_arrays",
+    "cmb_index_layout_of", "cmb_index_seq_starts", "cmb_index_create_empty", "cmb_index_device_arrays", "cmb_index_validate",
     "cmb_strategy_create_named", "cmb_strategy_create_from_dir", "cmb_strategy_create",
     "cmb_strategy_add_scheme", "cmb_strategy_set_partition_params", "cmb_strategy_destroy",
     "cmb_strategy_describe", "cmb_strategy_export_scheme", "cmb_strategy_export_partition", "cmb_match_batch", "cmb_batch_create", "cmb_batch_run", "cmb_batch_stage_reads",
@@ -133,6 +133,7 @@ def lib():
         L.cmb_index_seq_starts.argtypes = [vp, vp]
         L.cmb_index_create_empty.argtypes = [C.POINTER(IndexLayout), vp, i32, C.POINTER(vp)]
         L.cmb_index_device_arrays.argtypes = [vp, C.POINTER(vp * DEV_ARRAYS), C.POINTER(u64 * DEV_ARRAYS)]
+        L.cmb_index_validate.argtypes = [vp]
         L.cmb_strategy_create_named.argtypes = [C.c_char_p, i32, i32, C.POINTER(vp)]
         L.cmb_strategy_create_from_dir.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
         L.cmb_strategy_create.argtypes = [i32, i32, u32, C.POINTER(vp)]
@@ -254,6 +255,10 @@ class Index:
         h = C.c_void_p()
         _chk(lib().cmb_index_create_empty(C.byref(layout), _p(starts), device, C.byref(h)))
         return cls(int(layout.text_length), kmer_size=int(layout.kmer_size), device=device, _handle=h)
+
+    def validate(self):
+        """consistency probe of the device arrays (after they were filled by a collective)"""
+        _chk(lib().cmb_index_validate(self.h))
 
     def device_tensors(self):
         """the device arrays of the index as flat uint8 torch tensors sharing the library's memory (no copy)"""

@@ -135,6 +135,33 @@ extern "C" const char* cmb_version(void) { return "columba_amd 0.1 (gfx950)"; }
 
 static void useDevice(int device) { HIPCHK(hipSetDevice(device)); }
 
+// k_check_index on the arrays of an index (at creation, and after its arrays were filled by a collective)
+static int probeIndex(cmb_index* ix) {
+    DevBuf<uint32_t> bad;
+    bad.alloc(1);
+    HIPCHK(hipMemset(bad.p, 0, sizeof(uint32_t)));
+    const uint32_t nProbe = std::min<uint32_t>(ix->d.n, 1u << 20);
+    if (!nProbe) return CMB_OK;
+    hipLaunchKernelGGL(k_check_index, dim3((nProbe + 255) / 256), dim3(256), 0, 0, ix->d, ix->saSparseness, nProbe, bad.p);
+    HIPCHK(hipGetLastError());
+    uint32_t hb = 0;
+    HIPCHK(hipMemcpy(&hb, bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (hb)
+        return fail(CMB_ERR_INVALID, "the index arrays do not belong together: " + std::to_string(hb) + " of " + std::to_string(nProbe) +
+                                         " probed suffix-array rows do not reach a sampled row within " + std::to_string(ix->saSparseness) +
+                                         " LF steps (wrong sparseness, or bit vectors / samples / BWT of different texts)");
+    return CMB_OK;
+}
+extern "C" int cmb_index_validate(cmb_index* idx) {
+    if (!idx) return fail(CMB_ERR_INVALID, "null argument");
+    try {
+        useDevice(idx->device);
+        return probeIndex(idx);
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}
+
 extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_index** out) {
     if (!desc || !out) return fail(CMB_ERR_INVALID, "null argument");
     if (desc->text_length == 0 || desc->text_length >= 0xFFFFFFFFull)
@@ -219,21 +246,7 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         hipLaunchKernelGGL(k_kmer_table, dim3((total + 255) / 256), dim3(256), 0, 0, d, ix->kmer.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipDeviceSynchronize());
-        { // the arrays must belong together, or findSA would never end (k_check_index)
-            DevBuf<uint32_t> bad;
-            bad.alloc(1);
-            HIPCHK(hipMemset(bad.p, 0, sizeof(uint32_t)));
-            const uint32_t nProbe = (uint32_t)std::min<uint64_t>(n, 1u << 20);
-            hipLaunchKernelGGL(k_check_index, dim3((nProbe + 255) / 256), dim3(256), 0, 0, d, desc->sa_sparseness, nProbe, bad.p);
-            HIPCHK(hipGetLastError());
-            uint32_t hb = 0;
-            HIPCHK(hipMemcpy(&hb, bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
-            if (hb)
-                return fail(CMB_ERR_INVALID, "the index arrays do not belong together: " + std::to_string(hb) + " of " +
-                                                 std::to_string(nProbe) + " probed suffix-array rows do not reach a sampled row within " +
-                                                 std::to_string(desc->sa_sparseness) + " LF steps (wrong sparseness, or bit vectors / "
-                                                 "samples / BWT of different texts)");
-        }
+        if (int rc = probeIndex(ix.get())) return rc; // the arrays must belong together, or findSA would never end
         ix->bytes = ix->blkF.bytes() + ix->blkR.bytes() + ix->saBlk.bytes() + ix->saSamples.bytes() + ix->text.bytes() + ix->text2.bytes() + ix->kmer.bytes();
         ix->uploadSeqStarts();
         *out = ix.release();

@@ -65,6 +65,8 @@ def broadcast_device_index(index, rank: int, device: int = 0):
     for t in index.device_tensors():
         if t is not None:
             dist.broadcast(t, src=0)
+    if rank != 0:
+        index.validate()   # (a truncated or mixed-up transfer would otherwise hang the first locate)
     return index
 
 

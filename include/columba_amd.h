@@ -93,6 +93,9 @@ int cmb_index_layout_of(const cmb_index* idx, cmb_index_layout* out);
 int cmb_index_seq_starts(const cmb_index* idx, uint32_t* out /* [n_seqs] */);
 int cmb_index_create_empty(const cmb_index_layout* layout, const uint32_t* seq_starts, int device, cmb_index** out);
 int cmb_index_device_arrays(cmb_index* idx, void** ptrs /* [CMB_DEV_ARRAYS] */, uint64_t* bytes /* [CMB_DEV_ARRAYS] */);
+/* after the arrays of an empty twin have been filled: the consistency probe cmb_index_create runs (every probed row of the
+ * suffix array reaches a sampled row within sa_sparseness LF steps, FMIndex::findSA, src/fmindex/fmindex.cpp:53-60) */
+int cmb_index_validate(cmb_index* idx);
 /* copy the device k-mer table (4^kmer_size x {sa.b,sa.e,rev.b,rev.e}) to host: test hook for
  * IndexInterface::populateTable (indexinterface.cpp:294-335) */
 int cmb_index_kmer_table(const cmb_index* idx, uint32_t* out /* 4 * 4^kmer_size */);
