@@ -4,6 +4,8 @@
 // oracle's restatement (oracle_core.hpp / oracle_search.hpp).  tests/ diff its
 // output with the fixtures that ref_driver (the real reference code) produced.
 // ============================================================================
+#include "move_driver_common.hpp"
+#include "oracle_move.hpp"
 #include "oracle_search.hpp"
 #include <algorithm>
 #include <fstream>
@@ -23,6 +25,41 @@ static string cigarStr(const vector<pair<char, uint32_t>>& c) {
     return s;
 }
 
+// twin of ref_driver_rlc.cpp's "move" command on the restated move table
+template <typename L> static void moveCommand(istringstream& in, ostream& os) {
+    string text;
+    int reversed, nq;
+    in >> text >> reversed >> nq;
+    const movedrv::Prepared p = movedrv::prepare(text, reversed != 0);
+    const L cum[5] = {p.cum[0], p.cum[1], p.cum[2], p.cum[3], p.cum[4]};
+    MoveLFT<L> built;
+    buildMoveRows<L>(p.bwt, cum, built);
+    const vector<uint8_t> file = built.fileBytes();
+    movedrv::hexBytes(os, file);
+    MoveLFT<L> rows;
+    if (!rows.loadBytes(file.data(), file.size())) os << " LOADFAILED";
+    const L r = rows.size();
+    os << " | " << r;
+    for (L i = 0; i <= r; i++)
+        os << ' ' << (int)rows.getRunHead(i) << ':' << rows.getInputStartPos(i) << ':' << rows.getOutputStartPos(i) << ':'
+           << rows.getOutputStartRun(i);
+    for (int q = 0; q < nq; q++) {
+        L b, e, c;
+        in >> b >> e >> c;
+        MoveRangeT<L> range(b, e, 0, r - 1, false), child;
+        rows.computeRunIndices(range);
+        rows.addChar(range, child, c);
+        os << " | " << range.beginRun << ' ' << range.endRun << ' ' << range.runIndicesValid << ' ' << child.begin << ' ' << child.end
+           << ' ' << child.beginRun << ' ' << child.endRun << ' ' << child.runIndicesValid << ' ' << rows.countChar(range, c) << ' '
+           << rows.getCumulativeCounts(range, c);
+        L pos = b, run = range.beginRun;
+        rows.findLF(pos, run);
+        L pos2 = e - 1;
+        rows.findLFWithoutFastForward(pos2, range.endRun);
+        os << ' ' << pos << ' ' << run << ' ' << pos2;
+    }
+}
+
 int main() {
     string line;
     while (getline(cin, line)) {
@@ -30,7 +67,12 @@ int main() {
         string cmd;
         in >> cmd;
         ostringstream os;
-        if (cmd == "bwt") {
+        if (cmd == "move") {
+            int width;
+            in >> width;
+            if (width == 64) moveCommand<uint64_t>(in, os);
+            else moveCommand<uint32_t>(in, os);
+        } else if (cmd == "bwt") {
             string bwt;
             in >> bwt;
             vector<uint8_t> codes(bwt.size());

@@ -125,3 +125,42 @@ def test_sparse_sa_files_of_the_reference_load(tmp_path):
         assert np.array_equal(mine, words) and np.array_equal(s2, samples)
         seen += 1
     assert seen >= 20
+
+
+# ---- run-length compressed flavour: the move table ----------------------------------------------
+def _load_rlc():
+    cmds = open(os.path.join(GOLD, "ref_vectors_rlc.cmds")).read().splitlines()
+    outs = open(os.path.join(GOLD, "ref_vectors_rlc.out")).read().splitlines()
+    assert len(cmds) == len(outs) and len(cmds) >= 100
+    return cmds, outs
+
+
+def test_move_table_matches_reference_vectors(oracle_built):
+    """MoveLFReprBP (bmove/moverepr.cpp) built through its own setters, written by its writer, read back by its loader and
+    queried (computeRunIndices, addChar, countChar, getCumulativeCounts, findLF with and without fast-forward), in the
+    64-bit and the 32-bit build: the oracle's restatement prints the same file bytes, rows and answers."""
+    cmds, outs = _load_rlc()
+    res = subprocess.run([os.path.join(oracle_built, "oracle_driver")], input="\n".join(cmds) + "\n",
+                         capture_output=True, text=True, check=True, cwd=GOLD).stdout.splitlines()
+    assert res == outs
+    # not vacuous: empty children, children narrower than the parent, both widths, both text directions
+    empty = narrower = 0
+    for c, o in zip(cmds, outs):
+        for q in o.split(" | ")[2:]:
+            t = q.split()
+            empty += t[3] == "0" and t[4] == "0"
+            narrower += int(t[4]) - int(t[3]) > 0
+    assert empty > 100 and narrower > 300
+    assert {c.split()[1] for c in cmds} == {"32", "64"} and {c.split()[3] for c in cmds} == {"0", "1"}
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(HERE), "oracle", "_ref", "ref_driver_rlc64")),
+                    reason="oracle/_ref/ref_driver_rlc* are only built where /root/reference exists")
+def test_rlc_fixture_is_what_the_reference_prints_today():
+    cmds, outs = _load_rlc()
+    for width in ("64", "32"):
+        drv = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "ref_driver_rlc" + width)
+        idx = [i for i, c in enumerate(cmds) if c.split()[1] == width]
+        res = subprocess.run([drv], input="\n".join(cmds[i] for i in idx) + "\n", capture_output=True, text=True,
+                             check=True, cwd=GOLD).stdout.splitlines()
+        assert res == [outs[i] for i in idx]
