@@ -4,6 +4,7 @@
 // __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Never linked into
 // or called from the product library.
 // ============================================================================
+#include "oracle_move.hpp"
 #include "oracle_search.hpp"
 #include <atomic>
 #include <thread>
@@ -469,5 +470,86 @@ void orc_result_copy(void* r, orc_occ* occs, uint64_t* offs, uint64_t* counters)
 }
 void orc_result_free(void* r) { delete (OrcResult*)r; }
 uint32_t orc_num_counters() { return COUNTER_TYPE_MAX; }
+
+// ---- run-length compressed backend (oracle_move.hpp) -----------------------------------------------------------------
+// same record as include/columba_amd.h: cmb_move_range
+struct orc_move_range {
+    uint64_t begin, end, begin_run, end_run;
+    uint64_t rev_begin, rev_end, rev_begin_run, rev_end_run;
+    uint64_t toehold;
+    uint32_t original_depth;
+    uint8_t runs_valid, rev_runs_valid, toehold_represents_end, reserved;
+};
+static orc::MovePair64 toPair(const orc_move_range& r) {
+    return orc::MovePair64(orc::MoveRange64(r.begin, r.end, r.begin_run, r.end_run, r.runs_valid != 0),
+                           orc::MoveRange64(r.rev_begin, r.rev_end, r.rev_begin_run, r.rev_end_run, r.rev_runs_valid != 0), r.toehold,
+                           r.toehold_represents_end != 0, r.original_depth);
+}
+static orc_move_range fromPair(const orc::MovePair64& p) {
+    orc_move_range r;
+    r.begin = p.sa.begin, r.end = p.sa.end, r.begin_run = p.sa.beginRun, r.end_run = p.sa.endRun;
+    r.rev_begin = p.rev.begin, r.rev_end = p.rev.end, r.rev_begin_run = p.rev.beginRun, r.rev_end_run = p.rev.endRun;
+    r.toehold = p.toehold, r.original_depth = (uint32_t)p.originalDepth;
+    r.runs_valid = p.sa.runIndicesValid, r.rev_runs_valid = p.rev.runIndicesValid, r.toehold_represents_end = p.toeholdRepresentsEnd;
+    r.reserved = 0;
+    return r;
+}
+
+void* orc_move_create(const uint8_t* lf, uint64_t lfLen, const uint8_t* lr, uint64_t lrLen, const uint64_t* smpf, const uint64_t* smpl,
+                      const uint64_t* rsmpf, const uint64_t* rsmpl, const uint64_t* predFirst, const uint64_t* firstToRun,
+                      const uint64_t* predLast, const uint64_t* lastToRun, const uint32_t* plcp) {
+    auto* ix = new orc::BMoveIndex64();
+    if (!ix->move.loadBytes(lf, lfLen) || !ix->moveR.loadBytes(lr, lrLen)) {
+        delete ix;
+        return nullptr;
+    }
+    ix->textLength = ix->move.getTextSize();
+    const uint64_t r = ix->move.size(), rr = ix->moveR.size();
+    ix->samplesFirst.assign(smpf, smpf + r);
+    ix->samplesLast.assign(smpl, smpl + r);
+    ix->revSamplesFirst.assign(rsmpf, rsmpf + rr);
+    ix->revSamplesLast.assign(rsmpl, rsmpl + rr);
+    if (predFirst) {
+        ix->predFirst.assign(predFirst, predFirst + r);
+        ix->firstToRun.assign(firstToRun, firstToRun + r);
+        ix->predLast.assign(predLast, predLast + r);
+        ix->lastToRun.assign(lastToRun, lastToRun + r);
+        ix->plcp.assign(plcp, plcp + ix->textLength);
+    }
+    return ix;
+}
+void orc_move_destroy(void* h) { delete (orc::BMoveIndex64*)h; }
+void orc_move_complete_range(void* h, orc_move_range* out) { *out = fromPair(((orc::BMoveIndex64*)h)->getCompleteRange()); }
+// rows of a table as (head, inputStart, outputStart, outputRun), nrOfRuns + 1 of them; returns nrOfRuns
+uint64_t orc_move_rows(void* h, int rev, uint64_t* out) {
+    auto* ix = (orc::BMoveIndex64*)h;
+    const auto& m = rev ? ix->moveR : ix->move;
+    if (out)
+        for (uint64_t i = 0; i <= m.size(); i++) {
+            out[4 * i] = m.getRunHead(i), out[4 * i + 1] = m.getInputStartPos(i);
+            out[4 * i + 2] = m.getOutputStartPos(i), out[4 * i + 3] = m.getOutputStartRun(i);
+        }
+    return m.size();
+}
+// mode 0 forward, 1 backward, 2 unidirectional backward (as cmb_extend_batch); c = 1..4; returns the rows stepped over
+uint64_t orc_move_extend(void* h, int mode, uint64_t n, const orc_move_range* parents, const uint8_t* c, orc_move_range* children,
+                         uint8_t* ok) {
+    auto* ix = (orc::BMoveIndex64*)h;
+    const uint64_t before = ix->counters.rowSteps;
+    for (uint64_t i = 0; i < n; i++) {
+        orc::MovePair64 child;
+        ok[i] = ix->extend(mode, c[i], toPair(parents[i]), child);
+        children[i] = fromPair(child);
+    }
+    return ix->counters.rowSteps - before;
+}
+// text positions of a range (bmove.cpp:543-560); returns the count (positions beyond cap are not stored)
+uint64_t orc_move_locate(void* h, const orc_move_range* r, uint64_t* out, uint64_t cap) {
+    auto* ix = (orc::BMoveIndex64*)h;
+    std::vector<uint64_t> pos;
+    ix->locate(toPair(*r), pos);
+    for (uint64_t i = 0; i < pos.size() && i < cap; i++) out[i] = pos[i];
+    return pos.size();
+}
 
 } // extern "C"

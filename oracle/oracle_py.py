@@ -96,6 +96,16 @@ def lib():
         L.orc_encode_bwt.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         L.orc_bwt_at.restype = C.c_uint64
         L.orc_bwt_at.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_move_create.restype = C.c_void_p
+        L.orc_move_create.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64] + [C.c_void_p] * 9
+        L.orc_move_destroy.argtypes = [C.c_void_p]
+        L.orc_move_complete_range.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_move_rows.restype = C.c_uint64
+        L.orc_move_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_move_extend.restype = C.c_uint64
+        L.orc_move_extend.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_move_locate.restype = C.c_uint64
+        L.orc_move_locate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         _lib = L
     return _lib
 
@@ -322,3 +332,59 @@ def search_info(pi, lo, up):
     out = np.zeros(5 * n, np.uint32)
     lib().orc_search_info(_p(pi), _p(lo), _p(up), n, _p(out))
     return out.reshape(5, n)
+
+
+# ---- run-length compressed backend (oracle_move.hpp) ------------------------------------------------------------------
+MOVE_RANGE_DTYPE = np.dtype([("begin", np.uint64), ("end", np.uint64), ("begin_run", np.uint64), ("end_run", np.uint64),
+                             ("rev_begin", np.uint64), ("rev_end", np.uint64), ("rev_begin_run", np.uint64),
+                             ("rev_end_run", np.uint64), ("toehold", np.uint64), ("original_depth", np.uint32),
+                             ("runs_valid", np.uint8), ("rev_runs_valid", np.uint8), ("toehold_represents_end", np.uint8),
+                             ("reserved", np.uint8)])
+assert MOVE_RANGE_DTYPE.itemsize == 80
+
+
+class OracleMoveIndex:
+    """The restated b-move index (bmove/bmove.{h,cpp}) over the arrays of columba_amd.movebuild.build_move."""
+
+    def __init__(self, mv, with_locate: bool = True):
+        L = lib()
+        self._keep = [np.ascontiguousarray(a) for a in (mv.lfbp_fwd, mv.lfbp_rev, mv.smpf, mv.smpl, mv.rev_smpf, mv.rev_smpl,
+                                                        mv.pred_first, mv.first_to_run, mv.pred_last, mv.last_to_run, mv.plcp)]
+        k = self._keep
+        loc = [_p(a) for a in k[6:]] if with_locate else [None] * 5
+        self.h = L.orc_move_create(_p(k[0]), k[0].nbytes, _p(k[1]), k[1].nbytes, _p(k[2]), _p(k[3]), _p(k[4]), _p(k[5]), *loc)
+        if not self.h:
+            raise ValueError("malformed move table")
+        self.n = mv.n
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.orc_move_destroy(self.h)
+            self.h = None
+
+    def complete_range(self) -> np.ndarray:
+        out = np.zeros(1, dtype=MOVE_RANGE_DTYPE)
+        lib().orc_move_complete_range(self.h, _p(out))
+        return out
+
+    def rows(self, rev: int) -> np.ndarray:
+        r = lib().orc_move_rows(self.h, rev, None)
+        out = np.zeros((r + 1, 4), dtype=np.uint64)
+        lib().orc_move_rows(self.h, rev, _p(out))
+        return out
+
+    def extend(self, mode: int, parents: np.ndarray, c: np.ndarray):
+        """children, ok flags and the number of table rows the reference's walks step over"""
+        parents = np.ascontiguousarray(parents, dtype=MOVE_RANGE_DTYPE)
+        c = np.ascontiguousarray(c, dtype=np.uint8)
+        children = np.zeros(parents.shape[0], dtype=MOVE_RANGE_DTYPE)
+        ok = np.zeros(parents.shape[0], dtype=np.uint8)
+        steps = lib().orc_move_extend(self.h, mode, parents.shape[0], _p(parents), _p(c), _p(children), _p(ok))
+        return children, ok, int(steps)
+
+    def locate(self, rng: np.ndarray) -> np.ndarray:
+        rng = np.ascontiguousarray(rng, dtype=MOVE_RANGE_DTYPE)
+        cap = int(rng["end"][0] - rng["begin"][0]) + 8
+        out = np.zeros(cap, dtype=np.uint64)
+        cnt = lib().orc_move_locate(self.h, _p(rng), _p(out), cap)
+        return out[:min(cnt, cap)]
