@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("CMB_LIB") or os.path.join(_HERE, "libcolumba_amd.so")
 _SRC = os.path.join(_HERE, "csrc", "columba_amd.hip")
 
 CMB_OK = 0
+CMB_ERR_INVALID, CMB_ERR_DEVICE, CMB_ERR_UNSUPPORTED, CMB_ERR_OVERFLOW, CMB_ERR_INTERNAL = -1, -2, -3, -4, -5
 ERRORS = {-1: "CMB_ERR_INVALID", -2: "CMB_ERR_DEVICE", -3: "CMB_ERR_UNSUPPORTED", -4: "CMB_ERR_OVERFLOW",
           -5: "CMB_ERR_INTERNAL"}
 COUNTER_NAMES = ["NODE_COUNTER", "TOTAL_REPORTED_POSITIONS", "IN_TEXT_STARTED", "ABORTED_IN_TEXT_VERIF",
@@ -46,6 +47,8 @@ EXPORTS = [
     "cmb_batch_want_alignments", "cmb_batch_alignments", "cmb_sam_se", "cmb_sam_se_xa", "cmb_sam_unmapped_se",
     "cmb_read_prepare", "cmb_batch_sam", "cmb_batch_filter_per_strand", "cmb_match_best", "cmb_best_sizes", "cmb_best_results",
     "cmb_best_destroy",
+    "cmb_move_create", "cmb_move_destroy", "cmb_move_device_bytes", "cmb_move_info", "cmb_move_complete_range", "cmb_move_rows",
+    "cmb_move_extend_batch", "cmb_move_extend_bench", "cmb_move_locate_batch",
     "cmb_last_error", "cmb_version",
 ]
 
@@ -57,15 +60,30 @@ class CmbError(RuntimeError):
 
 
 def build_library(force: bool = False) -> str:
-    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
-    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "columba_amd.h"))
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
-        return LIB_PATH
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU): one object per translation unit
+    (the matcher; the b-move backend), linked into one shared library."""
+    csrc = os.path.join(_HERE, "csrc")
+    header = os.path.join(os.path.dirname(_HERE), "include", "columba_amd.h")
+    units = {"columba_amd.hip": [f for f in os.listdir(csrc) if not f.startswith("move_")],
+             "move_backend.hip": [f for f in os.listdir(csrc) if f.startswith("move_")]}
+    every = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [header]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in every):
+        return LIB_PATH  # (the objects are build scratch: only the library travels to the GPU box)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wno-unused-variable", "-o", LIB_PATH, _SRC]
-    subprocess.check_call(cmd)
+    objdir = os.path.join(_HERE, "_build")
+    os.makedirs(objdir, exist_ok=True)
+    objs, relink = [], force or not os.path.exists(LIB_PATH)
+    for unit, deps in units.items():
+        obj = os.path.join(objdir, unit.replace(".hip", ".o"))
+        srcs = [os.path.join(csrc, f) for f in deps] + [header]
+        if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(s) for s in srcs):
+            subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                                   "-Wno-unused-variable", "-c", "-o", obj, os.path.join(csrc, unit)])
+            relink = True
+        relink = relink or os.path.getmtime(obj) > os.path.getmtime(LIB_PATH)
+        objs.append(obj)
+    if relink:
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
     return LIB_PATH
 
 
@@ -77,6 +95,18 @@ class _IndexDesc(C.Structure):
         ("sa_bv", C.c_void_p), ("sa_bv_counts", C.c_void_p), ("sa_samples", C.c_void_p),
         ("n_samples", C.c_uint64), ("sa_sparseness", C.c_uint32), ("seq_starts", C.c_void_p),
         ("n_seqs", C.c_uint32), ("kmer_size", C.c_uint32), ("in_text_switch", C.c_uint32),
+    ]
+
+
+class _MoveDesc(C.Structure):
+    """cmb_move_desc (include/columba_amd.h)"""
+    _fields_ = [
+        ("lfbp", C.c_void_p), ("lfbp_bytes", C.c_uint64), ("rev_lfbp", C.c_void_p), ("rev_lfbp_bytes", C.c_uint64),
+        ("length_bits", C.c_uint32),
+        ("samples_first", C.c_void_p), ("samples_last", C.c_void_p), ("rev_samples_first", C.c_void_p),
+        ("rev_samples_last", C.c_void_p),
+        ("pred_first", C.c_void_p), ("first_to_run", C.c_void_p), ("pred_last", C.c_void_p), ("last_to_run", C.c_void_p),
+        ("plcp_pos", C.c_void_p), ("plcp_sum", C.c_void_p), ("n_plcp", C.c_uint64),
     ]
 
 
@@ -175,6 +205,16 @@ def lib():
         L.cmb_best_destroy.argtypes = [vp]
         L.cmb_batch_want_alignments.argtypes = [vp, i32]
         L.cmb_batch_alignments.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
+        L.cmb_move_create.argtypes = [C.POINTER(_MoveDesc), i32, C.POINTER(vp)]
+        L.cmb_move_destroy.argtypes = [vp]
+        L.cmb_move_device_bytes.restype = u64
+        L.cmb_move_device_bytes.argtypes = [vp]
+        L.cmb_move_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+        L.cmb_move_complete_range.argtypes = [vp, vp]
+        L.cmb_move_rows.argtypes = [vp, i32, u64, u64, vp]
+        L.cmb_move_extend_batch.argtypes = [vp, i32, vp, u64, vp, vp]
+        L.cmb_move_extend_bench.argtypes = [vp, i32, vp, u64, vp, vp, u32, C.POINTER(C.c_float)]
+        L.cmb_move_locate_batch.argtypes = [vp, vp, u64, vp, vp]
         _lib = L
     return _lib
 
@@ -576,3 +616,91 @@ def shard_bounds(n_reads: int, world_size: int, rank: int) -> Tuple[int, int]:
     per = (n_reads + world_size - 1) // world_size
     lo = min(n_reads, rank * per)
     return lo, min(n_reads, lo + per)
+
+
+# ---- b-move: the run-length compressed backend (first stage: index structures, extension, locate) ----------------------
+MOVE_RANGE_DTYPE = np.dtype([("begin", np.uint64), ("end", np.uint64), ("begin_run", np.uint64), ("end_run", np.uint64),
+                             ("rev_begin", np.uint64), ("rev_end", np.uint64), ("rev_begin_run", np.uint64),
+                             ("rev_end_run", np.uint64), ("toehold", np.uint64), ("original_depth", np.uint32),
+                             ("runs_valid", np.uint8), ("rev_runs_valid", np.uint8), ("toehold_represents_end", np.uint8),
+                             ("reserved", np.uint8)])
+assert MOVE_RANGE_DTYPE.itemsize == 80  # cmb_move_range
+
+
+def plcp_runs(plcp: np.ndarray):
+    """Run-length form of a PLCP array as cmb_move_desc takes it: the positions where PLCP[q] != PLCP[q - 1] - 1 (0 among
+    them) and PLCP[q] + q there."""
+    p = np.asarray(plcp).astype(np.int64)
+    brk = np.concatenate([[True], p[1:] != p[:-1] - 1])
+    pos = np.flatnonzero(brk).astype(np.uint64)
+    return pos, (p[brk] + np.flatnonzero(brk)).astype(np.uint64)
+
+
+class MoveIndex:
+    """Device-resident b-move index (cmb_move_index) over the arrays of columba_amd.movebuild.build_move, or any object
+    with the same members read from the reference's files."""
+
+    def __init__(self, mv, device: int = 0, with_locate: bool = True, length_bits: int = 64):
+        L = lib()
+        keep = [np.ascontiguousarray(a) for a in (mv.lfbp_fwd, mv.lfbp_rev)]
+        keep += [np.ascontiguousarray(a, dtype=np.uint64) for a in (mv.smpf, mv.smpl, mv.rev_smpf, mv.rev_smpl)]
+        d = _MoveDesc()
+        d.lfbp, d.lfbp_bytes, d.rev_lfbp, d.rev_lfbp_bytes = keep[0].ctypes.data, keep[0].nbytes, keep[1].ctypes.data, keep[1].nbytes
+        d.length_bits = length_bits
+        d.samples_first, d.samples_last, d.rev_samples_first, d.rev_samples_last = (a.ctypes.data for a in keep[2:6])
+        if with_locate:
+            pos, sm = plcp_runs(mv.plcp)
+            loc = [np.ascontiguousarray(a, dtype=np.uint64) for a in (mv.pred_first, mv.first_to_run, mv.pred_last, mv.last_to_run, pos, sm)]
+            keep += loc
+            d.pred_first, d.first_to_run, d.pred_last, d.last_to_run, d.plcp_pos, d.plcp_sum = (a.ctypes.data for a in loc)
+            d.n_plcp = pos.shape[0]
+        h = C.c_void_p()
+        _chk(L.cmb_move_create(C.byref(d), device, C.byref(h)))
+        self.h = h
+        n, r, rr = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _chk(L.cmb_move_info(self.h, C.byref(n), C.byref(r), C.byref(rr)))
+        self.n, self.runs, self.rev_runs = n.value, r.value, rr.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cmb_move_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_bytes(self) -> int:
+        return int(lib().cmb_move_device_bytes(self.h))
+
+    def complete_range(self) -> np.ndarray:
+        out = np.zeros(1, dtype=MOVE_RANGE_DTYPE)
+        _chk(lib().cmb_move_complete_range(self.h, _p(out)))
+        return out
+
+    def rows(self, rev: int) -> np.ndarray:
+        cnt = (self.rev_runs if rev else self.runs) + 1
+        out = np.zeros((cnt, 4), dtype=np.uint64)
+        _chk(lib().cmb_move_rows(self.h, rev, 0, cnt, _p(out)))
+        return out
+
+    def extend(self, mode: int, parents: np.ndarray):
+        """all four children of every parent: (n x 4 ranges, n x 4 ok flags)"""
+        parents = np.ascontiguousarray(parents, dtype=MOVE_RANGE_DTYPE)
+        n = parents.shape[0]
+        children = np.zeros((n, 4), dtype=MOVE_RANGE_DTYPE)
+        ok = np.zeros((n, 4), dtype=np.uint8)
+        _chk(lib().cmb_move_extend_batch(self.h, mode, _p(parents), n, _p(children), _p(ok)))
+        return children, ok
+
+    def locate(self, ranges: np.ndarray):
+        """(positions, offsets): range i holds positions[offsets[i]:offsets[i + 1]] in the reference's order"""
+        ranges = np.ascontiguousarray(ranges, dtype=MOVE_RANGE_DTYPE)
+        n = ranges.shape[0]
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(ranges["end"] - ranges["begin"], out=offs[1:])
+        pos = np.zeros(int(offs[-1]), dtype=np.uint64)
+        _chk(lib().cmb_move_locate_batch(self.h, _p(ranges), n, _p(offs), _p(pos)))
+        return pos, offs

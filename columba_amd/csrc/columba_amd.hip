@@ -19,6 +19,9 @@ static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+namespace cmb {
+int failWith(int code, const std::string& msg) { return fail(code, msg); } // for the library's other translation units
+}
 #define HIPCHK(expr)                                                                                  \
     do {                                                                                              \
         hipError_t _e = (expr);                                                                       \

@@ -52,7 +52,7 @@ def _bits(v: int) -> int:
     return int(math.ceil(math.log2(v)))  # moverepr.h:44-46
 
 
-def pack_lfbp(bwt: np.ndarray, cum: np.ndarray) -> np.ndarray:
+def pack_lfbp(bwt: np.ndarray, cum: np.ndarray, length_bits: int = 64) -> np.ndarray:
     """The bytes of a .LFBP file for BWT codes `bwt` (0..4) — buildindex.cpp:826-915 + moverepr.cpp:145-181."""
     n = int(bwt.shape[0])
     starts = np.flatnonzero(np.concatenate([[True], bwt[1:] != bwt[:-1]])).astype(np.uint64)
@@ -94,7 +94,7 @@ def pack_lfbp(bwt: np.ndarray, cum: np.ndarray) -> np.ndarray:
     place(b, bits_c + bits_n)
     place(d, bits_c + 2 * bits_n)
     rows = np.stack([lo, hi], axis=1).view(np.uint8).reshape(r + 1, 16)[:, :total_bytes]
-    header = np.array([n, r, zero_pos], dtype=np.uint64).view(np.uint8)
+    header = np.array([n, r, zero_pos], dtype=np.uint64 if length_bits == 64 else np.uint32).view(np.uint8)
     return np.concatenate([header, rows.reshape(-1)])
 
 

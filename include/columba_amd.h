@@ -315,6 +315,76 @@ int cmb_verify_batch_staged(cmb_index* idx, const char* pattern, uint32_t plen, 
                             uint64_t n, uint32_t max_ed, uint32_t min_ed, int fixed_start, cmb_occ* out,
                             uint64_t out_cap, uint64_t* n_out, uint64_t* counters);
 
+/* --- b-move: the run-length compressed backend ------------------------------------------
+ * First stage: the index structures in HBM and the two index operations of that backend as batch hooks — character
+ * extension with toehold maintenance (BMove::findRangesWithExtraChar{Forward,Backward,BackwardUniDirectional},
+ * src/bmove/bmove.cpp:328-478, over MoveLFReprBP, src/bmove/moverepr.cpp) and locate (BMove::collectTextPositions,
+ * bmove.cpp:500-560).  The search of cmb_match_batch does not run on this backend yet (CMB_ERR_UNSUPPORTED there).
+ * 64-bit positions throughout (the RUN_LENGTH_COMPRESSION flavour builds with 64-bit length_t, CMakeLists.txt:41-63);
+ * texts below 2^40 characters. */
+typedef struct cmb_move_index cmb_move_index;
+
+typedef struct {
+    /* contents of <base>.LFBP and <base>.rev.LFBP exactly as MoveLFReprBP::write leaves them (moverepr.cpp:145-168:
+     * textSize, nrOfRuns, zeroCharPos as length_t, then nrOfRuns + 1 bit-packed rows) */
+    const uint8_t* lfbp;
+    uint64_t lfbp_bytes;
+    const uint8_t* rev_lfbp;
+    uint64_t rev_lfbp_bytes;
+    uint32_t length_bits; /* width of length_t in those files: 64 (the flavour's default) or 32 */
+    /* suffix array samples at the run boundaries (buildindex.cpp:942-953; BMove::samplesFirst / samplesLast and the
+     * reverse pair, <base>.smpf / .smpl / .rev.smpf / .rev.smpl as plain 64-bit values), nrOfRuns each */
+    const uint64_t* samples_first;
+    const uint64_t* samples_last;
+    const uint64_t* rev_samples_first;
+    const uint64_t* rev_samples_last;
+    /* locate (all NULL: an index for extension only).  pred_first / pred_last: the marked positions of BMove::predFirst /
+     * predLast in increasing order (buildindex.cpp:990-1013), nrOfRuns each; first_to_run / last_to_run
+     * (buildindex.cpp:1044-1066).  The PLCP array (bmove/plcp.h) in run-length form: plcp_pos = the positions q, in
+     * increasing order and starting with 0, where PLCP[q] != PLCP[q - 1] - 1, and plcp_sum[j] = PLCP[q_j] + q_j;
+     * PLCP[i] = plcp_sum[j] - i for the last q_j <= i. */
+    const uint64_t* pred_first;
+    const uint64_t* first_to_run;
+    const uint64_t* pred_last;
+    const uint64_t* last_to_run;
+    const uint64_t* plcp_pos;
+    const uint64_t* plcp_sum;
+    uint64_t n_plcp;
+} cmb_move_desc;
+
+/* SARangePair of the RLC flavour (indexhelpers.h:137-255, :1040-1260): both ranges with their run indices, the toehold */
+typedef struct {
+    uint64_t begin, end, begin_run, end_run;                 /* range over the suffix array of the text; end_run inclusive */
+    uint64_t rev_begin, rev_end, rev_begin_run, rev_end_run; /* ... of the reversed text */
+    uint64_t toehold;                                        /* a text position of one occurrence */
+    uint32_t original_depth;
+    uint8_t runs_valid, rev_runs_valid; /* run indices exact (otherwise: enclosing, searched on use) */
+    uint8_t toehold_represents_end;
+    uint8_t reserved;
+} cmb_move_range;
+
+/* copies into HBM, converts the rows to the device layout and CHECKS the tables (order of the runs, LF targets,
+ * terminating row; increasing locate positions): CMB_ERR_INVALID for files that are not a consistent move table */
+int cmb_move_create(const cmb_move_desc* desc, int device, cmb_move_index** out);
+void cmb_move_destroy(cmb_move_index* idx);
+uint64_t cmb_move_device_bytes(const cmb_move_index* idx);
+int cmb_move_info(const cmb_move_index* idx, uint64_t* text_length, uint64_t* runs, uint64_t* rev_runs);
+/* BMove::getCompleteRange (bmove.h:369-373) */
+int cmb_move_complete_range(const cmb_move_index* idx, cmb_move_range* out);
+/* rows first .. first + count - 1 of a table as {head, inputStartPos, outputStartPos, outputStartRun} (4 x count values);
+ * row nrOfRuns is the terminating row */
+int cmb_move_rows(const cmb_move_index* idx, int rev, uint64_t first, uint64_t count, uint64_t* out);
+/* all four children (A, C, G, T) of n parents: children n x 4, ok n x 4.  mode 0 forward, 1 backward,
+ * 2 uni-directional backward (as cmb_extend_batch).  Host buffers. */
+int cmb_move_extend_batch(const cmb_move_index* idx, int mode, const cmb_move_range* parents, uint64_t n, cmb_move_range* children,
+                          uint8_t* ok);
+/* device-resident variant for the microbenchmark: average kernel time of `iters` launches (HIP events on the launch stream) */
+int cmb_move_extend_bench(const cmb_move_index* idx, int mode, const void* d_parents, uint64_t n, void* d_children, void* d_ok,
+                          uint32_t iters, float* avg_ms);
+/* text positions of n ranges in the reference's order (the toehold's occurrence, its phi chain, its phi^-1 chain):
+ * range i writes end - begin values at positions[offsets[i]]; offsets has n + 1 entries */
+int cmb_move_locate_batch(const cmb_move_index* idx, const cmb_move_range* ranges, uint64_t n, const uint64_t* offsets, uint64_t* positions);
+
 const char* cmb_last_error(void);
 const char* cmb_version(void);
 
