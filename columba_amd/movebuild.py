@@ -129,7 +129,7 @@ def _plcp(tc: np.ndarray, sa: np.ndarray) -> np.ndarray:
     return plcp
 
 
-def build_move(text, device: str | torch.device = "cpu") -> MoveArrays:
+def build_move(text, device: str | torch.device = "cpu", with_locate: bool = True) -> MoveArrays:
     t = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.asarray(text, dtype=np.uint8)
     if t.size == 0 or t[-1] != ord("$"):
         t = np.concatenate([t, np.array([ord("$")], dtype=np.uint8)])
@@ -160,4 +160,4 @@ def build_move(text, device: str | torch.device = "cpu") -> MoveArrays:
     pl, ltr = pred(smpl)
     return MoveArrays(n=n, lfbp_fwd=pack_lfbp(bwt, cum), lfbp_rev=pack_lfbp(rbwt, cum), smpf=smpf, smpl=smpl,
                       rev_smpf=rsmpf, rev_smpl=rsmpl, pred_first=pf, first_to_run=ftr, pred_last=pl, last_to_run=ltr,
-                      plcp=_plcp(tc, sa), sa=sa.astype(np.uint64), rev_sa=rsa.astype(np.uint64), text=t)
+                      plcp=_plcp(tc, sa) if with_locate else np.zeros(0, np.uint32), sa=sa.astype(np.uint64), rev_sa=rsa.astype(np.uint64), text=t)
