@@ -48,7 +48,7 @@ EXPORTS = [
     "cmb_read_prepare", "cmb_batch_sam", "cmb_batch_filter_per_strand", "cmb_match_best", "cmb_best_sizes", "cmb_best_results",
     "cmb_best_destroy",
     "cmb_move_create", "cmb_move_destroy", "cmb_move_device_bytes", "cmb_move_info", "cmb_move_complete_range", "cmb_move_rows",
-    "cmb_move_extend_batch", "cmb_move_extend_bench", "cmb_move_locate_batch",
+    "cmb_move_extend_batch", "cmb_move_extend_bench", "cmb_move_locate_batch", "cmb_move_match_exact",
     "cmb_last_error", "cmb_version",
 ]
 
@@ -215,6 +215,7 @@ def lib():
         L.cmb_move_extend_batch.argtypes = [vp, i32, vp, u64, vp, vp]
         L.cmb_move_extend_bench.argtypes = [vp, i32, vp, u64, vp, vp, u32, C.POINTER(C.c_float)]
         L.cmb_move_locate_batch.argtypes = [vp, vp, u64, vp, vp]
+        L.cmb_move_match_exact.argtypes = [vp, vp, vp, u64, vp, u64, vp, C.POINTER(u64), vp]
         _lib = L
     return _lib
 
@@ -625,6 +626,7 @@ MOVE_RANGE_DTYPE = np.dtype([("begin", np.uint64), ("end", np.uint64), ("begin_r
                              ("runs_valid", np.uint8), ("rev_runs_valid", np.uint8), ("toehold_represents_end", np.uint8),
                              ("reserved", np.uint8)])
 assert MOVE_RANGE_DTYPE.itemsize == 80  # cmb_move_range
+MOVE_OCC_DTYPE = np.dtype([("begin", np.uint64), ("end", np.uint64), ("distance", np.uint32), ("strand", np.uint32)])  # cmb_move_occ
 
 
 def plcp_runs(plcp: np.ndarray):
@@ -704,3 +706,21 @@ class MoveIndex:
         pos = np.zeros(int(offs[-1]), dtype=np.uint64)
         _chk(lib().cmb_move_locate_batch(self.h, _p(ranges), n, _p(offs), _p(pos)))
         return pos, offs
+
+    def match_exact(self, reads):
+        """k = 0 end to end: (occurrences, per-read offsets, counters); occurrences in the reference's order"""
+        buf = np.frombuffer(b"".join(reads), dtype=np.uint8).copy() if reads else np.zeros(0, np.uint8)
+        offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(r) for r in reads])
+        o = np.zeros(len(reads) + 1, dtype=np.uint64)
+        cnt = np.zeros(2, dtype=np.uint64)
+        n_occ = C.c_uint64()
+        cap = max(1024, 2 * len(reads))
+        while True:
+            occ = np.zeros(cap, dtype=MOVE_OCC_DTYPE)
+            rc = lib().cmb_move_match_exact(self.h, _p(buf), _p(offs), len(reads), _p(occ), cap, _p(o), C.byref(n_occ), _p(cnt))
+            if rc == CMB_ERR_OVERFLOW:
+                cap = int(n_occ.value)
+                continue
+            _chk(rc)
+            return occ[:n_occ.value], o, {"NODE_COUNTER": int(cnt[0]), "TOTAL_REPORTED_POSITIONS": int(cnt[1])}

@@ -3,6 +3,8 @@
 #include "../../include/columba_amd.h"
 #include "move_dev.hpp"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -330,7 +332,7 @@ extern "C" int cmb_move_locate_batch(const cmb_move_index* idx, const cmb_move_r
         dpos.alloc(total);
         bad.alloc(1);
         MV_HIPCHK(hipMemset(bad.p, 0, sizeof(uint32_t)));
-        if (n) hipLaunchKernelGGL(k_move_locate, dim3(gridFor(n)), dim3(256), 0, 0, idx->d, din.p, n, doff.p, dpos.p - offsets[0], bad.p);
+        if (n) hipLaunchKernelGGL(k_move_locate, dim3(gridFor(n)), dim3(256), 0, 0, idx->d, din.p, n, doff.p, dpos.p - offsets[0], bad.p, false);
         MV_HIPCHK(hipGetLastError());
         uint32_t hb = 0;
         MV_HIPCHK(hipMemcpy(&hb, bad.p, sizeof(hb), hipMemcpyDeviceToHost));
@@ -338,6 +340,74 @@ extern "C" int cmb_move_locate_batch(const cmb_move_index* idx, const cmb_move_r
             return failWith(CMB_ERR_INVALID, std::to_string(hb) + " of the ranges do not belong to this index (toehold, depth and width "
                                                                   "do not describe one suffix array interval)");
         if (total) MV_HIPCHK(hipMemcpy(positions + offsets[0], dpos.p, total * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return failWith(CMB_ERR_DEVICE, e.what());
+    }
+}
+
+// k = 0 on the b-move index (SearchStrategy::matchApproxAllMap with maxED = 0, searchstrategy.cpp:499-510)
+extern "C" int cmb_move_match_exact(const cmb_move_index* idx, const char* reads, const uint64_t* read_offsets, uint64_t n_reads,
+                                    cmb_move_occ* occ_out, uint64_t occ_cap, uint64_t* occ_offsets, uint64_t* n_occ, uint64_t* counters) {
+    if (!idx || !read_offsets || !n_occ || (n_reads && !reads) || (occ_cap && !occ_out)) return failWith(CMB_ERR_INVALID, "bad argument");
+    if (!idx->hasLocate) return failWith(CMB_ERR_INVALID, "this index was created without the locate arrays");
+    static_assert(sizeof(cmb_move_occ) == sizeof(MoveOccRec), "cmb_move_occ layout");
+    if (n_reads >= (1ull << 30)) return failWith(CMB_ERR_UNSUPPORTED, "2^30 reads and more per call");
+    for (uint64_t i = 0; i < n_reads; i++)
+        if (read_offsets[i + 1] < read_offsets[i]) return failWith(CMB_ERR_INVALID, "read offsets must not decrease");
+    try {
+        MV_HIPCHK(hipSetDevice(idx->device));
+        const uint64_t nTasks = 2 * n_reads, nChars = read_offsets[n_reads] - read_offsets[0];
+        MvBuf<uint8_t> dReads;
+        MvBuf<uint64_t> dOff, dWidth, dTaskOff, dPos, dReadOcc;
+        MvBuf<MoveRangeRec> dRanges;
+        MvBuf<unsigned long long> dNodes;
+        MvBuf<uint32_t> bad;
+        dReads.upload((const uint8_t*)reads + read_offsets[0], nChars);
+        std::vector<uint64_t> off(read_offsets, read_offsets + n_reads + 1);
+        for (auto& o : off) o -= read_offsets[0];
+        dOff.upload(off.data(), n_reads + 1);
+        dWidth.alloc(nTasks + 1);
+        dTaskOff.alloc(nTasks + 1);
+        dRanges.alloc(nTasks);
+        dNodes.alloc(1);
+        bad.alloc(1);
+        MV_HIPCHK(hipMemset(dNodes.p, 0, sizeof(unsigned long long)));
+        MV_HIPCHK(hipMemset(bad.p, 0, sizeof(uint32_t)));
+        MV_HIPCHK(hipMemset(dWidth.p, 0, (nTasks + 1) * sizeof(uint64_t)));
+        if (nTasks) hipLaunchKernelGGL(k_move_exact, dim3(gridFor(nTasks)), dim3(256), 0, 0, idx->d, dReads.p, dOff.p, nTasks, dRanges.p, dWidth.p, dNodes.p);
+        MV_HIPCHK(hipGetLastError());
+        // offsets of the tasks' occurrences: exclusive prefix sum over nTasks + 1 widths (the last one is zero)
+        size_t tmpBytes = 0;
+        MV_HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, dWidth.p, dTaskOff.p, (int)(nTasks + 1)));
+        MvBuf<uint8_t> tmp;
+        tmp.alloc(tmpBytes);
+        MV_HIPCHK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmpBytes, dWidth.p, dTaskOff.p, (int)(nTasks + 1)));
+        uint64_t total = 0;
+        MV_HIPCHK(hipMemcpy(&total, dTaskOff.p + nTasks, sizeof(total), hipMemcpyDeviceToHost));
+        unsigned long long nodes = 0;
+        MV_HIPCHK(hipMemcpy(&nodes, dNodes.p, sizeof(nodes), hipMemcpyDeviceToHost));
+        *n_occ = total;
+        if (counters) counters[0] = nodes, counters[1] = total;
+        if (occ_offsets) {
+            dReadOcc.alloc(n_reads + 1);
+            hipLaunchKernelGGL(k_move_read_offsets, dim3(gridFor(n_reads + 1)), dim3(256), 0, 0, dTaskOff.p, n_reads, dReadOcc.p);
+            MV_HIPCHK(hipMemcpy(occ_offsets, dReadOcc.p, (n_reads + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        }
+        if (total > occ_cap)
+            return failWith(CMB_ERR_OVERFLOW, std::to_string(total) + " occurrences, room for " + std::to_string(occ_cap) + " (n_occ holds the number needed)");
+        if (total) {
+            dPos.alloc(total);
+            MvBuf<MoveOccRec> dOcc;
+            dOcc.alloc(total);
+            hipLaunchKernelGGL(k_move_locate, dim3(gridFor(nTasks)), dim3(256), 0, 0, idx->d, dRanges.p, nTasks, dTaskOff.p, dPos.p, bad.p, true);
+            hipLaunchKernelGGL(k_move_occ, dim3(gridFor(total)), dim3(256), 0, 0, dPos.p, dTaskOff.p, nTasks, total, dOff.p, dOcc.p);
+            MV_HIPCHK(hipGetLastError());
+            uint32_t hb = 0;
+            MV_HIPCHK(hipMemcpy(&hb, bad.p, sizeof(hb), hipMemcpyDeviceToHost));
+            if (hb) return failWith(CMB_ERR_INTERNAL, std::to_string(hb) + " ranges whose phi chains do not have the width of the range (inconsistent locate arrays)");
+            MV_HIPCHK(hipMemcpy(occ_out, dOcc.p, total * sizeof(MoveOccRec), hipMemcpyDeviceToHost));
+        }
         return CMB_OK;
     } catch (const std::exception& e) {
         return failWith(CMB_ERR_DEVICE, e.what());

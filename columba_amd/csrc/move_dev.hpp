@@ -375,11 +375,12 @@ __global__ void k_move_extend(const MoveDev ix, const int mode, const MoveRangeR
 // the toehold's position, its phi chain while PLCP >= depth, then the phi^-1 chain).  A range of width w writes w
 // positions at out[offsets[i]]; bad[0] counts ranges whose chain does not have exactly that length.
 __global__ void k_move_locate(const MoveDev ix, const MoveRangeRec* __restrict__ ranges, uint64_t n, const uint64_t* __restrict__ offsets,
-                              uint64_t* __restrict__ out, uint32_t* __restrict__ bad) {
+                              uint64_t* __restrict__ out, uint32_t* __restrict__ bad, const bool skipEmpty) {
     const uint64_t stop = ix.fwd.samplesLast[ix.fwd.runs - 1]; // getInitialToehold() + 1 (bmove.h:139-142)
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const MoveRangeRec q = ranges[i];
         const uint64_t width = q.end - q.begin, depth = q.depth;
+        if (skipEmpty && width == 0) continue;
         uint64_t* o = out + offsets[i];
         const uint64_t firstPos = q.toehold - (q.repEnd ? depth - 1 : 0); // bmove.cpp:553-556
         if (depth == 0 || width == 0 || firstPos >= ix.n) {
@@ -410,6 +411,104 @@ __global__ void k_move_locate(const MoveDev ix, const MoveRangeRec* __restrict__
         }
         if (!exact || cnt != width) atomicAdd(&bad[0], 1u);
     }
+}
+
+
+// MoveLFReprBP::findLF on a row that is already in registers
+__device__ inline void moveLFRow(const MoveTable& t, const uint4 rowWord, uint64_t& pos, uint64_t& run) {
+    const MoveRow r = unpackMoveRow(rowWord);
+    pos = r.out + (pos - r.in);
+    run = r.outRun;
+    while (rowIn(t.rows[run + 1]) <= pos) run++;
+}
+
+// One range with its toehold extended by one character: BMove::findRangeWithExtraCharBackward (bmove.cpp:299-326) over
+// MoveLFReprBP::addChar (moverepr.cpp:309-327).  The range's run indices are exact on entry and on exit; the toehold never
+// represents the end on this path.  Returns false (range untouched) if the character does not occur in the range.
+__device__ inline bool moveExtendOne(const MoveTable& t, const uint32_t c, MvRange& r, uint64_t& toehold) {
+    uint64_t run1 = r.beginRun, pos1 = r.begin;
+    uint4 row1 = t.rows[run1];
+    while (rowHead(row1) != c) { // walkToNextRun
+        if (run1 == r.endRun) return false;
+        run1++;
+        row1 = t.rows[run1];
+        pos1 = rowIn(row1);
+    }
+    uint64_t run2 = r.endRun, pos2 = r.end - 1;
+    uint4 row2 = t.rows[run2];
+    while (rowHead(row2) != c) { // walkToPreviousRun: ends at run1 at the latest
+        pos2 = rowIn(row2) - 1;
+        run2--;
+        row2 = t.rows[run2];
+    }
+    const uint64_t parentWidth = r.end - r.begin, lastRun = run2, endRun = r.endRun;
+    moveLFRow(t, row1, pos1, run1);
+    moveLFRow(t, row2, pos2, run2);
+    if (pos2 + 1 - pos1 == parentWidth) toehold -= 1; // toehold - !toeholdRepresentsEnd
+    else toehold = (lastRun == endRun ? t.samplesFirst[endRun] : t.samplesLast[lastRun]) - 1; // computeToehold (bmove.cpp:222-243)
+    r.begin = pos1, r.end = pos2 + 1, r.beginRun = run1, r.endRun = run2;
+    return true;
+}
+
+// character codes of a read as Read / ReadBundle clean it (reads.h:43-58): upper case, anything outside ACGT is N (0 here)
+__device__ inline uint32_t readCode(uint8_t ch) {
+    ch &= 0xDF; // upper case
+    return ch == 'A' ? 1u : ch == 'C' ? 2u : ch == 'G' ? 3u : ch == 'T' ? 4u : 0u;
+}
+
+// k = 0 on the b-move index: IndexInterface::exactMatchesOutput (indexinterface.cpp:947-1014, RLC branch) of every read
+// (task 2 i) and of its reverse complement (task 2 i + 1): the range of the whole string by backward extension, with its
+// toehold.  widths[task] = number of occurrences; nodes = NODE_COUNTER.
+__global__ void k_move_exact(const MoveDev ix, const uint8_t* __restrict__ reads, const uint64_t* __restrict__ readOff, uint64_t nTasks,
+                             MoveRangeRec* __restrict__ ranges, uint64_t* __restrict__ widths, unsigned long long* __restrict__ nodes) {
+    unsigned long long myNodes = 0;
+    for (uint64_t task = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; task < nTasks; task += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t rd = task >> 1, b = readOff[rd], len = readOff[rd + 1] - b;
+        const bool rc = task & 1;
+        MvRange r = {0, ix.n, 0, ix.fwd.runs - 1, true}; // getCompleteRange (bmove.h:369-373)
+        uint64_t toehold = ix.fwd.samplesLast[ix.fwd.runs - 1] - 1;
+        bool alive = len > 0;
+        for (uint64_t step = 0; alive && step < len; step++) {
+            // the string is matched from its last character to its first; the reverse complement's character len-1-step
+            // is the complement of the read's character `step` (nucleotide.h:250)
+            uint32_t c = readCode(reads[b + (rc ? step : len - 1 - step)]);
+            if (rc && c) c = 5 - c;
+            alive = c != 0 && moveExtendOne(ix.fwd, c, r, toehold);
+            myNodes += alive;
+        }
+        MvPair p;
+        p.sa = alive ? r : MvRange{0, 0, 0, 0, false};
+        p.rev = MvRange{0, 0, 0, 0, true};
+        p.toehold = alive ? toehold : 0, p.repEnd = false, p.depth = alive ? (uint32_t)len : 0;
+        ranges[task] = storePair(p);
+        widths[task] = alive ? r.end - r.begin : 0;
+    }
+    for (int o = 32; o; o >>= 1) myNodes += __shfl_down(myNodes, o);
+    if ((threadIdx.x & 63) == 0 && myNodes) atomicAdd(nodes, myNodes);
+}
+
+struct MoveOccRec { // cmb_move_occ
+    uint64_t begin, end;
+    uint32_t distance, strand;
+};
+static_assert(sizeof(MoveOccRec) == 24, "record layout");
+
+// positions of the located tasks -> occurrence records {begin, begin + read length, 0, strand}; one lane per occurrence
+__global__ void k_move_occ(const uint64_t* __restrict__ positions, const uint64_t* __restrict__ taskOff, uint64_t nTasks, uint64_t total,
+                           const uint64_t* __restrict__ readOff, MoveOccRec* __restrict__ out) {
+    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < total; j += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t lo = 0, hi = nTasks; // the last task whose offset is <= j
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (taskOff[mid] <= j) lo = mid;
+            else hi = mid;
+        }
+        const uint64_t rd = lo >> 1, len = readOff[rd + 1] - readOff[rd];
+        out[j] = MoveOccRec{positions[j], positions[j] + len, 0u, (uint32_t)(lo & 1)};
+    }
+}
+__global__ void k_move_read_offsets(const uint64_t* __restrict__ taskOff, uint64_t nReads, uint64_t* __restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= nReads; i += (uint64_t)gridDim.x * blockDim.x) out[i] = taskOff[2 * i];
 }
 
 } // namespace cmb

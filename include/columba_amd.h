@@ -385,6 +385,21 @@ int cmb_move_extend_bench(const cmb_move_index* idx, int mode, const void* d_par
  * range i writes end - begin values at positions[offsets[i]]; offsets has n + 1 entries */
 int cmb_move_locate_batch(const cmb_move_index* idx, const cmb_move_range* ranges, uint64_t n, const uint64_t* offsets, uint64_t* positions);
 
+/* k = 0 on the b-move index, end to end: SearchStrategy::matchApproxAllMap with maxED = 0 (searchstrategy.cpp:499-510) =
+ * IndexInterface::exactMatchesOutput (indexinterface.cpp:947-1014, RLC branch) of every read and of its reverse complement.
+ * Reads as for cmb_match_batch (characters + n_reads + 1 offsets; lower case accepted, a read with anything outside ACGT
+ * has no exact occurrence).  Per read the occurrences of the forward strand, then those of the reverse complement, each in
+ * the order of BMove::collectTextPositions — the reference's order before its output stage sorts.  occ_offsets (n_reads + 1,
+ * may be NULL); counters (may be NULL): [0] NODE_COUNTER, [1] TOTAL_REPORTED_POSITIONS.  CMB_ERR_OVERFLOW with *n_occ =
+ * the number needed if occ_cap is too small (nothing is truncated). */
+typedef struct {
+    uint64_t begin, end; /* text coordinates, end exclusive */
+    uint32_t distance;   /* 0 */
+    uint32_t strand;     /* 0 forward, 1 reverse complement */
+} cmb_move_occ;
+int cmb_move_match_exact(const cmb_move_index* idx, const char* reads, const uint64_t* read_offsets, uint64_t n_reads,
+                         cmb_move_occ* occ_out, uint64_t occ_cap, uint64_t* occ_offsets, uint64_t* n_occ, uint64_t* counters);
+
 const char* cmb_last_error(void);
 const char* cmb_version(void);
 

@@ -552,4 +552,44 @@ uint64_t orc_move_locate(void* h, const orc_move_range* r, uint64_t* out, uint64
     return pos.size();
 }
 
+// k = 0 on the b-move index: matchApproxAllMap with maxED = 0 (searchstrategy.cpp:499-510): exactMatchesOutput of the read
+// (forward strand) and of its reverse complement.  occ: {begin, end, distance = 0, strand} as 4 x uint64 per occurrence, in
+// the reference's order; offsets: n + 1.  counters[0] NODE_COUNTER, counters[1] TOTAL_REPORTED_POSITIONS.  Returns the
+// number of occurrences (those beyond cap are not stored).
+uint64_t orc_move_match_exact(void* h, const char* reads, const uint64_t* readOffsets, uint64_t n, uint64_t* occ, uint64_t cap,
+                              uint64_t* offsets, uint64_t* counters) {
+    auto* ix = (orc::BMoveIndex64*)h;
+    uint64_t total = 0, nodes = 0;
+    auto code = [](char c) { // reads.h:43-58 (upper case; everything outside ACGT becomes N), alphabet.h c2i
+        switch (c) {
+        case 'A': case 'a': return 1;
+        case 'C': case 'c': return 2;
+        case 'G': case 'g': return 3;
+        case 'T': case 't': return 4;
+        default: return -1;
+        }
+    };
+    for (uint64_t i = 0; i < n; i++) {
+        offsets[i] = total;
+        const uint64_t len = readOffsets[i + 1] - readOffsets[i];
+        std::vector<int> fw(len), rc(len);
+        for (uint64_t j = 0; j < len; j++) {
+            fw[j] = code(reads[readOffsets[i] + j]);
+            rc[len - 1 - j] = fw[j] < 0 ? -1 : 5 - fw[j]; // nucleotide.h:250 (reverse complement; N stays N)
+        }
+        for (int strand = 0; strand < 2; strand++) {
+            std::vector<uint64_t> pos;
+            ix->exactMatches(strand ? rc : fw, pos, nodes);
+            for (uint64_t p : pos) {
+                if (total < cap) occ[4 * total] = p, occ[4 * total + 1] = p + len, occ[4 * total + 2] = 0, occ[4 * total + 3] = strand;
+                total++;
+            }
+        }
+    }
+    offsets[n] = total;
+    counters[0] = nodes;
+    counters[1] = total;
+    return total;
+}
+
 } // extern "C"

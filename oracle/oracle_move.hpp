@@ -379,6 +379,42 @@ template <typename L> class BMoveIndexT {
         child = MovePair(range1, MoveRange(), newToehold, false, parent.originalDepth + 1);
         return true;
     }
+    // bmove.cpp:299-326 (findRangeWithExtraCharBackward: one range with its toehold)
+    bool extendRangeBackward(L c, MoveRange& range, L& toehold, bool& repEnd, L& depth) const {
+        MoveRange range1, trivial = range;
+        if (!trivial.runIndicesValid) move.computeRunIndices(trivial);
+        move.addChar(trivial, range1, c, &counters.rowSteps);
+        if (range1.empty()) {
+            range = range1;
+            toehold = 0, repEnd = false, depth = 0;
+            return false;
+        }
+        if (trivial.width() == range1.width()) {
+            toehold = toehold - !repEnd;
+        } else {
+            toehold = computeToeholdOn(move, samplesFirst, samplesLast, trivial, c);
+            repEnd = false;
+        }
+        range = range1;
+        depth = depth + 1;
+        return true;
+    }
+    // indexinterface.cpp:947-1014 (exactMatchesOutput, RUN_LENGTH_COMPRESSION branch): begin positions of the exact
+    // occurrences of s (codes 1..4; anything else: not in the alphabet -> no occurrence), in the order of
+    // collectTextPositions; nodes = NODE_COUNTER increments
+    void exactMatches(const std::vector<int>& s, std::vector<L>& positions, uint64_t& nodes) const {
+        if (s.empty()) return;
+        const MovePair all = getCompleteRange();
+        MoveRange range = all.sa;
+        L toehold = all.toehold, depth = all.originalDepth;
+        bool repEnd = all.toeholdRepresentsEnd;
+        for (size_t i = s.size(); i-- > 0;) {
+            if (s[i] < 1 || s[i] > 4 || !extendRangeBackward((L)s[i], range, toehold, repEnd, depth)) return;
+            nodes++;
+        }
+        MovePair p(range, MoveRange(), toehold, repEnd, depth);
+        locate(p, positions); // getBeginPositions (bmove.cpp:562-575)
+    }
     bool extend(int mode, L c, const MovePair& parent, MovePair& child) const {
         return mode == 0 ? extendForward(c, parent, child) : mode == 1 ? extendBackward(c, parent, child) : extendBackwardUni(c, parent, child);
     }

@@ -104,6 +104,8 @@ def lib():
         L.orc_move_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_move_extend.restype = C.c_uint64
         L.orc_move_extend.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_move_match_exact.restype = C.c_uint64
+        L.orc_move_match_exact.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.orc_move_locate.restype = C.c_uint64
         L.orc_move_locate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         _lib = L
@@ -388,3 +390,17 @@ class OracleMoveIndex:
         out = np.zeros(cap, dtype=np.uint64)
         cnt = lib().orc_move_locate(self.h, _p(rng), _p(out), cap)
         return out[:min(cnt, cap)]
+
+    def match_exact(self, reads: Sequence[bytes]):
+        """(occurrences n x {begin, end, distance, strand}, offsets, counters) in the reference's order"""
+        buf, offs = pack_reads(reads)
+        offs = offs.astype(np.uint64)
+        o = np.zeros(len(reads) + 1, dtype=np.uint64)
+        cnt = np.zeros(2, dtype=np.uint64)
+        cap = 1 << 16
+        while True:
+            occ = np.zeros((cap, 4), dtype=np.uint64)
+            tot = lib().orc_move_match_exact(self.h, buf.tobytes(), _p(offs), len(reads), _p(occ), cap, _p(o), _p(cnt))
+            if tot <= cap:
+                return occ[:tot], o, {"NODE_COUNTER": int(cnt[0]), "TOTAL_REPORTED_POSITIONS": int(cnt[1])}
+            cap = int(tot)

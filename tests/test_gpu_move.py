@@ -186,3 +186,44 @@ def test_malformed_tables_and_ranges_are_refused(mworld):
     with pytest.raises(ca.CmbError):
         d2.locate(ch[0, 1:2])
     d2.close()
+
+
+def test_exact_matching_end_to_end(mworld):
+    """k = 0 on the b-move index: reads in, occurrences out — the oracle's order (forward strand, then reverse complement,
+    each as collectTextPositions walks), its counters, and a naive scan of the text"""
+    dev, orc, mv, rng = mworld["dev"], mworld["orc"], mworld["mv"], mworld["rng"]
+    t = mv.text.tobytes()
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads = [b"", b"A", b"N", b"ACGTN", b"a" * 20, b"AC" * 30]
+    for i in range(3000):
+        L = int(rng.choice([1, 2, 5, 12, 20, 36, 100, 150, 250]))
+        p0 = int(rng.integers(0, len(t) - 1 - L))
+        r = bytearray(t[p0:p0 + L])
+        u = rng.random()
+        if u < 0.15:
+            r[int(rng.integers(0, L))] = b"ACGT"[int(rng.integers(0, 4))]
+        elif u < 0.2:
+            r[int(rng.integers(0, L))] = ord("N")
+        elif u < 0.5:
+            r = bytearray(bytes(r).translate(comp)[::-1])
+        elif u < 0.55:
+            r = bytearray(bytes(r).lower())
+        reads.append(bytes(r))
+    d_occ, d_off, d_cnt = dev.match_exact(reads)
+    o_occ, o_off, o_cnt = orc.match_exact(reads)
+    assert np.array_equal(d_off, o_off) and d_cnt == o_cnt
+    for j, f in enumerate(("begin", "end", "distance", "strand")):
+        assert np.array_equal(d_occ[f].astype(np.uint64), o_occ[:, j]), f
+    assert d_occ.shape[0] > 20_000 and (d_occ["strand"] == 1).sum() > 3000
+    # naive scan for a slice of the reads
+    for i in range(6, 300, 5):
+        ru = reads[i].upper()
+        want = []
+        if b"N" not in ru:
+            for strand, pat in ((0, ru), (1, ru.translate(comp)[::-1])):
+                k = t.find(pat)
+                while k >= 0:
+                    want.append((k, k + len(pat), strand))
+                    k = t.find(pat, k + 1)
+        got = [(int(o["begin"]), int(o["end"]), int(o["strand"])) for o in d_occ[int(d_off[i]):int(d_off[i + 1])]]
+        assert sorted(got) == sorted(want), i

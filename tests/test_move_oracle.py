@@ -154,3 +154,47 @@ def test_run_indices_are_exact(small_world):
                         nxt.append(child)
         frontier = nxt[:150]
     assert seen > 500
+
+
+def test_exact_matching_against_naive_search(small_world):
+    """exactMatchesOutput of the RLC flavour (both strands) = every occurrence a naive scan of the text finds"""
+    w = small_world
+    orc, t, rng = w["orc"], w["t"], w["rng"]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads = []
+    for _ in range(150):
+        L = int(rng.integers(1, 60))
+        p0 = int(rng.integers(0, len(t) - 1 - L))
+        r = bytearray(t[p0:p0 + L])
+        u = rng.random()
+        if u < 0.2:
+            r[int(rng.integers(0, L))] = b"ACGT"[int(rng.integers(0, 4))]
+        elif u < 0.3:
+            r[int(rng.integers(0, L))] = ord("N")
+        elif u < 0.5:
+            r = bytearray(bytes(r).translate(comp)[::-1])
+        elif u < 0.55:
+            r = bytearray(bytes(r).lower())
+        reads.append(bytes(r))
+    occ, offs, cnt = orc.match_exact(reads)
+    assert offs[-1] == occ.shape[0] == cnt["TOTAL_REPORTED_POSITIONS"]
+
+    def find_all(pat):
+        out, i = [], t.find(pat)
+        while i >= 0:
+            out.append(i)
+            i = t.find(pat, i + 1)
+        return out
+
+    hits = 0
+    for i, r in enumerate(reads):
+        ru = r.upper()
+        want = []
+        if b"N" not in ru:
+            want = [(p, p + len(ru), 0, 0) for p in find_all(ru)] + [(p, p + len(ru), 0, 1) for p in find_all(ru.translate(comp)[::-1])]
+        got = [tuple(int(v) for v in row) for row in occ[int(offs[i]):int(offs[i + 1])]]
+        assert sorted(got) == sorted(want), (i, r)
+        # forward strand first (searchstrategy.cpp:499-510)
+        assert [g[3] for g in got] == sorted(g[3] for g in got)
+        hits += len(got) > 0
+    assert hits > 80 and cnt["NODE_COUNTER"] > 1000
