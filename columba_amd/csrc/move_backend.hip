@@ -346,6 +346,14 @@ extern "C" int cmb_move_locate_batch(const cmb_move_index* idx, const cmb_move_r
     }
 }
 
+static thread_local float g_exactMs[3] = {0, 0, 0};
+// device time of the calling thread's last cmb_move_match_exact: [0] k_move_exact, [1] prefix sum, [2] k_move_locate + k_move_occ
+extern "C" int cmb_move_last_timings(float* ms, uint32_t n) {
+    if (!ms) return failWith(CMB_ERR_INVALID, "bad argument");
+    for (uint32_t i = 0; i < n && i < 3; i++) ms[i] = g_exactMs[i];
+    return CMB_OK;
+}
+
 // k = 0 on the b-move index (SearchStrategy::matchApproxAllMap with maxED = 0, searchstrategy.cpp:499-510)
 extern "C" int cmb_move_match_exact(const cmb_move_index* idx, const char* reads, const uint64_t* read_offsets, uint64_t n_reads,
                                     cmb_move_occ* occ_out, uint64_t occ_cap, uint64_t* occ_offsets, uint64_t* n_occ, uint64_t* counters) {
@@ -375,16 +383,30 @@ extern "C" int cmb_move_match_exact(const cmb_move_index* idx, const char* reads
         MV_HIPCHK(hipMemset(dNodes.p, 0, sizeof(unsigned long long)));
         MV_HIPCHK(hipMemset(bad.p, 0, sizeof(uint32_t)));
         MV_HIPCHK(hipMemset(dWidth.p, 0, (nTasks + 1) * sizeof(uint64_t)));
+        hipEvent_t ev[4];
+        for (auto& e : ev) MV_HIPCHK(hipEventCreate(&e));
+        struct EvGuard {
+            hipEvent_t* e;
+            ~EvGuard() {
+                for (int i = 0; i < 4; i++) (void)hipEventDestroy(e[i]);
+            }
+        } evGuard{ev};
+        g_exactMs[0] = g_exactMs[1] = g_exactMs[2] = 0;
+        MV_HIPCHK(hipEventRecord(ev[0], 0));
         if (nTasks) hipLaunchKernelGGL(k_move_exact, dim3(gridFor(nTasks)), dim3(256), 0, 0, idx->d, dReads.p, dOff.p, nTasks, dRanges.p, dWidth.p, dNodes.p);
         MV_HIPCHK(hipGetLastError());
+        MV_HIPCHK(hipEventRecord(ev[1], 0));
         // offsets of the tasks' occurrences: exclusive prefix sum over nTasks + 1 widths (the last one is zero)
         size_t tmpBytes = 0;
         MV_HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, dWidth.p, dTaskOff.p, (int)(nTasks + 1)));
         MvBuf<uint8_t> tmp;
         tmp.alloc(tmpBytes);
         MV_HIPCHK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmpBytes, dWidth.p, dTaskOff.p, (int)(nTasks + 1)));
+        MV_HIPCHK(hipEventRecord(ev[2], 0));
         uint64_t total = 0;
         MV_HIPCHK(hipMemcpy(&total, dTaskOff.p + nTasks, sizeof(total), hipMemcpyDeviceToHost));
+        MV_HIPCHK(hipEventElapsedTime(&g_exactMs[0], ev[0], ev[1]));
+        MV_HIPCHK(hipEventElapsedTime(&g_exactMs[1], ev[1], ev[2]));
         unsigned long long nodes = 0;
         MV_HIPCHK(hipMemcpy(&nodes, dNodes.p, sizeof(nodes), hipMemcpyDeviceToHost));
         *n_occ = total;
@@ -400,9 +422,13 @@ extern "C" int cmb_move_match_exact(const cmb_move_index* idx, const char* reads
             dPos.alloc(total);
             MvBuf<MoveOccRec> dOcc;
             dOcc.alloc(total);
+            MV_HIPCHK(hipEventRecord(ev[2], 0));
             hipLaunchKernelGGL(k_move_locate, dim3(gridFor(nTasks)), dim3(256), 0, 0, idx->d, dRanges.p, nTasks, dTaskOff.p, dPos.p, bad.p, true);
             hipLaunchKernelGGL(k_move_occ, dim3(gridFor(total)), dim3(256), 0, 0, dPos.p, dTaskOff.p, nTasks, total, dOff.p, dOcc.p);
             MV_HIPCHK(hipGetLastError());
+            MV_HIPCHK(hipEventRecord(ev[3], 0));
+            MV_HIPCHK(hipEventSynchronize(ev[3]));
+            MV_HIPCHK(hipEventElapsedTime(&g_exactMs[2], ev[2], ev[3]));
             uint32_t hb = 0;
             MV_HIPCHK(hipMemcpy(&hb, bad.p, sizeof(hb), hipMemcpyDeviceToHost));
             if (hb) return failWith(CMB_ERR_INTERNAL, std::to_string(hb) + " ranges whose phi chains do not have the width of the range (inconsistent locate arrays)");

@@ -399,6 +399,9 @@ typedef struct {
 } cmb_move_occ;
 int cmb_move_match_exact(const cmb_move_index* idx, const char* reads, const uint64_t* read_offsets, uint64_t n_reads,
                          cmb_move_occ* occ_out, uint64_t occ_cap, uint64_t* occ_offsets, uint64_t* n_occ, uint64_t* counters);
+/* device time (ms, HIP events) of the calling thread's last cmb_move_match_exact: [0] the backward extension of all reads,
+ * [1] the prefix sum of the widths, [2] locate + occurrence records */
+int cmb_move_last_timings(float* ms, uint32_t n);
 
 const char* cmb_last_error(void);
 const char* cmb_version(void);

@@ -25,6 +25,28 @@ import columba_amd as ca  # noqa: E402
 from columba_amd import movebuild  # noqa: E402
 
 
+def plcp_gpu(text, mv):
+    """PLCP values of a (repetitive) text on the GPU: PLCP[SA[i]] = LCP of the suffixes SA[i - 1] and SA[i], found by doubling
+    comparisons of 8-byte words (the harness' stand-in for the reference's Kasai loop, bmove/plcp.h:56-80)."""
+    n = mv.n
+    t = torch.from_numpy(np.concatenate([mv.text, np.zeros(16, np.uint8)])).cuda()
+    sa = torch.from_numpy(mv.sa.astype(np.int64)).cuda()
+    cur, prv = sa[1:], sa[:-1]
+    lcp = torch.zeros(n - 1, dtype=torch.int64, device="cuda")
+    active = torch.arange(n - 1, device="cuda")
+    while active.numel():
+        a = (cur[active] + lcp[active]).clamp_(max=n)
+        b = (prv[active] + lcp[active]).clamp_(max=n + 1)
+        eq = t[a] == t[b]
+        eq &= (a < n) & (b < n)
+        idx = active[eq]
+        lcp[idx] += 1
+        active = idx
+    out = torch.zeros(n, dtype=torch.int64, device="cuda")
+    out[cur] = lcp
+    return out.cpu().numpy().astype(np.uint32)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--base-mbp", type=float, default=2.0)
@@ -34,6 +56,7 @@ def main():
     ap.add_argument("--check", type=int, default=100_000)
     ap.add_argument("--cpu-sample", type=int, default=200_000)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads of the exact-matching leg (250 bp, BASELINE config 5's length)")
     args = ap.parse_args()
     rng = np.random.default_rng(1)
     base_len = int(args.base_mbp * 1e6)
@@ -49,8 +72,10 @@ def main():
         text = text[:-1]
     t0 = time.time()
     mv = movebuild.build_move(text, device="cuda", with_locate=False)
+    if args.reads:  # locate arrays for the exact-matching leg: PLCP of a repetitive text through the suffix array on the GPU
+        mv.plcp = plcp_gpu(text, mv)
     print(f"text {mv.n / 1e6:.1f} Mbp, {mv.runs_fwd} / {mv.runs_rev} runs (n/r = {mv.n / mv.runs_fwd:.1f}), built in {time.time() - t0:.0f} s", flush=True)
-    dev = ca.MoveIndex(mv, with_locate=False)
+    dev = ca.MoveIndex(mv, with_locate=bool(args.reads))
     print(f"index in HBM: {dev.device_bytes() / 1e6:.1f} MB", flush=True)
     # ranges: a breadth-first walk that alternates direction, a slice of every level
     frontier = dev.complete_range()
@@ -73,7 +98,7 @@ def main():
           f"runs spanned median {int(np.median(nruns))}, p90 {int(np.percentile(nruns, 90))}", flush=True)
     # soak: device vs oracle
     import oracle_py as op
-    orc = op.OracleMoveIndex(mv, with_locate=False)
+    orc = op.OracleMoveIndex(mv, with_locate=bool(args.reads))
     sample = parents[rng.choice(parents.shape[0], min(args.check, parents.shape[0]), replace=False)]
     fields = [f for f in ca.MOVE_RANGE_DTYPE.names if f != "reserved"]
     for mode in (0, 1, 2):
@@ -108,6 +133,38 @@ def main():
            "io_bytes_per_parent": 80 + 4 * 80 + 4,
            "cpu_port_1core_M_parents_per_s": round(ns / cpu_s / 1e6, 3), "cpu_sample": ns,
            "reference_rows_stepped_per_parent": round(steps / ns, 2), "reference_row_bytes": int(row_bytes)}
+    if args.reads:
+        # exact matching end to end: 250 bp reads sampled from the text, half of them reverse-complemented, 10 % with one
+        # substitution (no occurrence as a rule)
+        comp = np.zeros(256, dtype=np.uint8)
+        for a, b in zip(b"ACGT", b"TGCA"):
+            comp[a] = b
+        L = 250
+        starts = rng.integers(0, mv.n - 1 - L, args.reads)
+        reads = []
+        for i, p0 in enumerate(starts):
+            r = text[p0:p0 + L].copy()
+            if i % 10 == 0:
+                r[L // 2] = b"ACGT"[(b"ACGT".index(r[L // 2]) + 1) % 4]
+            if i % 2:
+                r = comp[r][::-1]
+            reads.append(r.tobytes())
+        t0 = time.time()
+        occ, offs, cnt = dev.match_exact(reads)
+        wall = time.time() - t0
+        ms = dev.last_ms
+        ns = min(2000, len(reads))
+        t0 = time.time()
+        o_occ, o_offs, o_cnt = orc.match_exact(reads[:ns])
+        cpu_s = time.time() - t0
+        assert np.array_equal(offs[:ns + 1], o_offs) and np.array_equal(occ["begin"][:int(o_offs[-1])], o_occ[:, 0])
+        dev_ms = ms["extend"] + ms["scan"] + ms["locate"]
+        out["exact_250bp"] = {"reads": len(reads), "occurrences": int(occ.shape[0]), "nodes": cnt["NODE_COUNTER"],
+                              "device_ms": {k: round(v, 3) for k, v in ms.items()},
+                              "M_reads_per_s_device": round(len(reads) / dev_ms / 1e3, 2),
+                              "M_reads_per_s_with_transfers": round(len(reads) / wall / 1e6, 3),
+                              "cpu_port_1core_reads_per_s": round(ns / cpu_s, 1), "cpu_sample": ns,
+                              "checked_against_oracle": ns}
     print(json.dumps(out))
 
 
