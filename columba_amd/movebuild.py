@@ -161,3 +161,16 @@ def build_move(text, device: str | torch.device = "cpu", with_locate: bool = Tru
     return MoveArrays(n=n, lfbp_fwd=pack_lfbp(bwt, cum), lfbp_rev=pack_lfbp(rbwt, cum), smpf=smpf, smpl=smpl,
                       rev_smpf=rsmpf, rev_smpl=rsmpl, pred_first=pf, first_to_run=ftr, pred_last=pl, last_to_run=ltr,
                       plcp=_plcp(tc, sa) if with_locate else np.zeros(0, np.uint32), sa=sa.astype(np.uint64), rev_sa=rsa.astype(np.uint64), text=t)
+
+
+def save_move(mv: MoveArrays, base: str) -> None:
+    """Write the index parts as include/columba_amd_bmove.hpp (BMove) reads them: the two .LFBP files in the reference's
+    format, everything the reference keeps in sdsl containers as plain little-endian 64-bit arrays."""
+    from . import plcp_runs
+    mv.lfbp_fwd.tofile(base + ".LFBP")
+    mv.lfbp_rev.tofile(base + ".rev.LFBP")
+    pos, sm = plcp_runs(mv.plcp)
+    for ext, a in ((".smpf", mv.smpf), (".smpl", mv.smpl), (".rev.smpf", mv.rev_smpf), (".rev.smpl", mv.rev_smpl),
+                   (".prdf", mv.pred_first), (".ftr", mv.first_to_run), (".prdl", mv.pred_last), (".ltr", mv.last_to_run),
+                   (".plcp.pos", pos), (".plcp.sum", sm)):
+        np.ascontiguousarray(a, dtype="<u8").tofile(base + ext + ".u64")

@@ -1,0 +1,214 @@
+// columba_amd_bmove.hpp — C++ host adapter over the b-move part of the C-ABI (include/columba_amd.h, section "b-move").
+//
+// Keeps the names and argument meaning of the reference's run-length compressed index class for the operations that run
+// on the device (reference src/, RUN_LENGTH_COMPRESSION flavour, 64-bit length_t):
+//
+//   reference                                                        here (namespace columba_amd::rlc)
+//   ---------------------------------------------------------------  -------------------------------------------------
+//   BMove(baseFile, ...) -> fromFiles            bmove/bmove.cpp:45   BMove(baseFile, device)
+//   BMove::getCompleteRange                      bmove/bmove.h:369    same
+//   BMove::findRangesWithExtraCharForward / Backward /                same names (one parent, one character) and
+//          BackwardUniDirectional                bmove.cpp:328-478    extendFMPos for a batch (all four children each)
+//   BMove::getTextPositionsFromSARange           bmove.cpp:543-560    same, and a batch variant
+//   IndexInterface::exactMatchesOutput           indexinterface.cpp:947   exactMatchesOutput for a chunk of reads
+//   SARangePair / MoveRange (SARange)            indexhelpers.h:137-255, :1117   value types with the same accessors
+//
+// Files: <base>.LFBP and <base>.rev.LFBP are the reference's own (MoveLFReprBP::write).  The reference keeps the samples,
+// the phi predecessors and the PLCP in sdsl containers, whose serialisation belongs to sdsl; this loader reads their
+// CONTENTS as plain little-endian 64-bit arrays: <base>.smpf.u64 .smpl.u64 .rev.smpf.u64 .rev.smpl.u64 (samples),
+// .prdf.u64 .prdl.u64 (marked positions of predFirst / predLast, increasing), .ftr.u64 .ltr.u64, and .plcp.pos.u64 /
+// .plcp.sum.u64 (run-length form of the PLCP, see cmb_move_desc).  columba_amd/movebuild.py writes all of them.
+//
+// Errors are std::runtime_error with the reference's texts where it has them ("Cannot open file: ...").
+#pragma once
+#include "columba_amd.h"
+
+#include <cstdint>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace columba_amd {
+namespace rlc {
+
+typedef uint64_t length_t;
+enum Strand { FORWARD_STRAND = 0, REVERSE_C_STRAND = 1 };
+
+inline void check(int rc) {
+    if (rc != CMB_OK) throw std::runtime_error(cmb_last_error());
+}
+
+class MoveRange { // indexhelpers.h:137-255
+    length_t b, e, bRun, eRun;
+    bool valid;
+
+  public:
+    MoveRange(length_t begin = 0, length_t end = 0, length_t beginRun = 0, length_t endRun = 0, bool runIndicesValid = true)
+        : b(begin), e(end), bRun(beginRun), eRun(endRun), valid(runIndicesValid) {}
+    length_t getBegin() const { return b; }
+    length_t getEnd() const { return e; }
+    length_t getBeginRun() const { return bRun; }
+    length_t getEndRun() const { return eRun; }
+    bool getRunIndicesValid() const { return valid; }
+    bool empty() const { return e <= b; }
+    length_t width() const { return empty() ? 0 : e - b; }
+    bool operator==(const MoveRange& o) const { return b == o.b && e == o.e && bRun == o.bRun && eRun == o.eRun; }
+};
+typedef MoveRange SARange;
+
+class SARangePair { // indexhelpers.h:1117-1260 with ToeholdInterface (:1040-1111)
+    cmb_move_range r;
+
+  public:
+    SARangePair() : r{} { r.runs_valid = r.rev_runs_valid = 1; }
+    explicit SARangePair(const cmb_move_range& raw) : r(raw) {}
+    SARangePair(const SARange& sa, const SARange& rev, length_t toehold, bool toeholdRepresentsEnd, length_t originalDepth) : r{} {
+        r.begin = sa.getBegin(), r.end = sa.getEnd(), r.begin_run = sa.getBeginRun(), r.end_run = sa.getEndRun();
+        r.rev_begin = rev.getBegin(), r.rev_end = rev.getEnd(), r.rev_begin_run = rev.getBeginRun(), r.rev_end_run = rev.getEndRun();
+        r.runs_valid = sa.getRunIndicesValid(), r.rev_runs_valid = rev.getRunIndicesValid();
+        r.toehold = toehold, r.toehold_represents_end = toeholdRepresentsEnd, r.original_depth = (uint32_t)originalDepth;
+    }
+    SARange getRangeSA() const { return SARange(r.begin, r.end, r.begin_run, r.end_run, r.runs_valid != 0); }
+    SARange getRangeSARev() const { return SARange(r.rev_begin, r.rev_end, r.rev_begin_run, r.rev_end_run, r.rev_runs_valid != 0); }
+    length_t getToehold() const { return r.toehold; }
+    bool getToeholdRepresentsEnd() const { return r.toehold_represents_end != 0; }
+    length_t getOriginalDepth() const { return r.original_depth; }
+    bool empty() const { return r.end <= r.begin; }
+    length_t width() const { return empty() ? 0 : r.end - r.begin; }
+    const cmb_move_range& raw() const { return r; }
+};
+
+class TextOcc {
+    length_t b, e, d;
+    Strand s;
+
+  public:
+    TextOcc(length_t begin, length_t end, length_t distance, Strand strand) : b(begin), e(end), d(distance), s(strand) {}
+    length_t getBegin() const { return b; }
+    length_t getEnd() const { return e; }
+    length_t getDistance() const { return d; }
+    Strand getStrand() const { return s; }
+    bool isRevCompl() const { return s == REVERSE_C_STRAND; }
+};
+
+class BMove {
+    cmb_move_index* h = nullptr;
+    length_t textLength = 0, nRuns = 0, nRunsRev = 0;
+
+    static std::vector<uint8_t> slurp(const std::string& fn) {
+        std::ifstream f(fn, std::ios::binary);
+        if (!f) throw std::runtime_error("Cannot open file: " + fn); // bmove.cpp:53, :62, ...
+        return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    }
+    static std::vector<uint64_t> slurp64(const std::string& fn) {
+        const std::vector<uint8_t> b = slurp(fn);
+        std::vector<uint64_t> v(b.size() / 8);
+        for (size_t i = 0; i < v.size(); i++) {
+            uint64_t x = 0;
+            for (int k = 7; k >= 0; k--) x = x << 8 | b[8 * i + k];
+            v[i] = x;
+        }
+        return v;
+    }
+
+  public:
+    // BMove::fromFiles (bmove.cpp:45-170); lengthBits: width of length_t in the .LFBP files (64 unless built with THIRTY_TWO)
+    explicit BMove(const std::string& baseFile, int device = 0, bool withLocate = true, unsigned lengthBits = 64) {
+        const std::vector<uint8_t> lf = slurp(baseFile + ".LFBP"), lr = slurp(baseFile + ".rev.LFBP");
+        const std::vector<uint64_t> sf = slurp64(baseFile + ".smpf.u64"), sl = slurp64(baseFile + ".smpl.u64"),
+                                    rsf = slurp64(baseFile + ".rev.smpf.u64"), rsl = slurp64(baseFile + ".rev.smpl.u64");
+        std::vector<uint64_t> pf, ftr, pl, ltr, pp, ps;
+        cmb_move_desc d{};
+        d.lfbp = lf.data(), d.lfbp_bytes = lf.size(), d.rev_lfbp = lr.data(), d.rev_lfbp_bytes = lr.size(), d.length_bits = lengthBits;
+        d.samples_first = sf.data(), d.samples_last = sl.data(), d.rev_samples_first = rsf.data(), d.rev_samples_last = rsl.data();
+        if (withLocate) {
+            pf = slurp64(baseFile + ".prdf.u64"), ftr = slurp64(baseFile + ".ftr.u64"), pl = slurp64(baseFile + ".prdl.u64");
+            ltr = slurp64(baseFile + ".ltr.u64"), pp = slurp64(baseFile + ".plcp.pos.u64"), ps = slurp64(baseFile + ".plcp.sum.u64");
+            d.pred_first = pf.data(), d.first_to_run = ftr.data(), d.pred_last = pl.data(), d.last_to_run = ltr.data();
+            d.plcp_pos = pp.data(), d.plcp_sum = ps.data(), d.n_plcp = pp.size();
+        }
+        check(cmb_move_create(&d, device, &h));
+        check(cmb_move_info(h, &textLength, &nRuns, &nRunsRev));
+        if (sf.size() != nRuns || sl.size() != nRuns || rsf.size() != nRunsRev || rsl.size() != nRunsRev) {
+            cmb_move_destroy(h);
+            throw std::runtime_error("sample arrays do not have one entry per run");
+        }
+    }
+    ~BMove() { cmb_move_destroy(h); }
+    BMove(const BMove&) = delete;
+    BMove& operator=(const BMove&) = delete;
+
+    length_t getTextSize() const { return textLength; }
+    length_t getNumberOfRuns() const { return nRuns; }
+    length_t getSwitchPoint() const { return 0; } // bmove.cpp:172-174: no in-text verification with b-move
+    cmb_move_index* handle() const { return h; }
+
+    SARangePair getCompleteRange() const { // bmove.h:369-373
+        cmb_move_range r;
+        check(cmb_move_complete_range(h, &r));
+        return SARangePair(r);
+    }
+
+    // IndexInterface::extendFMPos (indexinterface.cpp:675-697) for a batch: children[4 i + c - 1] is parent i extended with
+    // character c (1..4 = ACGT); mode 0 forward, 1 backward, 2 uni-directional backward
+    void extendFMPos(const std::vector<SARangePair>& parents, int mode, std::vector<SARangePair>& children, std::vector<uint8_t>& ok) const {
+        std::vector<cmb_move_range> in(parents.size()), out(4 * parents.size());
+        for (size_t i = 0; i < parents.size(); i++) in[i] = parents[i].raw();
+        ok.assign(4 * parents.size(), 0);
+        check(cmb_move_extend_batch(h, mode, in.data(), in.size(), out.data(), ok.data()));
+        children.clear();
+        for (const auto& r : out) children.emplace_back(r);
+    }
+    bool extendOne(int mode, length_t positionInAlphabet, const SARangePair& parent, SARangePair& child) const {
+        if (positionInAlphabet < 1 || positionInAlphabet > 4) throw std::runtime_error("character outside the alphabet");
+        std::vector<SARangePair> ch;
+        std::vector<uint8_t> ok;
+        extendFMPos({parent}, mode, ch, ok);
+        child = ch[positionInAlphabet - 1];
+        return ok[positionInAlphabet - 1] != 0;
+    }
+    bool findRangesWithExtraCharForward(length_t c, const SARangePair& p, SARangePair& ch) const { return extendOne(0, c, p, ch); }   // bmove.cpp:384
+    bool findRangesWithExtraCharBackward(length_t c, const SARangePair& p, SARangePair& ch) const { return extendOne(1, c, p, ch); }  // bmove.cpp:328
+    bool findRangesWithExtraCharBackwardUniDirectional(length_t c, const SARangePair& p, SARangePair& ch) const { return extendOne(2, c, p, ch); } // :444
+
+    // bmove.cpp:543-560; the batch variant returns the positions of range i in positions[i]
+    void getTextPositionsFromSARange(const SARangePair& ranges, std::vector<length_t>& positions) const {
+        std::vector<std::vector<length_t>> all;
+        getTextPositionsFromSARanges({ranges}, all);
+        positions = all[0];
+    }
+    void getTextPositionsFromSARanges(const std::vector<SARangePair>& ranges, std::vector<std::vector<length_t>>& positions) const {
+        std::vector<cmb_move_range> in(ranges.size());
+        std::vector<uint64_t> off(ranges.size() + 1, 0);
+        for (size_t i = 0; i < ranges.size(); i++) in[i] = ranges[i].raw(), off[i + 1] = off[i] + ranges[i].width();
+        std::vector<uint64_t> flat(off.back());
+        check(cmb_move_locate_batch(h, in.data(), in.size(), off.data(), flat.data()));
+        positions.assign(ranges.size(), {});
+        for (size_t i = 0; i < ranges.size(); i++) positions[i].assign(flat.begin() + off[i], flat.begin() + off[i + 1]);
+    }
+
+    // indexinterface.cpp:947-1014 for a chunk of reads, both strands (searchstrategy.cpp:499-510): matches[i] = the occurrences
+    // of read i, forward strand first; returns NODE_COUNTER
+    uint64_t exactMatchesOutput(const std::vector<std::string>& reads, std::vector<std::vector<TextOcc>>& matches) const {
+        std::string buf;
+        std::vector<uint64_t> off(reads.size() + 1, 0), occOff(reads.size() + 1, 0);
+        for (size_t i = 0; i < reads.size(); i++) buf += reads[i], off[i + 1] = buf.size();
+        std::vector<cmb_move_occ> occ(reads.size() * 2 + 64);
+        uint64_t nOcc = 0, counters[2] = {0, 0};
+        int rc = cmb_move_match_exact(h, buf.data(), off.data(), reads.size(), occ.data(), occ.size(), occOff.data(), &nOcc, counters);
+        if (rc == CMB_ERR_OVERFLOW) {
+            occ.resize(nOcc);
+            rc = cmb_move_match_exact(h, buf.data(), off.data(), reads.size(), occ.data(), occ.size(), occOff.data(), &nOcc, counters);
+        }
+        check(rc);
+        matches.assign(reads.size(), {});
+        for (size_t i = 0; i < reads.size(); i++)
+            for (uint64_t j = occOff[i]; j < occOff[i + 1]; j++)
+                matches[i].emplace_back(occ[j].begin, occ[j].end, occ[j].distance, occ[j].strand ? REVERSE_C_STRAND : FORWARD_STRAND);
+        return counters[0];
+    }
+};
+
+} // namespace rlc
+} // namespace columba_amd

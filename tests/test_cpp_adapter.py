@@ -111,3 +111,59 @@ def test_align_driver_fastq_to_sam(tmp_path, oracle_built):
         else:
             j = int(o_off[i])
             assert (f[2], int(f[3]), f[5], f[11]) == (names[int(o_sid[j])], int(o_sb[j]) + 1, o_cig[j], f"AS:i:{int(o_best[i])}")
+
+
+def _build_bmove(tmp):
+    ca.build_library()
+    exe = os.path.join(tmp, "bmove_exact")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "bmove_exact.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "columba_amd"), "-lcolumba_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "columba_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_bmove_adapter_compiles_and_reports_missing_index(tmp_path):
+    exe = _build_bmove(str(tmp_path))
+    r = subprocess.run([exe, str(tmp_path / "nope"), str(tmp_path / "reads.txt")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Cannot open file" in r.stderr and ".LFBP" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bmove_adapter_example_matches_python_binding(tmp_path):
+    """BMove of include/columba_amd_bmove.hpp on files written by movebuild.save_move: exactMatchesOutput of a chunk =
+    the Python binding's occurrences; a bidirectional walk with the reference's method names ends on the same interval"""
+    from columba_amd import movebuild
+    exe = _build_bmove(str(tmp_path))
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 4, 5000)
+    parts = []
+    for _ in range(12):
+        s = base.copy()
+        m = rng.random(base.shape[0]) < 0.01
+        s[m] = rng.integers(0, 4, int(m.sum()))
+        parts.append(s)
+    text = np.frombuffer(b"ACGT", dtype=np.uint8)[np.concatenate(parts)]
+    mv = movebuild.build_move(text.tobytes(), device="cuda")
+    movebuild.save_move(mv, str(tmp_path / "idx"))
+    t = mv.text.tobytes()
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads = []
+    for i in range(200):
+        L = int(rng.choice([8, 20, 60, 150]))
+        p0 = int(rng.integers(0, len(t) - 1 - L))
+        r = t[p0:p0 + L]
+        reads.append(r.translate(comp)[::-1] if i % 3 == 1 else r)
+    (tmp_path / "reads.txt").write_bytes(b"\n".join(reads) + b"\n")
+    r = subprocess.run([exe, str(tmp_path / "idx"), str(tmp_path / "reads.txt")], capture_output=True, text=True, check=True)
+    got = [tuple(int(x) for x in line.split()) for line in r.stdout.splitlines()]
+    dev = ca.MoveIndex(mv)
+    occ, offs, cnt = dev.match_exact(reads)
+    exp = [(i, int(o["begin"]), int(o["end"]), int(o["distance"]), int(o["strand"]))
+           for i in range(len(reads)) for o in occ[int(offs[i]):int(offs[i + 1])]]
+    assert got == exp and len(exp) > 1000
+    err = r.stderr.split("\n")
+    assert err[0] == f"nodes {cnt['NODE_COUNTER']}"
+    walk = err[1].split()
+    fw = sorted(int(o["begin"]) for o in occ[int(offs[0]):int(offs[1])] if o["strand"] == 0)
+    assert walk[0] == "walk" and int(walk[1]) == len(reads[0]) and [int(x) for x in walk[4:]] == fw
