@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""b-move backend on tiny and degenerate texts (1 ... 400 characters: random, homopolymers, tandem repeats, copies): every
+extension of a breadth-first walk, locate of every range met, and exact matching of substrings / mutated substrings — device
+against oracle.  usage: python tools/soak_move_tiny.py [texts]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import columba_amd as ca  # noqa: E402
+from columba_amd import movebuild  # noqa: E402
+import oracle_py as op  # noqa: E402
+
+FIELDS = [f for f in ca.MOVE_RANGE_DTYPE.names if f != "reserved"]
+
+
+def one_text(text: bytes, rng):
+    n = len(text) + 1
+    if n & (n - 1) == 0:
+        text += b"C"
+    mv = movebuild.build_move(text)
+    dev, orc = ca.MoveIndex(mv), op.OracleMoveIndex(mv)
+    for rev in (0, 1):
+        assert np.array_equal(dev.rows(rev), orc.rows(rev))
+    stats = [0, 0, 0]
+    for modes in ((1, 0) * 6, (0, 1, 1, 0) * 3, (2,) * 10):
+        frontier = dev.complete_range()
+        for mode in modes:
+            d_ch, d_ok = dev.extend(mode, frontier)
+            for c in range(4):
+                o_ch, o_ok, _ = orc.extend(mode, frontier, np.full(frontier.shape[0], c + 1, dtype=np.uint8))
+                assert np.array_equal(d_ok[:, c], o_ok), (text, mode, c)
+                for f in FIELDS:
+                    assert np.array_equal(d_ch[:, c][f], o_ch[f]), (text, mode, c, f)
+            nxt = d_ch.reshape(-1)[d_ok.reshape(-1) == 1]
+            stats[0] += nxt.shape[0]
+            if nxt.shape[0] == 0:
+                break
+            if nxt.shape[0] > 300:
+                nxt = nxt[np.sort(rng.choice(nxt.shape[0], 300, replace=False))]
+            pos, offs = dev.locate(nxt)
+            for i in range(nxt.shape[0]):
+                want = orc.locate(nxt[i:i + 1])
+                assert np.array_equal(pos[int(offs[i]):int(offs[i + 1])], want), (text, mode, i)
+                b, e = int(nxt["begin"][i]), int(nxt["end"][i])
+                assert np.array_equal(np.sort(want), np.sort(mv.sa[b:e]))
+            stats[1] += nxt.shape[0]
+            frontier = nxt
+    t = mv.text.tobytes()[:-1]
+    reads = [b"", b"N", t, t + b"A", t[::-1]]
+    for _ in range(60):
+        L = int(rng.integers(1, max(2, min(len(t), 40)) + 1))
+        p0 = int(rng.integers(0, max(1, len(t) - L + 1)))
+        r = bytearray(t[p0:p0 + L])
+        if r and rng.random() < 0.3:
+            r[int(rng.integers(0, len(r)))] = b"ACGTN"[int(rng.integers(0, 5))]
+        reads.append(bytes(r))
+    d_occ, d_off, d_cnt = dev.match_exact(reads)
+    o_occ, o_off, o_cnt = orc.match_exact(reads)
+    assert np.array_equal(d_off, o_off) and d_cnt == o_cnt, text
+    for j, f in enumerate(("begin", "end", "distance", "strand")):
+        assert np.array_equal(d_occ[f].astype(np.uint64), o_occ[:, j]), (text, f)
+    stats[2] += d_occ.shape[0]
+    dev.close()
+    return stats
+
+
+def texts(rng, count):
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    yield b"A"
+    yield b"AC"
+    yield b"AAAA"
+    yield b"ACGT"
+    yield b"T" * 50
+    yield b"AC" * 40
+    yield b"ACG" * 30 + b"T"
+    for i in range(count):
+        kind = i % 4
+        n = int(rng.integers(1, 400))
+        if kind == 0:
+            yield acgt[rng.integers(0, 4, n)].tobytes()
+        elif kind == 1:
+            unit = acgt[rng.integers(0, 4, int(rng.integers(1, 12)))].tobytes()
+            yield (unit * (n // len(unit) + 1))[:n]
+        elif kind == 2:
+            base = acgt[rng.integers(0, 4, max(1, n // 8))]
+            parts = []
+            for _ in range(8):
+                s = base.copy()
+                m = rng.random(s.shape[0]) < 0.05
+                s[m] = acgt[rng.integers(0, 4, int(m.sum()))]
+                parts.append(s)
+            yield np.concatenate(parts).tobytes()
+        else:
+            yield acgt[rng.integers(0, 2, n)].tobytes()  # two-letter text: long runs
+
+
+def main():
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    rng = np.random.default_rng(11)
+    tot = np.zeros(3, dtype=np.int64)
+    k = 0
+    for t in texts(rng, count):
+        tot += one_text(t, rng)
+        k += 1
+    print(f"OK: {k} texts, {tot[0]} children, {tot[1]} ranges located, {tot[2]} exact occurrences — identical to the oracle")
+
+
+if __name__ == "__main__":
+    main()
