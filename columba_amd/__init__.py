@@ -110,7 +110,7 @@ class _MoveDesc(C.Structure):
     ]
 
 
-DEV_ARRAYS = 7
+DEV_ARRAYS = 6
 
 
 class IndexLayout(C.Structure):

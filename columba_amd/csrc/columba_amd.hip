@@ -91,7 +91,6 @@ struct cmb_index {
     uint32_t saSparseness = 0;
     DevIndex d{};
     DevBuf<uint4> blkF, blkR; // 32-byte rank blocks
-    DevBuf<uint64_t> saBlk;
     DevBuf<uint32_t> saSamples;
     DevBuf<uint8_t> text;
     DevBuf<uint32_t> text2;
@@ -145,7 +144,7 @@ static int probeIndex(cmb_index* ix) {
     HIPCHK(hipMemset(bad.p, 0, sizeof(uint32_t)));
     const uint32_t nProbe = std::min<uint32_t>(ix->d.n, 1u << 20);
     if (!nProbe) return CMB_OK;
-    hipLaunchKernelGGL(k_check_index, dim3((nProbe + 255) / 256), dim3(256), 0, 0, ix->d, ix->saSparseness, nProbe, bad.p);
+    hipLaunchKernelGGL(k_check_index, dim3((nProbe + 255) / 256), dim3(256), 0, 0, ix->d, ix->saSparseness, nProbe, (uint32_t)std::min<size_t>(ix->saSamples.n, 0xFFFFFFFFu), bad.p);
     HIPCHK(hipGetLastError());
     uint32_t hb = 0;
     HIPCHK(hipMemcpy(&hb, bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -195,14 +194,12 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
             HIPCHK(hipDeviceSynchronize());
         }
         const uint64_t saW = (n + 63) / 64;
-        { // sampled-row bitvector + rank9 counts -> 64-byte records (k_relayout_sa); the originals are dropped
+        { // the sparse suffix array's bitvector + rank9 counts ride in slot 3 of the forward blocks (k_relayout_sa)
             DevBuf<uint64_t> bv, cnt;
             bv.upload(desc->sa_bv, saW);
             cnt.upload(desc->sa_bv_counts, (saW + 7) / 4);
-            const uint64_t nSaBlocks = n / SA_BLOCK + 2;
-            ix->saBlk.alloc(nSaBlocks * 8);
-            hipLaunchKernelGGL(k_relayout_sa, dim3((unsigned)((nSaBlocks + 255) / 256)), dim3(256), 0, 0, bv.p, cnt.p, saW,
-                               nSaBlocks, ix->saBlk.p);
+            hipLaunchKernelGGL(k_relayout_sa, dim3((unsigned)((nBlocks + 255) / 256)), dim3(256), 0, 0, bv.p, cnt.p, saW,
+                               nBlocks, ix->blkF.p);
             HIPCHK(hipGetLastError());
             HIPCHK(hipDeviceSynchronize());
         }
@@ -238,7 +235,6 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         for (int i = 0; i < 5; i++) d.counts[i] = (uint32_t)desc->counts[i];
         d.fwd = DevBWT{ix->blkF.p, (uint32_t)desc->dollar_pos_fwd};
         d.rev = DevBWT{ix->blkR.p, (uint32_t)desc->dollar_pos_rev};
-        d.saBlk = ix->saBlk.p;
         d.saSamples = ix->saSamples.p;
         d.text = ix->text.p;
         d.text2 = packedOk ? ix->text2.p : nullptr;
@@ -250,7 +246,7 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         HIPCHK(hipGetLastError());
         HIPCHK(hipDeviceSynchronize());
         if (int rc = probeIndex(ix.get())) return rc; // the arrays must belong together, or findSA would never end
-        ix->bytes = ix->blkF.bytes() + ix->blkR.bytes() + ix->saBlk.bytes() + ix->saSamples.bytes() + ix->text.bytes() + ix->text2.bytes() + ix->kmer.bytes();
+        ix->bytes = ix->blkF.bytes() + ix->blkR.bytes() + ix->saSamples.bytes() + ix->text.bytes() + ix->text2.bytes() + ix->kmer.bytes();
         ix->uploadSeqStarts();
         *out = ix.release();
         return CMB_OK;
@@ -269,17 +265,15 @@ struct ArrayRef {
 inline void indexArrays(cmb_index* ix, ArrayRef out[CMB_DEV_ARRAYS]) {
     out[0] = {(void**)&ix->blkF.p, &ix->blkF.n, sizeof(uint4)};
     out[1] = {(void**)&ix->blkR.p, &ix->blkR.n, sizeof(uint4)};
-    out[2] = {(void**)&ix->saBlk.p, &ix->saBlk.n, sizeof(uint64_t)};
-    out[3] = {(void**)&ix->saSamples.p, &ix->saSamples.n, sizeof(uint32_t)};
-    out[4] = {(void**)&ix->text.p, &ix->text.n, sizeof(uint8_t)};
-    out[5] = {(void**)&ix->text2.p, &ix->text2.n, sizeof(uint32_t)};
-    out[6] = {(void**)&ix->kmer.p, &ix->kmer.n, sizeof(uint4)};
+    out[2] = {(void**)&ix->saSamples.p, &ix->saSamples.n, sizeof(uint32_t)};
+    out[3] = {(void**)&ix->text.p, &ix->text.n, sizeof(uint8_t)};
+    out[4] = {(void**)&ix->text2.p, &ix->text2.n, sizeof(uint32_t)};
+    out[5] = {(void**)&ix->kmer.p, &ix->kmer.n, sizeof(uint4)};
 }
 inline void bindDevIndex(cmb_index* ix) { // DevIndex pointers from the owning buffers
     DevIndex& d = ix->d;
     d.fwd.blk = ix->blkF.p;
     d.rev.blk = ix->blkR.p;
-    d.saBlk = ix->saBlk.p;
     d.saSamples = ix->saSamples.p;
     d.text = ix->text.p;
     d.text2 = ix->text2.n ? ix->text2.p : nullptr;
@@ -331,7 +325,7 @@ extern "C" int cmb_index_create_empty(const cmb_index_layout* L, const uint32_t*
             *a[i].n = L->bytes[i] / a[i].elem;
             total += L->bytes[i];
         }
-        if (!ix->blkF.p || !ix->blkR.p || !ix->saBlk.p || !ix->text.p || !ix->kmer.p)
+        if (!ix->blkF.p || !ix->blkR.p || !ix->text.p || !ix->kmer.p)
             return fail(CMB_ERR_INVALID, "index layout: a required array is missing");
         DevIndex& d = ix->d;
         d.n = (uint32_t)L->text_length;

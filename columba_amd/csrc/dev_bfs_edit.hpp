@@ -193,8 +193,8 @@ __device__ __forceinline__ void takeRanks(const DevIndex& ix, int mode, const Ra
                                           uint32_t Re[4], uint32_t& db, uint32_t& de) {
     const uint32_t dollar = mode == 0 ? ix.rev.dollarPos : ix.fwd.dollarPos;
     const uint32_t b = mode == 0 ? p.rev.b : p.sa.b, e = mode == 0 ? p.rev.e : p.sa.e;
-    ranksFromRaw(v, b, Rb);
-    ranksFromRaw(v + 2, e, Re);
+    ranksFromRaw(v, b, dollar, Rb);
+    ranksFromRaw(v + 2, e, dollar, Re);
     db = b > dollar ? 1u : 0u;
     de = e > dollar ? 1u : 0u;
 }

@@ -11,10 +11,16 @@
 // HBM layout: the reference's two arrays per BWT (interleaved bitvector words + interleaved L1/L2
 // counts, bitvec.h:209-232) are re-packed at index creation (k_relayout) into self-contained
 // 32-byte rank blocks, one per 32 positions:
-//     chunk 0      u32 abs[4]    cumulative rank of bitvector c at the block start
-//     chunk 1      u32 bits[4]   the 32 bits of bitvectors 0..3 for the block's positions
+//     chunk 0      u32 abs[4]    cumulative rank of bitvector c at the block start (c = 0..2)
+//     chunk 1      u32 bits[4]   the 32 bits of bitvectors 0..2 for the block's positions
 // rank = abs + popcount(bits & lowmask): TWO 16-byte loads from one 32-byte sector (the reference layout
-// needs a 64-byte count line plus a 32-byte bit group in another line).  One byte per position and
+// needs a 64-byte count line plus a 32-byte bit group in another line).
+// Bitvector 3 is not stored: every position but the '$' has its bit set (bwtrepr.h:57-68), so its rank at p is
+// p - (p > dollarPos).  Its slots hold, in the blocks of the text's own BWT, the SPARSE SUFFIX ARRAY's bitvector instead:
+// bits[3] = which of the block's 32 rows are sampled, abs[3] = the number of sampled rows before the block (the rank9
+// structure of bitvec.h:155-170 folded in) — an LF step of findSA and its "is this row sampled, and which sample is it"
+// come out of the SAME 32-byte sector (the reference reads the BWT word, two rank lines, the sampled-row word and its
+// rank9 counts).  One byte per position and
 // direction — 1.5 x the 128-byte blocks of 192 positions used before, which needed four loads per rank:
 // the extension kernels are bound by the NUMBER of scattered loads, and memory is not
 // what an MI355X lacks.
@@ -35,7 +41,6 @@ struct DevIndex {
     uint32_t n; // text length including '$'
     uint32_t counts[5];
     DevBWT fwd, rev;
-    const uint64_t* saBlk; // sampled-row bitvector with its ranks, 64-byte records of 384 rows (k_relayout_sa)
     const uint32_t* saSamples;
     const uint8_t* text;
     const uint32_t* text2; // 2 bits per character, 16 per word (nullptr if the text holds non-ACGT characters before '$')
@@ -67,12 +72,13 @@ __device__ __forceinline__ void loadRankChunks(const DevBWT& t, uint32_t p, Rank
     k.abs = B[0];
     k.bits = B[1];
 }
-__device__ __forceinline__ void ranksFromChunks(const RankChunks& k, uint32_t R[4]) {
+// (p, dollarPos: bitvector 3 is implicit — all positions but the '$')
+__device__ __forceinline__ void ranksFromChunks(const RankChunks& k, uint32_t p, uint32_t dollarPos, uint32_t R[4]) {
     const uint32_t lowmask = (1u << k.bit) - 1u; // bitvec.h:371: bits below position `bit`
     R[0] = k.abs.x + (uint32_t)__popc(k.bits.x & lowmask);
     R[1] = k.abs.y + (uint32_t)__popc(k.bits.y & lowmask);
     R[2] = k.abs.z + (uint32_t)__popc(k.bits.z & lowmask);
-    R[3] = k.abs.w + (uint32_t)__popc(k.bits.w & lowmask);
+    R[3] = p - (p > dollarPos ? 1u : 0u);
 }
 
 // the same as two raw 16-byte chunks {abs, bits} (callers that share the reply registers with other kinds of loads)
@@ -96,12 +102,12 @@ __device__ __forceinline__ void loadRankPairRaw(const DevBWT& t, uint32_t pb, ui
         v[3] = E[1];
     }
 }
-__device__ __forceinline__ void ranksFromRaw(const uint4 v[2], uint32_t p, uint32_t R[4]) {
+__device__ __forceinline__ void ranksFromRaw(const uint4 v[2], uint32_t p, uint32_t dollarPos, uint32_t R[4]) {
     const uint32_t lowmask = (1u << (p & 31u)) - 1u;
     R[0] = v[0].x + (uint32_t)__popc(v[1].x & lowmask);
     R[1] = v[0].y + (uint32_t)__popc(v[1].y & lowmask);
     R[2] = v[0].z + (uint32_t)__popc(v[1].z & lowmask);
-    R[3] = v[0].w + (uint32_t)__popc(v[1].w & lowmask);
+    R[3] = p - (p > dollarPos ? 1u : 0u);
 }
 
 // ranks of the four cumulative bitvectors at position p: R[i] = #{j < p : 1 <= BWT[j] <= i+1}
@@ -109,7 +115,7 @@ __device__ __forceinline__ void ranksFromRaw(const uint4 v[2], uint32_t p, uint3
 __device__ __forceinline__ void rank4(const DevBWT& t, uint32_t p, uint32_t R[4]) {
     RankChunks k;
     loadRankChunks(t, p, k);
-    ranksFromChunks(k, R);
+    ranksFromChunks(k, p, t.dollarPos, R);
 }
 
 // single rank(c, p) — test hook
@@ -193,8 +199,8 @@ __device__ __forceinline__ void loadExtendRanks(const DevIndex& ix, int mode, co
     }
     uint4 v[4];
     loadRankPairRaw(t, tr.b, tr.e, v);
-    ranksFromRaw(v, tr.b, Rb);
-    ranksFromRaw(v + 2, tr.e, Re);
+    ranksFromRaw(v, tr.b, t.dollarPos, Rb);
+    ranksFromRaw(v + 2, tr.e, t.dollarPos, Re);
     db = tr.b > t.dollarPos ? 1u : 0u;
     de = tr.e > t.dollarPos ? 1u : 0u;
 }
@@ -207,66 +213,55 @@ __device__ __forceinline__ bool extendOne(const DevIndex& ix, int mode, const Ra
     return childFromRanks(ix, mode, p, c, Rb, Re, db, de, child);
 }
 
-// rank9 Bitvec (bitvec.h:155-170) of the sampled suffix-array rows, re-packed (k_relayout_sa) so that "is this row
-// sampled" and "its rank" come from ONE 64-byte record: six 64-bit words of bits (384 rows), the number of set
-// bits before the record, and the five 9-bit counts of set bits before words 1..5 of the record.
-constexpr uint32_t SA_BLOCK = 384;
-struct SaPos {
-    uint32_t blk, off; // record, row inside the record
-};
-__device__ __forceinline__ SaPos saPos(uint32_t row) {
-    const uint32_t blk = row / SA_BLOCK;
-    return SaPos{blk, row - blk * SA_BLOCK};
+// The sparse suffix array (suffixArray.h:131-148, :229: a Bitvec over the rows with rank9, samples in row order) lives in
+// slot 3 of the forward rank blocks (see the layout above).
+__device__ __forceinline__ bool rowSampled(const RankChunks& k) { return (k.bits.w >> k.bit) & 1u; }
+__device__ __forceinline__ uint32_t sampleIndex(const RankChunks& k) { // Bitvec::rank of the row (bitvec.h:155-170)
+    return k.abs.w + (uint32_t)__popc(k.bits.w & ((1u << k.bit) - 1u));
 }
-__device__ __forceinline__ uint64_t saWord(const DevIndex& ix, SaPos p) { return ix.saBlk[(size_t)p.blk * 8 + (p.off >> 6)]; }
-__device__ __forceinline__ bool saMarked(const DevIndex& ix, uint32_t i) {
-    const SaPos p = saPos(i);
-    return (saWord(ix, p) >> (p.off & 63u)) & 1ull;
-}
-// rank with the bitvector word of the row already at hand
-__device__ __forceinline__ uint32_t saRankW(const DevIndex& ix, SaPos p, uint64_t word) {
-    const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(ix.saBlk + (size_t)p.blk * 8 + 6);
-    uint64_t rv = c.x;
-    const uint32_t sub = p.off >> 6, b = p.off & 63u;
-    if (sub) rv += (c.y >> ((sub - 1u) * 9u)) & 0x1FFull;
-    const uint64_t lowmask = b ? (~0ull >> (64u - b)) : 0ull;
-    return (uint32_t)rv + (uint32_t)__popcll(word & lowmask);
+__device__ __forceinline__ bool saMarked(const DevIndex& ix, uint32_t row) {
+    RankChunks k;
+    loadRankChunks(ix.fwd, row, k);
+    return rowSampled(k);
 }
 __device__ __forceinline__ uint32_t saRank(const DevIndex& ix, uint32_t row) {
-    const SaPos p = saPos(row);
-    return saRankW(ix, p, saWord(ix, p));
+    RankChunks k;
+    loadRankChunks(ix.fwd, row, k);
+    return sampleIndex(k);
 }
 
-// findLF (fmindex.cpp:47-51): BWT symbol decoded from the cumulative bitvectors
-__device__ __forceinline__ uint32_t findLF(const DevIndex& ix, uint32_t k) {
-    const DevBWT& t = ix.fwd;
-    if (k == t.dollarPos) {
+// findLF (fmindex.cpp:47-51) on a block that is already in registers: BWT symbol decoded from the cumulative bitvectors
+__device__ __forceinline__ uint32_t lfFromChunks(const DevIndex& ix, const RankChunks& ch, uint32_t k) {
+    if (k == ix.fwd.dollarPos) {
         // symbol '$' (index 0): counts[0] + occ(0,k) = 0 + (k <= dollarPos ? 0 : 1) = 0
         return ix.counts[0];
     }
-    RankChunks ch;
-    loadRankChunks(t, k, ch);
     uint32_t R[4];
-    ranksFromChunks(ch, R);
+    ranksFromChunks(ch, k, ix.fwd.dollarPos, R);
     const uint32_t bit = ch.bit;
     // smallest c with bit (c-1) set
     const uint32_t c = ((ch.bits.x >> bit) & 1u) ? 1u : ((ch.bits.y >> bit) & 1u) ? 2u : ((ch.bits.z >> bit) & 1u) ? 3u : 4u;
     return ix.counts[c] + occFromR(R, c);
 }
+__device__ __forceinline__ uint32_t findLF(const DevIndex& ix, uint32_t k) {
+    if (k == ix.fwd.dollarPos) return ix.counts[0];
+    RankChunks ch;
+    loadRankChunks(ix.fwd, k, ch);
+    return lfFromChunks(ix, ch, k);
+}
 
-// findSA (fmindex.cpp:53-60); *lf accumulates the number of LF steps
+// findSA (fmindex.cpp:53-60); *lf accumulates the number of LF steps.  One 32-byte sector per visited row.
 __device__ __forceinline__ uint32_t findSA(const DevIndex& ix, uint32_t row, uint32_t* lf) {
     uint32_t l = 0;
-    SaPos p = saPos(row);
-    uint64_t word = saWord(ix, p);
-    while (!((word >> (p.off & 63u)) & 1ull)) { // not a sampled row
-        row = findLF(ix, row);
-        p = saPos(row);
-        word = saWord(ix, p);
+    RankChunks ch;
+    loadRankChunks(ix.fwd, row, ch);
+    while (!rowSampled(ch)) {
+        row = lfFromChunks(ix, ch, row);
+        loadRankChunks(ix.fwd, row, ch);
         l++;
     }
     if (lf) *lf += l;
-    return ix.saSamples[saRankW(ix, p, word)] + l;
+    return ix.saSamples[sampleIndex(ch)] + l;
 }
 
 } // namespace cmb

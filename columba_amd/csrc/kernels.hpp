@@ -27,7 +27,24 @@ __global__ void k_rank(DevIndex ix, int rev, const uint32_t* __restrict__ c, con
     out[i] = rank1(rev ? ix.rev : ix.fwd, c[i], p[i]);
 }
 
-// Re-pack one BWT's reference arrays into 32-byte rank blocks (dev_index.hpp); one thread per block.
+// Bitvec::rank (rank9, bitvec.h:155-170) on the reference's own arrays; used once, by k_relayout.  Rows past the last
+// word count everything.
+__device__ __forceinline__ uint32_t rank9RefLayout(const uint64_t* bv, const uint64_t* cnt, uint64_t nWords, uint64_t p) {
+    uint64_t w = p >> 6, b = p & 63;
+    if (nWords == 0) return 0;
+    if (w >= nWords) {
+        w = nWords - 1;
+        b = 64;
+    }
+    uint64_t rv = cnt[(w >> 3) * 2];
+    const uint32_t sub = (uint32_t)(w & 7u);
+    if (sub) rv += (cnt[(w >> 3) * 2 + 1] >> ((sub - 1u) * 9u)) & 0x1FFull;
+    const uint64_t lowmask = b >= 64 ? ~0ull : b ? (~0ull >> (64 - b)) : 0ull;
+    return (uint32_t)rv + (uint32_t)__popcll((unsigned long long)(bv[w] & lowmask));
+}
+
+// Re-pack one BWT's reference arrays into 32-byte rank blocks (dev_index.hpp); one thread per block.  Slot 3 (the
+// bitvector that is all ones but for the '$') stays empty here; k_relayout_sa fills it in the forward table.
 __global__ void k_relayout(const uint64_t* __restrict__ bv, const uint64_t* __restrict__ cnt, uint64_t N,
                            uint64_t nBlocks, uint4* __restrict__ out) {
     const uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -35,15 +52,27 @@ __global__ void k_relayout(const uint64_t* __restrict__ bv, const uint64_t* __re
     const uint64_t nWords = (N + 63) / 64;
     const uint64_t w = blk >> 1;
     const uint32_t sh = (uint32_t)(blk & 1u) * 32u;
-    uint32_t bits[4];
-    for (uint32_t c = 0; c < 4; c++) bits[c] = w < nWords ? (uint32_t)(bv[w * 4 + c] >> sh) : 0u;
+    uint32_t bits[3];
+    for (uint32_t c = 0; c < 3; c++) bits[c] = w < nWords ? (uint32_t)(bv[w * 4 + c] >> sh) : 0u;
     uint4 abs;
     abs.x = rankRefLayout(bv, cnt, 0, blk * RANK_BLOCK, N);
     abs.y = rankRefLayout(bv, cnt, 1, blk * RANK_BLOCK, N);
     abs.z = rankRefLayout(bv, cnt, 2, blk * RANK_BLOCK, N);
-    abs.w = rankRefLayout(bv, cnt, 3, blk * RANK_BLOCK, N);
+    abs.w = 0;
     out[blk * 2] = abs;
-    out[blk * 2 + 1] = make_uint4(bits[0], bits[1], bits[2], bits[3]);
+    out[blk * 2 + 1] = make_uint4(bits[0], bits[1], bits[2], 0u);
+}
+
+// The sparse suffix array's bitvector (suffixArray.h:131-148) and its rank9 counts into slot 3 of the forward rank blocks:
+// bits.w = which of the block's 32 rows are sampled, abs.w = the number of sampled rows before the block.
+__global__ void k_relayout_sa(const uint64_t* __restrict__ saBv, const uint64_t* __restrict__ saCnt, uint64_t saWords, uint64_t nBlocks,
+                              uint4* __restrict__ out) {
+    const uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= nBlocks) return;
+    const uint64_t w = blk >> 1;
+    const uint32_t sh = (uint32_t)(blk & 1u) * 32u;
+    reinterpret_cast<uint32_t*>(out + blk * 2)[3] = rank9RefLayout(saBv, saCnt, saWords, blk * RANK_BLOCK);
+    reinterpret_cast<uint32_t*>(out + blk * 2 + 1)[3] = w < saWords ? (uint32_t)(saBv[w] >> sh) : 0u;
 }
 
 // all four children of each parent; one thread per parent.
@@ -81,53 +110,23 @@ __global__ void k_locate(DevIndex ix, const uint32_t* __restrict__ rows, uint64_
 // `sparseness` steps — IF the sampled-row bitvector, the samples and the BWT belong together.  With arrays that do not
 // (a sparse suffix array of another sparseness or of another text) the walk of findSA would not end.  nProbe rows spread
 // over the suffix array are walked with that bound; `bad` counts the rows that break it or leave the text.
-__global__ void k_check_index(DevIndex ix, uint32_t maxSteps, uint32_t nProbe, uint32_t* __restrict__ bad) {
+__global__ void k_check_index(DevIndex ix, uint32_t maxSteps, uint32_t nProbe, uint32_t nSamples, uint32_t* __restrict__ bad) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nProbe) return;
     uint32_t row = (uint32_t)(((uint64_t)i * ix.n) / nProbe);
     for (uint32_t l = 0;; l++) {
         if (row >= ix.n) break;
-        const SaPos p = saPos(row);
-        const uint64_t word = saWord(ix, p);
-        if ((word >> (p.off & 63u)) & 1ull) {
-            if ((uint64_t)ix.saSamples[saRankW(ix, p, word)] + l < ix.n) return; // a position of the text: fine
+        RankChunks ch;
+        loadRankChunks(ix.fwd, row, ch);
+        if (rowSampled(ch)) {
+            const uint32_t si = sampleIndex(ch);
+            if (si < nSamples && (uint64_t)ix.saSamples[si] + l < ix.n) return; // a position of the text: fine
             break;
         }
         if (l == maxSteps) break;
-        row = findLF(ix, row);
+        row = lfFromChunks(ix, ch, row);
     }
     atomicAdd(bad, 1u);
-}
-
-// Re-packs the sampled-row bitvector and its rank9 counts (bitvec.h:155-170: per 512 rows the count before the block
-// and seven 9-bit in-block counts) into the 64-byte records of dev_index.hpp (SA_BLOCK rows each).
-__global__ void k_relayout_sa(const uint64_t* __restrict__ bv, const uint64_t* __restrict__ cnt, uint64_t nWords,
-                              uint64_t nBlocks, uint64_t* __restrict__ out) {
-    const uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (blk >= nBlocks) return;
-    const uint64_t w0 = blk * (SA_BLOCK / 64);
-    // set bits before word w0 (rank9 of the original arrays)
-    uint64_t before = 0;
-    if (w0 < nWords) {
-        before = cnt[(w0 >> 3) * 2];
-        const uint32_t sub = (uint32_t)(w0 & 7u);
-        if (sub) before += (cnt[(w0 >> 3) * 2 + 1] >> ((sub - 1u) * 9u)) & 0x1FFull;
-    } else if (nWords) { // past the end: everything
-        const uint64_t wl = nWords - 1;
-        before = cnt[(wl >> 3) * 2];
-        const uint32_t sub = (uint32_t)(wl & 7u);
-        if (sub) before += (cnt[(wl >> 3) * 2 + 1] >> ((sub - 1u) * 9u)) & 0x1FFull;
-        before += (uint64_t)__popcll((unsigned long long)bv[wl]);
-    }
-    uint64_t subs = 0, run = 0;
-    for (uint32_t j = 0; j < SA_BLOCK / 64; j++) {
-        const uint64_t word = w0 + j < nWords ? bv[w0 + j] : 0ull;
-        out[blk * 8 + j] = word;
-        if (j) subs |= run << ((j - 1u) * 9u);
-        run += (uint64_t)__popcll((unsigned long long)word);
-    }
-    out[blk * 8 + 6] = before;
-    out[blk * 8 + 7] = subs;
 }
 
 // k-mer table: entry `key` = ranges of the k-mer after `kmerSize` forward extensions from the
@@ -360,8 +359,8 @@ __device__ __forceinline__ bool takeExtend(const DevIndex& ix, int mode, const R
         tr = parent.rev;
     }
     uint32_t Rb[4], Re[4];
-    ranksFromRaw(v, tr.b, Rb);
-    ranksFromRaw(v + 2, tr.e, Re);
+    ranksFromRaw(v, tr.b, t.dollarPos, Rb);
+    ranksFromRaw(v + 2, tr.e, t.dollarPos, Re);
     return childFromRanks(ix, mode, parent, code, Rb, Re, tr.b > t.dollarPos ? 1u : 0u, tr.e > t.dollarPos ? 1u : 0u,
                           child);
 }

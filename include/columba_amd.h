@@ -80,7 +80,7 @@ uint64_t cmb_index_device_bytes(const cmb_index* idx);
  * an index with empty arrays of the same sizes (cmb_index_create_empty), all ranks hand the raw device pointers
  * (cmb_index_device_arrays) to the collective library — one broadcast per array straight into the index, no host
  * round trip, no second re-layout. */
-#define CMB_DEV_ARRAYS 7 /* rank blocks fwd, rank blocks rev, sampled-row records, SA samples, text codes, 2-bit text, k-mer table */
+#define CMB_DEV_ARRAYS 6 /* rank blocks fwd (with the sampled-row bits of the sparse suffix array), rank blocks rev, SA samples, text codes, 2-bit text, k-mer table */
 typedef struct {
     uint64_t text_length;
     uint64_t counts[5];
