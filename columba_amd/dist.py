@@ -47,9 +47,9 @@ def broadcast_index(ix: Optional[ib.IndexArrays], rank: int, dev) -> ib.IndexArr
 
 
 def broadcast_device_index(index, rank: int, device: int = 0):
-    """Replicate the DEVICE layout of rank 0's index on every rank: the 32-byte rank blocks, sampled-row records,
-    samples, text codes, 2-bit text and k-mer table are broadcast straight into the arrays of an empty twin index
-    (one collective per array, 12.5 GB for a 3 Gbp reference; per-link bound on xGMI) — no host round trip and no
+    """Replicate the DEVICE layout of rank 0's index on every rank: the 32-byte rank blocks (the forward ones carry the
+    sampled-row bits), samples, text codes, 2-bit text and k-mer table are broadcast straight into the arrays of an empty twin index
+    (one collective per array, 12.8 GB for a 3 Gbp reference; per-link bound on xGMI) — no host round trip and no
     second re-layout.  `index` is a columba_amd.Index on rank 0 and ignored elsewhere."""
     import ctypes as C
     import torch.distributed as dist
@@ -68,6 +68,36 @@ def broadcast_device_index(index, rank: int, device: int = 0):
     if rank != 0:
         index.validate()   # (a truncated or mixed-up transfer would otherwise hang the first locate)
     return index
+
+
+MOVE_FIELDS = ["lfbp_fwd", "lfbp_rev", "smpf", "smpl", "rev_smpf", "rev_smpl", "pred_first", "first_to_run", "pred_last",
+               "last_to_run", "plcp", "sa", "rev_sa", "text"]
+
+
+def broadcast_move_arrays(mv, rank: int, dev):
+    """Replicate the parts of a b-move index (columba_amd.movebuild.MoveArrays: the two .LFBP files, samples, locate arrays)
+    held by rank 0 on every rank, one broadcast per array; every rank then creates its own columba_amd.MoveIndex from them
+    (cmb_move_create converts and checks the tables on its GPU).  The index is read-only and replicated, as the FM-index is."""
+    import torch.distributed as dist
+    from .movebuild import MoveArrays
+    meta = [None]
+    if rank == 0:
+        meta = [{"n": mv.n, "shapes": {f: (tuple(getattr(mv, f).shape), str(getattr(mv, f).dtype)) for f in MOVE_FIELDS}}]
+    dist.broadcast_object_list(meta, src=0)
+    m = meta[0]
+    arrays = {}
+    for f in MOVE_FIELDS:
+        shape, dt = m["shapes"][f]
+        nbytes = int(np.prod(shape)) * np.dtype(dt).itemsize
+        if rank == 0:
+            t = torch.from_numpy(np.ascontiguousarray(getattr(mv, f)).view(np.uint8).reshape(-1).copy()).to(dev)
+        else:
+            t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if nbytes:
+            dist.broadcast(t, src=0)
+        arrays[f] = getattr(mv, f) if rank == 0 else t.cpu().numpy().view(dt).reshape(shape)
+        del t
+    return mv if rank == 0 else MoveArrays(n=m["n"], **arrays)
 
 
 def _wire(dev):

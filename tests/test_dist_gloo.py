@@ -90,3 +90,46 @@ def test_shard_bounds_cover_everything():
             spans = [ca.shard_bounds(n, w, r) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _move_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+    import columba_amd as ca
+    from columba_amd import movebuild
+    from columba_amd.dist import broadcast_move_arrays
+    import oracle_py as op
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(9)
+    text = np.frombuffer(b"ACGT", dtype=np.uint8)[np.tile(rng.integers(0, 4, 700), 6)]
+    text = text.copy()
+    text[rng.integers(0, text.shape[0], 40)] = ord("A")
+    mv = movebuild.build_move(text.tobytes()) if rank == 0 else None
+    mv = broadcast_move_arrays(mv, rank, "cpu")
+    # every rank matches its shard of the reads on its replica (the oracle stands in for the GPU in the CPU suite)
+    t = mv.text.tobytes()
+    reads = [t[p:p + 25] for p in range(0, 2000, 10)]
+    lo, hi = ca.shard_bounds(len(reads), world, rank)
+    occ, offs, cnt = op.OracleMoveIndex(mv).match_exact(reads[lo:hi])
+    np.save(os.path.join(tmp, f"mv_occ{rank}.npy"), occ)
+    np.save(os.path.join(tmp, f"mv_cnt{rank}.npy"), np.array([cnt["NODE_COUNTER"], cnt["TOTAL_REPORTED_POSITIONS"], lo, hi]))
+    if rank == 0:
+        o_all, _, c_all = op.OracleMoveIndex(mv).match_exact(reads)
+        np.save(os.path.join(tmp, "mv_all.npy"), o_all)
+        np.save(os.path.join(tmp, "mv_call.npy"), np.array([c_all["NODE_COUNTER"], c_all["TOTAL_REPORTED_POSITIONS"]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_move_index_replication(tmp_path, oracle_built):
+    """the b-move index parts broadcast from rank 0: both replicas answer their read shards; shards in rank order = one run"""
+    world = 2
+    mp.spawn(_move_worker, args=(world, 29519, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"mv_occ{r}.npy") for r in range(world)]
+    cnts = [np.load(tmp_path / f"mv_cnt{r}.npy") for r in range(world)]
+    assert np.array_equal(np.concatenate(parts), np.load(tmp_path / "mv_all.npy")) and sum(p.shape[0] for p in parts) > 500
+    assert [int(sum(c[i] for c in cnts)) for i in (0, 1)] == [int(v) for v in np.load(tmp_path / "mv_call.npy")]
+    assert int(cnts[0][3]) == int(cnts[1][2])
