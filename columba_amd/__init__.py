@@ -716,7 +716,7 @@ class MoveIndex:
         o = np.zeros(len(reads) + 1, dtype=np.uint64)
         cnt = np.zeros(2, dtype=np.uint64)
         n_occ = C.c_uint64()
-        cap = max(1024, 2 * len(reads))
+        cap = max(1024, 64 * len(reads))  # (a second pass only for chunks with more occurrences than that)
         while True:
             occ = np.zeros(cap, dtype=MOVE_OCC_DTYPE)
             rc = lib().cmb_move_match_exact(self.h, _p(buf), _p(offs), len(reads), _p(occ), cap, _p(o), C.byref(n_occ), _p(cnt))
