@@ -48,7 +48,7 @@ EXPORTS = [
     "cmb_read_prepare", "cmb_batch_sam", "cmb_batch_filter_per_strand", "cmb_match_best", "cmb_best_sizes", "cmb_best_results",
     "cmb_best_destroy",
     "cmb_move_create", "cmb_move_destroy", "cmb_move_device_bytes", "cmb_move_info", "cmb_move_complete_range", "cmb_move_rows",
-    "cmb_move_extend_batch", "cmb_move_extend_bench", "cmb_move_locate_batch", "cmb_move_match_exact", "cmb_move_last_timings",
+    "cmb_move_extend_batch", "cmb_move_extend_bench", "cmb_move_locate_batch", "cmb_move_match_exact", "cmb_move_last_timings", "cmb_move_kmer_table",
     "cmb_last_error", "cmb_version",
 ]
 
@@ -217,6 +217,7 @@ def lib():
         L.cmb_move_locate_batch.argtypes = [vp, vp, u64, vp, vp]
         L.cmb_move_match_exact.argtypes = [vp, vp, vp, u64, vp, u64, vp, C.POINTER(u64), vp]
         L.cmb_move_last_timings.argtypes = [vp, u32]
+        L.cmb_move_kmer_table.argtypes = [vp, u32, vp]
         _lib = L
     return _lib
 
@@ -728,3 +729,8 @@ class MoveIndex:
             _chk(lib().cmb_move_last_timings(_p(ms), 3))
             self.last_ms = {"extend": float(ms[0]), "scan": float(ms[1]), "locate": float(ms[2])}
             return occ[:n_occ.value], o, {"NODE_COUNTER": int(cnt[0]), "TOTAL_REPORTED_POSITIONS": int(cnt[1])}
+
+    def kmer_table(self, word_size: int) -> np.ndarray:
+        out = np.zeros(4 ** word_size, dtype=MOVE_RANGE_DTYPE)
+        _chk(lib().cmb_move_kmer_table(self.h, word_size, _p(out)))
+        return out

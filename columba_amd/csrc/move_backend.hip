@@ -439,3 +439,20 @@ extern "C" int cmb_move_match_exact(const cmb_move_index* idx, const char* reads
         return failWith(CMB_ERR_DEVICE, e.what());
     }
 }
+
+// IndexInterface::populateTable of the RLC flavour (indexinterface.cpp:294-335)
+extern "C" int cmb_move_kmer_table(const cmb_move_index* idx, uint32_t word_size, cmb_move_range* out) {
+    if (!idx || !out || word_size > 12) return failWith(CMB_ERR_INVALID, "bad argument (k-mer size up to 12)");
+    try {
+        MV_HIPCHK(hipSetDevice(idx->device));
+        const uint64_t total = 1ull << (2 * word_size);
+        MvBuf<MoveRangeRec> d;
+        d.alloc(total);
+        hipLaunchKernelGGL(k_move_kmer_table, dim3(gridFor(total)), dim3(256), 0, 0, idx->d, word_size, d.p);
+        MV_HIPCHK(hipGetLastError());
+        MV_HIPCHK(hipMemcpy(out, d.p, total * sizeof(MoveRangeRec), hipMemcpyDeviceToHost));
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return failWith(CMB_ERR_DEVICE, e.what());
+    }
+}

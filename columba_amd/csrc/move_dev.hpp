@@ -511,4 +511,32 @@ __global__ void k_move_read_offsets(const uint64_t* __restrict__ taskOff, uint64
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= nReads; i += (uint64_t)gridDim.x * blockDim.x) out[i] = taskOff[2 * i];
 }
 
+// IndexInterface::populateTable of the RLC flavour (indexinterface.cpp:294-335): entry `key` = the ranges of the k-mer after
+// wordSize forward extensions from the complete range, run indices of the SA range made exact (updateRangeSARuns); k-mers
+// that do not occur keep SARangePair().  Key: 2 bits per character, the first character in the highest bits.
+__global__ void k_move_kmer_table(const MoveDev ix, const uint32_t wordSize, MoveRangeRec* __restrict__ table) {
+    const uint64_t total = 1ull << (2 * wordSize);
+    for (uint64_t key = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; key < total; key += (uint64_t)gridDim.x * blockDim.x) {
+        MvPair cur;
+        cur.sa = {0, ix.n, 0, ix.fwd.runs - 1, true};
+        cur.rev = {0, ix.n, 0, ix.rev.runs - 1, true};
+        cur.toehold = ix.fwd.samplesLast[ix.fwd.runs - 1] - 1, cur.repEnd = false, cur.depth = 0;
+        bool ok = true;
+        for (int i = (int)wordSize - 1; i >= 0 && ok; i--) {
+            const uint32_t c = (uint32_t)((key >> (2 * i)) & 3u);
+            MvPair ch[4];
+            const uint32_t mask = moveChildren(ix, 0, cur, ch);
+            ok = mask >> c & 1u;
+            cur = c == 0 ? ch[0] : c == 1 ? ch[1] : c == 2 ? ch[2] : ch[3];
+        }
+        if (ok) computeRunIndices(ix.fwd, cur.sa);
+        else {
+            cur.sa = {0, 0, 0, 0, true};
+            cur.rev = cur.sa;
+            cur.toehold = 0, cur.repEnd = false, cur.depth = 0;
+        }
+        table[key] = storePair(cur);
+    }
+}
+
 } // namespace cmb

@@ -381,6 +381,9 @@ int cmb_move_extend_batch(const cmb_move_index* idx, int mode, const cmb_move_ra
 /* device-resident variant for the microbenchmark: average kernel time of `iters` launches (HIP events on the launch stream) */
 int cmb_move_extend_bench(const cmb_move_index* idx, int mode, const void* d_parents, uint64_t n, void* d_children, void* d_ok,
                           uint32_t iters, float* avg_ms);
+/* IndexInterface::populateTable of the RLC flavour (indexinterface.cpp:294-335): the ranges of all 4^word_size k-mers (key: two
+ * bits per character, the first character in the highest bits; SARangePair() for k-mers that do not occur) */
+int cmb_move_kmer_table(const cmb_move_index* idx, uint32_t word_size, cmb_move_range* out);
 /* text positions of n ranges in the reference's order (the toehold's occurrence, its phi chain, its phi^-1 chain):
  * range i writes end - begin values at positions[offsets[i]]; offsets has n + 1 entries */
 int cmb_move_locate_batch(const cmb_move_index* idx, const cmb_move_range* ranges, uint64_t n, const uint64_t* offsets, uint64_t* positions);

@@ -592,4 +592,10 @@ uint64_t orc_move_match_exact(void* h, const char* reads, const uint64_t* readOf
     return total;
 }
 
+// populateTable of the RLC flavour: 4^wordSize records
+void orc_move_kmer_table(void* h, uint32_t wordSize, orc_move_range* out) {
+    const auto t = ((orc::BMoveIndex64*)h)->kmerTable(wordSize);
+    for (size_t i = 0; i < t.size(); i++) out[i] = fromPair(t[i]);
+}
+
 } // extern "C"

@@ -415,6 +415,24 @@ template <typename L> class BMoveIndexT {
         MovePair p(range, MoveRange(), toehold, repEnd, depth);
         locate(p, positions); // getBeginPositions (bmove.cpp:562-575)
     }
+    // indexinterface.cpp:294-335 (populateTable, RLC branch): the ranges of every k-mer after `wordSize` forward extensions
+    // from the complete range, run indices of the SA range made exact (updateRangeSARuns -> computeRunIndices, bmove.cpp:272-274);
+    // key = 2 bits per character, first character in the highest bits; k-mers that do not occur keep SARangePair()
+    std::vector<MovePair> kmerTable(unsigned wordSize) const {
+        std::vector<MovePair> table((size_t)1 << (2 * wordSize));
+        for (size_t key = 0; key < table.size(); key++) {
+            MovePair cur = getCompleteRange(), next;
+            bool ok = true;
+            for (int i = (int)wordSize - 1; i >= 0 && ok; i--) {
+                ok = extendForward((L)((key >> (2 * i)) & 3) + 1, cur, next);
+                cur = next;
+            }
+            if (!ok) continue;
+            move.computeRunIndices(cur.sa);
+            table[key] = cur;
+        }
+        return table;
+    }
     bool extend(int mode, L c, const MovePair& parent, MovePair& child) const {
         return mode == 0 ? extendForward(c, parent, child) : mode == 1 ? extendBackward(c, parent, child) : extendBackwardUni(c, parent, child);
     }

@@ -106,6 +106,7 @@ def lib():
         L.orc_move_extend.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_move_match_exact.restype = C.c_uint64
         L.orc_move_match_exact.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.orc_move_kmer_table.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_move_locate.restype = C.c_uint64
         L.orc_move_locate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         _lib = L
@@ -404,3 +405,8 @@ class OracleMoveIndex:
             if tot <= cap:
                 return occ[:tot], o, {"NODE_COUNTER": int(cnt[0]), "TOTAL_REPORTED_POSITIONS": int(cnt[1])}
             cap = int(tot)
+
+    def kmer_table(self, word_size: int) -> np.ndarray:
+        out = np.zeros(4 ** word_size, dtype=MOVE_RANGE_DTYPE)
+        lib().orc_move_kmer_table(self.h, word_size, _p(out))
+        return out

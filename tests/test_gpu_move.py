@@ -227,3 +227,12 @@ def test_exact_matching_end_to_end(mworld):
                     k = t.find(pat, k + 1)
         got = [(int(o["begin"]), int(o["end"]), int(o["strand"])) for o in d_occ[int(d_off[i]):int(d_off[i + 1])]]
         assert sorted(got) == sorted(want), i
+
+
+def test_kmer_table(mworld):
+    """populateTable of the RLC flavour on the device: all 4^k entries equal to the oracle's, field by field"""
+    dev, orc = mworld["dev"], mworld["orc"]
+    for k in (1, 3, 6, 8):
+        d, o = dev.kmer_table(k), orc.kmer_table(k)
+        _same(d, o, ("kmer table", k))
+        assert (d["end"] > d["begin"]).sum() > min(4 ** k, 3000) * 0.9

@@ -198,3 +198,31 @@ def test_exact_matching_against_naive_search(small_world):
         assert [g[3] for g in got] == sorted(g[3] for g in got)
         hits += len(got) > 0
     assert hits > 80 and cnt["NODE_COUNTER"] > 1000
+
+
+def test_kmer_table_against_the_suffix_array(small_world):
+    """populateTable of the RLC flavour: every entry = the suffix-array intervals of its k-mer in both texts, exact run
+    indices of the SA range, a toehold that is an occurrence; absent k-mers are SARangePair()"""
+    w = small_world
+    orc, t, mv = w["orc"], w["t"], w["mv"]
+    starts = orc.rows(0)[:-1, 1]
+    for k in (1, 2, 4):
+        tab = orc.kmer_table(k)
+        present = 0
+        for key in range(4 ** k):
+            word = bytes(b"ACGT"[(key >> (2 * i)) & 3] for i in range(k - 1, -1, -1))
+            lo, hi = _interval(w["suf"], t, word)
+            e = tab[key]
+            if lo == hi:
+                assert int(e["begin"]) == 0 and int(e["end"]) == 0 and e["runs_valid"] == 1 and int(e["original_depth"]) == 0
+                continue
+            present += 1
+            assert (int(e["begin"]), int(e["end"])) == (lo, hi) and int(e["original_depth"]) == k
+            rlo, rhi = _interval(w["rsuf"], t[::-1], word[::-1])
+            assert (int(e["rev_begin"]), int(e["rev_end"])) == (rlo, rhi)
+            assert e["runs_valid"] == 1
+            assert int(e["begin_run"]) == np.searchsorted(starts, lo, side="right") - 1
+            assert int(e["end_run"]) == np.searchsorted(starts, hi - 1, side="right") - 1
+            start = int(e["toehold"]) - (k - 1 if e["toehold_represents_end"] else 0)
+            assert t[start:start + k] == word
+        assert present >= min(4 ** k, 200)
