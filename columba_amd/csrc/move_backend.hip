@@ -332,7 +332,7 @@ extern "C" int cmb_move_locate_batch(const cmb_move_index* idx, const cmb_move_r
         dpos.alloc(total);
         bad.alloc(1);
         MV_HIPCHK(hipMemset(bad.p, 0, sizeof(uint32_t)));
-        if (n) hipLaunchKernelGGL(k_move_locate, dim3(gridFor(n)), dim3(256), 0, 0, idx->d, din.p, n, doff.p, dpos.p - offsets[0], bad.p, false);
+        if (n) hipLaunchKernelGGL(k_move_locate, dim3(gridFor(n)), dim3(256), 0, 0, idx->d, din.p, n, doff.p, offsets[0], dpos.p, bad.p, false);
         MV_HIPCHK(hipGetLastError());
         uint32_t hb = 0;
         MV_HIPCHK(hipMemcpy(&hb, bad.p, sizeof(hb), hipMemcpyDeviceToHost));
@@ -423,7 +423,7 @@ extern "C" int cmb_move_match_exact(const cmb_move_index* idx, const char* reads
             MvBuf<MoveOccRec> dOcc;
             dOcc.alloc(total);
             MV_HIPCHK(hipEventRecord(ev[2], 0));
-            hipLaunchKernelGGL(k_move_locate, dim3(gridFor(nTasks)), dim3(256), 0, 0, idx->d, dRanges.p, nTasks, dTaskOff.p, dPos.p, bad.p, true);
+            hipLaunchKernelGGL(k_move_locate, dim3(gridFor(nTasks)), dim3(256), 0, 0, idx->d, dRanges.p, nTasks, dTaskOff.p, (uint64_t)0, dPos.p, bad.p, true);
             hipLaunchKernelGGL(k_move_occ, dim3(gridFor(total)), dim3(256), 0, 0, dPos.p, dTaskOff.p, nTasks, total, dOff.p, dOcc.p);
             MV_HIPCHK(hipGetLastError());
             MV_HIPCHK(hipEventRecord(ev[3], 0));

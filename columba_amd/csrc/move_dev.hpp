@@ -373,15 +373,15 @@ __global__ void k_move_extend(const MoveDev ix, const int mode, const MoveRangeR
 
 // hook: the text positions of every range (BMove::collectTextPositions, bmove.cpp:500-541, in the reference's order:
 // the toehold's position, its phi chain while PLCP >= depth, then the phi^-1 chain).  A range of width w writes w
-// positions at out[offsets[i]]; bad[0] counts ranges whose chain does not have exactly that length.
+// positions at out[offsets[i] - offsetBase]; bad[0] counts ranges whose chain does not have exactly that length.
 __global__ void k_move_locate(const MoveDev ix, const MoveRangeRec* __restrict__ ranges, uint64_t n, const uint64_t* __restrict__ offsets,
-                              uint64_t* __restrict__ out, uint32_t* __restrict__ bad, const bool skipEmpty) {
+                              const uint64_t offsetBase, uint64_t* __restrict__ out, uint32_t* __restrict__ bad, const bool skipEmpty) {
     const uint64_t stop = ix.fwd.samplesLast[ix.fwd.runs - 1]; // getInitialToehold() + 1 (bmove.h:139-142)
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const MoveRangeRec q = ranges[i];
         const uint64_t width = q.end - q.begin, depth = q.depth;
         if (skipEmpty && width == 0) continue;
-        uint64_t* o = out + offsets[i];
+        uint64_t* o = out + (offsets[i] - offsetBase);
         const uint64_t firstPos = q.toehold - (q.repEnd ? depth - 1 : 0); // bmove.cpp:553-556
         if (depth == 0 || width == 0 || firstPos >= ix.n) {
             atomicAdd(&bad[0], 1u);
