@@ -49,6 +49,7 @@ EXPORTS = [
     "cmb_best_destroy",
     "cmb_move_create", "cmb_move_destroy", "cmb_move_device_bytes", "cmb_move_info", "cmb_move_complete_range", "cmb_move_rows",
     "cmb_move_extend_batch", "cmb_move_extend_bench", "cmb_move_locate_batch", "cmb_move_match_exact", "cmb_move_last_timings", "cmb_move_kmer_table",
+    "cmb_move_layout_of", "cmb_move_create_empty", "cmb_move_device_arrays", "cmb_move_validate",
     "cmb_last_error", "cmb_version",
 ]
 
@@ -108,6 +109,16 @@ class _MoveDesc(C.Structure):
         ("pred_first", C.c_void_p), ("first_to_run", C.c_void_p), ("pred_last", C.c_void_p), ("last_to_run", C.c_void_p),
         ("plcp_pos", C.c_void_p), ("plcp_sum", C.c_void_p), ("n_plcp", C.c_uint64),
     ]
+
+
+MOVE_DEV_ARRAYS = 15
+
+
+class MoveLayout(C.Structure):
+    """cmb_move_layout (include/columba_amd.h): everything but the array contents of a device b-move index"""
+    _fields_ = [("text_length", C.c_uint64), ("runs", C.c_uint64 * 2), ("zero_char_pos", C.c_uint64 * 2),
+                ("set_count", C.c_uint64 * 3), ("set_shift", C.c_uint32 * 3), ("has_locate", C.c_uint32),
+                ("bytes", C.c_uint64 * MOVE_DEV_ARRAYS)]
 
 
 DEV_ARRAYS = 6
@@ -218,6 +229,10 @@ def lib():
         L.cmb_move_match_exact.argtypes = [vp, vp, vp, u64, vp, u64, vp, C.POINTER(u64), vp]
         L.cmb_move_last_timings.argtypes = [vp, u32]
         L.cmb_move_kmer_table.argtypes = [vp, u32, vp]
+        L.cmb_move_layout_of.argtypes = [vp, C.POINTER(MoveLayout)]
+        L.cmb_move_create_empty.argtypes = [C.POINTER(MoveLayout), i32, C.POINTER(vp)]
+        L.cmb_move_device_arrays.argtypes = [vp, C.POINTER(vp * MOVE_DEV_ARRAYS), C.POINTER(u64 * MOVE_DEV_ARRAYS)]
+        L.cmb_move_validate.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -644,8 +659,15 @@ class MoveIndex:
     """Device-resident b-move index (cmb_move_index) over the arrays of columba_amd.movebuild.build_move, or any object
     with the same members read from the reference's files."""
 
-    def __init__(self, mv, device: int = 0, with_locate: bool = True, length_bits: int = 64):
+    def __init__(self, mv, device: int = 0, with_locate: bool = True, length_bits: int = 64, _handle=None):
         L = lib()
+        self.device = device
+        if _handle is not None:  # (the receiving side of a broadcast: MoveIndex.empty_like)
+            self.h = _handle
+            n, r, rr = C.c_uint64(), C.c_uint64(), C.c_uint64()
+            _chk(L.cmb_move_info(self.h, C.byref(n), C.byref(r), C.byref(rr)))
+            self.n, self.runs, self.rev_runs = n.value, r.value, rr.value
+            return
         keep = [np.ascontiguousarray(a) for a in (mv.lfbp_fwd, mv.lfbp_rev)]
         keep += [np.ascontiguousarray(a, dtype=np.uint64) for a in (mv.smpf, mv.smpl, mv.rev_smpf, mv.rev_smpl)]
         d = _MoveDesc()
@@ -678,6 +700,30 @@ class MoveIndex:
 
     def device_bytes(self) -> int:
         return int(lib().cmb_move_device_bytes(self.h))
+
+    def layout(self) -> MoveLayout:
+        lay = MoveLayout()
+        _chk(lib().cmb_move_layout_of(self.h, C.byref(lay)))
+        return lay
+
+    @classmethod
+    def empty_like(cls, layout: MoveLayout, device: int = 0) -> "MoveIndex":
+        """an index with the arrays of `layout` allocated but not filled (the receiving side of a broadcast)"""
+        h = C.c_void_p()
+        _chk(lib().cmb_move_create_empty(C.byref(layout), device, C.byref(h)))
+        return cls(None, device=device, _handle=h)
+
+    def validate(self):
+        """the consistency checks of cmb_move_create on arrays that were filled by a collective"""
+        _chk(lib().cmb_move_validate(self.h))
+
+    def device_tensors(self):
+        """the device arrays of the index as flat uint8 torch tensors sharing the library's memory (no copy)"""
+        import torch
+        ptrs, nbytes = (C.c_void_p * MOVE_DEV_ARRAYS)(), (C.c_uint64 * MOVE_DEV_ARRAYS)()
+        _chk(lib().cmb_move_device_arrays(self.h, C.byref(ptrs), C.byref(nbytes)))
+        return [torch.as_tensor(_DevArray(int(ptrs[i]), int(nbytes[i]), self), device=torch.device("cuda", self.device)) if nbytes[i] else None
+                for i in range(MOVE_DEV_ARRAYS)]
 
     def complete_range(self) -> np.ndarray:
         out = np.zeros(1, dtype=MOVE_RANGE_DTYPE)

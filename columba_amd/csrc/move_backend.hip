@@ -94,6 +94,21 @@ struct cmb_move_index {
     MoveDev d{};
 };
 
+static void bindMoveDev(cmb_move_index* ix) { // MoveDev pointers from the owning buffers
+    ix->d = MoveDev{};
+    ix->d.n = ix->n;
+    ix->d.fwd = ix->tab[0].dev();
+    ix->d.rev = ix->tab[1].dev();
+    if (ix->hasLocate) {
+        ix->d.predFirst = ix->predFirst.dev();
+        ix->d.predLast = ix->predLast.dev();
+        ix->d.plcpPos = ix->plcpPos.dev();
+        ix->d.firstToRun = ix->firstToRun.p;
+        ix->d.lastToRun = ix->lastToRun.p;
+        ix->d.plcpSum = ix->plcpSum.p;
+    }
+}
+
 // one .LFBP file (moverepr.cpp:103-168) -> 16-byte rows in HBM, checked
 static void loadTable(TableHost& t, const uint8_t* file, uint64_t fileBytes, uint32_t lengthBits, const uint64_t* smpF,
                       const uint64_t* smpL, uint64_t& nOut, uint32_t* dFlags, const char* what) {
@@ -169,17 +184,7 @@ extern "C" int cmb_move_create(const cmb_move_desc* desc, int device, cmb_move_i
             return failWith(CMB_ERR_INVALID, "inconsistent move table (" + std::to_string(h[0]) + " rows of .LFBP, " + std::to_string(h[1]) +
                                                  " rows of .rev.LFBP break the order of the runs, the LF targets or the terminating row)");
         if (h[2]) return failWith(CMB_ERR_INVALID, "inconsistent locate arrays (positions not increasing / outside the text, or run numbers outside the table)");
-        ix->d.n = ix->n;
-        ix->d.fwd = ix->tab[0].dev();
-        ix->d.rev = ix->tab[1].dev();
-        if (loc) {
-            ix->d.predFirst = ix->predFirst.dev();
-            ix->d.predLast = ix->predLast.dev();
-            ix->d.plcpPos = ix->plcpPos.dev();
-            ix->d.firstToRun = ix->firstToRun.p;
-            ix->d.lastToRun = ix->lastToRun.p;
-            ix->d.plcpSum = ix->plcpSum.p;
-        }
+        bindMoveDev(ix.get());
         *out = ix.release();
         return CMB_OK;
     } catch (const std::invalid_argument& e) {
@@ -451,6 +456,129 @@ extern "C" int cmb_move_kmer_table(const cmb_move_index* idx, uint32_t word_size
         hipLaunchKernelGGL(k_move_kmer_table, dim3(gridFor(total)), dim3(256), 0, 0, idx->d, word_size, d.p);
         MV_HIPCHK(hipGetLastError());
         MV_HIPCHK(hipMemcpy(out, d.p, total * sizeof(MoveRangeRec), hipMemcpyDeviceToHost));
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return failWith(CMB_ERR_DEVICE, e.what());
+    }
+}
+
+// ---- replication of a built index on other GPUs: the DEVICE layout travels (as for the FM-index, cmb_index_layout_of ...) ----
+namespace {
+struct MvArrayRef {
+    void** p;
+    size_t* n;
+    size_t elem;
+};
+void moveArrays(cmb_move_index* ix, MvArrayRef out[CMB_MOVE_DEV_ARRAYS]) {
+    int k = 0;
+    for (int t = 0; t < 2; t++) {
+        out[k++] = {(void**)&ix->tab[t].rows.p, &ix->tab[t].rows.n, sizeof(uint4)};
+        out[k++] = {(void**)&ix->tab[t].smpF.p, &ix->tab[t].smpF.n, sizeof(uint64_t)};
+        out[k++] = {(void**)&ix->tab[t].smpL.p, &ix->tab[t].smpL.n, sizeof(uint64_t)};
+    }
+    PosSetHost* sets[3] = {&ix->predFirst, &ix->predLast, &ix->plcpPos};
+    for (auto* ps : sets) {
+        out[k++] = {(void**)&ps->pos.p, &ps->pos.n, sizeof(uint64_t)};
+        out[k++] = {(void**)&ps->dir.p, &ps->dir.n, sizeof(uint64_t)};
+    }
+    out[k++] = {(void**)&ix->firstToRun.p, &ix->firstToRun.n, sizeof(uint64_t)};
+    out[k++] = {(void**)&ix->lastToRun.p, &ix->lastToRun.n, sizeof(uint64_t)};
+    out[k++] = {(void**)&ix->plcpSum.p, &ix->plcpSum.n, sizeof(uint64_t)};
+}
+} // namespace
+
+extern "C" int cmb_move_layout_of(const cmb_move_index* idx, cmb_move_layout* out) {
+    if (!idx || !out) return failWith(CMB_ERR_INVALID, "bad argument");
+    std::memset(out, 0, sizeof(*out));
+    out->text_length = idx->n;
+    for (int t = 0; t < 2; t++) out->runs[t] = idx->tab[t].runs, out->zero_char_pos[t] = idx->tab[t].zeroCharPos;
+    out->has_locate = idx->hasLocate;
+    const PosSetHost* sets[3] = {&idx->predFirst, &idx->predLast, &idx->plcpPos};
+    for (int i = 0; i < 3; i++) out->set_count[i] = sets[i]->count, out->set_shift[i] = sets[i]->shift;
+    MvArrayRef a[CMB_MOVE_DEV_ARRAYS];
+    moveArrays(const_cast<cmb_move_index*>(idx), a);
+    for (int i = 0; i < CMB_MOVE_DEV_ARRAYS; i++) out->bytes[i] = *a[i].p ? (uint64_t)(*a[i].n * a[i].elem) : 0;
+    return CMB_OK;
+}
+
+extern "C" int cmb_move_create_empty(const cmb_move_layout* L, int device, cmb_move_index** out) {
+    if (!L || !out) return failWith(CMB_ERR_INVALID, "bad argument");
+    if (L->text_length < 2 || L->text_length >= (1ull << 40) || L->runs[0] < 2 || L->runs[1] < 2) return failWith(CMB_ERR_INVALID, "move index layout out of range");
+    *out = nullptr;
+    try {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
+            return failWith(CMB_ERR_DEVICE, "no such GPU (the move tables live in HBM; there is no CPU path)");
+        MV_HIPCHK(hipSetDevice(device));
+        std::unique_ptr<cmb_move_index> ix(new cmb_move_index());
+        ix->device = device;
+        ix->n = L->text_length;
+        ix->hasLocate = L->has_locate != 0;
+        for (int t = 0; t < 2; t++) ix->tab[t].runs = L->runs[t], ix->tab[t].zeroCharPos = L->zero_char_pos[t];
+        PosSetHost* sets[3] = {&ix->predFirst, &ix->predLast, &ix->plcpPos};
+        for (int i = 0; i < 3; i++) sets[i]->count = L->set_count[i], sets[i]->shift = L->set_shift[i];
+        MvArrayRef a[CMB_MOVE_DEV_ARRAYS];
+        moveArrays(ix.get(), a);
+        for (int i = 0; i < CMB_MOVE_DEV_ARRAYS; i++) {
+            if (L->bytes[i] % a[i].elem) return failWith(CMB_ERR_INVALID, "move index layout: array size is not a whole number of elements");
+            if (L->bytes[i] == 0) continue; // absent (an index without the locate arrays)
+            MV_HIPCHK(hipMalloc(a[i].p, L->bytes[i]));
+            *a[i].n = L->bytes[i] / a[i].elem;
+        }
+        // sizes must fit what the kernels index
+        bool okSizes = true;
+        for (int t = 0; t < 2; t++)
+            okSizes = okSizes && ix->tab[t].rows.n >= ix->tab[t].runs + 2 && ix->tab[t].smpF.n >= ix->tab[t].runs && ix->tab[t].smpL.n >= ix->tab[t].runs;
+        if (ix->hasLocate) {
+            for (int i = 0; i < 3; i++)
+                okSizes = okSizes && sets[i]->shift < 41 && sets[i]->pos.n >= sets[i]->count && sets[i]->dir.n >= (ix->n >> sets[i]->shift) + 2 && sets[i]->count >= 1;
+            okSizes = okSizes && ix->firstToRun.n >= ix->predFirst.count && ix->lastToRun.n >= ix->predLast.count && ix->plcpSum.n >= ix->plcpPos.count &&
+                      ix->predFirst.count == ix->tab[0].runs && ix->predLast.count == ix->tab[0].runs;
+        }
+        if (!okSizes) return failWith(CMB_ERR_INVALID, "move index layout: array sizes do not fit the numbers of runs / samples");
+        bindMoveDev(ix.get());
+        *out = ix.release();
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return failWith(CMB_ERR_DEVICE, e.what());
+    }
+}
+
+extern "C" int cmb_move_device_arrays(cmb_move_index* idx, void** ptrs, uint64_t* bytes) {
+    if (!idx || !ptrs || !bytes) return failWith(CMB_ERR_INVALID, "bad argument");
+    MvArrayRef a[CMB_MOVE_DEV_ARRAYS];
+    moveArrays(idx, a);
+    for (int i = 0; i < CMB_MOVE_DEV_ARRAYS; i++) {
+        ptrs[i] = *a[i].p;
+        bytes[i] = *a[i].p ? (uint64_t)(*a[i].n * a[i].elem) : 0;
+    }
+    return CMB_OK;
+}
+
+// the checks of cmb_move_create on arrays that arrived through a collective
+extern "C" int cmb_move_validate(cmb_move_index* idx) {
+    if (!idx) return failWith(CMB_ERR_INVALID, "bad argument");
+    try {
+        MV_HIPCHK(hipSetDevice(idx->device));
+        MvBuf<uint32_t> flags;
+        flags.alloc(4);
+        MV_HIPCHK(hipMemset(flags.p, 0, 4 * sizeof(uint32_t)));
+        for (int t = 0; t < 2; t++)
+            hipLaunchKernelGGL(k_move_check, dim3(gridFor(idx->tab[t].runs + 1)), dim3(256), 0, 0, idx->tab[t].rows.p, idx->tab[t].runs, idx->n, flags.p + t);
+        if (idx->hasLocate) {
+            const PosSetHost* sets[3] = {&idx->predFirst, &idx->predLast, &idx->plcpPos};
+            for (auto* ps : sets) hipLaunchKernelGGL(k_posset_check, dim3(gridFor(ps->count)), dim3(256), 0, 0, ps->pos.p, ps->count, idx->n, flags.p + 2);
+            const uint64_t r = idx->tab[0].runs;
+            hipLaunchKernelGGL(k_run_map_check, dim3(gridFor(r)), dim3(256), 0, 0, idx->firstToRun.p, r, r, flags.p + 2);
+            hipLaunchKernelGGL(k_run_map_check, dim3(gridFor(r)), dim3(256), 0, 0, idx->lastToRun.p, r, r, flags.p + 2);
+            for (auto* ps : sets) hipLaunchKernelGGL(k_posset_dir_check, dim3(gridFor((idx->n >> ps->shift) + 2)), dim3(256), 0, 0, ps->pos.p, ps->count, ps->shift, (idx->n >> ps->shift) + 1, ps->dir.p, flags.p + 3);
+        }
+        MV_HIPCHK(hipGetLastError());
+        uint32_t h[4];
+        MV_HIPCHK(hipMemcpy(h, flags.p, sizeof(h), hipMemcpyDeviceToHost));
+        if (h[0] || h[1] || h[2] || h[3])
+            return failWith(CMB_ERR_INVALID, "inconsistent move index arrays (" + std::to_string(h[0]) + " / " + std::to_string(h[1]) + " table rows, " +
+                                                 std::to_string(h[2]) + " locate entries, " + std::to_string(h[3]) + " directory entries)");
         return CMB_OK;
     } catch (const std::exception& e) {
         return failWith(CMB_ERR_DEVICE, e.what());

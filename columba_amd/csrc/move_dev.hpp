@@ -334,6 +334,14 @@ __global__ void k_posset_dir(const uint64_t* __restrict__ pos, uint64_t count, u
         dir[b] = lo;
     }
 }
+// a directory that arrived from elsewhere: the same values k_posset_dir would write
+__global__ void k_posset_dir_check(const uint64_t* __restrict__ pos, uint64_t count, uint32_t shift, uint64_t buckets, const uint64_t* __restrict__ dir,
+                                   uint32_t* __restrict__ flags) {
+    for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b <= buckets; b += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t x = b << shift, d = dir[b];
+        if (d > count || (d < count && pos[d] < x) || (d > 0 && pos[d - 1] >= x)) atomicAdd(&flags[0], 1u);
+    }
+}
 // strictly increasing?
 __global__ void k_posset_check(const uint64_t* __restrict__ pos, uint64_t count, uint64_t limit, uint32_t* __restrict__ flags) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x)

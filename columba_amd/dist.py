@@ -100,6 +100,27 @@ def broadcast_move_arrays(mv, rank: int, dev):
     return mv if rank == 0 else MoveArrays(n=m["n"], **arrays)
 
 
+def broadcast_device_move_index(index, rank: int, device: int = 0):
+    """Replicate the DEVICE layout of rank 0's b-move index on every rank: the 16-byte move rows of both directions, the
+    samples and the locate arrays with their directories are broadcast straight into the arrays of an empty twin
+    (cmb_move_layout_of / cmb_move_create_empty / cmb_move_device_arrays) — no second conversion of the .LFBP rows, no host
+    round trip.  `index` is a columba_amd.MoveIndex on rank 0 and ignored elsewhere; replicas are validated on arrival."""
+    import torch.distributed as dist
+    from . import MoveIndex, MoveLayout
+    meta = [None]
+    if rank == 0:
+        meta = [bytes(index.layout())]
+    dist.broadcast_object_list(meta, src=0)
+    if rank != 0:
+        index = MoveIndex.empty_like(MoveLayout.from_buffer_copy(meta[0]), device)
+    for t in index.device_tensors():
+        if t is not None:
+            dist.broadcast(t, src=0)
+    if rank != 0:
+        index.validate()
+    return index
+
+
 def _wire(dev):
     """the device collectives / point-to-point transfers run on: the GPU with RCCL ("nccl"); host memory with gloo,
     which serves scatter and send/recv for CPU tensors only (CPU tests, single-GPU rehearsals of the N > 1 path)"""

@@ -388,6 +388,24 @@ int cmb_move_kmer_table(const cmb_move_index* idx, uint32_t word_size, cmb_move_
  * range i writes end - begin values at positions[offsets[i]]; offsets has n + 1 entries */
 int cmb_move_locate_batch(const cmb_move_index* idx, const cmb_move_range* ranges, uint64_t n, const uint64_t* offsets, uint64_t* positions);
 
+/* replication on other GPUs, the DEVICE layout (as cmb_index_layout_of / cmb_index_create_empty / cmb_index_device_arrays for the
+ * FM-index): rank 0 describes its arrays, every other rank creates an index with empty arrays of those sizes, a collective per
+ * array fills them, cmb_move_validate repeats the consistency checks of cmb_move_create on what arrived. */
+#define CMB_MOVE_DEV_ARRAYS 15 /* per direction: rows, samplesFirst, samplesLast; predFirst, predLast, PLCP positions (values + directory each); firstToRun, lastToRun, PLCP sums */
+typedef struct {
+    uint64_t text_length;
+    uint64_t runs[2];          /* text, reversed text */
+    uint64_t zero_char_pos[2];
+    uint64_t set_count[3];     /* predFirst, predLast, PLCP run starts */
+    uint32_t set_shift[3];     /* bucket width (log2) of their directories */
+    uint32_t has_locate;
+    uint64_t bytes[CMB_MOVE_DEV_ARRAYS]; /* 0: absent (an index without the locate arrays) */
+} cmb_move_layout;
+int cmb_move_layout_of(const cmb_move_index* idx, cmb_move_layout* out);
+int cmb_move_create_empty(const cmb_move_layout* layout, int device, cmb_move_index** out);
+int cmb_move_device_arrays(cmb_move_index* idx, void** ptrs /* [CMB_MOVE_DEV_ARRAYS] */, uint64_t* bytes /* [CMB_MOVE_DEV_ARRAYS] */);
+int cmb_move_validate(cmb_move_index* idx);
+
 /* k = 0 on the b-move index, end to end: SearchStrategy::matchApproxAllMap with maxED = 0 (searchstrategy.cpp:499-510) =
  * IndexInterface::exactMatchesOutput (indexinterface.cpp:947-1014, RLC branch) of every read and of its reverse complement.
  * Reads as for cmb_match_batch (characters + n_reads + 1 offsets; lower case accepted, a read with anything outside ACGT
