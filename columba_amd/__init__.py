@@ -45,6 +45,7 @@ EXPORTS = [
     "cmb_batch_result_size", "cmb_batch_results", "cmb_batch_timings", "cmb_batch_destroy",
     "cmb_rank_batch", "cmb_extend_batch", "cmb_extend_bench", "cmb_locate_batch", "cmb_verify_batch", "cmb_verify_batch_staged", "cmb_verify_window", "cmb_cigar_windows",
     "cmb_batch_want_alignments", "cmb_batch_alignments", "cmb_sam_se", "cmb_sam_se_xa", "cmb_sam_unmapped_se",
+    "cmb_sam_pe", "cmb_sam_unpaired", "cmb_sam_unmapped_pe",
     "cmb_read_prepare", "cmb_batch_sam", "cmb_batch_filter_per_strand", "cmb_match_best", "cmb_best_sizes", "cmb_best_results",
     "cmb_best_destroy",
     "cmb_move_create", "cmb_move_destroy", "cmb_move_device_bytes", "cmb_move_info", "cmb_move_complete_range", "cmb_move_rows",
@@ -62,11 +63,12 @@ class CmbError(RuntimeError):
 
 def build_library(force: bool = False) -> str:
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU): one object per translation unit
-    (the matcher; the b-move backend), linked into one shared library."""
+    (the matcher; the b-move backend; the paired-end records), linked into one shared library."""
     csrc = os.path.join(_HERE, "csrc")
     header = os.path.join(os.path.dirname(_HERE), "include", "columba_amd.h")
-    units = {"columba_amd.hip": [f for f in os.listdir(csrc) if not f.startswith("move_")],
-             "move_backend.hip": [f for f in os.listdir(csrc) if f.startswith("move_")]}
+    units = {"columba_amd.hip": [f for f in os.listdir(csrc) if not f.startswith(("move_", "pair_"))],
+             "move_backend.hip": [f for f in os.listdir(csrc) if f.startswith("move_")],
+             "pair_sam.hip": [f for f in os.listdir(csrc) if f.startswith("pair_")] + ["host_sam.hpp"]}
     every = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [header]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in every):
         return LIB_PATH  # (the objects are build scratch: only the library travels to the GPU box)
@@ -204,6 +206,12 @@ def lib():
         L.cmb_sam_se.argtypes = [C.c_char_p, C.POINTER(SamHit), i32, u32, u32, C.c_char_p, C.c_char_p, vp, u64]
         L.cmb_sam_se_xa.restype = C.c_int64
         L.cmb_sam_se_xa.argtypes = [C.c_char_p, C.POINTER(SamHit), u32, u32, C.c_char_p, C.c_char_p, vp, u64]
+        L.cmb_sam_pe.restype = C.c_int64
+        L.cmb_sam_pe.argtypes = [C.c_char_p, C.POINTER(SamHit), i32, C.POINTER(SamHit), u32, u32, u32, i32, i32, C.c_char_p, C.c_char_p, vp, u64]
+        L.cmb_sam_unpaired.restype = C.c_int64
+        L.cmb_sam_unpaired.argtypes = [C.c_char_p, C.POINTER(SamHit), i32, u32, u32, i32, C.c_char_p, C.c_char_p, vp, u64]
+        L.cmb_sam_unmapped_pe.restype = C.c_int64
+        L.cmb_sam_unmapped_pe.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, i32, i32, i32, vp, u64]
         L.cmb_sam_unmapped_se.restype = C.c_int64
         L.cmb_sam_unmapped_se.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, vp, u64]
         L.cmb_read_prepare.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, vp, vp, vp, vp]
@@ -496,6 +504,26 @@ def sam_se_xa(read_id: str, hits, n_hits: int, seq: str, qual: str) -> str:
 
 def sam_unmapped_se(read_id: str, seq: str, qual: str) -> str:
     return _sam_call(lib().cmb_sam_unmapped_se, read_id.encode(), seq.encode(), qual.encode())
+
+
+def sam_pe(read_id: str, hit, first_in_pair: bool, mate, n_pairs: int, min_score: int, frag_size: int, discordant: bool, primary: bool,
+           seq: str, qual: str) -> str:
+    """one record of a paired read (TextOcc::generateSAMPairedEnd); mate = None: the mate is not mapped"""
+    h = _sam_hit(hit[0].encode(), *hit[1:])
+    m = _sam_hit(mate[0].encode(), *mate[1:]) if mate is not None else None
+    return _sam_call(lib().cmb_sam_pe, read_id.encode(), C.byref(h), int(first_in_pair), C.byref(m) if m is not None else None, n_pairs,
+                     min_score, frag_size, int(discordant), int(primary), seq.encode(), qual.encode())
+
+
+def sam_unpaired(read_id: str, hit, first_in_pair: bool, n_hits: int, min_score: int, primary: bool, seq: str, qual: str) -> str:
+    h = _sam_hit(hit[0].encode(), *hit[1:])
+    return _sam_call(lib().cmb_sam_unpaired, read_id.encode(), C.byref(h), int(first_in_pair), n_hits, min_score, int(primary),
+                     seq.encode(), qual.encode())
+
+
+def sam_unmapped_pe(read_id: str, seq: str, qual: str, first_in_pair: bool, mate_mapped: bool, mate_revcomp: bool) -> str:
+    return _sam_call(lib().cmb_sam_unmapped_pe, read_id.encode(), seq.encode(), qual.encode(), int(first_in_pair), int(mate_mapped),
+                     int(mate_revcomp))
 
 
 def read_prepare(read_id: str, seq: str, qual: str = ""):

@@ -263,6 +263,19 @@ int64_t cmb_sam_se(const char* read_id, const cmb_sam_hit* hit, int primary, uin
 int64_t cmb_sam_se_xa(const char* read_id, const cmb_sam_hit* hits, uint32_t n, uint32_t n_hits, const char* print_seq,
                       const char* print_qual, char* out, uint64_t cap);
 int64_t cmb_sam_unmapped_se(const char* read_id, const char* seq, const char* qual, char* out, uint64_t cap);
+/* --- paired-end records (the records only — the pairing of the mates' occurrences,
+ * src/searchstrategy.cpp:746-1820, stays with the caller).  mate = NULL: the mate is not mapped.  print_seq / print_qual as for
+ * cmb_sam_se (the read as it aligns; an empty quality prints as "*"). */
+/* TextOcc::generateSAMPairedEnd (indexhelpers.cpp:114-166) with getFlagsPE and getMapQPairedEnd (indexhelpers.h:340-371, :396-410) */
+int64_t cmb_sam_pe(const char* read_id, const cmb_sam_hit* hit, int first_in_pair, const cmb_sam_hit* mate, uint32_t n_pairs,
+                   uint32_t min_score, uint32_t frag_size, int discordant, int primary, const char* print_seq, const char* print_qual,
+                   char* out, uint64_t cap);
+/* TextOcc::generateSAMUnpaired (indexhelpers.cpp:215-262): an occurrence of a read whose pair could not be formed */
+int64_t cmb_sam_unpaired(const char* read_id, const cmb_sam_hit* hit, int first_in_pair, uint32_t n_hits, uint32_t min_score, int primary,
+                         const char* print_seq, const char* print_qual, char* out, uint64_t cap);
+/* TextOcc::createUnmappedSAMOccurrencePE (indexhelpers.cpp:186-213) */
+int64_t cmb_sam_unmapped_pe(const char* read_id, const char* seq, const char* qual, int first_in_pair, int mate_mapped, int mate_revcomp,
+                            char* out, uint64_t cap);
 /* SAM text of a whole chunk matched in ALL mode (SearchStrategy::generateOutputSingleEnd, src/searchstrategy.cpp:1824-1902:
  * sequence assignment incl. trimming at sequence ends, primary = first occurrence of minimal distance, the others as
  * secondary lines or, with xa_tag, in the primary's XA tag; unmapped_records: a flag-4 record for reads without any).

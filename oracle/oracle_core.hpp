@@ -491,6 +491,53 @@ inline std::string samUnmappedSE(const std::string& seqID, const std::string& re
     return seqID + "\t4\t*\t0\t0\t*\t*\t0\t0\t" + read + "\t" + qual + "\tPG:Z:Columba\n";
 }
 
+// SAM records of paired-end reads (indexhelpers.cpp:114-262; indexhelpers.h:340-371 getFlagsPE, :378-410 getMapQ /
+// getMapQPairedEnd).  A mate that is not mapped has valid = false (TextOcc::isValid: its range is empty).
+struct SamMate {
+    bool valid = false, revCompl = false, firstInPair = false;
+    std::string seqName;
+    len_t begin = 0, distance = 0;
+};
+inline std::string samPairedEnd(const std::string& seqID, const SamOcc& t, bool firstInPair, const SamMate& mate, len_t nPairs,
+                                len_t minScore, len_t fragSize, bool discordant, bool primary, const std::string& printSeq,
+                                std::string printQual) {
+    if (printQual.empty()) printQual = "*";
+    unsigned flags = 1;
+    flags |= (unsigned)(!discordant && mate.valid) << 1;
+    flags |= (unsigned)!mate.valid << 3;
+    flags |= (unsigned)t.revCompl << 4;
+    flags |= (unsigned)mate.revCompl << 5;
+    flags |= (unsigned)firstInPair << 6;
+    flags |= (unsigned)mate.firstInPair << 7;
+    flags |= (unsigned)!primary << 8;
+    int mapq = 0;
+    if (!(t.distance + mate.distance > minScore)) mapq = nPairs == 1 ? 60 : (int)std::round(-10.0 * std::log10(1 - 1.0 / nPairs));
+    std::ostringstream o;
+    o << seqID << '\t' << flags << '\t' << t.seqName << '\t' << (t.begin + 1) << '\t' << mapq << '\t' << t.cigar << '\t'
+      << (mate.valid ? mate.seqName : std::string("*")) << '\t' << (mate.valid ? mate.begin + 1 : 0) << '\t'
+      << (mate.valid && t.begin > mate.begin ? "-" : "") << (mate.valid ? fragSize : 0) << '\t' << printSeq << '\t' << printQual
+      << "\tAS:i:" << t.distance << "\tNM:i:" << t.distance << "\tPG:Z:Columba\n";
+    return o.str();
+}
+// indexhelpers.cpp:215-262 (generateSAMUnpaired: no strand flag; sequence and quality only on the primary line)
+inline std::string samUnpaired(const std::string& seqID, const SamOcc& t, bool firstInPair, len_t nHits, len_t minScore, bool primary,
+                               const std::string& printSeqPrimary, std::string printQualPrimary) {
+    std::string printSeq = primary ? printSeqPrimary : "*", printQual = primary ? printQualPrimary : "*";
+    if (printQual.empty()) printQual = "*";
+    const unsigned flags = (1u + (firstInPair ? 64u : 128u)) | ((unsigned)!primary << 8);
+    std::ostringstream o;
+    o << seqID << '\t' << flags << '\t' << t.seqName << '\t' << (t.begin + 1) << '\t' << samMapQ(t.distance, nHits, minScore) << '\t'
+      << t.cigar << "\t*\t0\t0\t" << printSeq << '\t' << printQual << "\tAS:i:" << t.distance << "\tNM:i:" << t.distance
+      << "\tPG:Z:Columba\n";
+    return o.str();
+}
+// indexhelpers.cpp:186-213 (createUnmappedSAMOccurrencePE)
+inline std::string samUnmappedPE(const std::string& seqID, const std::string& read, const std::string& qual, bool firstInPair,
+                                 bool mateMapped, bool mateRevCompl) {
+    const unsigned flags = 1u | 4u | (mateMapped ? 0u : 8u) | (mateRevCompl ? 32u : 0u) | (firstInPair ? 64u : 128u);
+    return seqID + "\t" + std::to_string(flags) + "\t*\t0\t0\t*\t*\t0\t0\t" + read + "\t" + qual + "\tPG:Z:Columba\n";
+}
+
 // ----------------------------------------------------------------------------
 // SparseSuffixArray (fmindex/suffixArray.h:160-243): rows whose suffix-array value is a
 // multiple of the sparseness factor are marked in a rank9 Bitvec (.sa.bv.<s>: N, words,

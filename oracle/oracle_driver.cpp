@@ -466,6 +466,56 @@ int main() {
                 if (c == '\t') c = '|';
                 else if (c == '\n') c = '~';
             os << line;
+        } else if (cmd == "sampe" || cmd == "samunpaired" || cmd == "samunpe") {
+            const vector<string> seqNames = {"chr1", "chr2_alt", "seqC"};
+            string id, rd, ql;
+            in >> id >> rd >> ql;
+            if (ql == "-") ql = "";
+            const string sid = cleanSeqID(id), read = cleanReadSeq(rd), rc = Matcher::revCompl(read);
+            string rq = ql;
+            std::reverse(rq.begin(), rq.end());
+            auto readOcc = [&]() {
+                uint32_t b, e, d, st, sq;
+                string cg;
+                in >> b >> e >> d >> cg >> st >> sq;
+                SamOcc t;
+                t.seqName = seqNames[sq];
+                t.cigar = cg;
+                t.begin = b;
+                t.distance = d;
+                t.revCompl = st != 0;
+                return t;
+            };
+            string line;
+            if (cmd == "samunpe") {
+                uint32_t first, mateMapped, mateRev;
+                in >> first >> mateMapped >> mateRev;
+                line = samUnmappedPE(sid, read, ql, first != 0, mateMapped != 0, mateRev != 0);
+            } else if (cmd == "samunpaired") {
+                uint32_t first, nHits, minScore, primary;
+                in >> first >> nHits >> minScore >> primary;
+                const SamOcc t = readOcc();
+                line = samUnpaired(sid, t, first != 0, nHits, minScore, primary != 0, t.revCompl ? rc : read, t.revCompl ? rq : ql);
+            } else {
+                uint32_t first, nPairs, minScore, fragSize, discordant, primary, mateMapped;
+                in >> first >> nPairs >> minScore >> fragSize >> discordant >> primary >> mateMapped;
+                const SamOcc t = readOcc();
+                SamMate m;
+                m.firstInPair = first == 0;
+                if (mateMapped) {
+                    const SamOcc mo = readOcc();
+                    m.valid = true, m.revCompl = mo.revCompl, m.seqName = mo.seqName, m.begin = mo.begin, m.distance = mo.distance;
+                } else {
+                    uint32_t mateRev;
+                    in >> mateRev; // (the unmapped mate lies on the forward strand with distance 0, indexhelpers.cpp:190-193)
+                }
+                line = samPairedEnd(sid, t, first != 0, m, nPairs, minScore, fragSize, discordant != 0, primary != 0, t.revCompl ? rc : read,
+                                    t.revCompl ? rq : ql);
+            }
+            for (auto& c : line)
+                if (c == '\t') c = '|';
+                else if (c == '\n') c = '~';
+            os << line;
         } else if (cmd == "consts") {
             os << BitParallelED64::MATRIX_MAX_ED << ' ' << BitParallelED64::LEFT << ' ' << 13 << ' ' << 10
                << ' ' << 4 << ' ' << sizeof(len_t);

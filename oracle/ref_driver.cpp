@@ -486,6 +486,54 @@ int main() {
                 if (c == '\t') c = '|';
                 else if (c == '\n') c = '~';
             os << line;
+        } else if (cmd == "sampe" || cmd == "samunpaired" || cmd == "samunpe") {
+            // SAM records of paired-end reads (indexhelpers.cpp:114-262; indexhelpers.h:340-371, :378-410): tabs printed as '|'
+            const vector<string> seqNames = {"chr1", "chr2_alt", "seqC"};
+            string id, rd, ql;
+            in >> id >> rd >> ql;
+            if (ql == "-") ql = "";
+            Read r(id, rd, ql);
+            ReadBundle bundle(r);
+            auto readOcc = [&](PairStatus ps) {
+                uint32_t b, e, d, st, sq;
+                string cg;
+                in >> b >> e >> d >> cg >> st >> sq;
+                TextOcc t(Range(b, e), d, cg, st ? REVERSE_C_STRAND : FORWARD_STRAND, ps);
+                t.setAssignedSequence(FOUND, sq);
+                return t;
+            };
+            string line;
+            if (cmd == "samunpe") { // first mateMapped mateRev
+                uint32_t first, mateMapped, mateRev;
+                in >> first >> mateMapped >> mateRev;
+                line = TextOcc::createUnmappedSAMOccurrencePE(bundle, first ? FIRST_IN_PAIR : SECOND_IN_PAIR, mateMapped != 0,
+                                                              mateRev ? REVERSE_C_STRAND : FORWARD_STRAND)
+                           .getOutputLine();
+            } else if (cmd == "samunpaired") { // first nHits minScore primary occ
+                uint32_t first, nHits, minScore, primary;
+                in >> first >> nHits >> minScore >> primary;
+                TextOcc t = readOcc(first ? FIRST_IN_PAIR : SECOND_IN_PAIR);
+                t.generateSAMUnpaired(bundle, nHits, minScore, primary != 0, seqNames);
+                line = t.getOutputLine();
+            } else { // first nPairs minScore fragSize discordant primary mateMapped occ [mateOcc | mateRev]
+                uint32_t first, nPairs, minScore, fragSize, discordant, primary, mateMapped;
+                in >> first >> nPairs >> minScore >> fragSize >> discordant >> primary >> mateMapped;
+                TextOcc t = readOcc(first ? FIRST_IN_PAIR : SECOND_IN_PAIR);
+                TextOcc mate;
+                if (mateMapped) mate = readOcc(first ? SECOND_IN_PAIR : FIRST_IN_PAIR);
+                else { // the unmapped mate as the reference creates it (searchstrategy.cpp:1463-1517)
+                    uint32_t mateRev;
+                    in >> mateRev;
+                    mate = TextOcc::createUnmappedSAMOccurrencePE(bundle, first ? SECOND_IN_PAIR : FIRST_IN_PAIR, true,
+                                                                  t.isRevCompl() ? REVERSE_C_STRAND : FORWARD_STRAND);
+                }
+                t.generateSAMPairedEnd(bundle, nPairs, minScore, mate, fragSize, discordant != 0, primary != 0, seqNames);
+                line = t.getOutputLine();
+            }
+            for (auto& c : line)
+                if (c == '\t') c = '|';
+                else if (c == '\n') c = '~';
+            os << line;
         } else if (cmd == "consts") {
             os << BitParallelED64::getMatrixMaxED() << ' ' << BitParallelED64::getMaxFirstColRows() << ' '
                << MAX_K << ' ' << CIGAR_THRESHOLD << ' ' << DEFAULT_SPARSENESS << ' ' << sizeof(length_t);

@@ -409,6 +409,28 @@ for _ in range(60):
     if rng4.random() < 0.5:
         cmds.append(f"matrix128 {X} {Y} {max_ed} {nz}")
 
+# f4: SAM records of paired-end reads (generateSAMPairedEnd, generateSAMUnpaired, createUnmappedSAMOccurrencePE)
+rng5 = random.Random(20261005)
+for _ in range(90):
+    rid = rng5.choice("@>") + "".join(rng5.choice("pairAB27:/") for _ in range(rng5.randint(1, 10)))
+    ln = rng5.randint(4, 40)
+    rd = "".join(rng5.choice("ACGTNacgt") for _ in range(ln))
+    ql = "".join(chr(rng5.randint(33, 73)) for _ in range(ln)) if rng5.random() < 0.85 else "-"
+
+    def occ5():
+        b = rng5.randint(0, 100000)
+        return f"{b} {b + ln} {rng5.randint(0, 6)} {rng5.choice(CIGS)} {rng5.randint(0, 1)} {rng5.randint(0, 2)}"
+    u = rng5.random()
+    first = rng5.randint(0, 1)
+    if u < 0.6:
+        mate_mapped = 1 if rng5.random() < 0.8 else 0
+        cmds.append(f"sampe {rid} {rd} {ql} {first} {rng5.randint(1, 30)} {rng5.randint(0, 12)} {rng5.randint(0, 900)} "
+                    f"{rng5.randint(0, 1)} {rng5.randint(0, 1)} {mate_mapped} {occ5()} " + (occ5() if mate_mapped else str(rng5.randint(0, 1))))
+    elif u < 0.85:
+        cmds.append(f"samunpaired {rid} {rd} {ql} {first} {rng5.randint(1, 30)} {rng5.randint(0, 6)} {rng5.randint(0, 1)} {occ5()}")
+    else:
+        cmds.append(f"samunpe {rid} {rd} {ql if ql != '-' else '*'} {first} {rng5.randint(0, 1)} {rng5.randint(0, 1)}")
+
 
 def main():
     if not os.path.exists(DRIVER):

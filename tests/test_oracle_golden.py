@@ -40,7 +40,7 @@ def test_vectors_are_not_vacuous():
     cmds, outs = _load()
     kinds = Counter(c.split(" ")[0] for c in cmds)
     for k in ("bwt", "bitvec9", "enc", "matrix", "traceback", "search", "scheme", "cluster", "verify",
-              "occsort", "revcomp", "ssa", "read", "kmer", "substr", "readscheme"):
+              "occsort", "revcomp", "ssa", "read", "kmer", "substr", "readscheme", "sampe", "samunpaired"):
         assert kinds[k] >= 10, k
     # every scheme file of the reference's search_schemes/ is read by the reference's own reader
     ok = sum(1 for c, o in zip(cmds, outs) if c.startswith("readscheme search_schemes/") and o.startswith("ok "))

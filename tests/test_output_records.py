@@ -61,6 +61,36 @@ def test_sam_lines_like_the_reference():
     assert seen["sam1"] >= 20 and seen["samxa"] >= 15 and seen["samun"] >= 2
 
 
+def test_paired_end_sam_lines_like_the_reference():
+    """generateSAMPairedEnd / generateSAMUnpaired / createUnmappedSAMOccurrencePE (90 vectors of the reference's own code)"""
+    seen = {"sampe": 0, "samunpaired": 0, "samunpe": 0}
+    flags = set()
+    for kind in seen:
+        for args, out in _vectors(kind):
+            want = out.replace("|", "\t").replace("~", "\n")
+            rid, seq, qual = args[:3]
+            qual = "" if qual == "-" else qual
+            sid, read, rc, rq = ca.read_prepare(rid, seq, qual)
+            if kind == "samunpe":
+                first, mate_mapped, mate_rev = map(int, args[3:6])
+                got = ca.sam_unmapped_pe(sid, read, qual, bool(first), bool(mate_mapped), bool(mate_rev))
+            elif kind == "samunpaired":
+                first, n_hits, min_score, primary = map(int, args[3:7])
+                h = _hit(args[7:13])
+                got = ca.sam_unpaired(sid, h, bool(first), n_hits, min_score, bool(primary), rc if h[3] else read, rq if h[3] else qual)
+            else:
+                first, n_pairs, min_score, frag, disc, primary, mate_mapped = map(int, args[3:10])
+                h = _hit(args[10:16])
+                mate = _hit(args[16:22]) if mate_mapped else None
+                got = ca.sam_pe(sid, h, bool(first), mate, n_pairs, min_score, frag, bool(disc), bool(primary),
+                                rc if h[3] else read, rq if h[3] else qual)
+            assert got == want, (kind, args)
+            flags.add(int(got.split("\t")[1]))
+            seen[kind] += 1
+    assert seen["sampe"] >= 40 and seen["samunpaired"] >= 12 and seen["samunpe"] >= 6
+    assert len(flags) >= 25  # proper / discordant pairs, both strands of read and mate, first / second, secondary, unmapped mates
+
+
 def test_cigar_string_round_trip():
     for cig in ("100M", "57M1I42M", "3M1D97M", "1I99M", "20M2I30M1D48M"):
         assert ca.cigar_string(ca.parse_cigar(cig)) == cig

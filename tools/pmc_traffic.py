@@ -14,8 +14,8 @@ def source_digest():  # the same digest bench.py computes: a profile only speaks
     h = hashlib.sha256()
     d = os.path.join(root, "columba_amd", "csrc")
     for fn in sorted(os.listdir(d)):
-        if fn.startswith("move_"):
-            continue  # the b-move backend: a translation unit of its own, none of the kernels timed here
+        if fn.startswith(("move_", "pair_")):
+            continue  # translation units of their own (b-move backend, paired-end records): none of the kernels timed here
         with open(os.path.join(d, fn), "rb") as f:
             h.update(fn.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
