@@ -45,7 +45,7 @@ EXPORTS = [
     "cmb_batch_result_size", "cmb_batch_results", "cmb_batch_timings", "cmb_batch_destroy",
     "cmb_rank_batch", "cmb_extend_batch", "cmb_extend_bench", "cmb_locate_batch", "cmb_verify_batch", "cmb_verify_batch_staged", "cmb_verify_window", "cmb_cigar_windows",
     "cmb_batch_want_alignments", "cmb_batch_alignments", "cmb_sam_se", "cmb_sam_se_xa", "cmb_sam_unmapped_se",
-    "cmb_sam_pe", "cmb_sam_unpaired", "cmb_sam_unmapped_pe",
+    "cmb_sam_pe", "cmb_sam_unpaired", "cmb_sam_unmapped_pe", "cmb_pair_sam",
     "cmb_read_prepare", "cmb_batch_sam", "cmb_batch_filter_per_strand", "cmb_match_best", "cmb_best_sizes", "cmb_best_results",
     "cmb_best_destroy",
     "cmb_move_create", "cmb_move_destroy", "cmb_move_device_bytes", "cmb_move_info", "cmb_move_complete_range", "cmb_move_rows",
@@ -144,6 +144,27 @@ class _DevArray:
         self._owner = owner
 
 
+class PairOcc(C.Structure):
+    """cmb_pair_occ"""
+    _fields_ = [("seq_id", C.c_uint32), ("begin", C.c_uint32), ("end", C.c_uint32), ("index_begin", C.c_uint32),
+                ("distance", C.c_uint32), ("strand", C.c_uint32), ("cigar_ops", C.c_void_p), ("n_ops", C.c_uint32)]
+
+
+class PairRead(C.Structure):
+    """cmb_pair_read"""
+    _fields_ = [("id", C.c_char_p), ("seq", C.c_char_p), ("revcomp", C.c_char_p), ("qual", C.c_char_p), ("revqual", C.c_char_p),
+                ("occ", C.POINTER(PairOcc)), ("n_occ", C.c_uint32)]
+
+
+class PairParams(C.Structure):
+    """cmb_pair_params"""
+    _fields_ = [("orientation", C.c_uint32), ("max_frag", C.c_uint32), ("min_frag", C.c_uint32), ("discordant_allowed", C.c_int),
+                ("unmapped_records", C.c_int)]
+
+
+ORIENTATION_FR, ORIENTATION_RF, ORIENTATION_FF = 0, 1, 2
+
+
 class SamHit(C.Structure):
     """cmb_sam_hit"""
     _fields_ = [("seq_name", C.c_char_p), ("pos0", C.c_uint32), ("distance", C.c_uint32), ("revcomp", C.c_uint32),
@@ -212,6 +233,8 @@ def lib():
         L.cmb_sam_unpaired.argtypes = [C.c_char_p, C.POINTER(SamHit), i32, u32, u32, i32, C.c_char_p, C.c_char_p, vp, u64]
         L.cmb_sam_unmapped_pe.restype = C.c_int64
         L.cmb_sam_unmapped_pe.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, i32, i32, i32, vp, u64]
+        L.cmb_pair_sam.restype = C.c_int64
+        L.cmb_pair_sam.argtypes = [C.POINTER(PairParams), C.POINTER(PairRead), C.POINTER(PairRead), vp, vp, u64, C.POINTER(u32)]
         L.cmb_sam_unmapped_se.restype = C.c_int64
         L.cmb_sam_unmapped_se.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, vp, u64]
         L.cmb_read_prepare.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, vp, vp, vp, vp]
@@ -524,6 +547,34 @@ def sam_unpaired(read_id: str, hit, first_in_pair: bool, n_hits: int, min_score:
 def sam_unmapped_pe(read_id: str, seq: str, qual: str, first_in_pair: bool, mate_mapped: bool, mate_revcomp: bool) -> str:
     return _sam_call(lib().cmb_sam_unmapped_pe, read_id.encode(), seq.encode(), qual.encode(), int(first_in_pair), int(mate_mapped),
                      int(mate_revcomp))
+
+
+def pair_sam(read1, read2, seq_names, orientation: int = ORIENTATION_FR, max_frag: int = 500, min_frag: int = 0,
+             discordant_allowed: bool = True, unmapped_records: bool = True):
+    """SAM text of one read pair in ALL mode (cmb_pair_sam).  read = (id, seq, revcomp, qual, revqual, occurrences) with
+    occurrences = [(seq_id or None, begin, end, index_begin, distance, strand, cigar ops)]; returns (text, TOTAL_UNIQUE_PAIRS)."""
+    keep = []
+
+    def mk(rd):
+        rid, seq, rc, qual, rq, occs = rd
+        arr = (PairOcc * max(len(occs), 1))()
+        for i, (sid, b, e, ib, d, st, ops) in enumerate(occs):
+            o = np.ascontiguousarray(ops, dtype=np.uint16)
+            keep.append(o)
+            arr[i] = PairOcc(0xFFFFFFFF if sid is None else sid, b, e, ib, d, st, o.ctypes.data, o.shape[0])
+        keep.append(arr)
+        return PairRead(rid.encode(), seq.encode(), rc.encode(), qual.encode(), rq.encode(), arr, len(occs))
+
+    r1, r2 = mk(read1), mk(read2)
+    names = (C.c_char_p * len(seq_names))(*[n.encode() for n in seq_names])
+    prm = PairParams(orientation, max_frag, min_frag, int(discordant_allowed), int(unmapped_records))
+    n_pairs = C.c_uint32()
+    n = lib().cmb_pair_sam(C.byref(prm), C.byref(r1), C.byref(r2), names, None, 0, C.byref(n_pairs))
+    if n < 0:
+        _chk(int(n))
+    buf = C.create_string_buffer(int(n) + 1)
+    lib().cmb_pair_sam(C.byref(prm), C.byref(r1), C.byref(r2), names, buf, int(n) + 1, C.byref(n_pairs))
+    return buf.value.decode(), int(n_pairs.value)
 
 
 def read_prepare(read_id: str, seq: str, qual: str = ""):

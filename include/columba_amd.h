@@ -276,6 +276,40 @@ int64_t cmb_sam_unpaired(const char* read_id, const cmb_sam_hit* hit, int first_
 /* TextOcc::createUnmappedSAMOccurrencePE (indexhelpers.cpp:186-213) */
 int64_t cmb_sam_unmapped_pe(const char* read_id, const char* seq, const char* qual, int first_in_pair, int mate_mapped, int mate_revcomp,
                             char* out, uint64_t cap);
+/* Pairing of the single-end occurrences of two mates in ALL mode and the SAM text of the pair:
+ * SearchStrategy::pairSingleEndedMatchesAll (src/searchstrategy.cpp:1345-1399: concordant pairs by orientation and fragment size,
+ * otherwise discordant pairs / unpaired records / one or both mates unmapped) with generateSAMPairedEnd (:1904-1970), lines in the
+ * order OutputWriter::writeChunks prints them (src/fastq.cpp:662-702).  The occurrences are the mates' ALL-mode results with their
+ * sequence assignment (cmb_batch_alignments). */
+#define CMB_ORIENTATION_FR 0 /* definitions.h:122 */
+#define CMB_ORIENTATION_RF 1
+#define CMB_ORIENTATION_FF 2
+typedef struct {
+    uint32_t seq_id;           /* assigned sequence; 0xFFFFFFFF: none (findSeqName returned NOT_FOUND) */
+    uint32_t begin, end;       /* inside that sequence, after trimming */
+    uint32_t index_begin;      /* begin in the concatenated text (TextOcc::getIndexBegin) */
+    uint32_t distance, strand; /* strand 0 forward, 1 reverse complement */
+    const uint16_t* cigar_ops; /* run-length operations as in cmb_sam_hit */
+    uint32_t n_ops;
+} cmb_pair_occ;
+typedef struct {
+    const char* id;      /* cleaned identifier (cmb_read_prepare) */
+    const char* seq;     /* cleaned read */
+    const char* revcomp; /* its reverse complement */
+    const char* qual;    /* may be NULL */
+    const char* revqual; /* reversed quality, may be NULL */
+    const cmb_pair_occ* occ;
+    uint32_t n_occ;
+} cmb_pair_read;
+typedef struct {
+    uint32_t orientation;       /* CMB_ORIENTATION_* */
+    uint32_t max_frag, min_frag;
+    int discordant_allowed;     /* -nD not given */
+    int unmapped_records;       /* records for unmapped reads (SearchStrategy::unmappedSAM) */
+} cmb_pair_params;
+/* returns the length of the text (written if cap is larger); n_pairs_out (may be NULL): TOTAL_UNIQUE_PAIRS of the pair */
+int64_t cmb_pair_sam(const cmb_pair_params* params, const cmb_pair_read* read1, const cmb_pair_read* read2, const char* const* seq_names,
+                     char* out, uint64_t cap, uint32_t* n_pairs_out);
 /* SAM text of a whole chunk matched in ALL mode (SearchStrategy::generateOutputSingleEnd, src/searchstrategy.cpp:1824-1902:
  * sequence assignment incl. trimming at sequence ends, primary = first occurrence of minimal distance, the others as
  * secondary lines or, with xa_tag, in the primary's XA tag; unmapped_records: a flag-4 record for reads without any).
