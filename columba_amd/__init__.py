@@ -859,3 +859,43 @@ class MoveIndex:
         out = np.zeros(4 ** word_size, dtype=MOVE_RANGE_DTYPE)
         _chk(lib().cmb_move_kmer_table(self.h, word_size, _p(out)))
         return out
+
+
+def pair_chunk_sam(index: "Index", strategy: "SearchStrategy", max_distance: int, reads1, reads2, ids1, ids2, quals1, quals2, seq_names,
+                   orientation: int = ORIENTATION_FR, max_frag: int = 500, min_frag: int = 0, discordant_allowed: bool = True,
+                   unmapped_records: bool = True):
+    """A chunk of read pairs in ALL mode, end to end: both mates through the GPU matcher (one batch each, with alignments), then
+    cmb_pair_sam per pair (SearchStrategy::pairSingleEndedMatchesAll on the mates' single-end results).  Occurrences that run
+    past the end of their sequence (cmb_aln.spans) take no part in the pairing.  Returns (SAM text, number of properly or
+    discordantly mapped pairs)."""
+    per_mate = []
+    for reads in (reads1, reads2):
+        b = Batch(index, strategy, max_distance, reads=reads)
+        b.want_alignments()
+        b.run()
+        occ, offs, _ = b.results()
+        aln, ops = b.alignments()
+        per_mate.append((occ, offs, aln, ops))
+        b.close() if hasattr(b, "close") else None
+    starts = index.seq_starts()
+    text, mapped_pairs = [], 0
+    for i in range(len(reads1)):
+        rd = []
+        for m, (reads, ids, quals) in enumerate(((reads1, ids1, quals1), (reads2, ids2, quals2))):
+            occ, offs, aln, ops = per_mate[m]
+            sid, seq, rc, rq = read_prepare(ids[i], reads[i].decode() if isinstance(reads[i], bytes) else reads[i], quals[i])
+            lst = []
+            for j in range(int(offs[i]), int(offs[i + 1])):
+                a = aln[j]
+                o = ops[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])]
+                width = int(occ["end"][j]) - int(occ["begin"][j])
+                if a["spans"]:
+                    lst.append((None, 0, width, int(occ["begin"][j]), int(occ["distance"][j]), int(occ["strand"][j]), o))
+                else:
+                    lst.append((int(a["seq_id"]), int(a["seq_begin"]), int(a["seq_begin"]) + width, int(occ["begin"][j]),
+                                int(occ["distance"][j]), int(occ["strand"][j]), o))
+            rd.append((sid, seq, rc, quals[i], rq, lst))
+        t, n = pair_sam(rd[0], rd[1], seq_names, orientation, max_frag, min_frag, discordant_allowed, unmapped_records)
+        text.append(t)
+        mapped_pairs += n > 0
+    return "".join(text), mapped_pairs

@@ -563,3 +563,51 @@ def test_sam_records_of_a_chunk(world, spec, metric, k, xa):
         assert a == w
     assert len(gl) == len(wl)
     assert any("\t4\t*\t0\t0\t*" in x for x in wl) and any("\t16\t" in x or "\t272\t" in x for x in wl)
+
+
+def test_paired_end_chunk_end_to_end(world):
+    """read pairs sampled as FR fragments: both mates through the GPU matcher, pairing and SAM text by cmb_pair_sam — every
+    pair whose mates carry few errors comes back as a proper pair at the fragment it was cut from (the pairing logic itself is
+    tested on the CPU, tests/test_pairing.py)"""
+    g = world["genome"]
+    rng = np.random.default_rng(77)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    n, L = 300, 100
+    reads1, reads2, truth = [], [], []
+    for i in range(n):
+        frag = int(rng.integers(220, 420))
+        p0 = int(rng.integers(1000, len(g) - 1000))
+        f = bytearray(g[p0:p0 + frag].tobytes())
+        m1, m2 = bytearray(f[:L]), bytearray(bytes(f[-L:]).translate(comp)[::-1])
+        for m in (m1, m2):
+            for _ in range(int(rng.integers(0, 3))):
+                q = int(rng.integers(1, L - 1))
+                m[q] = b"ACGT"[(b"ACGT".index(bytes([m[q]])) + 1) % 4] if bytes([m[q]]) in b"ACGT" else m[q]
+        if i % 2:  # the fragment from the other strand: mate 1 is the reverse-complement end
+            m1, m2 = m2, m1
+        reads1.append(bytes(m1))
+        reads2.append(bytes(m2))
+        truth.append((p0, frag))
+    ids1 = [f"@frag{i}/1" for i in range(n)]
+    ids2 = [f"@frag{i}/2" for i in range(n)]
+    quals = ["I" * L] * n
+    strat = ca.SearchStrategy("multiple_opt", "edit", "dynamic")
+    names = [f"seq{i}" for i in range(len(world["dev"].seq_starts()) - 1)] or ["seq0"]
+    text, mapped = ca.pair_chunk_sam(world["dev"], strat, 2, reads1, reads2, ids1, ids2, quals, quals, names, ca.ORIENTATION_FR, 600, 100,
+                                     True, True)
+    lines = [ln.split("\t") for ln in text.splitlines()]
+    by_pair = {}
+    for f in lines:
+        by_pair.setdefault(f[0].split("/")[0], []).append(f)
+    assert len(by_pair) == n and mapped >= 0.9 * n
+    starts = world["dev"].seq_starts()
+    right = 0
+    for i in range(n):
+        recs = by_pair[f"frag{i}"]
+        prim = [f for f in recs if int(f[1]) & 2 and not int(f[1]) & 256]
+        if len(prim) == 2:
+            p0, frag = truth[i]
+            sid = int(np.searchsorted(starts, p0, side="right") - 1)
+            fwd = [f for f in prim if not int(f[1]) & 16][0]
+            right += names[sid] == fwd[2] and abs(int(fwd[3]) - 1 - (p0 - int(starts[sid]))) <= 2 and abs(abs(int(fwd[8])) - frag) <= 4
+    assert right >= 0.85 * n, right
