@@ -1,22 +1,25 @@
-// A Columba-style single-end aligner over the C-ABI (the counterpart of `columba` for the hot path this library
+// A Columba-style aligner (single-end; paired-end in ALL mode) over the C-ABI (the counterpart of `columba` for the hot path this library
 // accelerates: reference src/parallel.cpp main / threadEntrySingleEnd / processChunk):
 //   columba_align -r <index base> -f <reads.fq|fa> -o <out.sam> [-e <max distance>] [-a all|best] [-x <strata>]
 //                 [-I <min identity>] [-S <strategy>] [-m edit|hamming] [-p uniform|static|dynamic]
 //                 [-s <SA sparseness>] [-K <k-mer size>] [-b <reads per chunk>] [-XA] [-nU]
+//                 [-F <mates.fq> -O fr|rf|ff -X <max insert> -N <min insert> -nD]      (pairs: -a all only)
 // FASTQ / FASTA in, SAM out (header of <base>.headerSN.bin, records in input order).
 #include "columba_amd.hpp"
 #include "columba_amd_io.hpp"
 
 #include <cstring>
 #include <iostream>
+#include <memory>
 
 using namespace columba_amd;
 
 int main(int argc, char** argv) {
-    std::string base, readsFile, outFile, strategyName = "columba", mode = "best", metric = "edit", part = "dynamic", cmdline;
+    std::string base, readsFile, matesFile, orientation = "fr", outFile, strategyName = "columba", mode = "best", metric = "edit", part = "dynamic", cmdline;
     int k = 0, x = 0, identity = 95, sparse = 4, kmer = 10;
     size_t chunkReads = 1000000;
-    bool xa = false, unmapped = true;
+    bool xa = false, unmapped = true, discordant = true;
+    unsigned maxInsert = 500, minInsert = 0;
     for (int i = 0; i < argc; i++) cmdline += std::string(i ? " " : "") + argv[i];
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -40,6 +43,11 @@ int main(int argc, char** argv) {
             else if (a == "-b") chunkReads = (size_t)std::stoul(val());
             else if (a == "-XA") xa = true;
             else if (a == "-nU") unmapped = false;
+            else if (a == "-F") matesFile = val();
+            else if (a == "-O") orientation = val();
+            else if (a == "-X") maxInsert = (unsigned)std::stoul(val());
+            else if (a == "-N") minInsert = (unsigned)std::stoul(val());
+            else if (a == "-nD") discordant = false;
             else throw std::runtime_error("unknown option " + a);
         } catch (const std::exception& e) {
             std::cerr << "Fatal error: " << e.what() << "\n";
@@ -59,7 +67,10 @@ int main(int argc, char** argv) {
         const std::vector<std::string> seqNames = readSequenceNames(base);
         std::vector<const char*> seqNamePtrs;
         for (const auto& s : seqNames) seqNamePtrs.push_back(s.c_str());
+        if (!matesFile.empty() && mode != "all") throw std::runtime_error("paired-end reads are supported in ALL mode only (-a all)");
+        const uint32_t ori = orientation == "rf" ? CMB_ORIENTATION_RF : orientation == "ff" ? CMB_ORIENTATION_FF : CMB_ORIENTATION_FR;
         Reader reader(readsFile);
+        std::unique_ptr<Reader> mateReader(matesFile.empty() ? nullptr : new Reader(matesFile));
         OutputWriter writer(outFile, base + ".headerSN.bin", cmdline);
         std::vector<SequenceRecord> chunk;
         size_t chunkID = 0, nReads = 0, nMapped = 0;
@@ -74,7 +85,11 @@ int main(int argc, char** argv) {
                 quals.push_back(chunk[i].qual.c_str());
             }
             std::string text;
-            if (mode == "all") {
+            if (mateReader) {
+                std::vector<SequenceRecord> mates;
+                mateReader->getNextChunk(mates, chunkReads);
+                text = strategy.samOfChunkPairedAll(chunk, mates, seqNamePtrs, (length_t)k, ori, maxInsert, minInsert, discordant, unmapped, nMapped);
+            } else if (mode == "all") {
                 text = strategy.samOfChunkAll(seqs, offs, ids, quals, seqNamePtrs, (length_t)k, unmapped, xa);
             } else {
                 text = strategy.samOfChunkBest(seqs, offs, chunk, seqNames, (uint32_t)x, (uint32_t)identity, unmapped, xa, nMapped);

@@ -268,6 +268,82 @@ class SearchStrategy {
         text.resize((size_t)n);
         return text;
     }
+    // the SAM text of a chunk of read PAIRS in ALL mode: both mates matched single-ended (one batch each), then paired as
+    // SearchStrategy::pairSingleEndedMatchesAll does (searchstrategy.cpp:1345-1399) with the records of generateSAMPairedEnd.
+    // orientation: CMB_ORIENTATION_*.  Occurrences that run past the end of their sequence take no part in the pairing.
+    template <class Record>
+    std::string samOfChunkPairedAll(const std::vector<Record>& mates1, const std::vector<Record>& mates2,
+                                    const std::vector<const char*>& seqNames, length_t maxED, uint32_t orientation, uint32_t maxFragSize,
+                                    uint32_t minFragSize, bool discordantAllowed, bool unmappedRecords, size_t& mappedPairs) {
+        if (mates1.size() != mates2.size()) throw std::runtime_error("the two read files do not hold the same number of reads");
+        struct Mate {
+            std::vector<cmb_occ> occ;
+            std::vector<cmb_aln> aln;
+            std::vector<uint16_t> ops;
+            std::vector<uint64_t> oo;
+        } M[2];
+        const std::vector<Record>* in[2] = {&mates1, &mates2};
+        for (int m = 0; m < 2; m++) {
+            std::string seqs;
+            std::vector<uint64_t> offs(in[m]->size() + 1, 0);
+            for (size_t i = 0; i < in[m]->size(); i++) seqs += (*in[m])[i].read, offs[i + 1] = seqs.size();
+            cmb_batch* b = nullptr;
+            check(cmb_batch_create(index.handle(), h, maxED, seqs.data(), offs.data(), (uint32_t)in[m]->size(), &b));
+            struct Guard {
+                cmb_batch* b;
+                ~Guard() { cmb_batch_destroy(b); }
+            } guard{b};
+            check(cmb_batch_want_alignments(b, 1));
+            check(cmb_batch_run(b));
+            uint64_t n = 0, nOps = 0;
+            check(cmb_batch_result_size(b, &n));
+            M[m].occ.resize(n ? n : 1);
+            M[m].aln.resize(n ? n : 1);
+            M[m].oo.resize(in[m]->size() + 1);
+            std::vector<uint64_t> cnt(CMB_CNT_MAX);
+            check(cmb_batch_results(b, M[m].occ.data(), M[m].occ.size(), M[m].oo.data(), cnt.data()));
+            (void)cmb_batch_alignments(b, M[m].aln.data(), 0, nullptr, 0, &nOps); // sizes first
+            M[m].ops.resize(nOps ? nOps : 1);
+            check(cmb_batch_alignments(b, M[m].aln.data(), M[m].aln.size(), M[m].ops.data(), M[m].ops.size(), &nOps));
+        }
+        const cmb_pair_params prm = {orientation, maxFragSize, minFragSize, discordantAllowed ? 1 : 0, unmappedRecords ? 1 : 0};
+        std::string text;
+        std::vector<char> buf;
+        for (size_t i = 0; i < mates1.size(); i++) {
+            std::vector<cmb_pair_occ> po[2];
+            std::vector<char> id[2], sq[2], rc[2], rq[2];
+            cmb_pair_read rd[2];
+            for (int m = 0; m < 2; m++) {
+                const Record& r = (*in[m])[i];
+                id[m].resize(r.seqID.size() + 1), sq[m].resize(r.read.size() + 1), rc[m].resize(r.read.size() + 1), rq[m].resize(r.qual.size() + 1);
+                check(cmb_read_prepare(r.seqID.c_str(), r.read.c_str(), r.qual.c_str(), id[m].data(), sq[m].data(), rc[m].data(), rq[m].data()));
+                for (uint64_t j = M[m].oo[i]; j < M[m].oo[i + 1]; j++) {
+                    const cmb_occ& o = M[m].occ[j];
+                    const cmb_aln& a = M[m].aln[j];
+                    const uint32_t width = o.end - o.begin;
+                    cmb_pair_occ p;
+                    p.seq_id = a.spans ? 0xFFFFFFFFu : a.seq_id;
+                    p.begin = a.spans ? 0 : a.seq_begin;
+                    p.end = p.begin + width;
+                    p.index_begin = o.begin;
+                    p.distance = o.distance;
+                    p.strand = o.strand;
+                    p.cigar_ops = M[m].ops.data() + a.cigar_off;
+                    p.n_ops = a.cigar_len;
+                    po[m].push_back(p);
+                }
+                rd[m] = cmb_pair_read{id[m].data(), sq[m].data(), rc[m].data(), r.qual.c_str(), rq[m].data(), po[m].data(), (uint32_t)po[m].size()};
+            }
+            uint32_t nPairs = 0;
+            const int64_t n = cmb_pair_sam(&prm, &rd[0], &rd[1], seqNames.data(), nullptr, 0, &nPairs);
+            if (n < 0) check((int)n);
+            buf.resize((size_t)n + 1);
+            cmb_pair_sam(&prm, &rd[0], &rd[1], seqNames.data(), buf.data(), (uint64_t)n + 1, &nPairs);
+            text.append(buf.data(), (size_t)n);
+            mappedPairs += nPairs > 0;
+        }
+        return text;
+    }
     // the SAM text of a chunk in BEST (+x strata) mode (matchApproxBestPlusX, searchstrategy.cpp:714-746, + generateSE_SAM)
     template <class Record>
     std::string samOfChunkBest(const std::string& seqs, const std::vector<uint64_t>& offs, const std::vector<Record>& recs,

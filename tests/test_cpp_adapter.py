@@ -167,3 +167,47 @@ def test_bmove_adapter_example_matches_python_binding(tmp_path):
     walk = err[1].split()
     fw = sorted(int(o["begin"]) for o in occ[int(offs[0]):int(offs[1])] if o["strand"] == 0)
     assert walk[0] == "walk" and int(walk[1]) == len(reads[0]) and [int(x) for x in walk[4:]] == fw
+
+
+@pytest.mark.gpu
+def test_align_driver_paired_end(tmp_path):
+    """two FASTQ files in, SAM out through the C++ host layer in paired mode (samOfChunkPairedAll: two GPU batches + cmb_pair_sam
+    per pair, chunks of 120 pairs): the records equal what the Python host layer makes of the same reads"""
+    from columba_amd import indexbuild as ib, synth
+    exe = _build_align(str(tmp_path))
+    g, starts = synth.genome_rep(seed=2, n=300_000, scale=2.0)
+    ix = ib.build_index(g.tobytes(), seq_starts=starts, device="cuda")
+    names = [f"chr{i}" for i in range(len(starts) - 1)]
+    ix.seq_names = names
+    ib.save_index(ix, str(tmp_path / "idx"))
+    rng = np.random.default_rng(4)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    n, L = 300, 80
+    r1, r2 = [], []
+    for i in range(n):
+        frag = int(rng.integers(200, 380))
+        p0 = int(rng.integers(500, len(g) - 900))
+        f = g[p0:p0 + frag].tobytes()
+        a, b = bytearray(f[:L]), bytearray(f[-L:].translate(comp)[::-1])
+        if i % 7 == 0:
+            b = bytearray(bytes(rng.choice(list(b"ACGT"), L).astype(np.uint8)))  # a mate from nowhere
+        if i % 5 == 0:
+            a[10] = ord("N")
+        if i % 2:
+            a, b = b, a
+        r1.append(bytes(a))
+        r2.append(bytes(b))
+    q = "I" * L
+    (tmp_path / "r1.fq").write_text("".join(f"@p{i}/1 x\n{r1[i].decode()}\n+\n{q}\n" for i in range(n)))
+    (tmp_path / "r2.fq").write_text("".join(f"@p{i}/2 x\n{r2[i].decode()}\n+\n{q}\n" for i in range(n)))
+    out = tmp_path / "o.sam"
+    run = subprocess.run([exe, "-r", str(tmp_path / "idx"), "-f", str(tmp_path / "r1.fq"), "-F", str(tmp_path / "r2.fq"), "-o", str(out),
+                          "-a", "all", "-e", "2", "-S", "multiple_opt", "-b", "120", "-X", "500", "-N", "100"], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+    body = "".join(ln for ln in out.read_text().splitlines(keepends=True) if not ln.startswith("@"))
+    dev = ca.Index(ix)
+    want, mapped = ca.pair_chunk_sam(dev, ca.SearchStrategy("multiple_opt", "edit", "dynamic"), 2, r1, r2, [f"@p{i}/1 x" for i in range(n)],
+                                     [f"@p{i}/2 x" for i in range(n)], [q] * n, [q] * n, names, ca.ORIENTATION_FR, 500, 100, True, True)
+    assert body == want and mapped > 0.6 * n
+    flags = [int(ln.split("\t")[1]) for ln in body.splitlines()]
+    assert sum(1 for f in flags if f & 2) > n and any(f & 8 for f in flags)  # proper pairs, and pairs with an unmapped mate
