@@ -45,7 +45,7 @@ EXPORTS = [
     "cmb_batch_result_size", "cmb_batch_results", "cmb_batch_timings", "cmb_batch_destroy",
     "cmb_rank_batch", "cmb_extend_batch", "cmb_extend_bench", "cmb_locate_batch", "cmb_verify_batch", "cmb_verify_batch_staged", "cmb_verify_window", "cmb_cigar_windows",
     "cmb_batch_want_alignments", "cmb_batch_alignments", "cmb_sam_se", "cmb_sam_se_xa", "cmb_sam_unmapped_se",
-    "cmb_sam_pe", "cmb_sam_unpaired", "cmb_sam_unmapped_pe", "cmb_pair_sam",
+    "cmb_sam_pe", "cmb_sam_unpaired", "cmb_sam_unmapped_pe", "cmb_pair_sam", "cmb_pair_infer",
     "cmb_read_prepare", "cmb_batch_sam", "cmb_batch_filter_per_strand", "cmb_match_best", "cmb_best_sizes", "cmb_best_results",
     "cmb_best_destroy",
     "cmb_move_create", "cmb_move_destroy", "cmb_move_device_bytes", "cmb_move_info", "cmb_move_complete_range", "cmb_move_rows",
@@ -162,7 +162,21 @@ class PairParams(C.Structure):
                 ("unmapped_records", C.c_int)]
 
 
+class PairInferred(C.Structure):
+    """cmb_pair_inferred"""
+    _fields_ = [("n_pairs", C.c_uint64), ("inferred", C.c_uint32), ("orientation", C.c_uint32), ("max_insert", C.c_uint32),
+                ("min_insert", C.c_uint32), ("mean_insert", C.c_float), ("stddev_insert", C.c_float)]
+
+
 ORIENTATION_FR, ORIENTATION_RF, ORIENTATION_FF = 0, 1, 2
+
+
+def pair_infer(samples) -> "PairInferred":
+    """orientation and insert-size bounds from unambiguously mapped pairs; samples: n x (begin1, end1, strand1, begin2, end2, strand2)"""
+    a = np.ascontiguousarray(samples, dtype=np.uint32).reshape(-1, 6)
+    out = PairInferred()
+    _chk(lib().cmb_pair_infer(_p(a), a.shape[0], C.byref(out)))
+    return out
 
 
 class SamHit(C.Structure):
@@ -233,6 +247,7 @@ def lib():
         L.cmb_sam_unpaired.argtypes = [C.c_char_p, C.POINTER(SamHit), i32, u32, u32, i32, C.c_char_p, C.c_char_p, vp, u64]
         L.cmb_sam_unmapped_pe.restype = C.c_int64
         L.cmb_sam_unmapped_pe.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, i32, i32, i32, vp, u64]
+        L.cmb_pair_infer.argtypes = [vp, u64, C.POINTER(PairInferred)]
         L.cmb_pair_sam.restype = C.c_int64
         L.cmb_pair_sam.argtypes = [C.POINTER(PairParams), C.POINTER(PairRead), C.POINTER(PairRead), vp, vp, u64, C.POINTER(u32)]
         L.cmb_sam_unmapped_se.restype = C.c_int64

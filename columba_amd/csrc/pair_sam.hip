@@ -320,3 +320,63 @@ extern "C" int64_t cmb_pair_sam(const cmb_pair_params* prm, const cmb_pair_read*
     if (n_pairs_out) *n_pairs_out = mapped ? (uint32_t)pairs.size() : 0; // TOTAL_UNIQUE_PAIRS
     return putText(text, out, cap);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Inference of the paired-end parameters from pairs whose mates both map unambiguously: addFragmentAndOrientation
+// (parallel.cpp:329-360) per pair, then inferPairedEndParameters (:402-466): fragment sizes without the outliers beyond six
+// median absolute deviations, mean and standard deviation in single precision as there, max / min insert size = mean -+ 6
+// standard deviations, the most frequent orientation.
+// ------------------------------------------------------------------------------------------------------------------------------
+extern "C" int cmb_pair_infer(const cmb_pair_sample* samples, uint64_t n, cmb_pair_inferred* out) {
+    if (!out || (n && !samples)) return failWith(CMB_ERR_INVALID, "bad argument");
+    std::memset(out, 0, sizeof(*out));
+    out->n_pairs = n;
+    if (n == 0) return CMB_OK; // "No pairs mapped unambiguously. Using default values!" (parallel.cpp:408-413): nothing inferred
+    std::vector<uint32_t> frag;
+    uint64_t cnt[3] = {0, 0, 0};
+    for (uint64_t i = 0; i < n; i++) {
+        const cmb_pair_sample& s = samples[i];
+        const bool firstFirst = s.begin1 < s.begin2;
+        frag.push_back(firstFirst ? s.end2 - s.begin1 : s.end1 - s.begin2);
+        const bool rc1 = s.strand1 != 0, rc2 = s.strand2 != 0;
+        cnt[rc1 == rc2 ? CMB_ORIENTATION_FF : (firstFirst == rc1 ? CMB_ORIENTATION_RF : CMB_ORIENTATION_FR)]++;
+    }
+    auto median = [](std::vector<uint32_t>& d) -> uint32_t { // calcMedian (:365-372): sorts its argument
+        std::sort(d.begin(), d.end());
+        return d.size() % 2 == 0 ? (d[d.size() / 2 - 1] + d[d.size() / 2]) / 2 : d[d.size() / 2];
+    };
+    auto average = [](const std::vector<uint32_t>& v) -> float { // :378-380
+        double acc = 0.0;
+        for (uint32_t x : v) acc += x;
+        return (float)(acc / v.size());
+    };
+    auto stddev = [](const std::vector<uint32_t>& v, float mean) -> float { // :389-394 (Bessel's correction, float accumulator)
+        float accum = 0.0f;
+        for (uint32_t x : v) {
+            const float d = (float)x;
+            accum += (d - mean) * (d - mean);
+        }
+        return std::sqrt(accum / (v.size() - 1));
+    };
+    const int32_t med = (int32_t)median(frag);
+    std::vector<uint32_t> dev;
+    for (uint32_t f : frag) dev.push_back((uint32_t)std::abs((int32_t)f - med));
+    const uint32_t mad = median(dev);
+    std::vector<uint32_t> kept;
+    for (uint32_t f : frag)
+        if ((uint32_t)std::abs((int32_t)f - med) < 6u * mad) kept.push_back(f); // PE_STD_DEV_CONSIDERED (definitions.h:54-55)
+    float mean = average(kept), sd = stddev(kept, mean);
+    if (mean == 0 || sd == 0 || !(mean == mean) || !(sd == sd)) { // (an empty or one-element selection gives NaN there; the reference tests == 0 only)
+        mean = average(frag);
+        sd = stddev(frag, mean);
+    }
+    const uint32_t maxDev = (uint32_t)(6 * sd);
+    out->mean_insert = mean;
+    out->stddev_insert = sd;
+    out->max_insert = (uint32_t)(mean + maxDev);
+    out->min_insert = mean > maxDev ? (uint32_t)(mean - maxDev) : 0;
+    const uint64_t rf = cnt[CMB_ORIENTATION_RF], fr = cnt[CMB_ORIENTATION_FR], ff = cnt[CMB_ORIENTATION_FF];
+    out->orientation = (fr >= rf && fr >= ff) ? CMB_ORIENTATION_FR : (rf >= ff) ? CMB_ORIENTATION_RF : CMB_ORIENTATION_FF;
+    out->inferred = 1;
+    return CMB_OK;
+}

@@ -310,6 +310,21 @@ typedef struct {
 /* returns the length of the text (written if cap is larger); n_pairs_out (may be NULL): TOTAL_UNIQUE_PAIRS of the pair */
 int64_t cmb_pair_sam(const cmb_pair_params* params, const cmb_pair_read* read1, const cmb_pair_read* read2, const char* const* seq_names,
                      char* out, uint64_t cap, uint32_t* n_pairs_out);
+/* Inference of orientation and insert-size bounds from pairs whose two mates map unambiguously (src/parallel.cpp:329-360
+ * addFragmentAndOrientation, :402-466 inferPairedEndParameters; the caller selects the pairs as :236-262 / :700-727 do: exactly
+ * one occurrence per mate).  Coordinates of the two occurrences as reported; n == 0: nothing inferred (inferred = 0). */
+typedef struct {
+    uint32_t begin1, end1, strand1;
+    uint32_t begin2, end2, strand2;
+} cmb_pair_sample;
+typedef struct {
+    uint64_t n_pairs;
+    uint32_t inferred;     /* 0: no sample, the caller keeps its defaults */
+    uint32_t orientation;  /* CMB_ORIENTATION_* */
+    uint32_t max_insert, min_insert;
+    float mean_insert, stddev_insert;
+} cmb_pair_inferred;
+int cmb_pair_infer(const cmb_pair_sample* samples, uint64_t n, cmb_pair_inferred* out);
 /* SAM text of a whole chunk matched in ALL mode (SearchStrategy::generateOutputSingleEnd, src/searchstrategy.cpp:1824-1902:
  * sequence assignment incl. trimming at sequence ends, primary = first occurrence of minimal distance, the others as
  * secondary lines or, with xa_tag, in the primary's XA tag; unmapped_records: a flag-4 record for reads without any).

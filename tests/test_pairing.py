@@ -219,3 +219,74 @@ def test_too_many_discordant_candidates_follow_the_reference_to_the_letter():
     assert n == 0 and len(lines) == 2 and [int(ln.split("\t")[1]) for ln in lines] == [77, 141]
     want, _, _ = _reference_pairing(r1, r2, ca.ORIENTATION_FR, 500, 0, True, True)
     assert text == want
+
+
+def _infer_reference(samples):
+    """parallel.cpp:329-360 + :402-466 in numpy with the reference's types (length_t fragment sizes, float statistics)"""
+    frag, ori = [], []
+    for b1, e1, s1, b2, e2, s2 in samples:
+        first = b1 < b2
+        frag.append(e2 - b1 if first else e1 - b2)
+        ori.append(ca.ORIENTATION_FF if bool(s1) == bool(s2) else (ca.ORIENTATION_RF if first == bool(s1) else ca.ORIENTATION_FR))
+
+    def median(v):
+        v = sorted(v)
+        return (v[len(v) // 2 - 1] + v[len(v) // 2]) // 2 if len(v) % 2 == 0 else v[len(v) // 2]
+
+    def avg(v):
+        return np.float32(np.float64(sum(v)) / len(v))
+
+    def sd(v, m):
+        acc = np.float32(0)
+        for x in v:
+            d = np.float32(x) - m
+            acc = np.float32(acc + d * d)
+        return np.float32(np.sqrt(acc / np.float32(len(v) - 1)))
+
+    med = median(frag)
+    mad = median([abs(f - med) for f in frag])
+    kept = [f for f in frag if abs(f - med) < 6 * mad]
+    with np.errstate(all="ignore"):
+        mean = avg(kept) if kept else np.float32("nan")
+        dev = sd(kept, mean) if kept else np.float32("nan")
+        if mean == 0 or dev == 0 or np.isnan(mean) or np.isnan(dev):
+            mean = avg(frag)
+            dev = sd(frag, mean)
+    max_dev = int(np.float32(6) * dev)
+    cnt = [ori.count(o) for o in (ca.ORIENTATION_FR, ca.ORIENTATION_RF, ca.ORIENTATION_FF)]
+    o = ca.ORIENTATION_FR if cnt[0] >= cnt[1] and cnt[0] >= cnt[2] else (ca.ORIENTATION_RF if cnt[1] >= cnt[2] else ca.ORIENTATION_FF)
+    return o, int(mean + np.float32(max_dev)), int(mean - np.float32(max_dev)) if mean > max_dev else 0, float(mean), float(dev)
+
+
+def test_inference_of_the_paired_end_parameters():
+    rng = np.random.default_rng(12)
+    for trial in range(60):
+        n = int(rng.choice([2, 3, 10, 200, 750]))
+        mode = trial % 3
+        samples = []
+        for _ in range(n):
+            frag = max(60, int(rng.normal(320, 35)))
+            if rng.random() < 0.03:
+                frag = int(rng.integers(2000, 50000))  # a chimeric pair: an outlier
+            p0 = int(rng.integers(0, 10 ** 6))
+            up, down = (p0, p0 + 50), (p0 + frag - 50, p0 + frag)
+            first_is_up = bool(rng.integers(0, 2))
+            if mode == 0:      # FR: the upstream mate forward, the downstream one reverse complement
+                su, sd_ = 0, 1
+            elif mode == 1:    # RF
+                su, sd_ = 1, 0
+            else:              # FF
+                su = sd_ = int(rng.integers(0, 2))
+            if rng.random() < 0.1:
+                su, sd_ = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+            a, b = ((up, su), (down, sd_)) if first_is_up else ((down, sd_), (up, su))
+            samples.append((a[0][0], a[0][1], a[1], b[0][0], b[0][1], b[1]))
+        got = ca.pair_infer(samples)
+        o, mx, mn, mean, dev = _infer_reference(samples)
+        assert got.inferred == 1 and got.n_pairs == n
+        assert (got.orientation, got.max_insert, got.min_insert) == (o, mx, mn), (trial, got.max_insert, mx)
+        assert abs(got.mean_insert - mean) < 1e-3 * max(1.0, mean) and abs(got.stddev_insert - dev) < 1e-3 * max(1.0, dev)
+        if n >= 200:
+            assert got.orientation == (ca.ORIENTATION_FR, ca.ORIENTATION_RF, ca.ORIENTATION_FF)[mode]
+            assert 250 < got.mean_insert < 400 and got.max_insert < 1500
+    assert ca.pair_infer(np.zeros((0, 6), np.uint32)).inferred == 0
