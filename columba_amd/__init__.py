@@ -878,15 +878,19 @@ class MoveIndex:
 
 def pair_chunk_sam(index: "Index", strategy: "SearchStrategy", max_distance: int, reads1, reads2, ids1, ids2, quals1, quals2, seq_names,
                    orientation: int = ORIENTATION_FR, max_frag: int = 500, min_frag: int = 0, discordant_allowed: bool = True,
-                   unmapped_records: bool = True):
+                   unmapped_records: bool = True, per_strand: bool = False):
     """A chunk of read pairs in ALL mode, end to end: both mates through the GPU matcher (one batch each, with alignments), then
-    cmb_pair_sam per pair (SearchStrategy::pairSingleEndedMatchesAll on the mates' single-end results).  Occurrences that run
+    cmb_pair_sam per pair (SearchStrategy::pairSingleEndedMatchesAll on the mates' single-end results).  per_strand: the strands
+    of a mate are filtered each by itself, as matchApproxPairedEndAll's mapRead does (searchstrategy.cpp:746-776,
+    searchstrategy.h:753-774), instead of together (matchApproxAllMap).  Occurrences that run
     past the end of their sequence (cmb_aln.spans) take no part in the pairing.  Returns (SAM text, number of properly or
     discordantly mapped pairs)."""
     per_mate = []
     for reads in (reads1, reads2):
         b = Batch(index, strategy, max_distance, reads=reads)
         b.want_alignments()
+        if per_strand:
+            _chk(lib().cmb_batch_filter_per_strand(b.h, 1))
         b.run()
         occ, offs, _ = b.results()
         aln, ops = b.alignments()

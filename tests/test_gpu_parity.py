@@ -611,3 +611,8 @@ def test_paired_end_chunk_end_to_end(world):
             fwd = [f for f in prim if not int(f[1]) & 16][0]
             right += names[sid] == fwd[2] and abs(int(fwd[3]) - 1 - (p0 - int(starts[sid]))) <= 2 and abs(abs(int(fwd[8])) - frag) <= 4
     assert right >= 0.85 * n, right
+    # the strands of a mate filtered each by itself (matchApproxPairedEndAll's mapRead): the same proper pairs here
+    text2, mapped2 = ca.pair_chunk_sam(world["dev"], strat, 2, reads1, reads2, ids1, ids2, quals, quals, names, ca.ORIENTATION_FR, 600, 100,
+                                       True, True, per_strand=True)
+    prop = lambda t: sorted(ln for ln in t.splitlines() if int(ln.split("\t")[1]) & 2 and not int(ln.split("\t")[1]) & 256)
+    assert mapped2 == mapped and prop(text2) == prop(text)
