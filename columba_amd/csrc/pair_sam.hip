@@ -168,7 +168,7 @@ extern "C" int64_t cmb_pair_sam(const cmb_pair_params* prm, const cmb_pair_read*
             st[r][o.strand].push_back(POcc{&o, r == 1});
         }
     for (int r = 0; r < 2; r++)
-        for (int s = 0; s < 2; s++) std::sort(st[r][s].begin(), st[r][s].end(), occLess); // searchstrategy.cpp:1368-1378
+        for (int s = 0; s < 2; s++) std::stable_sort(st[r][s].begin(), st[r][s].end(), occLess); // searchstrategy.cpp:1368-1378 (its DEVELOPER_MODE order: ties keep the caller's order)
     std::vector<PPair> pairs;
     // pairOccurrences (searchstrategy.cpp:1281-1344)
     auto pairOccurrences = [&](const std::vector<POcc>& U, const std::vector<POcc>& D) {
