@@ -622,12 +622,22 @@ class Batch:
         self.h = h
 
     def run(self):
+        # a run consumes the staged chunk (cmb_batch_run waits for its copy first): from here on the batch's reads ARE that
+        # chunk — sam() must see them — and the chunk before it may still be the source of nothing
+        staged = getattr(self, "_staged", None)
+        if staged is not None:
+            self._retired = self._packed  # (one more generation alive: its upload finished before this run started)
+            self._packed = staged
+            self._staged = None
         _chk(lib().cmb_batch_run(self.h))
 
     def stage(self, packed):
         """copy the next chunk (buf, offs: same number of reads) to the device while the current one is matched"""
         buf, offs = packed
-        self._staged = (buf, offs)  # (kept alive until the next run has taken them)
+        # a chunk staged earlier and never run may still be the source of a copy in flight: keep it alive as well
+        if getattr(self, "_staged", None) is not None:
+            self._superseded = self._staged
+        self._staged = (buf, offs)
         _chk(lib().cmb_batch_stage_reads(self.h, _p(buf), _p(offs), offs.shape[0] - 1))
 
     def results(self, reuse: bool = False):

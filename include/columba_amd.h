@@ -174,7 +174,21 @@ enum {
 /* One-shot host-buffer entry: the body of processChunk's loop (parallel.cpp:67-78) for a whole
  * chunk.  seqs: concatenated read characters (any case; non-ACGT treated as N, reads.h:43-58),
  * offs[nReads+1].  out/outOffs are caller-allocated; on CMB_ERR_OVERFLOW *needed holds the required
- * number of cmb_occ and nothing is written. */
+ * number of cmb_occ and nothing is written.
+ *
+ * Per read the list is what SearchStrategy::matchApprox leaves in `matches` before generateOutputSingleEnd
+ * (searchstrategy.cpp:529), with three deviations in places where the reference's own result is not a function of its
+ * input (a maintainer diffing against `columba` output will meet exactly these and no others):
+ *  1. strand label of a tie: when the same (begin, end, distance) is found on both strands, which label survives
+ *     Occurrences::eraseDoublesAndSortText is decided by an unstable std::sort (indexhelpers.h:2148-2156, TextOcc::==
+ *     ignores the strand, :811); this library always keeps strand 0.
+ *  2. order at max_distance = 0: the reference leaves exact matches in suffix-array order, forward strand first
+ *     (searchstrategy.cpp:499-510); this library returns them sorted by (begin, strand).  The SET is identical; which of
+ *     several exact matches becomes the primary SAM record may therefore differ.
+ *  3. counters only: in-index occurrences that are equal under FMOcc::== but separated by the unstable sort of
+ *     Occurrences::eraseDoublesFM (indexhelpers.h:2135-2146) are located twice by the reference; this library removes
+ *     every duplicate, so CMB_CNT_TOTAL_REPORTED, CMB_CNT_LF_STEPS and CMB_CNT_LOCATED_ROWS can be lower than the
+ *     reference's by the repeated work (well below 1 %); the occurrence lists are unaffected. */
 int cmb_match_batch(cmb_index* idx, const cmb_strategy* st, uint32_t max_distance, const char* seqs,
                     const uint64_t* offs, uint32_t n_reads, cmb_occ* out, uint64_t out_cap,
                     uint64_t* out_offs /* [n_reads+1] */, uint64_t* counters /* [CMB_CNT_MAX] or NULL */,
