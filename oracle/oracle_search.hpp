@@ -38,58 +38,64 @@ struct TextOcc {
     }
 };
 
-struct FMPos {
-    RangePair ranges;
+// The types below are templates on the range-pair type RP: orc::RangePair for the FM-index (Vanilla flavour), the move
+// ranges with toehold of the run-length compressed flavour (indexhelpers.h:1117-1260 under RUN_LENGTH_COMPRESSION,
+// oracle_move.hpp: MovePairT) — the search layer is the same code in the reference, compiled twice.
+inline len_t saBeginOf(const RangePair& r) { return r.sa.b; }
+
+template <class RP> struct FMPosT {
+    RP ranges;
     len_t depth = 0;
-    FMPos() {}
-    FMPos(const RangePair& r, len_t d) : ranges(r), depth(d) {}
+    FMPosT() {}
+    FMPosT(const RP& r, len_t d) : ranges(r), depth(d) {}
     bool isValid() const { return !ranges.empty(); }
 };
 
-struct FMOcc {
-    FMPos pos;
+template <class RP> struct FMOccT {
+    FMPosT<RP> pos;
     len_t distance = 0;
     len_t shift = 0;
     Strand strand = FORWARD_STRAND;
-    FMOcc() {}
-    FMOcc(const RangePair& r, len_t dist, len_t depth, Strand s = FORWARD_STRAND,
+    FMOccT() {}
+    FMOccT(const RP& r, len_t dist, len_t depth, Strand s = FORWARD_STRAND,
           len_t sh = 0)
         : pos(r, depth), distance(dist), shift(sh), strand(s) {}
-    const RangePair& getRanges() const { return pos.ranges; }
+    const RP& getRanges() const { return pos.ranges; }
     len_t getDepth() const { return pos.depth; }
     bool isValid() const { return pos.isValid(); }
     // indexhelpers.h:1506-1524
-    bool operator<(const FMOcc& rhs) const {
-        if (pos.ranges.sa.b != rhs.pos.ranges.sa.b) return pos.ranges.sa.b < rhs.pos.ranges.sa.b;
+    bool operator<(const FMOccT& rhs) const {
+        if (saBeginOf(pos.ranges) != saBeginOf(rhs.pos.ranges)) return saBeginOf(pos.ranges) < saBeginOf(rhs.pos.ranges);
         if (distance != rhs.distance) return distance < rhs.distance;
         if (pos.ranges.width() != rhs.pos.ranges.width())
             return pos.ranges.width() < rhs.pos.ranges.width();
         return shift < rhs.shift;
     }
     // indexhelpers.h:1529
-    bool operator==(const FMOcc& rhs) const {
+    bool operator==(const FMOccT& rhs) const {
         return getRanges() == rhs.getRanges() && distance == rhs.distance &&
                getDepth() == rhs.getDepth() && shift == rhs.shift && strand == rhs.strand;
     }
 };
 
-struct FMPosExt : FMPos {
+template <class RP> struct FMPosExtT : FMPosT<RP> {
     char c = 0;
     bool reported = false;
-    FMPosExt() {}
-    FMPosExt(char ch, const RangePair& r, len_t row) : FMPos(r, row), c(ch) {}
-    len_t getRow() const { return depth; }
+    FMPosExtT() {}
+    FMPosExtT(char ch, const RP& r, len_t row) : FMPosT<RP>(r, row), c(ch) {}
+    len_t getRow() const { return this->depth; }
     // indexhelpers.h:1586-1601
-    void report(FMOcc& occ, len_t startDepth, len_t EDFound, bool noDoubleReports,
+    void report(FMOccT<RP>& occ, len_t startDepth, len_t EDFound, bool noDoubleReports,
                 len_t shift) {
         if (!reported) {
-            occ = FMOcc(ranges, EDFound, depth + startDepth, FORWARD_STRAND, shift);
+            occ = FMOccT<RP>(this->ranges, EDFound, this->depth + startDepth, FORWARD_STRAND, shift);
             if (noDoubleReports) reported = true;
         }
     }
 };
 
-struct Occurrences { // indexhelpers.h:1957
+template <class RP> struct OccurrencesT { // indexhelpers.h:1957
+    typedef FMOccT<RP> FMOcc;
     std::vector<TextOcc> inTextOcc;
     std::vector<FMOcc> inFMOcc;
     void eraseDoublesFM() { // :2135 (DEVELOPER_MODE: stable)
@@ -106,13 +112,15 @@ struct Occurrences { // indexhelpers.h:1957
 // MatrixMetaInfo — the final-column cluster (indexhelpers.h:1677-1838,
 // indexhelpers.cpp:276-382)
 // ----------------------------------------------------------------------------
-struct Cluster {
+template <class RP> struct ClusterT {
+    typedef FMOccT<RP> FMOcc;
+    typedef FMPosExtT<RP> FMPosExt;
     std::vector<uint16_t> eds;
     std::vector<FMPosExt> nodes;
     len_t lastCell;
     uint16_t maxED;
     len_t startDepth, shift;
-    Cluster(len_t size, len_t maxED_, len_t startDepth_, len_t shift_)
+    ClusterT(len_t size, len_t maxED_, len_t startDepth_, len_t shift_)
         : eds(size, (uint16_t)(maxED_ + 1)), nodes(size), lastCell((len_t)-1),
           maxED((uint16_t)maxED_), startDepth(startDepth_), shift(shift_) {}
     void setValue(len_t idx, const FMPosExt& node, len_t ed) {
@@ -219,6 +227,12 @@ struct Cluster {
     }
 };
 
+typedef FMPosT<RangePair> FMPos;
+typedef FMOccT<RangePair> FMOcc;
+typedef FMPosExtT<RangePair> FMPosExt;
+typedef OccurrencesT<RangePair> Occurrences;
+typedef ClusterT<RangePair> Cluster;
+
 // ----------------------------------------------------------------------------
 // Strategy description (searchstrategy.h: SearchStrategy + derived classes)
 // ----------------------------------------------------------------------------
@@ -260,7 +274,7 @@ struct Strategy {
         return b;
     }
     // MultipleSchemes::createSearches searchstrategy.h:2505-2537
-    const std::vector<Search>& createSearches(len_t k, const std::vector<RangePair>& ranges) const {
+    template <class RP> const std::vector<Search>& createSearches(len_t k, const std::vector<RP>& ranges) const {
         const auto& schemes = schemesPerK[k];
         if (schemes.size() == 1) return schemes[0].searches;
         unsigned numParts = schemes.front().getNumParts();
@@ -283,14 +297,22 @@ struct Strategy {
 // ----------------------------------------------------------------------------
 // Matcher: per-thread state of IndexInterface + SearchStrategy
 // ----------------------------------------------------------------------------
-class Matcher {
+template <class IX> class MatcherT {
   public:
-    const Index& index;
+    typedef typename IX::RangePair RangePair; // (shadows orc::RangePair inside the matcher)
+    typedef typename IX::SARange SARange;
+    typedef FMPosT<RangePair> FMPos;
+    typedef FMOccT<RangePair> FMOcc;
+    typedef FMPosExtT<RangePair> FMPosExt;
+    typedef OccurrencesT<RangePair> Occurrences;
+    typedef ClusterT<RangePair> Cluster;
+    static constexpr bool RLC = IX::RLC; // the reference's RUN_LENGTH_COMPRESSION branches
+    const IX& index;
     const Strategy& strat;
     bool noCIGAR = true;
     Counters counters;
 
-    Matcher(const Index& idx, const Strategy& st) : index(idx), strat(st) {}
+    MatcherT(const IX& idx, const Strategy& st) : index(idx), strat(st) {}
 
     // === SearchStrategy::matchApproxAllMap (searchstrategy.cpp:495-535) ===
     std::vector<TextOcc> matchApproxAll(const std::string& read, len_t maxED) {
@@ -330,6 +352,8 @@ class Matcher {
     // fmindex.cpp:312-342 (+ InTextVerificationTask::doTask): one window, one zero in the first column
     void inTextVerificationOneString(len_t startPos, len_t endPos, len_t maxED, len_t minED, Occurrences& occ,
                                      const std::string& pattern) {
+        if constexpr (RLC) throw std::runtime_error("oracle: no in-text verification on the b-move index (bmove.cpp:590-596)");
+        else {
         BitParallelED64& matrix = fullReadMatrix();
         Substring pat(pattern.data(), (len_t)pattern.size(), 0, (len_t)pattern.size(), FORWARD);
         if (!matrix.sequenceSet()) matrix.setSequence(pat);
@@ -363,6 +387,7 @@ class Matcher {
             t.cigar = cigar;
             occ.inTextOcc.emplace_back(std::move(t));
         }
+        }
     }
     // IndexInterface::generateCIGAR: findCIGAR of the occurrence's text range (bitparallelmatrix.h:460-527)
     void generateCIGAR(TextOcc& t, const std::string& seq) {
@@ -370,10 +395,13 @@ class Matcher {
             t.cigar = {{'M', (uint32_t)seq.size()}};
             return;
         }
+        if constexpr (RLC) throw std::runtime_error("oracle: CIGAR from the matched string is not restated for the b-move index");
+        else {
         BitParallelED64 M;
         M.setSequence(Substring(seq.data(), (len_t)seq.size(), 0, (len_t)seq.size(), FORWARD));
         Substring ref((const char*)index.text, index.textLength, t.range.b, t.range.e);
         M.findCIGAR(ref, t.distance, t.cigar);
+        }
     }
     // IndexInterface::findSeqName (indexinterface.cpp:799-899); returns 0 FOUND, 1 FOUND_WITH_TRIMMING, 2 NOT_FOUND
     int findSeqName(BestOcc& o, len_t largestStratum, const std::string& pattern) {
@@ -650,14 +678,14 @@ class Matcher {
                                   : (dir == FORWARD ? index.extendForward(i, parent, child)
                                                     : index.extendBackward(i, parent, child));
             if (ok) {
-                stack.emplace_back(Index::i2c((int)i), child, row + 1);
+                stack.emplace_back(IX::i2c((int)i), child, row + 1);
                 counters.inc(NODE_COUNTER);
             }
         }
     }
     // indexinterface.cpp:1034-1049
     bool addChar(char c, RangePair& r) {
-        int pos = Index::c2i(c);
+        int pos = IX::c2i(c);
         if (pos > -1) {
             counters.inc(EXPANSIONS);
             RangePair child;
@@ -684,10 +712,24 @@ class Matcher {
     // === exact matching (indexinterface.cpp:918-1014) ===
     void exactMatchesOutput(const std::string& s, std::vector<TextOcc>& tOcc) {
         if (s.size() == 0) return;
+        if constexpr (RLC) { // the RUN_LENGTH_COMPRESSION branches of :955-962, :976-981, :1002-1010: no in-text switch
+            auto range = index.exactStart(); // SARangeBackwards with the toehold of the complete range
+            for (len_t i = (len_t)s.size(); i-- > 0;) {
+                int pos = IX::c2i(s[i]);
+                if (pos == -1) return;
+                counters.inc(EXPANSIONS);
+                if (!index.extendExact(pos, range)) return;
+                counters.inc(NODE_COUNTER);
+            }
+            for (len_t pos : index.beginPositionsExact(range, counters))
+                tOcc.emplace_back(Range(pos, pos + (len_t)s.size()), 0, strand);
+            counters.inc(TOTAL_REPORTED_POSITIONS, tOcc.size());
+            return;
+        } else {
         Range range = index.completeRange().sa;
         len_t i = (len_t)s.size();
         for (; i-- > 0;) {
-            int pos = Index::c2i(s[i]);
+            int pos = IX::c2i(s[i]);
             if (pos == -1) return;
             counters.inc(EXPANSIONS);
             if (!index.extendRangeBackward(pos, range, range)) return;
@@ -728,6 +770,7 @@ class Matcher {
         }
         (void)before;
         counters.inc(TOTAL_REPORTED_POSITIONS, tOcc.size());
+        }
     }
 
     // === in-text verification (fmindex.cpp:245-310, indexhelpers.cpp:518-574) ===
@@ -745,6 +788,8 @@ class Matcher {
     template <class Matrix>
     void inTextVerificationOn(Matrix& matrix, const std::vector<len_t>& startPos, len_t maxED, len_t minED,
                               Occurrences& occ, const Substring& pattern, len_t nZeros) {
+        if constexpr (RLC) throw std::runtime_error("oracle: no in-text verification on the b-move index");
+        else {
         if (!matrix.sequenceSet()) matrix.setSequence(pattern);
         matrix.initializeMatrix(maxED, std::vector<uint32_t>(nZeros, 0u));
         len_t nRows = matrix.getNumberOfRows();
@@ -783,16 +828,19 @@ class Matcher {
                 occ.inTextOcc.emplace_back(std::move(t));
             }
         }
+        }
     }
 
     // fmindex.cpp:245-265
     void verifyExactPartialMatchInText(const FMOcc& startMatch, len_t beginInPattern,
                                        len_t maxED, Occurrences& occ, len_t minED,
                                        const Substring& pattern) {
+        if constexpr (!RLC) {
         counters.inc(IMMEDIATE_SWITCH);
         len_t startDiff = (beginInPattern == 0) ? 0 : beginInPattern + maxED;
         auto starts = index.getBeginPositions(startMatch.getRanges().sa, startDiff, 0, counters);
         inTextVerification(starts, maxED, minED, occ, pattern, beginInPattern == 0);
+        }
     }
 
     // === edit-distance DFS (indexinterface.cpp:340-669, :1306-1325) ===
@@ -801,6 +849,7 @@ class Matcher {
                                     const Substring& pattern, len_t idx, BitParallelED64* bpED,
                                     const FMOcc& sMatch, const std::vector<FMPosExt>& dOther,
                                     const std::vector<uint16_t>& iOther) {
+        if constexpr (!RLC) { // (:345-348: the function does nothing in case of run-length compression)
         len_t st = parts[s.getLowestPartProcessedBefore(idx)].begin();
         len_t startDiff = st + s.getMaxED();
         if (st == 0) {
@@ -814,6 +863,7 @@ class Matcher {
         }
         auto pos = index.getBeginPositions(node.ranges.sa, startDiff, sMatch.shift, counters);
         inTextVerification(pos, s.getMaxED(), s.getMinED(), occ, pattern, st == 0);
+        }
     }
 
     void recApproxMatchEdit(const Search& s, const FMOcc& startMatch, Occurrences& occ,
@@ -887,7 +937,7 @@ class Matcher {
                                descOther, noDesc)) {
                 continue;
             }
-            if (currentNode.ranges.width() <= inTextSwitchPoint && !idxZero) {
+            if (!RLC && currentNode.ranges.width() <= inTextSwitchPoint && !idxZero) {
                 goToInTextVerificationEdit(currentNode, s, parts, occ, pattern, idx, bpED,
                                            startMatch, descOther, initOther);
                 continue;
@@ -970,7 +1020,7 @@ class Matcher {
     // indexinterface.cpp:1306-1325
     void recApproxMatchEditEntry(const Search& search, const FMOcc& startMatch, Occurrences& occ,
                                  const std::vector<Substring>& parts, int idx) {
-        if (startMatch.getRanges().width() > index.switchPoint) {
+        if (RLC || startMatch.getRanges().width() > index.switchPoint) {
             counters.inc(SEARCH_STARTED);
             recApproxMatchEdit(search, startMatch, occ, parts, idx, {}, {}, {}, {});
             return;
@@ -981,8 +1031,9 @@ class Matcher {
     }
 
     // === Hamming DFS (indexinterface.cpp:1211-1304; fmindex.cpp:344-428) ===
-    void inTextVerificationHammingRange(const Range& r, const Substring& pattern, len_t maxEDFull,
+    void inTextVerificationHammingRange(const SARange& r, const Substring& pattern, len_t maxEDFull,
                                         len_t minEDFull, len_t lengthBefore, Occurrences& occ) {
+        if constexpr (!RLC) {
         const len_t pSize = pattern.size();
         for (len_t i = r.b; i < r.e; i++) {
             len_t Tb = index.findSA(i, counters);
@@ -998,6 +1049,7 @@ class Matcher {
             }
             if (score <= maxEDFull && score >= minEDFull)
                 occ.inTextOcc.emplace_back(Range(Tb, Te), score, strand);
+        }
         }
     }
     void recApproxMatchHamming(const Search& s, const FMOcc& startMatch, Occurrences& occ,
@@ -1015,7 +1067,7 @@ class Matcher {
         while (!stack.empty()) {
             const FMPosExt node = stack.back();
             stack.pop_back();
-            if (node.ranges.width() <= index.switchPoint) {
+            if (!RLC && node.ranges.width() <= index.switchPoint) { // (:1245-1249: FM flavour only)
                 // fmindex.cpp:409-428
                 len_t lengthBefore =
                     ((idx == 0) ? 0 : parts[s.getLowestPartProcessedBefore(idx)].begin()) -
@@ -1070,10 +1122,12 @@ class Matcher {
                     occurrences.inFMOcc.emplace_back(currentNode.ranges, matrix->at(row, lastCol),
                                                      currentNode.depth, strand);
             }
+            if constexpr (!RLC) { // (:1120-1132)
             if (currentNode.ranges.width() <= index.switchPoint) {
                 auto startPos = index.getBeginPositions(currentNode.ranges.sa, 0, 0, counters);
                 inTextVerification(startPos, maxED, 0, occurrences, fwd, true);
                 continue;
+            }
             }
             extendFMPos(currentNode.ranges, stack, currentNode.depth);
         }
@@ -1087,7 +1141,7 @@ class Matcher {
         while (!stack.empty()) {
             const FMPosExt node = stack.back();
             stack.pop_back();
-            if (node.ranges.width() <= index.switchPoint) {
+            if (!RLC && node.ranges.width() <= index.switchPoint) { // (:1170-1175)
                 inTextVerificationHammingRange(node.ranges.sa, fwd, maxED, 0, 0, occ);
                 continue;
             }
@@ -1254,7 +1308,7 @@ class Matcher {
             for (auto& t : textOccs) occs.inTextOcc.emplace_back(std::move(t));
             return;
         }
-        for (uint16_t i = 0; i < numParts; i++) {
+        for (uint16_t i = 0; !RLC && i < numParts; i++) { // (#ifndef RUN_LENGTH_COMPRESSION, searchstrategy.cpp:461)
             size_t width = exactMatchRanges[i].width();
             if (width != 0 && width <= index.switchPoint) {
                 const auto& part = parts[i];
@@ -1318,13 +1372,11 @@ class Matcher {
         len_t size = occ.inFMOcc.empty() ? 0 : occ.inFMOcc[0].getDepth();
         for (size_t fi = 0; fi < occ.inFMOcc.size(); fi++) {
             const auto& f = occ.inFMOcc[fi];
-            const Range& saRange = f.getRanges().sa;
+            const SARange& saRange = f.getRanges().sa;
             counters.inc(TOTAL_REPORTED_POSITIONS, saRange.width());
             const uint64_t lf0 = counters.c[LF_STEPS];
-            for (len_t i = saRange.b; i < saRange.e; i++) {
-                len_t p = index.findSA(i, counters);
+            for (len_t p : index.textPositions(f.getRanges(), counters)) // getTextPositionsFromSARange
                 occ.inTextOcc.emplace_back(Range(p, p + size), f.distance, f.strand);
-            }
             noteSurvivingDuplicate(occ, fi, lf0);
         }
         occ.eraseDoublesAndSortText();
@@ -1346,12 +1398,11 @@ class Matcher {
         occ.eraseDoublesFM();
         for (size_t fi = 0; fi < occ.inFMOcc.size(); fi++) {
             const auto& f = occ.inFMOcc[fi];
-            const Range& saRange = f.getRanges().sa;
+            const SARange& saRange = f.getRanges().sa;
             counters.inc(TOTAL_REPORTED_POSITIONS, saRange.width());
             len_t depth = f.getDepth(), distance = f.distance, shift = f.shift;
             const uint64_t lf0 = counters.c[LF_STEPS];
-            for (len_t i = saRange.b; i < saRange.e; i++) {
-                len_t p = index.findSA(i, counters);
+            for (len_t p : index.textPositions(f.getRanges(), counters)) { // getTextPositionsFromSARange
                 len_t startPos = p + shift;
                 occ.inTextOcc.emplace_back(Range(startPos, startPos + depth), distance, f.strand);
             }
@@ -1380,5 +1431,7 @@ class Matcher {
         return nonRedundantOcc;
     }
 };
+
+typedef MatcherT<Index> Matcher;
 
 } // namespace orc
