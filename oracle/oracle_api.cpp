@@ -6,6 +6,7 @@
 // ============================================================================
 #include "oracle_move.hpp"
 #include "oracle_search.hpp"
+#include "oracle_move_search.hpp"
 #include <atomic>
 #include <thread>
 
@@ -338,6 +339,56 @@ void* orc_match_batch(void* h, void* sp, uint32_t k, const char* seqs, const uin
     for (auto& c : cnts) res->counters.add(c);
     return res;
 }
+// the same call on the run-length compressed flavour (h: orc_move_create); wordSize: k-mer table of the index
+void* orc_move_match_batch(void* h, void* sp, uint32_t k, const char* seqs, const uint64_t* offs, uint32_t nReads,
+                           uint32_t nThreads, uint32_t wordSize) {
+    const orc::BMoveIndex64& bm = *(orc::BMoveIndex64*)h;
+    Strategy& st = *(Strategy*)sp;
+    OrcResult* res = new OrcResult();
+    std::vector<std::vector<orc_occ>> per(nReads);
+    if (nThreads == 0) nThreads = 1;
+    std::vector<Counters> cnts(nThreads);
+    std::vector<std::string> errs(nThreads);
+    std::atomic<uint32_t> next(0);
+    try {
+        const orc::MoveIndexAdapter x(bm, wordSize);
+        auto work = [&](uint32_t tid) {
+            orc::MoveMatcher m(x, st);
+            const uint64_t rows0 = *bm.rowStepsPtr();
+            try {
+                for (;;) {
+                    uint32_t base = next.fetch_add(64);
+                    if (base >= nReads) break;
+                    uint32_t end = std::min(nReads, base + 64);
+                    for (uint32_t r = base; r < end; r++) {
+                        std::string read = orc::MoveMatcher::cleanRead(std::string(seqs + offs[r], offs[r + 1] - offs[r]));
+                        auto v = m.matchApproxAll(read, k);
+                        per[r].reserve(v.size());
+                        for (auto& t : v) per[r].push_back({t.range.b, t.range.e, t.distance, (uint32_t)t.strand});
+                    }
+                }
+            } catch (const std::exception& e) {
+                errs[tid] = e.what();
+            }
+            m.counters.inc(ROW_STEPS, *bm.rowStepsPtr() - rows0);
+            cnts[tid] = m.counters;
+        };
+        std::vector<std::thread> th;
+        for (uint32_t t = 1; t < nThreads; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto& t : th) t.join();
+    } catch (const std::exception& e) {
+        res->error = e.what();
+    }
+    for (auto& e : errs)
+        if (!e.empty()) res->error = e;
+    res->offs.resize(nReads + 1, 0);
+    for (uint32_t r = 0; r < nReads; r++) res->offs[r + 1] = res->offs[r] + per[r].size();
+    res->occs.reserve(res->offs[nReads]);
+    for (uint32_t r = 0; r < nReads; r++) res->occs.insert(res->occs.end(), per[r].begin(), per[r].end());
+    for (auto& c : cnts) res->counters.add(c);
+    return res;
+}
 // ---- BEST (+x strata) mode for a chunk of reads: occurrences (concatenated-text coordinates) + assignment + CIGAR
 struct OrcBest {
     std::vector<orc_occ> occs;
@@ -535,13 +586,13 @@ uint64_t orc_move_rows(void* h, int rev, uint64_t* out) {
 uint64_t orc_move_extend(void* h, int mode, uint64_t n, const orc_move_range* parents, const uint8_t* c, orc_move_range* children,
                          uint8_t* ok) {
     auto* ix = (orc::BMoveIndex64*)h;
-    const uint64_t before = ix->counters.rowSteps;
+    const uint64_t before = *ix->rowStepsPtr();
     for (uint64_t i = 0; i < n; i++) {
         orc::MovePair64 child;
         ok[i] = ix->extend(mode, c[i], toPair(parents[i]), child);
         children[i] = fromPair(child);
     }
-    return ix->counters.rowSteps - before;
+    return *ix->rowStepsPtr() - before;
 }
 // text positions of a range (bmove.cpp:543-560); returns the count (positions beyond cap are not stored)
 uint64_t orc_move_locate(void* h, const orc_move_range* r, uint64_t* out, uint64_t cap) {

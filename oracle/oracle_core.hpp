@@ -69,6 +69,9 @@ enum CounterType {
     // LF_STEPS is such repeated work (the device removes every duplicate).
     SURVIVING_DUP_ROWS,
     SURVIVING_DUP_LF,
+    // run-length compressed flavour only: table rows stepped over by the reference's run walks and fast-forwards
+    // (walkToNextRun / walkToPreviousRun / fastForward, moverepr.cpp:251-297) — that backend's byte-model unit
+    ROW_STEPS,
     COUNTER_TYPE_MAX
 };
 struct Counters {
@@ -257,6 +260,9 @@ struct EncodedBWT {
 // Index view (fmindex/fmindex.h:43-62, indexinterface.h protected members)
 // ----------------------------------------------------------------------------
 struct Index {
+    typedef ::orc::RangePair RangePair; // (what MatcherT<Index> works on; the b-move adapter has ranges with toeholds)
+    typedef Range SARange;
+    static constexpr bool RLC = false;
     len_t textLength = 0;     // n including the final '$'
     const uint8_t* text = 0;  // ASCII text, text[n-1] == '$'
     len_t counts[5] = {0, 0, 0, 0, 0}; // cumulative counts ($,A,C,G,T) indexinterface.cpp:143-150
@@ -362,6 +368,13 @@ struct Index {
             len_t sum = findSA(i, cnt) + shift;
             positions[i - r.b] = sum >= startDiff ? sum - startDiff : 0;
         }
+        return positions;
+    }
+    // fmindex.cpp:62-69 (getTextPositionsFromSARange): findSA of every row
+    std::vector<len_t> textPositions(const RangePair& r, Counters& cnt) const {
+        std::vector<len_t> positions;
+        positions.reserve(r.sa.width());
+        for (len_t i = r.sa.b; i < r.sa.e; i++) positions.push_back(findSA(i, cnt));
         return positions;
     }
     // indexinterface.h:590-594 + tkmer.h (2-bit packed k-mer key).  Entries of

@@ -298,7 +298,11 @@ template <typename L> class BMoveIndexT {
     // locate: the sorted marked positions of predFirst / predLast (buildindex.cpp:990-1013) with firstToRun / lastToRun
     // (buildindex.cpp:1044-1066), and the PLCP array (bmove/plcp.h; held plain here, operator[] = the array element)
     std::vector<L> predFirst, predLast, firstToRun, lastToRun, plcp;
-    mutable MoveCounters counters;
+    // rows stepped over by the walks, per thread (the matcher runs one thread per read shard on the same index)
+    static uint64_t* rowStepsPtr() {
+        static thread_local MoveCounters c;
+        return &c.rowSteps;
+    }
 
     L getInitialToehold() const { return samplesLast.back() - 1; } // bmove.h:139-142
     MovePair getCompleteRange() const {                                    // bmove.h:369-373
@@ -310,7 +314,7 @@ template <typename L> class BMoveIndexT {
                             L c) const { // bmove.cpp:222-266 (computeToehold / computeToeholdRev)
         if (m.getRunHead(r.endRun) == c) return first[r.endRun] - 1;
         L prevPos, prevRun;
-        m.walkToPreviousRun(r, prevPos, prevRun, c, &counters.rowSteps);
+        m.walkToPreviousRun(r, prevPos, prevRun, c, rowStepsPtr());
         return last[prevRun] - 1;
     }
 
@@ -318,7 +322,7 @@ template <typename L> class BMoveIndexT {
     bool extendBackward(L c, const MovePair& parent, MovePair& child) const {
         MoveRange range1, trivial = parent.sa;
         if (!trivial.runIndicesValid) move.computeRunIndices(trivial); // bmove.cpp:289-297
-        move.addChar(trivial, range1, c, &counters.rowSteps);
+        move.addChar(trivial, range1, c, rowStepsPtr());
         if (range1.empty()) {
             child = MovePair(range1, range1, 0, false, 0);
             return false;
@@ -330,7 +334,7 @@ template <typename L> class BMoveIndexT {
             return true;
         }
         L s = parent.rev.begin;
-        L x = move.getCumulativeCounts(trivial, c, &counters.rowSteps);
+        L x = move.getCumulativeCounts(trivial, c, rowStepsPtr());
         MoveRange range2(s + x, s + x + range1.width(), other.beginRun, other.endRun);
         range2.runIndicesValid = false;
         L newToehold = computeToeholdOn(move, samplesFirst, samplesLast, trivial, c);
@@ -342,7 +346,7 @@ template <typename L> class BMoveIndexT {
         MoveRange trivial = parent.rev;
         if (!trivial.runIndicesValid) moveR.computeRunIndices(trivial);
         MoveRange range1;
-        moveR.addChar(trivial, range1, c, &counters.rowSteps);
+        moveR.addChar(trivial, range1, c, rowStepsPtr());
         if (range1.empty()) {
             child = MovePair(range1, range1, 0, false, 0);
             return false;
@@ -354,7 +358,7 @@ template <typename L> class BMoveIndexT {
             return true;
         }
         L s = parent.sa.begin;
-        L x = moveR.getCumulativeCounts(trivial, c, &counters.rowSteps);
+        L x = moveR.getCumulativeCounts(trivial, c, rowStepsPtr());
         MoveRange range2(s + x, s + x + range1.width(), other.beginRun, other.endRun);
         range2.runIndicesValid = false;
         L newToehold = textLength - 1 - computeToeholdOn(moveR, revSamplesFirst, revSamplesLast, trivial, c);
@@ -365,7 +369,7 @@ template <typename L> class BMoveIndexT {
     bool extendBackwardUni(L c, const MovePair& parent, MovePair& child) const {
         MoveRange range1, trivial = parent.sa;
         if (!trivial.runIndicesValid) move.computeRunIndices(trivial);
-        move.addChar(trivial, range1, c, &counters.rowSteps);
+        move.addChar(trivial, range1, c, rowStepsPtr());
         if (range1.empty()) {
             child = MovePair(range1, range1, 0, false, 0);
             return false;
@@ -383,7 +387,7 @@ template <typename L> class BMoveIndexT {
     bool extendRangeBackward(L c, MoveRange& range, L& toehold, bool& repEnd, L& depth) const {
         MoveRange range1, trivial = range;
         if (!trivial.runIndicesValid) move.computeRunIndices(trivial);
-        move.addChar(trivial, range1, c, &counters.rowSteps);
+        move.addChar(trivial, range1, c, rowStepsPtr());
         if (range1.empty()) {
             range = range1;
             toehold = 0, repEnd = false, depth = 0;
@@ -474,6 +478,16 @@ template <typename L> class BMoveIndexT {
         }
     }
 };
+
+// MoveRange::operator== (indexhelpers.h:243-246), ToeholdInterface::operator== (:1098-1102), SARangePair::operator== (:1226-1233)
+template <typename L> inline bool operator==(const MoveRangeT<L>& a, const MoveRangeT<L>& b) {
+    return a.begin == b.begin && a.end == b.end && a.beginRun == b.beginRun && a.endRun == b.endRun;
+}
+template <typename L> inline bool operator==(const MovePairT<L>& a, const MovePairT<L>& b) {
+    return a.sa == b.sa && a.toehold == b.toehold && a.toeholdRepresentsEnd == b.toeholdRepresentsEnd &&
+           a.originalDepth == b.originalDepth;
+}
+template <typename L> inline L saBeginOf(const MovePairT<L>& r) { return r.sa.begin; }
 
 typedef MoveRangeT<uint64_t> MoveRange64;
 typedef MoveLFT<uint64_t> MoveLF64;

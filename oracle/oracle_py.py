@@ -21,13 +21,14 @@ COUNTER_NAMES = [
     "NODE_COUNTER", "TOTAL_REPORTED_POSITIONS", "IN_TEXT_STARTED", "ABORTED_IN_TEXT_VERIF",
     "CIGARS_IN_TEXT_VERIFICATION", "IMMEDIATE_SWITCH", "SEARCH_STARTED",
     "EXPANSIONS", "LF_STEPS", "LOCATED_ROWS", "TEXT_BYTES", "MATRIX_ROWS",
-    "SURVIVING_DUP_ROWS", "SURVIVING_DUP_LF",
+    "SURVIVING_DUP_ROWS", "SURVIVING_DUP_LF", "ROW_STEPS",
 ]
 
 
 def build(force: bool = False) -> str:
     """Compile liboracle.so with g++ (seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("oracle_api.cpp", "oracle_core.hpp", "oracle_search.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_api.cpp", "oracle_core.hpp", "oracle_search.hpp", "oracle_move.hpp",
+                                             "oracle_move_search.hpp")]
     if not force and os.path.exists(_LIB_PATH) and all(
             os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return _LIB_PATH
@@ -107,6 +108,8 @@ def lib():
         L.orc_move_match_exact.restype = C.c_uint64
         L.orc_move_match_exact.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.orc_move_kmer_table.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_move_match_batch.restype = C.c_void_p
+        L.orc_move_match_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_move_locate.restype = C.c_uint64
         L.orc_move_locate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         _lib = L
@@ -410,3 +413,23 @@ class OracleMoveIndex:
         out = np.zeros(4 ** word_size, dtype=MOVE_RANGE_DTYPE)
         lib().orc_move_kmer_table(self.h, word_size, _p(out))
         return out
+
+    def match_batch(self, strat: "OracleStrategy", k: int, reads: Sequence[bytes], threads: int = 1, word_size: int = 10):
+        """SearchStrategy::matchApprox of the RUN_LENGTH_COMPRESSION flavour for a chunk of reads (ALL mode):
+        (occurrences, offsets, counters) as match_batch of the FM-index flavour"""
+        buf, offs = pack_reads(reads)
+        if buf.shape[0] == 0:
+            buf = np.zeros(1, np.uint8)
+        r = lib().orc_move_match_batch(self.h, strat.h, k, _p(buf), _p(offs), len(reads), threads, word_size)
+        try:
+            err = lib().orc_result_error(r)
+            if err:
+                raise RuntimeError(err.decode())
+            n = lib().orc_result_size(r)
+            occs = np.zeros(max(n, 1), OCC_DTYPE)
+            ro = np.zeros(len(reads) + 1, np.uint64)
+            cnt = np.zeros(lib().orc_num_counters(), np.uint64)
+            lib().orc_result_copy(r, _p(occs), _p(ro), _p(cnt))
+        finally:
+            lib().orc_result_free(r)
+        return occs[:n], ro, dict(zip(COUNTER_NAMES, cnt.tolist()))
