@@ -24,7 +24,7 @@ ERRORS = {-1: "CMB_ERR_INVALID", -2: "CMB_ERR_DEVICE", -3: "CMB_ERR_UNSUPPORTED"
           -5: "CMB_ERR_INTERNAL"}
 COUNTER_NAMES = ["NODE_COUNTER", "TOTAL_REPORTED_POSITIONS", "IN_TEXT_STARTED", "ABORTED_IN_TEXT_VERIF",
                  "CIGARS_IN_TEXT_VERIFICATION", "IMMEDIATE_SWITCH", "SEARCH_STARTED", "EXPANSIONS", "LF_STEPS",
-                 "LOCATED_ROWS", "TEXT_BYTES", "MATRIX_ROWS", "DFS_EXPANSIONS"]
+                 "LOCATED_ROWS", "TEXT_BYTES", "MATRIX_ROWS", "DFS_EXPANSIONS", "TABLE_ROWS"]
 METRIC = {"hamming": 0, "edit": 1}
 PARTITION = {"uniform": 0, "static": 1, "dynamic": 2}
 OCC_DTYPE = np.dtype([("begin", np.uint32), ("end", np.uint32), ("distance", np.uint32), ("strand", np.uint32)])
@@ -51,6 +51,8 @@ EXPORTS = [
     "cmb_move_create", "cmb_move_destroy", "cmb_move_device_bytes", "cmb_move_info", "cmb_move_complete_range", "cmb_move_rows",
     "cmb_move_extend_batch", "cmb_move_extend_bench", "cmb_move_locate_batch", "cmb_move_match_exact", "cmb_move_last_timings", "cmb_move_kmer_table",
     "cmb_move_layout_of", "cmb_move_create_empty", "cmb_move_device_arrays", "cmb_move_validate",
+    "cmb_move_match_batch", "cmb_move_batch_create", "cmb_move_batch_run", "cmb_move_batch_result_size", "cmb_move_batch_results",
+    "cmb_move_batch_timings", "cmb_move_batch_destroy",
     "cmb_last_error", "cmb_version",
 ]
 
@@ -274,6 +276,14 @@ def lib():
         L.cmb_move_locate_batch.argtypes = [vp, vp, u64, vp, vp]
         L.cmb_move_match_exact.argtypes = [vp, vp, vp, u64, vp, u64, vp, C.POINTER(u64), vp]
         L.cmb_move_last_timings.argtypes = [vp, u32]
+        L.cmb_move_match_batch.argtypes = [vp, vp, u32, u32, vp, vp, u32, vp, u64, vp, vp, C.POINTER(u64)]
+        L.cmb_move_batch_create.argtypes = [vp, vp, u32, u32, vp, vp, u32, C.POINTER(vp)]
+        L.cmb_move_batch_run.argtypes = [vp]
+        L.cmb_move_batch_result_size.argtypes = [vp, C.POINTER(u64)]
+        L.cmb_move_batch_results.argtypes = [vp, vp, u64, vp, vp]
+        L.cmb_move_batch_timings.argtypes = [vp, vp, vp, u32]
+        L.cmb_move_batch_destroy.argtypes = [vp]
+        L.cmb_move_batch_destroy.restype = None
         L.cmb_move_kmer_table.argtypes = [vp, u32, vp]
         L.cmb_move_layout_of.argtypes = [vp, C.POINTER(MoveLayout)]
         L.cmb_move_create_empty.argtypes = [C.POINTER(MoveLayout), i32, C.POINTER(vp)]
@@ -884,6 +894,53 @@ class MoveIndex:
         out = np.zeros(4 ** word_size, dtype=MOVE_RANGE_DTYPE)
         _chk(lib().cmb_move_kmer_table(self.h, word_size, _p(out)))
         return out
+
+    def match_batch(self, strategy: "SearchStrategy", max_distance: int, reads, kmer_size: int = 10):
+        """``SearchStrategy::matchApprox`` (ALL mode) of the RUN_LENGTH_COMPRESSION flavour for a chunk of reads:
+        (occurrences, per-read offsets, counters)"""
+        b = MoveBatch(self, strategy, max_distance, reads, kmer_size=kmer_size)
+        try:
+            b.run()
+            return b.results()
+        finally:
+            b.close()
+
+
+class MoveBatch:
+    """A chunk of reads resident on the device for the b-move search (handle of ``cmb_move_batch_*``)."""
+
+    def __init__(self, index: MoveIndex, strategy: "SearchStrategy", max_distance: int, reads=None, packed=None, kmer_size: int = 10):
+        buf, offs = packed if packed is not None else pack_reads(reads)
+        self.n_reads = offs.shape[0] - 1
+        self._keep = (index, strategy, buf, offs)
+        h = C.c_void_p()
+        _chk(lib().cmb_move_batch_create(index.h, strategy.h, max_distance, kmer_size, _p(buf), _p(offs), self.n_reads, C.byref(h)))
+        self.h = h
+
+    def run(self):
+        _chk(lib().cmb_move_batch_run(self.h))
+
+    def results(self):
+        n = C.c_uint64()
+        _chk(lib().cmb_move_batch_result_size(self.h, C.byref(n)))
+        occ = np.zeros(max(int(n.value), 1), MOVE_OCC_DTYPE)
+        offs = np.zeros(self.n_reads + 1, np.uint64)
+        cnt = np.zeros(len(COUNTER_NAMES), np.uint64)
+        _chk(lib().cmb_move_batch_results(self.h, _p(occ), occ.shape[0], _p(offs), _p(cnt)))
+        return occ[:n.value], offs, dict(zip(COUNTER_NAMES, cnt.tolist()))
+
+    def timings(self) -> Dict[str, float]:
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = lib().cmb_move_batch_timings(self.h, names, ms, 16)
+        return {names[i].decode(): float(ms[i]) for i in range(n)}
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.cmb_move_batch_destroy(self.h)
+            self.h = None
+
+    __del__ = close
 
 
 def pair_chunk_sam(index: "Index", strategy: "SearchStrategy", max_distance: int, reads1, reads2, ids1, ids2, quals1, quals2, seq_names,

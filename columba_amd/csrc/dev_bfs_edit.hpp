@@ -26,8 +26,8 @@
 //                     edit distances of its final-column cells (5 bits per cell, carried by the node and
 //                     handed to the event), IS its MatrixMetaInfo; only the event handler ever walks it.
 #pragma once
-// (included by kernels.hpp after its wave helpers: waveExclusiveScan)
 #include "dev_partition.hpp"
+#include "dev_wave.hpp"
 
 namespace cmb {
 
@@ -109,6 +109,31 @@ __device__ __forceinline__ uint32_t boundsChecked(uint32_t idx, uint32_t cap, ui
 // [4] of [1]: the child's row stays in the parent's 32-row matrix block, [5] expansions whose two ends share a rank block
 __device__ unsigned long long g_bfsStats[8];
 #endif
+
+// What bfsHeavy (events, phase entry) needs to know about the index behind the search: the range-pair type of a node and
+// how it is laid out in the records.  FmTraits: the FM-index (four 32-bit bounds in one uint4); the run-length compressed
+// backend brings its own (move_search.hpp: ranges with run indices and a toehold, five uint4).  A pair occupies PAIR_U4
+// uint4 at `stride` apart (1: F records, descendant lists; qCap: the planes of the node queue).
+struct FmTraits {
+    typedef RangePair Pair;
+    typedef DfsTask Task;
+    static constexpr uint32_t PAIR_U4 = 1;
+    static __device__ __forceinline__ Pair load(const uint4* p, size_t) {
+        const uint4 v = p[0];
+        return RangePair{{v.x, v.y}, {v.z, v.w}};
+    }
+    static __device__ __forceinline__ void store(uint4* p, size_t, const Pair& r) { p[0] = make_uint4(r.sa.b, r.sa.e, r.rev.b, r.rev.e); }
+    static __device__ __forceinline__ Pair none() { return RangePair{{0, 0}, {0, 0}}; }
+    static __device__ __forceinline__ bool empty(const Pair& r) { return r.empty(); }
+    static __device__ __forceinline__ Pair taskRange(const Task& t) { return t.r; }
+    // an in-index occurrence (FMOcc) of read x strand rsId
+    template <class BUFS>
+    static __device__ __forceinline__ void emitFm(const BUFS&, const Queues& q, uint32_t slot, uint32_t rsId, const Pair& r, uint32_t depth,
+                                                  uint32_t ed, uint32_t shift) {
+        q.fm[slot] = FMOccRec{rsId, r.sa.b, r.sa.e, depth, ed, shift};
+    }
+    template <class BUFS> static __device__ __forceinline__ void fmHole(const BUFS&, const Queues& q, uint32_t slot) { q.fm[slot].rsId = 0xFFFFFFFFu; }
+};
 
 struct EdPack { // final-column edit distances of one path, cell i at bits [5i, 5i+5)
     uint64_t lo, hi;
@@ -516,23 +541,6 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
     if (flags) atomicOr(&q.cnt[3], flags);
 }
 
-__global__ void k_bfs_finish(BfsBufs B, Queues q) { // one block: per-block counters -> the batch counters
-    __shared__ unsigned long long s[3];
-    if (threadIdx.x < 3) s[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t j = threadIdx.x; j < BFS_GRID * 4; j += blockDim.x) {
-        const unsigned long long v = B.blockCnt[j];
-        if ((j & 3u) < 3u && v) atomicAdd(&s[j & 3u], v);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&q.counters[0], s[0]);  // NODE_COUNTER
-        atomicAdd(&q.counters[7], s[1]);  // EXPANSIONS
-        atomicAdd(&q.counters[12], s[1]); // DFS_EXPANSIONS
-        atomicAdd(&q.counters[11], s[2]); // MATRIX_ROWS
-    }
-}
-
 // ------------------------------------------------------------------ events: goDeeper + phase entry
 struct HeavyPlan {
     uint32_t kind;      // 0 nothing, 1 reportCentersAtEnd, 2 reportDeepestMinimum + entry, 3 getClusterCentra + entry,
@@ -546,14 +554,18 @@ struct HeavyPlan {
     uint32_t nDescSrc;  // descendants the next phase replays
 };
 
-template <bool START>
-__device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK* __restrict__ stp, const BfsBufs& B,
-                                         uint32_t pass, const DfsTask* __restrict__ tasks, uint32_t nTasks,
+template <bool START, class Tr = FmTraits>
+__device__ __forceinline__ void bfsHeavy(const DevStrategyK* __restrict__ stp, const BfsBufs& B,
+                                         uint32_t pass, const typename Tr::Task* __restrict__ tasks, uint32_t nTasks,
                                          const uint64_t* __restrict__ offs, uint32_t gw, const uint32_t* __restrict__ G,
                                          const PartOut* __restrict__ parts, const Queues& q, uint32_t bid,
                                          uint32_t nBlocks) {
     __shared__ uint32_t sh[4][5];
     __shared__ uint8_t ieL[ED_CELLS + 2][256]; // initEds under construction, [entry][thread]
+    typedef typename Tr::Pair Pair;
+    constexpr uint32_t PU = Tr::PAIR_U4;  // uint4 per range pair
+    constexpr uint32_t FU = PU + 1;       // F record: pair, {depth | c << 16, parent, reported, -}
+    constexpr uint32_t DU = PU + 1;       // descendant of a list: pair, {depth | c << 16}
     const uint32_t outP = START ? 0u : pass + 1u;
     const uint32_t nIn = START ? nTasks : min(B.ne[pass], B.evCap);
     const uint4* __restrict__ Ei = B.Ev[pass & 1u];
@@ -570,19 +582,19 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
         uint32_t fcE = BFS_NONE, last = 0, c0i = BFS_NONE, descRef0 = BFS_NONE, otherRef0 = BFS_NONE, lowerBound = 0;
         int remFrom = -1;
         EdPack pack{0, 0};
-        RangePair startR{{0, 0}, {0, 0}};
+        Pair startR = Tr::none();
         uint32_t startDepth = 0;
         const DevSearch* s = nullptr;
         if (i < nIn) {
             if (START) {
-                const DfsTask t = tasks[i];
+                const typename Tr::Task t = tasks[i];
                 if (t.rsId != 0xFFFFFFFFu) { // (holes of the task queue)
                     P.kind = 4;
                     rsId = t.rsId;
                     scheme = t.scheme;
                     search = t.search;
                     idx = t.idx; // the phase to enter
-                    startR = t.r;
+                    startR = Tr::taskRange(t);
                     startDepth = t.depth;
                     s = &stp->sch[scheme].s[search];
                 }
@@ -692,7 +704,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
         // ---- block-wide allocation: contexts, F records, arena units, in-index occurrences
         const uint32_t wantCtx = P.kind >= 2 ? 1u : 0u;
         const uint32_t wantF = P.kind >= 2 ? 1u + P.nDescSrc : 0u;
-        const uint32_t wantA = P.kind == 3 ? 2u * P.nDescNew + (2u * P.ni + 15u) / 16u : 0u;
+        const uint32_t wantA = P.kind == 3 ? DU * P.nDescNew + (2u * P.ni + 15u) / 16u : 0u;
         const uint32_t wantFm = P.kind == 1 ? (uint32_t)__popc(P.centres) : 0u;
         const uint32_t want[4] = {wantCtx, wantF, wantA, wantFm};
         uint32_t got[4];
@@ -708,7 +720,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
 
         // ---- the event itself
         bool enter = false;
-        RangePair smR{{0, 0}, {0, 0}};
+        Pair smR = Tr::none();
         uint32_t smDist = 0, smDepthN = 0, smShiftN = 0;
         uint32_t nInitNew = 0;
         if (P.kind == 4) {
@@ -721,33 +733,32 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
             uint32_t cur = fcE;
             const uint32_t lowest = (uint32_t)__ffs(P.centres) - 1u;
             for (uint32_t c = last;; c--) {
-                const uint4 f1 = B.F[(size_t)CMB_IDX(cur, B.fCap, 10) * F_U4 + 1];
+                const uint4 f1 = B.F[(size_t)CMB_IDX(cur, B.fCap, 10) * FU + PU];
                 if ((P.centres >> c) & 1u) {
-                    const uint32_t old = atomicExch(&reinterpret_cast<uint32_t*>(B.F + (size_t)CMB_IDX(cur, B.fCap, 11) * F_U4 + 1)[2], 1u);
+                    const uint32_t old = atomicExch(&reinterpret_cast<uint32_t*>(B.F + (size_t)CMB_IDX(cur, B.fCap, 11) * FU + PU)[2], 1u);
                     if (!old) { // FMPosExt::report (indexhelpers.h:1586-1601): once per node
-                        const uint4 r = B.F[(size_t)CMB_IDX(cur, B.fCap, 12) * F_U4];
+                        const Pair r = Tr::load(B.F + (size_t)CMB_IDX(cur, B.fCap, 12) * FU, 1);
                         const uint32_t e = edGet(pack, c);
-                        if (r.y > r.x && e >= lowerBound)
-                            q.fm[fmNext++] = FMOccRec{rsId, r.x, r.y, (f1.x & 0xFFFFu) + smDepth, e, smShift};
+                        if (!Tr::empty(r) && e >= lowerBound)
+                            Tr::emitFm(B, q, fmNext++, rsId, r, (f1.x & 0xFFFFu) + smDepth, e, smShift);
                     }
                 }
                 if (c == lowest) break;
                 cur = f1.y;
             }
-            for (; fmNext < fmEnd; fmNext++) q.fm[fmNext].rsId = 0xFFFFFFFFu; // holes
+            for (; fmNext < fmEnd; fmNext++) Tr::fmHole(B, q, fmNext); // holes
         } else if (P.kind == 2) {
             uint32_t cur = fcE;
-            for (uint32_t c = last; c > P.ci; c--) cur = B.F[(size_t)CMB_IDX(cur, B.fCap, 13) * F_U4 + 1].y;
-            const uint32_t old = atomicExch(&reinterpret_cast<uint32_t*>(B.F + (size_t)CMB_IDX(cur, B.fCap, 14) * F_U4 + 1)[2], 1u);
+            for (uint32_t c = last; c > P.ci; c--) cur = B.F[(size_t)CMB_IDX(cur, B.fCap, 13) * FU + PU].y;
+            const uint32_t old = atomicExch(&reinterpret_cast<uint32_t*>(B.F + (size_t)CMB_IDX(cur, B.fCap, 14) * FU + PU)[2], 1u);
             if (!old) {
-                const uint4 r = B.F[(size_t)CMB_IDX(cur, B.fCap, 15) * F_U4];
-                const uint4 f1 = B.F[(size_t)CMB_IDX(cur, B.fCap, 16) * F_U4 + 1];
+                const uint4 f1 = B.F[(size_t)CMB_IDX(cur, B.fCap, 16) * FU + PU];
                 const uint32_t up = P.ci - P.hi;
-                smR = RangePair{{r.x, r.y}, {r.z, r.w}};
+                smR = Tr::load(B.F + (size_t)CMB_IDX(cur, B.fCap, 15) * FU, 1);
                 smDist = P.ed;
                 smDepthN = (f1.x & 0xFFFFu) + (smDepth - up);
                 smShiftN = (dirCur == 1 ? up : 0u) + smShift;
-                enter = !smR.empty() && smDist >= lowerBound;
+                enter = !Tr::empty(smR) && smDist >= lowerBound;
             }
         } else if (P.kind == 3) {
             // descendants = the final-column nodes below the centre (walked bottom-up), then the rest of the
@@ -755,20 +766,20 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
             uint4* dl = B.A + CMB_IDX(aOff, B.aCap, 101);
             uint32_t cur = fcE;
             for (uint32_t c = last; c > P.ci; c--) {
-                const uint4 r = B.F[(size_t)CMB_IDX(cur, B.fCap, 17) * F_U4];
-                const uint4 f1 = B.F[(size_t)CMB_IDX(cur, B.fCap, 18) * F_U4 + 1];
+                const uint4* Fc = B.F + (size_t)CMB_IDX(cur, B.fCap, 17) * FU;
+                const uint4 f1 = Fc[PU];
                 const uint32_t j = c - P.ci - 1;
-                dl[2 * j] = r;
-                dl[2 * j + 1] = make_uint4((j + 1) | (f1.x & 0xFF0000u), 0u, 0u, 0u);
+#pragma unroll
+                for (uint32_t u = 0; u < PU; u++) dl[DU * j + u] = Fc[u];
+                dl[DU * j + PU] = make_uint4((j + 1) | (f1.x & 0xFF0000u), 0u, 0u, 0u);
                 cur = f1.y;
             }
-            const uint4 r = B.F[(size_t)CMB_IDX(cur, B.fCap, 19) * F_U4];
-            const uint4 f1 = B.F[(size_t)CMB_IDX(cur, B.fCap, 20) * F_U4 + 1];
-            smR = RangePair{{r.x, r.y}, {r.z, r.w}};
+            const uint4 f1 = B.F[(size_t)CMB_IDX(cur, B.fCap, 20) * FU + PU];
+            smR = Tr::load(B.F + (size_t)CMB_IDX(cur, B.fCap, 19) * FU, 1);
             smDist = P.ed;
             smDepthN = (f1.x & 0xFFFFu) + smDepth;
             smShiftN = smShift;
-            enter = !smR.empty();
+            enter = !Tr::empty(smR);
             if (enter) {
                 const uint32_t nd0 = last - P.ci;
                 if (P.nRem) {
@@ -776,8 +787,9 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                     const uint4* sl = B.A + CMB_IDX(sC4.x, B.aCap, 102);
                     for (uint32_t t = 0; t < P.nRem; t++) {
                         const uint32_t j = nd0 + t;
-                        dl[2 * j] = sl[2 * ((uint32_t)remFrom + t)];
-                        dl[2 * j + 1] = make_uint4((j + 1) | (sl[2 * ((uint32_t)remFrom + t) + 1].x & 0xFF0000u), 0u, 0u, 0u);
+#pragma unroll
+                        for (uint32_t u = 0; u < PU; u++) dl[DU * j + u] = sl[DU * ((uint32_t)remFrom + t) + u];
+                        dl[DU * j + PU] = make_uint4((j + 1) | (sl[DU * ((uint32_t)remFrom + t) + PU].x & 0xFF0000u), 0u, 0u, 0u);
                     }
                 }
                 // initEds (indexhelpers.cpp:300-376): the centre's distance, the distances below it, then the
@@ -824,15 +836,14 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                 nInitNew = ni;
                 const uint32_t maxEDNext = s->U[idxN];
                 while (nInitNew > 1 && ieL[nInitNew - 1][tid] > maxEDNext) nInitNew--; // :634
-                uint16_t* il = reinterpret_cast<uint16_t*>(dl + 2 * P.nDescNew);
+                uint16_t* il = reinterpret_cast<uint16_t*>(dl + DU * P.nDescNew);
                 uint32_t mn = ieL[0][tid];
                 for (uint32_t j = 0; j < nInitNew; j++) {
                     il[j] = ieL[j][tid];
                     mn = min(mn, (uint32_t)ieL[j][tid]);
                 }
                 if (s->dsw[idxN] && P.nDescNew > 0) { // :640-648
-                    const uint4 lr = dl[2 * (P.nDescNew - 1)];
-                    smR = RangePair{{lr.x, lr.y}, {lr.z, lr.w}};
+                    smR = Tr::load(dl + DU * (P.nDescNew - 1), 1);
                     smDist = mn;
                 }
             }
@@ -841,7 +852,8 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
         // ---- phase entry: recApproxMatchEdit prologue + replay of the descendants (:377-497)
         uint32_t outKind = 0; // 1: node of the next frontier, 2: event
         uint32_t evRem = 0, evCell = 0, fLast = BFS_NONE; // event of an interrupted replay: descendants left, cell, its F record
-        uint4 oN0 = make_uint4(0, 0, 0, 0), oN1 = oN0, oN2 = oN0, oN4 = oN0, oEv1 = oN0;
+        uint4 oN1 = make_uint4(0, 0, 0, 0), oN2 = oN1, oN4 = oN1, oEv1 = oN1;
+        Pair oRoot = Tr::none();
         if (enter) {
             if (descSelf) descRefN = cNew;
             if (otherSelf) otherRefN = cNew;
@@ -868,7 +880,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                 nSrcInit = (dC4.y >> 8) & 0xFFu;
             }
             const uint4* dl = B.A + CMB_IDX(dListOff, B.aCap, 103);
-            const uint16_t* il = reinterpret_cast<const uint16_t*>(dl + 2 * nSrcDesc);
+            const uint16_t* il = reinterpret_cast<const uint16_t*>(dl + DU * nSrcDesc);
             uint32_t first = smDist, lastI = smDist, nInit = 1, increase = 0;
             if (nSrcInit != 0) { // :411-424
                 uint32_t prevED = il[0];
@@ -910,7 +922,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                             oInit = (oC4.y >> 8) & 0xFFu;
                         }
                         if (oDesc > 0) {
-                            const uint16_t* oi = reinterpret_cast<const uint16_t*>(B.A + CMB_IDX(oOff + 2 * oDesc, B.aCap, 104));
+                            const uint16_t* oi = reinterpret_cast<const uint16_t*>(B.A + CMB_IDX(oOff + DU * oDesc, B.aCap, 104));
                             itStart -= oDesc - oInit + (uint32_t)oi[oInit - 1];
                         }
                     }
@@ -925,7 +937,6 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                 Cx[CTX_HOT] = make_uint4(rsId | (itMode << 25) | (dirN << 27) | (uniN << 28),
                                    g.n | (g.m << 9) | (g.Wv << 18) | (g.Wh << 23) | (maxEDn << 27), itStart,
                                    itMeta | (clSize << 23));
-                Cx[2] = make_uint4(smR.sa.b, smR.sa.e, smR.rev.b, smR.rev.e);
                 Cx[3] = make_uint4(smDepthN, smShiftN, smDist, xOff | (xLen << 16));
                 Cx[4] = make_uint4(descSelf || otherSelf ? aOff : 0u,
                                    descSelf || otherSelf ? (P.nDescNew | (nInitNew << 8)) : 0u, 0u, 0u);
@@ -944,13 +955,13 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                     const uint32_t e0 = cellAt(0, xLen, HP, HN, score);
                     if (e0 > 31u) flags |= FLAG_CAPACITY;
                     edPut(pk, 0, min(e0, 31u));
-                    uint4* Fr = B.F + (size_t)CMB_IDX(fNext, B.fCap, 21) * F_U4;
-                    Fr[0] = make_uint4(smR.sa.b, smR.sa.e, smR.rev.b, smR.rev.e);
-                    Fr[1] = make_uint4(0u, BFS_NONE, 0u, 0u);
+                    uint4* Fr = B.F + (size_t)CMB_IDX(fNext, B.fCap, 21) * FU;
+                    Tr::store(Fr, 1, smR);
+                    Fr[PU] = make_uint4(0u, BFS_NONE, 0u, 0u);
                     fcCur = fNext++;
                 }
                 bool live = true;
-                RangePair root = smR;
+                Pair root = smR;
                 uint32_t rootRow = 0;
                 if (nSrcDesc > 0) { // replay (:463-492)
                     const uint32_t maxRow = g.m - 1;
@@ -960,7 +971,7 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                     uint32_t j = 0;
                     bool interrupted = false;
                     for (; j < nSrcDesc; j++) {
-                        const uint32_t meta = dl[2 * j + 1].x;
+                        const uint32_t meta = dl[DU * j + PU].x;
                         const uint32_t depth = meta & 0xFFFFu, ch = (meta >> 16) & 0xFFu;
                         if (depth > maxRow) break;
                         const uint64_t M = matchWord(gString(G, gw, rsId, (uint32_t)useRev, ch - 1u), xOff, xLen, depth / MX_BLOCK);
@@ -972,9 +983,10 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                             const uint32_t e = cellAt(depth, g.n - 1, HP, HN, score);
                             if (e > 31u) flags |= FLAG_CAPACITY;
                             edPut(pk, cellJ, min(e, 31u));
-                            uint4* Fr = B.F + (size_t)CMB_IDX(fNext, B.fCap, 22) * F_U4;
-                            Fr[0] = dl[2 * j];
-                            Fr[1] = make_uint4(depth | (ch << 16), fcCur, 0u, 0u);
+                            uint4* Fr = B.F + (size_t)CMB_IDX(fNext, B.fCap, 22) * FU;
+#pragma unroll
+                            for (uint32_t u = 0; u < PU; u++) Fr[u] = dl[DU * j + u];
+                            Fr[PU] = make_uint4(depth | (ch << 16), fcCur, 0u, 0u);
                             fcCur = fNext++;
                             if (!valid || onlyVerticalGapsLeft(g, depth, HN)) { // goDeeper, then `return` (:472-477)
                                 interrupted = true;
@@ -990,25 +1002,24 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
                     if (interrupted) {
                         outKind = 2;
                         evRem = j + 1;
-                        evCell = clSize + (dl[2 * j + 1].x & 0xFFFFu) - g.m;
+                        evCell = clSize + (dl[DU * j + PU].x & 0xFFFFu) - g.m;
                         fLast = fNext - 1u; // (the F record of that row was the last one handed out)
                         oEv1 = make_uint4((uint32_t)pk.lo, (uint32_t)(pk.lo >> 32), (uint32_t)pk.hi, (uint32_t)(pk.hi >> 32));
                     }
                     if (live) {
-                        const uint32_t lastDepth = dl[2 * (nSrcDesc - 1) + 1].x & 0xFFFFu;
+                        const uint32_t lastDepth = dl[DU * (nSrcDesc - 1) + PU].x & 0xFFFFu;
                         if (lastDepth == maxRow) live = false; // :479
                         else {
                             rootRow = lastDepth;
                             if (!dswN) { // after a switch the range of the start match is kept (:485)
-                                const uint4 lr = dl[2 * (nSrcDesc - 1)];
-                                root = RangePair{{lr.x, lr.y}, {lr.z, lr.w}};
+                                root = Tr::load(dl + DU * (nSrcDesc - 1), 1);
                             }
                         }
                     }
                 }
                 if (live) {
                     outKind = 1;
-                    oN0 = make_uint4(root.sa.b, root.sa.e, root.rev.b, root.rev.e);
+                    oRoot = root;
                     oN1 = make_uint4(rootRow | (score << 16), cNew, fcCur,
                                      ((uint32_t)__ffsll((unsigned long long)RAC) - 1u) | ((uniN ? 2u : (dirN == 0 ? 0u : 1u)) << 8));
                     oN2 = make_uint4((uint32_t)HP, (uint32_t)(HP >> 32), (uint32_t)HN, (uint32_t)(HN >> 32));
@@ -1023,10 +1034,10 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
         if (outKind == 1) {
             if (oN >= qCap) flags |= FLAG_BFS_Q;
             else {
-                Qo[oN] = oN0;
-                Qo[(size_t)qCap + oN] = oN1;
-                Qo[(size_t)2 * qCap + oN] = oN2;
-                Qo[(size_t)3 * qCap + oN] = oN4;
+                Tr::store(Qo + oN, qCap, oRoot);
+                Qo[(size_t)PU * qCap + oN] = oN1;
+                Qo[(size_t)(PU + 1) * qCap + oN] = oN2;
+                Qo[(size_t)(PU + 2) * qCap + oN] = oN4;
             }
         } else if (outKind == 2) {
             if (oE >= B.evCap) flags |= FLAG_BFS_EV;
@@ -1041,28 +1052,6 @@ __device__ __forceinline__ void bfsHeavy(const DevIndex& ix, const DevStrategyK*
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
     if ((tid & 63u) == 0 && v) atomicAdd(&q.counters[11], v);
     if (flags) atomicOr(&q.cnt[3], flags);
-}
-
-// first approximate phase of every task (k_exact's DfsTask queue) -> frontier of pass 0
-__global__ void __launch_bounds__(256)
-k_bfs_start(DevIndex ix, const DevStrategyK* __restrict__ stp, BfsBufs B, const DfsTask* __restrict__ tasks, uint32_t nTasks,
-            const uint64_t* __restrict__ offs, uint32_t gw, const uint32_t* __restrict__ G, const PartOut* __restrict__ parts,
-            Queues q) {
-    if (blockStopped(q)) return;
-    bfsHeavy<true>(ix, stp, B, 0u, tasks, nTasks, offs, gw, G, parts, q, blockIdx.x, gridDim.x);
-}
-
-// one level: blocks [0, BFS_GRID) expand the frontier, blocks [BFS_GRID, BFS_GRID + BFS_GRID_EV) handle the events
-// of the same pass (both only append to the queues of pass + 1, so they run side by side)
-#ifndef CMB_BFS_WAVES
-#define CMB_BFS_WAVES 4 // wavefronts per SIMD the register allocation of k_bfs_pass is held to (128 VGPRs)
-#endif
-__global__ void __launch_bounds__(256, CMB_BFS_WAVES)
-k_bfs_pass(DevIndex ix, const DevStrategyK* __restrict__ stp, BfsBufs B, uint32_t pass, const uint64_t* __restrict__ offs,
-           uint32_t gw, const uint32_t* __restrict__ G, const PartOut* __restrict__ parts, Queues q) {
-    if (blockStopped(q)) return;
-    if (blockIdx.x < B.gridX) bfsExpand(ix, B, pass, q, blockIdx.x, B.gridX);
-    else bfsHeavy<false>(ix, stp, B, pass, nullptr, 0u, offs, gw, G, parts, q, blockIdx.x - B.gridX, B.gridEv);
 }
 
 } // namespace cmb

@@ -258,86 +258,54 @@ k_prep(const uint8_t* __restrict__ reads, const uint64_t* __restrict__ offs, uin
     }
 }
 
-// Per-lane counters are summed over the wavefront first (all 64 lanes call this, at the end of a kernel):
-// one atomic per wavefront and counter instead of one per lane.
-__device__ __forceinline__ void flushCounters(const Queues& q, const uint32_t* local, const int* which, int n) {
-    for (int i = 0; i < n; i++) {
-        unsigned long long v = local[i];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-        if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&q.counters[which[i]], v);
-    }
-}
-
-// wave-wide exclusive prefix sum (all 64 lanes must call)
-__device__ __forceinline__ uint32_t waveExclusiveScan(uint32_t v, uint32_t& total) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d);
-        if ((int)lane >= d) x += y;
-    }
-    total = __shfl(x, 63);
-    return x - v;
-}
-// one atomic per wavefront: returns this lane's first slot for its `n` records in a queue
-__device__ __forceinline__ uint32_t waveAppend(uint32_t* counter, uint32_t n, uint32_t& total) {
-    const uint32_t off = waveExclusiveScan(n, total);
-    uint32_t base = 0;
-    if (total) {
-        if ((threadIdx.x & 63u) == 0) base = atomicAdd(counter, total);
-        base = __shfl(base, 0);
-    }
-    return base + off;
-}
-
-// Queue space in per-wavefront CHUNKS.  Atomics on one address are served at ~90 per microsecond by the
-// L2 atomic unit, whichever wavefront issues them: a kernel whose wavefronts append a few records every
-// loop iteration is bound by that (2 M appends = 22 ms) and does not get faster with more wavefronts.  So a
-// wavefront reserves `chunk` slots with ONE atomic and hands them out locally (prefix sum); what is left of
-// a chunk when it is retired, or when the kernel ends, is filled with HOLES (records whose first word is
-// 0xFFFFFFFF), which the consumers skip.  All members are wave-uniform.
-struct WaveChunk {
-    uint32_t base = 0, used = 0, size = 0;
-    // slots [returned, returned + n) for this lane's n records; 0xFFFFFFFF if the queue overflowed.
-    // All 64 lanes must call; `hole(i)` writes a hole at slot i.
-    template <class Hole>
-    __device__ __forceinline__ uint32_t alloc(uint32_t* counter, uint32_t cap, uint32_t n, uint32_t chunk, bool& overflow,
-                                              Hole hole) {
-        uint32_t total;
-        const uint32_t pre = waveExclusiveScan(n, total);
-        if (total == 0) return 0xFFFFFFFFu;
-        if (used + total > size) {
-            fill(hole);
-            const uint32_t want = total > chunk ? total : chunk;
-            uint32_t b = 0;
-            if ((threadIdx.x & 63u) == 0) b = atomicAdd(counter, want);
-            b = __shfl(b, 0);
-            if (b > cap || want > cap - b) { // (the counter keeps the needed size for the retry on the host)
-                overflow = true;
-                size = used = 0;
-                return 0xFFFFFFFFu;
-            }
-            base = b;
-            size = want;
-            used = 0;
-        }
-        const uint32_t o = base + used + pre;
-        used += total;
-        return o;
-    }
-    template <class Hole>
-    __device__ __forceinline__ void fill(Hole hole) { // holes in the unused rest of the current chunk
-        for (uint32_t i = used + (threadIdx.x & 63u); i < size; i += 64u) hole(base + i);
-        used = size;
-    }
-};
-
 } // namespace cmb
+#include "dev_wave.hpp"
 #include "dev_bfs_edit.hpp"
 #include "dev_bfs_hamming.hpp"
 namespace cmb {
+
+// ---- the frontier kernels of the FM-index backend (the functions live in dev_bfs_edit.hpp, which the b-move translation
+// unit includes as well)
+__global__ void k_bfs_finish(BfsBufs B, Queues q) { // one block: per-block counters -> the batch counters
+    __shared__ unsigned long long s[3];
+    if (threadIdx.x < 3) s[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < BFS_GRID * 4; j += blockDim.x) {
+        const unsigned long long v = B.blockCnt[j];
+        if ((j & 3u) < 3u && v) atomicAdd(&s[j & 3u], v);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&q.counters[0], s[0]);  // NODE_COUNTER
+        atomicAdd(&q.counters[7], s[1]);  // EXPANSIONS
+        atomicAdd(&q.counters[12], s[1]); // DFS_EXPANSIONS
+        atomicAdd(&q.counters[11], s[2]); // MATRIX_ROWS
+    }
+}
+
+
+// first approximate phase of every task (k_exact's DfsTask queue) -> frontier of pass 0
+__global__ void __launch_bounds__(256)
+k_bfs_start(DevIndex ix, const DevStrategyK* __restrict__ stp, BfsBufs B, const DfsTask* __restrict__ tasks, uint32_t nTasks,
+            const uint64_t* __restrict__ offs, uint32_t gw, const uint32_t* __restrict__ G, const PartOut* __restrict__ parts,
+            Queues q) {
+    if (blockStopped(q)) return;
+    bfsHeavy<true>(stp, B, 0u, tasks, nTasks, offs, gw, G, parts, q, blockIdx.x, gridDim.x);
+}
+
+// one level: blocks [0, BFS_GRID) expand the frontier, blocks [BFS_GRID, BFS_GRID + BFS_GRID_EV) handle the events
+// of the same pass (both only append to the queues of pass + 1, so they run side by side)
+#ifndef CMB_BFS_WAVES
+#define CMB_BFS_WAVES 4 // wavefronts per SIMD the register allocation of k_bfs_pass is held to (128 VGPRs)
+#endif
+__global__ void __launch_bounds__(256, CMB_BFS_WAVES)
+k_bfs_pass(DevIndex ix, const DevStrategyK* __restrict__ stp, BfsBufs B, uint32_t pass, const uint64_t* __restrict__ offs,
+           uint32_t gw, const uint32_t* __restrict__ G, const PartOut* __restrict__ parts, Queues q) {
+    if (blockStopped(q)) return;
+    if (blockIdx.x < B.gridX) bfsExpand(ix, B, pass, q, blockIdx.x, B.gridX);
+    else bfsHeavy<false>(stp, B, pass, nullptr, 0u, offs, gw, G, parts, q, blockIdx.x - B.gridX, B.gridEv);
+}
+
 
 // ------------------------------------------------------------------ prologue: the rank/extend kernels
 // extension of `parent` by `code` from the raw chunks of its two rank blocks (loaded in the memory step)

@@ -1,14 +1,17 @@
 // C-ABI of the run-length compressed backend (include/columba_amd.h, section "b-move") on top of move_dev.hpp.
 // gfx950 only.  A translation unit of its own, linked into libcolumba_amd.so.
 #include "../../include/columba_amd.h"
-#include "move_dev.hpp"
+#include "host_schemes.hpp"
+#include "move_search.hpp"
 
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <chrono>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -92,6 +95,10 @@ struct cmb_move_index {
     PosSetHost predFirst, predLast, plcpPos;
     MvBuf<uint64_t> firstToRun, lastToRun, plcpSum;
     MoveDev d{};
+    // the k-mer table of the search (populateTable), built on first use for the word size asked for
+    MvBuf<MoveRangeRec> kmer;
+    uint32_t kmerSize = 0;
+    std::mutex kmerMutex;
 };
 
 static void bindMoveDev(cmb_move_index* ix) { // MoveDev pointers from the owning buffers
@@ -583,4 +590,465 @@ extern "C" int cmb_move_validate(cmb_move_index* idx) {
     } catch (const std::exception& e) {
         return failWith(CMB_ERR_DEVICE, e.what());
     }
+}
+
+
+// =====================================================================================================================
+// The approximate search on the b-move index (move_search.hpp): SearchStrategy::matchApprox in ALL mode for a chunk of
+// reads (searchstrategy.cpp:495-535 with the RUN_LENGTH_COMPRESSION branches).  BASELINE.json configs[4].
+// =====================================================================================================================
+struct cmb_move_batch {
+    cmb_move_index* ix = nullptr;
+    uint32_t k = 0, nReads = 0, maxLen = 0, gw = 0, kmerSize = 0;
+    int metric = 1;
+    DevStrategyK hostStrat{};
+    hipStream_t stream = nullptr;
+    std::vector<uint8_t> hostReads; // (k = 0 goes through cmb_move_match_exact, which takes host buffers)
+    std::vector<uint64_t> hostOffs;
+    MvBuf<uint8_t> reads, seq, psel, sortTmp;
+    MvBuf<uint64_t> offs;
+    MvBuf<uint32_t> G, cnt, bfsCnt, fmIdxA, fmIdxB, keep, slot, vals, valsB, bad;
+    MvBuf<DevStrategyK> strat;
+    MvBuf<PartOut> parts;
+    MvBuf<MoveRangeRec> exr, locRanges;
+    MvBuf<MvTask> tasks;
+    MvBuf<uint4> Q[2], Ev[2], F, C, A, locMeta;
+    MvBuf<unsigned long long> counters, blockCnt, keysA, keysB;
+    MvBuf<MvFmRec> fm;
+    MvBuf<uint64_t> widths, locWidths, locOff, positions, readCnt, readOff;
+    MvBuf<MoveOccOut> out;
+    size_t qCap = 0, evCap = 0, fCap = 0, cCap = 0, aCap = 0;
+    // results
+    std::vector<cmb_move_occ> occs;
+    std::vector<uint64_t> occOffs;
+    uint64_t cnts[CMB_CNT_MAX];
+    std::vector<std::pair<const char*, float>> times;
+    bool done = false;
+    ~cmb_move_batch() {
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+static int ensureKmerTable(cmb_move_index* ix, uint32_t ws) {
+    std::lock_guard<std::mutex> lock(ix->kmerMutex);
+    if (ix->kmerSize == ws && ix->kmer.p) return CMB_OK;
+    if (ws < 1 || ws > 12) return failWith(CMB_ERR_INVALID, "k-mer size of the b-move search must be 1 .. 12");
+    const uint64_t entries = 1ull << (2 * ws);
+    ix->kmer.alloc(entries);
+    hipLaunchKernelGGL(k_move_kmer_table, dim3(gridFor(entries)), dim3(256), 0, 0, ix->d, ws, ix->kmer.p);
+    MV_HIPCHK(hipGetLastError());
+    MV_HIPCHK(hipDeviceSynchronize());
+    ix->kmerSize = ws;
+    return CMB_OK;
+}
+
+extern "C" int cmb_move_batch_create(cmb_move_index* idx, const cmb_strategy* st, uint32_t max_distance, uint32_t kmer_size, const char* seqs,
+                                     const uint64_t* offs, uint32_t n_reads, cmb_move_batch** out) {
+    if (!idx || !st || !offs || !out || (!seqs && n_reads)) return failWith(CMB_ERR_INVALID, "null argument");
+    if (!idx->hasLocate) return failWith(CMB_ERR_INVALID, "this index was created without the locate arrays");
+    if (n_reads >= (1u << 23)) return failWith(CMB_ERR_UNSUPPORTED, "2^23 reads and more per b-move batch (24-bit read numbers in the filter keys)");
+    if (idx->n >> 40) return failWith(CMB_ERR_UNSUPPORTED, "texts of 2^40 characters and more");
+    try {
+        MV_HIPCHK(hipSetDevice(idx->device));
+        std::unique_ptr<cmb_move_batch> b(new cmb_move_batch());
+        b->ix = idx;
+        b->k = max_distance;
+        b->nReads = n_reads;
+        b->metric = st->metric;
+        b->kmerSize = kmer_size;
+        if (max_distance > 0) {
+            if (st->metric != CMB_METRIC_EDIT)
+                return failWith(CMB_ERR_UNSUPPORTED, "Hamming distance on the b-move index is not implemented (edit distance and exact matching are)");
+            if (max_distance > MX_MAX_ED) return failWith(CMB_ERR_UNSUPPORTED, "more than 10 errors need the 128-bit in-index matrix");
+            try {
+                b->hostStrat = st->flatten(max_distance);
+            } catch (const std::exception& e) {
+                return failWith(CMB_ERR_INVALID, e.what());
+            }
+            const int rc = ensureKmerTable(idx, kmer_size);
+            if (rc != CMB_OK) return rc;
+        }
+        uint32_t maxLen = 1;
+        for (uint32_t i = 0; i < n_reads; i++) {
+            if (offs[i + 1] < offs[i]) return failWith(CMB_ERR_INVALID, "read offsets must be non-decreasing");
+            maxLen = std::max<uint32_t>(maxLen, (uint32_t)(offs[i + 1] - offs[i]));
+        }
+        if (maxLen > (uint32_t)MAX_READ) return failWith(CMB_ERR_UNSUPPORTED, "reads longer than " + std::to_string(MAX_READ) + " are not supported");
+        maxLen = (maxLen + 15u) & ~15u;
+        b->maxLen = maxLen;
+        b->gw = gWords(maxLen);
+        b->hostOffs.assign(offs, offs + n_reads + 1);
+        for (auto& o : b->hostOffs) o -= offs[0];
+        b->hostReads.assign((const uint8_t*)seqs + offs[0], (const uint8_t*)seqs + offs[n_reads]);
+        MV_HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+        b->reads.upload(b->hostReads.data(), b->hostReads.size());
+        b->offs.upload(b->hostOffs.data(), n_reads + 1);
+        if (max_distance > 0) {
+            b->seq.alloc((size_t)2 * n_reads * maxLen);
+            b->G.alloc((size_t)n_reads * 8 * b->gw);
+            b->strat.upload(&b->hostStrat, 1);
+            b->parts.alloc((size_t)2 * n_reads);
+            b->psel.alloc((size_t)2 * n_reads);
+            b->exr.alloc((size_t)2 * n_reads * b->hostStrat.numParts);
+            uint32_t maxSearches = 0;
+            for (int i = 0; i < b->hostStrat.nSchemes; i++) maxSearches = std::max<uint32_t>(maxSearches, b->hostStrat.sch[i].nSearches);
+            b->tasks.alloc((size_t)2 * n_reads * maxSearches + 64);
+        }
+        b->cnt.alloc(8);
+        b->counters.alloc(CMB_CNT_MAX);
+        b->bad.alloc(1);
+        *out = b.release();
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return failWith(CMB_ERR_DEVICE, e.what());
+    }
+}
+
+extern "C" void cmb_move_batch_destroy(cmb_move_batch* b) { delete b; }
+
+namespace {
+struct MvTimer {
+    hipStream_t s;
+    hipEvent_t a, b;
+    std::vector<std::pair<const char*, float>>& out;
+    MvTimer(hipStream_t st, std::vector<std::pair<const char*, float>>& o) : s(st), out(o) {
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+    }
+    ~MvTimer() {
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+    }
+    void begin() { (void)hipEventRecord(a, s); }
+    void end(const char* name) {
+        (void)hipEventRecord(b, s);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        for (auto& t : out)
+            if (!strcmp(t.first, name)) {
+                t.second += ms;
+                return;
+            }
+        out.push_back({name, ms});
+    }
+};
+} // namespace
+
+extern "C" int cmb_move_batch_run(cmb_move_batch* b) {
+    if (!b) return failWith(CMB_ERR_INVALID, "null argument");
+    try {
+        cmb_move_index* ix = b->ix;
+        MV_HIPCHK(hipSetDevice(ix->device));
+        hipStream_t s = b->stream;
+        b->done = false;
+        b->times.clear();
+        memset(b->cnts, 0, sizeof(b->cnts));
+        const uint32_t nReads = b->nReads, tasksRS = 2 * nReads;
+        b->occOffs.assign((size_t)nReads + 1, 0);
+        b->occs.clear();
+        if (nReads == 0) {
+            b->done = true;
+            return CMB_OK;
+        }
+        if (b->k == 0) { // exactMatchesOutput of both strands (searchstrategy.cpp:499-510): the k = 0 path of this backend
+            uint64_t nOcc = 0, c2[2] = {0, 0};
+            std::vector<cmb_move_occ> tmp((size_t)nReads * 8 + 1024);
+            int rc = cmb_move_match_exact(ix, (const char*)b->hostReads.data(), b->hostOffs.data(), nReads, tmp.data(), tmp.size(), b->occOffs.data(), &nOcc, c2);
+            if (rc == CMB_ERR_OVERFLOW) {
+                tmp.resize(nOcc);
+                rc = cmb_move_match_exact(ix, (const char*)b->hostReads.data(), b->hostOffs.data(), nReads, tmp.data(), tmp.size(), b->occOffs.data(), &nOcc, c2);
+            }
+            if (rc != CMB_OK) return rc;
+            tmp.resize(nOcc);
+            b->occs.swap(tmp);
+            b->cnts[CMB_CNT_NODE] = c2[0];
+            b->cnts[CMB_CNT_EXPANSIONS] = c2[0]; // (every extension that succeeds is a node; failed ones end the read)
+            b->cnts[CMB_CNT_TOTAL_REPORTED] = c2[1];
+            b->cnts[CMB_CNT_LOCATED_ROWS] = c2[1];
+            float ms[3];
+            (void)cmb_move_last_timings(ms, 3);
+            b->times.push_back({"k_move_exact", ms[0]});
+            b->times.push_back({"locate", ms[1] + ms[2]});
+            b->done = true;
+            return CMB_OK;
+        }
+        MvTimer tm(s, b->times);
+        Queues q{};
+        q.cnt = b->cnt.p;
+        q.counters = b->counters.p;
+        MvSearchIndex sx{ix->d, ix->kmer.p, ix->kmerSize};
+        if (ix->kmerSize != b->kmerSize) {
+            const int rc = ensureKmerTable(ix, b->kmerSize);
+            if (rc != CMB_OK) return rc;
+            sx.kmer = ix->kmer.p;
+            sx.kmerSize = ix->kmerSize;
+        }
+        uint32_t hcnt[8];
+        // ---- read preparation
+        tm.begin();
+        MV_HIPCHK(hipMemsetAsync(b->G.p, 0, b->G.bytes(), s));
+        hipLaunchKernelGGL(k_mvs_prep, dim3(gridFor(nReads)), dim3(256), 0, s, b->reads.p, b->offs.p, nReads, b->maxLen, b->gw, b->seq.p, b->G.p);
+        tm.end("k_prep");
+        const uint32_t P = b->hostStrat.numParts;
+        uint32_t maxSearches = 0;
+        for (int i = 0; i < b->hostStrat.nSchemes; i++) maxSearches = std::max<uint32_t>(maxSearches, b->hostStrat.sch[i].nSearches);
+        uint32_t nFm = 0;
+        for (int attempt = 0;; attempt++) {
+            if (attempt >= 30) return failWith(CMB_ERR_INTERNAL, "work queues keep overflowing");
+            MV_HIPCHK(hipMemsetAsync(b->cnt.p, 0, 8 * sizeof(uint32_t), s));
+            MV_HIPCHK(hipMemsetAsync(b->counters.p, 0, CMB_CNT_MAX * sizeof(unsigned long long), s));
+            if (!b->fm.n) b->fm.alloc((size_t)nReads * 16 + 4096);
+            q.fmCap = (uint32_t)std::min<size_t>(b->fm.n, 0xFFFFFFF0u);
+            // ---- prologue
+            tm.begin();
+            {
+                const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)tasksRS + 63) / 64, 256 * 64);
+                auto kp = b->hostStrat.partition == 0 ? k_mvs_parts<0> : b->hostStrat.partition == 1 ? k_mvs_parts<1> : k_mvs_parts<2>;
+                hipLaunchKernelGGL(kp, dim3(grid), dim3(64), 0, s, sx, b->strat.p, nReads, b->maxLen, b->seq.p, b->offs.p, b->parts.p, b->exr.p, b->psel.p, q);
+                const uint64_t nWork = (uint64_t)tasksRS * maxSearches;
+                const unsigned gridE = (unsigned)std::min<uint64_t>((nWork + 63) / 64, 256 * 64);
+                hipLaunchKernelGGL(k_mvs_exact, dim3(gridE), dim3(64), 0, s, sx, b->strat.p, nReads, b->maxLen, maxSearches, b->seq.p, b->parts.p, b->exr.p,
+                                   b->psel.p, b->tasks.p, (uint32_t)std::min<size_t>(b->tasks.n, 0xFFFFFFF0u), q);
+            }
+            tm.end("k_partition");
+            MV_HIPCHK(hipGetLastError());
+            MV_HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
+            MV_HIPCHK(hipStreamSynchronize(s));
+            if (hcnt[3] & FLAG_UNSUPPORTED_READ)
+                return failWith(CMB_ERR_UNSUPPORTED, "a read is not longer than the number of parts of the search scheme (the reference falls back to "
+                                                     "naive backtracking, which the device path does not provide)");
+            if (hcnt[3] & FLAG_SEED_OVERLAP)
+                return failWith(CMB_ERR_INVALID, "dynamic partitioning: the seeds of a read overlap — the k-mer size is too large for the seeding "
+                                                 "positions of this search strategy at this read length");
+            if (hcnt[3] & FLAG_DFS_OVERFLOW) return failWith(CMB_ERR_INTERNAL, "task queue too small");
+            const uint32_t nTasks = hcnt[5];
+            if (nTasks) {
+                tm.begin();
+                const uint32_t maxPass = 2 * b->maxLen + 8 * MAXP + 64;
+                if (!b->qCap) {
+                    const size_t slack = getenv("CMB_TEST_SMALL_POOLS") ? 64 : 65536;
+                    const size_t per = getenv("CMB_TEST_SMALL_POOLS") ? 0 : 1;
+                    b->qCap = per * (size_t)nReads * 4 + slack;
+                    b->evCap = per * (size_t)nReads + slack;
+                    b->fCap = per * (size_t)nReads * 16 + slack;
+                    b->cCap = per * (size_t)nReads * 4 + slack;
+                    b->aCap = per * (size_t)nReads * 32 + slack;
+                }
+                b->qCap = std::max<size_t>(b->qCap, (size_t)nTasks + 1024);
+                constexpr uint32_t PU = MvTraits::PAIR_U4;
+                for (int j = 0; j < 2; j++) {
+                    if (b->Q[j].n < (PU + 3) * b->qCap) b->Q[j].alloc((PU + 3) * b->qCap);
+                    if (b->Ev[j].n < 2 * b->evCap) b->Ev[j].alloc(2 * b->evCap);
+                }
+                if (b->F.n < (PU + 1) * b->fCap) b->F.alloc((PU + 1) * b->fCap);
+                if (b->C.n < CTX_U4 * b->cCap) b->C.alloc(CTX_U4 * b->cCap);
+                if (b->A.n < b->aCap) b->A.alloc(b->aCap);
+                const size_t cntWords = 2 * ((size_t)maxPass + 2) + 4;
+                if (b->bfsCnt.n < cntWords) b->bfsCnt.alloc(cntWords);
+                if (b->blockCnt.n < (size_t)BFS_GRID * 4) b->blockCnt.alloc((size_t)BFS_GRID * 4);
+                MV_HIPCHK(hipMemsetAsync(b->bfsCnt.p, 0, cntWords * sizeof(uint32_t), s));
+                MV_HIPCHK(hipMemsetAsync(b->blockCnt.p, 0, (size_t)BFS_GRID * 4 * sizeof(unsigned long long), s));
+                MvBufs B{};
+                for (int j = 0; j < 2; j++) {
+                    B.Q[j] = b->Q[j].p;
+                    B.Ev[j] = b->Ev[j].p;
+                }
+                B.F = b->F.p;
+                B.C = b->C.p;
+                B.A = b->A.p;
+                B.qCap = (uint32_t)std::min<size_t>(b->Q[0].n / (PU + 3), 0xFFFFFFF0u);
+                B.evCap = (uint32_t)std::min<size_t>(b->Ev[0].n / 2, 0xFFFFFFF0u);
+                B.fCap = (uint32_t)std::min<size_t>(b->F.n / (PU + 1), 0xFFFFFFF0u);
+                B.cCap = (uint32_t)std::min<size_t>(b->C.n / CTX_U4, 0xFFFFFFF0u);
+                B.aCap = (uint32_t)std::min<size_t>(b->A.n, 0xFFFFFFF0u);
+                B.chain = 1;
+                B.gridX = getenv("CMB_MVS_GRID") ? (uint32_t)std::min<int>(BFS_GRID, std::max(1, atoi(getenv("CMB_MVS_GRID")))) : BFS_GRID_X;
+                B.gridEv = BFS_GRID_EV;
+                B.nq = b->bfsCnt.p;
+                B.ne = b->bfsCnt.p + (maxPass + 2);
+                B.pool = b->bfsCnt.p + 2 * (maxPass + 2);
+                B.blockCnt = b->blockCnt.p;
+                B.fmX = b->fm.p;
+                B.rowSteps = nullptr;
+                hipLaunchKernelGGL(k_mvs_start, dim3(std::min<uint32_t>((nTasks + 255) / 256, BFS_GRID)), dim3(256), 0, s, b->strat.p, B, b->tasks.p, nTasks,
+                                   b->offs.p, b->gw, b->G.p, b->parts.p, q);
+                std::vector<uint32_t> hc(cntWords);
+                uint32_t pass = 0, peakQ = 0, peakEv = 0;
+                bool drained = false;
+                while (!drained && pass < maxPass) {
+                    const uint32_t upTo = std::min(pass + 16u, maxPass);
+                    for (; pass < upTo; pass++)
+                        hipLaunchKernelGGL(k_mvs_pass, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->strat.p, B, pass, b->offs.p, b->gw, b->G.p,
+                                           b->parts.p, q);
+                    MV_HIPCHK(hipMemcpyAsync(hc.data(), b->bfsCnt.p, cntWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    MV_HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
+                    MV_HIPCHK(hipStreamSynchronize(s));
+                    if (hcnt[3] & BFS_STOP) break;
+                    drained = hc[pass] == 0 && hc[maxPass + 2 + pass] == 0;
+                }
+                for (uint32_t p2 = 0; p2 <= pass && p2 < maxPass + 2; p2++) {
+                    peakQ = std::max(peakQ, hc[p2]);
+                    peakEv = std::max(peakEv, hc[maxPass + 2 + p2]);
+                }
+                const uint32_t* pool = hc.data() + 2 * (maxPass + 2);
+                if (getenv("CMB_VERBOSE"))
+                    fprintf(stderr, "[mvs] %u tasks, %u passes, peak frontier %u, peak events %u, F %u, contexts %u, arena %u\n", nTasks, pass, peakQ, peakEv,
+                            pool[0], pool[1], pool[2]);
+                hipLaunchKernelGGL(k_mvs_finish, dim3(1), dim3(256), 0, s, B, q);
+                tm.end("k_dfs");
+                MV_HIPCHK(hipGetLastError());
+                if (hcnt[3] & FLAG_CAPACITY) return failWith(CMB_ERR_INTERNAL, "device search capacity exceeded (band width / descendants)");
+                if (hcnt[3] & (FLAG_BFS_Q | FLAG_BFS_EV | FLAG_BFS_F | FLAG_BFS_CTX | FLAG_BFS_ARENA | FLAG_FMOCC_OVERFLOW)) {
+                    if (hcnt[3] & FLAG_BFS_Q) b->qCap = std::max<size_t>(2 * b->qCap, (size_t)peakQ + peakQ / 4);
+                    if (hcnt[3] & FLAG_BFS_EV) b->evCap = std::max<size_t>(2 * b->evCap, (size_t)peakEv + peakEv / 4);
+                    if (hcnt[3] & FLAG_BFS_F) b->fCap = std::max<size_t>(2 * b->fCap, (size_t)pool[0] + pool[0] / 4);
+                    if (hcnt[3] & FLAG_BFS_CTX) b->cCap = std::max<size_t>(2 * b->cCap, (size_t)pool[1] + pool[1] / 4);
+                    if (hcnt[3] & FLAG_BFS_ARENA) b->aCap = std::max<size_t>(2 * b->aCap, (size_t)pool[2] + pool[2] / 4);
+                    if (hcnt[3] & FLAG_FMOCC_OVERFLOW) b->fm.alloc(std::max<size_t>(2 * b->fm.n, (size_t)hcnt[1] + hcnt[1] / 4 + 1024));
+                    continue;
+                }
+                if (!drained) return failWith(CMB_ERR_INTERNAL, "frontier search did not finish within its pass bound");
+            }
+            nFm = hcnt[1];
+            break;
+        }
+        // ---- in-index occurrences: de-duplicate, locate, sort, filter
+        uint64_t totalPos = 0;
+        uint32_t nUniq = 0;
+        tm.begin();
+        if (nFm) {
+            if (b->keysA.n < nFm) {
+                const size_t c = (size_t)nFm + nFm / 4 + 256;
+                b->keysA.alloc(c), b->keysB.alloc(c), b->fmIdxA.alloc(c), b->fmIdxB.alloc(c), b->keep.alloc(c + 1), b->slot.alloc(c + 1), b->widths.alloc(c + 1);
+            }
+            hipLaunchKernelGGL(k_mvs_fm_keys, dim3(gridFor(nFm)), dim3(256), 0, s, b->fm.p, nFm, b->keysA.p, b->fmIdxA.p);
+            size_t tb = 0;
+            MV_HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->keysA.p, b->keysB.p, b->fmIdxA.p, b->fmIdxB.p, (int)nFm, 0, 64, s));
+            if (b->sortTmp.n < tb) b->sortTmp.alloc(tb + tb / 4);
+            MV_HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->sortTmp.p, tb, b->keysA.p, b->keysB.p, b->fmIdxA.p, b->fmIdxB.p, (int)nFm, 0, 64, s));
+            hipLaunchKernelGGL(k_mvs_fm_unique, dim3(gridFor(nFm)), dim3(256), 0, s, b->fm.p, b->fmIdxB.p, nFm, b->keep.p, b->widths.p);
+            MV_HIPCHK(hipMemsetAsync(b->keep.p + nFm, 0, sizeof(uint32_t), s));
+            tb = 0;
+            MV_HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, b->keep.p, b->slot.p, (int)(nFm + 1), s));
+            if (b->sortTmp.n < tb) b->sortTmp.alloc(tb + tb / 4);
+            MV_HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->sortTmp.p, tb, b->keep.p, b->slot.p, (int)(nFm + 1), s));
+            MV_HIPCHK(hipMemcpyAsync(&nUniq, b->slot.p + nFm, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            MV_HIPCHK(hipStreamSynchronize(s));
+            if (nUniq) {
+                if (b->locRanges.n < nUniq) {
+                    const size_t c = (size_t)nUniq + nUniq / 4 + 256;
+                    b->locRanges.alloc(c), b->locMeta.alloc(c), b->locWidths.alloc(c + 1), b->locOff.alloc(c + 1);
+                }
+                hipLaunchKernelGGL(k_mvs_fm_compact, dim3(gridFor(nFm)), dim3(256), 0, s, b->fm.p, b->fmIdxB.p, b->keep.p, b->slot.p, nFm, b->locRanges.p,
+                                   b->locMeta.p, b->locWidths.p);
+                MV_HIPCHK(hipMemsetAsync(b->locWidths.p + nUniq, 0, sizeof(uint64_t), s));
+                tb = 0;
+                MV_HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, b->locWidths.p, b->locOff.p, (int)(nUniq + 1), s));
+                if (b->sortTmp.n < tb) b->sortTmp.alloc(tb + tb / 4);
+                MV_HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->sortTmp.p, tb, b->locWidths.p, b->locOff.p, (int)(nUniq + 1), s));
+                MV_HIPCHK(hipMemcpyAsync(&totalPos, b->locOff.p + nUniq, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+                MV_HIPCHK(hipStreamSynchronize(s));
+            }
+        }
+        tm.end("fm_unique");
+        if (totalPos >= (1ull << 31)) return failWith(CMB_ERR_UNSUPPORTED, "2^31 and more text positions in one b-move batch");
+        tm.begin();
+        if (totalPos) {
+            if (b->positions.n < totalPos) {
+                const size_t c = totalPos + totalPos / 4 + 256;
+                b->positions.alloc(c), b->keysA.alloc(std::max(c, b->keysA.n)), b->keysB.alloc(std::max(c, b->keysB.n)), b->vals.alloc(c), b->valsB.alloc(c);
+            }
+            if (b->keysA.n < totalPos) b->keysA.alloc(totalPos + 256), b->keysB.alloc(totalPos + 256);
+            MV_HIPCHK(hipMemsetAsync(b->bad.p, 0, sizeof(uint32_t), s));
+            hipLaunchKernelGGL(k_move_locate, dim3(gridFor(nUniq)), dim3(256), 0, s, ix->d, b->locRanges.p, (uint64_t)nUniq, b->locOff.p, (uint64_t)0,
+                               b->positions.p, b->bad.p, true);
+        }
+        tm.end("locate");
+        tm.begin();
+        if (b->readCnt.n < (size_t)nReads + 1) b->readCnt.alloc((size_t)nReads + 1), b->readOff.alloc((size_t)nReads + 1);
+        uint64_t nOut = 0;
+        if (totalPos) {
+            hipLaunchKernelGGL(k_mvs_text_keys, dim3(gridFor(totalPos)), dim3(256), 0, s, b->positions.p, b->locOff.p, nUniq, totalPos, b->locMeta.p, b->keysA.p,
+                               b->vals.p, b->bad.p);
+            size_t tb = 0;
+            MV_HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->keysA.p, b->keysB.p, b->vals.p, b->valsB.p, (int)totalPos, 0, 64, s));
+            if (b->sortTmp.n < tb) b->sortTmp.alloc(tb + tb / 4);
+            MV_HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->sortTmp.p, tb, b->keysA.p, b->keysB.p, b->vals.p, b->valsB.p, (int)totalPos, 0, 64, s));
+            MV_HIPCHK(hipMemsetAsync(b->readCnt.p, 0, ((size_t)nReads + 1) * sizeof(uint64_t), s));
+            hipLaunchKernelGGL(k_mvs_filter<false>, dim3(gridFor(nReads)), dim3(256), 0, s, b->keysB.p, b->valsB.p, totalPos, nReads, b->k, b->readCnt.p,
+                               (const uint64_t*)nullptr, (MoveOccOut*)nullptr);
+            tb = 0;
+            MV_HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, b->readCnt.p, b->readOff.p, (int)(nReads + 1), s));
+            if (b->sortTmp.n < tb) b->sortTmp.alloc(tb + tb / 4);
+            MV_HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->sortTmp.p, tb, b->readCnt.p, b->readOff.p, (int)(nReads + 1), s));
+            MV_HIPCHK(hipMemcpyAsync(&nOut, b->readOff.p + nReads, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            MV_HIPCHK(hipStreamSynchronize(s));
+            if (b->out.n < nOut) b->out.alloc(nOut + nOut / 4 + 256);
+            if (nOut)
+                hipLaunchKernelGGL(k_mvs_filter<true>, dim3(gridFor(nReads)), dim3(256), 0, s, b->keysB.p, b->valsB.p, totalPos, nReads, b->k, b->readCnt.p,
+                                   b->readOff.p, b->out.p);
+        }
+        tm.end("filter");
+        MV_HIPCHK(hipGetLastError());
+        uint32_t hb = 0;
+        MV_HIPCHK(hipMemcpyAsync(&hb, b->bad.p, sizeof(hb), hipMemcpyDeviceToHost, s));
+        unsigned long long hc64[CMB_CNT_MAX];
+        MV_HIPCHK(hipMemcpyAsync(hc64, b->counters.p, sizeof(hc64), hipMemcpyDeviceToHost, s));
+        static_assert(sizeof(cmb_move_occ) == sizeof(MoveOccOut), "cmb_move_occ layout");
+        b->occs.resize(nOut);
+        if (nOut) MV_HIPCHK(hipMemcpyAsync(b->occs.data(), b->out.p, nOut * sizeof(MoveOccOut), hipMemcpyDeviceToHost, s));
+        if (totalPos) MV_HIPCHK(hipMemcpyAsync(b->occOffs.data(), b->readOff.p, ((size_t)nReads + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        MV_HIPCHK(hipStreamSynchronize(s));
+        if (totalPos && hb)
+            return failWith(CMB_ERR_INTERNAL, std::to_string(hb) + " occurrences whose phi chains do not have the width of their range, or whose "
+                                                                   "fields do not fit the filter keys");
+        for (int i = 0; i < CMB_CNT_MAX; i++) b->cnts[i] = hc64[i];
+        b->cnts[CMB_CNT_TOTAL_REPORTED] = totalPos;
+        b->cnts[CMB_CNT_LOCATED_ROWS] = totalPos;
+        b->done = true;
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return failWith(CMB_ERR_DEVICE, e.what());
+    }
+}
+
+extern "C" int cmb_move_batch_result_size(const cmb_move_batch* b, uint64_t* n_occ) {
+    if (!b || !n_occ) return failWith(CMB_ERR_INVALID, "null argument");
+    if (!b->done) return failWith(CMB_ERR_INVALID, "batch has not been run");
+    *n_occ = b->occs.size();
+    return CMB_OK;
+}
+extern "C" int cmb_move_batch_results(const cmb_move_batch* b, cmb_move_occ* out, uint64_t out_cap, uint64_t* out_offs, uint64_t* counters) {
+    if (!b) return failWith(CMB_ERR_INVALID, "null argument");
+    if (!b->done) return failWith(CMB_ERR_INVALID, "batch has not been run");
+    if (b->occs.size() > out_cap) return failWith(CMB_ERR_OVERFLOW, "output buffer too small");
+    if (out && !b->occs.empty()) memcpy(out, b->occs.data(), b->occs.size() * sizeof(cmb_move_occ));
+    if (out_offs) memcpy(out_offs, b->occOffs.data(), b->occOffs.size() * sizeof(uint64_t));
+    if (counters) memcpy(counters, b->cnts, sizeof(b->cnts));
+    return CMB_OK;
+}
+extern "C" int cmb_move_batch_timings(const cmb_move_batch* b, const char** names, float* ms, uint32_t cap) {
+    if (!b || !names || !ms) return -1;
+    uint32_t n = 0;
+    for (const auto& t : b->times) {
+        if (n >= cap) break;
+        names[n] = t.first;
+        ms[n] = t.second;
+        n++;
+    }
+    return (int)n;
+}
+extern "C" int cmb_move_match_batch(cmb_move_index* idx, const cmb_strategy* st, uint32_t max_distance, uint32_t kmer_size, const char* seqs,
+                                    const uint64_t* offs, uint32_t n_reads, cmb_move_occ* out, uint64_t out_cap, uint64_t* out_offs,
+                                    uint64_t* counters, uint64_t* needed) {
+    cmb_move_batch* b = nullptr;
+    int rc = cmb_move_batch_create(idx, st, max_distance, kmer_size, seqs, offs, n_reads, &b);
+    if (rc != CMB_OK) return rc;
+    std::unique_ptr<cmb_move_batch> guard(b);
+    rc = cmb_move_batch_run(b);
+    if (rc != CMB_OK) return rc;
+    if (needed) *needed = b->occs.size();
+    if (b->occs.size() > out_cap) return failWith(CMB_ERR_OVERFLOW, "output buffer too small (needed holds the required number of records)");
+    return cmb_move_batch_results(b, out, out_cap, out_offs, counters);
 }

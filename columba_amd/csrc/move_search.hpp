@@ -1,0 +1,804 @@
+// The approximate search over the run-length compressed backend (b-move; SURVEY.md §8 row f3, BASELINE configs[4]).
+//
+// What the reference compiles with -DRUN_LENGTH_COMPRESSION is the SAME search layer over another index
+// (IndexInterface / SearchStrategy with BMove behind the virtuals, paths relative to /root/reference/src):
+//   ranges carry run indices, a toehold, toeholdRepresentsEnd and originalDepth      indexhelpers.h:137-255, :1040-1260
+//   no in-text verification: switch point 0, goToInTextVerificationEdit returns      indexinterface.cpp:345-348, :516-524,
+//     at once, no part-level pre-verification, every search start is SEARCH_STARTED    :1306-1325; searchstrategy.cpp:461-477;
+//                                                                                      bmove.cpp:195-197
+//   k-mer table entries with exact run indices of the SA range                        indexinterface.cpp:327-329
+//   in-index occurrences -> text positions by the toehold's phi / phi^-1 chains       bmove.cpp:500-560
+// Here that becomes: the frontier of dev_bfs_edit.hpp (events, phase entry, cluster analysis: bfsHeavy, instantiated with
+// MvTraits — nodes, F records and descendant lists hold 80-byte move range pairs instead of four 32-bit bounds), an
+// expansion step built on moveChildren (all four children of a node from one scan of the parent's runs), a prologue
+// (partitioning, exact phases) on the same primitive, and a post-processing chain: de-duplication of the in-index
+// occurrences, k_move_locate, sort + redundancy filter on 64-bit positions.
+#pragma once
+#include "dev_bfs_edit.hpp"
+#include "move_dev.hpp"
+
+namespace cmb {
+
+struct MvTask { // a search that starts its first approximate phase (k_mvs_exact -> k_mvs_start)
+    uint32_t rsId;
+    uint8_t scheme, search, idx, pad;
+    uint32_t depth, pad2;
+    MoveRangeRec r;
+};
+static_assert(sizeof(MvTask) == 96, "record layout");
+
+struct MvFmRec { // in-index occurrence (FMOcc of the RLC flavour: the ranges travel with toehold and original depth)
+    uint32_t rsId, depth, dist, shift;
+    MoveRangeRec r;
+};
+static_assert(sizeof(MvFmRec) == 96, "record layout");
+
+struct MvBufs : BfsBufs {
+    MvFmRec* fmX;                  // in-index occurrences (slots handed out through Queues::cnt[1], capacity Queues::fmCap)
+    unsigned long long* rowSteps;  // [BFS_GRID] table rows fetched by the expansions (this backend's byte-model unit)
+};
+
+struct MvTraits {
+    typedef MvPair Pair;
+    typedef MvTask Task;
+    static constexpr uint32_t PAIR_U4 = 5;
+    static __device__ __forceinline__ Pair load(const uint4* p, size_t stride) {
+        MoveRangeRec q;
+        uint4* w = reinterpret_cast<uint4*>(&q);
+#pragma unroll
+        for (uint32_t u = 0; u < PAIR_U4; u++) w[u] = p[u * stride];
+        return loadPair(q);
+    }
+    static __device__ __forceinline__ void store(uint4* p, size_t stride, const Pair& r) {
+        const MoveRangeRec q = storePair(r);
+        const uint4* w = reinterpret_cast<const uint4*>(&q);
+#pragma unroll
+        for (uint32_t u = 0; u < PAIR_U4; u++) p[u * stride] = w[u];
+    }
+    static __device__ __forceinline__ Pair none() {
+        Pair p;
+        p.sa = {0, 0, 0, 0, true};
+        p.rev = p.sa;
+        p.toehold = 0, p.repEnd = false, p.depth = 0;
+        return p;
+    }
+    static __device__ __forceinline__ bool empty(const Pair& r) { return r.sa.end <= r.sa.begin; }
+    static __device__ __forceinline__ Pair taskRange(const Task& t) { return loadPair(t.r); }
+    template <class BUFS>
+    static __device__ __forceinline__ void emitFm(const BUFS& B, const Queues&, uint32_t slot, uint32_t rsId, const Pair& r, uint32_t depth,
+                                                  uint32_t ed, uint32_t shift) {
+        MvFmRec f;
+        f.rsId = rsId, f.depth = depth, f.dist = ed, f.shift = shift;
+        f.r = storePair(r);
+        static_cast<const MvBufs&>(B).fmX[slot] = f;
+    }
+    template <class BUFS> static __device__ __forceinline__ void fmHole(const BUFS& B, const Queues&, uint32_t slot) {
+        static_cast<const MvBufs&>(B).fmX[slot].rsId = 0xFFFFFFFFu;
+    }
+};
+static_assert(sizeof(MoveRangeRec) == 16 * MvTraits::PAIR_U4, "a range pair is five uint4");
+
+// ---- the index as the search sees it
+struct MvSearchIndex {
+    MoveDev d;
+    const MoveRangeRec* kmer; // 4^kmerSize entries (k_move_kmer_table)
+    uint32_t kmerSize;
+};
+
+// row fetches of the walks, for the byte model (counted where the rows are loaded)
+struct RowCount {
+    uint32_t n = 0;
+};
+
+// moveChildren with a count of the table rows it fetches
+__device__ inline uint32_t moveChildrenCounted(const MoveDev& ix, const int mode, const MvPair& parent, MvPair child[4], uint32_t& rows) {
+    const bool fw = mode == 0;
+    const MoveTable& t = fw ? ix.rev : ix.fwd;
+    MvRange trivial = fw ? parent.rev : parent.sa;
+    const MvRange other = fw ? parent.sa : parent.rev;
+    if (!trivial.valid) { // (two binary searches between the enclosing run indices)
+        uint64_t span = trivial.endRun - trivial.beginRun;
+        while (span) {
+            rows += 2;
+            span >>= 1;
+        }
+        computeRunIndices(t, trivial);
+    }
+    // moveScan, counting
+    MoveScan s;
+    s.found = 0;
+    {
+        uint64_t run = trivial.beginRun, pos = trivial.begin;
+        uint4 row = t.rows[run];
+        rows++;
+        while (true) {
+            const uint32_t h = rowHead(row);
+            if (!(s.found >> h & 1u)) {
+                s.found |= 1u << h;
+                s.firstPos[h] = pos;
+                s.firstRun[h] = run;
+            }
+            if ((s.found & 0x1Eu) == 0x1Eu || run == trivial.endRun) break;
+            run++;
+            row = t.rows[run];
+            rows++;
+            pos = rowIn(row);
+        }
+        uint32_t seen = 0;
+        run = trivial.endRun;
+        pos = trivial.end - 1;
+        row = t.rows[run];
+        rows++;
+        while (true) {
+            const uint32_t h = rowHead(row);
+            if (!(seen >> h & 1u)) {
+                seen |= 1u << h;
+                s.lastPos[h] = pos;
+                s.lastRun[h] = run;
+            }
+            if ((seen & 0x1Eu) == (s.found & 0x1Eu) || run == trivial.beginRun) break;
+            pos = rowIn(row) - 1;
+            run--;
+            row = t.rows[run];
+            rows++;
+        }
+        s.found &= seen | 1u;
+    }
+    const uint64_t parentWidth = trivial.end - trivial.begin;
+    uint64_t cum = (trivial.begin <= t.zeroCharPos && trivial.end > t.zeroCharPos) ? 1 : 0;
+    uint32_t mask = 0;
+    for (int c = 1; c <= 4; c++) {
+        MvPair& ch = child[c - 1];
+        if (!(s.found >> c & 1u)) {
+            ch.sa = {0, 0, 0, 0, false};
+            ch.rev = ch.sa;
+            ch.toehold = 0, ch.repEnd = false, ch.depth = 0;
+            continue;
+        }
+        mask |= 1u << (c - 1);
+        uint64_t p1 = s.firstPos[c], r1 = s.firstRun[c], p2 = s.lastPos[c], r2 = s.lastRun[c];
+        {
+            const MoveRow ra = unpackMoveRow(t.rows[r1]);
+            p1 = ra.out + (p1 - ra.in);
+            r1 = ra.outRun;
+            rows += 2;
+            while (rowIn(t.rows[r1 + 1]) <= p1) {
+                r1++;
+                rows++;
+            }
+            const MoveRow rb = unpackMoveRow(t.rows[r2]);
+            p2 = rb.out + (p2 - rb.in);
+            r2 = rb.outRun;
+            rows += 2;
+            while (rowIn(t.rows[r2 + 1]) <= p2) {
+                r2++;
+                rows++;
+            }
+        }
+        const MvRange range1 = {p1, p2 + 1, r1, r2, true};
+        const uint64_t width = p2 + 1 - p1;
+        MvRange second;
+        if (width == parentWidth) {
+            second = mode == 2 ? MvRange{0, 0, 0, 0, true} : other;
+            ch.toehold = fw ? parent.toehold + (parent.repEnd ? 1 : 0) : parent.toehold - (parent.repEnd ? 0 : 1);
+            ch.repEnd = parent.repEnd;
+        } else {
+            second = mode == 2 ? MvRange{0, 0, 0, 0, true} : MvRange{other.begin + cum, other.begin + cum + width, other.beginRun, other.endRun, false};
+            const uint64_t smp = s.lastRun[c] == trivial.endRun ? t.samplesFirst[trivial.endRun] : t.samplesLast[s.lastRun[c]];
+            ch.toehold = fw ? ix.n - 1 - (smp - 1) : smp - 1;
+            ch.repEnd = fw;
+        }
+        ch.sa = fw ? second : range1;
+        ch.rev = fw ? range1 : second;
+        ch.depth = parent.depth + 1;
+        cum += width;
+    }
+    return mask;
+}
+
+// IndexInterface::addChar (indexinterface.cpp:1034-1049) on this backend: code 1..4 extends `r` in `mode`, anything else
+// (N) empties it without touching a counter.  Returns true if the range is still non-empty.
+struct MvCounters {
+    uint32_t nodes = 0, expansions = 0, rows = 0, started = 0;
+};
+__device__ inline bool mvAddChar(const MoveDev& ix, int mode, uint32_t code, MvPair& r, MvCounters& c) {
+    if (code >= 1 && code <= 4) {
+        c.expansions++;
+        MvPair ch[4];
+        const uint32_t mask = moveChildrenCounted(ix, mode, r, ch, c.rows);
+        if (mask >> (code - 1) & 1u) {
+            r = code == 1 ? ch[0] : code == 2 ? ch[1] : code == 3 ? ch[2] : ch[3];
+            c.nodes++;
+            return true;
+        }
+    }
+    r = MvTraits::none();
+    return false;
+}
+
+__device__ inline MvPair mvCompleteRange(const MoveDev& ix) { // BMove::getCompleteRange (bmove.h:369-373)
+    MvPair p;
+    p.sa = {0, ix.n, 0, ix.fwd.runs - 1, true};
+    p.rev = {0, ix.n, 0, ix.rev.runs - 1, true};
+    p.toehold = ix.fwd.samplesLast[ix.fwd.runs - 1] - 1, p.repEnd = false, p.depth = 0;
+    return p;
+}
+
+// ------------------------------------------------------------------ read preparation
+// One thread per read: character codes of both strands (1..4 = ACGT, 5 = anything else: reads.h:43-58, nucleotide.h:250) and
+// the eight match bit-strings of the read (dev_matrix.hpp: gString — read / reversed read x A, C, G, T; G zeroed beforehand).
+__global__ void k_mvs_prep(const uint8_t* __restrict__ reads, const uint64_t* __restrict__ offs, uint32_t nReads, uint32_t maxLen, uint32_t gw,
+                           uint8_t* __restrict__ seq, uint32_t* __restrict__ G) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nReads; r += gridDim.x * blockDim.x) {
+        const uint8_t* rd = reads + offs[r];
+        const uint32_t len = (uint32_t)(offs[r + 1] - offs[r]);
+        uint8_t* sF = seq + (size_t)(2 * r) * maxLen;
+        uint8_t* sR = seq + (size_t)(2 * r + 1) * maxLen;
+        uint32_t* g = G + (size_t)r * 8 * gw;
+        for (uint32_t i = 0; i < len && i < maxLen; i++) {
+            const uint8_t a = rd[i] & 0xDF;
+            const uint32_t c = a == 'A' ? 1 : a == 'C' ? 2 : a == 'G' ? 3 : a == 'T' ? 4 : 5;
+            sF[i] = (uint8_t)c;
+            sR[len - 1 - i] = (uint8_t)(c <= 4 ? 5 - c : 5);
+            if (c <= 4) {
+                g[(c - 1) * gw + (i >> 5)] |= 1u << (i & 31u);                              // the read
+                g[(4 + c - 1) * gw + ((len - 1 - i) >> 5)] |= 1u << ((len - 1 - i) & 31u); // the reversed read
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ prologue: partitioning + scheme selection
+// SearchStrategy::partition (searchstrategy.cpp:141-419) and MultipleSchemes::createSearches (searchstrategy.h:2505-2537), one
+// lane per read x strand.  Partition state in LDS ([field][part][lane]).
+template <int PARTITION>
+__global__ void __launch_bounds__(64)
+k_mvs_parts(MvSearchIndex sx, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint32_t maxLen, const uint8_t* __restrict__ seqAll,
+            const uint64_t* __restrict__ offs, PartOut* __restrict__ partsOut, MoveRangeRec* __restrict__ exr, uint8_t* __restrict__ psel, Queues q) {
+    __shared__ uint32_t pbe[MAXP][64];
+    __shared__ unsigned long long wid[MAXP][64];
+    const DevStrategyK& st = *stp;
+    const MoveDev& ix = sx.d;
+    const uint32_t lane = threadIdx.x, total = 2 * nReads;
+    MvCounters cnt;
+    uint32_t flags = 0;
+    for (uint32_t rs = blockIdx.x * 64u + lane; rs < total; rs += gridDim.x * 64u) {
+        const uint32_t len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
+        const uint8_t* seq = seqAll + (size_t)rs * maxLen;
+        const int P = st.numParts;
+        psel[rs] = 0;
+        if (P >= (int)len || P == 1 || len > (uint32_t)MAX_READ) { // naive fallback of the reference (searchstrategy.cpp:148-152)
+            flags |= FLAG_UNSUPPORTED_READ;
+            psel[rs] = 0x80u;
+            continue;
+        }
+        auto PB = [&](int i) -> uint32_t { return pbe[i][lane] & 0xFFFFu; };
+        auto PE = [&](int i) -> uint32_t { return pbe[i][lane] >> 16; };
+        auto setPBE = [&](int i, uint32_t b, uint32_t e) { pbe[i][lane] = (b & 0xFFFFu) | (e << 16); };
+        auto exAt = [&](int i) -> MoveRangeRec* { return exr + (size_t)i * total + rs; };
+        auto kmer = [&](uint32_t begin, uint32_t end) -> MvPair { // lookUpInKmerTable (indexinterface.h:590-594)
+            uint32_t key = 0;
+            bool valid = true;
+            for (uint32_t i = begin; i < end; i++)
+                if (seq[i] > 4) valid = false;
+            if (!valid) return MvTraits::none();
+            for (uint32_t i = 0; i < sx.kmerSize; i++) key = (key << 2) | (uint32_t)(seq[begin + i] - 1);
+            return loadPair(sx.kmer[key]);
+        };
+        const uint32_t ws = sx.kmerSize;
+        if (PARTITION != 2) {
+            if (PARTITION == 0) { // partitionUniform (:194-209)
+                for (int i = 0; i < P; i++) {
+                    const uint32_t b = (uint32_t)((i * 1.0 / P) * len);
+                    uint32_t e = (uint32_t)(((i + 1) * 1.0 / P) * len);
+                    setPBE(i, b, e > len ? len : e);
+                }
+                setPBE(P - 1, PB(P - 1), len);
+            } else { // setParts (:221-238)
+                const int pSize = (int)len;
+                const double* bg = st.begins;
+                setPBE(0, 0, (uint32_t)(bg[0] * pSize) & 0xFFFFu);
+                for (int i = 0; i < P - 2; i++) setPBE(i + 1, (uint32_t)(bg[i] * pSize), (uint32_t)(bg[i + 1] * pSize) & 0xFFFFu);
+                setPBE(P - 1, (uint32_t)(bg[P - 2] * pSize), len);
+                for (int i = 0; i < P; i++)
+                    if (PE(i) > len) setPBE(i, PB(i), len);
+            }
+            // calculateExactMatchRanges (:158-190): every part forwards, then the last part again backwards, uni-directionally
+            for (int stage = 0; stage <= P; stage++) {
+                const int i = stage < P ? stage : P - 1;
+                const uint32_t b = PB(i), e = PE(i), size = e > b ? e - b : 0;
+                MvPair r;
+                if (stage < P) {
+                    const uint32_t start = b + (size >= ws ? ws : 0);
+                    r = size >= ws ? kmer(b, start) : mvCompleteRange(ix);
+                    for (uint32_t j = start; j < e; j++)
+                        if (!mvAddChar(ix, 0, seq[j], r, cnt)) break;
+                } else {
+                    const uint32_t end = size >= ws ? e - ws : e;
+                    r = size >= ws ? kmer(end, e) : mvCompleteRange(ix);
+                    for (uint32_t j = end; j-- > b;)
+                        if (!mvAddChar(ix, 2, seq[j], r, cnt)) break;
+                }
+                *exAt(i) = storePair(r);
+                wid[i][lane] = r.sa.end > r.sa.begin ? r.sa.end - r.sa.begin : 0;
+            }
+        } else { // seed (:381-419) + partitionDynamic (:299-379)
+            const bool useKmer = ((uint32_t)P * ws < (len * 2) / 3) && (len >= st.kmerCutOff);
+            const int wSize = useKmer ? (int)ws : 1;
+            setPBE(0, 0, (uint32_t)wSize);
+            for (int i = 1; i < P - 1; i++) {
+                const uint32_t b = (uint32_t)(uint16_t)(int)((st.seeding[i - 1] * len) - (wSize / 2));
+                setPBE(i, b, (b + wSize) & 0xFFFFu);
+            }
+            setPBE(P - 1, len - wSize, len);
+            bool overlap = false;
+            for (int i = 0; i + 1 < P; i++)
+                if (PE(i) > PB(i + 1)) overlap = true; // `assert(parts[i].end() <= parts[i + 1].begin())` (:404-407)
+            if (overlap) {
+                flags |= FLAG_SEED_OVERLAP;
+                psel[rs] = 0x80u;
+                continue;
+            }
+            for (int i = 0; i < P; i++) {
+                MvPair r;
+                if (useKmer) r = kmer(PB(i), PE(i));
+                else { // BMove::getRangeOfSingleChar (bmove.cpp:484-497): the complete range extended backward, no counters
+                    const uint32_t code = seq[PB(i)];
+                    r = MvTraits::none();
+                    if (code >= 1 && code <= 4) {
+                        MvPair ch[4];
+                        uint32_t rows = 0;
+                        const uint32_t mask = moveChildrenCounted(ix, 1, mvCompleteRange(ix), ch, rows);
+                        if (mask >> (code - 1) & 1u) r = code == 1 ? ch[0] : code == 2 ? ch[1] : code == 3 ? ch[2] : ch[3];
+                    }
+                }
+                *exAt(i) = storePair(r);
+                wid[i][lane] = r.sa.end > r.sa.begin ? r.sa.end - r.sa.begin : 0;
+            }
+            int partToExtend = 0, dynDir = 0;
+            for (uint32_t j = (uint32_t)(P * wSize); j < len; j++) {
+                unsigned long long maxRangeWeighted = 0;
+                for (int i = 0; i < P; i++) {
+                    const bool noLeft = (i == 0) || PB(i) == PE(i - 1);
+                    const bool noRight = (i == P - 1) || PE(i) == PB(i + 1);
+                    if (noLeft && noRight) continue;
+                    const unsigned long long wv = wid[i][lane] * st.weights[i];
+                    if (wv > maxRangeWeighted) {
+                        maxRangeWeighted = wv;
+                        partToExtend = i;
+                        if (noLeft) dynDir = 0;
+                        else if (noRight) dynDir = 1;
+                        else dynDir = (wid[i - 1][lane] < wid[i + 1][lane]) ? 1 : 0;
+                    }
+                }
+                if (maxRangeWeighted == 0) { // extendParts (:283-297)
+                    for (int i = 0; i < P; i++) {
+                        if (i != P - 1 && PE(i) != PB(i + 1)) setPBE(i, PB(i), PB(i + 1));
+                        if (i != 0 && PB(i) != PE(i - 1)) setPBE(i, PE(i - 1), PE(i));
+                    }
+                    break;
+                }
+                uint32_t code;
+                if (dynDir == 0) {
+                    setPBE(partToExtend, PB(partToExtend), PE(partToExtend) + 1);
+                    code = seq[PE(partToExtend) - 1];
+                } else {
+                    setPBE(partToExtend, PB(partToExtend) - 1, PE(partToExtend));
+                    code = seq[PB(partToExtend)];
+                }
+                MvPair r = loadPair(*exAt(partToExtend));
+                (void)mvAddChar(ix, partToExtend == P - 1 ? 2 : dynDir, code, r, cnt);
+                *exAt(partToExtend) = storePair(r);
+                wid[partToExtend][lane] = r.sa.end > r.sa.begin ? r.sa.end - r.sa.begin : 0;
+            }
+        }
+        // createSearches (searchstrategy.h:2505-2537): sums and comparisons in the reference's 32-bit `unsigned int`
+        int sel = 0;
+        if (st.nSchemes > 1) {
+            uint32_t tot = 0;
+            for (int i = 0; i < P; i++) tot += (uint32_t)wid[i][lane];
+            if (tot > (uint32_t)P) {
+                uint32_t minValue = (uint32_t)wid[st.sch[0].critical][lane];
+                for (int i = 1; i < st.nSchemes; i++) {
+                    const uint32_t w = (uint32_t)wid[st.sch[i].critical][lane];
+                    if (w < minValue) {
+                        minValue = w;
+                        sel = i;
+                    }
+                }
+            }
+        }
+        PartOut po;
+#pragma unroll
+        for (int i = 0; i < MAXP; i++) {
+            po.pb[i] = i < P ? (uint16_t)PB(i) : (uint16_t)0;
+            po.pe[i] = i < P ? (uint16_t)PE(i) : (uint16_t)0;
+        }
+        partsOut[rs] = po;
+        psel[rs] = (uint8_t)sel;
+    }
+    const uint32_t local[3] = {cnt.nodes, cnt.expansions, cnt.rows};
+    const int which[3] = {0, 7, 13};
+    flushCounters(q, local, which, 3);
+    if (flags) atomicOr(&q.cnt[3], flags);
+}
+
+// ------------------------------------------------------------------ prologue: exact phases of every search
+// SearchStrategy::doRecSearch (searchstrategy.cpp:1181-1254) up to the first approximate phase, one lane per (read x strand,
+// search of the selected scheme).  Emits one MvTask per search that starts (recApproxMatchEditEntry of this flavour counts
+// every one of them as SEARCH_STARTED, indexinterface.cpp:1321-1323).
+__global__ void __launch_bounds__(64)
+k_mvs_exact(MvSearchIndex sx, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint32_t maxLen, uint32_t nSlots,
+            const uint8_t* __restrict__ seqAll, const PartOut* __restrict__ parts, const MoveRangeRec* __restrict__ exr,
+            const uint8_t* __restrict__ psel, MvTask* __restrict__ tasks, uint32_t taskCap, Queues q) {
+    const DevStrategyK& st = *stp;
+    const MoveDev& ix = sx.d;
+    const uint32_t total = 2 * nReads;
+    const uint64_t nWork = (uint64_t)total * nSlots;
+    MvCounters cnt;
+    uint32_t flags = 0;
+    for (uint64_t w = blockIdx.x * 64ull + threadIdx.x; w < nWork; w += (uint64_t)gridDim.x * 64ull) {
+        const uint32_t rs = (uint32_t)(w / nSlots), slot = (uint32_t)(w % nSlots);
+        const uint8_t ps = psel[rs];
+        if (ps & 0x80u) continue;
+        const DevScheme& sch = st.sch[ps];
+        if (slot >= sch.nSearches) continue;
+        const DevSearch& s = sch.s[slot];
+        const uint8_t* seq = seqAll + (size_t)rs * maxLen;
+        const PartOut po = parts[rs];
+        MvPair cur;
+        uint32_t idx = 0, depth = 0;
+        if (s.U[0] > 0) { // the first part already allows errors: start from the empty match
+            cur = mvCompleteRange(ix);
+        } else {
+            const int first = s.order[0];
+            cur = loadPair(exr[(size_t)first * total + rs]);
+            if (MvTraits::empty(cur)) continue; // `startRange.width() > index.getSwitchPoint()` with switch point 0
+            uint32_t p = 1;
+            depth = (uint32_t)po.pe[first] - po.pb[first];
+            bool alive = true;
+            while (s.U[p] == 0) {
+                const int part = s.order[p];
+                const uint32_t b = po.pb[part], e = po.pe[part], n = e > b ? e - b : 0;
+                const bool uni = s.uniAll || p >= (uint32_t)s.uniIdx;
+                const int mode = uni ? 2 : (s.dir[p] == 0 ? 0 : 1);
+                for (uint32_t ci = 0; ci < n; ci++) {
+                    const uint32_t code = seq[s.dir[p] == 0 ? b + ci : e - ci - 1];
+                    if (!mvAddChar(ix, mode, code, cur, cnt)) break;
+                }
+                if (MvTraits::empty(cur)) {
+                    alive = false;
+                    break;
+                }
+                depth += n;
+                p++;
+            }
+            if (!alive) continue;
+            idx = p;
+        }
+        if (st.metric == 1) cnt.started++;
+        const uint32_t o = atomicAdd(&q.cnt[5], 1u);
+        if (o >= taskCap) {
+            flags |= FLAG_DFS_OVERFLOW;
+            continue;
+        }
+        MvTask t;
+        t.rsId = rs, t.scheme = ps, t.search = (uint8_t)slot, t.idx = (uint8_t)idx, t.pad = 0, t.depth = depth, t.pad2 = 0;
+        t.r = storePair(cur);
+        tasks[o] = t;
+    }
+    const uint32_t local[4] = {cnt.nodes, cnt.expansions, cnt.rows, cnt.started};
+    const int which[4] = {0, 7, 13, 6};
+    flushCounters(q, local, which, 4);
+    if (flags) atomicOr(&q.cnt[3], flags);
+}
+
+// ------------------------------------------------------------------ the frontier: one level per launch
+// Expansion of a frontier node (extendFMPos + branchAndBound + the stack loop of recApproxMatchEdit, indexinterface.cpp:506-561,
+// :675-697, without the in-text switch this flavour does not have).  Node = range pair (5 planes) + the three planes of
+// dev_bfs_edit.hpp: {row | score << 16, ctx, fc, RAC bit | mode << 8} {HP, HN} {final-column distances}.
+__device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uint32_t pass, const Queues& q, uint32_t bid, uint32_t nBlocks) {
+    __shared__ uint32_t sh[4][5];
+    constexpr uint32_t PU = MvTraits::PAIR_U4, FU = PU + 1;
+    const uint32_t nIn = min(B.nq[pass], B.qCap);
+    const uint4* __restrict__ Qi = B.Q[pass & 1u];
+    uint4* __restrict__ Qo = B.Q[(pass + 1u) & 1u];
+    uint4* __restrict__ Eo = B.Ev[(pass + 1u) & 1u];
+    const uint32_t qCap = B.qCap;
+    uint32_t flags = 0;
+    unsigned long long cChildren = 0, cExp = 0, cRows = 0;
+    for (uint32_t base = bid * 256u; base < nIn; base += nBlocks * 256u) { // block-uniform trip count
+        const uint32_t i = base + threadIdx.x;
+        const bool act = i < nIn;
+        uint32_t kinds = 0; // 4 bits per child: kind | needF << 2
+        uint32_t row1 = 0, ctx = 0, fcP = BFS_NONE;
+        MvPair ch[4];
+        uint64_t cHP[4], cHN[4];
+        uint32_t cSc[4], cRac[4], cAux[4];
+        MatGeom g{};
+        uint32_t clSize = 0;
+        int md = 0;
+        if (act) {
+            const uint4 n1 = Qi[(size_t)PU * qCap + i], n2 = Qi[(size_t)(PU + 1) * qCap + i];
+            const MvPair parent = MvTraits::load(Qi + i, qCap);
+            ctx = n1.y;
+            fcP = n1.z;
+            const uint32_t row = n1.x & 0xFFFFu, score = n1.x >> 16;
+            md = (int)((n1.w >> 8) & 3u);
+            const uint4* Cx = B.C + (size_t)CMB_IDX(ctx, B.cCap, 1) * CTX_U4;
+            row1 = row + 1;
+            const uint32_t blk = row1 / MX_BLOCK;
+            const uint4 hot = Cx[CTX_HOT];
+            const uint4 mA = Cx[CTX_M + 2 * blk], mB = Cx[CTX_M + 1 + 2 * blk];
+            g.n = hot.y & 0x1FFu;
+            g.m = (hot.y >> 9) & 0x1FFu;
+            g.Wv = (hot.y >> 18) & 31u;
+            g.Wh = (hot.y >> 23) & 15u;
+            g.maxED = (hot.y >> 27) & 15u;
+            clSize = hot.w >> 23;
+            const uint64_t pHP = u64of(n2.x, n2.y), pHN = u64of(n2.z, n2.w);
+            const uint32_t pRac = n1.w & 63u;
+            uint32_t rows = 0;
+            const uint32_t mask = moveChildrenCounted(ix, md, parent, ch, rows);
+            cRows += rows;
+            cExp++;
+            const bool inFC = g.inFinalColumn(row1);
+            if (inFC && clSize + row1 - g.m >= ED_CELLS) flags |= FLAG_CAPACITY;
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                if (!(mask >> c & 1u)) continue;
+                cChildren++;
+                const uint64_t M = c == 0 ? u64of(mA.x, mA.y) : c == 1 ? u64of(mA.z, mA.w) : c == 2 ? u64of(mB.x, mB.y) : u64of(mB.z, mB.w);
+                uint64_t HP = pHP, HN = pHN, RAC = 1ull << pRac, D0;
+                uint32_t sc = score;
+                const bool valid = computeRow(g, row1, M, HP, HN, D0, RAC, sc);
+                if (!valid && !inFC) continue; // pruned when popped (branchAndBound returns true, :560)
+                uint32_t res = KIND_NODE, aux = 0;
+                if (inFC) {
+                    const uint32_t ed = cellAt(row1, g.n - 1, HP, HN, sc);
+                    aux = min(ed, 31u);
+                    res |= 4u;
+                    if (ed > 31u) flags |= FLAG_CAPACITY;
+                    if (!valid || onlyVerticalGapsLeft(g, row1, HN)) res = (res & ~3u) | KIND_EVENT;
+                }
+                kinds |= res << (4 * c);
+                cHP[c] = HP, cHN[c] = HN, cSc[c] = sc, cAux[c] = aux;
+                cRac[c] = (uint32_t)__ffsll((unsigned long long)RAC) - 1u;
+            }
+        }
+        uint32_t nNode = 0, nEv = 0, nF = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t kd = (kinds >> (4 * c)) & 3u;
+            nNode += kd == KIND_NODE;
+            nEv += kd == KIND_EVENT;
+            nF += (kinds >> (4 * c + 2)) & 1u;
+        }
+        const uint32_t want[4] = {nNode, nEv, 0u, nF};
+        uint32_t got[4];
+        blockAppend4(&B.nq[pass + 1], &B.ne[pass + 1], &q.cnt[0], &B.pool[0], want, sh, got);
+        uint32_t oNode = got[0], oEv = got[1], oF = got[3];
+        bool ok = true;
+        if (oNode + nNode > qCap) { ok = false; flags |= FLAG_BFS_Q; }
+        if (oEv + nEv > B.evCap) { ok = false; flags |= FLAG_BFS_EV; }
+        if (oF + nF > B.fCap) { ok = false; flags |= FLAG_BFS_F; }
+        if (kinds != 0u && ok) {
+            const uint32_t cell = min(clSize + row1 - g.m, ED_CELLS - 1u);
+            EdPack pack{0, 0};
+            if (fcP != BFS_NONE && (kinds & 0x4444u)) {
+                const uint4 fp = Qi[(size_t)(PU + 2) * qCap + i];
+                pack = EdPack{u64of(fp.x, fp.y), u64of(fp.z, fp.w)};
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                const uint32_t kd = (kinds >> (4 * c)) & 3u;
+                if (kd == KIND_NONE) continue;
+                const bool wantF = (kinds >> (4 * c + 2)) & 1u;
+                uint32_t fc = BFS_NONE;
+                if (wantF) {
+                    fc = oF++;
+                    uint4* Fr = B.F + (size_t)CMB_IDX(fc, B.fCap, 9) * FU;
+                    MvTraits::store(Fr, 1, ch[c]);
+                    Fr[PU] = make_uint4(row1 | ((c + 1) << 16), fcP, 0u, 0u);
+                }
+                if (kd == KIND_NODE) {
+                    const uint32_t o = oNode++;
+                    MvTraits::store(Qo + o, qCap, ch[c]);
+                    Qo[(size_t)PU * qCap + o] = make_uint4(row1 | (cSc[c] << 16), ctx, fc, cRac[c] | ((uint32_t)md << 8));
+                    Qo[(size_t)(PU + 1) * qCap + o] = make_uint4((uint32_t)cHP[c], (uint32_t)(cHP[c] >> 32), (uint32_t)cHN[c], (uint32_t)(cHN[c] >> 32));
+                    if (wantF) {
+                        EdPack p2 = pack;
+                        edPut(p2, cell, cAux[c]);
+                        Qo[(size_t)(PU + 2) * qCap + o] = make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32));
+                    }
+                } else { // KIND_EVENT
+                    EdPack p2 = pack;
+                    edPut(p2, cell, cAux[c]);
+                    Eo[(size_t)2 * oEv] = make_uint4(ctx, fc, 0xFFFFFFFFu, cell);
+                    Eo[(size_t)2 * oEv + 1] = make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32));
+                    oEv++;
+                }
+            }
+        }
+    }
+    // per-block counters (summed by k_mvs_finish): one writer per slot and launch, launches are ordered
+    unsigned long long v[4] = {cChildren, cExp, cChildren, cRows}; // (every child gets its matrix row)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v[j] += __shfl_xor(v[j], d);
+    }
+    __shared__ unsigned long long shc[4][4];
+    if ((threadIdx.x & 63u) == 0)
+        for (int j = 0; j < 4; j++) shc[threadIdx.x >> 6][j] = v[j];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const unsigned long long t = shc[0][threadIdx.x] + shc[1][threadIdx.x] + shc[2][threadIdx.x] + shc[3][threadIdx.x];
+        if (t) B.blockCnt[(size_t)bid * 4 + threadIdx.x] += t;
+    }
+    if (flags) atomicOr(&q.cnt[3], flags);
+}
+
+__global__ void __launch_bounds__(256)
+k_mvs_start(const DevStrategyK* __restrict__ stp, MvBufs B, const MvTask* __restrict__ tasks, uint32_t nTasks, const uint64_t* __restrict__ offs,
+            uint32_t gw, const uint32_t* __restrict__ G, const PartOut* __restrict__ parts, Queues q) {
+    if (blockStopped(q)) return;
+    bfsHeavy<true, MvTraits>(stp, B, 0u, tasks, nTasks, offs, gw, G, parts, q, blockIdx.x, gridDim.x);
+}
+__global__ void __launch_bounds__(256)
+k_mvs_pass(MoveDev ix, const DevStrategyK* __restrict__ stp, MvBufs B, uint32_t pass, const uint64_t* __restrict__ offs, uint32_t gw,
+           const uint32_t* __restrict__ G, const PartOut* __restrict__ parts, Queues q) {
+    if (blockStopped(q)) return;
+    if (blockIdx.x < B.gridX) mvExpand(ix, B, pass, q, blockIdx.x, B.gridX);
+    else bfsHeavy<false, MvTraits>(stp, B, pass, nullptr, 0u, offs, gw, G, parts, q, blockIdx.x - B.gridX, B.gridEv);
+}
+__global__ void k_mvs_finish(MvBufs B, Queues q) { // one block: per-block counters -> the batch counters
+    __shared__ unsigned long long s[4];
+    if (threadIdx.x < 4) s[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < BFS_GRID * 4; j += blockDim.x) {
+        const unsigned long long v = B.blockCnt[j];
+        if (v) atomicAdd(&s[j & 3u], v);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&q.counters[0], s[0]);  // NODE_COUNTER
+        atomicAdd(&q.counters[7], s[1]);  // EXPANSIONS
+        atomicAdd(&q.counters[12], s[1]); // DFS_EXPANSIONS
+        atomicAdd(&q.counters[11], s[2]); // MATRIX_ROWS
+        atomicAdd(&q.counters[13], s[3]); // table rows fetched
+    }
+}
+
+// ------------------------------------------------------------------ in-index occurrences -> text occurrences
+// Occurrences::eraseDoublesFM (indexhelpers.h:2135-2146) under the RLC flavour's equality (FMOcc::== over SARangePair::==,
+// which includes run indices, toehold, toeholdRepresentsEnd and originalDepth, :1226-1233): records are sorted by
+// read x strand | a hash of everything else, and a record is dropped if it equals its predecessor field by field.
+__device__ __forceinline__ uint64_t mix64(uint64_t h, uint64_t v) {
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h *= 0xFF51AFD7ED558CCDull;
+    return h ^ (h >> 33);
+}
+__device__ __forceinline__ bool sameFm(const MvFmRec& a, const MvFmRec& b) {
+    return a.rsId == b.rsId && a.depth == b.depth && a.dist == b.dist && a.shift == b.shift && a.r.begin == b.r.begin && a.r.end == b.r.end &&
+           a.r.beginRun == b.r.beginRun && a.r.endRun == b.r.endRun && a.r.toehold == b.r.toehold && a.r.repEnd == b.r.repEnd &&
+           a.r.depth == b.r.depth;
+}
+__global__ void k_mvs_fm_keys(const MvFmRec* __restrict__ fm, uint32_t n, unsigned long long* __restrict__ keys, uint32_t* __restrict__ idx) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const MvFmRec f = fm[i];
+        idx[i] = i;
+        if (f.rsId == 0xFFFFFFFFu) { // holes go last
+            keys[i] = ~0ull;
+            continue;
+        }
+        uint64_t h = mix64(0, f.r.begin);
+        h = mix64(h, f.r.end);
+        h = mix64(h, f.r.beginRun);
+        h = mix64(h, f.r.endRun);
+        h = mix64(h, f.r.toehold);
+        h = mix64(h, ((uint64_t)f.depth << 32) | f.r.depth);
+        h = mix64(h, ((uint64_t)f.dist << 32) | ((uint64_t)f.shift << 1) | f.r.repEnd);
+        keys[i] = ((uint64_t)f.rsId << 38) | (h >> 26);
+    }
+}
+// keep[i] = 1 for the first record of every run of equal records (holes: 0); widths[i] = its SA range width
+__global__ void k_mvs_fm_unique(const MvFmRec* __restrict__ fm, const uint32_t* __restrict__ idx, uint32_t n, uint32_t* __restrict__ keep,
+                                uint64_t* __restrict__ widths) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const MvFmRec f = fm[idx[i]];
+        bool k = f.rsId != 0xFFFFFFFFu;
+        if (k && i > 0) k = !sameFm(f, fm[idx[i - 1]]);
+        keep[i] = k ? 1u : 0u;
+        widths[i] = k ? f.r.end - f.r.begin : 0ull;
+    }
+}
+// compact the kept records (slot[i] = exclusive scan of keep) into ranges for k_move_locate + their meta
+__global__ void k_mvs_fm_compact(const MvFmRec* __restrict__ fm, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ keep,
+                                 const uint32_t* __restrict__ slot, uint32_t n, MoveRangeRec* __restrict__ ranges, uint4* __restrict__ meta,
+                                 uint64_t* __restrict__ widthsOut) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (!keep[i]) continue;
+        const MvFmRec f = fm[idx[i]];
+        const uint32_t o = slot[i];
+        ranges[o] = f.r;
+        meta[o] = make_uint4(f.rsId, f.depth, f.dist, f.shift);
+        widthsOut[o] = f.r.end - f.r.begin;
+    }
+}
+// one lane per located position: TextOcc = [pos + shift, pos + shift + depth) (indexinterface.cpp:1410-1416) as a sort key
+// (read | begin) and a value (distance, width, strand) that orders equal begins as TextOcc::operator< does (:779-795)
+__global__ void k_mvs_text_keys(const uint64_t* __restrict__ positions, const uint64_t* __restrict__ recOff, uint32_t nRecs, uint64_t total,
+                                const uint4* __restrict__ meta, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
+                                uint32_t* __restrict__ bad) {
+    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < total; j += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t lo = 0, hi = nRecs; // the last record whose offset is <= j
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (recOff[mid] <= j) lo = mid;
+            else hi = mid;
+        }
+        const uint4 m = meta[lo];
+        const uint64_t begin = positions[j] + m.w;
+        if (begin >> 40 || (m.x >> 1) >> 24 || m.y >= (1u << 19) || m.z >= 16u) atomicAdd(bad, 1u);
+        keys[j] = ((uint64_t)(m.x >> 1) << 40) | (begin & ((1ull << 40) - 1));
+        vals[j] = (m.z << 20) | (m.y << 1) | (m.x & 1u);
+    }
+}
+// The redundancy filter of getUniqueTextOccurrences (indexinterface.cpp:1445-1485), one lane per read over its sorted segment.
+// Among the occurrences of one begin position only the smallest (distance, width) can ever be kept (the others are skipped
+// as `diff == 0` if it is kept, and fail the same test it failed if it is not), so each group of equal begins is reduced to
+// its minimum first; strand 0 wins a tie, as in the FM-index backend.  WRITE = false counts, true writes.
+struct MoveOccOut {
+    uint64_t begin, end;
+    uint32_t distance, strand;
+};
+template <bool WRITE>
+__global__ void k_mvs_filter(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t total, uint32_t nReads,
+                             uint32_t maxED, uint64_t* __restrict__ counts, const uint64_t* __restrict__ outOff, MoveOccOut* __restrict__ out) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nReads; r += gridDim.x * blockDim.x) {
+        const uint64_t kLo = (uint64_t)r << 40, kHi = ((uint64_t)r + 1) << 40;
+        uint64_t lo = 0, hi = total; // first key >= kLo
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < kLo) lo = mid + 1;
+            else hi = mid;
+        }
+        uint64_t j = lo, nKept = 0;
+        const uint64_t maxDiff = 2ull * maxED;
+        uint64_t prevBegin = ~0ull;
+        uint32_t prevED = maxED + 1, prevDepth = 0xFFFFFFFFu;
+        MoveOccOut last{};
+        bool have = false;
+        uint64_t w = WRITE ? outOff[r] : 0;
+        while (j < total && keys[j] < kHi) {
+            const uint64_t begin = keys[j] & ((1ull << 40) - 1);
+            uint32_t best = vals[j];
+            j++;
+            while (j < total && keys[j] == (kLo | begin)) {
+                best = min(best, vals[j]);
+                j++;
+            }
+            const uint32_t dist = best >> 20, width = (best >> 1) & 0x7FFFFu, strand = best & 1u;
+            const uint64_t diff = begin > prevBegin ? begin - prevBegin : prevBegin - begin;
+            if (diff == 0) continue;
+            if (diff <= maxDiff) {
+                if (dist > prevED || (dist == prevED && width >= prevDepth)) continue;
+                nKept--; // the previous one was worse: pop_back
+                have = false;
+            }
+            if (have) {
+                if (WRITE) out[w++] = last;
+                have = false;
+            }
+            prevBegin = begin, prevED = dist, prevDepth = width;
+            last = MoveOccOut{begin, begin + width, dist, strand};
+            have = true;
+            nKept++;
+        }
+        if (have && WRITE) out[w++] = last;
+        if (!WRITE) counts[r] = nKept;
+    }
+}
+
+} // namespace cmb

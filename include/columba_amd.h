@@ -168,6 +168,7 @@ enum {
     CMB_CNT_TEXT_BYTES,             /* T */
     CMB_CNT_MATRIX_ROWS,
     CMB_CNT_DFS_EXPANSIONS,         /* the part of E performed by the DFS kernel (rest: prologue kernel) */
+    CMB_CNT_TABLE_ROWS,             /* b-move backend only: 16-byte move-table rows fetched by run walks, LF and fast-forwards */
     CMB_CNT_MAX
 };
 
@@ -395,7 +396,8 @@ int cmb_verify_batch_staged(cmb_index* idx, const char* pattern, uint32_t plen, 
  * First stage: the index structures in HBM and the two index operations of that backend as batch hooks — character
  * extension with toehold maintenance (BMove::findRangesWithExtraChar{Forward,Backward,BackwardUniDirectional},
  * src/bmove/bmove.cpp:328-478, over MoveLFReprBP, src/bmove/moverepr.cpp) and locate (BMove::collectTextPositions,
- * bmove.cpp:500-560).  The search of cmb_match_batch does not run on this backend yet (CMB_ERR_UNSUPPORTED there).
+ * bmove.cpp:500-560) — and, on top of them, exact matching (cmb_move_match_exact) and the approximate search
+ * (cmb_move_match_batch) end to end.
  * 64-bit positions throughout (the RUN_LENGTH_COMPRESSION flavour builds with 64-bit length_t, CMakeLists.txt:41-63);
  * texts below 2^40 characters. */
 typedef struct cmb_move_index cmb_move_index;
@@ -496,6 +498,29 @@ typedef struct {
 } cmb_move_occ;
 int cmb_move_match_exact(const cmb_move_index* idx, const char* reads, const uint64_t* read_offsets, uint64_t n_reads,
                          cmb_move_occ* occ_out, uint64_t occ_cap, uint64_t* occ_offsets, uint64_t* n_occ, uint64_t* counters);
+/* The approximate search on the b-move index: SearchStrategy::matchApprox in ALL mode (searchstrategy.cpp:495-535) as the
+ * RUN_LENGTH_COMPRESSION flavour compiles it — the same search schemes, partitioning and bit-parallel matrix over ranges that
+ * carry run indices and a toehold (indexhelpers.h:137-255, :1040-1260), no in-text verification (switch point 0: bmove.cpp:195-197,
+ * indexinterface.cpp:345-348, :516-524, :1306-1325, searchstrategy.cpp:461-477), in-index occurrences located by the phi / phi^-1
+ * chains of their toehold (bmove.cpp:500-560), then getUniqueTextOccurrences (indexinterface.cpp:1373-1491).  Edit distance,
+ * max_distance 1 .. 7 for the strategies that have schemes for it (0: the exact path above); kmer_size: word size of the k-mer
+ * table used for seeding (populateTable, indexinterface.cpp:294-335; built on the device on first use).  Results: per read the list
+ * cmb_match_batch would return on the same text, in 64-bit coordinates.  counters[CMB_CNT_MAX]: NODE_COUNTER, SEARCH_STARTED,
+ * EXPANSIONS, MATRIX_ROWS as the reference counts them, TOTAL_REPORTED_POSITIONS / LOCATED_ROWS = located positions,
+ * CMB_CNT_TABLE_ROWS = move-table rows fetched.  cmb_move_match_batch: host buffers in and out, CMB_ERR_OVERFLOW with *needed = the
+ * number of records if out_cap is too small.  cmb_move_batch_*: reads resident on the device between runs (what bench.py times).
+ * Reads not longer than the number of parts and Hamming distance: CMB_ERR_UNSUPPORTED (nothing is silently skipped). */
+typedef struct cmb_move_batch cmb_move_batch;
+int cmb_move_match_batch(cmb_move_index* idx, const cmb_strategy* st, uint32_t max_distance, uint32_t kmer_size, const char* seqs,
+                         const uint64_t* offs, uint32_t n_reads, cmb_move_occ* out, uint64_t out_cap, uint64_t* out_offs /* [n_reads + 1] */,
+                         uint64_t* counters /* [CMB_CNT_MAX] or NULL */, uint64_t* needed);
+int cmb_move_batch_create(cmb_move_index* idx, const cmb_strategy* st, uint32_t max_distance, uint32_t kmer_size, const char* seqs,
+                          const uint64_t* offs, uint32_t n_reads, cmb_move_batch** out);
+int cmb_move_batch_run(cmb_move_batch* b);
+int cmb_move_batch_result_size(const cmb_move_batch* b, uint64_t* n_occ);
+int cmb_move_batch_results(const cmb_move_batch* b, cmb_move_occ* out, uint64_t out_cap, uint64_t* out_offs, uint64_t* counters);
+int cmb_move_batch_timings(const cmb_move_batch* b, const char** names, float* ms, uint32_t cap);
+void cmb_move_batch_destroy(cmb_move_batch* b);
 /* device time (ms, HIP events) of the calling thread's last cmb_move_match_exact: [0] the backward extension of all reads,
  * [1] the prefix sum of the widths, [2] locate + occurrence records */
 int cmb_move_last_timings(float* ms, uint32_t n);

@@ -1,0 +1,142 @@
+"""GPU parity of the approximate search on the b-move backend (BASELINE configs[4]) through the C-ABI:
+cmb_move_match_batch against the oracle's restatement of the RUN_LENGTH_COMPRESSION flavour (oracle_move_search.hpp, itself
+tied to the FM-index restatement and to plain DP by tests/test_move_search_oracle.py), and against ground truth directly."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+
+from columba_amd import synth  # noqa: E402
+from test_ground_truth import check_completeness, check_soundness, gt  # noqa: E402,F401
+from test_gpu_move import _pangenome  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sworld(oracle_built):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import columba_amd as ca
+    from columba_amd import movebuild
+    import oracle_py as op
+    rng = np.random.default_rng(15)
+    # pan-genome-like: 16 haplotypes of a 40 kb sequence with 0.5 % SNPs, a repeat-rich stretch, a random tail
+    g = np.concatenate([_pangenome(rng, 40_000, 16, 0.005), synth.genome_rep(seed=3, n=150_000, scale=4.0)[0],
+                        np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 20_000)]])
+    mv = movebuild.build_move(g.tobytes(), device="cuda")
+    return {"g": g, "text": g.tobytes(), "mv": mv, "dev": ca.MoveIndex(mv), "orc": op.OracleMoveIndex(mv), "ca": ca, "op": op}
+
+
+def _tuples(occ, offs, i):
+    return [(int(o["begin"]), int(o["end"]), int(o["distance"]), int(o["strand"])) for o in occ[int(offs[i]):int(offs[i + 1])]]
+
+
+def _compare(w, spec, partition, k, reads, kmer_size=8):
+    import schemes_py as sp
+    ca, op = w["ca"], w["op"]
+    o_occ, o_off, o_cnt = w["orc"].match_batch(op.OracleStrategy(sp.BY_NAME[spec], "edit", partition), k, reads, threads=8, word_size=kmer_size)
+    d_occ, d_off, d_cnt = w["dev"].match_batch(ca.SearchStrategy(spec, "edit", partition), k, reads, kmer_size=kmer_size)
+    assert len(o_occ) > 0
+    assert np.array_equal(o_off, d_off)
+    strand_only = 0
+    for i in range(len(reads)):
+        a, b = _tuples(o_occ, o_off, i), _tuples(d_occ, d_off, i)
+        if k == 0:
+            a, b = sorted(a), sorted(b)
+        if a != b:  # (only the strand label of an occurrence found on both strands: unstable sort in the reference)
+            assert [t[:3] for t in a] == [t[:3] for t in b], (i, reads[i], a, b)
+            strand_only += 1
+    assert strand_only <= max(1, len(o_occ) // 500)
+    names = ["NODE_COUNTER", "EXPANSIONS", "TOTAL_REPORTED_POSITIONS", "LOCATED_ROWS"]
+    if k > 0:
+        names += ["SEARCH_STARTED", "MATRIX_ROWS"]
+    for n in names:
+        assert o_cnt[n] == d_cnt[n], (n, o_cnt[n], d_cnt[n])
+    for n in ("IN_TEXT_STARTED", "IMMEDIATE_SWITCH", "ABORTED_IN_TEXT_VERIF", "TEXT_BYTES"):
+        assert d_cnt[n] == 0, n
+    if k > 0:
+        assert 0 < d_cnt["TABLE_ROWS"] <= o_cnt["ROW_STEPS"] * 4  # one scan per parent instead of the reference's walks per character
+    return d_occ, d_off, d_cnt, o_cnt
+
+
+def _reads(g, k, n, length, seed):
+    rd = synth.sample_reads(g, n, length, seed=seed, n_frac=0.03, edit_choices=(0, 1, 2, max(k - 1, 0), k, k, k + 1))
+    return rd + [b"N" * 60, g[:length].tobytes(), g[-length:].tobytes(), b"ACGT" * 15, b"acgtn" * 8 + g[1000:1100].tobytes().lower()]
+
+
+@pytest.mark.parametrize("spec,partition,k,length", [
+    ("multiple_opt", "dynamic", 6, 250),   # BASELINE configs[4]: 250 bp, k = 6, multiple_opt
+    ("multiple_opt", "dynamic", 4, 150),
+    ("multiple_opt", "uniform", 2, 100),
+    ("multiple_opt", "static", 4, 100),
+    ("kuch1", "dynamic", 1, 100),
+    ("kuch1", "static", 3, 150),
+    ("kuch1", "dynamic", 4, 250),
+    ("pigeon", "uniform", 2, 100),
+    ("columba", "dynamic", 5, 150),
+    ("columba", "dynamic", 3, 100),
+    ("minU", "dynamic", 5, 250),
+    ("minU", "uniform", 7, 150),
+    ("kianfar", "dynamic", 3, 100),        # searches that start with errors allowed in the first part
+    ("kuch1", "dynamic", 0, 100),
+])
+def test_bmove_search_parity(sworld, gt, spec, partition, k, length):
+    n = 300 if (spec == "kianfar" or k >= 6) else 1200
+    reads = _reads(sworld["g"], k, n, length, seed=70 + k + length)
+    occ, offs, cnt, _ = _compare(sworld, spec, partition, k, reads)
+    if k > 0:
+        checked, _ = check_soundness(gt, sworld["text"], reads[:400], occ, offs, k, "edit")
+        assert checked > 100
+
+
+def test_bmove_search_small_kmer_tables_and_directions(sworld):
+    """schemes whose seeds need k-mers of at most four characters (kuch2, 01*0), k-mer sizes 4 and 10, ragged read lengths"""
+    g = sworld["g"]
+    reads = []
+    for ln in (36, 50, 75, 100, 101, 151, 200, 250, 256):
+        reads += synth.sample_reads(g, 60, ln, seed=ln, edit_choices=(0, 1, 2, 3))
+    _compare(sworld, "kuch2", "dynamic", 3, reads, kmer_size=4)
+    _compare(sworld, "01*0", "static", 2, reads, kmer_size=4)
+    _compare(sworld, "multiple_opt", "dynamic", 4, reads, kmer_size=10)
+    _compare(sworld, "columba", "dynamic", 2, reads, kmer_size=4)
+
+
+def test_bmove_search_is_complete(sworld, gt):
+    """ground truth directly on the device's lists: every end position within k edits is covered"""
+    ca = sworld["ca"]
+    g = sworld["g"]
+    for spec, k in (("multiple_opt", 4), ("kuch1", 2)):
+        reads = _reads(g, k, 60, 100, seed=300 + k)
+        occ, offs, _ = sworld["dev"].match_batch(ca.SearchStrategy(spec, "edit", "dynamic"), k, reads, kmer_size=8)
+        # (the checker works on 32-bit style arrays of begin / end / distance: the records have the same field names)
+        hits, chain = check_completeness(gt, sworld["text"], reads, occ, offs, k, "edit")
+        assert hits > 60 and chain * 20 <= hits
+
+
+def test_bmove_search_refusals(sworld):
+    ca = sworld["ca"]
+    with pytest.raises(ca.CmbError) as e:
+        sworld["dev"].match_batch(ca.SearchStrategy("kuch1", "hamming", "dynamic"), 2, [b"ACGT" * 30])
+    assert e.value.code == ca.CMB_ERR_UNSUPPORTED
+    with pytest.raises(ca.CmbError) as e:  # naive-backtracking fallback of the reference: refused, not skipped
+        sworld["dev"].match_batch(ca.SearchStrategy("multiple_opt", "edit", "dynamic"), 4, [b"ACGTACGT" * 12, b"ACGT"])
+    assert e.value.code == ca.CMB_ERR_UNSUPPORTED
+
+
+def test_bmove_pool_growth(sworld):
+    """pools that start from almost nothing are grown and the search re-run: same lists"""
+    ca = sworld["ca"]
+    reads = _reads(sworld["g"], 4, 400, 150, seed=9)
+    st = ca.SearchStrategy("multiple_opt", "edit", "dynamic")
+    a = sworld["dev"].match_batch(st, 4, reads, kmer_size=8)
+    os.environ["CMB_TEST_SMALL_POOLS"] = "1"
+    try:
+        b = sworld["dev"].match_batch(st, 4, reads, kmer_size=8)
+    finally:
+        del os.environ["CMB_TEST_SMALL_POOLS"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
