@@ -359,6 +359,7 @@ extern "C" int cmb_move_locate_batch(const cmb_move_index* idx, const cmb_move_r
 }
 
 static thread_local float g_exactMs[3] = {0, 0, 0};
+static thread_local unsigned long long g_exactExpansions = 0; // extensions attempted by the calling thread's last cmb_move_match_exact
 // device time of the calling thread's last cmb_move_match_exact: [0] k_move_exact, [1] prefix sum, [2] k_move_locate + k_move_occ
 extern "C" int cmb_move_last_timings(float* ms, uint32_t n) {
     if (!ms) return failWith(CMB_ERR_INVALID, "bad argument");
@@ -390,9 +391,9 @@ extern "C" int cmb_move_match_exact(const cmb_move_index* idx, const char* reads
         dWidth.alloc(nTasks + 1);
         dTaskOff.alloc(nTasks + 1);
         dRanges.alloc(nTasks);
-        dNodes.alloc(1);
+        dNodes.alloc(2);
         bad.alloc(1);
-        MV_HIPCHK(hipMemset(dNodes.p, 0, sizeof(unsigned long long)));
+        MV_HIPCHK(hipMemset(dNodes.p, 0, 2 * sizeof(unsigned long long)));
         MV_HIPCHK(hipMemset(bad.p, 0, sizeof(uint32_t)));
         MV_HIPCHK(hipMemset(dWidth.p, 0, (nTasks + 1) * sizeof(uint64_t)));
         hipEvent_t ev[4];
@@ -419,8 +420,10 @@ extern "C" int cmb_move_match_exact(const cmb_move_index* idx, const char* reads
         MV_HIPCHK(hipMemcpy(&total, dTaskOff.p + nTasks, sizeof(total), hipMemcpyDeviceToHost));
         MV_HIPCHK(hipEventElapsedTime(&g_exactMs[0], ev[0], ev[1]));
         MV_HIPCHK(hipEventElapsedTime(&g_exactMs[1], ev[1], ev[2]));
-        unsigned long long nodes = 0;
-        MV_HIPCHK(hipMemcpy(&nodes, dNodes.p, sizeof(nodes), hipMemcpyDeviceToHost));
+        unsigned long long nodes = 0, nodes2[2] = {0, 0};
+        MV_HIPCHK(hipMemcpy(nodes2, dNodes.p, sizeof(nodes2), hipMemcpyDeviceToHost));
+        nodes = nodes2[0];
+        g_exactExpansions = nodes2[1];
         *n_occ = total;
         if (counters) counters[0] = nodes, counters[1] = total;
         if (occ_offsets) {
@@ -763,7 +766,7 @@ extern "C" int cmb_move_batch_run(cmb_move_batch* b) {
             tmp.resize(nOcc);
             b->occs.swap(tmp);
             b->cnts[CMB_CNT_NODE] = c2[0];
-            b->cnts[CMB_CNT_EXPANSIONS] = c2[0]; // (every extension that succeeds is a node; failed ones end the read)
+            b->cnts[CMB_CNT_EXPANSIONS] = g_exactExpansions;
             b->cnts[CMB_CNT_TOTAL_REPORTED] = c2[1];
             b->cnts[CMB_CNT_LOCATED_ROWS] = c2[1];
             float ms[3];

@@ -469,7 +469,7 @@ __device__ inline uint32_t readCode(uint8_t ch) {
 // toehold.  widths[task] = number of occurrences; nodes = NODE_COUNTER.
 __global__ void k_move_exact(const MoveDev ix, const uint8_t* __restrict__ reads, const uint64_t* __restrict__ readOff, uint64_t nTasks,
                              MoveRangeRec* __restrict__ ranges, uint64_t* __restrict__ widths, unsigned long long* __restrict__ nodes) {
-    unsigned long long myNodes = 0;
+    unsigned long long myNodes = 0, myExp = 0; // NODE_COUNTER; extensions attempted (the byte model's unit: nodes[1])
     for (uint64_t task = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; task < nTasks; task += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t rd = task >> 1, b = readOff[rd], len = readOff[rd + 1] - b;
         const bool rc = task & 1;
@@ -481,6 +481,7 @@ __global__ void k_move_exact(const MoveDev ix, const uint8_t* __restrict__ reads
             // is the complement of the read's character `step` (nucleotide.h:250)
             uint32_t c = readCode(reads[b + (rc ? step : len - 1 - step)]);
             if (rc && c) c = 5 - c;
+            myExp += c != 0;
             alive = c != 0 && moveExtendOne(ix.fwd, c, r, toehold);
             myNodes += alive;
         }
@@ -491,8 +492,14 @@ __global__ void k_move_exact(const MoveDev ix, const uint8_t* __restrict__ reads
         ranges[task] = storePair(p);
         widths[task] = alive ? r.end - r.begin : 0;
     }
-    for (int o = 32; o; o >>= 1) myNodes += __shfl_down(myNodes, o);
-    if ((threadIdx.x & 63) == 0 && myNodes) atomicAdd(nodes, myNodes);
+    for (int o = 32; o; o >>= 1) {
+        myNodes += __shfl_down(myNodes, o);
+        myExp += __shfl_down(myExp, o);
+    }
+    if ((threadIdx.x & 63) == 0 && myExp) {
+        atomicAdd(nodes, myNodes);
+        atomicAdd(nodes + 1, myExp);
+    }
 }
 
 struct MoveOccRec { // cmb_move_occ

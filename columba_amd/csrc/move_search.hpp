@@ -204,6 +204,13 @@ struct MvCounters {
 __device__ inline bool mvAddChar(const MoveDev& ix, int mode, uint32_t code, MvPair& r, MvCounters& c) {
     if (code >= 1 && code <= 4) {
         c.expansions++;
+        // an empty range has no children (matchStringBidirectionally keeps calling addChar on the empty ranges of a k-mer
+        // with an N or one that does not occur: the reference's walks then run on the range (0, 0) of run 0 and come back
+        // empty as well, moverepr.cpp:309-327 — the extension is counted, nothing is walked here)
+        if (MvTraits::empty(r)) {
+            r = MvTraits::none();
+            return false;
+        }
         MvPair ch[4];
         const uint32_t mask = moveChildrenCounted(ix, mode, r, ch, c.rows);
         if (mask >> (code - 1) & 1u) {

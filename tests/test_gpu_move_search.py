@@ -55,8 +55,13 @@ def _compare(w, spec, partition, k, reads, kmer_size=8):
     names = ["NODE_COUNTER", "EXPANSIONS", "TOTAL_REPORTED_POSITIONS", "LOCATED_ROWS"]
     if k > 0:
         names += ["SEARCH_STARTED", "MATRIX_ROWS"]
+    # in-index occurrences that the reference's sort + adjacent-unique leaves in twice are located twice there
+    # (Occurrences::eraseDoublesFM, indexhelpers.h:2135-2146: operator< ignores fields operator== compares); the device
+    # removes every duplicate, the oracle counts the repeated work
+    surplus = {"TOTAL_REPORTED_POSITIONS": o_cnt["SURVIVING_DUP_ROWS"], "LOCATED_ROWS": o_cnt["SURVIVING_DUP_ROWS"]}
     for n in names:
-        assert o_cnt[n] == d_cnt[n], (n, o_cnt[n], d_cnt[n])
+        assert o_cnt[n] - surplus.get(n, 0) == d_cnt[n], (n, o_cnt[n], surplus.get(n, 0), d_cnt[n])
+    assert o_cnt["SURVIVING_DUP_ROWS"] * 20 <= max(o_cnt["LOCATED_ROWS"], 1)
     for n in ("IN_TEXT_STARTED", "IMMEDIATE_SWITCH", "ABORTED_IN_TEXT_VERIF", "TEXT_BYTES"):
         assert d_cnt[n] == 0, n
     if k > 0:
