@@ -111,8 +111,118 @@ def load_traffic(args, genome_bp, reads, group):
                         "(tools/profile_round.sh writes profiles/*_pmc_traffic.json with kernel_src_sha)")
 
 
+def main_rlc(args):
+    """BASELINE.json configs[4] on ONE GPU: a pan-genome-like text under the run-length compressed b-move index, 250 bp reads,
+    k = 6 edit distance, multiple_opt schemes.  `python bench.py --config rlc [--haplotypes 64 --base-mbp 4 --snp 0.005 --reads N]`.
+    A step = cmb_move_batch_run on the resident reads (prologue, frontier search, de-duplication, locate, filter, results on the
+    host).  The 64-haplotype HUMAN collection of the config (200 Gbp, tables of ~130 GB) cannot be built offline; the stand-in keeps
+    what the b-move kernels react to — n / r of the BWT and tables far beyond the 256 MB Infinity Cache."""
+    from columba_amd import movebuild
+    if args.gpus != 1:
+        sys.exit("bench.py --config rlc runs on one GPU (every rank of a multi-GPU job would hold a replica and its own read shard, "
+                 "as for the FM-index; columba_amd.dist.broadcast_device_move_index replicates the index)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(0)
+    ca.lib()
+    t0 = time.time()
+    text = movebuild.pangenome(int(args.base_mbp * 1e6), args.haplotypes, args.snp, seed=1)
+    mv = movebuild.build_move(text, device="cuda", with_locate=False)
+    mv.plcp = movebuild.plcp_gpu(mv)
+    torch.cuda.empty_cache()
+    index = ca.MoveIndex(mv)
+    log(f"[bench] b-move index of {mv.n / 1e6:.1f} Mbp ({args.haplotypes} haplotypes of {args.base_mbp} Mbp, {args.snp} SNPs): "
+        f"{mv.runs_fwd} / {mv.runs_rev} runs (n/r = {mv.n / mv.runs_fwd:.1f}), {index.device_bytes() / 1e6:.0f} MB in HBM, built in "
+        f"{time.time() - t0:.0f} s")
+    R, L, k = args.reads, args.read_len, args.k
+    buf, _ = synth.sample_reads_fast(torch.from_numpy(mv.text[:-1]).cuda(), R, L, seed=3, device="cuda",
+                                     edit_choices=(0, 1, 2, 3, 4, 5, 6))
+    offs = np.arange(R + 1, dtype=np.uint64) * np.uint64(L)
+    torch.cuda.empty_cache()
+    strategy = ca.SearchStrategy("multiple_opt", "edit", "dynamic")
+    batch = ca.MoveBatch(index, strategy, k, packed=(buf, offs), kmer_size=args.kmer_size)
+    for _ in range(args.warmup):
+        batch.run()
+    torch.cuda.synchronize()
+    kern = {}
+    tstart = time.perf_counter()
+    for _ in range(args.steps):
+        batch.run()
+        for kname, ms in batch.timings().items():
+            kern[kname] = kern.get(kname, 0.0) + ms
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - tstart
+    steps = max(args.steps, 1)
+    occ, occ_offs, cnt = batch.results()
+    avg = {kn: v / steps for kn, v in kern.items()}
+    dominant = max(avg, key=avg.get)
+    # algorithmic bytes (DESIGN.md §4.9): one move-table row fetched = 16 B (an aligned 16-byte row here; the reference reads the
+    # same 16 bytes with one unaligned 128-bit load per row access, moverepr.cpp:36-47).  Rows are counted on the device where
+    # they are loaded: run scans, LF rows, fast-forward steps, run-index searches.
+    alg = {"k_partition": 16.0 * (cnt["TABLE_ROWS"] - cnt["DFS_TABLE_ROWS"]), "k_dfs": 16.0 * cnt["DFS_TABLE_ROWS"]}
+    per_kernel = {}
+    for kname, ms in avg.items():
+        gbs = alg[kname] / (ms * 1e-3) / 1e9 if ms > 0 and kname in alg else None
+        per_kernel[kname] = {"ms": round(ms, 3), "algorithmic_GBps": None if gbs is None else round(gbs, 1),
+                             "frac_of_hbm_peak": None if gbs is None else round(gbs / HBM_PEAK_GBS, 4)}
+    achieved = per_kernel[dominant]["algorithmic_GBps"] or 0.0
+    passes = None
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "traffic_note": "PMC passes of this command: tools/profile_rlc.sh -> profiles/*_rlc_*",
+                "avg_launch_ms": round(avg[dominant], 3),
+                "unit_note": "16 B per move-table row fetched (TABLE_ROWS counted on the device); "
+                             f"{cnt['DFS_TABLE_ROWS'] / max(cnt['DFS_EXPANSIONS'], 1):.1f} rows per node expansion of the search",
+                "per_kernel": per_kernel}
+    cpu = None
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_py as op
+        import schemes_py as sp
+        ns = min(args.cpu_sample if args.cpu_sample != 1_000_000 else 20_000, R)
+        cores = os.cpu_count() or 1
+        oidx = op.OracleMoveIndex(mv)
+        oidx.prepare(args.kmer_size)   # (the k-mer table: index loading, not matching)
+        ost = op.OracleStrategy(sp.MULTIPLE_OPT, "edit", "dynamic")
+        packed = (np.ascontiguousarray(buf[:ns * L]), offs[:ns + 1].copy())
+        tc = time.perf_counter()
+        o_occ, o_off, o_cnt = oidx.match_batch(ost, k, threads=cores, word_size=args.kmer_size, packed=packed)
+        dt = time.perf_counter() - tc
+        m = int(occ_offs[ns])
+        same = (len(o_occ) == m and np.array_equal(o_occ["begin"].astype(np.uint64), occ["begin"][:m]) and
+                np.array_equal(o_occ["end"].astype(np.uint64), occ["end"][:m]) and
+                np.array_equal(o_occ["distance"], occ["distance"][:m]))
+        cpu = {"value": round(ns / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
+               "sample": f"first {ns} reads of the GPU batch, oracle/ (C++ restatement of the RUN_LENGTH_COMPRESSION flavour) with {cores} "
+                         f"threads, {dt:.1f} s (reads packed and k-mer table built before the clock); occurrences identical to the GPU's: "
+                         f"{bool(same)}; table rows stepped over by the reference's walks on the sample: {o_cnt['ROW_STEPS']}"}
+    line = {
+        "metric": "reads/sec (250bp, k=6 edit, pan-genome RLC b-move index)",
+        "value": round(R * steps / elapsed, 1), "unit": "reads/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[4] stand-in: {args.haplotypes} haplotypes x {args.base_mbp} Mbp with {args.snp} SNPs "
+                               f"({mv.n / 1e6:.0f} Mbp, r = {mv.runs_fwd}, n/r = {mv.n / mv.runs_fwd:.1f}) under the b-move index, {R} x {L} bp "
+                               f"reads, k={k} edit distance, ALL mode, multiple_opt schemes with dynamic selection, dynamic partitioning, "
+                               f"k-mer size {args.kmer_size}",
+                   "reads_per_gpu": R, "read_len": L, "k": k, "text_bp": int(mv.n), "runs": [int(mv.runs_fwd), int(mv.runs_rev)],
+                   "index_bytes_hbm": index.device_bytes(), "occurrences": int(len(occ)),
+                   "counters": {kk: int(cnt[kk]) for kk in ("NODE_COUNTER", "EXPANSIONS", "DFS_EXPANSIONS", "TABLE_ROWS",
+                                                            "DFS_TABLE_ROWS", "TOTAL_REPORTED_POSITIONS", "SEARCH_STARTED", "MATRIX_ROWS")}},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(line), flush=True)
+    batch.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=["fm", "rlc"], default="fm",
+                    help="fm: BASELINE configs[2] on the FM-index (the headline line, default); rlc: configs[4] on the b-move index")
+    ap.add_argument("--haplotypes", type=int, default=64)
+    ap.add_argument("--base-mbp", type=float, default=4.0)
+    ap.add_argument("--snp", type=float, default=0.005)
+    ap.add_argument("--kmer-size", type=int, default=10)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -133,6 +243,16 @@ def main():
                          "(cmb_batch_stage_reads uploads chunk i + 1 while chunk i is matched); reported as `streaming`, "
                          "never as `value`")
     args = ap.parse_args()
+    if args.config == "rlc":
+        if "--reads" not in " ".join(sys.argv):
+            args.reads = 1_000_000
+        if "--read-len" not in " ".join(sys.argv):
+            args.read_len = 250
+        if "--k" not in sys.argv:
+            args.k = 6
+        if "--steps" not in " ".join(sys.argv):
+            args.steps = 3
+        return main_rlc(args)
 
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus))  # (before any GPU call in this process)
@@ -331,9 +451,9 @@ def main():
             oidx = op.OracleIndex(ix)
             ost = op.OracleStrategy(sp.MULTIPLE_OPT, "edit", "dynamic")
             cores = os.cpu_count() or 1
-            sample = [buf[i * L:(i + 1) * L].tobytes() for i in range(ns)]
+            packed = (np.ascontiguousarray(buf[:ns * L]), offs[:ns + 1].copy())  # (packed before the clock starts)
             tc = time.perf_counter()
-            o_occ, o_off, _ = op.match_batch(oidx, ost, args.k, sample, threads=cores)
+            o_occ, o_off, _ = op.match_batch(oidx, ost, args.k, threads=cores, packed=packed)
             dt = time.perf_counter() - tc
             same = (len(o_occ) == int(occ_offs[ns]) and
                     np.array_equal(o_occ["begin"], occ["begin"][:len(o_occ)]) and

@@ -24,7 +24,7 @@ ERRORS = {-1: "CMB_ERR_INVALID", -2: "CMB_ERR_DEVICE", -3: "CMB_ERR_UNSUPPORTED"
           -5: "CMB_ERR_INTERNAL"}
 COUNTER_NAMES = ["NODE_COUNTER", "TOTAL_REPORTED_POSITIONS", "IN_TEXT_STARTED", "ABORTED_IN_TEXT_VERIF",
                  "CIGARS_IN_TEXT_VERIFICATION", "IMMEDIATE_SWITCH", "SEARCH_STARTED", "EXPANSIONS", "LF_STEPS",
-                 "LOCATED_ROWS", "TEXT_BYTES", "MATRIX_ROWS", "DFS_EXPANSIONS", "TABLE_ROWS"]
+                 "LOCATED_ROWS", "TEXT_BYTES", "MATRIX_ROWS", "DFS_EXPANSIONS", "TABLE_ROWS", "DFS_TABLE_ROWS"]
 METRIC = {"hamming": 0, "edit": 1}
 PARTITION = {"uniform": 0, "static": 1, "dynamic": 2}
 OCC_DTYPE = np.dtype([("begin", np.uint32), ("end", np.uint32), ("distance", np.uint32), ("strand", np.uint32)])

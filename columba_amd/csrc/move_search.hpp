@@ -674,6 +674,7 @@ __global__ void k_mvs_finish(MvBufs B, Queues q) { // one block: per-block count
         atomicAdd(&q.counters[12], s[1]); // DFS_EXPANSIONS
         atomicAdd(&q.counters[11], s[2]); // MATRIX_ROWS
         atomicAdd(&q.counters[13], s[3]); // table rows fetched
+        atomicAdd(&q.counters[14], s[3]); // ... by the frontier search
     }
 }
 

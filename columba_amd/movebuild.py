@@ -174,3 +174,43 @@ def save_move(mv: MoveArrays, base: str) -> None:
                    (".prdf", mv.pred_first), (".ftr", mv.first_to_run), (".prdl", mv.pred_last), (".ltr", mv.last_to_run),
                    (".plcp.pos", pos), (".plcp.sum", sm)):
         np.ascontiguousarray(a, dtype="<u8").tofile(base + ext + ".u64")
+
+
+def plcp_gpu(mv: MoveArrays) -> np.ndarray:
+    """PLCP values of a (repetitive) text on the GPU: PLCP[SA[i]] = LCP of the suffixes SA[i - 1] and SA[i], found by
+    comparing one more character per round for the pairs still equal (the harness' stand-in for the reference's Kasai loop,
+    bmove/plcp.h:56-80, which is what `build_move(with_locate=True)` runs on the CPU)."""
+    n = mv.n
+    t = torch.from_numpy(np.concatenate([mv.text, np.zeros(16, np.uint8)])).cuda()
+    sa = torch.from_numpy(mv.sa.astype(np.int64)).cuda()
+    cur, prv = sa[1:], sa[:-1]
+    lcp = torch.zeros(n - 1, dtype=torch.int64, device="cuda")
+    active = torch.arange(n - 1, device="cuda")
+    while active.numel():
+        a = (cur[active] + lcp[active]).clamp_(max=n)
+        b = (prv[active] + lcp[active]).clamp_(max=n + 1)
+        eq = t[a] == t[b]
+        eq &= (a < n) & (b < n)
+        idx = active[eq]
+        lcp[idx] += 1
+        active = idx
+    out = torch.zeros(n, dtype=torch.int64, device="cuda")
+    out[cur] = lcp
+    return out.cpu().numpy().astype(np.uint32)
+
+
+def pangenome(base_len: int, copies: int, snp: float, seed: int = 1) -> np.ndarray:
+    """`copies` haplotypes of one random sequence of `base_len` characters, each with its own substitutions at rate `snp`
+    (ASCII, no '$'): the repetitiveness (n / r of the BWT) of a collection of genomes of one species."""
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 4, base_len, dtype=np.uint8)
+    parts = []
+    for _ in range(copies):
+        s = base.copy()
+        m = rng.random(base_len) < snp
+        s[m] = rng.integers(0, 4, int(m.sum()), dtype=np.uint8)
+        parts.append(s)
+    text = np.frombuffer(b"ACGT", dtype=np.uint8)[np.concatenate(parts)]
+    if (text.shape[0] + 1) & text.shape[0] == 0:  # (a text size that is a power of two cannot be packed)
+        text = text[:-1]
+    return text

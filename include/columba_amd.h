@@ -169,6 +169,7 @@ enum {
     CMB_CNT_MATRIX_ROWS,
     CMB_CNT_DFS_EXPANSIONS,         /* the part of E performed by the DFS kernel (rest: prologue kernel) */
     CMB_CNT_TABLE_ROWS,             /* b-move backend only: 16-byte move-table rows fetched by run walks, LF and fast-forwards */
+    CMB_CNT_DFS_TABLE_ROWS,         /* ... the part of them fetched by the frontier search (rest: prologue kernels) */
     CMB_CNT_MAX
 };
 

@@ -8,6 +8,9 @@
 #include "oracle_search.hpp"
 #include "oracle_move_search.hpp"
 #include <atomic>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <thread>
 
 using namespace orc;
@@ -339,6 +342,17 @@ void* orc_match_batch(void* h, void* sp, uint32_t k, const char* seqs, const uin
     for (auto& c : cnts) res->counters.add(c);
     return res;
 }
+// the search view of a b-move index with its k-mer table (populateTable: index loading in the reference, not matching),
+// built once per (index, word size)
+static std::mutex g_adapterMu;
+static std::map<std::pair<const void*, uint32_t>, std::unique_ptr<orc::MoveIndexAdapter>> g_adapters;
+static const orc::MoveIndexAdapter& moveAdapter(const orc::BMoveIndex64& bm, uint32_t wordSize) {
+    std::lock_guard<std::mutex> lock(g_adapterMu);
+    auto& slot = g_adapters[{&bm, wordSize}];
+    if (!slot) slot.reset(new orc::MoveIndexAdapter(bm, wordSize));
+    return *slot;
+}
+void orc_move_prepare(void* h, uint32_t wordSize) { (void)moveAdapter(*(orc::BMoveIndex64*)h, wordSize); }
 // the same call on the run-length compressed flavour (h: orc_move_create); wordSize: k-mer table of the index
 void* orc_move_match_batch(void* h, void* sp, uint32_t k, const char* seqs, const uint64_t* offs, uint32_t nReads,
                            uint32_t nThreads, uint32_t wordSize) {
@@ -351,7 +365,7 @@ void* orc_move_match_batch(void* h, void* sp, uint32_t k, const char* seqs, cons
     std::vector<std::string> errs(nThreads);
     std::atomic<uint32_t> next(0);
     try {
-        const orc::MoveIndexAdapter x(bm, wordSize);
+        const orc::MoveIndexAdapter& x = moveAdapter(bm, wordSize);
         auto work = [&](uint32_t tid) {
             orc::MoveMatcher m(x, st);
             const uint64_t rows0 = *bm.rowStepsPtr();
@@ -569,7 +583,13 @@ void* orc_move_create(const uint8_t* lf, uint64_t lfLen, const uint8_t* lr, uint
     }
     return ix;
 }
-void orc_move_destroy(void* h) { delete (orc::BMoveIndex64*)h; }
+void orc_move_destroy(void* h) {
+    {
+        std::lock_guard<std::mutex> lock(g_adapterMu);
+        for (auto it = g_adapters.begin(); it != g_adapters.end();) it = it->first.first == h ? g_adapters.erase(it) : std::next(it);
+    }
+    delete (orc::BMoveIndex64*)h;
+}
 void orc_move_complete_range(void* h, orc_move_range* out) { *out = fromPair(((orc::BMoveIndex64*)h)->getCompleteRange()); }
 // rows of a table as (head, inputStart, outputStart, outputRun), nrOfRuns + 1 of them; returns nrOfRuns
 uint64_t orc_move_rows(void* h, int rev, uint64_t* out) {

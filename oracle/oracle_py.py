@@ -301,10 +301,12 @@ def pack_reads(reads: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
     return buf, offs
 
 
-def match_batch(index: OracleIndex, strat: OracleStrategy, k: int, reads: Sequence[bytes],
-                threads: int = 1):
-    """Returns (occs structured array, offs uint64[n+1], counters dict)."""
-    buf, offs = pack_reads(reads)
+def match_batch(index: OracleIndex, strat: OracleStrategy, k: int, reads: Sequence[bytes] = None,
+                threads: int = 1, packed=None):
+    """Returns (occs structured array, offs uint64[n+1], counters dict).  packed = (characters, offsets): reads already
+    packed (a timed caller packs before the clock starts)."""
+    buf, offs = packed if packed is not None else pack_reads(reads)
+    reads = range(offs.shape[0] - 1) if reads is None else reads
     if buf.shape[0] == 0:
         buf = np.zeros(1, np.uint8)
     r = lib().orc_match_batch(index.h, strat.h, k, _p(buf), _p(offs), len(reads), threads)
@@ -414,10 +416,16 @@ class OracleMoveIndex:
         lib().orc_move_kmer_table(self.h, word_size, _p(out))
         return out
 
-    def match_batch(self, strat: "OracleStrategy", k: int, reads: Sequence[bytes], threads: int = 1, word_size: int = 10):
+    def prepare(self, word_size: int = 10):
+        """build the k-mer table of the search (index loading in the reference: not part of a timed match)"""
+        lib().orc_move_prepare.argtypes = [C.c_void_p, C.c_uint32]
+        lib().orc_move_prepare(self.h, word_size)
+
+    def match_batch(self, strat: "OracleStrategy", k: int, reads: Sequence[bytes] = None, threads: int = 1, word_size: int = 10, packed=None):
         """SearchStrategy::matchApprox of the RUN_LENGTH_COMPRESSION flavour for a chunk of reads (ALL mode):
         (occurrences, offsets, counters) as match_batch of the FM-index flavour"""
-        buf, offs = pack_reads(reads)
+        buf, offs = packed if packed is not None else pack_reads(reads)
+        reads = range(offs.shape[0] - 1) if reads is None else reads
         if buf.shape[0] == 0:
             buf = np.zeros(1, np.uint8)
         r = lib().orc_move_match_batch(self.h, strat.h, k, _p(buf), _p(offs), len(reads), threads, word_size)
