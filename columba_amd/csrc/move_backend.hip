@@ -686,17 +686,7 @@ extern "C" int cmb_move_batch_create(cmb_move_index* idx, const cmb_strategy* st
         MV_HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
         b->reads.upload(b->hostReads.data(), b->hostReads.size());
         b->offs.upload(b->hostOffs.data(), n_reads + 1);
-        if (max_distance > 0) {
-            b->seq.alloc((size_t)2 * n_reads * maxLen);
-            b->G.alloc((size_t)n_reads * 8 * b->gw);
-            b->strat.upload(&b->hostStrat, 1);
-            b->parts.alloc((size_t)2 * n_reads);
-            b->psel.alloc((size_t)2 * n_reads);
-            b->exr.alloc((size_t)2 * n_reads * b->hostStrat.numParts);
-            uint32_t maxSearches = 0;
-            for (int i = 0; i < b->hostStrat.nSchemes; i++) maxSearches = std::max<uint32_t>(maxSearches, b->hostStrat.sch[i].nSearches);
-            b->tasks.alloc((size_t)2 * n_reads * maxSearches + 64);
-        }
+        if (max_distance > 0) b->strat.upload(&b->hostStrat, 1); // (per-read scratch is sized per slice, at the first run)
         b->cnt.alloc(8);
         b->counters.alloc(CMB_CNT_MAX);
         b->bad.alloc(1);
@@ -738,22 +728,36 @@ struct MvTimer {
 };
 } // namespace
 
+static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi);
+
+// The pools of the frontier search hold up to ~100 KB per read at k = 6 / 250 bp (600 final-column records of 96 bytes, 90
+// contexts of 512 bytes): a large chunk is matched as consecutive SLICES that reuse one set of pools (CMB_MOVE_SLICE=n reads per
+// slice; results and counters are those of the whole chunk).
 extern "C" int cmb_move_batch_run(cmb_move_batch* b) {
     if (!b) return failWith(CMB_ERR_INVALID, "null argument");
+    b->done = false;
+    b->times.clear();
+    memset(b->cnts, 0, sizeof(b->cnts));
+    b->occOffs.assign((size_t)b->nReads + 1, 0);
+    b->occs.clear();
+    uint32_t slice = b->k >= 5 ? (1u << 18) : b->k >= 3 ? (1u << 19) : (1u << 20);
+    if (getenv("CMB_MOVE_SLICE")) slice = (uint32_t)std::max(1, atoi(getenv("CMB_MOVE_SLICE")));
+    if (b->k == 0) slice = b->nReads ? b->nReads : 1;
+    for (uint32_t lo = 0; lo < b->nReads; lo += slice) {
+        const int rc = runSlice(b, lo, std::min<uint64_t>((uint64_t)lo + slice, b->nReads));
+        if (rc != CMB_OK) return rc;
+    }
+    b->done = true;
+    return CMB_OK;
+}
+
+static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
     try {
         cmb_move_index* ix = b->ix;
         MV_HIPCHK(hipSetDevice(ix->device));
         hipStream_t s = b->stream;
-        b->done = false;
-        b->times.clear();
-        memset(b->cnts, 0, sizeof(b->cnts));
-        const uint32_t nReads = b->nReads, tasksRS = 2 * nReads;
-        b->occOffs.assign((size_t)nReads + 1, 0);
-        b->occs.clear();
-        if (nReads == 0) {
-            b->done = true;
-            return CMB_OK;
-        }
+        const uint32_t nReads = hi - lo, tasksRS = 2 * nReads;
+        const uint64_t* dOffs = b->offs.p + lo; // (the kernels number the slice's reads from 0; offsets stay absolute)
         if (b->k == 0) { // exactMatchesOutput of both strands (searchstrategy.cpp:499-510): the k = 0 path of this backend
             uint64_t nOcc = 0, c2[2] = {0, 0};
             std::vector<cmb_move_occ> tmp((size_t)nReads * 8 + 1024);
@@ -773,7 +777,6 @@ extern "C" int cmb_move_batch_run(cmb_move_batch* b) {
             (void)cmb_move_last_timings(ms, 3);
             b->times.push_back({"k_move_exact", ms[0]});
             b->times.push_back({"locate", ms[1] + ms[2]});
-            b->done = true;
             return CMB_OK;
         }
         MvTimer tm(s, b->times);
@@ -788,10 +791,20 @@ extern "C" int cmb_move_batch_run(cmb_move_batch* b) {
             sx.kmerSize = ix->kmerSize;
         }
         uint32_t hcnt[8];
+        if (b->parts.n < (size_t)2 * nReads) { // per-read scratch of a slice
+            b->seq.alloc((size_t)2 * nReads * b->maxLen);
+            b->G.alloc((size_t)nReads * 8 * b->gw);
+            b->parts.alloc((size_t)2 * nReads);
+            b->psel.alloc((size_t)2 * nReads);
+            b->exr.alloc((size_t)2 * nReads * b->hostStrat.numParts);
+            uint32_t ms2 = 0;
+            for (int i = 0; i < b->hostStrat.nSchemes; i++) ms2 = std::max<uint32_t>(ms2, b->hostStrat.sch[i].nSearches);
+            b->tasks.alloc((size_t)2 * nReads * ms2 + 64);
+        }
         // ---- read preparation
         tm.begin();
-        MV_HIPCHK(hipMemsetAsync(b->G.p, 0, b->G.bytes(), s));
-        hipLaunchKernelGGL(k_mvs_prep, dim3(gridFor(nReads)), dim3(256), 0, s, b->reads.p, b->offs.p, nReads, b->maxLen, b->gw, b->seq.p, b->G.p);
+        MV_HIPCHK(hipMemsetAsync(b->G.p, 0, (size_t)nReads * 8 * b->gw * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_mvs_prep, dim3(gridFor(nReads)), dim3(256), 0, s, b->reads.p, dOffs, nReads, b->maxLen, b->gw, b->seq.p, b->G.p);
         tm.end("k_prep");
         const uint32_t P = b->hostStrat.numParts;
         uint32_t maxSearches = 0;
@@ -808,7 +821,7 @@ extern "C" int cmb_move_batch_run(cmb_move_batch* b) {
             {
                 const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)tasksRS + 63) / 64, 256 * 64);
                 auto kp = b->hostStrat.partition == 0 ? k_mvs_parts<0> : b->hostStrat.partition == 1 ? k_mvs_parts<1> : k_mvs_parts<2>;
-                hipLaunchKernelGGL(kp, dim3(grid), dim3(64), 0, s, sx, b->strat.p, nReads, b->maxLen, b->seq.p, b->offs.p, b->parts.p, b->exr.p, b->psel.p, q);
+                hipLaunchKernelGGL(kp, dim3(grid), dim3(64), 0, s, sx, b->strat.p, nReads, b->maxLen, b->seq.p, dOffs, b->parts.p, b->exr.p, b->psel.p, q);
                 const uint64_t nWork = (uint64_t)tasksRS * maxSearches;
                 const unsigned gridE = (unsigned)std::min<uint64_t>((nWork + 63) / 64, 256 * 64);
                 hipLaunchKernelGGL(k_mvs_exact, dim3(gridE), dim3(64), 0, s, sx, b->strat.p, nReads, b->maxLen, maxSearches, b->seq.p, b->parts.p, b->exr.p,
@@ -875,14 +888,14 @@ extern "C" int cmb_move_batch_run(cmb_move_batch* b) {
                 B.fmX = b->fm.p;
                 B.rowSteps = nullptr;
                 hipLaunchKernelGGL(k_mvs_start, dim3(std::min<uint32_t>((nTasks + 255) / 256, BFS_GRID)), dim3(256), 0, s, b->strat.p, B, b->tasks.p, nTasks,
-                                   b->offs.p, b->gw, b->G.p, b->parts.p, q);
+                                   dOffs, b->gw, b->G.p, b->parts.p, q);
                 std::vector<uint32_t> hc(cntWords);
                 uint32_t pass = 0, peakQ = 0, peakEv = 0;
                 bool drained = false;
                 while (!drained && pass < maxPass) {
                     const uint32_t upTo = std::min(pass + 16u, maxPass);
                     for (; pass < upTo; pass++)
-                        hipLaunchKernelGGL(k_mvs_pass, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->strat.p, B, pass, b->offs.p, b->gw, b->G.p,
+                        hipLaunchKernelGGL(k_mvs_pass, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->strat.p, B, pass, dOffs, b->gw, b->G.p,
                                            b->parts.p, q);
                     MV_HIPCHK(hipMemcpyAsync(hc.data(), b->bfsCnt.p, cntWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                     MV_HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
@@ -999,17 +1012,19 @@ extern "C" int cmb_move_batch_run(cmb_move_batch* b) {
         unsigned long long hc64[CMB_CNT_MAX];
         MV_HIPCHK(hipMemcpyAsync(hc64, b->counters.p, sizeof(hc64), hipMemcpyDeviceToHost, s));
         static_assert(sizeof(cmb_move_occ) == sizeof(MoveOccOut), "cmb_move_occ layout");
-        b->occs.resize(nOut);
-        if (nOut) MV_HIPCHK(hipMemcpyAsync(b->occs.data(), b->out.p, nOut * sizeof(MoveOccOut), hipMemcpyDeviceToHost, s));
-        if (totalPos) MV_HIPCHK(hipMemcpyAsync(b->occOffs.data(), b->readOff.p, ((size_t)nReads + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        const size_t occBase = b->occs.size();
+        b->occs.resize(occBase + nOut);
+        std::vector<uint64_t> sliceOffs((size_t)nReads + 1, 0);
+        if (nOut) MV_HIPCHK(hipMemcpyAsync(b->occs.data() + occBase, b->out.p, nOut * sizeof(MoveOccOut), hipMemcpyDeviceToHost, s));
+        if (totalPos) MV_HIPCHK(hipMemcpyAsync(sliceOffs.data(), b->readOff.p, ((size_t)nReads + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         MV_HIPCHK(hipStreamSynchronize(s));
+        for (uint32_t i = 0; i <= nReads; i++) b->occOffs[(size_t)lo + i] = occBase + sliceOffs[i];
         if (totalPos && hb)
             return failWith(CMB_ERR_INTERNAL, std::to_string(hb) + " occurrences whose phi chains do not have the width of their range, or whose "
                                                                    "fields do not fit the filter keys");
-        for (int i = 0; i < CMB_CNT_MAX; i++) b->cnts[i] = hc64[i];
-        b->cnts[CMB_CNT_TOTAL_REPORTED] = totalPos;
-        b->cnts[CMB_CNT_LOCATED_ROWS] = totalPos;
-        b->done = true;
+        for (int i = 0; i < CMB_CNT_MAX; i++) b->cnts[i] += hc64[i];
+        b->cnts[CMB_CNT_TOTAL_REPORTED] += totalPos;
+        b->cnts[CMB_CNT_LOCATED_ROWS] += totalPos;
         return CMB_OK;
     } catch (const std::exception& e) {
         return failWith(CMB_ERR_DEVICE, e.what());

@@ -90,8 +90,18 @@ struct RowCount {
     uint32_t n = 0;
 };
 
-// moveChildren with a count of the table rows it fetches
-__device__ inline uint32_t moveChildrenCounted(const MoveDev& ix, const int mode, const MvPair& parent, MvPair child[4], uint32_t& rows) {
+// moveChildren (move_dev.hpp) arranged for the memory system, with a count of the table rows it fetches:
+//  * the two ends of the range are scanned TOGETHER (one loop, two cursors: their row loads overlap);
+//  * a row that holds the first / last occurrence of a character is mapped by LF when it is seen (the row is in registers:
+//    no second fetch), so the scan leaves, per character, the LF images of its first and last occurrence and their runs;
+//    countChar (moverepr.cpp:329-345) = the distance of the two images — the widths of ALL children and the cumulative
+//    counts cost no further memory access;
+//  * only the fast-forwards (moverepr.cpp:283-293) of the children in `need` are walked, all of them in one loop (every
+//    round issues the next row of every unfinished end point before any reply is consumed).
+// Everything indexed by character is unrolled: the state stays in registers.  `need`: bit c - 1 = child c is wanted in
+// full; the others only contribute their width to the cumulative counts.  Returns the mask of non-empty children.
+__device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const int mode, const MvPair& parent, MvPair child[4], uint32_t& rows,
+                                               const uint32_t need = 0xFu) {
     const bool fw = mode == 0;
     const MoveTable& t = fw ? ix.rev : ix.fwd;
     MvRange trivial = fw ? parent.rev : parent.sa;
@@ -104,93 +114,122 @@ __device__ inline uint32_t moveChildrenCounted(const MoveDev& ix, const int mode
         }
         computeRunIndices(t, trivial);
     }
-    // moveScan, counting
-    MoveScan s;
-    s.found = 0;
+    uint64_t fOut[4], fRun[4], lOut[4], lRun[4], lSrc[4]; // LF images of the first / last occurrence, run of the last occurrence
+    uint32_t found = 0, seen = 0;                          // bits 0..4: character seen from the front / from the back
     {
-        uint64_t run = trivial.beginRun, pos = trivial.begin;
-        uint4 row = t.rows[run];
-        rows++;
+        uint64_t runF = trivial.beginRun, posF = trivial.begin, runB = trivial.endRun, posB = trivial.end - 1;
+        uint4 rowF = t.rows[runF], rowB = t.rows[runB];
+        rows += 2;
+        bool fDone = false, bDone = false;
         while (true) {
-            const uint32_t h = rowHead(row);
-            if (!(s.found >> h & 1u)) {
-                s.found |= 1u << h;
-                s.firstPos[h] = pos;
-                s.firstRun[h] = run;
+            if (!fDone) {
+                const uint32_t h = rowHead(rowF);
+                if (!(found >> h & 1u)) {
+                    found |= 1u << h;
+                    const MoveRow r = unpackMoveRow(rowF);
+#pragma unroll
+                    for (uint32_t c = 0; c < 4; c++)
+                        if (h == c + 1) {
+                            fOut[c] = r.out + (posF - r.in);
+                            fRun[c] = r.outRun;
+                        }
+                }
+                fDone = (found & 0x1Eu) == 0x1Eu || runF == trivial.endRun;
             }
-            if ((s.found & 0x1Eu) == 0x1Eu || run == trivial.endRun) break;
-            run++;
-            row = t.rows[run];
-            rows++;
-            pos = rowIn(row);
-        }
-        uint32_t seen = 0;
-        run = trivial.endRun;
-        pos = trivial.end - 1;
-        row = t.rows[run];
-        rows++;
-        while (true) {
-            const uint32_t h = rowHead(row);
-            if (!(seen >> h & 1u)) {
-                seen |= 1u << h;
-                s.lastPos[h] = pos;
-                s.lastRun[h] = run;
+            if (!bDone) {
+                const uint32_t h = rowHead(rowB);
+                if (!(seen >> h & 1u)) {
+                    seen |= 1u << h;
+                    const MoveRow r = unpackMoveRow(rowB);
+#pragma unroll
+                    for (uint32_t c = 0; c < 4; c++)
+                        if (h == c + 1) {
+                            lOut[c] = r.out + (posB - r.in);
+                            lRun[c] = r.outRun;
+                            lSrc[c] = runB;
+                        }
+                }
+                // every character of the forward pass is met again at the latest when the walk reaches the run that pass
+                // stopped in; characters it did not meet (the forward pass ended early with all four) cannot exist
+                bDone = (seen & 0x1Eu) == 0x1Eu || runB == trivial.beginRun || (fDone && (seen & 0x1Eu) == (found & 0x1Eu));
             }
-            if ((seen & 0x1Eu) == (s.found & 0x1Eu) || run == trivial.beginRun) break;
-            pos = rowIn(row) - 1;
-            run--;
-            row = t.rows[run];
-            rows++;
+            if (fDone && bDone) break;
+            if (!fDone) {
+                runF++;
+                rowF = t.rows[runF];
+                rows++;
+            }
+            if (!bDone) {
+                posB = rowIn(rowB) - 1;
+                runB--;
+                rowB = t.rows[runB];
+                rows++;
+            }
+            if (!fDone) posF = rowIn(rowF);
         }
-        s.found &= seen | 1u;
+        found &= seen | 1u;
+    }
+    // fast-forwards of the wanted children: end point 2 c = first occurrence of character c + 1, 2 c + 1 = last
+    {
+        uint32_t act = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < 4; c++)
+            if ((found >> (c + 1) & 1u) && (need >> c & 1u)) act |= 3u << (2 * c);
+        while (act) {
+            uint64_t nx[8];
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                if (act >> (2 * c) & 1u) nx[2 * c] = rowIn(t.rows[fRun[c] + 1]);
+                if (act >> (2 * c + 1) & 1u) nx[2 * c + 1] = rowIn(t.rows[lRun[c] + 1]);
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                if (act >> (2 * c) & 1u) {
+                    rows++;
+                    if (nx[2 * c] <= fOut[c]) fRun[c]++;
+                    else act &= ~(1u << (2 * c));
+                }
+                if (act >> (2 * c + 1) & 1u) {
+                    rows++;
+                    if (nx[2 * c + 1] <= lOut[c]) lRun[c]++;
+                    else act &= ~(1u << (2 * c + 1));
+                }
+            }
+        }
     }
     const uint64_t parentWidth = trivial.end - trivial.begin;
+    // MoveLFReprBP::getCumulativeCounts (moverepr.cpp:347-365): the '$' of the range, then the smaller characters
     uint64_t cum = (trivial.begin <= t.zeroCharPos && trivial.end > t.zeroCharPos) ? 1 : 0;
     uint32_t mask = 0;
-    for (int c = 1; c <= 4; c++) {
-        MvPair& ch = child[c - 1];
-        if (!(s.found >> c & 1u)) {
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++) {
+        MvPair& ch = child[c];
+        if (!(found >> (c + 1) & 1u)) { // addChar: setEmpty() (moverepr.cpp:313-316), SARangePair(range1, range1, 0, false, 0)
             ch.sa = {0, 0, 0, 0, false};
             ch.rev = ch.sa;
             ch.toehold = 0, ch.repEnd = false, ch.depth = 0;
             continue;
         }
-        mask |= 1u << (c - 1);
-        uint64_t p1 = s.firstPos[c], r1 = s.firstRun[c], p2 = s.lastPos[c], r2 = s.lastRun[c];
-        {
-            const MoveRow ra = unpackMoveRow(t.rows[r1]);
-            p1 = ra.out + (p1 - ra.in);
-            r1 = ra.outRun;
-            rows += 2;
-            while (rowIn(t.rows[r1 + 1]) <= p1) {
-                r1++;
-                rows++;
+        mask |= 1u << c;
+        const uint64_t width = lOut[c] + 1 - fOut[c]; // = countChar(trivial, c + 1)
+        if (need >> c & 1u) {
+            const MvRange range1 = {fOut[c], lOut[c] + 1, fRun[c], lRun[c], true};
+            MvRange second;
+            if (width == parentWidth) { // the other range and the toehold carry over
+                second = mode == 2 ? MvRange{0, 0, 0, 0, true} : other;
+                ch.toehold = fw ? parent.toehold + (parent.repEnd ? 1 : 0) : parent.toehold - (parent.repEnd ? 0 : 1);
+                ch.repEnd = parent.repEnd;
+            } else {
+                second = mode == 2 ? MvRange{0, 0, 0, 0, true} : MvRange{other.begin + cum, other.begin + cum + width, other.beginRun, other.endRun, false};
+                // BMove::computeToehold / computeToeholdRev (bmove.cpp:222-266): the last run of the range that holds the character
+                const uint64_t smp = lSrc[c] == trivial.endRun ? t.samplesFirst[trivial.endRun] : t.samplesLast[lSrc[c]];
+                ch.toehold = fw ? ix.n - 1 - (smp - 1) : smp - 1;
+                ch.repEnd = fw;
             }
-            const MoveRow rb = unpackMoveRow(t.rows[r2]);
-            p2 = rb.out + (p2 - rb.in);
-            r2 = rb.outRun;
-            rows += 2;
-            while (rowIn(t.rows[r2 + 1]) <= p2) {
-                r2++;
-                rows++;
-            }
+            ch.sa = fw ? second : range1;
+            ch.rev = fw ? range1 : second;
+            ch.depth = parent.depth + 1;
         }
-        const MvRange range1 = {p1, p2 + 1, r1, r2, true};
-        const uint64_t width = p2 + 1 - p1;
-        MvRange second;
-        if (width == parentWidth) {
-            second = mode == 2 ? MvRange{0, 0, 0, 0, true} : other;
-            ch.toehold = fw ? parent.toehold + (parent.repEnd ? 1 : 0) : parent.toehold - (parent.repEnd ? 0 : 1);
-            ch.repEnd = parent.repEnd;
-        } else {
-            second = mode == 2 ? MvRange{0, 0, 0, 0, true} : MvRange{other.begin + cum, other.begin + cum + width, other.beginRun, other.endRun, false};
-            const uint64_t smp = s.lastRun[c] == trivial.endRun ? t.samplesFirst[trivial.endRun] : t.samplesLast[s.lastRun[c]];
-            ch.toehold = fw ? ix.n - 1 - (smp - 1) : smp - 1;
-            ch.repEnd = fw;
-        }
-        ch.sa = fw ? second : range1;
-        ch.rev = fw ? range1 : second;
-        ch.depth = parent.depth + 1;
         cum += width;
     }
     return mask;
@@ -201,7 +240,7 @@ __device__ inline uint32_t moveChildrenCounted(const MoveDev& ix, const int mode
 struct MvCounters {
     uint32_t nodes = 0, expansions = 0, rows = 0, started = 0;
 };
-__device__ inline bool mvAddChar(const MoveDev& ix, int mode, uint32_t code, MvPair& r, MvCounters& c) {
+__device__ __forceinline__ bool mvAddChar(const MoveDev& ix, int mode, uint32_t code, MvPair& r, MvCounters& c) {
     if (code >= 1 && code <= 4) {
         c.expansions++;
         // an empty range has no children (matchStringBidirectionally keeps calling addChar on the empty ranges of a k-mer
@@ -212,9 +251,12 @@ __device__ inline bool mvAddChar(const MoveDev& ix, int mode, uint32_t code, MvP
             return false;
         }
         MvPair ch[4];
-        const uint32_t mask = moveChildrenCounted(ix, mode, r, ch, c.rows);
+        const uint32_t mask = moveChildrenCounted(ix, mode, r, ch, c.rows, 1u << (code - 1));
         if (mask >> (code - 1) & 1u) {
-            r = code == 1 ? ch[0] : code == 2 ? ch[1] : code == 3 ? ch[2] : ch[3];
+            // (assigned under a condition per child, not selected with ?: — a select between objects keeps them in scratch memory)
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++)
+                if (code == j + 1) r = ch[j];
             c.nodes++;
             return true;
         }
@@ -355,8 +397,12 @@ k_mvs_parts(MvSearchIndex sx, const DevStrategyK* __restrict__ stp, uint32_t nRe
                     if (code >= 1 && code <= 4) {
                         MvPair ch[4];
                         uint32_t rows = 0;
-                        const uint32_t mask = moveChildrenCounted(ix, 1, mvCompleteRange(ix), ch, rows);
-                        if (mask >> (code - 1) & 1u) r = code == 1 ? ch[0] : code == 2 ? ch[1] : code == 3 ? ch[2] : ch[3];
+                        const uint32_t mask = moveChildrenCounted(ix, 1, mvCompleteRange(ix), ch, rows, 1u << (code - 1));
+                        if (mask >> (code - 1) & 1u) {
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; j++)
+                                if (code == j + 1) r = ch[j];
+                        }
                     }
                 }
                 *exAt(i) = storePair(r);
