@@ -136,6 +136,7 @@ static void loadTable(TableHost& t, const uint8_t* file, uint64_t fileBytes, uin
     t.rows.alloc(runs + 2);
     MV_HIPCHK(hipMemset(t.rows.p + runs + 1, 0xFF, sizeof(uint4)));
     hipLaunchKernelGGL(k_move_unpack, dim3(gridFor(runs + 1)), dim3(256), 0, 0, packed.p, runs + 1, rowBytes, bitsN, bitsR, t.rows.p);
+    hipLaunchKernelGGL(k_move_gaps, dim3(gridFor(runs)), dim3(256), 0, 0, t.rows.p, runs);
     hipLaunchKernelGGL(k_move_check, dim3(gridFor(runs + 1)), dim3(256), 0, 0, t.rows.p, runs, n, dFlags);
     MV_HIPCHK(hipGetLastError());
     MV_HIPCHK(hipDeviceSynchronize());

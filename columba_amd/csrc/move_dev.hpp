@@ -11,6 +11,10 @@
 //     bits   3..42  inputStartPos   (40 bits: texts up to 2^40 - 1 characters)
 //     bits  43..82  outputStartPos  (40 bits)
 //     bits  83..122 outputStartRun  (40 bits)
+//     bits 123..127 gap = min(31, inputStartPos[outputStartRun + 1] - outputStartPos): how far the LF image of the run's
+//                    first position is from the next run boundary.  An LF image out + offset with offset < gap lies in
+//                    outputStartRun itself — the fast-forward (moverepr.cpp:283-293) then needs no table access at all, and
+//                    with gap < 31 <= ... otherwise it starts one run further on.  (k_move_gaps fills it after the unpacking.)
 // so a run walk is a stream of consecutive 16-byte loads (eight rows per 128-byte line), and the whole row of a run
 // arrives in one request.  `k_move_unpack` converts the reference's file rows on the device.
 //
@@ -48,6 +52,8 @@ __host__ __device__ inline MoveRow unpackMoveRow(const uint4 v) {
     r.outRun = (hi >> 19) & MV_M40;
     return r;
 }
+constexpr uint32_t MV_GAP_MAX = 31;
+__device__ inline uint32_t rowGap(const uint4 v) { return v.w >> 27; }
 __device__ inline uint32_t rowHead(const uint4 v) { return v.x & 7u; }
 __device__ inline uint64_t rowIn(const uint4 v) { return (((uint64_t)v.x | (uint64_t)v.y << 32) >> 3) & MV_M40; }
 
@@ -172,9 +178,14 @@ __device__ inline void moveScan(const MoveTable& t, const MvRange& r, MoveScan& 
 
 // MoveLFReprBP::findLF (moverepr.cpp:283-301)
 __device__ inline void moveLF(const MoveTable& t, uint64_t& pos, uint64_t& run) {
-    const MoveRow r = unpackMoveRow(t.rows[run]);
-    pos = r.out + (pos - r.in);
+    const uint4 w = t.rows[run];
+    const MoveRow r = unpackMoveRow(w);
+    const uint64_t off = pos - r.in;
+    const uint32_t gap = rowGap(w);
+    pos = r.out + off;
     run = r.outRun;
+    if (off < gap) return; // still inside the run the LF image of the run's first position lies in
+    if (gap < MV_GAP_MAX) run++;
     while (rowIn(t.rows[run + 1]) <= pos) run++; // fast-forward; the terminating row (inputStartPos = n) stops it
 }
 
@@ -303,6 +314,22 @@ __global__ void k_move_unpack(const uint8_t* __restrict__ packed, uint64_t rowsT
     }
 }
 
+// the gap field of every row (see the layout above); after k_move_unpack
+__global__ void k_move_gaps(uint4* __restrict__ rows, uint64_t runs) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < runs; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint4 w = rows[i];
+        const MoveRow r = unpackMoveRow(w);
+        uint64_t gap = MV_GAP_MAX;
+        if (r.outRun < runs) {
+            const uint64_t nx = rowIn(rows[r.outRun + 1]);
+            gap = nx > r.out ? nx - r.out : 0;
+            if (gap > MV_GAP_MAX) gap = MV_GAP_MAX;
+        }
+        w.w = (w.w & 0x07FFFFFFu) | ((uint32_t)gap << 27);
+        rows[i] = w;
+    }
+}
+
 // consistency of an unpacked table: what every walk relies on to stay inside it.  flags[0] counts violations.
 __global__ void k_move_check(const uint4* __restrict__ rows, uint64_t runs, uint64_t n, uint32_t* __restrict__ flags) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= runs; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -312,9 +339,10 @@ __global__ void k_move_check(const uint4* __restrict__ rows, uint64_t runs, uint
         else {
             const MoveRow nx = unpackMoveRow(rows[i + 1]);
             bad = r.head > 4 || (i == 0 && r.in != 0) || r.in >= nx.in || r.out >= n || r.outRun >= runs || r.out + (nx.in - r.in) > n;
-            if (!bad) { // outputStartRun is the run that holds outputStartPos
+            if (!bad) { // outputStartRun is the run that holds outputStartPos; the gap field says how far the next run is
                 const uint64_t a = rowIn(rows[r.outRun]), b = rowIn(rows[r.outRun + 1]);
                 bad = !(a <= r.out && r.out < b);
+                if (!bad) bad = rowGap(rows[i]) != (uint32_t)(b - r.out > MV_GAP_MAX ? MV_GAP_MAX : b - r.out);
             }
         }
         if (bad) atomicAdd(&flags[0], 1u);
@@ -425,8 +453,12 @@ __global__ void k_move_locate(const MoveDev ix, const MoveRangeRec* __restrict__
 // MoveLFReprBP::findLF on a row that is already in registers
 __device__ inline void moveLFRow(const MoveTable& t, const uint4 rowWord, uint64_t& pos, uint64_t& run) {
     const MoveRow r = unpackMoveRow(rowWord);
-    pos = r.out + (pos - r.in);
+    const uint64_t off = pos - r.in;
+    const uint32_t gap = rowGap(rowWord);
+    pos = r.out + off;
     run = r.outRun;
+    if (off < gap) return;
+    if (gap < MV_GAP_MAX) run++;
     while (rowIn(t.rows[run + 1]) <= pos) run++;
 }
 

@@ -116,6 +116,7 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
     }
     uint64_t fOut[4], fRun[4], lOut[4], lRun[4], lSrc[4]; // LF images of the first / last occurrence, run of the last occurrence
     uint32_t found = 0, seen = 0;                          // bits 0..4: character seen from the front / from the back
+    uint32_t ffNeed = 0;                                   // end points (2 c: first, 2 c + 1: last) whose image left its target run
     {
         uint64_t runF = trivial.beginRun, posF = trivial.begin, runB = trivial.endRun, posB = trivial.end - 1;
         uint4 rowF = t.rows[runF], rowB = t.rows[runB];
@@ -130,8 +131,14 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
 #pragma unroll
                     for (uint32_t c = 0; c < 4; c++)
                         if (h == c + 1) {
-                            fOut[c] = r.out + (posF - r.in);
+                            const uint64_t off = posF - r.in;
+                            const uint32_t gap = rowGap(rowF);
+                            fOut[c] = r.out + off;
                             fRun[c] = r.outRun;
+                            if (off >= gap) { // (the row's gap field, move_dev.hpp: most images stay in the target run)
+                                ffNeed |= 1u << (2 * c);
+                                if (gap < MV_GAP_MAX) fRun[c]++;
+                            }
                         }
                 }
                 fDone = (found & 0x1Eu) == 0x1Eu || runF == trivial.endRun;
@@ -144,9 +151,15 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
 #pragma unroll
                     for (uint32_t c = 0; c < 4; c++)
                         if (h == c + 1) {
-                            lOut[c] = r.out + (posB - r.in);
+                            const uint64_t off = posB - r.in;
+                            const uint32_t gap = rowGap(rowB);
+                            lOut[c] = r.out + off;
                             lRun[c] = r.outRun;
                             lSrc[c] = runB;
+                            if (off >= gap) {
+                                ffNeed |= 2u << (2 * c);
+                                if (gap < MV_GAP_MAX) lRun[c]++;
+                            }
                         }
                 }
                 // every character of the forward pass is met again at the latest when the walk reaches the run that pass
@@ -175,6 +188,7 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
 #pragma unroll
         for (uint32_t c = 0; c < 4; c++)
             if ((found >> (c + 1) & 1u) && (need >> c & 1u)) act |= 3u << (2 * c);
+        act &= ffNeed;
         while (act) {
             uint64_t nx[8];
 #pragma unroll
@@ -698,7 +712,10 @@ k_mvs_start(const DevStrategyK* __restrict__ stp, MvBufs B, const MvTask* __rest
     if (blockStopped(q)) return;
     bfsHeavy<true, MvTraits>(stp, B, 0u, tasks, nTasks, offs, gw, G, parts, q, blockIdx.x, gridDim.x);
 }
-__global__ void __launch_bounds__(256)
+#ifndef CMB_MVS_WAVES
+#define CMB_MVS_WAVES 2 // wavefronts per SIMD the register allocation of k_mvs_pass is held to
+#endif
+__global__ void __launch_bounds__(256, CMB_MVS_WAVES)
 k_mvs_pass(MoveDev ix, const DevStrategyK* __restrict__ stp, MvBufs B, uint32_t pass, const uint64_t* __restrict__ offs, uint32_t gw,
            const uint32_t* __restrict__ G, const PartOut* __restrict__ parts, Queues q) {
     if (blockStopped(q)) return;
