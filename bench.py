@@ -67,6 +67,32 @@ def launch_ranks(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def pin_to_gpu_numa_node(local: int):
+    """Keep this rank's host threads (the Python thread and the library's sub-batch workers, which inherit the mask) on the
+    CPUs of the NUMA node its GPU hangs on: eight ranks x three workers otherwise wander across both sockets.  Best effort:
+    returns a description for the JSON line, or None when the topology cannot be read."""
+    try:
+        prop = torch.cuda.get_device_properties(local)
+        bus, dom, devn = getattr(prop, "pci_bus_id", None), getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_device_id", 0)
+        if bus is None:
+            return None
+        path = f"/sys/bus/pci/devices/{dom:04x}:{bus:02x}:{devn:02x}.0/numa_node"
+        node = int(open(path).read().strip())
+        if node < 0:
+            return None
+        cpus = []
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus += list(range(int(a), int(b or a) + 1))
+        allowed = sorted(set(cpus) & os.sched_getaffinity(0))
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return {"numa_node": node, "cpus": len(allowed)}
+    except Exception as e:  # (no sysfs, no permission: run unpinned)
+        return {"error": str(e)[:80]}
+
+
 def source_digest() -> str:
     """what a committed PMC profile must have been measured on: the kernel sources of this tree"""
     import hashlib
@@ -233,6 +259,9 @@ def main():
     ap.add_argument("--traffic-from", default=None,
                     help="JSON written by tools/profile_round.sh (PMC passes of this same command); default: the "
                          "newest profiles/*_pmc_traffic.json measured on the same workload")
+    ap.add_argument("--total-reads", type=int, default=0,
+                    help="STRONG scaling: this many reads for the whole job, split evenly over the ranks (BASELINE.json configs[3]: "
+                         "100 M reads over 8 GPUs = 12.5 M per GPU); default 0 = weak scaling with --reads per GPU")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--k", type=int, default=4)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU oracle (bounded sample)")
@@ -269,7 +298,9 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    affinity = pin_to_gpu_numa_node(local) if not os.environ.get("CMB_BENCH_NO_PIN") else None
     dist = None
+    rccl_ranks = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -278,6 +309,13 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # proof that the collective library really spans all ranks: a sum of ones over device tensors (RCCL for `nccl`)
+        ones = torch.ones(1, dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, dist.get_world_size(), world)
+    if args.total_reads:
+        args.reads = args.total_reads // world
 
     ca.lib()  # fail loudly if the HIP extension is missing
     n = int(args.genome_mbp * 1e6)
@@ -291,13 +329,17 @@ def main():
         log(f"[bench] index for {n / 1e6:.0f} Mbp built in {time.time() - t0:.1f} s "
             f"({ix.nbytes() / 1e9:.2f} GB host arrays)")
     index = ca.Index(ix, in_text_switch=4, kmer_size=10, device=local) if rank == 0 else None
+    broadcast_ms = None
     if world > 1:
+        dist.barrier()
         tb = time.time()
         index = broadcast_device_index(index, rank, local)  # the device layout itself, one collective per array
         torch.cuda.synchronize()
+        dist.barrier()
+        broadcast_ms = (time.time() - tb) * 1e3
         if rank == 0:
             log(f"[bench] device index ({index.device_bytes() / 1e9:.2f} GB) broadcast to {world - 1} peers in "
-                f"{time.time() - tb:.2f} s")
+                f"{broadcast_ms / 1e3:.2f} s")
     strategy = ca.SearchStrategy("multiple_opt", "edit", "dynamic")
 
     # reads: rank 0 samples the global batch on its GPU and scatters equal shards
@@ -335,8 +377,14 @@ def main():
             kern[kname] = kern.get(kname, 0.0) + ms
     sync()
     elapsed = time.perf_counter() - tstart
+    per_rank_ms = [round(elapsed / max(args.steps, 1) * 1e3, 3)]
     if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+        cdev = "cpu" if dist.get_backend() == "gloo" else dev
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        every = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [round(float(t.item()) / max(args.steps, 1) * 1e3, 3) for t in every]
+        te = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     # kernel table: one extra step with the sub-batches of the batch run one after the other, so that every kernel
@@ -466,7 +514,9 @@ def main():
             "metric": "reads/sec (150bp, k=4 edit, human ref)",
             "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "scaling": "strong" if args.total_reads else "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "rccl_ranks": rccl_ranks, "per_rank_ms_per_step": per_rank_ms, "index_broadcast_ms": None if broadcast_ms is None else round(broadcast_ms, 1),
+            "host_affinity": affinity,
             "config": {"workload": f"synthetic human-like reference {n / 1e6:.0f} Mbp (GRCh38 is not available "
                                    f"offline), {R} x {L} bp reads per GPU, k={args.k} edit distance, ALL mode, "
                                    "multiple_opt schemes with dynamic selection, dynamic partitioning, "
