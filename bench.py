@@ -36,6 +36,10 @@ from columba_amd.dist import (allreduce_counters, broadcast_device_index, gather
                               scatter_reads)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
+# MI355X_MICROARCH.md "Wave scheduling": a wave64 VALU instruction issues over 2 cycles on its SIMD-32; 256 CUs x 4 SIMDs at 2.4 GHz
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2
+# profiles/r03_fetch_calibration.txt: scattered 16 / 32-byte loads sustain 43 - 45 G distinct 128-byte lines per second
+RANDOM_LINE_RATE = 45.0e9
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
@@ -123,6 +127,32 @@ def source_digest() -> str:
         with open(os.path.join(d, fn), "rb") as f:
             h.update(fn.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
+
+
+def load_counters(args, genome_bp, reads, group, names):
+    """sums of SQ counters per step over the kernels of a group, from the same profile file as load_traffic (or None)"""
+    import glob
+    cands = [args.traffic_from] if args.traffic_from else sorted(
+        glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True)
+    for f in cands:
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        w = d.get("workload", {})
+        if w.get("genome_bp") != genome_bp or w.get("reads_per_gpu") != reads or w.get("k") != args.k:
+            continue
+        if d.get("kernel_src_sha") != source_digest() and not args.traffic_from:
+            continue
+        out = {}
+        for kn in GROUP_KERNELS.get(group, [group]):
+            e = d.get("kernels", {}).get(kn, {})
+            for nm in names:
+                if nm in e:
+                    out[nm] = out.get(nm, 0.0) + e[nm]
+        if out:
+            return out
+    return None
 
 
 def load_traffic(args, genome_bp, reads, group):
@@ -498,8 +528,31 @@ def main():
             per_kernel[kname] = {"ms": round(ms, 3),
                                  "algorithmic_GBps": None if gbs is None else round(gbs, 1),
                                  "frac_of_hbm_peak": None if gbs is None else round(gbs / HBM_PEAK_GBS, 4)}
+        # the matrix kernels are bound by VALU issue, not by bytes: their fraction of THAT peak, where a PMC pass
+        # of these kernel sources is on record (SQ_INSTS_VALU = wave-instructions)
+        valu = None
+        for kname in ("k_verify_edit", "k_traceback"):
+            c = load_counters(args, n, R, kname, ["SQ_INSTS_VALU"])
+            if c and kname in avg and avg[kname] > 0:
+                rate = c["SQ_INSTS_VALU"] / (avg[kname] * 1e-3)
+                per_kernel[kname]["valu_wave_insts_per_step"] = c["SQ_INSTS_VALU"]
+                per_kernel[kname]["frac_of_valu_peak"] = round(rate / VALU_PEAK_WAVE_INSTS, 4)
+                if valu is None:
+                    valu = {"bound": "valu", "kernel": kname, "achieved": round(rate / 1e9, 1), "peak": round(VALU_PEAK_WAVE_INSTS / 1e9, 1),
+                            "unit": "G wave-instructions/s", "frac": round(rate / VALU_PEAK_WAVE_INSTS, 4),
+                            "note": "SQ_INSTS_VALU per step (rocprofv3 --pmc pass of these kernel sources) / HIP-event time; peak = 256 CUs x 4 SIMD-32 "
+                                    "x 2.4 GHz / 2 cycles per wave64 instruction"}
         achieved = per_kernel[dominant]["algorithmic_GBps"] or 0.0
         traffic, traffic_source, traffic_note = load_traffic(args, n, R, dominant)
+        # lines, not bytes, are what scattered rank fetches cost (profiles/r03_fetch_calibration.txt): HBM lines moved per second
+        # by the dominant kernel against the rate at which the chip serves random 128-byte lines
+        line_rate = None
+        if traffic:
+            lr = traffic * 1e9 / 128.0 / (avg[dominant] * 1e-3)
+            line_rate = {"achieved_Glines_s": round(lr / 1e9, 2), "ceiling_Glines_s": RANDOM_LINE_RATE / 1e9, "frac": round(lr / RANDOM_LINE_RATE, 4),
+                         "lines_per_expansion": round(traffic * 1e9 / 128.0 / max(cnt["DFS_EXPANSIONS"] if dominant == "k_dfs" else
+                                                                                   cnt["EXPANSIONS"] - cnt["DFS_EXPANSIONS"], 1), 3)
+                         if dominant in ("k_dfs", "k_partition") else None}
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "traffic_source": traffic_source, "kernel_src_sha": source_digest(),
@@ -508,6 +561,7 @@ def main():
                                    "batch's sub-batches run one after the other; in the timed steps the sub-batches "
                                    "overlap (busy ms per step there: see concurrent_ms)",
                     "concurrent_ms": {k: round(v, 3) for k, v in avg_concurrent.items()},
+                    "line_rate": line_rate, "valu": valu,
                     "per_kernel": per_kernel}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

@@ -22,7 +22,8 @@ def source_digest():  # the same digest bench.py computes: a profile only speaks
 
 
 line = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-steps_run = float(sys.argv[4]) if len(sys.argv) > 4 else 2.0
+steps_run = float(sys.argv[4]) if len(sys.argv) > 4 and not os.path.isdir(sys.argv[4]) else 2.0
+sq_dir = next((a for a in sys.argv[4:] if os.path.isdir(a)), None)  # the SQ_* pass (wave-instructions per kernel)
 out = {"workload": {k: line["config"][k] for k in ("genome_bp", "reads_per_gpu", "read_len", "k")},
        "kernel_src_sha": source_digest(),
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one pass each, bench.py --steps 1 --warmup 0 "
@@ -43,4 +44,16 @@ for d, name in ((sys.argv[2], "FETCH_SIZE"), (sys.argv[3], "WRITE_SIZE")):
         for k, v in agg.items():
             out["kernels"][k][name + "_KiB"] = round(v / steps_run, 1)
             out["kernels"][k]["dispatches_per_step"] = calls[k] / steps_run
+if sq_dir:
+    for f in glob.glob(sq_dir + "/**/*_counter_collection.csv", recursive=True):
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] not in ("SQ_INSTS_VALU", "SQ_INSTS_VMEM", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"):
+                continue
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+            if k.startswith("cmb::"):
+                agg[k[len("cmb::"):]][r["Counter_Name"]] += float(r["Counter_Value"])
+        for k, v in agg.items():
+            for c, x in v.items():
+                out["kernels"][k][c] = round(x / steps_run, 1)
 print(json.dumps(out, indent=1))

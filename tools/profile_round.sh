@@ -43,5 +43,5 @@ CMB_SERIAL_SUBBATCHES=1 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VA
 python3 $R/tools/pmc_summary.py /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE /tmp/prof_SQ > $OUT/pmc_summary.txt 2>&1
 # 3) the plain bench line (not under the profiler), then the per-kernel traffic table bench.py reads back
 cd $R && python3 bench.py $ARGS > $OUT/bench_line.json 2> $OUT/bench_stderr.log
-python3 $R/tools/pmc_traffic.py $OUT/bench_line.json /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE > $OUT/pmc_traffic.json
+python3 $R/tools/pmc_traffic.py $OUT/bench_line.json /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE /tmp/prof_SQ > $OUT/pmc_traffic.json
 ls -la $OUT
