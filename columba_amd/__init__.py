@@ -51,6 +51,7 @@ EXPORTS = [
     "cmb_move_create", "cmb_move_destroy", "cmb_move_device_bytes", "cmb_move_info", "cmb_move_complete_range", "cmb_move_rows",
     "cmb_move_extend_batch", "cmb_move_extend_bench", "cmb_move_locate_batch", "cmb_move_match_exact", "cmb_move_last_timings", "cmb_move_kmer_table",
     "cmb_move_layout_of", "cmb_move_create_empty", "cmb_move_device_arrays", "cmb_move_validate",
+    "cmb_batch_allow_unsupported", "cmb_batch_read_status",
     "cmb_move_match_batch", "cmb_move_batch_create", "cmb_move_batch_run", "cmb_move_batch_result_size", "cmb_move_batch_results",
     "cmb_move_batch_timings", "cmb_move_batch_destroy",
     "cmb_last_error", "cmb_version",
@@ -258,6 +259,8 @@ def lib():
         L.cmb_batch_sam.restype = C.c_int64
         L.cmb_batch_sam.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, u64]
         L.cmb_batch_filter_per_strand.argtypes = [vp, i32]
+        L.cmb_batch_allow_unsupported.argtypes = [vp, i32]
+        L.cmb_batch_read_status.argtypes = [vp, vp, C.POINTER(u32)]
         L.cmb_match_best.argtypes = [vp, vp, u32, u32, vp, vp, u32, C.POINTER(vp)]
         L.cmb_best_sizes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
         L.cmb_best_results.argtypes = [vp, vp, vp, u64, vp, u64, vp, vp, vp, vp]
@@ -666,6 +669,16 @@ class Batch:
         cnt = np.zeros(len(COUNTER_NAMES), np.uint64)
         _chk(lib().cmb_batch_results(self.h, _p(occs), occs.shape[0], _p(offs), _p(cnt)))
         return occs[:n.value], offs, dict(zip(COUNTER_NAMES, cnt.tolist()))
+
+    def allow_unsupported(self, on: bool = True):
+        """reads the device does not match (the reference's naive-backtracking fallback) are flagged instead of failing the run"""
+        _chk(lib().cmb_batch_allow_unsupported(self.h, int(on)))
+
+    def read_status(self) -> np.ndarray:
+        st = np.zeros(max(self.n_reads, 1), np.uint8)
+        n = C.c_uint32()
+        _chk(lib().cmb_batch_read_status(self.h, _p(st), C.byref(n)))
+        return st[:self.n_reads]
 
     def want_alignments(self, on: bool = True):
         _chk(lib().cmb_batch_want_alignments(self.h, int(on)))

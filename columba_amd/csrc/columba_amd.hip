@@ -545,6 +545,7 @@ struct cmb_batch {
     uint32_t nSlots = 0;
     std::vector<uint64_t> hostOffs;
     bool perStrand = false; // every strand filtered by itself (BEST mode: mapRead, searchstrategy.h:490-523)
+    bool allowUnsupported = false; // cmb_batch_allow_unsupported: reads the device path does not match are flagged, not fatal
     // alignments of the final occurrences (cmb_batch_want_alignments): CIGAR runs + sequence assignment
     bool wantAln = false;
     DevBuf<uint32_t> foutRead;
@@ -979,7 +980,7 @@ static int batchRunOne(cmb_batch* b) {
             HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             uint32_t flags = hcnt[3];
-            if (flags & FLAG_UNSUPPORTED_READ) {
+            if ((flags & FLAG_UNSUPPORTED_READ) && !b->allowUnsupported) {
                 // name the read: the caller has to drop it (k_parts marks such reads in psel)
                 std::string which;
                 if (b->psel.p && tasks) {
@@ -1583,6 +1584,38 @@ extern "C" int cmb_batch_timings(const cmb_batch* b, const char** names, float* 
     }
     return (int)n;
 }
+// Reads the device path does not match: not longer than the number of parts of the search scheme — the reference matches
+// those by naive backtracking (searchstrategy.cpp:148-152, :442-459; indexinterface.cpp:1055-1210).  By default one such read
+// fails cmb_batch_run with CMB_ERR_UNSUPPORTED (nothing is ever silently skipped); with cmb_batch_allow_unsupported(b, 1) the
+// run succeeds, their lists are empty and cmb_batch_read_status says which they are, so that the caller routes exactly those
+// reads to its own fallback (a Columba host: IndexInterface::approxMatchesNaive) and keeps the rest of the chunk.
+extern "C" int cmb_batch_allow_unsupported(cmb_batch* b, int on) {
+    if (!b) return fail(CMB_ERR_INVALID, "null argument");
+    b->allowUnsupported = on != 0;
+    for (cmb_batch* c : b->subs) c->allowUnsupported = on != 0;
+    return CMB_OK;
+}
+static uint32_t readStatusOne(const cmb_batch* b, uint8_t* status) {
+    uint32_t n = 0;
+    const uint32_t P = b->k ? b->hostStrat.numParts : 0;
+    for (uint32_t i = 0; i < b->nReads; i++) {
+        const uint64_t len = b->hostOffs[i + 1] - b->hostOffs[i];
+        const bool naive = b->k > 0 && (P >= len || P == 1);
+        if (status) status[i] = naive ? CMB_READ_NAIVE_FALLBACK : 0;
+        n += naive;
+    }
+    return n;
+}
+extern "C" int cmb_batch_read_status(const cmb_batch* b, uint8_t* status, uint32_t* n_flagged) {
+    if (!b) return fail(CMB_ERR_INVALID, "null argument");
+    uint32_t n = 0;
+    if (b->subs.empty()) n = readStatusOne(b, status);
+    else
+        for (size_t j = 0; j < b->subs.size(); j++) n += readStatusOne(b->subs[j], status ? status + b->subBound[j] : nullptr);
+    if (n_flagged) *n_flagged = n;
+    return CMB_OK;
+}
+
 extern "C" void cmb_batch_destroy(cmb_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->ix->device);

@@ -221,6 +221,8 @@ class SearchStrategy {
   public:
     SearchStrategy(const SearchStrategy&) = delete;
     virtual ~SearchStrategy() { cmb_strategy_destroy(h); }
+    // reads of the last matchApproxBatch chunk that the device did not match (indices into the chunk): see there
+    std::vector<size_t> needNaiveFallback;
 
     // the body of processChunk's loop for a whole chunk: result[i] = occurrences of reads[i]
     void matchApproxBatch(const std::vector<ReadBundle>& reads, length_t maxED, Counters& counters,
@@ -237,7 +239,19 @@ class SearchStrategy {
             cmb_batch* b;
             ~Guard() { cmb_batch_destroy(b); }
         } guard{b};
+        // reads the device does not match (not longer than the number of parts: the reference's naive-backtracking fallback,
+        // searchstrategy.cpp:148-152) do not fail the chunk: they come back with empty lists and are named in
+        // needNaiveFallback, for the host to hand to IndexInterface::approxMatchesNaive (indexinterface.cpp:1055)
+        check(cmb_batch_allow_unsupported(b, 1));
         check(cmb_batch_run(b));
+        needNaiveFallback.clear();
+        {
+            std::vector<uint8_t> status(reads.size() ? reads.size() : 1);
+            uint32_t flagged = 0;
+            check(cmb_batch_read_status(b, status.data(), &flagged));
+            for (size_t i = 0; flagged && i < reads.size(); i++)
+                if (status[i] & CMB_READ_NAIVE_FALLBACK) needNaiveFallback.push_back(i);
+        }
         uint64_t n = 0;
         check(cmb_batch_result_size(b, &n));
         std::vector<cmb_occ> occ(n ? n : 1);

@@ -206,3 +206,37 @@ def test_staged_chunks_stream_through_one_batch(big):
             os.environ.pop("CMB_SUBBATCHES", None)
         for w, g in zip(want, got):
             assert np.array_equal(w[0], g[0]) and np.array_equal(w[1], g[1]) and w[2] == g[2]
+
+
+@pytest.fixture(scope="module")
+def world():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    g, starts = synth.genome_rep(seed=11, n=1_000_000, scale=1.5)
+    ix = ib.build_index(g.tobytes(), seq_starts=starts, device="cuda")
+    return {"genome": g, "dev": ca.Index(ix)}
+
+
+def test_reads_that_need_the_naive_fallback_are_flagged_not_fatal(world):
+    """Reads not longer than the number of parts (searchstrategy.cpp:148-152): by default the run fails loudly and names the
+    read; with allow_unsupported the chunk is matched, those reads are flagged and everything else is unchanged"""
+    g = world["genome"]
+    reads = synth.sample_reads(g, 400, 150, seed=77)
+    mixed = reads[:100] + [b"ACG", b"ACGTA", b""] + reads[100:]
+    st = ca.SearchStrategy("multiple_opt", "edit", "dynamic")
+    with pytest.raises(ca.CmbError) as e:
+        ca.match_batch(world["dev"], st, 4, mixed)
+    assert e.value.code == ca.CMB_ERR_UNSUPPORTED and "read 100" in str(e.value)
+    b = ca.Batch(world["dev"], st, 4, mixed)
+    b.allow_unsupported()
+    b.run()
+    occ, offs, cnt = b.results()
+    status = b.read_status()
+    assert status.tolist() == [0] * 100 + [1, 1, 1] + [0] * 300
+    assert int(offs[100]) == int(offs[103])  # empty lists for the flagged reads
+    ref_occ, ref_offs, ref_cnt = ca.match_batch(world["dev"], st, 4, reads)
+    keep = np.r_[0:100, 103:403]
+    assert np.array_equal(np.diff(offs.astype(np.int64))[keep], np.diff(ref_offs.astype(np.int64)))
+    assert np.array_equal(occ, ref_occ)
+    assert cnt["NODE_COUNTER"] == ref_cnt["NODE_COUNTER"]
+    b.close()
