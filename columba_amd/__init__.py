@@ -51,7 +51,7 @@ EXPORTS = [
     "cmb_move_create", "cmb_move_destroy", "cmb_move_device_bytes", "cmb_move_info", "cmb_move_complete_range", "cmb_move_rows",
     "cmb_move_extend_batch", "cmb_move_extend_bench", "cmb_move_locate_batch", "cmb_move_match_exact", "cmb_move_last_timings", "cmb_move_kmer_table",
     "cmb_move_layout_of", "cmb_move_create_empty", "cmb_move_device_arrays", "cmb_move_validate",
-    "cmb_batch_allow_unsupported", "cmb_batch_read_status",
+    "cmb_batch_allow_unsupported", "cmb_batch_read_status", "cmb_trim_occurrence",
     "cmb_move_match_batch", "cmb_move_batch_create", "cmb_move_batch_run", "cmb_move_batch_result_size", "cmb_move_batch_results",
     "cmb_move_batch_timings", "cmb_move_batch_destroy",
     "cmb_last_error", "cmb_version",
@@ -259,6 +259,7 @@ def lib():
         L.cmb_batch_sam.restype = C.c_int64
         L.cmb_batch_sam.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, u64]
         L.cmb_batch_filter_per_strand.argtypes = [vp, i32]
+        L.cmb_trim_occurrence.argtypes = [vp, vp, u32, u32, i32, vp, vp, vp, u32, C.POINTER(u32), C.POINTER(i32)]
         L.cmb_batch_allow_unsupported.argtypes = [vp, i32]
         L.cmb_batch_read_status.argtypes = [vp, vp, C.POINTER(u32)]
         L.cmb_match_best.argtypes = [vp, vp, u32, u32, vp, vp, u32, C.POINTER(vp)]
@@ -958,13 +959,14 @@ class MoveBatch:
 
 def pair_chunk_sam(index: "Index", strategy: "SearchStrategy", max_distance: int, reads1, reads2, ids1, ids2, quals1, quals2, seq_names,
                    orientation: int = ORIENTATION_FR, max_frag: int = 500, min_frag: int = 0, discordant_allowed: bool = True,
-                   unmapped_records: bool = True, per_strand: bool = False):
+                   unmapped_records: bool = True, per_strand: bool = True):
     """A chunk of read pairs in ALL mode, end to end: both mates through the GPU matcher (one batch each, with alignments), then
     cmb_pair_sam per pair (SearchStrategy::pairSingleEndedMatchesAll on the mates' single-end results).  per_strand: the strands
     of a mate are filtered each by itself, as matchApproxPairedEndAll's mapRead does (searchstrategy.cpp:746-776,
-    searchstrategy.h:753-774), instead of together (matchApproxAllMap).  Occurrences that run
-    past the end of their sequence (cmb_aln.spans) take no part in the pairing.  Returns (SAM text, number of properly or
-    discordantly mapped pairs)."""
+    searchstrategy.h:753-774) — the default — instead of together (matchApproxAllMap; the view of pairSingleEndedMatchesAll).
+    Occurrences that run past the end of their sequence (cmb_aln.spans) are trimmed and verified again as assignSequence ->
+    findSeqName does (indexinterface.cpp:833-899: cmb_trim_occurrence) and paired with their trimmed coordinates, distance and
+    CIGAR; those for which that fails are dropped.  Returns (SAM text, number of properly or discordantly mapped pairs)."""
     per_mate = []
     for reads in (reads1, reads2):
         b = Batch(index, strategy, max_distance, reads=reads)
@@ -989,7 +991,18 @@ def pair_chunk_sam(index: "Index", strategy: "SearchStrategy", max_distance: int
                 o = ops[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])]
                 width = int(occ["end"][j]) - int(occ["begin"][j])
                 if a["spans"]:
-                    lst.append((None, 0, width, int(occ["begin"][j]), int(occ["distance"][j]), int(occ["strand"][j]), o))
+                    oc1 = np.array([tuple(occ[j])], dtype=OCC_DTYPE)
+                    al1 = np.array([tuple(a)], dtype=ALN_DTYPE)
+                    ops1 = np.zeros(2 * max_distance + 8, np.uint16)
+                    nops, found = C.c_uint32(), C.c_int32()
+                    pat = (rc if int(occ["strand"][j]) else seq).encode()
+                    _chk(lib().cmb_trim_occurrence(index.h, pat, len(pat), max_distance, METRIC["edit"], _p(oc1), _p(al1), _p(ops1), ops1.shape[0],
+                                                   C.byref(nops), C.byref(found)))
+                    if not found.value:
+                        continue  # NOT_FOUND: the occurrence takes no part in the pairing
+                    w1 = int(oc1["end"][0]) - int(oc1["begin"][0])
+                    lst.append((int(al1["seq_id"][0]), int(al1["seq_begin"][0]), int(al1["seq_begin"][0]) + w1, int(oc1["begin"][0]),
+                                int(oc1["distance"][0]), int(oc1["strand"][0]), ops1[:nops.value].copy()))
                 else:
                     lst.append((int(a["seq_id"]), int(a["seq_begin"]), int(a["seq_begin"]) + width, int(occ["begin"][j]),
                                 int(occ["distance"][j]), int(occ["strand"][j]), o))

@@ -2099,6 +2099,31 @@ static bool trimOccurrence(cmb_index* idx, const std::string& seq, uint32_t larg
 
 } // namespace
 
+// IndexInterface::findSeqName for ONE occurrence that runs over the end of its sequence (cmb_aln.spans == 1), for host layers
+// that build their own records (paired reads): FOUND_WITH_TRIMMING -> *found = 1 and occ / aln / CIGAR updated; NOT_FOUND -> 0.
+extern "C" int cmb_trim_occurrence(cmb_index* idx, const char* pattern, uint32_t plen, uint32_t largest_stratum, int metric, cmb_occ* occ,
+                                   cmb_aln* aln, uint16_t* cigar_ops, uint32_t ops_cap, uint32_t* n_ops, int* found) {
+    if (!idx || !pattern || !occ || !aln || !found) return fail(CMB_ERR_INVALID, "null argument");
+    try {
+        BestOcc o;
+        o.occ = *occ;
+        o.aln = *aln;
+        const bool ok = trimOccurrence(idx, std::string(pattern, plen), largest_stratum, metric, o, nullptr);
+        *found = ok ? 1 : 0;
+        if (ok) {
+            if (o.ops.size() > ops_cap) return fail(CMB_ERR_OVERFLOW, "room for the CIGAR operations of the trimmed occurrence");
+            *occ = o.occ;
+            *aln = o.aln;
+            aln->cigar_len = (uint16_t)o.ops.size();
+            for (size_t i = 0; i < o.ops.size() && cigar_ops; i++) cigar_ops[i] = o.ops[i];
+            if (n_ops) *n_ops = (uint32_t)o.ops.size();
+        }
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}
+
 // SAM text of a whole chunk in ALL mode: matchApproxAllMap D) -> SearchStrategy::generateOutputSingleEnd
 // (searchstrategy.cpp:530-533, :1824-1902) -> generateSE_SAM / generateSE_SAM_XATag (searchstrategy.h:1612-1641), from the
 // occurrences, CIGARs and sequence assignments the device produced (cmb_batch_want_alignments before cmb_batch_run).

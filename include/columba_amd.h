@@ -390,6 +390,14 @@ int cmb_verify_batch(cmb_index* idx, const char* pattern, uint32_t plen, const u
 int cmb_verify_window(cmb_index* idx, const char* pattern, uint32_t plen, uint32_t start, uint32_t end,
                       uint32_t max_ed, uint32_t min_ed, cmb_occ* out, uint64_t out_cap, uint64_t* n_out,
                       uint64_t* counters);
+/* IndexInterface::findSeqName (indexinterface.cpp:833-899) for one occurrence that runs over the end of its sequence (cmb_aln.spans
+ * == 1 after cmb_batch_alignments): trimmed to the sequence it mostly lies in and verified again inside that window, as the
+ * single-end record path (cmb_batch_sam) does.  pattern: the cleaned read of the occurrence's strand (its reverse complement for
+ * strand 1); largest_stratum: the distance the chunk was matched at.  *found = 1 (FOUND_WITH_TRIMMING): occ (begin, end, distance),
+ * aln (seq_id, seq_begin, spans = 2, cigar_len) and cigar_ops (*n_ops of them, at most 2 * largest_stratum + 3) are the trimmed
+ * occurrence's; *found = 0 (NOT_FOUND): the occurrence is to be dropped.  Edit distance only (Hamming: always NOT_FOUND). */
+int cmb_trim_occurrence(cmb_index* idx, const char* pattern, uint32_t plen, uint32_t largest_stratum, int metric, cmb_occ* occ,
+                        cmb_aln* aln, uint16_t* cigar_ops, uint32_t ops_cap, uint32_t* n_ops, int* found);
 /* IBitParallelED::findCIGAR (bitparallelmatrix.h:460-527) of one pattern against n text windows [begin, end) with given
  * distances: ops_out holds n x stride run-length operations (length << 2 | op, from the begin of the alignment),
  * n_ops_out[i] of them for window i; stride >= 2 * largest distance + 3 */

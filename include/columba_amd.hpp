@@ -25,6 +25,7 @@
 #include <array>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <stdexcept>
 #include <string>
@@ -284,7 +285,7 @@ class SearchStrategy {
     }
     // the SAM text of a chunk of read PAIRS in ALL mode: both mates matched single-ended (one batch each), then paired as
     // SearchStrategy::pairSingleEndedMatchesAll does (searchstrategy.cpp:1345-1399) with the records of generateSAMPairedEnd.
-    // orientation: CMB_ORIENTATION_*.  Occurrences that run past the end of their sequence take no part in the pairing.
+    // orientation: CMB_ORIENTATION_*.  Occurrences that run past the end of their sequence are trimmed as findSeqName does.
     template <class Record>
     std::string samOfChunkPairedAll(const std::vector<Record>& mates1, const std::vector<Record>& mates2,
                                     const std::vector<const char*>& seqNames, length_t maxED, uint32_t orientation, uint32_t maxFragSize,
@@ -308,6 +309,7 @@ class SearchStrategy {
                 ~Guard() { cmb_batch_destroy(b); }
             } guard{b};
             check(cmb_batch_want_alignments(b, 1));
+            check(cmb_batch_filter_per_strand(b, 1)); // (mapRead filters every strand by itself: searchstrategy.cpp:746-776)
             check(cmb_batch_run(b));
             uint64_t n = 0, nOps = 0;
             check(cmb_batch_result_size(b, &n));
@@ -325,25 +327,40 @@ class SearchStrategy {
         std::vector<char> buf;
         for (size_t i = 0; i < mates1.size(); i++) {
             std::vector<cmb_pair_occ> po[2];
+            std::vector<uint16_t> trimmedOps[2]; // (reserved up front: the records point into it)
             std::vector<char> id[2], sq[2], rc[2], rq[2];
             cmb_pair_read rd[2];
             for (int m = 0; m < 2; m++) {
                 const Record& r = (*in[m])[i];
                 id[m].resize(r.seqID.size() + 1), sq[m].resize(r.read.size() + 1), rc[m].resize(r.read.size() + 1), rq[m].resize(r.qual.size() + 1);
                 check(cmb_read_prepare(r.seqID.c_str(), r.read.c_str(), r.qual.c_str(), id[m].data(), sq[m].data(), rc[m].data(), rq[m].data()));
+                trimmedOps[m].clear();
+                trimmedOps[m].reserve((M[m].oo[i + 1] - M[m].oo[i]) * (2 * (size_t)maxED + 8));
                 for (uint64_t j = M[m].oo[i]; j < M[m].oo[i + 1]; j++) {
-                    const cmb_occ& o = M[m].occ[j];
-                    const cmb_aln& a = M[m].aln[j];
+                    cmb_occ o = M[m].occ[j];
+                    cmb_aln a = M[m].aln[j];
+                    const uint16_t* ops = M[m].ops.data() + a.cigar_off;
+                    uint32_t nOpsJ = a.cigar_len;
+                    if (a.spans == 1) { // runs past the end of its sequence: assignSequence -> findSeqName trims it (indexinterface.cpp:833-899)
+                        const size_t at = trimmedOps[m].size();
+                        trimmedOps[m].resize(at + 2 * (size_t)maxED + 8);
+                        int found = 0;
+                        const char* pat = o.strand ? rc[m].data() : sq[m].data();
+                        check(cmb_trim_occurrence(index.handle(), pat, (uint32_t)strlen(pat), maxED, CMB_METRIC_EDIT, &o, &a, trimmedOps[m].data() + at,
+                                                  (uint32_t)(2 * maxED + 8), &nOpsJ, &found));
+                        if (!found) continue; // NOT_FOUND: takes no part in the pairing
+                        ops = trimmedOps[m].data() + at;
+                    }
                     const uint32_t width = o.end - o.begin;
                     cmb_pair_occ p;
-                    p.seq_id = a.spans ? 0xFFFFFFFFu : a.seq_id;
-                    p.begin = a.spans ? 0 : a.seq_begin;
+                    p.seq_id = a.seq_id;
+                    p.begin = a.seq_begin;
                     p.end = p.begin + width;
                     p.index_begin = o.begin;
                     p.distance = o.distance;
                     p.strand = o.strand;
-                    p.cigar_ops = M[m].ops.data() + a.cigar_off;
-                    p.n_ops = a.cigar_len;
+                    p.cigar_ops = ops;
+                    p.n_ops = nOpsJ;
                     po[m].push_back(p);
                 }
                 rd[m] = cmb_pair_read{id[m].data(), sq[m].data(), rc[m].data(), r.qual.c_str(), rq[m].data(), po[m].data(), (uint32_t)po[m].size()};

@@ -613,6 +613,48 @@ def test_paired_end_chunk_end_to_end(world):
     assert right >= 0.85 * n, right
     # the strands of a mate filtered each by itself (matchApproxPairedEndAll's mapRead): the same proper pairs here
     text2, mapped2 = ca.pair_chunk_sam(world["dev"], strat, 2, reads1, reads2, ids1, ids2, quals, quals, names, ca.ORIENTATION_FR, 600, 100,
-                                       True, True, per_strand=True)
+                                       True, True, per_strand=False)  # (the joint filter of pairSingleEndedMatchesAll's view)
     prop = lambda t: sorted(ln for ln in t.splitlines() if int(ln.split("\t")[1]) & 2 and not int(ln.split("\t")[1]) & 256)
     assert mapped2 == mapped and prop(text2) == prop(text)
+
+
+def test_paired_mates_across_sequence_boundaries_are_trimmed(world):
+    """A mate whose only hit runs over the end of its sequence: assignSequence -> findSeqName trims it (indexinterface.cpp:833-899,
+    FOUND_WITH_TRIMMING: new range, distance, CIGAR) and the pair forms with the trimmed mate — the same record the single-end
+    path (cmb_batch_sam) writes for that read; it is not reported unmapped."""
+    g = world["genome"]
+    starts = world["dev"].seq_starts()
+    assert len(starts) >= 3
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    names = [f"seq{i}" for i in range(len(starts) - 1)]
+    L, k = 100, 2
+    reads1, reads2, want = [], [], []
+    for j, over in enumerate((1, 2, 2, 1)):          # characters of mate 2's window that lie beyond the boundary
+        b = int(starts[1 + j % (len(starts) - 2)])   # a boundary between two sequences
+        frag_end = b + over                          # the fragment ends `over` characters into the next sequence
+        p0 = frag_end - 300
+        f = g[p0:frag_end].tobytes()
+        reads1.append(f[:L])
+        reads2.append(f[-L:].translate(comp)[::-1])
+        want.append((int(np.searchsorted(starts, p0, side="right") - 1), p0, over))
+    ids1 = [f"@s{i}/1" for i in range(len(reads1))]
+    ids2 = [f"@s{i}/2" for i in range(len(reads1))]
+    quals = ["I" * L] * len(reads1)
+    strat = ca.SearchStrategy("multiple_opt", "edit", "dynamic")
+    text, mapped = ca.pair_chunk_sam(world["dev"], strat, k, reads1, reads2, ids1, ids2, quals, quals, names, ca.ORIENTATION_FR, 600, 100, True, True)
+    assert mapped == len(reads1), text
+    # the single-end records of the mates that cross the boundary (trimmed by cmb_batch_sam)
+    b2 = ca.Batch(world["dev"], strat, k, reads2)
+    b2.want_alignments()
+    b2.run()
+    se = [ln.split("\t") for ln in b2.sam([i[1:] for i in ids2], quals, names).splitlines() if not int(ln.split("\t")[1]) & 256]
+    assert len(se) == len(reads2)  # (one primary record per read, in read order)
+    b2.close()
+    for i, (sid, p0, over) in enumerate(want):
+        recs = [ln.split("\t") for ln in text.splitlines() if ln.split("\t")[0].split("/")[0] == f"s{i}"]
+        prim = [f for f in recs if int(f[1]) & 2 and not int(f[1]) & 256]
+        assert len(prim) == 2, recs
+        m2 = [f for f in prim if int(f[1]) & 128][0]
+        s2 = se[i]
+        assert (m2[2], m2[3], m2[5]) == (s2[2], s2[3], s2[5]), (m2, s2)   # sequence, position and CIGAR of the trimmed mate
+        assert m2[2] == names[sid] and "S" not in m2[5]
