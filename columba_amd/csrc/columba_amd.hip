@@ -317,6 +317,20 @@ extern "C" int cmb_index_create_empty(const cmb_index_layout* L, const uint32_t*
         ix->saSparseness = L->sa_sparseness;
         ArrayRef a[CMB_DEV_ARRAYS];
         indexArrays(ix.get(), a);
+        {   // the sizes must be those cmb_index_create gives an index of this text length (a kernel indexes them by position)
+            const uint64_t n = L->text_length, rankBytes = ((n + 1) / RANK_BLOCK + 1) * 2 * sizeof(uint4);
+            if (L->sa_sparseness == 0 || (L->sa_sparseness & (L->sa_sparseness - 1)))
+                return fail(CMB_ERR_INVALID, "index layout: suffix array sparseness must be a power of two");
+            if (L->bytes[0] != rankBytes || L->bytes[1] != rankBytes)
+                return fail(CMB_ERR_INVALID, "index layout: rank blocks do not have the size of this text length");
+            if (L->bytes[2] < ((n + L->sa_sparseness - 1) / L->sa_sparseness) * sizeof(uint32_t))
+                return fail(CMB_ERR_INVALID, "index layout: fewer suffix array samples than text length / sparseness");
+            if (L->bytes[3] < n) return fail(CMB_ERR_INVALID, "index layout: text shorter than the text length");
+            if (L->bytes[4] != 0 && L->bytes[4] < (n + 15) / 16 * sizeof(uint32_t))
+                return fail(CMB_ERR_INVALID, "index layout: 2-bit text shorter than the text length");
+            if (L->bytes[5] != (sizeof(uint4) << (2 * L->kmer_size)))
+                return fail(CMB_ERR_INVALID, "index layout: k-mer table does not have 4^k entries");
+        }
         uint64_t total = 0;
         for (int i = 0; i < CMB_DEV_ARRAYS; i++) {
             if (L->bytes[i] % a[i].elem) return fail(CMB_ERR_INVALID, "index layout: array size is not a whole number of elements");

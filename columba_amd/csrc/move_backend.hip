@@ -587,6 +587,11 @@ extern "C" int cmb_move_validate(cmb_move_index* idx) {
         MV_HIPCHK(hipGetLastError());
         uint32_t h[4];
         MV_HIPCHK(hipMemcpy(h, flags.p, sizeof(h), hipMemcpyDeviceToHost));
+        if (idx->hasLocate) { // plcpAt reads plcpSum[rank - 1]: position 0 must be a PLCP run start (cmb_move_create checks the same)
+            uint64_t first = ~0ull;
+            if (idx->plcpPos.count) MV_HIPCHK(hipMemcpy(&first, idx->plcpPos.pos.p, sizeof(first), hipMemcpyDeviceToHost));
+            if (first != 0) return failWith(CMB_ERR_INVALID, "inconsistent move index arrays (the PLCP run starts do not begin at position 0)");
+        }
         if (h[0] || h[1] || h[2] || h[3])
             return failWith(CMB_ERR_INVALID, "inconsistent move index arrays (" + std::to_string(h[0]) + " / " + std::to_string(h[1]) + " table rows, " +
                                                  std::to_string(h[2]) + " locate entries, " + std::to_string(h[3]) + " directory entries)");

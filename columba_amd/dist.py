@@ -65,8 +65,19 @@ def broadcast_device_index(index, rank: int, device: int = 0):
     for t in index.device_tensors():
         if t is not None:
             dist.broadcast(t, src=0)
+    # every replica runs the consistency probe of cmb_index_create on what arrived (a truncated or mixed-up transfer would
+    # otherwise hang the first locate) — and all ranks learn the outcome before any of them enters the next collective
+    err = ""
     if rank != 0:
-        index.validate()   # (a truncated or mixed-up transfer would otherwise hang the first locate)
+        try:
+            index.validate()
+        except Exception as e:  # noqa: BLE001
+            err = str(e)
+    errs = [None] * dist.get_world_size()
+    dist.all_gather_object(errs, err)
+    bad = [(r, e) for r, e in enumerate(errs) if e]
+    if bad:
+        raise RuntimeError("index replica failed validation on rank(s) " + ", ".join(f"{r}: {e}" for r, e in bad))
     return index
 
 
