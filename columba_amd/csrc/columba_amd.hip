@@ -495,13 +495,13 @@ extern "C" int cmb_strategy_export_partition(const cmb_strategy* s, uint32_t k, 
                                              double* begins, uint32_t cap, uint32_t* kmer_cutoff) {
     if (!s) return fail(CMB_ERR_INVALID, "null argument");
     try {
-        const DevStrategyK d = s->flatten(k);
-        const uint32_t P = d.numParts;
+        const PartitionParams d = s->partitionFor(k);
+        const uint32_t P = (uint32_t)d.weights.size();
         if (P > cap) return fail(CMB_ERR_OVERFLOW, "output arrays too small");
         for (uint32_t i = 0; i + 2 < P && seeding; i++) seeding[i] = d.seeding[i];
         for (uint32_t i = 0; i < P && weights; i++) weights[i] = d.weights[i];
         for (uint32_t i = 0; i + 1 < P && begins; i++) begins[i] = d.begins[i];
-        if (kmer_cutoff) *kmer_cutoff = d.kmerCutOff;
+        if (kmer_cutoff) *kmer_cutoff = s->kmerCutOff;
         return CMB_OK;
     } catch (const std::exception& e) {
         return fail(CMB_ERR_INVALID, e.what());

@@ -170,6 +170,39 @@ struct cmb_strategy {
     std::map<uint32_t, std::vector<cmb::HostScheme>> schemes; // k -> alternatives (dynamic selection)
     std::map<uint32_t, cmb::PartitionParams> params;          // k -> overrides
 
+    // partitioning parameters for distance k as the host sees them (any number of parts): base-class defaults
+    // (searchstrategy.h:245, :283, :1825) overridden by the strategy's own
+    cmb::PartitionParams partitionFor(uint32_t k) const {
+        using namespace cmb;
+        auto it = schemes.find(k);
+        if (it == schemes.end() || it->second.empty())
+            throw std::runtime_error("the search strategy does not support distance " + std::to_string(k));
+        const int P = (int)it->second.front().numParts();
+        PartitionParams out;
+        for (int i = 1; i < P - 1; i++) out.seeding.push_back(i * (1.0 / (P - 1)));
+        out.weights.assign(P, 1);
+        out.weights[0] = 2;
+        out.weights[P - 1] = 2;
+        for (int i = 1; i < P; i++) out.begins.push_back(i * (1.0 / P));
+        auto pp = params.find(k);
+        if (pp != params.end()) {
+            const auto& q = pp->second;
+            if (!q.seeding.empty()) {
+                if ((int)q.seeding.size() != P - 2) throw std::runtime_error("wrong number of seeding positions");
+                out.seeding = q.seeding;
+            }
+            if (!q.weights.empty()) {
+                if ((int)q.weights.size() != P) throw std::runtime_error("wrong number of weights");
+                out.weights = q.weights;
+            }
+            if (!q.begins.empty()) {
+                if ((int)q.begins.size() != P - 1) throw std::runtime_error("wrong number of static positions");
+                out.begins = q.begins;
+            }
+        }
+        return out;
+    }
+
     // flatten everything matchWithSearches needs for distance k
     cmb::DevStrategyK flatten(uint32_t k) const {
         using namespace cmb;
@@ -178,6 +211,9 @@ struct cmb_strategy {
             throw std::runtime_error("the search strategy does not support distance " + std::to_string(k));
         const auto& alts = it->second;
         if (alts.size() > (size_t)MAXSCH) throw std::runtime_error("too many alternative schemes");
+        if (alts.front().numParts() > (uint32_t)MAXP)
+            throw std::runtime_error("search schemes with more than " + std::to_string(MAXP) + " parts (" + std::to_string(k) +
+                                     " errors) cannot be run on the device: its tables hold " + std::to_string(MAXP) + " parts");
         DevStrategyK d{};
         d.metric = (uint8_t)metric;
         d.partition = (uint8_t)partition;
@@ -231,9 +267,10 @@ inline HostScheme schemeFromRows(uint32_t k, std::initializer_list<const char*> 
         std::string a, b, c;
         ss >> a >> b >> c;
         HostSearch s;
-        for (char ch : a) s.pi.push_back(ch - '0');
-        for (char ch : b) s.L.push_back(ch - '0');
-        for (char ch : c) s.U.push_back(ch - '0');
+        auto val = [](char ch) -> uint32_t { return ch >= 'a' ? (uint32_t)(ch - 'a' + 10) : (uint32_t)(ch - '0'); }; // (a = 10 ...)
+        for (char ch : a) s.pi.push_back(val(ch));
+        for (char ch : b) s.L.push_back(val(ch));
+        for (char ch : c) s.U.push_back(val(ch));
         s.sIdx = idx++;
         sch.searches.push_back(s);
     }
@@ -275,6 +312,57 @@ inline HostScheme minU(uint32_t k) {
                                   "32104567 01133333 01337777", "45673210 00000004 01337777", "54673210 01111115 01337777",
                                   "67543210 00022226 01337777", "76543210 01133337 01337777"});
     default: throw std::runtime_error("minU schemes exist for 1 to 7 errors");
+    }
+}
+
+// ColumbaSearchStrategy's greedy schemes for 8 .. 13 errors (searchstrategy.h:3417-3658: ED8 .. ED13; k + 1 parts, k + 1
+// searches; digits beyond 9 are written a, b, c, d).  The rows are the reference's data files search_schemes/pigeon_adapted/<k>/
+// searches.txt (tools/gen_greedy_schemes.py), which hold the same tables as the class source.
+inline HostScheme greedy(uint32_t k) {
+    switch (k) {
+    case 8:
+        return schemeFromRows(8, {"012345678 012345678 023578888", "102345678 001234567 014578888",
+                                  "210345678 000001234 012678888", "321045678 000112345 013378888",
+                                  "432105678 000023456 013448888", "543210678 000000012 012555888",
+                                  "654321078 000000123 012566688", "765432108 000000000 012377778",
+                                  "876543210 000000001 012388888"});
+    case 9:
+        return schemeFromRows(9, {"0123456789 0000000000 0123499999", "1234567890 0000000012 0123888889",
+                                  "2345678910 0000000001 0123777799", "3456789210 0000001234 0126666999",
+                                  "4567893210 0000000123 0125559999", "5678943210 0000345678 0144499999",
+                                  "6789543210 0000012345 0133799999", "7896543210 0023456789 0225799999",
+                                  "8976543210 0001123456 0135799999", "9876543210 0112234567 0135799999"});
+    case 10:
+        return schemeFromRows(10, {"0123456789a 0123456789a 023579aaaaa", "1023456789a 00123456789 014579aaaaa",
+                                  "2103456789a 00000123456 012679aaaaa", "3210456789a 00011234567 013379aaaaa",
+                                  "4321056789a 00002345678 013449aaaaa", "5432106789a 00000001234 012555aaaaa",
+                                  "6543210789a 00000012345 0125666aaaa", "7654321089a 00000000012 01237777aaa",
+                                  "8765432109a 00000000123 012388888aa", "9876543210a 00000000000 0123499999a",
+                                  "a9876543210 00000000001 01234aaaaaa"});
+    case 11:
+        return schemeFromRows(11, {"0123456789ab 000000000000 012345bbbbbb", "123456789ab0 000000000012 01234aaaaaab",
+                                  "23456789ab10 000000000001 0123499999bb", "3456789ab210 000000001234 012388888bbb",
+                                  "456789ab3210 000000000123 01237777bbbb", "56789ab43210 000000123456 0125666bbbbb",
+                                  "6789ab543210 000000012345 012555bbbbbb", "789ab6543210 000023456789 013449bbbbbb",
+                                  "89ab76543210 000112345678 013379bbbbbb", "9ab876543210 000001234567 012679bbbbbb",
+                                  "ab9876543210 00123456789a 014579bbbbbb", "ba9876543210 0123456789ab 023579bbbbbb"});
+    case 12:
+        return schemeFromRows(12, {"0123456789abc 0123456789abc 023579bcccccc", "1023456789abc 00123456789ab 014579bcccccc",
+                                  "2103456789abc 0000012345678 012679bcccccc", "3210456789abc 0001123456789 013379bcccccc",
+                                  "4321056789abc 000023456789a 013449bcccccc", "5432106789abc 0000000123456 012555bcccccc",
+                                  "6543210789abc 0000001234567 0125666cccccc", "7654321089abc 0000000001234 01237777ccccc",
+                                  "8765432109abc 0000000012345 012388888cccc", "9876543210abc 0000000000012 0123499999ccc",
+                                  "a9876543210bc 0000000000123 01234aaaaaacc", "ba9876543210c 0000000000000 012345bbbbbbc",
+                                  "cba9876543210 0000000000001 012345ccccccc"});
+    case 13:
+        return schemeFromRows(13, {"0123456789abcd 00000000000000 0123456ddddddd", "123456789abcd0 00000000000012 012345cccccccd",
+                                  "23456789abcd10 00000000000001 012345bbbbbbdd", "3456789abcd210 00000000001234 01234aaaaaaddd",
+                                  "456789abcd3210 00000000000123 0123499999dddd", "56789abcd43210 00000000123456 012388888ddddd",
+                                  "6789abcd543210 00000000012345 01237777dddddd", "789abcd6543210 00000012345678 0125666ddddddd",
+                                  "89abcd76543210 00000001234567 012555bddddddd", "9abcd876543210 000023456789ab 013449bddddddd",
+                                  "abcd9876543210 0001123456789a 013379bddddddd", "bcda9876543210 00000123456789 012679bddddddd",
+                                  "cdba9876543210 00123456789abc 014579bddddddd", "dcba9876543210 0123456789abcd 023579bddddddd"});
+    default: throw std::runtime_error("the greedy schemes exist for 8 to 13 errors");
     }
 }
 
@@ -361,12 +449,13 @@ inline void fillNamed(cmb_strategy& st, const std::string& name) {
         for (uint32_t k = 1; k <= 7; k++) st.schemes[k] = {minU(k)};
     } else if (name == "columba") {
         // `-S columba`, the CLI default: DynamicColumbaStrategy (searchstrategy.h:3666-3736) = for every k the scheme of
-        // ColumbaSearchStrategy (minU up to 7 errors; the greedy schemes for 8..13 errors need more parts than the
-        // device tables hold and are not built in) and its mirror image (MultipleSchemes ctor, :2468-2477), then the
-        // "middle" schemes for k = 2, 4, 6 (+ the mirror of the k = 6 one); base-class partition defaults.
+        // ColumbaSearchStrategy (minU up to 7 errors, the greedy schemes for 8 .. 13 errors) and its mirror image
+        // (MultipleSchemes ctor, :2468-2477), then the "middle" schemes for k = 2, 4, 6 (+ the mirror of the k = 6 one);
+        // base-class partition defaults.  (The tables for 8 .. 13 errors can be described, exported and checked; a batch
+        // at those distances is refused at creation: the device tables hold MAXP parts and the in-text matrix 7 errors.)
         st.kmerCutOff = 20;
-        for (uint32_t k = 1; k <= 7; k++) {
-            const HostScheme m = minU(k);
+        for (uint32_t k = 1; k <= 13; k++) {
+            const HostScheme m = k <= 7 ? minU(k) : greedy(k);
             st.schemes[k] = {m, mirrored(m)};
         }
         st.schemes[2].push_back(schemeFromRows(2, {"210 011 022", "120 000 012", "012 002 012"}));

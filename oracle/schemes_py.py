@@ -112,9 +112,14 @@ MINU["schemes"][1] = [[([0, 1], [0, 0], [0, 1]), ([1, 0], [0, 0], [0, 1])]]  # s
 
 
 def _columba():
-    # DynamicColumbaStrategy::createDynamicColumbaStrategy (searchstrategy.h:3720-3735); minU part only (k <= 7)
+    # DynamicColumbaStrategy::createDynamicColumbaStrategy (searchstrategy.h:3720-3735): minU up to 7 errors, the greedy schemes
+    # of ColumbaSearchStrategy for 8 .. 13 (:3417-3658 = the data files search_schemes/pigeon_adapted/<k>)
     spec = {"kmer_cutoff": 20, "schemes": {}}
     for k, (sch,) in MINU["schemes"].items():
+        spec["schemes"][k] = [sch, mirror(sch)]
+    greedy = load_custom_dir("pigeon_adapted")["schemes"]
+    for k in range(8, 14):
+        (sch,) = greedy[k]
         spec["schemes"][k] = [sch, mirror(sch)]
     mid = {2: MULTIPLE_OPT["schemes"][2][1], 4: MULTIPLE_OPT["schemes"][4][1], 6: MULTIPLE_OPT["schemes"][6][1]}
     # getMidSearch2 / 4 / 6 (searchstrategy.h:3669-3706) — checked against these data files in the tests

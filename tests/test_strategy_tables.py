@@ -122,6 +122,24 @@ def test_columba_default_strategy_assembly():
         assert st.scheme(k, 2) == g[4] and st.describe(k)[2][2] == g[2]
     g6 = GOLDEN[_file_key("multiple_opt", "6", "scheme2.txt")]
     assert st.scheme(6, 3) == g6[5] and st.describe(6)[2][3] == g6[3]
+    # 8 .. 13 errors: ColumbaSearchStrategy's greedy schemes (searchstrategy.h:3417-3658) and their mirror images — the tables the
+    # reference ships as search_schemes/pigeon_adapted/<k>, as its own reader parsed and mirrored them
+    for k in range(8, 14):
+        g = GOLDEN[_file_key("pigeon_adapted", str(k), "searches.txt")]
+        assert st.describe(k) == (2, k + 1, [g[2], g[3]])
+        assert st.scheme(k, 0) == g[4] and st.scheme(k, 1) == g[5]
+    assert not st.supports(14) and not st.supports(0)
+    if os.path.isdir("/root/reference/src"):   # (build container: the class source holds the same tables as the data files)
+        import re
+        src = open("/root/reference/src/searchstrategy.h").read()
+        blk = src[src.index("class ColumbaSearchStrategy"):src.index("class DynamicColumbaStrategy")]
+        nums = lambda t: [int(x) for x in t.split(",")]
+        found = re.findall(r"makeSearch\(\s*\{([^}]*)\},\s*\{([^}]*)\},\s*\{([^}]*)\}", blk)
+        by_k = {}
+        for a, b, c in found:
+            by_k.setdefault(len(nums(a)) - 1, []).append((nums(a), nums(b), nums(c)))
+        for k in range(8, 14):
+            assert by_k[k] == st.scheme(k, 0), k
 
 
 def test_custom_dir_with_dynamic_selection():
