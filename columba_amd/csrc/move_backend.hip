@@ -666,9 +666,7 @@ extern "C" int cmb_move_batch_create(cmb_move_index* idx, const cmb_strategy* st
         b->metric = st->metric;
         b->kmerSize = kmer_size;
         if (max_distance > 0) {
-            if (st->metric != CMB_METRIC_EDIT)
-                return failWith(CMB_ERR_UNSUPPORTED, "Hamming distance on the b-move index is not implemented (edit distance and exact matching are)");
-            if (max_distance > MX_MAX_ED) return failWith(CMB_ERR_UNSUPPORTED, "more than 10 errors need the 128-bit in-index matrix");
+            if (st->metric == CMB_METRIC_EDIT && max_distance > MX_MAX_ED) return failWith(CMB_ERR_UNSUPPORTED, "more than 10 errors need the 128-bit in-index matrix");
             try {
                 b->hostStrat = st->flatten(max_distance);
             } catch (const std::exception& e) {
@@ -845,7 +843,56 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                                                  "positions of this search strategy at this read length");
             if (hcnt[3] & FLAG_DFS_OVERFLOW) return failWith(CMB_ERR_INTERNAL, "task queue too small");
             const uint32_t nTasks = hcnt[5];
-            if (nTasks) {
+            if (nTasks && b->metric != CMB_METRIC_EDIT) {
+                // ---- Hamming distance: the frontier without a matrix (k_mvs_hbfs), one row per pass
+                tm.begin();
+                const uint32_t maxPass = b->maxLen + 2 * MAXP + 16;
+                constexpr uint32_t PU = MvTraits::PAIR_U4;
+                if (!b->qCap) b->qCap = (getenv("CMB_TEST_SMALL_POOLS") ? 0 : (size_t)nReads * 8) + 1024;
+                b->qCap = std::max<size_t>(b->qCap, (size_t)nTasks + 1024);
+                for (int j = 0; j < 2; j++)
+                    if (b->Q[j].n < (PU + 1) * b->qCap) b->Q[j].alloc((PU + 1) * b->qCap);
+                const size_t cntWords = (size_t)maxPass + 2;
+                if (b->bfsCnt.n < cntWords) b->bfsCnt.alloc(cntWords);
+                if (b->blockCnt.n < (size_t)BFS_GRID * 4) b->blockCnt.alloc((size_t)BFS_GRID * 4);
+                MV_HIPCHK(hipMemsetAsync(b->bfsCnt.p, 0, cntWords * sizeof(uint32_t), s));
+                MV_HIPCHK(hipMemsetAsync(b->blockCnt.p, 0, (size_t)BFS_GRID * 4 * sizeof(unsigned long long), s));
+                MvHbfsBufs H{};
+                H.Q[0] = b->Q[0].p;
+                H.Q[1] = b->Q[1].p;
+                H.qCap = (uint32_t)std::min<size_t>(b->Q[0].n / (PU + 1), 0xFFFFFFF0u);
+                H.nq = b->bfsCnt.p;
+                H.blockCnt = b->blockCnt.p;
+                H.fmX = b->fm.p;
+                hipLaunchKernelGGL(k_mvs_hbfs<true>, dim3(std::min<uint32_t>((nTasks + 255) / 256, BFS_GRID)), dim3(256), 0, s, ix->d, b->strat.p, H, 0u,
+                                   b->tasks.p, nTasks, b->maxLen, b->seq.p, b->parts.p, q);
+                std::vector<uint32_t> hc(cntWords);
+                uint32_t pass = 0, peakQ = 0;
+                bool drained = false;
+                while (!drained && pass < maxPass) {
+                    const uint32_t upTo = std::min(pass + 16u, maxPass);
+                    for (; pass < upTo; pass++)
+                        hipLaunchKernelGGL(k_mvs_hbfs<false>, dim3(BFS_GRID), dim3(256), 0, s, ix->d, b->strat.p, H, pass, (const MvTask*)nullptr, 0u,
+                                           b->maxLen, b->seq.p, b->parts.p, q);
+                    MV_HIPCHK(hipMemcpyAsync(hc.data(), b->bfsCnt.p, cntWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    MV_HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
+                    MV_HIPCHK(hipStreamSynchronize(s));
+                    if (hcnt[3] & BFS_STOP) break;
+                    drained = hc[pass] == 0;
+                }
+                for (uint32_t p2 = 0; p2 <= pass && p2 < cntWords; p2++) peakQ = std::max(peakQ, hc[p2]);
+                MvBufs Bf{};
+                Bf.blockCnt = b->blockCnt.p;
+                hipLaunchKernelGGL(k_mvs_finish, dim3(1), dim3(256), 0, s, Bf, q);
+                tm.end("k_dfs");
+                MV_HIPCHK(hipGetLastError());
+                if (hcnt[3] & (FLAG_BFS_Q | FLAG_FMOCC_OVERFLOW)) {
+                    if (hcnt[3] & FLAG_BFS_Q) b->qCap = std::max<size_t>(2 * b->qCap, (size_t)peakQ + peakQ / 4);
+                    if (hcnt[3] & FLAG_FMOCC_OVERFLOW) b->fm.alloc(std::max<size_t>(2 * b->fm.n, (size_t)hcnt[1] + hcnt[1] / 4 + 1024));
+                    continue;
+                }
+                if (!drained) return failWith(CMB_ERR_INTERNAL, "frontier search did not finish within its pass bound");
+            } else if (nTasks) {
                 tm.begin();
                 const uint32_t maxPass = 2 * b->maxLen + 8 * MAXP + 64;
                 if (!b->qCap) {
@@ -998,7 +1045,8 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
             if (b->sortTmp.n < tb) b->sortTmp.alloc(tb + tb / 4);
             MV_HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->sortTmp.p, tb, b->keysA.p, b->keysB.p, b->vals.p, b->valsB.p, (int)totalPos, 0, 64, s));
             MV_HIPCHK(hipMemsetAsync(b->readCnt.p, 0, ((size_t)nReads + 1) * sizeof(uint64_t), s));
-            hipLaunchKernelGGL(k_mvs_filter<false>, dim3(gridFor(nReads)), dim3(256), 0, s, b->keysB.p, b->valsB.p, totalPos, nReads, b->k, b->readCnt.p,
+            const uint32_t window = b->metric == CMB_METRIC_EDIT ? b->k : 0u; // (getTextOccHamming, indexinterface.cpp:1331-1371: no redundancy filter)
+            hipLaunchKernelGGL(k_mvs_filter<false>, dim3(gridFor(nReads)), dim3(256), 0, s, b->keysB.p, b->valsB.p, totalPos, nReads, window, b->readCnt.p,
                                (const uint64_t*)nullptr, (MoveOccOut*)nullptr);
             tb = 0;
             MV_HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, b->readCnt.p, b->readOff.p, (int)(nReads + 1), s));
@@ -1008,7 +1056,7 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
             MV_HIPCHK(hipStreamSynchronize(s));
             if (b->out.n < nOut) b->out.alloc(nOut + nOut / 4 + 256);
             if (nOut)
-                hipLaunchKernelGGL(k_mvs_filter<true>, dim3(gridFor(nReads)), dim3(256), 0, s, b->keysB.p, b->valsB.p, totalPos, nReads, b->k, b->readCnt.p,
+                hipLaunchKernelGGL(k_mvs_filter<true>, dim3(gridFor(nReads)), dim3(256), 0, s, b->keysB.p, b->valsB.p, totalPos, nReads, window, b->readCnt.p,
                                    b->readOff.p, b->out.p);
         }
         tm.end("filter");

@@ -741,6 +741,140 @@ __global__ void k_mvs_finish(MvBufs B, Queues q) { // one block: per-block count
     }
 }
 
+// ------------------------------------------------------------------ Hamming distance: the frontier without a matrix
+// IndexInterface::recApproxMatchHamming (indexinterface.cpp:1211-1304, RUN_LENGTH_COMPRESSION branches: no in-text switch).  As
+// dev_bfs_hamming.hpp on this backend: a node is the range pair (5 planes) + one plane {rsId, scheme | search << 4 | idx << 9 |
+// row << 13, mismatches | startDepth << 8, pb | pe << 9}; a child that completes its part enters the next phase at once; a child
+// that completes the last part is an in-index occurrence.  One row per pass.
+struct MvHbfsBufs {
+    uint4* Q[2];
+    uint32_t qCap;
+    uint32_t* nq;                 // [pass]
+    unsigned long long* blockCnt; // [BFS_GRID][4]: children, expansions, -, table rows
+    MvFmRec* fmX;
+};
+template <bool START>
+__global__ void __launch_bounds__(256)
+k_mvs_hbfs(MoveDev ix, const DevStrategyK* __restrict__ stp, MvHbfsBufs B, uint32_t pass, const MvTask* __restrict__ tasks, uint32_t nTasks,
+           uint32_t maxLen, const uint8_t* __restrict__ seq, const PartOut* __restrict__ parts, Queues q) {
+    __shared__ uint32_t sh[4][5];
+    if (blockStopped(q)) return;
+    constexpr uint32_t PU = MvTraits::PAIR_U4;
+    const DevStrategyK& st = *stp;
+    const uint32_t outP = START ? 0u : pass + 1u;
+    const uint32_t nIn = START ? nTasks : min(B.nq[pass], B.qCap);
+    const uint4* __restrict__ Qi = B.Q[pass & 1u];
+    uint4* __restrict__ Qo = B.Q[outP & 1u];
+    const uint32_t qCap = B.qCap;
+    unsigned long long cNode = 0, cExp = 0, cRows = 0;
+    uint32_t flags = 0;
+    for (uint32_t base = blockIdx.x * 256u; base < nIn; base += gridDim.x * 256u) { // block-uniform trip count
+        const uint32_t i = base + threadIdx.x;
+        uint32_t kinds = 0; // 4 bits per child: 1 node, 3 in-index occurrence
+        MvPair ch[4];
+        uint32_t cMeta[4], cVd[4], cPw[4];
+        uint32_t rsId = 0, fmDepth = 0, nNode = 0, nFm = 0;
+        if (START) {
+            if (i < nIn) {
+                const MvTask t = tasks[i];
+                const DevSearch& s = st.sch[t.scheme].s[t.search];
+                const PartOut po = parts[t.rsId];
+                rsId = t.rsId;
+                ch[0] = loadPair(t.r);
+                cMeta[0] = (uint32_t)t.scheme | ((uint32_t)t.search << 4) | ((uint32_t)t.idx << 9);
+                cVd[0] = t.depth << 8;
+                cPw[0] = (uint32_t)po.pb[s.order[t.idx]] | ((uint32_t)po.pe[s.order[t.idx]] << 9);
+                kinds = 1;
+                nNode = 1;
+            }
+        } else if (i < nIn) {
+            const uint4 n1 = Qi[(size_t)PU * qCap + i];
+            const MvPair parent = MvTraits::load(Qi + i, qCap);
+            rsId = n1.x;
+            const uint32_t scheme = n1.y & 15u, search = (n1.y >> 4) & 31u, idx = (n1.y >> 9) & 15u, row = n1.y >> 13;
+            const uint32_t v = n1.z & 0xFFu, smDepth = n1.z >> 8;
+            const uint32_t pb = n1.w & 0x1FFu, pe = (n1.w >> 9) & 0x1FFu;
+            const DevSearch& s = st.sch[scheme].s[search];
+            const uint32_t dir = s.dir[idx];
+            const int md = (s.uniAll || idx >= (uint32_t)s.uniIdx) ? 2 : (dir == 0 ? 0 : 1);
+            const uint32_t xLen = pe - pb;
+            const uint32_t pc = seq[(size_t)rsId * maxLen + (dir == 0 ? pb + row : pe - row - 1)];
+            uint32_t rows = 0;
+            const uint32_t mask = moveChildrenCounted(ix, md, parent, ch, rows);
+            cRows += rows;
+            cExp++;
+            const uint32_t row1 = row + 1;
+            fmDepth = smDepth + xLen;
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                if (!(mask >> c & 1u)) continue;
+                cNode++;
+                const uint32_t v1 = v + (c + 1 != pc ? 1u : 0u);
+                if (v1 > s.U[idx]) continue; // backtrack
+                if (row1 == xLen) {          // end of the part
+                    if (v1 < s.L[idx]) continue;
+                    if (idx == (uint32_t)s.n - 1) {
+                        kinds |= 3u << (4 * c);
+                        cVd[c] = v1;
+                        nFm++;
+                    } else { // recApproxMatchHamming(s, match, ..., idx + 1): the child is the start match
+                        const PartOut po = parts[rsId];
+                        kinds |= 1u << (4 * c);
+                        cMeta[c] = scheme | (search << 4) | ((idx + 1) << 9);
+                        cVd[c] = v1 | (fmDepth << 8);
+                        cPw[c] = (uint32_t)po.pb[s.order[idx + 1]] | ((uint32_t)po.pe[s.order[idx + 1]] << 9);
+                        nNode++;
+                    }
+                    continue;
+                }
+                kinds |= 1u << (4 * c);
+                cMeta[c] = scheme | (search << 4) | (idx << 9) | (row1 << 13);
+                cVd[c] = v1 | (smDepth << 8);
+                cPw[c] = n1.w;
+                nNode++;
+            }
+        }
+        const uint32_t want[4] = {nNode, 0u, nFm, 0u};
+        uint32_t got[4];
+        blockAppend4(&B.nq[outP], &q.cnt[0], &q.cnt[1], &q.cnt[1], want, sh, got);
+        uint32_t oNode = got[0], oFm = got[2];
+        bool ok = true;
+        if (oNode + nNode > qCap) { ok = false; flags |= FLAG_BFS_Q; }
+        if (oFm + nFm > q.fmCap) { ok = false; flags |= FLAG_FMOCC_OVERFLOW; }
+        if (ok) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t kd = (kinds >> (4 * c)) & 15u;
+                if (kd == 1) {
+                    MvTraits::store(Qo + oNode, qCap, ch[c]);
+                    Qo[(size_t)PU * qCap + oNode] = make_uint4(rsId, cMeta[c], cVd[c], cPw[c]);
+                    oNode++;
+                } else if (kd == 3) {
+                    MvFmRec f;
+                    f.rsId = rsId, f.depth = fmDepth, f.dist = cVd[c], f.shift = 0;
+                    f.r = storePair(ch[c]);
+                    B.fmX[oFm++] = f;
+                }
+            }
+        }
+    }
+    unsigned long long v2[4] = {cNode, cExp, 0ull, cRows};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v2[j] += __shfl_xor(v2[j], d);
+    }
+    __shared__ unsigned long long shc[4][4];
+    if ((threadIdx.x & 63u) == 0)
+        for (int j = 0; j < 4; j++) shc[threadIdx.x >> 6][j] = v2[j];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const unsigned long long t = shc[0][threadIdx.x] + shc[1][threadIdx.x] + shc[2][threadIdx.x] + shc[3][threadIdx.x];
+        if (t) B.blockCnt[(size_t)blockIdx.x * 4 + threadIdx.x] += t;
+    }
+    if (flags) atomicOr(&q.cnt[3], flags);
+}
+
 // ------------------------------------------------------------------ in-index occurrences -> text occurrences
 // Occurrences::eraseDoublesFM (indexhelpers.h:2135-2146) under the RLC flavour's equality (FMOcc::== over SARangePair::==,
 // which includes run indices, toehold, toeholdRepresentsEnd and originalDepth, :1226-1233): records are sorted by

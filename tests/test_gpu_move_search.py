@@ -36,11 +36,11 @@ def _tuples(occ, offs, i):
     return [(int(o["begin"]), int(o["end"]), int(o["distance"]), int(o["strand"])) for o in occ[int(offs[i]):int(offs[i + 1])]]
 
 
-def _compare(w, spec, partition, k, reads, kmer_size=8):
+def _compare(w, spec, partition, k, reads, kmer_size=8, metric="edit"):
     import schemes_py as sp
     ca, op = w["ca"], w["op"]
-    o_occ, o_off, o_cnt = w["orc"].match_batch(op.OracleStrategy(sp.BY_NAME[spec], "edit", partition), k, reads, threads=8, word_size=kmer_size)
-    d_occ, d_off, d_cnt = w["dev"].match_batch(ca.SearchStrategy(spec, "edit", partition), k, reads, kmer_size=kmer_size)
+    o_occ, o_off, o_cnt = w["orc"].match_batch(op.OracleStrategy(sp.BY_NAME[spec], metric, partition), k, reads, threads=8, word_size=kmer_size)
+    d_occ, d_off, d_cnt = w["dev"].match_batch(ca.SearchStrategy(spec, metric, partition), k, reads, kmer_size=kmer_size)
     assert len(o_occ) > 0
     assert np.array_equal(o_off, d_off)
     strand_only = 0
@@ -53,7 +53,7 @@ def _compare(w, spec, partition, k, reads, kmer_size=8):
             strand_only += 1
     assert strand_only <= max(1, len(o_occ) // 500)
     names = ["NODE_COUNTER", "EXPANSIONS", "TOTAL_REPORTED_POSITIONS", "LOCATED_ROWS"]
-    if k > 0:
+    if k > 0 and metric == "edit":
         names += ["SEARCH_STARTED", "MATRIX_ROWS"]
     # in-index occurrences that the reference's sort + adjacent-unique leaves in twice are located twice there
     # (Occurrences::eraseDoublesFM, indexhelpers.h:2135-2146: operator< ignores fields operator== compares); the device
@@ -99,6 +99,25 @@ def test_bmove_search_parity(sworld, gt, spec, partition, k, length):
         assert checked > 100
 
 
+@pytest.mark.parametrize("spec,partition,k,length", [
+    ("kuch1", "dynamic", 2, 100),
+    ("kuch1", "static", 3, 150),
+    ("multiple_opt", "uniform", 4, 150),
+    ("multiple_opt", "dynamic", 6, 250),
+    ("columba", "dynamic", 3, 100),
+    ("pigeon", "uniform", 1, 100),
+    ("kianfar", "dynamic", 4, 100),
+])
+def test_bmove_hamming_parity(sworld, gt, spec, partition, k, length):
+    """recApproxMatchHamming on the b-move index (indexinterface.cpp:1211-1304, RLC branches) + getTextOccHamming"""
+    reads = _reads(sworld["g"], k, 1500, length, seed=170 + k + length)
+    # (substitutions only would be the typical Hamming input; reads with indels simply have fewer occurrences)
+    reads += synth.sample_reads(sworld["g"], 500, length, seed=5 + k, p_sub=1.0, p_ins=0.0, edit_choices=(0, 1, k, k))
+    occ, offs, cnt, _ = _compare(sworld, spec, partition, k, reads, metric="hamming")
+    checked, _ = check_soundness(gt, sworld["text"], reads[:300], occ, offs, k, "hamming")
+    assert checked > 50
+
+
 def test_bmove_search_small_kmer_tables_and_directions(sworld):
     """schemes whose seeds need k-mers of at most four characters (kuch2, 01*0), k-mer sizes 4 and 10, ragged read lengths"""
     g = sworld["g"]
@@ -125,9 +144,6 @@ def test_bmove_search_is_complete(sworld, gt):
 
 def test_bmove_search_refusals(sworld):
     ca = sworld["ca"]
-    with pytest.raises(ca.CmbError) as e:
-        sworld["dev"].match_batch(ca.SearchStrategy("kuch1", "hamming", "dynamic"), 2, [b"ACGT" * 30])
-    assert e.value.code == ca.CMB_ERR_UNSUPPORTED
     with pytest.raises(ca.CmbError) as e:  # naive-backtracking fallback of the reference: refused, not skipped
         sworld["dev"].match_batch(ca.SearchStrategy("multiple_opt", "edit", "dynamic"), 4, [b"ACGTACGT" * 12, b"ACGT"])
     assert e.value.code == ca.CMB_ERR_UNSUPPORTED
