@@ -1,7 +1,8 @@
 // Exact matching of a chunk of reads on the run-length compressed (b-move) index through the C++ adapter — the k = 0 branch of
 // SearchStrategy::matchApproxAllMap (reference src/searchstrategy.cpp:499-510) — followed by a walk that exercises the
 // extension and locate calls with the reference's method names.
-//   usage: bmove_exact <index base> <reads file: one sequence per line>
+//   usage: bmove_exact <index base> <reads file: one sequence per line> [k [strategy [k-mer size]]]
+// with k > 0: the approximate search of SearchStrategy::matchApproxAllMap (searchstrategy.cpp:495-535, RLC flavour) instead
 // prints:  <read#> <begin> <end> <distance> <strand>      (stdout)
 //          nodes <NODE_COUNTER>; walk <depth> <width> <positions found>   (stderr)
 #include "columba_amd_bmove.hpp"
@@ -23,13 +24,22 @@ int main(int argc, char** argv) {
         std::string line;
         while (std::getline(f, line)) chunk.push_back(line);
         std::vector<std::vector<TextOcc>> matches;
-        const uint64_t nodes = index.exactMatchesOutput(chunk, matches);
+        const int k = argc > 3 ? atoi(argv[3]) : 0;
+        uint64_t nodes = 0;
+        if (k > 0) {
+            SearchStrategy strategy(index, argc > 4 ? argv[4] : "multiple_opt", CMB_PARTITION_DYNAMIC, CMB_METRIC_EDIT, argc > 5 ? atoi(argv[5]) : 10);
+            std::vector<uint64_t> counters;
+            strategy.matchApproxBatch(chunk, (length_t)k, counters, matches);
+            nodes = counters[CMB_CNT_NODE];
+        } else {
+            nodes = index.exactMatchesOutput(chunk, matches);
+        }
         for (size_t i = 0; i < matches.size(); i++)
             for (const auto& o : matches[i])
                 std::cout << i << ' ' << o.getBegin() << ' ' << o.getEnd() << ' ' << o.getDistance() << ' ' << (o.isRevCompl() ? 1 : 0) << "\n";
         std::cerr << "nodes " << nodes << "\n";
         // the first read once more, character by character from its middle: right with ...Forward, then left with ...Backward
-        if (!chunk.empty() && chunk[0].size() >= 2) {
+        if (k == 0 && !chunk.empty() && chunk[0].size() >= 2) {
             const std::string& s = chunk[0];
             auto code = [](char c) -> length_t { return c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 3 : c == 'T' ? 4 : 0; };
             SARangePair cur = index.getCompleteRange(), next;

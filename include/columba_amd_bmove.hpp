@@ -11,6 +11,8 @@
 //          BackwardUniDirectional                bmove.cpp:328-478    extendFMPos for a batch (all four children each)
 //   BMove::getTextPositionsFromSARange           bmove.cpp:543-560    same, and a batch variant
 //   IndexInterface::exactMatchesOutput           indexinterface.cpp:947   exactMatchesOutput for a chunk of reads
+//   SearchStrategy::matchApprox (ALL mode)       searchstrategy.cpp:495   SearchStrategy::matchApproxBatch for a chunk of reads
+//     (the RUN_LENGTH_COMPRESSION branches: no in-text verification, locate through the toeholds)
 //   SARangePair / MoveRange (SARange)            indexhelpers.h:137-255, :1117   value types with the same accessors
 //
 // Files: <base>.LFBP and <base>.rev.LFBP are the reference's own (MoveLFReprBP::write).  The reference keeps the samples,
@@ -207,6 +209,46 @@ class BMove {
             for (uint64_t j = occOff[i]; j < occOff[i + 1]; j++)
                 matches[i].emplace_back(occ[j].begin, occ[j].end, occ[j].distance, occ[j].strand ? REVERSE_C_STRAND : FORWARD_STRAND);
         return counters[0];
+    }
+};
+
+// SearchStrategy of the RLC flavour for the path that runs on the device: the body of processChunk's loop (parallel.cpp:67-78)
+// for a whole chunk in ALL mode.  name: one of the reference's -S names ("columba", "multiple_opt", "kuch1", "kuch2", "kianfar",
+// "01*0", "pigeon", "minU"; alignparameters.cpp:1341-1372); partitioning 0 uniform, 1 static, 2 dynamic; metric 0 Hamming, 1 edit.
+class SearchStrategy {
+    BMove& index;
+    cmb_strategy* h = nullptr;
+    unsigned kmerSize;
+
+  public:
+    SearchStrategy(BMove& idx, const std::string& name, int partitioning = CMB_PARTITION_DYNAMIC, int metric = CMB_METRIC_EDIT,
+                   unsigned kmerSize_ = 10)
+        : index(idx), kmerSize(kmerSize_) {
+        check(cmb_strategy_create_named(name.c_str(), metric, partitioning, &h));
+    }
+    SearchStrategy(const SearchStrategy&) = delete;
+    ~SearchStrategy() { cmb_strategy_destroy(h); }
+    // matches[i] = the occurrences of reads[i] as filterPtr leaves them (searchstrategy.cpp:529); counters[CMB_CNT_*]
+    void matchApproxBatch(const std::vector<std::string>& reads, length_t maxED, std::vector<uint64_t>& counters,
+                          std::vector<std::vector<TextOcc>>& matches) {
+        std::string buf;
+        std::vector<uint64_t> off(reads.size() + 1, 0), occOff(reads.size() + 1, 0);
+        for (size_t i = 0; i < reads.size(); i++) buf += reads[i], off[i + 1] = buf.size();
+        std::vector<cmb_move_occ> occ(reads.size() * 4 + 64);
+        counters.assign(CMB_CNT_MAX, 0);
+        uint64_t needed = 0;
+        int rc = cmb_move_match_batch(index.handle(), h, (uint32_t)maxED, kmerSize, buf.data(), off.data(), (uint32_t)reads.size(), occ.data(),
+                                      occ.size(), occOff.data(), counters.data(), &needed);
+        if (rc == CMB_ERR_OVERFLOW) {
+            occ.resize(needed);
+            rc = cmb_move_match_batch(index.handle(), h, (uint32_t)maxED, kmerSize, buf.data(), off.data(), (uint32_t)reads.size(), occ.data(),
+                                      occ.size(), occOff.data(), counters.data(), &needed);
+        }
+        check(rc);
+        matches.assign(reads.size(), {});
+        for (size_t i = 0; i < reads.size(); i++)
+            for (uint64_t j = occOff[i]; j < occOff[i + 1]; j++)
+                matches[i].emplace_back(occ[j].begin, occ[j].end, occ[j].distance, occ[j].strand ? REVERSE_C_STRAND : FORWARD_STRAND);
     }
 };
 

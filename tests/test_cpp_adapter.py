@@ -143,7 +143,7 @@ def test_bmove_adapter_compiles_and_reports_missing_index(tmp_path):
 def test_bmove_adapter_example_matches_python_binding(tmp_path):
     """BMove of include/columba_amd_bmove.hpp on files written by movebuild.save_move: exactMatchesOutput of a chunk =
     the Python binding's occurrences; a bidirectional walk with the reference's method names ends on the same interval"""
-    from columba_amd import movebuild
+    from columba_amd import movebuild, synth
     exe = _build_bmove(str(tmp_path))
     rng = np.random.default_rng(3)
     base = rng.integers(0, 4, 5000)
@@ -177,6 +177,16 @@ def test_bmove_adapter_example_matches_python_binding(tmp_path):
     walk = err[1].split()
     fw = sorted(int(o["begin"]) for o in occ[int(offs[0]):int(offs[1])] if o["strand"] == 0)
     assert walk[0] == "walk" and int(walk[1]) == len(reads[0]) and [int(x) for x in walk[4:]] == fw
+    # the approximate search through the adapter (rlc::SearchStrategy::matchApproxBatch): the Python binding's lists and node count
+    areads = [bytes(r) for r in synth.sample_reads(np.frombuffer(t[:-1], dtype=np.uint8), 150, 100, seed=8, edit_choices=(0, 1, 2, 3))]
+    (tmp_path / "areads.txt").write_bytes(b"\n".join(areads) + b"\n")
+    r = subprocess.run([exe, str(tmp_path / "idx"), str(tmp_path / "areads.txt"), "3", "kuch1", "6"], capture_output=True, text=True, check=True)
+    got = [tuple(int(x) for x in line.split()) for line in r.stdout.splitlines()]
+    occ, offs, cnt = dev.match_batch(ca.SearchStrategy("kuch1", "edit", "dynamic"), 3, areads, kmer_size=6)
+    exp = [(i, int(o["begin"]), int(o["end"]), int(o["distance"]), int(o["strand"]))
+           for i in range(len(areads)) for o in occ[int(offs[i]):int(offs[i + 1])]]
+    assert got == exp and len(exp) > 100
+    assert r.stderr.split("\n")[0] == f"nodes {cnt['NODE_COUNTER']}"
 
 
 @pytest.mark.gpu
