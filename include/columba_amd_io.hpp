@@ -14,15 +14,97 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#if defined(__has_include)
+#if __has_include(<zlib.h>)
+#include <zlib.h> // gz-compressed read files (the reference: HAVE_ZLIB, seqfile.cpp); link with -lz
+#define COLUMBA_AMD_HAVE_ZLIB 1
+#endif
+#endif
 
 namespace columba_amd {
+
+// A read file as a stream of lines, plain or gz-compressed by its extension (SeqFile, seqfile.{h,cpp}: ".gz" selects zlib)
+class LineSource {
+    std::ifstream in;
+#ifdef COLUMBA_AMD_HAVE_ZLIB
+    gzFile gz = nullptr;
+#endif
+    bool compressed = false;
+    std::string buf;
+    size_t pos = 0;
+    bool exhausted = false;
+
+    bool fill() { // more bytes into buf; false at the end of the file
+        if (exhausted) return false;
+        buf.erase(0, pos);
+        pos = 0;
+        char tmp[1 << 16];
+        long n = 0;
+        if (compressed) {
+#ifdef COLUMBA_AMD_HAVE_ZLIB
+            n = gzread(gz, tmp, sizeof(tmp));
+            if (n < 0) throw std::ios::failure("error while reading a gz-compressed file");
+#endif
+        } else {
+            in.read(tmp, sizeof(tmp));
+            n = (long)in.gcount();
+        }
+        if (n <= 0) {
+            exhausted = true;
+            return false;
+        }
+        buf.append(tmp, (size_t)n);
+        return true;
+    }
+
+  public:
+    explicit LineSource(const std::string& file) {
+        compressed = file.size() > 3 && file.compare(file.size() - 3, 3, ".gz") == 0;
+        if (compressed) {
+#ifdef COLUMBA_AMD_HAVE_ZLIB
+            gz = gzopen(file.c_str(), "rb");
+            if (!gz) throw std::runtime_error("Cannot open file: " + file);
+#else
+            throw std::runtime_error("gz-compressed input needs zlib (built without it): " + file);
+#endif
+        } else {
+            in.open(file, std::ios::binary);
+            if (!in) throw std::runtime_error("Cannot open file: " + file);
+        }
+    }
+    LineSource(const LineSource&) = delete;
+    ~LineSource() {
+#ifdef COLUMBA_AMD_HAVE_ZLIB
+        if (gz) gzclose(gz);
+#endif
+    }
+    int peek() { // the next character, EOF at the end
+        if (pos >= buf.size() && !fill()) return EOF;
+        return (unsigned char)buf[pos];
+    }
+    bool getline(std::string& line) { // without the newline; false at the end of the file
+        line.clear();
+        for (;;) {
+            const size_t nl = buf.find('\n', pos);
+            if (nl != std::string::npos) {
+                line.append(buf, pos, nl - pos);
+                pos = nl + 1;
+                return true;
+            }
+            line.append(buf, pos, std::string::npos);
+            pos = buf.size();
+            if (!fill()) return !line.empty();
+        }
+    }
+    bool good() { return peek() != EOF; }
+};
 
 struct SequenceRecord { // fastq.h SequenceRecord: identifier line as read (with @ or >), sequence, quality ("*" for FASTA)
     std::string seqID, read, qual;
 };
 
-class Reader { // fastq.h Reader (single-end; plain text)
-    std::ifstream in;
+class Reader { // fastq.h Reader (single-end; plain text or .gz)
+    LineSource in;
     std::string fileName;
     bool fastq = false;
     bool typeKnown = false;
@@ -36,14 +118,12 @@ class Reader { // fastq.h Reader (single-end; plain text)
             if (c == EOF) return false;
             if (c != '\n' && c != '\r') return true;
             std::string dummy;
-            std::getline(in, dummy);
+            in.getline(dummy);
         }
     }
 
   public:
-    explicit Reader(const std::string& file) : in(file), fileName(file) {
-        if (!in) throw std::runtime_error("Cannot open file: " + file);
-    }
+    explicit Reader(const std::string& file) : in(file), fileName(file) {}
     // one record; false at the end of the file
     bool next(SequenceRecord& r) {
         r.seqID.clear();
@@ -58,21 +138,21 @@ class Reader { // fastq.h Reader (single-end; plain text)
         if (fastq) { // fastq.cpp:43-99
             if (c != '@') throw std::ios::failure("File " + fileName + " doesn't appear to be in FastQ format");
             std::string plus;
-            std::getline(in, r.seqID);
-            std::getline(in, r.read);
-            std::getline(in, plus);
-            std::getline(in, r.qual);
+            in.getline(r.seqID);
+            in.getline(r.read);
+            in.getline(plus);
+            in.getline(r.qual);
             chomp(r.seqID);
             chomp(r.read);
             chomp(r.qual);
             return !r.read.empty();
         }
         if (c != '>') throw std::ios::failure("File " + fileName + " doesn't appear to be in Fasta format");
-        std::getline(in, r.seqID); // fastq.cpp:101-146
+        in.getline(r.seqID); // fastq.cpp:101-146
         chomp(r.seqID);
         std::string line;
         while (in.good() && in.peek() != '>' && in.peek() != EOF) {
-            std::getline(in, line);
+            in.getline(line);
             chomp(line);
             r.read += line;
         }

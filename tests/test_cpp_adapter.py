@@ -60,7 +60,7 @@ def _build_align(tmp):
     exe = os.path.join(tmp, "columba_align")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "examples", "columba_align.cpp"), "-o", exe,
-                           "-L", os.path.join(ROOT, "columba_amd"), "-lcolumba_amd",
+                           "-L", os.path.join(ROOT, "columba_amd"), "-lcolumba_amd", "-lz",
                            "-Wl,-rpath," + os.path.join(ROOT, "columba_amd"), "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
@@ -106,6 +106,14 @@ def test_align_driver_fastq_to_sam(tmp_path, oracle_built):
     want = op.match_batch_sam(op.OracleIndex(ix), op.OracleStrategy(sp.COLUMBA, "edit", "dynamic"), 4, reads, ids, quals, names,
                               unmapped=True, xa=False).splitlines()
     assert [x for x in lines if not x.startswith("@")] == want and len(want) > 1000
+    # the same reads gz-compressed (SeqFile of the reference picks zlib by the .gz extension, seqfile.cpp): the same records
+    import gzip
+    with gzip.open(tmp_path / "reads.fq.gz", "wb") as f:
+        f.write((tmp_path / "reads.fq").read_bytes())
+    outz = tmp_path / "all_gz.sam"
+    subprocess.run([exe, "-r", str(tmp_path / "idx"), "-f", str(tmp_path / "reads.fq.gz"), "-o", str(outz), "-a", "all", "-e", "4",
+                    "-S", "columba", "-b", "400"], check=True, capture_output=True, text=True)
+    assert [x for x in outz.read_text().splitlines() if not x.startswith("@")] == want
     # BEST mode (the reference's default): one primary record per read, in input order
     outb = tmp_path / "best.sam"
     subprocess.run([exe, "-r", str(tmp_path / "idx"), "-f", str(tmp_path / "reads.fq"), "-o", str(outb), "-I", "95"], check=True,
