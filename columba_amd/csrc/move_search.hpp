@@ -9,7 +9,7 @@
 //   k-mer table entries with exact run indices of the SA range                        indexinterface.cpp:327-329
 //   in-index occurrences -> text positions by the toehold's phi / phi^-1 chains       bmove.cpp:500-560
 // Here that becomes: the frontier of dev_bfs_edit.hpp (events, phase entry, cluster analysis: bfsHeavy, instantiated with
-// MvTraits — nodes, F records and descendant lists hold 80-byte move range pairs instead of four 32-bit bounds), an
+// MvTraits — nodes, F records and descendant lists hold move range pairs packed into 48 bytes instead of four 32-bit bounds), an
 // expansion step built on moveChildren (all four children of a node from one scan of the parent's runs), a prologue
 // (partitioning, exact phases) on the same primitive, and a post-processing chain: de-duplication of the in-index
 // occurrences, k_move_locate, sort + redundancy filter on 64-bit positions.
@@ -38,22 +38,44 @@ struct MvBufs : BfsBufs {
     unsigned long long* rowSteps;  // [BFS_GRID] table rows fetched by the expansions (this backend's byte-model unit)
 };
 
+// In the records of the frontier (node planes, F records, descendant lists) a range pair is packed into THREE uint4: nine 40-bit
+// fields (both ranges with their run indices, the toehold: texts and tables below 2^40, checked at index creation), the 16-bit
+// original depth and the three flags — 379 of 384 bits, against the 80-byte cmb_move_range of the C-ABI.
 struct MvTraits {
     typedef MvPair Pair;
     typedef MvTask Task;
-    static constexpr uint32_t PAIR_U4 = 5;
+    static constexpr uint32_t PAIR_U4 = 3;
     static __device__ __forceinline__ Pair load(const uint4* p, size_t stride) {
-        MoveRangeRec q;
-        uint4* w = reinterpret_cast<uint4*>(&q);
-#pragma unroll
-        for (uint32_t u = 0; u < PAIR_U4; u++) w[u] = p[u * stride];
-        return loadPair(q);
+        const uint4 a = p[0], b = p[stride], c = p[2 * stride];
+        const uint64_t w0 = u64of(a.x, a.y), w1 = u64of(a.z, a.w), w2 = u64of(b.x, b.y), w3 = u64of(b.z, b.w), w4 = u64of(c.x, c.y),
+                       w5 = u64of(c.z, c.w);
+        Pair r;
+        r.sa.begin = w0 & MV_M40;
+        r.sa.end = (w0 >> 40 | w1 << 24) & MV_M40;
+        r.sa.beginRun = (w1 >> 16) & MV_M40;
+        r.sa.endRun = (w1 >> 56 | w2 << 8) & MV_M40;
+        r.rev.begin = (w2 >> 32 | w3 << 32) & MV_M40;
+        r.rev.end = (w3 >> 8) & MV_M40;
+        r.rev.beginRun = (w3 >> 48 | w4 << 16) & MV_M40;
+        r.rev.endRun = (w4 >> 24) & MV_M40;
+        r.toehold = w5 & MV_M40;
+        r.depth = (uint32_t)(w5 >> 40) & 0xFFFFu;
+        r.sa.valid = (w5 >> 56) & 1u;
+        r.rev.valid = (w5 >> 57) & 1u;
+        r.repEnd = (w5 >> 58) & 1u;
+        return r;
     }
     static __device__ __forceinline__ void store(uint4* p, size_t stride, const Pair& r) {
-        const MoveRangeRec q = storePair(r);
-        const uint4* w = reinterpret_cast<const uint4*>(&q);
-#pragma unroll
-        for (uint32_t u = 0; u < PAIR_U4; u++) p[u * stride] = w[u];
+        const uint64_t w0 = (r.sa.begin & MV_M40) | r.sa.end << 40;
+        const uint64_t w1 = (r.sa.end & MV_M40) >> 24 | (r.sa.beginRun & MV_M40) << 16 | r.sa.endRun << 56;
+        const uint64_t w2 = (r.sa.endRun & MV_M40) >> 8 | r.rev.begin << 32;
+        const uint64_t w3 = (r.rev.begin & MV_M40) >> 32 | (r.rev.end & MV_M40) << 8 | r.rev.beginRun << 48;
+        const uint64_t w4 = (r.rev.beginRun & MV_M40) >> 16 | (r.rev.endRun & MV_M40) << 24;
+        const uint64_t w5 = (r.toehold & MV_M40) | (uint64_t)(r.depth & 0xFFFFu) << 40 | (uint64_t)(r.sa.valid ? 1 : 0) << 56 |
+                            (uint64_t)(r.rev.valid ? 1 : 0) << 57 | (uint64_t)(r.repEnd ? 1 : 0) << 58;
+        p[0] = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
+        p[stride] = make_uint4((uint32_t)w2, (uint32_t)(w2 >> 32), (uint32_t)w3, (uint32_t)(w3 >> 32));
+        p[2 * stride] = make_uint4((uint32_t)w4, (uint32_t)(w4 >> 32), (uint32_t)w5, (uint32_t)(w5 >> 32));
     }
     static __device__ __forceinline__ Pair none() {
         Pair p;
@@ -76,7 +98,6 @@ struct MvTraits {
         static_cast<const MvBufs&>(B).fmX[slot].rsId = 0xFFFFFFFFu;
     }
 };
-static_assert(sizeof(MoveRangeRec) == 16 * MvTraits::PAIR_U4, "a range pair is five uint4");
 
 // ---- the index as the search sees it
 struct MvSearchIndex {
@@ -562,7 +583,7 @@ k_mvs_exact(MvSearchIndex sx, const DevStrategyK* __restrict__ stp, uint32_t nRe
 
 // ------------------------------------------------------------------ the frontier: one level per launch
 // Expansion of a frontier node (extendFMPos + branchAndBound + the stack loop of recApproxMatchEdit, indexinterface.cpp:506-561,
-// :675-697, without the in-text switch this flavour does not have).  Node = range pair (5 planes) + the three planes of
+// :675-697, without the in-text switch this flavour does not have).  Node = range pair (3 planes) + the three planes of
 // dev_bfs_edit.hpp: {row | score << 16, ctx, fc, RAC bit | mode << 8} {HP, HN} {final-column distances}.
 __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uint32_t pass, const Queues& q, uint32_t bid, uint32_t nBlocks) {
     __shared__ uint32_t sh[4][5];
@@ -743,7 +764,7 @@ __global__ void k_mvs_finish(MvBufs B, Queues q) { // one block: per-block count
 
 // ------------------------------------------------------------------ Hamming distance: the frontier without a matrix
 // IndexInterface::recApproxMatchHamming (indexinterface.cpp:1211-1304, RUN_LENGTH_COMPRESSION branches: no in-text switch).  As
-// dev_bfs_hamming.hpp on this backend: a node is the range pair (5 planes) + one plane {rsId, scheme | search << 4 | idx << 9 |
+// dev_bfs_hamming.hpp on this backend: a node is the range pair (3 planes) + one plane {rsId, scheme | search << 4 | idx << 9 |
 // row << 13, mismatches | startDepth << 8, pb | pe << 9}; a child that completes its part enters the next phase at once; a child
 // that completes the last part is an in-index occurrence.  One row per pass.
 struct MvHbfsBufs {
