@@ -41,6 +41,17 @@ def _worker(rank, world, port, tmp):
     np.save(os.path.join(tmp, f"mocc{rank}.npy"), occ)
     np.save(os.path.join(tmp, f"moffs{rank}.npy"), offs)
     np.save(os.path.join(tmp, f"mcnt{rank}.npy"), np.array([cnt["NODE_COUNTER"], cnt["TOTAL_REPORTED_POSITIONS"]]))
+    # the approximate search on the replica: every rank matches ITS shard of the reads (sharded job: no collective on the
+    # data path), rank 0's index was created from the files, rank 1's arrived through the collective
+    areads = [text[p:p + 100].replace(b"ACG", b"ATG", 1) for p in range(50, 70000, 53)]
+    lo, hi = ca.shard_bounds(len(areads), world, rank)
+    a_occ, a_offs, a_cnt = index.match_batch(ca.SearchStrategy("multiple_opt", "edit", "dynamic"), 4, areads[lo:hi], kmer_size=6)
+    np.save(os.path.join(tmp, f"aocc{rank}.npy"), a_occ)
+    np.save(os.path.join(tmp, f"aoffs{rank}.npy"), a_offs)
+    if rank == 1:  # ... and the whole chunk on the replica, for the comparison with the concatenated shards
+        w_occ, w_offs, _ = index.match_batch(ca.SearchStrategy("multiple_opt", "edit", "dynamic"), 4, areads, kmer_size=6)
+        np.save(os.path.join(tmp, "awhole_occ.npy"), w_occ)
+        np.save(os.path.join(tmp, "awhole_offs.npy"), w_offs)
     np.save(os.path.join(tmp, f"mkmer{rank}.npy"), index.kmer_table(5))
     np.save(os.path.join(tmp, f"mrows{rank}.npy"), index.rows(1))
     if rank == 1:  # a replica whose arrays are damaged afterwards is refused by the validation
@@ -65,3 +76,8 @@ def test_device_layout_broadcast_of_the_move_index(tmp_path):
     for name in ("moffs", "mcnt", "mkmer", "mrows"):
         assert np.array_equal(np.load(tmp_path / f"{name}0.npy"), np.load(tmp_path / f"{name}1.npy")), name
     assert bool(np.load(tmp_path / "mrefused.npy")[0])
+    # read shards matched on the two replicas, concatenated in rank order = the whole chunk matched on one
+    a0, a1, w = np.load(tmp_path / "aocc0.npy"), np.load(tmp_path / "aocc1.npy"), np.load(tmp_path / "awhole_occ.npy")
+    assert len(w) > 1000 and np.array_equal(np.concatenate([a0, a1]), w)
+    f0, f1, fw = np.load(tmp_path / "aoffs0.npy"), np.load(tmp_path / "aoffs1.npy"), np.load(tmp_path / "awhole_offs.npy")
+    assert np.array_equal(np.concatenate([f0, f1[1:] + f0[-1]]), fw)
