@@ -536,6 +536,11 @@ struct cmb_batch {
     DevBuf<uint32_t> bfsCnt;               // nq[passes], ne[passes], pool[4]
     DevBuf<unsigned long long> bfsBlockCnt; // [BFS_GRID][4]
     size_t bfsQCap = 0, bfsEvCap = 0, bfsFCap = 0, bfsCCap = 0, bfsACap = 0;
+    // naive backtracking (dev_bfs_naive.hpp): node double buffer, nodes per pass
+    DevBuf<uint4> nvQ[2];
+    DevBuf<uint32_t> nvCnt;
+    size_t nvQCap = 0;
+    bool hasNaive = false; // reads of the running chunk take that path (k_parts marked them in psel)
     DevBuf<PartOut> parts;
     DevBuf<DfsTask> dfs;
     DevBuf<uint64_t> vW; // packed trace rows [row][slot]
@@ -888,6 +893,7 @@ static int batchRunOne(cmb_batch* b) {
         }
         b->times.clear();
         b->done = false;
+        b->hasNaive = false;
         Timer tm(s, b->times);
         const uint32_t nReads = b->nReads;
         const uint32_t tasks = 2 * nReads;
@@ -994,24 +1000,52 @@ static int batchRunOne(cmb_batch* b) {
             HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             uint32_t flags = hcnt[3];
-            if ((flags & FLAG_UNSUPPORTED_READ) && !b->allowUnsupported) {
-                // name the read: the caller has to drop it (k_parts marks such reads in psel)
-                std::string which;
-                if (b->psel.p && tasks) {
-                    std::vector<uint8_t> hp(tasks);
-                    HIPCHK(hipMemcpy(hp.data(), b->psel.p, tasks, hipMemcpyDeviceToHost));
-                    for (uint32_t t = 0; t < tasks; t++)
-                        if (hp[t] & 0x80u) {
-                            const uint32_t r = t >> 1;
-                            const uint64_t global = (b->parent ? b->parent->subBound[b->subIndex] : 0u) + (uint64_t)r;
-                            which = " (first: read " + std::to_string(global) + " of the batch, " +
-                                    std::to_string(b->hostOffs[r + 1] - b->hostOffs[r]) + " characters)";
-                            break;
-                        }
+            // ---- reads not longer than the number of parts (and every read of a one-part strategy): naive backtracking
+            // (searchstrategy.cpp:148-152, :442-459 -> dev_bfs_naive.hpp); k_parts marked them in psel
+            b->hasNaive = (flags & FLAG_UNSUPPORTED_READ) != 0;
+            if (b->hasNaive) {
+                tm.begin();
+                const uint32_t maxPassN = b->maxLen + 2 * b->k + 4; // (rows of the matrix: len + 2 k + 1 at most)
+                if (!b->nvQCap) b->nvQCap = getenv("CMB_TEST_SMALL_POOLS") ? 64 : 16384;
+                for (int j = 0; j < 2; j++)
+                    if (b->nvQ[j].n < 3 * b->nvQCap) b->nvQ[j].alloc(3 * b->nvQCap);
+                const size_t cntWords = (size_t)maxPassN + 2;
+                if (b->nvCnt.n < cntWords) b->nvCnt.alloc(cntWords);
+                HIPCHK(hipMemsetAsync(b->nvCnt.p, 0, cntWords * sizeof(uint32_t), s));
+                NaiveBufs N{};
+                N.Q[0] = b->nvQ[0].p;
+                N.Q[1] = b->nvQ[1].p;
+                N.qCap = (uint32_t)std::min<size_t>(b->nvQ[0].n / 3, 0xFFFFFFF0u);
+                N.nq = b->nvCnt.p;
+                const bool edit = b->metric == CMB_METRIC_EDIT;
+                hipLaunchKernelGGL(k_naive_start, dim3((tasks + 255) / 256), dim3(256), 0, s, ix->d, b->psel.p, b->offs.p, tasks,
+                                   b->k, edit ? 0u : 1u, N, q);
+                std::vector<uint32_t> hc(cntWords);
+                uint32_t pass = 0, peakQ = 0;
+                bool drained = false;
+                while (!drained && pass < maxPassN) {
+                    const uint32_t upTo = std::min(pass + 16u, maxPassN);
+                    for (; pass < upTo; pass++)
+                        hipLaunchKernelGGL(edit ? k_naive_pass<true> : k_naive_pass<false>, dim3(BFS_GRID), dim3(256), 0, s, ix->d, N,
+                                           pass, b->offs.p, b->gw, b->G.p, b->seq.p, b->maxLen, b->k, q);
+                    HIPCHK(hipMemcpyAsync(hc.data(), b->nvCnt.p, cntWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
+                    HIPCHK(hipStreamSynchronize(s));
+                    if (hcnt[3] & (FLAG_NAIVE_Q | FLAG_ITEM_OVERFLOW | FLAG_FMOCC_OVERFLOW)) break;
+                    drained = hc[pass] == 0;
                 }
-                return fail(CMB_ERR_UNSUPPORTED,
-                            "a read is not longer than the number of parts of the search scheme (the reference "
-                            "falls back to naive backtracking, which the device path does not provide)" + which);
+                for (uint32_t p2 = 0; p2 <= pass && p2 < cntWords; p2++) peakQ = std::max(peakQ, hc[p2]);
+                if (verbose) fprintf(stderr, "[naive] %u roots, %u passes, peak frontier %u\n", hc[0], pass, peakQ);
+                tm.end("k_naive");
+                HIPCHK(hipGetLastError());
+                flags = hcnt[3];
+                if (flags & FLAG_NAIVE_Q) {
+                    if (attempt >= 30) return fail(CMB_ERR_INTERNAL, "the naive search's frontier keeps overflowing");
+                    b->nvQCap = std::max<size_t>(2 * b->nvQCap, (size_t)peakQ + peakQ / 4);
+                    continue;
+                }
+                if (!drained && !(flags & (FLAG_ITEM_OVERFLOW | FLAG_FMOCC_OVERFLOW)))
+                    return fail(CMB_ERR_INTERNAL, "the naive search did not finish within its pass bound");
             }
             if (flags & FLAG_SEED_OVERLAP)
                 return fail(CMB_ERR_INVALID,
@@ -1374,7 +1408,7 @@ static int batchRunOne(cmb_batch* b) {
             }
             break;
         }
-        const uint32_t nText = hcnt[2];
+        uint32_t nText = hcnt[2];
         lap("verify + traceback + fmocc");
         if (preset) { // the raw text occurrences and the counters are the result
             if (hcnt[3] & (FLAG_CAPACITY | FLAG_TRACE_RULE)) return fail(CMB_ERR_INTERNAL, "a traceback left the band");
@@ -1387,11 +1421,71 @@ static int batchRunOne(cmb_batch* b) {
             return CMB_OK;
         }
 
+        // ---- naive backtracking: the filter pass of approxMatchesNaive[Hamming] itself, per read x strand (dev_bfs_naive.hpp)
+        uint64_t naiveSurvivors = 0;
+        if (b->hasNaive && nText) {
+            tm.begin();
+            const uint32_t nG = 2u * nReads;
+            if (nG >= (1u << 24)) return fail(CMB_ERR_UNSUPPORTED, "more than 2^23 reads in a sub-batch with reads matched by naive backtracking");
+            if (b->keysA.n < nText) {
+                b->keysA.alloc((size_t)nText + nText / 8 + 256);
+                b->keysB.alloc((size_t)nText + nText / 8 + 256);
+            }
+            if (b->fcounts.n < (size_t)nG + 1) {
+                b->fcounts.alloc((size_t)nG + 1);
+                b->foffs.alloc((size_t)nG + 1);
+                b->fsegB.alloc((size_t)nG + 1);
+                b->fsegE.alloc((size_t)nG + 1);
+            }
+            if (b->frank.n < nText) b->frank.alloc((size_t)nText + nText / 8 + 256);
+            hipLaunchKernelGGL(k_pack_keys, dim3((nText + 255) / 256), dim3(256), 0, s, b->text.p, nText, b->offs.p, b->k, b->keysA.p,
+                               b->cnt.p, 1u, (const uint8_t*)b->psel.p);
+            size_t tmpBytes = 0;
+            HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, b->keysA.p, b->keysB.p, nText, 0, 64, s));
+            if (b->sortTmp.n < tmpBytes) b->sortTmp.alloc(tmpBytes + 256);
+            HIPCHK(rocprim::radix_sort_keys(b->sortTmp.p, tmpBytes, b->keysA.p, b->keysB.p, nText, 0, 64, s));
+            const int mode = b->metric == CMB_METRIC_HAMMING ? 1 : 2;
+            HIPCHK(hipMemsetAsync(b->fcounts.p, 0, ((size_t)nG + 1) * sizeof(uint32_t), s));
+            HIPCHK(hipMemsetAsync(b->fsegB.p, 0xFF, ((size_t)nG + 1) * sizeof(uint32_t), s));
+            HIPCHK(hipMemsetAsync(b->frank.p, 0xFF, (size_t)nText * sizeof(uint32_t), s));
+            hipLaunchKernelGGL(k_filter_segments, dim3((nText + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->fsegB.p, b->fsegE.p);
+            hipLaunchKernelGGL(k_filter_mark, dim3((nG + 255) / 256), dim3(256), 0, s, b->keysB.p, nG, b->k, mode, b->fcounts.p,
+                               b->frank.p, b->fsegB.p, b->fsegE.p);
+            size_t scanBytes = 0;
+            HIPCHK(rocprim::exclusive_scan(nullptr, scanBytes, b->fcounts.p, b->foffs.p, (uint64_t)0, (size_t)nG + 1,
+                                           rocprim::plus<uint64_t>(), s));
+            if (b->scanTmp.n < scanBytes) b->scanTmp.alloc(scanBytes + 256);
+            HIPCHK(rocprim::exclusive_scan(b->scanTmp.p, scanBytes, b->fcounts.p, b->foffs.p, (uint64_t)0, (size_t)nG + 1,
+                                           rocprim::plus<uint64_t>(), s));
+            HIPCHK(hipMemcpyAsync(&naiveSurvivors, b->foffs.p + nG, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (hcnt[3] & FLAG_CAPACITY)
+                return fail(CMB_ERR_INTERNAL, "occurrence does not fit the filter key (width / distance range) or a traceback left the band");
+            if ((uint64_t)nText + naiveSurvivors >= 0xFFFFFFF0ull) return fail(CMB_ERR_UNSUPPORTED, "too many occurrences in one sub-batch");
+            if (b->text.n < (size_t)nText + naiveSurvivors) { // grow, keeping the records
+                DevBuf<TextOccRec> bigger;
+                bigger.alloc((size_t)nText + naiveSurvivors + 1024);
+                HIPCHK(hipMemcpyAsync(bigger.p, b->text.p, (size_t)nText * sizeof(TextOccRec), hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipStreamSynchronize(s));
+                std::swap(bigger.p, b->text.p);
+                std::swap(bigger.n, b->text.n);
+            }
+            hipLaunchKernelGGL(k_naive_drop, dim3((nText + 255) / 256), dim3(256), 0, s, b->text.p, nText, (const uint8_t*)b->psel.p);
+            if (naiveSurvivors)
+                hipLaunchKernelGGL(k_naive_keep, dim3((nText + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->offs.p, b->k,
+                                   b->frank.p, b->foffs.p, b->text.p + nText);
+            HIPCHK(hipGetLastError());
+            nText += (uint32_t)naiveSurvivors;
+            tm.end("k_naive_filter");
+        }
+
         // ---- sort + filter on the device (getUniqueTextOccurrences / getTextOccHamming,
         // indexinterface.cpp:1331-1491): pack -> one 64-bit radix sort -> per-read scan
         unsigned long long hc[CMB_CNT_MAX];
         HIPCHK(hipMemcpy(hc, b->counters.p, sizeof(hc), hipMemcpyDeviceToHost));
         for (int i = 0; i < CMB_CNT_MAX; i++) b->cnts[i] = hc[i];
+        b->cnts[1] += naiveSurvivors; // reported once more, as text occurrences of the read (indexinterface.cpp:1333, :1378)
         // groups of the filter: reads, or read x strand when every strand is filtered by itself
         const uint32_t nGroups = b->perStrand ? 2u * nReads : nReads;
         if (nGroups >= (1u << 24)) return fail(CMB_ERR_UNSUPPORTED, "more than 2^24 filter groups in one sub-batch");

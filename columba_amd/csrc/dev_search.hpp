@@ -67,10 +67,12 @@ enum : uint32_t { FLAG_ITEM_OVERFLOW = 1, FLAG_FMOCC_OVERFLOW = 2, FLAG_TEXT_OVE
                   FLAG_BFS_Q = 128, FLAG_BFS_EV = 256, FLAG_BFS_F = 512, FLAG_BFS_CTX = 1024, FLAG_BFS_ARENA = 2048,
                   // dynamic partitioning: the initial seeds of a read overlap (the reference asserts they do not,
                   // searchstrategy.cpp:404-407, and its CLI caps the k-mer size accordingly, alignparameters.cpp:1070-1114)
-                  FLAG_SEED_OVERLAP = 4096 };
+                  FLAG_SEED_OVERLAP = 4096,
+                  // naive backtracking (dev_bfs_naive.hpp): its node queue
+                  FLAG_NAIVE_Q = 8192 };
 constexpr uint32_t FLAG_BITS[] = {FLAG_ITEM_OVERFLOW, FLAG_FMOCC_OVERFLOW, FLAG_TEXT_OVERFLOW, FLAG_CAPACITY,
                                   FLAG_UNSUPPORTED_READ, FLAG_DFS_OVERFLOW, FLAG_TRACE_RULE, FLAG_BFS_Q, FLAG_BFS_EV,
-                                  FLAG_BFS_F, FLAG_BFS_CTX, FLAG_BFS_ARENA, FLAG_SEED_OVERLAP};
+                                  FLAG_BFS_F, FLAG_BFS_CTX, FLAG_BFS_ARENA, FLAG_SEED_OVERLAP, FLAG_NAIVE_Q};
 constexpr bool flagBitsDisjoint() {
     uint32_t seen = 0;
     for (uint32_t b : FLAG_BITS) {

@@ -39,7 +39,7 @@ inline DevSearch toDevSearch(const HostSearch& h) {
     const size_t n = h.pi.size();
     if (n != h.L.size() || n != h.U.size())
         throw std::runtime_error("Could not create search, the sizes of all vectors are not equal");
-    if (n < 2 || n > (size_t)MAXP) throw std::runtime_error("unsupported number of parts in search");
+    if (n < 1 || n > (size_t)MAXP) throw std::runtime_error("unsupported number of parts in search");
     DevSearch d{};
     d.n = (uint8_t)n;
     for (size_t i = 0; i < n; i++) {
@@ -48,7 +48,7 @@ inline DevSearch toDevSearch(const HostSearch& h) {
         d.U[i] = (uint8_t)h.U[i];
     }
     // directions: phase 0 copies phase 1 (search.h:131)
-    d.dir[0] = h.pi[1] > h.pi[0] ? 0 : 1;
+    d.dir[0] = (n > 1 && h.pi[1] > h.pi[0]) ? 0 : 1; // (one part, `-S naive`: the search is never run)
     for (size_t i = 1; i < n; i++) d.dir[i] = h.pi[i] > h.pi[i - 1] ? 0 : 1;
     d.dsw[0] = d.dsw[1] = 0;
     for (size_t i = 2; i < n; i++) d.dsw[i] = d.dir[i] != d.dir[i - 1];
@@ -466,6 +466,15 @@ inline void fillNamed(cmb_strategy& st, const std::string& name) {
                                                    "6543210 0111111 0133666"});
         st.schemes[6].push_back(mid6);
         st.schemes[6].push_back(mirrored(mid6));
+    } else if (name == "naive") {
+        // `-S naive`: NaiveBackTrackingStrategy (searchstrategy.h:2785-2820) — ONE part for every k, so partition() never splits
+        // (searchstrategy.cpp:148-152) and every read is matched by IndexInterface::approxMatchesNaive[Hamming] (:442-459).  The
+        // single search (0)(0)(k) the class lists is never run.
+        st.kmerCutOff = 20;
+        for (uint32_t k = 1; k <= 13; k++) {
+            const std::string row = std::string("0 0 ") + (char)(k < 10 ? '0' + k : 'a' + (k - 10));
+            st.schemes[k] = {schemeFromRows(k, {row.c_str()})};
+        }
     } else {
         throw std::runtime_error(name + " is not an option as search scheme");
     }

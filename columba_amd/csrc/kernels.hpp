@@ -262,6 +262,7 @@ k_prep(const uint8_t* __restrict__ reads, const uint64_t* __restrict__ offs, uin
 #include "dev_wave.hpp"
 #include "dev_bfs_edit.hpp"
 #include "dev_bfs_hamming.hpp"
+#include "dev_bfs_naive.hpp"
 namespace cmb {
 
 // ---- the frontier kernels of the FM-index backend (the functions live in dev_bfs_edit.hpp, which the b-move translation
@@ -1549,11 +1550,12 @@ __global__ void __launch_bounds__(256)
 k_pack_keys(const TextOccRec* __restrict__ text, uint32_t n, const uint64_t* __restrict__ offs, uint32_t k,
             unsigned long long* __restrict__ keys, uint32_t* __restrict__ cnt,
             uint32_t perStrand /* BEST mode filters every strand by itself (mapRead, searchstrategy.h:490-523): the group of a
-                                  key is then read x strand, not the read */) {
+                                  key is then read x strand, not the read */,
+            const uint8_t* __restrict__ only = nullptr /* dev_bfs_naive.hpp: keys for the reads marked here (bit 7), holes for the rest */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const TextOccRec t = text[i];
-    if (t.rsId == 0xFFFFFFFFu) { // a hole: sorts behind every read
+    if (t.rsId == 0xFFFFFFFFu || (only && !(only[t.rsId] & 0x80u))) { // a hole: sorts behind every read
         keys[i] = ~0ull;
         return;
     }

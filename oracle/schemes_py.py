@@ -131,5 +131,9 @@ def _columba():
 
 COLUMBA = _columba()
 
+# NaiveBackTrackingStrategy (searchstrategy.h:2785-2820): one part for every k (the search it lists is never run: every read
+# goes to approxMatchesNaive, searchstrategy.cpp:148-152, :442-459)
+NAIVE = {"kmer_cutoff": 20, "schemes": {k: [[([0], [0], [k])]] for k in range(1, 14)}}
+
 BY_NAME = {"multiple_opt": MULTIPLE_OPT, "kuch1": KUCH1, "kuch2": KUCH2, "kianfar": KIANFAR, "01*0": O1STAR,
-           "pigeon": PIGEON, "minU": MINU, "columba": COLUMBA}
+           "pigeon": PIGEON, "minU": MINU, "columba": COLUMBA, "naive": NAIVE}

@@ -1,0 +1,89 @@
+"""Naive backtracking on the device (dev_bfs_naive.hpp) against the oracle's restatement of
+IndexInterface::approxMatchesNaive / approxMatchesNaiveHamming (indexinterface.cpp:1055-1209): reads that are not longer
+than the number of parts of the search scheme (searchstrategy.cpp:148-152, :442-459) and every read under `-S naive`.
+Bar: occurrences and counters bit-exact.  Small texts: a read of five characters with four errors matches everywhere."""
+import numpy as np
+import pytest
+
+import columba_amd as ca
+from columba_amd import indexbuild as ib
+from columba_amd import synth
+from test_gpu_parity import _compare
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny(oracle_built):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import oracle_py as op
+    g, starts = synth.genome_rep(seed=5, n=30_000, scale=1.0)
+    ix = ib.build_index(g.tobytes(), seq_starts=starts, device="cuda")
+    return {"genome": g, "ix": ix, "dev": ca.Index(ix, kmer_size=4), "orc": op.OracleIndex(ix, kmer_size=4), "op": op}
+
+
+def _short_reads(g, rng, n, lo, hi):
+    out = []
+    for _ in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        p = int(rng.integers(0, len(g) - L - 1))
+        r = bytearray(bytes(g[p:p + L]))
+        if L and rng.random() < 0.3:
+            r[int(rng.integers(0, L))] = b"ACGT"[int(rng.integers(0, 4))]
+        out.append(bytes(r))
+    return out
+
+
+@pytest.mark.parametrize("spec,metric,partition,k", [
+    ("kuch1", "edit", "dynamic", 1), ("kuch1", "edit", "uniform", 2), ("kuch2", "edit", "static", 2),
+    ("multiple_opt", "edit", "dynamic", 2), ("pigeon", "edit", "dynamic", 3), ("columba", "edit", "dynamic", 3),
+    ("kuch1", "hamming", "dynamic", 1), ("pigeon", "hamming", "uniform", 2), ("columba", "hamming", "dynamic", 3),
+    ("kianfar", "hamming", "static", 2),
+])
+def test_reads_not_longer_than_the_number_of_parts(tiny, spec, metric, partition, k):
+    """a chunk that mixes ordinary reads with reads of 1 .. P characters: the short ones take the naive path, the chunk is
+    matched as a whole"""
+    rng = np.random.default_rng(100 * k + len(spec))
+    g = tiny["genome"]
+    P = {"kuch1": k + 1, "kuch2": k + 2, "pigeon": k + 1, "multiple_opt": k + 1, "columba": k + 1, "kianfar": k + 1}[spec]
+    reads = [bytes(g[p:p + 40]) for p in rng.integers(0, len(g) - 50, 60)]
+    short = _short_reads(g, rng, 25, 1, P) + ([b""] if metric == "edit" else [])
+    mixed = []
+    for i, r in enumerate(reads):
+        mixed.append(r)
+        if i < len(short):
+            mixed.append(short[i])
+    _compare(tiny, spec, metric, partition, k, mixed, dups_rare=False)
+    st = ca.SearchStrategy(spec, metric, partition)
+    b = ca.Batch(tiny["dev"], st, k, mixed)
+    b.run()
+    status = b.read_status()
+    assert [bool(s & 1) for s in status] == [len(r) <= P for r in mixed]
+    b.close()
+
+
+@pytest.mark.parametrize("metric,k,length", [("edit", 1, 20), ("edit", 2, 24), ("edit", 3, 16), ("hamming", 1, 18),
+                                             ("hamming", 2, 22), ("hamming", 3, 30)])
+def test_naive_strategy(tiny, metric, k, length):
+    """`-S naive`: one part, every read is matched by backtracking over the whole pattern"""
+    rng = np.random.default_rng(7 * k + length)
+    g = tiny["genome"]
+    reads = []
+    for _ in range(80):
+        L = int(rng.integers(max(2, length - 6), length + 1))
+        p = int(rng.integers(0, len(g) - L - 1))
+        r = bytearray(bytes(g[p:p + L]))
+        for _ in range(int(rng.integers(0, k + 1))):
+            r[int(rng.integers(0, L))] = b"ACGT"[int(rng.integers(0, 4))]
+        reads.append(bytes(r))
+    reads += [b"ACGTN", b"acgtacgtac", b"N" * 6]
+    _compare(tiny, "naive", metric, "dynamic", k, reads, dups_rare=False)
+
+
+def test_naive_pool_growth(tiny, monkeypatch):
+    monkeypatch.setenv("CMB_TEST_SMALL_POOLS", "1")
+    rng = np.random.default_rng(3)
+    g = tiny["genome"]
+    reads = [bytes(g[p:p + 14]) for p in rng.integers(0, len(g) - 20, 300)]
+    _compare(tiny, "naive", "edit", "dynamic", 2, reads, dups_rare=False)
