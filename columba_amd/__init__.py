@@ -672,10 +672,11 @@ class Batch:
         return occs[:n.value], offs, dict(zip(COUNTER_NAMES, cnt.tolist()))
 
     def allow_unsupported(self, on: bool = True):
-        """reads the device does not match (the reference's naive-backtracking fallback) are flagged instead of failing the run"""
+        """kept for older callers; no effect (reads not longer than the number of parts are matched by naive backtracking on the device)"""
         _chk(lib().cmb_batch_allow_unsupported(self.h, int(on)))
 
     def read_status(self) -> np.ndarray:
+        """per read: bit 0 = matched by naive backtracking instead of a search scheme (searchstrategy.cpp:148-152)"""
         st = np.zeros(max(self.n_reads, 1), np.uint8)
         n = C.c_uint32()
         _chk(lib().cmb_batch_read_status(self.h, _p(st), C.byref(n)))

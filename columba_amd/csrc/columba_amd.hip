@@ -564,7 +564,7 @@ struct cmb_batch {
     uint32_t nSlots = 0;
     std::vector<uint64_t> hostOffs;
     bool perStrand = false; // every strand filtered by itself (BEST mode: mapRead, searchstrategy.h:490-523)
-    bool allowUnsupported = false; // cmb_batch_allow_unsupported: reads the device path does not match are flagged, not fatal
+    bool allowUnsupported = false; // (cmb_batch_allow_unsupported: no effect any more)
     // alignments of the final occurrences (cmb_batch_want_alignments): CIGAR runs + sequence assignment
     bool wantAln = false;
     DevBuf<uint32_t> foutRead;
@@ -1692,11 +1692,9 @@ extern "C" int cmb_batch_timings(const cmb_batch* b, const char** names, float* 
     }
     return (int)n;
 }
-// Reads the device path does not match: not longer than the number of parts of the search scheme — the reference matches
-// those by naive backtracking (searchstrategy.cpp:148-152, :442-459; indexinterface.cpp:1055-1210).  By default one such read
-// fails cmb_batch_run with CMB_ERR_UNSUPPORTED (nothing is ever silently skipped); with cmb_batch_allow_unsupported(b, 1) the
-// run succeeds, their lists are empty and cmb_batch_read_status says which they are, so that the caller routes exactly those
-// reads to its own fallback (a Columba host: IndexInterface::approxMatchesNaive) and keeps the rest of the chunk.
+// Reads not longer than the number of parts of the search scheme (and every read of a one-part strategy) are matched by naive
+// backtracking, as in the reference (searchstrategy.cpp:148-152, :442-459; indexinterface.cpp:1055-1210 -> dev_bfs_naive.hpp).
+// cmb_batch_read_status says which reads took that path; cmb_batch_allow_unsupported is kept for older callers and has no effect.
 extern "C" int cmb_batch_allow_unsupported(cmb_batch* b, int on) {
     if (!b) return fail(CMB_ERR_INVALID, "null argument");
     b->allowUnsupported = on != 0;

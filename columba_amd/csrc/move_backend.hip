@@ -627,6 +627,12 @@ struct cmb_move_batch {
     MvBuf<uint64_t> widths, locWidths, locOff, positions, readCnt, readOff;
     MvBuf<MoveOccOut> out;
     size_t qCap = 0, evCap = 0, fCap = 0, cCap = 0, aCap = 0;
+    // naive backtracking (k_mvs_naive): node double buffer, nodes per pass, the survivors of its own filter pass per read x strand
+    MvBuf<uint4> nvQ[2];
+    MvBuf<uint32_t> nvCnt;
+    size_t nvQCap = 0;
+    MvBuf<MoveOccOut> naiveOut;
+    MvBuf<uint64_t> naiveOff;
     // results
     std::vector<cmb_move_occ> occs;
     std::vector<uint64_t> occOffs;
@@ -814,6 +820,7 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
         uint32_t maxSearches = 0;
         for (int i = 0; i < b->hostStrat.nSchemes; i++) maxSearches = std::max<uint32_t>(maxSearches, b->hostStrat.sch[i].nSearches);
         uint32_t nFm = 0;
+        bool hasNaive = false; // reads of the slice are matched by naive backtracking (k_mvs_parts marked them in psel)
         for (int attempt = 0;; attempt++) {
             if (attempt >= 30) return failWith(CMB_ERR_INTERNAL, "work queues keep overflowing");
             MV_HIPCHK(hipMemsetAsync(b->cnt.p, 0, 8 * sizeof(uint32_t), s));
@@ -825,7 +832,8 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
             {
                 const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)tasksRS + 63) / 64, 256 * 64);
                 auto kp = b->hostStrat.partition == 0 ? k_mvs_parts<0> : b->hostStrat.partition == 1 ? k_mvs_parts<1> : k_mvs_parts<2>;
-                hipLaunchKernelGGL(kp, dim3(grid), dim3(64), 0, s, sx, b->strat.p, nReads, b->maxLen, b->seq.p, dOffs, b->parts.p, b->exr.p, b->psel.p, q);
+                hipLaunchKernelGGL(kp, dim3(grid), dim3(64), (size_t)P * 3 * 64 * sizeof(uint4), s, sx, b->strat.p, nReads, b->maxLen, b->seq.p, dOffs, b->parts.p, b->exr.p,
+                                   b->psel.p, q);
                 const uint64_t nWork = (uint64_t)tasksRS * maxSearches;
                 const unsigned gridE = (unsigned)std::min<uint64_t>((nWork + 63) / 64, 256 * 64);
                 hipLaunchKernelGGL(k_mvs_exact, dim3(gridE), dim3(64), 0, s, sx, b->strat.p, nReads, b->maxLen, maxSearches, b->seq.p, b->parts.p, b->exr.p,
@@ -835,13 +843,56 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
             MV_HIPCHK(hipGetLastError());
             MV_HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
             MV_HIPCHK(hipStreamSynchronize(s));
-            if (hcnt[3] & FLAG_UNSUPPORTED_READ)
-                return failWith(CMB_ERR_UNSUPPORTED, "a read is not longer than the number of parts of the search scheme (the reference falls back to "
-                                                     "naive backtracking, which the device path does not provide)");
+            hasNaive = (hcnt[3] & FLAG_UNSUPPORTED_READ) != 0;
             if (hcnt[3] & FLAG_SEED_OVERLAP)
                 return failWith(CMB_ERR_INVALID, "dynamic partitioning: the seeds of a read overlap — the k-mer size is too large for the seeding "
                                                  "positions of this search strategy at this read length");
             if (hcnt[3] & FLAG_DFS_OVERFLOW) return failWith(CMB_ERR_INTERNAL, "task queue too small");
+            if (hasNaive) {
+                // ---- reads not longer than the number of parts / one-part strategies: naive backtracking (k_mvs_naive)
+                tm.begin();
+                const bool edit = b->metric == CMB_METRIC_EDIT;
+                const uint32_t maxPassN = b->maxLen + 2 * b->k + 4;
+                constexpr uint32_t PU = MvTraits::PAIR_U4;
+                if (!b->nvQCap) b->nvQCap = getenv("CMB_TEST_SMALL_POOLS") ? 64 : 16384;
+                for (int j = 0; j < 2; j++)
+                    if (b->nvQ[j].n < (PU + 2) * b->nvQCap) b->nvQ[j].alloc((PU + 2) * b->nvQCap);
+                const size_t cntWords = (size_t)maxPassN + 2;
+                if (b->nvCnt.n < cntWords) b->nvCnt.alloc(cntWords);
+                MV_HIPCHK(hipMemsetAsync(b->nvCnt.p, 0, cntWords * sizeof(uint32_t), s));
+                MvHbfsBufs N{};
+                N.Q[0] = b->nvQ[0].p;
+                N.Q[1] = b->nvQ[1].p;
+                N.qCap = (uint32_t)std::min<size_t>(b->nvQ[0].n / (PU + 2), 0xFFFFFFF0u);
+                N.nq = b->nvCnt.p;
+                N.blockCnt = nullptr;
+                N.fmX = b->fm.p;
+                hipLaunchKernelGGL((edit ? k_mvs_naive<true, true> : k_mvs_naive<false, true>), dim3((tasksRS + 255) / 256), dim3(256), 0, s, ix->d, N, 0u,
+                                   (const uint8_t*)b->psel.p, tasksRS, dOffs, b->gw, b->G.p, b->seq.p, b->maxLen, b->k, q);
+                std::vector<uint32_t> hc(cntWords);
+                uint32_t pass = 0, peakQ = 0;
+                bool drained = false;
+                while (!drained && pass < maxPassN) {
+                    const uint32_t upTo = std::min(pass + 16u, maxPassN);
+                    for (; pass < upTo; pass++)
+                        hipLaunchKernelGGL((edit ? k_mvs_naive<true, false> : k_mvs_naive<false, false>), dim3(BFS_GRID), dim3(256), 0, s, ix->d, N, pass,
+                                           (const uint8_t*)b->psel.p, tasksRS, dOffs, b->gw, b->G.p, b->seq.p, b->maxLen, b->k, q);
+                    MV_HIPCHK(hipMemcpyAsync(hc.data(), b->nvCnt.p, cntWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    MV_HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
+                    MV_HIPCHK(hipStreamSynchronize(s));
+                    if (hcnt[3] & MVS_NAIVE_STOP) break;
+                    drained = hc[pass] == 0;
+                }
+                for (uint32_t p2 = 0; p2 <= pass && p2 < cntWords; p2++) peakQ = std::max(peakQ, hc[p2]);
+                tm.end("k_naive");
+                MV_HIPCHK(hipGetLastError());
+                if (hcnt[3] & MVS_NAIVE_STOP) {
+                    if (hcnt[3] & FLAG_NAIVE_Q) b->nvQCap = std::max<size_t>(2 * b->nvQCap, (size_t)peakQ + peakQ / 4);
+                    if (hcnt[3] & FLAG_FMOCC_OVERFLOW) b->fm.alloc(std::max<size_t>(2 * b->fm.n, (size_t)hcnt[1] + hcnt[1] / 4 + 1024));
+                    continue;
+                }
+                if (!drained) return failWith(CMB_ERR_INTERNAL, "the naive search did not finish within its pass bound");
+            }
             const uint32_t nTasks = hcnt[5];
             if (nTasks && b->metric != CMB_METRIC_EDIT) {
                 // ---- Hamming distance: the frontier without a matrix (k_mvs_hbfs), one row per pass
@@ -931,7 +982,7 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                 B.fCap = (uint32_t)std::min<size_t>(b->F.n / (PU + 1), 0xFFFFFFF0u);
                 B.cCap = (uint32_t)std::min<size_t>(b->C.n / CTX_U4, 0xFFFFFFF0u);
                 B.aCap = (uint32_t)std::min<size_t>(b->A.n, 0xFFFFFFF0u);
-                B.chain = 1;
+                B.chain = getenv("CMB_MVS_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("CMB_MVS_CHAIN"))) : MVS_CHAIN;
                 B.gridX = getenv("CMB_MVS_GRID") ? (uint32_t)std::min<int>(BFS_GRID, std::max(1, atoi(getenv("CMB_MVS_GRID")))) : BFS_GRID_X;
                 B.gridEv = BFS_GRID_EV;
                 B.nq = b->bfsCnt.p;
@@ -1035,29 +1086,49 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
         }
         tm.end("locate");
         tm.begin();
-        if (b->readCnt.n < (size_t)nReads + 1) b->readCnt.alloc((size_t)nReads + 1), b->readOff.alloc((size_t)nReads + 1);
-        uint64_t nOut = 0;
-        if (totalPos) {
-            hipLaunchKernelGGL(k_mvs_text_keys, dim3(gridFor(totalPos)), dim3(256), 0, s, b->positions.p, b->locOff.p, nUniq, totalPos, b->locMeta.p, b->keysA.p,
-                               b->vals.p, b->bad.p);
+        if (b->readCnt.n < (size_t)2 * nReads + 1) b->readCnt.alloc((size_t)2 * nReads + 1), b->readOff.alloc((size_t)2 * nReads + 1);
+        uint64_t nOut = 0, nNaiveKept = 0;
+        const uint32_t window = b->metric == CMB_METRIC_EDIT ? b->k : 0u;
+        const uint32_t uniqueOnly = b->metric == CMB_METRIC_EDIT ? 0u : 1u; // (getTextOccHamming, indexinterface.cpp:1331-1371: no redundancy filter)
+        auto sortAndFilter = [&](uint64_t nKeys, uint32_t nGroups, MvBuf<MoveOccOut>& dst, uint64_t& kept) {
             size_t tb = 0;
-            MV_HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->keysA.p, b->keysB.p, b->vals.p, b->valsB.p, (int)totalPos, 0, 64, s));
+            MV_HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->keysA.p, b->keysB.p, b->vals.p, b->valsB.p, (int)nKeys, 0, 64, s));
             if (b->sortTmp.n < tb) b->sortTmp.alloc(tb + tb / 4);
-            MV_HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->sortTmp.p, tb, b->keysA.p, b->keysB.p, b->vals.p, b->valsB.p, (int)totalPos, 0, 64, s));
-            MV_HIPCHK(hipMemsetAsync(b->readCnt.p, 0, ((size_t)nReads + 1) * sizeof(uint64_t), s));
-            const uint32_t window = b->metric == CMB_METRIC_EDIT ? b->k : 0u; // (getTextOccHamming, indexinterface.cpp:1331-1371: no redundancy filter)
-            hipLaunchKernelGGL(k_mvs_filter<false>, dim3(gridFor(nReads)), dim3(256), 0, s, b->keysB.p, b->valsB.p, totalPos, nReads, window, b->readCnt.p,
-                               (const uint64_t*)nullptr, (MoveOccOut*)nullptr);
+            MV_HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->sortTmp.p, tb, b->keysA.p, b->keysB.p, b->vals.p, b->valsB.p, (int)nKeys, 0, 64, s));
+            MV_HIPCHK(hipMemsetAsync(b->readCnt.p, 0, ((size_t)nGroups + 1) * sizeof(uint64_t), s));
+            hipLaunchKernelGGL(k_mvs_filter<false>, dim3(gridFor(nGroups)), dim3(256), 0, s, b->keysB.p, b->valsB.p, nKeys, nGroups, window, b->readCnt.p,
+                               (const uint64_t*)nullptr, (MoveOccOut*)nullptr, uniqueOnly);
             tb = 0;
-            MV_HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, b->readCnt.p, b->readOff.p, (int)(nReads + 1), s));
+            MV_HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, b->readCnt.p, b->readOff.p, (int)(nGroups + 1), s));
             if (b->sortTmp.n < tb) b->sortTmp.alloc(tb + tb / 4);
-            MV_HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->sortTmp.p, tb, b->readCnt.p, b->readOff.p, (int)(nReads + 1), s));
-            MV_HIPCHK(hipMemcpyAsync(&nOut, b->readOff.p + nReads, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            MV_HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->sortTmp.p, tb, b->readCnt.p, b->readOff.p, (int)(nGroups + 1), s));
+            MV_HIPCHK(hipMemcpyAsync(&kept, b->readOff.p + nGroups, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
             MV_HIPCHK(hipStreamSynchronize(s));
-            if (b->out.n < nOut) b->out.alloc(nOut + nOut / 4 + 256);
-            if (nOut)
-                hipLaunchKernelGGL(k_mvs_filter<true>, dim3(gridFor(nReads)), dim3(256), 0, s, b->keysB.p, b->valsB.p, totalPos, nReads, window, b->readCnt.p,
-                                   b->readOff.p, b->out.p);
+            if (dst.n < kept) dst.alloc(kept + kept / 4 + 256);
+            if (kept)
+                hipLaunchKernelGGL(k_mvs_filter<true>, dim3(gridFor(nGroups)), dim3(256), 0, s, b->keysB.p, b->valsB.p, nKeys, nGroups, window, b->readCnt.p,
+                                   b->readOff.p, dst.p, uniqueOnly);
+        };
+        if (totalPos) {
+            if (hasNaive) { // the naive path's own filter pass, per read x strand (indexinterface.cpp:1137, :1205)
+                hipLaunchKernelGGL(k_mvs_text_keys, dim3(gridFor(totalPos)), dim3(256), 0, s, b->positions.p, b->locOff.p, nUniq, totalPos, b->locMeta.p,
+                                   b->keysA.p, b->vals.p, b->bad.p, (const uint8_t*)b->psel.p, 1);
+                sortAndFilter(totalPos, 2 * nReads, b->naiveOut, nNaiveKept);
+                if (b->naiveOff.n < (size_t)2 * nReads + 1) b->naiveOff.alloc((size_t)2 * nReads + 1);
+                MV_HIPCHK(hipMemcpyAsync(b->naiveOff.p, b->readOff.p, ((size_t)2 * nReads + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+                const uint64_t need = totalPos + nNaiveKept;
+                if (need >= (1ull << 31)) return failWith(CMB_ERR_UNSUPPORTED, "2^31 and more text positions in one b-move batch");
+                if (b->keysA.n < need || b->vals.n < need) {
+                    MV_HIPCHK(hipStreamSynchronize(s));
+                    b->keysA.alloc(need + 256), b->keysB.alloc(need + 256), b->vals.alloc(need + 256), b->valsB.alloc(need + 256);
+                }
+            }
+            hipLaunchKernelGGL(k_mvs_text_keys, dim3(gridFor(totalPos)), dim3(256), 0, s, b->positions.p, b->locOff.p, nUniq, totalPos, b->locMeta.p, b->keysA.p,
+                               b->vals.p, b->bad.p, (const uint8_t*)b->psel.p, hasNaive ? 2 : 0);
+            if (nNaiveKept)
+                hipLaunchKernelGGL(k_mvs_occ_keys, dim3(gridFor(2 * nReads)), dim3(256), 0, s, b->naiveOut.p, b->naiveOff.p, 2 * nReads, b->keysA.p + totalPos,
+                                   b->vals.p + totalPos);
+            sortAndFilter(totalPos + nNaiveKept, nReads, b->out, nOut);
         }
         tm.end("filter");
         MV_HIPCHK(hipGetLastError());
@@ -1077,7 +1148,7 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
             return failWith(CMB_ERR_INTERNAL, std::to_string(hb) + " occurrences whose phi chains do not have the width of their range, or whose "
                                                                    "fields do not fit the filter keys");
         for (int i = 0; i < CMB_CNT_MAX; i++) b->cnts[i] += hc64[i];
-        b->cnts[CMB_CNT_TOTAL_REPORTED] += totalPos;
+        b->cnts[CMB_CNT_TOTAL_REPORTED] += totalPos + nNaiveKept; // (the naive path's survivors are reported again as text occurrences of the read)
         b->cnts[CMB_CNT_LOCATED_ROWS] += totalPos;
         return CMB_OK;
     } catch (const std::exception& e) {

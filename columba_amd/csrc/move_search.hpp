@@ -45,8 +45,7 @@ struct MvTraits {
     typedef MvPair Pair;
     typedef MvTask Task;
     static constexpr uint32_t PAIR_U4 = 3;
-    static __device__ __forceinline__ Pair load(const uint4* p, size_t stride) {
-        const uint4 a = p[0], b = p[stride], c = p[2 * stride];
+    static __device__ __forceinline__ Pair unpack(const uint4& a, const uint4& b, const uint4& c) {
         const uint64_t w0 = u64of(a.x, a.y), w1 = u64of(a.z, a.w), w2 = u64of(b.x, b.y), w3 = u64of(b.z, b.w), w4 = u64of(c.x, c.y),
                        w5 = u64of(c.z, c.w);
         Pair r;
@@ -65,7 +64,7 @@ struct MvTraits {
         r.repEnd = (w5 >> 58) & 1u;
         return r;
     }
-    static __device__ __forceinline__ void store(uint4* p, size_t stride, const Pair& r) {
+    static __device__ __forceinline__ void pack(const Pair& r, uint4& a, uint4& b, uint4& c) {
         const uint64_t w0 = (r.sa.begin & MV_M40) | r.sa.end << 40;
         const uint64_t w1 = (r.sa.end & MV_M40) >> 24 | (r.sa.beginRun & MV_M40) << 16 | r.sa.endRun << 56;
         const uint64_t w2 = (r.sa.endRun & MV_M40) >> 8 | r.rev.begin << 32;
@@ -73,9 +72,17 @@ struct MvTraits {
         const uint64_t w4 = (r.rev.beginRun & MV_M40) >> 16 | (r.rev.endRun & MV_M40) << 24;
         const uint64_t w5 = (r.toehold & MV_M40) | (uint64_t)(r.depth & 0xFFFFu) << 40 | (uint64_t)(r.sa.valid ? 1 : 0) << 56 |
                             (uint64_t)(r.rev.valid ? 1 : 0) << 57 | (uint64_t)(r.repEnd ? 1 : 0) << 58;
-        p[0] = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
-        p[stride] = make_uint4((uint32_t)w2, (uint32_t)(w2 >> 32), (uint32_t)w3, (uint32_t)(w3 >> 32));
-        p[2 * stride] = make_uint4((uint32_t)w4, (uint32_t)(w4 >> 32), (uint32_t)w5, (uint32_t)(w5 >> 32));
+        a = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
+        b = make_uint4((uint32_t)w2, (uint32_t)(w2 >> 32), (uint32_t)w3, (uint32_t)(w3 >> 32));
+        c = make_uint4((uint32_t)w4, (uint32_t)(w4 >> 32), (uint32_t)w5, (uint32_t)(w5 >> 32));
+    }
+    static __device__ __forceinline__ Pair load(const uint4* p, size_t stride) { return unpack(p[0], p[stride], p[2 * stride]); }
+    static __device__ __forceinline__ void store(uint4* p, size_t stride, const Pair& r) {
+        uint4 a, b, c;
+        pack(r, a, b, c);
+        p[0] = a;
+        p[stride] = b;
+        p[2 * stride] = c;
     }
     static __device__ __forceinline__ Pair none() {
         Pair p;
@@ -121,12 +128,23 @@ struct RowCount {
 //    round issues the next row of every unfinished end point before any reply is consumed).
 // Everything indexed by character is unrolled: the state stays in registers.  `need`: bit c - 1 = child c is wanted in
 // full; the others only contribute their width to the cumulative counts.  Returns the mask of non-empty children.
+// (a range chosen field by field: `cond ? a : b` on the objects makes the compiler choose between two ADDRESSES, which puts both
+// objects — and whatever they were copied from — into scratch memory)
+__device__ __forceinline__ MvRange selRange(bool c, const MvRange& a, const MvRange& b) {
+    MvRange r;
+    r.begin = c ? a.begin : b.begin;
+    r.end = c ? a.end : b.end;
+    r.beginRun = c ? a.beginRun : b.beginRun;
+    r.endRun = c ? a.endRun : b.endRun;
+    r.valid = c ? a.valid : b.valid;
+    return r;
+}
 __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const int mode, const MvPair& parent, MvPair child[4], uint32_t& rows,
                                                const uint32_t need = 0xFu) {
     const bool fw = mode == 0;
     const MoveTable& t = fw ? ix.rev : ix.fwd;
-    MvRange trivial = fw ? parent.rev : parent.sa;
-    const MvRange other = fw ? parent.sa : parent.rev;
+    MvRange trivial = selRange(fw, parent.rev, parent.sa);
+    const MvRange other = selRange(fw, parent.sa, parent.rev);
     if (!trivial.valid) { // (two binary searches between the enclosing run indices)
         uint64_t span = trivial.endRun - trivial.beginRun;
         while (span) {
@@ -250,19 +268,21 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
         if (need >> c & 1u) {
             const MvRange range1 = {fOut[c], lOut[c] + 1, fRun[c], lRun[c], true};
             MvRange second;
+            const MvRange noRange{0, 0, 0, 0, true};
             if (width == parentWidth) { // the other range and the toehold carry over
-                second = mode == 2 ? MvRange{0, 0, 0, 0, true} : other;
+                second = selRange(mode == 2, noRange, other);
                 ch.toehold = fw ? parent.toehold + (parent.repEnd ? 1 : 0) : parent.toehold - (parent.repEnd ? 0 : 1);
                 ch.repEnd = parent.repEnd;
             } else {
-                second = mode == 2 ? MvRange{0, 0, 0, 0, true} : MvRange{other.begin + cum, other.begin + cum + width, other.beginRun, other.endRun, false};
+                const MvRange narrowed{other.begin + cum, other.begin + cum + width, other.beginRun, other.endRun, false};
+                second = selRange(mode == 2, noRange, narrowed);
                 // BMove::computeToehold / computeToeholdRev (bmove.cpp:222-266): the last run of the range that holds the character
                 const uint64_t smp = lSrc[c] == trivial.endRun ? t.samplesFirst[trivial.endRun] : t.samplesLast[lSrc[c]];
                 ch.toehold = fw ? ix.n - 1 - (smp - 1) : smp - 1;
                 ch.repEnd = fw;
             }
-            ch.sa = fw ? second : range1;
-            ch.rev = fw ? range1 : second;
+            ch.sa = selRange(fw, second, range1);
+            ch.rev = selRange(fw, range1, second);
             ch.depth = parent.depth + 1;
         }
         cum += width;
@@ -341,6 +361,10 @@ k_mvs_parts(MvSearchIndex sx, const DevStrategyK* __restrict__ stp, uint32_t nRe
             const uint64_t* __restrict__ offs, PartOut* __restrict__ partsOut, MoveRangeRec* __restrict__ exr, uint8_t* __restrict__ psel, Queues q) {
     __shared__ uint32_t pbe[MAXP][64];
     __shared__ unsigned long long wid[MAXP][64];
+    // the exact-match range pair of every part while the read is partitioned: [part][plane][lane], packed as in the frontier's
+    // records (3 x 16 bytes).  Dynamic partitioning extends a different part at almost every step; with the pairs in global memory
+    // each step was a scattered 80-byte load and store around its row fetches (k_partition: 528 GB of traffic per 10^6-read step).
+    extern __shared__ uint4 exLds[];
     const DevStrategyK& st = *stp;
     const MoveDev& ix = sx.d;
     const uint32_t lane = threadIdx.x, total = 2 * nReads;
@@ -359,7 +383,8 @@ k_mvs_parts(MvSearchIndex sx, const DevStrategyK* __restrict__ stp, uint32_t nRe
         auto PB = [&](int i) -> uint32_t { return pbe[i][lane] & 0xFFFFu; };
         auto PE = [&](int i) -> uint32_t { return pbe[i][lane] >> 16; };
         auto setPBE = [&](int i, uint32_t b, uint32_t e) { pbe[i][lane] = (b & 0xFFFFu) | (e << 16); };
-        auto exAt = [&](int i) -> MoveRangeRec* { return exr + (size_t)i * total + rs; };
+        auto putEx = [&](int i, const MvPair& r) { MvTraits::pack(r, exLds[(i * 3 + 0) * 64 + lane], exLds[(i * 3 + 1) * 64 + lane], exLds[(i * 3 + 2) * 64 + lane]); };
+        auto getEx = [&](int i) -> MvPair { return MvTraits::unpack(exLds[(i * 3 + 0) * 64 + lane], exLds[(i * 3 + 1) * 64 + lane], exLds[(i * 3 + 2) * 64 + lane]); };
         auto kmer = [&](uint32_t begin, uint32_t end) -> MvPair { // lookUpInKmerTable (indexinterface.h:590-594)
             uint32_t key = 0;
             bool valid = true;
@@ -403,7 +428,7 @@ k_mvs_parts(MvSearchIndex sx, const DevStrategyK* __restrict__ stp, uint32_t nRe
                     for (uint32_t j = end; j-- > b;)
                         if (!mvAddChar(ix, 2, seq[j], r, cnt)) break;
                 }
-                *exAt(i) = storePair(r);
+                putEx(i, r);
                 wid[i][lane] = r.sa.end > r.sa.begin ? r.sa.end - r.sa.begin : 0;
             }
         } else { // seed (:381-419) + partitionDynamic (:299-379)
@@ -440,7 +465,7 @@ k_mvs_parts(MvSearchIndex sx, const DevStrategyK* __restrict__ stp, uint32_t nRe
                         }
                     }
                 }
-                *exAt(i) = storePair(r);
+                putEx(i, r);
                 wid[i][lane] = r.sa.end > r.sa.begin ? r.sa.end - r.sa.begin : 0;
             }
             int partToExtend = 0, dynDir = 0;
@@ -474,9 +499,9 @@ k_mvs_parts(MvSearchIndex sx, const DevStrategyK* __restrict__ stp, uint32_t nRe
                     setPBE(partToExtend, PB(partToExtend) - 1, PE(partToExtend));
                     code = seq[PB(partToExtend)];
                 }
-                MvPair r = loadPair(*exAt(partToExtend));
+                MvPair r = getEx(partToExtend);
                 (void)mvAddChar(ix, partToExtend == P - 1 ? 2 : dynDir, code, r, cnt);
-                *exAt(partToExtend) = storePair(r);
+                putEx(partToExtend, r);
                 wid[partToExtend][lane] = r.sa.end > r.sa.begin ? r.sa.end - r.sa.begin : 0;
             }
         }
@@ -504,6 +529,7 @@ k_mvs_parts(MvSearchIndex sx, const DevStrategyK* __restrict__ stp, uint32_t nRe
         }
         partsOut[rs] = po;
         psel[rs] = (uint8_t)sel;
+        for (int i = 0; i < P; i++) exr[(size_t)i * total + rs] = storePair(getEx(i)); // (k_mvs_exact starts from these)
     }
     const uint32_t local[3] = {cnt.nodes, cnt.expansions, cnt.rows};
     const int which[3] = {0, 7, 13};
@@ -600,59 +626,113 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
         const bool act = i < nIn;
         uint32_t kinds = 0; // 4 bits per child: kind | needF << 2
         uint32_t row1 = 0, ctx = 0, fcP = BFS_NONE;
-        MvPair ch[4];
+        uint4 pk[4][3]; // the children's range pairs, packed as they are stored (twelve registers each instead of twenty-one)
         uint64_t cHP[4], cHN[4];
-        uint32_t cSc[4], cRac[4], cAux[4];
+        uint32_t cMeta[4]; // score << 16 | RAC bit << 8 | final-column distance
         MatGeom g{};
         uint32_t clSize = 0;
         int md = 0;
+        MvPair parent{};
+        uint32_t row = 0, score = 0, pRac = 0, blk = 0;
+        uint64_t pHP = 0, pHN = 0;
+        uint4 mA = make_uint4(0, 0, 0, 0), mB = mA;
+        const uint4* Cx = B.C;
         if (act) {
             const uint4 n1 = Qi[(size_t)PU * qCap + i], n2 = Qi[(size_t)(PU + 1) * qCap + i];
-            const MvPair parent = MvTraits::load(Qi + i, qCap);
+            parent = MvTraits::load(Qi + i, qCap);
             ctx = n1.y;
             fcP = n1.z;
-            const uint32_t row = n1.x & 0xFFFFu, score = n1.x >> 16;
+            row = n1.x & 0xFFFFu;
+            score = n1.x >> 16;
             md = (int)((n1.w >> 8) & 3u);
-            const uint4* Cx = B.C + (size_t)CMB_IDX(ctx, B.cCap, 1) * CTX_U4;
-            row1 = row + 1;
-            const uint32_t blk = row1 / MX_BLOCK;
+            Cx = B.C + (size_t)CMB_IDX(ctx, B.cCap, 1) * CTX_U4;
+            blk = (row + 1) / MX_BLOCK;
             const uint4 hot = Cx[CTX_HOT];
-            const uint4 mA = Cx[CTX_M + 2 * blk], mB = Cx[CTX_M + 1 + 2 * blk];
+            mA = Cx[CTX_M + 2 * blk];
+            mB = Cx[CTX_M + 1 + 2 * blk];
             g.n = hot.y & 0x1FFu;
             g.m = (hot.y >> 9) & 0x1FFu;
             g.Wv = (hot.y >> 18) & 31u;
             g.Wh = (hot.y >> 23) & 15u;
             g.maxED = (hot.y >> 27) & 15u;
             clSize = hot.w >> 23;
-            const uint64_t pHP = u64of(n2.x, n2.y), pHN = u64of(n2.z, n2.w);
-            const uint32_t pRac = n1.w & 63u;
-            uint32_t rows = 0;
-            const uint32_t mask = moveChildrenCounted(ix, md, parent, ch, rows);
-            cRows += rows;
-            cExp++;
-            const bool inFC = g.inFinalColumn(row1);
-            if (inFC && clSize + row1 - g.m >= ED_CELLS) flags |= FLAG_CAPACITY;
-#pragma unroll
-            for (uint32_t c = 0; c < 4; c++) {
-                if (!(mask >> c & 1u)) continue;
-                cChildren++;
-                const uint64_t M = c == 0 ? u64of(mA.x, mA.y) : c == 1 ? u64of(mA.z, mA.w) : c == 2 ? u64of(mB.x, mB.y) : u64of(mB.z, mB.w);
-                uint64_t HP = pHP, HN = pHN, RAC = 1ull << pRac, D0;
-                uint32_t sc = score;
-                const bool valid = computeRow(g, row1, M, HP, HN, D0, RAC, sc);
-                if (!valid && !inFC) continue; // pruned when popped (branchAndBound returns true, :560)
-                uint32_t res = KIND_NODE, aux = 0;
-                if (inFC) {
-                    const uint32_t ed = cellAt(row1, g.n - 1, HP, HN, sc);
-                    aux = min(ed, 31u);
-                    res |= 4u;
-                    if (ed > 31u) flags |= FLAG_CAPACITY;
-                    if (!valid || onlyVerticalGapsLeft(g, row1, HN)) res = (res & ~3u) | KIND_EVENT;
+            pHP = u64of(n2.x, n2.y);
+            pHN = u64of(n2.z, n2.w);
+            pRac = n1.w & 63u;
+        }
+        // ---- walk: an expansion that yields exactly one plain node (outside the final column) is followed at once by the
+        // expansion of that child, by the same lane — no node record written and read back, no queue slot — for up to B.chain
+        // rows; on this index most of a search is such a path (no in-text switch ends it: ranges stay narrow down to the last
+        // row).  The lane stops at the first expansion that produces anything else; its children are what is appended below.
+        bool walking = act;
+        for (uint32_t step = 0; step < B.chain; step++) { // (wave-uniform exit below)
+            if (walking) {
+                row1 = row + 1;
+                if (row1 / MX_BLOCK != blk) { // the walk crossed into the next 32-row block: its match words
+                    blk = row1 / MX_BLOCK;
+                    mA = Cx[CTX_M + 2 * blk];
+                    mB = Cx[CTX_M + 1 + 2 * blk];
                 }
-                kinds |= res << (4 * c);
-                cHP[c] = HP, cHN[c] = HN, cSc[c] = sc, cAux[c] = aux;
-                cRac[c] = (uint32_t)__ffsll((unsigned long long)RAC) - 1u;
+                uint32_t rows = 0, mask;
+#pragma unroll
+                for (uint32_t c = 0; c < 4; c++) { // (nothing of the previous expansion stays alive across the scan)
+                    pk[c][0] = pk[c][1] = pk[c][2] = make_uint4(0, 0, 0, 0);
+                    cHP[c] = cHN[c] = 0;
+                    cMeta[c] = 0;
+                }
+                {
+                    MvPair ch[4];
+                    mask = moveChildrenCounted(ix, md, parent, ch, rows);
+#pragma unroll
+                    for (uint32_t c = 0; c < 4; c++)
+                        if (mask >> c & 1u) MvTraits::pack(ch[c], pk[c][0], pk[c][1], pk[c][2]);
+                }
+                cRows += rows;
+                cExp++;
+                const bool inFC = g.inFinalColumn(row1);
+                if (inFC && clSize + row1 - g.m >= ED_CELLS) flags |= FLAG_CAPACITY;
+                kinds = 0;
+#pragma unroll
+                for (uint32_t c = 0; c < 4; c++) {
+                    if (!(mask >> c & 1u)) continue;
+                    cChildren++;
+                    const uint64_t M = c == 0 ? u64of(mA.x, mA.y) : c == 1 ? u64of(mA.z, mA.w) : c == 2 ? u64of(mB.x, mB.y) : u64of(mB.z, mB.w);
+                    uint64_t HP = pHP, HN = pHN, RAC = 1ull << pRac, D0;
+                    uint32_t sc = score;
+                    const bool valid = computeRow(g, row1, M, HP, HN, D0, RAC, sc);
+                    if (!valid && !inFC) continue; // pruned when popped (branchAndBound returns true, :560)
+                    uint32_t res = KIND_NODE, aux = 0;
+                    if (inFC) {
+                        const uint32_t ed = cellAt(row1, g.n - 1, HP, HN, sc);
+                        aux = min(ed, 31u);
+                        res |= 4u;
+                        if (ed > 31u) flags |= FLAG_CAPACITY;
+                        if (!valid || onlyVerticalGapsLeft(g, row1, HN)) res = (res & ~3u) | KIND_EVENT;
+                    }
+                    kinds |= res << (4 * c);
+                    cHP[c] = HP, cHN[c] = HN;
+                    if (sc > 0xFFFFu) flags |= FLAG_CAPACITY;
+                    cMeta[c] = (sc << 16) | (((uint32_t)__ffsll((unsigned long long)RAC) - 1u) << 8) | aux;
+                }
+                const bool single = kinds == (uint32_t)KIND_NODE || kinds == ((uint32_t)KIND_NODE << 4) || kinds == ((uint32_t)KIND_NODE << 8) ||
+                                    kinds == ((uint32_t)KIND_NODE << 12);
+                if (single && step + 1u < B.chain && row1 + 1u < (uint32_t)CTX_MBLK * MX_BLOCK) {
+#pragma unroll
+                    for (uint32_t c = 0; c < 4; c++)
+                        if (kinds == ((uint32_t)KIND_NODE << (4 * c))) {
+                            parent = MvTraits::unpack(pk[c][0], pk[c][1], pk[c][2]);
+                            pHP = cHP[c];
+                            pHN = cHN[c];
+                            score = cMeta[c] >> 16;
+                            pRac = (cMeta[c] >> 8) & 63u;
+                        }
+                    row = row1;
+                    kinds = 0; // (nothing of this expansion is left to append)
+                } else {
+                    walking = false;
+                }
             }
+            if (__ballot(walking) == 0ull) break;
         }
         uint32_t nNode = 0, nEv = 0, nF = 0;
 #pragma unroll
@@ -686,22 +766,22 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
                 if (wantF) {
                     fc = oF++;
                     uint4* Fr = B.F + (size_t)CMB_IDX(fc, B.fCap, 9) * FU;
-                    MvTraits::store(Fr, 1, ch[c]);
+                    Fr[0] = pk[c][0], Fr[1] = pk[c][1], Fr[2] = pk[c][2];
                     Fr[PU] = make_uint4(row1 | ((c + 1) << 16), fcP, 0u, 0u);
                 }
                 if (kd == KIND_NODE) {
                     const uint32_t o = oNode++;
-                    MvTraits::store(Qo + o, qCap, ch[c]);
-                    Qo[(size_t)PU * qCap + o] = make_uint4(row1 | (cSc[c] << 16), ctx, fc, cRac[c] | ((uint32_t)md << 8));
+                    Qo[o] = pk[c][0], Qo[(size_t)qCap + o] = pk[c][1], Qo[(size_t)2 * qCap + o] = pk[c][2];
+                    Qo[(size_t)PU * qCap + o] = make_uint4(row1 | (cMeta[c] & 0xFFFF0000u), ctx, fc, ((cMeta[c] >> 8) & 63u) | ((uint32_t)md << 8));
                     Qo[(size_t)(PU + 1) * qCap + o] = make_uint4((uint32_t)cHP[c], (uint32_t)(cHP[c] >> 32), (uint32_t)cHN[c], (uint32_t)(cHN[c] >> 32));
                     if (wantF) {
                         EdPack p2 = pack;
-                        edPut(p2, cell, cAux[c]);
+                        edPut(p2, cell, cMeta[c] & 31u);
                         Qo[(size_t)(PU + 2) * qCap + o] = make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32));
                     }
                 } else { // KIND_EVENT
                     EdPack p2 = pack;
-                    edPut(p2, cell, cAux[c]);
+                    edPut(p2, cell, cMeta[c] & 31u);
                     Eo[(size_t)2 * oEv] = make_uint4(ctx, fc, 0xFFFFFFFFu, cell);
                     Eo[(size_t)2 * oEv + 1] = make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32));
                     oEv++;
@@ -733,6 +813,7 @@ k_mvs_start(const DevStrategyK* __restrict__ stp, MvBufs B, const MvTask* __rest
     if (blockStopped(q)) return;
     bfsHeavy<true, MvTraits>(stp, B, 0u, tasks, nTasks, offs, gw, G, parts, q, blockIdx.x, gridDim.x);
 }
+constexpr uint32_t MVS_CHAIN = 8; // expansions a lane makes in a row while each yields exactly one plain node (CMB_MVS_CHAIN)
 #ifndef CMB_MVS_WAVES
 #define CMB_MVS_WAVES 2 // wavefronts per SIMD the register allocation of k_mvs_pass is held to
 #endif
@@ -896,6 +977,145 @@ k_mvs_hbfs(MoveDev ix, const DevStrategyK* __restrict__ stp, MvHbfsBufs B, uint3
     if (flags) atomicOr(&q.cnt[3], flags);
 }
 
+// ------------------------------------------------------------------ naive backtracking
+// IndexInterface::approxMatchesNaive / approxMatchesNaiveHamming (indexinterface.cpp:1055-1209, RUN_LENGTH_COMPRESSION branches: no
+// in-text switch) for the reads k_mvs_parts marks (psel bit 7: not longer than the number of parts, or a one-part strategy —
+// searchstrategy.cpp:148-152, :442-459).  As dev_bfs_naive.hpp on this backend: a node is the range pair (3 planes) + one plane
+// {rsId, row | score << 16, RAC bit | mismatches << 8, -} + (edit distance) one plane {HP, HN}; the whole pattern is matched backward
+// from the complete range (unidirectional: mode 2), every final-column node within the bound is an in-index occurrence.
+constexpr uint32_t MVS_NAIVE_STOP = FLAG_NAIVE_Q | FLAG_FMOCC_OVERFLOW;
+template <bool EDIT, bool START>
+__global__ void __launch_bounds__(256)
+k_mvs_naive(MoveDev ix, MvHbfsBufs B, uint32_t pass, const uint8_t* __restrict__ psel, uint32_t tasksRS, const uint64_t* __restrict__ offs,
+            uint32_t gw, const uint32_t* __restrict__ G, const uint8_t* __restrict__ seq, uint32_t maxLen, uint32_t k, Queues q) {
+    __shared__ uint32_t sh[4][5];
+    __shared__ uint32_t stopWord;
+    if (threadIdx.x == 0) stopWord = __hip_atomic_load(&q.cnt[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & MVS_NAIVE_STOP;
+    __syncthreads();
+    if (stopWord) return; // (an earlier pass dropped nodes: the host grows the queue and runs the search again)
+    constexpr uint32_t PU = MvTraits::PAIR_U4;
+    const uint32_t outP = START ? 0u : pass + 1u;
+    const uint32_t nIn = START ? tasksRS : min(B.nq[pass], B.qCap);
+    const uint4* __restrict__ Qi = B.Q[pass & 1u];
+    uint4* __restrict__ Qo = B.Q[outP & 1u];
+    const uint32_t qCap = B.qCap;
+    uint32_t cNode = 0, cExp = 0, cMx = 0, cRows = 0, flags = 0;
+    for (uint32_t base = blockIdx.x * 256u; base < nIn; base += gridDim.x * 256u) { // block-uniform trip count
+        const uint32_t i = base + threadIdx.x;
+        uint32_t kinds = 0; // per child: bit 0 node, bit 2 in-index occurrence
+        MvPair ch[4];
+        uint64_t cHP[4], cHN[4];
+        uint32_t cState[4], cAux[4], cDist[4];
+        uint32_t rsId = 0, row1 = 0, nNode = 0, nFm = 0;
+        if (START) {
+            if (i < nIn && (psel[i] & 0x80u) && !(!EDIT && offs[(i >> 1) + 1] == offs[i >> 1])) { // (Hamming, empty read: pattern[-1] in the reference)
+                rsId = i;
+                ch[0] = mvCompleteRange(ix);
+                const uint64_t HP0 = (~0ull) << MX_LEFT;
+                cHP[0] = HP0;
+                cHN[0] = ~HP0;
+                cState[0] = 0;
+                cAux[0] = MX_DIAG + k;
+                kinds = 1;
+                nNode = 1;
+            }
+        } else if (i < nIn) {
+            const uint4 n1 = Qi[(size_t)PU * qCap + i];
+            const MvPair parent = MvTraits::load(Qi + i, qCap);
+            rsId = n1.x;
+            const uint32_t row = n1.y & 0xFFFFu, score = n1.y >> 16, rac = n1.z & 0xFFu, v = n1.z >> 8;
+            const uint32_t len = (uint32_t)(offs[(rsId >> 1) + 1] - offs[rsId >> 1]);
+            uint64_t pHP = 0, pHN = 0;
+            MatGeom g;
+            g.n = len + 1;
+            g.maxED = k;
+            g.Wv = k;
+            g.Wh = k;
+            g.m = max(g.Wv + g.n, g.Wv + g.Wh + 1u);
+            if (EDIT) {
+                const uint4 n2 = Qi[(size_t)(PU + 1) * qCap + i];
+                pHP = u64of(n2.x, n2.y);
+                pHN = u64of(n2.z, n2.w);
+            }
+            uint32_t rows = 0;
+            const uint32_t mask = moveChildrenCounted(ix, 2, parent, ch, rows);
+            cRows += rows;
+            cExp++;
+            row1 = row + 1;
+            const uint32_t pc = EDIT ? 0u : seq[(size_t)rsId * maxLen + (len - row1)];
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                if (!(mask >> c & 1u)) continue;
+                cNode++;
+                uint32_t kd = 0;
+                if (EDIT) {
+                    if (row1 >= g.m) continue; // (:1098)
+                    cMx++;
+                    uint64_t HP = pHP, HN = pHN, D0, RAC = 1ull << rac;
+                    uint32_t sc = score;
+                    const uint64_t M = matchWord(gString(G, gw, rsId, 1u, c), 0u, len, row1 / MX_BLOCK);
+                    if (!computeRow(g, row1, M, HP, HN, D0, RAC, sc)) continue;
+                    if (g.inFinalColumn(row1)) {
+                        const uint32_t d = cellAt(row1, len, HP, HN, sc);
+                        if (d <= k) {
+                            kd |= 4u;
+                            cDist[c] = d;
+                        }
+                    }
+                    kd |= 1u; // (no in-text verification on this index: every valid node is extended)
+                    cHP[c] = HP;
+                    cHN[c] = HN;
+                    cState[c] = row1 | (sc << 16);
+                    cAux[c] = (uint32_t)__ffsll((unsigned long long)RAC) - 1u;
+                } else {
+                    const uint32_t v1 = v + (c + 1 != pc ? 1u : 0u);
+                    if (v1 > k) continue;
+                    if (row1 == len) {
+                        kd = 4u;
+                        cDist[c] = v1;
+                    } else {
+                        kd = 1u;
+                        cState[c] = row1;
+                        cAux[c] = v1 << 8;
+                    }
+                }
+                kinds |= kd << (4 * c);
+                nNode += kd & 1u;
+                nFm += (kd >> 2) & 1u;
+            }
+        }
+        const uint32_t want[4] = {nNode, 0u, nFm, 0u};
+        uint32_t got[4];
+        blockAppend4(&B.nq[outP], &q.cnt[0], &q.cnt[1], &q.cnt[1], want, sh, got);
+        uint32_t oNode = got[0], oFm = got[2];
+        bool ok = true;
+        if (oNode + nNode > qCap) { ok = false; flags |= FLAG_NAIVE_Q; }
+        if (oFm + nFm > q.fmCap) { ok = false; flags |= FLAG_FMOCC_OVERFLOW; }
+        if (ok && kinds) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t kd = (kinds >> (4 * c)) & 15u;
+                if (kd & 4u) {
+                    MvFmRec f;
+                    f.rsId = rsId, f.depth = row1, f.dist = cDist[c], f.shift = 0;
+                    f.r = storePair(ch[c]);
+                    B.fmX[oFm++] = f;
+                }
+                if (kd & 1u) {
+                    MvTraits::store(Qo + oNode, qCap, ch[c]);
+                    Qo[(size_t)PU * qCap + oNode] = make_uint4(rsId, cState[c], cAux[c], 0u);
+                    if (EDIT) Qo[(size_t)(PU + 1) * qCap + oNode] = make_uint4((uint32_t)cHP[c], (uint32_t)(cHP[c] >> 32), (uint32_t)cHN[c], (uint32_t)(cHN[c] >> 32));
+                    oNode++;
+                }
+            }
+        }
+    }
+    const uint32_t local[4] = {cNode, cExp, cMx, cRows};
+    const int which[4] = {0, 7, 11, 13}; // NODE_COUNTER, EXPANSIONS, MATRIX_ROWS, table rows fetched
+    flushCounters(q, local, which, 4);
+    if (flags) atomicOr(&q.cnt[3], flags);
+}
+
 // ------------------------------------------------------------------ in-index occurrences -> text occurrences
 // Occurrences::eraseDoublesFM (indexhelpers.h:2135-2146) under the RLC flavour's equality (FMOcc::== over SARangePair::==,
 // which includes run indices, toehold, toeholdRepresentsEnd and originalDepth, :1226-1233): records are sorted by
@@ -954,9 +1174,12 @@ __global__ void k_mvs_fm_compact(const MvFmRec* __restrict__ fm, const uint32_t*
 }
 // one lane per located position: TextOcc = [pos + shift, pos + shift + depth) (indexinterface.cpp:1410-1416) as a sort key
 // (read | begin) and a value (distance, width, strand) that orders equal begins as TextOcc::operator< does (:779-795)
+// which: 0 every record, groups = reads; 1 only the reads matched by naive backtracking (psel bit 7), groups = read x strand — that
+// path filters its occurrences per strand first (indexinterface.cpp:1137, :1205); 2 all other reads (the survivors of pass 1 join
+// them through k_mvs_occ_keys).  Records left out get the all-ones key, which sorts behind every group.
 __global__ void k_mvs_text_keys(const uint64_t* __restrict__ positions, const uint64_t* __restrict__ recOff, uint32_t nRecs, uint64_t total,
                                 const uint4* __restrict__ meta, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
-                                uint32_t* __restrict__ bad) {
+                                uint32_t* __restrict__ bad, const uint8_t* __restrict__ psel = nullptr, int which = 0) {
     for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < total; j += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t lo = 0, hi = nRecs; // the last record whose offset is <= j
         while (hi - lo > 1) {
@@ -966,8 +1189,11 @@ __global__ void k_mvs_text_keys(const uint64_t* __restrict__ positions, const ui
         }
         const uint4 m = meta[lo];
         const uint64_t begin = positions[j] + m.w;
-        if (begin >> 40 || (m.x >> 1) >> 24 || m.y >= (1u << 19) || m.z >= 16u) atomicAdd(bad, 1u);
-        keys[j] = ((uint64_t)(m.x >> 1) << 40) | (begin & ((1ull << 40) - 1));
+        if (begin >> 40 || m.x >> 24 || m.y >= (1u << 19) || m.z >= 16u) atomicAdd(bad, 1u);
+        const bool naive = which != 0 && (psel[m.x] & 0x80u) != 0u;
+        const uint64_t grp = which == 1 ? m.x : m.x >> 1;
+        const bool leftOut = (which == 1 && !naive) || (which == 2 && naive);
+        keys[j] = leftOut ? ~0ull : ((grp << 40) | (begin & ((1ull << 40) - 1)));
         vals[j] = (m.z << 20) | (m.y << 1) | (m.x & 1u);
     }
 }
@@ -979,9 +1205,13 @@ struct MoveOccOut {
     uint64_t begin, end;
     uint32_t distance, strand;
 };
+// uniqueOnly: getTextOccHamming (indexinterface.cpp:1331-1371) — sort + unique under TextOcc::operator== (range and distance): per
+// begin every distinct (distance, width) is kept, in ascending order, strand 0 winning a tie (the two strands of a read can match
+// the same range at different distances).
 template <bool WRITE>
 __global__ void k_mvs_filter(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t total, uint32_t nReads,
-                             uint32_t maxED, uint64_t* __restrict__ counts, const uint64_t* __restrict__ outOff, MoveOccOut* __restrict__ out) {
+                             uint32_t maxED, uint64_t* __restrict__ counts, const uint64_t* __restrict__ outOff, MoveOccOut* __restrict__ out,
+                             uint32_t uniqueOnly) {
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nReads; r += gridDim.x * blockDim.x) {
         const uint64_t kLo = (uint64_t)r << 40, kHi = ((uint64_t)r + 1) << 40;
         uint64_t lo = 0, hi = total; // first key >= kLo
@@ -991,6 +1221,31 @@ __global__ void k_mvs_filter(const unsigned long long* __restrict__ keys, const 
             else hi = mid;
         }
         uint64_t j = lo, nKept = 0;
+        if (uniqueOnly) {
+            uint64_t w = WRITE ? outOff[r] : 0;
+            while (j < total && keys[j] < kHi) {
+                const uint64_t key = keys[j], begin = key & ((1ull << 40) - 1);
+                uint64_t e = j + 1;
+                while (e < total && keys[e] == key) e++;
+                uint32_t lastV = 0;
+                bool first = true;
+                for (;;) { // the group's values in ascending order, one per distinct (distance, width)
+                    uint32_t best = 0xFFFFFFFFu;
+                    for (uint64_t t = j; t < e; t++) {
+                        const uint32_t v = vals[t];
+                        if ((first || (v >> 1) > (lastV >> 1)) && v < best) best = v;
+                    }
+                    if (best == 0xFFFFFFFFu) break;
+                    if (WRITE) out[w++] = MoveOccOut{begin, begin + ((best >> 1) & 0x7FFFFu), best >> 20, best & 1u};
+                    nKept++;
+                    lastV = best;
+                    first = false;
+                }
+                j = e;
+            }
+            if (!WRITE) counts[r] = nKept;
+            continue;
+        }
         const uint64_t maxDiff = 2ull * maxED;
         uint64_t prevBegin = ~0ull;
         uint32_t prevED = maxED + 1, prevDepth = 0xFFFFFFFFu;
@@ -1025,6 +1280,18 @@ __global__ void k_mvs_filter(const unsigned long long* __restrict__ keys, const 
         if (have && WRITE) out[w++] = last;
         if (!WRITE) counts[r] = nKept;
     }
+}
+
+// the survivors of the naive path's own filter pass (groups = read x strand) as keys of their READ, behind the keys of the other
+// reads: they pass the filter of the mapping mode a second time (searchstrategy.cpp:455-457)
+__global__ void k_mvs_occ_keys(const MoveOccOut* __restrict__ occ, const uint64_t* __restrict__ occOff, uint32_t nGroups,
+                               unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nGroups; g += gridDim.x * blockDim.x)
+        for (uint64_t e = occOff[g]; e < occOff[g + 1]; e++) {
+            const MoveOccOut o = occ[e];
+            keys[e] = ((uint64_t)(g >> 1) << 40) | o.begin;
+            vals[e] = (o.distance << 20) | ((uint32_t)(o.end - o.begin) << 1) | (g & 1u);
+        }
 }
 
 } // namespace cmb

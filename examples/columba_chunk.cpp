@@ -34,10 +34,9 @@ int main(int argc, char** argv) {
             for (const auto& o : matches[i])
                 std::cout << i << ' ' << o.getBegin() << ' ' << o.getEnd() << ' ' << o.getDistance() << ' '
                           << (o.isRevCompl() ? 1 : 0) << "\n";
-        // reads the device did not match (the reference's naive-backtracking fallback applies): a Columba host calls
-        // IndexInterface::approxMatchesNaive for exactly these; this driver names them
-        for (size_t i : strategy.needNaiveFallback)
-            std::cerr << "read " << i << " (" << chunk[i].getRead().size() << " characters) needs the naive-backtracking fallback\n";
+        // reads not longer than the number of parts of the scheme: matched by naive backtracking, as the reference does
+        for (size_t i : strategy.matchedNaively)
+            std::cerr << "read " << i << " (" << chunk[i].getRead().size() << " characters) was matched by naive backtracking\n";
         std::cerr << "nodes " << counters.get(Counters::NODE_COUNTER) << "\n";
     } catch (const std::exception& e) {
         std::cerr << "Fatal error: " << e.what() << "\n";

@@ -239,12 +239,13 @@ int cmb_batch_alignments(const cmb_batch* b, cmb_aln* out, uint64_t cap, uint16_
  * mapRead works on one strand, src/searchstrategy.h:490-523); the result list of a read then holds the forward
  * strand's occurrences followed by the reverse-complement strand's */
 int cmb_batch_filter_per_strand(cmb_batch* b, int on);
-/* Reads the device path does not match: reads not longer than the number of parts of the search scheme, which the reference
- * matches by naive backtracking instead of a search scheme (searchstrategy.cpp:148-152, :442-459; indexinterface.cpp:1055-1210).
- * Default: one such read fails cmb_batch_run / cmb_match_batch with CMB_ERR_UNSUPPORTED, naming the read — nothing is silently
- * skipped.  After cmb_batch_allow_unsupported(b, 1) the run succeeds: the lists of those reads are empty and
- * cmb_batch_read_status marks them (status[i] & CMB_READ_NAIVE_FALLBACK), so that a host keeps the chunk and hands exactly those
- * reads to its own fallback (Columba: IndexInterface::approxMatchesNaive).  status may be NULL (count only). */
+/* Reads not longer than the number of parts of the search scheme — and every read under the one-part strategy "naive" — are not
+ * matched with a search scheme: the reference falls back to naive backtracking over the whole pattern
+ * (SearchStrategy::partition / matchWithSearches, searchstrategy.cpp:148-152, :442-459; IndexInterface::approxMatchesNaive[Hamming],
+ * indexinterface.cpp:1055-1209).  The device does the same inside the chunk (dev_bfs_naive.hpp; move_search.hpp: k_mvs_naive for the
+ * b-move index), including that path's own filter pass per strand; no read of a valid chunk fails the run.
+ * cmb_batch_read_status marks the reads that took that path (status[i] & CMB_READ_NAIVE_FALLBACK) — information only; status may be
+ * NULL (count only).  cmb_batch_allow_unsupported is kept for callers written against earlier versions and has no effect. */
 #define CMB_READ_NAIVE_FALLBACK 1
 int cmb_batch_allow_unsupported(cmb_batch* b, int on);
 int cmb_batch_read_status(const cmb_batch* b, uint8_t* status /* [n_reads] */, uint32_t* n_flagged);

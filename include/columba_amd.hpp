@@ -222,8 +222,9 @@ class SearchStrategy {
   public:
     SearchStrategy(const SearchStrategy&) = delete;
     virtual ~SearchStrategy() { cmb_strategy_destroy(h); }
-    // reads of the last matchApproxBatch chunk that the device did not match (indices into the chunk): see there
-    std::vector<size_t> needNaiveFallback;
+    // reads of the last matchApproxBatch chunk that were matched by naive backtracking instead of a search scheme (not longer than
+    // the number of parts: searchstrategy.cpp:148-152) — information only, their occurrences are in the result like all others
+    std::vector<size_t> matchedNaively;
 
     // the body of processChunk's loop for a whole chunk: result[i] = occurrences of reads[i]
     void matchApproxBatch(const std::vector<ReadBundle>& reads, length_t maxED, Counters& counters,
@@ -240,18 +241,14 @@ class SearchStrategy {
             cmb_batch* b;
             ~Guard() { cmb_batch_destroy(b); }
         } guard{b};
-        // reads the device does not match (not longer than the number of parts: the reference's naive-backtracking fallback,
-        // searchstrategy.cpp:148-152) do not fail the chunk: they come back with empty lists and are named in
-        // needNaiveFallback, for the host to hand to IndexInterface::approxMatchesNaive (indexinterface.cpp:1055)
-        check(cmb_batch_allow_unsupported(b, 1));
         check(cmb_batch_run(b));
-        needNaiveFallback.clear();
+        matchedNaively.clear();
         {
             std::vector<uint8_t> status(reads.size() ? reads.size() : 1);
             uint32_t flagged = 0;
             check(cmb_batch_read_status(b, status.data(), &flagged));
             for (size_t i = 0; flagged && i < reads.size(); i++)
-                if (status[i] & CMB_READ_NAIVE_FALLBACK) needNaiveFallback.push_back(i);
+                if (status[i] & CMB_READ_NAIVE_FALLBACK) matchedNaively.push_back(i);
         }
         uint64_t n = 0;
         check(cmb_batch_result_size(b, &n));

@@ -43,16 +43,17 @@ def test_adapter_example_matches_python_binding(tmp_path):
     exp = sorted((i, int(o["begin"]), int(o["end"]), int(o["distance"]), int(o["strand"]))
                  for i in range(len(reads)) for o in occ[int(offs[i]):int(offs[i + 1])])
     assert got == exp and len(exp) > 0
-    # a chunk with reads of 3 and 5 characters (the reference's naive-backtracking fallback): the chunk is not failed, the short
-    # reads are named, every other read keeps its list
+    # a chunk with reads of 3 and 5 characters (matched by naive backtracking, as in the reference): the short reads are named,
+    # every other read keeps its list
     mixed = reads[:50] + [b"ACG", b"ACGTA"] + reads[50:100]
     (tmp_path / "mixed.txt").write_bytes(b"\n".join(mixed) + b"\n")
     r = subprocess.run([exe, str(tmp_path / "idx"), str(tmp_path / "mixed.txt"), "4"], capture_output=True, text=True, check=True)
     got = sorted(tuple(int(x) for x in line.split()) for line in r.stdout.splitlines())
     shift = lambda i: i if i < 50 else i + 2
-    assert got == sorted((shift(t[0]),) + t[1:] for t in exp if t[0] < 100)
-    assert "read 50 (3 characters) needs the naive-backtracking fallback" in r.stderr
-    assert "read 51 (5 characters) needs the naive-backtracking fallback" in r.stderr
+    assert [t for t in got if t[0] not in (50, 51)] == sorted((shift(t[0]),) + t[1:] for t in exp if t[0] < 100)
+    assert sum(t[0] == 50 for t in got) > 1000 and sum(t[0] == 51 for t in got) > 1000   # (they match all over the text)
+    assert "read 50 (3 characters) was matched by naive backtracking" in r.stderr
+    assert "read 51 (5 characters) was matched by naive backtracking" in r.stderr
 
 
 def _build_align(tmp):

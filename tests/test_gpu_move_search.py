@@ -142,11 +142,56 @@ def test_bmove_search_is_complete(sworld, gt):
         assert hits > 60 and chain * 20 <= hits
 
 
-def test_bmove_search_refusals(sworld):
-    ca = sworld["ca"]
-    with pytest.raises(ca.CmbError) as e:  # naive-backtracking fallback of the reference: refused, not skipped
-        sworld["dev"].match_batch(ca.SearchStrategy("multiple_opt", "edit", "dynamic"), 4, [b"ACGTACGT" * 12, b"ACGT"])
-    assert e.value.code == ca.CMB_ERR_UNSUPPORTED
+@pytest.fixture(scope="module")
+def tinyworld(oracle_built):
+    """a small pan-genome for the naive-backtracking tests: a read of three characters with two errors matches everywhere"""
+    import columba_amd as ca
+    from columba_amd import movebuild
+    import oracle_py as op
+    rng = np.random.default_rng(21)
+    g = np.concatenate([_pangenome(rng, 3_000, 6, 0.01), np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 4_000)]])
+    mv = movebuild.build_move(g.tobytes(), device="cuda")
+    return {"g": g, "text": g.tobytes(), "mv": mv, "dev": ca.MoveIndex(mv), "orc": op.OracleMoveIndex(mv), "ca": ca, "op": op}
+
+
+@pytest.mark.parametrize("spec,metric,partition,k", [("kuch1", "edit", "dynamic", 1), ("multiple_opt", "edit", "uniform", 2),
+                                                     ("pigeon", "edit", "static", 3), ("columba", "edit", "dynamic", 3),
+                                                     ("kuch1", "hamming", "dynamic", 2), ("columba", "hamming", "uniform", 3)])
+def test_bmove_reads_not_longer_than_the_number_of_parts(tinyworld, spec, metric, partition, k):
+    """searchstrategy.cpp:148-152, :442-459: such reads are matched by naive backtracking (k_mvs_naive) inside the chunk"""
+    g = tinyworld["g"]
+    rng = np.random.default_rng(10 * k + len(spec))
+    reads = []
+    for i in range(40):
+        p = int(rng.integers(0, len(g) - 60))
+        reads.append(g[p:p + 50].tobytes())
+        L = int(rng.integers(1, k + 2))
+        p = int(rng.integers(0, len(g) - 10))
+        reads.append(g[p:p + L].tobytes())
+    if metric == "edit":
+        reads.append(b"")
+    _compare(tinyworld, spec, partition, k, reads, kmer_size=4, metric=metric)
+
+
+@pytest.mark.parametrize("metric,k,length", [("edit", 1, 18), ("edit", 2, 20), ("edit", 3, 14), ("hamming", 2, 20), ("hamming", 3, 26)])
+def test_bmove_naive_strategy(tinyworld, metric, k, length):
+    """`-S naive` (NaiveBackTrackingStrategy, searchstrategy.h:2785-2820): every read by backtracking over the whole pattern"""
+    g = tinyworld["g"]
+    rng = np.random.default_rng(5 * k + length)
+    reads = []
+    for _ in range(60):
+        L = int(rng.integers(max(2, length - 5), length + 1))
+        p = int(rng.integers(0, len(g) - L - 1))
+        r = bytearray(g[p:p + L].tobytes())
+        for _ in range(int(rng.integers(0, k + 1))):
+            r[int(rng.integers(0, L))] = b"ACGT"[int(rng.integers(0, 4))]
+        reads.append(bytes(r))
+    reads += [b"ACGTN", b"acgtacgtac"]
+    os.environ["CMB_TEST_SMALL_POOLS"] = "1"   # (the node queue of the naive search starts small and is grown)
+    try:
+        _compare(tinyworld, "naive", "dynamic", k, reads, kmer_size=4, metric=metric)
+    finally:
+        del os.environ["CMB_TEST_SMALL_POOLS"]
 
 
 def test_bmove_pool_growth(sworld):
