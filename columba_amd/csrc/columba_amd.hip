@@ -206,7 +206,7 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
         ix->saSamples.upload(desc->sa_samples, desc->n_samples);
         // padded: the verification kernels read (unaligned) 16-byte chunks up to two chunks ahead, and lanes whose
         // candidate has ended keep prefetching while their wavefront runs (at most MAX_READ + 3 k rows + 48 bytes)
-        constexpr uint64_t TEXT_PAD = 512;
+        constexpr uint64_t TEXT_PAD = 640;
         static_assert(TEXT_PAD >= (uint64_t)VROWS + 64, "text padding must cover the longest verification window");
         ix->text.alloc(n + TEXT_PAD);
         HIPCHK(hipMemset(ix->text.p, 0, n + TEXT_PAD));
@@ -1075,7 +1075,8 @@ static int batchRunOne(cmb_batch* b) {
                         if (b->bfsEv[j].n < 2 * b->bfsEvCap) b->bfsEv[j].alloc(2 * b->bfsEvCap);
                     }
                     if (b->bfsF.n < F_U4 * b->bfsFCap) b->bfsF.alloc(F_U4 * b->bfsFCap);
-                    if (b->bfsC.n < CTX_U4 * b->bfsCCap) b->bfsC.alloc(CTX_U4 * b->bfsCCap);
+                    const uint32_t ctxU4 = ctxU4For(b->maxLen);
+                    if (b->bfsC.n < (size_t)ctxU4 * b->bfsCCap) b->bfsC.alloc((size_t)ctxU4 * b->bfsCCap);
                     if (b->bfsA.n < b->bfsACap) b->bfsA.alloc(b->bfsACap);
                     const size_t cntWords = 2 * ((size_t)maxPass + 2) + 4;
                     if (b->bfsCnt.n < cntWords) b->bfsCnt.alloc(cntWords);
@@ -1093,7 +1094,9 @@ static int batchRunOne(cmb_batch* b) {
                     B.qCap = (uint32_t)std::min<size_t>(b->bfsQ[0].n / 4, 0xFFFFFFF0u);
                     B.evCap = (uint32_t)std::min<size_t>(b->bfsEv[0].n / 2, 0xFFFFFFF0u);
                     B.fCap = (uint32_t)std::min<size_t>(b->bfsF.n / F_U4, 0xFFFFFFF0u);
-                    B.cCap = (uint32_t)std::min<size_t>(b->bfsC.n / CTX_U4, 0xFFFFFFF0u);
+                    B.cCap = (uint32_t)std::min<size_t>(b->bfsC.n / ctxU4, 0xFFFFFFF0u);
+                    B.ctxU4 = ctxU4;
+                    B.ctxMblk = ctxMblkFor(b->maxLen);
                     B.aCap = (uint32_t)std::min<size_t>(b->bfsA.n, 0xFFFFFFF0u);
                     B.chain = getenv("CMB_BFS_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("CMB_BFS_CHAIN"))) : BFS_CHAIN;
                     B.gridX = getenv("CMB_BFS_GRID") ? (uint32_t)std::min<int>(BFS_GRID, std::max(1, atoi(getenv("CMB_BFS_GRID")))) : BFS_GRID_X;

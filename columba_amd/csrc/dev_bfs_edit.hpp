@@ -38,10 +38,14 @@ constexpr uint32_t ED_CELLS = 24; // final-column cells per phase (5 bits each i
 // hot word in line 0 the kernel took 72 instead of 66 ms) —, lines 2 and 3 the match words of row blocks 3..10
 // (a part of a 256-character read can span all of it: 256 + 20 rows; with three lines a part beyond 223 rows — one
 // of the two parts of a long read at k = 1 — stopped the whole batch with CMB_ERR_INTERNAL).
-constexpr uint32_t CTX_U4 = 32;
+constexpr uint32_t CTX_U4 = 32;    // uint4 per context for reads of up to 320 characters (BfsBufs::ctxU4 is what the kernels use)
 constexpr uint32_t CTX_HOT = 8;   // uint4 index of the hot word
 constexpr uint32_t CTX_M = 10;    // uint4 index of the match words of row block 0 ({A,C}, {G,T} per block)
-constexpr uint32_t CTX_MBLK = 11; // row blocks with cached match words (rows < 352)
+constexpr uint32_t CTX_MBLK = 11; // row blocks with cached match words (rows < 352) in a context of CTX_U4
+// longer reads (up to MAX_READ): contexts of 48 uint4 with the match words of 16 row blocks (rows < 512)
+constexpr uint32_t CTX_U4_LONG = 48, CTX_MBLK_LONG = 16;
+__host__ __device__ inline uint32_t ctxU4For(uint32_t maxLen) { return maxLen > 320u ? CTX_U4_LONG : CTX_U4; }
+__host__ __device__ inline uint32_t ctxMblkFor(uint32_t maxLen) { return maxLen > 320u ? CTX_MBLK_LONG : CTX_MBLK; }
 constexpr uint32_t F_U4 = 2;      // uint4 per F record: {ranges} {depth | c << 16, parent, reported, -}
 // (all blocks of a pass should be resident together — 3 blocks of 256 threads per CU at ~160 VGPRs — or the event
 // blocks, which come last in the grid, only start when expansion blocks have finished)
@@ -71,9 +75,10 @@ struct BfsBufs {
     uint4* Ev[2]; // events, 2 x 16 B: {ctx, F index of the node that ended its path, remaining-descendants index | -1,
                   // cell} {final-column distances of the path}
     uint4* F;     // final-column records, 2 x 16 B: {ranges} {depth | c << 16, parent, reported, -}
-    uint4* C;     // contexts, CTX_U4 x 16 B
+    uint4* C;     // contexts, ctxU4 x 16 B
     uint4* A;     // list arena: descendants (2 x 16 B each: ranges, {depth | c << 16}) and initial distances (u16)
     uint32_t qCap, evCap, fCap, cCap, aCap;
+    uint32_t ctxU4, ctxMblk; // size of a context in uint4 / row blocks whose match words it caches (ctxU4For, ctxMblkFor)
     uint32_t chain;  // expansions a lane makes in a row while each yields exactly one plain node (BFS_CHAIN)
     uint32_t gridX, gridEv; // blocks of k_bfs_pass that expand / that handle events
     uint32_t* nq;    // [pass] number of frontier nodes consumed by pass `pass`
@@ -332,7 +337,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
             parent = RangePair{{n0.x, n0.y}, {n0.z, n0.w}};
             uint4 rk[4];
             issueRanks(ix, md, parent, rk);
-            const uint4* Cx = B.C + (size_t)CMB_IDX(ctx, B.cCap, 1) * CTX_U4;
+            const uint4* Cx = B.C + (size_t)CMB_IDX(ctx, B.cCap, 1) * B.ctxU4;
             blk = (row + 1) / MX_BLOCK;
             const uint4 hot = Cx[CTX_HOT]; // everything the expansion needs of its context, in ONE 16-byte request
             const uint4 mA = Cx[CTX_M + 2 * blk], mB = Cx[CTX_M + 1 + 2 * blk];
@@ -470,7 +475,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
             }
             uint32_t rsId = 0, itMeta = 0;
             if (nIt) {
-                const uint4 hot = B.C[(size_t)CMB_IDX(ctx, B.cCap, 2) * CTX_U4 + CTX_HOT];
+                const uint4 hot = B.C[(size_t)CMB_IDX(ctx, B.cCap, 2) * B.ctxU4 + CTX_HOT];
                 rsId = hot.x & 0x1FFFFFFu;
                 itMeta = hot.w & 0x7FFFFFu;
             }
@@ -604,7 +609,7 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyK* __restrict__ stp, c
                 fcE = ev.y;
                 remFrom = (int)ev.z;
                 last = ev.w;
-                const uint4* Cx = B.C + (size_t)CMB_IDX(c0i, B.cCap, 3) * CTX_U4;
+                const uint4* Cx = B.C + (size_t)CMB_IDX(c0i, B.cCap, 3) * B.ctxU4;
                 const uint4 c0 = Cx[0], c1 = Cx[1], c3 = Cx[3];
                 const uint4 fp = Ei[(size_t)2 * i + 1]; // final-column distances of the path (travel with the event)
                 pack = EdPack{u64of(fp.x, fp.y), u64of(fp.z, fp.w)};
@@ -666,7 +671,7 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyK* __restrict__ stp, c
                         const uint32_t nd0 = last - P.ci;
                         P.ni = nd0 + 1;
                         if (remFrom >= 0) { // :625 (descRef0 is valid: the event came out of a replay)
-                            const uint32_t dn = B.C[(size_t)CMB_IDX(descRef0, B.cCap, 4) * CTX_U4 + 4].y & 0xFFu;
+                            const uint32_t dn = B.C[(size_t)CMB_IDX(descRef0, B.cCap, 4) * B.ctxU4 + 4].y & 0xFFu;
                             P.nRem = dn > (uint32_t)remFrom ? dn - (uint32_t)remFrom : 0u;
                         }
                         P.nDescNew = nd0 + P.nRem;
@@ -697,7 +702,7 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyK* __restrict__ stp, c
             }
             if (descSelf) P.nDescSrc = P.nDescNew;
             else if (descRefN != BFS_NONE) {
-                dC4 = B.C[(size_t)CMB_IDX(descRefN, B.cCap, 5) * CTX_U4 + 4];
+                dC4 = B.C[(size_t)CMB_IDX(descRefN, B.cCap, 5) * B.ctxU4 + 4];
                 P.nDescSrc = dC4.y & 0xFFu;
             }
         }
@@ -783,7 +788,7 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyK* __restrict__ stp, c
             if (enter) {
                 const uint32_t nd0 = last - P.ci;
                 if (P.nRem) {
-                    const uint4 sC4 = B.C[(size_t)CMB_IDX(descRef0, B.cCap, 6) * CTX_U4 + 4];
+                    const uint4 sC4 = B.C[(size_t)CMB_IDX(descRef0, B.cCap, 6) * B.ctxU4 + 4];
                     const uint4* sl = B.A + CMB_IDX(sC4.x, B.aCap, 102);
                     for (uint32_t t = 0; t < P.nRem; t++) {
                         const uint32_t j = nd0 + t;
@@ -897,7 +902,7 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyK* __restrict__ stp, c
             initMatrix(g, xLen, maxEDn, first, lastI, nSrcInit ? il : nullptr, increase, nInit, HP, HN, RAC, score);
             const uint32_t clSize = g.sfc();
             const uint32_t nBlk = (g.m - 1) / MX_BLOCK + 1;
-            if (g.Wv > 2 * MX_MAX_ED || clSize > ED_CELLS || nBlk > CTX_MBLK || g.m > 0xFFFFu) {
+            if (g.Wv > 2 * MX_MAX_ED || clSize > ED_CELLS || nBlk > B.ctxMblk || g.m > 0xFFFFu) {
                 flags |= FLAG_CAPACITY;
             } else {
                 // in-text switch parameters of the phase (goToInTextVerificationEdit, :340-375)
@@ -916,7 +921,7 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyK* __restrict__ stp, c
                             oDesc = P.nDescNew;
                             oInit = nInitNew;
                         } else {
-                            const uint4 oC4 = B.C[(size_t)CMB_IDX(otherRefN, B.cCap, 7) * CTX_U4 + 4];
+                            const uint4 oC4 = B.C[(size_t)CMB_IDX(otherRefN, B.cCap, 7) * B.ctxU4 + 4];
                             oOff = oC4.x;
                             oDesc = oC4.y & 0xFFu;
                             oInit = (oC4.y >> 8) & 0xFFu;
@@ -928,7 +933,7 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyK* __restrict__ stp, c
                     }
                     itMeta = packMeta(smShiftN, maxEDs, minEDs, stt == 0, ITEM_EDIT);
                 }
-                uint4* Cx = B.C + (size_t)CMB_IDX(cNew, B.cCap, 8) * CTX_U4;
+                uint4* Cx = B.C + (size_t)CMB_IDX(cNew, B.cCap, 8) * B.ctxU4;
                 Cx[0] = make_uint4(rsId, g.n | (g.m << 16), g.Wv | (g.Wh << 8) | (maxEDn << 16) | (clSize << 24),
                                    idxN | (dirN << 4) | (uniN << 5) | (useRev << 6) | (itMode << 7) | (scheme << 12) |
                                        (search << 16));

@@ -22,7 +22,8 @@ namespace cmb {
 constexpr int MAXP = 8;      // max parts (k <= 6 -> 7 parts in multiple_opt)
 constexpr int MAXS = 16;     // max searches per scheme
 constexpr int MAXSCH = 4;    // max alternative schemes per k (dynamic selection)
-constexpr int MAX_READ = 320; // (contexts cache the match words of 352 rows, dev_bfs_edit.hpp: CTX_MBLK; 2 x 300 bp reads fit)
+constexpr int MAX_READ = 480; // (9-bit part bounds and matrix dimensions in the records: < 512 with the band; contexts of batches with reads beyond
+                              // 320 characters cache the match words of 512 rows instead of 352, dev_bfs_edit.hpp: ctxGeometry)
 constexpr int DESC_MAX = 56; // descendants handed to the next phase
 
 // ---- strategy tables (built on the host by host/schemes.cpp) -------------------------------

@@ -962,7 +962,8 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                     if (b->Ev[j].n < 2 * b->evCap) b->Ev[j].alloc(2 * b->evCap);
                 }
                 if (b->F.n < (PU + 1) * b->fCap) b->F.alloc((PU + 1) * b->fCap);
-                if (b->C.n < CTX_U4 * b->cCap) b->C.alloc(CTX_U4 * b->cCap);
+                const uint32_t ctxU4 = ctxU4For(b->maxLen);
+                if (b->C.n < (size_t)ctxU4 * b->cCap) b->C.alloc((size_t)ctxU4 * b->cCap);
                 if (b->A.n < b->aCap) b->A.alloc(b->aCap);
                 const size_t cntWords = 2 * ((size_t)maxPass + 2) + 4;
                 if (b->bfsCnt.n < cntWords) b->bfsCnt.alloc(cntWords);
@@ -980,7 +981,9 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                 B.qCap = (uint32_t)std::min<size_t>(b->Q[0].n / (PU + 3), 0xFFFFFFF0u);
                 B.evCap = (uint32_t)std::min<size_t>(b->Ev[0].n / 2, 0xFFFFFFF0u);
                 B.fCap = (uint32_t)std::min<size_t>(b->F.n / (PU + 1), 0xFFFFFFF0u);
-                B.cCap = (uint32_t)std::min<size_t>(b->C.n / CTX_U4, 0xFFFFFFF0u);
+                B.cCap = (uint32_t)std::min<size_t>(b->C.n / ctxU4, 0xFFFFFFF0u);
+                B.ctxU4 = ctxU4;
+                B.ctxMblk = ctxMblkFor(b->maxLen);
                 B.aCap = (uint32_t)std::min<size_t>(b->A.n, 0xFFFFFFF0u);
                 B.chain = getenv("CMB_MVS_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("CMB_MVS_CHAIN"))) : MVS_CHAIN;
                 B.gridX = getenv("CMB_MVS_GRID") ? (uint32_t)std::min<int>(BFS_GRID, std::max(1, atoi(getenv("CMB_MVS_GRID")))) : BFS_GRID_X;

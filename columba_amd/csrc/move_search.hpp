@@ -645,7 +645,7 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
             row = n1.x & 0xFFFFu;
             score = n1.x >> 16;
             md = (int)((n1.w >> 8) & 3u);
-            Cx = B.C + (size_t)CMB_IDX(ctx, B.cCap, 1) * CTX_U4;
+            Cx = B.C + (size_t)CMB_IDX(ctx, B.cCap, 1) * B.ctxU4;
             blk = (row + 1) / MX_BLOCK;
             const uint4 hot = Cx[CTX_HOT];
             mA = Cx[CTX_M + 2 * blk];
@@ -716,7 +716,7 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
                 }
                 const bool single = kinds == (uint32_t)KIND_NODE || kinds == ((uint32_t)KIND_NODE << 4) || kinds == ((uint32_t)KIND_NODE << 8) ||
                                     kinds == ((uint32_t)KIND_NODE << 12);
-                if (single && step + 1u < B.chain && row1 + 1u < (uint32_t)CTX_MBLK * MX_BLOCK) {
+                if (single && step + 1u < B.chain && row1 + 1u < B.ctxMblk * MX_BLOCK) {
 #pragma unroll
                     for (uint32_t c = 0; c < 4; c++)
                         if (kinds == ((uint32_t)KIND_NODE << (4 * c))) {
@@ -813,7 +813,7 @@ k_mvs_start(const DevStrategyK* __restrict__ stp, MvBufs B, const MvTask* __rest
     if (blockStopped(q)) return;
     bfsHeavy<true, MvTraits>(stp, B, 0u, tasks, nTasks, offs, gw, G, parts, q, blockIdx.x, gridDim.x);
 }
-constexpr uint32_t MVS_CHAIN = 8; // expansions a lane makes in a row while each yields exactly one plain node (CMB_MVS_CHAIN)
+constexpr uint32_t MVS_CHAIN = 2; // expansions a lane makes in a row while each yields exactly one plain node (CMB_MVS_CHAIN)
 #ifndef CMB_MVS_WAVES
 #define CMB_MVS_WAVES 2 // wavefronts per SIMD the register allocation of k_mvs_pass is held to
 #endif

@@ -89,6 +89,8 @@ def _reads(g, k, n, length, seed):
     ("minU", "uniform", 7, 150),
     ("kianfar", "dynamic", 3, 100),        # searches that start with errors allowed in the first part
     ("kuch1", "dynamic", 0, 100),
+    ("multiple_opt", "dynamic", 4, 400),   # reads beyond 320 characters: contexts with the match words of 16 row blocks
+    ("kuch1", "dynamic", 1, 480),
 ])
 def test_bmove_search_parity(sworld, gt, spec, partition, k, length):
     n = 300 if (spec == "kianfar" or k >= 6) else 1200

@@ -274,6 +274,24 @@ def test_ragged_and_odd_reads(world):
     _compare(world, "multiple_opt", "edit", "dynamic", 4, long_reads)
 
 
+def test_reads_of_up_to_480_characters(world):
+    """reads beyond 320 characters: contexts with the match words of 16 row blocks (dev_bfs_edit.hpp: ctxU4For), the long-read
+    instances of k_parts / k_exact, longer verification windows; mixed with ordinary and with very short reads in one chunk"""
+    g = world["genome"]
+    reads = []
+    for ln in (321, 352, 400, 401, 450, 480):
+        reads += synth.sample_reads(g, 40, ln, seed=2000 + ln, n_frac=0.02, edit_choices=(0, 1, 3, 5, 7))
+    reads += synth.sample_reads(g, 60, 150, seed=5, edit_choices=(0, 2, 4))
+    reads += [g[-481:-1].tobytes(), g[0:480].tobytes(), b"ACGTA", b"ACG"]
+    _compare(world, "multiple_opt", "edit", "dynamic", 4, reads, dups_rare=False)
+    long_only = [r for r in reads if len(r) > 100]
+    _compare(world, "columba", "edit", "dynamic", 7, long_only)
+    _compare(world, "columba", "edit", "uniform", 1, long_only)    # two parts: phases of 240 rows
+    _compare(world, "kuch1", "edit", "dynamic", 1, long_only)      # (dynamic partitioning: one part may take most of the read)
+    _compare(world, "kuch1", "hamming", "static", 3, long_only)
+    _compare(world, "pigeon", "edit", "dynamic", 0, long_only)
+
+
 @pytest.mark.parametrize("spec,k", [("columba", 7), ("columba", 5), ("multiple_opt", 6)])
 def test_short_reads_with_many_errors(world, spec, k):
     """Reads of 40 ... 100 characters at 5 ... 7 errors: short parts, replays of long descendant lists that are interrupted
@@ -400,7 +418,7 @@ def test_errors_are_loud(world):
     with pytest.raises(ca.CmbError) as e:   # beyond the in-text matrix of the device (k <= 7) / without a scheme
         ca.match_batch(world["dev"], ca.SearchStrategy("pigeon"), 8, [b"ACGT" * 30])
     with pytest.raises(ca.CmbError):
-        ca.match_batch(world["dev"], st, 4, [b"A" * 321])   # (reads of up to 320 characters are supported)
+        ca.match_batch(world["dev"], st, 4, [b"A" * 481])   # (reads of up to 480 characters are supported)
     with pytest.raises(ca.CmbError) as e:   # seeds placed for 4-mers on an index with a 10-mer table
         ca.match_batch(world["dev"], ca.SearchStrategy("01*0", "edit", "dynamic"), 2, [b"ACGT" * 37 + b"AC"])
     assert e.value.code == -1 and "seeds of a read overlap" in str(e.value)
