@@ -186,6 +186,41 @@ def load_traffic(args, genome_bp, reads, group):
                         "(tools/profile_round.sh writes profiles/*_pmc_traffic.json with kernel_src_sha)")
 
 
+def setup_ranks(args):
+    """one process per GPU: rank / world from the launcher's environment, this rank's device, host affinity and — for N > 1 —
+    the process group (RCCL, or gloo for the one-GPU rehearsal), proven to span all ranks by an all-reduce of ones"""
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # CMB_BENCH_SHARE_GPU=1 + CMB_DIST_BACKEND=gloo: all ranks on cuda:0 — a rehearsal of the N > 1 code path on a
+    # one-GPU box (RCCL refuses two ranks on one device); numbers from such a run mean nothing
+    if os.environ.get("CMB_BENCH_SHARE_GPU"):
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    affinity = pin_to_gpu_numa_node(local) if not os.environ.get("CMB_BENCH_NO_PIN") else None
+    dist = None
+    rccl_ranks = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("CMB_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        # proof that the collective library really spans all ranks: a sum of ones over device tensors (RCCL for `nccl`)
+        ones = torch.ones(1, dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, dist.get_world_size(), world)
+    return rank, world, local, dev, affinity, dist, rccl_ranks
+
+
 def main_rlc(args):
     """BASELINE.json configs[4] on ONE GPU: a pan-genome-like text under the run-length compressed b-move index, 250 bp reads,
     k = 6 edit distance, multiple_opt schemes.  `python bench.py --config rlc [--haplotypes 64 --base-mbp 4 --snp 0.005 --reads N]`.
@@ -193,42 +228,86 @@ def main_rlc(args):
     host).  The 64-haplotype HUMAN collection of the config (200 Gbp, tables of ~130 GB) cannot be built offline; the stand-in keeps
     what the b-move kernels react to — n / r of the BWT and tables far beyond the 256 MB Infinity Cache."""
     from columba_amd import movebuild
-    if args.gpus != 1:
-        sys.exit("bench.py --config rlc runs on one GPU (every rank of a multi-GPU job would hold a replica and its own read shard, "
-                 "as for the FM-index; columba_amd.dist.broadcast_device_move_index replicates the index)")
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(0)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))  # (before any GPU call in this process)
+    rank, world, local, dev, affinity, dist, rccl_ranks = setup_ranks(args)
     ca.lib()
     t0 = time.time()
-    text = movebuild.pangenome(int(args.base_mbp * 1e6), args.haplotypes, args.snp, seed=1)
-    mv = movebuild.build_move(text, device="cuda", with_locate=False)
-    mv.plcp = movebuild.plcp_gpu(mv)
-    torch.cuda.empty_cache()
-    index = ca.MoveIndex(mv)
-    log(f"[bench] b-move index of {mv.n / 1e6:.1f} Mbp ({args.haplotypes} haplotypes of {args.base_mbp} Mbp, {args.snp} SNPs): "
-        f"{mv.runs_fwd} / {mv.runs_rev} runs (n/r = {mv.n / mv.runs_fwd:.1f}), {index.device_bytes() / 1e6:.0f} MB in HBM, built in "
-        f"{time.time() - t0:.0f} s")
+    mv = index = None
+    if rank == 0:
+        text = movebuild.pangenome(int(args.base_mbp * 1e6), args.haplotypes, args.snp, seed=1)
+        mv = movebuild.build_move(text, device=dev, with_locate=False)
+        mv.plcp = movebuild.plcp_gpu(mv)
+        torch.cuda.empty_cache()
+        index = ca.MoveIndex(mv, device=local)
+        log(f"[bench] b-move index of {mv.n / 1e6:.1f} Mbp ({args.haplotypes} haplotypes of {args.base_mbp} Mbp, {args.snp} SNPs): "
+            f"{mv.runs_fwd} / {mv.runs_rev} runs (n/r = {mv.n / mv.runs_fwd:.1f}), {index.device_bytes() / 1e6:.0f} MB in HBM, built in "
+            f"{time.time() - t0:.0f} s")
     R, L, k = args.reads, args.read_len, args.k
-    buf, _ = synth.sample_reads_fast(torch.from_numpy(mv.text[:-1]).cuda(), R, L, seed=3, device="cuda",
-                                     edit_choices=(0, 1, 2, 3, 4, 5, 6))
+    broadcast_ms = None
+    if world > 1:
+        # replicated index (its DEVICE layout travels, one collective per array), sharded reads — as for the FM-index (§5)
+        from columba_amd.dist import broadcast_device_move_index, scatter_reads
+        dist.barrier()
+        tb = time.perf_counter()
+        index = broadcast_device_move_index(index, rank, local)
+        torch.cuda.synchronize()
+        dist.barrier()
+        broadcast_ms = (time.perf_counter() - tb) * 1e3
+        allr = None
+        if rank == 0:
+            log(f"[bench] device index ({index.device_bytes() / 1e9:.2f} GB) broadcast to {world - 1} peers in {broadcast_ms:.0f} ms")
+            buf, _ = synth.sample_reads_fast(torch.from_numpy(mv.text[:-1]).to(dev), R * world, L, seed=3, device=dev,
+                                             edit_choices=(0, 1, 2, 3, 4, 5, 6))
+            allr = torch.from_numpy(buf).to(dev).reshape(world, R * L)
+        buf = scatter_reads(allr, R * L, rank, world, dev)
+        del allr
+    else:
+        buf, _ = synth.sample_reads_fast(torch.from_numpy(mv.text[:-1]).to(dev), R, L, seed=3, device=dev,
+                                         edit_choices=(0, 1, 2, 3, 4, 5, 6))
     offs = np.arange(R + 1, dtype=np.uint64) * np.uint64(L)
     torch.cuda.empty_cache()
     strategy = ca.SearchStrategy("multiple_opt", "edit", "dynamic")
     batch = ca.MoveBatch(index, strategy, k, packed=(buf, offs), kmer_size=args.kmer_size)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         batch.run()
-    torch.cuda.synchronize()
+    sync()
     kern = {}
     tstart = time.perf_counter()
     for _ in range(args.steps):
         batch.run()
         for kname, ms in batch.timings().items():
             kern[kname] = kern.get(kname, 0.0) + ms
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - tstart
     steps = max(args.steps, 1)
+    per_rank_ms = [round(elapsed / steps * 1e3, 3)]
     occ, occ_offs, cnt = batch.results()
+    total_occ = len(occ)
+    if dist is not None:
+        from columba_amd.dist import allreduce_counters
+        cdev = "cpu" if dist.get_backend() == "gloo" else dev
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        every = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [round(float(t.item()) / steps * 1e3, 3) for t in every]
+        elapsed = max(float(t.item()) for t in every)
+        tt = torch.tensor([total_occ], dtype=torch.int64, device=cdev)
+        dist.all_reduce(tt)
+        total_occ = int(tt.item())
+        cnt = allreduce_counters(cnt, dev)   # (counters of the whole job; the occurrence lists stay on their ranks)
+    if rank != 0:
+        batch.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     avg = {kn: v / steps for kn, v in kern.items()}
     dominant = max(avg, key=avg.get)
     # algorithmic bytes (DESIGN.md §4.9): one move-table row fetched = 16 B (an aligned 16-byte row here; the reference reads the
@@ -250,7 +329,7 @@ def main_rlc(args):
                              f"{cnt['DFS_TABLE_ROWS'] / max(cnt['DFS_EXPANSIONS'], 1):.1f} rows per node expansion of the search",
                 "per_kernel": per_kernel}
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_py as op
         import schemes_py as sp
@@ -273,21 +352,25 @@ def main_rlc(args):
                          f"{bool(same)}; table rows stepped over by the reference's walks on the sample: {o_cnt['ROW_STEPS']}"}
     line = {
         "metric": "reads/sec (250bp, k=6 edit, pan-genome RLC b-move index)",
-        "value": round(R * steps / elapsed, 1), "unit": "reads/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "value": round(world * R * steps / elapsed, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64", "data": "synthetic",
+        "dtype": "u64", "data": "synthetic", "rccl_ranks": rccl_ranks, "per_rank_ms_per_step": per_rank_ms,
+        "index_broadcast_ms": None if broadcast_ms is None else round(broadcast_ms, 1), "host_affinity": affinity,
         "config": {"workload": f"BASELINE configs[4] stand-in: {args.haplotypes} haplotypes x {args.base_mbp} Mbp with {args.snp} SNPs "
                                f"({mv.n / 1e6:.0f} Mbp, r = {mv.runs_fwd}, n/r = {mv.n / mv.runs_fwd:.1f}) under the b-move index, {R} x {L} bp "
                                f"reads, k={k} edit distance, ALL mode, multiple_opt schemes with dynamic selection, dynamic partitioning, "
                                f"k-mer size {args.kmer_size}",
                    "reads_per_gpu": R, "read_len": L, "k": k, "text_bp": int(mv.n), "runs": [int(mv.runs_fwd), int(mv.runs_rev)],
-                   "index_bytes_hbm": index.device_bytes(), "occurrences": int(len(occ)),
+                   "index_bytes_hbm": index.device_bytes(), "occurrences": int(total_occ), "parallelism": f"read-shard x{world}",
                    "counters": {kk: int(cnt[kk]) for kk in ("NODE_COUNTER", "EXPANSIONS", "DFS_EXPANSIONS", "TABLE_ROWS",
                                                             "DFS_TABLE_ROWS", "TOTAL_REPORTED_POSITIONS", "SEARCH_STARTED", "MATRIX_ROWS")}},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)
     batch.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -334,35 +417,7 @@ def main():
 
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus))  # (before any GPU call in this process)
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus:
-        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
-    # CMB_BENCH_SHARE_GPU=1 + CMB_DIST_BACKEND=gloo: all ranks on cuda:0 — a rehearsal of the N > 1 code path on a
-    # one-GPU box (RCCL refuses two ranks on one device); numbers from such a run mean nothing
-    if os.environ.get("CMB_BENCH_SHARE_GPU"):
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    affinity = pin_to_gpu_numa_node(local) if not os.environ.get("CMB_BENCH_NO_PIN") else None
-    dist = None
-    rccl_ranks = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("CMB_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-        # proof that the collective library really spans all ranks: a sum of ones over device tensors (RCCL for `nccl`)
-        ones = torch.ones(1, dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else dev)
-        dist.all_reduce(ones)
-        rccl_ranks = int(ones.item())
-        assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, dist.get_world_size(), world)
+    rank, world, local, dev, affinity, dist, rccl_ranks = setup_ranks(args)
     if args.total_reads:
         args.reads = args.total_reads // world
 
