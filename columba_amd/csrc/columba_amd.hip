@@ -954,6 +954,7 @@ static int batchRunOne(cmb_batch* b) {
             q.items = b->items.p;
             q.itemCap = (uint32_t)std::min<size_t>(b->items.n, 0xFFFFFFF0u);
         }
+        int bfsAttempts = 0;
         for (int attempt = 0; !preset; attempt++) {
             HIPCHK(hipMemsetAsync(b->cnt.p, 0, 8 * sizeof(uint32_t), s));
             if (attempt) {
@@ -1040,8 +1041,8 @@ static int batchRunOne(cmb_batch* b) {
                 HIPCHK(hipGetLastError());
                 flags = hcnt[3];
                 if (flags & FLAG_NAIVE_Q) {
-                    if (attempt >= 30) return fail(CMB_ERR_INTERNAL, "the naive search's frontier keeps overflowing");
-                    b->nvQCap = std::max<size_t>(2 * b->nvQCap, (size_t)peakQ + peakQ / 4);
+                    if (attempt >= 60) return fail(CMB_ERR_INTERNAL, "the naive search's frontier keeps overflowing");
+                    b->nvQCap = std::max<size_t>(4 * b->nvQCap, (size_t)peakQ + peakQ / 4);
                     continue;
                 }
                 if (!drained && !(flags & (FLAG_ITEM_OVERFLOW | FLAG_FMOCC_OVERFLOW)))
@@ -1137,7 +1138,7 @@ static int batchRunOne(cmb_batch* b) {
                     hipLaunchKernelGGL(k_bfs_finish, dim3(1), dim3(256), 0, s, B, q);
                     if (hcnt[3] & (FLAG_BFS_Q | FLAG_BFS_EV | FLAG_BFS_F | FLAG_BFS_CTX | FLAG_BFS_ARENA)) {
                         // a pool was too small: grow what was asked for (at least x2) and run the search again
-                        if (attempt >= 24) return fail(CMB_ERR_INTERNAL, "frontier pools keep overflowing");
+                        if (++bfsAttempts >= 24) return fail(CMB_ERR_INTERNAL, "frontier pools keep overflowing");
                         if (hcnt[3] & FLAG_BFS_Q) b->bfsQCap = std::max<size_t>(2 * b->bfsQCap, (size_t)peakQ + peakQ / 4);
                         if (hcnt[3] & FLAG_BFS_EV) b->bfsEvCap = std::max<size_t>(2 * b->bfsEvCap, (size_t)peakEv + peakEv / 4);
                         if (hcnt[3] & FLAG_BFS_F) b->bfsFCap = std::max<size_t>(2 * b->bfsFCap, (size_t)pool[0] + pool[0] / 4);
@@ -1190,7 +1191,7 @@ static int batchRunOne(cmb_batch* b) {
                     Bf.blockCnt = b->bfsBlockCnt.p;
                     hipLaunchKernelGGL(k_bfs_finish, dim3(1), dim3(256), 0, s, Bf, q);
                     if (hcnt[3] & FLAG_BFS_Q) {
-                        if (attempt >= 24) return fail(CMB_ERR_INTERNAL, "frontier keeps overflowing");
+                        if (++bfsAttempts >= 24) return fail(CMB_ERR_INTERNAL, "frontier keeps overflowing");
                         b->bfsQCap = std::max<size_t>(2 * b->bfsQCap, (size_t)peakQ + peakQ / 4);
                         HIPCHK(hipStreamSynchronize(s));
                         tm.end("k_dfs");
@@ -1208,9 +1209,12 @@ static int batchRunOne(cmb_batch* b) {
             if (flags & FLAG_CAPACITY)
                 return fail(CMB_ERR_INTERNAL, "device search capacity exceeded (band width / descendants / stack)");
             if (flags & (FLAG_ITEM_OVERFLOW | FLAG_FMOCC_OVERFLOW | FLAG_DFS_OVERFLOW)) {
-                if (attempt >= 30) return fail(CMB_ERR_INTERNAL, "work queues keep overflowing");
-                if (hcnt[0] > q.itemCap) b->items.alloc((size_t)hcnt[0] * 2 + 1024);
-                if (hcnt[1] > q.fmCap) b->fm.alloc((size_t)hcnt[1] * 2 + 1024);
+                if (attempt >= 60) return fail(CMB_ERR_INTERNAL, "work queues keep overflowing");
+                // (a search that stopped at the overflow has only counted what it needed up to there: the naive search of very
+                // short reads, which match all over the text, asks for orders of magnitude more than the first guess)
+                const size_t grow = b->hasNaive ? 8 : 2;
+                if (hcnt[0] > q.itemCap) b->items.alloc((size_t)hcnt[0] * grow + 1024);
+                if (hcnt[1] > q.fmCap) b->fm.alloc((size_t)hcnt[1] * grow + 1024);
                 if (hcnt[5] > dfsCap) b->dfs.alloc((size_t)hcnt[5] + hcnt[5] / 8 + 1024);
                 continue;
             }

@@ -868,7 +868,7 @@ __device__ __forceinline__ bool verifyEdit(const DevIndex& ix, const uint64_t* o
     g.maxED = maxED;
     g.Wv = nZeros - 1 + maxED;
     g.Wh = maxED;
-    g.m = g.Wv + g.n;
+    g.m = max(g.Wv + g.n, g.Wv + g.Wh + 1u); // (bitparallelmatrix.cpp:98-103: reads shorter than the band)
     const uint32_t maxEnd = ix.n - 1;
     const uint32_t hEnd = limitEnd ? min(maxEnd, limitEnd) : min(maxEnd, start + g.m - 1);
     const uint32_t size = hEnd > start ? hEnd - start : 0;
@@ -1125,7 +1125,7 @@ k_verify_stage(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
         g.maxED = maxED;
         g.Wv = nZeros - 1 + maxED;
         g.Wh = maxED;
-        g.m = g.Wv + g.n;
+        g.m = max(g.Wv + g.n, g.Wv + g.Wh + 1u); // (bitparallelmatrix.cpp:98-103: reads shorter than the band)
         const uint32_t sfc = g.sfc();
         const uint32_t firstRow = (g.m - 1) - sfc;
         const uint32_t col = g.n - 1;
@@ -1327,7 +1327,7 @@ k_traceback(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf,
             g.maxED = maxED;
             g.Wv = nZeros - 1 + maxED;
             g.Wh = maxED;
-            g.m = g.Wv + g.n;
+            g.m = max(g.Wv + g.n, g.Wv + g.Wh + 1u); // (bitparallelmatrix.cpp:98-103: reads shorter than the band)
             firstRow = (g.m - 1) - g.sfc();
             col = g.n - 1;
             relLeft = TBW_BELOW - g.Wv; // (the wide rows' window; used by the wide walk only)
@@ -1777,7 +1777,7 @@ k_cigar(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf, const uint4* _
         g.maxED = maxED;
         g.Wv = maxED;
         g.Wh = maxED;
-        g.m = g.Wv + g.n;
+        g.m = max(g.Wv + g.n, g.Wv + g.Wh + 1u); // (bitparallelmatrix.cpp:98-103: reads shorter than the band)
         col = len;
         bool trace = have && maxED > 0 && size > 0 && !gapless;
         if (trace && NARROW && maxED > TBN_MAX_ED) { // (the host picks the wide kernel for k > 4)

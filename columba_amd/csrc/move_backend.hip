@@ -822,7 +822,7 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
         uint32_t nFm = 0;
         bool hasNaive = false; // reads of the slice are matched by naive backtracking (k_mvs_parts marked them in psel)
         for (int attempt = 0;; attempt++) {
-            if (attempt >= 30) return failWith(CMB_ERR_INTERNAL, "work queues keep overflowing");
+            if (attempt >= 60) return failWith(CMB_ERR_INTERNAL, "work queues keep overflowing");
             MV_HIPCHK(hipMemsetAsync(b->cnt.p, 0, 8 * sizeof(uint32_t), s));
             MV_HIPCHK(hipMemsetAsync(b->counters.p, 0, CMB_CNT_MAX * sizeof(unsigned long long), s));
             if (!b->fm.n) b->fm.alloc((size_t)nReads * 16 + 4096);
@@ -887,8 +887,9 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                 tm.end("k_naive");
                 MV_HIPCHK(hipGetLastError());
                 if (hcnt[3] & MVS_NAIVE_STOP) {
-                    if (hcnt[3] & FLAG_NAIVE_Q) b->nvQCap = std::max<size_t>(2 * b->nvQCap, (size_t)peakQ + peakQ / 4);
-                    if (hcnt[3] & FLAG_FMOCC_OVERFLOW) b->fm.alloc(std::max<size_t>(2 * b->fm.n, (size_t)hcnt[1] + hcnt[1] / 4 + 1024));
+                    // (the search stopped at the overflow: it has only counted what it needed up to there)
+                    if (hcnt[3] & FLAG_NAIVE_Q) b->nvQCap = std::max<size_t>(4 * b->nvQCap, (size_t)peakQ + peakQ / 4);
+                    if (hcnt[3] & FLAG_FMOCC_OVERFLOW) b->fm.alloc(std::max<size_t>(8 * b->fm.n, (size_t)hcnt[1] + hcnt[1] / 4 + 1024));
                     continue;
                 }
                 if (!drained) return failWith(CMB_ERR_INTERNAL, "the naive search did not finish within its pass bound");

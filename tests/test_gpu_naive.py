@@ -87,3 +87,20 @@ def test_naive_pool_growth(tiny, monkeypatch):
     g = tiny["genome"]
     reads = [bytes(g[p:p + 14]) for p in rng.integers(0, len(g) - 20, 300)]
     _compare(tiny, "naive", "edit", "dynamic", 2, reads, dups_rare=False)
+
+
+def test_short_reads_reach_the_in_text_verification(oracle_built):
+    """On a larger text the naive search of a short read crosses over to in-text verification with patterns shorter than the band
+    (the matrix then has 2 k + 1 rows whatever the pattern length, bitparallelmatrix.cpp:98-103: found by
+    tools/soak_mixed_lengths.py as a difference in MATRIX_ROWS / ABORTED_IN_TEXT_VERIF with identical occurrences)"""
+    import oracle_py as op
+    g, starts = synth.genome_rep(seed=31, n=300_000, scale=1.5)
+    ix = ib.build_index(g.tobytes(), seq_starts=starts, device="cuda")
+    w = {"genome": g, "ix": ix, "dev": ca.Index(ix), "orc": op.OracleIndex(ix), "op": op}
+    rng = np.random.default_rng(4)
+    reads = synth.sample_reads(g, 300, 100, seed=8, edit_choices=(0, 2, 4))
+    reads += [g[p:p + int(rng.integers(0, 7))].tobytes() for p in rng.integers(0, len(g) - 10, 40)]
+    _compare(w, "multiple_opt", "edit", "dynamic", 4, reads, dups_rare=False)
+    _compare(w, "columba", "edit", "dynamic", 7, reads[:300] + [r for r in reads[300:] if len(r) >= 4][:6], dups_rare=False)
+    w["dev"].close()
+
