@@ -521,6 +521,13 @@ struct cmb_batch {
                          // that carry final-column code)
     int metric = 1;
     DevStrategyK hostStrat{};
+    // schemes with more than MAXP parts (the greedy schemes for 8 ... 13 errors): tables of MAXP_WIDE parts, run by the wide instances
+    // of k_parts / k_exact / k_hbfs (Hamming distance; the edit-distance matcher stops at 7 errors)
+    bool wide = false;
+    DevStrategyKT<MAXP_WIDE> hostStratW{};
+    DevBuf<DevStrategyKT<MAXP_WIDE>> stratW;
+    DevBuf<PartOutT<MAXP_WIDE>> partsW;
+    uint32_t sNumParts = 0, sPartition = 0, sNSchemes = 0, sMaxSearches = 0; // of whichever table the batch runs on
     hipStream_t stream = nullptr;
     DevBuf<uint8_t> reads, seq;
     DevBuf<uint32_t> rec; // read records for k_parts / k_exact (k_prep)
@@ -691,7 +698,19 @@ static int batchCreateOne(cmb_index* idx, const cmb_strategy* st, uint32_t max_d
             if (st->metric == CMB_METRIC_EDIT && 3 * max_distance + 1 > MXW_LEFT)
                 return fail(CMB_ERR_UNSUPPORTED, "k >= 8 needs a wider in-text matrix, which is not implemented");
             try {
-                b->hostStrat = st->flatten(max_distance);
+                b->wide = st->numPartsFor(max_distance) > (uint32_t)MAXP;
+                if (b->wide && st->metric == CMB_METRIC_EDIT)
+                    return fail(CMB_ERR_UNSUPPORTED, "edit distance with search schemes of more than 8 parts is not implemented (Hamming distance is)");
+                if (max_distance > 13) return fail(CMB_ERR_UNSUPPORTED, "more than 13 errors (MAX_K, definitions.h:50)");
+                if (b->wide) {
+                    b->hostStratW = st->flatten<MAXP_WIDE>(max_distance);
+                    b->sNumParts = b->hostStratW.numParts, b->sPartition = b->hostStratW.partition, b->sNSchemes = b->hostStratW.nSchemes;
+                    for (int i = 0; i < b->hostStratW.nSchemes; i++) b->sMaxSearches = std::max<uint32_t>(b->sMaxSearches, b->hostStratW.sch[i].nSearches);
+                } else {
+                    b->hostStrat = st->flatten<MAXP>(max_distance);
+                    b->sNumParts = b->hostStrat.numParts, b->sPartition = b->hostStrat.partition, b->sNSchemes = b->hostStrat.nSchemes;
+                    for (int i = 0; i < b->hostStrat.nSchemes; i++) b->sMaxSearches = std::max<uint32_t>(b->sMaxSearches, b->hostStrat.sch[i].nSearches);
+                }
             } catch (const std::exception& e) {
                 return fail(CMB_ERR_INVALID, e.what());
             }
@@ -718,8 +737,13 @@ static int batchCreateOne(cmb_index* idx, const cmb_strategy* st, uint32_t max_d
         b->G.alloc((size_t)n_reads * 8 * b->gw); // eight bit-strings per read (both strands use them: gString)
         b->recW = ((1 + 2 * ((maxLen + 31) / 32)) + 3) / 4 * 4;
         b->rec.alloc((size_t)2 * n_reads * b->recW);
-        b->strat.upload(&b->hostStrat, 1);
-        b->parts.alloc((size_t)2 * n_reads);
+        if (b->wide) {
+            b->stratW.upload(&b->hostStratW, 1);
+            b->partsW.alloc((size_t)2 * n_reads);
+        } else {
+            b->strat.upload(&b->hostStrat, 1);
+            b->parts.alloc((size_t)2 * n_reads);
+        }
         b->dfs.alloc((size_t)n_reads * 2 + 4096);
         b->items.alloc((size_t)n_reads * 64 + 4096);
         b->fm.alloc((size_t)n_reads * 8 + 4096);
@@ -968,32 +992,42 @@ static int batchRunOne(cmb_batch* b) {
             q.textCap = (uint32_t)std::min<size_t>(b->text.n, 0xFFFFFFF0u);
             const uint32_t dfsCap = (uint32_t)std::min<size_t>(b->dfs.n, 0xFFFFFFF0u);
             tm.begin();
-            const uint32_t pParts = b->k ? b->hostStrat.numParts : 1;
-            const uint32_t stratBytes = (uint32_t)((sizeof(DevStrategyK) + 15) / 16 * 16);
+            const uint32_t pParts = b->k ? b->sNumParts : 1;
+            const uint32_t stratBytes = (uint32_t)(((b->wide ? sizeof(DevStrategyKT<MAXP_WIDE>) : sizeof(DevStrategyK)) + 15) / 16 * 16);
             const uint32_t rdWords = 2 * ((b->maxLen + 31) / 32);
             uint32_t nSlots = 1; // k = 0: one exact search per read x strand
+            const bool longReads = b->maxLen > 256;
             if (b->k) {
                 if (b->exr.n < (size_t)pParts * tasks) {
                     b->exr.alloc((size_t)pParts * tasks);
                     b->psel.alloc(tasks);
                 }
-                {
-                    const bool longReads = b->maxLen > 256;
-                    auto kp = longReads ? (b->hostStrat.partition == 0 ? k_parts<0, true> : b->hostStrat.partition == 1 ? k_parts<1, true> : k_parts<2, true>)
-                                        : (b->hostStrat.partition == 0 ? k_parts<0, false> : b->hostStrat.partition == 1 ? k_parts<1, false> : k_parts<2, false>);
-                    hipLaunchKernelGGL(kp, dim3(pSlots / 256), dim3(256),
-                                   stratBytes + (5 * pParts + rdWords) * 256 * sizeof(uint32_t), s, ix->d, b->strat.p, nReads,
+                const size_t pLds = stratBytes + (5 * pParts + rdWords) * 256 * sizeof(uint32_t);
+                if (b->wide) {
+                    constexpr int W = MAXP_WIDE;
+                    auto kp = longReads ? (b->sPartition == 0 ? k_parts<0, true, W> : b->sPartition == 1 ? k_parts<1, true, W> : k_parts<2, true, W>)
+                                        : (b->sPartition == 0 ? k_parts<0, false, W> : b->sPartition == 1 ? k_parts<1, false, W> : k_parts<2, false, W>);
+                    if (pLds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pLds));
+                    hipLaunchKernelGGL(kp, dim3(pSlots / 256), dim3(256), pLds, s, ix->d, b->stratW.p, nReads, b->k, b->maxLen, b->seq.p,
+                                       (const uint4*)b->rec.p, b->recW / 4, b->partsW.p, b->exr.p, b->psel.p, q);
+                } else {
+                    auto kp = longReads ? (b->sPartition == 0 ? k_parts<0, true> : b->sPartition == 1 ? k_parts<1, true> : k_parts<2, true>)
+                                        : (b->sPartition == 0 ? k_parts<0, false> : b->sPartition == 1 ? k_parts<1, false> : k_parts<2, false>);
+                    hipLaunchKernelGGL(kp, dim3(pSlots / 256), dim3(256), pLds, s, ix->d, b->strat.p, nReads,
                                    b->k, b->maxLen, b->seq.p, (const uint4*)b->rec.p, b->recW / 4, b->parts.p, b->exr.p,
                                    b->psel.p, q);
                 }
-                uint32_t maxSearches = 0;
-                for (int i = 0; i < b->hostStrat.nSchemes; i++)
-                    maxSearches = std::max<uint32_t>(maxSearches, b->hostStrat.sch[i].nSearches);
-                nSlots = maxSearches + 1; // + the part-level pre-verification
+                nSlots = b->sMaxSearches + 1; // + the part-level pre-verification
             }
             const uint64_t eTasks = (uint64_t)tasks * nSlots;
             const uint32_t eSlots = (uint32_t)std::min<uint64_t>(((eTasks + 255) / 256) * 256, 256ull * 4096ull);
-            hipLaunchKernelGGL(b->maxLen > 256 ? k_exact<true> : k_exact<false>, dim3(eSlots / 256), dim3(256), stratBytes + (pParts + rdWords) * 256 * sizeof(uint32_t),
+            const size_t eLds = stratBytes + (pParts + rdWords) * 256 * sizeof(uint32_t);
+            if (b->wide)
+                hipLaunchKernelGGL((longReads ? k_exact<true, MAXP_WIDE> : k_exact<false, MAXP_WIDE>), dim3(eSlots / 256), dim3(256), eLds, s, ix->d,
+                                   b->stratW.p, nReads, b->k, b->maxLen, nSlots, b->seq.p, (const uint4*)b->rec.p, b->recW / 4, b->partsW.p,
+                                   b->exr.p, b->psel.p, b->dfs.p, dfsCap, q);
+            else
+                hipLaunchKernelGGL(longReads ? k_exact<true> : k_exact<false>, dim3(eSlots / 256), dim3(256), eLds,
                                s, ix->d, b->strat.p, nReads, b->k, b->maxLen, nSlots, b->seq.p, (const uint4*)b->rec.p,
                                b->recW / 4, b->parts.p, b->exr.p, b->psel.p, b->dfs.p, dfsCap, q);
             tm.end("k_partition");
@@ -1152,7 +1186,7 @@ static int batchRunOne(cmb_batch* b) {
                         return fail(CMB_ERR_INTERNAL, "frontier search did not finish within its pass bound");
                 } else {
                     // ---- Hamming distance: the same frontier idea without a matrix (dev_bfs_hamming.hpp)
-                    const uint32_t maxPass = b->maxLen + 2 * MAXP + 16;
+                    const uint32_t maxPass = b->maxLen + 2 * (b->wide ? MAXP_WIDE : MAXP) + 16;
                     if (!b->bfsQCap) b->bfsQCap = (getenv("CMB_TEST_SMALL_POOLS") ? 0 : (size_t)nReads * 4) + 1024;
                     b->bfsQCap = std::max<size_t>(b->bfsQCap, (size_t)nDfs + 1024);
                     for (int j = 0; j < 2; j++)
@@ -1168,8 +1202,12 @@ static int batchRunOne(cmb_batch* b) {
                     H.qCap = (uint32_t)std::min<size_t>(b->bfsQ[0].n / 2, 0xFFFFFFF0u);
                     H.nq = b->bfsCnt.p;
                     H.blockCnt = b->bfsBlockCnt.p;
-                    const uint32_t hLds = (uint32_t)((sizeof(DevStrategyK) + 15) / 16 * 16);
-                    hipLaunchKernelGGL(k_hbfs<true>, dim3(std::min<uint32_t>((nDfs + 255) / 256, BFS_GRID)), dim3(256), hLds, s,
+                    const uint32_t hLds = stratBytes;
+                    if (b->wide)
+                        hipLaunchKernelGGL((k_hbfs<true, MAXP_WIDE>), dim3(std::min<uint32_t>((nDfs + 255) / 256, BFS_GRID)), dim3(256), hLds, s,
+                                           ix->d, b->stratW.p, H, 0u, b->dfs.p, nDfs, b->maxLen, b->seq.p, b->partsW.p, q);
+                    else
+                        hipLaunchKernelGGL(k_hbfs<true>, dim3(std::min<uint32_t>((nDfs + 255) / 256, BFS_GRID)), dim3(256), hLds, s,
                                        ix->d, b->strat.p, H, 0u, b->dfs.p, nDfs, b->maxLen, b->seq.p, b->parts.p, q);
                     std::vector<uint32_t> hc(cntWords);
                     uint32_t pass = 0, peakQ = 0;
@@ -1177,7 +1215,11 @@ static int batchRunOne(cmb_batch* b) {
                     while (!drained && pass < maxPass) {
                         const uint32_t upTo = std::min(pass + 16u, maxPass);
                         for (; pass < upTo; pass++)
-                            hipLaunchKernelGGL(k_hbfs<false>, dim3(BFS_GRID), dim3(256), hLds, s, ix->d, b->strat.p, H, pass,
+                            if (b->wide)
+                                hipLaunchKernelGGL((k_hbfs<false, MAXP_WIDE>), dim3(BFS_GRID), dim3(256), hLds, s, ix->d, b->stratW.p, H, pass,
+                                                   (const DfsTask*)nullptr, 0u, b->maxLen, b->seq.p, b->partsW.p, q);
+                            else
+                                hipLaunchKernelGGL(k_hbfs<false>, dim3(BFS_GRID), dim3(256), hLds, s, ix->d, b->strat.p, H, pass,
                                                (const DfsTask*)nullptr, 0u, b->maxLen, b->seq.p, b->parts.p, q);
                         HIPCHK(hipMemcpyAsync(hc.data(), b->bfsCnt.p, cntWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                         HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
@@ -1446,7 +1488,7 @@ static int batchRunOne(cmb_batch* b) {
             }
             if (b->frank.n < nText) b->frank.alloc((size_t)nText + nText / 8 + 256);
             hipLaunchKernelGGL(k_pack_keys, dim3((nText + 255) / 256), dim3(256), 0, s, b->text.p, nText, b->offs.p, b->k, b->keysA.p,
-                               b->cnt.p, 1u, (const uint8_t*)b->psel.p);
+                               b->cnt.p, 1u, (const uint8_t*)b->psel.p, b->metric == CMB_METRIC_HAMMING ? 1u : 0u);
             size_t tmpBytes = 0;
             HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, b->keysA.p, b->keysB.p, nText, 0, 64, s));
             if (b->sortTmp.n < tmpBytes) b->sortTmp.alloc(tmpBytes + 256);
@@ -1481,7 +1523,7 @@ static int batchRunOne(cmb_batch* b) {
             hipLaunchKernelGGL(k_naive_drop, dim3((nText + 255) / 256), dim3(256), 0, s, b->text.p, nText, (const uint8_t*)b->psel.p);
             if (naiveSurvivors)
                 hipLaunchKernelGGL(k_naive_keep, dim3((nText + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->offs.p, b->k,
-                                   b->frank.p, b->foffs.p, b->text.p + nText);
+                                   b->frank.p, b->foffs.p, b->text.p + nText, b->metric == CMB_METRIC_HAMMING ? 1u : 0u);
             HIPCHK(hipGetLastError());
             nText += (uint32_t)naiveSurvivors;
             tm.end("k_naive_filter");
@@ -1510,7 +1552,8 @@ static int batchRunOne(cmb_batch* b) {
             }
             if (nText) {
                 hipLaunchKernelGGL(k_pack_keys, dim3((nText + 255) / 256), dim3(256), 0, s, b->text.p, nText, b->offs.p,
-                                   b->k, b->keysA.p, b->cnt.p, b->perStrand ? 1u : 0u);
+                                   b->k, b->keysA.p, b->cnt.p, b->perStrand ? 1u : 0u, (const uint8_t*)nullptr,
+                                   b->metric == CMB_METRIC_HAMMING ? 1u : 0u);
                 size_t tmpBytes = 0;
                 HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, b->keysA.p, b->keysB.p, nText, 0, 64, s));
                 if (b->sortTmp.n < tmpBytes) b->sortTmp.alloc(tmpBytes + 256);
@@ -1545,7 +1588,7 @@ static int batchRunOne(cmb_batch* b) {
             if (total)
                 hipLaunchKernelGGL(k_filter_write, dim3((nText + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->offs.p,
                                    b->k, b->frank.p, b->foffs.p, b->fout.p, b->wantAln ? b->foutRead.p : (uint32_t*)nullptr,
-                                   b->perStrand ? 1u : 0u);
+                                   b->perStrand ? 1u : 0u, b->metric == CMB_METRIC_HAMMING ? 1u : 0u);
             HIPCHK(hipGetLastError());
             tm.end("k_filter");
             lap("filter");
@@ -1710,7 +1753,7 @@ extern "C" int cmb_batch_allow_unsupported(cmb_batch* b, int on) {
 }
 static uint32_t readStatusOne(const cmb_batch* b, uint8_t* status) {
     uint32_t n = 0;
-    const uint32_t P = b->k ? b->hostStrat.numParts : 0;
+    const uint32_t P = b->k ? b->sNumParts : 0;
     for (uint32_t i = 0; i < b->nReads; i++) {
         const uint64_t len = b->hostOffs[i + 1] - b->hostOffs[i];
         const bool naive = b->k > 0 && (P >= len || P == 1);

@@ -21,16 +21,20 @@ struct HbfsBufs {
 
 // phase entry: what a node of phase `idx` carries (IndexInterface::recApproxMatchHamming prologue + the
 // length before the pattern's leftmost processed part used by the in-text switch)
-__device__ __forceinline__ uint32_t hbfsPhaseWord(const DevSearch& s, const PartOut& po, int idx) {
+template <int MP>
+__device__ __forceinline__ uint32_t hbfsPhaseWord(const DevSearchT<MP>& s, const PartOutT<MP>& po, int idx) {
     const int part = s.order[idx];
     const uint32_t lb = idx == 0 ? 0u : (uint32_t)po.pb[s.low[idx - 1]];
     return (uint32_t)po.pb[part] | ((uint32_t)po.pe[part] << 9) | (lb << 18);
 }
 
-template <bool START>
+template <bool START, int MP = MAXP>
 __global__ void __launch_bounds__(256)
-k_hbfs(DevIndex ix, const DevStrategyK* __restrict__ stp, HbfsBufs B, uint32_t pass, const DfsTask* __restrict__ tasks,
-       uint32_t nTasks, uint32_t maxLen, const uint8_t* __restrict__ seq, const PartOut* __restrict__ parts, Queues q) {
+k_hbfs(DevIndex ix, const DevStrategyKT<MP>* __restrict__ stp, HbfsBufs B, uint32_t pass, const DfsTask* __restrict__ tasks,
+       uint32_t nTasks, uint32_t maxLen, const uint8_t* __restrict__ seq, const PartOutT<MP>* __restrict__ parts, Queues q) {
+    typedef DevStrategyKT<MP> DevStrategyK; // (the instance's table size)
+    typedef DevSearchT<MP> DevSearch;
+    typedef PartOutT<MP> PartOut;
     __shared__ uint32_t sh[4][5];
     extern __shared__ uint32_t stratLds[];
     if (blockStopped(q)) return;

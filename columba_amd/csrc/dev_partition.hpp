@@ -25,9 +25,10 @@ struct DfsTask {
     uint32_t depth;                   // exact length matched so far
 };
 
-struct PartOut { // per read x strand: the parts, needed again by k_dfs
-    uint16_t pb[MAXP], pe[MAXP];
+template <int MP> struct PartOutT { // per read x strand: the parts, needed again by k_dfs
+    uint16_t pb[MP], pe[MP];
 };
+typedef PartOutT<MAXP> PartOut;
 
 enum : int { PH_CALC = 0, PH_DYN, PH_SEED, PH_FIN, PH_DONE };
 // what a lane asks of the iteration's single memory step
@@ -36,10 +37,10 @@ enum : int { RQ_NONE = 0, RQ_RANK, RQ_SEED, RQ_REC };
 // PARTITION: 0 uniform, 1 static, 2 dynamic (searchstrategy.h PartitionStrategy) — a template parameter, so that
 // each k_parts instance only carries the phases of its own mode (the extension loop of the dynamic mode is a
 // third of the instructions of the generic one).
-template <int PARTITION>
+template <int PARTITION, int MP = MAXP>
 struct PartMachine {
     const DevIndex& ix;
-    const DevStrategyK& st;
+    const DevStrategyKT<MP>& st;
     // task
     uint32_t rsId = 0, len = 0, k = 0;
     const uint8_t* seq = nullptr;
@@ -88,7 +89,7 @@ struct PartMachine {
     uint32_t reqCode = 0;
     RangePair reqParent;
 
-    __device__ PartMachine(const DevIndex& i, const DevStrategyK& s, uint32_t* ldsBase, uint32_t tid, uint32_t stride)
+    __device__ PartMachine(const DevIndex& i, const DevStrategyKT<MP>& s, uint32_t* ldsBase, uint32_t tid, uint32_t stride)
         : ix(i), st(s), lds(ldsBase), ltid(tid), lstride(stride), lparts(s.numParts ? s.numParts : 1) {}
     __device__ void setReadWords(uint32_t maxLen) { // LDS words after the 5 x lparts partition fields
         rdBase = 5u * lparts;
@@ -235,9 +236,9 @@ struct PartMachine {
     }
 
     // RQ_SEED: issue the k-mer table loads of all parts (indexinterface.h:590), then take the replies
-    __device__ __forceinline__ void seedIssue(uint4 v[8]) const {
+    __device__ __forceinline__ void seedIssue(uint4 v[MP]) const {
 #pragma unroll
-        for (int i = 0; i < MAXP; i++)
+        for (int i = 0; i < MP; i++)
             if (i < numParts) {
                 bool valid;
                 const uint32_t key = kmerKey(PB(i), PE(i), valid);
@@ -245,9 +246,9 @@ struct PartMachine {
                 if (valid) v[i] = ix.kmer[key];
             }
     }
-    __device__ __forceinline__ void seedTake(const uint4 v[8]) {
+    __device__ __forceinline__ void seedTake(const uint4 v[MP]) {
 #pragma unroll
-        for (int i = 0; i < MAXP; i++)
+        for (int i = 0; i < MP; i++)
             if (i < numParts) setEX(i, RangePair{{v[i].x, v[i].y}, {v[i].z, v[i].w}});
         phase = PH_DYN;
     }
@@ -382,7 +383,7 @@ struct PartMachine {
 
     // partitioning done: select the scheme (MultipleSchemes::createSearches, searchstrategy.h:2505-2537) and
     // hand parts, exact ranges and selection to k_exact
-    __device__ void finish(PartOut* parts, uint4* exr, uint8_t* psel, uint32_t total) {
+    __device__ void finish(PartOutT<MP>* parts, uint4* exr, uint8_t* psel, uint32_t total) {
         int sel = 0;
         if (st.nSchemes > 1) {
             uint32_t tot = 0;
@@ -398,9 +399,9 @@ struct PartMachine {
                 }
             }
         }
-        PartOut po;
+        PartOutT<MP> po;
 #pragma unroll
-        for (int i = 0; i < MAXP; i++) {
+        for (int i = 0; i < MP; i++) {
             po.pb[i] = i < numParts ? (uint16_t)PB(i) : (uint16_t)0;
             po.pe[i] = i < numParts ? (uint16_t)PE(i) : (uint16_t)0;
         }
@@ -420,9 +421,10 @@ struct PartMachine {
 // k = 0            : one lane per read x strand, exactMatchesOutput (indexinterface.cpp:947-1014).
 enum : int { EX_IDLE = 0, EX_HDR, EX_LOAD, EX_RUN, EX_K0 };
 
+template <int MP = MAXP>
 struct ExactLane {
     const DevIndex& ix;
-    const DevStrategyK& st;
+    const DevStrategyKT<MP>& st;
     // LDS per lane: lparts words (pb | pe << 16), then 2 x pw1 read words (low / high code bits)
     uint32_t* lds;
     uint32_t ltid, lstride, lparts, pw1;
@@ -452,7 +454,7 @@ struct ExactLane {
     // counters
     uint32_t cNode = 0, cExp = 0, cImm = 0, cStart = 0;
 
-    __device__ ExactLane(const DevIndex& i, const DevStrategyK& s, uint32_t* ldsBase, uint32_t tid, uint32_t stride,
+    __device__ ExactLane(const DevIndex& i, const DevStrategyKT<MP>& s, uint32_t* ldsBase, uint32_t tid, uint32_t stride,
                          uint32_t maxLen)
         : ix(i), st(s), lds(ldsBase), ltid(tid), lstride(stride), lparts(s.numParts ? s.numParts : 1),
           pw1((maxLen + 31) / 32) {}
@@ -497,7 +499,7 @@ struct ExactLane {
 
     // the search starts from the exact range of its first part (doRecSearch, searchstrategy.cpp:1181-1254)
     __device__ void startSearch(const RangePair& first) {
-        const DevSearch& s = st.sch[sel].s[slot];
+        const DevSearchT<MP>& s = st.sch[sel].s[slot];
         cur = first;
         if (cur.width() <= ix.switchPoint) { // covered by the part-level pre-verification
             phase = EX_IDLE;
@@ -512,7 +514,7 @@ struct ExactLane {
 
     // bookkeeping up to the next extension of the running search
     __device__ void advance() {
-        const DevSearch& s = st.sch[sel].s[slot];
+        const DevSearchT<MP>& s = st.sch[sel].s[slot];
         for (;;) {
             if (s.U[partInSearch] == 0) {
                 const int part = s.order[partInSearch];

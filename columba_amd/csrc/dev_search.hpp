@@ -19,7 +19,8 @@
 
 namespace cmb {
 
-constexpr int MAXP = 8;      // max parts (k <= 6 -> 7 parts in multiple_opt)
+constexpr int MAXP = 8;      // max parts of the COMMON tables (k <= 7: k + 1 parts; k + 2 for kuch2 / 01*0 up to k = 4 ...)
+constexpr int MAXP_WIDE = 16; // ... and of the wide ones (the greedy schemes for 8 ... 13 errors have k + 1 parts: searchstrategy.h:3396-3658)
 constexpr int MAXS = 16;     // max searches per scheme
 constexpr int MAXSCH = 4;    // max alternative schemes per k (dynamic selection)
 constexpr int MAX_READ = 480; // (9-bit part bounds and matrix dimensions in the records: < 512 with the band; contexts of batches with reads beyond
@@ -27,24 +28,29 @@ constexpr int MAX_READ = 480; // (9-bit part bounds and matrix dimensions in the
 constexpr int DESC_MAX = 56; // descendants handed to the next phase
 
 // ---- strategy tables (built on the host by host/schemes.cpp) -------------------------------
-struct DevSearch { // Search, src/search.h:55-101
+// Templates over the number of parts the tables hold: the kernels of the headline path are instances for MAXP (their registers,
+// LDS and record sizes are those of that size), batches whose scheme has more parts run instances for MAXP_WIDE.
+template <int MP> struct DevSearchT { // Search, src/search.h:55-101
     uint8_t n;
-    uint8_t order[MAXP], L[MAXP], U[MAXP], dir[MAXP], dsw[MAXP];
-    uint8_t low[MAXP], high[MAXP]; // lowestAndHighestPartsProcessedBefore[i]
-    uint8_t uniAll, uniIdx;        // isUnidirectionalBackwards(i) = uniAll || i >= uniIdx (:479)
+    uint8_t order[MP], L[MP], U[MP], dir[MP], dsw[MP];
+    uint8_t low[MP], high[MP]; // lowestAndHighestPartsProcessedBefore[i]
+    uint8_t uniAll, uniIdx;    // isUnidirectionalBackwards(i) = uniAll || i >= uniIdx (:479)
 };
-struct DevScheme {
+template <int MP> struct DevSchemeT {
     uint8_t nSearches, critical; // SearchScheme::criticalPartIndex (search.h:525)
-    DevSearch s[MAXS];
+    DevSearchT<MP> s[MAXS];
 };
-struct DevStrategyK { // everything matchWithSearches needs for one distance k
+template <int MP> struct DevStrategyKT { // everything matchWithSearches needs for one distance k
     uint8_t metric, partition, numParts, nSchemes;
     uint32_t kmerCutOff;
-    double seeding[MAXP]; // getSeedingPositions (searchstrategy.h:1825)
-    uint64_t weights[MAXP]; // getWeights (:283)
-    double begins[MAXP];  // getBegins (:245)
-    DevScheme sch[MAXSCH];
+    double seeding[MP];   // getSeedingPositions (searchstrategy.h:1825)
+    uint64_t weights[MP]; // getWeights (:283)
+    double begins[MP];    // getBegins (:245)
+    DevSchemeT<MP> sch[MAXSCH];
 };
+typedef DevSearchT<MAXP> DevSearch;
+typedef DevSchemeT<MAXP> DevScheme;
+typedef DevStrategyKT<MAXP> DevStrategyK;
 
 // ---- work items -----------------------------------------------------------------------------
 enum { ITEM_EDIT = 0, ITEM_HAMMING = 1, ITEM_EXACT = 2 };

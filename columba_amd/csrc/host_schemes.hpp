@@ -35,12 +35,13 @@ struct HostSearch {
     }
 };
 
-inline DevSearch toDevSearch(const HostSearch& h) {
+template <int MP = MAXP_WIDE>
+inline DevSearchT<MP> toDevSearch(const HostSearch& h) {
     const size_t n = h.pi.size();
     if (n != h.L.size() || n != h.U.size())
         throw std::runtime_error("Could not create search, the sizes of all vectors are not equal");
-    if (n < 1 || n > (size_t)MAXP) throw std::runtime_error("unsupported number of parts in search");
-    DevSearch d{};
+    if (n < 1 || n > (size_t)MP) throw std::runtime_error("unsupported number of parts in search");
+    DevSearchT<MP> d{};
     d.n = (uint8_t)n;
     for (size_t i = 0; i < n; i++) {
         d.order[i] = (uint8_t)h.pi[i];
@@ -203,17 +204,25 @@ struct cmb_strategy {
         return out;
     }
 
-    // flatten everything matchWithSearches needs for distance k
-    cmb::DevStrategyK flatten(uint32_t k) const {
+    // number of parts of the schemes for distance k (0: the strategy has none)
+    uint32_t numPartsFor(uint32_t k) const {
+        auto it = schemes.find(k);
+        return it == schemes.end() || it->second.empty() ? 0u : it->second.front().numParts();
+    }
+    // flatten everything matchWithSearches needs for distance k into device tables of MP parts (MAXP: the common kernels,
+    // MAXP_WIDE: the instances for schemes with more parts)
+    template <int MP = cmb::MAXP>
+    cmb::DevStrategyKT<MP> flatten(uint32_t k) const {
         using namespace cmb;
+        typedef DevStrategyKT<MP> DevStrategyK;
         auto it = schemes.find(k);
         if (it == schemes.end() || it->second.empty())
             throw std::runtime_error("the search strategy does not support distance " + std::to_string(k));
         const auto& alts = it->second;
         if (alts.size() > (size_t)MAXSCH) throw std::runtime_error("too many alternative schemes");
-        if (alts.front().numParts() > (uint32_t)MAXP)
-            throw std::runtime_error("search schemes with more than " + std::to_string(MAXP) + " parts (" + std::to_string(k) +
-                                     " errors) cannot be run on the device: its tables hold " + std::to_string(MAXP) + " parts");
+        if (alts.front().numParts() > (uint32_t)MP)
+            throw std::runtime_error("search schemes with more than " + std::to_string(MP) + " parts (" + std::to_string(k) +
+                                     " errors) cannot be run on the device: its tables hold " + std::to_string(MP) + " parts");
         DevStrategyK d{};
         d.metric = (uint8_t)metric;
         d.partition = (uint8_t)partition;
@@ -249,7 +258,7 @@ struct cmb_strategy {
             if (h.searches.size() > (size_t)MAXS) throw std::runtime_error("too many searches in scheme");
             d.sch[a].nSearches = (uint8_t)h.searches.size();
             d.sch[a].critical = (uint8_t)h.critical;
-            for (size_t i = 0; i < h.searches.size(); i++) d.sch[a].s[i] = toDevSearch(h.searches[i]);
+            for (size_t i = 0; i < h.searches.size(); i++) d.sch[a].s[i] = toDevSearch<MP>(h.searches[i]);
         }
         return d;
     }

@@ -338,11 +338,12 @@ __device__ __forceinline__ bool takeExtend(const DevIndex& ix, int mode, const R
 // (the partitioning of every read costs about the same).  Every loop iteration has ONE memory step: each lane
 // issues the loads of its request — the two rank blocks of an extension (4 x 16 B from 2 sectors), the k-mer
 // table entries of its seeds, or its read record — before any reply is consumed.
-template <int PARTITION, bool LONG>
-__global__ void __launch_bounds__(256, 4)
-k_parts(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint32_t k, uint32_t maxLen,
-        const uint8_t* __restrict__ seq, const uint4* __restrict__ rec, uint32_t recQ, PartOut* __restrict__ parts,
+template <int PARTITION, bool LONG, int MP = MAXP>
+__global__ void __launch_bounds__(256, MP == MAXP ? 4 : 2)
+k_parts(DevIndex ix, const DevStrategyKT<MP>* __restrict__ stp, uint32_t nReads, uint32_t k, uint32_t maxLen,
+        const uint8_t* __restrict__ seq, const uint4* __restrict__ rec, uint32_t recQ, PartOutT<MP>* __restrict__ parts,
         uint4* __restrict__ exr, uint8_t* __restrict__ psel, Queues q) {
+    typedef DevStrategyKT<MP> DevStrategyK; // (the instance's table size)
     // LDS: a copy of the strategy tables, then per lane 5 x numParts partition words and 2 x ceil(maxLen/32)
     // read words
     extern __shared__ uint32_t partLds[];
@@ -351,7 +352,7 @@ k_parts(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
         partLds[i] = reinterpret_cast<const uint32_t*>(stp)[i];
     __syncthreads();
     const DevStrategyK& lst = *reinterpret_cast<const DevStrategyK*>(partLds);
-    PartMachine<PARTITION> m(ix, lst, partLds + STRAT_WORDS, threadIdx.x, blockDim.x);
+    PartMachine<PARTITION, MP> m(ix, lst, partLds + STRAT_WORDS, threadIdx.x, blockDim.x);
     m.setReadWords(maxLen);
     const uint32_t total = 2 * nReads;
     // Lock-step batches: every lane of the wavefront takes one read x strand, all load their read records, all
@@ -363,7 +364,7 @@ k_parts(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
     const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t base = first & ~63u; base < total; base += stride) { // wave-uniform trip count
         const uint32_t rs = base + (threadIdx.x & 63u);
-        uint4 v[8];
+        uint4 v[MP];
         m.phase = PH_DONE;
         m.req = RQ_NONE;
         if (rs < total) {
@@ -402,19 +403,21 @@ k_parts(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
 
 // Exact phases of the searches + part-level pre-verification (dev_partition.hpp: ExactLane); k = 0: the whole
 // exact search.  One lane per (read x strand, slot), static round-robin; same one-memory-step loop.
-template <bool LONG>
-__global__ void __launch_bounds__(256, 4)
-k_exact(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint32_t k, uint32_t maxLen,
+template <bool LONG, int MP = MAXP>
+__global__ void __launch_bounds__(256, MP == MAXP ? 4 : 2)
+k_exact(DevIndex ix, const DevStrategyKT<MP>* __restrict__ stp, uint32_t nReads, uint32_t k, uint32_t maxLen,
         uint32_t nSlots, const uint8_t* __restrict__ seq, const uint4* __restrict__ rec, uint32_t recQ,
-        const PartOut* __restrict__ parts, const uint4* __restrict__ exr, const uint8_t* __restrict__ psel,
+        const PartOutT<MP>* __restrict__ parts, const uint4* __restrict__ exr, const uint8_t* __restrict__ psel,
         DfsTask* __restrict__ dfsQ, uint32_t dfsCap, Queues q) {
+    typedef DevStrategyKT<MP> DevStrategyK; // (the instance's table size)
+    typedef DevSchemeT<MP> DevScheme;
     extern __shared__ uint32_t partLds[]; // strategy tables, then per lane numParts + 2 x ceil(maxLen/32) words
     constexpr uint32_t STRAT_WORDS = (uint32_t)((sizeof(DevStrategyK) + 15) / 16 * 4);
     for (uint32_t i = threadIdx.x; i < sizeof(DevStrategyK) / 4; i += blockDim.x)
         partLds[i] = reinterpret_cast<const uint32_t*>(stp)[i];
     __syncthreads();
     const DevStrategyK& lst = *reinterpret_cast<const DevStrategyK*>(partLds);
-    ExactLane m(ix, lst, partLds + STRAT_WORDS, threadIdx.x, blockDim.x, maxLen);
+    ExactLane<MP> m(ix, lst, partLds + STRAT_WORDS, threadIdx.x, blockDim.x, maxLen);
     const uint32_t total = 2 * nReads;
     const uint64_t nTasks = (uint64_t)total * nSlots;
     uint64_t nextT = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -442,7 +445,7 @@ k_exact(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
             else if (m.phase == EX_K0) m.advanceK0();
         }
         // (3) the memory step
-        uint4 v[8];
+        uint4 v[MP];
         uint32_t hdr = 0;
         const int ph = done ? EX_IDLE : m.phase;
         const bool isPost = m.slot == nSlots - 1;
@@ -451,8 +454,8 @@ k_exact(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
         } else if (ph == EX_HDR) { // scheme selection + parts
             hdr = psel[m.rsId];
             const uint4* pp = reinterpret_cast<const uint4*>(parts + m.rsId);
-            v[0] = pp[0];
-            v[1] = pp[1];
+#pragma unroll
+            for (int j = 0; j < MP / 4; j++) v[j] = pp[j]; // (pb[MP], pe[MP]: 4 MP bytes)
         } else if (ph == EX_LOAD) {
             if (k == 0 || !isPost) { // read record (+ exact range of the first part of the search)
 #pragma unroll
@@ -461,7 +464,7 @@ k_exact(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
                 if (k != 0) v[5] = exr[(size_t)lst.sch[m.sel].s[m.slot].order[0] * total + m.rsId];
             } else { // exact ranges of all parts
 #pragma unroll
-                for (int i = 0; i < MAXP; i++)
+                for (int i = 0; i < MP; i++)
                     if (i < numParts) v[i] = exr[(size_t)i * total + m.rsId];
             }
         }
@@ -474,8 +477,8 @@ k_exact(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
             m.sel = (int)(hdr & 0x7Fu);
             const uint16_t* pv = reinterpret_cast<const uint16_t*>(v);
 #pragma unroll
-            for (int i = 0; i < MAXP; i++)
-                if (i < numParts) m.PBE(i) = (uint32_t)pv[i] | ((uint32_t)pv[MAXP + i] << 16);
+            for (int i = 0; i < MP; i++)
+                if (i < numParts) m.PBE(i) = (uint32_t)pv[i] | ((uint32_t)pv[MP + i] << 16);
             m.phase = EX_LOAD;
             if (hdr & 0x80u) m.phase = EX_IDLE; // unsupported read (reported by k_parts)
             else if (!isPost) {
@@ -504,7 +507,7 @@ k_exact(DevIndex ix, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint
         if (__ballot(ph == EX_LOAD && k != 0 && isPost) != 0ull) {
             const bool mine = ph == EX_LOAD && k != 0 && isPost;
 #pragma unroll
-            for (int i = 0; i < MAXP; i++) {
+            for (int i = 0; i < MP; i++) {
                 if (i >= numParts) break;
                 uint32_t n = 0, a = 0, meta = 0;
                 if (mine) {
@@ -1543,6 +1546,7 @@ k_fmocc(DevIndex ix, const FMOccRec* __restrict__ recs, uint32_t n, Queues q) {
 // src/indexinterface.cpp:1331-1491) on the device.  Every raw text occurrence is packed into ONE 64-bit
 // key whose natural order is the reference's TextOcc::operator< (src/indexhelpers.h:779-795) within a
 // read:   read[63:40] | begin[39:8] | distance[7:5] | (width - (len - k))[4:1] | strand[0]
+// Hamming distance (every occurrence has the width of the read): distance[7:4] | 0[3:1] | strand[0] — four bits, for up to 13 errors
 // One radix sort of the keys (rocPRIM) therefore groups the occurrences per read AND orders them;
 // k_filter then walks each read's segment once: unique (same range and distance, :811), then the
 // redundancy filter (:1447-1485).
@@ -1551,7 +1555,8 @@ k_pack_keys(const TextOccRec* __restrict__ text, uint32_t n, const uint64_t* __r
             unsigned long long* __restrict__ keys, uint32_t* __restrict__ cnt,
             uint32_t perStrand /* BEST mode filters every strand by itself (mapRead, searchstrategy.h:490-523): the group of a
                                   key is then read x strand, not the read */,
-            const uint8_t* __restrict__ only = nullptr /* dev_bfs_naive.hpp: keys for the reads marked here (bit 7), holes for the rest */) {
+            const uint8_t* __restrict__ only = nullptr /* dev_bfs_naive.hpp: keys for the reads marked here (bit 7), holes for the rest */,
+            uint32_t hamming = 0 /* the Hamming layout of the low byte */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const TextOccRec t = text[i];
@@ -1563,10 +1568,17 @@ k_pack_keys(const TextOccRec* __restrict__ text, uint32_t n, const uint64_t* __r
     const uint32_t len = (uint32_t)(offs[r + 1] - offs[r]);
     const uint32_t width = t.end - t.begin;
     const uint32_t wrel = width - (len - k); // in [0, 2k] for every occurrence of a read of length len
-    if (wrel > 15u || t.dist > 7u) atomicOr(&cnt[3], (uint32_t)FLAG_CAPACITY);
     const uint32_t grp = perStrand ? t.rsId : r;
-    keys[i] = ((unsigned long long)grp << 40) | ((unsigned long long)t.begin << 8) | ((unsigned long long)(t.dist & 7u) << 5) |
-              ((unsigned long long)(wrel & 15u) << 1) | (unsigned long long)(perStrand ? 0u : (t.rsId & 1u));
+    uint32_t low;
+    if (hamming) {
+        if (width != len || t.dist > 15u) atomicOr(&cnt[3], (uint32_t)FLAG_CAPACITY);
+        low = (t.dist & 15u) << 4;
+    } else {
+        if (wrel > 15u || t.dist > 7u) atomicOr(&cnt[3], (uint32_t)FLAG_CAPACITY);
+        low = ((t.dist & 7u) << 5) | ((wrel & 15u) << 1);
+    }
+    keys[i] = ((unsigned long long)grp << 40) | ((unsigned long long)t.begin << 8) | (unsigned long long)low |
+              (unsigned long long)(perStrand ? 0u : (t.rsId & 1u));
 }
 
 // segment of every read in the sorted keys: segBeg[r] = first key of read r (one coalesced pass; reads without
@@ -1609,7 +1621,7 @@ k_filter_mark(const unsigned long long* __restrict__ keys, uint32_t nReads, uint
         unsigned long long prevKey = ~0ull;
     };
     auto stepCore = [&](State& st, uint32_t i, unsigned long long key, uint32_t& replaced) -> uint32_t {
-        const uint32_t begin = (uint32_t)(key >> 8), dist = (uint32_t)(key >> 5) & 7u;
+        const uint32_t begin = (uint32_t)(key >> 8), dist = (uint32_t)(key >> 5) & 7u; // (mode 2; the other modes compare whole keys)
         const uint32_t width = (uint32_t)(key >> 1) & 15u; // relative to len - k: the same for all keys of a read
         replaced = FILTER_NONE;
         bool keep = true;
@@ -1706,7 +1718,7 @@ k_filter_mark(const unsigned long long* __restrict__ keys, uint32_t nReads, uint
 __global__ void __launch_bounds__(256)
 k_filter_write(const unsigned long long* __restrict__ keys, uint32_t n, const uint64_t* __restrict__ offs, uint32_t k,
                const uint32_t* __restrict__ rank, const uint64_t* __restrict__ outOffs, uint4* __restrict__ out,
-               uint32_t* __restrict__ outRead /* read of every occurrence, or null */, uint32_t perStrand) {
+               uint32_t* __restrict__ outRead /* read of every occurrence, or null */, uint32_t perStrand, uint32_t hamming) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t rk = rank[i];
@@ -1715,8 +1727,8 @@ k_filter_write(const unsigned long long* __restrict__ keys, uint32_t n, const ui
     const uint32_t grp = (uint32_t)(key >> 40);
     const uint32_t r = perStrand ? grp >> 1 : grp;
     const uint32_t len = (uint32_t)(offs[r + 1] - offs[r]);
-    const uint32_t begin = (uint32_t)(key >> 8), dist = (uint32_t)(key >> 5) & 7u;
-    const uint32_t width = len - k + ((uint32_t)(key >> 1) & 15u), strand = perStrand ? (grp & 1u) : ((uint32_t)key & 1u);
+    const uint32_t begin = (uint32_t)(key >> 8), dist = hamming ? (uint32_t)(key >> 4) & 15u : (uint32_t)(key >> 5) & 7u;
+    const uint32_t width = hamming ? len : len - k + ((uint32_t)(key >> 1) & 15u), strand = perStrand ? (grp & 1u) : ((uint32_t)key & 1u);
     out[outOffs[grp] + rk] = make_uint4(begin, begin + width, dist, strand);
     if (outRead) outRead[outOffs[grp] + rk] = r;
 }

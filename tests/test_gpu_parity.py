@@ -292,6 +292,26 @@ def test_reads_of_up_to_480_characters(world):
     _compare(world, "pigeon", "edit", "dynamic", 0, long_only)
 
 
+@pytest.mark.parametrize("partition,k,length", [("dynamic", 8, 150), ("uniform", 10, 150), ("static", 13, 200), ("dynamic", 13, 250),
+                                                ("dynamic", 9, 100), ("dynamic", 11, 400)])
+def test_hamming_distance_with_eight_to_thirteen_errors(world, partition, k, length):
+    """`-S columba` beyond 7 errors: the greedy schemes of ColumbaSearchStrategy (searchstrategy.h:3396-3658; k + 1 parts, up to
+    fourteen) on the wide instances of k_parts / k_exact / k_hbfs — Hamming distance (the edit-distance matcher stops at 7); a few
+    reads not longer than the number of parts ride along (naive backtracking)"""
+    g = world["genome"]
+    reads = synth.sample_reads(g, 1200, length, seed=900 + k, n_frac=0.01, edit_choices=(0, 2, 5, 8, k, k, k + 1))
+    reads += [g[5000:5000 + k + 1].tobytes(), g[77:80].tobytes(), b"N" * length, g[-length - 1:-1].tobytes()]
+    _compare(world, "columba", "hamming", partition, k, reads, dups_rare=False)
+
+
+def test_edit_distance_beyond_seven_errors_is_refused_up_front(world):
+    with pytest.raises(ca.CmbError) as e:
+        ca.match_batch(world["dev"], ca.SearchStrategy("columba", "edit", "dynamic"), 8, [b"ACGT" * 40])
+    assert e.value.code == ca.CMB_ERR_UNSUPPORTED
+    with pytest.raises(ca.CmbError):
+        ca.match_batch(world["dev"], ca.SearchStrategy("columba", "hamming", "dynamic"), 14, [b"ACGT" * 40])
+
+
 @pytest.mark.parametrize("spec,k", [("columba", 7), ("columba", 5), ("multiple_opt", 6)])
 def test_short_reads_with_many_errors(world, spec, k):
     """Reads of 40 ... 100 characters at 5 ... 7 errors: short parts, replays of long descendant lists that are interrupted
