@@ -1597,7 +1597,7 @@ static int batchRunOne(cmb_batch* b) {
                 b->alnStride = 2u * b->k + 3u;
                 if (b->alnRec.n < total) {
                     b->alnRec.alloc((size_t)total + total / 8 + 256);
-                    b->alnOps.alloc(b->alnRec.n * (2u * 7u + 3u));
+                    b->alnOps.alloc(b->alnRec.n * std::max<size_t>(b->alnStride, 2u * 7u + 3u));
                 }
                 if (total) {
                     const uint32_t cSlots = (uint32_t)std::min<uint64_t>(((total + 255) / 256) * 256, 512u * 1024u);
@@ -2386,7 +2386,7 @@ extern "C" int cmb_match_best(cmb_index* idx, const cmb_strategy* st, uint32_t x
         uint32_t maxSupported = 0;
         while (st->schemes.count(maxSupported + 1) && !st->schemes.at(maxSupported + 1).empty()) maxSupported++;
         if (st->metric == CMB_METRIC_EDIT) maxSupported = std::min<uint32_t>(maxSupported, (MXW_LEFT - 1) / 3);
-        maxSupported = std::min<uint32_t>(maxSupported, 7u); // (3-bit distance of the filter key)
+        maxSupported = std::min<uint32_t>(maxSupported, st->metric == CMB_METRIC_EDIT ? 7u : 13u); // (distance bits of the filter keys; MAX_K)
         std::unique_ptr<cmb_best> R(new cmb_best());
         memset(R->cnts, 0, sizeof(R->cnts));
         std::vector<BestRead> rd(n_reads);

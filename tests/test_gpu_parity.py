@@ -507,7 +507,8 @@ def test_alignments_cigar_and_sequence(world, oracle_built, spec, metric, k):
 
 @pytest.mark.parametrize("spec,metric,x,min_identity", [("columba", "edit", 0, 96), ("columba", "edit", 1, 96),
                                                         ("multiple_opt", "edit", 0, 97), ("kuch1", "hamming", 0, 98),
-                                                        ("minU", "edit", 2, 97), ("columba", "edit", 0, 95)])
+                                                        ("minU", "edit", 2, 97), ("columba", "edit", 0, 95),
+                                                        ("columba", "hamming", 0, 91), ("columba", "hamming", 1, 90)])
 def test_best_mode(world, spec, metric, x, min_identity):
     """BEST (+x strata) mode — the reference's default (`-a best`, SearchStrategy::matchApproxBestPlusX,
     searchstrategy.cpp:623-746): per read the best distance, the number of hits at it, and the alignments of the best
@@ -517,7 +518,7 @@ def test_best_mode(world, spec, metric, x, min_identity):
     import schemes_py as sp
     op = world["op"]
     g = world["genome"]
-    reads = synth.sample_reads(g, 2500, 150, seed=800 + x, n_frac=0.01, edit_choices=(0, 0, 1, 2, 3, 5, 6, 9))
+    reads = synth.sample_reads(g, 2500, 150, seed=800 + x, n_frac=0.01, edit_choices=(0, 0, 1, 2, 3, 5, 6, 9) + ((11, 13) if min_identity < 95 else ()))
     starts = np.asarray(world["ix"].seq_starts, dtype=np.int64)
     for s in starts[1:-1][:12]:   # reads across sequence boundaries: trimmed or dropped (findSeqName)
         reads.append(g[int(s) - 75:int(s) + 75].tobytes())
@@ -528,7 +529,7 @@ def test_best_mode(world, spec, metric, x, min_identity):
     max_sup = 0
     while (max_sup + 1) in spec_tables["schemes"]:
         max_sup += 1
-    max_sup = min(max_sup, 7)
+    max_sup = min(max_sup, 7 if metric == "edit" else 13)   # (Hamming distance: the strata 9 and 13 of the reference's walk run too)
     o_occ, o_sid, o_sb, o_cig, o_off, o_best, o_hits, o_cnt = op.match_best(
         world["orc"], op.OracleStrategy(spec_tables, metric, "dynamic"), reads, x=x, min_identity=min_identity,
         max_supported=max_sup, threads=8)
@@ -538,7 +539,7 @@ def test_best_mode(world, spec, metric, x, min_identity):
     # (multiple_opt has no scheme for 1 error: its best mode stops at exact matches, searchstrategy.h:2744-2750)
     # (with x > 0 the reference never looks at stratum 0 — its loop over the strata to check starts at prevK + 1 = 1,
     # searchstrategy.cpp:688 — so reads that only match exactly stay unmapped there; Hamming cut-off 3 at 98 %)
-    assert (o_best != 0xFFFFFFFF).sum() > (1500 if (spec, x) == ("columba", 0) else 300) and (o_best == 0xFFFFFFFF).sum() > 0
+    assert (o_best != 0xFFFFFFFF).sum() > (1500 if (spec, x, metric) == ("columba", 0, "edit") else 300) and (o_best == 0xFFFFFFFF).sum() > 0
     assert np.array_equal(o_hits, d_hits)
     assert np.array_equal(o_off, d_off)
     for f in ("begin", "end", "distance", "strand"):
