@@ -33,7 +33,7 @@ extern "C" {
 #define CMB_OK 0
 #define CMB_ERR_INVALID (-1)     /* bad argument / malformed scheme (search.h:559-586) */
 #define CMB_ERR_DEVICE (-2)      /* HIP runtime failure / no GPU */
-#define CMB_ERR_UNSUPPORTED (-3) /* k >= 8 for edit distance, reads longer than 480, 64-bit length_t on the FM-index path */
+#define CMB_ERR_UNSUPPORTED (-3) /* k >= 8 for edit distance (Hamming distance: up to 13), reads longer than 480, 64-bit length_t on the FM-index path */
 #define CMB_ERR_OVERFLOW (-4)    /* caller-provided output buffer too small: nothing truncated silently */
 #define CMB_ERR_INTERNAL (-5)    /* device-side capacity exceeded for a read (reported, never silent) */
 
