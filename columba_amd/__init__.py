@@ -53,7 +53,8 @@ EXPORTS = [
     "cmb_move_layout_of", "cmb_move_create_empty", "cmb_move_device_arrays", "cmb_move_validate",
     "cmb_batch_allow_unsupported", "cmb_batch_read_status", "cmb_trim_occurrence",
     "cmb_move_match_batch", "cmb_move_batch_create", "cmb_move_batch_run", "cmb_move_batch_result_size", "cmb_move_batch_results",
-    "cmb_move_batch_timings", "cmb_move_batch_destroy",
+    "cmb_move_batch_timings", "cmb_move_batch_destroy", "cmb_move_attach_text", "cmb_move_text_index", "cmb_index_create_text_only", "cmb_sam_chunk", "cmb_move_batch_want_alignments",
+    "cmb_move_batch_alignments",
     "cmb_last_error", "cmb_version",
 ]
 
@@ -288,6 +289,14 @@ def lib():
         L.cmb_move_batch_timings.argtypes = [vp, vp, vp, u32]
         L.cmb_move_batch_destroy.argtypes = [vp]
         L.cmb_move_batch_destroy.restype = None
+        L.cmb_move_attach_text.argtypes = [vp, vp, u64, vp, u32]
+        L.cmb_sam_chunk.argtypes = [vp, u32, i32, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, u64]
+        L.cmb_sam_chunk.restype = C.c_int64
+        L.cmb_move_text_index.argtypes = [vp]
+        L.cmb_move_text_index.restype = vp
+        L.cmb_index_create_text_only.argtypes = [vp, u64, vp, u32, i32, C.POINTER(vp)]
+        L.cmb_move_batch_want_alignments.argtypes = [vp, i32]
+        L.cmb_move_batch_alignments.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
         L.cmb_move_kmer_table.argtypes = [vp, u32, vp]
         L.cmb_move_layout_of.argtypes = [vp, C.POINTER(MoveLayout)]
         L.cmb_move_create_empty.argtypes = [C.POINTER(MoveLayout), i32, C.POINTER(vp)]
@@ -910,6 +919,13 @@ class MoveIndex:
         _chk(lib().cmb_move_kmer_table(self.h, word_size, _p(out)))
         return out
 
+    def attach_text(self, text, seq_starts=None):
+        """the text beside the index (for the alignments of the occurrences: MoveBatch.want_alignments); `text` bytes or uint8
+        array with or without the final '$', seq_starts: begin positions of the sequences + the final n - 1, as IndexArrays.seq_starts"""
+        t = np.frombuffer(text, np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, np.uint8)
+        st = None if seq_starts is None else np.ascontiguousarray(seq_starts, np.uint32)
+        _chk(lib().cmb_move_attach_text(self.h, _p(t), t.shape[0], None if st is None else _p(st), 0 if st is None else st.shape[0]))
+
     def match_batch(self, strategy: "SearchStrategy", max_distance: int, reads, kmer_size: int = 10):
         """``SearchStrategy::matchApprox`` (ALL mode) of the RUN_LENGTH_COMPRESSION flavour for a chunk of reads:
         (occurrences, per-read offsets, counters)"""
@@ -927,6 +943,7 @@ class MoveBatch:
     def __init__(self, index: MoveIndex, strategy: "SearchStrategy", max_distance: int, reads=None, packed=None, kmer_size: int = 10):
         buf, offs = packed if packed is not None else pack_reads(reads)
         self.n_reads = offs.shape[0] - 1
+        self.max_distance = max_distance
         self._keep = (index, strategy, buf, offs)
         h = C.c_void_p()
         _chk(lib().cmb_move_batch_create(index.h, strategy.h, max_distance, kmer_size, _p(buf), _p(offs), self.n_reads, C.byref(h)))
@@ -943,6 +960,43 @@ class MoveBatch:
         cnt = np.zeros(len(COUNTER_NAMES), np.uint64)
         _chk(lib().cmb_move_batch_results(self.h, _p(occ), occ.shape[0], _p(offs), _p(cnt)))
         return occ[:n.value], offs, dict(zip(COUNTER_NAMES, cnt.tolist()))
+
+    def want_alignments(self, on: bool = True):
+        """CIGAR and sequence of every occurrence (needs MoveIndex.attach_text)"""
+        _chk(lib().cmb_move_batch_want_alignments(self.h, int(on)))
+
+    def alignments(self):
+        """(cmb_aln records parallel to the occurrences, pool of CIGAR run-length operations), as Batch.alignments"""
+        n = C.c_uint64()
+        _chk(lib().cmb_move_batch_result_size(self.h, C.byref(n)))
+        aln = np.zeros(max(int(n.value), 1), ALN_DTYPE)
+        nops = C.c_uint64()
+        lib().cmb_move_batch_alignments(self.h, _p(aln), 0, None, 0, C.byref(nops))  # (sizes first)
+        ops = np.zeros(max(int(nops.value), 1), np.uint16)
+        _chk(lib().cmb_move_batch_alignments(self.h, _p(aln), aln.shape[0], _p(ops), ops.shape[0], C.byref(nops)))
+        return aln[:n.value], ops[:nops.value]
+
+    def sam(self, ids, quals, seq_names, unmapped: bool = True, xa: bool = False, metric: str = "edit") -> str:
+        """SAM text of the chunk (SearchStrategy::generateOutputSingleEnd) from the batch's occurrences and alignments; needs
+        MoveIndex.attach_text and want_alignments() before run()"""
+        index, strategy, buf, offs = self._keep
+        occ, occ_offs, _ = self.results()
+        aln, ops = self.alignments()
+        occ32 = np.zeros(max(len(occ), 1), OCC_DTYPE)
+        for f in ("begin", "end", "distance", "strand"):
+            occ32[f][:len(occ)] = occ[f]
+        arr = lambda strs: (C.c_char_p * len(strs))(*[s.encode() for s in strs])
+        ai, aq, an = arr(ids), arr(quals), arr(seq_names)
+        tix = lib().cmb_move_text_index(index.h)
+        args = (tix, self.max_distance, METRIC[metric], _p(buf), _p(offs),
+                self.n_reads, ai, aq, an, _p(occ32), _p(occ_offs), _p(aln if len(aln) else np.zeros(1, ALN_DTYPE)),
+                _p(ops if len(ops) else np.zeros(1, np.uint16)), int(unmapped), int(xa))
+        n = lib().cmb_sam_chunk(*args, None, 0)
+        if n < 0:
+            raise CmbError(int(n), lib().cmb_last_error().decode(errors="replace"))
+        out = C.create_string_buffer(int(n) + 1)
+        lib().cmb_sam_chunk(*args, out, int(n) + 1)
+        return out.value.decode()
 
     def timings(self) -> Dict[str, float]:
         names = (C.c_char_p * 16)()

@@ -99,6 +99,7 @@ struct cmb_index {
     DevBuf<uint32_t> seqStartsDev; // the same on the device (k_cigar: sequence assignment); [0, n - 1] if none were given
     uint32_t nSeqsDev = 0;
     uint64_t bytes = 0;
+    bool textOnly = false; // cmb_index_create_text_only: no BWT, no suffix array — alignments and SAM records only
     void uploadSeqStarts() {
         std::vector<uint32_t> v = seqStarts;
         if (v.size() < 2) v = {0u, d.n ? d.n - 1u : 0u};
@@ -303,6 +304,46 @@ extern "C" int cmb_index_seq_starts(const cmb_index* idx, uint32_t* out) {
     if (!idx->seqStarts.empty()) memcpy(out, idx->seqStarts.data(), idx->seqStarts.size() * sizeof(uint32_t));
     return CMB_OK;
 }
+// An index that holds ONLY the text (codes + 2-bit copy) and the sequence starts: what alignments, trimming at sequence ends and SAM
+// records need of an index — for the b-move flavour, whose own index has no text (cmb_move_attach_text).  No batch can be created on it.
+extern "C" int cmb_index_create_text_only(const char* text, uint64_t n, const uint32_t* seq_starts, uint32_t n_seqs, int device,
+                                          cmb_index** out) {
+    if (!text || !out) return fail(CMB_ERR_INVALID, "null argument");
+    if (n == 0 || n >= 0xFFFFFF00ull) return fail(CMB_ERR_UNSUPPORTED, "text length must fit a 32-bit length_t");
+    try {
+        useDevice(device);
+        std::unique_ptr<cmb_index> ix(new cmb_index());
+        ix->device = device;
+        ix->textOnly = true;
+        constexpr uint64_t TEXT_PAD = 640;
+        ix->text.alloc(n + TEXT_PAD);
+        HIPCHK(hipMemset(ix->text.p, 0, n + TEXT_PAD));
+        HIPCHK(hipMemcpy(ix->text.p, text, n, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_encode_text, dim3(4096), dim3(256), 0, 0, ix->text.p, n, n + TEXT_PAD);
+        const uint64_t nWords = (n + TEXT_PAD) / 16;
+        ix->text2.alloc(nWords + 16);
+        HIPCHK(hipMemset(ix->text2.p, 0, (nWords + 16) * sizeof(uint32_t)));
+        DevBuf<uint32_t> bad;
+        bad.alloc(1);
+        HIPCHK(hipMemset(bad.p, 0, sizeof(uint32_t)));
+        hipLaunchKernelGGL(k_pack_text, dim3(4096), dim3(256), 0, 0, ix->text.p, n, nWords, ix->text2.p, bad.p);
+        HIPCHK(hipGetLastError());
+        uint32_t hb = 0;
+        HIPCHK(hipMemcpy(&hb, bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (hb) ix->text2.release();
+        if (seq_starts && n_seqs) ix->seqStarts.assign(seq_starts, seq_starts + n_seqs); // (entries: the starts and the final n - 1, as cmb_index_desc)
+        ix->d.n = (uint32_t)n;
+        ix->d.text = ix->text.p;
+        ix->d.text2 = hb ? nullptr : ix->text2.p;
+        ix->uploadSeqStarts();
+        ix->bytes = ix->text.bytes() + ix->text2.bytes();
+        *out = ix.release();
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}
+
 extern "C" int cmb_index_create_empty(const cmb_index_layout* L, const uint32_t* seq_starts, int device, cmb_index** out) {
     if (!L || !out) return fail(CMB_ERR_INVALID, "null argument");
     if (L->text_length == 0 || L->text_length >= 0xFFFFFFFFull || L->kmer_size > 12)
@@ -623,6 +664,7 @@ constexpr uint32_t MAX_SUB_READS = 1u << 23; // reads per sub-batch (keys: kerne
 extern "C" int cmb_batch_create(cmb_index* idx, const cmb_strategy* st, uint32_t max_distance, const char* seqs,
                                 const uint64_t* offs, uint32_t n_reads, cmb_batch** out) {
     if (!idx || !st || !offs || !out || (!seqs && n_reads)) return fail(CMB_ERR_INVALID, "null argument");
+    if (idx->textOnly) return fail(CMB_ERR_INVALID, "this index holds only the text (cmb_index_create_text_only): nothing can be matched on it");
     if (n_reads >= 0x7FFFFFFFu) return fail(CMB_ERR_INVALID, "too many reads in one batch");
     // sub-batches: 3 from 8 M reads, 2 from 2 M (below that the fixed cost per frontier level dominates; measured
     // on 10 M reads: 1 -> 26.4, 2 -> 30.4, 3 -> 30.6, 4 -> 29.5 M reads/s); CMB_SUBBATCHES overrides
@@ -1651,6 +1693,54 @@ static int batchRunOne(cmb_batch* b) {
     }
 }
 
+// ---- what the b-move translation unit borrows from this one (move_backend.hip: cmb_move_attach_text, alignments) -------------
+// The b-move index holds no text (the reference builds the CIGAR of that flavour from a matched string that travels with the search,
+// indexinterface.h:294-303).  With 288 GB of HBM a 2-bit copy of the text fits beside the index (a quarter byte per character: 50 GB for
+// 64 human haplotypes next to ~130 GB of tables), and the matched string of an occurrence IS text[begin, end): findCIGAR on that
+// window (k_cigar) gives the reference's CIGAR without carrying anything through the frontier.
+namespace cmb {
+// CIGAR and sequence assignment of nOcc occurrences {begin, end, distance, strand} of the reads `occRead` on a text: the k_cigar launch
+// of batchRunOne for a caller that has the pieces (device pointers throughout; aln: nOcc x 16 bytes {seqId, seqBegin, nOps, spans};
+// ops: nOcc x stride, stored end to begin as for cmb_batch_alignments).
+int moveCigarsOnText(cmb_index* textIndex, hipStream_t s, const uint64_t* offs, const uint32_t* G, uint32_t gw, uint32_t nReads, uint32_t maxLen,
+                     uint32_t k, int gapless, const void* occs, const uint32_t* occRead, uint64_t nOcc, void* aln, uint16_t* ops, uint32_t stride,
+                     uint32_t* flagWord) {
+    try {
+        HIPCHK(hipSetDevice(textIndex->device));
+        if (!nOcc) return CMB_OK;
+        const DevIndex& d = textIndex->d;
+        const uint32_t* text2 = d.text2;
+        const uint32_t* seqStartsDev = textIndex->seqStartsDev.p;
+        const uint32_t nSeqs = textIndex->nSeqsDev;
+        DevBuf<uint4> mfull;
+        MFull mf{nullptr, 0};
+        if (!gapless) {
+            mf.nBlk = mfullBlocks(maxLen);
+            const uint64_t nW = (uint64_t)2 * nReads * mf.nBlk;
+            mfull.alloc(2 * nW);
+            hipLaunchKernelGGL(k_match_words, dim3((unsigned)((nW + 255) / 256)), dim3(256), 0, s, G, gw, offs, 2 * nReads, mf.nBlk, mfull.p);
+            mf.p = mfull.p;
+        }
+        const uint32_t cSlots = (uint32_t)std::min<uint64_t>(((nOcc + 255) / 256) * 256, 512u * 1024u);
+        const bool narrow = k <= TBN_MAX_ED;
+        const uint32_t tLines = narrow ? (vRows(maxLen) + 15u) / 16u + 2u : (vRows(maxLen) + 7u) / 8u + 2u;
+        DevBuf<uint64_t> vW;
+        vW.alloc((size_t)tLines * 8 * cSlots);
+        VPlanes vp{vW.p, cSlots, tLines};
+        auto kc = k_cigar<false, false>;
+        if (narrow) kc = text2 ? k_cigar<true, true> : k_cigar<true, false>;
+        else if (text2) kc = k_cigar<false, true>;
+        hipLaunchKernelGGL(kc, dim3(cSlots / 256), dim3(256), 0, s, d, offs, mf, (const uint4*)occs, occRead, nOcc, vp, seqStartsDev, nSeqs, ops,
+                           stride, (AlnRec*)aln, flagWord, gapless ? 1u : 0u);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s)); // (the temporaries above go out of scope)
+        return CMB_OK;
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}
+} // namespace cmb
+
 extern "C" int cmb_batch_result_size(const cmb_batch* b, uint64_t* n_occ) {
     if (!b || !n_occ) return fail(CMB_ERR_INVALID, "null argument");
     if (!b->done) return fail(CMB_ERR_INVALID, "batch has not been run");
@@ -2285,6 +2375,44 @@ extern "C" int cmb_trim_occurrence(cmb_index* idx, const char* pattern, uint32_t
 // occurrences, CIGARs and sequence assignments the device produced (cmb_batch_want_alignments before cmb_batch_run).
 // Occurrences that run over the end of their sequence are trimmed and verified again (findSeqName,
 // indexinterface.cpp:833-899) through the device hooks.
+// the SAM records of one read from its occurrences with alignments (generateOutputSingleEnd, searchstrategy.cpp:1824-1902)
+static void samOfRead(std::string& text, cmb_index* idx, uint32_t k, int metric, const std::string& read, const std::string& revC,
+                      const std::string& sid, const std::string& qual, std::vector<BestOcc>& occs, const char* const* seq_names,
+                      int unmapped_records, int xa_tag) {
+    std::string revQ = qual;
+    std::reverse(revQ.begin(), revQ.end());
+    std::vector<SamHit> hits;
+    for (BestOcc& o : occs) {
+        if (o.aln.spans == 1 && !trimOccurrence(idx, o.occ.strand ? revC : read, k, metric, o, nullptr)) continue; // NOT_FOUND
+        SamHit h;
+        h.seqName = seq_names[o.aln.seq_id];
+        h.cigar = cigarString(o.ops.data(), (uint32_t)o.ops.size());
+        h.pos0 = o.aln.seq_begin;
+        h.distance = o.occ.distance;
+        h.revCompl = o.occ.strand != 0;
+        hits.push_back(h);
+    }
+    if (hits.empty()) {
+        if (unmapped_records) text += samLineUnmappedSE(sid, read, qual);
+        return;
+    }
+    // primary = the first occurrence of minimal distance, swapped to the front (:1883-1899)
+    size_t mi = 0;
+    for (size_t j = 1; j < hits.size(); j++)
+        if (hits[j].distance < hits[mi].distance) mi = j;
+    const uint32_t minScore = hits[mi].distance;
+    uint32_t nHits = 0;
+    for (const SamHit& h : hits) nHits += h.distance == minScore;
+    if (mi != 0) std::swap(hits[0], hits[mi]);
+    const bool rcFirst = hits[0].revCompl;
+    if (xa_tag) {
+        text += samLineSEWithXA(sid, hits, nHits, rcFirst ? revC : read, rcFirst ? revQ : qual);
+    } else {
+        text += samLineSE(sid, hits[0], true, nHits, minScore, rcFirst ? revC : read, rcFirst ? revQ : qual);
+        for (size_t j = 1; j < hits.size(); j++) text += samLineSE(sid, hits[j], false, nHits, minScore, "*", "*");
+    }
+}
+
 extern "C" int64_t cmb_batch_sam(const cmb_batch* b, const char* seqs, const char* const* read_ids, const char* const* quals,
                                  const char* const* seq_names, int unmapped_records, int xa_tag, char* out, uint64_t cap) {
     if (!b || !seqs || !read_ids || !seq_names) return fail(CMB_ERR_INVALID, "null argument");
@@ -2305,12 +2433,7 @@ extern "C" int64_t cmb_batch_sam(const cmb_batch* b, const char* seqs, const cha
                 const std::string read = cleanReadSeq(std::string(seqs + o0, seqs + o1)), revC = revComplWithN(read);
                 const std::string sid = cleanSeqID(read_ids[gi]);
                 const std::string qual = quals && quals[gi] ? quals[gi] : "*";
-                std::string revQ = qual;
-                std::reverse(revQ.begin(), revQ.end());
-                struct Hit {
-                    SamHit h;
-                };
-                std::vector<SamHit> hits;
+                std::vector<BestOcc> occs;
                 const uint64_t q0 = c->occOffs.data()[c->perStrand ? 2 * (size_t)i : i], q1 = c->occOffs.data()[c->perStrand ? 2 * (size_t)i + 2 : i + 1];
                 for (uint64_t q2 = q0; q2 < q1; q2++) {
                     BestOcc o;
@@ -2319,37 +2442,42 @@ extern "C" int64_t cmb_batch_sam(const cmb_batch* b, const char* seqs, const cha
                     o.aln = cmb_aln{ar.seqId, ar.seqBegin, 0, (uint16_t)ar.nOps, (uint16_t)ar.spans, 0};
                     const uint16_t* src = c->hAlnOps.data() + q2 * c->alnStride;
                     for (uint32_t j = 0; j < ar.nOps; j++) o.ops.push_back(src[ar.nOps - 1 - j]);
-                    if (o.aln.spans == 1 && !trimOccurrence(idx, o.occ.strand ? revC : read, c->k, c->metric, o, nullptr)) continue; // NOT_FOUND
-                    SamHit h;
-                    h.seqName = seq_names[o.aln.seq_id];
-                    h.cigar = cigarString(o.ops.data(), (uint32_t)o.ops.size());
-                    h.pos0 = o.aln.seq_begin;
-                    h.distance = o.occ.distance;
-                    h.revCompl = o.occ.strand != 0;
-                    hits.push_back(h);
+                    occs.push_back(std::move(o));
                 }
-                if (hits.empty()) {
-                    if (unmapped_records) text += samLineUnmappedSE(sid, read, qual);
-                    continue;
-                }
-                // primary = the first occurrence of minimal distance, swapped to the front (:1883-1899)
-                size_t mi = 0;
-                for (size_t j = 1; j < hits.size(); j++)
-                    if (hits[j].distance < hits[mi].distance) mi = j;
-                const uint32_t minScore = hits[mi].distance;
-                uint32_t nHits = 0;
-                for (const SamHit& h : hits) nHits += h.distance == minScore;
-                if (mi != 0) std::swap(hits[0], hits[mi]);
-                const bool rcFirst = hits[0].revCompl;
-                if (xa_tag) {
-                    text += samLineSEWithXA(sid, hits, nHits, rcFirst ? revC : read, rcFirst ? revQ : qual);
-                } else {
-                    text += samLineSE(sid, hits[0], true, nHits, minScore, rcFirst ? revC : read, rcFirst ? revQ : qual);
-                    for (size_t j = 1; j < hits.size(); j++) text += samLineSE(sid, hits[j], false, nHits, minScore, "*", "*");
-                }
+                samOfRead(text, idx, c->k, c->metric, read, revC, sid, qual, occs, seq_names, unmapped_records, xa_tag);
             }
             readBase += c->nReads;
             charBase += c->hostOffs[c->nReads];
+        }
+        return putString(text, out, cap);
+    } catch (const std::exception& e) {
+        return fail(CMB_ERR_DEVICE, e.what());
+    }
+}
+
+// The same for occurrences and alignments the caller holds (cmb_batch_results + cmb_batch_alignments, or their b-move
+// counterparts with the text-only index of cmb_move_text_index): occ_offs[n_reads + 1], aln[i].cigar_off into cigar_ops.
+extern "C" int64_t cmb_sam_chunk(cmb_index* idx, uint32_t max_distance, int metric, const char* seqs, const uint64_t* offs, uint32_t n_reads,
+                                 const char* const* read_ids, const char* const* quals, const char* const* seq_names, const cmb_occ* occ,
+                                 const uint64_t* occ_offs, const cmb_aln* aln, const uint16_t* cigar_ops, int unmapped_records, int xa_tag,
+                                 char* out, uint64_t cap) {
+    if (!idx || !seqs || !offs || !read_ids || !seq_names || !occ_offs || (occ_offs[n_reads] && (!occ || !aln || !cigar_ops)))
+        return fail(CMB_ERR_INVALID, "null argument");
+    try {
+        std::string text;
+        for (uint32_t i = 0; i < n_reads; i++) {
+            const std::string read = cleanReadSeq(std::string(seqs + offs[i], seqs + offs[i + 1])), revC = revComplWithN(read);
+            const std::string sid = cleanSeqID(read_ids[i]);
+            const std::string qual = quals && quals[i] ? quals[i] : "*";
+            std::vector<BestOcc> occs;
+            for (uint64_t q2 = occ_offs[i]; q2 < occ_offs[i + 1]; q2++) {
+                BestOcc o;
+                o.occ = occ[q2];
+                o.aln = aln[q2];
+                o.ops.assign(cigar_ops + aln[q2].cigar_off, cigar_ops + aln[q2].cigar_off + aln[q2].cigar_len);
+                occs.push_back(std::move(o));
+            }
+            samOfRead(text, idx, max_distance, metric, read, revC, sid, qual, occs, seq_names, unmapped_records, xa_tag);
         }
         return putString(text, out, cap);
     } catch (const std::exception& e) {

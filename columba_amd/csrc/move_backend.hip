@@ -87,6 +87,12 @@ uint32_t bitsFor(double v) { return (uint32_t)std::ceil(std::log2(v)); } // move
 
 } // namespace
 
+namespace cmb { // (columba_amd.hip: the text kernels and k_cigar live in that translation unit)
+int moveCigarsOnText(cmb_index* textIndex, hipStream_t s, const uint64_t* offs, const uint32_t* G, uint32_t gw, uint32_t nReads, uint32_t maxLen,
+                     uint32_t k, int gapless, const void* occs, const uint32_t* occRead, uint64_t nOcc, void* aln, uint16_t* ops, uint32_t stride,
+                     uint32_t* flagWord);
+} // namespace cmb
+
 struct cmb_move_index {
     int device = 0;
     uint64_t n = 0;
@@ -99,6 +105,11 @@ struct cmb_move_index {
     MvBuf<MoveRangeRec> kmer;
     uint32_t kmerSize = 0;
     std::mutex kmerMutex;
+    // optional: the text itself (cmb_move_attach_text), for the CIGARs of the occurrences — codes and a 2-bit copy
+    cmb_index* textIndex = nullptr; // (cmb_index_create_text_only: codes, 2-bit copy, sequence starts)
+    ~cmb_move_index() {
+        if (textIndex) cmb_index_destroy(textIndex);
+    }
 };
 
 static void bindMoveDev(cmb_move_index* ix) { // MoveDev pointers from the owning buffers
@@ -209,6 +220,21 @@ extern "C" void cmb_move_destroy(cmb_move_index* idx) {
     (void)hipSetDevice(idx->device);
     delete idx;
 }
+
+// The text beside the index (optional): what the alignments of the occurrences, the trimming at sequence ends and the SAM records are
+// computed on (a text-only cmb_index: cmb_index_create_text_only).  seq_starts / n_seqs as in cmb_index_desc (the starts and the final
+// n - 1), or NULL.
+extern "C" int cmb_move_attach_text(cmb_move_index* idx, const char* text, uint64_t n, const uint32_t* seq_starts, uint32_t n_seqs) {
+    if (!idx || !text) return failWith(CMB_ERR_INVALID, "null argument");
+    if (n != idx->n && n + 1 != idx->n) return failWith(CMB_ERR_INVALID, "the text does not have the length of the indexed text");
+    if (idx->n >= 0xFFFFFF00ull) return failWith(CMB_ERR_UNSUPPORTED, "alignments on texts of 2^32 characters and more are not implemented");
+    if (idx->textIndex) cmb_index_destroy(idx->textIndex);
+    idx->textIndex = nullptr;
+    std::string t(text, text + n);
+    if (n + 1 == idx->n) t.push_back('$');
+    return cmb_index_create_text_only(t.data(), t.size(), seq_starts, n_seqs, idx->device, &idx->textIndex);
+}
+extern "C" cmb_index* cmb_move_text_index(const cmb_move_index* idx) { return idx ? idx->textIndex : nullptr; }
 
 extern "C" uint64_t cmb_move_device_bytes(const cmb_move_index* idx) {
     if (!idx) return 0;
@@ -633,6 +659,14 @@ struct cmb_move_batch {
     size_t nvQCap = 0;
     MvBuf<MoveOccOut> naiveOut;
     MvBuf<uint64_t> naiveOff;
+    // alignments of the final occurrences (cmb_move_batch_want_alignments; needs cmb_move_attach_text)
+    bool wantAln = false;
+    uint32_t alnStride = 0;
+    MvBuf<uint4> occ32, alnRec;
+    MvBuf<uint32_t> occRead;
+    MvBuf<uint16_t> alnOps;
+    std::vector<uint4> hAlnRec; // {seqId, seqBegin, nOps, spans} per occurrence
+    std::vector<uint16_t> hAlnOps;
     // results
     std::vector<cmb_move_occ> occs;
     std::vector<uint64_t> occOffs;
@@ -750,6 +784,9 @@ extern "C" int cmb_move_batch_run(cmb_move_batch* b) {
     memset(b->cnts, 0, sizeof(b->cnts));
     b->occOffs.assign((size_t)b->nReads + 1, 0);
     b->occs.clear();
+    b->hAlnRec.clear();
+    b->hAlnOps.clear();
+    b->alnStride = 2u * b->k + 3u;
     uint32_t slice = b->k >= 5 ? (1u << 18) : b->k >= 3 ? (1u << 19) : (1u << 20);
     if (getenv("CMB_MOVE_SLICE")) slice = (uint32_t)std::max(1, atoi(getenv("CMB_MOVE_SLICE")));
     if (b->k == 0) slice = b->nReads ? b->nReads : 1;
@@ -1136,6 +1173,30 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
         }
         tm.end("filter");
         MV_HIPCHK(hipGetLastError());
+        if (b->wantAln && nOut) { // CIGAR and sequence of every final occurrence: findCIGAR on text[begin, end) (k_cigar)
+            tm.begin();
+            if (b->occ32.n < nOut) {
+                const size_t c = nOut + nOut / 4 + 256;
+                b->occ32.alloc(c), b->alnRec.alloc(c), b->occRead.alloc(c), b->alnOps.alloc(c * b->alnStride);
+            }
+            hipLaunchKernelGGL(k_mvs_occ32, dim3(gridFor(nReads)), dim3(256), 0, s, b->out.p, b->readOff.p, nReads, b->occ32.p, b->occRead.p);
+            uint32_t flagBefore = 0;
+            MV_HIPCHK(hipMemcpyAsync(&flagBefore, b->cnt.p + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            const int rc = cmb::moveCigarsOnText(ix->textIndex, s, dOffs, b->G.p, b->gw, nReads, b->maxLen, b->k, b->metric == CMB_METRIC_EDIT ? 0 : 1,
+                                                 b->occ32.p, b->occRead.p, nOut, b->alnRec.p, b->alnOps.p, b->alnStride, b->cnt.p + 3);
+            if (rc != CMB_OK) return rc;
+            const size_t base = b->hAlnRec.size();
+            b->hAlnRec.resize(base + nOut);
+            b->hAlnOps.resize((base + nOut) * b->alnStride);
+            MV_HIPCHK(hipMemcpyAsync(b->hAlnRec.data() + base, b->alnRec.p, nOut * sizeof(uint4), hipMemcpyDeviceToHost, s));
+            MV_HIPCHK(hipMemcpyAsync(b->hAlnOps.data() + base * b->alnStride, b->alnOps.p, nOut * b->alnStride * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+            uint32_t flagAfter = 0;
+            MV_HIPCHK(hipMemcpyAsync(&flagAfter, b->cnt.p + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            MV_HIPCHK(hipStreamSynchronize(s));
+            tm.end("k_cigar");
+            if ((flagAfter & ~flagBefore) & FLAG_CAPACITY)
+                return failWith(CMB_ERR_INTERNAL, "a CIGAR traceback left the band or an occurrence is not an alignment within its distance");
+        }
         uint32_t hb = 0;
         MV_HIPCHK(hipMemcpyAsync(&hb, b->bad.p, sizeof(hb), hipMemcpyDeviceToHost, s));
         unsigned long long hc64[CMB_CNT_MAX];
@@ -1173,6 +1234,33 @@ extern "C" int cmb_move_batch_results(const cmb_move_batch* b, cmb_move_occ* out
     if (out && !b->occs.empty()) memcpy(out, b->occs.data(), b->occs.size() * sizeof(cmb_move_occ));
     if (out_offs) memcpy(out_offs, b->occOffs.data(), b->occOffs.size() * sizeof(uint64_t));
     if (counters) memcpy(counters, b->cnts, sizeof(b->cnts));
+    return CMB_OK;
+}
+extern "C" int cmb_move_batch_want_alignments(cmb_move_batch* b, int on) {
+    if (!b) return failWith(CMB_ERR_INVALID, "null argument");
+    if (on && !b->ix->textIndex) return failWith(CMB_ERR_INVALID, "alignments need the text beside the index (cmb_move_attach_text)");
+    if (on && b->k > 7 && b->metric == CMB_METRIC_EDIT) return failWith(CMB_ERR_UNSUPPORTED, "alignments beyond 7 errors");
+    b->wantAln = on != 0;
+    return CMB_OK;
+}
+// as cmb_batch_alignments: one record per occurrence of cmb_move_batch_results, CIGAR runs (length << 2 | op, op 0 M / 1 I / 2 D) in a pool
+extern "C" int cmb_move_batch_alignments(const cmb_move_batch* b, cmb_aln* out, uint64_t cap, uint16_t* cigar_ops, uint64_t ops_cap, uint64_t* n_ops) {
+    if (!b) return failWith(CMB_ERR_INVALID, "null argument");
+    if (!b->done) return failWith(CMB_ERR_INVALID, "batch has not been run");
+    if (!b->wantAln) return failWith(CMB_ERR_INVALID, "alignments were not requested (cmb_move_batch_want_alignments)");
+    const uint64_t total = b->hAlnRec.size();
+    uint64_t ops = 0;
+    for (const uint4& r : b->hAlnRec) ops += r.z;
+    if (n_ops) *n_ops = ops;
+    if (cap < total || ops_cap < ops) return failWith(CMB_ERR_OVERFLOW, "output buffer too small");
+    uint64_t po = 0;
+    for (uint64_t i = 0; i < total; i++) {
+        const uint4& r = b->hAlnRec[i];
+        out[i] = cmb_aln{r.x, r.y, po, (uint16_t)r.z, (uint16_t)r.w};
+        const uint16_t* src = b->hAlnOps.data() + i * b->alnStride;
+        for (uint32_t j = 0; j < r.z; j++) cigar_ops[po + j] = src[r.z - 1 - j]; // (stored end to begin)
+        po += r.z;
+    }
     return CMB_OK;
 }
 extern "C" int cmb_move_batch_timings(const cmb_move_batch* b, const char** names, float* ms, uint32_t cap) {

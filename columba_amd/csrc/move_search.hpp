@@ -1294,4 +1294,15 @@ __global__ void k_mvs_occ_keys(const MoveOccOut* __restrict__ occ, const uint64_
         }
 }
 
+// the final occurrences as k_cigar takes them: {begin, end, distance, strand} in 32 bits (texts below 2^32) and the read of each
+__global__ void k_mvs_occ32(const MoveOccOut* __restrict__ occ, const uint64_t* __restrict__ occOff, uint32_t nReads, uint4* __restrict__ out,
+                            uint32_t* __restrict__ outRead) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nReads; r += gridDim.x * blockDim.x)
+        for (uint64_t e = occOff[r]; e < occOff[r + 1]; e++) {
+            const MoveOccOut o = occ[e];
+            out[e] = make_uint4((uint32_t)o.begin, (uint32_t)o.end, o.distance, o.strand);
+            outRead[e] = r;
+        }
+}
+
 } // namespace cmb

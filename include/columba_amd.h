@@ -92,6 +92,10 @@ typedef struct {
 int cmb_index_layout_of(const cmb_index* idx, cmb_index_layout* out);
 int cmb_index_seq_starts(const cmb_index* idx, uint32_t* out /* [n_seqs] */);
 int cmb_index_create_empty(const cmb_index_layout* layout, const uint32_t* seq_starts, int device, cmb_index** out);
+/* an index that holds ONLY the text (codes + 2-bit copy) and the sequence starts: what alignments (cmb_cigar_windows), trimming at
+ * sequence ends (cmb_trim_occurrence) and SAM records need — for the b-move flavour, whose own index has no text.  No batch can be
+ * created on it.  seq_starts / n_seqs as in cmb_index_desc. */
+int cmb_index_create_text_only(const char* text, uint64_t n, const uint32_t* seq_starts, uint32_t n_seqs, int device, cmb_index** out);
 int cmb_index_device_arrays(cmb_index* idx, void** ptrs /* [CMB_DEV_ARRAYS] */, uint64_t* bytes /* [CMB_DEV_ARRAYS] */);
 /* after the arrays of an empty twin have been filled: the consistency probe cmb_index_create runs (every probed row of the
  * suffix array reaches a sampled row within sa_sparseness LF steps, FMIndex::findSA, src/fmindex/fmindex.cpp:53-60) */
@@ -359,6 +363,13 @@ int cmb_pair_infer(const cmb_pair_sample* samples, uint64_t n, cmb_pair_inferred
  * seq_names = names of the reference sequences.  Returns the length of the text (written if cap is larger). */
 int64_t cmb_batch_sam(const cmb_batch* b, const char* seqs, const char* const* read_ids, const char* const* quals,
                       const char* const* seq_names, int unmapped_records, int xa_tag, char* out, uint64_t cap);
+/* the same for occurrences and alignments the caller holds — cmb_batch_results + cmb_batch_alignments, or cmb_move_batch_results
+ * (begin / end narrowed to 32 bits) + cmb_move_batch_alignments with the text-only index of cmb_move_text_index: occ_offs[n_reads + 1],
+ * aln[i].cigar_off / cigar_len into cigar_ops.  `idx` serves the trimming of occurrences that run over a sequence end. */
+int64_t cmb_sam_chunk(cmb_index* idx, uint32_t max_distance, int metric, const char* seqs, const uint64_t* offs, uint32_t n_reads,
+                      const char* const* read_ids, const char* const* quals, const char* const* seq_names, const cmb_occ* occ,
+                      const uint64_t* occ_offs, const cmb_aln* aln, const uint16_t* cigar_ops, int unmapped_records, int xa_tag, char* out,
+                      uint64_t cap);
 /* Read::cleanUpRecord + ReadBundle (src/reads.h:43-58, :97-160): identifier without its first character and without
  * anything from the first space on; upper-case sequence with every non-ACGT character replaced by N; its reverse
  * complement; the reversed quality string.  Output buffers hold strlen(input) + 1 bytes each (any may be NULL). */
@@ -540,6 +551,16 @@ int cmb_move_batch_result_size(const cmb_move_batch* b, uint64_t* n_occ);
 int cmb_move_batch_results(const cmb_move_batch* b, cmb_move_occ* out, uint64_t out_cap, uint64_t* out_offs, uint64_t* counters);
 int cmb_move_batch_timings(const cmb_move_batch* b, const char** names, float* ms, uint32_t cap);
 void cmb_move_batch_destroy(cmb_move_batch* b);
+/* Alignments of the occurrences of a b-move batch.  The reference builds the CIGAR of this flavour from the matched string, which its
+ * search carries along (src/indexinterface.h:294-303) because the index holds no text.  That string is text[begin, end) of the
+ * occurrence: with the text beside the index in HBM (cmb_move_attach_text: one byte + a quarter byte per character; texts below 2^32
+ * characters) the CIGAR is IBitParallelED::findCIGAR of that window — what cmb_batch_alignments computes for the FM-index flavour, same
+ * kernel.  seq_starts as for cmb_index_desc (NULL: one sequence).  cmb_move_batch_alignments: records parallel to
+ * cmb_move_batch_results, CIGAR runs as for cmb_batch_alignments; an occurrence that runs over the end of its sequence has spans = 1. */
+int cmb_move_attach_text(cmb_move_index* idx, const char* text, uint64_t n, const uint32_t* seq_starts, uint32_t n_seqs);
+cmb_index* cmb_move_text_index(const cmb_move_index* idx); /* the text-only index behind it (owned by idx), or NULL */
+int cmb_move_batch_want_alignments(cmb_move_batch* b, int on);
+int cmb_move_batch_alignments(const cmb_move_batch* b, cmb_aln* out, uint64_t cap, uint16_t* cigar_ops, uint64_t ops_cap, uint64_t* n_ops);
 /* device time (ms, HIP events) of the calling thread's last cmb_move_match_exact: [0] the backward extension of all reads,
  * [1] the prefix sum of the widths, [2] locate + occurrence records */
 int cmb_move_last_timings(float* ms, uint32_t n);

@@ -196,6 +196,67 @@ def test_bmove_naive_strategy(tinyworld, metric, k, length):
         del os.environ["CMB_TEST_SMALL_POOLS"]
 
 
+@pytest.mark.parametrize("spec,k,length", [("multiple_opt", 4, 150), ("columba", 6, 250), ("kuch1", 2, 100), ("columba", 7, 100)])
+def test_bmove_alignments(sworld, spec, k, length):
+    """CIGAR and sequence of the occurrences on the b-move index (cmb_move_attach_text + cmb_move_batch_alignments: findCIGAR on
+    text[begin, end), which is the matched string the reference's search carries along for this flavour): equal to those of the
+    FM-index flavour on the same text — the two flavours report the same occurrences when the FM-index never switches to in-text
+    verification (tests/test_move_search_oracle.py), and that path's alignments are checked against the oracle — and every CIGAR
+    re-derives its distance."""
+    from columba_amd import indexbuild as ib
+    ca = sworld["ca"]
+    g = sworld["g"]
+    starts = np.array([0, 250_000, 640_000, len(g)], dtype=np.uint64)
+    reads = _reads(g, k, 500, length, seed=40 + k)
+    for s0 in (250_000, 640_000):   # reads across sequence boundaries: spans = 1
+        reads.append(g[s0 - length // 2:s0 + length - length // 2].tobytes())
+    st = ca.SearchStrategy(spec, "edit", "dynamic")
+    fm = ca.Index(ib.build_index(sworld["text"], seq_starts=starts.astype(np.int64), device="cuda"), in_text_switch=0, kmer_size=8)
+    fb = ca.Batch(fm, st, k, reads)
+    fb.want_alignments()
+    fb.run()
+    f_occ, f_off, _ = fb.results()
+    f_aln, f_ops = fb.alignments()
+    sworld["dev"].attach_text(sworld["text"], starts)
+    mb = ca.MoveBatch(sworld["dev"], st, k, reads=reads, kmer_size=8)
+    mb.want_alignments()
+    mb.run()
+    m_occ, m_off, _ = mb.results()
+    m_aln, m_ops = mb.alignments()
+    assert len(m_occ) > 400 and np.array_equal(f_off, m_off)
+    for f in ("begin", "end", "distance"):
+        assert np.array_equal(f_occ[f].astype(np.uint64), m_occ[f].astype(np.uint64)), f
+    assert np.array_equal(f_aln["seq_id"], m_aln["seq_id"]) and np.array_equal(f_aln["seq_begin"], m_aln["seq_begin"])
+    assert np.array_equal(f_aln["spans"], m_aln["spans"]) and int(m_aln["spans"].sum()) >= 2
+    same_strand = f_occ["strand"] == m_occ["strand"]
+    assert (~same_strand).sum() <= max(1, len(m_occ) // 500)
+    n_edits = 0
+    for j in range(len(m_occ)):
+        a, b = m_aln[j], f_aln[j]
+        cm = ca.cigar_string(m_ops[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])])
+        if same_strand[j]:
+            assert cm == ca.cigar_string(f_ops[int(b["cigar_off"]):int(b["cigar_off"]) + int(b["cigar_len"])]), (j, m_occ[j])
+        # the CIGAR is an alignment of the read with its text window at the reported distance
+        import re
+        ops = [(int(n), o) for n, o in re.findall(r"(\d+)([MID])", cm)]
+        assert sum(n for n, o in ops if o in "MI") == len(reads[int(np.searchsorted(m_off, j, side="right") - 1)])
+        assert sum(n for n, o in ops if o in "MD") == int(m_occ[j]["end"]) - int(m_occ[j]["begin"])
+        n_edits += int(m_occ[j]["distance"]) > 0
+    assert n_edits > 50
+    # ... and the SAM records of the chunk (generateOutputSingleEnd through cmb_sam_chunk on the text-only index) are the FM-index flavour's
+    ids = [f"r{i} extra" for i in range(len(reads))]
+    quals = ["I" * len(r) for r in reads]
+    names = ["chrA", "chrB", "chrC"]
+    sam_m = mb.sam(ids, quals, names).splitlines()
+    sam_f = fb.sam(ids, quals, names).splitlines()
+    assert len(sam_m) == len(sam_f) > len(reads)
+    diff = [i for i in range(len(sam_m)) if sam_m[i] != sam_f[i]]
+    assert len(diff) <= max(2, len(sam_m) // 300), (len(diff), sam_m[diff[0]], sam_f[diff[0]])   # (strand labels of palindromic hits)
+    fb.close()
+    mb.close()
+    fm.close()
+
+
 def test_bmove_pool_growth(sworld):
     """pools that start from almost nothing are grown and the search re-run: same lists"""
     ca = sworld["ca"]
