@@ -26,6 +26,16 @@ int main(int argc, char** argv) {
         std::vector<std::vector<TextOcc>> matches;
         const int k = argc > 3 ? atoi(argv[3]) : 0;
         uint64_t nodes = 0;
+        if (k > 0 && argc > 6) { // ... <text file>: the SAM records of the chunk (the text beside the index serves CIGARs and trimming)
+            std::ifstream tf(argv[6], std::ios::binary);
+            const std::string text((std::istreambuf_iterator<char>(tf)), std::istreambuf_iterator<char>());
+            index.attachText(text);
+            SearchStrategy strategy(index, argv[4], CMB_PARTITION_DYNAMIC, CMB_METRIC_EDIT, atoi(argv[5]));
+            std::vector<std::string> ids, quals;
+            for (size_t i = 0; i < chunk.size(); i++) ids.push_back("r" + std::to_string(i)), quals.push_back(std::string(chunk[i].size(), 'I'));
+            std::cout << strategy.samOfChunk(ids, chunk, quals, {"seq0"}, (length_t)k);
+            return 0;
+        }
         if (k > 0) {
             SearchStrategy strategy(index, argc > 4 ? argv[4] : "multiple_opt", CMB_PARTITION_DYNAMIC, CMB_METRIC_EDIT, argc > 5 ? atoi(argv[5]) : 10);
             std::vector<uint64_t> counters;

@@ -145,6 +145,12 @@ class BMove {
     length_t getNumberOfRuns() const { return nRuns; }
     length_t getSwitchPoint() const { return 0; } // bmove.cpp:172-174: no in-text verification with b-move
     cmb_move_index* handle() const { return h; }
+    // The text beside the index: what the CIGARs and SAM records of the occurrences are computed on (the reference's search carries
+    // the matched string instead, indexinterface.h:294-303; here 288 GB of HBM hold a 2-bit copy of the text next to the tables).
+    // seqStarts: begin of every sequence in the concatenated text + the final n - 1 (the .pos file, indexinterface.cpp:162), or empty.
+    void attachText(const std::string& text, const std::vector<uint32_t>& seqStarts = {}) {
+        check(cmb_move_attach_text(h, text.data(), text.size(), seqStarts.empty() ? nullptr : seqStarts.data(), (uint32_t)seqStarts.size()));
+    }
 
     SARangePair getCompleteRange() const { // bmove.h:369-373
         cmb_move_range r;
@@ -228,6 +234,47 @@ class SearchStrategy {
     }
     SearchStrategy(const SearchStrategy&) = delete;
     ~SearchStrategy() { cmb_strategy_destroy(h); }
+    // The SAM records of a chunk in ALL mode (generateOutputSingleEnd, searchstrategy.cpp:1824-1902): occurrences, their CIGARs
+    // (findCIGAR on text[begin, end) — the matched string of this flavour, indexinterface.h:294-303) and sequence names.  Needs
+    // BMove::attachText.  ids / quals as read from the FASTQ file; seqNames: the sequences of the index in text order.
+    std::string samOfChunk(const std::vector<std::string>& ids, const std::vector<std::string>& reads, const std::vector<std::string>& quals,
+                           const std::vector<std::string>& seqNames, length_t maxED, int metric = CMB_METRIC_EDIT, bool unmappedRecords = true,
+                           bool xaTag = false) {
+        std::string buf;
+        std::vector<uint64_t> off(reads.size() + 1, 0), occOff(reads.size() + 1, 0);
+        for (size_t i = 0; i < reads.size(); i++) buf += reads[i], off[i + 1] = buf.size();
+        cmb_move_batch* b = nullptr;
+        check(cmb_move_batch_create(index.handle(), h, (uint32_t)maxED, kmerSize, buf.data(), off.data(), (uint32_t)reads.size(), &b));
+        struct Guard {
+            cmb_move_batch* b;
+            ~Guard() { cmb_move_batch_destroy(b); }
+        } guard{b};
+        check(cmb_move_batch_want_alignments(b, 1));
+        check(cmb_move_batch_run(b));
+        uint64_t n = 0, nOps = 0;
+        check(cmb_move_batch_result_size(b, &n));
+        std::vector<cmb_move_occ> occ(n ? n : 1);
+        check(cmb_move_batch_results(b, occ.data(), occ.size(), occOff.data(), nullptr));
+        std::vector<cmb_aln> aln(n ? n : 1);
+        (void)cmb_move_batch_alignments(b, aln.data(), 0, nullptr, 0, &nOps); // (sizes first)
+        std::vector<uint16_t> ops(nOps ? nOps : 1);
+        check(cmb_move_batch_alignments(b, aln.data(), aln.size(), ops.data(), ops.size(), &nOps));
+        std::vector<cmb_occ> occ32(n ? n : 1);
+        for (uint64_t i = 0; i < n; i++) occ32[i] = cmb_occ{(uint32_t)occ[i].begin, (uint32_t)occ[i].end, occ[i].distance, occ[i].strand};
+        std::vector<const char*> pi, pq, pn;
+        for (const auto& x : ids) pi.push_back(x.c_str());
+        for (const auto& x : quals) pq.push_back(x.c_str());
+        for (const auto& x : seqNames) pn.push_back(x.c_str());
+        cmb_index* tix = cmb_move_text_index(index.handle());
+        const int64_t len = cmb_sam_chunk(tix, (uint32_t)maxED, metric, buf.data(), off.data(), (uint32_t)reads.size(), pi.data(), pq.data(), pn.data(),
+                                          occ32.data(), occOff.data(), aln.data(), ops.data(), unmappedRecords, xaTag, nullptr, 0);
+        if (len < 0) check((int)len);
+        std::string out((size_t)len + 1, '\0');
+        (void)cmb_sam_chunk(tix, (uint32_t)maxED, metric, buf.data(), off.data(), (uint32_t)reads.size(), pi.data(), pq.data(), pn.data(), occ32.data(),
+                            occOff.data(), aln.data(), ops.data(), unmappedRecords, xaTag, &out[0], out.size());
+        out.resize((size_t)len);
+        return out;
+    }
     // matches[i] = the occurrences of reads[i] as filterPtr leaves them (searchstrategy.cpp:529); counters[CMB_CNT_*]
     void matchApproxBatch(const std::vector<std::string>& reads, length_t maxED, std::vector<uint64_t>& counters,
                           std::vector<std::vector<TextOcc>>& matches) {

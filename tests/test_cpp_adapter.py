@@ -196,6 +196,16 @@ def test_bmove_adapter_example_matches_python_binding(tmp_path):
            for i in range(len(areads)) for o in occ[int(offs[i]):int(offs[i + 1])]]
     assert got == exp and len(exp) > 100
     assert r.stderr.split("\n")[0] == f"nodes {cnt['NODE_COUNTER']}"
+    # SAM records through the adapter (BMove::attachText + rlc::SearchStrategy::samOfChunk) = the Python binding's
+    (tmp_path / "text.txt").write_bytes(t[:-1])
+    r = subprocess.run([exe, str(tmp_path / "idx"), str(tmp_path / "areads.txt"), "3", "kuch1", "6", str(tmp_path / "text.txt")],
+                       capture_output=True, text=True, check=True)
+    dev.attach_text(t)
+    mb = ca.MoveBatch(dev, ca.SearchStrategy("kuch1", "edit", "dynamic"), 3, reads=areads, kmer_size=6)
+    mb.want_alignments()
+    mb.run()
+    sam = mb.sam([f"r{i}" for i in range(len(areads))], ["I" * len(x) for x in areads], ["seq0"])
+    assert r.stdout == sam and sam.count("\n") >= len(areads) and "\t100M\t" in sam
 
 
 @pytest.mark.gpu
