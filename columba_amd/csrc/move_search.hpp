@@ -19,6 +19,27 @@
 
 namespace cmb {
 
+// Frontier records are written once and read once, a pass later: with CMB_MVS_NT (A/B build) their loads and stores carry the
+// non-temporal hint, so that they do not push move-table rows out of the L2 and the Infinity Cache.
+typedef uint32_t mvs_v4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 qLoad(const uint4* p) {
+#ifdef CMB_MVS_NT
+    const mvs_v4 v = __builtin_nontemporal_load(reinterpret_cast<const mvs_v4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void qStore(uint4* p, const uint4& a) {
+#ifdef CMB_MVS_NT
+    mvs_v4 v;
+    v.x = a.x, v.y = a.y, v.z = a.z, v.w = a.w;
+    __builtin_nontemporal_store(v, reinterpret_cast<mvs_v4*>(p));
+#else
+    *p = a;
+#endif
+}
+
 struct MvTask { // a search that starts its first approximate phase (k_mvs_exact -> k_mvs_start)
     uint32_t rsId;
     uint8_t scheme, search, idx, pad;
@@ -638,8 +659,8 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
         uint4 mA = make_uint4(0, 0, 0, 0), mB = mA;
         const uint4* Cx = B.C;
         if (act) {
-            const uint4 n1 = Qi[(size_t)PU * qCap + i], n2 = Qi[(size_t)(PU + 1) * qCap + i];
-            parent = MvTraits::load(Qi + i, qCap);
+            const uint4 n1 = qLoad(Qi + (size_t)PU * qCap + i), n2 = qLoad(Qi + (size_t)(PU + 1) * qCap + i);
+            parent = MvTraits::unpack(qLoad(Qi + i), qLoad(Qi + (size_t)qCap + i), qLoad(Qi + (size_t)2 * qCap + i));
             ctx = n1.y;
             fcP = n1.z;
             row = n1.x & 0xFFFFu;
@@ -754,7 +775,7 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
             const uint32_t cell = min(clSize + row1 - g.m, ED_CELLS - 1u);
             EdPack pack{0, 0};
             if (fcP != BFS_NONE && (kinds & 0x4444u)) {
-                const uint4 fp = Qi[(size_t)(PU + 2) * qCap + i];
+                const uint4 fp = qLoad(Qi + (size_t)(PU + 2) * qCap + i);
                 pack = EdPack{u64of(fp.x, fp.y), u64of(fp.z, fp.w)};
             }
 #pragma unroll
@@ -771,13 +792,13 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
                 }
                 if (kd == KIND_NODE) {
                     const uint32_t o = oNode++;
-                    Qo[o] = pk[c][0], Qo[(size_t)qCap + o] = pk[c][1], Qo[(size_t)2 * qCap + o] = pk[c][2];
-                    Qo[(size_t)PU * qCap + o] = make_uint4(row1 | (cMeta[c] & 0xFFFF0000u), ctx, fc, ((cMeta[c] >> 8) & 63u) | ((uint32_t)md << 8));
-                    Qo[(size_t)(PU + 1) * qCap + o] = make_uint4((uint32_t)cHP[c], (uint32_t)(cHP[c] >> 32), (uint32_t)cHN[c], (uint32_t)(cHN[c] >> 32));
+                    qStore(Qo + o, pk[c][0]), qStore(Qo + (size_t)qCap + o, pk[c][1]), qStore(Qo + (size_t)2 * qCap + o, pk[c][2]);
+                    qStore(Qo + (size_t)PU * qCap + o, make_uint4(row1 | (cMeta[c] & 0xFFFF0000u), ctx, fc, ((cMeta[c] >> 8) & 63u) | ((uint32_t)md << 8)));
+                    qStore(Qo + (size_t)(PU + 1) * qCap + o, make_uint4((uint32_t)cHP[c], (uint32_t)(cHP[c] >> 32), (uint32_t)cHN[c], (uint32_t)(cHN[c] >> 32)));
                     if (wantF) {
                         EdPack p2 = pack;
                         edPut(p2, cell, cMeta[c] & 31u);
-                        Qo[(size_t)(PU + 2) * qCap + o] = make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32));
+                        qStore(Qo + (size_t)(PU + 2) * qCap + o, make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32)));
                     }
                 } else { // KIND_EVENT
                     EdPack p2 = pack;
