@@ -432,7 +432,8 @@ def main():
         torch.cuda.empty_cache()
         log(f"[bench] index for {n / 1e6:.0f} Mbp built in {time.time() - t0:.1f} s "
             f"({ix.nbytes() / 1e9:.2f} GB host arrays)")
-    index = ca.Index(ix, in_text_switch=4, kmer_size=10, device=local) if rank == 0 else None
+    fm_kmer = args.kmer_size if "--kmer-size" in " ".join(sys.argv) else 10   # (the reference's default -K 10)
+    index = ca.Index(ix, in_text_switch=4, kmer_size=fm_kmer, device=local) if rank == 0 else None
     broadcast_ms = None
     if world > 1:
         dist.barrier()
@@ -624,7 +625,7 @@ def main():
             import oracle_py as op
             import schemes_py as sp
             ns = min(args.cpu_sample, R)
-            oidx = op.OracleIndex(ix)
+            oidx = op.OracleIndex(ix, kmer_size=fm_kmer)
             ost = op.OracleStrategy(sp.MULTIPLE_OPT, "edit", "dynamic")
             cores = effective_cpus()
             packed = (np.ascontiguousarray(buf[:ns * L]), offs[:ns + 1].copy())  # (packed before the clock starts)
@@ -650,7 +651,7 @@ def main():
             "config": {"workload": f"synthetic human-like reference {n / 1e6:.0f} Mbp (GRCh38 is not available "
                                    f"offline), {R} x {L} bp reads per GPU, k={args.k} edit distance, ALL mode, "
                                    "multiple_opt schemes with dynamic selection, dynamic partitioning, "
-                                   "in-text switch 4, SA sparseness 4",
+                                   "in-text switch 4, SA sparseness 4" + ("" if fm_kmer == 10 else f", k-mer table of {fm_kmer}-mers (-K {fm_kmer}; the reference's default is 10)"),
                        "reads_per_gpu": R, "read_len": L, "k": args.k, "genome_bp": n,
                        "index_bytes_hbm": index.device_bytes(), "parallelism": f"read-shard x{world}",
                        "occurrences": total_occ, "result_gather_ms": None if gather_ms is None else round(gather_ms, 1)},

@@ -169,7 +169,7 @@ extern "C" int cmb_index_create(const cmb_index_desc* desc, int device, cmb_inde
     if (!desc || !out) return fail(CMB_ERR_INVALID, "null argument");
     if (desc->text_length == 0 || desc->text_length >= 0xFFFFFFFFull)
         return fail(CMB_ERR_UNSUPPORTED, "text length must fit a 32-bit length_t");
-    if (desc->kmer_size > 12) return fail(CMB_ERR_INVALID, "k-mer size > 12 not supported");
+    if (desc->kmer_size > 15) return fail(CMB_ERR_INVALID, "k-mer size > 15 (the reference's -K option takes 0 ... 15, alignparameters.cpp:449)");
     if (desc->sa_sparseness == 0 || (desc->sa_sparseness & (desc->sa_sparseness - 1)))
         return fail(CMB_ERR_INVALID, "suffix array sparseness must be a power of two");
     try {
@@ -346,7 +346,7 @@ extern "C" int cmb_index_create_text_only(const char* text, uint64_t n, const ui
 
 extern "C" int cmb_index_create_empty(const cmb_index_layout* L, const uint32_t* seq_starts, int device, cmb_index** out) {
     if (!L || !out) return fail(CMB_ERR_INVALID, "null argument");
-    if (L->text_length == 0 || L->text_length >= 0xFFFFFFFFull || L->kmer_size > 12)
+    if (L->text_length == 0 || L->text_length >= 0xFFFFFFFFull || L->kmer_size > 15)
         return fail(CMB_ERR_INVALID, "index layout out of range");
     try {
         int ndev = 0;

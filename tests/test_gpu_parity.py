@@ -400,7 +400,7 @@ def test_byte_text_path(world):
         assert c1 == c2
 
 
-@pytest.mark.parametrize("sparseness,switch,kmer", [(1, 4, 10), (8, 0, 10), (32, 1, 8), (4, 10, 12), (16, 50, 4), (2, 7, 6)])
+@pytest.mark.parametrize("sparseness,switch,kmer", [(1, 4, 10), (8, 0, 10), (32, 1, 8), (4, 10, 12), (16, 50, 4), (2, 7, 6), (4, 4, 13)])
 def test_index_parameters(world, sparseness, switch, kmer):
     """Suffix-array sparseness, in-text switch point and k-mer size of the seed table away from their defaults (4, 4, 10;
     tools/soak_index_params.py runs the full grid at scale)."""
