@@ -381,6 +381,7 @@ def main():
     ap.add_argument("--base-mbp", type=float, default=4.0)
     ap.add_argument("--snp", type=float, default=0.005)
     ap.add_argument("--kmer-size", type=int, default=10)
+    ap.add_argument("--sparseness", type=int, default=4, help="suffix-array sparseness of the FM-index (the reference's -s option; default 4)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -427,7 +428,7 @@ def main():
     ix = None
     if rank == 0:
         g, starts = synth.genome_human_like(n, seed=2025, device=dev)
-        ix = ib.build_index(g, seq_starts=starts, device=dev, with_bwt=(world == 1 and not args.no_cpu_baseline))
+        ix = ib.build_index(g, sparseness=args.sparseness, seq_starts=starts, device=dev, with_bwt=(world == 1 and not args.no_cpu_baseline))
         del g
         torch.cuda.empty_cache()
         log(f"[bench] index for {n / 1e6:.0f} Mbp built in {time.time() - t0:.1f} s "
@@ -651,7 +652,7 @@ def main():
             "config": {"workload": f"synthetic human-like reference {n / 1e6:.0f} Mbp (GRCh38 is not available "
                                    f"offline), {R} x {L} bp reads per GPU, k={args.k} edit distance, ALL mode, "
                                    "multiple_opt schemes with dynamic selection, dynamic partitioning, "
-                                   "in-text switch 4, SA sparseness 4" + ("" if fm_kmer == 10 else f", k-mer table of {fm_kmer}-mers (-K {fm_kmer}; the reference's default is 10)"),
+                                   f"in-text switch 4, SA sparseness {args.sparseness}" + ("" if fm_kmer == 10 else f", k-mer table of {fm_kmer}-mers (-K {fm_kmer}; the reference's default is 10)"),
                        "reads_per_gpu": R, "read_len": L, "k": args.k, "genome_bp": n,
                        "index_bytes_hbm": index.device_bytes(), "parallelism": f"read-shard x{world}",
                        "occurrences": total_occ, "result_gather_ms": None if gather_ms is None else round(gather_ms, 1)},
