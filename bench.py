@@ -382,6 +382,7 @@ def main():
     ap.add_argument("--snp", type=float, default=0.005)
     ap.add_argument("--kmer-size", type=int, default=10)
     ap.add_argument("--sparseness", type=int, default=4, help="suffix-array sparseness of the FM-index (the reference's -s option; default 4)")
+    ap.add_argument("--in-text-switch", type=int, default=4, help="range width at which the search switches to in-text verification (the reference's -i option; default 4)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -434,7 +435,7 @@ def main():
         log(f"[bench] index for {n / 1e6:.0f} Mbp built in {time.time() - t0:.1f} s "
             f"({ix.nbytes() / 1e9:.2f} GB host arrays)")
     fm_kmer = args.kmer_size if "--kmer-size" in " ".join(sys.argv) else 10   # (the reference's default -K 10)
-    index = ca.Index(ix, in_text_switch=4, kmer_size=fm_kmer, device=local) if rank == 0 else None
+    index = ca.Index(ix, in_text_switch=args.in_text_switch, kmer_size=fm_kmer, device=local) if rank == 0 else None
     broadcast_ms = None
     if world > 1:
         dist.barrier()
@@ -626,7 +627,7 @@ def main():
             import oracle_py as op
             import schemes_py as sp
             ns = min(args.cpu_sample, R)
-            oidx = op.OracleIndex(ix, kmer_size=fm_kmer)
+            oidx = op.OracleIndex(ix, kmer_size=fm_kmer, switch_point=args.in_text_switch)
             ost = op.OracleStrategy(sp.MULTIPLE_OPT, "edit", "dynamic")
             cores = effective_cpus()
             packed = (np.ascontiguousarray(buf[:ns * L]), offs[:ns + 1].copy())  # (packed before the clock starts)
@@ -652,7 +653,7 @@ def main():
             "config": {"workload": f"synthetic human-like reference {n / 1e6:.0f} Mbp (GRCh38 is not available "
                                    f"offline), {R} x {L} bp reads per GPU, k={args.k} edit distance, ALL mode, "
                                    "multiple_opt schemes with dynamic selection, dynamic partitioning, "
-                                   f"in-text switch 4, SA sparseness {args.sparseness}" + ("" if fm_kmer == 10 else f", k-mer table of {fm_kmer}-mers (-K {fm_kmer}; the reference's default is 10)"),
+                                   f"in-text switch {args.in_text_switch}, SA sparseness {args.sparseness}" + ("" if fm_kmer == 10 else f", k-mer table of {fm_kmer}-mers (-K {fm_kmer}; the reference's default is 10)"),
                        "reads_per_gpu": R, "read_len": L, "k": args.k, "genome_bp": n,
                        "index_bytes_hbm": index.device_bytes(), "parallelism": f"read-shard x{world}",
                        "occurrences": total_occ, "result_gather_ms": None if gather_ms is None else round(gather_ms, 1)},
