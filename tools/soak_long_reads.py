@@ -33,8 +33,8 @@ cig = all(ca.cigar_string(d[2][int(a["cigar_off"]):int(a["cigar_off"]) + int(a["
 print("best mode, 300 bp:", "identical" if ok and cig else "DIFFER", len(d[0]), flush=True)
 bad += not (ok and cig)
 try:
-    ca.match_batch(dev, ca.SearchStrategy("multiple_opt"), 4, [b"ACGT" * 81])
-    print("321-character read accepted?!"); bad += 1
+    ca.match_batch(dev, ca.SearchStrategy("multiple_opt"), 4, [b"ACGT" * 121])
+    print("484-character read accepted?!"); bad += 1
 except ca.CmbError as e:
-    print("321 characters:", str(e)[:80])
+    print("484 characters (the limit is 480):", str(e)[:80])
 print("long reads:", "OK" if not bad else f"{bad} problems")
