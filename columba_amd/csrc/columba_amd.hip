@@ -565,6 +565,7 @@ struct cmb_batch {
     // schemes with more than MAXP parts (the greedy schemes for 8 ... 13 errors): tables of MAXP_WIDE parts, run by the wide instances
     // of k_parts / k_exact / k_hbfs (Hamming distance; the edit-distance matcher stops at 7 errors)
     bool wide = false;
+    bool wideEdit = false; // edit distance 8 ... 10: wide records AND the wide layout of the filter keys
     DevStrategyKT<MAXP_WIDE> hostStratW{};
     DevBuf<DevStrategyKT<MAXP_WIDE>> stratW;
     DevBuf<PartOutT<MAXP_WIDE>> partsW;
@@ -672,7 +673,8 @@ extern "C" int cmb_batch_create(cmb_index* idx, const cmb_strategy* st, uint32_t
     if (getenv("CMB_SUBBATCHES")) S = (uint32_t)std::max(1, atoi(getenv("CMB_SUBBATCHES")));
     // a sub-batch holds fewer than 2^24 reads (24-bit read number of the filter key, 25 bits of read x strand in the
     // verification key): larger batches are cut into more sub-batches up front, never refused after the work is done
-    S = std::max<uint32_t>(S, (uint32_t)(((uint64_t)n_reads + MAX_SUB_READS - 1) / MAX_SUB_READS));
+    const uint32_t maxSub = (st->metric == CMB_METRIC_EDIT && max_distance > 7) ? (1u << 20) : MAX_SUB_READS; // (22 group bits in the wide filter keys)
+    S = std::max<uint32_t>(S, (uint32_t)(((uint64_t)n_reads + maxSub - 1) / maxSub));
     S = std::min<uint32_t>(S, std::max<uint32_t>(n_reads, 1u));
     if (S <= 1) return batchCreateOne(idx, st, max_distance, seqs, offs, n_reads, out);
     std::unique_ptr<cmb_batch> parent(new cmb_batch());
@@ -737,12 +739,17 @@ static int batchCreateOne(cmb_index* idx, const cmb_strategy* st, uint32_t max_d
         if (max_distance > 0) {
             // in-text verification: nZeros + maxED = 3k+1 must fit the first column of the in-text matrix (the reference
             // switches to its 128-bit matrix at k = 7, fmindex.h:240-246; here: 64-bit words / 16-row blocks, LEFT = 22)
-            if (st->metric == CMB_METRIC_EDIT && 3 * max_distance + 1 > MXW_LEFT)
-                return fail(CMB_ERR_UNSUPPORTED, "k >= 8 needs a wider in-text matrix, which is not implemented");
+            // edit distance beyond 7 errors: the in-index search runs up to 10 (the 64-bit in-index matrix, bitparallelmatrix.h:309-316; wide
+            // record geometry GeoW), the in-text matrices stop at 7 — such a batch needs an index that never switches to in-text
+            // verification (in-text switch point 0: the reference's -i 0)
+            b->wideEdit = st->metric == CMB_METRIC_EDIT && 3 * max_distance + 1 > MXW_LEFT;
+            if (b->wideEdit && max_distance > MX_MAX_ED)
+                return fail(CMB_ERR_UNSUPPORTED, "edit distance beyond 10 errors needs the 128-bit in-index matrix, which is not implemented");
+            if (b->wideEdit && idx->d.switchPoint != 0)
+                return fail(CMB_ERR_UNSUPPORTED, "edit distance at 8 ... 10 errors runs on indexes with in-text switch point 0 only (-i 0): the in-text "
+                                                 "matrices of the device hold 7 errors");
             try {
-                b->wide = st->numPartsFor(max_distance) > (uint32_t)MAXP;
-                if (b->wide && st->metric == CMB_METRIC_EDIT)
-                    return fail(CMB_ERR_UNSUPPORTED, "edit distance with search schemes of more than 8 parts is not implemented (Hamming distance is)");
+                b->wide = st->numPartsFor(max_distance) > (uint32_t)MAXP || b->wideEdit;
                 if (max_distance > 13) return fail(CMB_ERR_UNSUPPORTED, "more than 13 errors (MAX_K, definitions.h:50)");
                 if (b->wide) {
                     b->hostStratW = st->flatten<MAXP_WIDE>(max_distance);
@@ -1134,7 +1141,9 @@ static int batchRunOne(cmb_batch* b) {
                 tm.begin();
                 if (b->metric == CMB_METRIC_EDIT) {
                     // ---- frontier search: start pass, then (expand, events) per level until both queues drain
-                    const uint32_t maxPass = 2 * b->maxLen + 8 * MAXP + 64;
+                    const uint32_t maxPass = 2 * b->maxLen + 8 * (b->wide ? MAXP_WIDE : MAXP) + 64;
+                    // node planes / uint4 per event of the record geometry (dev_bfs_edit.hpp: GeoN, GeoW)
+                    const size_t qPlanes = 3 + (b->wide ? GeoW::PK_U4 : GeoN::PK_U4), evU4 = 1 + (b->wide ? GeoW::PK_U4 : GeoN::PK_U4);
                     if (!b->bfsQCap) {
                         // first guess; every pool grows (and the search re-runs) when it turns out too small.
                         // CMB_TEST_SMALL_POOLS starts from almost nothing so that tests exercise that path.
@@ -1148,8 +1157,8 @@ static int batchRunOne(cmb_batch* b) {
                     }
                     b->bfsQCap = std::max<size_t>(b->bfsQCap, (size_t)nDfs + 1024);
                     for (int j = 0; j < 2; j++) {
-                        if (b->bfsQ[j].n < 4 * b->bfsQCap) b->bfsQ[j].alloc(4 * b->bfsQCap);
-                        if (b->bfsEv[j].n < 2 * b->bfsEvCap) b->bfsEv[j].alloc(2 * b->bfsEvCap);
+                        if (b->bfsQ[j].n < qPlanes * b->bfsQCap) b->bfsQ[j].alloc(qPlanes * b->bfsQCap);
+                        if (b->bfsEv[j].n < evU4 * b->bfsEvCap) b->bfsEv[j].alloc(evU4 * b->bfsEvCap);
                     }
                     if (b->bfsF.n < F_U4 * b->bfsFCap) b->bfsF.alloc(F_U4 * b->bfsFCap);
                     const uint32_t ctxU4 = ctxU4For(b->maxLen);
@@ -1168,8 +1177,8 @@ static int batchRunOne(cmb_batch* b) {
                     B.F = b->bfsF.p;
                     B.C = b->bfsC.p;
                     B.A = b->bfsA.p;
-                    B.qCap = (uint32_t)std::min<size_t>(b->bfsQ[0].n / 4, 0xFFFFFFF0u);
-                    B.evCap = (uint32_t)std::min<size_t>(b->bfsEv[0].n / 2, 0xFFFFFFF0u);
+                    B.qCap = (uint32_t)std::min<size_t>(b->bfsQ[0].n / qPlanes, 0xFFFFFFF0u);
+                    B.evCap = (uint32_t)std::min<size_t>(b->bfsEv[0].n / evU4, 0xFFFFFFF0u);
                     B.fCap = (uint32_t)std::min<size_t>(b->bfsF.n / F_U4, 0xFFFFFFF0u);
                     B.cCap = (uint32_t)std::min<size_t>(b->bfsC.n / ctxU4, 0xFFFFFFF0u);
                     B.ctxU4 = ctxU4;
@@ -1182,7 +1191,11 @@ static int batchRunOne(cmb_batch* b) {
                     B.ne = b->bfsCnt.p + (maxPass + 2);
                     B.pool = b->bfsCnt.p + 2 * (maxPass + 2);
                     B.blockCnt = b->bfsBlockCnt.p;
-                    hipLaunchKernelGGL(k_bfs_start, dim3(std::min<uint32_t>((nDfs + 255) / 256, BFS_GRID)), dim3(256), 0, s,
+                    if (b->wide)
+                        hipLaunchKernelGGL(k_bfs_start<GeoW>, dim3(std::min<uint32_t>((nDfs + 255) / 256, BFS_GRID)), dim3(256), 0, s,
+                                           ix->d, b->stratW.p, B, b->dfs.p, nDfs, b->offs.p, b->gw, b->G.p, b->partsW.p, q);
+                    else
+                        hipLaunchKernelGGL(k_bfs_start<GeoN>, dim3(std::min<uint32_t>((nDfs + 255) / 256, BFS_GRID)), dim3(256), 0, s,
                                        ix->d, b->strat.p, B, b->dfs.p, nDfs, b->offs.p, b->gw, b->G.p, b->parts.p, q);
                     std::vector<uint32_t> hc(cntWords);
                     const uint32_t CHECK = 16; // passes between two looks at the queue sizes
@@ -1191,7 +1204,11 @@ static int batchRunOne(cmb_batch* b) {
                     while (!drained && pass < maxPass) {
                         const uint32_t upTo = std::min(pass + CHECK, maxPass);
                         for (; pass < upTo; pass++) {
-                            hipLaunchKernelGGL(k_bfs_pass, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->strat.p, B,
+                            if (b->wide)
+                                hipLaunchKernelGGL(k_bfs_pass<GeoW>, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->stratW.p, B,
+                                                   pass, b->offs.p, b->gw, b->G.p, b->partsW.p, q);
+                            else
+                                hipLaunchKernelGGL(k_bfs_pass<GeoN>, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->strat.p, B,
                                                pass, b->offs.p, b->gw, b->G.p, b->parts.p, q);
                         }
                         HIPCHK(hipMemcpyAsync(hc.data(), b->bfsCnt.p, cntWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -1512,12 +1529,14 @@ static int batchRunOne(cmb_batch* b) {
             return CMB_OK;
         }
 
+        const uint32_t keyLayout = b->metric == CMB_METRIC_HAMMING ? 1u : b->wideEdit ? 2u : 0u; // (kernels.hpp: keyBits)
+        const uint32_t groupShift = keyBits(keyLayout).group;
         // ---- naive backtracking: the filter pass of approxMatchesNaive[Hamming] itself, per read x strand (dev_bfs_naive.hpp)
         uint64_t naiveSurvivors = 0;
         if (b->hasNaive && nText) {
             tm.begin();
             const uint32_t nG = 2u * nReads;
-            if (nG >= (1u << 24)) return fail(CMB_ERR_UNSUPPORTED, "more than 2^23 reads in a sub-batch with reads matched by naive backtracking");
+            if (nG >= (1u << (64u - groupShift))) return fail(CMB_ERR_UNSUPPORTED, "more than 2^23 reads in a sub-batch with reads matched by naive backtracking");
             if (b->keysA.n < nText) {
                 b->keysA.alloc((size_t)nText + nText / 8 + 256);
                 b->keysB.alloc((size_t)nText + nText / 8 + 256);
@@ -1530,7 +1549,7 @@ static int batchRunOne(cmb_batch* b) {
             }
             if (b->frank.n < nText) b->frank.alloc((size_t)nText + nText / 8 + 256);
             hipLaunchKernelGGL(k_pack_keys, dim3((nText + 255) / 256), dim3(256), 0, s, b->text.p, nText, b->offs.p, b->k, b->keysA.p,
-                               b->cnt.p, 1u, (const uint8_t*)b->psel.p, b->metric == CMB_METRIC_HAMMING ? 1u : 0u);
+                               b->cnt.p, 1u, (const uint8_t*)b->psel.p, keyLayout);
             size_t tmpBytes = 0;
             HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, b->keysA.p, b->keysB.p, nText, 0, 64, s));
             if (b->sortTmp.n < tmpBytes) b->sortTmp.alloc(tmpBytes + 256);
@@ -1539,9 +1558,9 @@ static int batchRunOne(cmb_batch* b) {
             HIPCHK(hipMemsetAsync(b->fcounts.p, 0, ((size_t)nG + 1) * sizeof(uint32_t), s));
             HIPCHK(hipMemsetAsync(b->fsegB.p, 0xFF, ((size_t)nG + 1) * sizeof(uint32_t), s));
             HIPCHK(hipMemsetAsync(b->frank.p, 0xFF, (size_t)nText * sizeof(uint32_t), s));
-            hipLaunchKernelGGL(k_filter_segments, dim3((nText + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->fsegB.p, b->fsegE.p);
+            hipLaunchKernelGGL(k_filter_segments, dim3((nText + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->fsegB.p, b->fsegE.p, groupShift);
             hipLaunchKernelGGL(k_filter_mark, dim3((nG + 255) / 256), dim3(256), 0, s, b->keysB.p, nG, b->k, mode, b->fcounts.p,
-                               b->frank.p, b->fsegB.p, b->fsegE.p);
+                               b->frank.p, b->fsegB.p, b->fsegE.p, keyLayout);
             size_t scanBytes = 0;
             HIPCHK(rocprim::exclusive_scan(nullptr, scanBytes, b->fcounts.p, b->foffs.p, (uint64_t)0, (size_t)nG + 1,
                                            rocprim::plus<uint64_t>(), s));
@@ -1565,7 +1584,7 @@ static int batchRunOne(cmb_batch* b) {
             hipLaunchKernelGGL(k_naive_drop, dim3((nText + 255) / 256), dim3(256), 0, s, b->text.p, nText, (const uint8_t*)b->psel.p);
             if (naiveSurvivors)
                 hipLaunchKernelGGL(k_naive_keep, dim3((nText + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->offs.p, b->k,
-                                   b->frank.p, b->foffs.p, b->text.p + nText, b->metric == CMB_METRIC_HAMMING ? 1u : 0u);
+                                   b->frank.p, b->foffs.p, b->text.p + nText, keyLayout);
             HIPCHK(hipGetLastError());
             nText += (uint32_t)naiveSurvivors;
             tm.end("k_naive_filter");
@@ -1579,7 +1598,7 @@ static int batchRunOne(cmb_batch* b) {
         b->cnts[1] += naiveSurvivors; // reported once more, as text occurrences of the read (indexinterface.cpp:1333, :1378)
         // groups of the filter: reads, or read x strand when every strand is filtered by itself
         const uint32_t nGroups = b->perStrand ? 2u * nReads : nReads;
-        if (nGroups >= (1u << 24)) return fail(CMB_ERR_UNSUPPORTED, "more than 2^24 filter groups in one sub-batch");
+        if (nGroups >= (1u << (64u - groupShift))) return fail(CMB_ERR_UNSUPPORTED, "more filter groups in one sub-batch than the keys number");
         {
             tm.begin();
             if (b->keysA.n < nText) {
@@ -1595,7 +1614,7 @@ static int batchRunOne(cmb_batch* b) {
             if (nText) {
                 hipLaunchKernelGGL(k_pack_keys, dim3((nText + 255) / 256), dim3(256), 0, s, b->text.p, nText, b->offs.p,
                                    b->k, b->keysA.p, b->cnt.p, b->perStrand ? 1u : 0u, (const uint8_t*)nullptr,
-                                   b->metric == CMB_METRIC_HAMMING ? 1u : 0u);
+                                   keyLayout);
                 size_t tmpBytes = 0;
                 HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, b->keysA.p, b->keysB.p, nText, 0, 64, s));
                 if (b->sortTmp.n < tmpBytes) b->sortTmp.alloc(tmpBytes + 256);
@@ -1606,11 +1625,11 @@ static int batchRunOne(cmb_batch* b) {
             HIPCHK(hipMemsetAsync(b->fsegB.p, 0xFF, ((size_t)nGroups + 1) * sizeof(uint32_t), s));
             if (nText)
                 hipLaunchKernelGGL(k_filter_segments, dim3((nText + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->fsegB.p,
-                                   b->fsegE.p);
+                                   b->fsegE.p, groupShift);
             if (b->frank.n < nText) b->frank.alloc((size_t)nText + nText / 8 + 256);
             if (nText) HIPCHK(hipMemsetAsync(b->frank.p, 0xFF, (size_t)nText * sizeof(uint32_t), s));
             hipLaunchKernelGGL(k_filter_mark, dim3((nGroups + 255) / 256), dim3(256), 0, s, b->keysB.p, nGroups, b->k, mode,
-                               b->fcounts.p, b->frank.p, b->fsegB.p, b->fsegE.p);
+                               b->fcounts.p, b->frank.p, b->fsegB.p, b->fsegE.p, keyLayout);
             size_t scanBytes = 0;
             HIPCHK(rocprim::exclusive_scan(nullptr, scanBytes, b->fcounts.p, b->foffs.p, (uint64_t)0, (size_t)nGroups + 1,
                                            rocprim::plus<uint64_t>(), s));
@@ -1630,7 +1649,7 @@ static int batchRunOne(cmb_batch* b) {
             if (total)
                 hipLaunchKernelGGL(k_filter_write, dim3((nText + 255) / 256), dim3(256), 0, s, b->keysB.p, nText, b->offs.p,
                                    b->k, b->frank.p, b->foffs.p, b->fout.p, b->wantAln ? b->foutRead.p : (uint32_t*)nullptr,
-                                   b->perStrand ? 1u : 0u, b->metric == CMB_METRIC_HAMMING ? 1u : 0u);
+                                   b->perStrand ? 1u : 0u, keyLayout);
             HIPCHK(hipGetLastError());
             tm.end("k_filter");
             lap("filter");

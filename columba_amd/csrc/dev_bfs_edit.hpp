@@ -153,6 +153,54 @@ __device__ __forceinline__ void edPut(EdPack& p, uint32_t i, uint32_t v) { // ce
 
 __device__ __forceinline__ uint64_t u64of(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
 
+// The wide pack (edit distance 8 ... 10): a phase has up to 3 k + 2 = 32 final-column cells, and the distances below a cluster centre
+// reach maxED + 31, so a cell takes 6 bits: ten cells per 64-bit word, four words.
+struct EdPackW {
+    uint64_t w[4];
+};
+__device__ __forceinline__ uint32_t edGet(const EdPackW& p, uint32_t i) {
+    const uint32_t q = i / 10u, r = i - 10u * q;
+    const uint64_t x = q == 0 ? p.w[0] : q == 1 ? p.w[1] : q == 2 ? p.w[2] : p.w[3];
+    return (uint32_t)(x >> (6u * r)) & 63u;
+}
+__device__ __forceinline__ void edPut(EdPackW& p, uint32_t i, uint32_t v) { // cell i is still zero
+    const uint32_t q = i / 10u, r = i - 10u * q;
+    const uint64_t x = (uint64_t)v << (6u * r);
+    if (q == 0) p.w[0] |= x;
+    else if (q == 1) p.w[1] |= x;
+    else if (q == 2) p.w[2] |= x;
+    else p.w[3] |= x;
+}
+// a pack in the records: PK_U4 consecutive planes (nodes) or uint4 (events)
+__device__ __forceinline__ void packLoad(const uint4* p, size_t stride, EdPack& out) {
+    const uint4 a = p[0];
+    out = EdPack{(uint64_t)a.x | ((uint64_t)a.y << 32), (uint64_t)a.z | ((uint64_t)a.w << 32)};
+}
+__device__ __forceinline__ void packStore(uint4* p, size_t stride, const EdPack& k) {
+    p[0] = make_uint4((uint32_t)k.lo, (uint32_t)(k.lo >> 32), (uint32_t)k.hi, (uint32_t)(k.hi >> 32));
+}
+__device__ __forceinline__ void packLoad(const uint4* p, size_t stride, EdPackW& out) {
+    const uint4 a = p[0], b = p[stride];
+    out.w[0] = u64of(a.x, a.y), out.w[1] = u64of(a.z, a.w), out.w[2] = u64of(b.x, b.y), out.w[3] = u64of(b.z, b.w);
+}
+__device__ __forceinline__ void packStore(uint4* p, size_t stride, const EdPackW& k) {
+    p[0] = make_uint4((uint32_t)k.w[0], (uint32_t)(k.w[0] >> 32), (uint32_t)k.w[1], (uint32_t)(k.w[1] >> 32));
+    p[stride] = make_uint4((uint32_t)k.w[2], (uint32_t)(k.w[2] >> 32), (uint32_t)k.w[3], (uint32_t)(k.w[3] >> 32));
+}
+// The two geometries of the frontier's records: GeoN is the common path (tables of MAXP parts, 24 cells of 5 bits: k <= 7) — every
+// kernel of the headline path is the GeoN instance, with the registers and record sizes it always had; GeoW: tables of MAXP_WIDE parts,
+// 32 cells of 6 bits (k = 8 ... 10), one more plane per node and one more uint4 per event.
+struct GeoN {
+    static constexpr int MP = MAXP;
+    typedef EdPack Pack;
+    static constexpr uint32_t CELLS = 24, PK_U4 = 1, ED_MAX = 31;
+};
+struct GeoW {
+    static constexpr int MP = MAXP_WIDE;
+    typedef EdPackW Pack;
+    static constexpr uint32_t CELLS = 32, PK_U4 = 2, ED_MAX = 63;
+};
+
 // block-wide exclusive prefix sum + ONE atomic for the whole block.  Every thread of the (256-thread) block
 // calls; returns this thread's first slot.  `sh` = 5 words of LDS per call site in flight.
 __device__ __forceinline__ uint32_t blockAppend(uint32_t* counter, uint32_t n, uint32_t* sh, uint32_t& blockTotal) {
@@ -253,7 +301,7 @@ struct ChildState {
     uint32_t sc, aux; // aux: final-column distance of the child (needF) or in-text start difference (KIND_ITEMS)
 };
 // kind of child `ch` of `parent` at row `row1` | needF << 2 | capacity problem << 3; FULL: also its state
-template <bool FULL>
+template <bool FULL, uint32_t EDMAX = 31u>
 __device__ __forceinline__ uint32_t evalChild(const DevIndex& ix, int md, const RangePair& parent, uint32_t ch,
                                               const uint32_t Rb[4], const uint32_t Re[4], uint32_t db, uint32_t de,
                                               const ExpandCtx& e, uint32_t row1, bool inFC, uint64_t M, uint64_t pHP,
@@ -268,9 +316,9 @@ __device__ __forceinline__ uint32_t evalChild(const DevIndex& ix, int md, const 
     uint32_t res = KIND_NODE, aux = 0;
     if (inFC) {
         const uint32_t ed = cellAt(row1, e.g.n - 1, HP, HN, sc);
-        aux = min(ed, 31u);
+        aux = min(ed, EDMAX);
         res |= 4u;
-        if (ed > 31u) res |= 8u;
+        if (ed > EDMAX) res |= 8u;
         if (!valid || onlyVerticalGapsLeft(e.g, row1, HN)) res = (res & ~3u) | KIND_EVENT;
     }
     if ((res & 3u) == KIND_NODE && child.sa.width() <= e.switchPoint && e.itMode != 0) { // goToInTextVerificationEdit (:340-375)
@@ -293,6 +341,7 @@ __device__ __forceinline__ uint32_t evalChild(const DevIndex& ix, int md, const 
     return res;
 }
 
+template <class Geo = GeoN>
 __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, uint32_t pass, const Queues& q,
                                           uint32_t bid, uint32_t nBlocks) {
     __shared__ uint32_t sh[4][5];
@@ -393,7 +442,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
                 row1 = row + 1;
                 ldsCnt[1][tid] += 1u;
                 const bool inFC = e.g.inFinalColumn(row1);
-                if (inFC && e.clSize + row1 - e.g.m >= ED_CELLS) flags |= FLAG_CAPACITY; // (a row beyond the matrix)
+                if (inFC && e.clSize + row1 - e.g.m >= Geo::CELLS) flags |= FLAG_CAPACITY; // (a row beyond the matrix)
                 kinds = 0;
                 nIt = 0;
                 uint32_t nOut = 0, nChildren = 0;
@@ -401,7 +450,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
                 for (uint32_t ch = 1; ch <= 4; ch++) {
                     bool nonEmpty;
                     ChildState cs;
-                    const uint32_t k4 = evalChild<false>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, ldsM[ch - 1][tid], pHP,
+                    const uint32_t k4 = evalChild<false, Geo::ED_MAX>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, ldsM[ch - 1][tid], pHP,
                                                          pHN, 1ull << pRac, score, nonEmpty, cs);
                     nChildren += nonEmpty ? 1u : 0u;
                     if (k4 & 8u) flags |= FLAG_CAPACITY;
@@ -422,7 +471,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
                     const uint64_t M = ch == 1 ? ldsM[0][tid] : ch == 2 ? ldsM[1][tid] : ch == 3 ? ldsM[2][tid] : ldsM[3][tid];
                     bool nonEmpty;
                     ChildState one;
-                    (void)evalChild<true>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, M, pHP, pHN, 1ull << pRac, score,
+                    (void)evalChild<true, Geo::ED_MAX>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, M, pHP, pHN, 1ull << pRac, score,
                                           nonEmpty, one);
                     parent = one.r;
                     score = one.sc;
@@ -465,14 +514,11 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
         if (oF + nF > B.fCap) { okF = false; flags |= FLAG_BFS_F; }
         if (kinds != 0u && okF && okNode && okEv && okIt) {
             const bool inFC = e.g.inFinalColumn(row1);
-            const uint32_t cell = min(e.clSize + row1 - e.g.m, ED_CELLS - 1u);
+            const uint32_t cell = min(e.clSize + row1 - e.g.m, Geo::CELLS - 1u);
             // what only the records need is fetched again now: the final-column distances of the path so far (nodes in
             // the final column: one in thirty), read number and item word of the context (in-text items)
-            EdPack pack{0, 0};
-            if (fcP != BFS_NONE && (kinds & 0x4444u)) {
-                const uint4 fp = Qi[(size_t)3 * qCap + i];
-                pack = EdPack{u64of(fp.x, fp.y), u64of(fp.z, fp.w)};
-            }
+            typename Geo::Pack pack{};
+            if (fcP != BFS_NONE && (kinds & 0x4444u)) packLoad(Qi + (size_t)3 * qCap + i, qCap, pack);
             uint32_t rsId = 0, itMeta = 0;
             if (nIt) {
                 const uint4 hot = B.C[(size_t)CMB_IDX(ctx, B.cCap, 2) * B.ctxU4 + CTX_HOT];
@@ -491,7 +537,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
                 if (kd == KIND_NONE) continue;
                 bool nonEmpty;
                 ChildState cs;
-                (void)evalChild<true>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, ldsM[ch - 1][tid], pHP, pHN, 1ull << pRac,
+                (void)evalChild<true, Geo::ED_MAX>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, ldsM[ch - 1][tid], pHP, pHN, 1ull << pRac,
                                       score, nonEmpty, cs);
                 const bool wantF = (kinds >> (4 * (ch - 1) + 2)) & 1u;
                 const uint4 cr = make_uint4(cs.r.sa.b, cs.r.sa.e, cs.r.rev.b, cs.r.rev.e);
@@ -510,15 +556,16 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
                     Qo[(size_t)2 * qCap + o] = make_uint4((uint32_t)cs.HP, (uint32_t)(cs.HP >> 32), (uint32_t)cs.HN,
                                                           (uint32_t)(cs.HN >> 32));
                     if (wantF) {
-                        EdPack p2 = pack;
+                        typename Geo::Pack p2 = pack;
                         edPut(p2, cell, cs.aux);
-                        Qo[(size_t)3 * qCap + o] = make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32));
+                        packStore(Qo + (size_t)3 * qCap + o, qCap, p2);
                     }
                 } else if (kd == KIND_EVENT) {
-                    EdPack p2 = pack;
+                    typename Geo::Pack p2 = pack;
                     edPut(p2, cell, cs.aux);
-                    Eo[(size_t)2 * oEv] = make_uint4(ctx, fc, 0xFFFFFFFFu, cell);
-                    Eo[(size_t)2 * oEv + 1] = make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32));
+                    constexpr uint32_t EV_U4 = 1u + Geo::PK_U4;
+                    Eo[(size_t)EV_U4 * oEv] = make_uint4(ctx, fc, 0xFFFFFFFFu, cell);
+                    packStore(Eo + (size_t)EV_U4 * oEv + 1, 1, p2);
                     oEv++;
                 } else {
                     const uint32_t w = cs.r.sa.e - cs.r.sa.b;
@@ -559,12 +606,16 @@ struct HeavyPlan {
     uint32_t nDescSrc;  // descendants the next phase replays
 };
 
-template <bool START, class Tr = FmTraits>
-__device__ __forceinline__ void bfsHeavy(const DevStrategyK* __restrict__ stp, const BfsBufs& B,
+template <bool START, class Tr = FmTraits, class Geo = GeoN>
+__device__ __forceinline__ void bfsHeavy(const DevStrategyKT<Geo::MP>* __restrict__ stp, const BfsBufs& B,
                                          uint32_t pass, const typename Tr::Task* __restrict__ tasks, uint32_t nTasks,
                                          const uint64_t* __restrict__ offs, uint32_t gw, const uint32_t* __restrict__ G,
-                                         const PartOut* __restrict__ parts, const Queues& q, uint32_t bid,
+                                         const PartOutT<Geo::MP>* __restrict__ parts, const Queues& q, uint32_t bid,
                                          uint32_t nBlocks) {
+    typedef DevSearchT<Geo::MP> DevSearch; // (the instance's table size)
+    typedef PartOutT<Geo::MP> PartOut;
+    typedef typename Geo::Pack EdPack;     // ... and final-column pack
+    constexpr uint32_t ED_CELLS = Geo::CELLS, ED_MAX = Geo::ED_MAX, PK = Geo::PK_U4, EV_U4 = 1u + Geo::PK_U4;
     __shared__ uint32_t sh[4][5];
     __shared__ uint8_t ieL[ED_CELLS + 2][256]; // initEds under construction, [entry][thread]
     typedef typename Tr::Pair Pair;
@@ -586,7 +637,7 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyK* __restrict__ stp, c
         uint32_t rsId = 0, scheme = 0, search = 0, idx = 0, dirCur = 0, smDepth = 0, smShift = 0, maxED = 0;
         uint32_t fcE = BFS_NONE, last = 0, c0i = BFS_NONE, descRef0 = BFS_NONE, otherRef0 = BFS_NONE, lowerBound = 0;
         int remFrom = -1;
-        EdPack pack{0, 0};
+        EdPack pack{};
         Pair startR = Tr::none();
         uint32_t startDepth = 0;
         const DevSearch* s = nullptr;
@@ -604,15 +655,14 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyK* __restrict__ stp, c
                     s = &stp->sch[scheme].s[search];
                 }
             } else {
-                const uint4 ev = Ei[(size_t)2 * i];
+                const uint4 ev = Ei[(size_t)EV_U4 * i];
                 c0i = ev.x;
                 fcE = ev.y;
                 remFrom = (int)ev.z;
                 last = ev.w;
                 const uint4* Cx = B.C + (size_t)CMB_IDX(c0i, B.cCap, 3) * B.ctxU4;
                 const uint4 c0 = Cx[0], c1 = Cx[1], c3 = Cx[3];
-                const uint4 fp = Ei[(size_t)2 * i + 1]; // final-column distances of the path (travel with the event)
-                pack = EdPack{u64of(fp.x, fp.y), u64of(fp.z, fp.w)};
+                packLoad(Ei + (size_t)EV_U4 * i + 1, 1, pack); // final-column distances of the path (travel with the event)
                 rsId = c0.x;
                 maxED = (c0.z >> 16) & 0xFFu;
                 const uint32_t fl = c0.w;
@@ -857,7 +907,8 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyK* __restrict__ stp, c
         // ---- phase entry: recApproxMatchEdit prologue + replay of the descendants (:377-497)
         uint32_t outKind = 0; // 1: node of the next frontier, 2: event
         uint32_t evRem = 0, evCell = 0, fLast = BFS_NONE; // event of an interrupted replay: descendants left, cell, its F record
-        uint4 oN1 = make_uint4(0, 0, 0, 0), oN2 = oN1, oN4 = oN1, oEv1 = oN1;
+        uint4 oN1 = make_uint4(0, 0, 0, 0), oN2 = oN1;
+        EdPack oPack{}; // the final-column pack of the node / event this lane produces
         Pair oRoot = Tr::none();
         if (enter) {
             if (descSelf) descRefN = cNew;
@@ -954,12 +1005,12 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyK* __restrict__ stp, c
                     Cx[CTX_M + 1 + 2 * b] = make_uint4((uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)t, (uint32_t)(t >> 32));
                 }
                 // first cell of the cluster (:452-461)
-                EdPack pk{0, 0};
+                EdPack pk{};
                 uint32_t fcCur = BFS_NONE;
                 if (g.inFinalColumn(0)) {
                     const uint32_t e0 = cellAt(0, xLen, HP, HN, score);
-                    if (e0 > 31u) flags |= FLAG_CAPACITY;
-                    edPut(pk, 0, min(e0, 31u));
+                    if (e0 > ED_MAX) flags |= FLAG_CAPACITY;
+                    edPut(pk, 0, min(e0, ED_MAX));
                     uint4* Fr = B.F + (size_t)CMB_IDX(fNext, B.fCap, 21) * FU;
                     Tr::store(Fr, 1, smR);
                     Fr[PU] = make_uint4(0u, BFS_NONE, 0u, 0u);
@@ -986,8 +1037,8 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyK* __restrict__ stp, c
                         if (g.inFinalColumn(depth)) {
                             const uint32_t cellJ = clSize + depth - g.m;
                             const uint32_t e = cellAt(depth, g.n - 1, HP, HN, score);
-                            if (e > 31u) flags |= FLAG_CAPACITY;
-                            edPut(pk, cellJ, min(e, 31u));
+                            if (e > ED_MAX) flags |= FLAG_CAPACITY;
+                            edPut(pk, cellJ, min(e, ED_MAX));
                             uint4* Fr = B.F + (size_t)CMB_IDX(fNext, B.fCap, 22) * FU;
 #pragma unroll
                             for (uint32_t u = 0; u < PU; u++) Fr[u] = dl[DU * j + u];
@@ -1009,7 +1060,7 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyK* __restrict__ stp, c
                         evRem = j + 1;
                         evCell = clSize + (dl[DU * j + PU].x & 0xFFFFu) - g.m;
                         fLast = fNext - 1u; // (the F record of that row was the last one handed out)
-                        oEv1 = make_uint4((uint32_t)pk.lo, (uint32_t)(pk.lo >> 32), (uint32_t)pk.hi, (uint32_t)(pk.hi >> 32));
+                        oPack = pk;
                     }
                     if (live) {
                         const uint32_t lastDepth = dl[DU * (nSrcDesc - 1) + PU].x & 0xFFFFu;
@@ -1028,7 +1079,7 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyK* __restrict__ stp, c
                     oN1 = make_uint4(rootRow | (score << 16), cNew, fcCur,
                                      ((uint32_t)__ffsll((unsigned long long)RAC) - 1u) | ((uniN ? 2u : (dirN == 0 ? 0u : 1u)) << 8));
                     oN2 = make_uint4((uint32_t)HP, (uint32_t)(HP >> 32), (uint32_t)HN, (uint32_t)(HN >> 32));
-                    oN4 = make_uint4((uint32_t)pk.lo, (uint32_t)(pk.lo >> 32), (uint32_t)pk.hi, (uint32_t)(pk.hi >> 32));
+                    oPack = pk;
                 }
             }
         }
@@ -1042,13 +1093,13 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyK* __restrict__ stp, c
                 Tr::store(Qo + oN, qCap, oRoot);
                 Qo[(size_t)PU * qCap + oN] = oN1;
                 Qo[(size_t)(PU + 1) * qCap + oN] = oN2;
-                Qo[(size_t)(PU + 2) * qCap + oN] = oN4;
+                packStore(Qo + (size_t)(PU + 2) * qCap + oN, qCap, oPack);
             }
         } else if (outKind == 2) {
             if (oE >= B.evCap) flags |= FLAG_BFS_EV;
             else {
-                Eo[(size_t)2 * oE] = make_uint4(cNew, fLast, evRem, evCell);
-                Eo[(size_t)2 * oE + 1] = oEv1;
+                Eo[(size_t)EV_U4 * oE] = make_uint4(cNew, fLast, evRem, evCell);
+                packStore(Eo + (size_t)EV_U4 * oE + 1, 1, oPack);
             }
         }
     }

@@ -198,16 +198,17 @@ k_naive_drop(TextOccRec* __restrict__ text, uint32_t n, const uint8_t* __restric
 }
 __global__ void __launch_bounds__(256)
 k_naive_keep(const unsigned long long* __restrict__ keys, uint32_t n, const uint64_t* __restrict__ offs, uint32_t k,
-             const uint32_t* __restrict__ rank, const uint64_t* __restrict__ outOffs, TextOccRec* __restrict__ out, uint32_t hamming) {
+             const uint32_t* __restrict__ rank, const uint64_t* __restrict__ outOffs, TextOccRec* __restrict__ out, uint32_t layout) {
+    const KeyBits kb = keyBits(layout);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t rk = rank[i];
     if (rk == 0xFFFFFFFFu) return;
     const unsigned long long key = keys[i]; // (k_pack_keys, read x strand groups)
-    const uint32_t rs = (uint32_t)(key >> 40), r = rs >> 1;
+    const uint32_t rs = (uint32_t)(key >> kb.group), r = rs >> 1;
     const uint32_t len = (uint32_t)(offs[r + 1] - offs[r]);
-    const uint32_t begin = (uint32_t)(key >> 8), dist = hamming ? (uint32_t)(key >> 4) & 15u : (uint32_t)(key >> 5) & 7u;
-    const uint32_t width = hamming ? len : len - k + ((uint32_t)(key >> 1) & 15u);
+    const uint32_t begin = (uint32_t)(key >> kb.begin), dist = (uint32_t)(key >> kb.dist) & kb.distMask;
+    const uint32_t width = layout == 1u ? len : len - k + ((uint32_t)(key >> 1) & kb.wMask);
     out[outOffs[rs] + rk] = TextOccRec{rs, begin, begin + width, dist};
 }
 

@@ -286,12 +286,13 @@ __global__ void k_bfs_finish(BfsBufs B, Queues q) { // one block: per-block coun
 
 
 // first approximate phase of every task (k_exact's DfsTask queue) -> frontier of pass 0
+template <class Geo = GeoN>
 __global__ void __launch_bounds__(256)
-k_bfs_start(DevIndex ix, const DevStrategyK* __restrict__ stp, BfsBufs B, const DfsTask* __restrict__ tasks, uint32_t nTasks,
-            const uint64_t* __restrict__ offs, uint32_t gw, const uint32_t* __restrict__ G, const PartOut* __restrict__ parts,
+k_bfs_start(DevIndex ix, const DevStrategyKT<Geo::MP>* __restrict__ stp, BfsBufs B, const DfsTask* __restrict__ tasks, uint32_t nTasks,
+            const uint64_t* __restrict__ offs, uint32_t gw, const uint32_t* __restrict__ G, const PartOutT<Geo::MP>* __restrict__ parts,
             Queues q) {
     if (blockStopped(q)) return;
-    bfsHeavy<true>(stp, B, 0u, tasks, nTasks, offs, gw, G, parts, q, blockIdx.x, gridDim.x);
+    bfsHeavy<true, FmTraits, Geo>(stp, B, 0u, tasks, nTasks, offs, gw, G, parts, q, blockIdx.x, gridDim.x);
 }
 
 // one level: blocks [0, BFS_GRID) expand the frontier, blocks [BFS_GRID, BFS_GRID + BFS_GRID_EV) handle the events
@@ -299,12 +300,13 @@ k_bfs_start(DevIndex ix, const DevStrategyK* __restrict__ stp, BfsBufs B, const 
 #ifndef CMB_BFS_WAVES
 #define CMB_BFS_WAVES 4 // wavefronts per SIMD the register allocation of k_bfs_pass is held to (128 VGPRs)
 #endif
-__global__ void __launch_bounds__(256, CMB_BFS_WAVES)
-k_bfs_pass(DevIndex ix, const DevStrategyK* __restrict__ stp, BfsBufs B, uint32_t pass, const uint64_t* __restrict__ offs,
-           uint32_t gw, const uint32_t* __restrict__ G, const PartOut* __restrict__ parts, Queues q) {
+template <class Geo = GeoN>
+__global__ void __launch_bounds__(256, Geo::MP == MAXP ? CMB_BFS_WAVES : 2)
+k_bfs_pass(DevIndex ix, const DevStrategyKT<Geo::MP>* __restrict__ stp, BfsBufs B, uint32_t pass, const uint64_t* __restrict__ offs,
+           uint32_t gw, const uint32_t* __restrict__ G, const PartOutT<Geo::MP>* __restrict__ parts, Queues q) {
     if (blockStopped(q)) return;
-    if (blockIdx.x < B.gridX) bfsExpand(ix, B, pass, q, blockIdx.x, B.gridX);
-    else bfsHeavy<false>(stp, B, pass, nullptr, 0u, offs, gw, G, parts, q, blockIdx.x - B.gridX, B.gridEv);
+    if (blockIdx.x < B.gridX) bfsExpand<Geo>(ix, B, pass, q, blockIdx.x, B.gridX);
+    else bfsHeavy<false, FmTraits, Geo>(stp, B, pass, nullptr, 0u, offs, gw, G, parts, q, blockIdx.x - B.gridX, B.gridEv);
 }
 
 
@@ -1556,7 +1558,7 @@ k_pack_keys(const TextOccRec* __restrict__ text, uint32_t n, const uint64_t* __r
             uint32_t perStrand /* BEST mode filters every strand by itself (mapRead, searchstrategy.h:490-523): the group of a
                                   key is then read x strand, not the read */,
             const uint8_t* __restrict__ only = nullptr /* dev_bfs_naive.hpp: keys for the reads marked here (bit 7), holes for the rest */,
-            uint32_t hamming = 0 /* the Hamming layout of the low byte */) {
+            uint32_t layout = 0 /* keyBits */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const TextOccRec t = text[i];
@@ -1569,29 +1571,31 @@ k_pack_keys(const TextOccRec* __restrict__ text, uint32_t n, const uint64_t* __r
     const uint32_t width = t.end - t.begin;
     const uint32_t wrel = width - (len - k); // in [0, 2k] for every occurrence of a read of length len
     const uint32_t grp = perStrand ? t.rsId : r;
+    const KeyBits kb = keyBits(layout);
     uint32_t low;
-    if (hamming) {
-        if (width != len || t.dist > 15u) atomicOr(&cnt[3], (uint32_t)FLAG_CAPACITY);
-        low = (t.dist & 15u) << 4;
+    if (layout == 1u) {
+        if (width != len || t.dist > kb.distMask) atomicOr(&cnt[3], (uint32_t)FLAG_CAPACITY);
+        low = (t.dist & kb.distMask) << kb.dist;
     } else {
-        if (wrel > 15u || t.dist > 7u) atomicOr(&cnt[3], (uint32_t)FLAG_CAPACITY);
-        low = ((t.dist & 7u) << 5) | ((wrel & 15u) << 1);
+        if (wrel > kb.wMask || t.dist > kb.distMask) atomicOr(&cnt[3], (uint32_t)FLAG_CAPACITY);
+        low = ((t.dist & kb.distMask) << kb.dist) | ((wrel & kb.wMask) << 1);
     }
-    keys[i] = ((unsigned long long)grp << 40) | ((unsigned long long)t.begin << 8) | (unsigned long long)low |
+    if ((unsigned long long)grp >> (64u - kb.group)) atomicOr(&cnt[3], (uint32_t)FLAG_CAPACITY);
+    keys[i] = ((unsigned long long)grp << kb.group) | ((unsigned long long)t.begin << kb.begin) | (unsigned long long)low |
               (unsigned long long)(perStrand ? 0u : (t.rsId & 1u));
 }
 
 // segment of every read in the sorted keys: segBeg[r] = first key of read r (one coalesced pass; reads without
 // occurrences keep the 0xFFFFFFFF the array was filled with and are skipped by k_filter)
 __global__ void k_filter_segments(const unsigned long long* __restrict__ keys, uint32_t n, uint32_t* __restrict__ segBeg,
-                                  uint32_t* __restrict__ segEnd) {
+                                  uint32_t* __restrict__ segEnd, uint32_t groupShift = 40u) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned long long key = keys[i];
     if (key == ~0ull) return; // holes sort behind every read
-    const uint32_t r = (uint32_t)(key >> 40);
-    if (i == 0 || (uint32_t)(keys[i - 1] >> 40) != r) segBeg[r] = i;
-    if (i + 1 == n || keys[i + 1] == ~0ull || (uint32_t)(keys[i + 1] >> 40) != r) segEnd[r] = i + 1;
+    const uint32_t r = (uint32_t)(key >> groupShift);
+    if (i == 0 || (uint32_t)(keys[i - 1] >> groupShift) != r) segBeg[r] = i;
+    if (i + 1 == n || keys[i + 1] == ~0ull || (uint32_t)(keys[i + 1] >> groupShift) != r) segEnd[r] = i + 1;
 }
 
 // mode 0: k = 0 (no filtering, searchstrategy.cpp:499-510); 1: Hamming (unique only); 2: edit distance
@@ -1606,7 +1610,8 @@ constexpr uint32_t FILTER_SHORT = 24;
 __global__ void __launch_bounds__(256)
 k_filter_mark(const unsigned long long* __restrict__ keys, uint32_t nReads, uint32_t k, int mode,
               uint32_t* __restrict__ counts, uint32_t* __restrict__ rank, const uint32_t* __restrict__ segBeg,
-              const uint32_t* __restrict__ segEnd) {
+              const uint32_t* __restrict__ segEnd, uint32_t layout = 0u) {
+    const KeyBits kb = keyBits(layout);
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t segLo = 0xFFFFFFFFu;
@@ -1621,8 +1626,8 @@ k_filter_mark(const unsigned long long* __restrict__ keys, uint32_t nReads, uint
         unsigned long long prevKey = ~0ull;
     };
     auto stepCore = [&](State& st, uint32_t i, unsigned long long key, uint32_t& replaced) -> uint32_t {
-        const uint32_t begin = (uint32_t)(key >> 8), dist = (uint32_t)(key >> 5) & 7u; // (mode 2; the other modes compare whole keys)
-        const uint32_t width = (uint32_t)(key >> 1) & 15u; // relative to len - k: the same for all keys of a read
+        const uint32_t begin = (uint32_t)(key >> kb.begin), dist = (uint32_t)(key >> kb.dist) & kb.distMask; // (mode 2; the other modes compare whole keys)
+        const uint32_t width = (uint32_t)(key >> 1) & kb.wMask; // relative to len - k: the same for all keys of a read
         replaced = FILTER_NONE;
         bool keep = true;
         if (mode != 0) {
@@ -1718,17 +1723,18 @@ k_filter_mark(const unsigned long long* __restrict__ keys, uint32_t nReads, uint
 __global__ void __launch_bounds__(256)
 k_filter_write(const unsigned long long* __restrict__ keys, uint32_t n, const uint64_t* __restrict__ offs, uint32_t k,
                const uint32_t* __restrict__ rank, const uint64_t* __restrict__ outOffs, uint4* __restrict__ out,
-               uint32_t* __restrict__ outRead /* read of every occurrence, or null */, uint32_t perStrand, uint32_t hamming) {
+               uint32_t* __restrict__ outRead /* read of every occurrence, or null */, uint32_t perStrand, uint32_t layout) {
+    const KeyBits kb = keyBits(layout);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t rk = rank[i];
     if (rk == FILTER_NONE) return;
     const unsigned long long key = keys[i];
-    const uint32_t grp = (uint32_t)(key >> 40);
+    const uint32_t grp = (uint32_t)(key >> kb.group);
     const uint32_t r = perStrand ? grp >> 1 : grp;
     const uint32_t len = (uint32_t)(offs[r + 1] - offs[r]);
-    const uint32_t begin = (uint32_t)(key >> 8), dist = hamming ? (uint32_t)(key >> 4) & 15u : (uint32_t)(key >> 5) & 7u;
-    const uint32_t width = hamming ? len : len - k + ((uint32_t)(key >> 1) & 15u), strand = perStrand ? (grp & 1u) : ((uint32_t)key & 1u);
+    const uint32_t begin = (uint32_t)(key >> kb.begin), dist = (uint32_t)(key >> kb.dist) & kb.distMask;
+    const uint32_t width = layout == 1u ? len : len - k + ((uint32_t)(key >> 1) & kb.wMask), strand = perStrand ? (grp & 1u) : ((uint32_t)key & 1u);
     out[outOffs[grp] + rk] = make_uint4(begin, begin + width, dist, strand);
     if (outRead) outRead[outOffs[grp] + rk] = r;
 }

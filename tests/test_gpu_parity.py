@@ -304,10 +304,30 @@ def test_hamming_distance_with_eight_to_thirteen_errors(world, partition, k, len
     _compare(world, "columba", "hamming", partition, k, reads, dups_rare=False)
 
 
+@pytest.fixture(scope="module")
+def world0(world):
+    """the same text under an index that never switches to in-text verification (the reference's -i 0)"""
+    op = world["op"]
+    return {"genome": world["genome"], "ix": world["ix"], "op": op, "dev": ca.Index(world["ix"], in_text_switch=0),
+            "orc": op.OracleIndex(world["ix"], switch_point=0)}
+
+
+@pytest.mark.parametrize("partition,k,length", [("dynamic", 8, 150), ("uniform", 9, 150), ("static", 10, 200), ("dynamic", 10, 250),
+                                                ("dynamic", 8, 100)])
+def test_edit_distance_with_eight_to_ten_errors_in_the_index(world0, partition, k, length):
+    """Edit distance beyond 7 errors on an index with in-text switch point 0: the whole search stays in the index — the greedy
+    schemes (9 ... 11 parts), the 64-bit in-index matrix (bitparallelmatrix.h:309-316: up to 10 errors), final-column packs of 32
+    cells of 6 bits (GeoW), filter keys with 4 + 5 bits for distance and width.  Occurrences and counters equal to the oracle's."""
+    g = world0["genome"]
+    reads = synth.sample_reads(g, 500, length, seed=700 + k, n_frac=0.01, edit_choices=(0, 3, 6, 8, k, k, k + 1))
+    reads += [b"N" * length, g[-length - 1:-1].tobytes(), g[0:length].tobytes()]
+    _compare(world0, "columba", "edit", partition, k, reads, dups_rare=False)
+
+
 def test_edit_distance_beyond_seven_errors_is_refused_up_front(world):
-    with pytest.raises(ca.CmbError) as e:
+    with pytest.raises(ca.CmbError) as e:   # (in-text switch point 4: the in-text matrices hold 7 errors)
         ca.match_batch(world["dev"], ca.SearchStrategy("columba", "edit", "dynamic"), 8, [b"ACGT" * 40])
-    assert e.value.code == ca.CMB_ERR_UNSUPPORTED
+    assert e.value.code == ca.CMB_ERR_UNSUPPORTED and "switch point 0" in str(e.value)
     with pytest.raises(ca.CmbError):
         ca.match_batch(world["dev"], ca.SearchStrategy("columba", "hamming", "dynamic"), 14, [b"ACGT" * 40])
 
