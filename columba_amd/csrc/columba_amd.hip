@@ -594,6 +594,7 @@ struct cmb_batch {
     DevBuf<DfsTask> dfs;
     DevBuf<uint64_t> vW; // packed trace rows [row][slot]
     DevBuf<uint4> tbq;
+    DevBuf<uint8_t> dpSlab; // k_verify_dp: the band rows of one candidate per slot
     DevBuf<uint4> items;
     DevBuf<FMOccRec> fm, fmUniq;
     DevBuf<TextOccRec> text;
@@ -740,14 +741,10 @@ static int batchCreateOne(cmb_index* idx, const cmb_strategy* st, uint32_t max_d
             // in-text verification: nZeros + maxED = 3k+1 must fit the first column of the in-text matrix (the reference
             // switches to its 128-bit matrix at k = 7, fmindex.h:240-246; here: 64-bit words / 16-row blocks, LEFT = 22)
             // edit distance beyond 7 errors: the in-index search runs up to 10 (the 64-bit in-index matrix, bitparallelmatrix.h:309-316; wide
-            // record geometry GeoW), the in-text matrices stop at 7 — such a batch needs an index that never switches to in-text
-            // verification (in-text switch point 0: the reference's -i 0)
+            // record geometry GeoW); the bit-parallel in-text matrices stop at 7, candidates are verified by k_verify_dp
             b->wideEdit = st->metric == CMB_METRIC_EDIT && 3 * max_distance + 1 > MXW_LEFT;
             if (b->wideEdit && max_distance > MX_MAX_ED)
                 return fail(CMB_ERR_UNSUPPORTED, "edit distance beyond 10 errors needs the 128-bit in-index matrix, which is not implemented");
-            if (b->wideEdit && idx->d.switchPoint != 0)
-                return fail(CMB_ERR_UNSUPPORTED, "edit distance at 8 ... 10 errors runs on indexes with in-text switch point 0 only (-i 0): the in-text "
-                                                 "matrices of the device hold 7 errors");
             try {
                 b->wide = st->numPartsFor(max_distance) > (uint32_t)MAXP || b->wideEdit;
                 if (max_distance > 13) return fail(CMB_ERR_UNSUPPORTED, "more than 13 errors (MAX_K, definitions.h:50)");
@@ -1383,7 +1380,14 @@ static int batchRunOne(cmb_batch* b) {
                 auto kv = dedup ? k_verify<true> : k_verify<false>;
                 hipLaunchKernelGGL(kv, dim3(vSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->maxLen, b->gw,
                                    b->seq.p, mf, b->items.p, nItems, b->tbq.p, tbCap,
-                                   dedup ? b->vkeysA.p : (unsigned long long*)nullptr, q);
+                                   dedup ? b->vkeysA.p : (unsigned long long*)nullptr, q, b->wideEdit ? 1u : 0u);
+                if (b->wideEdit) { // 8 ... 10 errors: the band does not fit the bit-parallel in-text matrices — k_verify_dp
+                    const uint32_t slotBytes = (dpRows(b->maxLen) + 1u) * DP_ROW_BYTES;
+                    const uint32_t dSlots = std::min<uint32_t>(((nItems + 255) / 256) * 256, 256u * 128u);
+                    if (b->dpSlab.n < (size_t)slotBytes * dSlots) b->dpSlab.alloc((size_t)slotBytes * dSlots);
+                    hipLaunchKernelGGL(k_verify_dp, dim3(dSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->maxLen, b->seq.p, b->items.p, nItems,
+                                       b->dpSlab.p, slotBytes, q);
+                }
                 if (dedup) {
                     uint32_t nRuns = 0;
                     size_t tmpBytes = 0;

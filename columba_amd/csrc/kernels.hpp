@@ -923,7 +923,8 @@ template <bool KEYS>
 __global__ void __launch_bounds__(256)
 k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32_t gw,
          const uint8_t* __restrict__ seq, MFull mf, const uint4* __restrict__ items,
-         uint32_t nItems, uint4* __restrict__ tbq, uint32_t tbCap, unsigned long long* __restrict__ vkeys, Queues q) {
+         uint32_t nItems, uint4* __restrict__ tbq, uint32_t tbCap, unsigned long long* __restrict__ vkeys, Queues q,
+         uint32_t skipEdit = 0 /* edit-distance candidates are left to k_verify_dp (8 ... 10 errors) */) {
     __shared__ uint64_t Ml[ML_WORDS];
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cLF = 0, cLoc = 0, cText = 0, cRows = 0, cAbort = 0, cCig = 0, cStarted = 0, cRep = 0, flags = 0;
@@ -942,7 +943,7 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
         unsigned long long vkey = ~0ull;
         uint4 item = make_uint4(0xFFFFFFFFu, 0, 0, 0);
         if (it < nItems) item = items[it];
-        if (item.x != 0xFFFFFFFFu) { // (holes: unused slots of a wavefront's chunk)
+        if (item.x != 0xFFFFFFFFu && !(skipEdit && ((item.w >> 21) & 3u) == ITEM_EDIT)) { // (holes: unused slots of a wavefront's chunk)
             rs = item.x;
             const uint32_t row = item.y, a = item.z, meta = item.w;
             const uint32_t kind = (meta >> 21) & 3u;
@@ -1046,6 +1047,147 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
     if (ovT) flags |= FLAG_TEXT_OVERFLOW;
     if (ovB) flags |= FLAG_CAPACITY; // (sized by the host for the worst case)
     const uint32_t local[8] = {cLF, cLoc, cText, cRows, cAbort, cCig, cStarted, cRep + cCig};
+    const int which[8] = {8, 9, 10, 11, 3, 4, 2, 1};
+    flushCounters(q, local, which, 8);
+    if (flags) atomicOr(&q.cnt[3], flags);
+}
+
+// In-text verification at 8 ... 10 errors (FMIndex::inTextVerification + InTextVerificationTask::doTask, fmindex.cpp:267-310,
+// indexhelpers.cpp:518-574, on the band of the reference's 128-bit matrix): the bit-parallel in-text matrices of this file hold bands of
+// up to 29 columns (k <= 7); a candidate without a fixed start at k = 10 has 41.  This kernel computes the SAME band cell by cell —
+// plain dynamic programming, one candidate per lane, the band's two current rows in registers, every row also written to the lane's
+// slab for the traceback.  Why the results are the reference's: a cell whose value is at most maxED has an optimal path through cells
+// of at most maxED, all inside the band, so those cells are exact here and in the bit-parallel matrix, and all other cells exceed maxED in
+// both; row validity (a cell <= maxED in the row), the cluster centres (comparisons of a value <= maxED with its neighbours) and the
+// traceback's tests along a path of cells <= maxED (horizontal: the left neighbour is one less; diagonal: the characters match, or the
+// cell differs from its diagonal neighbour: bitparallelmatrix.h:531-586) only read such comparisons.  Counters as k_verify_stage /
+// k_traceback count them.  Not a fast path: a slab row costs 48 bytes of traffic per matrix row.
+constexpr uint32_t DP_BAND = 41, DP_ROW_BYTES = 48, DP_INF = 255;
+__host__ __device__ inline uint32_t dpRows(uint32_t maxLen) { return maxLen + 3u * MX_MAX_ED + 4u; }
+__global__ void __launch_bounds__(256)
+k_verify_dp(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, const uint8_t* __restrict__ seq,
+            const uint4* __restrict__ items, uint32_t nItems, uint8_t* __restrict__ slab, uint32_t slotBytes, Queues q) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x, nSlots = gridDim.x * blockDim.x;
+    uint8_t* const Mx = slab + (size_t)slot * slotBytes;
+    uint32_t cLF = 0, cLoc = 0, cRows = 0, cAbort = 0, cCig = 0, cStarted = 0, flags = 0;
+    for (uint32_t it = slot; it < nItems; it += nSlots) {
+        const uint4 item = items[it];
+        if (item.x == 0xFFFFFFFFu) continue; // (holes of the item queue)
+        const uint32_t meta = item.w;
+        if (((meta >> 21) & 3u) != ITEM_EDIT) continue; // (exact candidates of the k = 0 phases: k_verify)
+        const uint32_t rs = item.x, maxED = (meta >> 12) & 15u, minED = (meta >> 16) & 15u, fixed = (meta >> 20) & 1u, shift = meta & 0xFFFu;
+        const uint32_t len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
+        const uint8_t* rd = seq + (size_t)rs * maxLen;
+        cLoc++;
+        const uint32_t pos = findSA(ix, item.y, &cLF);
+        const uint32_t sum = pos + shift, start = sum >= item.z ? sum - item.z : 0; // getBeginPositions (fmindex.h:374-379)
+        const uint32_t nZeros = fixed ? 1u : 2u * maxED + 1u;
+        const uint32_t Wv = nZeros - 1u + maxED, Wh = maxED, n = len + 1u;
+        const uint32_t m = max(Wv + n, Wv + Wh + 1u), sfc = Wh + Wv + 1u; // (bitparallelmatrix.cpp:87-103)
+        cStarted++;
+        const uint32_t maxEnd = ix.n - 1;
+        const uint32_t hEnd = min(maxEnd, start + m - 1);
+        const uint32_t size = hEnd > start ? hEnd - start : 0;
+        if (size < m - sfc) continue; // !inFinalColumn(size) (indexhelpers.cpp:527)
+        if (Wv + Wh + 1u > DP_BAND || (size + 1u) * DP_ROW_BYTES > slotBytes) {
+            flags |= FLAG_CAPACITY;
+            continue;
+        }
+        const uint32_t col = n - 1u;
+        // band cell d of row i is column j = i + d - Wv
+        uint32_t prev[DP_BAND], cur[DP_BAND];
+#pragma unroll
+        for (uint32_t d = 0; d < DP_BAND; d++) { // row 0: 0, 1, 2, ... up to column Wh
+            const int j = (int)d - (int)Wv;
+            prev[d] = (j >= 0 && (uint32_t)j <= Wh && (uint32_t)j <= col && d <= Wv + Wh) ? (uint32_t)j : DP_INF;
+        }
+        {
+            uint32_t w[12];
+#pragma unroll
+            for (uint32_t u = 0; u < 12; u++) w[u] = 0;
+#pragma unroll
+            for (uint32_t d = 0; d < DP_BAND; d++) w[d >> 2] |= prev[d] << (8u * (d & 3u));
+            uint4* R = reinterpret_cast<uint4*>(Mx);
+            R[0] = make_uint4(w[0], w[1], w[2], w[3]), R[1] = make_uint4(w[4], w[5], w[6], w[7]), R[2] = make_uint4(w[8], w[9], w[10], w[11]);
+        }
+        uint32_t i = 0;
+        for (uint32_t r = 1; r <= size; r++) {
+            const uint32_t tc = ix.text[start + r - 1];
+            bool valid = false;
+#pragma unroll
+            for (uint32_t d = 0; d < DP_BAND; d++) {
+                const int j = (int)r + (int)d - (int)Wv;
+                uint32_t v = DP_INF;
+                if (d <= Wv + Wh && j >= 0 && (uint32_t)j <= col) {
+                    if (j == 0) v = r < nZeros ? 0u : r - nZeros + 1u; // first column: nZeros zeros, then 1, 2, ...
+                    else {
+                        const uint32_t rc = rd[j - 1];
+                        const uint32_t diag = prev[d] + ((tc < 4u && tc + 1u == rc) ? 0u : 1u);
+                        const uint32_t up = d + 1 < DP_BAND ? prev[d + 1 < DP_BAND ? d + 1 : d] + 1u : DP_INF;
+                        const uint32_t left = d > 0 ? cur[d > 0 ? d - 1 : 0] + 1u : DP_INF;
+                        v = min(min(diag, up), min(left, 250u));
+                    }
+                }
+                cur[d] = v;
+                valid = valid || v <= maxED;
+            }
+            cRows++;
+            {
+                uint32_t w[12];
+#pragma unroll
+                for (uint32_t u = 0; u < 12; u++) w[u] = 0;
+#pragma unroll
+                for (uint32_t d = 0; d < DP_BAND; d++) w[d >> 2] |= cur[d] << (8u * (d & 3u));
+                uint4* R = reinterpret_cast<uint4*>(Mx + (size_t)r * DP_ROW_BYTES);
+                R[0] = make_uint4(w[0], w[1], w[2], w[3]), R[1] = make_uint4(w[4], w[5], w[6], w[7]), R[2] = make_uint4(w[8], w[9], w[10], w[11]);
+            }
+            if (!valid) break;
+            i = r;
+#pragma unroll
+            for (uint32_t d = 0; d < DP_BAND; d++) prev[d] = cur[d];
+        }
+        if (i <= size - sfc) { // (length_t arithmetic as in the reference, indexhelpers.cpp:542)
+            cAbort++;
+            continue;
+        }
+        auto cell = [&](uint32_t ri, uint32_t cj) -> uint32_t { // DP_INF outside the band
+            const int d = (int)cj - (int)ri + (int)Wv;
+            if (d < 0 || (uint32_t)d > Wv + Wh) return DP_INF;
+            return Mx[(size_t)ri * DP_ROW_BYTES + (uint32_t)d];
+        };
+        // findClusterCenters (bitparallelmatrix.h:591-614), then traceBack (:531-586) of every centre
+        const uint32_t firstRow = (m - 1u) - sfc;
+        uint32_t nCentres = 0;
+        for (uint32_t r = i; r > firstRow; r--) {
+            const uint32_t ED = cell(r, col);
+            if (ED > maxED || ED < minED) continue;
+            const bool betterThanAbove = r == firstRow || ED <= cell(r - 1u, col);
+            const bool betterThanBelow = r == i || ED <= cell(r + 1u, col);
+            if (!(betterThanAbove && betterThanBelow)) continue;
+            nCentres++;
+            uint32_t ti = r, tj = col;
+            while (tj > 0) {
+                const uint32_t here = cell(ti, tj), left = cell(ti, tj - 1u);
+                if (left != DP_INF && here == left + 1u) { // gap in horizontal (:553)
+                    --tj;
+                } else if (ti > 0) {
+                    const uint32_t tcode = ix.text[start + ti - 1u], rc = rd[tj - 1u];
+                    const bool match = tcode < 4u && tcode + 1u == rc;
+                    if (match || here != cell(ti - 1u, tj - 1u)) --tj; // diagonal (:559); else vertical
+                    --ti;
+                } else {
+                    flags |= FLAG_CAPACITY; // (row 0 only has horizontal steps)
+                    break;
+                }
+            }
+            cCig++;
+            const uint32_t o = atomicAdd(&q.cnt[2], 1u);
+            if (o < q.textCap) q.text[o] = TextOccRec{rs, start + ti, start + r, ED};
+            else flags |= FLAG_TEXT_OVERFLOW;
+        }
+        if (nCentres == 0) cAbort++; // indexhelpers.cpp:550
+    }
+    const uint32_t local[8] = {cLF, cLoc, cRows, cRows, cAbort, cCig, cStarted, cCig};
     const int which[8] = {8, 9, 10, 11, 3, 4, 2, 1};
     flushCounters(q, local, which, 8);
     if (flags) atomicOr(&q.cnt[3], flags);

@@ -324,10 +324,20 @@ def test_edit_distance_with_eight_to_ten_errors_in_the_index(world0, partition, 
     _compare(world0, "columba", "edit", partition, k, reads, dups_rare=False)
 
 
-def test_edit_distance_beyond_seven_errors_is_refused_up_front(world):
-    with pytest.raises(ca.CmbError) as e:   # (in-text switch point 4: the in-text matrices hold 7 errors)
-        ca.match_batch(world["dev"], ca.SearchStrategy("columba", "edit", "dynamic"), 8, [b"ACGT" * 40])
-    assert e.value.code == ca.CMB_ERR_UNSUPPORTED and "switch point 0" in str(e.value)
+@pytest.mark.parametrize("partition,k,length", [("dynamic", 8, 150), ("uniform", 9, 100), ("static", 10, 150), ("dynamic", 10, 250)])
+def test_edit_distance_with_eight_to_ten_errors(world, partition, k, length):
+    """... and on the default index (in-text switch point 4): candidates of up to 41 band columns are verified by k_verify_dp (plain
+    dynamic programming on the band of the reference's 128-bit matrix)"""
+    g = world["genome"]
+    reads = synth.sample_reads(g, 600, length, seed=300 + k, n_frac=0.01, edit_choices=(0, 3, 6, 8, k, k, k + 1))
+    reads += [b"N" * length, g[-length - 1:-1].tobytes(), g[0:length].tobytes()]
+    _compare(world, "columba", "edit", partition, k, reads, dups_rare=False)
+
+
+def test_edit_distance_beyond_ten_errors_is_refused_up_front(world):
+    with pytest.raises(ca.CmbError) as e:   # (the 128-bit in-index matrix)
+        ca.match_batch(world["dev"], ca.SearchStrategy("columba", "edit", "dynamic"), 11, [b"ACGT" * 40])
+    assert e.value.code == ca.CMB_ERR_UNSUPPORTED
     with pytest.raises(ca.CmbError):
         ca.match_batch(world["dev"], ca.SearchStrategy("columba", "hamming", "dynamic"), 14, [b"ACGT" * 40])
 
