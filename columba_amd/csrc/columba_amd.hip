@@ -2137,7 +2137,8 @@ static int verifyDirect(cmb_index* idx, const char* pattern, uint32_t plen, cons
                         uint64_t* n_out, uint64_t* counters) {
     if (!idx || !pattern || (n && !starts) || !n_out) return fail(CMB_ERR_INVALID, "null argument");
     if (plen == 0 || plen > (uint32_t)MAX_READ) return fail(CMB_ERR_UNSUPPORTED, "pattern length not supported");
-    if (3 * max_ed + 1 > MXW_LEFT || min_ed > 15) return fail(CMB_ERR_UNSUPPORTED, "needs a wider in-text matrix");
+    const bool dp = 3 * max_ed + 1 > MXW_LEFT; // beyond 7 errors: k_verify_dp (the band does not fit the bit-parallel in-text matrices)
+    if (max_ed > MX_MAX_ED || min_ed > 15) return fail(CMB_ERR_UNSUPPORTED, "more than 10 errors");
     for (uint64_t i = 0; i < n; i++)
         if (starts[i] > idx->d.n) return fail(CMB_ERR_INVALID, "start position beyond the text");
     try {
@@ -2189,7 +2190,14 @@ static int verifyDirect(cmb_index* idx, const char* pattern, uint32_t plen, cons
         hipLaunchKernelGGL(k_match_words, dim3(1), dim3(256), 0, 0, G.p, gw, offs.p, 2u, mf.nBlk, mfull.p);
         mf.p = mfull.p;
         uint32_t hc[8];
-        if (n) {
+        if (n && dp) {
+            DevBuf<uint8_t> slab;
+            const uint32_t slotBytes = (dpRows(mlen) + 1u) * DP_ROW_BYTES;
+            const uint32_t dSlots = (uint32_t)std::min<uint64_t>(((n + 255) / 256) * 256, 256u * 64u);
+            slab.alloc((size_t)slotBytes * dSlots);
+            hipLaunchKernelGGL(k_verify_dp, dim3(dSlots / 256), dim3(256), 0, 0, idx->d, offs.p, mlen, seq.p, items.p, (uint32_t)n, slab.p, slotBytes, q);
+            HIPCHK(hipDeviceSynchronize());
+        } else if (n) {
             hipLaunchKernelGGL(k_verify<false>, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, mlen, gw, seq.p, mf,
                                items.p, (uint32_t)n, tbq.p, (uint32_t)tbq.n, (unsigned long long*)nullptr, q);
             HIPCHK(hipMemcpy(hc, cnt.p, 32, hipMemcpyDeviceToHost));
@@ -2241,7 +2249,7 @@ extern "C" int cmb_cigar_windows(cmb_index* idx, const char* pattern, uint32_t p
         if (ends[i] - begins[i] > plen + distances[i]) return fail(CMB_ERR_INVALID, "text window longer than an alignment within the distance");
         maxD = std::max(maxD, distances[i]);
     }
-    if (3 * maxD + 1 > MXW_LEFT) return fail(CMB_ERR_UNSUPPORTED, "needs a wider in-text matrix");
+    if (maxD > MX_MAX_ED) return fail(CMB_ERR_UNSUPPORTED, "more than 10 errors"); // (fixed start: the band of 2 maxD + 1 columns fits the in-text matrix)
     if (stride < 2 * maxD + 3) return fail(CMB_ERR_INVALID, "stride must be at least 2 * distance + 3");
     if (n == 0) return CMB_OK;
     try {
@@ -2356,10 +2364,10 @@ static bool trimOccurrence(cmb_index* idx, const std::string& seq, uint32_t larg
     o.aln.seq_id = seqId;
     o.aln.seq_begin = bestO->begin - sp[seqId];
     o.aln.spans = 2; // found with trimming
-    uint16_t opsBuf[2 * 7 + 3];
+    uint16_t opsBuf[2 * 10 + 3];
     uint32_t nOps = 0;
     o.ops.clear();
-    if (cmb_cigar_windows(idx, seq.data(), (uint32_t)seq.size(), &o.occ.begin, &o.occ.end, &o.occ.distance, 1, opsBuf, 2 * 7 + 3,
+    if (cmb_cigar_windows(idx, seq.data(), (uint32_t)seq.size(), &o.occ.begin, &o.occ.end, &o.occ.distance, 1, opsBuf, 2 * 10 + 3,
                           &nOps) != CMB_OK)
         return false;
     o.ops.assign(opsBuf, opsBuf + nOps);

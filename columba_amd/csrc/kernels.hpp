@@ -1078,15 +1078,20 @@ k_verify_dp(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, con
         const uint32_t rs = item.x, maxED = (meta >> 12) & 15u, minED = (meta >> 16) & 15u, fixed = (meta >> 20) & 1u, shift = meta & 0xFFFu;
         const uint32_t len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
         const uint8_t* rd = seq + (size_t)rs * maxLen;
-        cLoc++;
-        const uint32_t pos = findSA(ix, item.y, &cLF);
-        const uint32_t sum = pos + shift, start = sum >= item.z ? sum - item.z : 0; // getBeginPositions (fmindex.h:374-379)
+        const bool direct = (meta >> 23) & 1u; // (hooks: item.y is the start position itself, item.z the explicit end of the window or 0)
+        uint32_t pos = item.y;
+        if (!direct) {
+            cLoc++;
+            pos = findSA(ix, item.y, &cLF);
+        }
+        const uint32_t startDiff = direct ? 0u : item.z, limitEnd = direct ? item.z : 0u;
+        const uint32_t sum = pos + shift, start = sum >= startDiff ? sum - startDiff : 0; // getBeginPositions (fmindex.h:374-379)
         const uint32_t nZeros = fixed ? 1u : 2u * maxED + 1u;
         const uint32_t Wv = nZeros - 1u + maxED, Wh = maxED, n = len + 1u;
         const uint32_t m = max(Wv + n, Wv + Wh + 1u), sfc = Wh + Wv + 1u; // (bitparallelmatrix.cpp:87-103)
         cStarted++;
         const uint32_t maxEnd = ix.n - 1;
-        const uint32_t hEnd = min(maxEnd, start + m - 1);
+        const uint32_t hEnd = limitEnd ? min(maxEnd, limitEnd) : min(maxEnd, start + m - 1); // (limitEnd: inTextVerificationOneString)
         const uint32_t size = hEnd > start ? hEnd - start : 0;
         if (size < m - sfc) continue; // !inFinalColumn(size) (indexhelpers.cpp:527)
         if (Wv + Wh + 1u > DP_BAND || (size + 1u) * DP_ROW_BYTES > slotBytes) {

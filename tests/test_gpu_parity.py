@@ -113,11 +113,12 @@ def test_kmer_table_and_locate(world):
 def test_in_text_verification_hook(world):
     g = world["genome"]
     rng = np.random.default_rng(8)
-    for trial in range(30):
-        k = int(rng.integers(1, 8))   # (k = 7 with a free start: the reference's 128-bit matrix)
+    for trial in range(60):
+        # (k = 7 with a free start: the reference's 128-bit matrix; 8 ... 10: k_verify_dp on that matrix's band)
+        k = int(rng.integers(1, 8)) if trial < 30 else int(rng.integers(8, 11))
         pos = int(rng.integers(100, len(g) - 400))
         pat = synth.sample_reads(g[pos:pos + 400], 1, int(rng.choice([50, 100, 150, 250])), seed=trial,
-                                 edit_choices=(0, 1, 2, k), rc_frac=0.0)[0]
+                                 edit_choices=(0, 1, 2, k, max(k - 1, 0)), rc_frac=0.0)[0]
         fixed = bool(trial % 2)
         starts = np.concatenate([rng.integers(0, len(g), 20), np.arange(max(0, pos - 30), pos + 60, 3),
                                  [len(g) - 5, len(g), 0]]).astype(np.uint32)
@@ -141,7 +142,7 @@ def test_production_edit_verification_path(world):
         k = int(rng.integers(1, 8))   # (k = 7 with a free start: the reference's 128-bit matrix)
         pos = int(rng.integers(100, len(g) - 400))
         pat = synth.sample_reads(g[pos:pos + 400], 1, int(rng.choice([50, 100, 150, 250])), seed=1000 + trial,
-                                 edit_choices=(0, 1, 2, k), rc_frac=0.0)[0]
+                                 edit_choices=(0, 1, 2, k, max(k - 1, 0)), rc_frac=0.0)[0]
         fixed = bool(trial % 2)
         base = np.concatenate([rng.integers(0, len(g), 20), np.arange(max(0, pos - 30), pos + 60, 3),
                                [len(g) - 5, len(g), 0]]).astype(np.uint32)
@@ -477,7 +478,7 @@ def test_errors_are_loud(world):
     assert len(occ) == 0 and offs.tolist() == [0]
 
 
-@pytest.mark.parametrize("spec,metric,k", [("multiple_opt", "edit", 4), ("columba", "edit", 6), ("kuch1", "edit", 2),
+@pytest.mark.parametrize("spec,metric,k", [("multiple_opt", "edit", 4), ("columba", "edit", 6), ("kuch1", "edit", 2), ("columba", "edit", 9),
                                            ("kuch1", "hamming", 3), ("kuch1", "edit", 0)])
 def test_alignments_cigar_and_sequence(world, oracle_built, spec, metric, k):
     """SURVEY.md §8f rank 1 on the device: the CIGAR of every final occurrence (k_cigar) is what the reference's
@@ -584,7 +585,8 @@ def test_best_mode(world, spec, metric, x, min_identity):
 
 
 @pytest.mark.parametrize("spec,metric,k,xa", [("columba", "edit", 4, False), ("multiple_opt", "edit", 2, True),
-                                              ("kuch1", "hamming", 2, False), ("kuch1", "edit", 0, False)])
+                                              ("kuch1", "hamming", 2, False), ("kuch1", "edit", 0, False),
+                                              ("columba", "edit", 9, False)])
 def test_sam_records_of_a_chunk(world, spec, metric, k, xa):
     """The SAM text of a chunk in ALL mode (cmb_batch_sam = generateOutputSingleEnd + generateSE_SAM[_XATag]) against
     the oracle's restatement: sequence names, 1-based positions, flags, mapping qualities, CIGARs, the read as it aligns
