@@ -2544,8 +2544,7 @@ extern "C" int cmb_match_best(cmb_index* idx, const cmb_strategy* st, uint32_t x
         // scheme — and, on this device, an in-text matrix (edit distance: 7, dev_matrix.hpp: MXW_*)
         uint32_t maxSupported = 0;
         while (st->schemes.count(maxSupported + 1) && !st->schemes.at(maxSupported + 1).empty()) maxSupported++;
-        if (st->metric == CMB_METRIC_EDIT) maxSupported = std::min<uint32_t>(maxSupported, (MXW_LEFT - 1) / 3);
-        maxSupported = std::min<uint32_t>(maxSupported, st->metric == CMB_METRIC_EDIT ? 7u : 13u); // (distance bits of the filter keys; MAX_K)
+        maxSupported = std::min<uint32_t>(maxSupported, st->metric == CMB_METRIC_EDIT ? MX_MAX_ED : 13u); // (edit distance: the 64-bit in-index matrix; MAX_K)
         std::unique_ptr<cmb_best> R(new cmb_best());
         memset(R->cnts, 0, sizeof(R->cnts));
         std::vector<BestRead> rd(n_reads);

@@ -539,7 +539,8 @@ def test_alignments_cigar_and_sequence(world, oracle_built, spec, metric, k):
 @pytest.mark.parametrize("spec,metric,x,min_identity", [("columba", "edit", 0, 96), ("columba", "edit", 1, 96),
                                                         ("multiple_opt", "edit", 0, 97), ("kuch1", "hamming", 0, 98),
                                                         ("minU", "edit", 2, 97), ("columba", "edit", 0, 95),
-                                                        ("columba", "hamming", 0, 91), ("columba", "hamming", 1, 90)])
+                                                        ("columba", "hamming", 0, 91), ("columba", "hamming", 1, 90),
+                                                        ("columba", "edit", 0, 93)])
 def test_best_mode(world, spec, metric, x, min_identity):
     """BEST (+x strata) mode — the reference's default (`-a best`, SearchStrategy::matchApproxBestPlusX,
     searchstrategy.cpp:623-746): per read the best distance, the number of hits at it, and the alignments of the best
@@ -560,7 +561,7 @@ def test_best_mode(world, spec, metric, x, min_identity):
     max_sup = 0
     while (max_sup + 1) in spec_tables["schemes"]:
         max_sup += 1
-    max_sup = min(max_sup, 7 if metric == "edit" else 13)   # (Hamming distance: the strata 9 and 13 of the reference's walk run too)
+    max_sup = min(max_sup, 10 if metric == "edit" else 13)   # (the device's limits: the 64-bit in-index matrix; MAX_K for Hamming distance)
     o_occ, o_sid, o_sb, o_cig, o_off, o_best, o_hits, o_cnt = op.match_best(
         world["orc"], op.OracleStrategy(spec_tables, metric, "dynamic"), reads, x=x, min_identity=min_identity,
         max_supported=max_sup, threads=8)
