@@ -1164,12 +1164,18 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                     b->keysA.alloc(need + 256), b->keysB.alloc(need + 256), b->vals.alloc(need + 256), b->valsB.alloc(need + 256);
                 }
             }
+            const int perStrand = b->perStrand ? 1 : 0;
             hipLaunchKernelGGL(k_mvs_text_keys, dim3(gridFor(totalPos)), dim3(256), 0, s, b->positions.p, b->locOff.p, nUniq, totalPos, b->locMeta.p, b->keysA.p,
-                               b->vals.p, b->bad.p, (const uint8_t*)b->psel.p, hasNaive ? 2 : 0);
+                               b->vals.p, b->bad.p, (const uint8_t*)b->psel.p, hasNaive ? 2 : 0, perStrand);
             if (nNaiveKept)
                 hipLaunchKernelGGL(k_mvs_occ_keys, dim3(gridFor(2 * nReads)), dim3(256), 0, s, b->naiveOut.p, b->naiveOff.p, 2 * nReads, b->keysA.p + totalPos,
-                                   b->vals.p + totalPos);
-            sortAndFilter(totalPos + nNaiveKept, nReads, b->out, nOut);
+                                   b->vals.p + totalPos, perStrand);
+            sortAndFilter(totalPos + nNaiveKept, perStrand ? 2 * nReads : nReads, b->out, nOut);
+            if (perStrand) { // per read again: the two strands of a read are neighbouring groups
+                if (b->rsOff.n < (size_t)2 * nReads + 1) b->rsOff.alloc((size_t)2 * nReads + 1);
+                MV_HIPCHK(hipMemcpyAsync(b->rsOff.p, b->readOff.p, ((size_t)2 * nReads + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+                hipLaunchKernelGGL(k_mvs_read_offsets, dim3(gridFor(nReads + 1)), dim3(256), 0, s, b->rsOff.p, nReads, b->readOff.p);
+            }
         }
         tm.end("filter");
         MV_HIPCHK(hipGetLastError());

@@ -1200,7 +1200,7 @@ __global__ void k_mvs_fm_compact(const MvFmRec* __restrict__ fm, const uint32_t*
 // them through k_mvs_occ_keys).  Records left out get the all-ones key, which sorts behind every group.
 __global__ void k_mvs_text_keys(const uint64_t* __restrict__ positions, const uint64_t* __restrict__ recOff, uint32_t nRecs, uint64_t total,
                                 const uint4* __restrict__ meta, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
-                                uint32_t* __restrict__ bad, const uint8_t* __restrict__ psel = nullptr, int which = 0) {
+                                uint32_t* __restrict__ bad, const uint8_t* __restrict__ psel = nullptr, int which = 0, int perStrand = 0) {
     for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < total; j += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t lo = 0, hi = nRecs; // the last record whose offset is <= j
         while (hi - lo > 1) {
@@ -1212,7 +1212,7 @@ __global__ void k_mvs_text_keys(const uint64_t* __restrict__ positions, const ui
         const uint64_t begin = positions[j] + m.w;
         if (begin >> 40 || m.x >> 24 || m.y >= (1u << 19) || m.z >= 16u) atomicAdd(bad, 1u);
         const bool naive = which != 0 && (psel[m.x] & 0x80u) != 0u;
-        const uint64_t grp = which == 1 ? m.x : m.x >> 1;
+        const uint64_t grp = (which == 1 || perStrand) ? m.x : m.x >> 1; // (perStrand: every strand filtered by itself, BEST mode's mapRead)
         const bool leftOut = (which == 1 && !naive) || (which == 2 && naive);
         keys[j] = leftOut ? ~0ull : ((grp << 40) | (begin & ((1ull << 40) - 1)));
         vals[j] = (m.z << 20) | (m.y << 1) | (m.x & 1u);
@@ -1306,13 +1306,18 @@ __global__ void k_mvs_filter(const unsigned long long* __restrict__ keys, const 
 // the survivors of the naive path's own filter pass (groups = read x strand) as keys of their READ, behind the keys of the other
 // reads: they pass the filter of the mapping mode a second time (searchstrategy.cpp:455-457)
 __global__ void k_mvs_occ_keys(const MoveOccOut* __restrict__ occ, const uint64_t* __restrict__ occOff, uint32_t nGroups,
-                               unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+                               unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, int perStrand = 0) {
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nGroups; g += gridDim.x * blockDim.x)
         for (uint64_t e = occOff[g]; e < occOff[g + 1]; e++) {
             const MoveOccOut o = occ[e];
-            keys[e] = ((uint64_t)(g >> 1) << 40) | o.begin;
+            keys[e] = ((uint64_t)(perStrand ? g : g >> 1) << 40) | o.begin;
             vals[e] = (o.distance << 20) | ((uint32_t)(o.end - o.begin) << 1) | (g & 1u);
         }
+}
+
+// offsets per read from offsets per read x strand (the per-strand filter of BEST mode: the two strands of a read are neighbours)
+__global__ void k_mvs_read_offsets(const uint64_t* __restrict__ rsOff, uint32_t nReads, uint64_t* __restrict__ readOff) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r <= nReads; r += gridDim.x * blockDim.x) readOff[r] = rsOff[2 * (size_t)r];
 }
 
 // the final occurrences as k_cigar takes them: {begin, end, distance, strand} in 32 bits (texts below 2^32) and the read of each

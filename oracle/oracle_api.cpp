@@ -413,12 +413,30 @@ struct OrcBest {
     Counters counters;
     std::string error;
 };
+extern "C++" {
+template <class M, class IX>
+static void* matchBestOn(const IX& ix, Strategy& st, uint32_t x, uint32_t minIdentity, uint32_t maxSupported, const char* seqs,
+                         const uint64_t* offs, uint32_t nReads, uint32_t nThreads);
+}
 void* orc_match_best(void* h, void* sp, uint32_t x, uint32_t minIdentity, uint32_t maxSupported, const char* seqs,
                      const uint64_t* offs, uint32_t nReads, uint32_t nThreads) {
-    Index& ix = ((OrcIndex*)h)->idx;
-    Strategy& st = *(Strategy*)sp;
+    return matchBestOn<Matcher>(((OrcIndex*)h)->idx, *(Strategy*)sp, x, minIdentity, maxSupported, seqs, offs, nReads, nThreads);
+}
+// the same on the run-length compressed flavour; the text beside the index (CIGARs, trimming: the occurrence's matched string)
+void orc_move_attach_text(void* h, uint32_t wordSize, const uint8_t* text, uint64_t n, const uint32_t* seqStarts, uint32_t nStarts) {
+    const_cast<orc::MoveIndexAdapter&>(moveAdapter(*(orc::BMoveIndex64*)h, wordSize)).attachText(text, n, seqStarts, nStarts);
+}
+void* orc_move_match_best(void* h, void* sp, uint32_t x, uint32_t minIdentity, uint32_t maxSupported, const char* seqs,
+                          const uint64_t* offs, uint32_t nReads, uint32_t nThreads, uint32_t wordSize) {
+    return matchBestOn<orc::MoveMatcher>(moveAdapter(*(orc::BMoveIndex64*)h, wordSize), *(Strategy*)sp, x, minIdentity, maxSupported, seqs, offs,
+                                         nReads, nThreads);
+}
+extern "C++" {
+template <class M, class IX>
+static void* matchBestOn(const IX& ix, Strategy& st, uint32_t x, uint32_t minIdentity, uint32_t maxSupported, const char* seqs,
+                         const uint64_t* offs, uint32_t nReads, uint32_t nThreads) {
     OrcBest* res = new OrcBest();
-    std::vector<std::vector<Matcher::BestOcc>> per(nReads);
+    std::vector<std::vector<typename M::BestOcc>> per(nReads);
     res->best.assign(nReads, 0xFFFFFFFFu);
     res->nHits.assign(nReads, 0);
     if (nThreads == 0) nThreads = 1;
@@ -426,14 +444,14 @@ void* orc_match_best(void* h, void* sp, uint32_t x, uint32_t minIdentity, uint32
     std::vector<std::string> errs(nThreads);
     std::atomic<uint32_t> next(0);
     auto work = [&](uint32_t tid) {
-        Matcher m(ix, st);
+        M m(ix, st);
         try {
             for (;;) {
                 uint32_t base = next.fetch_add(64);
                 if (base >= nReads) break;
                 uint32_t end = std::min(nReads, base + 64);
                 for (uint32_t r = base; r < end; r++) {
-                    std::string read = Matcher::cleanRead(std::string(seqs + offs[r], offs[r + 1] - offs[r]));
+                    std::string read = M::cleanRead(std::string(seqs + offs[r], offs[r + 1] - offs[r]));
                     uint32_t best = 0, nHits = 0;
                     bool found = false;
                     per[r] = m.matchApproxBestPlusX(read, x, minIdentity, maxSupported, best, nHits, found);
@@ -469,6 +487,7 @@ void* orc_match_best(void* h, void* sp, uint32_t x, uint32_t minIdentity, uint32
     for (auto& c : cnts) res->counters.add(c);
     return res;
 }
+} // extern "C++"
 const char* orc_best_error(void* r) { return ((OrcBest*)r)->error.c_str(); }
 uint64_t orc_best_size(void* r) { return ((OrcBest*)r)->occs.size(); }
 void orc_best_copy(void* r, orc_occ* occs, uint32_t* seqId, uint32_t* seqBegin, uint64_t* offs, uint32_t* best,

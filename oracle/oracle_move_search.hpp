@@ -25,6 +25,14 @@ struct MoveIndexAdapter {
     len_t wordSize = 10;
     std::vector<MovePair64> kmerTable; // populateTable, RLC flavour (BMoveIndexT::kmerTable)
     std::vector<len_t> seqStarts;
+    // the text beside the index (tests only: BEST mode's CIGARs and trimming read the occurrence's matched string from it)
+    const uint8_t* text = nullptr;
+    std::vector<uint8_t> textCopy;
+    void attachText(const uint8_t* t, uint64_t n, const uint32_t* starts, uint32_t nStarts) { // starts: as Index::seqStarts
+        textCopy.assign(t, t + n);
+        text = textCopy.data();
+        seqStarts.assign(starts, starts + nStarts);
+    }
 
     MoveIndexAdapter(const BMoveIndex64& b, len_t ws) : bm(b), textLength((len_t)b.textLength), wordSize(ws) {
         kmerTable = b.kmerTable(ws);

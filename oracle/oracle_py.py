@@ -237,7 +237,7 @@ class OracleStrategy:
 
 
 def match_best(index: "OracleIndex", strat: "OracleStrategy", reads: Sequence[bytes], x: int = 0, min_identity: int = 95,
-               max_supported: int = 6, threads: int = 1):
+               max_supported: int = 6, threads: int = 1, word_size: int = 10):
     """BEST (+x strata) mode of the oracle: (occs, seq ids, begins inside the sequence, CIGAR strings, offsets, best distance
     per read (0xFFFFFFFF: unmapped), hits at it, counters)"""
     L = lib()
@@ -252,7 +252,12 @@ def match_best(index: "OracleIndex", strat: "OracleStrategy", reads: Sequence[by
     L.orc_best_cigar.argtypes = [C.c_void_p, C.c_uint64]
     L.orc_best_free.argtypes = [C.c_void_p]
     buf, offs = pack_reads(reads)
-    r = L.orc_match_best(index.h, strat.h, x, min_identity, max_supported, _p(buf), _p(offs), len(reads), threads)
+    if isinstance(index, OracleMoveIndex):  # the RUN_LENGTH_COMPRESSION flavour (attach_text first: CIGARs, trimming)
+        L.orc_move_match_best.restype = C.c_void_p
+        L.orc_move_match_best.argtypes = L.orc_match_best.argtypes + [C.c_uint32]
+        r = L.orc_move_match_best(index.h, strat.h, x, min_identity, max_supported, _p(buf), _p(offs), len(reads), threads, word_size)
+    else:
+        r = L.orc_match_best(index.h, strat.h, x, min_identity, max_supported, _p(buf), _p(offs), len(reads), threads)
     try:
         err = L.orc_best_error(r)
         if err:
@@ -415,6 +420,14 @@ class OracleMoveIndex:
         out = np.zeros(4 ** word_size, dtype=MOVE_RANGE_DTYPE)
         lib().orc_move_kmer_table(self.h, word_size, _p(out))
         return out
+
+    def attach_text(self, text, seq_starts, word_size: int = 10):
+        """the text beside the index, for match_best (CIGARs and trimming read the matched string of an occurrence from it);
+        seq_starts as IndexArrays.seq_starts"""
+        t = np.frombuffer(text, np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, np.uint8)
+        st = np.ascontiguousarray(seq_starts, np.uint32)
+        lib().orc_move_attach_text.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]
+        lib().orc_move_attach_text(self.h, word_size, _p(t), t.shape[0], _p(st), st.shape[0])
 
     def prepare(self, word_size: int = 10):
         """build the k-mer table of the search (index loading in the reference: not part of a timed match)"""

@@ -352,41 +352,44 @@ template <class IX> class MatcherT {
     // fmindex.cpp:312-342 (+ InTextVerificationTask::doTask): one window, one zero in the first column
     void inTextVerificationOneString(len_t startPos, len_t endPos, len_t maxED, len_t minED, Occurrences& occ,
                                      const std::string& pattern) {
-        if constexpr (RLC) throw std::runtime_error("oracle: no in-text verification on the b-move index (bmove.cpp:590-596)");
-        else {
+        // RUN_LENGTH_COMPRESSION: findSeqName calls checkTrimmedMatch instead (indexinterface.cpp:722-796, :870-888) — the same matrix
+        // walk over the trimmed part of the occurrence's MATCHED STRING, which is text[startPos, endPos): the text the test attached
+        // to the adapter stands in for it (the index itself holds none, bmove.cpp:590-596); no counters in that flavour.
+        constexpr bool CNT = !RLC;
+        if constexpr (RLC)
+            if (!index.text) throw std::runtime_error("oracle: trimming on the b-move index needs the text beside it (orc_move_attach_text)");
         BitParallelED64& matrix = fullReadMatrix();
         Substring pat(pattern.data(), (len_t)pattern.size(), 0, (len_t)pattern.size(), FORWARD);
         if (!matrix.sequenceSet()) matrix.setSequence(pat);
         matrix.initializeMatrix(maxED, std::vector<uint32_t>(1, 0u));
-        counters.inc(IN_TEXT_STARTED);
+        if (CNT) counters.inc(IN_TEXT_STARTED);
         Substring ref((const char*)index.text, index.textLength, startPos, endPos);
         const len_t size = ref.size();
         if (!matrix.inFinalColumn(size)) return;
         len_t i;
         for (i = 0; i < size; ++i) {
-            counters.inc(MATRIX_ROWS);
-            counters.inc(TEXT_BYTES);
+            if (CNT) counters.inc(MATRIX_ROWS);
+            if (CNT) counters.inc(TEXT_BYTES);
             if (!matrix.computeRow(i + 1, ref.forwardAccessor(i))) break;
         }
         if (i <= size - matrix.getSizeOfFinalColumn()) {
-            counters.inc(ABORTED_IN_TEXT_VERIF);
+            if (CNT) counters.inc(ABORTED_IN_TEXT_VERIF);
             return;
         }
         std::vector<len_t> refEnds;
         matrix.findClusterCenters(i, refEnds, maxED, minED);
         if (refEnds.empty()) {
-            counters.inc(ABORTED_IN_TEXT_VERIF);
+            if (CNT) counters.inc(ABORTED_IN_TEXT_VERIF);
             return;
         }
         for (len_t refEnd : refEnds) {
             len_t bestScore = maxED + 1, bestBegin = 0;
             std::vector<std::pair<char, uint32_t>> cigar;
             matrix.traceBack(ref, refEnd, bestBegin, bestScore, &cigar);
-            counters.inc(CIGARS_IN_TEXT_VERIFICATION);
+            if (CNT) counters.inc(CIGARS_IN_TEXT_VERIFICATION);
             TextOcc t(Range(startPos + bestBegin, startPos + refEnd), bestScore, strand);
             t.cigar = cigar;
             occ.inTextOcc.emplace_back(std::move(t));
-        }
         }
     }
     // IndexInterface::generateCIGAR: findCIGAR of the occurrence's text range (bitparallelmatrix.h:460-527)
@@ -395,13 +398,14 @@ template <class IX> class MatcherT {
             t.cigar = {{'M', (uint32_t)seq.size()}};
             return;
         }
-        if constexpr (RLC) throw std::runtime_error("oracle: CIGAR from the matched string is not restated for the b-move index");
-        else {
+        // (RUN_LENGTH_COMPRESSION: the reference aligns the occurrence's matched string, indexinterface.h:966-971 — text[b, e) by
+        // construction; here read from the text the test attached to the adapter)
+        if constexpr (RLC)
+            if (!index.text) throw std::runtime_error("oracle: CIGARs on the b-move index need the text beside it (orc_move_attach_text)");
         BitParallelED64 M;
         M.setSequence(Substring(seq.data(), (len_t)seq.size(), 0, (len_t)seq.size(), FORWARD));
         Substring ref((const char*)index.text, index.textLength, t.range.b, t.range.e);
         M.findCIGAR(ref, t.distance, t.cigar);
-        }
     }
     // IndexInterface::findSeqName (indexinterface.cpp:799-899); returns 0 FOUND, 1 FOUND_WITH_TRIMMING, 2 NOT_FOUND
     int findSeqName(BestOcc& o, len_t largestStratum, const std::string& pattern) {
