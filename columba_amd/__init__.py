@@ -54,7 +54,7 @@ EXPORTS = [
     "cmb_batch_allow_unsupported", "cmb_batch_read_status", "cmb_trim_occurrence",
     "cmb_move_match_batch", "cmb_move_batch_create", "cmb_move_batch_run", "cmb_move_batch_result_size", "cmb_move_batch_results",
     "cmb_move_batch_timings", "cmb_move_batch_destroy", "cmb_move_attach_text", "cmb_move_text_index", "cmb_index_create_text_only", "cmb_sam_chunk", "cmb_move_batch_want_alignments",
-    "cmb_move_batch_alignments",
+    "cmb_move_batch_alignments", "cmb_move_batch_filter_per_strand", "cmb_move_match_best",
     "cmb_last_error", "cmb_version",
 ]
 
@@ -296,6 +296,8 @@ def lib():
         L.cmb_move_text_index.restype = vp
         L.cmb_index_create_text_only.argtypes = [vp, u64, vp, u32, i32, C.POINTER(vp)]
         L.cmb_move_batch_want_alignments.argtypes = [vp, i32]
+        L.cmb_move_batch_filter_per_strand.argtypes = [vp, i32]
+        L.cmb_move_match_best.argtypes = [vp, vp, u32, u32, u32, vp, vp, u32, C.POINTER(vp)]
         L.cmb_move_batch_alignments.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
         L.cmb_move_kmer_table.argtypes = [vp, u32, vp]
         L.cmb_move_layout_of.argtypes = [vp, C.POINTER(MoveLayout)]
@@ -744,12 +746,16 @@ def match_batch(index: Index, strategy: SearchStrategy, max_distance: int, reads
         b.close()
 
 
-def match_best(index: Index, strategy: SearchStrategy, reads: Sequence[bytes], x: int = 0, min_identity: int = 95):
+def match_best(index, strategy: SearchStrategy, reads: Sequence[bytes], x: int = 0, min_identity: int = 95, kmer_size: int = 10):
     """``SearchStrategy::matchApproxBestPlusX`` for a whole chunk (the reference's default mode): returns
-    (occurrences, alignments, CIGAR operations, per-read offsets, best distance per read, hits at that distance, counters)"""
+    (occurrences, alignments, CIGAR operations, per-read offsets, best distance per read, hits at that distance, counters).
+    ``index``: an ``Index``, or a ``MoveIndex`` with its text attached (``kmer_size``: the k-mer table of that flavour's search)"""
     buf, offs = pack_reads(reads)
     h = C.c_void_p()
-    _chk(lib().cmb_match_best(index.h, strategy.h, x, min_identity, _p(buf), _p(offs), len(reads), C.byref(h)))
+    if isinstance(index, MoveIndex):
+        _chk(lib().cmb_move_match_best(index.h, strategy.h, x, min_identity, kmer_size, _p(buf), _p(offs), len(reads), C.byref(h)))
+    else:
+        _chk(lib().cmb_match_best(index.h, strategy.h, x, min_identity, _p(buf), _p(offs), len(reads), C.byref(h)))
     try:
         n, nops = C.c_uint64(), C.c_uint64()
         _chk(lib().cmb_best_sizes(h, C.byref(n), C.byref(nops)))
@@ -960,6 +966,10 @@ class MoveBatch:
         cnt = np.zeros(len(COUNTER_NAMES), np.uint64)
         _chk(lib().cmb_move_batch_results(self.h, _p(occ), occ.shape[0], _p(offs), _p(cnt)))
         return occ[:n.value], offs, dict(zip(COUNTER_NAMES, cnt.tolist()))
+
+    def filter_per_strand(self, on: bool = True):
+        """every strand of a read filtered by itself (``mapRead``: BEST mode's strata); before run()"""
+        _chk(lib().cmb_move_batch_filter_per_strand(self.h, int(on)))
 
     def want_alignments(self, on: bool = True):
         """CIGAR and sequence of every occurrence (needs MoveIndex.attach_text)"""

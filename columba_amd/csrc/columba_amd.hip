@@ -6,6 +6,7 @@
 
 #include <chrono>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -1722,6 +1723,7 @@ static int batchRunOne(cmb_batch* b) {
 // 64 human haplotypes next to ~130 GB of tables), and the matched string of an occurrence IS text[begin, end): findCIGAR on that
 // window (k_cigar) gives the reference's CIGAR without carrying anything through the frontier.
 namespace cmb {
+const std::vector<uint32_t>& seqStartsOfIndex(const cmb_index* textIndex) { return textIndex->seqStarts; }
 // CIGAR and sequence assignment of nOcc occurrences {begin, end, distance, strand} of the reads `occRead` on a text: the k_cigar launch
 // of batchRunOne for a caller that has the pieces (device pointers throughout; aln: nOcc x 16 bytes {seqId, seqBegin, nOps, spans};
 // ops: nOcc x stride, stored end to begin as for cmb_batch_alignments).
@@ -2535,16 +2537,29 @@ struct cmb_best {
     uint64_t cnts[CMB_CNT_MAX];
 };
 
-extern "C" int cmb_match_best(cmb_index* idx, const cmb_strategy* st, uint32_t x, uint32_t min_identity, const char* seqs,
-                              const uint64_t* offs, uint32_t n_reads, cmb_best** out) {
+namespace {
+// what one stratum returns: the ALL-mode lists of a set of reads at distance k, both strands, every strand filtered by itself
+struct StratumOut {
+    std::vector<cmb_occ> oc;
+    std::vector<cmb_aln> al;
+    std::vector<uint16_t> ops;
+    std::vector<uint64_t> oo, cnt;
+};
+typedef std::function<int(const char* cat, const uint64_t* o, uint32_t n, uint32_t k, StratumOut& r)> StratumRunner;
+
+// idx: the index whose text and sequence starts serve the trimming (the FM-index itself, or the text beside a b-move index);
+// deviceCap: the largest distance the flavour's device path runs; trimCounters: the in-text counters of a trimming count
+// (FM-index flavour: inTextVerificationOneString; the b-move flavour's checkTrimmedMatch counts nothing, indexinterface.cpp:722-796)
+int matchBestWith(cmb_index* idx, const cmb_strategy* st, uint32_t deviceCap, bool trimCounters, const StratumRunner& runOn, uint32_t x,
+                  uint32_t min_identity, const char* seqs, const uint64_t* offs, uint32_t n_reads, cmb_best** out) {
     if (!idx || !st || !offs || !out || (!seqs && n_reads)) return fail(CMB_ERR_INVALID, "null argument");
     if (min_identity < 50 || min_identity > 100) return fail(CMB_ERR_INVALID, "the minimal identity lies between 50 and 100");
     try {
         // getMaxSupportedDistanceForBestMapping (searchstrategy.h:1864, :2744): the largest k such that 1..k all have a
-        // scheme — and, on this device, an in-text matrix (edit distance: 7, dev_matrix.hpp: MXW_*)
+        // scheme — and that this device runs (deviceCap)
         uint32_t maxSupported = 0;
         while (st->schemes.count(maxSupported + 1) && !st->schemes.at(maxSupported + 1).empty()) maxSupported++;
-        maxSupported = std::min<uint32_t>(maxSupported, st->metric == CMB_METRIC_EDIT ? MX_MAX_ED : 13u); // (edit distance: the 64-bit in-index matrix; MAX_K)
+        maxSupported = std::min<uint32_t>(maxSupported, deviceCap);
         std::unique_ptr<cmb_best> R(new cmb_best());
         memset(R->cnts, 0, sizeof(R->cnts));
         std::vector<BestRead> rd(n_reads);
@@ -2569,25 +2584,13 @@ extern "C" int cmb_match_best(cmb_index* idx, const cmb_strategy* st, uint32_t x
                 cat.append(seqs + offs[ids[j]], seqs + offs[ids[j] + 1]);
                 o[j + 1] = cat.size();
             }
-            cmb_batch* b = nullptr;
-            int rcode = cmb_batch_create(idx, st, k, cat.data(), o.data(), (uint32_t)ids.size(), &b);
+            StratumOut so;
+            const int rcode = runOn(cat.data(), o.data(), (uint32_t)ids.size(), k, so);
             if (rcode) return rcode;
-            struct Guard {
-                cmb_batch* b;
-                ~Guard() { cmb_batch_destroy(b); }
-            } guard{b};
-            cmb_batch_filter_per_strand(b, 1);
-            cmb_batch_want_alignments(b, 1);
-            if ((rcode = cmb_batch_run(b))) return rcode;
-            uint64_t n = 0, nOps = 0;
-            cmb_batch_result_size(b, &n);
-            std::vector<cmb_occ> oc(n ? n : 1);
-            std::vector<cmb_aln> al(n ? n : 1);
-            std::vector<uint64_t> oo(ids.size() + 1), cnt(CMB_CNT_MAX);
-            if ((rcode = cmb_batch_results(b, oc.data(), oc.size(), oo.data(), cnt.data()))) return rcode;
-            (void)cmb_batch_alignments(b, al.data(), 0, nullptr, 0, &nOps);
-            std::vector<uint16_t> ops(nOps ? nOps : 1);
-            if ((rcode = cmb_batch_alignments(b, al.data(), al.size(), ops.data(), ops.size(), &nOps))) return rcode;
+            const std::vector<cmb_occ>& oc = so.oc;
+            const std::vector<cmb_aln>& al = so.al;
+            const std::vector<uint16_t>& ops = so.ops;
+            const std::vector<uint64_t>&oo = so.oo, &cnt = so.cnt;
             for (int i = 0; i < CMB_CNT_MAX; i++) R->cnts[i] += cnt[i];
             for (size_t j = 0; j < ids.size(); j++) {
                 BestRead& r = rd[ids[j]];
@@ -2620,7 +2623,7 @@ extern "C" int cmb_match_best(cmb_index* idx, const cmb_strategy* st, uint32_t x
                     assigned.push_back(std::move(o));
                     if (l < r.best) r.best = l;
                 } else if (o.aln.spans == 1) {
-                    if (trimOccurrence(idx, s2 ? rc[i] : fw[i], cutOffTrim, st->metric, o, R->cnts) && o.occ.distance > l &&
+                    if (trimOccurrence(idx, s2 ? rc[i] : fw[i], cutOffTrim, st->metric, o, trimCounters ? R->cnts : nullptr) && o.occ.distance > l &&
                         o.occ.distance < r.ov[s2].size())
                         trimmed.push_back(std::move(o));
                 }
@@ -2750,6 +2753,73 @@ extern "C" int cmb_match_best(cmb_index* idx, const cmb_strategy* st, uint32_t x
     } catch (const std::exception& e) {
         return fail(CMB_ERR_DEVICE, e.what());
     }
+}
+} // namespace
+
+extern "C" int cmb_match_best(cmb_index* idx, const cmb_strategy* st, uint32_t x, uint32_t min_identity, const char* seqs,
+                              const uint64_t* offs, uint32_t n_reads, cmb_best** out) {
+    if (!idx || !st) return fail(CMB_ERR_INVALID, "null argument");
+    const StratumRunner run = [&](const char* cat, const uint64_t* o, uint32_t n, uint32_t k, StratumOut& r) -> int {
+        cmb_batch* b = nullptr;
+        int rcode = cmb_batch_create(idx, st, k, cat, o, n, &b);
+        if (rcode) return rcode;
+        struct Guard {
+            cmb_batch* b;
+            ~Guard() { cmb_batch_destroy(b); }
+        } guard{b};
+        cmb_batch_filter_per_strand(b, 1);
+        cmb_batch_want_alignments(b, 1);
+        if ((rcode = cmb_batch_run(b))) return rcode;
+        uint64_t nOcc = 0, nOps = 0;
+        cmb_batch_result_size(b, &nOcc);
+        r.oc.resize(nOcc ? nOcc : 1);
+        r.al.resize(nOcc ? nOcc : 1);
+        r.oo.resize((size_t)n + 1);
+        r.cnt.assign(CMB_CNT_MAX, 0);
+        if ((rcode = cmb_batch_results(b, r.oc.data(), r.oc.size(), r.oo.data(), r.cnt.data()))) return rcode;
+        (void)cmb_batch_alignments(b, r.al.data(), 0, nullptr, 0, &nOps);
+        r.ops.resize(nOps ? nOps : 1);
+        return cmb_batch_alignments(b, r.al.data(), r.al.size(), r.ops.data(), r.ops.size(), &nOps);
+    };
+    // (edit distance: the 64-bit in-index matrix; Hamming distance: MAX_K)
+    return matchBestWith(idx, st, st->metric == CMB_METRIC_EDIT ? MX_MAX_ED : 13u, true, run, x, min_identity, seqs, offs, n_reads, out);
+}
+// The same on the b-move index (the reference's RUN_LENGTH_COMPRESSION build runs the same matchApproxBestPlusX): the strata are
+// b-move batches, CIGARs and trimming read the matched string of an occurrence from the text beside the index (cmb_move_attach_text).
+extern "C" int cmb_move_match_best(cmb_move_index* idx, const cmb_strategy* st, uint32_t x, uint32_t min_identity, uint32_t kmer_size,
+                                   const char* seqs, const uint64_t* offs, uint32_t n_reads, cmb_best** out) {
+    if (!idx || !st) return fail(CMB_ERR_INVALID, "null argument");
+    cmb_index* text = cmb_move_text_index(idx);
+    if (!text) return fail(CMB_ERR_INVALID, "BEST mode on the b-move index needs the text beside it (cmb_move_attach_text)");
+    const StratumRunner run = [&](const char* cat, const uint64_t* o, uint32_t n, uint32_t k, StratumOut& r) -> int {
+        cmb_move_batch* b = nullptr;
+        int rcode = cmb_move_batch_create(idx, st, k, kmer_size, cat, o, n, &b);
+        if (rcode) return rcode;
+        struct Guard {
+            cmb_move_batch* b;
+            ~Guard() { cmb_move_batch_destroy(b); }
+        } guard{b};
+        cmb_move_batch_filter_per_strand(b, 1);
+        if ((rcode = cmb_move_batch_want_alignments(b, 1))) return rcode;
+        if ((rcode = cmb_move_batch_run(b))) return rcode;
+        uint64_t nOcc = 0, nOps = 0;
+        cmb_move_batch_result_size(b, &nOcc);
+        std::vector<cmb_move_occ> mo(nOcc ? nOcc : 1);
+        r.al.resize(nOcc ? nOcc : 1);
+        r.oo.resize((size_t)n + 1);
+        r.cnt.assign(CMB_CNT_MAX, 0);
+        if ((rcode = cmb_move_batch_results(b, mo.data(), mo.size(), r.oo.data(), r.cnt.data()))) return rcode;
+        r.oc.resize(nOcc ? nOcc : 1);
+        for (uint64_t i = 0; i < nOcc; i++) {
+            r.oc[i].begin = (uint32_t)mo[i].begin, r.oc[i].end = (uint32_t)mo[i].end; // (texts below 2^32: cmb_move_attach_text)
+            r.oc[i].distance = mo[i].distance, r.oc[i].strand = mo[i].strand;
+        }
+        (void)cmb_move_batch_alignments(b, r.al.data(), 0, nullptr, 0, &nOps);
+        r.ops.resize(nOps ? nOps : 1);
+        return cmb_move_batch_alignments(b, r.al.data(), r.al.size(), r.ops.data(), r.ops.size(), &nOps);
+    };
+    // (the b-move search runs on the tables of 8 parts and the narrow records: up to 7 errors)
+    return matchBestWith(text, st, 7u, false, run, x, min_identity, seqs, offs, n_reads, out);
 }
 extern "C" int cmb_best_sizes(const cmb_best* r, uint64_t* n_occ, uint64_t* n_ops) {
     if (!r) return fail(CMB_ERR_INVALID, "null argument");

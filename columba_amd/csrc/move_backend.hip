@@ -91,6 +91,7 @@ namespace cmb { // (columba_amd.hip: the text kernels and k_cigar live in that t
 int moveCigarsOnText(cmb_index* textIndex, hipStream_t s, const uint64_t* offs, const uint32_t* G, uint32_t gw, uint32_t nReads, uint32_t maxLen,
                      uint32_t k, int gapless, const void* occs, const uint32_t* occRead, uint64_t nOcc, void* aln, uint16_t* ops, uint32_t stride,
                      uint32_t* flagWord);
+const std::vector<uint32_t>& seqStartsOfIndex(const cmb_index* textIndex);
 } // namespace cmb
 
 struct cmb_move_index {
@@ -659,6 +660,9 @@ struct cmb_move_batch {
     size_t nvQCap = 0;
     MvBuf<MoveOccOut> naiveOut;
     MvBuf<uint64_t> naiveOff;
+    // BEST mode's strata (cmb_move_match_best): every strand of a read filtered by itself, as mapRead does (searchstrategy.h:490-523)
+    bool perStrand = false;
+    MvBuf<uint64_t> rsOff;
     // alignments of the final occurrences (cmb_move_batch_want_alignments; needs cmb_move_attach_text)
     bool wantAln = false;
     uint32_t alnStride = 0;
@@ -816,6 +820,21 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
             if (rc != CMB_OK) return rc;
             tmp.resize(nOcc);
             b->occs.swap(tmp);
+            if (b->wantAln) { // an exact match aligns as <length>M; its sequence by position (findSeqName, indexinterface.cpp:799-832)
+                const std::vector<uint32_t>& sp = cmb::seqStartsOfIndex(ix->textIndex);
+                b->hAlnRec.resize(nOcc);
+                b->hAlnOps.assign((size_t)nOcc * b->alnStride, 0);
+                for (uint64_t i = 0; i < nOcc; i++) {
+                    const cmb_move_occ& o = b->occs[i];
+                    if (sp.size() < 2) { // one sequence
+                        b->hAlnRec[i] = make_uint4(0u, (uint32_t)o.begin, 1u, 0u);
+                    } else {
+                        const uint32_t id = (uint32_t)(std::upper_bound(sp.begin(), sp.end() - 1, (uint32_t)o.begin) - sp.begin()) - 1;
+                        b->hAlnRec[i] = make_uint4(id, (uint32_t)o.begin - sp[id], 1u, o.end > sp[id + 1] ? 1u : 0u);
+                    }
+                    b->hAlnOps[i * b->alnStride] = (uint16_t)(((o.end - o.begin) << 2) | 0u);
+                }
+            }
             b->cnts[CMB_CNT_NODE] = c2[0];
             b->cnts[CMB_CNT_EXPANSIONS] = g_exactExpansions;
             b->cnts[CMB_CNT_TOTAL_REPORTED] = c2[1];
@@ -1240,6 +1259,11 @@ extern "C" int cmb_move_batch_results(const cmb_move_batch* b, cmb_move_occ* out
     if (out && !b->occs.empty()) memcpy(out, b->occs.data(), b->occs.size() * sizeof(cmb_move_occ));
     if (out_offs) memcpy(out_offs, b->occOffs.data(), b->occOffs.size() * sizeof(uint64_t));
     if (counters) memcpy(counters, b->cnts, sizeof(b->cnts));
+    return CMB_OK;
+}
+extern "C" int cmb_move_batch_filter_per_strand(cmb_move_batch* b, int on) {
+    if (!b) return failWith(CMB_ERR_INVALID, "null argument");
+    b->perStrand = on != 0;
     return CMB_OK;
 }
 extern "C" int cmb_move_batch_want_alignments(cmb_move_batch* b, int on) {

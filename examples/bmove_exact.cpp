@@ -1,7 +1,7 @@
 // Exact matching of a chunk of reads on the run-length compressed (b-move) index through the C++ adapter — the k = 0 branch of
 // SearchStrategy::matchApproxAllMap (reference src/searchstrategy.cpp:499-510) — followed by a walk that exercises the
 // extension and locate calls with the reference's method names.
-//   usage: bmove_exact <index base> <reads file: one sequence per line> [k [strategy [k-mer size]]]
+//   usage: bmove_exact <index base> <reads file: one sequence per line> [k [strategy [k-mer size [text file [best <x> <identity>]]]]]
 // with k > 0: the approximate search of SearchStrategy::matchApproxAllMap (searchstrategy.cpp:495-535, RLC flavour) instead
 // prints:  <read#> <begin> <end> <distance> <strand>      (stdout)
 //          nodes <NODE_COUNTER>; walk <depth> <width> <positions found>   (stderr)
@@ -33,6 +33,12 @@ int main(int argc, char** argv) {
             SearchStrategy strategy(index, argv[4], CMB_PARTITION_DYNAMIC, CMB_METRIC_EDIT, atoi(argv[5]));
             std::vector<std::string> ids, quals;
             for (size_t i = 0; i < chunk.size(); i++) ids.push_back("r" + std::to_string(i)), quals.push_back(std::string(chunk[i].size(), 'I'));
+            if (argc > 9 && std::string(argv[7]) == "best") { // ... best <x> <min identity>: BEST (+x strata) mode, the reference's default
+                size_t nMapped = 0;
+                std::cout << strategy.samOfChunkBest(ids, chunk, quals, {"seq0"}, (uint32_t)atoi(argv[8]), (uint32_t)atoi(argv[9]), true, false, nMapped);
+                std::cerr << "mapped " << nMapped << "\n";
+                return 0;
+            }
             std::cout << strategy.samOfChunk(ids, chunk, quals, {"seq0"}, (length_t)k);
             return 0;
         }

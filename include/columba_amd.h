@@ -562,6 +562,17 @@ int cmb_move_attach_text(cmb_move_index* idx, const char* text, uint64_t n, cons
 cmb_index* cmb_move_text_index(const cmb_move_index* idx); /* the text-only index behind it (owned by idx), or NULL */
 int cmb_move_batch_want_alignments(cmb_move_batch* b, int on);
 int cmb_move_batch_alignments(const cmb_move_batch* b, cmb_aln* out, uint64_t cap, uint16_t* cigar_ops, uint64_t ops_cap, uint64_t* n_ops);
+/* as cmb_batch_filter_per_strand: the redundancy filter takes every strand of a read by itself (what SearchStrategy::mapRead returns,
+ * src/searchstrategy.h:490-523); a read's occurrences are then those of its forward strand followed by those of the other one */
+int cmb_move_batch_filter_per_strand(cmb_move_batch* b, int on);
+/* BEST (+x strata) mode on the b-move index: cmb_match_best with b-move batches as strata — the reference's RUN_LENGTH_COMPRESSION build
+ * runs the same SearchStrategy::matchApproxBestPlusX (src/searchstrategy.cpp:623-746).  Needs cmb_move_attach_text: CIGARs
+ * (IndexInterface::generateCIGAR on the matched string, src/indexinterface.h:959-989) and the trimming of occurrences that run over a
+ * sequence end (checkTrimmedMatch, src/indexinterface.cpp:722-796, which walks the trimmed part of the matched string — no counters)
+ * read text[begin, end).  Cut-off: min(13, what the strategy has schemes for, 7 — the b-move search runs up to 7 errors —,
+ * len * (100 - min_identity) / 100).  Results through cmb_best_sizes / cmb_best_results / cmb_best_free. */
+int cmb_move_match_best(cmb_move_index* idx, const cmb_strategy* st, uint32_t x, uint32_t min_identity, uint32_t kmer_size,
+                        const char* seqs, const uint64_t* offs, uint32_t n_reads, cmb_best** out);
 /* device time (ms, HIP events) of the calling thread's last cmb_move_match_exact: [0] the backward extension of all reads,
  * [1] the prefix sum of the widths, [2] locate + occurrence records */
 int cmb_move_last_timings(float* ms, uint32_t n);

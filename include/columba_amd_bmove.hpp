@@ -24,6 +24,7 @@
 // Errors are std::runtime_error with the reference's texts where it has them ("Cannot open file: ...").
 #pragma once
 #include "columba_amd.h"
+#include "columba_amd_best.hpp"
 
 #include <cstdint>
 #include <fstream>
@@ -274,6 +275,22 @@ class SearchStrategy {
                             occOff.data(), aln.data(), ops.data(), unmappedRecords, xaTag, &out[0], out.size());
         out.resize((size_t)len);
         return out;
+    }
+    // The SAM records of a chunk in BEST (+x strata) mode — the reference's default, `-a best` (matchApproxBestPlusX,
+    // searchstrategy.cpp:714-746, + generateSE_SAM): cmb_move_match_best.  Needs BMove::attachText.
+    struct BestRecord {
+        std::string seqID, qual;
+    };
+    std::string samOfChunkBest(const std::vector<std::string>& ids, const std::vector<std::string>& reads, const std::vector<std::string>& quals,
+                               const std::vector<std::string>& seqNames, uint32_t x, uint32_t minIdentity, bool unmappedRecords, bool xaTag,
+                               size_t& nMapped) {
+        std::string buf;
+        std::vector<uint64_t> off(reads.size() + 1, 0);
+        std::vector<BestRecord> recs(reads.size());
+        for (size_t i = 0; i < reads.size(); i++) buf += reads[i], off[i + 1] = buf.size(), recs[i] = BestRecord{ids[i], quals[i]};
+        cmb_best* r = nullptr;
+        check(cmb_move_match_best(index.handle(), h, x, minIdentity, kmerSize, buf.data(), off.data(), (uint32_t)reads.size(), &r));
+        return samOfBest(r, buf, off, recs, seqNames, unmappedRecords, xaTag, nMapped);
     }
     // matches[i] = the occurrences of reads[i] as filterPtr leaves them (searchstrategy.cpp:529); counters[CMB_CNT_*]
     void matchApproxBatch(const std::vector<std::string>& reads, length_t maxED, std::vector<uint64_t>& counters,

@@ -206,6 +206,22 @@ def test_bmove_adapter_example_matches_python_binding(tmp_path):
     mb.run()
     sam = mb.sam([f"r{i}" for i in range(len(areads))], ["I" * len(x) for x in areads], ["seq0"])
     assert r.stdout == sam and sam.count("\n") >= len(areads) and "\t100M\t" in sam
+    # BEST mode through the adapter (rlc::SearchStrategy::samOfChunkBest = cmb_move_match_best + the record builders): one primary
+    # record per read carrying the binding's best alignment
+    r = subprocess.run([exe, str(tmp_path / "idx"), str(tmp_path / "areads.txt"), "3", "columba", "6", str(tmp_path / "text.txt"), "best", "0", "96"],
+                       capture_output=True, text=True, check=True)
+    b_occ, b_aln, b_ops, b_off, b_best, b_hits, _ = ca.match_best(dev, ca.SearchStrategy("columba", "edit", "dynamic"), areads, x=0,
+                                                                  min_identity=96, kmer_size=6)
+    prim = [f.split("\t") for f in r.stdout.splitlines() if not int(f.split("\t")[1]) & 256]
+    assert len(prim) == len(areads) and r.stderr.split("\n")[0] == f"mapped {int((b_best != 0xFFFFFFFF).sum())}"
+    for i, f in enumerate(prim):
+        if b_best[i] == 0xFFFFFFFF:
+            assert f[1] == "4"
+        else:
+            a = b_aln[int(b_off[i])]
+            cig = ca.cigar_string(b_ops[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])])
+            assert (f[2], int(f[3]), f[5], f[11]) == ("seq0", int(a["seq_begin"]) + 1, cig, f"AS:i:{int(b_best[i])}")
+    assert (b_best != 0xFFFFFFFF).sum() > 100
 
 
 @pytest.mark.gpu

@@ -269,3 +269,49 @@ def test_bmove_pool_growth(sworld):
     finally:
         del os.environ["CMB_TEST_SMALL_POOLS"]
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+
+@pytest.mark.parametrize("spec,metric,x,min_identity", [("columba", "edit", 0, 96), ("columba", "edit", 1, 96), ("multiple_opt", "edit", 0, 97),
+                                                        ("kuch1", "hamming", 0, 98), ("minU", "edit", 2, 97), ("columba", "hamming", 1, 96)])
+def test_bmove_best_mode(sworld, spec, metric, x, min_identity):
+    """BEST (+x strata) mode on the b-move index (cmb_move_match_best: matchApproxBestPlusX with b-move batches as strata, every
+    strand filtered by itself; CIGARs and trimming from the text beside the index) against the oracle's restatement of the
+    RUN_LENGTH_COMPRESSION flavour: best distance and hits per read, alignments in the reference's order, sequences, CIGARs, counters."""
+    import schemes_py as sp
+    ca, op = sworld["ca"], sworld["op"]
+    g = sworld["g"]
+    starts = np.array([0, 250_000, 640_000, len(g)], dtype=np.uint32)
+    sworld["dev"].attach_text(sworld["text"], starts)
+    sworld["orc"].attach_text(sworld["text"], starts, word_size=8)
+    reads = synth.sample_reads(g, 1200, 150, seed=300 + x, n_frac=0.01, edit_choices=(0, 0, 1, 2, 3, 5, 6, 9))
+    for s0 in (250_000, 640_000):   # reads across sequence ends: trimmed or dropped (findSeqName)
+        reads += [g[s0 - 75:s0 + 75].tobytes(), g[s0 - 3:s0 + 147].tobytes(), g[s0 - 147:s0 + 3].tobytes(), g[s0 - 5:s0 + 145].tobytes()]
+    reads += [b"ACGT" * 37 + b"AC", b"N" * 150, g[:150].tobytes(), g[-150:].tobytes()]
+    tab = sp.BY_NAME[spec]
+    max_sup = 0
+    while (max_sup + 1) in tab["schemes"]:
+        max_sup += 1
+    max_sup = min(max_sup, 7)   # (the b-move search runs up to 7 errors)
+    o_occ, o_sid, o_sb, o_cig, o_off, o_best, o_hits, o_cnt = op.match_best(
+        sworld["orc"], op.OracleStrategy(tab, metric, "dynamic"), reads, x=x, min_identity=min_identity, max_supported=max_sup, threads=8,
+        word_size=8)
+    d_occ, d_aln, d_ops, d_off, d_best, d_hits, d_cnt = ca.match_best(
+        sworld["dev"], ca.SearchStrategy(spec, metric, "dynamic"), reads, x=x, min_identity=min_identity, kmer_size=8)
+    assert np.array_equal(o_best, d_best)
+    assert (o_best != 0xFFFFFFFF).sum() > 150 and (o_best == 0xFFFFFFFF).sum() > 0
+    assert np.array_equal(o_hits, d_hits) and np.array_equal(o_off, d_off)
+    for f in ("begin", "end", "distance"):
+        assert np.array_equal(o_occ[f], d_occ[f]), f
+    same = o_occ["strand"] == d_occ["strand"]
+    assert (~same).sum() <= max(1, len(d_occ) // 500)   # (the strand label of an occurrence found on both strands)
+    assert np.array_equal(o_sid, d_aln["seq_id"]) and np.array_equal(o_sb, d_aln["seq_begin"])
+    for j in range(len(d_occ)):
+        a = d_aln[j]
+        got = ca.cigar_string(d_ops[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])])
+        assert not same[j] or got == o_cig[j], (j, d_occ[j], got, o_cig[j])
+    for n in ("NODE_COUNTER", "SEARCH_STARTED", "EXPANSIONS"):
+        assert o_cnt[n] == d_cnt[n], (n, o_cnt[n], d_cnt[n])
+    for n in ("IN_TEXT_STARTED", "IMMEDIATE_SWITCH", "ABORTED_IN_TEXT_VERIF"):
+        assert d_cnt[n] == 0, n
+    if (spec, metric, x) == ("columba", "edit", 0):   # the reads 3 and 5 characters over a sequence end are found with trimming
+        assert d_best[1205] <= 3 and d_best[1207] <= 5 and int(d_aln[int(d_off[1205])]["seq_begin"]) == 0

@@ -93,3 +93,39 @@ def test_bmove_search_equals_fm_search_without_in_text_verification(world, gt, s
     if k in (2, 3) and length <= 100:
         hits, chain = check_completeness(gt, world["text"], reads[:25], m_occ, m_off, k, metric)
         assert hits > 10 and chain * 20 <= hits
+
+
+@pytest.mark.parametrize("spec,metric,x,min_identity", [("columba", "edit", 0, 96), ("columba", "edit", 1, 95), ("kuch1", "hamming", 0, 97),
+                                                        ("minU", "edit", 2, 97)])
+def test_bmove_best_mode_equals_fm_best_mode_without_in_text_verification(world, spec, metric, x, min_identity):
+    """BEST (+x strata) mode is ONE function over both flavours (matchApproxBestPlusX, searchstrategy.cpp:623-746); what differs
+    below it is where the CIGAR's reference string comes from (the matched string instead of the text, indexinterface.h:966-971) and
+    how an occurrence over a sequence end is trimmed (checkTrimmedMatch on the matched string, indexinterface.cpp:722-796, instead
+    of inTextVerificationOneString) — both read text[begin, end): same alignments, sequences, CIGARs, best distances and hit counts
+    as the FM-index restatement with switch point 0 on the same text."""
+    import schemes_py as sp
+    op = world["op"]
+    g = world["g"]
+    n = len(world["text"])
+    starts = np.array([0, 30_000, 71_000, 100_000, n], dtype=np.int64)
+    ix = ib.build_index(world["text"], seq_starts=starts, device="cpu")
+    fm = op.OracleIndex(ix, switch_point=0, kmer_size=6)
+    world["move"].attach_text(world["text"], np.asarray(ix.seq_starts, dtype=np.uint32), word_size=6)
+    reads = synth.sample_reads(g, 300, 120, seed=70 + x, n_frac=0.02, edit_choices=(0, 0, 1, 2, 3, 5, 8))
+    for s in starts[1:-1]:   # reads across sequence ends: trimmed or dropped
+        reads += [g[int(s) - 60:int(s) + 60].tobytes(), g[int(s) - 3:int(s) + 117].tobytes(), g[int(s) - 117:int(s) + 3].tobytes()]
+    reads += [b"ACGT" * 30, b"N" * 120]
+    tab = sp.BY_NAME[spec]
+    st = op.OracleStrategy(tab, metric, "dynamic")
+    a = op.match_best(world["move"], st, reads, x=x, min_identity=min_identity, max_supported=7, threads=4, word_size=6)
+    b = op.match_best(fm, st, reads, x=x, min_identity=min_identity, max_supported=7, threads=4)
+    assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6]) and np.array_equal(a[4], b[4])
+    assert (a[5] != 0xFFFFFFFF).sum() > 150 and (a[5] == 0xFFFFFFFF).sum() > 0
+    for f in ("begin", "end", "distance"):
+        assert np.array_equal(a[0][f], b[0][f]), f
+    assert (a[0]["strand"] != b[0]["strand"]).sum() <= 2   # (palindromic hits: the strand label of a tie)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    same = a[0]["strand"] == b[0]["strand"]
+    assert all(ca == cb for ca, cb, s2 in zip(a[3], b[3], same) if s2)
+    for c in ("NODE_COUNTER", "EXPANSIONS", "SEARCH_STARTED"):
+        assert a[7][c] == b[7][c], c
