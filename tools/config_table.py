@@ -25,7 +25,11 @@ for name, spec, metric, part, k, n_reads, length in (
         ("configs[1]: k = 2 Hamming, kuch_k+1, 150 bp", "kuch1", "hamming", "dynamic", 2, 1_000_000, 150),
         ("configs[2] (the bench line): k = 4 edit, multiple_opt, 150 bp", "multiple_opt", "edit", "dynamic", 4, 10_000_000, 150),
         ("configs[4]'s reads on the FM-index: k = 6 edit, multiple_opt, 250 bp", "multiple_opt", "edit", "dynamic", 6, 2_000_000, 250),
-        ("k = 7 edit, columba strategy, 150 bp", "columba", "edit", "dynamic", 7, 1_000_000, 150)):
+        ("k = 7 edit, columba strategy, 150 bp", "columba", "edit", "dynamic", 7, 1_000_000, 150),
+        # new in round 3: the greedy schemes beyond 7 errors (wide device tables; in-text verification by k_verify_dp), long reads
+        ("k = 9 edit, columba strategy (greedy scheme, k_verify_dp), 150 bp", "columba", "edit", "dynamic", 9, 100_000, 150),
+        ("k = 12 Hamming, columba strategy (greedy scheme), 150 bp", "columba", "hamming", "dynamic", 12, 200_000, 150),
+        ("k = 4 edit, multiple_opt, 400 bp", "multiple_opt", "edit", "dynamic", 4, 2_000_000, 400)):
     buf, offs = synth.sample_reads_fast(ix.text[:-1], n_reads, length, seed=3, device="cuda")
     torch.cuda.empty_cache()
     b = ca.Batch(dev, ca.SearchStrategy(spec, metric, part), k, packed=(buf, offs))
