@@ -10,6 +10,22 @@ import torch
 
 from . import indexbuild as ib
 
+import os
+
+# bytes per collective: arrays of several GB (a 3 Gbp index holds 3 - 6 GB ones) go in pieces (CMB_BCAST_CHUNK: the tests' small pieces)
+BCAST_CHUNK = 1 << 30
+
+
+def broadcast_flat(t: "torch.Tensor", src: int = 0) -> None:
+    """broadcast a flat uint8 tensor in pieces of at most BCAST_CHUNK bytes — element counts stay far below 2^31 whatever the
+    backend's count type, and the pieces pipeline over the links"""
+    import torch.distributed as dist
+    n = int(t.numel())
+    chunk = int(os.environ.get("CMB_BCAST_CHUNK", BCAST_CHUNK))
+    for o in range(0, n, chunk):
+        dist.broadcast(t[o:o + chunk], src=src)
+
+
 INDEX_FIELDS = ["text", "counts", "bv_fwd", "cnt_fwd", "bv_rev", "cnt_rev", "bwt_words", "sa_bv",
                 "sa_bv_counts", "sa_samples", "seq_starts"]
 
@@ -33,7 +49,7 @@ def broadcast_index(ix: Optional[ib.IndexArrays], rank: int, dev) -> ib.IndexArr
         else:
             t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         if nbytes:  # (an absent array, e.g. the BWT words the device does not need, has no elements)
-            dist.broadcast(t, src=0)
+            broadcast_flat(t, src=0)
         arrays[f] = getattr(ix, f) if rank == 0 else t.cpu().numpy().view(dt).reshape(shape)
         del t
     if rank == 0:
@@ -64,7 +80,7 @@ def broadcast_device_index(index, rank: int, device: int = 0):
         index = Index.empty_like(lay, starts, device)
     for t in index.device_tensors():
         if t is not None:
-            dist.broadcast(t, src=0)
+            broadcast_flat(t, src=0)
     # every replica runs the consistency probe of cmb_index_create on what arrived (a truncated or mixed-up transfer would
     # otherwise hang the first locate) — and all ranks learn the outcome before any of them enters the next collective
     err = ""
@@ -105,7 +121,7 @@ def broadcast_move_arrays(mv, rank: int, dev):
         else:
             t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         if nbytes:
-            dist.broadcast(t, src=0)
+            broadcast_flat(t, src=0)
         arrays[f] = getattr(mv, f) if rank == 0 else t.cpu().numpy().view(dt).reshape(shape)
         del t
     return mv if rank == 0 else MoveArrays(n=m["n"], **arrays)
@@ -126,7 +142,7 @@ def broadcast_device_move_index(index, rank: int, device: int = 0):
         index = MoveIndex.empty_like(MoveLayout.from_buffer_copy(meta[0]), device)
     for t in index.device_tensors():
         if t is not None:
-            dist.broadcast(t, src=0)
+            broadcast_flat(t, src=0)
     if rank != 0:
         index.validate()
     return index

@@ -23,6 +23,7 @@ def _worker(rank, world, port, tmp):
     import schemes_py as sp
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["CMB_BCAST_CHUNK"] = "65536"   # (arrays travel in pieces: columba_amd.dist.broadcast_flat)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     R, L = 150, 100
     ix = None
@@ -102,6 +103,7 @@ def _move_worker(rank, world, port, tmp):
     import oracle_py as op
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["CMB_BCAST_CHUNK"] = "65536"   # (arrays travel in pieces: columba_amd.dist.broadcast_flat)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rng = np.random.default_rng(9)
     text = np.frombuffer(b"ACGT", dtype=np.uint8)[np.tile(rng.integers(0, 4, 700), 6)]

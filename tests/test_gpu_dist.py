@@ -22,6 +22,7 @@ def _worker(rank, world, port, tmp):
     from columba_amd.dist import allreduce_counters, broadcast_device_index
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["CMB_BCAST_CHUNK"] = str(1 << 20)   # (the device arrays travel in pieces: columba_amd.dist.broadcast_flat)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g, starts = synth.genome_rep(seed=21, n=400_000, scale=2.0)   # (same seed on both ranks: only rank 0 indexes it)
