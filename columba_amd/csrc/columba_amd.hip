@@ -595,7 +595,8 @@ struct cmb_batch {
     DevBuf<DfsTask> dfs;
     DevBuf<uint64_t> vW; // packed trace rows [row][slot]
     DevBuf<uint4> tbq;
-    DevBuf<uint8_t> dpSlab; // k_verify_dp: the band rows of one candidate per slot
+    DevBuf<uint8_t> dpSlab; // k_verify_wide: the band rows of one candidate per slot
+    DevBuf<uint32_t> dpList, dpWork; // k_wide_filter: the keys that go on to k_verify_wide; [0] next key, [1] number of those
     DevBuf<uint4> items;
     DevBuf<FMOccRec> fm, fmUniq;
     DevBuf<TextOccRec> text;
@@ -742,7 +743,7 @@ static int batchCreateOne(cmb_index* idx, const cmb_strategy* st, uint32_t max_d
             // in-text verification: nZeros + maxED = 3k+1 must fit the first column of the in-text matrix (the reference
             // switches to its 128-bit matrix at k = 7, fmindex.h:240-246; here: 64-bit words / 16-row blocks, LEFT = 22)
             // edit distance beyond 7 errors: the in-index search runs up to 10 (the 64-bit in-index matrix, bitparallelmatrix.h:309-316; wide
-            // record geometry GeoW); the bit-parallel in-text matrices stop at 7, candidates are verified by k_verify_dp
+            // record geometry GeoW); the bit-parallel in-text matrices stop at 7, candidates are verified by k_verify_wide
             b->wideEdit = st->metric == CMB_METRIC_EDIT && 3 * max_distance + 1 > MXW_LEFT;
             if (b->wideEdit && max_distance > MX_MAX_ED)
                 return fail(CMB_ERR_UNSUPPORTED, "edit distance beyond 10 errors needs the 128-bit in-index matrix, which is not implemented");
@@ -1368,7 +1369,9 @@ static int batchRunOne(cmb_batch* b) {
                 // one read seeding the same alignment) are performed once: k_verify only locates and emits a key per
                 // candidate, the keys are sorted and run-length encoded, k_verify_edit verifies the distinct ones and
                 // scales the counters by the multiplicities.
-                const bool dedup = b->metric == CMB_METRIC_EDIT && b->k > 0 && b->k <= 7 && 2ull * nReads < (1ull << 25); // 25 key bits for read x strand
+                // (25 key bits for read x strand; 21 in the key layout of batches at 8 ... 10 errors, whose sub-batches hold at most 2^20 reads)
+                const bool dedup = b->metric == CMB_METRIC_EDIT && b->k > 0 && 2ull * nReads < (b->wideEdit ? (1ull << 21) : (1ull << 25));
+                if (b->wideEdit && !dedup) return fail(CMB_ERR_INTERNAL, "a sub-batch at 8 ... 10 errors holds more reads than its verification keys number");
                 const uint32_t tbCap = (uint32_t)std::min<size_t>(b->tbq.n, 0xFFFFFFF0u);
                 const char* vGroup = "k_verify";
                 tm.begin();
@@ -1381,14 +1384,7 @@ static int batchRunOne(cmb_batch* b) {
                 auto kv = dedup ? k_verify<true> : k_verify<false>;
                 hipLaunchKernelGGL(kv, dim3(vSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->maxLen, b->gw,
                                    b->seq.p, mf, b->items.p, nItems, b->tbq.p, tbCap,
-                                   dedup ? b->vkeysA.p : (unsigned long long*)nullptr, q, b->wideEdit ? 1u : 0u);
-                if (b->wideEdit) { // 8 ... 10 errors: the band does not fit the bit-parallel in-text matrices — k_verify_dp
-                    const uint32_t slotBytes = (dpRows(b->maxLen) + 1u) * DP_ROW_BYTES;
-                    const uint32_t dSlots = std::min<uint32_t>(((nItems + 255) / 256) * 256, 256u * 128u);
-                    if (b->dpSlab.n < (size_t)slotBytes * dSlots) b->dpSlab.alloc((size_t)slotBytes * dSlots);
-                    hipLaunchKernelGGL(k_verify_dp, dim3(dSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->maxLen, b->seq.p, b->items.p, nItems,
-                                       b->dpSlab.p, slotBytes, q);
-                }
+                                   dedup ? b->vkeysA.p : (unsigned long long*)nullptr, q, b->wideEdit ? 1u : 0u); // (1: the wide key layout)
                 if (dedup) {
                     uint32_t nRuns = 0;
                     size_t tmpBytes = 0;
@@ -1396,7 +1392,7 @@ static int batchRunOne(cmb_batch* b) {
                     // that the all-ones key of the other items sorts behind every real key) — see packVerifyKey
                     uint32_t rsBits = 1;
                     while ((1ull << rsBits) <= 2ull * nReads) rsBits++;
-                    const uint32_t bit0 = 32u - VK_LOW, bit1 = 39u + rsBits;
+                    const uint32_t bit0 = 32u - VK_LOW, bit1 = (b->wideEdit ? VKW_RS : 39u) + rsBits;
                     HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, b->vkeysA.p, b->vkeysB.p, nItems, bit0, bit1, s));
                     if (b->sortTmp.n < tmpBytes) b->sortTmp.alloc(tmpBytes + 256);
                     HIPCHK(rocprim::radix_sort_keys(b->sortTmp.p, tmpBytes, b->vkeysA.p, b->vkeysB.p, nItems, bit0, bit1, s));
@@ -1412,7 +1408,30 @@ static int batchRunOne(cmb_batch* b) {
                     vGroup = "k_verify_edit";
                     tm.begin();
                     if (getenv("CMB_VERBOSE")) fprintf(stderr, "[verify] %u items, %u distinct keys\n", nItems, nRuns);
-                    if (nRuns) {
+                    if (nRuns && b->wideEdit) {
+                        // 8 ... 10 errors: the band (up to 41 columns) needs the wide left margin of the 64-bit in-text matrix (dev_matrix.hpp:
+                        // MXX_*): k_wide_filter sorts out the candidates that never reach their final column, k_verify_wide<true> verifies the rest
+                        const uint32_t fGrid = std::min<uint32_t>((nRuns + 255) / 256, 2048u);
+                        // (every key, the slots a wavefront leaves unused when it retires a chunk — fewer than 64 of 256 —, a chunk per wavefront)
+                        const size_t listNeed = (size_t)nRuns + nRuns / 3 + (size_t)fGrid * 4 * 256 + 512;
+                        if (b->dpList.n < listNeed) b->dpList.alloc(listNeed + listNeed / 8);
+                        if (b->dpWork.n < 4) b->dpWork.alloc(4);
+                        HIPCHK(hipMemsetAsync(b->dpWork.p, 0, 4 * sizeof(uint32_t), s));
+                        hipLaunchKernelGGL(k_wide_filter, dim3(fGrid), dim3(256), 0, s, ix->d, b->offs.p, b->G.p, b->gw, b->vkeysA.p, b->vcounts.p, nRuns,
+                                           b->dpWork.p, b->dpList.p, (uint32_t)std::min<size_t>(b->dpList.n, 0xFFFFFFF0u), q);
+                        const uint32_t slotBytes = (vwRows(b->maxLen) + 1u) * VW_ROW_BYTES;
+                        // (six wavefronts per SIMD: 1024 SIMDs x 6 x 64 lanes — forward pass and traceback wait for memory; a slot is 3 - 8 KB)
+                        const uint32_t dSlots = std::min<uint32_t>(((nRuns + 255) / 256) * 256, getenv("CMB_VW_SLOTS") ? (uint32_t)atoi(getenv("CMB_VW_SLOTS")) : 256u * 1536u);
+                        if (b->dpSlab.n < (size_t)slotBytes * dSlots) b->dpSlab.alloc((size_t)slotBytes * dSlots);
+                        hipLaunchKernelGGL(k_verify_wide<true>, dim3(dSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->maxLen, b->seq.p, b->G.p, b->gw,
+                                           (const uint4*)nullptr, (uint32_t)std::min<size_t>(b->dpList.n, 0xFFFFFFF0u), b->vkeysA.p, b->vcounts.p, b->dpList.p, b->dpWork.p + 1, b->dpSlab.p, slotBytes, q);
+                        if (verbose) {
+                            uint32_t hw[2];
+                            HIPCHK(hipMemcpyAsync(hw, b->dpWork.p, sizeof(hw), hipMemcpyDeviceToHost, s));
+                            HIPCHK(hipStreamSynchronize(s));
+                            fprintf(stderr, "[verify] %u list slots (survivors and holes) for %u distinct candidates\n", hw[1], nRuns);
+                        }
+                    } else if (nRuns) {
                         // staged verification (kernels.hpp: k_verify_stage): one launch per nb 32-row matrix blocks,
                         // survivor lists ping-pong, list sizes stay on the device
                         // nb 32-row blocks per stage: fewer stages re-fetch fewer text lines and move fewer survivor
@@ -2068,14 +2087,14 @@ extern "C" int cmb_locate_batch(cmb_index* idx, const uint32_t* rows, uint64_t n
 
 // The PRODUCTION edit-distance verification path for one pattern and n start positions: k_verify<KEYS> (one key per
 // candidate) -> radix sort + run-length encode (identical candidates are verified once, counters scaled by the
-// multiplicity) -> k_verify_stage x stages -> k_traceback, exactly as cmb_batch_run runs it (it IS cmb_batch_run on a
-// one-read batch whose in-text items are given).  Same contract as cmb_verify_batch, incl. duplicates in `starts`.
+// multiplicity) -> k_verify_stage x stages -> k_traceback (beyond 7 errors: -> k_wide_filter -> k_verify_wide), exactly as cmb_batch_run
+// runs it (it IS cmb_batch_run on a one-read batch whose in-text items are given).  Same contract as cmb_verify_batch, incl. duplicates in `starts`.
 extern "C" int cmb_verify_batch_staged(cmb_index* idx, const char* pattern, uint32_t plen, const uint32_t* starts,
                                        uint64_t n, uint32_t max_ed, uint32_t min_ed, int fixed_start, cmb_occ* out,
                                        uint64_t out_cap, uint64_t* n_out, uint64_t* counters) {
     if (!idx || !pattern || (n && !starts) || !n_out) return fail(CMB_ERR_INVALID, "null argument");
     if (plen == 0 || plen > (uint32_t)MAX_READ) return fail(CMB_ERR_UNSUPPORTED, "pattern length not supported");
-    if (max_ed == 0 || max_ed > 7 || 3 * max_ed + 1 > MXW_LEFT || min_ed > 7) return fail(CMB_ERR_UNSUPPORTED, "needs a wider in-text matrix");
+    if (max_ed == 0 || max_ed > MX_MAX_ED || min_ed > 15) return fail(CMB_ERR_UNSUPPORTED, "more than 10 errors"); // (8 ... 10: k_wide_filter + k_verify_wide)
     if (n >= (1ull << 31)) return fail(CMB_ERR_INVALID, "too many start positions");
     for (uint64_t i = 0; i < n; i++)
         if (starts[i] > idx->d.n) return fail(CMB_ERR_INVALID, "start position beyond the text");
@@ -2139,7 +2158,7 @@ static int verifyDirect(cmb_index* idx, const char* pattern, uint32_t plen, cons
                         uint64_t* n_out, uint64_t* counters) {
     if (!idx || !pattern || (n && !starts) || !n_out) return fail(CMB_ERR_INVALID, "null argument");
     if (plen == 0 || plen > (uint32_t)MAX_READ) return fail(CMB_ERR_UNSUPPORTED, "pattern length not supported");
-    const bool dp = 3 * max_ed + 1 > MXW_LEFT; // beyond 7 errors: k_verify_dp (the band does not fit the bit-parallel in-text matrices)
+    const bool dp = 3 * max_ed + 1 > MXW_LEFT; // beyond 7 errors: k_verify_wide (the band does not fit the bit-parallel in-text matrices)
     if (max_ed > MX_MAX_ED || min_ed > 15) return fail(CMB_ERR_UNSUPPORTED, "more than 10 errors");
     for (uint64_t i = 0; i < n; i++)
         if (starts[i] > idx->d.n) return fail(CMB_ERR_INVALID, "start position beyond the text");
@@ -2194,10 +2213,12 @@ static int verifyDirect(cmb_index* idx, const char* pattern, uint32_t plen, cons
         uint32_t hc[8];
         if (n && dp) {
             DevBuf<uint8_t> slab;
-            const uint32_t slotBytes = (dpRows(mlen) + 1u) * DP_ROW_BYTES;
+            const uint32_t slotBytes = (vwRows(mlen) + 1u) * VW_ROW_BYTES;
             const uint32_t dSlots = (uint32_t)std::min<uint64_t>(((n + 255) / 256) * 256, 256u * 64u);
             slab.alloc((size_t)slotBytes * dSlots);
-            hipLaunchKernelGGL(k_verify_dp, dim3(dSlots / 256), dim3(256), 0, 0, idx->d, offs.p, mlen, seq.p, items.p, (uint32_t)n, slab.p, slotBytes, q);
+            hipLaunchKernelGGL(k_verify_wide<false>, dim3(dSlots / 256), dim3(256), 0, 0, idx->d, offs.p, mlen, seq.p, G.p, gw, items.p, (uint32_t)n,
+                               (const unsigned long long*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, slab.p,
+                               slotBytes, q);
             HIPCHK(hipDeviceSynchronize());
         } else if (n) {
             hipLaunchKernelGGL(k_verify<false>, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, mlen, gw, seq.p, mf,

@@ -203,6 +203,64 @@ constexpr uint32_t MX32_BLOCK = 8, MX32_DIAG = 13, MX32_LEFT = 14, MX32_MAX_ED =
 // band, hence the same valid rows, centres and traces as the 128-bit matrix (pinned by the golden vectors of the
 // reference's BitParallelED128 through the oracle; tests/test_gpu_parity.py compares at k = 5, 6, 7).
 constexpr uint32_t MXW_BLOCK = 16, MXW_DIAG = 21, MXW_LEFT = 22, MXW_MAX_ED = 7;
+// ---- ... and on 64-bit words and 16-row blocks with a wider left margin (in-text verification, maxED 8 .. 10) ----
+// A candidate without a fixed start at k = 10 has Wv = 3 k = 30 columns left of the diagonal and Wh = k right of it: with BLOCK 16,
+// DIAG 30, LEFT 31 the band occupies bits r % 16 .. r % 16 + 40 and the rightmost active column stays below bit 56 — the reference's
+// own bound 3 maxED + 2 + BLOCK <= WORD (bitparallelmatrix.h:313) holds for 64 bits once the block is 16 rows.  Same band, same values in
+// the band as the reference's 128-bit matrix (fmindex.h:240-246), by the argument above.  The walk to the rightmost active column can
+// span Wv + Wh = 40 columns here: racWalkWide works on 64-bit windows.  Match words come straight from the read's bit-strings
+// (matchWordB: one funnel shift), not from the 32-row block words of k_match_words, whose 64 bits do not reach that far.
+constexpr uint32_t MXX_BLOCK = 16, MXX_DIAG = 30, MXX_LEFT = 31;
+// match word of block b for BLOCK-row blocks: bit t = column t - LEFT + BLOCK b of the read (xLen characters from bit 0 of G); the
+// columns left of the read are ones (bitparallelmatrix.cpp:44-47, carried into the next blocks by its shifts), those right of it zeros
+template <uint32_t LEFT, uint32_t BLOCK>
+__device__ __forceinline__ uint64_t matchWordB(const uint32_t* G, uint32_t xLen, uint32_t b) {
+    const int lim = (int)xLen + (int)LEFT - (int)(BLOCK * b); // number of meaningful low bits
+    if (lim <= 0) return 0ull;
+    const int s = (int)LEFT - (int)(BLOCK * b);
+    uint64_t m = s > 0 ? ((window64(G, 0u) << (uint32_t)s) | ((1ull << (uint32_t)s) - 1ull)) : window64(G, (uint32_t)(-s));
+    if (lim < 64) m &= (1ull << lim) - 1ull;
+    return m;
+}
+// racWalk on 64-bit windows (bit 63 is the RAC column)
+template <uint32_t BLOCK, uint32_t DIAG>
+__device__ __forceinline__ bool racWalkWide(const MatGeom& g, uint32_t i, uint64_t HP, uint64_t HN, uint64_t& RAC) {
+    const uint32_t diagBit = i % BLOCK + DIAG;
+    const uint32_t q = (uint32_t)__ffsll((unsigned long long)RAC) - 1u;
+    const uint32_t maxSteps = q - (diagBit - g.Wv); // the walk fails if it is still running at this step
+    const uint64_t hp = HP << (63u - q), hn = HN << (63u - q);
+    const uint32_t p1 = hp ? (uint32_t)__clzll((long long)hp) : 64u; // steps before the first HP bit
+    if (p1 >= maxSteps) return false;
+    uint32_t k = p1;
+    if (p1 != 0u && (hn >> (64u - p1)) != 0ull) { // HN bits before it: per HP bit, as racWalk
+        const uint64_t xs = maxSteps >= 64u ? hp : hp & ~(~0ull >> maxSteps);
+        uint64_t top = ~0ull;
+        int need = 1;
+        for (;;) {
+            const uint64_t xm = xs & top;
+            if (xm == 0ull) return false;
+            const uint32_t fh = (uint32_t)__clzll((long long)xm);
+            const uint64_t hb = 0x8000000000000000ull >> fh;
+            need += (int)__popcll(hn & top & ~((hb << 1u) - 1ull)) - 1;
+            if (need == 0) {
+                k = fh;
+                break;
+            }
+            top = hb - 1ull;
+        }
+    }
+    RAC = 1ull << (q - k - 1u);
+    return true;
+}
+template <uint32_t BLOCK, uint32_t DIAG>
+__device__ __forceinline__ bool computeRowWide(const MatGeom& g, uint32_t i, uint64_t M, uint64_t& HP, uint64_t& HN, uint64_t& D0, uint64_t& RAC,
+                                               uint32_t& score) {
+    racAdvance<BLOCK>(i, RAC);
+    computeRowCore<BLOCK>(i, M, HP, HN, D0);
+    score += (D0 & (1ull << (i % BLOCK + DIAG))) ? 0u : 1u;
+    if (!racHit(D0, RAC)) return racWalkWide<BLOCK, DIAG>(g, i, HP, HN, RAC);
+    return true;
+}
 // The match words of the full read (k_match_words: per 32-row block, bit t = character t - MXF_LEFT + 32 b) serve
 // both in-text matrices: a row's word is a shift of its block's word.
 // (23, not 22: with 22 the 32-bit matrix's shifts are whole bytes and the compiler turns the 64-bit LDS read of the

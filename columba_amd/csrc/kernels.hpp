@@ -857,6 +857,14 @@ __host__ __device__ __forceinline__ uint32_t verifyKeyStart(unsigned long long k
     const uint32_t v = (uint32_t)key;
     return (v << VK_LOW) | (v >> (32u - VK_LOW));
 }
+// ... and for batches at 8 ... 10 errors (k_wide_filter / k_verify_wide): four bits for each bound, read x strand from bit 41
+// (sub-batches of at most 2^20 reads)
+constexpr uint32_t VKW_RS = 41;
+__host__ __device__ __forceinline__ unsigned long long packVerifyKeyW(uint32_t rs, uint32_t start, uint32_t maxED, uint32_t minED,
+                                                                      uint32_t fixed) {
+    return ((unsigned long long)rs << VKW_RS) | ((unsigned long long)(maxED & 15u) << 37) | ((unsigned long long)(minED & 15u) << 33) |
+           ((unsigned long long)(fixed & 1u) << 32) | (unsigned long long)((start >> VK_LOW) | (start << (32u - VK_LOW)));
+}
 
 // one edit-distance verification (FMIndex::inTextVerification + InTextVerificationTask::doTask) of `mult`
 // identical candidates; returns true with a traceback task if the final column holds cluster centres
@@ -924,7 +932,7 @@ __global__ void __launch_bounds__(256)
 k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32_t gw,
          const uint8_t* __restrict__ seq, MFull mf, const uint4* __restrict__ items,
          uint32_t nItems, uint4* __restrict__ tbq, uint32_t tbCap, unsigned long long* __restrict__ vkeys, Queues q,
-         uint32_t skipEdit = 0 /* edit-distance candidates are left to k_verify_dp (8 ... 10 errors) */) {
+         uint32_t wideKeys = 0 /* KEYS: the key layout of batches at 8 ... 10 errors (packVerifyKeyW) */) {
     __shared__ uint64_t Ml[ML_WORDS];
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cLF = 0, cLoc = 0, cText = 0, cRows = 0, cAbort = 0, cCig = 0, cStarted = 0, cRep = 0, flags = 0;
@@ -943,7 +951,7 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
         unsigned long long vkey = ~0ull;
         uint4 item = make_uint4(0xFFFFFFFFu, 0, 0, 0);
         if (it < nItems) item = items[it];
-        if (item.x != 0xFFFFFFFFu && !(skipEdit && ((item.w >> 21) & 3u) == ITEM_EDIT)) { // (holes: unused slots of a wavefront's chunk)
+        if (item.x != 0xFFFFFFFFu) { // (holes: unused slots of a wavefront's chunk)
             rs = item.x;
             const uint32_t row = item.y, a = item.z, meta = item.w;
             const uint32_t kind = (meta >> 21) & 3u;
@@ -1027,7 +1035,7 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
                 const uint32_t sum = pos + shift; // getBeginPositions (fmindex.h:374-379)
                 const uint32_t start = sum >= startDiff ? sum - startDiff : 0;
                 if (KEYS) { // verified once per distinct key by k_verify_stage
-                    vkey = packVerifyKey(rs, start, maxED, minED, fixed);
+                    vkey = wideKeys ? packVerifyKeyW(rs, start, maxED, minED, fixed) : packVerifyKey(rs, start, maxED, minED, fixed);
                 } else if (verifyEdit(ix, offs, mf, rs, start, maxED, minED, fixed, 1u, cStarted, cRows, cText, cAbort,
                                       cCig, tbRec, Ml, direct ? a : 0u)) {
                     nTb = 1;
@@ -1053,145 +1061,322 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
 }
 
 // In-text verification at 8 ... 10 errors (FMIndex::inTextVerification + InTextVerificationTask::doTask, fmindex.cpp:267-310,
-// indexhelpers.cpp:518-574, on the band of the reference's 128-bit matrix): the bit-parallel in-text matrices of this file hold bands of
-// up to 29 columns (k <= 7); a candidate without a fixed start at k = 10 has 41.  This kernel computes the SAME band cell by cell —
-// plain dynamic programming, one candidate per lane, the band's two current rows in registers, every row also written to the lane's
-// slab for the traceback.  Why the results are the reference's: a cell whose value is at most maxED has an optimal path through cells
-// of at most maxED, all inside the band, so those cells are exact here and in the bit-parallel matrix, and all other cells exceed maxED in
-// both; row validity (a cell <= maxED in the row), the cluster centres (comparisons of a value <= maxED with its neighbours) and the
-// traceback's tests along a path of cells <= maxED (horizontal: the left neighbour is one less; diagonal: the characters match, or the
-// cell differs from its diagonal neighbour: bitparallelmatrix.h:531-586) only read such comparisons.  Counters as k_verify_stage /
-// k_traceback count them.  Not a fast path: a slab row costs 48 bytes of traffic per matrix row.
-constexpr uint32_t DP_BAND = 41, DP_ROW_BYTES = 48, DP_INF = 255;
-__host__ __device__ inline uint32_t dpRows(uint32_t maxLen) { return maxLen + 3u * MX_MAX_ED + 4u; }
+// indexhelpers.cpp:518-574).  A candidate without a fixed start has a band of 4 k + 1 columns — 41 at k = 10 — where the reference switches
+// to its 128-bit matrix; the SAME algorithm on 64-bit words with 16-row blocks and a left margin of 31 bits holds that band
+// (dev_matrix.hpp: MXX_*), so these kernels run the reference's recurrence, rightmost-active-column walk, cluster centres and traceback
+// as the staged path does for k <= 7, without its packed survivor / trace formats (which hold 7 errors):
+//   k_wide_filter   which of the distinct verification keys reach their final column at all?  Most candidates are abandoned after a few
+//                   dozen rows, the true locations run all len + 3 k of them.  A lane computes ONE row of its current candidate per
+//                   turn of the loop and takes the next key as soon as its candidate has ended (a wavefront takes VW_WORK_CHUNK keys
+//                   from the work counter at a time): the lanes stay busy whatever the lengths are; nothing is stored.  Candidates
+//                   that fail the reference's abort test (indexhelpers.cpp:542) are counted here (started, rows, aborted — times
+//                   their multiplicity); the others go on (`list`, per-wavefront chunks with holes).
+//   k_verify_wide   computes those again in step, one candidate per lane, every row's {HP, M | ~D0} stored (16 bytes; the rows of a
+//                   wavefront are contiguous), the values of the last column kept in registers; then findClusterCenters and traceBack
+//                   (bitparallelmatrix.h:591-614, :531-586) on the stored rows.  KEYED: the batch path (keys, multiplicities, the
+//                   list of k_wide_filter); otherwise the items of the hooks, each located and verified by itself.
+constexpr uint32_t VW_ROW_BYTES = 16, VW_WORK_CHUNK = 1024;
+__host__ __device__ inline uint32_t vwRows(uint32_t maxLen) { return maxLen + 3u * MX_MAX_ED + 4u; }
+struct WideRow { // the matrix state of one candidate, with the text codes and match words of its current 16-row block
+    uint64_t HP, HN, RAC;
+    uint32_t score;
+    uint64_t Mw[4];    // match words of the block, per text code
+    uint4 tx;          // text codes of rows 16 c + 1 .. 16 c + 16
+    uint32_t lastCode; // ... and of row 16 c (the last one of the previous chunk)
+    __device__ __forceinline__ void init(const MatGeom& g, uint32_t nZeros) { // (as forwardPass; bitparallelmatrix.cpp:105-121)
+        HP = (~0ull) << MXX_LEFT;
+        HN = (1ull << (MXX_LEFT + 1u - nZeros)) - 1ull;
+        RAC = 1ull << (MXX_DIAG + g.Wh);
+        score = 0;
+        tx = make_uint4(0, 0, 0, 0);
+    }
+    // before row 16 c (c = 0: before row 1): everything rows 16 c .. 16 c + 15 read from memory, in ONE round trip — a row by itself
+    // would wait for its text code and then for the match word that code selects
+    __device__ __forceinline__ void loadBlock(const DevIndex& ix, const uint32_t* G, uint32_t gw, uint32_t rs, uint32_t len, uint32_t start,
+                                              uint32_t c) {
+        lastCode = tx.w >> 24;
+        tx = loadText16(ix.text + start + 16u * c); // (the text allocation is padded)
+#pragma unroll
+        for (uint32_t ch = 0; ch < 4; ch++) Mw[ch] = matchWordB<MXX_LEFT, MXX_BLOCK>(gString(G, gw, rs, 0u, ch), len, c);
+    }
+    // row r; M and D0 of the row are returned for the traceback
+    __device__ __forceinline__ bool step(const MatGeom& g, uint32_t r, uint64_t& M, uint64_t& D0) {
+        const uint32_t t = (r - 1u) & 15u, w = t >> 2;
+        const uint32_t word = w == 0u ? tx.x : w == 1u ? tx.y : w == 2u ? tx.z : tx.w;
+        const uint32_t tc = (r & 15u) == 0u ? lastCode : (word >> (8u * (t & 3u))) & 0xFFu; // (text code 4: '$' / padding, matches nothing)
+        M = tc == 0u ? Mw[0] : tc == 1u ? Mw[1] : tc == 2u ? Mw[2] : tc == 3u ? Mw[3] : 0ull;
+        return computeRowWide<MXX_BLOCK, MXX_DIAG>(g, r, M, HP, HN, D0, RAC, score);
+    }
+};
+__device__ __forceinline__ MatGeom wideGeom(uint32_t len, uint32_t maxED, uint32_t nZeros) {
+    MatGeom g;
+    g.n = len + 1u;
+    g.maxED = maxED;
+    g.Wv = nZeros - 1u + maxED;
+    g.Wh = maxED;
+    g.m = max(g.Wv + g.n, g.Wv + g.Wh + 1u); // (bitparallelmatrix.cpp:98-103: reads shorter than the band)
+    return g;
+}
+
 __global__ void __launch_bounds__(256)
-k_verify_dp(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, const uint8_t* __restrict__ seq,
-            const uint4* __restrict__ items, uint32_t nItems, uint8_t* __restrict__ slab, uint32_t slotBytes, Queues q) {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x, nSlots = gridDim.x * blockDim.x;
-    uint8_t* const Mx = slab + (size_t)slot * slotBytes;
-    uint32_t cLF = 0, cLoc = 0, cRows = 0, cAbort = 0, cCig = 0, cStarted = 0, flags = 0;
-    for (uint32_t it = slot; it < nItems; it += nSlots) {
-        const uint4 item = items[it];
-        if (item.x == 0xFFFFFFFFu) continue; // (holes of the item queue)
-        const uint32_t meta = item.w;
-        if (((meta >> 21) & 3u) != ITEM_EDIT) continue; // (exact candidates of the k = 0 phases: k_verify)
-        const uint32_t rs = item.x, maxED = (meta >> 12) & 15u, minED = (meta >> 16) & 15u, fixed = (meta >> 20) & 1u, shift = meta & 0xFFFu;
-        const uint32_t len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
-        const uint8_t* rd = seq + (size_t)rs * maxLen;
-        const bool direct = (meta >> 23) & 1u; // (hooks: item.y is the start position itself, item.z the explicit end of the window or 0)
-        uint32_t pos = item.y;
-        if (!direct) {
-            cLoc++;
-            pos = findSA(ix, item.y, &cLF);
-        }
-        const uint32_t startDiff = direct ? 0u : item.z, limitEnd = direct ? item.z : 0u;
-        const uint32_t sum = pos + shift, start = sum >= startDiff ? sum - startDiff : 0; // getBeginPositions (fmindex.h:374-379)
-        const uint32_t nZeros = fixed ? 1u : 2u * maxED + 1u;
-        const uint32_t Wv = nZeros - 1u + maxED, Wh = maxED, n = len + 1u;
-        const uint32_t m = max(Wv + n, Wv + Wh + 1u), sfc = Wh + Wv + 1u; // (bitparallelmatrix.cpp:87-103)
-        cStarted++;
-        const uint32_t maxEnd = ix.n - 1;
-        const uint32_t hEnd = limitEnd ? min(maxEnd, limitEnd) : min(maxEnd, start + m - 1); // (limitEnd: inTextVerificationOneString)
-        const uint32_t size = hEnd > start ? hEnd - start : 0;
-        if (size < m - sfc) continue; // !inFinalColumn(size) (indexhelpers.cpp:527)
-        if (Wv + Wh + 1u > DP_BAND || (size + 1u) * DP_ROW_BYTES > slotBytes) {
-            flags |= FLAG_CAPACITY;
-            continue;
-        }
-        const uint32_t col = n - 1u;
-        // band cell d of row i is column j = i + d - Wv
-        uint32_t prev[DP_BAND], cur[DP_BAND];
-#pragma unroll
-        for (uint32_t d = 0; d < DP_BAND; d++) { // row 0: 0, 1, 2, ... up to column Wh
-            const int j = (int)d - (int)Wv;
-            prev[d] = (j >= 0 && (uint32_t)j <= Wh && (uint32_t)j <= col && d <= Wv + Wh) ? (uint32_t)j : DP_INF;
-        }
-        {
-            uint32_t w[12];
-#pragma unroll
-            for (uint32_t u = 0; u < 12; u++) w[u] = 0;
-#pragma unroll
-            for (uint32_t d = 0; d < DP_BAND; d++) w[d >> 2] |= prev[d] << (8u * (d & 3u));
-            uint4* R = reinterpret_cast<uint4*>(Mx);
-            R[0] = make_uint4(w[0], w[1], w[2], w[3]), R[1] = make_uint4(w[4], w[5], w[6], w[7]), R[2] = make_uint4(w[8], w[9], w[10], w[11]);
-        }
-        uint32_t i = 0;
-        for (uint32_t r = 1; r <= size; r++) {
-            const uint32_t tc = ix.text[start + r - 1];
-            bool valid = false;
-#pragma unroll
-            for (uint32_t d = 0; d < DP_BAND; d++) {
-                const int j = (int)r + (int)d - (int)Wv;
-                uint32_t v = DP_INF;
-                if (d <= Wv + Wh && j >= 0 && (uint32_t)j <= col) {
-                    if (j == 0) v = r < nZeros ? 0u : r - nZeros + 1u; // first column: nZeros zeros, then 1, 2, ...
-                    else {
-                        const uint32_t rc = rd[j - 1];
-                        const uint32_t diag = prev[d] + ((tc < 4u && tc + 1u == rc) ? 0u : 1u);
-                        const uint32_t up = d + 1 < DP_BAND ? prev[d + 1 < DP_BAND ? d + 1 : d] + 1u : DP_INF;
-                        const uint32_t left = d > 0 ? cur[d > 0 ? d - 1 : 0] + 1u : DP_INF;
-                        v = min(min(diag, up), min(left, 250u));
+k_wide_filter(DevIndex ix, const uint64_t* __restrict__ offs, const uint32_t* __restrict__ G, uint32_t gw,
+              const unsigned long long* __restrict__ ukeys, const uint32_t* __restrict__ counts, uint32_t nKeys, uint32_t* __restrict__ work,
+              uint32_t* __restrict__ list, uint32_t listCap, Queues q) {
+    uint32_t cRows = 0, cAbort = 0, cStarted = 0, flags = 0;
+    bool have = false, done = false;
+    uint32_t u = 0, mult = 0, rs = 0, len = 0, r = 0, size = 0, start = 0, rows = 0;
+    MatGeom g{0, 0, 0, 0, 0};
+    WideRow mx{0, 0, 0, 0};
+    const uint32_t lane = threadIdx.x & 63u;
+    // (atomics on one address are served at ~90 per microsecond, dev_wave.hpp: a chunk of keys per atomic, the survivors in
+    // per-wavefront chunks of `list`, holes = 0xFFFFFFFF; work: [0] next key, [1] list slots handed out — both zero at launch)
+    uint32_t chunkNext = 0, chunkEnd = 0; // (wave-uniform)
+    WaveChunk chS;
+    bool ovS = false;
+    auto holeS = [&](uint32_t i) { list[i] = 0xFFFFFFFFu; };
+    // The lanes of a wavefront keep their 16-row blocks in PHASE: a new candidate starts at a turn that is a multiple of 16 (a lane
+    // waits 8 turns on average for it), so that all lanes load their next block — text codes, four match words — in the same turn,
+    // one round trip per 16 rows of the whole wavefront.
+    for (uint32_t turn = 0;; turn++) {
+        bool skip = false;
+        if ((turn & 15u) == 0u) { // (wave-uniform)
+            bool fresh = false;
+            const unsigned long long need = __ballot(!have && !done);
+            if (need) {
+                if (chunkNext == chunkEnd) {
+                    uint32_t base = 0;
+                    if (lane == 0u) base = atomicAdd(&work[0], VW_WORK_CHUNK);
+                    chunkNext = (uint32_t)__shfl((int)base, 0);
+                    chunkEnd = chunkNext + VW_WORK_CHUNK;
+                }
+                const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull)), avail = chunkEnd - chunkNext;
+                const uint32_t idx = chunkNext + rank;
+                chunkNext += min((uint32_t)__popcll(need), avail);
+                if (!have && !done && rank < avail) { // (the others ask again 16 turns on: a new chunk)
+                    if (idx >= nKeys) {
+                        done = true;
+                    } else {
+                        const unsigned long long key = ukeys[idx];
+                        mult = counts[idx];
+                        if (key != ~0ull) { // (all ones: the run of the items that are no edit-distance candidates — it sorts last)
+                            rs = (uint32_t)(key >> VKW_RS);
+                            const uint32_t maxED = (uint32_t)(key >> 37) & 15u, fixed = (uint32_t)(key >> 32) & 1u;
+                            const uint32_t nZeros = fixed ? 1u : 2u * maxED + 1u;
+                            start = verifyKeyStart(key);
+                            len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
+                            g = wideGeom(len, maxED, nZeros);
+                            const uint32_t maxEnd = ix.n - 1, hEnd = min(maxEnd, start + g.m - 1);
+                            size = hEnd > start ? hEnd - start : 0;
+                            if (!g.inFinalColumn(size)) { // (indexhelpers.cpp:527): started, nothing computed
+                                cStarted += mult;
+                            } else if (g.Wv >= MXX_LEFT || maxED > MX_MAX_ED) {
+                                flags |= FLAG_CAPACITY;
+                            } else if (size == 0u) { // (no row to compute: the abort test of indexhelpers.cpp:542 with i = 0)
+                                cStarted += mult;
+                                cAbort += mult;
+                            } else {
+                                have = true;
+                                fresh = true;
+                                u = idx, r = 0u, rows = 0u;
+                                mx.init(g, nZeros);
+                            }
+                        }
                     }
                 }
-                cur[d] = v;
-                valid = valid || v <= maxED;
             }
-            cRows++;
-            {
-                uint32_t w[12];
-#pragma unroll
-                for (uint32_t u = 0; u < 12; u++) w[u] = 0;
-#pragma unroll
-                for (uint32_t d = 0; d < DP_BAND; d++) w[d >> 2] |= cur[d] << (8u * (d & 3u));
-                uint4* R = reinterpret_cast<uint4*>(Mx + (size_t)r * DP_ROW_BYTES);
-                R[0] = make_uint4(w[0], w[1], w[2], w[3]), R[1] = make_uint4(w[4], w[5], w[6], w[7]), R[2] = make_uint4(w[8], w[9], w[10], w[11]);
+            if (!__any(have)) {
+                if (__all(done)) break;
+                turn = 0xFFFFFFFFu; // (nobody has work yet: ask again at once)
+                continue;
             }
-            if (!valid) break;
-            i = r;
-#pragma unroll
-            for (uint32_t d = 0; d < DP_BAND; d++) prev[d] = cur[d];
+            if (have) mx.loadBlock(ix, G, gw, rs, len, start, r >> 4);
+            skip = fresh; // (row 0 is the initial state: a fresh candidate's first row comes in the next turn)
+            if (fresh) r = 1u;
         }
-        if (i <= size - sfc) { // (length_t arithmetic as in the reference, indexhelpers.cpp:542)
-            cAbort++;
-            continue;
-        }
-        auto cell = [&](uint32_t ri, uint32_t cj) -> uint32_t { // DP_INF outside the band
-            const int d = (int)cj - (int)ri + (int)Wv;
-            if (d < 0 || (uint32_t)d > Wv + Wh) return DP_INF;
-            return Mx[(size_t)ri * DP_ROW_BYTES + (uint32_t)d];
-        };
-        // findClusterCenters (bitparallelmatrix.h:591-614), then traceBack (:531-586) of every centre
-        const uint32_t firstRow = (m - 1u) - sfc;
-        uint32_t nCentres = 0;
-        for (uint32_t r = i; r > firstRow; r--) {
-            const uint32_t ED = cell(r, col);
-            if (ED > maxED || ED < minED) continue;
-            const bool betterThanAbove = r == firstRow || ED <= cell(r - 1u, col);
-            const bool betterThanBelow = r == i || ED <= cell(r + 1u, col);
-            if (!(betterThanAbove && betterThanBelow)) continue;
-            nCentres++;
-            uint32_t ti = r, tj = col;
-            while (tj > 0) {
-                const uint32_t here = cell(ti, tj), left = cell(ti, tj - 1u);
-                if (left != DP_INF && here == left + 1u) { // gap in horizontal (:553)
-                    --tj;
-                } else if (ti > 0) {
-                    const uint32_t tcode = ix.text[start + ti - 1u], rc = rd[tj - 1u];
-                    const bool match = tcode < 4u && tcode + 1u == rc;
-                    if (match || here != cell(ti - 1u, tj - 1u)) --tj; // diagonal (:559); else vertical
-                    --ti;
+        bool survives = false;
+        if (have && !skip) {
+            uint64_t M, D0;
+            const bool valid = mx.step(g, r, M, D0);
+            rows++;
+            if (!valid || r == size) {
+                const uint32_t i = valid ? r : r - 1u; // the last valid row
+                if (i <= size - g.sfc()) { // (length_t arithmetic as in the reference, indexhelpers.cpp:542)
+                    cStarted += mult;
+                    cRows += rows * mult;
+                    cAbort += mult;
                 } else {
-                    flags |= FLAG_CAPACITY; // (row 0 only has horizontal steps)
-                    break;
+                    survives = true;
+                }
+                have = false;
+            } else {
+                r++;
+            }
+        }
+        if (__any(survives)) { // (wave-uniform)
+            const uint32_t o = chS.alloc(&work[1], listCap, survives ? 1u : 0u, 256u, ovS, holeS);
+            if (survives && o != 0xFFFFFFFFu) list[o] = u;
+        }
+    }
+    chS.fill(holeS);
+    if (ovS) flags |= FLAG_CAPACITY; // (sized by the host: every key and a chunk per wavefront)
+    const uint32_t local[8] = {0u, 0u, cRows, cRows, cAbort, 0u, cStarted, 0u};
+    const int which[8] = {8, 9, 10, 11, 3, 4, 2, 1};
+    flushCounters(q, local, which, 8);
+    if (flags) atomicOr(&q.cnt[3], flags);
+}
+
+template <bool KEYED>
+__global__ void __launch_bounds__(256)
+k_verify_wide(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, const uint8_t* __restrict__ seq, const uint32_t* __restrict__ G,
+              uint32_t gw, const uint4* __restrict__ items, uint32_t nItems, const unsigned long long* __restrict__ ukeys,
+              const uint32_t* __restrict__ counts, const uint32_t* __restrict__ list, const uint32_t* __restrict__ nList,
+              uint8_t* __restrict__ slab, uint32_t slotBytes, Queues q) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x, nSlots = gridDim.x * blockDim.x, lane = threadIdx.x & 63u;
+    // the slab of a wavefront: 16 bytes {HP, M | ~D0} per matrix row and lane, row-major — the lanes of a wavefront compute their rows in
+    // step, so a row is ONE contiguous kilobyte
+    uint4* const rowBits = reinterpret_cast<uint4*>(slab + (size_t)(slot - lane) * slotBytes) + lane;
+    auto putRow = [&](uint32_t r, uint64_t a, uint64_t b) {
+        rowBits[(size_t)r * 64u] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+    };
+    uint32_t cLF = 0, cLoc = 0, cRows = 0, cAbort = 0, cCig = 0, cStarted = 0, flags = 0;
+    const uint32_t nIn = KEYED ? min(*nList, nItems) : nItems;
+    WaveChunk chT; // the occurrences go into per-wavefront chunks of the text-occurrence queue (one atomic per 256 of them)
+    bool ovT = false;
+    auto holeT = [&](uint32_t o) { q.text[o].rsId = 0xFFFFFFFFu; };
+    for (uint32_t base = slot - lane; base < nIn; base += nSlots) { // (wave-uniform trip count)
+        const uint32_t it = base + lane;
+        bool active = it < nIn;
+        uint32_t rs = 0, maxED = 0, minED = 0, fixed = 0, start = 0, limitEnd = 0u, mult = 1u;
+        if (active && KEYED) {
+            const uint32_t u = list[it];
+            if (u == 0xFFFFFFFFu) { // (holes of the list's per-wavefront chunks)
+                active = false;
+            } else {
+                const unsigned long long key = ukeys[u];
+                mult = counts[u];
+                rs = (uint32_t)(key >> VKW_RS), maxED = (uint32_t)(key >> 37) & 15u, minED = (uint32_t)(key >> 33) & 15u, fixed = (uint32_t)(key >> 32) & 1u;
+                start = verifyKeyStart(key);
+            }
+        } else if (active) {
+            const uint4 item = items[it];
+            const uint32_t meta = item.w;
+            // (holes of the item queue; exact candidates of the k = 0 phases: k_verify)
+            if (item.x == 0xFFFFFFFFu || ((meta >> 21) & 3u) != ITEM_EDIT) {
+                active = false;
+            } else {
+                rs = item.x, maxED = (meta >> 12) & 15u, minED = (meta >> 16) & 15u, fixed = (meta >> 20) & 1u;
+                const uint32_t shift = meta & 0xFFFu;
+                const bool direct = (meta >> 23) & 1u; // (hooks: item.y is the start position itself, item.z the explicit end of the window or 0)
+                uint32_t pos = item.y;
+                if (!direct) {
+                    cLoc++;
+                    pos = findSA(ix, item.y, &cLF);
+                }
+                const uint32_t startDiff = direct ? 0u : item.z;
+                limitEnd = direct ? item.z : 0u;
+                const uint32_t sum = pos + shift; // getBeginPositions (fmindex.h:374-379)
+                start = sum >= startDiff ? sum - startDiff : 0;
+            }
+        }
+        const uint32_t len = active ? (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]) : 0u;
+        const uint8_t* rd = seq + (size_t)rs * maxLen;
+        const uint32_t nZeros = fixed ? 1u : 2u * maxED + 1u;
+        const MatGeom g = wideGeom(len, maxED, nZeros);
+        const uint32_t sfc = g.sfc(), col = g.n - 1u, firstRow = (g.m - 1u) - sfc;
+        // the values of the last column from row firstRow on (at most sfc + 1 <= 42 of them), four bits each: all that is asked of them
+        // is how they compare with a value of at most maxED <= 10
+        unsigned long long lcw0 = 0ull, lcw1 = 0ull, lcw2 = 0ull;
+        auto lcPut = [&](uint32_t qi, uint32_t v) {
+            const unsigned long long x = (unsigned long long)min(v, 15u) << (4u * (qi & 15u));
+            lcw0 |= (qi >> 4) == 0u ? x : 0ull, lcw1 |= (qi >> 4) == 1u ? x : 0ull, lcw2 |= (qi >> 4) == 2u ? x : 0ull;
+        };
+        auto lcGet = [&](uint32_t qi) -> uint32_t {
+            const unsigned long long w = (qi >> 4) == 0u ? lcw0 : (qi >> 4) == 1u ? lcw1 : lcw2;
+            return (uint32_t)(w >> (4u * (qi & 15u))) & 15u;
+        };
+        uint32_t i = 0;
+        if (active) {
+            cStarted += mult;
+            const uint32_t maxEnd = ix.n - 1;
+            const uint32_t hEnd = limitEnd ? min(maxEnd, limitEnd) : min(maxEnd, start + g.m - 1); // (limitEnd: inTextVerificationOneString)
+            const uint32_t size = hEnd > start ? hEnd - start : 0;
+            if (!g.inFinalColumn(size)) { // (indexhelpers.cpp:527)
+                active = false;
+            } else if (g.Wv >= MXX_LEFT || maxED > MX_MAX_ED || (size + 1u) * VW_ROW_BYTES > slotBytes) {
+                flags |= FLAG_CAPACITY;
+                active = false;
+            } else {
+                WideRow mx;
+                mx.init(g, nZeros);
+                putRow(0u, mx.HP, ~0ull);
+                if (firstRow == 0u) lcPut(0u, cellAt<MXX_BLOCK, MXX_DIAG>(0u, col, mx.HP, mx.HN, mx.score));
+                for (uint32_t r = 1; r <= size; r++) {
+                    if (r == 1u || (r & 15u) == 0u) mx.loadBlock(ix, G, gw, rs, len, start, r >> 4);
+                    uint64_t M, D0;
+                    const bool valid = mx.step(g, r, M, D0);
+                    cRows += mult;
+                    putRow(r, mx.HP, M | ~D0);
+                    if (!valid) break;
+                    if (r >= firstRow) lcPut(r - firstRow, cellAt<MXX_BLOCK, MXX_DIAG>(r, col, mx.HP, mx.HN, mx.score));
+                    i = r;
+                }
+                if (i <= size - sfc) { // (length_t arithmetic as in the reference, indexhelpers.cpp:542)
+                    cAbort += mult;
+                    active = false;
                 }
             }
-            cCig++;
-            const uint32_t o = atomicAdd(&q.cnt[2], 1u);
-            if (o < q.textCap) q.text[o] = TextOccRec{rs, start + ti, start + r, ED};
-            else flags |= FLAG_TEXT_OVERFLOW;
         }
-        if (nCentres == 0) cAbort++; // indexhelpers.cpp:550
+        // findClusterCenters (bitparallelmatrix.h:591-614), then traceBack (:531-586) of every centre: rows i, i - 1, ... firstRow + 1 —
+        // the lanes of the wavefront walk their rows in step, so that the occurrences of a step are appended together
+        const uint32_t nCand = active && i > firstRow ? i - firstRow : 0u;
+        uint32_t nCentres = 0;
+        for (uint32_t t = 0; __any(t < nCand); t++) {
+            bool emit = false;
+            TextOccRec rec{0xFFFFFFFFu, 0u, 0u, 0u};
+            if (t < nCand) {
+                const uint32_t r = i - t;
+                const uint32_t ED = lcGet(r - firstRow); // (firstRow <= row <= i)
+                if (ED <= maxED && ED >= minED) {
+                    const bool betterThanAbove = r == firstRow || ED <= lcGet(r - 1u - firstRow);
+                    const bool betterThanBelow = r == i || ED <= lcGet(r + 1u - firstRow);
+                    if (betterThanAbove && betterThanBelow) {
+                        nCentres++;
+                        uint32_t ti = r, tj = col;
+                        while (tj > 0) {
+                            const uint32_t bitIdx = (tj - (ti / MXX_BLOCK) * MXX_BLOCK) + MXX_DIAG; // (:541-543; unsigned as there)
+                            if (bitIdx >= 64u) {
+                                flags |= FLAG_CAPACITY; // (a path of cells <= maxED stays inside the band)
+                                break;
+                            }
+                            const uint4 rb = rowBits[(size_t)ti * 64u];
+                            const uint64_t hp = rb.x | ((uint64_t)rb.y << 32), md = rb.z | ((uint64_t)rb.w << 32);
+                            if ((hp >> bitIdx) & 1ull) { // gap in horizontal (:553)
+                                --tj;
+                            } else if (ti > 0 && ((md >> bitIdx) & 1ull)) { // diagonal (:559): the characters match, or D0 is not set
+                                --ti;
+                                --tj;
+                            } else if (ti > 0) { // gap in vertical
+                                --ti;
+                            } else {
+                                flags |= FLAG_CAPACITY; // (row 0 only has horizontal steps)
+                                break;
+                            }
+                        }
+                        cCig += mult;
+                        emit = true;
+                        rec = TextOccRec{rs, start + ti, start + r, ED};
+                    }
+                }
+            }
+            if (__any(emit)) { // (wave-uniform)
+                const uint32_t o = chT.alloc(&q.cnt[2], q.textCap, emit ? 1u : 0u, 256u, ovT, holeT);
+                if (emit && o != 0xFFFFFFFFu) q.text[o] = rec;
+            }
+        }
+        if (active && nCentres == 0) cAbort += mult; // indexhelpers.cpp:550
     }
+    chT.fill(holeT);
+    if (ovT) flags |= FLAG_TEXT_OVERFLOW;
     const uint32_t local[8] = {cLF, cLoc, cRows, cRows, cAbort, cCig, cStarted, cCig};
     const int which[8] = {8, 9, 10, 11, 3, 4, 2, 1};
     flushCounters(q, local, which, 8);

@@ -114,7 +114,7 @@ def test_in_text_verification_hook(world):
     g = world["genome"]
     rng = np.random.default_rng(8)
     for trial in range(60):
-        # (k = 7 with a free start: the reference's 128-bit matrix; 8 ... 10: k_verify_dp on that matrix's band)
+        # (k = 7 with a free start: the reference's 128-bit matrix; 8 ... 10: k_verify_wide, the same band on 64-bit words with a wide left margin)
         k = int(rng.integers(1, 8)) if trial < 30 else int(rng.integers(8, 11))
         pos = int(rng.integers(100, len(g) - 400))
         pat = synth.sample_reads(g[pos:pos + 400], 1, int(rng.choice([50, 100, 150, 250])), seed=trial,
@@ -138,8 +138,9 @@ def test_production_edit_verification_path(world):
     g = world["genome"]
     rng = np.random.default_rng(18)
     dup_total = 0
-    for trial in range(24):
-        k = int(rng.integers(1, 8))   # (k = 7 with a free start: the reference's 128-bit matrix)
+    for trial in range(36):
+        k = int(rng.integers(1, 8)) if trial < 24 else 8 + trial % 3   # (from k = 7 with a free start: the reference's 128-bit matrix;
+        #                                                                  beyond 7: k_wide_filter + k_verify_wide on the band of that matrix)
         pos = int(rng.integers(100, len(g) - 400))
         pat = synth.sample_reads(g[pos:pos + 400], 1, int(rng.choice([50, 100, 150, 250])), seed=1000 + trial,
                                  edit_choices=(0, 1, 2, k, max(k - 1, 0)), rc_frac=0.0)[0]
@@ -327,8 +328,8 @@ def test_edit_distance_with_eight_to_ten_errors_in_the_index(world0, partition, 
 
 @pytest.mark.parametrize("partition,k,length", [("dynamic", 8, 150), ("uniform", 9, 100), ("static", 10, 150), ("dynamic", 10, 250)])
 def test_edit_distance_with_eight_to_ten_errors(world, partition, k, length):
-    """... and on the default index (in-text switch point 4): candidates of up to 41 band columns are verified by k_verify_dp (plain
-    dynamic programming on the band of the reference's 128-bit matrix)"""
+    """... and on the default index (in-text switch point 4): candidates of up to 41 band columns are verified by k_wide_filter + k_verify_wide
+    (the band of the reference's 128-bit matrix on 64-bit words with 16-row blocks and a left margin of 31 bits)"""
     g = world["genome"]
     reads = synth.sample_reads(g, 600, length, seed=300 + k, n_frac=0.01, edit_choices=(0, 3, 6, 8, k, k, k + 1))
     reads += [b"N" * length, g[-length - 1:-1].tobytes(), g[0:length].tobytes()]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The other configurations of BASELINE.json (parity-test cases, not bench lines) as the device runs them on the 3 Gbp
 human-like index: reads/s of cmb_batch_run with the reads resident (second of two runs), occurrences, kernel groups.
-usage: python tools/config_table.py [genome Mbp]"""
+usage: python tools/config_table.py [genome Mbp [only the configurations whose name contains this]]"""
 import json
 import os
 import sys
@@ -26,10 +26,12 @@ for name, spec, metric, part, k, n_reads, length in (
         ("configs[2] (the bench line): k = 4 edit, multiple_opt, 150 bp", "multiple_opt", "edit", "dynamic", 4, 10_000_000, 150),
         ("configs[4]'s reads on the FM-index: k = 6 edit, multiple_opt, 250 bp", "multiple_opt", "edit", "dynamic", 6, 2_000_000, 250),
         ("k = 7 edit, columba strategy, 150 bp", "columba", "edit", "dynamic", 7, 1_000_000, 150),
-        # new in round 3: the greedy schemes beyond 7 errors (wide device tables; in-text verification by k_verify_dp), long reads
-        ("k = 9 edit, columba strategy (greedy scheme, k_verify_dp), 150 bp", "columba", "edit", "dynamic", 9, 100_000, 150),
+        # new in round 3: the greedy schemes beyond 7 errors (wide device tables; in-text verification by k_wide_filter + k_verify_wide), long reads
+        ("k = 9 edit, columba strategy (greedy scheme, wide in-text matrix), 150 bp", "columba", "edit", "dynamic", 9, 100_000, 150),
         ("k = 12 Hamming, columba strategy (greedy scheme), 150 bp", "columba", "hamming", "dynamic", 12, 200_000, 150),
         ("k = 4 edit, multiple_opt, 400 bp", "multiple_opt", "edit", "dynamic", 4, 2_000_000, 400)):
+    if len(sys.argv) > 2 and sys.argv[2] not in name:
+        continue
     buf, offs = synth.sample_reads_fast(ix.text[:-1], n_reads, length, seed=3, device="cuda")
     torch.cuda.empty_cache()
     b = ca.Batch(dev, ca.SearchStrategy(spec, metric, part), k, packed=(buf, offs))
