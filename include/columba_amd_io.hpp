@@ -168,26 +168,68 @@ class Reader { // fastq.h Reader (single-end; plain text or .gz)
     }
 };
 
-class OutputWriter { // fastq.h OutputWriter: SAM header, then the chunks in the order of their ids
+class OutputWriter { // fastq.h OutputWriter: SAM header, then the chunks in the order of their ids; ".sam" or ".sam.gz" (fastq.cpp:466-493)
     std::ofstream out;
+#ifdef COLUMBA_AMD_HAVE_ZLIB
+    gzFile gz = nullptr;
+#endif
     std::map<size_t, std::string> pending;
     size_t nextChunkID = 0;
+    void put(const std::string& s) {
+#ifdef COLUMBA_AMD_HAVE_ZLIB
+        if (gz) {
+            for (size_t o = 0; o < s.size();) { // (gzwrite takes an unsigned count)
+                const unsigned n = (unsigned)(s.size() - o < (1u << 30) ? s.size() - o : (1u << 30));
+                if (gzwrite(gz, s.data() + o, n) != (int)n) throw std::ios::failure("error while writing a gz-compressed file");
+                o += n;
+            }
+            return;
+        }
+#endif
+        out << s;
+    }
 
   public:
-    OutputWriter(const std::string& file, const std::string& headerFile, const std::string& commandLine) : out(file) {
-        if (!out) throw std::runtime_error("Cannot open file: " + file);
-        out << "@HD\tVN:1.6\tSO:queryname\n"; // fastq.cpp:579-583
-        out << "@PG\tID:Columba-amd\tPN:Columba\tCL:" << commandLine << "\n";
+    OutputWriter(const std::string& file, const std::string& headerFile, const std::string& commandLine) {
+        std::string ext = file.size() >= 7 ? file.substr(file.size() - 7) : std::string();
+        for (auto& c : ext) c = (char)toupper((unsigned char)c);
+        if (ext == ".SAM.GZ") {
+#ifdef COLUMBA_AMD_HAVE_ZLIB
+            gz = gzopen(file.c_str(), "wb");
+            if (!gz) throw std::runtime_error("Cannot open file: " + file);
+#else
+            throw std::runtime_error("gz-compressed output needs zlib (built without it): " + file);
+#endif
+        } else {
+            out.open(file);
+            if (!out) throw std::runtime_error("Cannot open file: " + file);
+        }
+        put("@HD\tVN:1.6\tSO:queryname\n"); // fastq.cpp:579-583
+        put("@PG\tID:Columba-amd\tPN:Columba\tCL:" + commandLine + "\n");
         std::ifstream hs(headerFile, std::ios::binary);
         std::string line;
-        while (hs && std::getline(hs, line)) out << line << "\n";
+        while (hs && std::getline(hs, line)) put(line + "\n");
+    }
+    OutputWriter(const OutputWriter&) = delete;
+    ~OutputWriter() {
+#ifdef COLUMBA_AMD_HAVE_ZLIB
+        if (gz) gzclose(gz);
+#endif
     }
     void commitChunk(size_t id, std::string&& text) { // chunks may arrive out of order; they leave in order
         pending.emplace(id, std::move(text));
         for (auto it = pending.begin(); it != pending.end() && it->first == nextChunkID; it = pending.erase(it), nextChunkID++)
-            out << it->second;
+            put(it->second);
     }
-    void flush() { out.flush(); }
+    void flush() {
+#ifdef COLUMBA_AMD_HAVE_ZLIB
+        if (gz) {
+            gzflush(gz, Z_SYNC_FLUSH);
+            return;
+        }
+#endif
+        out.flush();
+    }
 };
 
 // sequence names of an index: <base>.sna (size_t length + bytes per name, indexinterface.cpp:175-195)

@@ -115,6 +115,12 @@ def test_align_driver_fastq_to_sam(tmp_path, oracle_built):
     subprocess.run([exe, "-r", str(tmp_path / "idx"), "-f", str(tmp_path / "reads.fq.gz"), "-o", str(outz), "-a", "all", "-e", "4",
                     "-S", "columba", "-b", "400"], check=True, capture_output=True, text=True)
     assert [x for x in outz.read_text().splitlines() if not x.startswith("@")] == want
+    # ... and a gz-compressed SAM file out (OutputWriter: ".sam.gz", fastq.cpp:482)
+    outgz = tmp_path / "all_out.sam.gz"
+    subprocess.run([exe, "-r", str(tmp_path / "idx"), "-f", str(tmp_path / "reads.fq"), "-o", str(outgz), "-a", "all", "-e", "4",
+                    "-S", "columba", "-b", "400"], check=True, capture_output=True, text=True)
+    with gzip.open(outgz, "rt") as f:
+        assert [x for x in f.read().splitlines() if not x.startswith("@")] == want
     # BEST mode (the reference's default): one primary record per read, in input order
     outb = tmp_path / "best.sam"
     subprocess.run([exe, "-r", str(tmp_path / "idx"), "-f", str(tmp_path / "reads.fq"), "-o", str(outb), "-I", "95"], check=True,
