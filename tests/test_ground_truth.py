@@ -202,17 +202,21 @@ def gpu_world(oracle_built):
 @pytest.mark.gpu
 @pytest.mark.parametrize("spec,metric,partition,k", CONFIGS + [
     ("columba", "edit", "dynamic", 7), ("multiple_opt", "edit", "dynamic", 6), ("kianfar", "edit", "dynamic", 3),
-    ("01*0", "edit", "static", 2), ("kuch2", "hamming", "dynamic", 3)])
+    ("01*0", "edit", "static", 2), ("kuch2", "hamming", "dynamic", 3),
+    # beyond 7 errors (greedy schemes, wide device tables and records, the in-text matrix with the wide left margin)
+    ("columba", "edit", "dynamic", 8), ("columba", "edit", "uniform", 10), ("columba", "hamming", "dynamic", 9),
+    ("columba", "hamming", "static", 13)])
 def test_device_is_sound_and_complete(gpu_world, gt, spec, metric, partition, k):
     ca = gpu_world["ca"]
     g = gpu_world["genome"]
-    reads = _reads_for(g, k, 250, seed=900 + k) + _reads_for(g, k, 80, length=151, seed=950 + k)
+    n1, n2 = (250, 80) if k <= 7 else (60, 30)   # (the lists grow quickly with k on this repeat-rich text)
+    reads = _reads_for(g, k, n1, seed=900 + k) + _reads_for(g, k, n2, length=151, seed=950 + k)
     reads += [b"N" * 60, gpu_world["text"][:100], gpu_world["text"][-100:], b"ACGT" * 20]
     dev = gpu_world["dev4" if spec in ("kuch2", "01*0") else "dev"]
     occ, offs, _ = ca.match_batch(dev, ca.SearchStrategy(spec, metric, partition), k, reads)
     checked, loose = check_soundness(gt, gpu_world["text"], reads, occ, offs, k, metric)
     hits, chain = check_completeness(gt, gpu_world["text"], reads, occ, offs, k, metric)
-    assert checked > 200 and hits > 200
+    assert checked > (200 if k <= 7 else 60) and hits > (200 if k <= 7 else 60)
     assert chain * 50 <= hits
 
 
