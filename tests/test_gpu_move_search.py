@@ -272,7 +272,8 @@ def test_bmove_pool_growth(sworld):
 
 
 @pytest.mark.parametrize("spec,metric,x,min_identity", [("columba", "edit", 0, 96), ("columba", "edit", 1, 96), ("multiple_opt", "edit", 0, 97),
-                                                        ("kuch1", "hamming", 0, 98), ("minU", "edit", 2, 97), ("columba", "hamming", 1, 96)])
+                                                        ("kuch1", "hamming", 0, 98), ("minU", "edit", 2, 97), ("columba", "hamming", 1, 96),
+                                                        ("kuch1", "edit", 0, 50)])
 def test_bmove_best_mode(sworld, spec, metric, x, min_identity):
     """BEST (+x strata) mode on the b-move index (cmb_move_match_best: matchApproxBestPlusX with b-move batches as strata, every
     strand filtered by itself; CIGARs and trimming from the text beside the index) against the oracle's restatement of the
@@ -287,6 +288,8 @@ def test_bmove_best_mode(sworld, spec, metric, x, min_identity):
     for s0 in (250_000, 640_000):   # reads across sequence ends: trimmed or dropped (findSeqName)
         reads += [g[s0 - 75:s0 + 75].tobytes(), g[s0 - 3:s0 + 147].tobytes(), g[s0 - 147:s0 + 3].tobytes(), g[s0 - 5:s0 + 145].tobytes()]
     reads += [b"ACGT" * 37 + b"AC", b"N" * 150, g[:150].tobytes(), g[-150:].tobytes()]
+    if min_identity == 50:   # strata of reads not longer than the number of parts: naive backtracking inside a stratum's batch
+        reads = reads[:400] + reads[1200:] + [b"A", b"AC", b"ACG", b"ACGTA", b"GATTACA", b""]
     tab = sp.BY_NAME[spec]
     max_sup = 0
     while (max_sup + 1) in tab["schemes"]:
@@ -303,7 +306,7 @@ def test_bmove_best_mode(sworld, spec, metric, x, min_identity):
     for f in ("begin", "end", "distance"):
         assert np.array_equal(o_occ[f], d_occ[f]), f
     same = o_occ["strand"] == d_occ["strand"]
-    assert (~same).sum() <= max(1, len(d_occ) // 500)   # (the strand label of an occurrence found on both strands)
+    assert (~same).sum() <= max(1, len(d_occ) // (20 if min_identity == 50 else 500))   # (the strand label of an occurrence found on both strands)
     assert np.array_equal(o_sid, d_aln["seq_id"]) and np.array_equal(o_sb, d_aln["seq_begin"])
     for j in range(len(d_occ)):
         a = d_aln[j]

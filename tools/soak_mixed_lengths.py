@@ -15,10 +15,9 @@ rng = np.random.default_rng(17)
 bad = 0
 
 
-def chunk(g, n, k, parts, short_frac, seed):
+def chunk(g, n, k, parts, short_frac, seed, lens=(20, 36, 50, 100, 150, 151, 250, 256, 257, 320, 321, 400, 480)):
     r = np.random.default_rng(seed)
     reads = []
-    lens = (20, 36, 50, 100, 150, 151, 250, 256, 257, 320, 321, 400, 480)
     for ln in lens:
         reads += synth.sample_reads(g, max(1, n // len(lens)), ln, seed=int(r.integers(1 << 30)), n_frac=0.02,
                                     edit_choices=(0, 1, 2, max(k - 1, 0), k, k + 1))
@@ -52,14 +51,21 @@ ix = ib.build_index(g.tobytes(), seq_starts=starts, device="cuda")
 FM = (("multiple_opt", "edit", "dynamic", 4, 5), ("columba", "edit", "dynamic", 7, 8), ("columba", "edit", "uniform", 1, 2),
       ("kuch1", "edit", "static", 2, 3), ("kuch2", "edit", "static", 3, 5), ("pigeon", "hamming", "dynamic", 3, 4),
       ("kianfar", "edit", "dynamic", 4, 5), ("minU", "hamming", "uniform", 5, 6), ("columba", "edit", "dynamic", 0, 1),
-      ("naive", "edit", "dynamic", 2, 1), ("naive", "hamming", "dynamic", 3, 1), ("01*0", "edit", "static", 2, 4))
+      ("naive", "edit", "dynamic", 2, 1), ("naive", "hamming", "dynamic", 3, 1), ("01*0", "edit", "static", 2, 4),
+      # beyond 7 errors: the greedy schemes on the wide device tables, the in-text matrix with the wide left margin (no reads below 60
+      # characters: at 10 errors those match all over the text)
+      ("columba", "edit", "dynamic", 8, 10), ("columba", "edit", "uniform", 10, 12), ("columba", "edit", "static", 9, 11),
+      ("columba", "hamming", "dynamic", 9, 11), ("columba", "hamming", "static", 13, 15))
 for spec, metric, part, k, P in FM:
     small = spec in ("kuch2", "01*0")
     dev, orc = ca.Index(ix, kmer_size=4 if small else 10), op.OracleIndex(ix, kmer_size=4 if small else 10)
     if spec == "naive":
         reads = [g[p:p + int(rng.integers(8, 26))].tobytes() for p in rng.integers(0, len(g) - 30, N // 6)] + [b"ACGTN", b""][:1 + (metric == "edit")]
+    elif k >= 8:
+        reads = chunk(g, max(N // 8, 100), k, P, 0.0, seed=int(rng.integers(1 << 30)), lens=(60, 100, 150, 151, 250, 257, 321, 400, 480))
     else:
         reads = chunk(g, N, k, P, 0.0 if k == 0 else 0.02, seed=int(rng.integers(1 << 30)))
+    if True:
         if metric == "hamming":
             reads = [r for r in reads if len(r) > 0]
     t = time.time()
