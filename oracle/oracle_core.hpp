@@ -587,10 +587,14 @@ struct BitVectorsT {
     uint64_t score;
 };
 typedef BitVectorsT<uint64_t> BitVectors;
-template <typename W>
+// BLOCK: rows per block — the reference's is half the word (bitparallelmatrix.h:311).  Other values exist for ONE experiment
+// (tests/test_narrow_block_matrix.py): a 64-bit word with 16-row blocks holds the band of 13 errors by the reference's own bound
+// (MATRIX_MAX_ED = (64 - 16 - 2) / 3 = 15), and the question is whether such a matrix — what a device kernel would carry per node —
+// can stand in for the reference's 64- and 128-bit in-index matrices, predicate onlyVerticalGapsLeft included (`emulate`).
+template <typename W, uint32_t BLOCK = sizeof(W) * 4>
 class BitParallelEDT {
   public:
-    static const uint32_t WORD_SIZE = sizeof(W) * 8, BLOCK_SIZE = WORD_SIZE / 2;
+    static const uint32_t WORD_SIZE = sizeof(W) * 8, BLOCK_SIZE = BLOCK;
     static int popcountW(W x) { return __builtin_popcountll((uint64_t)x) + (sizeof(W) > 8 ? __builtin_popcountll((uint64_t)(x >> (WORD_SIZE / 2))) : 0); }
     static const uint32_t MATRIX_MAX_ED = (WORD_SIZE - BLOCK_SIZE - 2) / 3; // 10 (20)
     static const uint32_t LEFT = 2 * MATRIX_MAX_ED + 1;                    // 21 (41)
@@ -704,7 +708,26 @@ class BitParallelEDT {
         return score;
     }
     // bitparallelmatrix.h:651-665
+    // the predicate of the reference's matrix on words of `refWord` bits (64 or 128), evaluated on THIS matrix: HN of the columns
+    // i - Wv + 1 .. n - 1 all set.  Where the reference's shift count goes negative (be > refWord) its answer is `true` whatever HN
+    // holds (see onlyVerticalGapsLeft); where the last column lies beyond this matrix' word it lies beyond the band, and on a VALID
+    // row — the only rows the search asks about, indexinterface.cpp:545 — a run of decreasing values that ends there cannot exist.
+    uint32_t emulate = 0;
+    bool onlyVerticalGapsLeftAs(uint32_t i, uint32_t refWord) const {
+        const uint32_t refBlock = refWord / 2, refMaxED = (refWord - refBlock - 2) / 3, refLEFT = 2 * refMaxED + 1, refDIAG = 2 * refMaxED;
+        if (i + refLEFT < n) return false;
+        const uint32_t be_ref = refDIAG + n - (i / refBlock) * refBlock;
+        if (be_ref > refWord) return true;
+        const uint32_t r = i % BLOCK_SIZE;
+        const uint32_t bb = DIAG_R0 - Wv + r + 1; // column i - Wv + 1
+        const int be = (int)DIAG_R0 + (int)r + ((int)n - (int)i); // one past column n - 1
+        if (be > (int)WORD_SIZE) return false;
+        if (be <= (int)bb) return true;
+        const W mask = (be >= (int)WORD_SIZE ? ~(W)0 : (((W)1 << be) - (W)1)) & ~(((W)1 << bb) - (W)1);
+        return (~bv[i].HN & mask) == (W)0;
+    }
     bool onlyVerticalGapsLeft(uint32_t i) const {
+        if (emulate) return onlyVerticalGapsLeftAs(i, emulate & 0xFFu) != ((emulate >> 8) != 0); // (bit 8: inverted — the test's self-check)
         if (i + LEFT < n) return false;
         const uint32_t b = i / BLOCK_SIZE;
         const uint32_t r = i % BLOCK_SIZE;
@@ -811,6 +834,7 @@ class BitParallelEDT {
 };
 typedef BitParallelEDT<uint64_t> BitParallelED64;
 typedef BitParallelEDT<unsigned __int128> BitParallelED128;
+typedef BitParallelEDT<uint64_t, 16> BitParallelED64N; // (the narrow-block experiment)
 
 // ----------------------------------------------------------------------------
 // Search / SearchScheme (search.h:55-495, :509-757)

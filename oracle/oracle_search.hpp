@@ -402,10 +402,17 @@ template <class IX> class MatcherT {
         // construction; here read from the text the test attached to the adapter)
         if constexpr (RLC)
             if (!index.text) throw std::runtime_error("oracle: CIGARs on the b-move index need the text beside it (orc_move_attach_text)");
-        BitParallelED64 M;
-        M.setSequence(Substring(seq.data(), (len_t)seq.size(), 0, (len_t)seq.size(), FORWARD));
         Substring ref((const char*)index.text, index.textLength, t.range.b, t.range.e);
-        M.findCIGAR(ref, t.distance, t.cigar);
+        const Substring pat(seq.data(), (len_t)seq.size(), 0, (len_t)seq.size(), FORWARD);
+        if (t.distance <= BitParallelED64::MATRIX_MAX_ED) { // (indexinterface.h:976-982)
+            BitParallelED64 M;
+            M.setSequence(pat);
+            M.findCIGAR(ref, t.distance, t.cigar);
+        } else {
+            BitParallelED128 M;
+            M.setSequence(pat);
+            M.findCIGAR(ref, t.distance, t.cigar);
+        }
     }
     // IndexInterface::findSeqName (indexinterface.cpp:799-899); returns 0 FOUND, 1 FOUND_WITH_TRIMMING, 2 NOT_FOUND
     int findSeqName(BestOcc& o, len_t largestStratum, const std::string& pattern) {
@@ -666,6 +673,10 @@ template <class IX> class MatcherT {
     Strand strand = FORWARD_STRAND;
     std::vector<std::vector<FMPosExt>> stacks;
     std::vector<BitParallelED64> matrices;
+    std::vector<BitParallelED128> matrices128; // the parts of a search whose upper bound exceeds 10 (indexinterface.cpp:391-398)
+    std::vector<BitParallelED64N> matricesN;   // ORC_NARROW_BLOCKS=1: the narrow-block experiment (oracle_core.hpp)
+    const bool narrowBlocks = getenv("ORC_NARROW_BLOCKS") != nullptr;
+    const bool narrowBroken = narrowBlocks && std::string(getenv("ORC_NARROW_BLOCKS")) == "inverted";
     BitParallelED64 fullReadMatrices[2];
     BitParallelED128 fullReadMatrices128[2]; // in-text verification beyond the 64-bit matrix (fmindex.h:240-246)
 
@@ -848,9 +859,10 @@ template <class IX> class MatcherT {
     }
 
     // === edit-distance DFS (indexinterface.cpp:340-669, :1306-1325) ===
+    template <class MX>
     void goToInTextVerificationEdit(const FMPosExt& node, const Search& s,
                                     const std::vector<Substring>& parts, Occurrences& occ,
-                                    const Substring& pattern, len_t idx, BitParallelED64* bpED,
+                                    const Substring& pattern, len_t idx, MX* bpED,
                                     const FMOcc& sMatch, const std::vector<FMPosExt>& dOther,
                                     const std::vector<uint16_t>& iOther) {
         if constexpr (!RLC) { // (:345-348: the function does nothing in case of run-length compression)
@@ -870,21 +882,38 @@ template <class IX> class MatcherT {
         }
     }
 
+    // The reference selects the matrix PER PART: 64-bit words where the search's upper bound at this part is at most 10, its 128-bit
+    // matrix beyond (indexinterface.cpp:391-398); the function itself works on the IBitParallelED interface.
     void recApproxMatchEdit(const Search& s, const FMOcc& startMatch, Occurrences& occ,
                             const std::vector<Substring>& parts, int idx,
                             const std::vector<FMPosExt>& descPrevDir,
                             const std::vector<uint16_t>& initPrevDir,
                             const std::vector<FMPosExt>& descNotPrevDir,
                             const std::vector<uint16_t>& initNotPrevDir) {
+        const size_t matrixIdx = s.getPart(idx) + (s.getDirection(idx) == BACKWARD) * s.getNumParts();
+        if (narrowBlocks) { // (experiment: ONE narrow-block matrix type in place of both, answering the predicate as the part's own would)
+            if (matricesN.size() < matrices.size()) matricesN.resize(matrices.size());
+            matricesN[matrixIdx].emulate = (s.getUpperBound(idx) <= BitParallelED64::MATRIX_MAX_ED ? 64u : 128u) | (narrowBroken ? 256u : 0u);
+            recApproxMatchEditOn(&matricesN[matrixIdx], s, startMatch, occ, parts, idx, descPrevDir, initPrevDir, descNotPrevDir, initNotPrevDir);
+        } else if (s.getUpperBound(idx) <= BitParallelED64::MATRIX_MAX_ED) {
+            recApproxMatchEditOn(&matrices[matrixIdx], s, startMatch, occ, parts, idx, descPrevDir, initPrevDir, descNotPrevDir, initNotPrevDir);
+        } else {
+            if (matrices128.size() < matrices.size()) matrices128.resize(matrices.size());
+            recApproxMatchEditOn(&matrices128[matrixIdx], s, startMatch, occ, parts, idx, descPrevDir, initPrevDir, descNotPrevDir, initNotPrevDir);
+        }
+    }
+    template <class MX>
+    void recApproxMatchEditOn(MX* bpED, const Search& s, const FMOcc& startMatch, Occurrences& occ,
+                              const std::vector<Substring>& parts, int idx,
+                              const std::vector<FMPosExt>& descPrevDir,
+                              const std::vector<uint16_t>& initPrevDir,
+                              const std::vector<FMPosExt>& descNotPrevDir,
+                              const std::vector<uint16_t>& initNotPrevDir) {
         const Substring& p = parts[s.getPart(idx)];
         const len_t maxED = s.getUpperBound(idx);
         const Direction dirIdx = s.getDirection(idx);
         const bool dSwitch = s.getDirectionSwitch(idx);
         auto& stack = stacks[idx];
-        size_t matrixIdx = s.getPart(idx) + (dirIdx == BACKWARD) * s.getNumParts();
-        if (maxED > BitParallelED64::MATRIX_MAX_ED)
-            throw std::runtime_error("oracle: 128-bit matrix path not restated");
-        BitParallelED64* bpED = &matrices[matrixIdx];
 
         const std::vector<uint16_t>& initEds = dSwitch ? initNotPrevDir : initPrevDir;
         const std::vector<FMPosExt>& descendants = dSwitch ? descNotPrevDir : descPrevDir;
@@ -951,7 +980,8 @@ template <class IX> class MatcherT {
     }
 
     // indexinterface.cpp:529-561
-    bool branchAndBound(BitParallelED64* bpED, Cluster& cluster, const FMPosExt& currentNode,
+    template <class MX>
+    bool branchAndBound(MX* bpED, Cluster& cluster, const FMPosExt& currentNode,
                         const Search& s, len_t idx, const std::vector<Substring>& parts,
                         Occurrences& occ, const std::vector<uint16_t>& initOther,
                         const std::vector<FMPosExt>& descOther,
@@ -1104,7 +1134,12 @@ template <class IX> class MatcherT {
     // === naive backtracking (indexinterface.cpp:1055-1209) ===
     void approxMatchesNaive(const std::string& pattern, len_t maxED, Occurrences& occurrences) {
         matrices.assign(2, BitParallelED64());
-        BitParallelED64* matrix = &matrices.front();
+        matrices128.assign(2, BitParallelED128());
+        if (maxED > BitParallelED64::MATRIX_MAX_ED) approxMatchesNaiveOn(&matrices128.front(), pattern, maxED, occurrences); // (:1063)
+        else approxMatchesNaiveOn(&matrices.front(), pattern, maxED, occurrences);
+    }
+    template <class MX>
+    void approxMatchesNaiveOn(MX* matrix, const std::string& pattern, len_t maxED, Occurrences& occurrences) {
         setDirection(BACKWARD, true);
         Substring p(pattern.data(), (len_t)pattern.size(), 0, (len_t)pattern.size(), BACKWARD);
         matrix->setSequence(p);
@@ -1333,6 +1368,8 @@ template <class IX> class MatcherT {
         const std::vector<Search>& searches = strat.createSearches(k, exactMatchRanges);
         stacks.assign(numParts, {});
         matrices.assign(2 * parts.size(), BitParallelED64());
+        matrices128.assign(k > BitParallelED64::MATRIX_MAX_ED ? 2 * parts.size() : 0, BitParallelED128());
+        matricesN.assign(narrowBlocks ? 2 * parts.size() : 0, BitParallelED64N());
         for (const Search& s : searches) doRecSearch(s, parts, occs, exactMatchRanges);
     }
 

@@ -150,17 +150,20 @@ def cpu_world(oracle_built):
     return {"genome": g, "text": g.tobytes(), "orc": op.OracleIndex(ix), "orc4": op.OracleIndex(ix, kmer_size=4), "op": op}
 
 
-@pytest.mark.parametrize("spec,metric,partition,k", CONFIGS)
+# (11 ... 13 errors under edit distance: the oracle alone — the reference runs the parts whose upper bound exceeds 10 on its 128-bit
+# in-index matrix, indexinterface.cpp:391-398, which the device does not have yet)
+@pytest.mark.parametrize("spec,metric,partition,k", CONFIGS + [("columba", "edit", "dynamic", 9), ("columba", "edit", "dynamic", 11),
+                                                              ("columba", "edit", "uniform", 12), ("columba", "edit", "static", 13)])
 def test_oracle_is_sound_and_complete(cpu_world, gt, spec, metric, partition, k):
     import schemes_py as sp
     op = cpu_world["op"]
-    reads = _reads_for(cpu_world["genome"], k, 60, seed=500 + k)
+    reads = _reads_for(cpu_world["genome"], k, 60 if k <= 7 else 24, length=100 if k <= 7 else 150, seed=500 + k)
     reads += [b"N" * 60, cpu_world["text"][:100], cpu_world["text"][-100:], b"ACGT" * 20]
     st = op.OracleStrategy(sp.BY_NAME[spec], metric, partition)
     occ, offs, _ = op.match_batch(cpu_world["orc"], st, k, reads, threads=4)
     checked, loose = check_soundness(gt, cpu_world["text"], reads, occ, offs, k, metric)
     hits, chain = check_completeness(gt, cpu_world["text"], reads, occ, offs, k, metric)
-    assert checked > 40 and hits > 40
+    assert checked > (40 if k <= 7 else 20) and hits > (40 if k <= 7 else 20)
     assert chain * 50 <= hits  # the chain rule is the exception
 
 

@@ -1,0 +1,65 @@
+"""An experiment on the CPU oracle, kept as a test because the next step of the device build rests on its outcome.
+
+The reference runs the in-index matrix of a search part on 64-bit words where the part's upper bound is at most 10 and on its 128-bit
+words beyond (indexinterface.cpp:391-398).  A device kernel would rather carry ONE matrix per node: a 64-bit word with 16-row blocks
+holds the band of 13 errors by the reference's own bound (bitparallelmatrix.h:313 with BLOCK 16: (64 - 16 - 2) / 3 = 15).  Cells of at
+most maxED are the same in any matrix that contains the band, so valid rows, final-column values, cluster centres and first columns
+agree; the open question was `onlyVerticalGapsLeft`, which reads HN bits of cells that may exceed maxED and, in the reference, shifts by a
+negative count near the end of a block (a region where its answer is `true` whatever the bits hold).  With ORC_NARROW_BLOCKS=1 the
+oracle's search runs every part on BitParallelEDT<uint64_t, 16> and answers that predicate as the part's own matrix would
+(onlyVerticalGapsLeftAs); occurrences and every counter must equal the run on the reference's matrices."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+
+from columba_amd import indexbuild as ib, synth  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def world(oracle_built):
+    import oracle_py as op
+    g, starts = synth.genome_rep(seed=41, n=400_000, scale=2.0)
+    ix = ib.build_index(g.tobytes(), seq_starts=starts, device="cpu")
+    return {"g": g, "op": op, "orc": {sw: op.OracleIndex(ix, switch_point=sw) for sw in (0, 4)}}
+
+
+@pytest.mark.parametrize("partition,k,length,switch", [("dynamic", 5, 100, 4), ("dynamic", 8, 150, 4), ("uniform", 10, 150, 0), ("dynamic", 11, 150, 4),
+                                                       ("static", 12, 250, 0), ("dynamic", 13, 150, 0), ("uniform", 13, 400, 4),
+                                                       ("dynamic", 13, 480, 0), ("dynamic", 7, 60, 0)])
+def test_one_narrow_block_matrix_stands_in_for_both_reference_matrices(world, partition, k, length, switch):
+    import schemes_py as sp
+    op = world["op"]
+    reads = synth.sample_reads(world["g"], 400, length, seed=60 + k + length, n_frac=0.01, edit_choices=(0, 2, 5, 8, k - 1, k, k, k + 1))
+    reads += [world["g"][:length].tobytes(), world["g"][-length - 1:-1].tobytes(), b"N" * length]
+    st = op.OracleStrategy(sp.BY_NAME["columba"], "edit", partition)
+    os.environ.pop("ORC_NARROW_BLOCKS", None)
+    a_occ, a_off, a_cnt = op.match_batch(world["orc"][switch], st, k, reads, threads=8)
+    os.environ["ORC_NARROW_BLOCKS"] = "1"
+    try:
+        b_occ, b_off, b_cnt = op.match_batch(world["orc"][switch], st, k, reads, threads=8)
+    finally:
+        del os.environ["ORC_NARROW_BLOCKS"]
+    assert len(a_occ) > 300
+    assert np.array_equal(a_off, b_off) and np.array_equal(a_occ, b_occ)
+    assert a_cnt == b_cnt, {n: (a_cnt[n], b_cnt[n]) for n in a_cnt if a_cnt[n] != b_cnt[n]}
+
+
+def test_the_experiment_sees_the_predicate(world):
+    """self-check: with the predicate's answer inverted the runs differ — the comparison above does exercise it"""
+    import schemes_py as sp
+    op = world["op"]
+    reads = synth.sample_reads(world["g"], 300, 150, seed=7, n_frac=0.01, edit_choices=(0, 2, 5, 8, 11, 12))
+    st = op.OracleStrategy(sp.BY_NAME["columba"], "edit", "dynamic")
+    os.environ.pop("ORC_NARROW_BLOCKS", None)
+    _, _, a_cnt = op.match_batch(world["orc"][0], st, 12, reads, threads=8)
+    os.environ["ORC_NARROW_BLOCKS"] = "inverted"
+    try:
+        _, _, b_cnt = op.match_batch(world["orc"][0], st, 12, reads, threads=8)
+    finally:
+        del os.environ["ORC_NARROW_BLOCKS"]
+    assert a_cnt["NODE_COUNTER"] != b_cnt["NODE_COUNTER"]
