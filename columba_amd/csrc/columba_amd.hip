@@ -566,7 +566,8 @@ struct cmb_batch {
     // schemes with more than MAXP parts (the greedy schemes for 8 ... 13 errors): tables of MAXP_WIDE parts, run by the wide instances
     // of k_parts / k_exact / k_hbfs (Hamming distance; the edit-distance matcher stops at 7 errors)
     bool wide = false;
-    bool wideEdit = false; // edit distance 8 ... 10: wide records AND the wide layout of the filter keys
+    bool wideEdit = false; // edit distance 8 ... 13: wide records AND the wide layout of the filter keys
+    bool geoX = false;     // ... 11 ... 13: the in-index matrix with 16-row blocks (GeoX), the in-text matrix with 8-row blocks
     DevStrategyKT<MAXP_WIDE> hostStratW{};
     DevBuf<DevStrategyKT<MAXP_WIDE>> stratW;
     DevBuf<PartOutT<MAXP_WIDE>> partsW;
@@ -745,8 +746,7 @@ static int batchCreateOne(cmb_index* idx, const cmb_strategy* st, uint32_t max_d
             // edit distance beyond 7 errors: the in-index search runs up to 10 (the 64-bit in-index matrix, bitparallelmatrix.h:309-316; wide
             // record geometry GeoW); the bit-parallel in-text matrices stop at 7, candidates are verified by k_verify_wide
             b->wideEdit = st->metric == CMB_METRIC_EDIT && 3 * max_distance + 1 > MXW_LEFT;
-            if (b->wideEdit && max_distance > MX_MAX_ED)
-                return fail(CMB_ERR_UNSUPPORTED, "edit distance beyond 10 errors needs the 128-bit in-index matrix, which is not implemented");
+            b->geoX = b->wideEdit && max_distance > MX_MAX_ED; // (beyond the reference's 64-bit in-index matrix: dev_matrix.hpp, MXN_*)
             try {
                 b->wide = st->numPartsFor(max_distance) > (uint32_t)MAXP || b->wideEdit;
                 if (max_distance > 13) return fail(CMB_ERR_UNSUPPORTED, "more than 13 errors (MAX_K, definitions.h:50)");
@@ -1102,14 +1102,16 @@ static int batchRunOne(cmb_batch* b) {
                 N.nq = b->nvCnt.p;
                 const bool edit = b->metric == CMB_METRIC_EDIT;
                 hipLaunchKernelGGL(k_naive_start, dim3((tasks + 255) / 256), dim3(256), 0, s, ix->d, b->psel.p, b->offs.p, tasks,
-                                   b->k, edit ? 0u : 1u, N, q);
+                                   b->k, edit ? 0u : 1u, N, q, b->geoX ? 1u : 0u);
                 std::vector<uint32_t> hc(cntWords);
                 uint32_t pass = 0, peakQ = 0;
                 bool drained = false;
+                auto kNaive = edit ? k_naive_pass<true, false> : k_naive_pass<false, false>;
+                if (b->geoX) kNaive = k_naive_pass<true, true>;
                 while (!drained && pass < maxPassN) {
                     const uint32_t upTo = std::min(pass + 16u, maxPassN);
                     for (; pass < upTo; pass++)
-                        hipLaunchKernelGGL(edit ? k_naive_pass<true> : k_naive_pass<false>, dim3(BFS_GRID), dim3(256), 0, s, ix->d, N,
+                        hipLaunchKernelGGL(kNaive, dim3(BFS_GRID), dim3(256), 0, s, ix->d, N,
                                            pass, b->offs.p, b->gw, b->G.p, b->seq.p, b->maxLen, b->k, q);
                     HIPCHK(hipMemcpyAsync(hc.data(), b->nvCnt.p, cntWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                     HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
@@ -1160,7 +1162,8 @@ static int batchRunOne(cmb_batch* b) {
                         if (b->bfsEv[j].n < evU4 * b->bfsEvCap) b->bfsEv[j].alloc(evU4 * b->bfsEvCap);
                     }
                     if (b->bfsF.n < F_U4 * b->bfsFCap) b->bfsF.alloc(F_U4 * b->bfsFCap);
-                    const uint32_t ctxU4 = ctxU4For(b->maxLen);
+                    // (GeoX: blocks of 16 rows — up to 32 of them for 480 + 26 rows, two uint4 of match words each)
+                    const uint32_t ctxU4 = b->geoX ? CTX_U4_X : ctxU4For(b->maxLen);
                     if (b->bfsC.n < (size_t)ctxU4 * b->bfsCCap) b->bfsC.alloc((size_t)ctxU4 * b->bfsCCap);
                     if (b->bfsA.n < b->bfsACap) b->bfsA.alloc(b->bfsACap);
                     const size_t cntWords = 2 * ((size_t)maxPass + 2) + 4;
@@ -1181,7 +1184,7 @@ static int batchRunOne(cmb_batch* b) {
                     B.fCap = (uint32_t)std::min<size_t>(b->bfsF.n / F_U4, 0xFFFFFFF0u);
                     B.cCap = (uint32_t)std::min<size_t>(b->bfsC.n / ctxU4, 0xFFFFFFF0u);
                     B.ctxU4 = ctxU4;
-                    B.ctxMblk = ctxMblkFor(b->maxLen);
+                    B.ctxMblk = b->geoX ? CTX_MBLK_X : ctxMblkFor(b->maxLen);
                     B.aCap = (uint32_t)std::min<size_t>(b->bfsA.n, 0xFFFFFFF0u);
                     B.chain = getenv("CMB_BFS_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("CMB_BFS_CHAIN"))) : BFS_CHAIN;
                     B.gridX = getenv("CMB_BFS_GRID") ? (uint32_t)std::min<int>(BFS_GRID, std::max(1, atoi(getenv("CMB_BFS_GRID")))) : BFS_GRID_X;
@@ -1190,7 +1193,10 @@ static int batchRunOne(cmb_batch* b) {
                     B.ne = b->bfsCnt.p + (maxPass + 2);
                     B.pool = b->bfsCnt.p + 2 * (maxPass + 2);
                     B.blockCnt = b->bfsBlockCnt.p;
-                    if (b->wide)
+                    if (b->geoX)
+                        hipLaunchKernelGGL(k_bfs_start<GeoX>, dim3(std::min<uint32_t>((nDfs + 255) / 256, BFS_GRID)), dim3(256), 0, s,
+                                           ix->d, b->stratW.p, B, b->dfs.p, nDfs, b->offs.p, b->gw, b->G.p, b->partsW.p, q);
+                    else if (b->wide)
                         hipLaunchKernelGGL(k_bfs_start<GeoW>, dim3(std::min<uint32_t>((nDfs + 255) / 256, BFS_GRID)), dim3(256), 0, s,
                                            ix->d, b->stratW.p, B, b->dfs.p, nDfs, b->offs.p, b->gw, b->G.p, b->partsW.p, q);
                     else
@@ -1203,7 +1209,10 @@ static int batchRunOne(cmb_batch* b) {
                     while (!drained && pass < maxPass) {
                         const uint32_t upTo = std::min(pass + CHECK, maxPass);
                         for (; pass < upTo; pass++) {
-                            if (b->wide)
+                            if (b->geoX)
+                                hipLaunchKernelGGL(k_bfs_pass<GeoX>, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->stratW.p, B,
+                                                   pass, b->offs.p, b->gw, b->G.p, b->partsW.p, q);
+                            else if (b->wide)
                                 hipLaunchKernelGGL(k_bfs_pass<GeoW>, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->stratW.p, B,
                                                    pass, b->offs.p, b->gw, b->G.p, b->partsW.p, q);
                             else
@@ -1417,13 +1426,16 @@ static int batchRunOne(cmb_batch* b) {
                         if (b->dpList.n < listNeed) b->dpList.alloc(listNeed + listNeed / 8);
                         if (b->dpWork.n < 4) b->dpWork.alloc(4);
                         HIPCHK(hipMemsetAsync(b->dpWork.p, 0, 4 * sizeof(uint32_t), s));
-                        hipLaunchKernelGGL(k_wide_filter, dim3(fGrid), dim3(256), 0, s, ix->d, b->offs.p, b->G.p, b->gw, b->vkeysA.p, b->vcounts.p, nRuns,
+                        auto kFilter = k_wide_filter<WxTen>;
+                        auto kWide = k_verify_wide<true, WxTen>;
+                        if (b->geoX) kFilter = k_wide_filter<WxThirteen>, kWide = k_verify_wide<true, WxThirteen>;
+                        hipLaunchKernelGGL(kFilter, dim3(fGrid), dim3(256), 0, s, ix->d, b->offs.p, b->G.p, b->gw, b->vkeysA.p, b->vcounts.p, nRuns,
                                            b->dpWork.p, b->dpList.p, (uint32_t)std::min<size_t>(b->dpList.n, 0xFFFFFFF0u), q);
                         const uint32_t slotBytes = (vwRows(b->maxLen) + 1u) * VW_ROW_BYTES;
                         // (six wavefronts per SIMD: 1024 SIMDs x 6 x 64 lanes — forward pass and traceback wait for memory; a slot is 3 - 8 KB)
                         const uint32_t dSlots = std::min<uint32_t>(((nRuns + 255) / 256) * 256, getenv("CMB_VW_SLOTS") ? (uint32_t)atoi(getenv("CMB_VW_SLOTS")) : 256u * 1536u);
                         if (b->dpSlab.n < (size_t)slotBytes * dSlots) b->dpSlab.alloc((size_t)slotBytes * dSlots);
-                        hipLaunchKernelGGL(k_verify_wide<true>, dim3(dSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->maxLen, b->seq.p, b->G.p, b->gw,
+                        hipLaunchKernelGGL(kWide, dim3(dSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->maxLen, b->seq.p, b->G.p, b->gw,
                                            (const uint4*)nullptr, (uint32_t)std::min<size_t>(b->dpList.n, 0xFFFFFFF0u), b->vkeysA.p, b->vcounts.p, b->dpList.p, b->dpWork.p + 1, b->dpSlab.p, slotBytes, q);
                         if (verbose) {
                             uint32_t hw[2];
@@ -2094,7 +2106,7 @@ extern "C" int cmb_verify_batch_staged(cmb_index* idx, const char* pattern, uint
                                        uint64_t out_cap, uint64_t* n_out, uint64_t* counters) {
     if (!idx || !pattern || (n && !starts) || !n_out) return fail(CMB_ERR_INVALID, "null argument");
     if (plen == 0 || plen > (uint32_t)MAX_READ) return fail(CMB_ERR_UNSUPPORTED, "pattern length not supported");
-    if (max_ed == 0 || max_ed > MX_MAX_ED || min_ed > 15) return fail(CMB_ERR_UNSUPPORTED, "more than 10 errors"); // (8 ... 10: k_wide_filter + k_verify_wide)
+    if (max_ed == 0 || max_ed > MXN_MAX_ED || min_ed > 15) return fail(CMB_ERR_UNSUPPORTED, "more than 13 errors"); // (8 ... 13: k_wide_filter + k_verify_wide)
     if (n >= (1ull << 31)) return fail(CMB_ERR_INVALID, "too many start positions");
     for (uint64_t i = 0; i < n; i++)
         if (starts[i] > idx->d.n) return fail(CMB_ERR_INVALID, "start position beyond the text");
@@ -2159,7 +2171,7 @@ static int verifyDirect(cmb_index* idx, const char* pattern, uint32_t plen, cons
     if (!idx || !pattern || (n && !starts) || !n_out) return fail(CMB_ERR_INVALID, "null argument");
     if (plen == 0 || plen > (uint32_t)MAX_READ) return fail(CMB_ERR_UNSUPPORTED, "pattern length not supported");
     const bool dp = 3 * max_ed + 1 > MXW_LEFT; // beyond 7 errors: k_verify_wide (the band does not fit the bit-parallel in-text matrices)
-    if (max_ed > MX_MAX_ED || min_ed > 15) return fail(CMB_ERR_UNSUPPORTED, "more than 10 errors");
+    if (max_ed > MXN_MAX_ED || min_ed > 15) return fail(CMB_ERR_UNSUPPORTED, "more than 13 errors");
     for (uint64_t i = 0; i < n; i++)
         if (starts[i] > idx->d.n) return fail(CMB_ERR_INVALID, "start position beyond the text");
     try {
@@ -2216,7 +2228,9 @@ static int verifyDirect(cmb_index* idx, const char* pattern, uint32_t plen, cons
             const uint32_t slotBytes = (vwRows(mlen) + 1u) * VW_ROW_BYTES;
             const uint32_t dSlots = (uint32_t)std::min<uint64_t>(((n + 255) / 256) * 256, 256u * 64u);
             slab.alloc((size_t)slotBytes * dSlots);
-            hipLaunchKernelGGL(k_verify_wide<false>, dim3(dSlots / 256), dim3(256), 0, 0, idx->d, offs.p, mlen, seq.p, G.p, gw, items.p, (uint32_t)n,
+            auto kWide = k_verify_wide<false, WxTen>;
+            if (max_ed > MX_MAX_ED) kWide = k_verify_wide<false, WxThirteen>;
+            hipLaunchKernelGGL(kWide, dim3(dSlots / 256), dim3(256), 0, 0, idx->d, offs.p, mlen, seq.p, G.p, gw, items.p, (uint32_t)n,
                                (const unsigned long long*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, slab.p,
                                slotBytes, q);
             HIPCHK(hipDeviceSynchronize());
@@ -2272,7 +2286,7 @@ extern "C" int cmb_cigar_windows(cmb_index* idx, const char* pattern, uint32_t p
         if (ends[i] - begins[i] > plen + distances[i]) return fail(CMB_ERR_INVALID, "text window longer than an alignment within the distance");
         maxD = std::max(maxD, distances[i]);
     }
-    if (maxD > MX_MAX_ED) return fail(CMB_ERR_UNSUPPORTED, "more than 10 errors"); // (fixed start: the band of 2 maxD + 1 columns fits the in-text matrix)
+    if (maxD > MXN_MAX_ED) return fail(CMB_ERR_UNSUPPORTED, "more than 13 errors"); // (fixed start: the band of 2 maxD + 1 <= 27 columns fits the in-text matrix)
     if (stride < 2 * maxD + 3) return fail(CMB_ERR_INVALID, "stride must be at least 2 * distance + 3");
     if (n == 0) return CMB_OK;
     try {
@@ -2387,10 +2401,10 @@ static bool trimOccurrence(cmb_index* idx, const std::string& seq, uint32_t larg
     o.aln.seq_id = seqId;
     o.aln.seq_begin = bestO->begin - sp[seqId];
     o.aln.spans = 2; // found with trimming
-    uint16_t opsBuf[2 * 10 + 3];
+    uint16_t opsBuf[2 * 13 + 3];
     uint32_t nOps = 0;
     o.ops.clear();
-    if (cmb_cigar_windows(idx, seq.data(), (uint32_t)seq.size(), &o.occ.begin, &o.occ.end, &o.occ.distance, 1, opsBuf, 2 * 10 + 3,
+    if (cmb_cigar_windows(idx, seq.data(), (uint32_t)seq.size(), &o.occ.begin, &o.occ.end, &o.occ.distance, 1, opsBuf, 2 * 13 + 3,
                           &nOps) != CMB_OK)
         return false;
     o.ops.assign(opsBuf, opsBuf + nOps);
@@ -2802,8 +2816,8 @@ extern "C" int cmb_match_best(cmb_index* idx, const cmb_strategy* st, uint32_t x
         r.ops.resize(nOps ? nOps : 1);
         return cmb_batch_alignments(b, r.al.data(), r.al.size(), r.ops.data(), r.ops.size(), &nOps);
     };
-    // (edit distance: the 64-bit in-index matrix; Hamming distance: MAX_K)
-    return matchBestWith(idx, st, st->metric == CMB_METRIC_EDIT ? MX_MAX_ED : 13u, true, run, x, min_identity, seqs, offs, n_reads, out);
+    // (MAX_K, definitions.h:50)
+    return matchBestWith(idx, st, 13u, true, run, x, min_identity, seqs, offs, n_reads, out);
 }
 // The same on the b-move index (the reference's RUN_LENGTH_COMPRESSION build runs the same matchApproxBestPlusX): the strata are
 // b-move batches, CIGARs and trimming read the matched string of an occurrence from the text beside the index (cmb_move_attach_text).

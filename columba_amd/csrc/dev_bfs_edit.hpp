@@ -44,6 +44,8 @@ constexpr uint32_t CTX_M = 10;    // uint4 index of the match words of row block
 constexpr uint32_t CTX_MBLK = 11; // row blocks with cached match words (rows < 352) in a context of CTX_U4
 // longer reads (up to MAX_READ): contexts of 48 uint4 with the match words of 16 row blocks (rows < 512)
 constexpr uint32_t CTX_U4_LONG = 48, CTX_MBLK_LONG = 16;
+// GeoX (11 ... 13 errors: 16-row blocks): 80 uint4 with the match words of 35 row blocks (rows < 560)
+constexpr uint32_t CTX_U4_X = 80, CTX_MBLK_X = 35;
 __host__ __device__ inline uint32_t ctxU4For(uint32_t maxLen) { return maxLen > 320u ? CTX_U4_LONG : CTX_U4; }
 __host__ __device__ inline uint32_t ctxMblkFor(uint32_t maxLen) { return maxLen > 320u ? CTX_MBLK_LONG : CTX_MBLK; }
 constexpr uint32_t F_U4 = 2;      // uint4 per F record: {ranges} {depth | c << 16, parent, reported, -}
@@ -190,15 +192,44 @@ __device__ __forceinline__ void packStore(uint4* p, size_t stride, const EdPackW
 // The two geometries of the frontier's records: GeoN is the common path (tables of MAXP parts, 24 cells of 5 bits: k <= 7) — every
 // kernel of the headline path is the GeoN instance, with the registers and record sizes it always had; GeoW: tables of MAXP_WIDE parts,
 // 32 cells of 6 bits (k = 8 ... 10), one more plane per node and one more uint4 per event.
-struct GeoN {
+// The in-index matrix of a geometry: the reference's 64-bit matrix (32-row blocks: up to 10 errors), or — GeoX, 11 ... 13 errors — the
+// 64-bit matrix with 16-row blocks that stands in for the reference's 64- AND 128-bit matrices (dev_matrix.hpp: MXN_*).
+struct MxRef64 {
+    static constexpr uint32_t BLOCK = MX_BLOCK, LEFT = MX_LEFT, DIAG = MX_DIAG;
+    static __device__ __forceinline__ bool row(const MatGeom& g, uint32_t i, uint64_t M, uint64_t& HP, uint64_t& HN, uint64_t& D0, uint64_t& RAC,
+                                               uint32_t& sc) {
+        return computeRow(g, i, M, HP, HN, D0, RAC, sc);
+    }
+    static __device__ __forceinline__ uint32_t cell(uint32_t i, uint32_t j, uint64_t HP, uint64_t HN, uint32_t sc) { return cellAt(i, j, HP, HN, sc); }
+    static __device__ __forceinline__ bool ovgl(const MatGeom& g, uint32_t i, uint64_t HN) { return onlyVerticalGapsLeft(g, i, HN); }
+};
+struct MxNarrow {
+    static constexpr uint32_t BLOCK = MXN_BLOCK, LEFT = MXN_LEFT, DIAG = MXN_DIAG;
+    static __device__ __forceinline__ bool row(const MatGeom& g, uint32_t i, uint64_t M, uint64_t& HP, uint64_t& HN, uint64_t& D0, uint64_t& RAC,
+                                               uint32_t& sc) {
+        return computeRowWide<BLOCK, DIAG>(g, i, M, HP, HN, D0, RAC, sc); // (the walk to the rightmost active column spans up to 39 columns)
+    }
+    static __device__ __forceinline__ uint32_t cell(uint32_t i, uint32_t j, uint64_t HP, uint64_t HN, uint32_t sc) {
+        return cellAt<BLOCK, DIAG>(i, j, HP, HN, sc);
+    }
+    static __device__ __forceinline__ bool ovgl(const MatGeom& g, uint32_t i, uint64_t HN) { // (as the part's own matrix would answer)
+        return onlyVerticalGapsLeftAs<BLOCK, DIAG>(g, i, HN, g.maxED <= MX_MAX_ED ? 64u : 128u);
+    }
+};
+struct GeoN : MxRef64 {
     static constexpr int MP = MAXP;
     typedef EdPack Pack;
     static constexpr uint32_t CELLS = 24, PK_U4 = 1, ED_MAX = 31;
 };
-struct GeoW {
+struct GeoW : MxRef64 {
     static constexpr int MP = MAXP_WIDE;
     typedef EdPackW Pack;
     static constexpr uint32_t CELLS = 32, PK_U4 = 2, ED_MAX = 63;
+};
+struct GeoX : MxNarrow { // 11 ... 13 errors: final columns of up to 3 * 13 + 1 = 40 cells (values up to 13 + 39)
+    static constexpr int MP = MAXP_WIDE;
+    typedef EdPackW Pack;
+    static constexpr uint32_t CELLS = 40, PK_U4 = 2, ED_MAX = 63;
 };
 
 // block-wide exclusive prefix sum + ONE atomic for the whole block.  Every thread of the (256-thread) block
@@ -301,7 +332,7 @@ struct ChildState {
     uint32_t sc, aux; // aux: final-column distance of the child (needF) or in-text start difference (KIND_ITEMS)
 };
 // kind of child `ch` of `parent` at row `row1` | needF << 2 | capacity problem << 3; FULL: also its state
-template <bool FULL, uint32_t EDMAX = 31u>
+template <bool FULL, class Geo = GeoN>
 __device__ __forceinline__ uint32_t evalChild(const DevIndex& ix, int md, const RangePair& parent, uint32_t ch,
                                               const uint32_t Rb[4], const uint32_t Re[4], uint32_t db, uint32_t de,
                                               const ExpandCtx& e, uint32_t row1, bool inFC, uint64_t M, uint64_t pHP,
@@ -311,21 +342,22 @@ __device__ __forceinline__ uint32_t evalChild(const DevIndex& ix, int md, const 
     if (!nonEmpty) return KIND_NONE;
     uint64_t HP = pHP, HN = pHN, RAC = pRAC, D0;
     uint32_t sc = score;
-    const bool valid = computeRow(e.g, row1, M, HP, HN, D0, RAC, sc);
+    constexpr uint32_t EDMAX = Geo::ED_MAX;
+    const bool valid = Geo::row(e.g, row1, M, HP, HN, D0, RAC, sc);
     if (!valid && !inFC) return KIND_NONE; // pruned when popped (branchAndBound returns true, :560)
     uint32_t res = KIND_NODE, aux = 0;
     if (inFC) {
-        const uint32_t ed = cellAt(row1, e.g.n - 1, HP, HN, sc);
+        const uint32_t ed = Geo::cell(row1, e.g.n - 1, HP, HN, sc);
         aux = min(ed, EDMAX);
         res |= 4u;
         if (ed > EDMAX) res |= 8u;
-        if (!valid || onlyVerticalGapsLeft(e.g, row1, HN)) res = (res & ~3u) | KIND_EVENT;
+        if (!valid || Geo::ovgl(e.g, row1, HN)) res = (res & ~3u) | KIND_EVENT;
     }
     if ((res & 3u) == KIND_NODE && child.sa.width() <= e.switchPoint && e.itMode != 0) { // goToInTextVerificationEdit (:340-375)
         uint32_t startDiff = e.itStart;
         if (e.itMode == 2) {
             const uint32_t col = e.g.firstColumn(row1);
-            startDiff -= col + cellAt(row1, col, HP, HN, sc);
+            startDiff -= col + Geo::cell(row1, col, HP, HN, sc);
         }
         aux = startDiff;
         res = (res & 8u) | KIND_ITEMS; // (a child that leaves the index needs no F record)
@@ -387,7 +419,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
             uint4 rk[4];
             issueRanks(ix, md, parent, rk);
             const uint4* Cx = B.C + (size_t)CMB_IDX(ctx, B.cCap, 1) * B.ctxU4;
-            blk = (row + 1) / MX_BLOCK;
+            blk = (row + 1) / Geo::BLOCK;
             const uint4 hot = Cx[CTX_HOT]; // everything the expansion needs of its context, in ONE 16-byte request
             const uint4 mA = Cx[CTX_M + 2 * blk], mB = Cx[CTX_M + 1 + 2 * blk];
             {
@@ -450,7 +482,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
                 for (uint32_t ch = 1; ch <= 4; ch++) {
                     bool nonEmpty;
                     ChildState cs;
-                    const uint32_t k4 = evalChild<false, Geo::ED_MAX>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, ldsM[ch - 1][tid], pHP,
+                    const uint32_t k4 = evalChild<false, Geo>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, ldsM[ch - 1][tid], pHP,
                                                          pHN, 1ull << pRac, score, nonEmpty, cs);
                     nChildren += nonEmpty ? 1u : 0u;
                     if (k4 & 8u) flags |= FLAG_CAPACITY;
@@ -466,12 +498,12 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
                 ldsCnt[0][tid] += nChildren;
                 // exactly one child, a plain node, with rows left in this matrix block: keep walking
                 const bool single = nOut == 1u && (kinds == 0x1u || kinds == 0x10u || kinds == 0x100u || kinds == 0x1000u);
-                if (single && step + 1u < B.chain && (row1 + 1u) / MX_BLOCK == blk) {
+                if (single && step + 1u < B.chain && (row1 + 1u) / Geo::BLOCK == blk) {
                     const uint32_t ch = ((31u - (uint32_t)__clz(kinds)) >> 2) + 1u;
                     const uint64_t M = ch == 1 ? ldsM[0][tid] : ch == 2 ? ldsM[1][tid] : ch == 3 ? ldsM[2][tid] : ldsM[3][tid];
                     bool nonEmpty;
                     ChildState one;
-                    (void)evalChild<true, Geo::ED_MAX>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, M, pHP, pHN, 1ull << pRac, score,
+                    (void)evalChild<true, Geo>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, M, pHP, pHN, 1ull << pRac, score,
                                           nonEmpty, one);
                     parent = one.r;
                     score = one.sc;
@@ -537,7 +569,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
                 if (kd == KIND_NONE) continue;
                 bool nonEmpty;
                 ChildState cs;
-                (void)evalChild<true, Geo::ED_MAX>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, ldsM[ch - 1][tid], pHP, pHN, 1ull << pRac,
+                (void)evalChild<true, Geo>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, ldsM[ch - 1][tid], pHP, pHN, 1ull << pRac,
                                       score, nonEmpty, cs);
                 const bool wantF = (kinds >> (4 * (ch - 1) + 2)) & 1u;
                 const uint4 cr = make_uint4(cs.r.sa.b, cs.r.sa.e, cs.r.rev.b, cs.r.rev.e);
@@ -950,10 +982,10 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyKT<Geo::MP>* __restric
             MatGeom g;
             uint64_t HP, HN, RAC;
             uint32_t score;
-            initMatrix(g, xLen, maxEDn, first, lastI, nSrcInit ? il : nullptr, increase, nInit, HP, HN, RAC, score);
+            initMatrix<Geo::LEFT, Geo::DIAG>(g, xLen, maxEDn, first, lastI, nSrcInit ? il : nullptr, increase, nInit, HP, HN, RAC, score);
             const uint32_t clSize = g.sfc();
-            const uint32_t nBlk = (g.m - 1) / MX_BLOCK + 1;
-            if (g.Wv > 2 * MX_MAX_ED || clSize > ED_CELLS || nBlk > B.ctxMblk || g.m > 0xFFFFu) {
+            const uint32_t nBlk = (g.m - 1) / Geo::BLOCK + 1;
+            if (g.Wv >= Geo::LEFT || clSize > ED_CELLS || nBlk > B.ctxMblk || g.m > 0xFFFFu) {
                 flags |= FLAG_CAPACITY;
             } else {
                 // in-text switch parameters of the phase (goToInTextVerificationEdit, :340-375)
@@ -999,8 +1031,8 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyKT<Geo::MP>* __restric
                 const uint32_t* Gs[4]; // the bit-strings of A, C, G, T for this read x strand and direction
                 for (uint32_t c4 = 0; c4 < 4; c4++) Gs[c4] = gString(G, gw, rsId, (uint32_t)useRev, c4);
                 for (uint32_t b = 0; b < nBlk; b++) {
-                    const uint64_t a = matchWord(Gs[0], xOff, xLen, b), c = matchWord(Gs[1], xOff, xLen, b);
-                    const uint64_t gg = matchWord(Gs[2], xOff, xLen, b), t = matchWord(Gs[3], xOff, xLen, b);
+                    const uint64_t a = matchWord<Geo::LEFT, Geo::BLOCK>(Gs[0], xOff, xLen, b), c = matchWord<Geo::LEFT, Geo::BLOCK>(Gs[1], xOff, xLen, b);
+                    const uint64_t gg = matchWord<Geo::LEFT, Geo::BLOCK>(Gs[2], xOff, xLen, b), t = matchWord<Geo::LEFT, Geo::BLOCK>(Gs[3], xOff, xLen, b);
                     Cx[CTX_M + 2 * b] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)c, (uint32_t)(c >> 32));
                     Cx[CTX_M + 1 + 2 * b] = make_uint4((uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)t, (uint32_t)(t >> 32));
                 }
@@ -1008,7 +1040,7 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyKT<Geo::MP>* __restric
                 EdPack pk{};
                 uint32_t fcCur = BFS_NONE;
                 if (g.inFinalColumn(0)) {
-                    const uint32_t e0 = cellAt(0, xLen, HP, HN, score);
+                    const uint32_t e0 = Geo::cell(0, xLen, HP, HN, score);
                     if (e0 > ED_MAX) flags |= FLAG_CAPACITY;
                     edPut(pk, 0, min(e0, ED_MAX));
                     uint4* Fr = B.F + (size_t)CMB_IDX(fNext, B.fCap, 21) * FU;
@@ -1030,13 +1062,13 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyKT<Geo::MP>* __restric
                         const uint32_t meta = dl[DU * j + PU].x;
                         const uint32_t depth = meta & 0xFFFFu, ch = (meta >> 16) & 0xFFu;
                         if (depth > maxRow) break;
-                        const uint64_t M = matchWord(gString(G, gw, rsId, (uint32_t)useRev, ch - 1u), xOff, xLen, depth / MX_BLOCK);
+                        const uint64_t M = matchWord<Geo::LEFT, Geo::BLOCK>(gString(G, gw, rsId, (uint32_t)useRev, ch - 1u), xOff, xLen, depth / Geo::BLOCK);
                         uint64_t D0;
-                        const bool valid = computeRow(g, depth, M, HP, HN, D0, RAC, score);
+                        const bool valid = Geo::row(g, depth, M, HP, HN, D0, RAC, score);
                         cRows++;
                         if (g.inFinalColumn(depth)) {
                             const uint32_t cellJ = clSize + depth - g.m;
-                            const uint32_t e = cellAt(depth, g.n - 1, HP, HN, score);
+                            const uint32_t e = Geo::cell(depth, g.n - 1, HP, HN, score);
                             if (e > ED_MAX) flags |= FLAG_CAPACITY;
                             edPut(pk, cellJ, min(e, ED_MAX));
                             uint4* Fr = B.F + (size_t)CMB_IDX(fNext, B.fCap, 22) * FU;
@@ -1044,7 +1076,7 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyKT<Geo::MP>* __restric
                             for (uint32_t u = 0; u < PU; u++) Fr[u] = dl[DU * j + u];
                             Fr[PU] = make_uint4(depth | (ch << 16), fcCur, 0u, 0u);
                             fcCur = fNext++;
-                            if (!valid || onlyVerticalGapsLeft(g, depth, HN)) { // goDeeper, then `return` (:472-477)
+                            if (!valid || Geo::ovgl(g, depth, HN)) { // goDeeper, then `return` (:472-477)
                                 interrupted = true;
                                 live = false;
                                 break;

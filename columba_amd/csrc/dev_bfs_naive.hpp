@@ -12,6 +12,7 @@
 // order, so the frontier advances one row per pass like the other two searches.  A node is (ranges, read x strand,
 // row, matrix row state | mismatches).  Reads that take this path are marked by k_parts (psel bit 7).
 #pragma once
+#include <type_traits>
 // (included by kernels.hpp after dev_bfs_hamming.hpp)
 
 namespace cmb {
@@ -27,7 +28,7 @@ struct NaiveBufs {
 // (bitparallelmatrix.cpp:77-123: Wv = Wh = maxED, score 0)
 __global__ void __launch_bounds__(256)
 k_naive_start(DevIndex ix, const uint8_t* __restrict__ psel, const uint64_t* __restrict__ offs, uint32_t tasks,
-              uint32_t k, uint32_t hamming, NaiveBufs B, Queues q) {
+              uint32_t k, uint32_t hamming, NaiveBufs B, Queues q, uint32_t narrow = 0 /* the matrix of 11 ... 13 errors (MXN_*) */) {
     const uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
     bool root = rs < tasks && (psel[rs] & 0x80u) != 0u;
     if (root && hamming && offs[(rs >> 1) + 1] == offs[rs >> 1]) root = false; // (the reference indexes pattern[-1]: no defined result)
@@ -38,9 +39,9 @@ k_naive_start(DevIndex ix, const uint8_t* __restrict__ psel, const uint64_t* __r
         atomicOr(&q.cnt[3], (uint32_t)FLAG_NAIVE_Q);
         return;
     }
-    const uint64_t HP0 = (~0ull) << MX_LEFT;
+    const uint64_t HP0 = (~0ull) << (narrow ? MXN_LEFT : MX_LEFT);
     B.Q[0][o] = make_uint4(0u, ix.n, 0u, ix.n);
-    B.Q[0][(size_t)B.qCap + o] = make_uint4(rs, 0u, MX_DIAG + k, 0u);
+    B.Q[0][(size_t)B.qCap + o] = make_uint4(rs, 0u, (narrow ? MXN_DIAG : MX_DIAG) + k, 0u);
     B.Q[0][(size_t)2 * B.qCap + o] = make_uint4((uint32_t)HP0, (uint32_t)(HP0 >> 32), (uint32_t)~HP0, (uint32_t)(~HP0 >> 32));
 }
 
@@ -55,10 +56,11 @@ __device__ __forceinline__ bool naiveStopped(const Queues& q) {
     return stopWord != 0u;
 }
 
-template <bool EDIT>
+template <bool EDIT, bool NARROW = false /* the matrix of 11 ... 13 errors: 16-row blocks (dev_matrix.hpp: MXN_*) */>
 __global__ void __launch_bounds__(256)
 k_naive_pass(DevIndex ix, NaiveBufs B, uint32_t pass, const uint64_t* __restrict__ offs, uint32_t gw,
              const uint32_t* __restrict__ G, const uint8_t* __restrict__ seq, uint32_t maxLen, uint32_t k, Queues q) {
+    using Mx = typename std::conditional<NARROW, MxNarrow, MxRef64>::type;
     __shared__ uint32_t sh[4][5];
     if (naiveStopped(q)) return;
     const uint32_t nIn = min(B.nq[pass], B.qCap);
@@ -110,10 +112,10 @@ k_naive_pass(DevIndex ix, NaiveBufs B, uint32_t pass, const uint64_t* __restrict
                     cRows++;
                     uint64_t HP = pHP, HN = pHN, D0, RAC = 1ull << rac;
                     uint32_t sc = score;
-                    const uint64_t M = matchWord(gString(G, gw, rsId, 1u, ch - 1u), 0u, len, row1 / MX_BLOCK);
-                    if (!computeRow(g, row1, M, HP, HN, D0, RAC, sc)) continue; // backtrack (:1104)
+                    const uint64_t M = matchWord<Mx::LEFT, Mx::BLOCK>(gString(G, gw, rsId, 1u, ch - 1u), 0u, len, row1 / Mx::BLOCK);
+                    if (!Mx::row(g, row1, M, HP, HN, D0, RAC, sc)) continue; // backtrack (:1104)
                     if (g.inFinalColumn(row1)) {
-                        const uint32_t d = cellAt(row1, len, HP, HN, sc);
+                        const uint32_t d = Mx::cell(row1, len, HP, HN, sc);
                         if (d <= k) {
                             kd |= 4u;
                             cDist[ch - 1] = d;

@@ -45,16 +45,13 @@ __device__ __forceinline__ const uint32_t* gString(const uint32_t* G, uint32_t g
 // `xOff` of G (G = forward bit-string for FORWARD parts, reversed-read bit-string for BACKWARD
 // parts).  Bit t of block b stands for column index j = t - LEFT + 32 b of X; the LEFT low bits of
 // block 0 are forced to one (bitparallelmatrix.cpp:44-47); bits of columns >= xLen are zero.
-template <uint32_t LEFT = MX_LEFT>
+template <uint32_t LEFT = MX_LEFT, uint32_t BLOCK = MX_BLOCK>
 __device__ __forceinline__ uint64_t matchWord(const uint32_t* G, uint32_t xOff, uint32_t xLen, uint32_t b) {
-    const int lim = (int)xLen + (int)LEFT - (int)(32u * b); // number of meaningful low bits
+    const int lim = (int)xLen + (int)LEFT - (int)(BLOCK * b); // number of meaningful low bits
     if (lim <= 0) return 0ull;
-    uint64_t m;
-    if (b == 0) {
-        m = (window64(G, xOff) << LEFT) | ((1ull << LEFT) - 1ull);
-    } else {
-        m = window64(G, xOff + 32u * b - LEFT);
-    }
+    // (with blocks of fewer rows than LEFT the forced ones reach into the blocks after the first: bitparallelmatrix.cpp:58 shifts them along)
+    const int s = (int)LEFT - (int)(BLOCK * b);
+    uint64_t m = s > 0 ? ((window64(G, xOff) << (uint32_t)s) | ((1ull << (uint32_t)s) - 1ull)) : window64(G, xOff + (uint32_t)(-s));
     if (lim < 64) m &= (1ull << lim) - 1ull;
     return m;
 }
@@ -71,6 +68,7 @@ struct MatGeom {
 // only used by findCIGAR / the naive search); `first` / `last` are initED[0] / initED[nInit-1].  The
 // first column is built from raw[] on the fly — no private array of initial distances is needed (it
 // would live in scratch memory).
+template <uint32_t LEFT = MX_LEFT, uint32_t DIAG = MX_DIAG>
 __device__ __forceinline__ void initMatrix(MatGeom& g, uint32_t xLen, uint32_t maxED, uint32_t first, uint32_t last,
                                            const uint16_t* raw, uint32_t increase, uint32_t nInit, uint64_t& HP0,
                                            uint64_t& HN0, uint64_t& RAC0, uint32_t& score0) {
@@ -81,19 +79,19 @@ __device__ __forceinline__ void initMatrix(MatGeom& g, uint32_t xLen, uint32_t m
     score0 = first;
     g.Wh = maxED - score0;
     if (g.Wv + g.Wh + 1 > g.m) g.m = g.Wv + g.Wh + 1;
-    HP0 = (~0ull) << MX_LEFT;
+    HP0 = (~0ull) << LEFT;
     HN0 = ~HP0;
-    const uint32_t nn = nInit < MX_LEFT + 1 ? nInit : MX_LEFT + 1;
+    const uint32_t nn = nInit < LEFT + 1 ? nInit : LEFT + 1;
     for (uint32_t i = 1; i < nn; ++i) {
         const uint32_t cur = raw[i] + increase, prev = raw[i - 1] + increase; // length_t arithmetic
         if (cur < prev) {
-            HP0 ^= 1ull << (MX_LEFT - i);
-            HN0 ^= 1ull << (MX_LEFT - i);
+            HP0 ^= 1ull << (LEFT - i);
+            HN0 ^= 1ull << (LEFT - i);
         } else if (cur == prev) {
-            HN0 ^= 1ull << (MX_LEFT - i);
+            HN0 ^= 1ull << (LEFT - i);
         }
     }
-    RAC0 = 1ull << (MX_DIAG + g.Wh);
+    RAC0 = 1ull << (DIAG + g.Wh);
 }
 
 // computeRow (bitparallelmatrix.h:352-415).  In/out: previous row state -> row i state.
@@ -209,19 +207,10 @@ constexpr uint32_t MXW_BLOCK = 16, MXW_DIAG = 21, MXW_LEFT = 22, MXW_MAX_ED = 7;
 // own bound 3 maxED + 2 + BLOCK <= WORD (bitparallelmatrix.h:313) holds for 64 bits once the block is 16 rows.  Same band, same values in
 // the band as the reference's 128-bit matrix (fmindex.h:240-246), by the argument above.  The walk to the rightmost active column can
 // span Wv + Wh = 40 columns here: racWalkWide works on 64-bit windows.  Match words come straight from the read's bit-strings
-// (matchWordB: one funnel shift), not from the 32-row block words of k_match_words, whose 64 bits do not reach that far.
+// (matchWord<LEFT, BLOCK>: one funnel shift), not from the 32-row block words of k_match_words, whose 64 bits do not reach that far.
 constexpr uint32_t MXX_BLOCK = 16, MXX_DIAG = 30, MXX_LEFT = 31;
-// match word of block b for BLOCK-row blocks: bit t = column t - LEFT + BLOCK b of the read (xLen characters from bit 0 of G); the
-// columns left of the read are ones (bitparallelmatrix.cpp:44-47, carried into the next blocks by its shifts), those right of it zeros
-template <uint32_t LEFT, uint32_t BLOCK>
-__device__ __forceinline__ uint64_t matchWordB(const uint32_t* G, uint32_t xLen, uint32_t b) {
-    const int lim = (int)xLen + (int)LEFT - (int)(BLOCK * b); // number of meaningful low bits
-    if (lim <= 0) return 0ull;
-    const int s = (int)LEFT - (int)(BLOCK * b);
-    uint64_t m = s > 0 ? ((window64(G, 0u) << (uint32_t)s) | ((1ull << (uint32_t)s) - 1ull)) : window64(G, (uint32_t)(-s));
-    if (lim < 64) m &= (1ull << lim) - 1ull;
-    return m;
-}
+// ... and for maxED 11 .. 13 (Wv = 39, Wh = 13): 8-row blocks, the band in bits r % 8 .. r % 8 + 52, the rightmost active column below bit 60
+constexpr uint32_t MXY_BLOCK = 8, MXY_DIAG = 39, MXY_LEFT = 40;
 // racWalk on 64-bit windows (bit 63 is the RAC column)
 template <uint32_t BLOCK, uint32_t DIAG>
 __device__ __forceinline__ bool racWalkWide(const MatGeom& g, uint32_t i, uint64_t HP, uint64_t HN, uint64_t& RAC) {
@@ -360,6 +349,33 @@ __device__ __forceinline__ bool onlyVerticalGapsLeft(const MatGeom& g, uint32_t 
     return (v << ((MX_WORD - be) & 63u)) == 0ull;
 }
 
+
+// ---- the in-index matrix at 11 ... 13 errors: 64-bit words, 16-row blocks ----
+// The reference runs a search part on 64-bit words where the part's upper bound is at most 10 and on its 128-bit words beyond
+// (indexinterface.cpp:391-398).  The frontier carries ONE matrix per node: BLOCK 16 gives the 64-bit word the reference's own bound of
+// (64 - 16 - 2) / 3 = 15 errors (bitparallelmatrix.h:313), LEFT 31, DIAG 30 — the geometry of the in-text matrix above.  Cells of at
+// most maxED are the same in every matrix that contains the band, hence valid rows, final-column values, cluster centres and first
+// columns; `onlyVerticalGapsLeft` reads HN bits of cells that may exceed maxED and, in the reference, shifts by a negative count near
+// the end of a block: it is answered as the part's OWN matrix would (refWord 64 or 128) — `true` where that shift count goes negative
+// (be > refWord: the shifted word keeps only bits below bb, which are cleared), `false` where the last column lies beyond this word
+// (it then lies beyond the band, and on a valid row — the only rows asked about, indexinterface.cpp:545 — a run of decreasing values
+// cannot end there), the HN bits of columns i - Wv + 1 ... n - 1 otherwise.  oracle/: BitParallelEDT<uint64_t, 16> with `emulate`;
+// tests/test_narrow_block_matrix.py and tools/soak_narrow_blocks.py (6.8e9 matrix rows) compare a search on it with the search on the
+// reference's matrices — occurrences and every counter.
+constexpr uint32_t MXN_BLOCK = 16, MXN_DIAG = 30, MXN_LEFT = 31, MXN_MAX_ED = 13;
+template <uint32_t BLOCK, uint32_t DIAG>
+__device__ __forceinline__ bool onlyVerticalGapsLeftAs(const MatGeom& g, uint32_t i, uint64_t HN, uint32_t refWord) {
+    const uint32_t refBlock = refWord / 2u, refMaxED = (refWord - refBlock - 2u) / 3u, refLEFT = 2u * refMaxED + 1u, refDIAG = 2u * refMaxED;
+    if (i + refLEFT < g.n) return false;
+    if (refDIAG + g.n - (i / refBlock) * refBlock > refWord) return true;
+    const uint32_t r = i % BLOCK;
+    const int bb = (int)(DIAG - g.Wv + r + 1u);                 // column i - Wv + 1
+    const int be = (int)(DIAG + r) + ((int)g.n - (int)i);       // one past column n - 1
+    if (be > 64) return false;
+    if (be <= bb) return true;
+    const uint64_t mask = (be >= 64 ? ~0ull : ((1ull << be) - 1ull)) & ~((1ull << bb) - 1ull);
+    return (~HN & mask) == 0ull;
+}
 
 // The two in-text matrices behind one set of names (k_verify_stage, forwardPass)
 template <bool W32>

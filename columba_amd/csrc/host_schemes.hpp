@@ -461,7 +461,7 @@ inline void fillNamed(cmb_strategy& st, const std::string& name) {
         // ColumbaSearchStrategy (minU up to 7 errors, the greedy schemes for 8 .. 13 errors) and its mirror image
         // (MultipleSchemes ctor, :2468-2477), then the "middle" schemes for k = 2, 4, 6 (+ the mirror of the k = 6 one);
         // base-class partition defaults.  (8 .. 13 errors: Hamming-distance batches run on the wide device tables, MAXP_WIDE parts;
-        // edit-distance batches run up to 10 errors — wide record geometry of the frontier, k_wide_filter / k_verify_wide — and are refused beyond.)
+        // edit-distance batches likewise: wide record geometry of the frontier, from 11 errors on the in-index matrix with 16-row blocks (GeoX).)
         st.kmerCutOff = 20;
         for (uint32_t k = 1; k <= 13; k++) {
             const HostScheme m = k <= 7 ? minU(k) : greedy(k);

@@ -596,8 +596,10 @@ constexpr uint32_t TB_BELOW = 18;  // narrow rows (32-bit matrix, maxED <= 4)
 constexpr uint32_t TBW_BELOW = 21; // wide rows (64-bit / 16-row-block matrix, maxED <= 7: Wv = 3 maxED <= 21, Wh <= 7)
 // low half: HP; high half: M | ~D0 — "the diagonal step is allowed" (bitparallelmatrix.h:559-562), folded in by the
 // forward pass, which has the row's match word at hand: the trace then needs neither the text nor match words.
-__device__ __forceinline__ uint64_t packTraceRow(uint32_t r, uint64_t HP, uint64_t diagOk) {
-    const uint32_t sh = (r % MXW_BLOCK) + MXW_DIAG - TBW_BELOW;
+// (below: columns of the window left of the diagonal — TBW_BELOW; k_cigar at 11 ... 13 errors, whose band is [-13, 13] around the
+// diagonal, takes 15: the window [-15, 16])
+__device__ __forceinline__ uint64_t packTraceRow(uint32_t r, uint64_t HP, uint64_t diagOk, uint32_t below = TBW_BELOW) {
+    const uint32_t sh = (r % MXW_BLOCK) + MXW_DIAG - below;
     return (uint64_t)(uint32_t)(HP >> sh) | ((uint64_t)(uint32_t)(diagOk >> sh) << 32);
 }
 // NARROW rows (maxED <= 4): 16 + 16 bits per row, sixteen rows per 64-byte line — half the trace traffic.
@@ -702,7 +704,7 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
                                                 const MatGeom& g, uint32_t nZeros, uint32_t start, uint32_t size,
                                                 uint32_t maxED, uint32_t minED, uint32_t& centreMask,
                                                 uint64_t& edPack, uint64_t& edPackHi, const VPlanes& V, uint32_t slot,
-                                                uint32_t& cRows, uint64_t* Ml, uint32_t rowMin = 0) {
+                                                uint32_t& cRows, uint64_t* Ml, uint32_t rowMin = 0, uint32_t twBelow = TBW_BELOW) {
     // NARROW (k <= 4) also means the matrix on 32-bit words / 8-row blocks (dev_matrix.hpp)
     typedef InTextMx<NARROW> MX; // NARROW: 32-bit words / 8-row blocks; else 64-bit words / 16-row blocks (dev_matrix.hpp)
     using W = typename MX::W;
@@ -777,7 +779,7 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
                         dAcc = 0;
                     }
                 }
-                if (STORE && !NARROW) buf[t & 7u] = packTraceRow(r, (uint64_t)HP, (uint64_t)(M | ~D0));
+                if (STORE && !NARROW) buf[t & 7u] = packTraceRow(r, (uint64_t)HP, (uint64_t)(M | ~D0), twBelow);
                 if (STORE && NARROW) bufN[t] = packTraceRowNarrow(r, (uint32_t)HP, (uint32_t)(M | ~D0));
                 if (!valid) {
                     alive = false;
@@ -1076,17 +1078,26 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
 //                   (bitparallelmatrix.h:591-614, :531-586) on the stored rows.  KEYED: the batch path (keys, multiplicities, the
 //                   list of k_wide_filter); otherwise the items of the hooks, each located and verified by itself.
 constexpr uint32_t VW_ROW_BYTES = 16, VW_WORK_CHUNK = 1024;
-__host__ __device__ inline uint32_t vwRows(uint32_t maxLen) { return maxLen + 3u * MX_MAX_ED + 4u; }
-struct WideRow { // the matrix state of one candidate, with the text codes and match words of its current 16-row block
+__host__ __device__ inline uint32_t vwRows(uint32_t maxLen) { return maxLen + 3u * MXN_MAX_ED + 4u; }
+// the two geometries of the wide in-text matrix (dev_matrix.hpp): 8 ... 10 errors, 11 ... 13 errors
+struct WxTen {
+    static constexpr uint32_t BLOCK = MXX_BLOCK, DIAG = MXX_DIAG, LEFT = MXX_LEFT;
+};
+struct WxThirteen {
+    static constexpr uint32_t BLOCK = MXY_BLOCK, DIAG = MXY_DIAG, LEFT = MXY_LEFT;
+};
+template <class WX>
+struct WideRow { // the matrix state of one candidate, with the text codes and match words of its current 16 rows
+    static constexpr uint32_t NB = 16u / WX::BLOCK; // matrix blocks per 16 rows
     uint64_t HP, HN, RAC;
     uint32_t score;
-    uint64_t Mw[4];    // match words of the block, per text code
-    uint4 tx;          // text codes of rows 16 c + 1 .. 16 c + 16
-    uint32_t lastCode; // ... and of row 16 c (the last one of the previous chunk)
+    uint64_t Mw[NB][4]; // match words of the blocks, per text code
+    uint4 tx;           // text codes of rows 16 c + 1 .. 16 c + 16
+    uint32_t lastCode;  // ... and of row 16 c (the last one of the previous chunk)
     __device__ __forceinline__ void init(const MatGeom& g, uint32_t nZeros) { // (as forwardPass; bitparallelmatrix.cpp:105-121)
-        HP = (~0ull) << MXX_LEFT;
-        HN = (1ull << (MXX_LEFT + 1u - nZeros)) - 1ull;
-        RAC = 1ull << (MXX_DIAG + g.Wh);
+        HP = (~0ull) << WX::LEFT;
+        HN = (1ull << (WX::LEFT + 1u - nZeros)) - 1ull;
+        RAC = 1ull << (WX::DIAG + g.Wh);
         score = 0;
         tx = make_uint4(0, 0, 0, 0);
     }
@@ -1097,15 +1108,20 @@ struct WideRow { // the matrix state of one candidate, with the text codes and m
         lastCode = tx.w >> 24;
         tx = loadText16(ix.text + start + 16u * c); // (the text allocation is padded)
 #pragma unroll
-        for (uint32_t ch = 0; ch < 4; ch++) Mw[ch] = matchWordB<MXX_LEFT, MXX_BLOCK>(gString(G, gw, rs, 0u, ch), len, c);
+        for (uint32_t h = 0; h < NB; h++)
+#pragma unroll
+            for (uint32_t ch = 0; ch < 4; ch++) Mw[h][ch] = matchWord<WX::LEFT, WX::BLOCK>(gString(G, gw, rs, 0u, ch), 0u, len, c * NB + h);
     }
     // row r; M and D0 of the row are returned for the traceback
     __device__ __forceinline__ bool step(const MatGeom& g, uint32_t r, uint64_t& M, uint64_t& D0) {
         const uint32_t t = (r - 1u) & 15u, w = t >> 2;
         const uint32_t word = w == 0u ? tx.x : w == 1u ? tx.y : w == 2u ? tx.z : tx.w;
         const uint32_t tc = (r & 15u) == 0u ? lastCode : (word >> (8u * (t & 3u))) & 0xFFu; // (text code 4: '$' / padding, matches nothing)
-        M = tc == 0u ? Mw[0] : tc == 1u ? Mw[1] : tc == 2u ? Mw[2] : tc == 3u ? Mw[3] : 0ull;
-        return computeRowWide<MXX_BLOCK, MXX_DIAG>(g, r, M, HP, HN, D0, RAC, score);
+        const uint32_t h = NB == 1u ? 0u : (r & 15u) / WX::BLOCK;
+        uint64_t m0 = Mw[0][0], m1 = Mw[0][1], m2 = Mw[0][2], m3 = Mw[0][3];
+        if (NB == 2u && h == 1u) m0 = Mw[NB - 1][0], m1 = Mw[NB - 1][1], m2 = Mw[NB - 1][2], m3 = Mw[NB - 1][3];
+        M = tc == 0u ? m0 : tc == 1u ? m1 : tc == 2u ? m2 : tc == 3u ? m3 : 0ull;
+        return computeRowWide<WX::BLOCK, WX::DIAG>(g, r, M, HP, HN, D0, RAC, score);
     }
 };
 __device__ __forceinline__ MatGeom wideGeom(uint32_t len, uint32_t maxED, uint32_t nZeros) {
@@ -1118,6 +1134,7 @@ __device__ __forceinline__ MatGeom wideGeom(uint32_t len, uint32_t maxED, uint32
     return g;
 }
 
+template <class WX>
 __global__ void __launch_bounds__(256)
 k_wide_filter(DevIndex ix, const uint64_t* __restrict__ offs, const uint32_t* __restrict__ G, uint32_t gw,
               const unsigned long long* __restrict__ ukeys, const uint32_t* __restrict__ counts, uint32_t nKeys, uint32_t* __restrict__ work,
@@ -1126,7 +1143,8 @@ k_wide_filter(DevIndex ix, const uint64_t* __restrict__ offs, const uint32_t* __
     bool have = false, done = false;
     uint32_t u = 0, mult = 0, rs = 0, len = 0, r = 0, size = 0, start = 0, rows = 0;
     MatGeom g{0, 0, 0, 0, 0};
-    WideRow mx{0, 0, 0, 0};
+    WideRow<WX> mx;
+    mx.HP = mx.HN = mx.RAC = 0, mx.score = 0, mx.tx = make_uint4(0, 0, 0, 0), mx.lastCode = 0;
     const uint32_t lane = threadIdx.x & 63u;
     // (atomics on one address are served at ~90 per microsecond, dev_wave.hpp: a chunk of keys per atomic, the survivors in
     // per-wavefront chunks of `list`, holes = 0xFFFFFFFF; work: [0] next key, [1] list slots handed out — both zero at launch)
@@ -1169,7 +1187,7 @@ k_wide_filter(DevIndex ix, const uint64_t* __restrict__ offs, const uint32_t* __
                             size = hEnd > start ? hEnd - start : 0;
                             if (!g.inFinalColumn(size)) { // (indexhelpers.cpp:527): started, nothing computed
                                 cStarted += mult;
-                            } else if (g.Wv >= MXX_LEFT || maxED > MX_MAX_ED) {
+                            } else if (g.Wv >= WX::LEFT) { // (the host picks the instance by the batch's distance)
                                 flags |= FLAG_CAPACITY;
                             } else if (size == 0u) { // (no row to compute: the abort test of indexhelpers.cpp:542 with i = 0)
                                 cStarted += mult;
@@ -1225,7 +1243,7 @@ k_wide_filter(DevIndex ix, const uint64_t* __restrict__ offs, const uint32_t* __
     if (flags) atomicOr(&q.cnt[3], flags);
 }
 
-template <bool KEYED>
+template <bool KEYED, class WX>
 __global__ void __launch_bounds__(256)
 k_verify_wide(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, const uint8_t* __restrict__ seq, const uint32_t* __restrict__ G,
               uint32_t gw, const uint4* __restrict__ items, uint32_t nItems, const unsigned long long* __restrict__ ukeys,
@@ -1283,15 +1301,15 @@ k_verify_wide(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, c
         const uint32_t nZeros = fixed ? 1u : 2u * maxED + 1u;
         const MatGeom g = wideGeom(len, maxED, nZeros);
         const uint32_t sfc = g.sfc(), col = g.n - 1u, firstRow = (g.m - 1u) - sfc;
-        // the values of the last column from row firstRow on (at most sfc + 1 <= 42 of them), four bits each: all that is asked of them
-        // is how they compare with a value of at most maxED <= 10
-        unsigned long long lcw0 = 0ull, lcw1 = 0ull, lcw2 = 0ull;
+        // the values of the last column from row firstRow on (at most sfc + 1 <= 54 of them), four bits each: all that is asked of them
+        // is how they compare with a value of at most maxED <= 13
+        unsigned long long lcw0 = 0ull, lcw1 = 0ull, lcw2 = 0ull, lcw3 = 0ull;
         auto lcPut = [&](uint32_t qi, uint32_t v) {
             const unsigned long long x = (unsigned long long)min(v, 15u) << (4u * (qi & 15u));
-            lcw0 |= (qi >> 4) == 0u ? x : 0ull, lcw1 |= (qi >> 4) == 1u ? x : 0ull, lcw2 |= (qi >> 4) == 2u ? x : 0ull;
+            lcw0 |= (qi >> 4) == 0u ? x : 0ull, lcw1 |= (qi >> 4) == 1u ? x : 0ull, lcw2 |= (qi >> 4) == 2u ? x : 0ull, lcw3 |= (qi >> 4) == 3u ? x : 0ull;
         };
         auto lcGet = [&](uint32_t qi) -> uint32_t {
-            const unsigned long long w = (qi >> 4) == 0u ? lcw0 : (qi >> 4) == 1u ? lcw1 : lcw2;
+            const unsigned long long w = (qi >> 4) == 0u ? lcw0 : (qi >> 4) == 1u ? lcw1 : (qi >> 4) == 2u ? lcw2 : lcw3;
             return (uint32_t)(w >> (4u * (qi & 15u))) & 15u;
         };
         uint32_t i = 0;
@@ -1302,14 +1320,14 @@ k_verify_wide(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, c
             const uint32_t size = hEnd > start ? hEnd - start : 0;
             if (!g.inFinalColumn(size)) { // (indexhelpers.cpp:527)
                 active = false;
-            } else if (g.Wv >= MXX_LEFT || maxED > MX_MAX_ED || (size + 1u) * VW_ROW_BYTES > slotBytes) {
+            } else if (g.Wv >= WX::LEFT || (size + 1u) * VW_ROW_BYTES > slotBytes) {
                 flags |= FLAG_CAPACITY;
                 active = false;
             } else {
-                WideRow mx;
+                WideRow<WX> mx;
                 mx.init(g, nZeros);
                 putRow(0u, mx.HP, ~0ull);
-                if (firstRow == 0u) lcPut(0u, cellAt<MXX_BLOCK, MXX_DIAG>(0u, col, mx.HP, mx.HN, mx.score));
+                if (firstRow == 0u) lcPut(0u, cellAt<WX::BLOCK, WX::DIAG>(0u, col, mx.HP, mx.HN, mx.score));
                 for (uint32_t r = 1; r <= size; r++) {
                     if (r == 1u || (r & 15u) == 0u) mx.loadBlock(ix, G, gw, rs, len, start, r >> 4);
                     uint64_t M, D0;
@@ -1317,7 +1335,7 @@ k_verify_wide(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, c
                     cRows += mult;
                     putRow(r, mx.HP, M | ~D0);
                     if (!valid) break;
-                    if (r >= firstRow) lcPut(r - firstRow, cellAt<MXX_BLOCK, MXX_DIAG>(r, col, mx.HP, mx.HN, mx.score));
+                    if (r >= firstRow) lcPut(r - firstRow, cellAt<WX::BLOCK, WX::DIAG>(r, col, mx.HP, mx.HN, mx.score));
                     i = r;
                 }
                 if (i <= size - sfc) { // (length_t arithmetic as in the reference, indexhelpers.cpp:542)
@@ -1343,7 +1361,7 @@ k_verify_wide(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, c
                         nCentres++;
                         uint32_t ti = r, tj = col;
                         while (tj > 0) {
-                            const uint32_t bitIdx = (tj - (ti / MXX_BLOCK) * MXX_BLOCK) + MXX_DIAG; // (:541-543; unsigned as there)
+                            const uint32_t bitIdx = (tj - (ti / WX::BLOCK) * WX::BLOCK) + WX::DIAG; // (:541-543; unsigned as there)
                             if (bitIdx >= 64u) {
                                 flags |= FLAG_CAPACITY; // (a path of cells <= maxED stays inside the band)
                                 break;
@@ -2137,8 +2155,9 @@ k_cigar(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf, const uint4* _
         uint32_t dummyMask;
         uint64_t ep, eph;
         // rows 1..size of the fresh matrix (all valid: an alignment within maxED exists), trace rows to the lane's slab
+        const uint32_t below = maxED > MX_MAX_ED ? 15u : TBW_BELOW; // (the wide trace window: 11 ... 13 errors need 13 columns right of the diagonal)
         const uint32_t rowsDone = forwardPass<true, NARROW, PACKED>(ix, mf, rs, g, 1u, o.x, trace ? size : 0u, maxED, 0, dummyMask,
-                                                                    ep, eph, V, slot, dummyRows, Ml);
+                                                                    ep, eph, V, slot, dummyRows, Ml, 0u, below);
         if (trace && rowsDone < size) { // (a row without a cell <= maxED: the occurrence is not an alignment within its distance)
             flags |= FLAG_CAPACITY;
             trace = false;
@@ -2163,7 +2182,7 @@ k_cigar(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf, const uint4* _
                 run++;
             };
             while (tj > 0) {
-                const uint32_t rel = tj + (NARROW ? TB_BELOW : TBW_BELOW) - ti;
+                const uint32_t rel = tj + (NARROW ? TB_BELOW : below) - ti;
                 bool hpBit, dgBit;
                 if (NARROW) {
                     uint32_t wn = packTraceRowNarrow(0, (~0u) << MX32_LEFT, 0u);
@@ -2190,7 +2209,7 @@ k_cigar(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf, const uint4* _
                     hpBit = rel >= TBN_HP_LO && ((wn >> (rel - TBN_HP_LO)) & 1u);
                     dgBit = rel == TBN_REL_HI || ((wn >> (16u + rel - TBN_DG_LO)) & 1u);
                 } else {
-                    uint64_t ww = packTraceRow(0, HP0, 0ull);
+                    uint64_t ww = packTraceRow(0, HP0, 0ull, below);
                     if (ti > 0) {
                         const uint32_t gq = (ti - 1) >> 3, jq = (ti - 1) & 7u;
                         if (gq != curG) {

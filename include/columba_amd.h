@@ -33,7 +33,7 @@ extern "C" {
 #define CMB_OK 0
 #define CMB_ERR_INVALID (-1)     /* bad argument / malformed scheme (search.h:559-586) */
 #define CMB_ERR_DEVICE (-2)      /* HIP runtime failure / no GPU */
-#define CMB_ERR_UNSUPPORTED (-3) /* more than 10 errors for edit distance (Hamming distance: more than 13), reads longer than 480, 64-bit length_t on the FM-index path */
+#define CMB_ERR_UNSUPPORTED (-3) /* more than 13 errors (MAX_K of the reference), reads longer than 480, 64-bit length_t on the FM-index path */
 #define CMB_ERR_OVERFLOW (-4)    /* caller-provided output buffer too small: nothing truncated silently */
 #define CMB_ERR_INTERNAL (-5)    /* device-side capacity exceeded for a read (reported, never silent) */
 
@@ -117,7 +117,7 @@ int cmb_index_kmer_table(const cmb_index* idx, uint32_t* out /* 4 * 4^kmer_size 
  * (O1StarSearchStrategy, :3115), "pigeon" (PigeonHoleSearchStrategy, :3221), "minU" (MinUSearchStrategy, :3284),
  * "columba" (the CLI default: DynamicColumbaStrategy, :3666 — minU schemes, their mirror images and the "middle"
  * schemes with dynamic selection; minU up to 7 errors, the greedy schemes for 8..13 errors: Hamming distance up to 13, edit
- * distance up to 10 — what the reference's 64-bit in-index matrix holds);
+ * distance up to 13 as well — beyond 10 the reference switches to its 128-bit matrices, here: 64-bit words with narrower blocks);
  * plus "multiple_opt" (the schemes of search_schemes/multiple_opt with dynamic selection, as `-d` loads them) */
 int cmb_strategy_create_named(const char* name, int metric, int partition, cmb_strategy** out);
 /* scheme directories: mode CMB_DIR_CUSTOM = `-c <dir> -nD` (CustomSearchStrategy, searchstrategy.cpp:1990),

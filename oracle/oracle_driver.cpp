@@ -420,11 +420,17 @@ int main() {
             string X, Y;
             uint32_t score;
             in >> X >> Y >> score;
-            BitParallelED64 M;
-            M.setSequence(Substring(X.data(), (len_t)X.size(), 0, (len_t)X.size(), FORWARD));
             Substring ref(Y.data(), (len_t)Y.size(), 0, (len_t)Y.size(), FORWARD);
             vector<pair<char, uint32_t>> cig;
-            M.findCIGAR(ref, score, cig);
+            if (score <= BitParallelED64::MATRIX_MAX_ED) { // (IndexInterface::generateCIGAR picks the matrix by the score, indexinterface.h:976-982)
+                BitParallelED64 M;
+                M.setSequence(Substring(X.data(), (len_t)X.size(), 0, (len_t)X.size(), FORWARD));
+                M.findCIGAR(ref, score, cig);
+            } else {
+                BitParallelED128 M;
+                M.setSequence(Substring(X.data(), (len_t)X.size(), 0, (len_t)X.size(), FORWARD));
+                M.findCIGAR(ref, score, cig);
+            }
             os << (cig.empty() ? string("*") : cigarStr(cig));
         } else if (cmd == "sam1" || cmd == "samxa" || cmd == "samun") {
             const vector<string> seqNames = {"chr1", "chr2_alt", "seqC"};

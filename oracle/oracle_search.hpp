@@ -358,7 +358,15 @@ template <class IX> class MatcherT {
         constexpr bool CNT = !RLC;
         if constexpr (RLC)
             if (!index.text) throw std::runtime_error("oracle: trimming on the b-move index needs the text beside it (orc_move_attach_text)");
-        BitParallelED64& matrix = fullReadMatrix();
+        // use64Matrix(1, maxED) (fmindex.cpp:318; the RLC flavour: indexinterface.cpp:874-881): the 128-bit matrix beyond 10 errors
+        if (!(BitParallelED64::LEFT >= 1 + maxED && BitParallelED64::MATRIX_MAX_ED >= maxED)) {
+            oneStringOn<CNT>(fullReadMatrices128[strand], startPos, endPos, maxED, minED, occ, pattern);
+            return;
+        }
+        oneStringOn<CNT>(fullReadMatrix(), startPos, endPos, maxED, minED, occ, pattern);
+    }
+    template <bool CNT, class MX>
+    void oneStringOn(MX& matrix, len_t startPos, len_t endPos, len_t maxED, len_t minED, Occurrences& occ, const std::string& pattern) {
         Substring pat(pattern.data(), (len_t)pattern.size(), 0, (len_t)pattern.size(), FORWARD);
         if (!matrix.sequenceSet()) matrix.setSequence(pat);
         matrix.initializeMatrix(maxED, std::vector<uint32_t>(1, 0u));

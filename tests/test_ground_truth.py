@@ -150,8 +150,8 @@ def cpu_world(oracle_built):
     return {"genome": g, "text": g.tobytes(), "orc": op.OracleIndex(ix), "orc4": op.OracleIndex(ix, kmer_size=4), "op": op}
 
 
-# (11 ... 13 errors under edit distance: the oracle alone — the reference runs the parts whose upper bound exceeds 10 on its 128-bit
-# in-index matrix, indexinterface.cpp:391-398, which the device does not have yet)
+# (11 ... 13 errors under edit distance: the reference runs the parts whose upper bound exceeds 10 on its 128-bit in-index matrix,
+# indexinterface.cpp:391-398)
 @pytest.mark.parametrize("spec,metric,partition,k", CONFIGS + [("columba", "edit", "dynamic", 9), ("columba", "edit", "dynamic", 11),
                                                               ("columba", "edit", "uniform", 12), ("columba", "edit", "static", 13)])
 def test_oracle_is_sound_and_complete(cpu_world, gt, spec, metric, partition, k):
@@ -208,7 +208,9 @@ def gpu_world(oracle_built):
     ("01*0", "edit", "static", 2), ("kuch2", "hamming", "dynamic", 3),
     # beyond 7 errors (greedy schemes, wide device tables and records, the in-text matrix with the wide left margin)
     ("columba", "edit", "dynamic", 8), ("columba", "edit", "uniform", 10), ("columba", "hamming", "dynamic", 9),
-    ("columba", "hamming", "static", 13)])
+    ("columba", "hamming", "static", 13),
+    # ... and beyond 10: the in-index matrix with 16-row blocks, the in-text matrix with 8-row blocks
+    ("columba", "edit", "dynamic", 11), ("columba", "edit", "static", 12), ("columba", "edit", "uniform", 13)])
 def test_device_is_sound_and_complete(gpu_world, gt, spec, metric, partition, k):
     ca = gpu_world["ca"]
     g = gpu_world["genome"]

@@ -28,6 +28,7 @@ for name, spec, metric, part, k, n_reads, length in (
         ("k = 7 edit, columba strategy, 150 bp", "columba", "edit", "dynamic", 7, 1_000_000, 150),
         # new in round 3: the greedy schemes beyond 7 errors (wide device tables; in-text verification by k_wide_filter + k_verify_wide), long reads
         ("k = 9 edit, columba strategy (greedy scheme, wide in-text matrix), 150 bp", "columba", "edit", "dynamic", 9, 100_000, 150),
+        ("k = 12 edit, columba strategy (greedy scheme, the matrices with narrow blocks), 150 bp", "columba", "edit", "dynamic", 12, 20_000, 150),
         ("k = 12 Hamming, columba strategy (greedy scheme), 150 bp", "columba", "hamming", "dynamic", 12, 200_000, 150),
         ("k = 4 edit, multiple_opt, 400 bp", "multiple_opt", "edit", "dynamic", 4, 2_000_000, 400)):
     if len(sys.argv) > 2 and sys.argv[2] not in name:

@@ -26,7 +26,7 @@ for spec, metric, part, k in (("multiple_opt", "edit", "dynamic", 4), ("columba"
 # alignments + best mode on long reads
 reads = synth.sample_reads(g, 4000, 300, seed=5, n_frac=0.01, edit_choices=(0, 1, 3, 5, 7, 9))
 tab = sp.BY_NAME["columba"]
-o = op.match_best(orc, op.OracleStrategy(tab, "edit", "dynamic"), reads, x=0, min_identity=97, max_supported=10, threads=64)
+o = op.match_best(orc, op.OracleStrategy(tab, "edit", "dynamic"), reads, x=0, min_identity=97, max_supported=13, threads=64)
 d = ca.match_best(dev, ca.SearchStrategy("columba", "edit", "dynamic"), reads, x=0, min_identity=97)
 ok = np.array_equal(o[5], d[4]) and np.array_equal(o[4], d[3]) and all(np.array_equal(o[0][f], d[0][f]) for f in ("begin", "end", "distance", "strand"))
 cig = all(ca.cigar_string(d[2][int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])]) == o[3][j] for j, a in enumerate(d[1]))

@@ -55,14 +55,15 @@ FM = (("multiple_opt", "edit", "dynamic", 4, 5), ("columba", "edit", "dynamic", 
       # beyond 7 errors: the greedy schemes on the wide device tables, the in-text matrix with the wide left margin (no reads below 60
       # characters: at 10 errors those match all over the text)
       ("columba", "edit", "dynamic", 8, 10), ("columba", "edit", "uniform", 10, 12), ("columba", "edit", "static", 9, 11),
-      ("columba", "hamming", "dynamic", 9, 11), ("columba", "hamming", "static", 13, 15))
+      ("columba", "hamming", "dynamic", 9, 11), ("columba", "hamming", "static", 13, 15),
+      ("columba", "edit", "dynamic", 11, 13), ("columba", "edit", "static", 12, 14), ("columba", "edit", "uniform", 13, 15))
 for spec, metric, part, k, P in FM:
     small = spec in ("kuch2", "01*0")
     dev, orc = ca.Index(ix, kmer_size=4 if small else 10), op.OracleIndex(ix, kmer_size=4 if small else 10)
     if spec == "naive":
         reads = [g[p:p + int(rng.integers(8, 26))].tobytes() for p in rng.integers(0, len(g) - 30, N // 6)] + [b"ACGTN", b""][:1 + (metric == "edit")]
     elif k >= 8:
-        reads = chunk(g, max(N // 8, 100), k, P, 0.0, seed=int(rng.integers(1 << 30)), lens=(60, 100, 150, 151, 250, 257, 321, 400, 480))
+        reads = chunk(g, max(N // 8, 100), k, P, 0.0, seed=int(rng.integers(1 << 30)), lens=(60, 100, 150, 151, 250, 257, 321, 400, 480) if k <= 10 else (100, 150, 151, 250, 257, 321, 400, 480))
     else:
         reads = chunk(g, N, k, P, 0.0 if k == 0 else 0.02, seed=int(rng.integers(1 << 30)))
     if True:

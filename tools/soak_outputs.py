@@ -37,7 +37,7 @@ def best_mixed(spec, metric, x, ident):
     ms = 0
     while (ms + 1) in tab["schemes"]:
         ms += 1
-    ms = min(ms, 10 if metric == "edit" else 13)   # (the device walks the strata up to 10 / 13 errors)
+    ms = min(ms, 13)   # (MAX_K)
     o = op.match_best(world["orc"], op.OracleStrategy(tab, metric, "dynamic"), reads, x=x, min_identity=ident, max_supported=ms, threads=64)
     d = ca.match_best(world["dev"], ca.SearchStrategy(spec, metric, "dynamic"), reads, x=x, min_identity=ident)
     o_occ, o_sid, o_sb, o_cig, o_off, o_best, o_hits, o_cnt = o
