@@ -1709,6 +1709,15 @@ static int batchRunOne(cmb_batch* b) {
                     auto kc = k_cigar<false, false>;
                     if (narrow) kc = ix->d.text2 ? k_cigar<true, true> : k_cigar<true, false>;
                     else if (ix->d.text2) kc = k_cigar<false, true>;
+                    if (b->metric == CMB_METRIC_EDIT && b->k > CIGAR_BLOCK_WORDS_MAX_ED) {
+                        // (k_cigar's match words reach 9 columns right of the diagonal: kernels.hpp, k_cigar_wide)
+                        const uint32_t wSlots = std::min<uint32_t>(cSlots, 256u * 256u);
+                        const uint32_t slotBytes = (vwRows(b->maxLen) + 1u) * VW_ROW_BYTES;
+                        if (b->dpSlab.n < (size_t)slotBytes * wSlots) b->dpSlab.alloc((size_t)slotBytes * wSlots);
+                        hipLaunchKernelGGL(k_cigar_wide, dim3(wSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, b->G.p, b->gw, b->fout.p, b->foutRead.p,
+                                           (uint64_t)total, b->dpSlab.p, slotBytes, ix->seqStartsDev.p, ix->nSeqsDev, b->alnOps.p, b->alnStride,
+                                           b->alnRec.p, b->cnt.p + 3, 0u);
+                    } else
                     hipLaunchKernelGGL(kc, dim3(cSlots / 256), dim3(256), 0, s, ix->d, b->offs.p, mfc, b->fout.p, b->foutRead.p,
                                        (uint64_t)total, vp, ix->seqStartsDev.p, ix->nSeqsDev, b->alnOps.p, b->alnStride, b->alnRec.p,
                                        b->cnt.p + 3, (b->metric != CMB_METRIC_EDIT || b->k == 0) ? 1u : 0u);
@@ -2327,6 +2336,13 @@ extern "C" int cmb_cigar_windows(cmb_index* idx, const char* pattern, uint32_t p
         auto kc = k_cigar<false, false>;
         if (narrow) kc = idx->d.text2 ? k_cigar<true, true> : k_cigar<true, false>;
         else if (idx->d.text2) kc = k_cigar<false, true>;
+        DevBuf<uint8_t> slab;
+        if (maxD > CIGAR_BLOCK_WORDS_MAX_ED) { // (k_cigar's match words reach 9 columns right of the diagonal: kernels.hpp, k_cigar_wide)
+            const uint32_t slotBytes = (vwRows(mlen) + 1u) * VW_ROW_BYTES;
+            slab.alloc((size_t)slotBytes * slots);
+            hipLaunchKernelGGL(k_cigar_wide, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, G.p, gw, occs.p, occRead.p, n, slab.p, slotBytes,
+                               idx->seqStartsDev.p, idx->nSeqsDev, ops.p, stride, aln.p, flag.p, 0u);
+        } else
         hipLaunchKernelGGL(kc, dim3(slots / 256), dim3(256), 0, 0, idx->d, offs.p, mf, occs.p, occRead.p, n, vp, idx->seqStartsDev.p,
                            idx->nSeqsDev, ops.p, stride, aln.p, flag.p, 0u);
         HIPCHK(hipGetLastError());

@@ -2103,6 +2103,7 @@ struct AlnRec {
     uint32_t seqId, seqBegin, nOps, spans;
 };
 constexpr uint32_t CIG_M = 0, CIG_I = 1, CIG_D = 2;
+constexpr uint32_t CIGAR_BLOCK_WORDS_MAX_ED = 9; // k_cigar up to this distance, k_cigar_wide beyond (see there)
 template <bool NARROW, bool PACKED>
 __global__ void __launch_bounds__(256)
 k_cigar(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf, const uint4* __restrict__ occs,
@@ -2255,6 +2256,111 @@ k_cigar(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf, const uint4* _
             if (nOps > stride) flags |= FLAG_CAPACITY;
         }
         if (have) aln[it].nOps = nOps;
+    }
+    if (flags) atomicOr(flagWord, flags);
+}
+
+// The same for batches beyond 9 errors.  k_cigar takes its match words from the 64-bit words of 32-row blocks (k_match_words), which reach
+// 40 columns past the block's first row: enough for a band of Wh <= 9 columns right of the diagonal in the block's last row, not for the
+// Wh = distance <= 13 of these alignments.  Here the rows come from the matrix with the wide left margin and match words taken straight from
+// the read's bit-strings (WideRow<WxTen>: a fixed start has Wv = Wh = distance <= 13), stored as in k_verify_wide — 16 bytes {HP, M | ~D0} per
+// row, the rows of a wavefront contiguous — and findCIGAR's walk (bitparallelmatrix.h:480-522) reads them from the last cell to (0, 0).
+__global__ void __launch_bounds__(256)
+k_cigar_wide(DevIndex ix, const uint64_t* __restrict__ offs, const uint32_t* __restrict__ G, uint32_t gw, const uint4* __restrict__ occs,
+             const uint32_t* __restrict__ occRead, uint64_t nOcc, uint8_t* __restrict__ slab, uint32_t slotBytes,
+             const uint32_t* __restrict__ seqStarts, uint32_t nSeqs, uint16_t* __restrict__ ops, uint32_t stride, AlnRec* __restrict__ aln,
+             uint32_t* __restrict__ flagWord, uint32_t gapless) {
+    typedef WxTen WX;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    uint4* const rowBits = reinterpret_cast<uint4*>(slab + (size_t)(slot - lane) * slotBytes) + lane;
+    uint32_t flags = 0;
+    const uint64_t strideT = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t base = slot - lane; base < nOcc; base += strideT) { // wave-uniform trip count
+        const uint64_t it = base + lane;
+        if (it >= nOcc) continue;
+        const uint4 o = occs[it];
+        const uint32_t rs = 2u * occRead[it] + (o.w & 1u);
+        const uint32_t len = (uint32_t)(offs[(rs >> 1) + 1] - offs[rs >> 1]);
+        const uint32_t size = o.y - o.x, maxED = o.z, col = len;
+        { // sequence of the occurrence: last start position <= begin (upper_bound - 1)
+            uint32_t lo = 0, hi = nSeqs; // seqStarts[0] == 0; seqStarts[nSeqs] = end of the last sequence
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (seqStarts[mid] <= o.x) lo = mid;
+                else hi = mid;
+            }
+            aln[it].seqId = lo;
+            aln[it].seqBegin = o.x - seqStarts[lo];
+            aln[it].spans = o.y > seqStarts[lo + 1] ? 1u : 0u;
+        }
+        uint32_t nOps = 0;
+        uint16_t* myOps = ops + it * stride;
+        bool trace = maxED > 0 && size > 0 && !gapless;
+        const MatGeom g = wideGeom(len, maxED, 1u);
+        if (trace && (g.Wv >= WX::LEFT || WX::DIAG + g.Wh + WX::BLOCK > 63u || (size + 1u) * VW_ROW_BYTES > slotBytes)) {
+            flags |= FLAG_CAPACITY;
+            trace = false;
+        }
+        if (!trace) { // distance 0 (or an empty range): len x M
+            if (len) myOps[nOps++] = (uint16_t)((len << 2) | CIG_M);
+            aln[it].nOps = nOps;
+            continue;
+        }
+        WideRow<WX> mx;
+        mx.init(g, 1u);
+        rowBits[0] = make_uint4((uint32_t)mx.HP, (uint32_t)(mx.HP >> 32), ~0u, ~0u);
+        bool ok = true;
+        for (uint32_t r = 1; r <= size; r++) { // rows 1 .. size of the fresh matrix (all valid: an alignment within maxED exists)
+            if (r == 1u || (r & 15u) == 0u) mx.loadBlock(ix, G, gw, rs, len, o.x, r >> 4);
+            uint64_t M, D0;
+            ok = mx.step(g, r, M, D0) && ok;
+            const uint64_t md = M | ~D0;
+            rowBits[(size_t)r * 64u] = make_uint4((uint32_t)mx.HP, (uint32_t)(mx.HP >> 32), (uint32_t)md, (uint32_t)(md >> 32));
+        }
+        if (!ok) flags |= FLAG_CAPACITY; // (a row without a cell <= maxED: the occurrence is not an alignment within its distance)
+        uint32_t ti = size, tj = col, state = 3u, run = 0;
+        auto emit = [&](uint32_t op) {
+            if (op != state) {
+                if (run) {
+                    if (nOps < stride) myOps[nOps] = (uint16_t)((run << 2) | state);
+                    nOps++;
+                }
+                state = op;
+                run = 0;
+            }
+            run++;
+        };
+        while (ok && tj > 0) {
+            const uint32_t bitIdx = (tj - (ti / WX::BLOCK) * WX::BLOCK) + WX::DIAG; // (unsigned arithmetic as in the reference, :486)
+            if (bitIdx >= 64u) {
+                flags |= FLAG_CAPACITY;
+                break;
+            }
+            const uint4 rb = rowBits[(size_t)ti * 64u];
+            const uint64_t hp = rb.x | ((uint64_t)rb.y << 32), md = rb.z | ((uint64_t)rb.w << 32);
+            if ((hp >> bitIdx) & 1ull) { // gap in horizontal direction: insertion (:488-494)
+                --tj;
+                emit(CIG_I);
+            } else if (ti > 0 && ((md >> bitIdx) & 1ull)) { // diagonal (:496-506)
+                --tj;
+                --ti;
+                emit(CIG_M);
+            } else { // gap in vertical direction (:508-514)
+                if (ti == 0) { // (row 0 only has horizontal steps)
+                    flags |= FLAG_CAPACITY;
+                    break;
+                }
+                --ti;
+                emit(CIG_D);
+            }
+        }
+        for (; ok && ti > 0; --ti) emit(CIG_D); // findCIGAR walks on to (0, 0): leading deletions
+        if (run) {
+            if (nOps < stride) myOps[nOps] = (uint16_t)((run << 2) | state);
+            nOps++;
+        }
+        if (nOps > stride) flags |= FLAG_CAPACITY;
+        aln[it].nOps = nOps;
     }
     if (flags) atomicOr(flagWord, flags);
 }

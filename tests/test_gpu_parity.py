@@ -735,3 +735,36 @@ def test_paired_mates_across_sequence_boundaries_are_trimmed(world):
         s2 = se[i]
         assert (m2[2], m2[3], m2[5]) == (s2[2], s2[3], s2[5]), (m2, s2)   # sequence, position and CIGAR of the trimmed mate
         assert m2[2] == names[sid] and "S" not in m2[5]
+
+
+def test_cigars_along_the_right_edge_of_the_band(world, oracle_built):
+    """findCIGAR (cmb_cigar_windows) of alignments that run Wh = distance columns right of the diagonal — leading and inner
+    insertions of up to 13 characters: beyond 9 errors the match words of 32-row blocks do not reach the band's right edge in a block's
+    last rows, and k_cigar_wide takes them from the read's bit-strings instead (a trimmed occurrence with eleven leading insertions lost
+    its SAM record before).  Against the oracle's findCIGAR on the reference's matrices (64 bits up to 10 errors, 128 beyond)."""
+    import ctypes as C
+    import subprocess
+    g = world["genome"]
+    L = ca.lib()
+    base = g[700_000:700_200].tobytes()
+    ins = b"ACGTACGTACGTACG"
+    cases = []
+    for n_ins in (6, 9, 10, 11, 12, 13):
+        for d in range(max(n_ins, 8), 14):
+            cases.append((ins[:n_ins] + base[:150 - n_ins], 700_000, 700_000 + 150 - n_ins, d))
+            cases.append((base[:70] + ins[:n_ins] + base[70:150 - n_ins], 700_000, 700_000 + 150 - n_ins, d))
+            cases.append((base[:150 - n_ins] + ins[:n_ins], 700_000, 700_000 + 150 - n_ins, d))
+            cases.append((base[:60] + base[60 + n_ins:150 + n_ins], 700_000, 700_000 + 150 + n_ins, d))
+    cmds, got = [], []
+    for read, b, e, d in cases:
+        bb, ee, dd = np.array([b], np.uint32), np.array([e], np.uint32), np.array([d], np.uint32)
+        ops, nops = np.zeros(40, np.uint16), np.zeros(1, np.uint32)
+        rc = L.cmb_cigar_windows(world["dev"].h, read, len(read), bb.ctypes.data_as(C.c_void_p), ee.ctypes.data_as(C.c_void_p),
+                                 dd.ctypes.data_as(C.c_void_p), 1, ops.ctypes.data_as(C.c_void_p), 40, nops.ctypes.data_as(C.c_void_p))
+        assert rc == 0, (read, d, L.cmb_last_error())
+        got.append(ca.cigar_string(ops[:int(nops[0])]))
+        cmds.append(f"findcigar {read.decode()} {g[b:e].tobytes().decode()} {d}")
+    res = subprocess.run([os.path.join(oracle_built, "oracle_driver")], input="\n".join(cmds) + "\n", capture_output=True, text=True,
+                         check=True).stdout.splitlines()
+    assert res == got
+    assert sum("I" in c for c in got) > 50 and sum("D" in c for c in got) > 20
