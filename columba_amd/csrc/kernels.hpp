@@ -596,10 +596,8 @@ constexpr uint32_t TB_BELOW = 18;  // narrow rows (32-bit matrix, maxED <= 4)
 constexpr uint32_t TBW_BELOW = 21; // wide rows (64-bit / 16-row-block matrix, maxED <= 7: Wv = 3 maxED <= 21, Wh <= 7)
 // low half: HP; high half: M | ~D0 — "the diagonal step is allowed" (bitparallelmatrix.h:559-562), folded in by the
 // forward pass, which has the row's match word at hand: the trace then needs neither the text nor match words.
-// (below: columns of the window left of the diagonal — TBW_BELOW; k_cigar at 11 ... 13 errors, whose band is [-13, 13] around the
-// diagonal, takes 15: the window [-15, 16])
-__device__ __forceinline__ uint64_t packTraceRow(uint32_t r, uint64_t HP, uint64_t diagOk, uint32_t below = TBW_BELOW) {
-    const uint32_t sh = (r % MXW_BLOCK) + MXW_DIAG - below;
+__device__ __forceinline__ uint64_t packTraceRow(uint32_t r, uint64_t HP, uint64_t diagOk) {
+    const uint32_t sh = (r % MXW_BLOCK) + MXW_DIAG - TBW_BELOW;
     return (uint64_t)(uint32_t)(HP >> sh) | ((uint64_t)(uint32_t)(diagOk >> sh) << 32);
 }
 // NARROW rows (maxED <= 4): 16 + 16 bits per row, sixteen rows per 64-byte line — half the trace traffic.
@@ -704,7 +702,7 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
                                                 const MatGeom& g, uint32_t nZeros, uint32_t start, uint32_t size,
                                                 uint32_t maxED, uint32_t minED, uint32_t& centreMask,
                                                 uint64_t& edPack, uint64_t& edPackHi, const VPlanes& V, uint32_t slot,
-                                                uint32_t& cRows, uint64_t* Ml, uint32_t rowMin = 0, uint32_t twBelow = TBW_BELOW) {
+                                                uint32_t& cRows, uint64_t* Ml, uint32_t rowMin = 0) {
     // NARROW (k <= 4) also means the matrix on 32-bit words / 8-row blocks (dev_matrix.hpp)
     typedef InTextMx<NARROW> MX; // NARROW: 32-bit words / 8-row blocks; else 64-bit words / 16-row blocks (dev_matrix.hpp)
     using W = typename MX::W;
@@ -779,7 +777,7 @@ __device__ __forceinline__ uint32_t forwardPass(const DevIndex& ix, const MFull&
                         dAcc = 0;
                     }
                 }
-                if (STORE && !NARROW) buf[t & 7u] = packTraceRow(r, (uint64_t)HP, (uint64_t)(M | ~D0), twBelow);
+                if (STORE && !NARROW) buf[t & 7u] = packTraceRow(r, (uint64_t)HP, (uint64_t)(M | ~D0));
                 if (STORE && NARROW) bufN[t] = packTraceRowNarrow(r, (uint32_t)HP, (uint32_t)(M | ~D0));
                 if (!valid) {
                     alive = false;
@@ -2156,9 +2154,12 @@ k_cigar(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf, const uint4* _
         uint32_t dummyMask;
         uint64_t ep, eph;
         // rows 1..size of the fresh matrix (all valid: an alignment within maxED exists), trace rows to the lane's slab
-        const uint32_t below = maxED > MX_MAX_ED ? 15u : TBW_BELOW; // (the wide trace window: 11 ... 13 errors need 13 columns right of the diagonal)
+        if (trace && maxED > CIGAR_BLOCK_WORDS_MAX_ED) { // (the host launches k_cigar_wide beyond: the match words of 32-row blocks end there)
+            flags |= FLAG_CAPACITY;
+            trace = false;
+        }
         const uint32_t rowsDone = forwardPass<true, NARROW, PACKED>(ix, mf, rs, g, 1u, o.x, trace ? size : 0u, maxED, 0, dummyMask,
-                                                                    ep, eph, V, slot, dummyRows, Ml, 0u, below);
+                                                                    ep, eph, V, slot, dummyRows, Ml);
         if (trace && rowsDone < size) { // (a row without a cell <= maxED: the occurrence is not an alignment within its distance)
             flags |= FLAG_CAPACITY;
             trace = false;
@@ -2183,7 +2184,7 @@ k_cigar(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf, const uint4* _
                 run++;
             };
             while (tj > 0) {
-                const uint32_t rel = tj + (NARROW ? TB_BELOW : below) - ti;
+                const uint32_t rel = tj + (NARROW ? TB_BELOW : TBW_BELOW) - ti;
                 bool hpBit, dgBit;
                 if (NARROW) {
                     uint32_t wn = packTraceRowNarrow(0, (~0u) << MX32_LEFT, 0u);
@@ -2210,7 +2211,7 @@ k_cigar(DevIndex ix, const uint64_t* __restrict__ offs, MFull mf, const uint4* _
                     hpBit = rel >= TBN_HP_LO && ((wn >> (rel - TBN_HP_LO)) & 1u);
                     dgBit = rel == TBN_REL_HI || ((wn >> (16u + rel - TBN_DG_LO)) & 1u);
                 } else {
-                    uint64_t ww = packTraceRow(0, HP0, 0ull, below);
+                    uint64_t ww = packTraceRow(0, HP0, 0ull);
                     if (ti > 0) {
                         const uint32_t gq = (ti - 1) >> 3, jq = (ti - 1) & 7u;
                         if (gq != curG) {

@@ -743,6 +743,7 @@ def test_cigars_along_the_right_edge_of_the_band(world, oracle_built):
     last rows, and k_cigar_wide takes them from the read's bit-strings instead (a trimmed occurrence with eleven leading insertions lost
     its SAM record before).  Against the oracle's findCIGAR on the reference's matrices (64 bits up to 10 errors, 128 beyond)."""
     import ctypes as C
+    import os
     import subprocess
     g = world["genome"]
     L = ca.lib()
