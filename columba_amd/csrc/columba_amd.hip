@@ -677,7 +677,9 @@ extern "C" int cmb_batch_create(cmb_index* idx, const cmb_strategy* st, uint32_t
     if (getenv("CMB_SUBBATCHES")) S = (uint32_t)std::max(1, atoi(getenv("CMB_SUBBATCHES")));
     // a sub-batch holds fewer than 2^24 reads (24-bit read number of the filter key, 25 bits of read x strand in the
     // verification key): larger batches are cut into more sub-batches up front, never refused after the work is done
-    const uint32_t maxSub = (st->metric == CMB_METRIC_EDIT && max_distance > 7) ? (1u << 20) : MAX_SUB_READS; // (22 group bits in the wide filter keys)
+    // (22 group bits in the wide filter keys; from 11 errors on the frontier of a read can hold millions of nodes on a large reference —
+    // 20 000 reads at 12 errors on 3 Gbp overflowed pools of 2^32 slots —, so those sub-batches are small and run three at a time)
+    const uint32_t maxSub = st->metric != CMB_METRIC_EDIT || max_distance <= 7 ? MAX_SUB_READS : max_distance <= MX_MAX_ED ? (1u << 20) : (1u << 11);
     S = std::max<uint32_t>(S, (uint32_t)(((uint64_t)n_reads + maxSub - 1) / maxSub));
     S = std::min<uint32_t>(S, std::max<uint32_t>(n_reads, 1u));
     if (S <= 1) return batchCreateOne(idx, st, max_distance, seqs, offs, n_reads, out);
@@ -861,10 +863,11 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
     // per-kernel timings and counters want (bench.py times its throughput steps concurrently and takes the
     // kernel table from one extra serial step)
     const bool serial = getenv("CMB_SERIAL_SUBBATCHES") != nullptr;
-    // workers take the sub-batches in order; CMB_MAX_CONCURRENT=m: at most m at a time (default: all of them)
+    // workers take the sub-batches in order, three at a time (the number that pays, cmb_batch_create); CMB_MAX_CONCURRENT=m: at most m
     const char* mcEnv = getenv("CMB_MAX_CONCURRENT");
-    size_t nWorkers = serial ? 1 : b->subs.size();
+    size_t nWorkers = serial ? 1 : std::min<size_t>(b->subs.size(), 3);
     if (mcEnv && !serial) nWorkers = std::min<size_t>(b->subs.size(), std::max(1, atoi(mcEnv)));
+    const bool manySubs = b->subs.size() > 3; // (then a finished sub-batch gives its pools back: the next one allocates what it needs)
     std::atomic<size_t> next{0};
     std::vector<std::thread> th;
     for (size_t w = 0; w < nWorkers; w++)
@@ -872,8 +875,14 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
             for (;;) {
                 const size_t j = next.fetch_add(1);
                 if (j >= b->subs.size()) break;
-                rc[j] = batchRunOne(b->subs[j]);
+                cmb_batch* c = b->subs[j];
+                rc[j] = batchRunOne(c);
                 if (rc[j] != CMB_OK) err[j] = cmb_last_error(); // (the message lives in the worker's thread-local storage)
+                if (manySubs) { // (results, alignments and counters are on the host; a second run allocates again)
+                    for (int q2 = 0; q2 < 2; q2++) c->bfsQ[q2].release(), c->bfsEv[q2].release();
+                    c->bfsF.release(), c->bfsC.release(), c->bfsA.release(), c->dpSlab.release(), c->dpList.release(), c->vW.release();
+                    c->sortTmp.release(), c->scanTmp.release(), c->vkeysA.release(), c->vkeysB.release();
+                }
             }
         });
     for (auto& t : th) t.join();
@@ -1239,12 +1248,15 @@ static int batchRunOne(cmb_batch* b) {
                     hipLaunchKernelGGL(k_bfs_finish, dim3(1), dim3(256), 0, s, B, q);
                     if (hcnt[3] & (FLAG_BFS_Q | FLAG_BFS_EV | FLAG_BFS_F | FLAG_BFS_CTX | FLAG_BFS_ARENA)) {
                         // a pool was too small: grow what was asked for (at least x2) and run the search again
-                        if (++bfsAttempts >= 24) return fail(CMB_ERR_INTERNAL, "frontier pools keep overflowing");
-                        if (hcnt[3] & FLAG_BFS_Q) b->bfsQCap = std::max<size_t>(2 * b->bfsQCap, (size_t)peakQ + peakQ / 4);
-                        if (hcnt[3] & FLAG_BFS_EV) b->bfsEvCap = std::max<size_t>(2 * b->bfsEvCap, (size_t)peakEv + peakEv / 4);
-                        if (hcnt[3] & FLAG_BFS_F) b->bfsFCap = std::max<size_t>(2 * b->bfsFCap, (size_t)pool[0] + pool[0] / 4);
-                        if (hcnt[3] & FLAG_BFS_CTX) b->bfsCCap = std::max<size_t>(2 * b->bfsCCap, (size_t)pool[1] + pool[1] / 4);
-                        if (hcnt[3] & FLAG_BFS_ARENA) b->bfsACap = std::max<size_t>(2 * b->bfsACap, (size_t)pool[2] + pool[2] / 4);
+                        // (an attempt only shows the demand up to the pass that overflowed: beyond 7 errors, where the first guesses are far
+                        // off — 64 reads at 12 errors on 3 Gbp took eleven attempts at x 2 —, the pools grow x 4)
+                        if (++bfsAttempts >= 48) return fail(CMB_ERR_INTERNAL, "frontier pools keep overflowing");
+                        const size_t gf = b->k > 7 ? 4 : 2;
+                        if (hcnt[3] & FLAG_BFS_Q) b->bfsQCap = std::max<size_t>(gf * b->bfsQCap, (size_t)peakQ + peakQ / 4);
+                        if (hcnt[3] & FLAG_BFS_EV) b->bfsEvCap = std::max<size_t>(gf * b->bfsEvCap, (size_t)peakEv + peakEv / 4);
+                        if (hcnt[3] & FLAG_BFS_F) b->bfsFCap = std::max<size_t>(gf * b->bfsFCap, (size_t)pool[0] + pool[0] / 4);
+                        if (hcnt[3] & FLAG_BFS_CTX) b->bfsCCap = std::max<size_t>(gf * b->bfsCCap, (size_t)pool[1] + pool[1] / 4);
+                        if (hcnt[3] & FLAG_BFS_ARENA) b->bfsACap = std::max<size_t>(gf * b->bfsACap, (size_t)pool[2] + pool[2] / 4);
                         HIPCHK(hipStreamSynchronize(s));
                         tm.end("k_dfs");
                         continue;
