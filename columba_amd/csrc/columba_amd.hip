@@ -745,8 +745,9 @@ static int batchCreateOne(cmb_index* idx, const cmb_strategy* st, uint32_t max_d
         if (max_distance > 0) {
             // in-text verification: nZeros + maxED = 3k+1 must fit the first column of the in-text matrix (the reference
             // switches to its 128-bit matrix at k = 7, fmindex.h:240-246; here: 64-bit words / 16-row blocks, LEFT = 22)
-            // edit distance beyond 7 errors: the in-index search runs up to 10 (the 64-bit in-index matrix, bitparallelmatrix.h:309-316; wide
-            // record geometry GeoW); the bit-parallel in-text matrices stop at 7, candidates are verified by k_verify_wide
+            // edit distance beyond 7 errors: the wide record geometry of the frontier (GeoW up to 10 errors, the reach of the reference's
+            // 64-bit in-index matrix; GeoX with its 16-row blocks beyond); the staged in-text matrices stop at 7, candidates are verified by
+            // k_wide_filter + k_verify_wide
             b->wideEdit = st->metric == CMB_METRIC_EDIT && 3 * max_distance + 1 > MXW_LEFT;
             b->geoX = b->wideEdit && max_distance > MX_MAX_ED; // (beyond the reference's 64-bit in-index matrix: dev_matrix.hpp, MXN_*)
             try {
@@ -1390,9 +1391,9 @@ static int batchRunOne(cmb_batch* b) {
                 // one read seeding the same alignment) are performed once: k_verify only locates and emits a key per
                 // candidate, the keys are sorted and run-length encoded, k_verify_edit verifies the distinct ones and
                 // scales the counters by the multiplicities.
-                // (25 key bits for read x strand; 21 in the key layout of batches at 8 ... 10 errors, whose sub-batches hold at most 2^20 reads)
+                // (25 key bits for read x strand; 21 in the key layout of batches at 8 ... 13 errors, whose sub-batches hold at most 2^20 reads)
                 const bool dedup = b->metric == CMB_METRIC_EDIT && b->k > 0 && 2ull * nReads < (b->wideEdit ? (1ull << 21) : (1ull << 25));
-                if (b->wideEdit && !dedup) return fail(CMB_ERR_INTERNAL, "a sub-batch at 8 ... 10 errors holds more reads than its verification keys number");
+                if (b->wideEdit && !dedup) return fail(CMB_ERR_INTERNAL, "a sub-batch beyond 7 errors holds more reads than its verification keys number");
                 const uint32_t tbCap = (uint32_t)std::min<size_t>(b->tbq.n, 0xFFFFFFF0u);
                 const char* vGroup = "k_verify";
                 tm.begin();
@@ -1430,8 +1431,8 @@ static int batchRunOne(cmb_batch* b) {
                     tm.begin();
                     if (getenv("CMB_VERBOSE")) fprintf(stderr, "[verify] %u items, %u distinct keys\n", nItems, nRuns);
                     if (nRuns && b->wideEdit) {
-                        // 8 ... 10 errors: the band (up to 41 columns) needs the wide left margin of the 64-bit in-text matrix (dev_matrix.hpp:
-                        // MXX_*): k_wide_filter sorts out the candidates that never reach their final column, k_verify_wide<true> verifies the rest
+                        // 8 ... 13 errors: the band (up to 53 columns) needs the wide left margins of the 64-bit in-text matrix (dev_matrix.hpp:
+                        // MXX_*, MXY_*): k_wide_filter sorts out the candidates that never reach their final column, k_verify_wide<true> verifies the rest
                         const uint32_t fGrid = std::min<uint32_t>((nRuns + 255) / 256, 2048u);
                         // (every key, the slots a wavefront leaves unused when it retires a chunk — fewer than 64 of 256 —, a chunk per wavefront)
                         const size_t listNeed = (size_t)nRuns + nRuns / 3 + (size_t)fGrid * 4 * 256 + 512;

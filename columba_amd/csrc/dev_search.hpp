@@ -91,7 +91,7 @@ constexpr bool flagBitsDisjoint() {
 static_assert(flagBitsDisjoint(), "every flag is one bit of its own");
 
 // The layouts of the low bits of a filter key (`layout`): 0 edit distance up to 7 (begin << 8 | distance[7:5] | width - (len - k) [4:1] |
-// strand), 1 Hamming distance (distance[7:4], the width is the read's), 2 edit distance 8 ... 10 (begin << 10 | distance[9:6] |
+// strand), 1 Hamming distance (distance[7:4], the width is the read's), 2 edit distance 8 ... 13 (begin << 10 | distance[9:6] |
 // width - (len - k) [5:1] | strand; 22 bits are left for the group: sub-batches of at most 2^21 reads).
 struct KeyBits {
     uint32_t group, begin, dist, distMask, wMask;

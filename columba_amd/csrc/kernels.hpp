@@ -857,7 +857,7 @@ __host__ __device__ __forceinline__ uint32_t verifyKeyStart(unsigned long long k
     const uint32_t v = (uint32_t)key;
     return (v << VK_LOW) | (v >> (32u - VK_LOW));
 }
-// ... and for batches at 8 ... 10 errors (k_wide_filter / k_verify_wide): four bits for each bound, read x strand from bit 41
+// ... and for batches at 8 ... 13 errors (k_wide_filter / k_verify_wide): four bits for each bound, read x strand from bit 41
 // (sub-batches of at most 2^20 reads)
 constexpr uint32_t VKW_RS = 41;
 __host__ __device__ __forceinline__ unsigned long long packVerifyKeyW(uint32_t rs, uint32_t start, uint32_t maxED, uint32_t minED,
@@ -932,7 +932,7 @@ __global__ void __launch_bounds__(256)
 k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32_t gw,
          const uint8_t* __restrict__ seq, MFull mf, const uint4* __restrict__ items,
          uint32_t nItems, uint4* __restrict__ tbq, uint32_t tbCap, unsigned long long* __restrict__ vkeys, Queues q,
-         uint32_t wideKeys = 0 /* KEYS: the key layout of batches at 8 ... 10 errors (packVerifyKeyW) */) {
+         uint32_t wideKeys = 0 /* KEYS: the key layout of batches at 8 ... 13 errors (packVerifyKeyW) */) {
     __shared__ uint64_t Ml[ML_WORDS];
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cLF = 0, cLoc = 0, cText = 0, cRows = 0, cAbort = 0, cCig = 0, cStarted = 0, cRep = 0, flags = 0;
@@ -1060,7 +1060,7 @@ k_verify(DevIndex ix, const uint64_t* __restrict__ offs, uint32_t maxLen, uint32
     if (flags) atomicOr(&q.cnt[3], flags);
 }
 
-// In-text verification at 8 ... 10 errors (FMIndex::inTextVerification + InTextVerificationTask::doTask, fmindex.cpp:267-310,
+// In-text verification at 8 ... 13 errors (FMIndex::inTextVerification + InTextVerificationTask::doTask, fmindex.cpp:267-310,
 // indexhelpers.cpp:518-574).  A candidate without a fixed start has a band of 4 k + 1 columns — 41 at k = 10 — where the reference switches
 // to its 128-bit matrix; the SAME algorithm on 64-bit words with 16-row blocks and a left margin of 31 bits holds that band
 // (dev_matrix.hpp: MXX_*), so these kernels run the reference's recurrence, rightmost-active-column walk, cluster centres and traceback

@@ -710,7 +710,7 @@ extern "C" int cmb_move_batch_create(cmb_move_index* idx, const cmb_strategy* st
         b->metric = st->metric;
         b->kmerSize = kmer_size;
         if (max_distance > 0) {
-            if (st->metric == CMB_METRIC_EDIT && max_distance > MX_MAX_ED) return failWith(CMB_ERR_UNSUPPORTED, "more than 10 errors need the 128-bit in-index matrix");
+            if (max_distance > 7) return failWith(CMB_ERR_UNSUPPORTED, "more than 7 errors are not provided on the b-move index (tables of 8 parts, narrow records)");
             try {
                 b->hostStrat = st->flatten(max_distance);
             } catch (const std::exception& e) {
