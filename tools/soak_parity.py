@@ -54,7 +54,11 @@ dev2, orc2 = ca.Index(ix2), op.OracleIndex(ix2)
 g2h = g2.cpu().numpy() if hasattr(g2, "cpu") else g2
 for spec, metric, part, k, n, ln in (("multiple_opt", "edit", "dynamic", 4, 200000, 150), ("columba", "edit", "dynamic", 7, 30000, 150),
                                      ("multiple_opt", "edit", "dynamic", 6, 60000, 250), ("columba", "edit", "dynamic", 4, 100000, 100),
-                                     ("kuch1", "hamming", "dynamic", 3, 200000, 150), ("minU", "edit", "static", 5, 60000, 76)):
+                                     ("kuch1", "hamming", "dynamic", 3, 200000, 150), ("minU", "edit", "static", 5, 60000, 76),
+                                     # beyond 7 errors: wide record geometries, the in-text matrices with wide left margins
+                                     ("columba", "edit", "dynamic", 9, 10000, 150), ("columba", "edit", "dynamic", 11, 6000, 150),
+                                     ("columba", "edit", "uniform", 12, 4000, 250), ("columba", "edit", "static", 13, 4000, 150),
+                                     ("columba", "hamming", "dynamic", 13, 20000, 150)):
     reads = synth.sample_reads(g2h, n, ln, seed=int(rng.integers(1 << 30)), n_frac=0.01, edit_choices=(0, 0, 1, 2, 3, k, k + 1))
     t = time.time()
     o_occ, o_off, o_cnt = op.match_batch(orc2, op.OracleStrategy(sp.BY_NAME[spec], metric, part), k, reads, threads=128)
