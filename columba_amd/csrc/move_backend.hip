@@ -638,6 +638,12 @@ struct cmb_move_batch {
     uint32_t k = 0, nReads = 0, maxLen = 0, gw = 0, kmerSize = 0;
     int metric = 1;
     DevStrategyK hostStrat{};
+    // more than 8 parts (the greedy schemes under Hamming distance at 8 ... 13 errors): the wide tables, as on the FM-index
+    bool wide = false;
+    DevStrategyKT<MAXP_WIDE> hostStratW{};
+    MvBuf<DevStrategyKT<MAXP_WIDE>> stratW;
+    MvBuf<PartOutT<MAXP_WIDE>> partsW;
+    uint32_t sNumParts = 0, sPartition = 0, sNSchemes = 0, sMaxSearches = 0;
     hipStream_t stream = nullptr;
     std::vector<uint8_t> hostReads; // (k = 0 goes through cmb_move_match_exact, which takes host buffers)
     std::vector<uint64_t> hostOffs;
@@ -710,9 +716,20 @@ extern "C" int cmb_move_batch_create(cmb_move_index* idx, const cmb_strategy* st
         b->metric = st->metric;
         b->kmerSize = kmer_size;
         if (max_distance > 0) {
-            if (max_distance > 7) return failWith(CMB_ERR_UNSUPPORTED, "more than 7 errors are not provided on the b-move index (tables of 8 parts, narrow records)");
+            if (st->metric == CMB_METRIC_EDIT && max_distance > 7)
+                return failWith(CMB_ERR_UNSUPPORTED, "more than 7 errors under edit distance are not provided on the b-move index (narrow records of its frontier)");
+            if (max_distance > 13) return failWith(CMB_ERR_UNSUPPORTED, "more than 13 errors (MAX_K, definitions.h:50)");
             try {
-                b->hostStrat = st->flatten(max_distance);
+                b->wide = st->numPartsFor(max_distance) > (uint32_t)MAXP;
+                if (b->wide) {
+                    b->hostStratW = st->flatten<MAXP_WIDE>(max_distance);
+                    b->sNumParts = b->hostStratW.numParts, b->sPartition = b->hostStratW.partition, b->sNSchemes = b->hostStratW.nSchemes;
+                    for (int i = 0; i < b->hostStratW.nSchemes; i++) b->sMaxSearches = std::max<uint32_t>(b->sMaxSearches, b->hostStratW.sch[i].nSearches);
+                } else {
+                    b->hostStrat = st->flatten(max_distance);
+                    b->sNumParts = b->hostStrat.numParts, b->sPartition = b->hostStrat.partition, b->sNSchemes = b->hostStrat.nSchemes;
+                    for (int i = 0; i < b->hostStrat.nSchemes; i++) b->sMaxSearches = std::max<uint32_t>(b->sMaxSearches, b->hostStrat.sch[i].nSearches);
+                }
             } catch (const std::exception& e) {
                 return failWith(CMB_ERR_INVALID, e.what());
             }
@@ -734,7 +751,10 @@ extern "C" int cmb_move_batch_create(cmb_move_index* idx, const cmb_strategy* st
         MV_HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
         b->reads.upload(b->hostReads.data(), b->hostReads.size());
         b->offs.upload(b->hostOffs.data(), n_reads + 1);
-        if (max_distance > 0) b->strat.upload(&b->hostStrat, 1); // (per-read scratch is sized per slice, at the first run)
+        if (max_distance > 0) { // (per-read scratch is sized per slice, at the first run)
+            if (b->wide) b->stratW.upload(&b->hostStratW, 1);
+            else b->strat.upload(&b->hostStrat, 1);
+        }
         b->cnt.alloc(8);
         b->counters.alloc(CMB_CNT_MAX);
         b->bad.alloc(1);
@@ -857,24 +877,21 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
             sx.kmerSize = ix->kmerSize;
         }
         uint32_t hcnt[8];
-        if (b->parts.n < (size_t)2 * nReads) { // per-read scratch of a slice
+        if ((b->wide ? b->partsW.n : b->parts.n) < (size_t)2 * nReads) { // per-read scratch of a slice
             b->seq.alloc((size_t)2 * nReads * b->maxLen);
             b->G.alloc((size_t)nReads * 8 * b->gw);
-            b->parts.alloc((size_t)2 * nReads);
+            if (b->wide) b->partsW.alloc((size_t)2 * nReads);
+            else b->parts.alloc((size_t)2 * nReads);
             b->psel.alloc((size_t)2 * nReads);
-            b->exr.alloc((size_t)2 * nReads * b->hostStrat.numParts);
-            uint32_t ms2 = 0;
-            for (int i = 0; i < b->hostStrat.nSchemes; i++) ms2 = std::max<uint32_t>(ms2, b->hostStrat.sch[i].nSearches);
-            b->tasks.alloc((size_t)2 * nReads * ms2 + 64);
+            b->exr.alloc((size_t)2 * nReads * b->sNumParts);
+            b->tasks.alloc((size_t)2 * nReads * b->sMaxSearches + 64);
         }
         // ---- read preparation
         tm.begin();
         MV_HIPCHK(hipMemsetAsync(b->G.p, 0, (size_t)nReads * 8 * b->gw * sizeof(uint32_t), s));
         hipLaunchKernelGGL(k_mvs_prep, dim3(gridFor(nReads)), dim3(256), 0, s, b->reads.p, dOffs, nReads, b->maxLen, b->gw, b->seq.p, b->G.p);
         tm.end("k_prep");
-        const uint32_t P = b->hostStrat.numParts;
-        uint32_t maxSearches = 0;
-        for (int i = 0; i < b->hostStrat.nSchemes; i++) maxSearches = std::max<uint32_t>(maxSearches, b->hostStrat.sch[i].nSearches);
+        const uint32_t P = b->sNumParts, maxSearches = b->sMaxSearches;
         uint32_t nFm = 0;
         bool hasNaive = false; // reads of the slice are matched by naive backtracking (k_mvs_parts marked them in psel)
         for (int attempt = 0;; attempt++) {
@@ -887,13 +904,22 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
             tm.begin();
             {
                 const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)tasksRS + 63) / 64, 256 * 64);
-                auto kp = b->hostStrat.partition == 0 ? k_mvs_parts<0> : b->hostStrat.partition == 1 ? k_mvs_parts<1> : k_mvs_parts<2>;
-                hipLaunchKernelGGL(kp, dim3(grid), dim3(64), (size_t)P * 3 * 64 * sizeof(uint4), s, sx, b->strat.p, nReads, b->maxLen, b->seq.p, dOffs, b->parts.p, b->exr.p,
-                                   b->psel.p, q);
                 const uint64_t nWork = (uint64_t)tasksRS * maxSearches;
                 const unsigned gridE = (unsigned)std::min<uint64_t>((nWork + 63) / 64, 256 * 64);
-                hipLaunchKernelGGL(k_mvs_exact, dim3(gridE), dim3(64), 0, s, sx, b->strat.p, nReads, b->maxLen, maxSearches, b->seq.p, b->parts.p, b->exr.p,
-                                   b->psel.p, b->tasks.p, (uint32_t)std::min<size_t>(b->tasks.n, 0xFFFFFFF0u), q);
+                const size_t exLdsBytes = (size_t)P * 3 * 64 * sizeof(uint4);
+                if (b->wide) {
+                    auto kp = b->sPartition == 0 ? k_mvs_parts<0, MAXP_WIDE> : b->sPartition == 1 ? k_mvs_parts<1, MAXP_WIDE> : k_mvs_parts<2, MAXP_WIDE>;
+                    hipLaunchKernelGGL(kp, dim3(grid), dim3(64), exLdsBytes, s, sx, b->stratW.p, nReads, b->maxLen, b->seq.p, dOffs, b->partsW.p, b->exr.p,
+                                       b->psel.p, q);
+                    hipLaunchKernelGGL(k_mvs_exact<MAXP_WIDE>, dim3(gridE), dim3(64), 0, s, sx, b->stratW.p, nReads, b->maxLen, maxSearches, b->seq.p, b->partsW.p,
+                                       b->exr.p, b->psel.p, b->tasks.p, (uint32_t)std::min<size_t>(b->tasks.n, 0xFFFFFFF0u), q);
+                } else {
+                    auto kp = b->sPartition == 0 ? k_mvs_parts<0, MAXP> : b->sPartition == 1 ? k_mvs_parts<1, MAXP> : k_mvs_parts<2, MAXP>;
+                    hipLaunchKernelGGL(kp, dim3(grid), dim3(64), exLdsBytes, s, sx, b->strat.p, nReads, b->maxLen, b->seq.p, dOffs, b->parts.p, b->exr.p,
+                                       b->psel.p, q);
+                    hipLaunchKernelGGL(k_mvs_exact<MAXP>, dim3(gridE), dim3(64), 0, s, sx, b->strat.p, nReads, b->maxLen, maxSearches, b->seq.p, b->parts.p,
+                                       b->exr.p, b->psel.p, b->tasks.p, (uint32_t)std::min<size_t>(b->tasks.n, 0xFFFFFFF0u), q);
+                }
             }
             tm.end("k_partition");
             MV_HIPCHK(hipGetLastError());
@@ -954,7 +980,7 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
             if (nTasks && b->metric != CMB_METRIC_EDIT) {
                 // ---- Hamming distance: the frontier without a matrix (k_mvs_hbfs), one row per pass
                 tm.begin();
-                const uint32_t maxPass = b->maxLen + 2 * MAXP + 16;
+                const uint32_t maxPass = b->maxLen + 2 * (b->wide ? MAXP_WIDE : MAXP) + 16;
                 constexpr uint32_t PU = MvTraits::PAIR_U4;
                 if (!b->qCap) b->qCap = (getenv("CMB_TEST_SMALL_POOLS") ? 0 : (size_t)nReads * 8) + 1024;
                 b->qCap = std::max<size_t>(b->qCap, (size_t)nTasks + 1024);
@@ -972,16 +998,24 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                 H.nq = b->bfsCnt.p;
                 H.blockCnt = b->blockCnt.p;
                 H.fmX = b->fm.p;
-                hipLaunchKernelGGL(k_mvs_hbfs<true>, dim3(std::min<uint32_t>((nTasks + 255) / 256, BFS_GRID)), dim3(256), 0, s, ix->d, b->strat.p, H, 0u,
-                                   b->tasks.p, nTasks, b->maxLen, b->seq.p, b->parts.p, q);
+                if (b->wide)
+                    hipLaunchKernelGGL((k_mvs_hbfs<true, MAXP_WIDE>), dim3(std::min<uint32_t>((nTasks + 255) / 256, BFS_GRID)), dim3(256), 0, s, ix->d, b->stratW.p,
+                                       H, 0u, b->tasks.p, nTasks, b->maxLen, b->seq.p, b->partsW.p, q);
+                else
+                    hipLaunchKernelGGL((k_mvs_hbfs<true, MAXP>), dim3(std::min<uint32_t>((nTasks + 255) / 256, BFS_GRID)), dim3(256), 0, s, ix->d, b->strat.p, H, 0u,
+                                       b->tasks.p, nTasks, b->maxLen, b->seq.p, b->parts.p, q);
                 std::vector<uint32_t> hc(cntWords);
                 uint32_t pass = 0, peakQ = 0;
                 bool drained = false;
                 while (!drained && pass < maxPass) {
                     const uint32_t upTo = std::min(pass + 16u, maxPass);
                     for (; pass < upTo; pass++)
-                        hipLaunchKernelGGL(k_mvs_hbfs<false>, dim3(BFS_GRID), dim3(256), 0, s, ix->d, b->strat.p, H, pass, (const MvTask*)nullptr, 0u,
-                                           b->maxLen, b->seq.p, b->parts.p, q);
+                        if (b->wide)
+                            hipLaunchKernelGGL((k_mvs_hbfs<false, MAXP_WIDE>), dim3(BFS_GRID), dim3(256), 0, s, ix->d, b->stratW.p, H, pass, (const MvTask*)nullptr,
+                                               0u, b->maxLen, b->seq.p, b->partsW.p, q);
+                        else
+                            hipLaunchKernelGGL((k_mvs_hbfs<false, MAXP>), dim3(BFS_GRID), dim3(256), 0, s, ix->d, b->strat.p, H, pass, (const MvTask*)nullptr, 0u,
+                                               b->maxLen, b->seq.p, b->parts.p, q);
                     MV_HIPCHK(hipMemcpyAsync(hc.data(), b->bfsCnt.p, cntWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                     MV_HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
                     MV_HIPCHK(hipStreamSynchronize(s));

@@ -376,17 +376,17 @@ __global__ void k_mvs_prep(const uint8_t* __restrict__ reads, const uint64_t* __
 // ------------------------------------------------------------------ prologue: partitioning + scheme selection
 // SearchStrategy::partition (searchstrategy.cpp:141-419) and MultipleSchemes::createSearches (searchstrategy.h:2505-2537), one
 // lane per read x strand.  Partition state in LDS ([field][part][lane]).
-template <int PARTITION>
+template <int PARTITION, int MP = MAXP>
 __global__ void __launch_bounds__(64)
-k_mvs_parts(MvSearchIndex sx, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint32_t maxLen, const uint8_t* __restrict__ seqAll,
-            const uint64_t* __restrict__ offs, PartOut* __restrict__ partsOut, MoveRangeRec* __restrict__ exr, uint8_t* __restrict__ psel, Queues q) {
-    __shared__ uint32_t pbe[MAXP][64];
-    __shared__ unsigned long long wid[MAXP][64];
+k_mvs_parts(MvSearchIndex sx, const DevStrategyKT<MP>* __restrict__ stp, uint32_t nReads, uint32_t maxLen, const uint8_t* __restrict__ seqAll,
+            const uint64_t* __restrict__ offs, PartOutT<MP>* __restrict__ partsOut, MoveRangeRec* __restrict__ exr, uint8_t* __restrict__ psel, Queues q) {
+    __shared__ uint32_t pbe[MP][64];
+    __shared__ unsigned long long wid[MP][64];
     // the exact-match range pair of every part while the read is partitioned: [part][plane][lane], packed as in the frontier's
     // records (3 x 16 bytes).  Dynamic partitioning extends a different part at almost every step; with the pairs in global memory
     // each step was a scattered 80-byte load and store around its row fetches (k_partition: 528 GB of traffic per 10^6-read step).
     extern __shared__ uint4 exLds[];
-    const DevStrategyK& st = *stp;
+    const DevStrategyKT<MP>& st = *stp;
     const MoveDev& ix = sx.d;
     const uint32_t lane = threadIdx.x, total = 2 * nReads;
     MvCounters cnt;
@@ -542,9 +542,9 @@ k_mvs_parts(MvSearchIndex sx, const DevStrategyK* __restrict__ stp, uint32_t nRe
                 }
             }
         }
-        PartOut po;
+        PartOutT<MP> po;
 #pragma unroll
-        for (int i = 0; i < MAXP; i++) {
+        for (int i = 0; i < MP; i++) {
             po.pb[i] = i < P ? (uint16_t)PB(i) : (uint16_t)0;
             po.pe[i] = i < P ? (uint16_t)PE(i) : (uint16_t)0;
         }
@@ -562,11 +562,12 @@ k_mvs_parts(MvSearchIndex sx, const DevStrategyK* __restrict__ stp, uint32_t nRe
 // SearchStrategy::doRecSearch (searchstrategy.cpp:1181-1254) up to the first approximate phase, one lane per (read x strand,
 // search of the selected scheme).  Emits one MvTask per search that starts (recApproxMatchEditEntry of this flavour counts
 // every one of them as SEARCH_STARTED, indexinterface.cpp:1321-1323).
+template <int MP = MAXP>
 __global__ void __launch_bounds__(64)
-k_mvs_exact(MvSearchIndex sx, const DevStrategyK* __restrict__ stp, uint32_t nReads, uint32_t maxLen, uint32_t nSlots,
-            const uint8_t* __restrict__ seqAll, const PartOut* __restrict__ parts, const MoveRangeRec* __restrict__ exr,
+k_mvs_exact(MvSearchIndex sx, const DevStrategyKT<MP>* __restrict__ stp, uint32_t nReads, uint32_t maxLen, uint32_t nSlots,
+            const uint8_t* __restrict__ seqAll, const PartOutT<MP>* __restrict__ parts, const MoveRangeRec* __restrict__ exr,
             const uint8_t* __restrict__ psel, MvTask* __restrict__ tasks, uint32_t taskCap, Queues q) {
-    const DevStrategyK& st = *stp;
+    const DevStrategyKT<MP>& st = *stp;
     const MoveDev& ix = sx.d;
     const uint32_t total = 2 * nReads;
     const uint64_t nWork = (uint64_t)total * nSlots;
@@ -576,11 +577,11 @@ k_mvs_exact(MvSearchIndex sx, const DevStrategyK* __restrict__ stp, uint32_t nRe
         const uint32_t rs = (uint32_t)(w / nSlots), slot = (uint32_t)(w % nSlots);
         const uint8_t ps = psel[rs];
         if (ps & 0x80u) continue;
-        const DevScheme& sch = st.sch[ps];
+        const DevSchemeT<MP>& sch = st.sch[ps];
         if (slot >= sch.nSearches) continue;
-        const DevSearch& s = sch.s[slot];
+        const DevSearchT<MP>& s = sch.s[slot];
         const uint8_t* seq = seqAll + (size_t)rs * maxLen;
-        const PartOut po = parts[rs];
+        const PartOutT<MP> po = parts[rs];
         MvPair cur;
         uint32_t idx = 0, depth = 0;
         if (s.U[0] > 0) { // the first part already allows errors: start from the empty match
@@ -876,14 +877,14 @@ struct MvHbfsBufs {
     unsigned long long* blockCnt; // [BFS_GRID][4]: children, expansions, -, table rows
     MvFmRec* fmX;
 };
-template <bool START>
+template <bool START, int MP = MAXP>
 __global__ void __launch_bounds__(256)
-k_mvs_hbfs(MoveDev ix, const DevStrategyK* __restrict__ stp, MvHbfsBufs B, uint32_t pass, const MvTask* __restrict__ tasks, uint32_t nTasks,
-           uint32_t maxLen, const uint8_t* __restrict__ seq, const PartOut* __restrict__ parts, Queues q) {
+k_mvs_hbfs(MoveDev ix, const DevStrategyKT<MP>* __restrict__ stp, MvHbfsBufs B, uint32_t pass, const MvTask* __restrict__ tasks, uint32_t nTasks,
+           uint32_t maxLen, const uint8_t* __restrict__ seq, const PartOutT<MP>* __restrict__ parts, Queues q) {
     __shared__ uint32_t sh[4][5];
     if (blockStopped(q)) return;
     constexpr uint32_t PU = MvTraits::PAIR_U4;
-    const DevStrategyK& st = *stp;
+    const DevStrategyKT<MP>& st = *stp;
     const uint32_t outP = START ? 0u : pass + 1u;
     const uint32_t nIn = START ? nTasks : min(B.nq[pass], B.qCap);
     const uint4* __restrict__ Qi = B.Q[pass & 1u];
@@ -900,8 +901,8 @@ k_mvs_hbfs(MoveDev ix, const DevStrategyK* __restrict__ stp, MvHbfsBufs B, uint3
         if (START) {
             if (i < nIn) {
                 const MvTask t = tasks[i];
-                const DevSearch& s = st.sch[t.scheme].s[t.search];
-                const PartOut po = parts[t.rsId];
+                const DevSearchT<MP>& s = st.sch[t.scheme].s[t.search];
+                const PartOutT<MP> po = parts[t.rsId];
                 rsId = t.rsId;
                 ch[0] = loadPair(t.r);
                 cMeta[0] = (uint32_t)t.scheme | ((uint32_t)t.search << 4) | ((uint32_t)t.idx << 9);
@@ -917,7 +918,7 @@ k_mvs_hbfs(MoveDev ix, const DevStrategyK* __restrict__ stp, MvHbfsBufs B, uint3
             const uint32_t scheme = n1.y & 15u, search = (n1.y >> 4) & 31u, idx = (n1.y >> 9) & 15u, row = n1.y >> 13;
             const uint32_t v = n1.z & 0xFFu, smDepth = n1.z >> 8;
             const uint32_t pb = n1.w & 0x1FFu, pe = (n1.w >> 9) & 0x1FFu;
-            const DevSearch& s = st.sch[scheme].s[search];
+            const DevSearchT<MP>& s = st.sch[scheme].s[search];
             const uint32_t dir = s.dir[idx];
             const int md = (s.uniAll || idx >= (uint32_t)s.uniIdx) ? 2 : (dir == 0 ? 0 : 1);
             const uint32_t xLen = pe - pb;
@@ -941,7 +942,7 @@ k_mvs_hbfs(MoveDev ix, const DevStrategyK* __restrict__ stp, MvHbfsBufs B, uint3
                         cVd[c] = v1;
                         nFm++;
                     } else { // recApproxMatchHamming(s, match, ..., idx + 1): the child is the start match
-                        const PartOut po = parts[rsId];
+                        const PartOutT<MP> po = parts[rsId];
                         kinds |= 1u << (4 * c);
                         cMeta[c] = scheme | (search << 4) | ((idx + 1) << 9);
                         cVd[c] = v1 | (fmDepth << 8);

@@ -109,10 +109,15 @@ def test_bmove_search_parity(sworld, gt, spec, partition, k, length):
     ("columba", "dynamic", 3, 100),
     ("pigeon", "uniform", 1, 100),
     ("kianfar", "dynamic", 4, 100),
+    # beyond 8 parts: the greedy schemes of the columba strategy on the wide tables (k_mvs_parts / k_mvs_exact / k_mvs_hbfs<.., MAXP_WIDE>)
+    ("columba", "dynamic", 8, 150),
+    ("columba", "uniform", 10, 150),
+    ("columba", "static", 13, 250),
+    ("columba", "dynamic", 13, 150),
 ])
 def test_bmove_hamming_parity(sworld, gt, spec, partition, k, length):
     """recApproxMatchHamming on the b-move index (indexinterface.cpp:1211-1304, RLC branches) + getTextOccHamming"""
-    reads = _reads(sworld["g"], k, 1500, length, seed=170 + k + length)
+    reads = _reads(sworld["g"], k, 1500 if k <= 7 else 600, length, seed=170 + k + length)
     # (substitutions only would be the typical Hamming input; reads with indels simply have fewer occurrences)
     reads += synth.sample_reads(sworld["g"], 500, length, seed=5 + k, p_sub=1.0, p_ins=0.0, edit_choices=(0, 1, k, k))
     occ, offs, cnt, _ = _compare(sworld, spec, partition, k, reads, metric="hamming")
