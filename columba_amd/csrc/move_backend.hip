@@ -716,11 +716,10 @@ extern "C" int cmb_move_batch_create(cmb_move_index* idx, const cmb_strategy* st
         b->metric = st->metric;
         b->kmerSize = kmer_size;
         if (max_distance > 0) {
-            if (st->metric == CMB_METRIC_EDIT && max_distance > 7)
-                return failWith(CMB_ERR_UNSUPPORTED, "more than 7 errors under edit distance are not provided on the b-move index (narrow records of its frontier)");
             if (max_distance > 13) return failWith(CMB_ERR_UNSUPPORTED, "more than 13 errors (MAX_K, definitions.h:50)");
             try {
-                b->wide = st->numPartsFor(max_distance) > (uint32_t)MAXP;
+                // (edit distance beyond 7 errors: the wide record geometries of the frontier, GeoW / GeoX, on the wide tables)
+                b->wide = st->numPartsFor(max_distance) > (uint32_t)MAXP || (st->metric == CMB_METRIC_EDIT && max_distance > 7);
                 if (b->wide) {
                     b->hostStratW = st->flatten<MAXP_WIDE>(max_distance);
                     b->sNumParts = b->hostStratW.numParts, b->sPartition = b->hostStratW.partition, b->sNSchemes = b->hostStratW.nSchemes;
@@ -949,7 +948,10 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                 N.nq = b->nvCnt.p;
                 N.blockCnt = nullptr;
                 N.fmX = b->fm.p;
-                hipLaunchKernelGGL((edit ? k_mvs_naive<true, true> : k_mvs_naive<false, true>), dim3((tasksRS + 255) / 256), dim3(256), 0, s, ix->d, N, 0u,
+                auto kNaiveStart = edit ? k_mvs_naive<true, true, false> : k_mvs_naive<false, true, false>;
+                auto kNaivePass = edit ? k_mvs_naive<true, false, false> : k_mvs_naive<false, false, false>;
+                if (edit && b->k > MX_MAX_ED) kNaiveStart = k_mvs_naive<true, true, true>, kNaivePass = k_mvs_naive<true, false, true>;
+                hipLaunchKernelGGL(kNaiveStart, dim3((tasksRS + 255) / 256), dim3(256), 0, s, ix->d, N, 0u,
                                    (const uint8_t*)b->psel.p, tasksRS, dOffs, b->gw, b->G.p, b->seq.p, b->maxLen, b->k, q);
                 std::vector<uint32_t> hc(cntWords);
                 uint32_t pass = 0, peakQ = 0;
@@ -957,7 +959,7 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                 while (!drained && pass < maxPassN) {
                     const uint32_t upTo = std::min(pass + 16u, maxPassN);
                     for (; pass < upTo; pass++)
-                        hipLaunchKernelGGL((edit ? k_mvs_naive<true, false> : k_mvs_naive<false, false>), dim3(BFS_GRID), dim3(256), 0, s, ix->d, N, pass,
+                        hipLaunchKernelGGL(kNaivePass, dim3(BFS_GRID), dim3(256), 0, s, ix->d, N, pass,
                                            (const uint8_t*)b->psel.p, tasksRS, dOffs, b->gw, b->G.p, b->seq.p, b->maxLen, b->k, q);
                     MV_HIPCHK(hipMemcpyAsync(hc.data(), b->nvCnt.p, cntWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                     MV_HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
@@ -1036,7 +1038,9 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                 if (!drained) return failWith(CMB_ERR_INTERNAL, "frontier search did not finish within its pass bound");
             } else if (nTasks) {
                 tm.begin();
-                const uint32_t maxPass = 2 * b->maxLen + 8 * MAXP + 64;
+                const uint32_t maxPass = 2 * b->maxLen + 8 * (b->wide ? MAXP_WIDE : MAXP) + 64;
+                const bool geoX = b->wide && b->k > MX_MAX_ED; // (11 ... 13 errors: the in-index matrix with 16-row blocks)
+                const uint32_t pkU4 = b->wide ? GeoW::PK_U4 : GeoN::PK_U4; // planes of a node's final-column pack / uint4 of an event's
                 if (!b->qCap) {
                     const size_t slack = getenv("CMB_TEST_SMALL_POOLS") ? 64 : 65536;
                     const size_t per = getenv("CMB_TEST_SMALL_POOLS") ? 0 : 1;
@@ -1049,11 +1053,11 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                 b->qCap = std::max<size_t>(b->qCap, (size_t)nTasks + 1024);
                 constexpr uint32_t PU = MvTraits::PAIR_U4;
                 for (int j = 0; j < 2; j++) {
-                    if (b->Q[j].n < (PU + 3) * b->qCap) b->Q[j].alloc((PU + 3) * b->qCap);
-                    if (b->Ev[j].n < 2 * b->evCap) b->Ev[j].alloc(2 * b->evCap);
+                    if (b->Q[j].n < (PU + 2 + pkU4) * b->qCap) b->Q[j].alloc((PU + 2 + pkU4) * b->qCap);
+                    if (b->Ev[j].n < (1 + pkU4) * b->evCap) b->Ev[j].alloc((1 + pkU4) * b->evCap);
                 }
                 if (b->F.n < (PU + 1) * b->fCap) b->F.alloc((PU + 1) * b->fCap);
-                const uint32_t ctxU4 = ctxU4For(b->maxLen);
+                const uint32_t ctxU4 = geoX ? CTX_U4_X : ctxU4For(b->maxLen);
                 if (b->C.n < (size_t)ctxU4 * b->cCap) b->C.alloc((size_t)ctxU4 * b->cCap);
                 if (b->A.n < b->aCap) b->A.alloc(b->aCap);
                 const size_t cntWords = 2 * ((size_t)maxPass + 2) + 4;
@@ -1069,12 +1073,12 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                 B.F = b->F.p;
                 B.C = b->C.p;
                 B.A = b->A.p;
-                B.qCap = (uint32_t)std::min<size_t>(b->Q[0].n / (PU + 3), 0xFFFFFFF0u);
-                B.evCap = (uint32_t)std::min<size_t>(b->Ev[0].n / 2, 0xFFFFFFF0u);
+                B.qCap = (uint32_t)std::min<size_t>(b->Q[0].n / (PU + 2 + pkU4), 0xFFFFFFF0u);
+                B.evCap = (uint32_t)std::min<size_t>(b->Ev[0].n / (1 + pkU4), 0xFFFFFFF0u);
                 B.fCap = (uint32_t)std::min<size_t>(b->F.n / (PU + 1), 0xFFFFFFF0u);
                 B.cCap = (uint32_t)std::min<size_t>(b->C.n / ctxU4, 0xFFFFFFF0u);
                 B.ctxU4 = ctxU4;
-                B.ctxMblk = ctxMblkFor(b->maxLen);
+                B.ctxMblk = geoX ? CTX_MBLK_X : ctxMblkFor(b->maxLen);
                 B.aCap = (uint32_t)std::min<size_t>(b->A.n, 0xFFFFFFF0u);
                 B.chain = getenv("CMB_MVS_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("CMB_MVS_CHAIN"))) : MVS_CHAIN;
                 B.gridX = getenv("CMB_MVS_GRID") ? (uint32_t)std::min<int>(BFS_GRID, std::max(1, atoi(getenv("CMB_MVS_GRID")))) : BFS_GRID_X;
@@ -1085,16 +1089,28 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                 B.blockCnt = b->blockCnt.p;
                 B.fmX = b->fm.p;
                 B.rowSteps = nullptr;
-                hipLaunchKernelGGL(k_mvs_start, dim3(std::min<uint32_t>((nTasks + 255) / 256, BFS_GRID)), dim3(256), 0, s, b->strat.p, B, b->tasks.p, nTasks,
-                                   dOffs, b->gw, b->G.p, b->parts.p, q);
+                const dim3 gStart(std::min<uint32_t>((nTasks + 255) / 256, BFS_GRID));
+                if (geoX)
+                    hipLaunchKernelGGL(k_mvs_start<GeoX>, gStart, dim3(256), 0, s, b->stratW.p, B, b->tasks.p, nTasks, dOffs, b->gw, b->G.p, b->partsW.p, q);
+                else if (b->wide)
+                    hipLaunchKernelGGL(k_mvs_start<GeoW>, gStart, dim3(256), 0, s, b->stratW.p, B, b->tasks.p, nTasks, dOffs, b->gw, b->G.p, b->partsW.p, q);
+                else
+                    hipLaunchKernelGGL(k_mvs_start<GeoN>, gStart, dim3(256), 0, s, b->strat.p, B, b->tasks.p, nTasks, dOffs, b->gw, b->G.p, b->parts.p, q);
                 std::vector<uint32_t> hc(cntWords);
                 uint32_t pass = 0, peakQ = 0, peakEv = 0;
                 bool drained = false;
                 while (!drained && pass < maxPass) {
                     const uint32_t upTo = std::min(pass + 16u, maxPass);
                     for (; pass < upTo; pass++)
-                        hipLaunchKernelGGL(k_mvs_pass, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->strat.p, B, pass, dOffs, b->gw, b->G.p,
-                                           b->parts.p, q);
+                        if (geoX)
+                            hipLaunchKernelGGL(k_mvs_pass<GeoX>, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->stratW.p, B, pass, dOffs, b->gw, b->G.p,
+                                               b->partsW.p, q);
+                        else if (b->wide)
+                            hipLaunchKernelGGL(k_mvs_pass<GeoW>, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->stratW.p, B, pass, dOffs, b->gw, b->G.p,
+                                               b->partsW.p, q);
+                        else
+                            hipLaunchKernelGGL(k_mvs_pass<GeoN>, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->strat.p, B, pass, dOffs, b->gw, b->G.p,
+                                               b->parts.p, q);
                     MV_HIPCHK(hipMemcpyAsync(hc.data(), b->bfsCnt.p, cntWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                     MV_HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
                     MV_HIPCHK(hipStreamSynchronize(s));

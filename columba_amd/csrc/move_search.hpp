@@ -14,6 +14,7 @@
 // (partitioning, exact phases) on the same primitive, and a post-processing chain: de-duplication of the in-index
 // occurrences, k_move_locate, sort + redundancy filter on 64-bit positions.
 #pragma once
+#include <type_traits>
 #include "dev_bfs_edit.hpp"
 #include "move_dev.hpp"
 
@@ -633,8 +634,13 @@ k_mvs_exact(MvSearchIndex sx, const DevStrategyKT<MP>* __restrict__ stp, uint32_
 // Expansion of a frontier node (extendFMPos + branchAndBound + the stack loop of recApproxMatchEdit, indexinterface.cpp:506-561,
 // :675-697, without the in-text switch this flavour does not have).  Node = range pair (3 planes) + the three planes of
 // dev_bfs_edit.hpp: {row | score << 16, ctx, fc, RAC bit | mode << 8} {HP, HN} {final-column distances}.
+// Geo: the record geometry of dev_bfs_edit.hpp — GeoN (up to 7 errors: the instance of BASELINE configs[4], unchanged), GeoW (8 ... 10),
+// GeoX (11 ... 13: the in-index matrix with 16-row blocks).
+template <class Geo = GeoN>
 __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uint32_t pass, const Queues& q, uint32_t bid, uint32_t nBlocks) {
     __shared__ uint32_t sh[4][5];
+    typedef typename Geo::Pack EdPack;
+    constexpr uint32_t ED_CELLS = Geo::CELLS, ED_MAX = Geo::ED_MAX, EV_U4 = 1u + Geo::PK_U4;
     constexpr uint32_t PU = MvTraits::PAIR_U4, FU = PU + 1;
     const uint32_t nIn = min(B.nq[pass], B.qCap);
     const uint4* __restrict__ Qi = B.Q[pass & 1u];
@@ -668,7 +674,7 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
             score = n1.x >> 16;
             md = (int)((n1.w >> 8) & 3u);
             Cx = B.C + (size_t)CMB_IDX(ctx, B.cCap, 1) * B.ctxU4;
-            blk = (row + 1) / MX_BLOCK;
+            blk = (row + 1) / Geo::BLOCK;
             const uint4 hot = Cx[CTX_HOT];
             mA = Cx[CTX_M + 2 * blk];
             mB = Cx[CTX_M + 1 + 2 * blk];
@@ -690,8 +696,8 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
         for (uint32_t step = 0; step < B.chain; step++) { // (wave-uniform exit below)
             if (walking) {
                 row1 = row + 1;
-                if (row1 / MX_BLOCK != blk) { // the walk crossed into the next 32-row block: its match words
-                    blk = row1 / MX_BLOCK;
+                if (row1 / Geo::BLOCK != blk) { // the walk crossed into the next row block: its match words
+                    blk = row1 / Geo::BLOCK;
                     mA = Cx[CTX_M + 2 * blk];
                     mB = Cx[CTX_M + 1 + 2 * blk];
                 }
@@ -721,15 +727,15 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
                     const uint64_t M = c == 0 ? u64of(mA.x, mA.y) : c == 1 ? u64of(mA.z, mA.w) : c == 2 ? u64of(mB.x, mB.y) : u64of(mB.z, mB.w);
                     uint64_t HP = pHP, HN = pHN, RAC = 1ull << pRac, D0;
                     uint32_t sc = score;
-                    const bool valid = computeRow(g, row1, M, HP, HN, D0, RAC, sc);
+                    const bool valid = Geo::row(g, row1, M, HP, HN, D0, RAC, sc);
                     if (!valid && !inFC) continue; // pruned when popped (branchAndBound returns true, :560)
                     uint32_t res = KIND_NODE, aux = 0;
                     if (inFC) {
-                        const uint32_t ed = cellAt(row1, g.n - 1, HP, HN, sc);
-                        aux = min(ed, 31u);
+                        const uint32_t ed = Geo::cell(row1, g.n - 1, HP, HN, sc);
+                        aux = min(ed, ED_MAX);
                         res |= 4u;
-                        if (ed > 31u) flags |= FLAG_CAPACITY;
-                        if (!valid || onlyVerticalGapsLeft(g, row1, HN)) res = (res & ~3u) | KIND_EVENT;
+                        if (ed > ED_MAX) flags |= FLAG_CAPACITY;
+                        if (!valid || Geo::ovgl(g, row1, HN)) res = (res & ~3u) | KIND_EVENT;
                     }
                     kinds |= res << (4 * c);
                     cHP[c] = HP, cHN[c] = HN;
@@ -738,7 +744,7 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
                 }
                 const bool single = kinds == (uint32_t)KIND_NODE || kinds == ((uint32_t)KIND_NODE << 4) || kinds == ((uint32_t)KIND_NODE << 8) ||
                                     kinds == ((uint32_t)KIND_NODE << 12);
-                if (single && step + 1u < B.chain && row1 + 1u < B.ctxMblk * MX_BLOCK) {
+                if (single && step + 1u < B.chain && row1 + 1u < B.ctxMblk * Geo::BLOCK) {
 #pragma unroll
                     for (uint32_t c = 0; c < 4; c++)
                         if (kinds == ((uint32_t)KIND_NODE << (4 * c))) {
@@ -774,11 +780,8 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
         if (oF + nF > B.fCap) { ok = false; flags |= FLAG_BFS_F; }
         if (kinds != 0u && ok) {
             const uint32_t cell = min(clSize + row1 - g.m, ED_CELLS - 1u);
-            EdPack pack{0, 0};
-            if (fcP != BFS_NONE && (kinds & 0x4444u)) {
-                const uint4 fp = qLoad(Qi + (size_t)(PU + 2) * qCap + i);
-                pack = EdPack{u64of(fp.x, fp.y), u64of(fp.z, fp.w)};
-            }
+            EdPack pack{};
+            if (fcP != BFS_NONE && (kinds & 0x4444u)) packLoad(Qi + (size_t)(PU + 2) * qCap + i, qCap, pack);
 #pragma unroll
             for (uint32_t c = 0; c < 4; c++) {
                 const uint32_t kd = (kinds >> (4 * c)) & 3u;
@@ -798,14 +801,14 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
                     qStore(Qo + (size_t)(PU + 1) * qCap + o, make_uint4((uint32_t)cHP[c], (uint32_t)(cHP[c] >> 32), (uint32_t)cHN[c], (uint32_t)(cHN[c] >> 32)));
                     if (wantF) {
                         EdPack p2 = pack;
-                        edPut(p2, cell, cMeta[c] & 31u);
-                        qStore(Qo + (size_t)(PU + 2) * qCap + o, make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32)));
+                        edPut(p2, cell, cMeta[c] & 0xFFu);
+                        packStore(Qo + (size_t)(PU + 2) * qCap + o, qCap, p2);
                     }
                 } else { // KIND_EVENT
                     EdPack p2 = pack;
-                    edPut(p2, cell, cMeta[c] & 31u);
-                    Eo[(size_t)2 * oEv] = make_uint4(ctx, fc, 0xFFFFFFFFu, cell);
-                    Eo[(size_t)2 * oEv + 1] = make_uint4((uint32_t)p2.lo, (uint32_t)(p2.lo >> 32), (uint32_t)p2.hi, (uint32_t)(p2.hi >> 32));
+                    edPut(p2, cell, cMeta[c] & 0xFFu);
+                    Eo[(size_t)EV_U4 * oEv] = make_uint4(ctx, fc, 0xFFFFFFFFu, cell);
+                    packStore(Eo + (size_t)EV_U4 * oEv + 1, 1, p2);
                     oEv++;
                 }
             }
@@ -829,22 +832,24 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
     if (flags) atomicOr(&q.cnt[3], flags);
 }
 
+template <class Geo = GeoN>
 __global__ void __launch_bounds__(256)
-k_mvs_start(const DevStrategyK* __restrict__ stp, MvBufs B, const MvTask* __restrict__ tasks, uint32_t nTasks, const uint64_t* __restrict__ offs,
-            uint32_t gw, const uint32_t* __restrict__ G, const PartOut* __restrict__ parts, Queues q) {
+k_mvs_start(const DevStrategyKT<Geo::MP>* __restrict__ stp, MvBufs B, const MvTask* __restrict__ tasks, uint32_t nTasks, const uint64_t* __restrict__ offs,
+            uint32_t gw, const uint32_t* __restrict__ G, const PartOutT<Geo::MP>* __restrict__ parts, Queues q) {
     if (blockStopped(q)) return;
-    bfsHeavy<true, MvTraits>(stp, B, 0u, tasks, nTasks, offs, gw, G, parts, q, blockIdx.x, gridDim.x);
+    bfsHeavy<true, MvTraits, Geo>(stp, B, 0u, tasks, nTasks, offs, gw, G, parts, q, blockIdx.x, gridDim.x);
 }
 constexpr uint32_t MVS_CHAIN = 2; // expansions a lane makes in a row while each yields exactly one plain node (CMB_MVS_CHAIN)
 #ifndef CMB_MVS_WAVES
 #define CMB_MVS_WAVES 2 // wavefronts per SIMD the register allocation of k_mvs_pass is held to
 #endif
+template <class Geo = GeoN>
 __global__ void __launch_bounds__(256, CMB_MVS_WAVES)
-k_mvs_pass(MoveDev ix, const DevStrategyK* __restrict__ stp, MvBufs B, uint32_t pass, const uint64_t* __restrict__ offs, uint32_t gw,
-           const uint32_t* __restrict__ G, const PartOut* __restrict__ parts, Queues q) {
+k_mvs_pass(MoveDev ix, const DevStrategyKT<Geo::MP>* __restrict__ stp, MvBufs B, uint32_t pass, const uint64_t* __restrict__ offs, uint32_t gw,
+           const uint32_t* __restrict__ G, const PartOutT<Geo::MP>* __restrict__ parts, Queues q) {
     if (blockStopped(q)) return;
-    if (blockIdx.x < B.gridX) mvExpand(ix, B, pass, q, blockIdx.x, B.gridX);
-    else bfsHeavy<false, MvTraits>(stp, B, pass, nullptr, 0u, offs, gw, G, parts, q, blockIdx.x - B.gridX, B.gridEv);
+    if (blockIdx.x < B.gridX) mvExpand<Geo>(ix, B, pass, q, blockIdx.x, B.gridX);
+    else bfsHeavy<false, MvTraits, Geo>(stp, B, pass, nullptr, 0u, offs, gw, G, parts, q, blockIdx.x - B.gridX, B.gridEv);
 }
 __global__ void k_mvs_finish(MvBufs B, Queues q) { // one block: per-block counters -> the batch counters
     __shared__ unsigned long long s[4];
@@ -1006,10 +1011,11 @@ k_mvs_hbfs(MoveDev ix, const DevStrategyKT<MP>* __restrict__ stp, MvHbfsBufs B, 
 // {rsId, row | score << 16, RAC bit | mismatches << 8, -} + (edit distance) one plane {HP, HN}; the whole pattern is matched backward
 // from the complete range (unidirectional: mode 2), every final-column node within the bound is an in-index occurrence.
 constexpr uint32_t MVS_NAIVE_STOP = FLAG_NAIVE_Q | FLAG_FMOCC_OVERFLOW;
-template <bool EDIT, bool START>
+template <bool EDIT, bool START, bool NARROW = false /* the matrix of 11 ... 13 errors: 16-row blocks (dev_matrix.hpp: MXN_*) */>
 __global__ void __launch_bounds__(256)
 k_mvs_naive(MoveDev ix, MvHbfsBufs B, uint32_t pass, const uint8_t* __restrict__ psel, uint32_t tasksRS, const uint64_t* __restrict__ offs,
             uint32_t gw, const uint32_t* __restrict__ G, const uint8_t* __restrict__ seq, uint32_t maxLen, uint32_t k, Queues q) {
+    using Mx = typename std::conditional<NARROW, MxNarrow, MxRef64>::type;
     __shared__ uint32_t sh[4][5];
     __shared__ uint32_t stopWord;
     if (threadIdx.x == 0) stopWord = __hip_atomic_load(&q.cnt[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & MVS_NAIVE_STOP;
@@ -1033,11 +1039,11 @@ k_mvs_naive(MoveDev ix, MvHbfsBufs B, uint32_t pass, const uint8_t* __restrict__
             if (i < nIn && (psel[i] & 0x80u) && !(!EDIT && offs[(i >> 1) + 1] == offs[i >> 1])) { // (Hamming, empty read: pattern[-1] in the reference)
                 rsId = i;
                 ch[0] = mvCompleteRange(ix);
-                const uint64_t HP0 = (~0ull) << MX_LEFT;
+                const uint64_t HP0 = (~0ull) << Mx::LEFT;
                 cHP[0] = HP0;
                 cHN[0] = ~HP0;
                 cState[0] = 0;
-                cAux[0] = MX_DIAG + k;
+                cAux[0] = Mx::DIAG + k;
                 kinds = 1;
                 nNode = 1;
             }
@@ -1075,10 +1081,10 @@ k_mvs_naive(MoveDev ix, MvHbfsBufs B, uint32_t pass, const uint8_t* __restrict__
                     cMx++;
                     uint64_t HP = pHP, HN = pHN, D0, RAC = 1ull << rac;
                     uint32_t sc = score;
-                    const uint64_t M = matchWord(gString(G, gw, rsId, 1u, c), 0u, len, row1 / MX_BLOCK);
-                    if (!computeRow(g, row1, M, HP, HN, D0, RAC, sc)) continue;
+                    const uint64_t M = matchWord<Mx::LEFT, Mx::BLOCK>(gString(G, gw, rsId, 1u, c), 0u, len, row1 / Mx::BLOCK);
+                    if (!Mx::row(g, row1, M, HP, HN, D0, RAC, sc)) continue;
                     if (g.inFinalColumn(row1)) {
-                        const uint32_t d = cellAt(row1, len, HP, HN, sc);
+                        const uint32_t d = Mx::cell(row1, len, HP, HN, sc);
                         if (d <= k) {
                             kd |= 4u;
                             cDist[c] = d;

@@ -323,3 +323,12 @@ def test_bmove_best_mode(sworld, spec, metric, x, min_identity):
         assert d_cnt[n] == 0, n
     if (spec, metric, x) == ("columba", "edit", 0):   # the reads 3 and 5 characters over a sequence end are found with trimming
         assert d_best[1205] <= 3 and d_best[1207] <= 5 and int(d_aln[int(d_off[1205])]["seq_begin"]) == 0
+
+
+@pytest.mark.parametrize("partition,k,length", [("dynamic", 8, 150), ("uniform", 10, 150), ("dynamic", 11, 150), ("static", 12, 250), ("dynamic", 13, 150)])
+def test_bmove_edit_distance_beyond_seven_errors(sworld, partition, k, length):
+    """the greedy schemes on the b-move index under edit distance: the wide record geometries of the frontier (mvExpand / bfsHeavy on
+    GeoW, from 11 errors on GeoX with its 16-row blocks) — occurrences and counters against the oracle's RLC flavour, which takes the
+    reference's 64- or 128-bit matrix per search part"""
+    reads = _reads(sworld["g"], k, 250, length, seed=400 + k)
+    _compare(sworld, "columba", partition, k, reads)
