@@ -93,10 +93,14 @@ mv = movebuild.build_move(pg.tobytes(), device="cuda")
 mdev, morc = ca.MoveIndex(mv), op.OracleMoveIndex(mv)
 MV = (("multiple_opt", "edit", "dynamic", 4, 5), ("columba", "edit", "dynamic", 6, 7), ("kuch1", "edit", "uniform", 1, 2),
       ("pigeon", "hamming", "dynamic", 2, 3), ("columba", "hamming", "static", 4, 5), ("naive", "edit", "dynamic", 2, 1),
-      ("kuch1", "edit", "dynamic", 0, 1))
+      ("kuch1", "edit", "dynamic", 0, 1),
+      # beyond 7 errors: the wide tables, the wide record geometries of the frontier
+      ("columba", "edit", "dynamic", 9, 11), ("columba", "edit", "static", 12, 14), ("columba", "hamming", "uniform", 13, 15))
 for spec, metric, part, k, P in MV:
     if spec == "naive":
         reads = [pg[p:p + int(rng.integers(8, 22))].tobytes() for p in rng.integers(0, len(pg) - 30, N // 10)]
+    elif k >= 8:   # (no reads below 100 characters: at these distances those match all over the text)
+        reads = chunk(pg, max(N // 16, 100), k, P, 0.0, seed=int(rng.integers(1 << 30)), lens=(100, 150, 151, 250, 257, 321, 400, 480))
     else:
         reads = chunk(pg, N // 2, k, P, 0.0 if k == 0 else 0.01, seed=int(rng.integers(1 << 30)))
         if metric == "hamming":
