@@ -201,7 +201,8 @@ def test_bmove_naive_strategy(tinyworld, metric, k, length):
         del os.environ["CMB_TEST_SMALL_POOLS"]
 
 
-@pytest.mark.parametrize("spec,k,length", [("multiple_opt", 4, 150), ("columba", 6, 250), ("kuch1", 2, 100), ("columba", 7, 100)])
+@pytest.mark.parametrize("spec,k,length", [("multiple_opt", 4, 150), ("columba", 6, 250), ("kuch1", 2, 100), ("columba", 7, 100),
+                                           ("columba", 9, 150)])
 def test_bmove_alignments(sworld, spec, k, length):
     """CIGAR and sequence of the occurrences on the b-move index (cmb_move_attach_text + cmb_move_batch_alignments: findCIGAR on
     text[begin, end), which is the matched string the reference's search carries along for this flavour): equal to those of the
