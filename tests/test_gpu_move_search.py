@@ -327,9 +327,14 @@ def test_bmove_best_mode(sworld, spec, metric, x, min_identity):
 
 
 @pytest.mark.parametrize("partition,k,length", [("dynamic", 8, 150), ("uniform", 10, 150), ("dynamic", 11, 150), ("static", 12, 250), ("dynamic", 13, 150)])
-def test_bmove_edit_distance_beyond_seven_errors(sworld, partition, k, length):
+def test_bmove_edit_distance_beyond_seven_errors(sworld, gt, partition, k, length):
     """the greedy schemes on the b-move index under edit distance: the wide record geometries of the frontier (mvExpand / bfsHeavy on
     GeoW, from 11 errors on GeoX with its 16-row blocks) — occurrences and counters against the oracle's RLC flavour, which takes the
     reference's 64- or 128-bit matrix per search part"""
     reads = _reads(sworld["g"], k, 250, length, seed=400 + k)
-    _compare(sworld, "columba", partition, k, reads)
+    occ, offs, _, _ = _compare(sworld, "columba", partition, k, reads)
+    # ... and against ground truth: every reported window has its distance by dynamic programming, every window within k errors is
+    # covered (tests/test_ground_truth.py)
+    checked, _ = check_soundness(gt, sworld["text"], reads[:60], occ, offs, k, "edit")
+    hits, chain = check_completeness(gt, sworld["text"], reads[:25], occ, offs, k, "edit")
+    assert checked > 20 and hits > 10 and chain * 20 <= hits
