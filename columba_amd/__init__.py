@@ -71,7 +71,8 @@ def build_library(force: bool = False) -> str:
     csrc = os.path.join(_HERE, "csrc")
     header = os.path.join(os.path.dirname(_HERE), "include", "columba_amd.h")
     units = {"columba_amd.hip": [f for f in os.listdir(csrc) if not f.startswith(("move_", "pair_"))],
-             "move_backend.hip": [f for f in os.listdir(csrc) if f.startswith("move_")],
+             # (the b-move backend shares the event handler, the matrix and the wave helpers with the matcher)
+             "move_backend.hip": [f for f in os.listdir(csrc) if not f.startswith("pair_") and f != "columba_amd.hip"],
              "pair_sam.hip": [f for f in os.listdir(csrc) if f.startswith("pair_")] + ["host_sam.hpp"]}
     every = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [header]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in every):

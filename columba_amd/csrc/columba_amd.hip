@@ -111,9 +111,9 @@ struct cmb_index {
 
 #ifdef CMB_BFS_STATS
 extern "C" int cmb_debug_bfs_stats(unsigned long long* out, int reset) { // diagnostic build only
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(cmb::g_bfsStats), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(cmb::g_bfsStats), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long z[16] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(cmb::g_bfsStats), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;
@@ -586,6 +586,7 @@ struct cmb_batch {
     DevBuf<uint4> bfsQ[2], bfsEv[2], bfsF, bfsC, bfsA;
     DevBuf<uint32_t> bfsCnt;               // nq[passes], ne[passes], pool[4]
     DevBuf<unsigned long long> bfsBlockCnt; // [BFS_GRID][4]
+    DevBuf<uint32_t> bfsQCnt[2], bfsWcSave; // bfsExpandWalk: node counts of the queue chunks; per-wavefront item / F chunks
     size_t bfsQCap = 0, bfsEvCap = 0, bfsFCap = 0, bfsCCap = 0, bfsACap = 0;
     // naive backtracking (dev_bfs_naive.hpp): node double buffer, nodes per pass
     DevBuf<uint4> nvQ[2];
@@ -1179,13 +1180,19 @@ static int batchRunOne(cmb_batch* b) {
                     const size_t cntWords = 2 * ((size_t)maxPass + 2) + 4;
                     if (b->bfsCnt.n < cntWords) b->bfsCnt.alloc(cntWords);
                     if (b->bfsBlockCnt.n < (size_t)BFS_GRID * 4) b->bfsBlockCnt.alloc((size_t)BFS_GRID * 4);
+                    for (int j = 0; j < 2; j++) // (bfsExpandWalk: one count per chunk of 64 slots)
+                        if (b->bfsQCnt[j].n < b->bfsQCap / 64 + 8) b->bfsQCnt[j].alloc(b->bfsQCap / 64 + 8);
+                    if (b->bfsWcSave.n < (size_t)BFS_GRID * 4 * WALK_SAVE_U32) b->bfsWcSave.alloc((size_t)BFS_GRID * 4 * WALK_SAVE_U32);
+                    HIPCHK(hipMemsetAsync(b->bfsWcSave.p, 0, b->bfsWcSave.n * sizeof(uint32_t), s));
                     HIPCHK(hipMemsetAsync(b->bfsCnt.p, 0, cntWords * sizeof(uint32_t), s));
                     HIPCHK(hipMemsetAsync(b->bfsBlockCnt.p, 0, (size_t)BFS_GRID * 4 * sizeof(unsigned long long), s));
                     BfsBufs B{};
                     for (int j = 0; j < 2; j++) {
                         B.Q[j] = b->bfsQ[j].p;
                         B.Ev[j] = b->bfsEv[j].p;
+                        B.qCnt[j] = b->bfsQCnt[j].p;
                     }
+                    B.wcSave = b->bfsWcSave.p;
                     B.F = b->bfsF.p;
                     B.C = b->bfsC.p;
                     B.A = b->bfsA.p;
@@ -1197,7 +1204,8 @@ static int batchRunOne(cmb_batch* b) {
                     B.ctxMblk = b->geoX ? CTX_MBLK_X : ctxMblkFor(b->maxLen);
                     B.aCap = (uint32_t)std::min<size_t>(b->bfsA.n, 0xFFFFFFF0u);
                     B.chain = getenv("CMB_BFS_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("CMB_BFS_CHAIN"))) : BFS_CHAIN;
-                    B.gridX = getenv("CMB_BFS_GRID") ? (uint32_t)std::min<int>(BFS_GRID, std::max(1, atoi(getenv("CMB_BFS_GRID")))) : BFS_GRID_X;
+                    B.gridX = getenv("CMB_BFS_GRID") ? (uint32_t)std::min<int>(BFS_GRID, std::max(1, atoi(getenv("CMB_BFS_GRID"))))
+                                                     : (CMB_BFS_WALK ? BFS_GRID_X_WALK : BFS_GRID_X);
                     B.gridEv = getenv("CMB_BFS_GRID_EV") ? (uint32_t)std::max(1, atoi(getenv("CMB_BFS_GRID_EV"))) : BFS_GRID_EV;
                     B.nq = b->bfsCnt.p;
                     B.ne = b->bfsCnt.p + (maxPass + 2);

@@ -87,20 +87,27 @@ __device__ __forceinline__ void loadRankChunksRaw(const DevBWT& t, uint32_t p, u
     v[0] = B[0];
     v[1] = B[1];
 }
-// both ends of a range: a narrow range often has both ends in ONE rank block — what the begin already fetched is
-// not requested again (the request rate of scattered 16-byte loads, not the bytes, bounds the extension kernels)
+// both ends of a range: a narrow range often has both ends in ONE rank block — what the begin already fetched is not requested again.
+// NOTHING here may read a reply: a copy `v[2] = v[0]` for the shared block made hipcc wait for the begin's chunks before it requested the
+// end's (round 4: two dependent memory round trips per extension in k_parts, k_exact and the frontier kernels instead of one).  The
+// consumer picks the end's chunks with rankPairEnd() once the replies are in.
 __device__ __forceinline__ void loadRankPairRaw(const DevBWT& t, uint32_t pb, uint32_t pe, uint4 v[4]) {
     const uint32_t blkB = pb >> 5, blkE = pe >> 5;
     const uint4* B = t.blk + (size_t)blkB * 2;
     const uint4* E = t.blk + (size_t)blkE * 2;
     v[0] = B[0];
     v[1] = B[1];
-    v[2] = v[0];
-    v[3] = v[1];
+    v[2] = v[3] = make_uint4(0u, 0u, 0u, 0u);
     if (blkE != blkB) {
         v[2] = E[0];
         v[3] = E[1];
     }
+}
+// the chunks {abs, bits} of the END of the range from what loadRankPairRaw requested
+__device__ __forceinline__ void rankPairEnd(const uint4 v[4], uint32_t pb, uint32_t pe, uint4 w[2]) {
+    const bool same = (pb >> 5) == (pe >> 5);
+    w[0] = same ? v[0] : v[2];
+    w[1] = same ? v[1] : v[3];
 }
 __device__ __forceinline__ void ranksFromRaw(const uint4 v[2], uint32_t p, uint32_t dollarPos, uint32_t R[4]) {
     const uint32_t lowmask = (1u << (p & 31u)) - 1u;
@@ -197,10 +204,11 @@ __device__ __forceinline__ void loadExtendRanks(const DevIndex& ix, int mode, co
         t = ix.rev;
         tr = p.rev;
     }
-    uint4 v[4];
+    uint4 v[4], w[2];
     loadRankPairRaw(t, tr.b, tr.e, v);
+    rankPairEnd(v, tr.b, tr.e, w);
     ranksFromRaw(v, tr.b, t.dollarPos, Rb);
-    ranksFromRaw(v + 2, tr.e, t.dollarPos, Re);
+    ranksFromRaw(w, tr.e, t.dollarPos, Re);
     db = tr.b > t.dollarPos ? 1u : 0u;
     de = tr.e > t.dollarPos ? 1u : 0u;
 }

@@ -28,6 +28,20 @@ __device__ __forceinline__ uint32_t waveExclusiveScan(uint32_t v, uint32_t& tota
     total = __shfl(x, 63);
     return x - v;
 }
+// the same on the cross-lane data path (DPP row shifts and row broadcasts instead of six LDS permutes): INCLUSIVE prefix sum over
+// the 64 lanes; all lanes must be active
+__device__ __forceinline__ uint32_t waveInclusiveScanDpp(uint32_t v) {
+    uint32_t x = v;
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false); // row_shr:1 (rows of 16 lanes; nothing shifted in: 0)
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false); // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false); // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false); // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+__device__ __forceinline__ uint32_t waveLastLane(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, 63); }
+
 // one atomic per wavefront: returns this lane's first slot for its `n` records in a queue
 __device__ __forceinline__ uint32_t waveAppend(uint32_t* counter, uint32_t n, uint32_t& total) {
     const uint32_t off = waveExclusiveScan(n, total);
@@ -54,14 +68,39 @@ struct WaveChunk {
                                               Hole hole) {
         uint32_t total;
         const uint32_t pre = waveExclusiveScan(n, total);
+        total = __builtin_amdgcn_readfirstlane(total);
         if (total == 0) return 0xFFFFFFFFu;
         if (used + total > size) {
             fill(hole);
             const uint32_t want = total > chunk ? total : chunk;
             uint32_t b = 0;
             if ((threadIdx.x & 63u) == 0) b = atomicAdd(counter, want);
-            b = __shfl(b, 0);
+            b = __builtin_amdgcn_readfirstlane(__shfl(b, 0)); // (wave-uniform: kept in a scalar register)
             if (b > cap || want > cap - b) { // (the counter keeps the needed size for the retry on the host)
+                overflow = true;
+                size = used = 0;
+                return 0xFFFFFFFFu;
+            }
+            base = b;
+            size = want;
+            used = 0;
+        }
+        const uint32_t o = base + used + pre;
+        used += total;
+        return o;
+    }
+    // the same with the prefix sum done by the caller: `pre` = the records of the lanes below, `total` (wave-uniform) of all lanes
+    template <class Hole>
+    __device__ __forceinline__ uint32_t allocPre(uint32_t* counter, uint32_t cap, uint32_t pre, uint32_t total, uint32_t chunk, bool& overflow,
+                                                 Hole hole) {
+        if (total == 0) return 0xFFFFFFFFu;
+        if (used + total > size) {
+            fill(hole);
+            const uint32_t want = total > chunk ? total : chunk;
+            uint32_t b = 0;
+            if ((threadIdx.x & 63u) == 0) b = atomicAdd(counter, want);
+            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+            if (b > cap || want > cap - b) {
                 overflow = true;
                 size = used = 0;
                 return 0xFFFFFFFFu;

@@ -67,6 +67,7 @@ struct MvTraits {
     typedef MvPair Pair;
     typedef MvTask Task;
     static constexpr uint32_t PAIR_U4 = 3;
+    static constexpr bool CHUNKED_Q = false; // (mvExpand reads the node queue entry by entry)
     static __device__ __forceinline__ Pair unpack(const uint4& a, const uint4& b, const uint4& c) {
         const uint64_t w0 = u64of(a.x, a.y), w1 = u64of(a.z, a.w), w2 = u64of(b.x, b.y), w3 = u64of(b.z, b.w), w4 = u64of(c.x, c.y),
                        w5 = u64of(c.z, c.w);
