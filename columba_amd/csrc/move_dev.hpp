@@ -113,22 +113,26 @@ struct MvRange {
 
 // MoveLFReprBP::getRunIndex / computeRunIndices (moverepr.cpp:213-249): the runs that hold begin and end - 1, searched
 // between the (stale but enclosing) run indices the range carries
+// (both searches step TOGETHER — two independent probes per memory round trip; the second one runs over the whole interval instead of
+// starting at the first one's result, which finds the same run)
 __device__ inline void computeRunIndices(const MoveTable& t, MvRange& r) {
-    uint64_t lo = r.beginRun, hi = r.endRun;
-    while (hi > lo) {
-        const uint64_t mid = (lo + hi + 1) >> 1;
-        if (rowIn(t.rows[mid]) <= r.begin) lo = mid;
-        else hi = mid - 1;
-    }
-    r.beginRun = lo;
-    hi = r.endRun;
+    uint64_t lo1 = r.beginRun, hi1 = r.endRun, lo2 = r.beginRun, hi2 = r.endRun;
     const uint64_t last = r.end - 1;
-    while (hi > lo) {
-        const uint64_t mid = (lo + hi + 1) >> 1;
-        if (rowIn(t.rows[mid]) <= last) lo = mid;
-        else hi = mid - 1;
+    while (hi1 > lo1 || hi2 > lo2) {
+        const uint64_t mid1 = (lo1 + hi1 + 1) >> 1, mid2 = (lo2 + hi2 + 1) >> 1;
+        const uint2 a = *reinterpret_cast<const uint2*>(t.rows + mid1), b = *reinterpret_cast<const uint2*>(t.rows + mid2);
+        const uint64_t in1 = (((uint64_t)a.x | (uint64_t)a.y << 32) >> 3) & MV_M40, in2 = (((uint64_t)b.x | (uint64_t)b.y << 32) >> 3) & MV_M40;
+        if (hi1 > lo1) {
+            if (in1 <= r.begin) lo1 = mid1;
+            else hi1 = mid1 - 1;
+        }
+        if (hi2 > lo2) {
+            if (in2 <= last) lo2 = mid2;
+            else hi2 = mid2 - 1;
+        }
     }
-    r.endRun = lo;
+    r.beginRun = lo1;
+    r.endRun = lo2;
     r.valid = true;
 }
 

@@ -165,7 +165,14 @@ __device__ __forceinline__ MvRange selRange(bool c, const MvRange& a, const MvRa
 __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const int mode, const MvPair& parent, MvPair child[4], uint32_t& rows,
                                                const uint32_t need = 0xFu) {
     const bool fw = mode == 0;
-    const MoveTable& t = fw ? ix.rev : ix.fwd;
+    // the table of the direction, chosen FIELD BY FIELD: a reference `fw ? ix.rev : ix.fwd` is a choice between two addresses — every use of
+    // a field then fetched the field from memory first (a pointer load and a wait in front of every sample and row access)
+    MoveTable t;
+    t.rows = fw ? ix.rev.rows : ix.fwd.rows;
+    t.runs = fw ? ix.rev.runs : ix.fwd.runs;
+    t.zeroCharPos = fw ? ix.rev.zeroCharPos : ix.fwd.zeroCharPos;
+    t.samplesFirst = fw ? ix.rev.samplesFirst : ix.fwd.samplesFirst;
+    t.samplesLast = fw ? ix.rev.samplesLast : ix.fwd.samplesLast;
     MvRange trivial = selRange(fw, parent.rev, parent.sa);
     const MvRange other = selRange(fw, parent.sa, parent.rev);
     if (!trivial.valid) { // (two binary searches between the enclosing run indices)
@@ -229,18 +236,24 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
                 bDone = (seen & 0x1Eu) == 0x1Eu || runB == trivial.beginRun || (fDone && (seen & 0x1Eu) == (found & 0x1Eu));
             }
             if (fDone && bDone) break;
+            // the next rows of both cursors are REQUESTED TOGETHER: nothing between the two loads reads a reply (with `posF = rowIn(rowF)`
+            // between them hipcc waited for the front row before it asked for the back row: two round trips per step of the scan)
+            const uint64_t posBNext = rowIn(rowB) - 1;
+            uint4 nextF = rowF, nextB = rowB;
+            if (!fDone) nextF = t.rows[runF + 1];
+            if (!bDone) nextB = t.rows[runB - 1];
             if (!fDone) {
                 runF++;
-                rowF = t.rows[runF];
+                rowF = nextF;
                 rows++;
+                posF = rowIn(rowF);
             }
             if (!bDone) {
-                posB = rowIn(rowB) - 1;
+                posB = posBNext;
                 runB--;
-                rowB = t.rows[runB];
+                rowB = nextB;
                 rows++;
             }
-            if (!fDone) posF = rowIn(rowF);
         }
         found &= seen | 1u;
     }
@@ -252,28 +265,46 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
             if ((found >> (c + 1) & 1u) && (need >> c & 1u)) act |= 3u << (2 * c);
         act &= ffNeed;
         while (act) {
-            uint64_t nx[8];
+            // (the raw words are requested first, all of them, and looked at afterwards: `rowIn(t.rows[...])` inside the condition made
+            // hipcc wait for every one of the up to eight loads before it issued the next)
+            // Loads under a condition do not do either: the compiler cannot tell that the conditional use has consumed the previous
+            // turn's reply and waits before it reuses the registers.  So every turn loads all eight words, the finished end points
+            // row 0 (one address for the whole wavefront).
+            uint2 raw[8];
 #pragma unroll
             for (uint32_t c = 0; c < 4; c++) {
-                if (act >> (2 * c) & 1u) nx[2 * c] = rowIn(t.rows[fRun[c] + 1]);
-                if (act >> (2 * c + 1) & 1u) nx[2 * c + 1] = rowIn(t.rows[lRun[c] + 1]);
+                const uint64_t iF = (act >> (2 * c) & 1u) ? fRun[c] + 1 : 0ull, iL = (act >> (2 * c + 1) & 1u) ? lRun[c] + 1 : 0ull;
+                raw[2 * c] = *reinterpret_cast<const uint2*>(t.rows + iF);
+                raw[2 * c + 1] = *reinterpret_cast<const uint2*>(t.rows + iL);
             }
 #pragma unroll
             for (uint32_t c = 0; c < 4; c++) {
                 if (act >> (2 * c) & 1u) {
                     rows++;
-                    if (nx[2 * c] <= fOut[c]) fRun[c]++;
+                    const uint64_t nx = (((uint64_t)raw[2 * c].x | (uint64_t)raw[2 * c].y << 32) >> 3) & MV_M40; // rowIn
+                    if (nx <= fOut[c]) fRun[c]++;
                     else act &= ~(1u << (2 * c));
                 }
                 if (act >> (2 * c + 1) & 1u) {
                     rows++;
-                    if (nx[2 * c + 1] <= lOut[c]) lRun[c]++;
+                    const uint64_t nx = (((uint64_t)raw[2 * c + 1].x | (uint64_t)raw[2 * c + 1].y << 32) >> 3) & MV_M40;
+                    if (nx <= lOut[c]) lRun[c]++;
                     else act &= ~(1u << (2 * c + 1));
                 }
             }
         }
     }
     const uint64_t parentWidth = trivial.end - trivial.begin;
+    // the toehold samples of the children that narrow the range (BMove::computeToehold / computeToeholdRev, bmove.cpp:222-266: the last
+    // run of the range that holds the character): requested together, before any is used
+    uint64_t smp[4];
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++) { // (unconditional loads, see above: a child that needs no sample reads samplesFirst[0])
+        const bool wanted = (found >> (c + 1) & 1u) && (need >> c & 1u) && lOut[c] + 1 - fOut[c] != parentWidth;
+        const bool atEnd = !wanted || lSrc[c] == trivial.endRun;
+        const uint64_t* sp = atEnd ? t.samplesFirst : t.samplesLast;
+        smp[c] = sp[wanted ? (atEnd ? trivial.endRun : lSrc[c]) : 0ull];
+    }
     // MoveLFReprBP::getCumulativeCounts (moverepr.cpp:347-365): the '$' of the range, then the smaller characters
     uint64_t cum = (trivial.begin <= t.zeroCharPos && trivial.end > t.zeroCharPos) ? 1 : 0;
     uint32_t mask = 0;
@@ -299,9 +330,7 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
             } else {
                 const MvRange narrowed{other.begin + cum, other.begin + cum + width, other.beginRun, other.endRun, false};
                 second = selRange(mode == 2, noRange, narrowed);
-                // BMove::computeToehold / computeToeholdRev (bmove.cpp:222-266): the last run of the range that holds the character
-                const uint64_t smp = lSrc[c] == trivial.endRun ? t.samplesFirst[trivial.endRun] : t.samplesLast[lSrc[c]];
-                ch.toehold = fw ? ix.n - 1 - (smp - 1) : smp - 1;
+                ch.toehold = fw ? ix.n - 1 - (smp[c] - 1) : smp[c] - 1;
                 ch.repEnd = fw;
             }
             ch.sa = selRange(fw, second, range1);
