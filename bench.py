@@ -373,6 +373,155 @@ def main_rlc(args):
         dist.destroy_process_group()
 
 
+def streaming_leg(index, strategy, k, buf, R, L, steps, rank, dev, dist, world):
+    """What a host that feeds chunks sees (never `value`): every step takes FRESH reads from page-locked host memory and hands its
+    results to the caller.  Two batches of R / 2 reads each, driven by two host threads: while one thread registers its next chunk
+    and copies its results out (34 ms per 10^7 reads), the other one's chunk is being matched; every run
+    uploads the chunk of its batch's NEXT run on a copy stream of its own (cmb_batch_stage_reads)."""
+    import threading
+    # chunk size: the batch's own R reads where HBM holds two such batches (each keeps its queues: ~10 KB per read), else halves
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    H = max(R, 1)
+    offs = np.arange(H + 1, dtype=np.uint64) * np.uint64(L)
+    first = ca.Batch(index, strategy, k, packed=(np.ascontiguousarray(buf[:H * L]), offs))
+    first.run()
+    torch.cuda.synchronize()
+    per_batch = free0 - torch.cuda.mem_get_info(dev)[0]
+    first.close()
+    if os.environ.get("CMB_BENCH_STREAM_HALVES") or 2.3 * per_batch > free0:
+        H = max(R // 2, 1)
+        offs = np.arange(H + 1, dtype=np.uint64) * np.uint64(L)
+    # four chunks in page-locked memory (batch j alternates chunks j and 2 + j): this rank's reads, whole or in halves, and copies
+    parts = [np.ascontiguousarray(buf[:H * L]), np.ascontiguousarray(buf[(R - H) * L:R * L])]
+    chunks = [torch.from_numpy(parts[j % 2 if j < 2 else (j + 1) % 2].copy()).pin_memory().numpy() for j in range(4)]
+    batches = [ca.Batch(index, strategy, k, packed=(chunks[j], offs)) for j in (0, 1)]
+    for j, b in enumerate(batches):   # warm-up: sizes the pools, uploads the first staged chunk
+        b.run()
+        b.stage((chunks[2 + j], offs))
+        b.run()
+        b.results(reuse=True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    host = [dict(stage=0.0, run=0.0, res=0.0) for _ in batches]
+    errs = []
+    # one chunk is matched at a time (two batches matching side by side share the device: 0.82 of the resident rate, measured);
+    # what overlaps with a chunk's matching is the OTHER batch's host work.  CMB_BENCH_STREAM_OVERLAP=1: no such turn-taking.
+    turn = threading.Lock() if not os.environ.get("CMB_BENCH_STREAM_OVERLAP") else None
+
+    def worker(j):
+        try:
+            b = batches[j]
+            for i in range(steps):
+                t0 = time.perf_counter()
+                b.stage((chunks[2 * (i % 2) + j], offs))   # registered; travels while this step's chunk is matched
+                t1 = time.perf_counter()
+                if turn is not None:
+                    with turn:
+                        b.run()
+                else:
+                    b.run()
+                t2 = time.perf_counter()
+                b.results(reuse=True)
+                t3 = time.perf_counter()
+                host[j]["stage"] += t1 - t0
+                host[j]["run"] += t2 - t1
+                host[j]["res"] += t3 - t2
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(j,)) for j in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - ts
+    for b in batches:
+        b.close()
+    if errs:
+        raise errs[0]
+    if dist is not None:
+        te = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        dt = float(te.item())
+    n = max(steps, 1)
+    return {"value": round(world * 2 * H * n / dt, 1), "unit": "reads/s", "ms_per_chunk": round(dt / (2 * n) * 1e3, 3),
+            "reads_per_chunk": H, "chunks": 2 * steps, "hbm_per_batch_GB": round(per_batch / 1e9, 1),
+            "host_ms_per_chunk": {"register next chunk": round(sum(h["stage"] for h in host) / (2 * n) * 1e3, 1),
+                                  "run (waiting for the turn + matching + upload of the next chunk)": round(sum(h["run"] for h in host) / (2 * n) * 1e3, 1),
+                                  "copy results out": round(sum(h["res"] for h in host) / (2 * n) * 1e3, 1)},
+            "note": "every step matches fresh reads taken from page-locked host memory (1.5 GB per 10 M reads over PCIe, uploaded by "
+                    "cmb_batch_stage_reads while the previous chunk is matched) and copies its results to the host; two batches, two "
+                    "host threads taking turns on the device: one batch's host work runs beside the other's matching"}
+
+
+def rlc_leg(args, dev, local):
+    """BASELINE configs[4] (b-move index, 250 bp, k = 6) as a bounded leg of the DEFAULT line, after the headline's timed region: the
+    stand-in of `--config rlc` (64 haplotypes x 4 Mbp, 0.5 % SNPs) with 10^6 reads, one warm-up and two timed steps, the oracle's RLC
+    flavour on the first 10 000 reads beside it.  `python bench.py --config rlc` is the full-length version of this leg."""
+    from columba_amd import movebuild
+    t0 = time.time()
+    text = movebuild.pangenome(int(args.base_mbp * 1e6), args.haplotypes, args.snp, seed=1)
+    mv = movebuild.build_move(text, device=dev, with_locate=False)
+    mv.plcp = movebuild.plcp_gpu(mv)
+    torch.cuda.empty_cache()
+    index = ca.MoveIndex(mv, device=local)
+    built = time.time() - t0
+    R, L, k, steps = 1_000_000, 250, 6, 2
+    buf, _ = synth.sample_reads_fast(torch.from_numpy(mv.text[:-1]).to(dev), R, L, seed=3, device=dev, edit_choices=(0, 1, 2, 3, 4, 5, 6))
+    offs = np.arange(R + 1, dtype=np.uint64) * np.uint64(L)
+    torch.cuda.empty_cache()
+    strategy = ca.SearchStrategy("multiple_opt", "edit", "dynamic")
+    batch = ca.MoveBatch(index, strategy, k, packed=(buf, offs), kmer_size=10)
+    batch.run()
+    torch.cuda.synchronize()
+    kern = {}
+    ts = time.perf_counter()
+    for _ in range(steps):
+        batch.run()
+        for kname, ms in batch.timings().items():
+            kern[kname] = kern.get(kname, 0.0) + ms
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - ts
+    occ, occ_offs, cnt = batch.results()
+    avg = {kn: v / steps for kn, v in kern.items()}
+    dominant = max(avg, key=avg.get)
+    alg = {"k_partition": 16.0 * (cnt["TABLE_ROWS"] - cnt["DFS_TABLE_ROWS"]), "k_dfs": 16.0 * cnt["DFS_TABLE_ROWS"]}
+    achieved = alg.get(dominant, 0.0) / (avg[dominant] * 1e-3) / 1e9 if avg[dominant] > 0 else 0.0
+    cpu = None
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_py as op
+        import schemes_py as sp
+        ns, cores = 10_000, effective_cpus()
+        oidx = op.OracleMoveIndex(mv)
+        oidx.prepare(10)
+        ost = op.OracleStrategy(sp.MULTIPLE_OPT, "edit", "dynamic")
+        packed = (np.ascontiguousarray(buf[:ns * L]), offs[:ns + 1].copy())
+        tc = time.perf_counter()
+        o_occ, o_off, o_cnt = oidx.match_batch(ost, k, threads=cores, word_size=10, packed=packed)
+        dc = time.perf_counter() - tc
+        m = int(occ_offs[ns])
+        same = (len(o_occ) == m and np.array_equal(o_occ["begin"].astype(np.uint64), occ["begin"][:m]) and
+                np.array_equal(o_occ["end"].astype(np.uint64), occ["end"][:m]) and np.array_equal(o_occ["distance"], occ["distance"][:m]))
+        cpu = {"value": round(ns / dc, 1), "unit": "reads/s", "cores": cores, "kind": "port",
+               "sample": f"first {ns} reads of the leg's batch, oracle/ (RLC flavour) with {cores} threads, {dc:.1f} s; occurrences identical to the GPU's: {bool(same)}"}
+    batch.close()
+    return {"metric": "reads/sec (250bp, k=6 edit, pan-genome RLC b-move index)", "value": round(R * steps / dt, 1), "unit": "reads/s",
+            "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": 1, "reads": R,
+            "config": {"workload": f"BASELINE configs[4] stand-in: {args.haplotypes} haplotypes x {args.base_mbp} Mbp with {args.snp} SNPs "
+                                   f"({mv.n / 1e6:.0f} Mbp, r = {mv.runs_fwd}, n/r = {mv.n / mv.runs_fwd:.1f}; index built in {built:.0f} s), "
+                                   f"{R} x {L} bp reads, k={k} edit distance, ALL mode, multiple_opt, dynamic partitioning",
+                       "index_bytes_hbm": index.device_bytes(), "occurrences": int(len(occ))},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(avg[dominant], 3),
+                         "unit_note": f"16 B per move-table row fetched; {cnt['DFS_TABLE_ROWS'] / max(cnt['DFS_EXPANSIONS'], 1):.1f} rows per node expansion",
+                         "per_kernel_ms": {kn: round(v, 3) for kn, v in avg.items()}},
+            "cpu_baseline": cpu}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", choices=["fm", "rlc"], default="fm",
@@ -401,10 +550,12 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU oracle (bounded sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the (untimed) gather of the results on rank 0")
-    ap.add_argument("--include-upload", action="store_true",
-                    help="also time steps that take a FRESH chunk of reads from page-locked host memory each "
-                         "(cmb_batch_stage_reads uploads chunk i + 1 while chunk i is matched); reported as `streaming`, "
-                         "never as `value`")
+    ap.add_argument("--include-upload", action="store_true", help="kept for older command lines: the streaming leg is part of the default line")
+    ap.add_argument("--no-streaming", action="store_true",
+                    help="skip the `streaming` leg (steps that take FRESH reads from page-locked host memory and hand their results to the "
+                         "host; reported beside `value`, never as `value`)")
+    ap.add_argument("--no-rlc", action="store_true",
+                    help="skip the bounded BASELINE configs[4] leg (`rlc`: b-move index, 250 bp, k = 6) of the default one-GPU line")
     args = ap.parse_args()
     if args.config == "rlc":
         if "--reads" not in " ".join(sys.argv):
@@ -528,41 +679,6 @@ def main():
                 del g_occ, g_offs
 
     streaming = None
-    if args.include_upload:
-        # two chunks of reads in page-locked host memory, alternating: the upload of the next one overlaps the matching
-        buf2, _ = synth.sample_reads_fast(torch.from_numpy(ix.text[:-1]).to(dev), R, L, seed=4 + rank, device=dev) if ix is not None \
-            else (buf.copy(), None)
-        chunks = [torch.from_numpy(np.ascontiguousarray(c)).pin_memory().numpy() for c in (buf, buf2)]
-        batch.stage((chunks[1], offs))
-        batch.run()   # (warm-up: matches the resident chunk, uploads chunk 1)
-        batch.results(reuse=True)
-        sync()
-        ts = time.perf_counter()
-        t_stage = t_run = t_res = 0.0
-        for i in range(args.steps):
-            t0 = time.perf_counter()
-            batch.stage((chunks[i % 2], offs))   # registered; travels while this step's chunk is matched
-            t1 = time.perf_counter()
-            batch.run()
-            t2 = time.perf_counter()
-            batch.results(reuse=True)
-            t_stage += t1 - t0
-            t_run += t2 - t1
-            t_res += time.perf_counter() - t2
-        sync()
-        dt = time.perf_counter() - ts
-        if dist is not None:
-            te = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
-            dist.all_reduce(te, op=dist.ReduceOp.MAX)
-            dt = float(te.item())
-        streaming = {"value": round(world * R * max(args.steps, 1) / dt, 1), "unit": "reads/s",
-                     "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3),
-                     "host_ms_per_step": {"register next chunk": round(t_stage / max(args.steps, 1) * 1e3, 1),
-                                          "run (matching + upload of the next chunk)": round(t_run / max(args.steps, 1) * 1e3, 1),
-                                          "copy results out": round(t_res / max(args.steps, 1) * 1e3, 1)},
-                     "note": "every step matches a fresh chunk taken from page-locked host memory (1.5 GB per 10 M reads over "
-                             "PCIe, uploaded by cmb_batch_stage_reads while the previous chunk is matched) and copies its "
-                             "results to the host"}
     if rank == 0:
         steps = max(args.steps, 1)
         value = world * R * steps / elapsed
@@ -643,6 +759,22 @@ def main():
                              f"use ({os.cpu_count()} hardware threads on the host), {dt:.1f} s, reads packed before the clock; "
                              f"{ns / dt / cores:.0f} reads/s per thread (BASELINE.md: Columba itself 21 k reads/s per thread on a cache-resident "
                              f"16 Mbp index, probe of the survey); occurrences identical to the GPU's: {bool(same)}"}
+    # ---- legs after the timed region (they leave `value` untouched): the resident batch gives its memory back first
+    batch.close()
+    del occ, occ_offs
+    torch.cuda.empty_cache()
+    rlc = None
+    if not args.no_streaming:
+        streaming = streaming_leg(index, strategy, args.k, buf, R, L, min(max(args.steps, 1), 8), rank, dev, dist, world)
+        if streaming is not None and rank == 0:
+            streaming["frac_of_resident"] = round(streaming["value"] / (world * R * max(args.steps, 1) / elapsed), 4)
+    if rank == 0 and world == 1 and not args.no_rlc:
+        torch.cuda.empty_cache()
+        try:
+            rlc = rlc_leg(args, dev, local)
+        except Exception as e:  # noqa: BLE001  (the headline line must not depend on the leg)
+            rlc = {"error": str(e)[:300]}
+    if rank == 0:
         line = {
             "metric": "reads/sec (150bp, k=4 edit, human ref)",
             "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps,
@@ -657,10 +789,9 @@ def main():
                        "reads_per_gpu": R, "read_len": L, "k": args.k, "genome_bp": n,
                        "index_bytes_hbm": index.device_bytes(), "parallelism": f"read-shard x{world}",
                        "occurrences": total_occ, "result_gather_ms": None if gather_ms is None else round(gather_ms, 1)},
-            "roofline": roofline, "cpu_baseline": cpu, "streaming": streaming,
+            "roofline": roofline, "cpu_baseline": cpu, "streaming": streaming, "rlc": rlc,
         }
         print(json.dumps(line), flush=True)
-    batch.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -22,7 +22,7 @@
 // come out of the SAME 32-byte sector (the reference reads the BWT word, two rank lines, the sampled-row word and its
 // rank9 counts).  One byte per position and
 // direction — 1.5 x the 128-byte blocks of 192 positions used before, which needed four loads per rank:
-// the extension kernels are bound by the NUMBER of scattered loads, and memory is not
+// a random fetch costs one 128-byte LINE of HBM traffic whatever it uses of it, and memory is not
 // what an MI355X lacks.
 // The BWT symbol needed by LF is decoded from the same bits (the bitvectors are cumulative:
 // bwtrepr.h:67-68), so the 3-bit EncodedText (.bwt) is not kept on the device at all.

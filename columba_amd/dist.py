@@ -83,18 +83,25 @@ def broadcast_device_index(index, rank: int, device: int = 0):
             broadcast_flat(t, src=0)
     # every replica runs the consistency probe of cmb_index_create on what arrived (a truncated or mixed-up transfer would
     # otherwise hang the first locate) — and all ranks learn the outcome before any of them enters the next collective
+    agree_on_replicas(index if rank != 0 else None)
+    return index
+
+
+def agree_on_replicas(replica, what: str = "index"):
+    """Validate this rank's replica (None: nothing to validate here, e.g. the rank that owns the original) and make EVERY rank
+    raise if ANY replica failed: a rank that raised on its own would leave the others waiting in the next collective."""
+    import torch.distributed as dist
     err = ""
-    if rank != 0:
+    if replica is not None:
         try:
-            index.validate()
+            replica.validate()
         except Exception as e:  # noqa: BLE001
-            err = str(e)
+            err = str(e) or type(e).__name__
     errs = [None] * dist.get_world_size()
     dist.all_gather_object(errs, err)
     bad = [(r, e) for r, e in enumerate(errs) if e]
     if bad:
-        raise RuntimeError("index replica failed validation on rank(s) " + ", ".join(f"{r}: {e}" for r, e in bad))
-    return index
+        raise RuntimeError(f"{what} replica failed validation on rank(s) " + ", ".join(f"{r}: {e}" for r, e in bad))
 
 
 MOVE_FIELDS = ["lfbp_fwd", "lfbp_rev", "smpf", "smpl", "rev_smpf", "rev_smpl", "pred_first", "first_to_run", "pred_last",
@@ -143,8 +150,7 @@ def broadcast_device_move_index(index, rank: int, device: int = 0):
     for t in index.device_tensors():
         if t is not None:
             broadcast_flat(t, src=0)
-    if rank != 0:
-        index.validate()
+    agree_on_replicas(index if rank != 0 else None, "b-move index")  # (as for the FM-index: all ranks learn the outcome)
     return index
 
 

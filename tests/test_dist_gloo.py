@@ -135,3 +135,50 @@ def test_two_rank_move_index_replication(tmp_path, oracle_built):
     assert np.array_equal(np.concatenate(parts), np.load(tmp_path / "mv_all.npy")) and sum(p.shape[0] for p in parts) > 500
     assert [int(sum(c[i] for c in cnts)) for i in (0, 1)] == [int(v) for v in np.load(tmp_path / "mv_call.npy")]
     assert int(cnts[0][3]) == int(cnts[1][2])
+
+
+class _Replica:
+    """stands in for a device index replica: validate() fails on the rank that got a damaged copy"""
+
+    def __init__(self, bad):
+        self.bad = bad
+
+    def validate(self):
+        if self.bad:
+            raise RuntimeError("row 17 of the move table points outside its run")
+
+
+def _agree_worker(rank, world, port, tmp, bad_rank):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from columba_amd.dist import agree_on_replicas
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    msg = ""
+    try:
+        # rank 0 owns the original (nothing to validate), the others their replicas — as broadcast_device_[move_]index call it
+        agree_on_replicas(None if rank == 0 else _Replica(rank == bad_rank), "b-move index")
+    except RuntimeError as e:
+        msg = str(e)
+    # nobody is left behind in a collective: the next one completes on every rank
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    with open(os.path.join(tmp, f"agree{rank}.txt"), "w") as f:
+        f.write(f"{int(t.item())}|{msg}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bad_rank", [1, 2, -1])
+def test_a_bad_replica_makes_every_rank_raise(tmp_path, bad_rank):
+    """broadcast_device_index / broadcast_device_move_index: one replica that fails validation is an error on ALL ranks (a rank
+    that raised alone would leave the others hanging in the next collective); no bad replica, no error"""
+    world = 3
+    mp.spawn(_agree_worker, args=(world, 29600 + os.getpid() % 300 + 2 * (bad_rank + 1), str(tmp_path), bad_rank), nprocs=world, join=True)
+    for r in range(world):
+        n, msg = open(tmp_path / f"agree{r}.txt").read().split("|", 1)
+        assert int(n) == world
+        if bad_rank < 0:
+            assert msg == ""
+        else:
+            assert "b-move index replica failed validation" in msg and f"{bad_rank}: row 17" in msg, (r, msg)

@@ -6,7 +6,7 @@ ARGS=$1; shift
 for SET in "$@"; do
   [ "$SET" = "-" ] && SET=""
   echo "=== $SET"
-  env $SET python3 $R/bench.py $ARGS --no-cpu-baseline 2>/dev/null | python3 -c "
+  env $SET python3 $R/bench.py $ARGS --no-cpu-baseline --no-streaming --no-rlc 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 pk=d['roofline']['per_kernel']

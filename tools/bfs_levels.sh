@@ -9,7 +9,7 @@ mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_lv
 export CMB_SERIAL_SUBBATCHES=1 CMB_VERBOSE=2
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_lv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/bfs_levels_bench_$TAG.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_lv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-streaming --no-rlc > $R/gpurun_out/bfs_levels_bench_$TAG.log 2>&1
 python3 - $R/gpurun_out/bfs_levels_bench_$TAG.log <<'PY' > $R/gpurun_out/bfs_levels_$TAG.txt
 import csv, glob, re, sys
 rows = []

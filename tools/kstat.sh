@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
-CMB_SERIAL_SUBBATCHES=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /tmp/ks_$TAG.log 2>&1
+CMB_SERIAL_SUBBATCHES=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-streaming --no-rlc > /tmp/ks_$TAG.log 2>&1
 python3 - <<PY
 import csv, glob
 rows=[]

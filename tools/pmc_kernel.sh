@@ -15,7 +15,7 @@ for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_I
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY" \
            "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_SMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH SQ_INSTS_SENDMSG"; do
   i=$((i+1))
-  rocprofv3 --pmc $SET --kernel-include-regex 'cmb::' --output-format csv -d /tmp/pmc_$i -- python3 $R/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pass_$i.log 2>&1
+  rocprofv3 --pmc $SET --kernel-include-regex 'cmb::' --output-format csv -d /tmp/pmc_$i -- python3 $R/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-streaming --no-rlc > $OUT/pass_$i.log 2>&1
   rc=$?
   if [ $rc -ne 0 ]; then
     echo "rocprofv3 pass $i ($SET) failed with exit code $rc; see $OUT/pass_$i.log" | tee $OUT/summary.txt

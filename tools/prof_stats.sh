@@ -4,7 +4,7 @@ TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 $R/bench.py "$@" --no-cpu-baseline > $R/gpurun_out/${TAG}_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 $R/bench.py "$@" --no-cpu-baseline --no-streaming --no-rlc > $R/gpurun_out/${TAG}_bench.log 2>&1
 python3 - <<PY > $R/gpurun_out/${TAG}_kernel_stats.csv
 import csv, glob
 rows = []

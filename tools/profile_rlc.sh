@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/profiles_${ROUND}_rlc
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--config rlc $@"
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rlc_stats -- python3 $R/bench.py $ARGS --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rlc_stats -- python3 $R/bench.py $ARGS --no-cpu-baseline --no-streaming --no-rlc > $OUT/bench_under_rocprof.log 2>&1
 python3 - <<PY > $OUT/kernel_stats.csv
 import csv, glob
 rows = []
@@ -21,7 +21,7 @@ for r in rows:
         print(",".join([n[:90].replace(",", ";"), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]))
 PY
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-include-regex 'k_mvs|k_move' --output-format csv -d /tmp/rlc_$C -- python3 $R/bench.py $ARGS --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-include-regex 'k_mvs|k_move' --output-format csv -d /tmp/rlc_$C -- python3 $R/bench.py $ARGS --steps 1 --warmup 1 --no-cpu-baseline --no-streaming --no-rlc > $OUT/pmc_$C.log 2>&1
 done
 python3 - <<'PY' > $OUT/pmc_traffic.txt
 import csv, glob, collections

@@ -2,7 +2,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
 for cfg in "$@"; do
   ( for kv in $cfg; do export "$kv"; done
-    python3 $R/bench.py --config rlc --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null |
+    python3 $R/bench.py --config rlc --steps 2 --warmup 1 --no-cpu-baseline --no-streaming --no-rlc 2>/dev/null |
     python3 -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$cfg', d['value'], d['ms_per_step'], {k:v['ms'] for k,v in d['roofline']['per_kernel'].items()})" )
 done
