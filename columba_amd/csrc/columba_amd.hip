@@ -1205,7 +1205,7 @@ static int batchRunOne(cmb_batch* b) {
                     B.aCap = (uint32_t)std::min<size_t>(b->bfsA.n, 0xFFFFFFF0u);
                     B.chain = getenv("CMB_BFS_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("CMB_BFS_CHAIN"))) : BFS_CHAIN;
                     B.gridX = getenv("CMB_BFS_GRID") ? (uint32_t)std::min<int>(BFS_GRID, std::max(1, atoi(getenv("CMB_BFS_GRID"))))
-                                                     : (CMB_BFS_WALK ? BFS_GRID_X_WALK : BFS_GRID_X);
+                                                     : (CMB_BFS_WALK == 1 ? BFS_GRID_X_WALK : BFS_GRID_X);
                     B.gridEv = getenv("CMB_BFS_GRID_EV") ? (uint32_t)std::max(1, atoi(getenv("CMB_BFS_GRID_EV"))) : BFS_GRID_EV;
                     B.nq = b->bfsCnt.p;
                     B.ne = b->bfsCnt.p + (maxPass + 2);

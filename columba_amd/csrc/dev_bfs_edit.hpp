@@ -697,7 +697,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
 #ifndef CMB_BFS_WALK
 #define CMB_BFS_WALK 0
 #endif
-constexpr uint32_t WALK_CH_EV = 16, WALK_CH_EV_SMALL = 4, WALK_CH_IT = 128, WALK_CH_F = 128;
+constexpr uint32_t WALK_CH_EV = 32, WALK_CH_EV_SMALL = 4, WALK_CH_IT = 512, WALK_CH_F = 512;
 constexpr uint32_t WALK_TAIL_MAX = 64;
 constexpr uint32_t WALK_SAVE_U32 = 8; // per wavefront: the item chunk and the F chunk {base, used, size}, two spare words
 
@@ -716,26 +716,33 @@ __device__ __forceinline__ void gldsU4(const uint4* src, uint4* ldsWaveBase) {
 }
 #define CMB_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory") /* lanes of ONE wavefront talking through LDS */
 
-// the wavefront's output chunk of the node queue: 64 slots, its count goes to qCnt when the chunk is left
-struct NodeChunk {
-    uint32_t base = 0xFFFFFFFFu, used = 64u;
+// The wavefront's output REGION of the chunked node queue: a run of whole chunks (64 slots each) taken with ONE atomic and filled from
+// the front; when it is left — used up, or at the end of the kernel — every chunk of it gets its count in qCnt (64, the rest, or 0: the
+// consumers pass over empty chunks).  One chunk per atomic was too little: 1.8 million atomics per sub-batch on the queue's counter
+// run into the ~90 same-address atomics per microsecond the L2 serves (the frontier kernel spent a third of its time queueing there).
+struct NodeRegion {
+    uint32_t base = 0xFFFFFFFFu, used = 0u, size = 0u;
     __device__ __forceinline__ void retire(uint32_t* qCnt) {
-        if (base != 0xFFFFFFFFu && (threadIdx.x & 63u) == 0) qCnt[base >> 6] = used;
+        const uint32_t lane = threadIdx.x & 63u;
+        if (base != 0xFFFFFFFFu)
+            for (uint32_t j = lane; j * 64u < size; j += 64u) qCnt[(base >> 6) + j] = used > j * 64u ? min(used - j * 64u, 64u) : 0u;
+        base = 0xFFFFFFFFu;
+        used = size = 0u;
     }
-    // first slot for the wavefront's `total` (<= 64) nodes; 0xFFFFFFFF: the queue is full
-    __device__ __forceinline__ uint32_t alloc(uint32_t* counter, uint32_t cap, uint32_t total, uint32_t* qCnt, bool& overflow) {
-        if (used + total > 64u) {
+    // first slot for the wavefront's `total` nodes (contiguous); 0xFFFFFFFF: the queue is full.  `slots`: size of a new region (x 64)
+    __device__ __forceinline__ uint32_t alloc(uint32_t* counter, uint32_t cap, uint32_t total, uint32_t slots, uint32_t* qCnt, bool& overflow) {
+        if (used + total > size) {
             retire(qCnt);
+            const uint32_t want = max(slots, (total + 63u) & ~63u);
             uint32_t b = 0;
-            if ((threadIdx.x & 63u) == 0) b = atomicAdd(counter, 64u);
+            if ((threadIdx.x & 63u) == 0) b = atomicAdd(counter, want);
             b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-            if (b > cap || 64u > cap - b) {
+            if (b > cap || want > cap - b) {
                 overflow = true;
-                base = 0xFFFFFFFFu;
-                used = 64u;
                 return 0xFFFFFFFFu;
             }
             base = b;
+            size = want;
             used = 0;
         }
         const uint32_t o = base + used;
@@ -743,6 +750,9 @@ struct NodeChunk {
         return o;
     }
 };
+__device__ __forceinline__ uint32_t nodeRegionSlots(uint32_t nIn, uint32_t W) { // what a wavefront is likely to append in a pass, 64 ... 512
+    return min(512u, max(64u, ((nIn / max(W, 1u)) + 63u) & ~63u));
+}
 
 template <class Geo = GeoN>
 __device__ __forceinline__ void bfsExpandWalk(const DevIndex& ix, const BfsBufs& B, uint32_t pass, const Queues& q,
@@ -791,7 +801,8 @@ __device__ __forceinline__ void bfsExpandWalk(const DevIndex& ix, const BfsBufs&
     int md = 0;
     uint32_t cntChildren = 0, cntExp = 0, flags = 0;
     uint32_t cur = 0; // round parity (wave-uniform)
-    NodeChunk ncNode;
+    NodeRegion ncNode;
+    const uint32_t regionSlots = nodeRegionSlots(nIn, W);
     WaveChunk wcEv, wcIt, wcF;
     uint32_t* save = B.wcSave + (size_t)wId * WALK_SAVE_U32;
     { // the item and F chunks of the wavefront's previous pass (zeroed before the search)
@@ -996,7 +1007,7 @@ __device__ __forceinline__ void bfsExpandWalk(const DevIndex& ix, const BfsBufs&
             const uint32_t inI = waveInclusiveScanDpp(nIt), tI = waveLastLane(inI);
             bool ovQ = false, ovE = false, ovI = false, ovF = false;
             uint32_t oNode = 0xFFFFFFFFu;
-            if (t3 & 0xFFu) oNode = ncNode.alloc(&B.nq[pass + 1], qCap, t3 & 0xFFu, cntOut, ovQ);
+            if (t3 & 0xFFu) oNode = ncNode.alloc(&B.nq[pass + 1], qCap, t3 & 0xFFu, regionSlots, cntOut, ovQ);
             const uint32_t oEv = wcEv.allocPre(&B.ne[pass + 1], B.evCap, ((in3 >> 8) & 0xFFu) - nEv, (t3 >> 8) & 0xFFu, chEv, ovE, holeEv);
             const uint32_t oF = wcF.allocPre(&B.pool[0], B.fCap, ((in3 >> 16) & 0xFFu) - nF, (t3 >> 16) & 0xFFu, WALK_CH_F, ovF, holeF);
             const uint32_t oIt = wcIt.allocPre(&q.cnt[0], q.itemCap, inI - nIt, tI, WALK_CH_IT, ovI, holeIt);
@@ -1094,6 +1105,335 @@ __device__ __forceinline__ void bfsExpandWalk(const DevIndex& ix, const BfsBufs&
     if (threadIdx.x < 3) {
         const unsigned long long t = shc[0][threadIdx.x] + shc[1][threadIdx.x] + shc[2][threadIdx.x] + shc[3][threadIdx.x];
         if (t) B.blockCnt[(size_t)bid * 4 + threadIdx.x] += t;
+    }
+    if (flags) atomicOr(&q.cnt[3], flags);
+}
+
+// ------------------------------------------------------------------ expand: bfsExpand per WAVEFRONT (round 4, CMB_BFS_WALK=2)
+// The per-node logic of bfsExpand, lane for lane (same classification, chain walk and records), without what a block-wide tile costs
+// it: three barriers and an atomic round trip per tile, and the node planes as a round trip of their own.  A wavefront works on its
+// own chunks of the chunked node queue (chunk c belongs to wavefront c % W, counts in BfsBufs::qCnt — as bfsExpandWalk):
+//   * the node planes of the NEXT chunk are copied into the lanes' LDS slots by global_load_lds while the current one is expanded;
+//   * queue slots come from per-wavefront chunks: one prefix sum over the lanes (DPP), an atomic only when a chunk is used up;
+//   * no barrier: the four wavefronts of a block drift apart, which is what hides their memory round trips from each other.
+template <class Geo = GeoN>
+__device__ __forceinline__ void bfsExpandWave(const DevIndex& ix, const BfsBufs& B, uint32_t pass, const Queues& q, uint32_t bid,
+                                              uint32_t nBlocks) {
+    constexpr uint32_t EV_U4 = 1u + Geo::PK_U4;
+    __shared__ uint4 ldsNext[3][256];  // node planes of the wavefront's next chunk
+    __shared__ uint64_t ldsM[4][256];
+    __shared__ uint32_t ldsR[8][256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
+    const uint32_t nIn = min(B.nq[pass], B.qCap);
+    const uint4* __restrict__ Qi = B.Q[pass & 1u];
+    uint4* __restrict__ Qo = B.Q[(pass + 1u) & 1u];
+    uint4* __restrict__ Eo = B.Ev[(pass + 1u) & 1u];
+    const uint32_t* __restrict__ cntIn = B.qCnt[pass & 1u];
+    uint32_t* __restrict__ cntOut = B.qCnt[(pass + 1u) & 1u];
+    const uint32_t qCap = B.qCap;
+    const uint32_t W = nBlocks * 4u, wId = bid * 4u + (tid >> 6), nChunks = (nIn + 63u) >> 6;
+    const uint32_t cntLast = nChunks ? nChunks - 1u : 0u;
+    uint32_t chunk = wId;
+    uint32_t cCnt = 0, nCnt = 0;
+    {
+        const uint32_t c0 = cntIn[min(chunk, cntLast)], c1 = cntIn[min(chunk + W, cntLast)];
+        cCnt = chunk < nChunks ? (uint32_t)__builtin_amdgcn_readfirstlane((int)min(c0, 64u)) : 0u;
+        nCnt = chunk + W < nChunks ? (uint32_t)__builtin_amdgcn_readfirstlane((int)min(c1, 64u)) : 0u;
+        if (lane < cCnt) {
+            const uint32_t i0 = chunk * 64u + lane;
+            gldsU4(Qi + i0, &ldsNext[0][wbase]);
+            gldsU4(Qi + (size_t)qCap + i0, &ldsNext[1][wbase]);
+            gldsU4(Qi + (size_t)2 * qCap + i0, &ldsNext[2][wbase]);
+        }
+    }
+    uint32_t flags = 0, cntChildren = 0, cntExp = 0;
+    NodeRegion ncNode;
+    const uint32_t regionSlots = nodeRegionSlots(nIn, W);
+    WaveChunk wcEv, wcIt, wcF;
+    uint32_t* save = B.wcSave + (size_t)wId * WALK_SAVE_U32;
+    { // the item and F chunks of the wavefront's previous pass (zeroed before the search)
+        wcIt.base = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[0]);
+        wcIt.used = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[1]);
+        wcIt.size = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[2]);
+        wcF.base = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[4]);
+        wcF.used = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[5]);
+        wcF.size = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[6]);
+    }
+    const uint32_t chEv = nIn < 262144u ? WALK_CH_EV_SMALL : WALK_CH_EV;
+    auto holeEv = [&](uint32_t o) { Eo[(size_t)EV_U4 * o] = make_uint4(BFS_NONE, 0u, 0u, 0u); };
+    auto holeIt = [&](uint32_t o) { q.items[o] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u); };
+    auto holeF = [&](uint32_t) {};
+#ifdef CMB_BFS_STATS
+    // diagnostic build only (tools/walk_stats.sh): [0] tiles, [1] active lanes, [3] cycles in the loop, [8..13] cycles: wait for the
+    // planes | first memory step + classification | chain steps | allocation | output | loop end
+    unsigned long long pf[16] = {};
+    const long long pfT0 = clock64();
+    long long pfT = pfT0;
+#endif
+    while (chunk < nChunks) { // (wave-uniform)
+        PF_LAP(13)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the chunk's node planes are in the lanes' slots
+        PF_LAP(8)
+        PF_ADD(0, lane == 0 ? 1u : 0u)
+        PF_ADD(1, lane < cCnt ? 1u : 0u)
+        const bool act = lane < cCnt;
+        const uint32_t i = chunk * 64u + lane;
+        uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0;
+        if (act) {
+            n0 = ldsNext[0][tid];
+            n1 = ldsNext[1][tid];
+            n2 = ldsNext[2][tid];
+        }
+        CMB_LDS_SYNC(); // (the slots are read before they are filled again)
+        // the next chunk of the wavefront: its planes travel while this one is expanded; the count of the one after it
+        const uint32_t chunkN = chunk + W;
+        if (chunkN < nChunks && lane < nCnt) {
+            const uint32_t i1 = chunkN * 64u + lane;
+            gldsU4(Qi + i1, &ldsNext[0][wbase]);
+            gldsU4(Qi + (size_t)qCap + i1, &ldsNext[1][wbase]);
+            gldsU4(Qi + (size_t)2 * qCap + i1, &ldsNext[2][wbase]);
+        }
+        const uint32_t n2Load = cntIn[min(chunkN + W, cntLast)];
+        if (cCnt == 0u) { // an empty chunk (the unused rest of a producer's region): on to the next
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            chunk = chunkN;
+            cCnt = nCnt;
+            nCnt = chunk + W < nChunks ? (uint32_t)__builtin_amdgcn_readfirstlane((int)min(n2Load, 64u)) : 0u;
+            continue;
+        }
+        uint32_t kinds = 0; // 4 bits per child: kind | needF << 2
+        uint32_t row1 = 0, ctx = 0, fcP = BFS_NONE, nIt = 0;
+        RangePair parent{{0, 0}, {0, 0}};
+        uint32_t row = 0, score = 0, blk = 0;
+        int md = 0;
+        uint64_t pHP = 0, pHN = 0;
+        uint32_t pRac = 0;
+        ExpandCtx e{};
+        e.switchPoint = ix.switchPoint;
+        uint32_t db = 0, de = 0;
+        uint32_t hotX = 0, hotW = 0;
+        bool walking = act;
+        if (act) {
+            ctx = n1.y;
+            fcP = n1.z;
+            row = n1.x & 0xFFFFu;
+            score = n1.x >> 16;
+            md = (int)((n1.w >> 8) & 3u);
+            parent = RangePair{{n0.x, n0.y}, {n0.z, n0.w}};
+            uint4 rk[4];
+            issueRanks(ix, md, parent, rk);
+            const uint4* Cx = B.C + (size_t)CMB_IDX(ctx, B.cCap, 1) * B.ctxU4;
+            blk = (row + 1) / Geo::BLOCK;
+            const uint4 hot = Cx[CTX_HOT];
+            const uint4 mA = Cx[CTX_M + 2 * blk], mB = Cx[CTX_M + 1 + 2 * blk];
+            {
+                uint32_t Rb[4], Re[4];
+                takeRanks(ix, md, parent, rk, Rb, Re, db, de);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    ldsR[c][tid] = Rb[c];
+                    ldsR[4 + c][tid] = Re[c];
+                }
+            }
+            e.itStart = hot.z;
+            e.g.n = hot.y & 0x1FFu;
+            e.g.m = (hot.y >> 9) & 0x1FFu;
+            e.g.Wv = (hot.y >> 18) & 31u;
+            e.g.Wh = (hot.y >> 23) & 15u;
+            e.g.maxED = (hot.y >> 27) & 15u;
+            e.clSize = hot.w >> 23;
+            e.itMode = (hot.x >> 25) & 3u;
+            hotX = hot.x;
+            hotW = hot.w;
+            pHP = u64of(n2.x, n2.y);
+            pHN = u64of(n2.z, n2.w);
+            pRac = n1.w & 63u;
+            ldsM[0][tid] = u64of(mA.x, mA.y);
+            ldsM[1][tid] = u64of(mA.z, mA.w);
+            ldsM[2][tid] = u64of(mB.x, mB.y);
+            ldsM[3][tid] = u64of(mB.z, mB.w);
+        }
+        // ---- walk (as bfsExpand)
+        for (uint32_t step = 0; step < B.chain; step++) { // (wave-uniform exit below)
+            if (step == 1u) { PF_LAP(9) }
+            if (walking) {
+                if (step) {
+                    uint4 rk[4];
+                    issueRanks(ix, md, parent, rk);
+                    uint32_t Rb[4], Re[4];
+                    takeRanks(ix, md, parent, rk, Rb, Re, db, de);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        ldsR[c][tid] = Rb[c];
+                        ldsR[4 + c][tid] = Re[c];
+                    }
+                }
+                uint32_t Rb[4], Re[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    Rb[c] = ldsR[c][tid];
+                    Re[c] = ldsR[4 + c][tid];
+                }
+                row1 = row + 1;
+                cntExp++;
+                const bool inFC = e.g.inFinalColumn(row1);
+                if (inFC && e.clSize + row1 - e.g.m >= Geo::CELLS) flags |= FLAG_CAPACITY;
+                kinds = 0;
+                nIt = 0;
+                uint32_t nOut = 0, nChildren = 0;
+#pragma unroll
+                for (uint32_t ch = 1; ch <= 4; ch++) {
+                    bool nonEmpty;
+                    ChildState cs;
+                    const uint32_t k4 = evalChild<false, Geo>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, ldsM[ch - 1][tid], pHP, pHN,
+                                                              1ull << pRac, score, nonEmpty, cs);
+                    nChildren += nonEmpty ? 1u : 0u;
+                    if (k4 & 8u) flags |= FLAG_CAPACITY;
+                    if ((k4 & 3u) == KIND_NONE) continue;
+                    kinds |= (k4 & 7u) << (4 * (ch - 1));
+                    nOut++;
+                    if ((k4 & 3u) == KIND_ITEMS) {
+                        RangePair child;
+                        (void)childFromRanks(ix, md, parent, ch, Rb, Re, db, de, child);
+                        nIt += child.sa.e - child.sa.b;
+                    }
+                }
+                cntChildren += nChildren;
+                const bool single = nOut == 1u && (kinds == 0x1u || kinds == 0x10u || kinds == 0x100u || kinds == 0x1000u);
+                if (single && step + 1u < B.chain && (row1 + 1u) / Geo::BLOCK == blk) {
+                    const uint32_t ch = ((31u - (uint32_t)__clz(kinds)) >> 2) + 1u;
+                    const uint64_t M = ch == 1 ? ldsM[0][tid] : ch == 2 ? ldsM[1][tid] : ch == 3 ? ldsM[2][tid] : ldsM[3][tid];
+                    bool nonEmpty;
+                    ChildState one;
+                    (void)evalChild<true, Geo>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, M, pHP, pHN, 1ull << pRac, score, nonEmpty, one);
+                    parent = one.r;
+                    score = one.sc;
+                    pHP = one.HP;
+                    pHN = one.HN;
+                    pRac = (uint32_t)__ffsll((unsigned long long)one.RAC) - 1u;
+                    row = row1;
+                    kinds = 0;
+                } else {
+                    walking = false;
+                }
+            }
+            if (__ballot(walking) == 0ull) break;
+        }
+        PF_LAP(10)
+        // ---- slots: one prefix sum over the lanes for nodes, events and F records, one for the items
+        uint32_t nNode = 0, nEv = 0, nF = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t kd = (kinds >> (4 * c)) & 3u;
+            nNode += kd == KIND_NODE;
+            nEv += kd == KIND_EVENT;
+            nF += (kinds >> (4 * c + 2)) & 1u;
+        }
+        const uint32_t pk3 = nNode | (nEv << 10) | (nF << 20);
+        const uint32_t in3 = waveInclusiveScanDpp(pk3), t3 = waveLastLane(in3);
+        const uint32_t inI = waveInclusiveScanDpp(nIt), tI = waveLastLane(inI);
+        bool ovE = false, ovI = false, ovF = false;
+        bool ovQ = false;
+        const uint32_t nb0 = (t3 & 0x3FFu) ? ncNode.alloc(&B.nq[pass + 1], qCap, t3 & 0x3FFu, regionSlots, cntOut, ovQ) : 0u;
+        const bool okQ = !ovQ;
+        uint32_t oEv = wcEv.allocPre(&B.ne[pass + 1], B.evCap, ((in3 >> 10) & 0x3FFu) - nEv, (t3 >> 10) & 0x3FFu, chEv, ovE, holeEv);
+        uint32_t oF = wcF.allocPre(&B.pool[0], B.fCap, ((in3 >> 20) & 0x3FFu) - nF, (t3 >> 20) & 0x3FFu, WALK_CH_F, ovF, holeF);
+        uint32_t oIt = wcIt.allocPre(&q.cnt[0], q.itemCap, inI - nIt, tI, WALK_CH_IT, ovI, holeIt);
+        uint32_t pNode = (in3 & 0x3FFu) - nNode; // this lane's first node among the wavefront's
+        if (!okQ) flags |= FLAG_BFS_Q;
+        if (ovE) flags |= FLAG_BFS_EV;
+        if (ovI) flags |= FLAG_ITEM_OVERFLOW;
+        if (ovF) flags |= FLAG_BFS_F;
+        PF_LAP(11)
+        if (kinds != 0u && okQ && !ovE && !ovI && !ovF) {
+            const bool inFC = e.g.inFinalColumn(row1);
+            const uint32_t cell = min(e.clSize + row1 - e.g.m, Geo::CELLS - 1u);
+            typename Geo::Pack pack{};
+            if (fcP != BFS_NONE && (kinds & 0x4444u)) packLoad(Qi + (size_t)3 * qCap + i, qCap, pack);
+            const uint32_t rsId = hotX & 0x1FFFFFFu, itMeta = hotW & 0x7FFFFFu;
+            uint32_t Rb[4], Re[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                Rb[c] = ldsR[c][tid];
+                Re[c] = ldsR[4 + c][tid];
+            }
+#pragma unroll
+            for (uint32_t ch = 1; ch <= 4; ch++) {
+                const uint32_t kd = (kinds >> (4 * (ch - 1))) & 3u;
+                if (kd == KIND_NONE) continue;
+                bool nonEmpty;
+                ChildState cs;
+                (void)evalChild<true, Geo>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, ldsM[ch - 1][tid], pHP, pHN, 1ull << pRac, score,
+                                           nonEmpty, cs);
+                const bool wantF = (kinds >> (4 * (ch - 1) + 2)) & 1u;
+                const uint4 cr = make_uint4(cs.r.sa.b, cs.r.sa.e, cs.r.rev.b, cs.r.rev.e);
+                uint32_t fc = BFS_NONE;
+                if (wantF) {
+                    fc = oF++;
+                    uint4* Fr = B.F + (size_t)CMB_IDX(fc, B.fCap, 9) * F_U4;
+                    Fr[0] = cr;
+                    Fr[1] = make_uint4(row1 | (ch << 16), fcP, 0u, 0u);
+                }
+                if (kd == KIND_NODE) {
+                    const uint32_t o = nb0 + pNode;
+                    pNode++;
+                    Qo[o] = cr;
+                    Qo[(size_t)qCap + o] = make_uint4(row1 | (cs.sc << 16), ctx, fc,
+                                                      ((uint32_t)__ffsll((unsigned long long)cs.RAC) - 1u) | ((uint32_t)md << 8));
+                    Qo[(size_t)2 * qCap + o] = make_uint4((uint32_t)cs.HP, (uint32_t)(cs.HP >> 32), (uint32_t)cs.HN, (uint32_t)(cs.HN >> 32));
+                    if (wantF) {
+                        typename Geo::Pack p2 = pack;
+                        edPut(p2, cell, cs.aux);
+                        packStore(Qo + (size_t)3 * qCap + o, qCap, p2);
+                    }
+                } else if (kd == KIND_EVENT) {
+                    typename Geo::Pack p2 = pack;
+                    edPut(p2, cell, cs.aux);
+                    Eo[(size_t)EV_U4 * oEv] = make_uint4(ctx, fc, 0xFFFFFFFFu, cell);
+                    packStore(Eo + (size_t)EV_U4 * oEv + 1, 1, p2);
+                    oEv++;
+                } else {
+                    const uint32_t w = cs.r.sa.e - cs.r.sa.b;
+                    for (uint32_t t = 0; t < w; t++) q.items[oIt + t] = make_uint4(rsId, cs.r.sa.b + t, cs.aux, itMeta);
+                    oIt += w;
+                }
+            }
+        }
+        PF_LAP(12)
+        // ---- on to the wavefront's next chunk
+        chunk = chunkN;
+        cCnt = nCnt;
+        nCnt = chunk + W < nChunks ? (uint32_t)__builtin_amdgcn_readfirstlane((int)min(n2Load, 64u)) : 0u;
+    }
+#ifdef CMB_BFS_STATS
+    if (lane == 0) pf[3] = (unsigned long long)(clock64() - pfT0);
+    for (int j = 0; j < 16; j++) {
+        unsigned long long x = pf[j];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+        if (lane == 0 && x) atomicAdd(&g_bfsStats[j], x);
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ncNode.retire(cntOut);
+    wcEv.fill(holeEv);
+    if (lane == 0) { // the item and F chunks go on in the wavefront's next pass
+        save[0] = wcIt.base, save[1] = wcIt.used, save[2] = wcIt.size;
+        save[4] = wcF.base, save[5] = wcF.used, save[6] = wcF.size;
+    }
+    unsigned long long v[3] = {cntChildren, cntExp, cntChildren};
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v[j] += __shfl_xor(v[j], d);
+    }
+    __shared__ unsigned long long shc[4][3];
+    if (lane == 0)
+        for (int j = 0; j < 3; j++) shc[tid >> 6][j] = v[j];
+    __syncthreads();
+    if (tid < 3) {
+        const unsigned long long t = shc[0][tid] + shc[1][tid] + shc[2][tid] + shc[3][tid];
+        if (t) B.blockCnt[(size_t)bid * 4 + tid] += t;
     }
     if (flags) atomicOr(&q.cnt[3], flags);
 }

@@ -310,7 +310,7 @@ k_bfs_start(DevIndex ix, const DevStrategyKT<Geo::MP>* __restrict__ stp, BfsBufs
 // one level: blocks [0, BFS_GRID) expand the frontier, blocks [BFS_GRID, BFS_GRID + BFS_GRID_EV) handle the events
 // of the same pass (both only append to the queues of pass + 1, so they run side by side)
 #ifndef CMB_BFS_WAVES
-#if CMB_BFS_WALK
+#if CMB_BFS_WALK == 1
 #define CMB_BFS_WAVES 2 // wavefronts per SIMD k_bfs_pass is built for (bfsExpandWalk: 64 KB of LDS per block, bound by instruction issue)
 #else
 #define CMB_BFS_WAVES 4 // (128 VGPRs: bfsExpand)
@@ -321,7 +321,9 @@ __global__ void __launch_bounds__(256, Geo::MP == MAXP ? CMB_BFS_WAVES : 2)
 k_bfs_pass(DevIndex ix, const DevStrategyKT<Geo::MP>* __restrict__ stp, BfsBufs B, uint32_t pass, const uint64_t* __restrict__ offs,
            uint32_t gw, const uint32_t* __restrict__ G, const PartOutT<Geo::MP>* __restrict__ parts, Queues q) {
     if (blockStopped(q)) return;
-#if CMB_BFS_WALK
+#if CMB_BFS_WALK == 2
+    if (blockIdx.x < B.gridX) bfsExpandWave<Geo>(ix, B, pass, q, blockIdx.x, B.gridX);
+#elif CMB_BFS_WALK
     if (blockIdx.x < B.gridX) bfsExpandWalk<Geo>(ix, B, pass, q, blockIdx.x, B.gridX);
 #else
     if (blockIdx.x < B.gridX) bfsExpand<Geo>(ix, B, pass, q, blockIdx.x, B.gridX);

@@ -41,5 +41,6 @@ for name, k in (("multiple_opt", 4),):
     print(f"  nodes taken {s[6]}, expansions per node taken {E / max(s[6], 1):.2f}")
     print("  cycles per round %.0f: take+request %.0f | issue %.0f | wait %.0f | parents %.0f | children %.0f | parents again %.0f | loop end %.0f" %
           (s[3] / r, s[8] / r, s[9] / r, s[2] / r, s[10] / r, s[11] / r, s[12] / r, s[13] / r), flush=True)
+    print("  raw per round/tile:", {j: round(s[j] / r, 1) for j in range(16)}, flush=True)
     b.close()
 PY
