@@ -568,6 +568,7 @@ struct cmb_batch {
     bool wide = false;
     bool wideEdit = false; // edit distance 8 ... 13: wide records AND the wide layout of the filter keys
     bool geoX = false;     // ... 11 ... 13: the in-index matrix with 16-row blocks (GeoX), the in-text matrix with 8-row blocks
+    bool noSmallMatrix = false; // a phase of an earlier run did not fit the 32-bit in-index matrix (GeoN32): this batch stays on GeoN
     DevStrategyKT<MAXP_WIDE> hostStratW{};
     DevBuf<DevStrategyKT<MAXP_WIDE>> stratW;
     DevBuf<PartOutT<MAXP_WIDE>> partsW;
@@ -585,8 +586,7 @@ struct cmb_batch {
     // frontier search (dev_bfs_edit.hpp): node / event double buffers, F records, contexts, list arena
     DevBuf<uint4> bfsQ[2], bfsEv[2], bfsF, bfsC, bfsA;
     DevBuf<uint32_t> bfsCnt;               // nq[passes], ne[passes], pool[4]
-    DevBuf<unsigned long long> bfsBlockCnt; // [BFS_GRID][4]
-    DevBuf<uint32_t> bfsQCnt[2], bfsWcSave; // bfsExpandWalk: node counts of the queue chunks; per-wavefront item / F chunks
+    DevBuf<unsigned long long> bfsBlockCnt; // [BFS_GRID_CNT][4]
     size_t bfsQCap = 0, bfsEvCap = 0, bfsFCap = 0, bfsCCap = 0, bfsACap = 0;
     // naive backtracking (dev_bfs_naive.hpp): node double buffer, nodes per pass
     DevBuf<uint4> nvQ[2];
@@ -869,7 +869,8 @@ extern "C" int cmb_batch_run(cmb_batch* b) {
     const char* mcEnv = getenv("CMB_MAX_CONCURRENT");
     size_t nWorkers = serial ? 1 : std::min<size_t>(b->subs.size(), 3);
     if (mcEnv && !serial) nWorkers = std::min<size_t>(b->subs.size(), std::max(1, atoi(mcEnv)));
-    const bool manySubs = b->subs.size() > 3; // (then a finished sub-batch gives its pools back: the next one allocates what it needs)
+    // (beyond 7 errors, where the sub-batches are many and their pools large, a finished sub-batch gives its pools back: the next one allocates what it needs)
+    const bool manySubs = b->subs.size() > 3 && b->k > 7;
     std::atomic<size_t> next{0};
     std::vector<std::thread> th;
     for (size_t w = 0; w < nWorkers; w++)
@@ -1179,20 +1180,14 @@ static int batchRunOne(cmb_batch* b) {
                     if (b->bfsA.n < b->bfsACap) b->bfsA.alloc(b->bfsACap);
                     const size_t cntWords = 2 * ((size_t)maxPass + 2) + 4;
                     if (b->bfsCnt.n < cntWords) b->bfsCnt.alloc(cntWords);
-                    if (b->bfsBlockCnt.n < (size_t)BFS_GRID * 4) b->bfsBlockCnt.alloc((size_t)BFS_GRID * 4);
-                    for (int j = 0; j < 2; j++) // (bfsExpandWalk: one count per chunk of 64 slots)
-                        if (b->bfsQCnt[j].n < b->bfsQCap / 64 + 8) b->bfsQCnt[j].alloc(b->bfsQCap / 64 + 8);
-                    if (b->bfsWcSave.n < (size_t)BFS_GRID * 4 * WALK_SAVE_U32) b->bfsWcSave.alloc((size_t)BFS_GRID * 4 * WALK_SAVE_U32);
-                    HIPCHK(hipMemsetAsync(b->bfsWcSave.p, 0, b->bfsWcSave.n * sizeof(uint32_t), s));
+                    if (b->bfsBlockCnt.n < (size_t)BFS_GRID_CNT * 4) b->bfsBlockCnt.alloc((size_t)BFS_GRID_CNT * 4);
                     HIPCHK(hipMemsetAsync(b->bfsCnt.p, 0, cntWords * sizeof(uint32_t), s));
-                    HIPCHK(hipMemsetAsync(b->bfsBlockCnt.p, 0, (size_t)BFS_GRID * 4 * sizeof(unsigned long long), s));
+                    HIPCHK(hipMemsetAsync(b->bfsBlockCnt.p, 0, (size_t)BFS_GRID_CNT * 4 * sizeof(unsigned long long), s));
                     BfsBufs B{};
                     for (int j = 0; j < 2; j++) {
                         B.Q[j] = b->bfsQ[j].p;
                         B.Ev[j] = b->bfsEv[j].p;
-                        B.qCnt[j] = b->bfsQCnt[j].p;
                     }
-                    B.wcSave = b->bfsWcSave.p;
                     B.F = b->bfsF.p;
                     B.C = b->bfsC.p;
                     B.A = b->bfsA.p;
@@ -1204,19 +1199,27 @@ static int batchRunOne(cmb_batch* b) {
                     B.ctxMblk = b->geoX ? CTX_MBLK_X : ctxMblkFor(b->maxLen);
                     B.aCap = (uint32_t)std::min<size_t>(b->bfsA.n, 0xFFFFFFF0u);
                     B.chain = getenv("CMB_BFS_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("CMB_BFS_CHAIN"))) : BFS_CHAIN;
-                    B.gridX = getenv("CMB_BFS_GRID") ? (uint32_t)std::min<int>(BFS_GRID, std::max(1, atoi(getenv("CMB_BFS_GRID"))))
-                                                     : (CMB_BFS_WALK == 1 ? BFS_GRID_X_WALK : BFS_GRID_X);
+                    B.gridX = getenv("CMB_BFS_GRID") ? (uint32_t)std::min<int>(BFS_GRID_CNT, std::max(1, atoi(getenv("CMB_BFS_GRID"))))
+                                                     : BFS_GRID_X;
                     B.gridEv = getenv("CMB_BFS_GRID_EV") ? (uint32_t)std::max(1, atoi(getenv("CMB_BFS_GRID_EV"))) : BFS_GRID_EV;
+                    // (CMB_TEST_NARROW_WV: tests lower the bound so that the re-run on the 64-bit geometry is exercised)
+                    B.narrowWv = getenv("CMB_TEST_NARROW_WV") ? (uint32_t)std::max(0, atoi(getenv("CMB_TEST_NARROW_WV"))) : 0xFFFFu;
                     B.nq = b->bfsCnt.p;
                     B.ne = b->bfsCnt.p + (maxPass + 2);
                     B.pool = b->bfsCnt.p + 2 * (maxPass + 2);
                     B.blockCnt = b->bfsBlockCnt.p;
+                    // up to 7 errors the frontier carries the in-index matrix on 32-bit words (GeoN32, dev_matrix.hpp: MXS_*); CMB_MATRIX64=1
+                    // keeps the reference's 64-bit words (GeoN), as does a batch one of whose phases did not fit the small matrix
+                    const bool small32 = !b->wide && b->k <= MXS_MAX_ED && !b->noSmallMatrix && !getenv("CMB_MATRIX64");
                     if (b->geoX)
                         hipLaunchKernelGGL(k_bfs_start<GeoX>, dim3(std::min<uint32_t>((nDfs + 255) / 256, BFS_GRID)), dim3(256), 0, s,
                                            ix->d, b->stratW.p, B, b->dfs.p, nDfs, b->offs.p, b->gw, b->G.p, b->partsW.p, q);
                     else if (b->wide)
                         hipLaunchKernelGGL(k_bfs_start<GeoW>, dim3(std::min<uint32_t>((nDfs + 255) / 256, BFS_GRID)), dim3(256), 0, s,
                                            ix->d, b->stratW.p, B, b->dfs.p, nDfs, b->offs.p, b->gw, b->G.p, b->partsW.p, q);
+                    else if (small32)
+                        hipLaunchKernelGGL(k_bfs_start<GeoN32>, dim3(std::min<uint32_t>((nDfs + 255) / 256, BFS_GRID)), dim3(256), 0, s,
+                                           ix->d, b->strat.p, B, b->dfs.p, nDfs, b->offs.p, b->gw, b->G.p, b->parts.p, q);
                     else
                         hipLaunchKernelGGL(k_bfs_start<GeoN>, dim3(std::min<uint32_t>((nDfs + 255) / 256, BFS_GRID)), dim3(256), 0, s,
                                        ix->d, b->strat.p, B, b->dfs.p, nDfs, b->offs.p, b->gw, b->G.p, b->parts.p, q);
@@ -1233,6 +1236,9 @@ static int batchRunOne(cmb_batch* b) {
                             else if (b->wide)
                                 hipLaunchKernelGGL(k_bfs_pass<GeoW>, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->stratW.p, B,
                                                    pass, b->offs.p, b->gw, b->G.p, b->partsW.p, q);
+                            else if (small32)
+                                hipLaunchKernelGGL(k_bfs_pass<GeoN32>, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->strat.p, B,
+                                                   pass, b->offs.p, b->gw, b->G.p, b->parts.p, q);
                             else
                                 hipLaunchKernelGGL(k_bfs_pass<GeoN>, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->strat.p, B,
                                                pass, b->offs.p, b->gw, b->G.p, b->parts.p, q);
@@ -1255,6 +1261,13 @@ static int batchRunOne(cmb_batch* b) {
                         for (uint32_t p2 = 0; p2 <= pass; p2++)
                             fprintf(stderr, "  pass %u: %u nodes, %u events\n", p2, hc[p2], hc[maxPass + 2 + p2]);
                     hipLaunchKernelGGL(k_bfs_finish, dim3(1), dim3(256), 0, s, B, q);
+                    if (hcnt[3] & FLAG_NARROW_MATRIX) { // (a first column wider than the small matrix holds: once more on the reference's words)
+                        if (verbose) fprintf(stderr, "[bfs] a phase did not fit the 32-bit in-index matrix: re-running on 64-bit words\n");
+                        b->noSmallMatrix = true;
+                        HIPCHK(hipStreamSynchronize(s));
+                        tm.end("k_dfs");
+                        continue;
+                    }
                     if (hcnt[3] & (FLAG_BFS_Q | FLAG_BFS_EV | FLAG_BFS_F | FLAG_BFS_CTX | FLAG_BFS_ARENA)) {
                         // a pool was too small: grow what was asked for (at least x2) and run the search again
                         // (an attempt only shows the demand up to the pass that overflowed: beyond 7 errors, where the first guesses are far
@@ -1281,9 +1294,9 @@ static int batchRunOne(cmb_batch* b) {
                         if (b->bfsQ[j].n < 2 * b->bfsQCap) b->bfsQ[j].alloc(2 * b->bfsQCap);
                     const size_t cntWords = (size_t)maxPass + 2;
                     if (b->bfsCnt.n < cntWords) b->bfsCnt.alloc(cntWords);
-                    if (b->bfsBlockCnt.n < (size_t)BFS_GRID * 4) b->bfsBlockCnt.alloc((size_t)BFS_GRID * 4);
+                    if (b->bfsBlockCnt.n < (size_t)BFS_GRID_CNT * 4) b->bfsBlockCnt.alloc((size_t)BFS_GRID_CNT * 4);
                     HIPCHK(hipMemsetAsync(b->bfsCnt.p, 0, cntWords * sizeof(uint32_t), s));
-                    HIPCHK(hipMemsetAsync(b->bfsBlockCnt.p, 0, (size_t)BFS_GRID * 4 * sizeof(unsigned long long), s));
+                    HIPCHK(hipMemsetAsync(b->bfsBlockCnt.p, 0, (size_t)BFS_GRID_CNT * 4 * sizeof(unsigned long long), s));
                     HbfsBufs H{};
                     H.Q[0] = b->bfsQ[0].p;
                     H.Q[1] = b->bfsQ[1].p;

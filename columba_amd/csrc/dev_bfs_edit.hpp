@@ -51,16 +51,17 @@ __host__ __device__ inline uint32_t ctxMblkFor(uint32_t maxLen) { return maxLen 
 constexpr uint32_t F_U4 = 2;      // uint4 per F record: {ranges} {depth | c << 16, parent, reported, -}
 // (all blocks of a pass should be resident together — 3 blocks of 256 threads per CU at ~160 VGPRs — or the event
 // blocks, which come last in the grid, only start when expansion blocks have finished)
-constexpr uint32_t BFS_CHAIN = 4;     // expansions a lane makes in a row while each yields exactly one plain node
-constexpr uint32_t BFS_GRID = 1024;   // MOST blocks that expand the frontier (grid-stride); sizes the per-block counters
+constexpr uint32_t BFS_CHAIN = 5;     // expansions a lane makes in a row while each yields exactly one plain node (4 before the chain
+                                      // could cross the 8-row blocks of the small matrix: 57.2 -> 55.8 ms)
+constexpr uint32_t BFS_GRID = 1024;   // blocks of the grid-stride frontier kernels without an event half (k_hbfs, k_naive_pass, ...)
+constexpr uint32_t BFS_GRID_CNT = 2048; // MOST blocks that expand the frontier in k_bfs_pass (CMB_BFS_GRID); sizes the per-block counters
 constexpr uint32_t BFS_GRID_X = 896;  // default: expanding blocks (k_bfs_pass runs four 256-thread blocks per CU) ...
 constexpr uint32_t BFS_GRID_EV = 128; // ... and blocks that handle the events of the same pass
-constexpr uint32_t BFS_GRID_X_WALK = 384; // bfsExpandWalk (64 KB of LDS per block: two blocks per CU, all of a pass resident together)
 
 // (the FLAG_BFS_* bits live in dev_search.hpp with all other bits of the flag word)
 // any of these set by an earlier pass: the frontier is incomplete, later passes do nothing (the host re-runs)
 constexpr uint32_t BFS_STOP = FLAG_BFS_Q | FLAG_BFS_EV | FLAG_BFS_F | FLAG_BFS_CTX | FLAG_BFS_ARENA | FLAG_ITEM_OVERFLOW |
-                              FLAG_FMOCC_OVERFLOW | FLAG_CAPACITY;
+                              FLAG_FMOCC_OVERFLOW | FLAG_CAPACITY | FLAG_NARROW_MATRIX;
 
 // "has an earlier pass stopped the search?" as ONE answer per block: other blocks of the same launch may set the
 // flag word while this one starts, so thread 0 reads it once and the block branches on the LDS copy (a per-thread
@@ -87,10 +88,8 @@ struct BfsBufs {
     uint32_t* nq;    // [pass] number of frontier nodes consumed by pass `pass`
     uint32_t* ne;    // [pass] number of events consumed by pass `pass`
     uint32_t* pool;  // [0] F records, [1] contexts, [2] arena units handed out
-    unsigned long long* blockCnt; // [BFS_GRID][4] per-block counters: nodes, expansions, rows, -
-    // bfsExpandWalk: the node queues are made of chunks of 64 slots; qCnt[j][c] = nodes in chunk c of Q[j]
-    uint32_t* qCnt[2];
-    uint32_t* wcSave; // [wavefront][WALK_SAVE_U32]: the item and F chunks a wavefront carries from pass to pass
+    unsigned long long* blockCnt; // [BFS_GRID_CNT][4] per-block counters: nodes, expansions, rows, -
+    uint32_t narrowWv;            // GeoN32: widest first column (Wv) a phase may have on the small matrix (its DIAG; tests lower it)
 };
 
 #ifdef CMB_BOUNDS
@@ -125,14 +124,10 @@ __device__ unsigned long long g_bfsStats[16];
 // how it is laid out in the records.  FmTraits: the FM-index (four 32-bit bounds in one uint4); the run-length compressed
 // backend brings its own (move_search.hpp: ranges with run indices and a toehold, five uint4).  A pair occupies PAIR_U4
 // uint4 at `stride` apart (1: F records, descendant lists; qCap: the planes of the node queue).
-#ifndef CMB_BFS_WALK
-#define CMB_BFS_WALK 0
-#endif
 struct FmTraits {
     typedef RangePair Pair;
     typedef DfsTask Task;
     static constexpr uint32_t PAIR_U4 = 1;
-    static constexpr bool CHUNKED_Q = CMB_BFS_WALK != 0; // nodes go to chunks of 64 slots with a count each (bfsExpandWalk reads them)
     static __device__ __forceinline__ Pair load(const uint4* p, size_t) {
         const uint4 v = p[0];
         return RangePair{{v.x, v.y}, {v.z, v.w}};
@@ -202,8 +197,21 @@ __device__ __forceinline__ void packStore(uint4* p, size_t stride, const EdPackW
 // 32 cells of 6 bits (k = 8 ... 10), one more plane per node and one more uint4 per event.
 // The in-index matrix of a geometry: the reference's 64-bit matrix (32-row blocks: up to 10 errors), or — GeoX, 11 ... 13 errors — the
 // 64-bit matrix with 16-row blocks that stands in for the reference's 64- AND 128-bit matrices (dev_matrix.hpp: MXN_*).
+// What a geometry says about its matrix: the word type W of a row's state (HP, HN; the rightmost active column is a one-bit mask of that
+// type, kept in records as its bit index), rows per block, left margin and diagonal offset, and CTX_BLOCK / CTX_LEFT: the blocks and the
+// margin of the 64-bit MATCH WORDS its contexts hold (`mword`: the match word of a row from its context block's word).
 struct MxRef64 {
-    static constexpr uint32_t BLOCK = MX_BLOCK, LEFT = MX_LEFT, DIAG = MX_DIAG;
+    typedef uint64_t W;
+    static constexpr uint32_t BLOCK = MX_BLOCK, LEFT = MX_LEFT, DIAG = MX_DIAG, CTX_BLOCK = MX_BLOCK, CTX_LEFT = MX_LEFT;
+    static constexpr bool NARROW_FALLBACK = false;
+    static __device__ __forceinline__ W mword(uint64_t M, uint32_t) { return M; }
+    static __device__ __forceinline__ W racBit(uint32_t idx) { return 1ull << idx; }
+    static __device__ __forceinline__ uint32_t racIdx(W rac) { return (uint32_t)__ffsll((unsigned long long)rac) - 1u; }
+    static __device__ __forceinline__ uint4 packRow(W HP, W HN) { return make_uint4((uint32_t)HP, (uint32_t)(HP >> 32), (uint32_t)HN, (uint32_t)(HN >> 32)); }
+    static __device__ __forceinline__ void unpackRow(const uint4& v, W& HP, W& HN) {
+        HP = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        HN = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    }
     static __device__ __forceinline__ bool row(const MatGeom& g, uint32_t i, uint64_t M, uint64_t& HP, uint64_t& HN, uint64_t& D0, uint64_t& RAC,
                                                uint32_t& sc) {
         return computeRow(g, i, M, HP, HN, D0, RAC, sc);
@@ -212,7 +220,17 @@ struct MxRef64 {
     static __device__ __forceinline__ bool ovgl(const MatGeom& g, uint32_t i, uint64_t HN) { return onlyVerticalGapsLeft(g, i, HN); }
 };
 struct MxNarrow {
-    static constexpr uint32_t BLOCK = MXN_BLOCK, LEFT = MXN_LEFT, DIAG = MXN_DIAG;
+    typedef uint64_t W;
+    static constexpr uint32_t BLOCK = MXN_BLOCK, LEFT = MXN_LEFT, DIAG = MXN_DIAG, CTX_BLOCK = MXN_BLOCK, CTX_LEFT = MXN_LEFT;
+    static constexpr bool NARROW_FALLBACK = false;
+    static __device__ __forceinline__ W mword(uint64_t M, uint32_t) { return M; }
+    static __device__ __forceinline__ W racBit(uint32_t idx) { return 1ull << idx; }
+    static __device__ __forceinline__ uint32_t racIdx(W rac) { return (uint32_t)__ffsll((unsigned long long)rac) - 1u; }
+    static __device__ __forceinline__ uint4 packRow(W HP, W HN) { return make_uint4((uint32_t)HP, (uint32_t)(HP >> 32), (uint32_t)HN, (uint32_t)(HN >> 32)); }
+    static __device__ __forceinline__ void unpackRow(const uint4& v, W& HP, W& HN) {
+        HP = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        HN = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    }
     static __device__ __forceinline__ bool row(const MatGeom& g, uint32_t i, uint64_t M, uint64_t& HP, uint64_t& HN, uint64_t& D0, uint64_t& RAC,
                                                uint32_t& sc) {
         return computeRowWide<BLOCK, DIAG>(g, i, M, HP, HN, D0, RAC, sc); // (the walk to the rightmost active column spans up to 39 columns)
@@ -224,7 +242,32 @@ struct MxNarrow {
         return onlyVerticalGapsLeftAs<BLOCK, DIAG>(g, i, HN, g.maxED <= MX_MAX_ED ? 64u : 128u);
     }
 };
+// the in-index matrix up to 7 errors on 32-bit words and 8-row blocks (dev_matrix.hpp: MXS_*): half the instructions of a matrix row; the
+// contexts keep the 64-bit match words of 32-row blocks, a lane keeps walking its chain across the 8-row blocks inside them
+struct MxSmall32 {
+    typedef uint32_t W;
+    static constexpr uint32_t BLOCK = MXS_BLOCK, LEFT = MXS_LEFT, DIAG = MXS_DIAG, CTX_BLOCK = MX_BLOCK, CTX_LEFT = MX_LEFT;
+    static constexpr bool NARROW_FALLBACK = true; // (a phase with Wv > DIAG: FLAG_NARROW_MATRIX, the host re-runs on GeoN)
+    static __device__ __forceinline__ W mword(uint64_t M, uint32_t i) { return matchWordSmall(M, i); }
+    static __device__ __forceinline__ W racBit(uint32_t idx) { return 1u << idx; }
+    static __device__ __forceinline__ uint32_t racIdx(W rac) { return 31u - (uint32_t)__clz((int)rac); }
+    static __device__ __forceinline__ uint4 packRow(W HP, W HN) { return make_uint4(HP, HN, 0u, 0u); }
+    static __device__ __forceinline__ void unpackRow(const uint4& v, W& HP, W& HN) {
+        HP = v.x;
+        HN = v.y;
+    }
+    static __device__ __forceinline__ bool row(const MatGeom& g, uint32_t i, W M, W& HP, W& HN, W& D0, W& RAC, uint32_t& sc) {
+        return computeRow<BLOCK, DIAG>(g, i, M, HP, HN, D0, RAC, sc);
+    }
+    static __device__ __forceinline__ uint32_t cell(uint32_t i, uint32_t j, W HP, W HN, uint32_t sc) { return cellAt<BLOCK, DIAG>(i, j, HP, HN, sc); }
+    static __device__ __forceinline__ bool ovgl(const MatGeom& g, uint32_t i, W HN) { return onlyVerticalGapsLeftAs<BLOCK, DIAG>(g, i, HN, 64u); }
+};
 struct GeoN : MxRef64 {
+    static constexpr int MP = MAXP;
+    typedef EdPack Pack;
+    static constexpr uint32_t CELLS = 24, PK_U4 = 1, ED_MAX = 31;
+};
+struct GeoN32 : MxSmall32 { // the common path since round 4: GeoN's records (the row state takes two words of its plane), the small matrix
     static constexpr int MP = MAXP;
     typedef EdPack Pack;
     static constexpr uint32_t CELLS = 24, PK_U4 = 1, ED_MAX = 31;
@@ -262,30 +305,6 @@ __device__ __forceinline__ uint32_t blockAppend(uint32_t* counter, uint32_t n, u
     return off + pre;
 }
 
-// the same into a queue made of chunks of 64 slots with a count each (the node queue that bfsExpandWalk reads): the block takes whole
-// chunks and writes their counts
-__device__ __forceinline__ uint32_t blockAppendChunked(uint32_t* counter, uint32_t n, uint32_t* sh, uint32_t& blockTotal, uint32_t* qCnt,
-                                                       uint32_t cap) {
-    uint32_t wTotal;
-    const uint32_t pre = waveExclusiveScan(n, wTotal);
-    const uint32_t w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63u) == 0) sh[w] = wTotal;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t t = sh[0] + sh[1] + sh[2] + sh[3];
-        sh[4] = t ? atomicAdd(counter, (t + 63u) & ~63u) : 0u;
-    }
-    __syncthreads();
-    uint32_t off = sh[4];
-    blockTotal = sh[0] + sh[1] + sh[2] + sh[3];
-    if (threadIdx.x < 4 && threadIdx.x * 64u < blockTotal && off + threadIdx.x * 64u < cap)
-        qCnt[(off >> 6) + threadIdx.x] = min(64u, blockTotal - threadIdx.x * 64u);
-    if (w > 0) off += sh[0];
-    if (w > 1) off += sh[1];
-    if (w > 2) off += sh[2];
-    __syncthreads(); // sh may be reused by the next call
-    return off + pre;
-}
 
 // Four appends at once: the four wave scans first, ONE barrier, four lanes issue the four atomics side by side
 // (one atomic round trip per tile instead of four), one more barrier.  sh = 4 x 5 words.
@@ -353,72 +372,71 @@ __device__ __forceinline__ void takeRanks(const DevIndex& ix, int mode, const Ra
 //   otherwise                                  -> node of the next frontier
 //
 // The kernel waits for scattered memory, so what it can keep in flight is set by its registers (measured: 2 / 3
-// wavefronts per SIMD = 99 / 71 ms per step).  Hence a lane never HOLDS the four children: it classifies them
-// (evalChild<false>: 4 bits per child), the block allocates the queue slots, and the children that leave are
-// computed again (evalChild<true>, ~50 VALU instructions each) straight into their records.
+// wavefronts per SIMD = 99 / 71 ms per step; a fifth wavefront — 96 registers, round 4 — bought nothing more).  Hence a lane
+// never HOLDS the four children: it classifies them (evalChildFlat: 4 bits per child, keeping the state of the last one that
+// leaves a record — THE child of a lane that walks on), the block allocates the queue slots, and the children that leave are
+// computed again straight into their records.
 enum : uint32_t { KIND_NONE = 0, KIND_NODE = 1, KIND_EVENT = 2, KIND_ITEMS = 3 };
 struct ExpandCtx { // what the expansions of one phase share (from the context's hot word)
     MatGeom g;
     uint32_t clSize, itMode, itStart, switchPoint;
 };
-struct ChildState {
+template <typename W = uint64_t>
+struct ChildStateT {
     RangePair r;
-    uint64_t HP, HN, RAC;
+    W HP, HN, RAC;
     uint32_t sc, aux; // aux: final-column distance of the child (needF) or in-text start difference (KIND_ITEMS)
 };
-// kind of a (non-empty) child at row `row1` | needF << 2 | capacity problem << 3, and its state: the child's matrix row (computeRow),
-// branchAndBound (:529-561), the in-text switch (:340-375, :516)
+typedef ChildStateT<> ChildState;
+// Kind of child `ch` of `parent` at row `row1` | needF << 2 | capacity problem << 3, and its state: the child's matrix row (computeRow),
+// branchAndBound (:529-561), the in-text switch (:340-375, :516).  Written WITHOUT nested control flow (round 4): as a nest of conditions —
+// final column or not, valid or not, gaps, in-text switch, extension mode — a child cost a wavefront ~205 instructions of which ~115
+// were the exec-mask bookkeeping of the nest.  Here the final-column distance, the gaps predicate and the in-text start difference are
+// computed for every child (a few vector instructions each on the small matrix) and the outcome is selected; what is left of the control
+// flow is "does the child exist" and the walk to the rightmost active column of a row whose RAC column missed: ~165 instructions per
+// child, 3 200 instead of 3 800 per tile.  (The time did not follow: see profiles/r04_frontier_experiments.txt.)  `out` is written only
+// for a child that leaves a record (kind != KIND_NONE); `width` is the child's range width (in-text items).
 template <class Geo = GeoN>
-__device__ __forceinline__ uint32_t evalRow(const RangePair& child, const ExpandCtx& e, uint32_t row1, bool inFC, uint64_t M, uint64_t pHP,
-                                            uint64_t pHN, uint64_t pRAC, uint32_t score, ChildState& out) {
-    uint64_t HP = pHP, HN = pHN, RAC = pRAC, D0;
+__device__ __forceinline__ uint32_t evalChildFlat(const DevIndex& ix, int md, const RangePair& parent, uint32_t ch, const uint32_t Rb[4],
+                                                  const uint32_t Re[4], uint32_t db, uint32_t de, const ExpandCtx& e, uint32_t row1, bool inFC,
+                                                  typename Geo::W M, typename Geo::W pHP, typename Geo::W pHN, typename Geo::W pRAC,
+                                                  uint32_t score, bool& nonEmpty, ChildStateT<typename Geo::W>& out, uint32_t& width) {
+    typedef typename Geo::W W;
+    RangePair child;
+    nonEmpty = childFromRanksFlat(ix, md, parent, ch, Rb, Re, db, de, child);
+    width = 0;
+    if (!nonEmpty) return KIND_NONE;
+    W HP = pHP, HN = pHN, RAC = pRAC, D0;
     uint32_t sc = score;
     constexpr uint32_t EDMAX = Geo::ED_MAX;
     const bool valid = Geo::row(e.g, row1, M, HP, HN, D0, RAC, sc);
-    if (!valid && !inFC) return KIND_NONE; // pruned when popped (branchAndBound returns true, :560)
-    uint32_t res = KIND_NODE, aux = 0;
-    if (inFC) {
-        const uint32_t ed = Geo::cell(row1, e.g.n - 1, HP, HN, sc);
-        aux = min(ed, EDMAX);
-        res |= 4u;
-        if (ed > EDMAX) res |= 8u;
-        if (!valid || Geo::ovgl(e.g, row1, HN)) res = (res & ~3u) | KIND_EVENT;
+    const uint32_t ed = Geo::cell(row1, e.g.n - 1, HP, HN, sc); // (meaningful in the final column only)
+    const bool gaps = Geo::ovgl(e.g, row1, HN);
+    const bool live = valid || inFC;                            // else pruned when popped (branchAndBound returns true, :560)
+    const bool event = inFC && (!valid || gaps);                // goDeeper
+    width = child.sa.e - child.sa.b;
+    const bool items = live && !event && width <= e.switchPoint && e.itMode != 0; // goToInTextVerificationEdit (:340-375)
+    const uint32_t col = e.g.firstColumn(row1);
+    const uint32_t startDiff = e.itStart - (e.itMode == 2 ? col + Geo::cell(row1, col, HP, HN, sc) : 0u);
+    uint32_t res = items ? (uint32_t)KIND_ITEMS : event ? (uint32_t)KIND_EVENT : (uint32_t)KIND_NODE;
+    res |= (inFC && !items) ? 4u : 0u;    // (a child that leaves the index needs no F record)
+    res |= (inFC && ed > EDMAX) ? 8u : 0u;
+    res = live ? res : (uint32_t)KIND_NONE;
+    if (live) {
+        out.r = child;
+        out.HP = HP;
+        out.HN = HN;
+        out.RAC = RAC;
+        out.sc = sc;
+        out.aux = items ? startDiff : inFC ? min(ed, EDMAX) : 0u;
     }
-    if ((res & 3u) == KIND_NODE && child.sa.width() <= e.switchPoint && e.itMode != 0) { // goToInTextVerificationEdit (:340-375)
-        uint32_t startDiff = e.itStart;
-        if (e.itMode == 2) {
-            const uint32_t col = e.g.firstColumn(row1);
-            startDiff -= col + Geo::cell(row1, col, HP, HN, sc);
-        }
-        aux = startDiff;
-        res = (res & 8u) | KIND_ITEMS; // (a child that leaves the index needs no F record)
-    }
-    out.r = child;
-    out.HP = HP;
-    out.HN = HN;
-    out.RAC = RAC;
-    out.sc = sc;
-    out.aux = aux;
-    return res;
-}
-// kind of child `ch` of `parent` at row `row1` | needF << 2 | capacity problem << 3; FULL: also its state
-template <bool FULL, class Geo = GeoN>
-__device__ __forceinline__ uint32_t evalChild(const DevIndex& ix, int md, const RangePair& parent, uint32_t ch,
-                                              const uint32_t Rb[4], const uint32_t Re[4], uint32_t db, uint32_t de,
-                                              const ExpandCtx& e, uint32_t row1, bool inFC, uint64_t M, uint64_t pHP,
-                                              uint64_t pHN, uint64_t pRAC, uint32_t score, bool& nonEmpty, ChildState& out) {
-    RangePair child;
-    nonEmpty = childFromRanks(ix, md, parent, ch, Rb, Re, db, de, child);
-    if (!nonEmpty) return KIND_NONE;
-    ChildState cs;
-    const uint32_t res = evalRow<Geo>(child, e, row1, inFC, M, pHP, pHN, pRAC, score, cs);
-    if (FULL && (res & 3u) != KIND_NONE) out = cs;
     return res;
 }
 
 template <class Geo = GeoN>
 __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, uint32_t pass, const Queues& q,
                                           uint32_t bid, uint32_t nBlocks) {
+    typedef typename Geo::W W;
     __shared__ uint32_t sh[4][5];
     // per-lane state that is touched once or twice per expansion lives in LDS, [field][lane], not in registers: the
     // four match words of the row block, the eight ranks of the pending expansion, the node's final-column pack
@@ -443,7 +461,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
         RangePair parent{{0, 0}, {0, 0}};
         uint32_t row = 0, score = 0, blk = 0;
         int md = 0;
-        uint64_t pHP = 0, pHN = 0;
+        W pHP = 0, pHN = 0;
         uint32_t pRac = 0; // (RAC is always a single bit: kept as its index)
         ExpandCtx e{};
         e.switchPoint = ix.switchPoint;
@@ -462,7 +480,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
             uint4 rk[4];
             issueRanks(ix, md, parent, rk);
             const uint4* Cx = B.C + (size_t)CMB_IDX(ctx, B.cCap, 1) * B.ctxU4;
-            blk = (row + 1) / Geo::BLOCK;
+            blk = (row + 1) / Geo::CTX_BLOCK;
             const uint4 hot = Cx[CTX_HOT]; // everything the expansion needs of its context, in ONE 16-byte request
             const uint4 mA = Cx[CTX_M + 2 * blk], mB = Cx[CTX_M + 1 + 2 * blk];
             {
@@ -482,8 +500,7 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
             e.g.maxED = (hot.y >> 27) & 15u;
             e.clSize = hot.w >> 23;
             e.itMode = (hot.x >> 25) & 3u; // 0: phase 0 (no switch), 1: start difference fixed, 2: BACKWARD
-            pHP = u64of(n2.x, n2.y);
-            pHN = u64of(n2.z, n2.w);
+            Geo::unpackRow(n2, pHP, pHN);
             pRac = n1.w & 63u;
             ldsM[0][tid] = u64of(mA.x, mA.y);
             ldsM[1][tid] = u64of(mA.z, mA.w);
@@ -521,38 +538,28 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
                 kinds = 0;
                 nIt = 0;
                 uint32_t nOut = 0, nChildren = 0;
+                ChildStateT<W> one{}; // the last child that leaves a record: THE child when the expansion yields exactly one plain node
 #pragma unroll
                 for (uint32_t ch = 1; ch <= 4; ch++) {
                     bool nonEmpty;
-                    ChildState cs;
-                    const uint32_t k4 = evalChild<false, Geo>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, ldsM[ch - 1][tid], pHP,
-                                                         pHN, 1ull << pRac, score, nonEmpty, cs);
+                    uint32_t width;
+                    const uint32_t k4 = evalChildFlat<Geo>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, Geo::mword(ldsM[ch - 1][tid], row1), pHP,
+                                                           pHN, Geo::racBit(pRac), score, nonEmpty, one, width);
                     nChildren += nonEmpty ? 1u : 0u;
-                    if (k4 & 8u) flags |= FLAG_CAPACITY;
-                    if ((k4 & 3u) == KIND_NONE) continue;
+                    flags |= (k4 & 8u) ? (uint32_t)FLAG_CAPACITY : 0u;
                     kinds |= (k4 & 7u) << (4 * (ch - 1));
-                    nOut++;
-                    if ((k4 & 3u) == KIND_ITEMS) { // (its width: the child's range again, a few instructions)
-                        RangePair child;
-                        (void)childFromRanks(ix, md, parent, ch, Rb, Re, db, de, child);
-                        nIt += child.sa.e - child.sa.b;
-                    }
+                    nOut += (k4 & 3u) != KIND_NONE ? 1u : 0u;
+                    nIt += (k4 & 3u) == KIND_ITEMS ? width : 0u;
                 }
                 ldsCnt[0][tid] += nChildren;
-                // exactly one child, a plain node, with rows left in this matrix block: keep walking
+                // exactly one child, a plain node, with rows left in this block of match words: keep walking
                 const bool single = nOut == 1u && (kinds == 0x1u || kinds == 0x10u || kinds == 0x100u || kinds == 0x1000u);
-                if (single && step + 1u < B.chain && (row1 + 1u) / Geo::BLOCK == blk) {
-                    const uint32_t ch = ((31u - (uint32_t)__clz(kinds)) >> 2) + 1u;
-                    const uint64_t M = ch == 1 ? ldsM[0][tid] : ch == 2 ? ldsM[1][tid] : ch == 3 ? ldsM[2][tid] : ldsM[3][tid];
-                    bool nonEmpty;
-                    ChildState one;
-                    (void)evalChild<true, Geo>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, M, pHP, pHN, 1ull << pRac, score,
-                                          nonEmpty, one);
+                if (single && step + 1u < B.chain && (row1 + 1u) / Geo::CTX_BLOCK == blk) {
                     parent = one.r;
                     score = one.sc;
                     pHP = one.HP;
                     pHN = one.HN;
-                    pRac = (uint32_t)__ffsll((unsigned long long)one.RAC) - 1u;
+                    pRac = Geo::racIdx(one.RAC);
                     row = row1;
                     kinds = 0; // (nothing of this expansion is left to append)
                 } else {
@@ -611,9 +618,10 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
                 const uint32_t kd = (kinds >> (4 * (ch - 1))) & 3u;
                 if (kd == KIND_NONE) continue;
                 bool nonEmpty;
-                ChildState cs;
-                (void)evalChild<true, Geo>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, ldsM[ch - 1][tid], pHP, pHN, 1ull << pRac,
-                                      score, nonEmpty, cs);
+                uint32_t width;
+                ChildStateT<W> cs{};
+                (void)evalChildFlat<Geo>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, Geo::mword(ldsM[ch - 1][tid], row1), pHP, pHN,
+                                         Geo::racBit(pRac), score, nonEmpty, cs, width);
                 const bool wantF = (kinds >> (4 * (ch - 1) + 2)) & 1u;
                 const uint4 cr = make_uint4(cs.r.sa.b, cs.r.sa.e, cs.r.rev.b, cs.r.rev.e);
                 uint32_t fc = BFS_NONE;
@@ -626,10 +634,8 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
                 if (kd == KIND_NODE) {
                     const uint32_t o = oNode++;
                     Qo[o] = cr;
-                    Qo[(size_t)qCap + o] = make_uint4(row1 | (cs.sc << 16), ctx, fc,
-                                                      ((uint32_t)__ffsll((unsigned long long)cs.RAC) - 1u) | ((uint32_t)md << 8));
-                    Qo[(size_t)2 * qCap + o] = make_uint4((uint32_t)cs.HP, (uint32_t)(cs.HP >> 32), (uint32_t)cs.HN,
-                                                          (uint32_t)(cs.HN >> 32));
+                    Qo[(size_t)qCap + o] = make_uint4(row1 | (cs.sc << 16), ctx, fc, Geo::racIdx(cs.RAC) | ((uint32_t)md << 8));
+                    Qo[(size_t)2 * qCap + o] = Geo::packRow(cs.HP, cs.HN);
                     if (wantF) {
                         typename Geo::Pack p2 = pack;
                         edPut(p2, cell, cs.aux);
@@ -664,776 +670,6 @@ __device__ __forceinline__ void bfsExpand(const DevIndex& ix, const BfsBufs& B, 
     if (threadIdx.x < 3) {
         const unsigned long long t = shc[0][threadIdx.x] + shc[1][threadIdx.x] + shc[2][threadIdx.x] + shc[3][threadIdx.x];
         if (t) B.blockCnt[(size_t)bid * 4 + threadIdx.x] += t;
-    }
-    if (flags) atomicOr(&q.cnt[3], flags);
-}
-
-// ------------------------------------------------------------------ expand: walking lanes over compacted children (round 4)
-// What bounds bfsExpand above is not the memory system but INSTRUCTION ISSUE (round 4: one round of the kernel costs a wavefront
-// ~20 000 cycles of which ~3 000 are the wait for its loads).  Two things waste issue slots there: of the four children every lane
-// evaluates — child range, matrix row, classification, ~150 instructions each — only 1.7 exist on average (the other ranges are empty, but
-// a wavefront executes the code while ANY lane needs it), and the chain steps run with ever fewer lanes.  Here a wavefront works in rounds
-// of ONE memory round trip, on its own (no block barrier, no same-address atomic in the loop):
-//   parents   every lane holds a node.  Its two rank blocks arrive, the lane computes the four child RANGES (cheap) and puts the
-//             non-empty ones on the wavefront's CHILD LIST in LDS (prefix sum over the lanes: compaction);
-//   children  the list is worked off 64 children at a time, one child per lane: the parent's row state, geometry and match word come
-//             from the parent's LDS slots, the lane computes the child's matrix row and classifies it (evalRow — exactly what
-//             bfsExpand does per child).  1.7 instead of 4 evaluations per expansion, all lanes busy;
-//   walking   the first plain node among the children of a parent CLAIMS the parent's lane (an LDS atomic): it is expanded by that lane
-//             in the next round — no node record, no queue slot, no context fetch, also across the 32-row matrix blocks (the match
-//             words of the new block arrive with the rank blocks).  Its siblings and every other kind of child (final column, event,
-//             in-text items) leave through the queues at once, slots by one prefix sum over the child lanes;
-//   refill    the node a lane takes up when its walk ends WAITS IN LDS: global_load_lds copies the three node planes into the lane's
-//             own slot ([plane][lane], no vector register) a round ahead, so that every lane expands in every round;
-//   queues    input: the node queue is made of CHUNKS of 64 slots with a count each (BfsBufs::qCnt), chunk c belongs to wavefront
-//             c % W — no atomics, no holes to skip.  Output: a wavefront fills a chunk of its own (one atomic per 64 nodes); events
-//             go to small per-wavefront chunks whose unused rest becomes holes (context index 0xFFFFFFFF); in-text items and F
-//             records to per-wavefront chunks that are kept ACROSS the passes (BfsBufs::wcSave; k_bfs_finish turns what is left of
-//             the item chunks into holes);
-//   tail      when a wavefront's input is used up its lanes walk on for a bounded number of rounds only (the emptier the machine, the
-//             longer: a pass of a few thousand nodes finishes whole phases), then write their node out.
-// Per child the semantics are those of bfsExpand line by line (same evalRow, same records, same counters); which lane expands a node,
-// and in which pass, is not part of the result.
-#ifndef CMB_BFS_WALK
-#define CMB_BFS_WALK 0
-#endif
-constexpr uint32_t WALK_CH_EV = 32, WALK_CH_EV_SMALL = 4, WALK_CH_IT = 512, WALK_CH_F = 512;
-constexpr uint32_t WALK_TAIL_MAX = 64;
-constexpr uint32_t WALK_SAVE_U32 = 8; // per wavefront: the item chunk and the F chunk {base, used, size}, two spare words
-
-// 16 bytes per active lane, global -> ldsWaveBase[lane], no vector register in between (global_load_lds_dwordx4).  Inline assembly, not
-// __builtin_amdgcn_global_load_lds: beside the builtin hipcc 7.2 waits for ALL outstanding vector memory operations — the stores of the
-// previous round included — before every LDS read that might alias and before the next such load (three extra round trips per round,
-// measured).  The kernel waits for these loads itself: ONE s_waitcnt vmcnt(0) per round.
-__device__ __forceinline__ void gldsU4(const uint4* src, uint4* ldsWaveBase) {
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_ptr_t)ldsWaveBase);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(src), "s"(dst)
-                 : "memory");
-}
-#define CMB_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory") /* lanes of ONE wavefront talking through LDS */
-
-// The wavefront's output REGION of the chunked node queue: a run of whole chunks (64 slots each) taken with ONE atomic and filled from
-// the front; when it is left — used up, or at the end of the kernel — every chunk of it gets its count in qCnt (64, the rest, or 0: the
-// consumers pass over empty chunks).  One chunk per atomic was too little: 1.8 million atomics per sub-batch on the queue's counter
-// run into the ~90 same-address atomics per microsecond the L2 serves (the frontier kernel spent a third of its time queueing there).
-struct NodeRegion {
-    uint32_t base = 0xFFFFFFFFu, used = 0u, size = 0u;
-    __device__ __forceinline__ void retire(uint32_t* qCnt) {
-        const uint32_t lane = threadIdx.x & 63u;
-        if (base != 0xFFFFFFFFu)
-            for (uint32_t j = lane; j * 64u < size; j += 64u) qCnt[(base >> 6) + j] = used > j * 64u ? min(used - j * 64u, 64u) : 0u;
-        base = 0xFFFFFFFFu;
-        used = size = 0u;
-    }
-    // first slot for the wavefront's `total` nodes (contiguous); 0xFFFFFFFF: the queue is full.  `slots`: size of a new region (x 64)
-    __device__ __forceinline__ uint32_t alloc(uint32_t* counter, uint32_t cap, uint32_t total, uint32_t slots, uint32_t* qCnt, bool& overflow) {
-        if (used + total > size) {
-            retire(qCnt);
-            const uint32_t want = max(slots, (total + 63u) & ~63u);
-            uint32_t b = 0;
-            if ((threadIdx.x & 63u) == 0) b = atomicAdd(counter, want);
-            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-            if (b > cap || want > cap - b) {
-                overflow = true;
-                return 0xFFFFFFFFu;
-            }
-            base = b;
-            size = want;
-            used = 0;
-        }
-        const uint32_t o = base + used;
-        used += total;
-        return o;
-    }
-};
-__device__ __forceinline__ uint32_t nodeRegionSlots(uint32_t nIn, uint32_t W) { // what a wavefront is likely to append in a pass, 64 ... 512
-    return min(512u, max(64u, ((nIn / max(W, 1u)) + 63u) & ~63u));
-}
-
-template <class Geo = GeoN>
-__device__ __forceinline__ void bfsExpandWalk(const DevIndex& ix, const BfsBufs& B, uint32_t pass, const Queues& q,
-                                              uint32_t bid, uint32_t nBlocks) {
-    constexpr uint32_t PK = Geo::PK_U4, EV_U4 = 1u + Geo::PK_U4;
-    __shared__ uint4 ldsNext[3][256];  // the node that waits for its lane: {ranges} {meta} {HP, HN}
-    __shared__ uint4 ldsM4[2][256];    // match words of the lane's row block: {A, C} {G, T}
-    __shared__ uint4 ldsPk[PK][256];   // final-column pack of a fresh node that already lies in the final column
-    __shared__ uint4 pA[2][256];       // row state {HP, HN} of the lane's node, by round parity (children read, the heir writes)
-    __shared__ uint2 pB[2][256];       // {row | score << 16, RAC bit | mode << 8}, likewise
-    __shared__ uint4 pG[256];          // hot word of the node's context
-    __shared__ uint4 pF[256];          // {context, F record of the nearest final-column node above, has a pack, -}
-    __shared__ uint4 aR[256];          // ranges of the child the lane walks on with
-    __shared__ uint32_t k4[256];       // bit 0: a child has claimed the lane
-    __shared__ uint4 clR[4][256];      // child list of the wavefront: ranges ...
-    __shared__ uint8_t clT[4][256];    // ... and parent lane | (character - 1) << 6
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u, wv = tid >> 6;
-    const uint32_t nIn = min(B.nq[pass], B.qCap);
-    const uint4* __restrict__ Qi = B.Q[pass & 1u];
-    uint4* __restrict__ Qo = B.Q[(pass + 1u) & 1u];
-    uint4* __restrict__ Eo = B.Ev[(pass + 1u) & 1u];
-    const uint32_t* __restrict__ cntIn = B.qCnt[pass & 1u];
-    uint32_t* __restrict__ cntOut = B.qCnt[(pass + 1u) & 1u];
-    const uint32_t qCap = B.qCap;
-    // input: chunk c of the node queue belongs to wavefront c % W
-    const uint32_t W = nBlocks * 4u, wId = bid * 4u + wv, nChunks = (nIn + 63u) >> 6;
-    // wave-uniform: entries [cUsed, cCnt) of `chunk` are left; nCnt, n2: the counts of chunk + W and of chunk + 2 W (n2 is fetched with
-    // every round's memory step, so that a count is there before its chunk becomes the next one)
-    uint32_t chunk = wId, cUsed = 0u, cCnt = 0u, nCnt = 0u, n2 = 0u;
-    const uint32_t cntLast = nChunks ? nChunks - 1u : 0u;
-    {
-        const uint32_t c0 = cntIn[min(chunk, cntLast)], c1 = cntIn[min(chunk + W, cntLast)], c2 = cntIn[min(chunk + 2u * W, cntLast)];
-        cCnt = chunk < nChunks ? (uint32_t)__builtin_amdgcn_readfirstlane((int)min(c0, 64u)) : 0u;
-        nCnt = chunk + W < nChunks ? (uint32_t)__builtin_amdgcn_readfirstlane((int)min(c1, 64u)) : 0u;
-        n2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(c2, 64u));
-    }
-    // rounds a lane may still walk once the wavefront's input is used up
-    uint32_t tail = B.chain;
-    if (nIn < W * 64u) tail = min(WALK_TAIL_MAX, max(B.chain, (W * 64u / max(nIn, 1u)) * B.chain));
-    tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail);
-    const uint32_t chEv = nIn < 262144u ? WALK_CH_EV_SMALL : WALK_CH_EV;
-    // per-lane state of a parent
-    bool have = false, nx = false, fresh = false, needM = false;
-    RangePair parent{{0, 0}, {0, 0}};
-    uint32_t row = 0, ctx = 0, fcP = BFS_NONE, nxIdx = 0, curIdx = 0, blk = 0, hotY = 0, clSize = 0;
-    int md = 0;
-    uint32_t cntChildren = 0, cntExp = 0, flags = 0;
-    uint32_t cur = 0; // round parity (wave-uniform)
-    NodeRegion ncNode;
-    const uint32_t regionSlots = nodeRegionSlots(nIn, W);
-    WaveChunk wcEv, wcIt, wcF;
-    uint32_t* save = B.wcSave + (size_t)wId * WALK_SAVE_U32;
-    { // the item and F chunks of the wavefront's previous pass (zeroed before the search)
-        wcIt.base = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[0]);
-        wcIt.used = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[1]);
-        wcIt.size = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[2]);
-        wcF.base = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[4]);
-        wcF.used = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[5]);
-        wcF.size = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[6]);
-    }
-#ifdef CMB_BFS_STATS
-    // diagnostic build only (tools/walk_stats.sh): [0] rounds, [1] lanes that expand, [2] cycles in the memory wait, [3] cycles in the
-    // loop, [4] turns of the child loop, [5] lanes that walk on, [6] nodes taken up, [7] children, [8..13] cycles: take + request | issue
-    // of the memory step | parents | children | parents again | -
-    unsigned long long pf[16] = {};
-    const long long pfT0 = clock64();
-    long long pfT = pfT0;
-#define PF_LAP(j)                                        \
-    {                                                    \
-        const long long now_ = clock64();                \
-        if ((tid & 63u) == 0) pf[j] += (unsigned long long)(now_ - pfT); \
-        pfT = now_;                                      \
-    }
-#define PF_ADD(j, x) pf[j] += (x);
-#else
-#define PF_LAP(j)
-#define PF_ADD(j, x)
-#endif
-    auto holeEv = [&](uint32_t o) { Eo[(size_t)EV_U4 * o] = make_uint4(BFS_NONE, 0u, 0u, 0u); };
-    auto holeIt = [&](uint32_t o) { q.items[o] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u); };
-    auto holeF = [&](uint32_t) {}; // (the pool of F records is never scanned)
-    for (;;) {
-        PF_LAP(13)
-        PF_ADD(6, (!have && nx) ? 1u : 0u)
-        // ---- a lane without a node takes up the one that waits in its slot (it arrived with the previous round's memory step)
-        if (!have && nx) {
-            const uint4 n0 = ldsNext[0][tid], n1 = ldsNext[1][tid], n2 = ldsNext[2][tid];
-            nx = false;
-            have = true;
-            fresh = true;
-            parent = RangePair{{n0.x, n0.y}, {n0.z, n0.w}};
-            row = n1.x & 0xFFFFu;
-            ctx = n1.y;
-            fcP = n1.z;
-            md = (int)((n1.w >> 8) & 3u);
-            blk = (row + 1u) / Geo::BLOCK;
-            curIdx = nxIdx;
-            pA[cur][tid] = n2;
-            pB[cur][tid] = make_uint2(n1.x, n1.w & 0x3FFu);
-        }
-        CMB_LDS_SYNC(); // (the slot is read before it is requested again)
-        // ---- ask for the next one: the lanes without a waiting node share out the next entries of the wavefront's chunks
-        uint32_t n2Load;
-        {
-            const bool want = !nx && chunk < nChunks;
-            const unsigned long long req = __ballot(want);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(req >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)req, 0u));
-            const uint32_t e = cUsed + rank;
-            uint32_t idx = 0xFFFFFFFFu;
-            if (e < cCnt) idx = chunk * 64u + e;
-            else if (e - cCnt < nCnt) idx = (chunk + W) * 64u + (e - cCnt);
-            if (want && idx != 0xFFFFFFFFu) {
-                gldsU4(Qi + idx, &ldsNext[0][wbase]);
-                gldsU4(Qi + (size_t)qCap + idx, &ldsNext[1][wbase]);
-                gldsU4(Qi + (size_t)2 * qCap + idx, &ldsNext[2][wbase]);
-                nx = true;
-                nxIdx = idx;
-            }
-            cUsed += (uint32_t)__popcll(req);
-            if (cUsed >= cCnt && chunk < nChunks) { // this chunk is handed out: on to the next (the counts are here already)
-                cUsed = min(cUsed - cCnt, nCnt);
-                chunk += W;
-                cCnt = nCnt;
-                nCnt = chunk + W < nChunks ? n2 : 0u;
-            }
-            n2Load = cntIn[min(chunk + 2u * W, cntLast)]; // (arrives with this round's memory step)
-        }
-        const bool exhausted = chunk >= nChunks; // (wave-uniform)
-        if (__ballot(have || nx) == 0ull && exhausted) break;
-        const bool walkOk = !exhausted || tail != 0u;
-        if (exhausted && tail) tail--;
-        PF_LAP(8)
-        // ---- the memory step of the round: rank blocks of every lane that holds a node; hot word, match words and final-column
-        // pack of a fresh node; match words of a walk that enters a new row block
-        uint4 rk[4];
-        uint4 hotN = make_uint4(0, 0, 0, 0);
-        const bool hasPack = have && fresh && fcP != BFS_NONE; // (only a fresh node can lie in the final column: such nodes are not walked on with)
-        if (have) {
-            issueRanks(ix, md, parent, rk);
-            if (fresh || needM) {
-                const uint4* Cx = B.C + (size_t)CMB_IDX(ctx, B.cCap, 1) * B.ctxU4;
-                if (fresh) hotN = Cx[CTX_HOT];
-                gldsU4(Cx + CTX_M + 2u * blk, &ldsM4[0][wbase]);
-                gldsU4(Cx + CTX_M + 1u + 2u * blk, &ldsM4[1][wbase]);
-                if (hasPack) {
-#pragma unroll
-                    for (uint32_t u = 0; u < PK; u++) gldsU4(Qi + (size_t)(3u + u) * qCap + curIdx, &ldsPk[u][wbase]);
-                }
-            }
-        }
-        PF_LAP(9)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PF_LAP(2)
-        PF_ADD(0, (tid & 63u) == 0 ? 1u : 0u)
-        PF_ADD(1, have ? 1u : 0u)
-        n2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(n2Load, 64u));
-        // ---- parents: the four child ranges, the non-empty ones onto the wavefront's child list
-        uint32_t nKids = 0;
-        RangePair kid[4];
-        uint32_t kidMask = 0;
-        if (have) {
-            if (fresh) {
-                pG[tid] = hotN;
-                pF[tid] = make_uint4(ctx, fcP, hasPack ? 1u : 0u, 0u);
-                hotY = hotN.y;
-                clSize = hotN.w >> 23;
-            }
-            fresh = false;
-            needM = false;
-            k4[tid] = 0u;
-            cntExp++;
-            uint32_t Rb[4], Re[4], db, de;
-            takeRanks(ix, md, parent, rk, Rb, Re, db, de);
-#pragma unroll
-            for (uint32_t ch = 1; ch <= 4; ch++) {
-                const bool ne = childFromRanks(ix, md, parent, ch, Rb, Re, db, de, kid[ch - 1]);
-                kidMask |= (ne ? 1u : 0u) << (ch - 1);
-            }
-            nKids = (uint32_t)__popc(kidMask);
-            cntChildren += nKids;
-            { // (a row beyond the matrix)
-                const uint32_t m = (hotY >> 9) & 0x1FFu, sfc = ((hotY >> 23) & 15u) + ((hotY >> 18) & 31u) + 1u;
-                if (row + 1u >= m - sfc && clSize + row + 1u - m >= Geo::CELLS) flags |= FLAG_CAPACITY;
-            }
-        }
-        const uint32_t incl = waveInclusiveScanDpp(nKids);
-        const uint32_t T = waveLastLane(incl); // children of the wavefront in this round
-        if (have) {
-            uint32_t o = incl - nKids;
-#pragma unroll
-            for (uint32_t c = 0; c < 4; c++) {
-                if ((kidMask >> c) & 1u) {
-                    clR[wv][o] = make_uint4(kid[c].sa.b, kid[c].sa.e, kid[c].rev.b, kid[c].rev.e);
-                    clT[wv][o] = (uint8_t)(lane | (c << 6));
-                    o++;
-                }
-            }
-        }
-        CMB_LDS_SYNC();
-        PF_LAP(10)
-        PF_ADD(7, nKids)
-        // ---- children: one per lane, 64 at a time
-        for (uint32_t g0 = 0; g0 < T; g0 += 64u) {
-            PF_ADD(4, (tid & 63u) == 0 ? 1u : 0u)
-            const uint32_t g = g0 + lane;
-            uint32_t res = KIND_NONE, par = tid, ch = 1, row1 = 0, mdC = 0;
-            ChildState cs{};
-            uint4 hg = make_uint4(0, 0, 0, 0);
-            if (g < T) {
-                const uint32_t t = clT[wv][g];
-                par = wbase + (t & 63u);
-                ch = (t >> 6) + 1u;
-                const uint4 r = clR[wv][g];
-                const uint4 a = pA[cur][par];
-                const uint2 b = pB[cur][par];
-                hg = pG[par];
-                const uint64_t M = reinterpret_cast<const uint64_t*>(&ldsM4[(ch - 1u) >> 1][par])[(ch - 1u) & 1u];
-                ExpandCtx e{};
-                e.switchPoint = ix.switchPoint;
-                e.itStart = hg.z;
-                e.g.n = hg.y & 0x1FFu;
-                e.g.m = (hg.y >> 9) & 0x1FFu;
-                e.g.Wv = (hg.y >> 18) & 31u;
-                e.g.Wh = (hg.y >> 23) & 15u;
-                e.g.maxED = (hg.y >> 27) & 15u;
-                e.clSize = hg.w >> 23;
-                e.itMode = (hg.x >> 25) & 3u; // 0: phase 0 (no switch), 1: start difference fixed, 2: BACKWARD
-                row1 = (b.x & 0xFFFFu) + 1u;
-                mdC = (b.y >> 8) & 3u;
-                const bool inFC = e.g.inFinalColumn(row1);
-                res = evalRow<Geo>(RangePair{{r.x, r.y}, {r.z, r.w}}, e, row1, inFC, M, u64of(a.x, a.y), u64of(a.z, a.w), 1ull << (b.y & 63u),
-                                   b.x >> 16, cs);
-                if (res & 8u) flags |= FLAG_CAPACITY;
-            }
-            uint32_t kd = res & 3u;
-            const bool wantF = (res >> 2) & 1u;
-            // the first plain node among a parent's children claims the parent's lane: the walk goes on with it
-            if (kd == KIND_NODE && !wantF && walkOk) {
-                const uint32_t old = atomicOr(&k4[par], 1u);
-                if (!(old & 1u)) {
-                    aR[par] = make_uint4(cs.r.sa.b, cs.r.sa.e, cs.r.rev.b, cs.r.rev.e);
-                    pA[cur ^ 1u][par] = make_uint4((uint32_t)cs.HP, (uint32_t)(cs.HP >> 32), (uint32_t)cs.HN, (uint32_t)(cs.HN >> 32));
-                    pB[cur ^ 1u][par] = make_uint2(row1 | (cs.sc << 16), ((uint32_t)__ffsll((unsigned long long)cs.RAC) - 1u) | (mdC << 8));
-                    kd = KIND_NONE;
-                }
-            }
-            // ---- slots for what leaves (one prefix sum over the child lanes for nodes, events and F records, one for the items)
-            const uint32_t nNode = kd == KIND_NODE ? 1u : 0u, nEv = kd == KIND_EVENT ? 1u : 0u, nF = (kd != KIND_NONE && wantF) ? 1u : 0u;
-            const uint32_t nIt = kd == KIND_ITEMS ? cs.r.sa.e - cs.r.sa.b : 0u;
-            const uint32_t pk3 = nNode | (nEv << 8) | (nF << 16);
-            const uint32_t in3 = waveInclusiveScanDpp(pk3), t3 = waveLastLane(in3);
-            const uint32_t inI = waveInclusiveScanDpp(nIt), tI = waveLastLane(inI);
-            bool ovQ = false, ovE = false, ovI = false, ovF = false;
-            uint32_t oNode = 0xFFFFFFFFu;
-            if (t3 & 0xFFu) oNode = ncNode.alloc(&B.nq[pass + 1], qCap, t3 & 0xFFu, regionSlots, cntOut, ovQ);
-            const uint32_t oEv = wcEv.allocPre(&B.ne[pass + 1], B.evCap, ((in3 >> 8) & 0xFFu) - nEv, (t3 >> 8) & 0xFFu, chEv, ovE, holeEv);
-            const uint32_t oF = wcF.allocPre(&B.pool[0], B.fCap, ((in3 >> 16) & 0xFFu) - nF, (t3 >> 16) & 0xFFu, WALK_CH_F, ovF, holeF);
-            const uint32_t oIt = wcIt.allocPre(&q.cnt[0], q.itemCap, inI - nIt, tI, WALK_CH_IT, ovI, holeIt);
-            if (oNode != 0xFFFFFFFFu) oNode += (in3 & 0xFFu) - nNode;
-            if (ovQ) flags |= FLAG_BFS_Q;
-            if (ovE) flags |= FLAG_BFS_EV;
-            if (ovI) flags |= FLAG_ITEM_OVERFLOW;
-            if (ovF) flags |= FLAG_BFS_F;
-            // (a wavefront whose share does not fit drops it: the host sees the needed sizes and re-runs)
-            if (kd != KIND_NONE && !(ovQ || ovE || ovI || ovF)) {
-                const uint4 pf = pF[par];
-                const uint32_t ctxC = pf.x, fcPC = pf.y;
-                const uint32_t mC = (hg.y >> 9) & 0x1FFu;
-                const uint32_t cell = min((hg.w >> 23) + row1 - mC, Geo::CELLS - 1u);
-                typename Geo::Pack pack{}; // final-column distances of the path so far
-                if (pf.z && (wantF || kd == KIND_EVENT)) packLoad(&ldsPk[0][par], 256, pack);
-                const uint4 cr = make_uint4(cs.r.sa.b, cs.r.sa.e, cs.r.rev.b, cs.r.rev.e);
-                uint32_t fc = BFS_NONE;
-                if (wantF) {
-                    fc = oF;
-                    uint4* Fr = B.F + (size_t)CMB_IDX(fc, B.fCap, 9) * F_U4;
-                    Fr[0] = cr;
-                    Fr[1] = make_uint4(row1 | (ch << 16), fcPC, 0u, 0u);
-                }
-                if (kd == KIND_NODE) {
-                    const uint32_t o = oNode;
-                    Qo[o] = cr;
-                    Qo[(size_t)qCap + o] = make_uint4(row1 | (cs.sc << 16), ctxC, fc,
-                                                      ((uint32_t)__ffsll((unsigned long long)cs.RAC) - 1u) | (mdC << 8));
-                    Qo[(size_t)2 * qCap + o] = make_uint4((uint32_t)cs.HP, (uint32_t)(cs.HP >> 32), (uint32_t)cs.HN,
-                                                          (uint32_t)(cs.HN >> 32));
-                    if (wantF) {
-                        typename Geo::Pack p2 = pack;
-                        edPut(p2, cell, cs.aux);
-                        packStore(Qo + (size_t)3 * qCap + o, qCap, p2);
-                    }
-                } else if (kd == KIND_EVENT) {
-                    typename Geo::Pack p2 = pack;
-                    edPut(p2, cell, cs.aux);
-                    Eo[(size_t)EV_U4 * oEv] = make_uint4(ctxC, fc, 0xFFFFFFFFu, cell);
-                    packStore(Eo + (size_t)EV_U4 * oEv + 1, 1, p2);
-                } else {
-                    const uint32_t w = cs.r.sa.e - cs.r.sa.b;
-                    const uint32_t rsId = hg.x & 0x1FFFFFFu, itMeta = hg.w & 0x7FFFFFu;
-                    for (uint32_t t = 0; t < w; t++) q.items[oIt + t] = make_uint4(rsId, cs.r.sa.b + t, cs.aux, itMeta);
-                }
-            }
-        }
-        CMB_LDS_SYNC();
-        PF_LAP(11)
-        // ---- parents again: walk on with the child that claimed the lane, or let go of the node
-        if (have) {
-            if (k4[tid] & 1u) {
-                const uint4 r = aR[tid];
-                parent = RangePair{{r.x, r.y}, {r.z, r.w}};
-                row = row + 1u;
-                if ((row + 1u) / Geo::BLOCK != blk) { // the next row lies in another row block: its match words
-                    blk = (row + 1u) / Geo::BLOCK;
-                    needM = true;
-                }
-            } else {
-                have = false;
-            }
-        }
-        cur ^= 1u;
-        PF_ADD(5, have ? 1u : 0u)
-        PF_LAP(12)
-    }
-#ifdef CMB_BFS_STATS
-    if ((tid & 63u) == 0) pf[3] = (unsigned long long)(clock64() - pfT0);
-    for (int j = 0; j < 16; j++) {
-        unsigned long long x = pf[j];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
-        if ((tid & 63u) == 0 && x) atomicAdd(&g_bfsStats[j], x);
-    }
-#endif
-    ncNode.retire(cntOut);
-    wcEv.fill(holeEv);
-    if ((tid & 63u) == 0) { // the item and F chunks go on in the wavefront's next pass
-        save[0] = wcIt.base, save[1] = wcIt.used, save[2] = wcIt.size;
-        save[4] = wcF.base, save[5] = wcF.used, save[6] = wcF.size;
-    }
-    // per-block counters (summed by k_bfs_finish): one writer per slot and launch, launches are ordered
-    unsigned long long v[3] = {cntChildren, cntExp, cntChildren}; // (every child gets its matrix row)
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v[j] += __shfl_xor(v[j], d);
-    }
-    __shared__ unsigned long long shc[4][3];
-    if ((threadIdx.x & 63u) == 0)
-        for (int j = 0; j < 3; j++) shc[threadIdx.x >> 6][j] = v[j];
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        const unsigned long long t = shc[0][threadIdx.x] + shc[1][threadIdx.x] + shc[2][threadIdx.x] + shc[3][threadIdx.x];
-        if (t) B.blockCnt[(size_t)bid * 4 + threadIdx.x] += t;
-    }
-    if (flags) atomicOr(&q.cnt[3], flags);
-}
-
-// ------------------------------------------------------------------ expand: bfsExpand per WAVEFRONT (round 4, CMB_BFS_WALK=2)
-// The per-node logic of bfsExpand, lane for lane (same classification, chain walk and records), without what a block-wide tile costs
-// it: three barriers and an atomic round trip per tile, and the node planes as a round trip of their own.  A wavefront works on its
-// own chunks of the chunked node queue (chunk c belongs to wavefront c % W, counts in BfsBufs::qCnt — as bfsExpandWalk):
-//   * the node planes of the NEXT chunk are copied into the lanes' LDS slots by global_load_lds while the current one is expanded;
-//   * queue slots come from per-wavefront chunks: one prefix sum over the lanes (DPP), an atomic only when a chunk is used up;
-//   * no barrier: the four wavefronts of a block drift apart, which is what hides their memory round trips from each other.
-template <class Geo = GeoN>
-__device__ __forceinline__ void bfsExpandWave(const DevIndex& ix, const BfsBufs& B, uint32_t pass, const Queues& q, uint32_t bid,
-                                              uint32_t nBlocks) {
-    constexpr uint32_t EV_U4 = 1u + Geo::PK_U4;
-    __shared__ uint4 ldsNext[3][256];  // node planes of the wavefront's next chunk
-    __shared__ uint64_t ldsM[4][256];
-    __shared__ uint32_t ldsR[8][256];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
-    const uint32_t nIn = min(B.nq[pass], B.qCap);
-    const uint4* __restrict__ Qi = B.Q[pass & 1u];
-    uint4* __restrict__ Qo = B.Q[(pass + 1u) & 1u];
-    uint4* __restrict__ Eo = B.Ev[(pass + 1u) & 1u];
-    const uint32_t* __restrict__ cntIn = B.qCnt[pass & 1u];
-    uint32_t* __restrict__ cntOut = B.qCnt[(pass + 1u) & 1u];
-    const uint32_t qCap = B.qCap;
-    const uint32_t W = nBlocks * 4u, wId = bid * 4u + (tid >> 6), nChunks = (nIn + 63u) >> 6;
-    const uint32_t cntLast = nChunks ? nChunks - 1u : 0u;
-    uint32_t chunk = wId;
-    uint32_t cCnt = 0, nCnt = 0;
-    {
-        const uint32_t c0 = cntIn[min(chunk, cntLast)], c1 = cntIn[min(chunk + W, cntLast)];
-        cCnt = chunk < nChunks ? (uint32_t)__builtin_amdgcn_readfirstlane((int)min(c0, 64u)) : 0u;
-        nCnt = chunk + W < nChunks ? (uint32_t)__builtin_amdgcn_readfirstlane((int)min(c1, 64u)) : 0u;
-        if (lane < cCnt) {
-            const uint32_t i0 = chunk * 64u + lane;
-            gldsU4(Qi + i0, &ldsNext[0][wbase]);
-            gldsU4(Qi + (size_t)qCap + i0, &ldsNext[1][wbase]);
-            gldsU4(Qi + (size_t)2 * qCap + i0, &ldsNext[2][wbase]);
-        }
-    }
-    uint32_t flags = 0, cntChildren = 0, cntExp = 0;
-    NodeRegion ncNode;
-    const uint32_t regionSlots = nodeRegionSlots(nIn, W);
-    WaveChunk wcEv, wcIt, wcF;
-    uint32_t* save = B.wcSave + (size_t)wId * WALK_SAVE_U32;
-    { // the item and F chunks of the wavefront's previous pass (zeroed before the search)
-        wcIt.base = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[0]);
-        wcIt.used = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[1]);
-        wcIt.size = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[2]);
-        wcF.base = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[4]);
-        wcF.used = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[5]);
-        wcF.size = (uint32_t)__builtin_amdgcn_readfirstlane((int)save[6]);
-    }
-    const uint32_t chEv = nIn < 262144u ? WALK_CH_EV_SMALL : WALK_CH_EV;
-    auto holeEv = [&](uint32_t o) { Eo[(size_t)EV_U4 * o] = make_uint4(BFS_NONE, 0u, 0u, 0u); };
-    auto holeIt = [&](uint32_t o) { q.items[o] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u); };
-    auto holeF = [&](uint32_t) {};
-#ifdef CMB_BFS_STATS
-    // diagnostic build only (tools/walk_stats.sh): [0] tiles, [1] active lanes, [3] cycles in the loop, [8..13] cycles: wait for the
-    // planes | first memory step + classification | chain steps | allocation | output | loop end
-    unsigned long long pf[16] = {};
-    const long long pfT0 = clock64();
-    long long pfT = pfT0;
-#endif
-    while (chunk < nChunks) { // (wave-uniform)
-        PF_LAP(13)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the chunk's node planes are in the lanes' slots
-        PF_LAP(8)
-        PF_ADD(0, lane == 0 ? 1u : 0u)
-        PF_ADD(1, lane < cCnt ? 1u : 0u)
-        const bool act = lane < cCnt;
-        const uint32_t i = chunk * 64u + lane;
-        uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0;
-        if (act) {
-            n0 = ldsNext[0][tid];
-            n1 = ldsNext[1][tid];
-            n2 = ldsNext[2][tid];
-        }
-        CMB_LDS_SYNC(); // (the slots are read before they are filled again)
-        // the next chunk of the wavefront: its planes travel while this one is expanded; the count of the one after it
-        const uint32_t chunkN = chunk + W;
-        if (chunkN < nChunks && lane < nCnt) {
-            const uint32_t i1 = chunkN * 64u + lane;
-            gldsU4(Qi + i1, &ldsNext[0][wbase]);
-            gldsU4(Qi + (size_t)qCap + i1, &ldsNext[1][wbase]);
-            gldsU4(Qi + (size_t)2 * qCap + i1, &ldsNext[2][wbase]);
-        }
-        const uint32_t n2Load = cntIn[min(chunkN + W, cntLast)];
-        if (cCnt == 0u) { // an empty chunk (the unused rest of a producer's region): on to the next
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            chunk = chunkN;
-            cCnt = nCnt;
-            nCnt = chunk + W < nChunks ? (uint32_t)__builtin_amdgcn_readfirstlane((int)min(n2Load, 64u)) : 0u;
-            continue;
-        }
-        uint32_t kinds = 0; // 4 bits per child: kind | needF << 2
-        uint32_t row1 = 0, ctx = 0, fcP = BFS_NONE, nIt = 0;
-        RangePair parent{{0, 0}, {0, 0}};
-        uint32_t row = 0, score = 0, blk = 0;
-        int md = 0;
-        uint64_t pHP = 0, pHN = 0;
-        uint32_t pRac = 0;
-        ExpandCtx e{};
-        e.switchPoint = ix.switchPoint;
-        uint32_t db = 0, de = 0;
-        uint32_t hotX = 0, hotW = 0;
-        bool walking = act;
-        if (act) {
-            ctx = n1.y;
-            fcP = n1.z;
-            row = n1.x & 0xFFFFu;
-            score = n1.x >> 16;
-            md = (int)((n1.w >> 8) & 3u);
-            parent = RangePair{{n0.x, n0.y}, {n0.z, n0.w}};
-            uint4 rk[4];
-            issueRanks(ix, md, parent, rk);
-            const uint4* Cx = B.C + (size_t)CMB_IDX(ctx, B.cCap, 1) * B.ctxU4;
-            blk = (row + 1) / Geo::BLOCK;
-            const uint4 hot = Cx[CTX_HOT];
-            const uint4 mA = Cx[CTX_M + 2 * blk], mB = Cx[CTX_M + 1 + 2 * blk];
-            {
-                uint32_t Rb[4], Re[4];
-                takeRanks(ix, md, parent, rk, Rb, Re, db, de);
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    ldsR[c][tid] = Rb[c];
-                    ldsR[4 + c][tid] = Re[c];
-                }
-            }
-            e.itStart = hot.z;
-            e.g.n = hot.y & 0x1FFu;
-            e.g.m = (hot.y >> 9) & 0x1FFu;
-            e.g.Wv = (hot.y >> 18) & 31u;
-            e.g.Wh = (hot.y >> 23) & 15u;
-            e.g.maxED = (hot.y >> 27) & 15u;
-            e.clSize = hot.w >> 23;
-            e.itMode = (hot.x >> 25) & 3u;
-            hotX = hot.x;
-            hotW = hot.w;
-            pHP = u64of(n2.x, n2.y);
-            pHN = u64of(n2.z, n2.w);
-            pRac = n1.w & 63u;
-            ldsM[0][tid] = u64of(mA.x, mA.y);
-            ldsM[1][tid] = u64of(mA.z, mA.w);
-            ldsM[2][tid] = u64of(mB.x, mB.y);
-            ldsM[3][tid] = u64of(mB.z, mB.w);
-        }
-        // ---- walk (as bfsExpand)
-        for (uint32_t step = 0; step < B.chain; step++) { // (wave-uniform exit below)
-            if (step == 1u) { PF_LAP(9) }
-            if (walking) {
-                if (step) {
-                    uint4 rk[4];
-                    issueRanks(ix, md, parent, rk);
-                    uint32_t Rb[4], Re[4];
-                    takeRanks(ix, md, parent, rk, Rb, Re, db, de);
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        ldsR[c][tid] = Rb[c];
-                        ldsR[4 + c][tid] = Re[c];
-                    }
-                }
-                uint32_t Rb[4], Re[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    Rb[c] = ldsR[c][tid];
-                    Re[c] = ldsR[4 + c][tid];
-                }
-                row1 = row + 1;
-                cntExp++;
-                const bool inFC = e.g.inFinalColumn(row1);
-                if (inFC && e.clSize + row1 - e.g.m >= Geo::CELLS) flags |= FLAG_CAPACITY;
-                kinds = 0;
-                nIt = 0;
-                uint32_t nOut = 0, nChildren = 0;
-#pragma unroll
-                for (uint32_t ch = 1; ch <= 4; ch++) {
-                    bool nonEmpty;
-                    ChildState cs;
-                    const uint32_t k4 = evalChild<false, Geo>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, ldsM[ch - 1][tid], pHP, pHN,
-                                                              1ull << pRac, score, nonEmpty, cs);
-                    nChildren += nonEmpty ? 1u : 0u;
-                    if (k4 & 8u) flags |= FLAG_CAPACITY;
-                    if ((k4 & 3u) == KIND_NONE) continue;
-                    kinds |= (k4 & 7u) << (4 * (ch - 1));
-                    nOut++;
-                    if ((k4 & 3u) == KIND_ITEMS) {
-                        RangePair child;
-                        (void)childFromRanks(ix, md, parent, ch, Rb, Re, db, de, child);
-                        nIt += child.sa.e - child.sa.b;
-                    }
-                }
-                cntChildren += nChildren;
-                const bool single = nOut == 1u && (kinds == 0x1u || kinds == 0x10u || kinds == 0x100u || kinds == 0x1000u);
-                if (single && step + 1u < B.chain && (row1 + 1u) / Geo::BLOCK == blk) {
-                    const uint32_t ch = ((31u - (uint32_t)__clz(kinds)) >> 2) + 1u;
-                    const uint64_t M = ch == 1 ? ldsM[0][tid] : ch == 2 ? ldsM[1][tid] : ch == 3 ? ldsM[2][tid] : ldsM[3][tid];
-                    bool nonEmpty;
-                    ChildState one;
-                    (void)evalChild<true, Geo>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, M, pHP, pHN, 1ull << pRac, score, nonEmpty, one);
-                    parent = one.r;
-                    score = one.sc;
-                    pHP = one.HP;
-                    pHN = one.HN;
-                    pRac = (uint32_t)__ffsll((unsigned long long)one.RAC) - 1u;
-                    row = row1;
-                    kinds = 0;
-                } else {
-                    walking = false;
-                }
-            }
-            if (__ballot(walking) == 0ull) break;
-        }
-        PF_LAP(10)
-        // ---- slots: one prefix sum over the lanes for nodes, events and F records, one for the items
-        uint32_t nNode = 0, nEv = 0, nF = 0;
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const uint32_t kd = (kinds >> (4 * c)) & 3u;
-            nNode += kd == KIND_NODE;
-            nEv += kd == KIND_EVENT;
-            nF += (kinds >> (4 * c + 2)) & 1u;
-        }
-        const uint32_t pk3 = nNode | (nEv << 10) | (nF << 20);
-        const uint32_t in3 = waveInclusiveScanDpp(pk3), t3 = waveLastLane(in3);
-        const uint32_t inI = waveInclusiveScanDpp(nIt), tI = waveLastLane(inI);
-        bool ovE = false, ovI = false, ovF = false;
-        bool ovQ = false;
-        const uint32_t nb0 = (t3 & 0x3FFu) ? ncNode.alloc(&B.nq[pass + 1], qCap, t3 & 0x3FFu, regionSlots, cntOut, ovQ) : 0u;
-        const bool okQ = !ovQ;
-        uint32_t oEv = wcEv.allocPre(&B.ne[pass + 1], B.evCap, ((in3 >> 10) & 0x3FFu) - nEv, (t3 >> 10) & 0x3FFu, chEv, ovE, holeEv);
-        uint32_t oF = wcF.allocPre(&B.pool[0], B.fCap, ((in3 >> 20) & 0x3FFu) - nF, (t3 >> 20) & 0x3FFu, WALK_CH_F, ovF, holeF);
-        uint32_t oIt = wcIt.allocPre(&q.cnt[0], q.itemCap, inI - nIt, tI, WALK_CH_IT, ovI, holeIt);
-        uint32_t pNode = (in3 & 0x3FFu) - nNode; // this lane's first node among the wavefront's
-        if (!okQ) flags |= FLAG_BFS_Q;
-        if (ovE) flags |= FLAG_BFS_EV;
-        if (ovI) flags |= FLAG_ITEM_OVERFLOW;
-        if (ovF) flags |= FLAG_BFS_F;
-        PF_LAP(11)
-        if (kinds != 0u && okQ && !ovE && !ovI && !ovF) {
-            const bool inFC = e.g.inFinalColumn(row1);
-            const uint32_t cell = min(e.clSize + row1 - e.g.m, Geo::CELLS - 1u);
-            typename Geo::Pack pack{};
-            if (fcP != BFS_NONE && (kinds & 0x4444u)) packLoad(Qi + (size_t)3 * qCap + i, qCap, pack);
-            const uint32_t rsId = hotX & 0x1FFFFFFu, itMeta = hotW & 0x7FFFFFu;
-            uint32_t Rb[4], Re[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                Rb[c] = ldsR[c][tid];
-                Re[c] = ldsR[4 + c][tid];
-            }
-#pragma unroll
-            for (uint32_t ch = 1; ch <= 4; ch++) {
-                const uint32_t kd = (kinds >> (4 * (ch - 1))) & 3u;
-                if (kd == KIND_NONE) continue;
-                bool nonEmpty;
-                ChildState cs;
-                (void)evalChild<true, Geo>(ix, md, parent, ch, Rb, Re, db, de, e, row1, inFC, ldsM[ch - 1][tid], pHP, pHN, 1ull << pRac, score,
-                                           nonEmpty, cs);
-                const bool wantF = (kinds >> (4 * (ch - 1) + 2)) & 1u;
-                const uint4 cr = make_uint4(cs.r.sa.b, cs.r.sa.e, cs.r.rev.b, cs.r.rev.e);
-                uint32_t fc = BFS_NONE;
-                if (wantF) {
-                    fc = oF++;
-                    uint4* Fr = B.F + (size_t)CMB_IDX(fc, B.fCap, 9) * F_U4;
-                    Fr[0] = cr;
-                    Fr[1] = make_uint4(row1 | (ch << 16), fcP, 0u, 0u);
-                }
-                if (kd == KIND_NODE) {
-                    const uint32_t o = nb0 + pNode;
-                    pNode++;
-                    Qo[o] = cr;
-                    Qo[(size_t)qCap + o] = make_uint4(row1 | (cs.sc << 16), ctx, fc,
-                                                      ((uint32_t)__ffsll((unsigned long long)cs.RAC) - 1u) | ((uint32_t)md << 8));
-                    Qo[(size_t)2 * qCap + o] = make_uint4((uint32_t)cs.HP, (uint32_t)(cs.HP >> 32), (uint32_t)cs.HN, (uint32_t)(cs.HN >> 32));
-                    if (wantF) {
-                        typename Geo::Pack p2 = pack;
-                        edPut(p2, cell, cs.aux);
-                        packStore(Qo + (size_t)3 * qCap + o, qCap, p2);
-                    }
-                } else if (kd == KIND_EVENT) {
-                    typename Geo::Pack p2 = pack;
-                    edPut(p2, cell, cs.aux);
-                    Eo[(size_t)EV_U4 * oEv] = make_uint4(ctx, fc, 0xFFFFFFFFu, cell);
-                    packStore(Eo + (size_t)EV_U4 * oEv + 1, 1, p2);
-                    oEv++;
-                } else {
-                    const uint32_t w = cs.r.sa.e - cs.r.sa.b;
-                    for (uint32_t t = 0; t < w; t++) q.items[oIt + t] = make_uint4(rsId, cs.r.sa.b + t, cs.aux, itMeta);
-                    oIt += w;
-                }
-            }
-        }
-        PF_LAP(12)
-        // ---- on to the wavefront's next chunk
-        chunk = chunkN;
-        cCnt = nCnt;
-        nCnt = chunk + W < nChunks ? (uint32_t)__builtin_amdgcn_readfirstlane((int)min(n2Load, 64u)) : 0u;
-    }
-#ifdef CMB_BFS_STATS
-    if (lane == 0) pf[3] = (unsigned long long)(clock64() - pfT0);
-    for (int j = 0; j < 16; j++) {
-        unsigned long long x = pf[j];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
-        if (lane == 0 && x) atomicAdd(&g_bfsStats[j], x);
-    }
-#endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ncNode.retire(cntOut);
-    wcEv.fill(holeEv);
-    if (lane == 0) { // the item and F chunks go on in the wavefront's next pass
-        save[0] = wcIt.base, save[1] = wcIt.used, save[2] = wcIt.size;
-        save[4] = wcF.base, save[5] = wcF.used, save[6] = wcF.size;
-    }
-    unsigned long long v[3] = {cntChildren, cntExp, cntChildren};
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v[j] += __shfl_xor(v[j], d);
-    }
-    __shared__ unsigned long long shc[4][3];
-    if (lane == 0)
-        for (int j = 0; j < 3; j++) shc[tid >> 6][j] = v[j];
-    __syncthreads();
-    if (tid < 3) {
-        const unsigned long long t = shc[0][tid] + shc[1][tid] + shc[2][tid] + shc[3][tid];
-        if (t) B.blockCnt[(size_t)bid * 4 + tid] += t;
     }
     if (flags) atomicOr(&q.cnt[3], flags);
 }
@@ -1499,7 +735,7 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyKT<Geo::MP>* __restric
                     startDepth = t.depth;
                     s = &stp->sch[scheme].s[search];
                 }
-            } else if (Ei[(size_t)EV_U4 * i].x != BFS_NONE) { // (holes: the unused rest of a wavefront's chunk, bfsExpandWalk)
+            } else if (Ei[(size_t)EV_U4 * i].x != BFS_NONE) { // (a record without a context is a hole)
                 const uint4 ev = Ei[(size_t)EV_U4 * i];
                 c0i = ev.x;
                 fcE = ev.y;
@@ -1793,12 +1029,14 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyKT<Geo::MP>* __restric
                 nInit = nSrcInit;
             }
             MatGeom g;
-            uint64_t HP, HN, RAC;
+            typename Geo::W HP, HN, RAC;
             uint32_t score;
-            initMatrix<Geo::LEFT, Geo::DIAG>(g, xLen, maxEDn, first, lastI, nSrcInit ? il : nullptr, increase, nInit, HP, HN, RAC, score);
+            initMatrix<Geo::LEFT, Geo::DIAG, typename Geo::W>(g, xLen, maxEDn, first, lastI, nSrcInit ? il : nullptr, increase, nInit, HP, HN, RAC, score);
             const uint32_t clSize = g.sfc();
-            const uint32_t nBlk = (g.m - 1) / Geo::BLOCK + 1;
-            if (g.Wv >= Geo::LEFT || clSize > ED_CELLS || nBlk > B.ctxMblk || g.m > 0xFFFFu) {
+            const uint32_t nBlk = (g.m - 1) / Geo::CTX_BLOCK + 1;
+            if (Geo::NARROW_FALLBACK && (g.Wv > min(Geo::DIAG, B.narrowWv) || maxEDn > MXS_MAX_ED)) {
+                flags |= FLAG_NARROW_MATRIX; // (the first column does not fit the small matrix: the host runs the batch on the 64-bit geometry)
+            } else if (g.Wv >= Geo::LEFT || clSize > ED_CELLS || nBlk > B.ctxMblk || g.m > 0xFFFFu) {
                 flags |= FLAG_CAPACITY;
             } else {
                 // in-text switch parameters of the phase (goToInTextVerificationEdit, :340-375)
@@ -1844,8 +1082,8 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyKT<Geo::MP>* __restric
                 const uint32_t* Gs[4]; // the bit-strings of A, C, G, T for this read x strand and direction
                 for (uint32_t c4 = 0; c4 < 4; c4++) Gs[c4] = gString(G, gw, rsId, (uint32_t)useRev, c4);
                 for (uint32_t b = 0; b < nBlk; b++) {
-                    const uint64_t a = matchWord<Geo::LEFT, Geo::BLOCK>(Gs[0], xOff, xLen, b), c = matchWord<Geo::LEFT, Geo::BLOCK>(Gs[1], xOff, xLen, b);
-                    const uint64_t gg = matchWord<Geo::LEFT, Geo::BLOCK>(Gs[2], xOff, xLen, b), t = matchWord<Geo::LEFT, Geo::BLOCK>(Gs[3], xOff, xLen, b);
+                    const uint64_t a = matchWord<Geo::CTX_LEFT, Geo::CTX_BLOCK>(Gs[0], xOff, xLen, b), c = matchWord<Geo::CTX_LEFT, Geo::CTX_BLOCK>(Gs[1], xOff, xLen, b);
+                    const uint64_t gg = matchWord<Geo::CTX_LEFT, Geo::CTX_BLOCK>(Gs[2], xOff, xLen, b), t = matchWord<Geo::CTX_LEFT, Geo::CTX_BLOCK>(Gs[3], xOff, xLen, b);
                     Cx[CTX_M + 2 * b] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)c, (uint32_t)(c >> 32));
                     Cx[CTX_M + 1 + 2 * b] = make_uint4((uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)t, (uint32_t)(t >> 32));
                 }
@@ -1875,8 +1113,9 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyKT<Geo::MP>* __restric
                         const uint32_t meta = dl[DU * j + PU].x;
                         const uint32_t depth = meta & 0xFFFFu, ch = (meta >> 16) & 0xFFu;
                         if (depth > maxRow) break;
-                        const uint64_t M = matchWord<Geo::LEFT, Geo::BLOCK>(gString(G, gw, rsId, (uint32_t)useRev, ch - 1u), xOff, xLen, depth / Geo::BLOCK);
-                        uint64_t D0;
+                        const typename Geo::W M = Geo::mword(
+                            matchWord<Geo::CTX_LEFT, Geo::CTX_BLOCK>(gString(G, gw, rsId, (uint32_t)useRev, ch - 1u), xOff, xLen, depth / Geo::CTX_BLOCK), depth);
+                        typename Geo::W D0;
                         const bool valid = Geo::row(g, depth, M, HP, HN, D0, RAC, score);
                         cRows++;
                         if (g.inFinalColumn(depth)) {
@@ -1921,17 +1160,15 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyKT<Geo::MP>* __restric
                 if (live) {
                     outKind = 1;
                     oRoot = root;
-                    oN1 = make_uint4(rootRow | (score << 16), cNew, fcCur,
-                                     ((uint32_t)__ffsll((unsigned long long)RAC) - 1u) | ((uniN ? 2u : (dirN == 0 ? 0u : 1u)) << 8));
-                    oN2 = make_uint4((uint32_t)HP, (uint32_t)(HP >> 32), (uint32_t)HN, (uint32_t)(HN >> 32));
+                    oN1 = make_uint4(rootRow | (score << 16), cNew, fcCur, Geo::racIdx(RAC) | ((uniN ? 2u : (dirN == 0 ? 0u : 1u)) << 8));
+                    oN2 = Geo::packRow(HP, HN);
                     oPack = pk;
                 }
             }
         }
         // ---- append the node / event this lane produced
         uint32_t t4, t5;
-        const uint32_t oN = Tr::CHUNKED_Q ? blockAppendChunked(&B.nq[outP], outKind == 1 ? 1u : 0u, sh[0], t4, B.qCnt[outP & 1u], qCap)
-                                          : blockAppend(&B.nq[outP], outKind == 1 ? 1u : 0u, sh[0], t4);
+        const uint32_t oN = blockAppend(&B.nq[outP], outKind == 1 ? 1u : 0u, sh[0], t4);
         const uint32_t oE = blockAppend(&B.ne[outP], outKind == 2 ? 1u : 0u, sh[1], t5);
         if (outKind == 1) {
             if (oN >= qCap) flags |= FLAG_BFS_Q;

@@ -193,6 +193,23 @@ __device__ __forceinline__ bool childFromRanks(const DevIndex& ix, int mode, con
     return !child.sa.empty();
 }
 
+// The same without control flow (the frontier kernels are bound by instruction issue, and what hipcc makes of the three modes above is a
+// nest of exec-mask saves and restores per child): both ranges are computed, the mode selects.
+__device__ __forceinline__ bool childFromRanksFlat(const DevIndex& ix, int mode, const RangePair& p, uint32_t c, const uint32_t Rb[4],
+                                                   const uint32_t Re[4], uint32_t db, uint32_t de, RangePair& child) {
+    const uint32_t start = ix.counts[c];
+    const uint32_t b1 = occFromR(Rb, c) + start, e1 = occFromR(Re, c) + start;
+    const uint32_t w1 = e1 > b1 ? e1 - b1 : 0u;
+    const uint32_t x = cumFromR(Re, c, de) - cumFromR(Rb, c, db);
+    const uint32_t b2 = (mode == 1 ? p.rev.b : p.sa.b) + x, e2 = b2 + w1;
+    const bool fwd = mode == 0, uni = mode == 2;
+    child.sa.b = fwd ? b2 : b1;
+    child.sa.e = fwd ? e2 : e1;
+    child.rev.b = uni ? 0u : fwd ? b1 : b2;
+    child.rev.e = uni ? 0u : fwd ? e1 : e2;
+    return e1 > b1; // (the two ranges of a child have the same width)
+}
+
 // ranks needed to extend p in `mode`
 __device__ __forceinline__ void loadExtendRanks(const DevIndex& ix, int mode, const RangePair& p,
                                                 uint32_t Rb[4], uint32_t Re[4], uint32_t& db,

@@ -68,10 +68,10 @@ struct MatGeom {
 // only used by findCIGAR / the naive search); `first` / `last` are initED[0] / initED[nInit-1].  The
 // first column is built from raw[] on the fly — no private array of initial distances is needed (it
 // would live in scratch memory).
-template <uint32_t LEFT = MX_LEFT, uint32_t DIAG = MX_DIAG>
+template <uint32_t LEFT = MX_LEFT, uint32_t DIAG = MX_DIAG, typename W = uint64_t>
 __device__ __forceinline__ void initMatrix(MatGeom& g, uint32_t xLen, uint32_t maxED, uint32_t first, uint32_t last,
-                                           const uint16_t* raw, uint32_t increase, uint32_t nInit, uint64_t& HP0,
-                                           uint64_t& HN0, uint64_t& RAC0, uint32_t& score0) {
+                                           const uint16_t* raw, uint32_t increase, uint32_t nInit, W& HP0,
+                                           W& HN0, W& RAC0, uint32_t& score0) {
     g.n = xLen + 1;
     g.maxED = maxED;
     g.Wv = nInit - 1 + maxED - last;
@@ -79,19 +79,19 @@ __device__ __forceinline__ void initMatrix(MatGeom& g, uint32_t xLen, uint32_t m
     score0 = first;
     g.Wh = maxED - score0;
     if (g.Wv + g.Wh + 1 > g.m) g.m = g.Wv + g.Wh + 1;
-    HP0 = (~0ull) << LEFT;
+    HP0 = (W)(~(W)0) << LEFT;
     HN0 = ~HP0;
     const uint32_t nn = nInit < LEFT + 1 ? nInit : LEFT + 1;
     for (uint32_t i = 1; i < nn; ++i) {
         const uint32_t cur = raw[i] + increase, prev = raw[i - 1] + increase; // length_t arithmetic
         if (cur < prev) {
-            HP0 ^= 1ull << (LEFT - i);
-            HN0 ^= 1ull << (LEFT - i);
+            HP0 ^= (W)1 << (LEFT - i);
+            HN0 ^= (W)1 << (LEFT - i);
         } else if (cur == prev) {
-            HN0 ^= 1ull << (LEFT - i);
+            HN0 ^= (W)1 << (LEFT - i);
         }
     }
-    RAC0 = 1ull << (DIAG + g.Wh);
+    RAC0 = (W)1 << (DIAG + g.Wh);
 }
 
 // computeRow (bitparallelmatrix.h:352-415).  In/out: previous row state -> row i state.
@@ -270,17 +270,18 @@ __device__ __forceinline__ uint32_t matchWord32(uint64_t M64, uint32_t i) {
 // at the highest bit of x when no HN bit lies above it (y <= x), and otherwise — the value can only reach zero AT an HP
 // bit — is walked per HP bit, not per column: the HN bits passed since the previous HP bit are counted, and the walk
 // ends at the first HP bit at which as many HP as HN bits (plus one) have been seen.
+template <uint32_t BLOCK = MX32_BLOCK, uint32_t DIAG = MX32_DIAG>
 __device__ __forceinline__ bool racWalk(const MatGeom& g, uint32_t i, uint32_t HP, uint32_t HN, uint32_t& rac) {
-    const uint32_t l = i % MX32_BLOCK;
+    const uint32_t l = i % BLOCK;
     const uint32_t below = (rac << 1u) - 1u; // the RAC column and everything left of it
     const uint32_t x = HP & below, y = HN & below;
-    // highest bit of x above column l + MX32_DIAG - Wv  <=>  x >> (l + 1) >= 2^(MX32_DIAG - Wv)
-    if ((x >> (l + 1u)) < (1u << (MX32_DIAG - g.Wv))) return false;
+    // highest bit of x above column l + DIAG - Wv  <=>  x >> (l + 1) >= 2^(DIAG - Wv)
+    if ((x >> (l + 1u)) < (1u << (DIAG - g.Wv))) return false;
     if (y <= x) {
         rac = 0x40000000u >> (uint32_t)__builtin_clz(x); // (x != 0 here)
         return true;
     }
-    const uint32_t xs = x & ~((2u << (l + MX32_DIAG - g.Wv)) - 1u); // zero reached AT the stop column still fails (:408)
+    const uint32_t xs = x & ~((2u << (l + DIAG - g.Wv)) - 1u); // zero reached AT the stop column still fails (:408)
     uint32_t top = below; // columns not yet passed
     int need = 1;         // HP bits still needed (rises with every HN bit passed)
     for (;;) {
@@ -295,15 +296,17 @@ __device__ __forceinline__ bool racWalk(const MatGeom& g, uint32_t i, uint32_t H
         top = hb - 1u;
     }
 }
+template <uint32_t BLOCK = MX32_BLOCK>
 __device__ __forceinline__ void racAdvance(uint32_t i, uint32_t& rac) {
     rac <<= 1u;
-    if (i % MX32_BLOCK == 0) rac >>= MX32_BLOCK;
+    if (i % BLOCK == 0) rac >>= BLOCK;
 }
 __device__ __forceinline__ bool racHit(uint32_t D0, uint32_t rac) { return (D0 & rac) != 0u; }
+template <uint32_t BLOCK = MX32_BLOCK>
 __device__ __forceinline__ void computeRowCore(uint32_t i, uint32_t M, uint32_t& HP, uint32_t& HN, uint32_t& D0) {
-    if (i % MX32_BLOCK == 0) {
-        HP >>= MX32_BLOCK;
-        HN >>= MX32_BLOCK;
+    if (i % BLOCK == 0) {
+        HP >>= BLOCK;
+        HN >>= BLOCK;
     }
     D0 = (((M & HP) + HP) ^ HP) | M | HN;
     const uint32_t VP = HN | ~(D0 | HP);
@@ -311,12 +314,13 @@ __device__ __forceinline__ void computeRowCore(uint32_t i, uint32_t M, uint32_t&
     HP = (VN << 1u) | ~(D0 | (VP << 1u));
     HN = (D0 & (VP << 1u));
 }
+template <uint32_t BLOCK = MX32_BLOCK, uint32_t DIAG = MX32_DIAG>
 __device__ __forceinline__ bool computeRow(const MatGeom& g, uint32_t i, uint32_t M, uint32_t& HP, uint32_t& HN,
                                            uint32_t& D0, uint32_t& rac, uint32_t& score) {
-    racAdvance(i, rac);
-    computeRowCore(i, M, HP, HN, D0);
-    score += (D0 >> (i % MX32_BLOCK + MX32_DIAG)) & 1u ? 0u : 1u;
-    if (!racHit(D0, rac)) return racWalk(g, i, HP, HN, rac);
+    racAdvance<BLOCK>(i, rac);
+    computeRowCore<BLOCK>(i, M, HP, HN, D0);
+    score += (D0 >> (i % BLOCK + DIAG)) & 1u ? 0u : 1u;
+    if (!racHit(D0, rac)) return racWalk<BLOCK, DIAG>(g, i, HP, HN, rac);
     return true;
 }
 // the RAC state of a matrix word type: a one-bit mask
@@ -324,8 +328,9 @@ __device__ __forceinline__ uint64_t racInit(uint64_t, uint32_t bit) { return 1ul
 __device__ __forceinline__ uint32_t racInit(uint32_t, uint32_t bit) { return 1u << bit; }
 __device__ __forceinline__ uint32_t racIndex(uint64_t rac) { return (uint32_t)__ffsll((unsigned long long)rac) - 1u; }
 __device__ __forceinline__ uint32_t racIndex(uint32_t rac) { return 31u - (uint32_t)__clz((int)rac); }
+template <uint32_t BLOCK = MX32_BLOCK, uint32_t DIAG = MX32_DIAG>
 __device__ __forceinline__ uint32_t cellAt(uint32_t i, uint32_t j, uint32_t HP, uint32_t HN, uint32_t score) {
-    const uint32_t bit = (i % MX32_BLOCK) + MX32_DIAG;
+    const uint32_t bit = (i % BLOCK) + DIAG;
     const uint32_t b = (i > j) ? bit - (i - j) + 1 : bit + 1;
     const uint32_t e = (i > j) ? bit + 1 : bit + (j - i) + 1;
     const uint32_t len = e - b;
@@ -375,6 +380,38 @@ __device__ __forceinline__ bool onlyVerticalGapsLeftAs(const MatGeom& g, uint32_
     if (be <= bb) return true;
     const uint64_t mask = (be >= 64 ? ~0ull : ((1ull << be) - 1ull)) & ~((1ull << bb) - 1ull);
     return (~HN & mask) == 0ull;
+}
+
+// ---- the in-index matrix up to 7 errors: 32-bit words, 8-row blocks (round 4: GeoN32 of dev_bfs_edit.hpp) ----
+// The frontier kernels are bound by instruction issue (profiles/r04_frontier_experiments.txt), and half of what they issue is the matrix
+// row of a child on 64-bit words — register pairs, 64-bit shifts — of which the band of up to 7 errors uses a third.  The reference's own
+// sizing rule (bitparallelmatrix.h:311-316) with WORD 32 and BLOCK 8 gives MATRIX_MAX_ED = (32 - 8 - 2) / 3 = 7, LEFT = 15, DIAG = 14: the
+// band (Wv <= 14 columns left of the diagonal, Wh <= 7 right of it) lies in bits r % 8 .. r % 8 + 21, the rightmost active column below bit
+// 29.  Cells of at most maxED are the same in every matrix that contains the band (see above), hence valid rows, final-column values,
+// cluster centres and first columns; `onlyVerticalGapsLeft` is answered as the reference's 64-bit matrix would answer it
+// (onlyVerticalGapsLeftAs, refWord 64).  As for the 16-row matrix of 11 ... 13 errors this was settled on the CPU before the device code
+// was written: the oracle's search on BitParallelEDT<uint32_t, 8> against the search on the reference's matrices — occurrences and EVERY
+// counter (tests/test_narrow_block_matrix.py, tools/soak_narrow32.py).  A phase whose first column does not fit (Wv > DIAG) raises
+// FLAG_NARROW_MATRIX and the host runs the batch on the 64-bit geometry instead.
+// The match words stay those of the contexts (64-bit words of 32-row blocks, LEFT 21): bit p of the 8-row block a row lies in is bit
+// p + 8 s + (21 - 15) of its 32-row block's word (s = the 8-row block's number within the 32 rows) — columns left of the sequence read as
+// ones and columns beyond it as zeros in both.
+constexpr uint32_t MXS_BLOCK = 8, MXS_DIAG = 14, MXS_LEFT = 15, MXS_MAX_ED = 7;
+__device__ __forceinline__ uint32_t matchWordSmall(uint64_t M64, uint32_t i) {
+    return (uint32_t)(M64 >> (((i % MX_BLOCK) / MXS_BLOCK) * MXS_BLOCK + (MX_LEFT - MXS_LEFT)));
+}
+template <uint32_t BLOCK, uint32_t DIAG>
+__device__ __forceinline__ bool onlyVerticalGapsLeftAs(const MatGeom& g, uint32_t i, uint32_t HN, uint32_t refWord) {
+    const uint32_t refBlock = refWord / 2u, refMaxED = (refWord - refBlock - 2u) / 3u, refLEFT = 2u * refMaxED + 1u, refDIAG = 2u * refMaxED;
+    if (i + refLEFT < g.n) return false;
+    if (refDIAG + g.n - (i / refBlock) * refBlock > refWord) return true;
+    const uint32_t r = i % BLOCK;
+    const int bb = (int)(DIAG - g.Wv + r + 1u);           // column i - Wv + 1
+    const int be = (int)(DIAG + r) + ((int)g.n - (int)i); // one past column n - 1
+    if (be > 32) return false;
+    if (be <= bb) return true;
+    const uint32_t mask = (be >= 32 ? ~0u : ((1u << be) - 1u)) & ~((1u << bb) - 1u);
+    return (~HN & mask) == 0u;
 }
 
 // The two in-text matrices behind one set of names (k_verify_stage, forwardPass)

@@ -76,10 +76,12 @@ enum : uint32_t { FLAG_ITEM_OVERFLOW = 1, FLAG_FMOCC_OVERFLOW = 2, FLAG_TEXT_OVE
                   // searchstrategy.cpp:404-407, and its CLI caps the k-mer size accordingly, alignparameters.cpp:1070-1114)
                   FLAG_SEED_OVERLAP = 4096,
                   // naive backtracking (dev_bfs_naive.hpp): its node queue
-                  FLAG_NAIVE_Q = 8192 };
+                  FLAG_NAIVE_Q = 8192,
+                  // a phase whose first column does not fit the 32-bit in-index matrix (dev_bfs_edit.hpp: GeoN32): the batch re-runs on GeoN
+                  FLAG_NARROW_MATRIX = 16384 };
 constexpr uint32_t FLAG_BITS[] = {FLAG_ITEM_OVERFLOW, FLAG_FMOCC_OVERFLOW, FLAG_TEXT_OVERFLOW, FLAG_CAPACITY,
                                   FLAG_UNSUPPORTED_READ, FLAG_DFS_OVERFLOW, FLAG_TRACE_RULE, FLAG_BFS_Q, FLAG_BFS_EV,
-                                  FLAG_BFS_F, FLAG_BFS_CTX, FLAG_BFS_ARENA, FLAG_SEED_OVERLAP, FLAG_NAIVE_Q};
+                                  FLAG_BFS_F, FLAG_BFS_CTX, FLAG_BFS_ARENA, FLAG_SEED_OVERLAP, FLAG_NAIVE_Q, FLAG_NARROW_MATRIX};
 constexpr bool flagBitsDisjoint() {
     uint32_t seen = 0;
     for (uint32_t b : FLAG_BITS) {

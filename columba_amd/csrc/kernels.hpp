@@ -271,23 +271,11 @@ __global__ void k_bfs_finish(BfsBufs B, Queues q) { // one block: per-block coun
     __shared__ unsigned long long s[3];
     if (threadIdx.x < 3) s[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t j = threadIdx.x; j < BFS_GRID * 4; j += blockDim.x) {
+    for (uint32_t j = threadIdx.x; j < BFS_GRID_CNT * 4; j += blockDim.x) {
         const unsigned long long v = B.blockCnt[j];
         if ((j & 3u) < 3u && v) atomicAdd(&s[j & 3u], v);
     }
     __syncthreads();
-#if CMB_BFS_WALK
-    // bfsExpandWalk: what is left of the wavefronts' item chunks becomes holes (the consumers skip them)
-    if (B.wcSave) {
-        const uint32_t nW = B.gridX * 4u;
-        for (uint32_t w = threadIdx.x; w < nW; w += blockDim.x) {
-            const uint32_t base = B.wcSave[(size_t)w * WALK_SAVE_U32], used = B.wcSave[(size_t)w * WALK_SAVE_U32 + 1],
-                           size = B.wcSave[(size_t)w * WALK_SAVE_U32 + 2];
-            for (uint32_t i = used; i < size; i++)
-                if (base + i < q.itemCap) q.items[base + i] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
-        }
-    }
-#endif
     if (threadIdx.x == 0) {
         atomicAdd(&q.counters[0], s[0]);  // NODE_COUNTER
         atomicAdd(&q.counters[7], s[1]);  // EXPANSIONS
@@ -310,24 +298,14 @@ k_bfs_start(DevIndex ix, const DevStrategyKT<Geo::MP>* __restrict__ stp, BfsBufs
 // one level: blocks [0, BFS_GRID) expand the frontier, blocks [BFS_GRID, BFS_GRID + BFS_GRID_EV) handle the events
 // of the same pass (both only append to the queues of pass + 1, so they run side by side)
 #ifndef CMB_BFS_WAVES
-#if CMB_BFS_WALK == 1
-#define CMB_BFS_WAVES 2 // wavefronts per SIMD k_bfs_pass is built for (bfsExpandWalk: 64 KB of LDS per block, bound by instruction issue)
-#else
-#define CMB_BFS_WAVES 4 // (128 VGPRs: bfsExpand)
-#endif
+#define CMB_BFS_WAVES 4 // wavefronts per SIMD k_bfs_pass is built for (128 VGPRs at most)
 #endif
 template <class Geo = GeoN>
 __global__ void __launch_bounds__(256, Geo::MP == MAXP ? CMB_BFS_WAVES : 2)
 k_bfs_pass(DevIndex ix, const DevStrategyKT<Geo::MP>* __restrict__ stp, BfsBufs B, uint32_t pass, const uint64_t* __restrict__ offs,
            uint32_t gw, const uint32_t* __restrict__ G, const PartOutT<Geo::MP>* __restrict__ parts, Queues q) {
     if (blockStopped(q)) return;
-#if CMB_BFS_WALK == 2
-    if (blockIdx.x < B.gridX) bfsExpandWave<Geo>(ix, B, pass, q, blockIdx.x, B.gridX);
-#elif CMB_BFS_WALK
-    if (blockIdx.x < B.gridX) bfsExpandWalk<Geo>(ix, B, pass, q, blockIdx.x, B.gridX);
-#else
     if (blockIdx.x < B.gridX) bfsExpand<Geo>(ix, B, pass, q, blockIdx.x, B.gridX);
-#endif
     else bfsHeavy<false, FmTraits, Geo>(stp, B, pass, nullptr, 0u, offs, gw, G, parts, q, blockIdx.x - B.gridX, B.gridEv);
 }
 

@@ -640,6 +640,7 @@ struct cmb_move_batch {
     DevStrategyK hostStrat{};
     // more than 8 parts (the greedy schemes under Hamming distance at 8 ... 13 errors): the wide tables, as on the FM-index
     bool wide = false;
+    bool noSmallMatrix = false; // a phase of an earlier run did not fit the 32-bit in-index matrix (GeoN32): this batch stays on GeoN
     DevStrategyKT<MAXP_WIDE> hostStratW{};
     MvBuf<DevStrategyKT<MAXP_WIDE>> stratW;
     MvBuf<PartOutT<MAXP_WIDE>> partsW;
@@ -1089,11 +1090,16 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                 B.blockCnt = b->blockCnt.p;
                 B.fmX = b->fm.p;
                 B.rowSteps = nullptr;
+                B.narrowWv = getenv("CMB_TEST_NARROW_WV") ? (uint32_t)std::max(0, atoi(getenv("CMB_TEST_NARROW_WV"))) : 0xFFFFu;
+                // up to 7 errors the in-index matrix runs on 32-bit words (GeoN32, dev_matrix.hpp: MXS_*) unless a phase did not fit it (CMB_MATRIX64=1: never)
+                const bool small32 = !b->wide && b->k <= MXS_MAX_ED && !b->noSmallMatrix && !getenv("CMB_MATRIX64");
                 const dim3 gStart(std::min<uint32_t>((nTasks + 255) / 256, BFS_GRID));
                 if (geoX)
                     hipLaunchKernelGGL(k_mvs_start<GeoX>, gStart, dim3(256), 0, s, b->stratW.p, B, b->tasks.p, nTasks, dOffs, b->gw, b->G.p, b->partsW.p, q);
                 else if (b->wide)
                     hipLaunchKernelGGL(k_mvs_start<GeoW>, gStart, dim3(256), 0, s, b->stratW.p, B, b->tasks.p, nTasks, dOffs, b->gw, b->G.p, b->partsW.p, q);
+                else if (small32)
+                    hipLaunchKernelGGL(k_mvs_start<GeoN32>, gStart, dim3(256), 0, s, b->strat.p, B, b->tasks.p, nTasks, dOffs, b->gw, b->G.p, b->parts.p, q);
                 else
                     hipLaunchKernelGGL(k_mvs_start<GeoN>, gStart, dim3(256), 0, s, b->strat.p, B, b->tasks.p, nTasks, dOffs, b->gw, b->G.p, b->parts.p, q);
                 std::vector<uint32_t> hc(cntWords);
@@ -1108,6 +1114,9 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                         else if (b->wide)
                             hipLaunchKernelGGL(k_mvs_pass<GeoW>, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->stratW.p, B, pass, dOffs, b->gw, b->G.p,
                                                b->partsW.p, q);
+                        else if (small32)
+                            hipLaunchKernelGGL(k_mvs_pass<GeoN32>, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->strat.p, B, pass, dOffs, b->gw, b->G.p,
+                                               b->parts.p, q);
                         else
                             hipLaunchKernelGGL(k_mvs_pass<GeoN>, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->strat.p, B, pass, dOffs, b->gw, b->G.p,
                                                b->parts.p, q);
@@ -1128,6 +1137,10 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                 hipLaunchKernelGGL(k_mvs_finish, dim3(1), dim3(256), 0, s, B, q);
                 tm.end("k_dfs");
                 MV_HIPCHK(hipGetLastError());
+                if (hcnt[3] & FLAG_NARROW_MATRIX) { // (a first column wider than the small matrix holds: once more on the reference's words)
+                    b->noSmallMatrix = true;
+                    continue;
+                }
                 if (hcnt[3] & FLAG_CAPACITY) return failWith(CMB_ERR_INTERNAL, "device search capacity exceeded (band width / descendants)");
                 if (hcnt[3] & (FLAG_BFS_Q | FLAG_BFS_EV | FLAG_BFS_F | FLAG_BFS_CTX | FLAG_BFS_ARENA | FLAG_FMOCC_OVERFLOW)) {
                     if (hcnt[3] & FLAG_BFS_Q) b->qCap = std::max<size_t>(2 * b->qCap, (size_t)peakQ + peakQ / 4);

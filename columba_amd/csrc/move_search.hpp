@@ -67,7 +67,6 @@ struct MvTraits {
     typedef MvPair Pair;
     typedef MvTask Task;
     static constexpr uint32_t PAIR_U4 = 3;
-    static constexpr bool CHUNKED_Q = false; // (mvExpand reads the node queue entry by entry)
     static __device__ __forceinline__ Pair unpack(const uint4& a, const uint4& b, const uint4& c) {
         const uint64_t w0 = u64of(a.x, a.y), w1 = u64of(a.z, a.w), w2 = u64of(b.x, b.y), w3 = u64of(b.z, b.w), w4 = u64of(c.x, c.y),
                        w5 = u64of(c.z, c.w);
@@ -664,11 +663,13 @@ k_mvs_exact(MvSearchIndex sx, const DevStrategyKT<MP>* __restrict__ stp, uint32_
 // Expansion of a frontier node (extendFMPos + branchAndBound + the stack loop of recApproxMatchEdit, indexinterface.cpp:506-561,
 // :675-697, without the in-text switch this flavour does not have).  Node = range pair (3 planes) + the three planes of
 // dev_bfs_edit.hpp: {row | score << 16, ctx, fc, RAC bit | mode << 8} {HP, HN} {final-column distances}.
-// Geo: the record geometry of dev_bfs_edit.hpp — GeoN (up to 7 errors: the instance of BASELINE configs[4], unchanged), GeoW (8 ... 10),
+// Geo: the record geometry of dev_bfs_edit.hpp — GeoN32 (up to 7 errors, the instance of BASELINE configs[4]: the in-index matrix on
+// 32-bit words since round 4; GeoN, the reference's 64-bit words, for a batch one of whose phases does not fit it), GeoW (8 ... 10),
 // GeoX (11 ... 13: the in-index matrix with 16-row blocks).
 template <class Geo = GeoN>
 __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uint32_t pass, const Queues& q, uint32_t bid, uint32_t nBlocks) {
     __shared__ uint32_t sh[4][5];
+    typedef typename Geo::W W; // the word of a matrix row (dev_bfs_edit.hpp: 64 bits, or 32 for GeoN32)
     typedef typename Geo::Pack EdPack;
     constexpr uint32_t ED_CELLS = Geo::CELLS, ED_MAX = Geo::ED_MAX, EV_U4 = 1u + Geo::PK_U4;
     constexpr uint32_t PU = MvTraits::PAIR_U4, FU = PU + 1;
@@ -685,14 +686,14 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
         uint32_t kinds = 0; // 4 bits per child: kind | needF << 2
         uint32_t row1 = 0, ctx = 0, fcP = BFS_NONE;
         uint4 pk[4][3]; // the children's range pairs, packed as they are stored (twelve registers each instead of twenty-one)
-        uint64_t cHP[4], cHN[4];
+        W cHP[4], cHN[4];
         uint32_t cMeta[4]; // score << 16 | RAC bit << 8 | final-column distance
         MatGeom g{};
         uint32_t clSize = 0;
         int md = 0;
         MvPair parent{};
         uint32_t row = 0, score = 0, pRac = 0, blk = 0;
-        uint64_t pHP = 0, pHN = 0;
+        W pHP = 0, pHN = 0;
         uint4 mA = make_uint4(0, 0, 0, 0), mB = mA;
         const uint4* Cx = B.C;
         if (act) {
@@ -704,7 +705,7 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
             score = n1.x >> 16;
             md = (int)((n1.w >> 8) & 3u);
             Cx = B.C + (size_t)CMB_IDX(ctx, B.cCap, 1) * B.ctxU4;
-            blk = (row + 1) / Geo::BLOCK;
+            blk = (row + 1) / Geo::CTX_BLOCK;
             const uint4 hot = Cx[CTX_HOT];
             mA = Cx[CTX_M + 2 * blk];
             mB = Cx[CTX_M + 1 + 2 * blk];
@@ -714,8 +715,7 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
             g.Wh = (hot.y >> 23) & 15u;
             g.maxED = (hot.y >> 27) & 15u;
             clSize = hot.w >> 23;
-            pHP = u64of(n2.x, n2.y);
-            pHN = u64of(n2.z, n2.w);
+            Geo::unpackRow(n2, pHP, pHN);
             pRac = n1.w & 63u;
         }
         // ---- walk: an expansion that yields exactly one plain node (outside the final column) is followed at once by the
@@ -726,8 +726,8 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
         for (uint32_t step = 0; step < B.chain; step++) { // (wave-uniform exit below)
             if (walking) {
                 row1 = row + 1;
-                if (row1 / Geo::BLOCK != blk) { // the walk crossed into the next row block: its match words
-                    blk = row1 / Geo::BLOCK;
+                if (row1 / Geo::CTX_BLOCK != blk) { // the walk crossed into the next block of match words
+                    blk = row1 / Geo::CTX_BLOCK;
                     mA = Cx[CTX_M + 2 * blk];
                     mB = Cx[CTX_M + 1 + 2 * blk];
                 }
@@ -754,8 +754,8 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
                 for (uint32_t c = 0; c < 4; c++) {
                     if (!(mask >> c & 1u)) continue;
                     cChildren++;
-                    const uint64_t M = c == 0 ? u64of(mA.x, mA.y) : c == 1 ? u64of(mA.z, mA.w) : c == 2 ? u64of(mB.x, mB.y) : u64of(mB.z, mB.w);
-                    uint64_t HP = pHP, HN = pHN, RAC = 1ull << pRac, D0;
+                    const W M = Geo::mword(c == 0 ? u64of(mA.x, mA.y) : c == 1 ? u64of(mA.z, mA.w) : c == 2 ? u64of(mB.x, mB.y) : u64of(mB.z, mB.w), row1);
+                    W HP = pHP, HN = pHN, RAC = Geo::racBit(pRac), D0;
                     uint32_t sc = score;
                     const bool valid = Geo::row(g, row1, M, HP, HN, D0, RAC, sc);
                     if (!valid && !inFC) continue; // pruned when popped (branchAndBound returns true, :560)
@@ -770,11 +770,11 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
                     kinds |= res << (4 * c);
                     cHP[c] = HP, cHN[c] = HN;
                     if (sc > 0xFFFFu) flags |= FLAG_CAPACITY;
-                    cMeta[c] = (sc << 16) | (((uint32_t)__ffsll((unsigned long long)RAC) - 1u) << 8) | aux;
+                    cMeta[c] = (sc << 16) | (Geo::racIdx(RAC) << 8) | aux;
                 }
                 const bool single = kinds == (uint32_t)KIND_NODE || kinds == ((uint32_t)KIND_NODE << 4) || kinds == ((uint32_t)KIND_NODE << 8) ||
                                     kinds == ((uint32_t)KIND_NODE << 12);
-                if (single && step + 1u < B.chain && row1 + 1u < B.ctxMblk * Geo::BLOCK) {
+                if (single && step + 1u < B.chain && row1 + 1u < B.ctxMblk * Geo::CTX_BLOCK) {
 #pragma unroll
                     for (uint32_t c = 0; c < 4; c++)
                         if (kinds == ((uint32_t)KIND_NODE << (4 * c))) {
@@ -828,7 +828,7 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
                     const uint32_t o = oNode++;
                     qStore(Qo + o, pk[c][0]), qStore(Qo + (size_t)qCap + o, pk[c][1]), qStore(Qo + (size_t)2 * qCap + o, pk[c][2]);
                     qStore(Qo + (size_t)PU * qCap + o, make_uint4(row1 | (cMeta[c] & 0xFFFF0000u), ctx, fc, ((cMeta[c] >> 8) & 63u) | ((uint32_t)md << 8)));
-                    qStore(Qo + (size_t)(PU + 1) * qCap + o, make_uint4((uint32_t)cHP[c], (uint32_t)(cHP[c] >> 32), (uint32_t)cHN[c], (uint32_t)(cHN[c] >> 32)));
+                    qStore(Qo + (size_t)(PU + 1) * qCap + o, Geo::packRow(cHP[c], cHN[c]));
                     if (wantF) {
                         EdPack p2 = pack;
                         edPut(p2, cell, cMeta[c] & 0xFFu);

@@ -688,4 +688,12 @@ void orc_move_kmer_table(void* h, uint32_t wordSize, orc_move_range* out) {
     for (size_t i = 0; i < t.size(); i++) out[i] = fromPair(t[i]);
 }
 
+// the 32-bit narrow-block experiment: {phases on the 32-bit matrix, phases that fell back}; reset on request
+void orc_narrow32_stats(uint64_t* out, int reset) {
+    for (int i = 0; i < 2; i++) {
+        out[i] = orc::g_narrow32Stats[i].load();
+        if (reset) orc::g_narrow32Stats[i].store(0);
+    }
+}
+
 } // extern "C"

@@ -10,9 +10,12 @@
 // the lines it follows.
 // ============================================================================
 #pragma once
+#include <atomic>
 #include "oracle_core.hpp"
 
 namespace orc {
+// the 32-bit narrow-block experiment (ORC_NARROW_BLOCKS=32): phases run on the 32-bit matrix / phases that fell back to the reference's
+inline std::atomic<uint64_t> g_narrow32Stats[2];
 
 // ----------------------------------------------------------------------------
 // Occurrence value types (indexhelpers.h:289, :1283, :1353, :1544)
@@ -683,8 +686,10 @@ template <class IX> class MatcherT {
     std::vector<BitParallelED64> matrices;
     std::vector<BitParallelED128> matrices128; // the parts of a search whose upper bound exceeds 10 (indexinterface.cpp:391-398)
     std::vector<BitParallelED64N> matricesN;   // ORC_NARROW_BLOCKS=1: the narrow-block experiment (oracle_core.hpp)
+    std::vector<BitParallelED32N> matricesN32; // ORC_NARROW_BLOCKS=32 (or "32inverted"): 32-bit words, 8-row blocks, up to 7 errors
     const bool narrowBlocks = getenv("ORC_NARROW_BLOCKS") != nullptr;
-    const bool narrowBroken = narrowBlocks && std::string(getenv("ORC_NARROW_BLOCKS")) == "inverted";
+    const bool narrow32 = narrowBlocks && std::string(getenv("ORC_NARROW_BLOCKS")).rfind("32", 0) == 0;
+    const bool narrowBroken = narrowBlocks && std::string(getenv("ORC_NARROW_BLOCKS")).find("inverted") != std::string::npos;
     BitParallelED64 fullReadMatrices[2];
     BitParallelED128 fullReadMatrices128[2]; // in-text verification beyond the 64-bit matrix (fmindex.h:240-246)
 
@@ -899,7 +904,26 @@ template <class IX> class MatcherT {
                             const std::vector<FMPosExt>& descNotPrevDir,
                             const std::vector<uint16_t>& initNotPrevDir) {
         const size_t matrixIdx = s.getPart(idx) + (s.getDirection(idx) == BACKWARD) * s.getNumParts();
-        if (narrowBlocks) { // (experiment: ONE narrow-block matrix type in place of both, answering the predicate as the part's own would)
+        if (narrow32 && s.getUpperBound(idx) <= BitParallelED32N::MATRIX_MAX_ED) { // (the device's GeoN32; a phase it cannot hold falls back below)
+            if (matricesN32.size() < matrices.size()) matricesN32.resize(matrices.size());
+            // Wv = |initED| - 1 + maxED - initED.back() must not exceed DIAG (14): the phase otherwise runs on the reference's matrix, as the
+            // device re-runs such a batch on GeoN (FLAG_CAPACITY)
+            const bool dSw = s.getDirectionSwitch(idx);
+            const std::vector<uint16_t>& ie = dSw ? initNotPrevDir : initPrevDir;
+            uint32_t wv = s.getUpperBound(idx);
+            if (!ie.empty()) {
+                const uint16_t prevED = dSw ? *std::min_element(ie.begin(), ie.end()) : ie[0];
+                wv = (uint32_t)ie.size() - 1 + s.getUpperBound(idx) - (ie.back() + (startMatch.distance - prevED));
+            }
+            if (wv <= BitParallelED32N::DIAG_R0) {
+                g_narrow32Stats[0].fetch_add(1, std::memory_order_relaxed);
+                matricesN32[matrixIdx].emulate = 64u | (narrowBroken ? 256u : 0u);
+                recApproxMatchEditOn(&matricesN32[matrixIdx], s, startMatch, occ, parts, idx, descPrevDir, initPrevDir, descNotPrevDir, initNotPrevDir);
+                return;
+            }
+            g_narrow32Stats[1].fetch_add(1, std::memory_order_relaxed);
+            recApproxMatchEditOn(&matrices[matrixIdx], s, startMatch, occ, parts, idx, descPrevDir, initPrevDir, descNotPrevDir, initNotPrevDir);
+        } else if (narrowBlocks && !narrow32) { // (experiment: ONE narrow-block matrix type in place of both, answering the predicate as the part's own would)
             if (matricesN.size() < matrices.size()) matricesN.resize(matrices.size());
             matricesN[matrixIdx].emulate = (s.getUpperBound(idx) <= BitParallelED64::MATRIX_MAX_ED ? 64u : 128u) | (narrowBroken ? 256u : 0u);
             recApproxMatchEditOn(&matricesN[matrixIdx], s, startMatch, occ, parts, idx, descPrevDir, initPrevDir, descNotPrevDir, initNotPrevDir);
@@ -1377,7 +1401,8 @@ template <class IX> class MatcherT {
         stacks.assign(numParts, {});
         matrices.assign(2 * parts.size(), BitParallelED64());
         matrices128.assign(k > BitParallelED64::MATRIX_MAX_ED ? 2 * parts.size() : 0, BitParallelED128());
-        matricesN.assign(narrowBlocks ? 2 * parts.size() : 0, BitParallelED64N());
+        matricesN.assign(narrowBlocks && !narrow32 ? 2 * parts.size() : 0, BitParallelED64N());
+        matricesN32.assign(narrow32 ? 2 * parts.size() : 0, BitParallelED32N());
         for (const Search& s : searches) doRecSearch(s, parts, occs, exactMatchRanges);
     }
 

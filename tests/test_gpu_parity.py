@@ -209,6 +209,23 @@ def test_match_batch_parity(world, spec, metric, partition, k):
         assert cnt["SEARCH_STARTED"] > 0 and cnt["IN_TEXT_STARTED"] > 0  # both regimes exercised
 
 
+@pytest.mark.parametrize("spec,partition,k,env", [
+    ("multiple_opt", "dynamic", 4, {"CMB_MATRIX64": "1"}),      # the reference's 64-bit words in the frontier (GeoN)
+    ("columba", "dynamic", 7, {"CMB_MATRIX64": "1"}),
+    ("kianfar", "static", 3, {"CMB_MATRIX64": "1"}),
+    ("columba", "dynamic", 6, {"CMB_TEST_NARROW_WV": "3"}),     # a phase "too wide" for the small matrix: the batch re-runs on GeoN
+    ("multiple_opt", "uniform", 4, {"CMB_TEST_NARROW_WV": "0"}),
+])
+def test_in_index_matrix_geometries(world, monkeypatch, spec, partition, k, env):
+    """Round 4: up to 7 errors the frontier carries the in-index matrix on 32-bit words with 8-row blocks (GeoN32) — every parity test above
+    runs on it.  Here the same results on the reference's 64-bit words, and through the re-run a phase triggers whose first column does not
+    fit the small matrix (the bound lowered by the test hook so that it happens)."""
+    for n, v in env.items():
+        monkeypatch.setenv(n, v)
+    reads = synth.sample_reads(world["genome"], 400 if spec == "kianfar" else 2000, 150, seed=300 + k, n_frac=0.02)
+    _compare(world, spec, "edit", partition, k, reads)
+
+
 @pytest.mark.parametrize("name,dirname,mode,metric,partition,k", [
     ("kuch1", "kuch_k+1", "custom", "edit", "dynamic", 4),
     ("kuch1", "kuch_k+1", "custom", "edit", "static", 3),

@@ -7,7 +7,11 @@ most maxED are the same in any matrix that contains the band, so valid rows, fin
 agree; the open question was `onlyVerticalGapsLeft`, which reads HN bits of cells that may exceed maxED and, in the reference, shifts by a
 negative count near the end of a block (a region where its answer is `true` whatever the bits hold).  With ORC_NARROW_BLOCKS=1 the
 oracle's search runs every part on BitParallelEDT<uint64_t, 16> and answers that predicate as the part's own matrix would
-(onlyVerticalGapsLeftAs); occurrences and every counter must equal the run on the reference's matrices."""
+(onlyVerticalGapsLeftAs); occurrences and every counter must equal the run on the reference's matrices.
+
+Round 4, the same question one size down: up to 7 errors a 32-bit word with 8-row blocks holds the band by the same bound ((32 - 8 - 2) / 3
+= 7, LEFT 15, DIAG 14) — ORC_NARROW_BLOCKS=32 runs every part on BitParallelEDT<uint32_t, 8>, the matrix the device's frontier kernels
+carry per node since round 4 (dev_bfs_edit.hpp: GeoN32); tools/soak_narrow32.py is the long run (300 configurations, 5.1e7 phases)."""
 import os
 import sys
 
@@ -60,6 +64,48 @@ def test_the_experiment_sees_the_predicate(world):
     os.environ["ORC_NARROW_BLOCKS"] = "inverted"
     try:
         _, _, b_cnt = op.match_batch(world["orc"][0], st, 12, reads, threads=8)
+    finally:
+        del os.environ["ORC_NARROW_BLOCKS"]
+    assert a_cnt["NODE_COUNTER"] != b_cnt["NODE_COUNTER"]
+
+
+@pytest.mark.parametrize("spec,partition,k,length,switch", [("multiple_opt", "dynamic", 4, 150, 4), ("columba", "dynamic", 7, 150, 4), ("columba", "uniform", 5, 480, 0),
+                                                            ("kuch1", "static", 3, 100, 0), ("kianfar", "dynamic", 4, 60, 4), ("columba", "static", 6, 60, 4),
+                                                            ("pigeon", "dynamic", 2, 250, 0), ("columba", "dynamic", 7, 40, 0)])
+def test_the_32_bit_matrix_stands_in_up_to_seven_errors(world, spec, partition, k, length, switch):
+    import ctypes as C
+    import schemes_py as sp
+    op = world["op"]
+    reads = synth.sample_reads(world["g"], 150 if spec == "kianfar" else 400, length, seed=90 + k + length, n_frac=0.01, edit_choices=(0, 1, 2, k - 1, k, k, k + 1))
+    reads += [world["g"][:length].tobytes(), world["g"][-length - 1:-1].tobytes(), b"N" * length]
+    st = op.OracleStrategy(sp.BY_NAME[spec], "edit", partition)
+    os.environ.pop("ORC_NARROW_BLOCKS", None)
+    a_occ, a_off, a_cnt = op.match_batch(world["orc"][switch], st, k, reads, threads=8)
+    L = C.CDLL(op.build())
+    stats = (C.c_uint64 * 2)()
+    L.orc_narrow32_stats(stats, 1)
+    os.environ["ORC_NARROW_BLOCKS"] = "32"
+    try:
+        b_occ, b_off, b_cnt = op.match_batch(world["orc"][switch], st, k, reads, threads=8)
+    finally:
+        del os.environ["ORC_NARROW_BLOCKS"]
+    L.orc_narrow32_stats(stats, 1)
+    assert stats[0] > 100, "the experiment did not run on the 32-bit matrix"
+    assert len(a_occ) > 100
+    assert np.array_equal(a_off, b_off) and np.array_equal(a_occ, b_occ)
+    assert a_cnt == b_cnt, {n: (a_cnt[n], b_cnt[n]) for n in a_cnt if a_cnt[n] != b_cnt[n]}
+
+
+def test_the_32_bit_experiment_sees_the_predicate(world):
+    import schemes_py as sp
+    op = world["op"]
+    reads = synth.sample_reads(world["g"], 300, 150, seed=8, n_frac=0.01, edit_choices=(0, 2, 4, 5, 6))
+    st = op.OracleStrategy(sp.BY_NAME["columba"], "edit", "dynamic")
+    os.environ.pop("ORC_NARROW_BLOCKS", None)
+    _, _, a_cnt = op.match_batch(world["orc"][0], st, 6, reads, threads=8)
+    os.environ["ORC_NARROW_BLOCKS"] = "32inverted"
+    try:
+        _, _, b_cnt = op.match_batch(world["orc"][0], st, 6, reads, threads=8)
     finally:
         del os.environ["ORC_NARROW_BLOCKS"]
     assert a_cnt["NODE_COUNTER"] != b_cnt["NODE_COUNTER"]
