@@ -1082,7 +1082,7 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                 B.ctxMblk = geoX ? CTX_MBLK_X : ctxMblkFor(b->maxLen);
                 B.aCap = (uint32_t)std::min<size_t>(b->A.n, 0xFFFFFFF0u);
                 B.chain = getenv("CMB_MVS_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("CMB_MVS_CHAIN"))) : MVS_CHAIN;
-                B.gridX = getenv("CMB_MVS_GRID") ? (uint32_t)std::min<int>(BFS_GRID, std::max(1, atoi(getenv("CMB_MVS_GRID")))) : BFS_GRID_X;
+                B.gridX = getenv("CMB_MVS_GRID") ? (uint32_t)std::min<int>(BFS_GRID, std::max(1, atoi(getenv("CMB_MVS_GRID")))) : (b->wide ? MVS_GRID_X_WIDE : MVS_GRID_X);
                 B.gridEv = BFS_GRID_EV;
                 B.nq = b->bfsCnt.p;
                 B.ne = b->bfsCnt.p + (maxPass + 2);

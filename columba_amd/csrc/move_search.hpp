@@ -161,8 +161,11 @@ __device__ __forceinline__ MvRange selRange(bool c, const MvRange& a, const MvRa
     r.valid = c ? a.valid : b.valid;
     return r;
 }
+// PACK: the children go straight into their packed form (MvTraits::pack, three uint4 each: twelve registers instead of twenty-one), one
+// after the other — the four unpacked pairs never exist side by side (`child` is not touched).
+template <bool PACK = false>
 __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const int mode, const MvPair& parent, MvPair child[4], uint32_t& rows,
-                                               const uint32_t need = 0xFu) {
+                                               const uint32_t need = 0xFu, uint4 (*pk)[3] = nullptr) {
     const bool fw = mode == 0;
     // the table of the direction, chosen FIELD BY FIELD: a reference `fw ? ix.rev : ix.fwd` is a choice between two addresses — every use of
     // a field then fetched the field from memory first (a pointer load and a wait in front of every sample and row access)
@@ -188,6 +191,10 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
     {
         uint64_t runF = trivial.beginRun, posF = trivial.begin, runB = trivial.endRun, posB = trivial.end - 1;
         uint4 rowF = t.rows[runF], rowB = t.rows[runB];
+        // the rows the two cursors move to next are requested WITH the first two (a range within one run asks for its own row again: the
+        // same address): a scan of up to four rows — the average is 3.6 — costs one memory round trip, and every later turn finds its rows
+        // requested a turn earlier.  Only rows a cursor moves to are counted.
+        uint4 preF = t.rows[runF < trivial.endRun ? runF + 1 : runF], preB = t.rows[runB > trivial.beginRun ? runB - 1 : runB];
         rows += 2;
         bool fDone = false, bDone = false;
         while (true) {
@@ -238,21 +245,21 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
             // the next rows of both cursors are REQUESTED TOGETHER: nothing between the two loads reads a reply (with `posF = rowIn(rowF)`
             // between them hipcc waited for the front row before it asked for the back row: two round trips per step of the scan)
             const uint64_t posBNext = rowIn(rowB) - 1;
-            uint4 nextF = rowF, nextB = rowB;
-            if (!fDone) nextF = t.rows[runF + 1];
-            if (!bDone) nextB = t.rows[runB - 1];
             if (!fDone) {
                 runF++;
-                rowF = nextF;
+                rowF = preF;
                 rows++;
                 posF = rowIn(rowF);
             }
             if (!bDone) {
                 posB = posBNext;
                 runB--;
-                rowB = nextB;
+                rowB = preB;
                 rows++;
             }
+            // (unconditional loads, clamped to the range's runs: a cursor that has finished asks for its last row again)
+            preF = t.rows[runF < trivial.endRun ? runF + 1 : runF];
+            preB = t.rows[runB > trivial.beginRun ? runB - 1 : runB];
         }
         found &= seen | 1u;
     }
@@ -309,7 +316,8 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
     uint32_t mask = 0;
 #pragma unroll
     for (uint32_t c = 0; c < 4; c++) {
-        MvPair& ch = child[c];
+        MvPair one;
+        MvPair& ch = PACK ? one : child[c];
         if (!(found >> (c + 1) & 1u)) { // addChar: setEmpty() (moverepr.cpp:313-316), SARangePair(range1, range1, 0, false, 0)
             ch.sa = {0, 0, 0, 0, false};
             ch.rev = ch.sa;
@@ -335,6 +343,7 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
             ch.sa = selRange(fw, second, range1);
             ch.rev = selRange(fw, range1, second);
             ch.depth = parent.depth + 1;
+            if (PACK) MvTraits::pack(ch, pk[c][0], pk[c][1], pk[c][2]);
         }
         cum += width;
     }
@@ -669,6 +678,10 @@ k_mvs_exact(MvSearchIndex sx, const DevStrategyKT<MP>* __restrict__ stp, uint32_
 template <class Geo = GeoN>
 __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uint32_t pass, const Queues& q, uint32_t bid, uint32_t nBlocks) {
     __shared__ uint32_t sh[4][5];
+    // per-lane state that is touched once per expansion lives in LDS, [field][lane], not in registers (the kernel waits for dependent row
+    // fetches: what it can keep in flight is set by its registers): the four match words of the row block
+    __shared__ uint64_t ldsM[4][256];
+    const uint32_t tid = threadIdx.x;
     typedef typename Geo::W W; // the word of a matrix row (dev_bfs_edit.hpp: 64 bits, or 32 for GeoN32)
     typedef typename Geo::Pack EdPack;
     constexpr uint32_t ED_CELLS = Geo::CELLS, ED_MAX = Geo::ED_MAX, EV_U4 = 1u + Geo::PK_U4;
@@ -679,7 +692,7 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
     uint4* __restrict__ Eo = B.Ev[(pass + 1u) & 1u];
     const uint32_t qCap = B.qCap;
     uint32_t flags = 0;
-    unsigned long long cChildren = 0, cExp = 0, cRows = 0;
+    uint32_t cChildren = 0, cExp = 0, cRows = 0; // (per lane and launch: far below 2^32)
     for (uint32_t base = bid * 256u; base < nIn; base += nBlocks * 256u) { // block-uniform trip count
         const uint32_t i = base + threadIdx.x;
         const bool act = i < nIn;
@@ -688,13 +701,11 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
         uint4 pk[4][3]; // the children's range pairs, packed as they are stored (twelve registers each instead of twenty-one)
         W cHP[4], cHN[4];
         uint32_t cMeta[4]; // score << 16 | RAC bit << 8 | final-column distance
-        MatGeom g{};
-        uint32_t clSize = 0;
+        uint32_t hotY = 0, clSize = 0; // (the band geometry stays packed as the context's hot word holds it)
         int md = 0;
         MvPair parent{};
         uint32_t row = 0, score = 0, pRac = 0, blk = 0;
         W pHP = 0, pHN = 0;
-        uint4 mA = make_uint4(0, 0, 0, 0), mB = mA;
         const uint4* Cx = B.C;
         if (act) {
             const uint4 n1 = qLoad(Qi + (size_t)PU * qCap + i), n2 = qLoad(Qi + (size_t)(PU + 1) * qCap + i);
@@ -707,13 +718,9 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
             Cx = B.C + (size_t)CMB_IDX(ctx, B.cCap, 1) * B.ctxU4;
             blk = (row + 1) / Geo::CTX_BLOCK;
             const uint4 hot = Cx[CTX_HOT];
-            mA = Cx[CTX_M + 2 * blk];
-            mB = Cx[CTX_M + 1 + 2 * blk];
-            g.n = hot.y & 0x1FFu;
-            g.m = (hot.y >> 9) & 0x1FFu;
-            g.Wv = (hot.y >> 18) & 31u;
-            g.Wh = (hot.y >> 23) & 15u;
-            g.maxED = (hot.y >> 27) & 15u;
+            const uint4 mA = Cx[CTX_M + 2 * blk], mB = Cx[CTX_M + 1 + 2 * blk];
+            ldsM[0][tid] = u64of(mA.x, mA.y), ldsM[1][tid] = u64of(mA.z, mA.w), ldsM[2][tid] = u64of(mB.x, mB.y), ldsM[3][tid] = u64of(mB.z, mB.w);
+            hotY = hot.y;
             clSize = hot.w >> 23;
             Geo::unpackRow(n2, pHP, pHN);
             pRac = n1.w & 63u;
@@ -728,8 +735,8 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
                 row1 = row + 1;
                 if (row1 / Geo::CTX_BLOCK != blk) { // the walk crossed into the next block of match words
                     blk = row1 / Geo::CTX_BLOCK;
-                    mA = Cx[CTX_M + 2 * blk];
-                    mB = Cx[CTX_M + 1 + 2 * blk];
+                    const uint4 mA = Cx[CTX_M + 2 * blk], mB = Cx[CTX_M + 1 + 2 * blk];
+                    ldsM[0][tid] = u64of(mA.x, mA.y), ldsM[1][tid] = u64of(mA.z, mA.w), ldsM[2][tid] = u64of(mB.x, mB.y), ldsM[3][tid] = u64of(mB.z, mB.w);
                 }
                 uint32_t rows = 0, mask;
 #pragma unroll
@@ -738,15 +745,15 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
                     cHP[c] = cHN[c] = 0;
                     cMeta[c] = 0;
                 }
-                {
-                    MvPair ch[4];
-                    mask = moveChildrenCounted(ix, md, parent, ch, rows);
-#pragma unroll
-                    for (uint32_t c = 0; c < 4; c++)
-                        if (mask >> c & 1u) MvTraits::pack(ch[c], pk[c][0], pk[c][1], pk[c][2]);
-                }
+                mask = moveChildrenCounted<true>(ix, md, parent, nullptr, rows, 0xFu, pk);
                 cRows += rows;
                 cExp++;
+                MatGeom g;
+                g.n = hotY & 0x1FFu;
+                g.m = (hotY >> 9) & 0x1FFu;
+                g.Wv = (hotY >> 18) & 31u;
+                g.Wh = (hotY >> 23) & 15u;
+                g.maxED = (hotY >> 27) & 15u;
                 const bool inFC = g.inFinalColumn(row1);
                 if (inFC && clSize + row1 - g.m >= ED_CELLS) flags |= FLAG_CAPACITY;
                 kinds = 0;
@@ -754,7 +761,7 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
                 for (uint32_t c = 0; c < 4; c++) {
                     if (!(mask >> c & 1u)) continue;
                     cChildren++;
-                    const W M = Geo::mword(c == 0 ? u64of(mA.x, mA.y) : c == 1 ? u64of(mA.z, mA.w) : c == 2 ? u64of(mB.x, mB.y) : u64of(mB.z, mB.w), row1);
+                    const W M = Geo::mword(ldsM[c][tid], row1);
                     W HP = pHP, HN = pHN, RAC = Geo::racBit(pRac), D0;
                     uint32_t sc = score;
                     const bool valid = Geo::row(g, row1, M, HP, HN, D0, RAC, sc);
@@ -809,7 +816,7 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
         if (oEv + nEv > B.evCap) { ok = false; flags |= FLAG_BFS_EV; }
         if (oF + nF > B.fCap) { ok = false; flags |= FLAG_BFS_F; }
         if (kinds != 0u && ok) {
-            const uint32_t cell = min(clSize + row1 - g.m, ED_CELLS - 1u);
+            const uint32_t cell = min(clSize + row1 - ((hotY >> 9) & 0x1FFu), ED_CELLS - 1u);
             EdPack pack{};
             if (fcP != BFS_NONE && (kinds & 0x4444u)) packLoad(Qi + (size_t)(PU + 2) * qCap + i, qCap, pack);
 #pragma unroll
@@ -869,12 +876,19 @@ k_mvs_start(const DevStrategyKT<Geo::MP>* __restrict__ stp, MvBufs B, const MvTa
     if (blockStopped(q)) return;
     bfsHeavy<true, MvTraits, Geo>(stp, B, 0u, tasks, nTasks, offs, gw, G, parts, q, blockIdx.x, gridDim.x);
 }
-constexpr uint32_t MVS_CHAIN = 2; // expansions a lane makes in a row while each yields exactly one plain node (CMB_MVS_CHAIN)
+constexpr uint32_t MVS_CHAIN = 3; // expansions a lane makes in a row while each yields exactly one plain node (CMB_MVS_CHAIN)
+// Round 4: k_mvs_pass ran at 246 registers = 2 wavefronts per SIMD.  With the match words of the row block in LDS, the band geometry kept
+// packed, 32-bit counters and the children packed one by one as the scan's results are turned into ranges (moveChildrenCounted<true>: the
+// four unpacked pairs never exist side by side) the common instances need 175, and fit 168 = 3 wavefronts per SIMD with four spilled
+// words outside the tile loop.  A grid that is resident in ONE round then pays (640 expanding + 128 event blocks = 3 per CU): BASELINE
+// configs[4] stand-in 942 k -> 1 123 k reads/s (2 wavefronts: 942 k at 896 + 128 blocks, 853 k at 384 + 128; 4 wavefronts = 128 registers
+// spill 50 words inside the loop: 770 k).  The wide geometries (8 ... 13 errors) stay at 2.
 #ifndef CMB_MVS_WAVES
-#define CMB_MVS_WAVES 2 // wavefronts per SIMD the register allocation of k_mvs_pass is held to
+#define CMB_MVS_WAVES 3 // wavefronts per SIMD the register allocation of k_mvs_pass<GeoN32 / GeoN> is held to
 #endif
+constexpr uint32_t MVS_GRID_X = 640, MVS_GRID_X_WIDE = 896; // expanding blocks of k_mvs_pass (CMB_MVS_GRID); + BFS_GRID_EV event blocks
 template <class Geo = GeoN>
-__global__ void __launch_bounds__(256, CMB_MVS_WAVES)
+__global__ void __launch_bounds__(256, Geo::MP == MAXP ? CMB_MVS_WAVES : 2)
 k_mvs_pass(MoveDev ix, const DevStrategyKT<Geo::MP>* __restrict__ stp, MvBufs B, uint32_t pass, const uint64_t* __restrict__ offs, uint32_t gw,
            const uint32_t* __restrict__ G, const PartOutT<Geo::MP>* __restrict__ parts, Queues q) {
     if (blockStopped(q)) return;
