@@ -97,6 +97,25 @@ def pin_to_gpu_numa_node(local: int):
         return {"error": str(e)[:80]}
 
 
+def confine_cpus(n: int):
+    """--cpus-per-rank N: this rank may use N CPUs (those numbered [rank N, rank N + N) of the CPUs it was given), set before the first
+    GPU call; returns the list, or None without the option.  With it the NUMA pinning is skipped (CMB_BENCH_NO_PIN)."""
+    if not n or not hasattr(os, "sched_setaffinity"):
+        return None
+    allowed = sorted(os.sched_getaffinity(0))
+    r = int(os.environ.get("RANK", 0))
+    mine = [allowed[(r * n + j) % len(allowed)] for j in range(min(n, len(allowed)))]
+    os.sched_setaffinity(0, mine)
+    os.environ["CMB_BENCH_NO_PIN"] = "1"
+    return mine
+
+
+def host_cpu_seconds() -> float:
+    """user + system CPU time of this process, all threads (the library's sub-batch workers included)"""
+    t = os.times()
+    return t.user + t.system
+
+
 def effective_cpus() -> int:
     """CPUs this process can really use: the affinity mask AND the cgroup CPU quota (the GPU boxes of this pool give a
     16-CPU share of a 256-thread host to a one-GPU job: 256 oracle threads then time-slice on 16 CPUs)"""
@@ -554,6 +573,9 @@ def main():
     ap.add_argument("--no-streaming", action="store_true",
                     help="skip the `streaming` leg (steps that take FRESH reads from page-locked host memory and hand their results to the "
                          "host; reported beside `value`, never as `value`)")
+    ap.add_argument("--cpus-per-rank", type=int, default=0,
+                    help="confine every rank to this many CPUs (set before anything touches the GPU): a rehearsal of a CPU-starved 8-rank "
+                         "node on a one-GPU box; the line's host_cpu field shows what a step costs the host")
     ap.add_argument("--no-rlc", action="store_true",
                     help="skip the bounded BASELINE configs[4] leg (`rlc`: b-move index, 250 bp, k = 6) of the default one-GPU line")
     args = ap.parse_args()
@@ -570,7 +592,10 @@ def main():
 
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus))  # (before any GPU call in this process)
+    confined = confine_cpus(args.cpus_per_rank)  # (before any GPU call as well: the library's worker threads inherit the mask)
     rank, world, local, dev, affinity, dist, rccl_ranks = setup_ranks(args)
+    if confined is not None:
+        affinity = {"confined_to": confined}
     if args.total_reads:
         args.reads = args.total_reads // world
 
@@ -628,6 +653,7 @@ def main():
         batch.run()
     sync()
     kern = {}
+    cpu0 = host_cpu_seconds()
     tstart = time.perf_counter()
     for _ in range(args.steps):
         batch.run()
@@ -635,6 +661,7 @@ def main():
             kern[kname] = kern.get(kname, 0.0) + ms
     sync()
     elapsed = time.perf_counter() - tstart
+    host_cpu_ms = [round((host_cpu_seconds() - cpu0) / max(args.steps, 1) * 1e3, 2)] # CPU time the host spent per step, this rank
     per_rank_ms = [round(elapsed / max(args.steps, 1) * 1e3, 3)]
     if dist is not None:
         cdev = "cpu" if dist.get_backend() == "gloo" else dev
@@ -642,6 +669,9 @@ def main():
         every = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank_ms = [round(float(t.item()) / max(args.steps, 1) * 1e3, 3) for t in every]
+        mine = torch.tensor([host_cpu_ms[0]], dtype=torch.float64, device=cdev)
+        dist.all_gather(every, mine)
+        host_cpu_ms = [round(float(t.item()), 2) for t in every]
         te = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -735,6 +765,8 @@ def main():
                                    "batch's sub-batches run one after the other; in the timed steps the sub-batches "
                                    "overlap (busy ms per step there: see concurrent_ms)",
                     "concurrent_ms": {k: round(v, 3) for k, v in avg_concurrent.items()},
+                    # the step against the sum of its kernel groups run one after the other (what the concurrent sub-batches hide)
+                    "overlap": {"serial_sum_ms": round(sum(avg.values()), 3), "step_over_serial_sum": round(elapsed / steps * 1e3 / max(sum(avg.values()), 1e-9), 4)},
                     "line_rate": line_rate, "valu": valu,
                     "per_kernel": per_kernel}
         cpu = None
@@ -782,6 +814,10 @@ def main():
             "scaling": "strong" if args.total_reads else "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "rccl_ranks": rccl_ranks, "per_rank_ms_per_step": per_rank_ms, "index_broadcast_ms": None if broadcast_ms is None else round(broadcast_ms, 1),
             "host_affinity": affinity,
+            # what a step costs the HOST: CPU time (all threads of the rank: three sub-batch workers + the Python thread) per step and
+            # its share of the step's wall time — the budget eight ranks must find on one node (the GPU boxes give a one-GPU job 16 CPUs)
+            "host_cpu": {"cpu_ms_per_step": host_cpu_ms, "cpus_busy": [round(c / max(elapsed / steps * 1e3, 1e-9), 2) for c in host_cpu_ms],
+                         "cpus_available": effective_cpus()},
             "config": {"workload": f"synthetic human-like reference {n / 1e6:.0f} Mbp (GRCh38 is not available "
                                    f"offline), {R} x {L} bp reads per GPU, k={args.k} edit distance, ALL mode, "
                                    "multiple_opt schemes with dynamic selection, dynamic partitioning, "

@@ -1224,7 +1224,8 @@ static int batchRunOne(cmb_batch* b) {
                         hipLaunchKernelGGL(k_bfs_start<GeoN>, dim3(std::min<uint32_t>((nDfs + 255) / 256, BFS_GRID)), dim3(256), 0, s,
                                        ix->d, b->strat.p, B, b->dfs.p, nDfs, b->offs.p, b->gw, b->G.p, b->parts.p, q);
                     std::vector<uint32_t> hc(cntWords);
-                    const uint32_t CHECK = 16; // passes between two looks at the queue sizes
+                    // passes between two looks at the queue sizes (a pass on a drained frontier costs the device ~4 us, a look costs the host a round trip)
+                    const uint32_t CHECK = getenv("CMB_BFS_CHECK") ? (uint32_t)std::max(1, atoi(getenv("CMB_BFS_CHECK"))) : 16;
                     uint32_t pass = 0, peakQ = 0, peakEv = 0;
                     bool drained = false;
                     while (!drained && pass < maxPass) {
