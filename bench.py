@@ -148,6 +148,41 @@ def source_digest() -> str:
     return h.hexdigest()[:16]
 
 
+def move_source_digest() -> str:
+    """the same for the b-move backend's translation unit: everything it is compiled from (its own files and the headers it shares with the matcher)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "columba_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.startswith("pair_") or fn == "columba_amd.hip":
+            continue
+        with open(os.path.join(d, fn), "rb") as f:
+            h.update(fn.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def load_rlc_traffic(reads, read_len, k):
+    """HBM bytes per step of the b-move frontier kernels (k_mvs_start / k_mvs_pass / k_mvs_finish) from tools/profile_rlc.sh's PMC passes
+    (profiles/*_rlc_pmc_traffic.json: the difference of a two-step and a one-step run, so that the pool-sizing warm-up cancels out), or
+    (None, None) when no profile was measured on these sources and this workload"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rlc_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        w = d.get("workload", {})
+        if (w.get("reads"), w.get("read_len"), w.get("k")) != (reads, read_len, k) or d.get("kernel_src_sha") != move_source_digest():
+            continue
+        tot = 0.0
+        for kn, e in d.get("kernels", {}).items():
+            if kn.startswith(("k_mvs_pass", "k_mvs_start", "k_mvs_finish")):
+                tot += 2.0 * e.get("FETCH_SIZE_KiB", 0.0) * 1024 + e.get("WRITE_SIZE_KiB", 0.0) * 1024
+        if tot > 0:
+            return round(tot / 1e9, 3), os.path.relpath(f, ROOT)
+    return None, None
+
+
 def load_counters(args, genome_bp, reads, group, names):
     """sums of SQ counters per step over the kernels of a group, from the same profile file as load_traffic (or None)"""
     import glob
@@ -340,9 +375,11 @@ def main_rlc(args):
                              "frac_of_hbm_peak": None if gbs is None else round(gbs / HBM_PEAK_GBS, 4)}
     achieved = per_kernel[dominant]["algorithmic_GBps"] or 0.0
     passes = None
+    traffic, traffic_source = load_rlc_traffic(R, L, k) if dominant == "k_dfs" else (None, None)
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "traffic_note": "PMC passes of this command: tools/profile_rlc.sh -> profiles/*_rlc_*",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source, "kernel_src_sha": move_source_digest(),
+                "traffic_note": "GB per step of the frontier kernels, 2 x FETCH_SIZE + WRITE_SIZE (separate rocprofv3 --pmc passes of this command, two-step "
+                                "minus one-step run: tools/profile_rlc.sh -> profiles/*_rlc_pmc_traffic.json)",
                 "avg_launch_ms": round(avg[dominant], 3),
                 "unit_note": "16 B per move-table row fetched (TABLE_ROWS counted on the device); "
                              f"{cnt['DFS_TABLE_ROWS'] / max(cnt['DFS_EXPANSIONS'], 1):.1f} rows per node expansion of the search",
@@ -535,7 +572,9 @@ def rlc_leg(args, dev, local):
                                    f"{R} x {L} bp reads, k={k} edit distance, ALL mode, multiple_opt, dynamic partitioning",
                        "index_bytes_hbm": index.device_bytes(), "occurrences": int(len(occ))},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(avg[dominant], 3),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_rlc_traffic(R, L, k)[0] if dominant == "k_dfs" else None,
+                         "traffic_source": load_rlc_traffic(R, L, k)[1] if dominant == "k_dfs" else None, "kernel_src_sha": move_source_digest(),
+                         "avg_launch_ms": round(avg[dominant], 3),
                          "unit_note": f"16 B per move-table row fetched; {cnt['DFS_TABLE_ROWS'] / max(cnt['DFS_EXPANSIONS'], 1):.1f} rows per node expansion",
                          "per_kernel_ms": {kn: round(v, 3) for kn, v in avg.items()}},
             "cpu_baseline": cpu}

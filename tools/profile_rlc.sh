@@ -20,24 +20,12 @@ for r in rows:
     if "cmb::" in n or "rocprim" in n or "hipcub" in n:
         print(",".join([n[:90].replace(",", ";"), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]))
 PY
+# HBM traffic counters: every run starts with a warm-up that sizes the pools, so one step = (two timed steps) - (one timed step)
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-include-regex 'k_mvs|k_move' --output-format csv -d /tmp/rlc_$C -- python3 $R/bench.py $ARGS --steps 1 --warmup 1 --no-cpu-baseline --no-streaming --no-rlc > $OUT/pmc_$C.log 2>&1
+  for N in 1 2; do
+    rocprofv3 --pmc $C --kernel-include-regex 'k_mvs|k_move' --output-format csv -d /tmp/rlc_${C}_$N -- python3 $R/bench.py $ARGS --steps $N --warmup 1 --no-cpu-baseline --no-streaming --no-rlc > $OUT/pmc_${C}_$N.log 2>&1
+  done
 done
-python3 - <<'PY' > $OUT/pmc_traffic.txt
-import csv, glob, collections
-def per_kernel(d, name):
-    agg, cnt = collections.defaultdict(float), collections.Counter()
-    for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == name:
-                k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("cmb::", "")
-                agg[k] += float(r["Counter_Value"]); cnt[k] += 1
-    return agg, cnt
-f, fc = per_kernel("/tmp/rlc_FETCH_SIZE", "FETCH_SIZE")
-w, _ = per_kernel("/tmp/rlc_WRITE_SIZE", "WRITE_SIZE")
-print("bench.py --config rlc --steps 1 --warmup 1: two runs of the hot path (the warm-up run includes the re-runs that size the pools); KiB -> GB, FETCH_SIZE x 2 (gfx950)")
-for k in sorted(f, key=lambda k: -f[k]):
-    print(f"{k:40s} dispatches {fc[k]:6d}  2 x FETCH_SIZE {2 * f[k] * 1024 / 1e9:9.2f} GB  WRITE_SIZE {w.get(k, 0) * 1024 / 1e9:9.2f} GB")
-PY
 cd $R && python3 bench.py $ARGS > $OUT/bench_line.json 2> $OUT/bench_stderr.log
+python3 $R/tools/pmc_traffic_rlc.py $OUT/bench_line.json /tmp/rlc_FETCH_SIZE_1 /tmp/rlc_FETCH_SIZE_2 /tmp/rlc_WRITE_SIZE_1 /tmp/rlc_WRITE_SIZE_2 > $OUT/pmc_traffic.json
 ls -la $OUT
