@@ -1822,6 +1822,19 @@ int moveCigarsOnText(cmb_index* textIndex, hipStream_t s, const uint64_t* offs, 
             mf.p = mfull.p;
         }
         const uint32_t cSlots = (uint32_t)std::min<uint64_t>(((nOcc + 255) / 256) * 256, 512u * 1024u);
+        if (!gapless && k > CIGAR_BLOCK_WORDS_MAX_ED) {
+            // beyond 9 errors (k_cigar's match words reach 9 columns right of the diagonal): the matrix with the wide left margin, as for
+            // the FM-index batches (kernels.hpp: k_cigar_wide; match words straight from the read's bit-strings)
+            const uint32_t wSlots = std::min<uint32_t>(cSlots, 256u * 256u);
+            const uint32_t slotBytes = (vwRows(maxLen) + 1u) * VW_ROW_BYTES;
+            DevBuf<uint8_t> slab;
+            slab.alloc((size_t)slotBytes * wSlots);
+            hipLaunchKernelGGL(k_cigar_wide, dim3(wSlots / 256), dim3(256), 0, s, d, offs, G, gw, (const uint4*)occs, occRead, nOcc, slab.p, slotBytes,
+                               seqStartsDev, nSeqs, ops, stride, (AlnRec*)aln, flagWord, 0u);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(s)); // (the slab goes out of scope)
+            return CMB_OK;
+        }
         const bool narrow = k <= TBN_MAX_ED;
         const uint32_t tLines = narrow ? (vRows(maxLen) + 15u) / 16u + 2u : (vRows(maxLen) + 7u) / 8u + 2u;
         DevBuf<uint64_t> vW;
@@ -2904,8 +2917,8 @@ extern "C" int cmb_move_match_best(cmb_move_index* idx, const cmb_strategy* st, 
         r.ops.resize(nOps ? nOps : 1);
         return cmb_move_batch_alignments(b, r.al.data(), r.al.size(), r.ops.data(), r.ops.size(), &nOps);
     };
-    // (the b-move search runs on the tables of 8 parts and the narrow records: up to 7 errors)
-    return matchBestWith(text, st, 7u, false, run, x, min_identity, seqs, offs, n_reads, out);
+    // (strata up to 13 errors, the reference's MAX_K, as on the FM-index: the b-move search runs that far since round 3, its alignments since round 4)
+    return matchBestWith(text, st, 13u, false, run, x, min_identity, seqs, offs, n_reads, out);
 }
 extern "C" int cmb_best_sizes(const cmb_best* r, uint64_t* n_occ, uint64_t* n_ops) {
     if (!r) return fail(CMB_ERR_INVALID, "null argument");

@@ -1332,8 +1332,6 @@ extern "C" int cmb_move_batch_filter_per_strand(cmb_move_batch* b, int on) {
 extern "C" int cmb_move_batch_want_alignments(cmb_move_batch* b, int on) {
     if (!b) return failWith(CMB_ERR_INVALID, "null argument");
     if (on && !b->ix->textIndex) return failWith(CMB_ERR_INVALID, "alignments need the text beside the index (cmb_move_attach_text)");
-    // (k_cigar's match words reach 9 columns right of the diagonal: kernels.hpp, CIGAR_BLOCK_WORDS_MAX_ED)
-    if (on && b->k > 9 && b->metric == CMB_METRIC_EDIT) return failWith(CMB_ERR_UNSUPPORTED, "alignments beyond 9 errors on the b-move index");
     b->wantAln = on != 0;
     return CMB_OK;
 }

@@ -569,8 +569,7 @@ int cmb_move_batch_filter_per_strand(cmb_move_batch* b, int on);
  * runs the same SearchStrategy::matchApproxBestPlusX (src/searchstrategy.cpp:623-746).  Needs cmb_move_attach_text: CIGARs
  * (IndexInterface::generateCIGAR on the matched string, src/indexinterface.h:959-989) and the trimming of occurrences that run over a
  * sequence end (checkTrimmedMatch, src/indexinterface.cpp:722-796, which walks the trimmed part of the matched string — no counters)
- * read text[begin, end).  Cut-off: min(13, what the strategy has schemes for, 7 — alignments on this flavour run up to 7 errors —,
- * len * (100 - min_identity) / 100).  Results through cmb_best_sizes / cmb_best_results / cmb_best_free. */
+ * read text[begin, end).  Cut-off: min(13, what the strategy has schemes for, len * (100 - min_identity) / 100), as on the FM-index.  Results through cmb_best_sizes / cmb_best_results / cmb_best_free. */
 int cmb_move_match_best(cmb_move_index* idx, const cmb_strategy* st, uint32_t x, uint32_t min_identity, uint32_t kmer_size,
                         const char* seqs, const uint64_t* offs, uint32_t n_reads, cmb_best** out);
 /* device time (ms, HIP events) of the calling thread's last cmb_move_match_exact: [0] the backward extension of all reads,
