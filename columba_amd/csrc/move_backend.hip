@@ -1093,6 +1093,9 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                 B.narrowWv = getenv("CMB_TEST_NARROW_WV") ? (uint32_t)std::max(0, atoi(getenv("CMB_TEST_NARROW_WV"))) : 0xFFFFu;
                 // up to 7 errors the in-index matrix runs on 32-bit words (GeoN32, dev_matrix.hpp: MXS_*) unless a phase did not fit it (CMB_MATRIX64=1: never)
                 const bool small32 = !b->wide && b->k <= MXS_MAX_ED && !b->noSmallMatrix && !getenv("CMB_MATRIX64");
+                // text and run counts below 2^32 (the reference's default build of length_t): the expanding blocks work on 32-bit positions
+                // (CMB_MOVE_POS64=1: the general 40-bit path)
+                const bool smallPos = ix->d.n < 0xFFFFFFF0ull && ix->d.fwd.runs < 0xFFFFFFF0ull && ix->d.rev.runs < 0xFFFFFFF0ull && !getenv("CMB_MOVE_POS64");
                 const dim3 gStart(std::min<uint32_t>((nTasks + 255) / 256, BFS_GRID));
                 if (geoX)
                     hipLaunchKernelGGL(k_mvs_start<GeoX>, gStart, dim3(256), 0, s, b->stratW.p, B, b->tasks.p, nTasks, dOffs, b->gw, b->G.p, b->partsW.p, q);
@@ -1115,11 +1118,11 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                             hipLaunchKernelGGL(k_mvs_pass<GeoW>, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->stratW.p, B, pass, dOffs, b->gw, b->G.p,
                                                b->partsW.p, q);
                         else if (small32)
-                            hipLaunchKernelGGL(k_mvs_pass<GeoN32>, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->strat.p, B, pass, dOffs, b->gw, b->G.p,
-                                               b->parts.p, q);
+                            hipLaunchKernelGGL((smallPos ? k_mvs_pass<GeoN32, true> : k_mvs_pass<GeoN32, false>), dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d,
+                                               b->strat.p, B, pass, dOffs, b->gw, b->G.p, b->parts.p, q);
                         else
-                            hipLaunchKernelGGL(k_mvs_pass<GeoN>, dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d, b->strat.p, B, pass, dOffs, b->gw, b->G.p,
-                                               b->parts.p, q);
+                            hipLaunchKernelGGL((smallPos ? k_mvs_pass<GeoN, true> : k_mvs_pass<GeoN, false>), dim3(B.gridX + B.gridEv), dim3(256), 0, s, ix->d,
+                                               b->strat.p, B, pass, dOffs, b->gw, b->G.p, b->parts.p, q);
                     MV_HIPCHK(hipMemcpyAsync(hc.data(), b->bfsCnt.p, cntWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                     MV_HIPCHK(hipMemcpyAsync(hcnt, b->cnt.p, sizeof(hcnt), hipMemcpyDeviceToHost, s));
                     MV_HIPCHK(hipStreamSynchronize(s));

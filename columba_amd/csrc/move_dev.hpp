@@ -106,22 +106,46 @@ struct MoveRangeRec {
 };
 static_assert(sizeof(MoveRangeRec) == 80, "record layout");
 
-struct MvRange {
-    uint64_t begin, end, beginRun, endRun;
+// (P: the type of a text position / run number — 64 bits in general; 32 bits for the frontier kernel's instance on indexes whose text and
+// run counts stay below 2^32, the reference's default build of length_t: move_search.hpp, mvExpand)
+template <typename P>
+struct MvRangeT {
+    P begin, end, beginRun, endRun;
     bool valid;
 };
+typedef MvRangeT<uint64_t> MvRange;
+// the fields of a row as positions of type P (P = uint32_t: the low 32 bits of the 40-bit fields, three funnel shifts)
+template <typename P> struct MoveRowT {
+    uint32_t head;
+    P in, out, outRun;
+};
+template <typename P> __device__ __forceinline__ P rowInT(const uint4 v);
+template <> __device__ __forceinline__ uint64_t rowInT<uint64_t>(const uint4 v) { return (((uint64_t)v.x | (uint64_t)v.y << 32) >> 3) & MV_M40; }
+template <> __device__ __forceinline__ uint32_t rowInT<uint32_t>(const uint4 v) { return __funnelshift_r(v.x, v.y, 3u); }
+template <typename P> __device__ __forceinline__ P rowInT(const uint2 v);
+template <> __device__ __forceinline__ uint64_t rowInT<uint64_t>(const uint2 v) { return (((uint64_t)v.x | (uint64_t)v.y << 32) >> 3) & MV_M40; }
+template <> __device__ __forceinline__ uint32_t rowInT<uint32_t>(const uint2 v) { return __funnelshift_r(v.x, v.y, 3u); }
+template <typename P> __device__ __forceinline__ MoveRowT<P> unpackMoveRowT(const uint4 v);
+template <> __device__ __forceinline__ MoveRowT<uint64_t> unpackMoveRowT<uint64_t>(const uint4 v) {
+    const MoveRow r = unpackMoveRow(v);
+    return MoveRowT<uint64_t>{r.head, r.in, r.out, r.outRun};
+}
+template <> __device__ __forceinline__ MoveRowT<uint32_t> unpackMoveRowT<uint32_t>(const uint4 v) { // fields at bits 3, 43, 83
+    return MoveRowT<uint32_t>{v.x & 7u, __funnelshift_r(v.x, v.y, 3u), __funnelshift_r(v.y, v.z, 11u), __funnelshift_r(v.z, v.w, 19u)};
+}
 
 // MoveLFReprBP::getRunIndex / computeRunIndices (moverepr.cpp:213-249): the runs that hold begin and end - 1, searched
 // between the (stale but enclosing) run indices the range carries
 // (both searches step TOGETHER — two independent probes per memory round trip; the second one runs over the whole interval instead of
 // starting at the first one's result, which finds the same run)
-__device__ inline void computeRunIndices(const MoveTable& t, MvRange& r) {
-    uint64_t lo1 = r.beginRun, hi1 = r.endRun, lo2 = r.beginRun, hi2 = r.endRun;
-    const uint64_t last = r.end - 1;
+template <typename P>
+__device__ inline void computeRunIndices(const MoveTable& t, MvRangeT<P>& r) {
+    P lo1 = r.beginRun, hi1 = r.endRun, lo2 = r.beginRun, hi2 = r.endRun;
+    const P last = r.end - 1;
     while (hi1 > lo1 || hi2 > lo2) {
-        const uint64_t mid1 = (lo1 + hi1 + 1) >> 1, mid2 = (lo2 + hi2 + 1) >> 1;
+        const P mid1 = (P)(((uint64_t)lo1 + hi1 + 1) >> 1), mid2 = (P)(((uint64_t)lo2 + hi2 + 1) >> 1);
         const uint2 a = *reinterpret_cast<const uint2*>(t.rows + mid1), b = *reinterpret_cast<const uint2*>(t.rows + mid2);
-        const uint64_t in1 = (((uint64_t)a.x | (uint64_t)a.y << 32) >> 3) & MV_M40, in2 = (((uint64_t)b.x | (uint64_t)b.y << 32) >> 3) & MV_M40;
+        const P in1 = rowInT<P>(a), in2 = rowInT<P>(b);
         if (hi1 > lo1) {
             if (in1 <= r.begin) lo1 = mid1;
             else hi1 = mid1 - 1;
@@ -193,12 +217,14 @@ __device__ inline void moveLF(const MoveTable& t, uint64_t& pos, uint64_t& run) 
     while (rowIn(t.rows[run + 1]) <= pos) run++; // fast-forward; the terminating row (inputStartPos = n) stops it
 }
 
-struct MvPair {
-    MvRange sa, rev;
-    uint64_t toehold;
+template <typename P>
+struct MvPairT {
+    MvRangeT<P> sa, rev;
+    P toehold;
     bool repEnd;
     uint32_t depth;
 };
+typedef MvPairT<uint64_t> MvPair;
 
 __device__ inline MvPair loadPair(const MoveRangeRec& q) {
     MvPair p;

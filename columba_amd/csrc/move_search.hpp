@@ -98,6 +98,32 @@ struct MvTraits {
         b = make_uint4((uint32_t)w2, (uint32_t)(w2 >> 32), (uint32_t)w3, (uint32_t)(w3 >> 32));
         c = make_uint4((uint32_t)w4, (uint32_t)(w4 >> 32), (uint32_t)w5, (uint32_t)(w5 >> 32));
     }
+    // the same records from / into 32-bit positions (indexes below 2^32: the nine 40-bit fields sit at bits 0, 40, ..., 320 — twelve dwords,
+    // every field the funnel shift of two of them; the high byte of a field is zero)
+    static __device__ __forceinline__ MvPairT<uint32_t> unpack32(const uint4& a, const uint4& b, const uint4& c) {
+        MvPairT<uint32_t> r;
+        r.sa.begin = a.x;
+        r.sa.end = __funnelshift_r(a.y, a.z, 8u);
+        r.sa.beginRun = __funnelshift_r(a.z, a.w, 16u);
+        r.sa.endRun = __funnelshift_r(a.w, b.x, 24u);
+        r.rev.begin = b.y;
+        r.rev.end = __funnelshift_r(b.z, b.w, 8u);
+        r.rev.beginRun = __funnelshift_r(b.w, c.x, 16u);
+        r.rev.endRun = __funnelshift_r(c.x, c.y, 24u);
+        r.toehold = c.z;
+        r.depth = (c.w >> 8) & 0xFFFFu;
+        r.sa.valid = (c.w >> 24) & 1u;
+        r.rev.valid = (c.w >> 25) & 1u;
+        r.repEnd = (c.w >> 26) & 1u;
+        return r;
+    }
+    static __device__ __forceinline__ void pack(const MvPairT<uint32_t>& r, uint4& a, uint4& b, uint4& c) {
+        a = make_uint4(r.sa.begin, r.sa.end << 8, (r.sa.end >> 24) | (r.sa.beginRun << 16), (r.sa.beginRun >> 16) | (r.sa.endRun << 24));
+        b = make_uint4(r.sa.endRun >> 8, r.rev.begin, r.rev.end << 8, (r.rev.end >> 24) | (r.rev.beginRun << 16));
+        c = make_uint4((r.rev.beginRun >> 16) | (r.rev.endRun << 24), r.rev.endRun >> 8, r.toehold,
+                       ((r.depth & 0xFFFFu) << 8) | ((r.sa.valid ? 1u : 0u) << 24) | ((r.rev.valid ? 1u : 0u) << 25) | ((r.repEnd ? 1u : 0u) << 26));
+    }
+    template <typename P> static __device__ __forceinline__ MvPairT<P> unpackT(const uint4& a, const uint4& b, const uint4& c);
     static __device__ __forceinline__ Pair load(const uint4* p, size_t stride) { return unpack(p[0], p[stride], p[2 * stride]); }
     static __device__ __forceinline__ void store(uint4* p, size_t stride, const Pair& r) {
         uint4 a, b, c;
@@ -128,6 +154,9 @@ struct MvTraits {
     }
 };
 
+template <> __device__ __forceinline__ MvPairT<uint64_t> MvTraits::unpackT<uint64_t>(const uint4& a, const uint4& b, const uint4& c) { return unpack(a, b, c); }
+template <> __device__ __forceinline__ MvPairT<uint32_t> MvTraits::unpackT<uint32_t>(const uint4& a, const uint4& b, const uint4& c) { return unpack32(a, b, c); }
+
 // ---- the index as the search sees it
 struct MvSearchIndex {
     MoveDev d;
@@ -152,8 +181,9 @@ struct RowCount {
 // full; the others only contribute their width to the cumulative counts.  Returns the mask of non-empty children.
 // (a range chosen field by field: `cond ? a : b` on the objects makes the compiler choose between two ADDRESSES, which puts both
 // objects — and whatever they were copied from — into scratch memory)
-__device__ __forceinline__ MvRange selRange(bool c, const MvRange& a, const MvRange& b) {
-    MvRange r;
+template <typename P>
+__device__ __forceinline__ MvRangeT<P> selRange(bool c, const MvRangeT<P>& a, const MvRangeT<P>& b) {
+    MvRangeT<P> r;
     r.begin = c ? a.begin : b.begin;
     r.end = c ? a.end : b.end;
     r.beginRun = c ? a.beginRun : b.beginRun;
@@ -163,8 +193,10 @@ __device__ __forceinline__ MvRange selRange(bool c, const MvRange& a, const MvRa
 }
 // PACK: the children go straight into their packed form (MvTraits::pack, three uint4 each: twelve registers instead of twenty-one), one
 // after the other — the four unpacked pairs never exist side by side (`child` is not touched).
-template <bool PACK = false>
-__device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const int mode, const MvPair& parent, MvPair child[4], uint32_t& rows,
+// P: the type of positions and run numbers (uint64_t; uint32_t for the frontier kernel on indexes below 2^32 — half the registers of the
+// scan's state and 32-bit instead of 64-bit arithmetic throughout).
+template <bool PACK = false, typename P = uint64_t>
+__device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const int mode, const MvPairT<P>& parent, MvPairT<P> child[4], uint32_t& rows,
                                                const uint32_t need = 0xFu, uint4 (*pk)[3] = nullptr) {
     const bool fw = mode == 0;
     // the table of the direction, chosen FIELD BY FIELD: a reference `fw ? ix.rev : ix.fwd` is a choice between two addresses — every use of
@@ -175,21 +207,21 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
     t.zeroCharPos = fw ? ix.rev.zeroCharPos : ix.fwd.zeroCharPos;
     t.samplesFirst = fw ? ix.rev.samplesFirst : ix.fwd.samplesFirst;
     t.samplesLast = fw ? ix.rev.samplesLast : ix.fwd.samplesLast;
-    MvRange trivial = selRange(fw, parent.rev, parent.sa);
-    const MvRange other = selRange(fw, parent.sa, parent.rev);
+    MvRangeT<P> trivial = selRange(fw, parent.rev, parent.sa);
+    const MvRangeT<P> other = selRange(fw, parent.sa, parent.rev);
     if (!trivial.valid) { // (two binary searches between the enclosing run indices)
-        uint64_t span = trivial.endRun - trivial.beginRun;
+        P span = trivial.endRun - trivial.beginRun;
         while (span) {
             rows += 2;
             span >>= 1;
         }
         computeRunIndices(t, trivial);
     }
-    uint64_t fOut[4], fRun[4], lOut[4], lRun[4], lSrc[4]; // LF images of the first / last occurrence, run of the last occurrence
+    P fOut[4], fRun[4], lOut[4], lRun[4], lSrc[4]; // LF images of the first / last occurrence, run of the last occurrence
     uint32_t found = 0, seen = 0;                          // bits 0..4: character seen from the front / from the back
     uint32_t ffNeed = 0;                                   // end points (2 c: first, 2 c + 1: last) whose image left its target run
     {
-        uint64_t runF = trivial.beginRun, posF = trivial.begin, runB = trivial.endRun, posB = trivial.end - 1;
+        P runF = trivial.beginRun, posF = trivial.begin, runB = trivial.endRun, posB = trivial.end - 1;
         uint4 rowF = t.rows[runF], rowB = t.rows[runB];
         // the rows the two cursors move to next are requested WITH the first two (a range within one run asks for its own row again: the
         // same address): a scan of up to four rows — the average is 3.6 — costs one memory round trip, and every later turn finds its rows
@@ -202,11 +234,11 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
                 const uint32_t h = rowHead(rowF);
                 if (!(found >> h & 1u)) {
                     found |= 1u << h;
-                    const MoveRow r = unpackMoveRow(rowF);
+                    const MoveRowT<P> r = unpackMoveRowT<P>(rowF);
 #pragma unroll
                     for (uint32_t c = 0; c < 4; c++)
                         if (h == c + 1) {
-                            const uint64_t off = posF - r.in;
+                            const P off = posF - r.in;
                             const uint32_t gap = rowGap(rowF);
                             fOut[c] = r.out + off;
                             fRun[c] = r.outRun;
@@ -222,11 +254,11 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
                 const uint32_t h = rowHead(rowB);
                 if (!(seen >> h & 1u)) {
                     seen |= 1u << h;
-                    const MoveRow r = unpackMoveRow(rowB);
+                    const MoveRowT<P> r = unpackMoveRowT<P>(rowB);
 #pragma unroll
                     for (uint32_t c = 0; c < 4; c++)
                         if (h == c + 1) {
-                            const uint64_t off = posB - r.in;
+                            const P off = posB - r.in;
                             const uint32_t gap = rowGap(rowB);
                             lOut[c] = r.out + off;
                             lRun[c] = r.outRun;
@@ -244,12 +276,12 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
             if (fDone && bDone) break;
             // the next rows of both cursors are REQUESTED TOGETHER: nothing between the two loads reads a reply (with `posF = rowIn(rowF)`
             // between them hipcc waited for the front row before it asked for the back row: two round trips per step of the scan)
-            const uint64_t posBNext = rowIn(rowB) - 1;
+            const P posBNext = rowInT<P>(rowB) - 1;
             if (!fDone) {
                 runF++;
                 rowF = preF;
                 rows++;
-                posF = rowIn(rowF);
+                posF = rowInT<P>(rowF);
             }
             if (!bDone) {
                 posB = posBNext;
@@ -279,7 +311,7 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
             uint2 raw[8];
 #pragma unroll
             for (uint32_t c = 0; c < 4; c++) {
-                const uint64_t iF = (act >> (2 * c) & 1u) ? fRun[c] + 1 : 0ull, iL = (act >> (2 * c + 1) & 1u) ? lRun[c] + 1 : 0ull;
+                const P iF = (act >> (2 * c) & 1u) ? fRun[c] + 1 : (P)0, iL = (act >> (2 * c + 1) & 1u) ? lRun[c] + 1 : (P)0;
                 raw[2 * c] = *reinterpret_cast<const uint2*>(t.rows + iF);
                 raw[2 * c + 1] = *reinterpret_cast<const uint2*>(t.rows + iL);
             }
@@ -287,37 +319,37 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
             for (uint32_t c = 0; c < 4; c++) {
                 if (act >> (2 * c) & 1u) {
                     rows++;
-                    const uint64_t nx = (((uint64_t)raw[2 * c].x | (uint64_t)raw[2 * c].y << 32) >> 3) & MV_M40; // rowIn
+                    const P nx = rowInT<P>(raw[2 * c]);
                     if (nx <= fOut[c]) fRun[c]++;
                     else act &= ~(1u << (2 * c));
                 }
                 if (act >> (2 * c + 1) & 1u) {
                     rows++;
-                    const uint64_t nx = (((uint64_t)raw[2 * c + 1].x | (uint64_t)raw[2 * c + 1].y << 32) >> 3) & MV_M40;
+                    const P nx = rowInT<P>(raw[2 * c + 1]);
                     if (nx <= lOut[c]) lRun[c]++;
                     else act &= ~(1u << (2 * c + 1));
                 }
             }
         }
     }
-    const uint64_t parentWidth = trivial.end - trivial.begin;
+    const P parentWidth = trivial.end - trivial.begin;
     // the toehold samples of the children that narrow the range (BMove::computeToehold / computeToeholdRev, bmove.cpp:222-266: the last
     // run of the range that holds the character): requested together, before any is used
-    uint64_t smp[4];
+    P smp[4];
 #pragma unroll
     for (uint32_t c = 0; c < 4; c++) { // (unconditional loads, see above: a child that needs no sample reads samplesFirst[0])
         const bool wanted = (found >> (c + 1) & 1u) && (need >> c & 1u) && lOut[c] + 1 - fOut[c] != parentWidth;
         const bool atEnd = !wanted || lSrc[c] == trivial.endRun;
         const uint64_t* sp = atEnd ? t.samplesFirst : t.samplesLast;
-        smp[c] = sp[wanted ? (atEnd ? trivial.endRun : lSrc[c]) : 0ull];
+        smp[c] = (P)sp[wanted ? (atEnd ? trivial.endRun : lSrc[c]) : (P)0];
     }
     // MoveLFReprBP::getCumulativeCounts (moverepr.cpp:347-365): the '$' of the range, then the smaller characters
-    uint64_t cum = (trivial.begin <= t.zeroCharPos && trivial.end > t.zeroCharPos) ? 1 : 0;
+    P cum = (trivial.begin <= t.zeroCharPos && trivial.end > t.zeroCharPos) ? 1 : 0;
     uint32_t mask = 0;
 #pragma unroll
     for (uint32_t c = 0; c < 4; c++) {
-        MvPair one;
-        MvPair& ch = PACK ? one : child[c];
+        MvPairT<P> one;
+        MvPairT<P>& ch = PACK ? one : child[c];
         if (!(found >> (c + 1) & 1u)) { // addChar: setEmpty() (moverepr.cpp:313-316), SARangePair(range1, range1, 0, false, 0)
             ch.sa = {0, 0, 0, 0, false};
             ch.rev = ch.sa;
@@ -325,19 +357,19 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
             continue;
         }
         mask |= 1u << c;
-        const uint64_t width = lOut[c] + 1 - fOut[c]; // = countChar(trivial, c + 1)
+        const P width = lOut[c] + 1 - fOut[c]; // = countChar(trivial, c + 1)
         if (need >> c & 1u) {
-            const MvRange range1 = {fOut[c], lOut[c] + 1, fRun[c], lRun[c], true};
-            MvRange second;
-            const MvRange noRange{0, 0, 0, 0, true};
+            const MvRangeT<P> range1 = {fOut[c], (P)(lOut[c] + 1), fRun[c], lRun[c], true};
+            MvRangeT<P> second;
+            const MvRangeT<P> noRange{0, 0, 0, 0, true};
             if (width == parentWidth) { // the other range and the toehold carry over
                 second = selRange(mode == 2, noRange, other);
                 ch.toehold = fw ? parent.toehold + (parent.repEnd ? 1 : 0) : parent.toehold - (parent.repEnd ? 0 : 1);
                 ch.repEnd = parent.repEnd;
             } else {
-                const MvRange narrowed{other.begin + cum, other.begin + cum + width, other.beginRun, other.endRun, false};
+                const MvRangeT<P> narrowed{(P)(other.begin + cum), (P)(other.begin + cum + width), other.beginRun, other.endRun, false};
                 second = selRange(mode == 2, noRange, narrowed);
-                ch.toehold = fw ? ix.n - 1 - (smp[c] - 1) : smp[c] - 1;
+                ch.toehold = fw ? (P)(ix.n - 1) - (smp[c] - 1) : smp[c] - 1;
                 ch.repEnd = fw;
             }
             ch.sa = selRange(fw, second, range1);
@@ -675,7 +707,7 @@ k_mvs_exact(MvSearchIndex sx, const DevStrategyKT<MP>* __restrict__ stp, uint32_
 // Geo: the record geometry of dev_bfs_edit.hpp — GeoN32 (up to 7 errors, the instance of BASELINE configs[4]: the in-index matrix on
 // 32-bit words since round 4; GeoN, the reference's 64-bit words, for a batch one of whose phases does not fit it), GeoW (8 ... 10),
 // GeoX (11 ... 13: the in-index matrix with 16-row blocks).
-template <class Geo = GeoN>
+template <class Geo = GeoN, typename P = uint64_t>
 __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uint32_t pass, const Queues& q, uint32_t bid, uint32_t nBlocks) {
     __shared__ uint32_t sh[4][5];
     // per-lane state that is touched once per expansion lives in LDS, [field][lane], not in registers (the kernel waits for dependent row
@@ -703,13 +735,13 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
         uint32_t cMeta[4]; // score << 16 | RAC bit << 8 | final-column distance
         uint32_t hotY = 0, clSize = 0; // (the band geometry stays packed as the context's hot word holds it)
         int md = 0;
-        MvPair parent{};
+        MvPairT<P> parent{};
         uint32_t row = 0, score = 0, pRac = 0, blk = 0;
         W pHP = 0, pHN = 0;
         const uint4* Cx = B.C;
         if (act) {
             const uint4 n1 = qLoad(Qi + (size_t)PU * qCap + i), n2 = qLoad(Qi + (size_t)(PU + 1) * qCap + i);
-            parent = MvTraits::unpack(qLoad(Qi + i), qLoad(Qi + (size_t)qCap + i), qLoad(Qi + (size_t)2 * qCap + i));
+            parent = MvTraits::unpackT<P>(qLoad(Qi + i), qLoad(Qi + (size_t)qCap + i), qLoad(Qi + (size_t)2 * qCap + i));
             ctx = n1.y;
             fcP = n1.z;
             row = n1.x & 0xFFFFu;
@@ -745,7 +777,7 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
                     cHP[c] = cHN[c] = 0;
                     cMeta[c] = 0;
                 }
-                mask = moveChildrenCounted<true>(ix, md, parent, nullptr, rows, 0xFu, pk);
+                mask = moveChildrenCounted<true, P>(ix, md, parent, nullptr, rows, 0xFu, pk);
                 cRows += rows;
                 cExp++;
                 MatGeom g;
@@ -785,7 +817,7 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
 #pragma unroll
                     for (uint32_t c = 0; c < 4; c++)
                         if (kinds == ((uint32_t)KIND_NODE << (4 * c))) {
-                            parent = MvTraits::unpack(pk[c][0], pk[c][1], pk[c][2]);
+                            parent = MvTraits::unpackT<P>(pk[c][0], pk[c][1], pk[c][2]);
                             pHP = cHP[c];
                             pHN = cHN[c];
                             score = cMeta[c] >> 16;
@@ -886,13 +918,18 @@ constexpr uint32_t MVS_CHAIN = 3; // expansions a lane makes in a row while each
 #ifndef CMB_MVS_WAVES
 #define CMB_MVS_WAVES 3 // wavefronts per SIMD the register allocation of k_mvs_pass<GeoN32 / GeoN> is held to
 #endif
+#ifndef CMB_MVS_WAVES_SMALL
+#define CMB_MVS_WAVES_SMALL 3 // ... and of its instances on 32-bit positions
+#endif
 constexpr uint32_t MVS_GRID_X = 640, MVS_GRID_X_WIDE = 896; // expanding blocks of k_mvs_pass (CMB_MVS_GRID); + BFS_GRID_EV event blocks
-template <class Geo = GeoN>
-__global__ void __launch_bounds__(256, Geo::MP == MAXP ? CMB_MVS_WAVES : 2)
+// SMALL: text and run counts below 2^32 — the expanding half works on 32-bit positions (the reference's default build of length_t; the
+// records keep their 40-bit fields, so the event half and every other kernel of the backend are the same)
+template <class Geo = GeoN, bool SMALL = false>
+__global__ void __launch_bounds__(256, Geo::MP == MAXP ? (SMALL ? CMB_MVS_WAVES_SMALL : CMB_MVS_WAVES) : 2)
 k_mvs_pass(MoveDev ix, const DevStrategyKT<Geo::MP>* __restrict__ stp, MvBufs B, uint32_t pass, const uint64_t* __restrict__ offs, uint32_t gw,
            const uint32_t* __restrict__ G, const PartOutT<Geo::MP>* __restrict__ parts, Queues q) {
     if (blockStopped(q)) return;
-    if (blockIdx.x < B.gridX) mvExpand<Geo>(ix, B, pass, q, blockIdx.x, B.gridX);
+    if (blockIdx.x < B.gridX) mvExpand<Geo, typename std::conditional<SMALL, uint32_t, uint64_t>::type>(ix, B, pass, q, blockIdx.x, B.gridX);
     else bfsHeavy<false, MvTraits, Geo>(stp, B, pass, nullptr, 0u, offs, gw, G, parts, q, blockIdx.x - B.gridX, B.gridEv);
 }
 __global__ void k_mvs_finish(MvBufs B, Queues q) { // one block: per-block counters -> the batch counters
