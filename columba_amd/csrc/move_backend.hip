@@ -1081,8 +1081,12 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                 B.ctxU4 = ctxU4;
                 B.ctxMblk = geoX ? CTX_MBLK_X : ctxMblkFor(b->maxLen);
                 B.aCap = (uint32_t)std::min<size_t>(b->A.n, 0xFFFFFFF0u);
-                B.chain = getenv("CMB_MVS_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("CMB_MVS_CHAIN"))) : MVS_CHAIN;
-                B.gridX = getenv("CMB_MVS_GRID") ? (uint32_t)std::min<int>(BFS_GRID, std::max(1, atoi(getenv("CMB_MVS_GRID")))) : (b->wide ? MVS_GRID_X_WIDE : MVS_GRID_X);
+                // text and run counts below 2^32 (the reference's default build of length_t): the expanding blocks work on 32-bit positions with
+                // the children in slots (mvExpandSlots; CMB_MOVE_POS64=1: the general 40-bit path)
+                const bool smallPos = !b->wide && ix->d.n < 0xFFFFFFF0ull && ix->d.fwd.runs < 0xFFFFFFF0ull && ix->d.rev.runs < 0xFFFFFFF0ull && !getenv("CMB_MOVE_POS64");
+                B.chain = getenv("CMB_MVS_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("CMB_MVS_CHAIN"))) : (smallPos ? MVS_CHAIN_SMALL : MVS_CHAIN);
+                B.gridX = getenv("CMB_MVS_GRID") ? (uint32_t)std::min<int>(BFS_GRID, std::max(1, atoi(getenv("CMB_MVS_GRID"))))
+                                                 : (b->wide ? MVS_GRID_X_WIDE : smallPos ? MVS_GRID_X_SMALL : MVS_GRID_X);
                 B.gridEv = BFS_GRID_EV;
                 B.nq = b->bfsCnt.p;
                 B.ne = b->bfsCnt.p + (maxPass + 2);
@@ -1093,9 +1097,6 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                 B.narrowWv = getenv("CMB_TEST_NARROW_WV") ? (uint32_t)std::max(0, atoi(getenv("CMB_TEST_NARROW_WV"))) : 0xFFFFu;
                 // up to 7 errors the in-index matrix runs on 32-bit words (GeoN32, dev_matrix.hpp: MXS_*) unless a phase did not fit it (CMB_MATRIX64=1: never)
                 const bool small32 = !b->wide && b->k <= MXS_MAX_ED && !b->noSmallMatrix && !getenv("CMB_MATRIX64");
-                // text and run counts below 2^32 (the reference's default build of length_t): the expanding blocks work on 32-bit positions
-                // (CMB_MOVE_POS64=1: the general 40-bit path)
-                const bool smallPos = ix->d.n < 0xFFFFFFF0ull && ix->d.fwd.runs < 0xFFFFFFF0ull && ix->d.rev.runs < 0xFFFFFFF0ull && !getenv("CMB_MOVE_POS64");
                 const dim3 gStart(std::min<uint32_t>((nTasks + 255) / 256, BFS_GRID));
                 if (geoX)
                     hipLaunchKernelGGL(k_mvs_start<GeoX>, gStart, dim3(256), 0, s, b->stratW.p, B, b->tasks.p, nTasks, dOffs, b->gw, b->G.p, b->partsW.p, q);

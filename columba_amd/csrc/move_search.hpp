@@ -382,6 +382,179 @@ __device__ __forceinline__ uint32_t moveChildrenCounted(const MoveDev& ix, const
     return mask;
 }
 
+// The children of a parent IN SLOTS (round 4, the frontier kernel's instance on 32-bit positions).  moveChildrenCounted above keeps
+// everything that is indexed by character in registers, unrolled over the four characters: a node has 1.1 children on average, so
+// three quarters of what a wavefront issues there — LF images, widths, ranges, packing, and afterwards the matrix rows and the stores of
+// the frontier kernel — is work on children that do not exist.  Here the scan's results live in LDS, [field][character][lane], written
+// with the character a row holds as a run-time index, and the children are materialised ONE PER TURN in ascending character order into
+// slot j = the lane's j-th existing child (static register indices; the loops over slots end as soon as no lane of the wavefront has a
+// j-th child): `chars` holds the character of every slot (2 bits each), the return value is the number of children.
+struct MvScanLds {
+    uint32_t fOut[4][256], fRun[4][256], lOut[4][256], lRun[4][256], lSrc[4][256], smp[4][256];
+};
+__device__ __forceinline__ uint32_t moveChildrenSlots(const MoveDev& ix, const int mode, const MvPairT<uint32_t>& parent, uint32_t& rows, MvScanLds& L,
+                                                      const uint32_t tid, uint4 (*pk)[3], uint32_t& chars) {
+    typedef uint32_t P;
+    const bool fw = mode == 0;
+    MoveTable t;
+    t.rows = fw ? ix.rev.rows : ix.fwd.rows;
+    t.runs = fw ? ix.rev.runs : ix.fwd.runs;
+    t.zeroCharPos = fw ? ix.rev.zeroCharPos : ix.fwd.zeroCharPos;
+    t.samplesFirst = fw ? ix.rev.samplesFirst : ix.fwd.samplesFirst;
+    t.samplesLast = fw ? ix.rev.samplesLast : ix.fwd.samplesLast;
+    MvRangeT<P> trivial = selRange(fw, parent.rev, parent.sa);
+    const MvRangeT<P> other = selRange(fw, parent.sa, parent.rev);
+    if (!trivial.valid) { // (two binary searches between the enclosing run indices)
+        P span = trivial.endRun - trivial.beginRun;
+        while (span) {
+            rows += 2;
+            span >>= 1;
+        }
+        computeRunIndices(t, trivial);
+    }
+    uint32_t found = 0, seen = 0; // bits 0..4: character seen from the front / from the back
+    uint32_t ffNeed = 0;          // end points (2 c: first, 2 c + 1: last) whose image left its target run
+    {
+        P runF = trivial.beginRun, posF = trivial.begin, runB = trivial.endRun, posB = trivial.end - 1;
+        uint4 rowF = t.rows[runF], rowB = t.rows[runB];
+        uint4 preF = t.rows[runF < trivial.endRun ? runF + 1 : runF], preB = t.rows[runB > trivial.beginRun ? runB - 1 : runB];
+        rows += 2;
+        bool fDone = false, bDone = false;
+        while (true) {
+            if (!fDone) {
+                const uint32_t h = rowHead(rowF);
+                if (!(found >> h & 1u)) {
+                    found |= 1u << h;
+                    if (h != 0u) {
+                        const MoveRowT<P> r = unpackMoveRowT<P>(rowF);
+                        const P off = posF - r.in;
+                        const uint32_t gap = rowGap(rowF);
+                        const bool ff = off >= gap; // (the row's gap field, move_dev.hpp: most images stay in the target run)
+                        L.fOut[h - 1u][tid] = r.out + off;
+                        L.fRun[h - 1u][tid] = r.outRun + ((ff && gap < MV_GAP_MAX) ? 1u : 0u);
+                        ffNeed |= ff ? 1u << (2u * (h - 1u)) : 0u;
+                    }
+                }
+                fDone = (found & 0x1Eu) == 0x1Eu || runF == trivial.endRun;
+            }
+            if (!bDone) {
+                const uint32_t h = rowHead(rowB);
+                if (!(seen >> h & 1u)) {
+                    seen |= 1u << h;
+                    if (h != 0u) {
+                        const MoveRowT<P> r = unpackMoveRowT<P>(rowB);
+                        const P off = posB - r.in;
+                        const uint32_t gap = rowGap(rowB);
+                        const bool ff = off >= gap;
+                        L.lOut[h - 1u][tid] = r.out + off;
+                        L.lRun[h - 1u][tid] = r.outRun + ((ff && gap < MV_GAP_MAX) ? 1u : 0u);
+                        L.lSrc[h - 1u][tid] = runB;
+                        ffNeed |= ff ? 2u << (2u * (h - 1u)) : 0u;
+                    }
+                }
+                bDone = (seen & 0x1Eu) == 0x1Eu || runB == trivial.beginRun || (fDone && (seen & 0x1Eu) == (found & 0x1Eu));
+            }
+            if (fDone && bDone) break;
+            const P posBNext = rowInT<P>(rowB) - 1;
+            if (!fDone) {
+                runF++;
+                rowF = preF;
+                rows++;
+                posF = rowInT<P>(rowF);
+            }
+            if (!bDone) {
+                posB = posBNext;
+                runB--;
+                rowB = preB;
+                rows++;
+            }
+            preF = t.rows[runF < trivial.endRun ? runF + 1 : runF];
+            preB = t.rows[runB > trivial.beginRun ? runB - 1 : runB];
+        }
+        found &= seen | 1u;
+    }
+    const uint32_t exist = (found >> 1) & 0xFu; // bit c: character c + 1 occurs in the range
+    // fast-forwards (moverepr.cpp:283-293) of the end points whose image left its target run: all of them step together
+    {
+        uint32_t act = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < 4; c++)
+            if (exist >> c & 1u) act |= 3u << (2 * c);
+        act &= ffNeed;
+        while (act) {
+            uint2 raw[8];
+            P run[8];
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) { // (unconditional loads: a finished end point reads row 0, see moveChildrenCounted)
+                run[2 * c] = (act >> (2 * c) & 1u) ? L.fRun[c][tid] : 0u;
+                run[2 * c + 1] = (act >> (2 * c + 1) & 1u) ? L.lRun[c][tid] : 0u;
+                raw[2 * c] = *reinterpret_cast<const uint2*>(t.rows + ((act >> (2 * c) & 1u) ? run[2 * c] + 1u : 0u));
+                raw[2 * c + 1] = *reinterpret_cast<const uint2*>(t.rows + ((act >> (2 * c + 1) & 1u) ? run[2 * c + 1] + 1u : 0u));
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                if (act >> (2 * c) & 1u) {
+                    rows++;
+                    if (rowInT<P>(raw[2 * c]) <= L.fOut[c][tid]) L.fRun[c][tid] = run[2 * c] + 1u;
+                    else act &= ~(1u << (2 * c));
+                }
+                if (act >> (2 * c + 1) & 1u) {
+                    rows++;
+                    if (rowInT<P>(raw[2 * c + 1]) <= L.lOut[c][tid]) L.lRun[c][tid] = run[2 * c + 1] + 1u;
+                    else act &= ~(1u << (2 * c + 1));
+                }
+            }
+        }
+    }
+    const P parentWidth = trivial.end - trivial.begin;
+    // the toehold samples of the children that narrow the range (bmove.cpp:222-266): requested together, before any is used
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++) { // (unconditional loads: a child that needs no sample reads samplesFirst[0])
+        const bool wanted = (exist >> c & 1u) && L.lOut[c][tid] + 1u - L.fOut[c][tid] != parentWidth;
+        const P src = wanted ? L.lSrc[c][tid] : 0u;
+        const bool atEnd = !wanted || src == trivial.endRun;
+        const uint64_t* sp = atEnd ? t.samplesFirst : t.samplesLast;
+        L.smp[c][tid] = (P)sp[wanted ? (atEnd ? trivial.endRun : src) : (P)0];
+    }
+    // MoveLFReprBP::getCumulativeCounts (moverepr.cpp:347-365): the '$' of the range, then the smaller characters
+    P cum = (trivial.begin <= t.zeroCharPos && trivial.end > t.zeroCharPos) ? 1 : 0;
+    uint32_t rem = exist, n = 0;
+    chars = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+        if (__ballot(rem != 0u) == 0ull) break; // (wave-uniform: no lane has a j-th child)
+        if (rem) {
+            const uint32_t c = (uint32_t)__ffs((int)rem) - 1u;
+            rem &= rem - 1u;
+            chars |= c << (2u * j);
+            n++;
+            const P fO = L.fOut[c][tid], lO = L.lOut[c][tid];
+            const P width = lO + 1u - fO; // = countChar(trivial, c + 1)
+            const MvRangeT<P> range1 = {fO, (P)(lO + 1u), L.fRun[c][tid], L.lRun[c][tid], true};
+            const MvRangeT<P> noRange{0, 0, 0, 0, true};
+            MvPairT<P> ch;
+            MvRangeT<P> second;
+            if (width == parentWidth) { // the other range and the toehold carry over
+                second = selRange(mode == 2, noRange, other);
+                ch.toehold = fw ? parent.toehold + (parent.repEnd ? 1 : 0) : parent.toehold - (parent.repEnd ? 0 : 1);
+                ch.repEnd = parent.repEnd;
+            } else {
+                const MvRangeT<P> narrowed{(P)(other.begin + cum), (P)(other.begin + cum + width), other.beginRun, other.endRun, false};
+                second = selRange(mode == 2, noRange, narrowed);
+                const P sm = L.smp[c][tid];
+                ch.toehold = fw ? (P)(ix.n - 1) - (sm - 1) : sm - 1;
+                ch.repEnd = fw;
+            }
+            ch.sa = selRange(fw, second, range1);
+            ch.rev = selRange(fw, range1, second);
+            ch.depth = parent.depth + 1;
+            MvTraits::pack(ch, pk[j][0], pk[j][1], pk[j][2]);
+            cum += width;
+        }
+    }
+    return n;
+}
+
 // IndexInterface::addChar (indexinterface.cpp:1034-1049) on this backend: code 1..4 extends `r` in `mode`, anything else
 // (N) empties it without touching a counter.  Returns true if the range is still non-empty.
 struct MvCounters {
@@ -901,6 +1074,208 @@ __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uin
     if (flags) atomicOr(&q.cnt[3], flags);
 }
 
+// The same on 32-bit positions with the children IN SLOTS (moveChildrenSlots): slot j = the lane's j-th existing child; the loops over
+// the children — matrix rows, the choice of the child a lane walks on with, the records — run over slots and end as soon as no lane of
+// the wavefront has a j-th child (1.1 children per node: most steps take one or two turns where the loops over characters took four).
+template <class Geo = GeoN>
+__device__ __forceinline__ void mvExpandSlots(const MoveDev& ix, const MvBufs& B, uint32_t pass, const Queues& q, uint32_t bid, uint32_t nBlocks) {
+    __shared__ uint32_t sh[4][5];
+    // per-lane state that is touched once per expansion lives in LDS, [field][lane], not in registers (the kernel waits for dependent row
+    // fetches: what it can keep in flight is set by its registers): the four match words of the row block
+    __shared__ uint64_t ldsM[4][256];
+    __shared__ MvScanLds scanLds; // the scan's results per character (moveChildrenSlots)
+    typedef uint32_t P;
+    const uint32_t tid = threadIdx.x;
+    typedef typename Geo::W W; // the word of a matrix row (dev_bfs_edit.hpp: 64 bits, or 32 for GeoN32)
+    typedef typename Geo::Pack EdPack;
+    constexpr uint32_t ED_CELLS = Geo::CELLS, ED_MAX = Geo::ED_MAX, EV_U4 = 1u + Geo::PK_U4;
+    constexpr uint32_t PU = MvTraits::PAIR_U4, FU = PU + 1;
+    const uint32_t nIn = min(B.nq[pass], B.qCap);
+    const uint4* __restrict__ Qi = B.Q[pass & 1u];
+    uint4* __restrict__ Qo = B.Q[(pass + 1u) & 1u];
+    uint4* __restrict__ Eo = B.Ev[(pass + 1u) & 1u];
+    const uint32_t qCap = B.qCap;
+    uint32_t flags = 0;
+    uint32_t cChildren = 0, cExp = 0, cRows = 0; // (per lane and launch: far below 2^32)
+    for (uint32_t base = bid * 256u; base < nIn; base += nBlocks * 256u) { // block-uniform trip count
+        const uint32_t i = base + threadIdx.x;
+        const bool act = i < nIn;
+        uint32_t kinds = 0; // 4 bits per child: kind | needF << 2
+        uint32_t row1 = 0, ctx = 0, fcP = BFS_NONE;
+        uint4 pk[4][3]; // the children's range pairs BY SLOT, packed as they are stored
+        uint32_t chars = 0, nCh = 0; // character of every slot (2 bits each), number of slots in use
+        W cHP[4], cHN[4];
+        uint32_t cMeta[4]; // score << 16 | RAC bit << 8 | final-column distance
+        uint32_t hotY = 0, clSize = 0; // (the band geometry stays packed as the context's hot word holds it)
+        int md = 0;
+        MvPairT<P> parent{};
+        uint32_t row = 0, score = 0, pRac = 0, blk = 0;
+        W pHP = 0, pHN = 0;
+        const uint4* Cx = B.C;
+        if (act) {
+            const uint4 n1 = qLoad(Qi + (size_t)PU * qCap + i), n2 = qLoad(Qi + (size_t)(PU + 1) * qCap + i);
+            parent = MvTraits::unpackT<P>(qLoad(Qi + i), qLoad(Qi + (size_t)qCap + i), qLoad(Qi + (size_t)2 * qCap + i));
+            ctx = n1.y;
+            fcP = n1.z;
+            row = n1.x & 0xFFFFu;
+            score = n1.x >> 16;
+            md = (int)((n1.w >> 8) & 3u);
+            Cx = B.C + (size_t)CMB_IDX(ctx, B.cCap, 1) * B.ctxU4;
+            blk = (row + 1) / Geo::CTX_BLOCK;
+            const uint4 hot = Cx[CTX_HOT];
+            const uint4 mA = Cx[CTX_M + 2 * blk], mB = Cx[CTX_M + 1 + 2 * blk];
+            ldsM[0][tid] = u64of(mA.x, mA.y), ldsM[1][tid] = u64of(mA.z, mA.w), ldsM[2][tid] = u64of(mB.x, mB.y), ldsM[3][tid] = u64of(mB.z, mB.w);
+            hotY = hot.y;
+            clSize = hot.w >> 23;
+            Geo::unpackRow(n2, pHP, pHN);
+            pRac = n1.w & 63u;
+        }
+        // ---- walk: an expansion that yields exactly one plain node (outside the final column) is followed at once by the
+        // expansion of that child, by the same lane — no node record written and read back, no queue slot — for up to B.chain
+        // rows; on this index most of a search is such a path (no in-text switch ends it: ranges stay narrow down to the last
+        // row).  The lane stops at the first expansion that produces anything else; its children are what is appended below.
+        bool walking = act;
+        for (uint32_t step = 0; step < B.chain; step++) { // (wave-uniform exit below)
+            if (walking) {
+                row1 = row + 1;
+                if (row1 / Geo::CTX_BLOCK != blk) { // the walk crossed into the next block of match words
+                    blk = row1 / Geo::CTX_BLOCK;
+                    const uint4 mA = Cx[CTX_M + 2 * blk], mB = Cx[CTX_M + 1 + 2 * blk];
+                    ldsM[0][tid] = u64of(mA.x, mA.y), ldsM[1][tid] = u64of(mA.z, mA.w), ldsM[2][tid] = u64of(mB.x, mB.y), ldsM[3][tid] = u64of(mB.z, mB.w);
+                }
+                uint32_t rows = 0;
+#pragma unroll
+                for (uint32_t c = 0; c < 4; c++) { // (nothing of the previous expansion stays alive across the scan)
+                    pk[c][0] = pk[c][1] = pk[c][2] = make_uint4(0, 0, 0, 0);
+                    cHP[c] = cHN[c] = 0;
+                    cMeta[c] = 0;
+                }
+                nCh = moveChildrenSlots(ix, md, parent, rows, scanLds, tid, pk, chars);
+                cRows += rows;
+                cExp++;
+                MatGeom g;
+                g.n = hotY & 0x1FFu;
+                g.m = (hotY >> 9) & 0x1FFu;
+                g.Wv = (hotY >> 18) & 31u;
+                g.Wh = (hotY >> 23) & 15u;
+                g.maxED = (hotY >> 27) & 15u;
+                const bool inFC = g.inFinalColumn(row1);
+                if (inFC && clSize + row1 - g.m >= ED_CELLS) flags |= FLAG_CAPACITY;
+                kinds = 0;
+#pragma unroll
+                for (uint32_t c = 0; c < 4; c++) { // (c: the slot)
+                    if (__ballot(c < nCh) == 0ull) break; // (wave-uniform)
+                    if (c >= nCh) continue;
+                    cChildren++;
+                    const W M = Geo::mword(ldsM[(chars >> (2u * c)) & 3u][tid], row1);
+                    W HP = pHP, HN = pHN, RAC = Geo::racBit(pRac), D0;
+                    uint32_t sc = score;
+                    const bool valid = Geo::row(g, row1, M, HP, HN, D0, RAC, sc);
+                    if (!valid && !inFC) continue; // pruned when popped (branchAndBound returns true, :560)
+                    uint32_t res = KIND_NODE, aux = 0;
+                    if (inFC) {
+                        const uint32_t ed = Geo::cell(row1, g.n - 1, HP, HN, sc);
+                        aux = min(ed, ED_MAX);
+                        res |= 4u;
+                        if (ed > ED_MAX) flags |= FLAG_CAPACITY;
+                        if (!valid || Geo::ovgl(g, row1, HN)) res = (res & ~3u) | KIND_EVENT;
+                    }
+                    kinds |= res << (4 * c);
+                    cHP[c] = HP, cHN[c] = HN;
+                    if (sc > 0xFFFFu) flags |= FLAG_CAPACITY;
+                    cMeta[c] = (sc << 16) | (Geo::racIdx(RAC) << 8) | aux;
+                }
+                const bool single = kinds == (uint32_t)KIND_NODE || kinds == ((uint32_t)KIND_NODE << 4) || kinds == ((uint32_t)KIND_NODE << 8) ||
+                                    kinds == ((uint32_t)KIND_NODE << 12);
+                if (single && step + 1u < B.chain && row1 + 1u < B.ctxMblk * Geo::CTX_BLOCK) {
+#pragma unroll
+                    for (uint32_t c = 0; c < 4; c++)
+                        if (kinds == ((uint32_t)KIND_NODE << (4 * c))) {
+                            parent = MvTraits::unpackT<P>(pk[c][0], pk[c][1], pk[c][2]);
+                            pHP = cHP[c];
+                            pHN = cHN[c];
+                            score = cMeta[c] >> 16;
+                            pRac = (cMeta[c] >> 8) & 63u;
+                        }
+                    row = row1;
+                    kinds = 0; // (nothing of this expansion is left to append)
+                } else {
+                    walking = false;
+                }
+            }
+            if (__ballot(walking) == 0ull) break;
+        }
+        uint32_t nNode = 0, nEv = 0, nF = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t kd = (kinds >> (4 * c)) & 3u;
+            nNode += kd == KIND_NODE;
+            nEv += kd == KIND_EVENT;
+            nF += (kinds >> (4 * c + 2)) & 1u;
+        }
+        const uint32_t want[4] = {nNode, nEv, 0u, nF};
+        uint32_t got[4];
+        blockAppend4(&B.nq[pass + 1], &B.ne[pass + 1], &q.cnt[0], &B.pool[0], want, sh, got);
+        uint32_t oNode = got[0], oEv = got[1], oF = got[3];
+        bool ok = true;
+        if (oNode + nNode > qCap) { ok = false; flags |= FLAG_BFS_Q; }
+        if (oEv + nEv > B.evCap) { ok = false; flags |= FLAG_BFS_EV; }
+        if (oF + nF > B.fCap) { ok = false; flags |= FLAG_BFS_F; }
+        if (kinds != 0u && ok) {
+            const uint32_t cell = min(clSize + row1 - ((hotY >> 9) & 0x1FFu), ED_CELLS - 1u);
+            EdPack pack{};
+            if (fcP != BFS_NONE && (kinds & 0x4444u)) packLoad(Qi + (size_t)(PU + 2) * qCap + i, qCap, pack);
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) { // (c: the slot)
+                if (__ballot((kinds >> (4 * c)) != 0u) == 0ull) break; // (wave-uniform: no lane has a record in this slot or a later one)
+                const uint32_t kd = (kinds >> (4 * c)) & 3u;
+                if (kd == KIND_NONE) continue;
+                const bool wantF = (kinds >> (4 * c + 2)) & 1u;
+                uint32_t fc = BFS_NONE;
+                if (wantF) {
+                    fc = oF++;
+                    uint4* Fr = B.F + (size_t)CMB_IDX(fc, B.fCap, 9) * FU;
+                    Fr[0] = pk[c][0], Fr[1] = pk[c][1], Fr[2] = pk[c][2];
+                    Fr[PU] = make_uint4(row1 | ((((chars >> (2u * c)) & 3u) + 1u) << 16), fcP, 0u, 0u);
+                }
+                if (kd == KIND_NODE) {
+                    const uint32_t o = oNode++;
+                    qStore(Qo + o, pk[c][0]), qStore(Qo + (size_t)qCap + o, pk[c][1]), qStore(Qo + (size_t)2 * qCap + o, pk[c][2]);
+                    qStore(Qo + (size_t)PU * qCap + o, make_uint4(row1 | (cMeta[c] & 0xFFFF0000u), ctx, fc, ((cMeta[c] >> 8) & 63u) | ((uint32_t)md << 8)));
+                    qStore(Qo + (size_t)(PU + 1) * qCap + o, Geo::packRow(cHP[c], cHN[c]));
+                    if (wantF) {
+                        EdPack p2 = pack;
+                        edPut(p2, cell, cMeta[c] & 0xFFu);
+                        packStore(Qo + (size_t)(PU + 2) * qCap + o, qCap, p2);
+                    }
+                } else { // KIND_EVENT
+                    EdPack p2 = pack;
+                    edPut(p2, cell, cMeta[c] & 0xFFu);
+                    Eo[(size_t)EV_U4 * oEv] = make_uint4(ctx, fc, 0xFFFFFFFFu, cell);
+                    packStore(Eo + (size_t)EV_U4 * oEv + 1, 1, p2);
+                    oEv++;
+                }
+            }
+        }
+    }
+    // per-block counters (summed by k_mvs_finish): one writer per slot and launch, launches are ordered
+    unsigned long long v[4] = {cChildren, cExp, cChildren, cRows}; // (every child gets its matrix row)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v[j] += __shfl_xor(v[j], d);
+    }
+    __shared__ unsigned long long shc[4][4];
+    if ((threadIdx.x & 63u) == 0)
+        for (int j = 0; j < 4; j++) shc[threadIdx.x >> 6][j] = v[j];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const unsigned long long t = shc[0][threadIdx.x] + shc[1][threadIdx.x] + shc[2][threadIdx.x] + shc[3][threadIdx.x];
+        if (t) B.blockCnt[(size_t)bid * 4 + threadIdx.x] += t;
+    }
+    if (flags) atomicOr(&q.cnt[3], flags);
+}
+
 template <class Geo = GeoN>
 __global__ void __launch_bounds__(256)
 k_mvs_start(const DevStrategyKT<Geo::MP>* __restrict__ stp, MvBufs B, const MvTask* __restrict__ tasks, uint32_t nTasks, const uint64_t* __restrict__ offs,
@@ -918,10 +1293,14 @@ constexpr uint32_t MVS_CHAIN = 3; // expansions a lane makes in a row while each
 #ifndef CMB_MVS_WAVES
 #define CMB_MVS_WAVES 3 // wavefronts per SIMD the register allocation of k_mvs_pass<GeoN32 / GeoN> is held to
 #endif
+// ... and of its instances on 32-bit positions with the children in slots (mvExpandSlots: 154 registers; at 128 two dozen words are
+// spilled at the start of a tile and reloaded in its output stage, none inside the chain loop): four wavefronts per SIMD, 896 + 128
+// blocks resident in one round, chains of 4: 1 153 k -> 1 209 k reads/s on the configs[4] stand-in
 #ifndef CMB_MVS_WAVES_SMALL
-#define CMB_MVS_WAVES_SMALL 3 // ... and of its instances on 32-bit positions
+#define CMB_MVS_WAVES_SMALL 4
 #endif
-constexpr uint32_t MVS_GRID_X = 640, MVS_GRID_X_WIDE = 896; // expanding blocks of k_mvs_pass (CMB_MVS_GRID); + BFS_GRID_EV event blocks
+constexpr uint32_t MVS_GRID_X = 640, MVS_GRID_X_WIDE = 896, MVS_GRID_X_SMALL = 896; // expanding blocks of k_mvs_pass (CMB_MVS_GRID); + BFS_GRID_EV event blocks
+constexpr uint32_t MVS_CHAIN_SMALL = 4;
 // SMALL: text and run counts below 2^32 — the expanding half works on 32-bit positions (the reference's default build of length_t; the
 // records keep their 40-bit fields, so the event half and every other kernel of the backend are the same)
 template <class Geo = GeoN, bool SMALL = false>
@@ -929,7 +1308,10 @@ __global__ void __launch_bounds__(256, Geo::MP == MAXP ? (SMALL ? CMB_MVS_WAVES_
 k_mvs_pass(MoveDev ix, const DevStrategyKT<Geo::MP>* __restrict__ stp, MvBufs B, uint32_t pass, const uint64_t* __restrict__ offs, uint32_t gw,
            const uint32_t* __restrict__ G, const PartOutT<Geo::MP>* __restrict__ parts, Queues q) {
     if (blockStopped(q)) return;
-    if (blockIdx.x < B.gridX) mvExpand<Geo, typename std::conditional<SMALL, uint32_t, uint64_t>::type>(ix, B, pass, q, blockIdx.x, B.gridX);
+    if (blockIdx.x < B.gridX) {
+        if (SMALL) mvExpandSlots<Geo>(ix, B, pass, q, blockIdx.x, B.gridX);
+        else mvExpand<Geo, uint64_t>(ix, B, pass, q, blockIdx.x, B.gridX);
+    }
     else bfsHeavy<false, MvTraits, Geo>(stp, B, pass, nullptr, 0u, offs, gw, G, parts, q, blockIdx.x - B.gridX, B.gridEv);
 }
 __global__ void k_mvs_finish(MvBufs B, Queues q) { // one block: per-block counters -> the batch counters
