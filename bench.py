@@ -718,12 +718,15 @@ def main():
     # has the device to itself (in the timed steps above they overlap, which is where 15 % of the throughput
     # comes from, but a kernel's duration then depends on what happens to run beside it)
     os.environ["CMB_SERIAL_SUBBATCHES"] = "1"
+    serial_runs = []
     try:
-        batch.run()
+        for _ in range(3):  # (three such steps, the median per kernel group: one sample moved by 3 ms between otherwise identical runs)
+            batch.run()
+            torch.cuda.synchronize()
+            serial_runs.append(dict(batch.timings()))
     finally:
         del os.environ["CMB_SERIAL_SUBBATCHES"]
-    torch.cuda.synchronize()
-    kern_serial = dict(batch.timings())
+    kern_serial = {kn: float(np.median([r.get(kn, 0.0) for r in serial_runs])) for kn in serial_runs[0]}
     occ, occ_offs, cnt = batch.results()
     total_occ = len(occ)
     gather_ms = None
@@ -800,7 +803,7 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "traffic_source": traffic_source, "kernel_src_sha": source_digest(),
                     "traffic_note": traffic_note, "avg_launch_ms": round(avg[dominant], 3),
-                    "timing_note": "kernel times (HIP events on the batch's streams) are from one extra step with the "
+                    "timing_note": "kernel times (HIP events on the batch's streams) are the medians of three extra steps with the "
                                    "batch's sub-batches run one after the other; in the timed steps the sub-batches "
                                    "overlap (busy ms per step there: see concurrent_ms)",
                     "concurrent_ms": {k: round(v, 3) for k, v in avg_concurrent.items()},

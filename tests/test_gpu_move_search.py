@@ -263,6 +263,23 @@ def test_bmove_alignments(sworld, spec, k, length):
     fm.close()
 
 
+@pytest.mark.parametrize("env", [{"CMB_MATRIX64": "1"}, {"CMB_TEST_NARROW_WV": "2"}, {"CMB_MOVE_POS64": "1"}])
+def test_bmove_frontier_code_paths(sworld, monkeypatch, env):
+    """Round 4: up to 7 errors the frontier of this backend carries the in-index matrix on 32-bit words (GeoN32) and, on indexes below 2^32,
+    works on 32-bit positions with the children in slots (mvExpandSlots) — every test above runs on that.  Here the same lists and counters
+    on the reference's 64-bit matrix words, through the re-run a phase triggers that does not fit the small matrix (bound lowered by the
+    test hook), and on the general 40-bit positions."""
+    ca = sworld["ca"]
+    reads = _reads(sworld["g"], 5, 600, 150, seed=77)
+    st = ca.SearchStrategy("columba", "edit", "dynamic")
+    a = sworld["dev"].match_batch(st, 5, reads, kmer_size=8)
+    for n, v in env.items():
+        monkeypatch.setenv(n, v)
+    b = sworld["dev"].match_batch(st, 5, reads, kmer_size=8)
+    assert len(a[0]) > 300
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+
 def test_bmove_pool_growth(sworld):
     """pools that start from almost nothing are grown and the search re-run: same lists"""
     ca = sworld["ca"]
