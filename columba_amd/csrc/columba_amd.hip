@@ -642,6 +642,11 @@ struct cmb_batch {
     DevBuf<uint8_t> readsStage;
     DevBuf<uint64_t> offsStage;
     std::vector<uint64_t> hostOffsStage, hostOffsActive;
+    // the offsets of a registered chunk once more in PAGE-LOCKED memory, two buffers taking turns: the upload a run starts must not stall
+    // the host (from pageable memory hipMemcpyAsync copies through bounce buffers before it returns — milliseconds in which the run has
+    // not launched a kernel yet), and the next registration must not overwrite offsets the copy engine is still reading
+    PinnedBuf<uint64_t> offsPin[2];
+    int pinNext = 0, pinStaged = 0;
     hipStream_t copyStream = nullptr;
     hipEvent_t copyDone = nullptr;
     bool staged = false;                 // readsStage / offsStage hold an uploaded chunk (or its upload is in flight)
@@ -935,6 +940,10 @@ extern "C" int cmb_batch_stage_reads(cmb_batch* b, const char* seqs, const uint6
     if (maxLen > b->maxLen) return fail(CMB_ERR_INVALID, "a staged read is longer than the batch was created for");
     if (b->pending) return fail(CMB_ERR_INVALID, "a chunk is already registered for the next run");
     b->hostOffsStage.assign(offs, offs + n_reads + 1);
+    b->offsPin[b->pinNext].resize((size_t)n_reads + 1);
+    memcpy(b->offsPin[b->pinNext].p, offs, ((size_t)n_reads + 1) * sizeof(uint64_t));
+    b->pinStaged = b->pinNext;
+    b->pinNext ^= 1;
     b->pendingSeqs = seqs;
     b->pending = true;
     return CMB_OK;
@@ -950,7 +959,7 @@ static void startStagedUpload(cmb_batch* b) {
     if (b->readsStage.n < nChars) b->readsStage.alloc(nChars + nChars / 16 + 256);
     if (b->offsStage.n < (size_t)n + 1) b->offsStage.alloc((size_t)n + 1);
     if (nChars) HIPCHK(hipMemcpyAsync(b->readsStage.p, b->pendingSeqs, nChars, hipMemcpyHostToDevice, b->copyStream));
-    HIPCHK(hipMemcpyAsync(b->offsStage.p, b->hostOffsStage.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice,
+    HIPCHK(hipMemcpyAsync(b->offsStage.p, b->offsPin[b->pinStaged].p, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice,
                           b->copyStream));
     HIPCHK(hipEventRecord(b->copyDone, b->copyStream));
     b->pending = false;
@@ -972,8 +981,8 @@ static int batchRunOne(cmb_batch* b) {
             b->staged = false;
         }
         if (b->pending) { // the chunk registered since travels to the device while this run's kernels execute
-            b->hostOffsActive = b->hostOffsStage; // (offsets of the chunk in flight: the batch's from the next run on)
             startStagedUpload(b);
+            b->hostOffsActive.swap(b->hostOffsStage); // (offsets of the chunk in flight: the batch's from the next run on; the next registration refills hostOffsStage)
         }
         b->times.clear();
         b->done = false;
