@@ -29,6 +29,43 @@ using namespace cmb;
 
 namespace {
 
+// a growing host array in PAGE-LOCKED memory (the occurrence records of a batch: 10^6 reads of BASELINE configs[4] leave 1.15 GB — into
+// a std::vector the device-to-host copy went through bounce buffers and the resize zeroed every record first); contents are kept when
+// it grows, the capacity is kept between runs
+template <typename T> struct MvHostVec {
+    T* p = nullptr;
+    size_t n = 0, cap = 0;
+    MvHostVec() {}
+    MvHostVec(const MvHostVec&) = delete;
+    MvHostVec& operator=(const MvHostVec&) = delete;
+    ~MvHostVec() {
+        if (p) (void)hipHostFree(p);
+    }
+    void resize(size_t count) {
+        if (count > cap) {
+            const size_t want = count + count / 2 + 1024;
+            T* q = nullptr;
+            MV_HIPCHK(hipHostMalloc((void**)&q, want * sizeof(T), hipHostMallocDefault));
+            if (n) memcpy(q, p, n * sizeof(T));
+            if (p) (void)hipHostFree(p);
+            p = q;
+            cap = want;
+        }
+        n = count;
+    }
+    void assign(const std::vector<T>& v) {
+        n = 0;
+        resize(v.size());
+        if (!v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
+    }
+    void clear() { n = 0; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    const T& operator[](size_t i) const { return p[i]; }
+};
+
 template <typename T> struct MvBuf {
     T* p = nullptr;
     size_t n = 0;
@@ -679,7 +716,7 @@ struct cmb_move_batch {
     std::vector<uint4> hAlnRec; // {seqId, seqBegin, nOps, spans} per occurrence
     std::vector<uint16_t> hAlnOps;
     // results
-    std::vector<cmb_move_occ> occs;
+    MvHostVec<cmb_move_occ> occs;
     std::vector<uint64_t> occOffs;
     uint64_t cnts[CMB_CNT_MAX];
     std::vector<std::pair<const char*, float>> times;
@@ -839,7 +876,7 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
             }
             if (rc != CMB_OK) return rc;
             tmp.resize(nOcc);
-            b->occs.swap(tmp);
+            b->occs.assign(tmp);
             if (b->wantAln) { // an exact match aligns as <length>M; its sequence by position (findSeqName, indexinterface.cpp:799-832)
                 const std::vector<uint32_t>& sp = cmb::seqStartsOfIndex(ix->textIndex);
                 b->hAlnRec.resize(nOcc);
