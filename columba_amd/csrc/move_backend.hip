@@ -926,7 +926,7 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
         // ---- read preparation
         tm.begin();
         MV_HIPCHK(hipMemsetAsync(b->G.p, 0, (size_t)nReads * 8 * b->gw * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(k_mvs_prep, dim3(gridFor(nReads)), dim3(256), 0, s, b->reads.p, dOffs, nReads, b->maxLen, b->gw, b->seq.p, b->G.p);
+        hipLaunchKernelGGL(k_mvs_prep, dim3(gridFor((uint64_t)nReads * b->gw)), dim3(256), 0, s, b->reads.p, dOffs, nReads, b->maxLen, b->gw, b->seq.p, b->G.p);
         tm.end("k_prep");
         const uint32_t P = b->sNumParts, maxSearches = b->sMaxSearches;
         uint32_t nFm = 0;

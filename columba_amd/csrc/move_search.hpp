@@ -598,21 +598,37 @@ __device__ inline MvPair mvCompleteRange(const MoveDev& ix) { // BMove::getCompl
 // the eight match bit-strings of the read (dev_matrix.hpp: gString — read / reversed read x A, C, G, T; G zeroed beforehand).
 __global__ void k_mvs_prep(const uint8_t* __restrict__ reads, const uint64_t* __restrict__ offs, uint32_t nReads, uint32_t maxLen, uint32_t gw,
                            uint8_t* __restrict__ seq, uint32_t* __restrict__ G) {
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nReads; r += gridDim.x * blockDim.x) {
+    // one thread per read and 32-character word (round 4; one thread per read with a read-modify-write of global memory per character
+    // took 23 ms and 123 GB of traffic for the 250 MB of reads of BASELINE configs[4]): the thread owns word w of all eight bit-strings —
+    // those of the read from the characters [32 w, 32 w + 32), those of the reversed read from the same positions counted from the end —
+    // and the codes of both strands at those positions; words beyond the read are written as zeros.
+    const uint64_t nW = (uint64_t)nReads * gw;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nW; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)(t / gw), w = (uint32_t)(t % gw);
         const uint8_t* rd = reads + offs[r];
-        const uint32_t len = (uint32_t)(offs[r + 1] - offs[r]);
+        const uint32_t len = min((uint32_t)(offs[r + 1] - offs[r]), maxLen);
         uint8_t* sF = seq + (size_t)(2 * r) * maxLen;
         uint8_t* sR = seq + (size_t)(2 * r + 1) * maxLen;
-        uint32_t* g = G + (size_t)r * 8 * gw;
-        for (uint32_t i = 0; i < len && i < maxLen; i++) {
-            const uint8_t a = rd[i] & 0xDF;
+        uint32_t fw[4] = {0, 0, 0, 0}, rv[4] = {0, 0, 0, 0};
+        for (uint32_t bb = 0; bb < 32; bb++) {
+            const uint32_t i = 32u * w + bb;
+            if (i >= len) break;
+            const uint8_t a = rd[i] & 0xDF, a2 = rd[len - 1 - i] & 0xDF; // (the reversed read holds character len - 1 - i at position i)
             const uint32_t c = a == 'A' ? 1 : a == 'C' ? 2 : a == 'G' ? 3 : a == 'T' ? 4 : 5;
+            const uint32_t c2 = a2 == 'A' ? 1 : a2 == 'C' ? 2 : a2 == 'G' ? 3 : a2 == 'T' ? 4 : 5;
             sF[i] = (uint8_t)c;
-            sR[len - 1 - i] = (uint8_t)(c <= 4 ? 5 - c : 5);
-            if (c <= 4) {
-                g[(c - 1) * gw + (i >> 5)] |= 1u << (i & 31u);                              // the read
-                g[(4 + c - 1) * gw + ((len - 1 - i) >> 5)] |= 1u << ((len - 1 - i) & 31u); // the reversed read
+            sR[i] = (uint8_t)(c2 <= 4 ? 5 - c2 : 5);
+#pragma unroll
+            for (uint32_t k4 = 0; k4 < 4; k4++) {
+                fw[k4] |= c == k4 + 1 ? 1u << bb : 0u;
+                rv[k4] |= c2 == k4 + 1 ? 1u << bb : 0u;
             }
+        }
+        uint32_t* g = G + (size_t)r * 8 * gw;
+#pragma unroll
+        for (uint32_t k4 = 0; k4 < 4; k4++) {
+            g[k4 * gw + w] = fw[k4];
+            g[(4 + k4) * gw + w] = rv[k4];
         }
     }
 }
