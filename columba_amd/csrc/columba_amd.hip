@@ -1217,7 +1217,7 @@ static int batchRunOne(cmb_batch* b) {
                     B.ne = b->bfsCnt.p + (maxPass + 2);
                     B.pool = b->bfsCnt.p + 2 * (maxPass + 2);
                     B.blockCnt = b->bfsBlockCnt.p;
-                    // up to 7 errors the frontier carries the in-index matrix on 32-bit words (GeoN32, dev_matrix.hpp: MXS_*); CMB_MATRIX64=1
+                    // up to 6 errors the frontier carries the in-index matrix on 32-bit words (GeoN32, dev_matrix.hpp: MXS_*); CMB_MATRIX64=1
                     // keeps the reference's 64-bit words (GeoN), as does a batch one of whose phases did not fit the small matrix
                     const bool small32 = !b->wide && b->k <= MXS_MAX_ED && !b->noSmallMatrix && !getenv("CMB_MATRIX64");
                     if (b->geoX)

@@ -242,12 +242,12 @@ struct MxNarrow {
         return onlyVerticalGapsLeftAs<BLOCK, DIAG>(g, i, HN, g.maxED <= MX_MAX_ED ? 64u : 128u);
     }
 };
-// the in-index matrix up to 7 errors on 32-bit words and 8-row blocks (dev_matrix.hpp: MXS_*): half the instructions of a matrix row; the
+// the in-index matrix up to 6 errors on 32-bit words and 8-row blocks (dev_matrix.hpp: MXS_*): half the instructions of a matrix row; the
 // contexts keep the 64-bit match words of 32-row blocks, a lane keeps walking its chain across the 8-row blocks inside them
 struct MxSmall32 {
     typedef uint32_t W;
     static constexpr uint32_t BLOCK = MXS_BLOCK, LEFT = MXS_LEFT, DIAG = MXS_DIAG, CTX_BLOCK = MX_BLOCK, CTX_LEFT = MX_LEFT;
-    static constexpr bool NARROW_FALLBACK = true; // (a phase with Wv > DIAG: FLAG_NARROW_MATRIX, the host re-runs on GeoN)
+    static constexpr bool NARROW_FALLBACK = true; // (a phase with Wv > DIAG - MXS_SLACK: FLAG_NARROW_MATRIX, the host re-runs on GeoN)
     static __device__ __forceinline__ W mword(uint64_t M, uint32_t i) { return matchWordSmall(M, i); }
     static __device__ __forceinline__ W racBit(uint32_t idx) { return 1u << idx; }
     static __device__ __forceinline__ uint32_t racIdx(W rac) { return 31u - (uint32_t)__clz((int)rac); }
@@ -1034,7 +1034,7 @@ __device__ __forceinline__ void bfsHeavy(const DevStrategyKT<Geo::MP>* __restric
             initMatrix<Geo::LEFT, Geo::DIAG, typename Geo::W>(g, xLen, maxEDn, first, lastI, nSrcInit ? il : nullptr, increase, nInit, HP, HN, RAC, score);
             const uint32_t clSize = g.sfc();
             const uint32_t nBlk = (g.m - 1) / Geo::CTX_BLOCK + 1;
-            if (Geo::NARROW_FALLBACK && (g.Wv > min(Geo::DIAG, B.narrowWv) || maxEDn > MXS_MAX_ED)) {
+            if (Geo::NARROW_FALLBACK && (g.Wv > min(Geo::DIAG - MXS_SLACK, B.narrowWv) || maxEDn > MXS_MAX_ED)) {
                 flags |= FLAG_NARROW_MATRIX; // (the first column does not fit the small matrix: the host runs the batch on the 64-bit geometry)
             } else if (g.Wv >= Geo::LEFT || clSize > ED_CELLS || nBlk > B.ctxMblk || g.m > 0xFFFFu) {
                 flags |= FLAG_CAPACITY;

@@ -382,7 +382,7 @@ __device__ __forceinline__ bool onlyVerticalGapsLeftAs(const MatGeom& g, uint32_
     return (~HN & mask) == 0ull;
 }
 
-// ---- the in-index matrix up to 7 errors: 32-bit words, 8-row blocks (round 4: GeoN32 of dev_bfs_edit.hpp) ----
+// ---- the in-index matrix up to 6 errors: 32-bit words, 8-row blocks (round 4: GeoN32 of dev_bfs_edit.hpp) ----
 // The frontier kernels are bound by instruction issue (profiles/r04_frontier_experiments.txt), and half of what they issue is the matrix
 // row of a child on 64-bit words — register pairs, 64-bit shifts — of which the band of up to 7 errors uses a third.  The reference's own
 // sizing rule (bitparallelmatrix.h:311-316) with WORD 32 and BLOCK 8 gives MATRIX_MAX_ED = (32 - 8 - 2) / 3 = 7, LEFT = 15, DIAG = 14: the
@@ -391,12 +391,18 @@ __device__ __forceinline__ bool onlyVerticalGapsLeftAs(const MatGeom& g, uint32_
 // cluster centres and first columns; `onlyVerticalGapsLeft` is answered as the reference's 64-bit matrix would answer it
 // (onlyVerticalGapsLeftAs, refWord 64).  As for the 16-row matrix of 11 ... 13 errors this was settled on the CPU before the device code
 // was written: the oracle's search on BitParallelEDT<uint32_t, 8> against the search on the reference's matrices — occurrences and EVERY
-// counter (tests/test_narrow_block_matrix.py, tools/soak_narrow32.py).  A phase whose first column does not fit (Wv > DIAG) raises
-// FLAG_NARROW_MATRIX and the host runs the batch on the 64-bit geometry instead.
+// counter (tests/test_narrow_block_matrix.py, tools/soak_narrow32.py, tools/soak_narrow32_periodic.py).  The sizing rule is an upper
+// bound at which the window has NO slack beside the band (Wv = 2 maxED = 14 = DIAG at 7 errors), and there the small matrix is not
+// the reference's 64-bit one, which at 7 errors has six spare columns: on periodic texts (tandem repeats, the widest first columns and
+// the most alternative alignments) a search at 7 errors computed a few matrix rows more or fewer in replays and once visited four
+// nodes more — found by tools/soak_tiny_texts.py on the device, reproduced by the CPU experiment.  With two spare columns nothing
+// differs (3 128 configurations on periodic texts, 300 on human-like ones): the small matrix serves batches of up to MXS_MAX_ED = 6
+// errors, and a phase whose first column leaves fewer than two spare columns (Wv > DIAG - 2) raises FLAG_NARROW_MATRIX — the host
+// then runs the batch on the 64-bit geometry.
 // The match words stay those of the contexts (64-bit words of 32-row blocks, LEFT 21): bit p of the 8-row block a row lies in is bit
 // p + 8 s + (21 - 15) of its 32-row block's word (s = the 8-row block's number within the 32 rows) — columns left of the sequence read as
 // ones and columns beyond it as zeros in both.
-constexpr uint32_t MXS_BLOCK = 8, MXS_DIAG = 14, MXS_LEFT = 15, MXS_MAX_ED = 7;
+constexpr uint32_t MXS_BLOCK = 8, MXS_DIAG = 14, MXS_LEFT = 15, MXS_MAX_ED = 6, MXS_SLACK = 2;
 __device__ __forceinline__ uint32_t matchWordSmall(uint64_t M64, uint32_t i) {
     return (uint32_t)(M64 >> (((i % MX_BLOCK) / MXS_BLOCK) * MXS_BLOCK + (MX_LEFT - MXS_LEFT)));
 }

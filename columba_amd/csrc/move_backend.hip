@@ -1132,7 +1132,7 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
                 B.fmX = b->fm.p;
                 B.rowSteps = nullptr;
                 B.narrowWv = getenv("CMB_TEST_NARROW_WV") ? (uint32_t)std::max(0, atoi(getenv("CMB_TEST_NARROW_WV"))) : 0xFFFFu;
-                // up to 7 errors the in-index matrix runs on 32-bit words (GeoN32, dev_matrix.hpp: MXS_*) unless a phase did not fit it (CMB_MATRIX64=1: never)
+                // up to 6 errors the in-index matrix runs on 32-bit words (GeoN32, dev_matrix.hpp: MXS_*) unless a phase did not fit it (CMB_MATRIX64=1: never)
                 const bool small32 = !b->wide && b->k <= MXS_MAX_ED && !b->noSmallMatrix && !getenv("CMB_MATRIX64");
                 const dim3 gStart(std::min<uint32_t>((nTasks + 255) / 256, BFS_GRID));
                 if (geoX)

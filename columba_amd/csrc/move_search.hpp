@@ -894,7 +894,7 @@ k_mvs_exact(MvSearchIndex sx, const DevStrategyKT<MP>* __restrict__ stp, uint32_
 // :675-697, without the in-text switch this flavour does not have).  Node = range pair (3 planes) + the three planes of
 // dev_bfs_edit.hpp: {row | score << 16, ctx, fc, RAC bit | mode << 8} {HP, HN} {final-column distances}.
 // Geo: the record geometry of dev_bfs_edit.hpp — GeoN32 (up to 7 errors, the instance of BASELINE configs[4]: the in-index matrix on
-// 32-bit words since round 4; GeoN, the reference's 64-bit words, for a batch one of whose phases does not fit it), GeoW (8 ... 10),
+// 32-bit words since round 4 up to 6 errors; GeoN, the reference's 64-bit words, at 7 errors and for a batch one of whose phases does not fit the small matrix), GeoW (8 ... 10),
 // GeoX (11 ... 13: the in-index matrix with 16-row blocks).
 template <class Geo = GeoN, typename P = uint64_t>
 __device__ __forceinline__ void mvExpand(const MoveDev& ix, const MvBufs& B, uint32_t pass, const Queues& q, uint32_t bid, uint32_t nBlocks) {

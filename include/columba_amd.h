@@ -208,7 +208,7 @@ int cmb_match_batch(cmb_index* idx, const cmb_strategy* st, uint32_t max_distanc
  * Diagnostic knobs, read per run, none of which changes a result: CMB_MATRIX_WIDE=1 (in-text matrices on 64-bit
  * words also for k <= 4), CMB_TRACE_WIDE=1 (8-byte traceback rows also for k <= 4; that kernel checks the rules the
  * 4-byte rows rely on), CMB_STAGE_BLOCKS=n (32-row blocks per verification launch), CMB_MATRIX64=1 (the frontier's in-index
- * matrix on the reference's 64-bit words instead of the 32-bit words with 8-row blocks it runs on up to 7 errors; a batch one of
+ * matrix on the reference's 64-bit words instead of the 32-bit words with 8-row blocks it runs on up to 6 errors; a batch one of
  * whose phases does not fit the small matrix switches by itself), CMB_VERBOSE=1.
  * cmb_batch_timings: device time per kernel group of the last run (HIP events on the batch's streams; summed
  * over the sub-batches). */

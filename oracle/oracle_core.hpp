@@ -836,7 +836,8 @@ typedef BitParallelEDT<uint64_t> BitParallelED64;
 typedef BitParallelEDT<unsigned __int128> BitParallelED128;
 typedef BitParallelEDT<uint64_t, 16> BitParallelED64N; // (the narrow-block experiment)
 // ... and its round-4 sibling: a 32-bit word with 8-row blocks — by the same bound (32 - 8 - 2) / 3 = 7 errors, LEFT 15, DIAG 14: what the
-// frontier kernels of the device carry per node up to 7 errors (dev_bfs_edit.hpp: GeoN32); ORC_NARROW_BLOCKS=32
+// frontier kernels of the device carry per node up to 6 errors and with two spare columns beside the band (dev_bfs_edit.hpp: GeoN32; at the
+// bound itself the window has no slack and the matrix is not the reference's: tools/soak_narrow32_periodic.py); ORC_NARROW_BLOCKS=32
 typedef BitParallelEDT<uint32_t, 8> BitParallelED32N;
 
 // ----------------------------------------------------------------------------

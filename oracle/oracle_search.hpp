@@ -904,7 +904,11 @@ template <class IX> class MatcherT {
                             const std::vector<FMPosExt>& descNotPrevDir,
                             const std::vector<uint16_t>& initNotPrevDir) {
         const size_t matrixIdx = s.getPart(idx) + (s.getDirection(idx) == BACKWARD) * s.getNumParts();
-        if (narrow32 && s.getUpperBound(idx) <= BitParallelED32N::MATRIX_MAX_ED) { // (the device's GeoN32; a phase it cannot hold falls back below)
+        // (the device's GeoN32: searches of batches up to 6 errors; ORC_NARROW32_MAX / ORC_NARROW32_SLACK override the two bounds for the
+        // experiment that found them)
+        const uint32_t n32Max = getenv("ORC_NARROW32_MAX") ? (uint32_t)atoi(getenv("ORC_NARROW32_MAX")) : 6u;
+        const uint32_t n32Slack = getenv("ORC_NARROW32_SLACK") ? (uint32_t)atoi(getenv("ORC_NARROW32_SLACK")) : 2u;
+        if (narrow32 && s.getMaxED() <= n32Max) { // (a phase it cannot hold falls back below)
             if (matricesN32.size() < matrices.size()) matricesN32.resize(matrices.size());
             // Wv = |initED| - 1 + maxED - initED.back() must not exceed DIAG (14): the phase otherwise runs on the reference's matrix, as the
             // device re-runs such a batch on GeoN (FLAG_CAPACITY)
@@ -915,7 +919,7 @@ template <class IX> class MatcherT {
                 const uint16_t prevED = dSw ? *std::min_element(ie.begin(), ie.end()) : ie[0];
                 wv = (uint32_t)ie.size() - 1 + s.getUpperBound(idx) - (ie.back() + (startMatch.distance - prevED));
             }
-            if (wv <= BitParallelED32N::DIAG_R0) {
+            if (wv + n32Slack <= BitParallelED32N::DIAG_R0) {
                 g_narrow32Stats[0].fetch_add(1, std::memory_order_relaxed);
                 matricesN32[matrixIdx].emulate = 64u | (narrowBroken ? 256u : 0u);
                 recApproxMatchEditOn(&matricesN32[matrixIdx], s, startMatch, occ, parts, idx, descPrevDir, initPrevDir, descNotPrevDir, initNotPrevDir);

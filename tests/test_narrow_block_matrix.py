@@ -9,9 +9,12 @@ negative count near the end of a block (a region where its answer is `true` what
 oracle's search runs every part on BitParallelEDT<uint64_t, 16> and answers that predicate as the part's own matrix would
 (onlyVerticalGapsLeftAs); occurrences and every counter must equal the run on the reference's matrices.
 
-Round 4, the same question one size down: up to 7 errors a 32-bit word with 8-row blocks holds the band by the same bound ((32 - 8 - 2) / 3
+Round 4, the same question one size down: a 32-bit word with 8-row blocks holds the band of 7 errors by the same bound ((32 - 8 - 2) / 3
 = 7, LEFT 15, DIAG 14) — ORC_NARROW_BLOCKS=32 runs every part on BitParallelEDT<uint32_t, 8>, the matrix the device's frontier kernels
-carry per node since round 4 (dev_bfs_edit.hpp: GeoN32); tools/soak_narrow32.py is the long run (300 configurations, 5.1e7 phases)."""
+carry per node since round 4 (dev_bfs_edit.hpp: GeoN32).  AT the bound the window has no slack beside the band and the matrix is not the
+reference's (a few matrix rows more or fewer in replays on periodic texts at 7 errors: test_at_the_bound_the_small_matrix_differs); with
+two spare columns — batches of up to 6 errors, Wv <= 12 — nothing differs: tools/soak_narrow32.py (human-like texts) and
+tools/soak_narrow32_periodic.py (tandem repeats) are the long runs."""
 import os
 import sys
 
@@ -69,10 +72,10 @@ def test_the_experiment_sees_the_predicate(world):
     assert a_cnt["NODE_COUNTER"] != b_cnt["NODE_COUNTER"]
 
 
-@pytest.mark.parametrize("spec,partition,k,length,switch", [("multiple_opt", "dynamic", 4, 150, 4), ("columba", "dynamic", 7, 150, 4), ("columba", "uniform", 5, 480, 0),
+@pytest.mark.parametrize("spec,partition,k,length,switch", [("multiple_opt", "dynamic", 4, 150, 4), ("columba", "dynamic", 6, 150, 4), ("columba", "uniform", 5, 480, 0),
                                                             ("kuch1", "static", 3, 100, 0), ("kianfar", "dynamic", 4, 60, 4), ("columba", "static", 6, 60, 4),
-                                                            ("pigeon", "dynamic", 2, 250, 0), ("columba", "dynamic", 7, 40, 0)])
-def test_the_32_bit_matrix_stands_in_up_to_seven_errors(world, spec, partition, k, length, switch):
+                                                            ("pigeon", "dynamic", 2, 250, 0), ("columba", "dynamic", 6, 40, 0)])
+def test_the_32_bit_matrix_stands_in_up_to_six_errors(world, spec, partition, k, length, switch):
     import ctypes as C
     import schemes_py as sp
     op = world["op"]
@@ -109,3 +112,51 @@ def test_the_32_bit_experiment_sees_the_predicate(world):
     finally:
         del os.environ["ORC_NARROW_BLOCKS"]
     assert a_cnt["NODE_COUNTER"] != b_cnt["NODE_COUNTER"]
+
+
+def _periodic_case(op):
+    import schemes_py as sp
+    t = (b"ACGTTGCA" * 26)[:200]
+    ix = ib.build_index(t, sparseness=4, seq_starts=np.array([0, 66, 200], np.uint32), device="cpu")
+    orc = op.OracleIndex(ix, kmer_size=4, switch_point=0)
+    g = np.frombuffer(t, np.uint8)
+    # (found by tools/soak_narrow32_periodic.py and a search over seeds: 510 nodes on the reference's matrix, 512 on the small one at its bound)
+    reads = [b"CGTTGCAACGTTGCAACGTTGCAACGTTGCAACGTGCAACGTTGCAACGTTGCAAACGTT",
+             b"GTTGCAACGTTGCAACGTTGCAACGTTGCAACGTTGCAACGTTGCAACGTTGCAACGTTGCAACGTTGCAACGTTGCAACGTTGCAACGTTCAACGTTGCAACGTTGCAACGTTGGCAACGTTGCAACGTTGCAACGTTGCAACGTTGCA"]
+    reads += synth.sample_reads(g, 200, 60, seed=5, edit_choices=(0, 1, 2, 6, 7, 8))
+    return orc, op.OracleStrategy(sp.BY_NAME["columba"], "edit", "dynamic"), reads
+
+
+def test_at_the_bound_the_small_matrix_differs(world, monkeypatch):
+    """7 errors on a tandem repeat: with the small matrix forced to its sizing bound (no spare column beside the band) the search computes a
+    different number of matrix rows than on the reference's matrices — the reason GeoN32 stops at 6 errors and two spare columns; with
+    the bounds the device uses the same batch runs on the reference's matrix and is identical."""
+    import ctypes as C
+    op = world["op"]
+    orc, st, reads = _periodic_case(op)
+    os.environ.pop("ORC_NARROW_BLOCKS", None)
+    a = op.match_batch(orc, st, 7, reads, threads=8)
+    monkeypatch.setenv("ORC_NARROW_BLOCKS", "32")
+    L = C.CDLL(op.build())
+    stats = (C.c_uint64 * 2)()
+    L.orc_narrow32_stats(stats, 1)
+    b = op.match_batch(orc, st, 7, reads, threads=8)
+    L.orc_narrow32_stats(stats, 1)
+    assert stats[0] == 0 and a[2] == b[2] and np.array_equal(a[0], b[0])          # the device's bounds: 7 errors stay on 64 bits
+    monkeypatch.setenv("ORC_NARROW32_MAX", "7")
+    monkeypatch.setenv("ORC_NARROW32_SLACK", "0")
+    c = op.match_batch(orc, st, 7, reads, threads=8)
+    L.orc_narrow32_stats(stats, 1)
+    assert stats[0] > 100
+    assert np.array_equal(a[0], c[0])                                              # (the occurrences survive; the traversal does not)
+    assert a[2]["MATRIX_ROWS"] != c[2]["MATRIX_ROWS"] or a[2]["NODE_COUNTER"] != c[2]["NODE_COUNTER"]
+    # 6 errors with two spare columns on the same text: identical, on the small matrix
+    monkeypatch.delenv("ORC_NARROW32_MAX")
+    monkeypatch.delenv("ORC_NARROW32_SLACK")
+    monkeypatch.delenv("ORC_NARROW_BLOCKS")
+    d = op.match_batch(orc, st, 6, reads, threads=8)
+    monkeypatch.setenv("ORC_NARROW_BLOCKS", "32")
+    L.orc_narrow32_stats(stats, 1)
+    e = op.match_batch(orc, st, 6, reads, threads=8)
+    L.orc_narrow32_stats(stats, 1)
+    assert stats[0] > 100 and d[2] == e[2] and np.array_equal(d[0], e[0]) and np.array_equal(d[1], e[1])
