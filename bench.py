@@ -46,6 +46,7 @@ def log(*a):
 
 
 # kernels behind each timed group of cmb_batch_timings (rocPRIM sorts / scans between them are not attributed)
+SERIAL_TABLE_STEPS = 3  # extra steps behind the timed region that the kernel table is the median of (tools/pmc_traffic.py divides by 1 + this)
 GROUP_KERNELS = {"k_prep": ["k_prep", "k_match_words"], "k_partition": ["k_parts", "k_exact"],
                  "k_dfs": ["k_bfs_start", "k_bfs_pass", "k_bfs_finish", "k_hbfs"],
                  "k_verify": ["k_verify"], "k_verify_edit": ["k_verify_stage"], "k_traceback": ["k_traceback"],
@@ -720,7 +721,7 @@ def main():
     os.environ["CMB_SERIAL_SUBBATCHES"] = "1"
     serial_runs = []
     try:
-        for _ in range(3):  # (three such steps, the median per kernel group: one sample moved by 3 ms between otherwise identical runs)
+        for _ in range(SERIAL_TABLE_STEPS):  # (three such steps, the median per kernel group: one sample moved by 3 ms between otherwise identical runs)
             batch.run()
             torch.cuda.synchronize()
             serial_runs.append(dict(batch.timings()))

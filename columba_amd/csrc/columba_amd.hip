@@ -1416,7 +1416,8 @@ static int batchRunOne(cmb_batch* b) {
             HIPCHK(hipMemcpyAsync(keep, b->counters.p, sizeof(keep), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             if (nItems) {
-                const uint32_t vCap = getenv("CMB_V_SLOTS") ? (uint32_t)std::min(256 * 2048, std::max(256, atoi(getenv("CMB_V_SLOTS")))) / 256u * 256u : 256u * 2048u;
+                // (lanes of k_verify: 128 k / 256 k / 512 k -> 34.8 / 32.0 / 35.9 ms of the locate group on the headline workload, round 4)
+                const uint32_t vCap = getenv("CMB_V_SLOTS") ? (uint32_t)std::min(256 * 2048, std::max(256, atoi(getenv("CMB_V_SLOTS")))) / 256u * 256u : 256u * 1024u;
                 const uint32_t vSlots = std::min<uint32_t>(((nItems + 255) / 256) * 256, vCap);
                 // Edit distance: identical verifications (same read x strand, text window and bounds — the parts of
                 // one read seeding the same alignment) are performed once: k_verify only locates and emits a key per
@@ -1493,7 +1494,8 @@ static int batchRunOne(cmb_batch* b) {
                         // nb 32-row blocks per stage: fewer stages re-fetch fewer text lines and move fewer survivor
                         // records, more blocks leave more lanes idle behind candidates that ended (CMB_STAGE_BLOCKS)
                         const char* nbEnv = getenv("CMB_STAGE_BLOCKS");
-                        const uint32_t nb = nbEnv ? std::min(8u, std::max(1u, (uint32_t)atoi(nbEnv))) : 2u;
+                        // (round 4, 150 bp reads at 4 errors: 1 / 2 / 3 / 4 / 6 blocks per stage -> 53.1 / 31.4 / 29.4 / 32.0 / 38.0 ms of k_verify_edit)
+                        const uint32_t nb = nbEnv ? std::min(8u, std::max(1u, (uint32_t)atoi(nbEnv))) : 3u;
                         const uint32_t nStages = (vRows(b->maxLen) + 32u * nb - 1u) / (32u * nb) + 1u;
                         for (int j = 0; j < 2; j++)
                             if (b->vsC[j].n < nRuns) {

@@ -3,8 +3,9 @@
     python tools/pmc_traffic.py <bench_line.json> <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> [steps run]  > *_pmc_traffic.json
 
 FETCH_SIZE / WRITE_SIZE are collected in separate passes (they do not fit one pass, MI355X_MICROARCH.md) of
-`bench.py --steps 1 --warmup 0`, which runs the hot path TWICE (one timed step + the serial step its kernel table
-comes from): the sums over all dispatches of a kernel are divided by the number of steps run.  Units: KiB.
+`bench.py --steps 1 --warmup 0`, which runs the hot path 1 + SERIAL_TABLE_STEPS times (one timed step + the serial steps its
+kernel table is the median of; the constant is read from bench.py): the sums over all dispatches of a kernel are divided by the
+number of steps run, and the division is checked against the dispatch count of k_parts (one launch per sub-batch and step).  Units: KiB.
 bench.py (load_traffic) applies the gfx950 correction (FETCH_SIZE x 2) when it reports `roofline.traffic`."""
 import collections, csv, glob, hashlib, json, os, sys
 
@@ -22,7 +23,10 @@ def source_digest():  # the same digest bench.py computes: a profile only speaks
 
 
 line = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-steps_run = float(sys.argv[4]) if len(sys.argv) > 4 and not os.path.isdir(sys.argv[4]) else 2.0
+import re
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_serial = int(re.search(r"^SERIAL_TABLE_STEPS = (\d+)", open(os.path.join(_root, "bench.py")).read(), re.M).group(1))
+steps_run = float(sys.argv[4]) if len(sys.argv) > 4 and not os.path.isdir(sys.argv[4]) else 1.0 + _serial
 sq_dir = next((a for a in sys.argv[4:] if os.path.isdir(a)), None)  # the SQ_* pass (wave-instructions per kernel)
 out = {"workload": {k: line["config"][k] for k in ("genome_bp", "reads_per_gpu", "read_len", "k")},
        "kernel_src_sha": source_digest(),
@@ -56,4 +60,10 @@ if sq_dir:
         for k, v in agg.items():
             for c, x in v.items():
                 out["kernels"][k][c] = round(x / steps_run, 1)
+out["steps_run"] = steps_run
+R = line["config"]["reads_per_gpu"]  # (columba_amd.hip: 3 sub-batches from 8 M reads, 2 from 2 M, CMB_SUBBATCHES overrides)
+sub = int(os.environ.get("CMB_SUBBATCHES", 3 if R >= 8000000 else 2 if R >= 2000000 else 1))
+if "k_parts" in out["kernels"] and abs(out["kernels"]["k_parts"]["dispatches_per_step"] - sub) > 1e-6:
+    sys.exit(f"k_parts was launched {out['kernels']['k_parts']['dispatches_per_step']} times per assumed step, the batch has {sub} sub-batches: "
+             f"wrong number of steps ({steps_run})")
 print(json.dumps(out, indent=1))
