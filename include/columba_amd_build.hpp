@@ -1,5 +1,6 @@
 // Index construction as product code: FASTA files in, the reference's Vanilla index files out — the
-// files `columba` itself and include/columba_amd.hpp (FMIndex) load.  Host C++ only; one-off preprocessing, not on the hot path.
+// files `columba` itself and include/columba_amd.hpp (FMIndex) load — and, further down, the run-length compressed flavour's move
+// tables, samples, predecessors and PLCP (buildMoveIndex).  Host C++ only; one-off preprocessing, not on the hot path.
 //
 // Mirrors (reference, src/):
 //   preprocessFastaFiles / concatenateAndTransform      buildindex.cpp:150-262, :614-683   (concatenation, upper case, non-ACGT
@@ -377,6 +378,184 @@ inline void buildIndex(const std::vector<std::string>& fastaFiles, const std::st
     }
     std::ofstream m = openOut(base + ".meta");
     m << 21 << "\n" << 4 << "\n" << "VANILLA" << "\n";
+}
+
+// ---------------------------------------------------------------- the run-length compressed flavour (b-move)
+// Mirrors (reference, src/, RUN_LENGTH_COMPRESSION build with its 64-bit length_t):
+//   processFastaFiles                                   buildindex.cpp:2008-2029   (seed length 100 by default, definitions.h:41; the text is
+//                                                       not written: noWriting)
+//   createIndex (RLC)                                   :1606-1687                  (PLCP, samples at run boundaries, predecessors, move tables
+//                                                       of the text and of the reversed text)
+//   buildSamples / processSamplesAndPreds               :950-1013, :1044-1066, :1540-1603
+//   createAndWriteMove + MoveLFReprBP::write            :826-915, bmove/moverepr.cpp:145-181, :75-77 (.LFBP: n, r, position of '$', then r + 1 rows of
+//                                                       ceil((3 + 2 ceil(log2 n) + ceil(log2 r)) / 8) bytes: character, run start, LF of the run
+//                                                       start and the run that holds it, every value cut to its field)
+//   PLCP (Kasai et al. through phi)                     bmove/plcp.h:56-80
+// The reference keeps samples, predecessors and PLCP in sdsl containers whose serialisation belongs to sdsl (absent here): their CONTENTS are
+// written as plain little-endian 64-bit arrays, the files include/columba_amd_bmove.hpp (BMove) reads — <base>.smpf.u64 .smpl.u64
+// .rev.smpf.u64 .rev.smpl.u64 .prdf.u64 .ftr.u64 .prdl.u64 .ltr.u64 .plcp.pos.u64 .plcp.sum.u64 — beside the two .LFBP files, which are
+// the reference's own format.  tests/test_cpp_builder.py compares every file with the harness builder's (columba_amd/movebuild.py).
+inline unsigned bitsFor(uint64_t v) { // ceil(log2(v)), moverepr.h:44-46
+    unsigned b = 0;
+    while (b < 64 && (1ull << b) < v) b++;
+    return b;
+}
+
+inline std::vector<uint8_t> packLFBP(const std::string& bwt) {
+    const uint64_t n = bwt.size();
+    if ((n & (n - 1)) == 0) // moverepr.cpp:75-77: the terminating row's start position n does not fit ceil(log2 n) bits
+        throw std::runtime_error("a text size that is a power of two cannot be packed into a move table");
+    uint64_t cnt[5] = {0, 0, 0, 0, 0}, cum[5], zeroPos = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint32_t c = codeOf(bwt[i]);
+        if (c == 0) zeroPos = i;
+        cnt[c]++;
+    }
+    cum[0] = 0;
+    for (int c = 1; c < 5; c++) cum[c] = cum[c - 1] + cnt[c - 1];
+    std::vector<uint64_t> starts, lf;
+    std::vector<uint8_t> head;
+    uint64_t seen[5] = {0, 0, 0, 0, 0};
+    for (uint64_t i = 0; i < n; i++) {
+        const uint32_t c = codeOf(bwt[i]);
+        if (i == 0 || bwt[i] != bwt[i - 1]) {
+            starts.push_back(i);
+            head.push_back((uint8_t)c);
+            lf.push_back(cum[c] + seen[c]); // LF of the run's first position
+        }
+        seen[c]++;
+    }
+    const uint64_t r = starts.size();
+    const unsigned bitsN = bitsFor(n), bitsR = bitsFor(r), bitsC = 3;
+    const unsigned totalBytes = (bitsC + 2 * bitsN + bitsR + 7) / 8;
+    const uint64_t maskN = bitsN >= 64 ? ~0ull : (1ull << bitsN) - 1, maskR = bitsR >= 64 ? ~0ull : (1ull << bitsR) - 1;
+    std::vector<uint8_t> out(24 + (size_t)(r + 1) * totalBytes, 0);
+    const uint64_t hdr[3] = {n, r, zeroPos};
+    std::memcpy(out.data(), hdr, 24);
+    auto place = [](unsigned __int128& row, uint64_t v, unsigned off) { row |= (unsigned __int128)v << off; };
+    for (uint64_t i = 0; i <= r; i++) {
+        uint64_t c, a, b, d;
+        if (i < r) {
+            c = head[i], a = starts[i], b = lf[i];
+            d = (uint64_t)(std::upper_bound(starts.begin(), starts.end(), b) - starts.begin()) - 1; // the run that holds the LF position
+        } else
+            c = 0, a = n, b = n, d = r; // the terminating row
+        unsigned __int128 row = 0;
+        place(row, c, 0);
+        place(row, a & maskN, bitsC);
+        place(row, b & maskN, bitsC + bitsN);
+        place(row, d & maskR, bitsC + 2 * bitsN);
+        std::memcpy(out.data() + 24 + (size_t)i * totalBytes, &row, totalBytes);
+    }
+    return out;
+}
+
+// suffix-array values at the first and the last position of every BWT run (buildSamples)
+inline void runSamples(const std::vector<uint32_t>& SA, const std::string& bwt, std::vector<uint64_t>& first, std::vector<uint64_t>& last) {
+    first.clear(), last.clear();
+    for (size_t i = 0; i < bwt.size(); i++) {
+        if (i == 0 || bwt[i] != bwt[i - 1]) first.push_back(SA[i]);
+        if (i + 1 == bwt.size() || bwt[i] != bwt[i + 1]) last.push_back(SA[i]);
+    }
+}
+
+// predecessor structure of phi / phi^-1: the text positions (sample - 1, cyclically) in increasing order and the run each belongs to
+inline void predecessors(const std::vector<uint64_t>& samples, uint64_t n, std::vector<uint64_t>& marked, std::vector<uint64_t>& toRun) {
+    std::vector<std::pair<uint64_t, uint64_t>> kv(samples.size());
+    for (size_t i = 0; i < samples.size(); i++) kv[i] = {samples[i] > 0 ? samples[i] - 1 : n - 1, (uint64_t)i};
+    std::sort(kv.begin(), kv.end());
+    marked.resize(kv.size()), toRun.resize(kv.size());
+    for (size_t i = 0; i < kv.size(); i++) marked[i] = kv[i].first, toRun[i] = kv[i].second;
+}
+
+// PLCP[p] = longest common prefix of the suffix at p and its predecessor in suffix-array order, in the run-length form cmb_move_desc takes:
+// the positions q with PLCP[q] != PLCP[q - 1] - 1 (0 among them) and PLCP[q] + q there
+inline void plcpRuns(const std::string& T, const std::vector<uint32_t>& SA, std::vector<uint64_t>& pos, std::vector<uint64_t>& sum) {
+    const size_t n = T.size();
+    std::vector<uint32_t> phi(n);
+    const uint32_t none = 0xFFFFFFFFu;
+    phi[SA[0]] = none;
+    for (size_t i = 1; i < n; i++) phi[SA[i]] = SA[i - 1];
+    pos.clear(), sum.clear();
+    size_t l = 0;
+    uint64_t prev = 0;
+    for (size_t p = 0; p < n; p++) {
+        if (phi[p] == none)
+            l = 0;
+        else {
+            const size_t q = phi[p];
+            while (p + l < n && q + l < n && T[p + l] == T[q + l]) l++;
+        }
+        if (p == 0 || (uint64_t)l + 1 != prev) pos.push_back(p), sum.push_back((uint64_t)l + p);
+        prev = l;
+        if (l > 0) l--;
+    }
+}
+
+inline void put64(const std::string& name, const std::vector<uint64_t>& v) {
+    std::ofstream f = openOut(name);
+    putAll(f, v);
+}
+
+// FASTA files -> <base>.{meta, cct, pos, sna, fsid, headerSN.bin, LFBP, rev.LFBP, *.u64} (64-bit length_t as the reference's RLC build);
+// keepText: also <base>.txt.bin — the reference's RLC flavour does not keep the text, this framework computes alignments of b-move
+// occurrences on it (BMove::attachText)
+inline void buildMoveIndex(const std::vector<std::string>& fastaFiles, const std::string& base, uint32_t seedLength = 100, bool keepText = false) {
+    const Text tx = preprocessFastaFiles(fastaFiles, seedLength);
+    const std::string& T = tx.T;
+    const size_t n = T.size();
+    {
+        if (keepText) {
+            std::ofstream f = openOut(base + ".txt.bin");
+            put<uint64_t>(f, (uint64_t)n);
+            f.write(T.data(), (std::streamsize)n);
+        }
+        std::ofstream h = openOut(base + ".headerSN.bin");
+        for (size_t i = 0; i < tx.seqNames.size(); i++)
+            h << "@SQ\tSN:" << tx.seqNames[i] << "\tLN:" << tx.positions[i + 1] - tx.positions[i] << "\n";
+        put64(base + ".pos", std::vector<uint64_t>(tx.positions.begin(), tx.positions.end()));
+        std::ofstream s = openOut(base + ".sna");
+        for (const std::string& name : tx.seqNames) {
+            put<uint64_t>(s, (uint64_t)name.size());
+            s.write(name.data(), (std::streamsize)name.size());
+        }
+        put64(base + ".fsid", std::vector<uint64_t>(tx.firstSeqIDPerFile.begin(), tx.firstSeqIDPerFile.end()));
+        std::vector<uint64_t> cct(256, 0);
+        for (char c : T) cct[(unsigned char)c]++;
+        put64(base + ".cct", cct);
+    }
+    auto writeBytes = [](const std::string& name, const std::vector<uint8_t>& b) {
+        std::ofstream f = openOut(name);
+        putAll(f, b);
+    };
+    {
+        const std::vector<uint32_t> SA = suffixArray(T);
+        std::string bwt(n, '$');
+        for (size_t i = 0; i < n; i++) bwt[i] = SA[i] > 0 ? T[SA[i] - 1] : T.back();
+        std::vector<uint64_t> a, b, c, d;
+        plcpRuns(T, SA, a, b);
+        put64(base + ".plcp.pos.u64", a), put64(base + ".plcp.sum.u64", b);
+        runSamples(SA, bwt, a, b);
+        put64(base + ".smpf.u64", a), put64(base + ".smpl.u64", b);
+        predecessors(a, n, c, d);
+        put64(base + ".prdf.u64", c), put64(base + ".ftr.u64", d);
+        predecessors(b, n, c, d);
+        put64(base + ".prdl.u64", c), put64(base + ".ltr.u64", d);
+        writeBytes(base + ".LFBP", packLFBP(bwt));
+    }
+    {
+        std::string revT(T.rbegin(), T.rend());
+        const std::vector<uint32_t> revSA = suffixArray(revT);
+        revT.clear();
+        std::string rbwt(n, '$');
+        for (size_t i = 0; i < n; i++) rbwt[i] = revSA[i] > 0 ? T[n - revSA[i]] : T.front();
+        std::vector<uint64_t> a, b;
+        runSamples(revSA, rbwt, a, b);
+        put64(base + ".rev.smpf.u64", a), put64(base + ".rev.smpl.u64", b);
+        writeBytes(base + ".rev.LFBP", packLFBP(rbwt));
+    }
+    std::ofstream m = openOut(base + ".meta");
+    m << 21 << "\n" << 8 << "\n" << "RLC" << "\n";
 }
 
 } // namespace build

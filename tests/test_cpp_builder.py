@@ -100,3 +100,55 @@ def test_suffix_array_against_plain_sorting(builder):
         t = text + b"$"
         want = sorted(range(len(t)), key=lambda i: t[i:])
         assert np.fromfile(base + ".sa.1", dtype=np.uint32).tolist() == want
+
+
+MOVE_FILES = ["LFBP", "rev.LFBP"] + [e + ".u64" for e in ("smpf", "smpl", "rev.smpf", "rev.smpl", "prdf", "ftr", "prdl", "ltr", "plcp.pos", "plcp.sum")]
+
+
+@pytest.mark.parametrize("base_len,copies,snp,n_seqs", [(3_000, 8, 0.01, 8), (701, 3, 0.0, 1), (20_000, 4, 0.002, 2), (97, 1, 0.0, 1)])
+def test_move_index_files_equal_the_harness_builder(builder, base_len, copies, snp, n_seqs):
+    """--rlc: move tables in the reference's .LFBP format, samples, predecessors and the run-length PLCP — byte for byte what
+    columba_amd/movebuild.py writes for the same text (whose tables the oracle's move_driver and the golden vectors of the b-move tests read)"""
+    from columba_amd import movebuild
+    exe, tmp = builder
+    text = movebuild.pangenome(base_len, copies, snp, seed=base_len)
+    n = int(text.shape[0])
+    cuts = np.linspace(0, n, n_seqs + 1).astype(np.int64).tolist()
+    records = [(f"hap{j}", text[cuts[j]:cuts[j + 1]].tobytes()) for j in range(n_seqs)]
+    fa = os.path.join(tmp, f"pg{base_len}.fa")
+    _write_fasta(fa, records, lower_every=3)
+    base_c = os.path.join(tmp, f"mc{base_len}")
+    subprocess.check_call([exe, "--rlc", "--keep-text", "-r", base_c, "-f", fa])
+    mv = movebuild.build_move(text, device="cpu")
+    base_p = os.path.join(tmp, f"mp{base_len}")
+    movebuild.save_move(mv, base_p)
+    for ext in MOVE_FILES:
+        a, b = open(f"{base_c}.{ext}", "rb").read(), open(f"{base_p}.{ext}", "rb").read()
+        assert a == b, (ext, len(a), len(b))
+    # the files every flavour has, in the 64-bit length_t of the reference's RLC build
+    assert np.fromfile(base_c + ".pos", dtype=np.uint64).tolist() == cuts
+    raw = open(base_c + ".txt.bin", "rb").read()
+    assert int(np.frombuffer(raw[:8], dtype=np.uint64)[0]) == n + 1 and raw[8:] == text.tobytes() + b"$"
+    cct = np.fromfile(base_c + ".cct", dtype=np.uint64)
+    assert cct.shape[0] == 256 and int(cct.sum()) == n + 1 and cct[ord("$")] == 1
+    assert open(base_c + ".meta").read().split() == ["21", "8", "RLC"]
+    assert not os.path.exists(base_c + ".bwt")
+
+
+def test_move_builder_defaults_and_refusals(builder):
+    """seed length 100 by default in this flavour (definitions.h:41): a run of N becomes the same 100-character pattern, restarted after
+    every ACGT character; no text file unless asked; a text of 2^k characters is refused as the reference's table does (moverepr.cpp:75-77)"""
+    exe, tmp = builder
+    fa = os.path.join(tmp, "n.fa")
+    _write_fasta(fa, [("a", b"ACGT" + b"N" * 230 + b"ACGTT" + b"N" * 30 + b"GG")])
+    base = os.path.join(tmp, "mdef")
+    subprocess.check_call([exe, "--rlc", "-r", base, "-f", fa])
+    assert not os.path.exists(base + ".txt.bin")
+    subprocess.check_call([exe, "--rlc", "--keep-text", "-r", base, "-f", fa])
+    t = open(base + ".txt.bin", "rb").read()[8:]
+    fill = t[4:234]
+    assert set(fill) <= set(b"ACGT") and fill[:100] == fill[100:200] and fill[:30] == fill[200:230] == t[239:269]
+    fa2 = os.path.join(tmp, "p2.fa")
+    _write_fasta(fa2, [("a", (b"ACGTTGCA" * 8)[:63])])   # 63 characters + '$'
+    r = subprocess.run([exe, "--rlc", "-r", os.path.join(tmp, "p2"), "-f", fa2], capture_output=True, text=True)
+    assert r.returncode != 0 and "power of two" in r.stderr
