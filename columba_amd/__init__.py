@@ -46,6 +46,8 @@ EXPORTS = [
     "cmb_rank_batch", "cmb_extend_batch", "cmb_extend_bench", "cmb_locate_batch", "cmb_verify_batch", "cmb_verify_batch_staged", "cmb_verify_window", "cmb_cigar_windows",
     "cmb_batch_want_alignments", "cmb_batch_alignments", "cmb_sam_se", "cmb_sam_se_xa", "cmb_sam_unmapped_se",
     "cmb_sam_pe", "cmb_sam_unpaired", "cmb_sam_unmapped_pe", "cmb_pair_sam", "cmb_pair_infer",
+    "cmb_pair_best_create", "cmb_pair_best_set_trim", "cmb_pair_best_cutoff", "cmb_pair_best_advance", "cmb_pair_best_supply", "cmb_pair_best_sam",
+    "cmb_pair_best_destroy",
     "cmb_read_prepare", "cmb_batch_sam", "cmb_batch_filter_per_strand", "cmb_match_best", "cmb_best_sizes", "cmb_best_results",
     "cmb_best_destroy",
     "cmb_move_create", "cmb_move_destroy", "cmb_move_device_bytes", "cmb_move_info", "cmb_move_complete_range", "cmb_move_rows",
@@ -67,13 +69,14 @@ class CmbError(RuntimeError):
 
 def build_library(force: bool = False) -> str:
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU): one object per translation unit
-    (the matcher; the b-move backend; the paired-end records), linked into one shared library."""
+    (the matcher; the b-move backend; the paired-end records; the pairing in BEST mode), linked into one shared library."""
     csrc = os.path.join(_HERE, "csrc")
     header = os.path.join(os.path.dirname(_HERE), "include", "columba_amd.h")
     units = {"columba_amd.hip": [f for f in os.listdir(csrc) if not f.startswith(("move_", "pair_"))],
              # (the b-move backend shares the event handler, the matrix and the wave helpers with the matcher)
              "move_backend.hip": [f for f in os.listdir(csrc) if not f.startswith("pair_") and f != "columba_amd.hip"],
-             "pair_sam.hip": [f for f in os.listdir(csrc) if f.startswith("pair_")] + ["host_sam.hpp"]}
+             "pair_sam.hip": ["pair_sam.hip", "host_sam.hpp"],
+             "pair_best.hip": ["pair_best.hip", "host_sam.hpp"]}
     every = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [header]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in every):
         return LIB_PATH  # (the objects are build scratch: only the library travels to the GPU box)
@@ -253,6 +256,15 @@ def lib():
         L.cmb_sam_unmapped_pe.restype = C.c_int64
         L.cmb_sam_unmapped_pe.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, i32, i32, i32, vp, u64]
         L.cmb_pair_infer.argtypes = [vp, u64, C.POINTER(PairInferred)]
+        L.cmb_pair_best_create.argtypes = [C.POINTER(PairParams), u32, u32, u32, i32, vp, u32, C.POINTER(PairRead), C.POINTER(PairRead), C.POINTER(vp)]
+        L.cmb_pair_best_set_trim.argtypes = [vp, vp, vp]
+        L.cmb_pair_best_cutoff.argtypes = [vp, u32, u32, C.POINTER(u32)]
+        L.cmb_pair_best_advance.argtypes = [vp, vp, u64, C.POINTER(u64)]
+        L.cmb_pair_best_supply.argtypes = [vp, u32, u32, u32, u32, vp, vp, u64, vp]
+        L.cmb_pair_best_sam.restype = C.c_int64
+        L.cmb_pair_best_sam.argtypes = [vp, u32, vp, vp, u64, C.POINTER(u32)]
+        L.cmb_pair_best_destroy.argtypes = [vp]
+        L.cmb_pair_best_destroy.restype = None
         L.cmb_pair_sam.restype = C.c_int64
         L.cmb_pair_sam.argtypes = [C.POINTER(PairParams), C.POINTER(PairRead), C.POINTER(PairRead), vp, vp, u64, C.POINTER(u32)]
         L.cmb_sam_unmapped_se.restype = C.c_int64
@@ -616,6 +628,88 @@ def pair_sam(read1, read2, seq_names, orientation: int = ORIENTATION_FR, max_fra
     buf = C.create_string_buffer(int(n) + 1)
     lib().cmb_pair_sam(C.byref(prm), C.byref(r1), C.byref(r2), names, buf, int(n) + 1, C.byref(n_pairs))
     return buf.value.decode(), int(n_pairs.value)
+
+
+PAIR_REQUEST_DTYPE = np.dtype([("pair", np.uint32), ("mate", np.uint32), ("strand", np.uint32), ("max_distance", np.uint32)])  # cmb_pair_request
+PAIR_TRIM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                           C.POINTER(C.c_uint32))
+
+
+class PairBest:
+    """A chunk of read pairs walking through their strata in BEST (+x) mode (cmb_pair_best_*: SearchStrategy::matchApproxPairedEndBestPlusX,
+    searchstrategy.cpp:1091-1179).  reads1 / reads2: per pair (id, seq, revcomp, qual, revqual) as read_prepare leaves them.
+    advance() -> requests (PAIR_REQUEST_DTYPE) for the lists the unfinished pairs wait for; supply(...) hands one in; sam(i, names)."""
+
+    def __init__(self, reads1, reads2, x: int, min_identity: int, max_supported: int, orientation: int = ORIENTATION_FR, max_frag: int = 500,
+                 min_frag: int = 0, discordant_allowed: bool = True, unmapped_records: bool = True, metric: str = "edit", text_index=None,
+                 trim=None):
+        n = len(reads1)
+        assert len(reads2) == n
+        self._keep = []
+
+        def mk(rds):
+            arr = (PairRead * max(n, 1))()
+            for i, (rid, seq, rc, qual, rq) in enumerate(rds):
+                arr[i] = PairRead(rid.encode(), seq.encode(), rc.encode(), qual.encode(), rq.encode(), None, 0)
+            return arr
+
+        a1, a2 = mk(reads1), mk(reads2)
+        prm = PairParams(orientation, max_frag, min_frag, int(discordant_allowed), int(unmapped_records))
+        self.h = C.c_void_p()
+        self.n = n
+        _chk(lib().cmb_pair_best_create(C.byref(prm), x, min_identity, max_supported, METRIC[metric], text_index.h if text_index is not None else None,
+                                        n, a1, a2, C.byref(self.h)))
+        if trim is not None:  # trim(pair, mate, strand, largest_stratum, (begin, end, distance)) -> None or (begin, end, distance, seq_id, seq_begin, ops)
+            def hook(_user, pair, mate, strand, stratum, occ_p, aln_p, ops_p, ops_cap, n_ops_p):
+                oc = np.ctypeslib.as_array(C.cast(occ_p, C.POINTER(C.c_uint32)), shape=(4,))
+                res = trim(int(pair), int(mate), int(strand), int(stratum), (int(oc[0]), int(oc[1]), int(oc[2])))
+                if res is None:
+                    return 0
+                b, e, d, sid, sb, ops = res
+                oc[0], oc[1], oc[2] = b, e, d
+                al = np.ctypeslib.as_array(C.cast(aln_p, C.POINTER(C.c_uint32)), shape=(2,))
+                al[0], al[1] = sid, sb
+                out = np.ctypeslib.as_array(C.cast(ops_p, C.POINTER(C.c_uint16)), shape=(int(ops_cap),))
+                out[:len(ops)] = ops
+                n_ops_p[0] = len(ops)
+                return 1
+            self._hook = PAIR_TRIM_FN(hook)
+            _chk(lib().cmb_pair_best_set_trim(self.h, C.cast(self._hook, C.c_void_p), None))
+
+    def cutoff(self, pair: int, mate: int) -> int:
+        v = C.c_uint32()
+        _chk(lib().cmb_pair_best_cutoff(self.h, pair, mate, C.byref(v)))
+        return int(v.value)
+
+    def advance(self) -> np.ndarray:
+        req = np.zeros(max(self.n, 1), dtype=PAIR_REQUEST_DTYPE)
+        n = C.c_uint64()
+        _chk(lib().cmb_pair_best_advance(self.h, _p(req), req.shape[0], C.byref(n)))
+        return req[:int(n.value)]
+
+    def supply(self, pair: int, mate: int, strand: int, max_distance: int, occ: np.ndarray, aln: np.ndarray, ops: np.ndarray):
+        occ = np.ascontiguousarray(occ, dtype=OCC_DTYPE)
+        aln = np.ascontiguousarray(aln, dtype=ALN_DTYPE)
+        ops = np.ascontiguousarray(ops, dtype=np.uint16)
+        _chk(lib().cmb_pair_best_supply(self.h, pair, mate, strand, max_distance, _p(occ) if occ.shape[0] else None, _p(aln) if aln.shape[0] else None,
+                                        occ.shape[0], _p(ops) if ops.shape[0] else None))
+
+    def sam(self, pair: int, seq_names):
+        names = (C.c_char_p * len(seq_names))(*[n.encode() for n in seq_names])
+        n_pairs = C.c_uint32()
+        n = lib().cmb_pair_best_sam(self.h, pair, names, None, 0, C.byref(n_pairs))
+        if n < 0:
+            _chk(int(n))
+        buf = C.create_string_buffer(int(n) + 1)
+        lib().cmb_pair_best_sam(self.h, pair, names, buf, int(n) + 1, C.byref(n_pairs))
+        return buf.value.decode(), int(n_pairs.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cmb_pair_best_destroy(self.h)
+            self.h = None
+
+    __del__ = close
 
 
 def read_prepare(read_id: str, seq: str, qual: str = ""):

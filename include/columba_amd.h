@@ -343,6 +343,43 @@ typedef struct {
 /* returns the length of the text (written if cap is larger); n_pairs_out (may be NULL): TOTAL_UNIQUE_PAIRS of the pair */
 int64_t cmb_pair_sam(const cmb_pair_params* params, const cmb_pair_read* read1, const cmb_pair_read* read2, const char* const* seq_names,
                      char* out, uint64_t cap, uint32_t* n_pairs_out);
+/* --- paired-end reads in BEST (+x strata) mode: SearchStrategy::matchApproxPairedEndBestPlusX (src/searchstrategy.cpp:1091-1179) with
+ * processCombFR / RF / FF (:936-1062), processComb (:834-912), pairOccurrencesForBestMapping (:1743-1815) and, without a concordant
+ * pair, pairDiscordantlyBest (:1664-1741); records by generateSAMPairedEnd (:1904-1970), lines in OutputWriter::writeChunks' order.
+ * The reference walks one pair through its strata and calls mapRead (searchstrategy.h:490-519: the ALL-mode search of ONE strand of one
+ * mate at one distance) for every stratum it has not looked at yet; which ones those are depends on what the earlier ones held.  Here a
+ * chunk of pairs is walked together: cmb_pair_best_advance runs every unfinished pair as far as the lists it holds allow and reports
+ * the list each of them waits for; the caller produces the lists — one device batch per distance over the reads asked for, each strand
+ * filtered by itself (cmb_batch_filter_per_strand) with alignments (cmb_batch_want_alignments) — hands them in with
+ * cmb_pair_best_supply and advances again, until no pair waits (n = 0).  Host code; the device is touched only to trim an occurrence that
+ * runs over the end of its sequence (cmb_trim_occurrence on text_index, or the caller's hook). */
+typedef struct cmb_pair_best cmb_pair_best;
+typedef struct {
+    uint32_t pair, mate;   /* mate 0: read 1, 1: read 2 */
+    uint32_t strand;       /* 0 forward, 1 reverse complement */
+    uint32_t max_distance; /* mapRead's maxED */
+} cmb_pair_request;
+/* findSeqName for an occurrence that runs over the end of its sequence: 1 = found with trimming (occ / aln / operations updated),
+ * 0 = not found, < 0 = failure.  Same contract as cmb_trim_occurrence, which is used when no hook is set. */
+typedef int (*cmb_pair_trim_fn)(void* user, uint32_t pair, uint32_t mate, uint32_t strand, uint32_t largest_stratum, cmb_occ* occ, cmb_aln* aln,
+                                uint16_t* cigar_ops, uint32_t ops_cap, uint32_t* n_ops);
+/* reads1[i] / reads2[i]: the mates of pair i as cmb_read_prepare leaves them (occ / n_occ unused).  max_supported: the largest distance
+ * the strategy has schemes for and the device runs (getMaxSupportedDistanceForBestMapping); a read's cut-off is
+ * min(max_supported, len * (100 - min_identity) / 100) (getMaxED). */
+int cmb_pair_best_create(const cmb_pair_params* params, uint32_t x, uint32_t min_identity, uint32_t max_supported, int metric,
+                         cmb_index* text_index, uint32_t n_pairs, const cmb_pair_read* reads1, const cmb_pair_read* reads2,
+                         cmb_pair_best** out);
+int cmb_pair_best_set_trim(cmb_pair_best* b, cmb_pair_trim_fn fn, void* user);
+int cmb_pair_best_cutoff(const cmb_pair_best* b, uint32_t pair, uint32_t mate, uint32_t* cut_off);
+/* at most one request per unfinished pair; CMB_ERR_OVERFLOW (with *n = the number wanted) if cap is too small — nothing is lost, call again */
+int cmb_pair_best_advance(cmb_pair_best* b, cmb_pair_request* requests, uint64_t cap, uint64_t* n);
+/* the ALL-mode result of that mate at that distance (occurrences of the other strand in the list are skipped, so one device result
+ * serves both strands with two calls); aln[j].cigar_off indexes cigar_ops */
+int cmb_pair_best_supply(cmb_pair_best* b, uint32_t pair, uint32_t mate, uint32_t strand, uint32_t max_distance, const cmb_occ* occ,
+                         const cmb_aln* aln, uint64_t n_occ, const uint16_t* cigar_ops);
+/* the records of a finished pair; n_pairs_out (may be NULL): TOTAL_UNIQUE_PAIRS of the pair */
+int64_t cmb_pair_best_sam(const cmb_pair_best* b, uint32_t pair, const char* const* seq_names, char* out, uint64_t cap, uint32_t* n_pairs_out);
+void cmb_pair_best_destroy(cmb_pair_best* b);
 /* Inference of orientation and insert-size bounds from pairs whose two mates map unambiguously (src/parallel.cpp:329-360
  * addFragmentAndOrientation, :402-466 inferPairedEndParameters; the caller selects the pairs as :236-262 / :700-727 do: exactly
  * one occurrence per mate).  Coordinates of the two occurrences as reported; n == 0: nothing inferred (inferred = 0). */
