@@ -1171,3 +1171,62 @@ def pair_chunk_sam(index: "Index", strategy: "SearchStrategy", max_distance: int
         text.append(t)
         mapped_pairs += n > 0
     return "".join(text), mapped_pairs
+
+
+def pair_chunk_sam_best(index: "Index", strategy: "SearchStrategy", reads1, reads2, ids1, ids2, quals1, quals2, seq_names, x: int = 0,
+                        min_identity: int = 95, orientation: int = ORIENTATION_FR, max_frag: int = 500, min_frag: int = 0,
+                        discordant_allowed: bool = True, unmapped_records: bool = True, max_supported: Optional[int] = None):
+    """A chunk of read pairs in BEST (+x strata) mode, end to end (SearchStrategy::matchApproxPairedEndBestPlusX,
+    searchstrategy.cpp:1091-1179): the pairs walk through their strata together (PairBest); every round, the lists the unfinished pairs
+    wait for — mapRead of one mate at one distance — are produced by ONE device batch per (mate, distance) over the reads that ask
+    (ALL mode, every strand filtered by itself, with alignments), and both strands of a result are handed in.  Returns (SAM text,
+    number of properly or discordantly mapped pairs, number of device batches)."""
+    n = len(reads1)
+    if max_supported is None:  # getMaxSupportedDistanceForBestMapping: the largest k such that 1 .. k all have a scheme (13 at most)
+        max_supported = 0
+        while max_supported < 13:
+            try:
+                if strategy.describe(max_supported + 1)[0] == 0:
+                    break
+            except CmbError:
+                break
+            max_supported += 1
+    mates = []
+    for reads, ids, quals in ((reads1, ids1, quals1), (reads2, ids2, quals2)):
+        prep = []
+        for i in range(n):
+            sid, seq, rc, rq = read_prepare(ids[i], reads[i].decode() if isinstance(reads[i], bytes) else reads[i], quals[i])
+            prep.append((sid, seq, rc, quals[i], rq))
+        mates.append(prep)
+    pb = PairBest(mates[0], mates[1], x, min_identity, max_supported, orientation, max_frag, min_frag, discordant_allowed, unmapped_records,
+                  text_index=index)
+    raw = [[r if isinstance(r, bytes) else r.encode() for r in reads] for reads in (reads1, reads2)]
+    batches = 0
+    while True:
+        req = pb.advance()
+        if req.shape[0] == 0:
+            break
+        groups = {}
+        for r in req:
+            groups.setdefault((int(r["mate"]), int(r["max_distance"])), []).append(int(r["pair"]))
+        for (mate, k), idxs in sorted(groups.items()):
+            b = Batch(index, strategy, k, reads=[raw[mate][i] for i in idxs])
+            b.want_alignments()
+            _chk(lib().cmb_batch_filter_per_strand(b.h, 1))
+            b.run()
+            batches += 1
+            occ, offs, _ = b.results()
+            aln, ops = b.alignments()
+            for j, i in enumerate(idxs):
+                lo, hi = int(offs[j]), int(offs[j + 1])
+                for strand in (0, 1):
+                    pb.supply(i, mate, strand, k, occ[lo:hi], aln[lo:hi], ops)
+            b.close() if hasattr(b, "close") else None
+    text, mapped = [], 0
+    for i in range(n):
+        t, n_pairs = pb.sam(i, seq_names)
+        text.append(t)
+        mapped += n_pairs > 0
+    pb.close()
+    return "".join(text), mapped, batches
+

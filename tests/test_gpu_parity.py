@@ -712,6 +712,94 @@ def test_paired_end_chunk_end_to_end(world):
     assert mapped2 == mapped and prop(text2) == prop(text)
 
 
+def test_paired_end_best_mode_chunk_end_to_end(world):
+    """read pairs in BEST mode (matchApproxPairedEndBestPlusX): the chunk walks through its strata together, one device batch per mate and
+    distance asked for (ca.pair_chunk_sam_best over cmb_pair_best_*).  Fragments with few errors come back as proper pairs where they were cut;
+    the proper pairs are the ALL-mode pairs (distance = the cut-off) of the smallest total distance; a mate that maps nowhere leaves its
+    partner with the unmapped-mate records; a pair too far apart is reported discordant.  The walk itself is tested on the CPU
+    (tests/test_pairing_best.py)."""
+    g = world["genome"]
+    rng = np.random.default_rng(78)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    n, L = 240, 100
+    reads1, reads2, truth = [], [], []
+    for i in range(n):
+        frag = int(rng.integers(220, 420))
+        p0 = int(rng.integers(1000, len(g) - 3000))
+        p1 = p0 + frag - L if i % 20 != 7 else p0 + 1500  # (every twentieth pair: too far apart for a proper pair)
+        m1, m2 = bytearray(g[p0:p0 + L].tobytes()), bytearray(g[p1:p1 + L].tobytes().translate(comp)[::-1])
+        for m, lim in ((m1, 3), (m2, 6 if i % 5 == 0 else 3)):
+            for _ in range(int(rng.integers(0, lim))):
+                q = int(rng.integers(1, L - 1))
+                m[q] = b"ACGT"[(b"ACGT".index(bytes([m[q]])) + 1) % 4] if bytes([m[q]]) in b"ACGT" else m[q]
+        if i % 20 == 13:
+            m2 = bytearray(rng.choice(np.frombuffer(b"ACGT", np.uint8), L).tobytes())  # a mate from nowhere
+        if i % 2:
+            m1, m2 = m2, m1
+        reads1.append(bytes(m1))
+        reads2.append(bytes(m2))
+        truth.append((p0, p1 + L - p0))
+    ids1 = [f"@frag{i}/1" for i in range(n)]
+    ids2 = [f"@frag{i}/2" for i in range(n)]
+    quals = ["I" * L] * n
+    strat = ca.SearchStrategy("columba", "edit", "dynamic")
+    starts = world["dev"].seq_starts()
+    names = [f"seq{i}" for i in range(len(starts) - 1)] or ["seq0"]
+    text, mapped, batches = ca.pair_chunk_sam_best(world["dev"], strat, reads1, reads2, ids1, ids2, quals, quals, names, x=0, min_identity=95,
+                                                   orientation=ca.ORIENTATION_FR, max_frag=600, min_frag=100)
+    assert batches <= 80, batches  # (two mates x the distances 0 .. 5 x a few rounds — not one search per pair and stratum: 48 here)
+    by_pair = {}
+    for ln in text.splitlines():
+        f = ln.split("\t")
+        by_pair.setdefault(f[0].split("/")[0], []).append(f)
+    assert len(by_pair) == n
+    text_all, _ = ca.pair_chunk_sam(world["dev"], strat, 5, reads1, reads2, ids1, ids2, quals, quals, names, ca.ORIENTATION_FR, 600, 100, True, True)
+    all_pairs = {}
+    for ln in text_all.splitlines():
+        f = ln.split("\t")
+        all_pairs.setdefault(f[0].split("/")[0], []).append(f)
+
+    def proper(recs):  # {(sequence, forward mate's position, template length)} -> total distance, over the records of proper pairs
+        out = {}
+        for f in recs:
+            if int(f[1]) & 2:
+                key = (f[2], min(int(f[3]), int(f[7])), abs(int(f[8])))
+                out[key] = out.get(key, 0) + int([t for t in f[11:] if t.startswith("NM:i:")][0][5:])
+        return out
+
+    right = same = with_pair = half_mapped = 0
+    for i in range(n):
+        recs = by_pair[f"frag{i}"]
+        flags = [int(f[1]) for f in recs]
+        if i % 20 == 13:  # the mate from nowhere is unmapped; its partner's records carry "mate unmapped" — or the partner is reported unmapped as
+            # well: after pairDiscordantlyBest has looked at every stratum by itself (mapStratum), findBestAlignments only asks the strata
+            # 0, 1, 3, 5, ... whether THEY hold something (hasUpdate, searchstrategy.cpp:674-681), so a partner whose best hit has 2 or 4
+            # errors is not seen.  The reference's behaviour, kept.
+            assert any(fl & 4 for fl in flags) and not any(fl & 2 for fl in flags), (i, flags)
+            half_mapped += any(fl & 8 and not fl & 4 for fl in flags)
+            continue
+        if i % 20 == 7:
+            assert not any(fl & 2 for fl in flags) and all(fl & 1 for fl in flags), (i, flags)
+            continue
+        best = proper(recs)
+        ref = proper(all_pairs[f"frag{i}"])
+        if ref:
+            with_pair += 1
+            lo = min(ref.values())
+            same += best == {k: v for k, v in ref.items() if v == lo}
+        p0, frag = truth[i]
+        sid = int(np.searchsorted(starts, p0, side="right") - 1)
+        right += any(k[0] == names[sid] and abs(k[1] - 1 - (p0 - int(starts[sid]))) <= 2 and abs(k[2] - frag) <= 4 for k in best)
+    assert right >= 0.85 * n * 0.9 and with_pair > 150 and same >= 0.97 * with_pair and half_mapped >= 4, (right, with_pair, same, half_mapped)
+    # the strata above the best one (x = 1) and the other orientations run through the same walk
+    t1, m1, _ = ca.pair_chunk_sam_best(world["dev"], strat, reads1[:60], reads2[:60], ids1[:60], ids2[:60], quals[:60], quals[:60], names, x=1,
+                                       min_identity=95, orientation=ca.ORIENTATION_FR, max_frag=600, min_frag=100)
+    assert m1 >= 45 and t1.count("\n") >= 120
+    t2, m2, _ = ca.pair_chunk_sam_best(world["dev"], strat, reads1[:60], reads2[:60], ids1[:60], ids2[:60], quals[:60], quals[:60], names, x=0,
+                                       min_identity=95, orientation=ca.ORIENTATION_FF, max_frag=600, min_frag=100)
+    assert not any(int(ln.split("\t")[1]) & 2 for ln in t2.splitlines()) and m2 >= 45  # (FR fragments under FF: discordant pairs)
+
+
 def test_paired_mates_across_sequence_boundaries_are_trimmed(world):
     """A mate whose only hit runs over the end of its sequence: assignSequence -> findSeqName trims it (indexinterface.cpp:833-899,
     FOUND_WITH_TRIMMING: new range, distance, CIGAR) and the pair forms with the trimmed mate — the same record the single-end
