@@ -1,9 +1,9 @@
-// A Columba-style aligner (single-end; paired-end in ALL mode) over the C-ABI (the counterpart of `columba` for the hot path this library
+// A Columba-style aligner (single-end and paired-end reads, ALL and BEST mode) over the C-ABI (the counterpart of `columba` for the hot path this library
 // accelerates: reference src/parallel.cpp main / threadEntrySingleEnd / processChunk):
 //   columba_align -r <index base> -f <reads.fq|fa> -o <out.sam> [-e <max distance>] [-a all|best] [-x <strata>]
 //                 [-I <min identity>] [-S <strategy>] [-m edit|hamming] [-p uniform|static|dynamic]
 //                 [-s <SA sparseness>] [-K <k-mer size>] [-b <reads per chunk>] [-XA] [-nU]
-//                 [-F <mates.fq> -O fr|rf|ff -X <max insert> -N <min insert> -nD]      (pairs: -a all only)
+//                 [-F <mates.fq> -O fr|rf|ff -X <max insert> -N <min insert> -nD]      (read pairs)
 // FASTQ / FASTA in, SAM out (header of <base>.headerSN.bin, records in input order).
 #include "columba_amd.hpp"
 #include "columba_amd_io.hpp"
@@ -67,7 +67,6 @@ int main(int argc, char** argv) {
         const std::vector<std::string> seqNames = readSequenceNames(base);
         std::vector<const char*> seqNamePtrs;
         for (const auto& s : seqNames) seqNamePtrs.push_back(s.c_str());
-        if (!matesFile.empty() && mode != "all") throw std::runtime_error("paired-end reads are supported in ALL mode only (-a all)");
         const uint32_t ori = orientation == "rf" ? CMB_ORIENTATION_RF : orientation == "ff" ? CMB_ORIENTATION_FF : CMB_ORIENTATION_FR;
         Reader reader(readsFile);
         std::unique_ptr<Reader> mateReader(matesFile.empty() ? nullptr : new Reader(matesFile));
@@ -88,7 +87,11 @@ int main(int argc, char** argv) {
             if (mateReader) {
                 std::vector<SequenceRecord> mates;
                 mateReader->getNextChunk(mates, chunkReads);
-                text = strategy.samOfChunkPairedAll(chunk, mates, seqNamePtrs, (length_t)k, ori, maxInsert, minInsert, discordant, unmapped, nMapped);
+                if (mode == "all")
+                    text = strategy.samOfChunkPairedAll(chunk, mates, seqNamePtrs, (length_t)k, ori, maxInsert, minInsert, discordant, unmapped, nMapped);
+                else
+                    text = strategy.samOfChunkPairedBest(chunk, mates, seqNamePtrs, (uint32_t)x, (uint32_t)identity, ori, maxInsert, minInsert, discordant,
+                                                         unmapped, nMapped);
             } else if (mode == "all") {
                 text = strategy.samOfChunkAll(seqs, offs, ids, quals, seqNamePtrs, (length_t)k, unmapped, xa);
             } else {

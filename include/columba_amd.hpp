@@ -29,6 +29,7 @@
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -369,6 +370,90 @@ class SearchStrategy {
             buf.resize((size_t)n + 1);
             cmb_pair_sam(&prm, &rd[0], &rd[1], seqNames.data(), buf.data(), (uint64_t)n + 1, &nPairs);
             text.append(buf.data(), (size_t)n);
+            mappedPairs += nPairs > 0;
+        }
+        return text;
+    }
+    // Read pairs in BEST (+x strata) mode: SearchStrategy::matchApproxPairedEndBestPlusX (searchstrategy.cpp:1091-1179) for a whole chunk.
+    // The pairs walk through their strata together (cmb_pair_best_*): every round, the lists the unfinished pairs wait for — mapRead of one
+    // mate at one distance — come from ONE device batch per (mate, distance) over the reads that ask (ALL mode, every strand filtered by
+    // itself, with alignments); both strands of a result are handed in.  maxSupported: getMaxSupportedDistanceForBestMapping of the
+    // strategy (the largest k such that 1 .. k all have schemes), 13 at most.
+    template <class Record>
+    std::string samOfChunkPairedBest(const std::vector<Record>& mates1, const std::vector<Record>& mates2, const std::vector<const char*>& seqNames,
+                                     uint32_t x, uint32_t minIdentity, uint32_t orientation, uint32_t maxFragSize, uint32_t minFragSize,
+                                     bool discordantAllowed, bool unmappedRecords, size_t& mappedPairs, size_t* deviceBatches = nullptr) {
+        if (mates1.size() != mates2.size()) throw std::runtime_error("the two read files do not hold the same number of reads");
+        const uint32_t n = (uint32_t)mates1.size();
+        uint32_t maxSupported = 0;
+        for (; maxSupported < 13; maxSupported++) {
+            uint32_t ns = 0, np = 0, crit[16];
+            if (cmb_strategy_describe(h, maxSupported + 1, &ns, &np, crit, 16) != CMB_OK || ns == 0) break;
+        }
+        const std::vector<Record>* in[2] = {&mates1, &mates2};
+        std::vector<std::vector<char>> store; // identifiers, reads, reverse complements and reversed qualities as cmb_read_prepare leaves them
+        store.reserve((size_t)n * 8);
+        std::vector<cmb_pair_read> rd[2];
+        for (int m = 0; m < 2; m++)
+            for (uint32_t i = 0; i < n; i++) {
+                const Record& r = (*in[m])[i];
+                const size_t at = store.size();
+                store.emplace_back(r.seqID.size() + 1), store.emplace_back(r.read.size() + 1), store.emplace_back(r.read.size() + 1), store.emplace_back(r.qual.size() + 1);
+                check(cmb_read_prepare(r.seqID.c_str(), r.read.c_str(), r.qual.c_str(), store[at].data(), store[at + 1].data(), store[at + 2].data(), store[at + 3].data()));
+                rd[m].push_back(cmb_pair_read{store[at].data(), store[at + 1].data(), store[at + 2].data(), r.qual.c_str(), store[at + 3].data(), nullptr, 0});
+            }
+        const cmb_pair_params prm = {orientation, maxFragSize, minFragSize, discordantAllowed ? 1 : 0, unmappedRecords ? 1 : 0};
+        cmb_pair_best* pb = nullptr;
+        check(cmb_pair_best_create(&prm, x, minIdentity, maxSupported, CMB_METRIC_EDIT, index.handle(), n, rd[0].data(), rd[1].data(), &pb));
+        struct Guard {
+            cmb_pair_best* p;
+            ~Guard() { cmb_pair_best_destroy(p); }
+        } guard{pb};
+        std::vector<cmb_pair_request> req(n ? n : 1);
+        for (;;) {
+            uint64_t nReq = 0;
+            check(cmb_pair_best_advance(pb, req.data(), req.size(), &nReq));
+            if (nReq == 0) break;
+            std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> groups; // (mate, distance) -> pairs
+            for (uint64_t j = 0; j < nReq; j++) groups[{req[j].mate, req[j].max_distance}].push_back(req[j].pair);
+            for (const auto& g : groups) {
+                const uint32_t mate = g.first.first, k = g.first.second;
+                std::string seqs;
+                std::vector<uint64_t> offs(g.second.size() + 1, 0);
+                for (size_t j = 0; j < g.second.size(); j++) seqs += (*in[mate])[g.second[j]].read, offs[j + 1] = seqs.size();
+                cmb_batch* b = nullptr;
+                check(cmb_batch_create(index.handle(), h, k, seqs.data(), offs.data(), (uint32_t)g.second.size(), &b));
+                struct BatchGuard {
+                    cmb_batch* b;
+                    ~BatchGuard() { cmb_batch_destroy(b); }
+                } bg{b};
+                check(cmb_batch_want_alignments(b, 1));
+                check(cmb_batch_filter_per_strand(b, 1)); // (mapRead filters the strand it searches by itself)
+                check(cmb_batch_run(b));
+                if (deviceBatches) (*deviceBatches)++;
+                uint64_t nOcc = 0, nOps = 0;
+                check(cmb_batch_result_size(b, &nOcc));
+                std::vector<cmb_occ> occ(nOcc ? nOcc : 1);
+                std::vector<cmb_aln> aln(nOcc ? nOcc : 1);
+                std::vector<uint64_t> oo(g.second.size() + 1), cnt(CMB_CNT_MAX);
+                check(cmb_batch_results(b, occ.data(), occ.size(), oo.data(), cnt.data()));
+                (void)cmb_batch_alignments(b, aln.data(), 0, nullptr, 0, &nOps); // sizes first
+                std::vector<uint16_t> ops(nOps ? nOps : 1);
+                check(cmb_batch_alignments(b, aln.data(), aln.size(), ops.data(), ops.size(), &nOps));
+                for (size_t j = 0; j < g.second.size(); j++)
+                    for (uint32_t strand = 0; strand < 2; strand++)
+                        check(cmb_pair_best_supply(pb, g.second[j], mate, strand, k, occ.data() + oo[j], aln.data() + oo[j], oo[j + 1] - oo[j], ops.data()));
+            }
+        }
+        std::string text;
+        std::vector<char> buf;
+        for (uint32_t i = 0; i < n; i++) {
+            uint32_t nPairs = 0;
+            const int64_t len = cmb_pair_best_sam(pb, i, seqNames.data(), nullptr, 0, &nPairs);
+            if (len < 0) check((int)len);
+            buf.resize((size_t)len + 1);
+            cmb_pair_best_sam(pb, i, seqNames.data(), buf.data(), (uint64_t)len + 1, &nPairs);
+            text.append(buf.data(), (size_t)len);
             mappedPairs += nPairs > 0;
         }
         return text;

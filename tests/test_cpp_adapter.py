@@ -272,3 +272,17 @@ def test_align_driver_paired_end(tmp_path):
     assert body == want and mapped > 0.6 * n
     flags = [int(ln.split("\t")[1]) for ln in body.splitlines()]
     assert sum(1 for f in flags if f & 2) > n and any(f & 8 for f in flags)  # proper pairs, and pairs with an unmapped mate
+    # the same pairs in BEST mode, the CLI's default (samOfChunkPairedBest: the chunk walks through its strata together over
+    # cmb_pair_best_*, a device batch per mate and distance asked for): the records of the Python host layer over the same C-ABI,
+    # chunk by chunk (pairs are independent of their chunk)
+    out2 = tmp_path / "o2.sam"
+    run = subprocess.run([exe, "-r", str(tmp_path / "idx"), "-f", str(tmp_path / "r1.fq"), "-F", str(tmp_path / "r2.fq"), "-o", str(out2),
+                          "-I", "95", "-x", "0", "-S", "columba", "-b", "120", "-X", "500", "-N", "100"], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+    body2 = "".join(ln for ln in out2.read_text().splitlines(keepends=True) if not ln.startswith("@"))
+    want2, mapped2, _ = ca.pair_chunk_sam_best(dev, ca.SearchStrategy("columba", "edit", "dynamic"), r1, r2, [f"@p{i}/1 x" for i in range(n)],
+                                               [f"@p{i}/2 x" for i in range(n)], [q] * n, [q] * n, names, x=0, min_identity=95,
+                                               orientation=ca.ORIENTATION_FR, max_frag=500, min_frag=100)
+    assert body2 == want2 and mapped2 > 0.6 * n
+    flags2 = [int(ln.split("\t")[1]) for ln in body2.splitlines()]
+    assert sum(1 for f in flags2 if f & 2) > n and any(f & 4 for f in flags2)
