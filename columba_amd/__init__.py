@@ -46,7 +46,7 @@ EXPORTS = [
     "cmb_rank_batch", "cmb_extend_batch", "cmb_extend_bench", "cmb_locate_batch", "cmb_verify_batch", "cmb_verify_batch_staged", "cmb_verify_window", "cmb_cigar_windows",
     "cmb_batch_want_alignments", "cmb_batch_alignments", "cmb_sam_se", "cmb_sam_se_xa", "cmb_sam_unmapped_se",
     "cmb_sam_pe", "cmb_sam_unpaired", "cmb_sam_unmapped_pe", "cmb_pair_sam", "cmb_pair_infer",
-    "cmb_pair_best_create", "cmb_pair_best_set_trim", "cmb_pair_best_cutoff", "cmb_pair_best_advance", "cmb_pair_best_supply", "cmb_pair_best_sam",
+    "cmb_pair_best_create", "cmb_pair_best_set_trim", "cmb_pair_best_cutoff", "cmb_pair_best_seed", "cmb_pair_best_advance", "cmb_pair_best_supply", "cmb_pair_best_sam",
     "cmb_pair_best_destroy",
     "cmb_read_prepare", "cmb_batch_sam", "cmb_batch_filter_per_strand", "cmb_match_best", "cmb_best_sizes", "cmb_best_results",
     "cmb_best_destroy",
@@ -259,6 +259,7 @@ def lib():
         L.cmb_pair_best_create.argtypes = [C.POINTER(PairParams), u32, u32, u32, i32, vp, u32, C.POINTER(PairRead), C.POINTER(PairRead), C.POINTER(vp)]
         L.cmb_pair_best_set_trim.argtypes = [vp, vp, vp]
         L.cmb_pair_best_cutoff.argtypes = [vp, u32, u32, C.POINTER(u32)]
+        L.cmb_pair_best_seed.argtypes = [vp, u32, vp, vp, u64, vp, vp, vp, u64, vp, i32]
         L.cmb_pair_best_advance.argtypes = [vp, vp, u64, C.POINTER(u64)]
         L.cmb_pair_best_supply.argtypes = [vp, u32, u32, u32, u32, vp, vp, u64, vp]
         L.cmb_pair_best_sam.restype = C.c_int64
@@ -680,6 +681,13 @@ class PairBest:
         v = C.c_uint32()
         _chk(lib().cmb_pair_best_cutoff(self.h, pair, mate, C.byref(v)))
         return int(v.value)
+
+    def seed(self, pair: int, se1, se2, read2_done: bool):
+        """start pair `pair` from the mates' single-end BEST results (cmb_pair_best_seed): se = (occ, aln, ops)"""
+        a = [np.ascontiguousarray(se1[0], dtype=OCC_DTYPE), np.ascontiguousarray(se1[1], dtype=ALN_DTYPE), np.ascontiguousarray(se1[2], dtype=np.uint16),
+             np.ascontiguousarray(se2[0], dtype=OCC_DTYPE), np.ascontiguousarray(se2[1], dtype=ALN_DTYPE), np.ascontiguousarray(se2[2], dtype=np.uint16)]
+        ptr = [(_p(x) if x.shape[0] else None) for x in a]
+        _chk(lib().cmb_pair_best_seed(self.h, pair, ptr[0], ptr[1], a[0].shape[0], ptr[2], ptr[3], ptr[4], a[3].shape[0], ptr[5], int(read2_done)))
 
     def advance(self) -> np.ndarray:
         req = np.zeros(max(self.n, 1), dtype=PAIR_REQUEST_DTYPE)

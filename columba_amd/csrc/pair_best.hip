@@ -82,6 +82,8 @@ struct PairState {
     uint32_t cutOff[2] = {0, 0};
     std::map<uint32_t, std::vector<BOcc>> lists[2][2]; // [mate][strand][distance]: mapRead's result, as supplied
     std::map<TrimKey, std::pair<bool, BOcc>> trims;     // findSeqName's outcome for occurrences that run over the end of a sequence
+    bool seeded = false, read2done = false; // addSingleEndedForBest: the walk starts from single-end results
+    std::vector<BOcc> seeds[2];
     bool finished = false;
     std::vector<BPair> pairs;       // the outcome: pairs ...
     std::vector<Unpaired> unpaired; // ... and unpaired records
@@ -110,6 +112,14 @@ struct Walk {
     Walk(cmb_pair_best& b, uint32_t i) : B(b), pairIndex(i), P(b.pairs[i]) {
         for (int m = 0; m < 2; m++)
             for (int s = 0; s < 2; s++) ov[m][s].assign(P.cutOff[m] + 1, Stratum());
+        if (P.seeded) { // addSingleEndedForBest (:1064-1089): the single-end matches in their strata; read 1 counts as looked at everywhere
+            for (int m = 0; m < 2; m++)
+                for (const BOcc& o : P.seeds[m]) ov[m][o.strand][o.distance].v.push_back(o);
+            for (int s = 0; s < 2; s++) {
+                for (Stratum& st : ov[0][s]) st.done = true;
+                for (Stratum& st : ov[1][s]) st.done = P.read2done;
+            }
+        }
     }
     const std::string& seqOf(int m, int s) const { return s ? P.rc[m] : P.seq[m]; }
 
@@ -560,6 +570,37 @@ extern "C" int cmb_pair_best_create(const cmb_pair_params* prm, uint32_t x, uint
 extern "C" int cmb_pair_best_set_trim(cmb_pair_best* b, cmb_pair_trim_fn fn, void* user) {
     if (!b) return failWith(CMB_ERR_INVALID, "null argument");
     b->trimFn = fn, b->trimUser = user;
+    return CMB_OK;
+}
+
+// addSingleEndedForBest (searchstrategy.cpp:1064-1089) for pairSingleEndedMatchesBest (searchstrategy.h:1454-1462, x = 0): the pair starts from the
+// mates' single-end BEST results (occurrences with their sequence assigned and their CIGAR)
+extern "C" int cmb_pair_best_seed(cmb_pair_best* b, uint32_t pair, const cmb_occ* occ1, const cmb_aln* aln1, uint64_t n1, const uint16_t* ops1,
+                                  const cmb_occ* occ2, const cmb_aln* aln2, uint64_t n2, const uint16_t* ops2, int read2_done) {
+    if (!b || pair >= b->pairs.size() || (n1 && (!occ1 || !aln1)) || (n2 && (!occ2 || !aln2))) return failWith(CMB_ERR_INVALID, "bad argument");
+    if (b->x != 0) return failWith(CMB_ERR_INVALID, "single-end results start a pair in BEST mode without further strata only (x = 0)");
+    PairState& P = b->pairs[pair];
+    if (P.finished || !P.lists[0][0].empty() || !P.lists[0][1].empty() || !P.lists[1][0].empty() || !P.lists[1][1].empty())
+        return failWith(CMB_ERR_INVALID, "the pair has started its walk already");
+    const cmb_occ* oc[2] = {occ1, occ2};
+    const cmb_aln* al[2] = {aln1, aln2};
+    const uint16_t* op[2] = {ops1, ops2};
+    const uint64_t cnt[2] = {n1, n2};
+    std::vector<BOcc> seeds[2];
+    for (int m = 0; m < 2; m++)
+        for (uint64_t j = 0; j < cnt[m]; j++) {
+            const cmb_occ& o = oc[m][j];
+            if (o.end < o.begin || o.strand > 1 || o.distance > P.cutOff[m]) return failWith(CMB_ERR_INVALID, "bad occurrence (or one beyond the read's cut-off)");
+            if (al[m][j].spans == 1) return failWith(CMB_ERR_INVALID, "single-end results come with their sequence assigned (trimmed where they ran over its end)");
+            if (al[m][j].cigar_len && !op[m]) return failWith(CMB_ERR_INVALID, "alignments without their operations");
+            BOcc s;
+            s.indexBegin = o.begin, s.width = o.end - o.begin, s.distance = o.distance, s.strand = (uint8_t)o.strand, s.second = (uint8_t)m;
+            s.seqId = al[m][j].seq_id, s.seqBegin = al[m][j].seq_begin, s.state = FOUND;
+            s.ops.assign(op[m] + al[m][j].cigar_off, op[m] + al[m][j].cigar_off + al[m][j].cigar_len);
+            seeds[m].push_back(std::move(s));
+        }
+    P.seeds[0] = std::move(seeds[0]), P.seeds[1] = std::move(seeds[1]);
+    P.seeded = true, P.read2done = read2_done != 0;
     return CMB_OK;
 }
 

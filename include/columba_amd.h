@@ -371,6 +371,12 @@ int cmb_pair_best_create(const cmb_pair_params* params, uint32_t x, uint32_t min
                          cmb_pair_best** out);
 int cmb_pair_best_set_trim(cmb_pair_best* b, cmb_pair_trim_fn fn, void* user);
 int cmb_pair_best_cutoff(const cmb_pair_best* b, uint32_t pair, uint32_t mate, uint32_t* cut_off);
+/* pairSingleEndedMatchesBest (src/searchstrategy.h:1454-1462) over addSingleEndedForBest (src/searchstrategy.cpp:1064-1089), x = 0: the pair
+ * starts from the mates' single-end BEST results (what the parameter-inference phase has computed, src/parallel.cpp:790-810) — occurrences
+ * with their sequence assigned (aln[j].spans != 1) and their CIGAR; every stratum of read 1 then counts as looked at, those of read 2 if
+ * read2_done.  Before the first cmb_pair_best_advance of that pair. */
+int cmb_pair_best_seed(cmb_pair_best* b, uint32_t pair, const cmb_occ* occ1, const cmb_aln* aln1, uint64_t n1, const uint16_t* cigar_ops1,
+                       const cmb_occ* occ2, const cmb_aln* aln2, uint64_t n2, const uint16_t* cigar_ops2, int read2_done);
 /* at most one request per unfinished pair; CMB_ERR_OVERFLOW (with *n = the number wanted) if cap is too small — nothing is lost, call again */
 int cmb_pair_best_advance(cmb_pair_best* b, cmb_pair_request* requests, uint64_t cap, uint64_t* n);
 /* the ALL-mode result of that mate at that distance (occurrences of the other strand in the list are skipped, so one device result

@@ -74,13 +74,24 @@ class Occ:
 class RefWalk:
     """one pair, straight through"""
 
-    def __init__(self, table, reads, cutoffs, x, orientation, max_frag, min_frag, disc, unmapped):
+    def __init__(self, table, reads, cutoffs, x, orientation, max_frag, min_frag, disc, unmapped, seeds=None):
         self.table, self.R, self.cut = table, reads, cutoffs
         self.x, self.ori, self.max_frag, self.min_frag, self.disc, self.unmapped = x, orientation, max_frag, min_frag, disc, unmapped
         self.ov = [[[[False, []] for _ in range(cutoffs[m] + 1)] for _s in (0, 1)] for m in (0, 1)]
         self.pairs = []     # [up, down, frag, distance, discordant]; up / down = Occ or ("unmapped", mate)
         self.unpaired = []  # ("occ", Occ, best_count, best, first) or ("unmapped", mate)
         self.asked = []
+        if seeds is not None:  # addSingleEndedForBest (searchstrategy.cpp:1064-1089)
+            se1, se2, read2done = seeds
+            for o in se1 + se2:
+                o = o.copy()
+                o.state = FOUND
+                self.ov[o.m][o.s][o.d][1].append(o)
+            for s in (0, 1):
+                for st in self.ov[0][s]:
+                    st[0] = True
+                for st in self.ov[1][s]:
+                    st[0] = read2done
 
     def map_read(self, m, s, k, min_d=0):
         self.asked.append((m, s, k))
@@ -494,7 +505,18 @@ def _make_pair(rng, i, len1, len2, min_identity, max_supported, kind, ori=None):
     return reads, cut, table, ori
 
 
-def _run_library(pairs, x, min_identity, max_supported, orientation, max_frag, min_frag, disc, unmapped):
+def _as_arrays(lst):
+    occ = np.zeros(len(lst), dtype=ca.OCC_DTYPE)
+    aln = np.zeros(len(lst), dtype=ca.ALN_DTYPE)
+    ops = []
+    for j, o in enumerate(lst):
+        occ[j] = (o.ib, o.ib + o.w, o.d, o.s)
+        aln[j] = (o.sid, o.sb, len(ops), len(o.ops), 1 if o.spans else 0, 0)
+        ops += o.ops
+    return occ, aln, np.asarray(ops, dtype=np.uint16)
+
+
+def _run_library(pairs, x, min_identity, max_supported, orientation, max_frag, min_frag, disc, unmapped, seeds=None):
     """drive cmb_pair_best_* over a chunk: answer every request from the pair's table"""
     def trim(pair, mate, strand, stratum, occ):
         return synthetic_trim(stratum, *occ)
@@ -502,6 +524,9 @@ def _run_library(pairs, x, min_identity, max_supported, orientation, max_frag, m
     pb = ca.PairBest([p[0][0] for p in pairs], [p[0][1] for p in pairs], x, min_identity, max_supported, orientation, max_frag, min_frag, disc,
                      unmapped, trim=trim)
     asked = [[] for _ in pairs]
+    for i, sd in enumerate(seeds or []):
+        if sd is not None:
+            pb.seed(i, _as_arrays(sd[0]), _as_arrays(sd[1]), sd[2])
     for rounds in range(400):
         req = pb.advance()
         if req.shape[0] == 0:
@@ -509,15 +534,7 @@ def _run_library(pairs, x, min_identity, max_supported, orientation, max_frag, m
         for r in req:
             i, m, s, k = int(r["pair"]), int(r["mate"]), int(r["strand"]), int(r["max_distance"])
             asked[i].append((m, s, k))
-            lst = pairs[i][2][(m, s, k)]
-            occ = np.zeros(len(lst), dtype=ca.OCC_DTYPE)
-            aln = np.zeros(len(lst), dtype=ca.ALN_DTYPE)
-            ops = []
-            for j, o in enumerate(lst):
-                occ[j] = (o.ib, o.ib + o.w, o.d, o.s)
-                aln[j] = (o.sid, o.sb, len(ops), len(o.ops), 1 if o.spans else 0, 0)
-                ops += o.ops
-            pb.supply(i, m, s, k, occ, aln, np.asarray(ops, dtype=np.uint16))
+            pb.supply(i, m, s, k, *_as_arrays(pairs[i][2][(m, s, k)]))
     else:
         raise AssertionError("the walk does not end")
     out = [pb.sam(i, SEQ_NAMES) for i in range(len(pairs))]
@@ -553,6 +570,37 @@ def test_best_pairing_equals_the_restatement(x, orientation):
             n_mapped += n > 0
             n_lines += text.count("\n")
         assert n_lines > 150 and (n_mapped > 10 or not disc)
+
+
+@pytest.mark.parametrize("orientation", [ca.ORIENTATION_FR, ca.ORIENTATION_RF, ca.ORIENTATION_FF])
+def test_pairs_that_start_from_single_end_results(orientation):
+    """pairSingleEndedMatchesBest (searchstrategy.h:1454-1462): the walk starts from the mates' single-end BEST results — the best stratum of
+    each mate, both strands — with every stratum of read 1 (and of read 2 if it was processed) counting as looked at"""
+    rng = np.random.default_rng(300 + orientation)
+    pairs, seeds = [], []
+    for i in range(240):
+        reads, cut, table, _ = _make_pair(rng, i, 100, int(rng.choice([80, 100])), 95, 5, KINDS[i % len(KINDS)], ori=orientation if i % 3 else None)
+        pairs.append((reads, cut, table))
+        se = []
+        for m in (0, 1):
+            every = [o for s in (0, 1) for o in table[(m, s, cut[m])] if not o.spans]
+            best = min((o.d for o in every), default=None)
+            se.append([o for o in every if o.d == best])
+        read2done = bool(i % 4)
+        seeds.append((se[0], se[1] if read2done else [], read2done))
+    got, asked, _ = _run_library(pairs, 0, 95, 5, orientation, 600, 0, True, True, seeds=seeds)
+    n_mapped = 0
+    for i, (reads, cut, table) in enumerate(pairs):
+        ref = RefWalk(table, reads, cut, 0, orientation, 600, 0, True, True, seeds=seeds[i]).run()
+        text, n = ref.sam()
+        assert got[i] == (text, n), (i, got[i], text)
+        assert asked[i] == list(dict.fromkeys(ref.asked)) and all(m == 1 for m, _s, _k in asked[i])  # read 1 is never searched again
+        n_mapped += n > 0
+    assert n_mapped > 60
+    pb = ca.PairBest([pairs[0][0][0]], [pairs[0][0][1]], 1, 95, 5)
+    with pytest.raises(ca.CmbError, match="x = 0"):
+        pb.seed(0, _as_arrays([]), _as_arrays([]), True)
+    pb.close()
 
 
 def test_best_pairs_are_the_best_concordant_pairs():
