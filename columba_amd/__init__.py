@@ -1183,12 +1183,22 @@ def pair_chunk_sam(index: "Index", strategy: "SearchStrategy", max_distance: int
 
 def pair_chunk_sam_best(index: "Index", strategy: "SearchStrategy", reads1, reads2, ids1, ids2, quals1, quals2, seq_names, x: int = 0,
                         min_identity: int = 95, orientation: int = ORIENTATION_FR, max_frag: int = 500, min_frag: int = 0,
-                        discordant_allowed: bool = True, unmapped_records: bool = True, max_supported: Optional[int] = None):
+                        discordant_allowed: bool = True, unmapped_records: bool = True, max_supported: Optional[int] = None, kmer_size: int = 10):
     """A chunk of read pairs in BEST (+x strata) mode, end to end (SearchStrategy::matchApproxPairedEndBestPlusX,
     searchstrategy.cpp:1091-1179): the pairs walk through their strata together (PairBest); every round, the lists the unfinished pairs
     wait for — mapRead of one mate at one distance — are produced by ONE device batch per (mate, distance) over the reads that ask
-    (ALL mode, every strand filtered by itself, with alignments), and both strands of a result are handed in.  Returns (SAM text,
-    number of properly or discordantly mapped pairs, number of device batches)."""
+    (ALL mode, every strand filtered by itself, with alignments), and both strands of a result are handed in.  `index`: an Index, or a
+    MoveIndex with its text attached (the b-move backend: MoveBatch per (mate, distance); kmer_size is its seed table's).  Returns (SAM
+    text, number of properly or discordantly mapped pairs, number of device batches)."""
+    is_move = isinstance(index, MoveIndex)
+    if is_move:
+        class _TextIndex:  # (the text beside the b-move index: what an occurrence over a sequence end is trimmed on)
+            h = C.c_void_p(lib().cmb_move_text_index(index.h))
+        if not _TextIndex.h:
+            raise CmbError(-1, "pairs on the b-move index need the text beside it (MoveIndex.attach_text)")
+        trim_index = _TextIndex
+    else:
+        trim_index = index
     n = len(reads1)
     if max_supported is None:  # getMaxSupportedDistanceForBestMapping: the largest k such that 1 .. k all have a scheme (13 at most)
         max_supported = 0
@@ -1207,7 +1217,7 @@ def pair_chunk_sam_best(index: "Index", strategy: "SearchStrategy", reads1, read
             prep.append((sid, seq, rc, quals[i], rq))
         mates.append(prep)
     pb = PairBest(mates[0], mates[1], x, min_identity, max_supported, orientation, max_frag, min_frag, discordant_allowed, unmapped_records,
-                  text_index=index)
+                  text_index=trim_index)
     raw = [[r if isinstance(r, bytes) else r.encode() for r in reads] for reads in (reads1, reads2)]
     batches = 0
     while True:
@@ -1218,13 +1228,23 @@ def pair_chunk_sam_best(index: "Index", strategy: "SearchStrategy", reads1, read
         for r in req:
             groups.setdefault((int(r["mate"]), int(r["max_distance"])), []).append(int(r["pair"]))
         for (mate, k), idxs in sorted(groups.items()):
-            b = Batch(index, strategy, k, reads=[raw[mate][i] for i in idxs])
-            b.want_alignments()
-            _chk(lib().cmb_batch_filter_per_strand(b.h, 1))
+            if is_move:
+                b = MoveBatch(index, strategy, k, reads=[raw[mate][i] for i in idxs], kmer_size=kmer_size)
+                b.want_alignments()
+                b.filter_per_strand()
+            else:
+                b = Batch(index, strategy, k, reads=[raw[mate][i] for i in idxs])
+                b.want_alignments()
+                _chk(lib().cmb_batch_filter_per_strand(b.h, 1))
             b.run()
             batches += 1
             occ, offs, _ = b.results()
             aln, ops = b.alignments()
+            if is_move:  # (64-bit positions there; alignments exist for texts below 2^32 only)
+                occ32 = np.zeros(len(occ), OCC_DTYPE)
+                for f in ("begin", "end", "distance", "strand"):
+                    occ32[f] = occ[f]
+                occ = occ32
             for j, i in enumerate(idxs):
                 lo, hi = int(offs[j]), int(offs[j + 1])
                 for strand in (0, 1):

@@ -358,3 +358,42 @@ def test_bmove_edit_distance_beyond_seven_errors(sworld, gt, partition, k, lengt
     checked, _ = check_soundness(gt, sworld["text"], reads[:60], occ, offs, k, "edit")
     hits, chain = check_completeness(gt, sworld["text"], reads[:25], occ, offs, k, "edit")
     assert checked > 20 and hits > 10 and chain * 20 <= hits
+
+
+def test_bmove_read_pairs_in_best_mode(sworld):
+    """Read pairs in BEST mode on the b-move index (ca.pair_chunk_sam_best over MoveBatch: the chunk walks through its strata together,
+    cmb_pair_best_*): the records equal those of the FM-index flavour on the same text when that one never switches to in-text
+    verification — the two flavours report the same occurrences then — and the simulated fragments come back as proper pairs."""
+    from columba_amd import indexbuild as ib
+    ca = sworld["ca"]
+    g = sworld["g"]
+    starts = np.array([0, 250_000, 640_000, len(g)], dtype=np.uint64)
+    rng = np.random.default_rng(91)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    n, L = 160, 100
+    r1, r2 = [], []
+    for i in range(n):
+        frag = int(rng.integers(220, 400))
+        p0 = int(rng.integers(640_100, len(g) - 1000)) if i % 3 else int(rng.integers(100, 600_000))  # (unique tail / repeated haplotypes)
+        a = bytearray(g[p0:p0 + L].tobytes())
+        b = bytearray(g[p0 + frag - L:p0 + frag].tobytes().translate(comp)[::-1])
+        for m in (a, b):
+            for _ in range(int(rng.integers(0, 3))):
+                q = int(rng.integers(1, L - 1))
+                m[q] = b"ACGT"[(b"ACGT".index(bytes([m[q]])) + 1) % 4]
+        if i % 2:
+            a, b = b, a
+        r1.append(bytes(a))
+        r2.append(bytes(b))
+    ids1, ids2, quals = [f"@f{i}/1" for i in range(n)], [f"@f{i}/2" for i in range(n)], ["I" * L] * n
+    names = ["hapA", "hapB", "tail"]
+    st = ca.SearchStrategy("columba", "edit", "dynamic")
+    sworld["dev"].attach_text(sworld["text"], starts)
+    text, mapped, batches = ca.pair_chunk_sam_best(sworld["dev"], st, r1, r2, ids1, ids2, quals, quals, names, x=0, min_identity=95,
+                                                   orientation=ca.ORIENTATION_FR, max_frag=600, min_frag=100, kmer_size=8)
+    fm = ca.Index(ib.build_index(sworld["text"], seq_starts=starts.astype(np.int64), device="cuda"), in_text_switch=0, kmer_size=8)
+    want, mapped_fm, _ = ca.pair_chunk_sam_best(fm, st, r1, r2, ids1, ids2, quals, quals, names, x=0, min_identity=95,
+                                                orientation=ca.ORIENTATION_FR, max_frag=600, min_frag=100)
+    assert text == want and mapped == mapped_fm and mapped > 0.85 * n and batches <= 80
+    flags = [int(ln.split("\t")[1]) for ln in text.splitlines()]
+    assert sum(1 for f in flags if f & 2) >= 2 * 0.8 * n
