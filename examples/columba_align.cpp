@@ -3,7 +3,10 @@
 //   columba_align -r <index base> -f <reads.fq|fa> -o <out.sam> [-e <max distance>] [-a all|best] [-x <strata>]
 //                 [-I <min identity>] [-S <strategy>] [-m edit|hamming] [-p uniform|static|dynamic]
 //                 [-s <SA sparseness>] [-K <k-mer size>] [-b <reads per chunk>] [-XA] [-nU]
-//                 [-F <mates.fq> -O fr|rf|ff -X <max insert> -N <min insert> -nD]      (read pairs)
+//                 [-F <mates.fq> -O fr|rf|ff -X <max insert> -N <min insert> -nD -nI]  (read pairs)
+// Read pairs in BEST mode: unless -nI or one of -O / -X / -N is given, orientation and insert-size bounds are inferred from the first pairs of
+// the files as the reference does (parallel.cpp:468-655, :862-935: up to 10 000 reads matched single-end, the pairs whose mates both map
+// unambiguously are the sample) and that first chunk is paired from its single-end results.
 // FASTQ / FASTA in, SAM out (header of <base>.headerSN.bin, records in input order).
 #include "columba_amd.hpp"
 #include "columba_amd_io.hpp"
@@ -18,7 +21,7 @@ int main(int argc, char** argv) {
     std::string base, readsFile, matesFile, orientation = "fr", outFile, strategyName = "columba", mode = "best", metric = "edit", part = "dynamic", cmdline;
     int k = 0, x = 0, identity = 95, sparse = 4, kmer = 10;
     size_t chunkReads = 1000000;
-    bool xa = false, unmapped = true, discordant = true;
+    bool xa = false, unmapped = true, discordant = true, noInfer = false, pairParamsGiven = false;
     unsigned maxInsert = 500, minInsert = 0;
     for (int i = 0; i < argc; i++) cmdline += std::string(i ? " " : "") + argv[i];
     for (int i = 1; i < argc; i++) {
@@ -44,9 +47,10 @@ int main(int argc, char** argv) {
             else if (a == "-XA") xa = true;
             else if (a == "-nU") unmapped = false;
             else if (a == "-F") matesFile = val();
-            else if (a == "-O") orientation = val();
-            else if (a == "-X") maxInsert = (unsigned)std::stoul(val());
-            else if (a == "-N") minInsert = (unsigned)std::stoul(val());
+            else if (a == "-O") orientation = val(), pairParamsGiven = true;
+            else if (a == "-X") maxInsert = (unsigned)std::stoul(val()), pairParamsGiven = true;
+            else if (a == "-N") minInsert = (unsigned)std::stoul(val()), pairParamsGiven = true;
+            else if (a == "-nI") noInfer = true;
             else if (a == "-nD") discordant = false;
             else throw std::runtime_error("unknown option " + a);
         } catch (const std::exception& e) {
@@ -67,12 +71,40 @@ int main(int argc, char** argv) {
         const std::vector<std::string> seqNames = readSequenceNames(base);
         std::vector<const char*> seqNamePtrs;
         for (const auto& s : seqNames) seqNamePtrs.push_back(s.c_str());
-        const uint32_t ori = orientation == "rf" ? CMB_ORIENTATION_RF : orientation == "ff" ? CMB_ORIENTATION_FF : CMB_ORIENTATION_FR;
+        uint32_t ori = orientation == "rf" ? CMB_ORIENTATION_RF : orientation == "ff" ? CMB_ORIENTATION_FF : CMB_ORIENTATION_FR;
         Reader reader(readsFile);
         std::unique_ptr<Reader> mateReader(matesFile.empty() ? nullptr : new Reader(matesFile));
         OutputWriter writer(outFile, base + ".headerSN.bin", cmdline);
         std::vector<SequenceRecord> chunk;
         size_t chunkID = 0, nReads = 0, nMapped = 0;
+        if (mateReader && mode != "all" && !noInfer && !pairParamsGiven) {
+            // PE_MAX_READS_FOR_INFERENCE = 10 000 reads (definitions.h:58): the first 5 000 pairs at most
+            std::vector<SequenceRecord> mates;
+            const size_t want = std::min<size_t>(chunkReads, 5000);
+            if (reader.getNextChunk(chunk, want)) {
+                mateReader->getNextChunk(mates, want);
+                uint32_t seqsInFirstFile = (uint32_t)seqNames.size();
+                {
+                    std::ifstream fs(base + ".fsid", std::ios::binary);
+                    uint32_t v[2] = {0, 0};
+                    if (fs.read(reinterpret_cast<char*>(v), sizeof(v))) seqsInFirstFile = v[1]; // (a second file starts at sequence v[1])
+                }
+                auto inf = strategy.inferPairedEndParameters(chunk, mates, (uint32_t)identity, seqsInFirstFile);
+                std::cerr << "Found " << inf.unambiguousPairs << " unambiguous pairs while processing " << inf.readsGiven
+                          << " reads for inferring paired-end parameters\n";
+                if (inf.inferred.inferred) {
+                    ori = inf.inferred.orientation, maxInsert = inf.inferred.max_insert, minInsert = inf.inferred.min_insert;
+                    std::cerr << "Inferred paired-end parameters: orientation " << (ori == CMB_ORIENTATION_FR ? "FR" : ori == CMB_ORIENTATION_RF ? "RF" : "FF")
+                              << ", insert size " << inf.inferred.mean_insert << " +- " << inf.inferred.stddev_insert << ", bounds [" << minInsert << ", "
+                              << maxInsert << "]\n";
+                } else
+                    std::cerr << "No pairs mapped unambiguously. Using default values!\n";
+                std::string text = strategy.samOfChunkPairedBest(chunk, mates, seqNamePtrs, 0, (uint32_t)identity, ori, maxInsert, minInsert, discordant, unmapped,
+                                                                 nMapped, nullptr, &inf);
+                nReads += chunk.size();
+                writer.commitChunk(chunkID++, std::move(text));
+            }
+        }
         while (reader.getNextChunk(chunk, chunkReads)) {
             std::string seqs;
             std::vector<uint64_t> offs(chunk.size() + 1, 0);

@@ -379,12 +379,96 @@ class SearchStrategy {
     // mate at one distance — come from ONE device batch per (mate, distance) over the reads that ask (ALL mode, every strand filtered by
     // itself, with alignments); both strands of a result are handed in.  maxSupported: getMaxSupportedDistanceForBestMapping of the
     // strategy (the largest k such that 1 .. k all have schemes), 13 at most.
+    // The single-end phase that infers the paired-end parameters (parallel.cpp:236-262 hasUnambiguousMatchInFirstFile, :276-312
+    // processChunkSingleEndForPairInferring, :700-727 and cmb_pair_infer for :329-466): read 1 of every pair in BEST mode; read 2 where read 1 has
+    // exactly one match in the first reference file; the pairs whose mates both do are the sample.  The single-end results stay here: the
+    // same chunk is then paired from them (samOfChunkPairedBest(..., &inference): pairSingleEndedMatchesBest, searchstrategy.h:1454-1462).
+    struct PairedEndInference {
+        cmb_pair_inferred inferred{};
+        size_t readsGiven = 0, unambiguousPairs = 0;
+        struct Single {
+            std::vector<cmb_occ> occ;
+            std::vector<cmb_aln> aln; // (cigar_off into ops)
+            std::vector<uint16_t> ops;
+        };
+        std::vector<Single> single[2]; // [mate][pair]
+        std::vector<uint8_t> read2done;
+    };
+    template <class Record>
+    PairedEndInference inferPairedEndParameters(const std::vector<Record>& mates1, const std::vector<Record>& mates2, uint32_t minIdentity,
+                                                uint32_t seqsInFirstFile) {
+        if (mates1.size() != mates2.size()) throw std::runtime_error("the two read files do not hold the same number of reads");
+        const size_t n = mates1.size();
+        PairedEndInference inf;
+        inf.single[0].resize(n), inf.single[1].resize(n), inf.read2done.assign(n, 0);
+        auto matchSingle = [&](const std::vector<Record>& recs, const std::vector<size_t>& ids, std::vector<typename PairedEndInference::Single>& out) {
+            std::string seqs;
+            std::vector<uint64_t> offs(ids.size() + 1, 0);
+            for (size_t j = 0; j < ids.size(); j++) seqs += recs[ids[j]].read, offs[j + 1] = seqs.size();
+            cmb_best* r = nullptr;
+            check(cmb_match_best(index.handle(), h, 0, minIdentity, seqs.data(), offs.data(), (uint32_t)ids.size(), &r));
+            struct Guard {
+                cmb_best* r;
+                ~Guard() { cmb_best_destroy(r); }
+            } guard{r};
+            uint64_t nOcc = 0, nOps = 0;
+            check(cmb_best_sizes(r, &nOcc, &nOps));
+            std::vector<cmb_occ> occ(nOcc ? nOcc : 1);
+            std::vector<cmb_aln> aln(nOcc ? nOcc : 1);
+            std::vector<uint16_t> ops(nOps ? nOps : 1);
+            std::vector<uint64_t> oo(ids.size() + 1);
+            std::vector<uint32_t> best(ids.size() ? ids.size() : 1), hits(ids.size() ? ids.size() : 1);
+            check(cmb_best_results(r, occ.data(), aln.data(), occ.size(), ops.data(), ops.size(), oo.data(), best.data(), hits.data(), nullptr));
+            for (size_t j = 0; j < ids.size(); j++) {
+                typename PairedEndInference::Single& s = out[ids[j]];
+                for (uint64_t q = oo[j]; q < oo[j + 1]; q++) {
+                    cmb_aln a = aln[q];
+                    const uint64_t from = a.cigar_off;
+                    a.cigar_off = s.ops.size();
+                    a.spans = 0; // (assigned; a trimmed occurrence carries its trimmed coordinates)
+                    s.ops.insert(s.ops.end(), ops.begin() + from, ops.begin() + from + a.cigar_len);
+                    s.occ.push_back(occ[q]);
+                    s.aln.push_back(a);
+                }
+            }
+        };
+        // hasUnambiguousMatchInFirstFile: exactly one of the matches lies in the first file; it moves to the front
+        auto unambiguous = [&](typename PairedEndInference::Single& s) {
+            size_t count = 0, at = 0;
+            for (size_t j = 0; j < s.occ.size(); j++)
+                if (s.aln[j].seq_id < seqsInFirstFile) {
+                    if (++count == 2) return false;
+                    at = j;
+                }
+            if (count == 1) std::swap(s.occ[0], s.occ[at]), std::swap(s.aln[0], s.aln[at]);
+            return count == 1;
+        };
+        std::vector<size_t> all(n);
+        for (size_t i = 0; i < n; i++) all[i] = i;
+        matchSingle(mates1, all, inf.single[0]);
+        std::vector<size_t> second;
+        for (size_t i = 0; i < n; i++)
+            if (unambiguous(inf.single[0][i])) second.push_back(i), inf.read2done[i] = 1;
+        matchSingle(mates2, second, inf.single[1]);
+        std::vector<cmb_pair_sample> samples;
+        for (size_t i : second)
+            if (unambiguous(inf.single[1][i])) {
+                const cmb_occ &o1 = inf.single[0][i].occ[0], &o2 = inf.single[1][i].occ[0];
+                const cmb_aln &a1 = inf.single[0][i].aln[0], &a2 = inf.single[1][i].aln[0];
+                samples.push_back(cmb_pair_sample{a1.seq_begin, a1.seq_begin + (o1.end - o1.begin), o1.strand, a2.seq_begin, a2.seq_begin + (o2.end - o2.begin), o2.strand});
+            }
+        inf.readsGiven = 2 * n, inf.unambiguousPairs = samples.size();
+        check(cmb_pair_infer(samples.data(), samples.size(), &inf.inferred));
+        return inf;
+    }
     template <class Record>
     std::string samOfChunkPairedBest(const std::vector<Record>& mates1, const std::vector<Record>& mates2, const std::vector<const char*>& seqNames,
                                      uint32_t x, uint32_t minIdentity, uint32_t orientation, uint32_t maxFragSize, uint32_t minFragSize,
-                                     bool discordantAllowed, bool unmappedRecords, size_t& mappedPairs, size_t* deviceBatches = nullptr) {
+                                     bool discordantAllowed, bool unmappedRecords, size_t& mappedPairs, size_t* deviceBatches = nullptr,
+                                     const PairedEndInference* startFrom = nullptr) {
         if (mates1.size() != mates2.size()) throw std::runtime_error("the two read files do not hold the same number of reads");
         const uint32_t n = (uint32_t)mates1.size();
+        if (startFrom) x = 0; // (pairSingleEndedMatchesBest: no strata beyond the best one)
         uint32_t maxSupported = 0;
         for (; maxSupported < 13; maxSupported++) {
             uint32_t ns = 0, np = 0, crit[16];
@@ -409,6 +493,14 @@ class SearchStrategy {
             cmb_pair_best* p;
             ~Guard() { cmb_pair_best_destroy(p); }
         } guard{pb};
+        if (startFrom) {
+            if (startFrom->read2done.size() != n) throw std::runtime_error("the single-end results are those of another chunk");
+            for (uint32_t i = 0; i < n; i++) {
+                const typename PairedEndInference::Single &s1 = startFrom->single[0][i], &s2 = startFrom->single[1][i];
+                check(cmb_pair_best_seed(pb, i, s1.occ.data(), s1.aln.data(), s1.occ.size(), s1.ops.data(), s2.occ.data(), s2.aln.data(), s2.occ.size(),
+                                         s2.ops.data(), startFrom->read2done[i]));
+            }
+        }
         std::vector<cmb_pair_request> req(n ? n : 1);
         for (;;) {
             uint64_t nReq = 0;

@@ -286,3 +286,28 @@ def test_align_driver_paired_end(tmp_path):
     assert body2 == want2 and mapped2 > 0.6 * n
     flags2 = [int(ln.split("\t")[1]) for ln in body2.splitlines()]
     assert sum(1 for f in flags2 if f & 2) > n and any(f & 4 for f in flags2)
+    # without -O / -X / -N the parameters are inferred from the first chunk (single-end, the pairs whose mates both map unambiguously:
+    # parallel.cpp:236-312, :402-466), which is then paired from its single-end results (cmb_pair_best_seed); the other chunks as before
+    out3 = tmp_path / "o3.sam"
+    run = subprocess.run([exe, "-r", str(tmp_path / "idx"), "-f", str(tmp_path / "r1.fq"), "-F", str(tmp_path / "r2.fq"), "-o", str(out3),
+                          "-I", "95", "-x", "0", "-S", "columba", "-b", "120"], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+    import re
+    m = re.search(r"Found (\d+) unambiguous pairs while processing 240 reads", run.stderr)
+    assert m and int(m.group(1)) > 50, run.stderr
+    m = re.search(r"orientation FR, insert size ([0-9.]+) \+- ([0-9.]+), bounds \[(\d+), (\d+)\]", run.stderr)
+    assert m and 250 < float(m.group(1)) < 330 and 30 < float(m.group(2)) < 80 and int(m.group(4)) > 400, run.stderr
+    body3 = [ln for ln in out3.read_text().splitlines() if not ln.startswith("@")]
+    by = {}
+    for ln in body3:
+        by.setdefault(ln.split("\t")[0].split("/")[0], []).append(int(ln.split("\t")[1]))
+    assert len(by) == n
+    assert sum(1 for fl in by.values() if any(f & 2 for f in fl)) > 0.6 * n
+    # beyond the first chunk the records are those of the run with the same bounds given
+    lo, hi = int(m.group(3)), int(m.group(4))
+    out4 = tmp_path / "o4.sam"
+    run = subprocess.run([exe, "-r", str(tmp_path / "idx"), "-f", str(tmp_path / "r1.fq"), "-F", str(tmp_path / "r2.fq"), "-o", str(out4),
+                          "-I", "95", "-x", "0", "-S", "columba", "-b", "120", "-X", str(hi), "-N", str(lo)], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+    later = lambda path: [ln for ln in path.read_text().splitlines() if not ln.startswith("@") and int(ln.split("\t")[0][1:].split("/")[0]) >= 120]
+    assert later(out3) == later(out4) and len(later(out3)) > 300
