@@ -674,3 +674,61 @@ def test_requests_and_errors():
                 aln = np.array([(o.sid, o.sb, 0, 1, 1 if o.spans else 0, 0) for o in lst], dtype=ca.ALN_DTYPE)
                 pb.supply(0, m, s, k, occ, aln, np.array([400], np.uint16))
     pb.close()
+
+
+def _table_from(cut, occs):
+    """(mate, strand, k) -> list for every k: occs = [(mate, strand, begin, width, distance)], lists that grow with the distance"""
+    t = {}
+    for m in (0, 1):
+        for s in (0, 1):
+            for k in range(cut[m] + 1):
+                t[(m, s, k)] = sorted((Occ(b, w, d, s, m, [w << 2]) for (mm, ss, b, w, d) in occs if mm == m and ss == s and d <= k), key=Occ.key)
+    return t
+
+
+def _fixed_reads():
+    out = []
+    for m, seq in enumerate(("ACGTTGCAAC" * 10, "TTGACCAGTA" * 10)):
+        _, cs, rc, rq = ca.read_prepare(f"@pair/{m + 1}", seq, "I" * 100)
+        out.append((f"pair/{m + 1}", cs, rc, "I" * 100, "I" * 100))
+    return out
+
+
+def test_hand_checked_cases():
+    """a few pairs whose outcome follows from the reference's text by hand (100 bp mates, 95 % identity: cut-off 5, FR, fragments up to 600)"""
+    reads, cut = _fixed_reads(), [5, 5]
+
+    def run(occs, x=0, disc=True):
+        got, asked, _ = _run_library([(reads, cut, _table_from(cut, occs))], x, 95, 5, ca.ORIENTATION_FR, 600, 0, disc, True)
+        return [ln.split("\t") for ln in got[0][0].splitlines()], got[0][1], asked[0]
+
+    # 1. both mates match exactly, read 1 forward upstream of read 2 reverse: found in the very first stratum — only the two lists of
+    #    distance 0 that this combination needs are ever asked for, then (nothing found for the 2-1 combination) its two lists
+    lines, n_pairs, asked = run([(0, 0, 1000, 100, 0), (1, 1, 1300, 100, 0)])
+    assert n_pairs == 1 and [int(l[1]) for l in lines] == [99, 147] and lines[0][3] == "1001" and lines[0][8] == "400" and lines[1][8] == "-400"
+    assert lines[0][4] == lines[1][4] == "60" and all(k == 0 for _m, _s, k in asked) and len(asked) <= 4
+    # 2. the best pair costs 1 + 2 errors; a second placement of read 2 with 4 errors is not reported at x = 0
+    lines, n_pairs, asked = run([(0, 0, 1000, 100, 1), (1, 1, 1300, 100, 2), (1, 1, 1350, 100, 4)])
+    assert n_pairs == 1 and [l[11] for l in lines] == ["AS:i:1", "AS:i:2"] and max(k for _m, _s, k in asked) <= 3
+    # 3. two placements of the same total: both pairs reported, the first one primary, MAPQ of two candidates
+    lines, n_pairs, _ = run([(0, 0, 1000, 100, 1), (1, 1, 1300, 100, 1), (0, 0, 50_000, 100, 0), (1, 1, 50_300, 100, 2)])
+    assert n_pairs == 2 and [int(l[1]) & 256 for l in lines] == [0, 0, 256, 256] and {l[4] for l in lines} == {"3"}
+    # 4. the mates lie on different sequences: no concordant pair; discordant pairs are allowed -> one pair without the "proper" bit and a
+    #    template length of 0; not allowed -> each mate's best alignments as unpaired records
+    occs = [(0, 0, 1000, 100, 0), (1, 1, 60_000, 100, 1)]
+    lines, n_pairs, _ = run(occs)
+    assert n_pairs == 1 and [int(l[1]) & 2 for l in lines] == [0, 0] and lines[0][8] == "0" and lines[0][6] == "chr2_alt"
+    lines, n_pairs, _ = run(occs, disc=False)
+    assert n_pairs == 0 and [int(l[1]) for l in lines] == [65, 129]
+    # 5. read 2 maps nowhere, read 1 exactly: read 1's record says "mate unmapped", read 2's is the unmapped record with the mate's data
+    lines, n_pairs, _ = run([(0, 0, 1000, 100, 0)])
+    assert n_pairs == 0 and [int(l[1]) for l in lines] == [73, 133]
+    # 6. ... but with read 1's only hit at 2 errors BOTH come out unmapped: pairDiscordantlyBest has looked at every stratum by itself
+    #    (mapStratum), and findBestAlignments then only asks the strata 1, 3, 5 whether THEY hold something (hasUpdate, :674-681)
+    lines, n_pairs, _ = run([(0, 0, 1000, 100, 2)])
+    assert n_pairs == 0 and [int(l[1]) for l in lines] == [77, 141]
+    lines, n_pairs, _ = run([(0, 0, 1000, 100, 3)])
+    assert n_pairs == 0 and [int(l[1]) for l in lines] == [73, 133] and lines[0][11] == "AS:i:3"
+    # 7. the mates are too far apart for the fragment bound: discordant, with the real template length
+    lines, n_pairs, _ = run([(0, 0, 1000, 100, 0), (1, 1, 5000, 100, 0)])
+    assert n_pairs == 1 and [int(l[1]) for l in lines] == [97, 145] and lines[0][8] == "4100"
