@@ -721,7 +721,19 @@ struct cmb_move_batch {
     uint64_t cnts[CMB_CNT_MAX];
     std::vector<std::pair<const char*, float>> times;
     bool done = false;
+    // the occurrence records of a slice travel to the host on a stream of their own while the next slice is matched
+    hipStream_t copyStream = nullptr;
+    hipEvent_t outReady = nullptr, copyDone = nullptr;
+    bool copyPending = false;
+    void waitForCopies() {
+        if (copyPending) (void)hipStreamSynchronize(copyStream);
+        copyPending = false;
+    }
     ~cmb_move_batch() {
+        waitForCopies(); // (the records land in page-locked memory this object frees)
+        if (copyStream) (void)hipStreamDestroy(copyStream);
+        if (outReady) (void)hipEventDestroy(outReady);
+        if (copyDone) (void)hipEventDestroy(copyDone);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -786,6 +798,9 @@ extern "C" int cmb_move_batch_create(cmb_move_index* idx, const cmb_strategy* st
         for (auto& o : b->hostOffs) o -= offs[0];
         b->hostReads.assign((const uint8_t*)seqs + offs[0], (const uint8_t*)seqs + offs[n_reads]);
         MV_HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+        MV_HIPCHK(hipStreamCreateWithFlags(&b->copyStream, hipStreamNonBlocking));
+        MV_HIPCHK(hipEventCreateWithFlags(&b->outReady, hipEventDisableTiming));
+        MV_HIPCHK(hipEventCreateWithFlags(&b->copyDone, hipEventDisableTiming));
         b->reads.upload(b->hostReads.data(), b->hostReads.size());
         b->offs.upload(b->hostOffs.data(), n_reads + 1);
         if (max_distance > 0) { // (per-read scratch is sized per slice, at the first run)
@@ -841,6 +856,7 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi);
 extern "C" int cmb_move_batch_run(cmb_move_batch* b) {
     if (!b) return failWith(CMB_ERR_INVALID, "null argument");
     b->done = false;
+    b->waitForCopies(); // (a run that failed half-way may have left one behind)
     b->times.clear();
     memset(b->cnts, 0, sizeof(b->cnts));
     b->occOffs.assign((size_t)b->nReads + 1, 0);
@@ -853,8 +869,12 @@ extern "C" int cmb_move_batch_run(cmb_move_batch* b) {
     if (b->k == 0) slice = b->nReads ? b->nReads : 1;
     for (uint32_t lo = 0; lo < b->nReads; lo += slice) {
         const int rc = runSlice(b, lo, std::min<uint64_t>((uint64_t)lo + slice, b->nReads));
-        if (rc != CMB_OK) return rc;
+        if (rc != CMB_OK) {
+            b->waitForCopies();
+            return rc;
+        }
     }
+    b->waitForCopies();
     b->done = true;
     return CMB_OK;
 }
@@ -1293,6 +1313,9 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
             if (nNaiveKept)
                 hipLaunchKernelGGL(k_mvs_occ_keys, dim3(gridFor(2 * nReads)), dim3(256), 0, s, b->naiveOut.p, b->naiveOff.p, 2 * nReads, b->keysA.p + totalPos,
                                    b->vals.p + totalPos, perStrand);
+            // (the previous slice's records may still be on their way out of b->out: this stream waits for them before the buffer is
+            // written or enlarged — sortAndFilter synchronises the stream before it allocates)
+            if (b->copyPending) MV_HIPCHK(hipStreamWaitEvent(s, b->copyDone, 0));
             sortAndFilter(totalPos + nNaiveKept, perStrand ? 2 * nReads : nReads, b->out, nOut);
             if (perStrand) { // per read again: the two strands of a read are neighbouring groups
                 if (b->rsOff.n < (size_t)2 * nReads + 1) b->rsOff.alloc((size_t)2 * nReads + 1);
@@ -1332,9 +1355,16 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi) {
         MV_HIPCHK(hipMemcpyAsync(hc64, b->counters.p, sizeof(hc64), hipMemcpyDeviceToHost, s));
         static_assert(sizeof(cmb_move_occ) == sizeof(MoveOccOut), "cmb_move_occ layout");
         const size_t occBase = b->occs.size();
+        if (occBase + nOut > b->occs.cap) b->waitForCopies(); // (the page-locked vector moves when it grows)
         b->occs.resize(occBase + nOut);
         std::vector<uint64_t> sliceOffs((size_t)nReads + 1, 0);
-        if (nOut) MV_HIPCHK(hipMemcpyAsync(b->occs.data() + occBase, b->out.p, nOut * sizeof(MoveOccOut), hipMemcpyDeviceToHost, s));
+        if (nOut) { // on the copy stream, behind everything this slice has queued: the next slice starts while the records travel
+            MV_HIPCHK(hipEventRecord(b->outReady, s));
+            MV_HIPCHK(hipStreamWaitEvent(b->copyStream, b->outReady, 0));
+            MV_HIPCHK(hipMemcpyAsync(b->occs.data() + occBase, b->out.p, nOut * sizeof(MoveOccOut), hipMemcpyDeviceToHost, b->copyStream));
+            MV_HIPCHK(hipEventRecord(b->copyDone, b->copyStream));
+            b->copyPending = true;
+        }
         if (totalPos) MV_HIPCHK(hipMemcpyAsync(sliceOffs.data(), b->readOff.p, ((size_t)nReads + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         MV_HIPCHK(hipStreamSynchronize(s));
         for (uint32_t i = 0; i <= nReads; i++) b->occOffs[(size_t)lo + i] = occBase + sliceOffs[i];
