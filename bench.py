@@ -162,6 +162,21 @@ def move_source_digest() -> str:
     return h.hexdigest()[:16]
 
 
+def serial_move_table(batch, n: int = 1):
+    """kernel table of a b-move batch: extra steps with the concurrent halves of the chunk run one after the other
+    (CMB_MOVE_SERIAL_SUBBATCHES), so that every kernel has the device to itself; the median per kernel group"""
+    os.environ["CMB_MOVE_SERIAL_SUBBATCHES"] = "1"
+    runs = []
+    try:
+        for _ in range(n):
+            batch.run()
+            torch.cuda.synchronize()
+            runs.append(dict(batch.timings()))
+    finally:
+        del os.environ["CMB_MOVE_SERIAL_SUBBATCHES"]
+    return {kn: float(np.median([r.get(kn, 0.0) for r in runs])) for kn in runs[0]}
+
+
 def load_rlc_traffic(reads, read_len, k):
     """HBM bytes per step of the b-move frontier kernels (k_mvs_start / k_mvs_pass / k_mvs_finish) from tools/profile_rlc.sh's PMC passes
     (profiles/*_rlc_pmc_traffic.json: the difference of a two-step and a one-step run, so that the pool-sizing warm-up cancels out), or
@@ -344,6 +359,8 @@ def main_rlc(args):
     elapsed = time.perf_counter() - tstart
     steps = max(args.steps, 1)
     per_rank_ms = [round(elapsed / steps * 1e3, 3)]
+    concurrent = {kn: round(v / steps, 3) for kn, v in kern.items()}  # busy ms per step, summed over the chunk's concurrent halves
+    serial = serial_move_table(batch, 1)
     occ, occ_offs, cnt = batch.results()
     total_occ = len(occ)
     if dist is not None:
@@ -363,7 +380,7 @@ def main_rlc(args):
         dist.barrier()
         dist.destroy_process_group()
         return
-    avg = {kn: v / steps for kn, v in kern.items()}
+    avg = serial
     dominant = max(avg, key=avg.get)
     # algorithmic bytes: one move-table row fetched = 16 B (an aligned 16-byte row here; the reference reads the
     # same 16 bytes with one unaligned 128-bit load per row access, moverepr.cpp:36-47).  Rows are counted on the device where
@@ -382,6 +399,10 @@ def main_rlc(args):
                 "traffic_note": "GB per step of the frontier kernels, 2 x FETCH_SIZE + WRITE_SIZE (separate rocprofv3 --pmc passes of this command, two-step "
                                 "minus one-step run: tools/profile_rlc.sh -> profiles/*_rlc_pmc_traffic.json)",
                 "avg_launch_ms": round(avg[dominant], 3),
+                "timing_note": "kernel times (HIP events on the batch's streams) are those of one extra step with the chunk's halves run one after "
+                               "the other; in the timed steps the halves overlap (busy ms per step there: see concurrent_ms)",
+                "concurrent_ms": concurrent,
+                "overlap": {"serial_sum_ms": round(sum(avg.values()), 3), "step_over_serial_sum": round(elapsed / steps * 1e3 / max(sum(avg.values()), 1e-9), 4)},
                 "unit_note": "16 B per move-table row fetched (TABLE_ROWS counted on the device); "
                              f"{cnt['DFS_TABLE_ROWS'] / max(cnt['DFS_EXPANSIONS'], 1):.1f} rows per node expansion of the search",
                 "per_kernel": per_kernel}
@@ -542,8 +563,9 @@ def rlc_leg(args, dev, local):
             kern[kname] = kern.get(kname, 0.0) + ms
     torch.cuda.synchronize()
     dt = time.perf_counter() - ts
+    concurrent = {kn: round(v / steps, 3) for kn, v in kern.items()}
+    avg = serial_move_table(batch, 1)  # (the chunk's halves one after the other: every kernel has the device to itself)
     occ, occ_offs, cnt = batch.results()
-    avg = {kn: v / steps for kn, v in kern.items()}
     dominant = max(avg, key=avg.get)
     alg = {"k_partition": 16.0 * (cnt["TABLE_ROWS"] - cnt["DFS_TABLE_ROWS"]), "k_dfs": 16.0 * cnt["DFS_TABLE_ROWS"]}
     achieved = alg.get(dominant, 0.0) / (avg[dominant] * 1e-3) / 1e9 if avg[dominant] > 0 else 0.0
@@ -577,7 +599,9 @@ def rlc_leg(args, dev, local):
                          "traffic_source": load_rlc_traffic(R, L, k)[1] if dominant == "k_dfs" else None, "kernel_src_sha": move_source_digest(),
                          "avg_launch_ms": round(avg[dominant], 3),
                          "unit_note": f"16 B per move-table row fetched; {cnt['DFS_TABLE_ROWS'] / max(cnt['DFS_EXPANSIONS'], 1):.1f} rows per node expansion",
-                         "per_kernel_ms": {kn: round(v, 3) for kn, v in avg.items()}},
+                         "per_kernel_ms": {kn: round(v, 3) for kn, v in avg.items()}, "concurrent_ms": concurrent,
+                         "overlap": {"serial_sum_ms": round(sum(avg.values()), 3),
+                                     "step_over_serial_sum": round(dt / steps * 1e3 / max(sum(avg.values()), 1e-9), 4)}},
             "cpu_baseline": cpu}
 
 

@@ -14,6 +14,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace cmb {
@@ -729,7 +730,13 @@ struct cmb_move_batch {
         if (copyPending) (void)hipStreamSynchronize(copyStream);
         copyPending = false;
     }
+    // A large chunk is matched as two halves side by side, each a batch of its own (pools, streams, host thread): the frontier search of
+    // one half is a chain of dependent round trips that leaves line rate unused, which the other half's partitioning, locate and filter
+    // kernels take (the FM-index batches do the same with three sub-batches).  The parent holds no device memory.
+    std::vector<cmb_move_batch*> subs;
+    std::vector<uint32_t> subLo;
     ~cmb_move_batch() {
+        for (cmb_move_batch* c : subs) delete c;
         waitForCopies(); // (the records land in page-locked memory this object frees)
         if (copyStream) (void)hipStreamDestroy(copyStream);
         if (outReady) (void)hipEventDestroy(outReady);
@@ -751,8 +758,40 @@ static int ensureKmerTable(cmb_move_index* ix, uint32_t ws) {
     return CMB_OK;
 }
 
+static int moveBatchCreateOne(cmb_move_index* idx, const cmb_strategy* st, uint32_t max_distance, uint32_t kmer_size, const char* seqs,
+                              const uint64_t* offs, uint32_t n_reads, cmb_move_batch** out);
+
 extern "C" int cmb_move_batch_create(cmb_move_index* idx, const cmb_strategy* st, uint32_t max_distance, uint32_t kmer_size, const char* seqs,
                                      const uint64_t* offs, uint32_t n_reads, cmb_move_batch** out) {
+    if (!idx || !st || !offs || !out || (!seqs && n_reads)) return failWith(CMB_ERR_INVALID, "null argument");
+    // two halves from 2^19 reads (two full slices at 5 errors and more); CMB_MOVE_SUBBATCHES=n overrides (1: one batch)
+    // (measured on the configs[4] stand-in, 10^6 x 250 bp at 6 errors: 1 / 2 / 3 parts 737 / 675 / 668 ms per step; four parts of 2^18 reads
+    // in flight ran out of the 288 GB — two halves hold their pools twice, so they are only taken with most of the HBM free)
+    uint32_t S = max_distance > 0 && n_reads >= (1u << 19) ? 2u : 1u;
+    if (S > 1) {
+        size_t freeB = 0, totalB = 0;
+        if (hipSetDevice(idx->device) != hipSuccess || hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < (size_t)160 << 30) S = 1;
+    }
+    if (const char* e = getenv("CMB_MOVE_SUBBATCHES")) S = max_distance > 0 ? (uint32_t)std::min(4, std::max(1, atoi(e))) : 1u;
+    if (S > n_reads) S = 1;
+    if (S == 1) return moveBatchCreateOne(idx, st, max_distance, kmer_size, seqs, offs, n_reads, out);
+    if (n_reads >= (1u << 23)) return failWith(CMB_ERR_UNSUPPORTED, "2^23 reads and more per b-move batch (24-bit read numbers in the filter keys)");
+    std::unique_ptr<cmb_move_batch> parent(new cmb_move_batch());
+    parent->ix = idx, parent->k = max_distance, parent->nReads = n_reads, parent->metric = st->metric, parent->kmerSize = kmer_size;
+    for (uint32_t j = 0; j < S; j++) {
+        const uint32_t lo = (uint32_t)((uint64_t)n_reads * j / S), hi = (uint32_t)((uint64_t)n_reads * (j + 1) / S);
+        cmb_move_batch* c = nullptr;
+        const int rc = moveBatchCreateOne(idx, st, max_distance, kmer_size, seqs, offs + lo, hi - lo, &c); // (offsets are rebased there)
+        if (rc != CMB_OK) return rc;
+        parent->subs.push_back(c);
+        parent->subLo.push_back(lo);
+    }
+    *out = parent.release();
+    return CMB_OK;
+}
+
+static int moveBatchCreateOne(cmb_move_index* idx, const cmb_strategy* st, uint32_t max_distance, uint32_t kmer_size, const char* seqs,
+                              const uint64_t* offs, uint32_t n_reads, cmb_move_batch** out) {
     if (!idx || !st || !offs || !out || (!seqs && n_reads)) return failWith(CMB_ERR_INVALID, "null argument");
     if (!idx->hasLocate) return failWith(CMB_ERR_INVALID, "this index was created without the locate arrays");
     if (n_reads >= (1u << 23)) return failWith(CMB_ERR_UNSUPPORTED, "2^23 reads and more per b-move batch (24-bit read numbers in the filter keys)");
@@ -853,8 +892,52 @@ static int runSlice(cmb_move_batch* b, uint32_t lo, uint32_t hi);
 // The pools of the frontier search hold up to ~100 KB per read at k = 6 / 250 bp (600 final-column records of 96 bytes, 90
 // contexts of 512 bytes): a large chunk is matched as consecutive SLICES that reuse one set of pools (CMB_MOVE_SLICE=n reads per
 // slice; results and counters are those of the whole chunk).
+static int moveBatchRunOne(cmb_move_batch* b);
+
 extern "C" int cmb_move_batch_run(cmb_move_batch* b) {
     if (!b) return failWith(CMB_ERR_INVALID, "null argument");
+    if (b->subs.empty()) return moveBatchRunOne(b);
+    b->done = false;
+    std::vector<int> rc(b->subs.size(), CMB_OK);
+    std::vector<std::string> err(b->subs.size());
+    // CMB_MOVE_SERIAL_SUBBATCHES: one part after the other — every kernel has the device to itself, which is what per-kernel timings want
+    // (bench.py times its steps concurrently and takes the kernel table from extra serial steps, as for the FM-index batches)
+    if (getenv("CMB_MOVE_SERIAL_SUBBATCHES")) {
+        for (size_t j = 0; j < b->subs.size(); j++) {
+            rc[j] = moveBatchRunOne(b->subs[j]);
+            if (rc[j] != CMB_OK) return rc[j];
+        }
+    } else {
+        std::vector<std::thread> th;
+        for (size_t j = 0; j < b->subs.size(); j++)
+            th.emplace_back([&, j] {
+                rc[j] = moveBatchRunOne(b->subs[j]);
+                if (rc[j] != CMB_OK) err[j] = cmb_last_error(); // (the message lives in the worker's thread-local storage)
+            });
+        for (auto& t : th) t.join();
+    }
+    for (size_t j = 0; j < rc.size(); j++)
+        if (rc[j] != CMB_OK)
+            return failWith(rc[j], err[j] + (err[j].find("out of memory") != std::string::npos
+                                                 ? " (the chunk is matched as " + std::to_string(b->subs.size()) + " concurrent parts with pools of their own: "
+                                                   "CMB_MOVE_SUBBATCHES=1 matches it as one batch)"
+                                                 : ""));
+    memset(b->cnts, 0, sizeof(b->cnts));
+    b->times.clear();
+    for (const cmb_move_batch* c : b->subs) {
+        for (int i = 0; i < CMB_CNT_MAX; i++) b->cnts[i] += c->cnts[i];
+        for (const auto& t : c->times) { // busy time per kernel group, summed over the halves (they overlap on the device)
+            bool found = false;
+            for (auto& u : b->times)
+                if (!strcmp(u.first, t.first)) u.second += t.second, found = true;
+            if (!found) b->times.push_back(t);
+        }
+    }
+    b->done = true;
+    return CMB_OK;
+}
+
+static int moveBatchRunOne(cmb_move_batch* b) {
     b->done = false;
     b->waitForCopies(); // (a run that failed half-way may have left one behind)
     b->times.clear();
@@ -867,6 +950,10 @@ extern "C" int cmb_move_batch_run(cmb_move_batch* b) {
     uint32_t slice = b->k >= 5 ? (1u << 18) : b->k >= 3 ? (1u << 19) : (1u << 20);
     if (getenv("CMB_MOVE_SLICE")) slice = (uint32_t)std::max(1, atoi(getenv("CMB_MOVE_SLICE")));
     if (b->k == 0) slice = b->nReads ? b->nReads : 1;
+    if (b->nReads > slice) { // slices of equal size (a short last slice runs its levels on a mostly empty device)
+        const uint32_t nSl = (b->nReads + slice - 1) / slice;
+        slice = (b->nReads + nSl - 1) / nSl;
+    }
     for (uint32_t lo = 0; lo < b->nReads; lo += slice) {
         const int rc = runSlice(b, lo, std::min<uint64_t>((uint64_t)lo + slice, b->nReads));
         if (rc != CMB_OK) {
@@ -1384,11 +1471,27 @@ extern "C" int cmb_move_batch_result_size(const cmb_move_batch* b, uint64_t* n_o
     if (!b || !n_occ) return failWith(CMB_ERR_INVALID, "null argument");
     if (!b->done) return failWith(CMB_ERR_INVALID, "batch has not been run");
     *n_occ = b->occs.size();
+    for (const cmb_move_batch* c : b->subs) *n_occ += c->occs.size();
     return CMB_OK;
 }
 extern "C" int cmb_move_batch_results(const cmb_move_batch* b, cmb_move_occ* out, uint64_t out_cap, uint64_t* out_offs, uint64_t* counters) {
     if (!b) return failWith(CMB_ERR_INVALID, "null argument");
     if (!b->done) return failWith(CMB_ERR_INVALID, "batch has not been run");
+    if (!b->subs.empty()) { // the halves' lists one after the other, offsets rebased
+        uint64_t total = 0;
+        for (const cmb_move_batch* c : b->subs) total += c->occs.size();
+        if (total > out_cap) return failWith(CMB_ERR_OVERFLOW, "output buffer too small");
+        uint64_t base = 0;
+        for (size_t j = 0; j < b->subs.size(); j++) {
+            const cmb_move_batch* c = b->subs[j];
+            if (out && !c->occs.empty()) memcpy(out + base, c->occs.data(), c->occs.size() * sizeof(cmb_move_occ));
+            if (out_offs)
+                for (uint32_t i = 0; i <= c->nReads; i++) out_offs[(size_t)b->subLo[j] + i] = base + c->occOffs[i];
+            base += c->occs.size();
+        }
+        if (counters) memcpy(counters, b->cnts, sizeof(b->cnts));
+        return CMB_OK;
+    }
     if (b->occs.size() > out_cap) return failWith(CMB_ERR_OVERFLOW, "output buffer too small");
     if (out && !b->occs.empty()) memcpy(out, b->occs.data(), b->occs.size() * sizeof(cmb_move_occ));
     if (out_offs) memcpy(out_offs, b->occOffs.data(), b->occOffs.size() * sizeof(uint64_t));
@@ -1398,12 +1501,14 @@ extern "C" int cmb_move_batch_results(const cmb_move_batch* b, cmb_move_occ* out
 extern "C" int cmb_move_batch_filter_per_strand(cmb_move_batch* b, int on) {
     if (!b) return failWith(CMB_ERR_INVALID, "null argument");
     b->perStrand = on != 0;
+    for (cmb_move_batch* c : b->subs) c->perStrand = on != 0;
     return CMB_OK;
 }
 extern "C" int cmb_move_batch_want_alignments(cmb_move_batch* b, int on) {
     if (!b) return failWith(CMB_ERR_INVALID, "null argument");
     if (on && !b->ix->textIndex) return failWith(CMB_ERR_INVALID, "alignments need the text beside the index (cmb_move_attach_text)");
     b->wantAln = on != 0;
+    for (cmb_move_batch* c : b->subs) c->wantAln = on != 0;
     return CMB_OK;
 }
 // as cmb_batch_alignments: one record per occurrence of cmb_move_batch_results, CIGAR runs (length << 2 | op, op 0 M / 1 I / 2 D) in a pool
@@ -1411,19 +1516,24 @@ extern "C" int cmb_move_batch_alignments(const cmb_move_batch* b, cmb_aln* out, 
     if (!b) return failWith(CMB_ERR_INVALID, "null argument");
     if (!b->done) return failWith(CMB_ERR_INVALID, "batch has not been run");
     if (!b->wantAln) return failWith(CMB_ERR_INVALID, "alignments were not requested (cmb_move_batch_want_alignments)");
-    const uint64_t total = b->hAlnRec.size();
-    uint64_t ops = 0;
-    for (const uint4& r : b->hAlnRec) ops += r.z;
+    std::vector<const cmb_move_batch*> parts(b->subs.begin(), b->subs.end()); // (the halves' records one after the other, as their occurrences)
+    if (parts.empty()) parts.push_back(b);
+    uint64_t total = 0, ops = 0;
+    for (const cmb_move_batch* c : parts) {
+        total += c->hAlnRec.size();
+        for (const uint4& r : c->hAlnRec) ops += r.z;
+    }
     if (n_ops) *n_ops = ops;
     if (cap < total || ops_cap < ops) return failWith(CMB_ERR_OVERFLOW, "output buffer too small");
-    uint64_t po = 0;
-    for (uint64_t i = 0; i < total; i++) {
-        const uint4& r = b->hAlnRec[i];
-        out[i] = cmb_aln{r.x, r.y, po, (uint16_t)r.z, (uint16_t)r.w};
-        const uint16_t* src = b->hAlnOps.data() + i * b->alnStride;
-        for (uint32_t j = 0; j < r.z; j++) cigar_ops[po + j] = src[r.z - 1 - j]; // (stored end to begin)
-        po += r.z;
-    }
+    uint64_t po = 0, at = 0;
+    for (const cmb_move_batch* c : parts)
+        for (uint64_t i = 0; i < c->hAlnRec.size(); i++, at++) {
+            const uint4& r = c->hAlnRec[i];
+            out[at] = cmb_aln{r.x, r.y, po, (uint16_t)r.z, (uint16_t)r.w};
+            const uint16_t* src = c->hAlnOps.data() + i * c->alnStride;
+            for (uint32_t j = 0; j < r.z; j++) cigar_ops[po + j] = src[r.z - 1 - j]; // (stored end to begin)
+            po += r.z;
+        }
     return CMB_OK;
 }
 extern "C" int cmb_move_batch_timings(const cmb_move_batch* b, const char** names, float* ms, uint32_t cap) {
@@ -1446,7 +1556,9 @@ extern "C" int cmb_move_match_batch(cmb_move_index* idx, const cmb_strategy* st,
     std::unique_ptr<cmb_move_batch> guard(b);
     rc = cmb_move_batch_run(b);
     if (rc != CMB_OK) return rc;
-    if (needed) *needed = b->occs.size();
-    if (b->occs.size() > out_cap) return failWith(CMB_ERR_OVERFLOW, "output buffer too small (needed holds the required number of records)");
+    uint64_t nOcc = 0;
+    (void)cmb_move_batch_result_size(b, &nOcc);
+    if (needed) *needed = nOcc;
+    if (nOcc > out_cap) return failWith(CMB_ERR_OVERFLOW, "output buffer too small (needed holds the required number of records)");
     return cmb_move_batch_results(b, out, out_cap, out_offs, counters);
 }

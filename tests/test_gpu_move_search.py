@@ -397,3 +397,33 @@ def test_bmove_read_pairs_in_best_mode(sworld):
     assert text == want and mapped == mapped_fm and mapped > 0.85 * n and batches <= 80
     flags = [int(ln.split("\t")[1]) for ln in text.splitlines()]
     assert sum(1 for f in flags if f & 2) >= 2 * 0.8 * n
+
+
+@pytest.mark.parametrize("halves", [2, 3])
+def test_bmove_concurrent_halves(sworld, monkeypatch, halves):
+    """A large chunk is matched as concurrent halves, each a batch of its own (from 2^19 reads; CMB_MOVE_SUBBATCHES forces it here): occurrences,
+    offsets, counters and alignments are those of the one batch"""
+    ca = sworld["ca"]
+    g = sworld["g"]
+    starts = np.array([0, 250_000, 640_000, len(g)], dtype=np.uint64)
+    sworld["dev"].attach_text(sworld["text"], starts)
+    reads = _reads(g, 4, 3001, 150, seed=77) + [b"N" * 150, g[:150].tobytes()]
+    st = ca.SearchStrategy("columba", "edit", "dynamic")
+
+    def run():
+        mb = ca.MoveBatch(sworld["dev"], st, 4, reads=reads, kmer_size=8)
+        mb.want_alignments()
+        mb.filter_per_strand()
+        mb.run()
+        occ, offs, cnt = mb.results()
+        aln, ops = mb.alignments()
+        t = mb.timings()
+        mb.close()
+        return occ, offs, cnt, aln, ops, t
+
+    monkeypatch.setenv("CMB_MOVE_SUBBATCHES", "1")
+    a = run()
+    monkeypatch.setenv("CMB_MOVE_SUBBATCHES", str(halves))
+    b = run()
+    assert len(a[0]) > 3000 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and set(a[5]) == set(b[5])

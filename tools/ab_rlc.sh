@@ -10,6 +10,6 @@ for SET in "$@"; do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r=d['roofline']
-print(round(d['value']/1e3,1),'k reads/s', d['ms_per_step'],'ms/step | ms:', r.get('per_kernel_ms'), '| frac', r['frac'], '| occurrences', d['config'].get('occurrences'))
+print(round(d['value']/1e3,1),'k reads/s', d['ms_per_step'],'ms/step | serial ms:', {k:v['ms'] for k,v in r.get('per_kernel',{}).items()}, '| frac', r['frac'], '| overlap', r.get('overlap'))
 "
 done
