@@ -5,7 +5,7 @@ set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wno-unused-variable -DCMB_STAGE_STATS \
-    -Iinclude -o /tmp/libcolumba_amd_sstats.so columba_amd/csrc/columba_amd.hip columba_amd/csrc/move_backend.hip columba_amd/csrc/pair_sam.hip
+    -Iinclude -o /tmp/libcolumba_amd_sstats.so columba_amd/csrc/columba_amd.hip columba_amd/csrc/move_backend.hip columba_amd/csrc/pair_sam.hip columba_amd/csrc/pair_best.hip
 python3 - "$@" <<'PY'
 import ctypes as C, sys, numpy as np, torch
 sys.path.insert(0, ".")
