@@ -8,7 +8,7 @@ NAME=$1; UNIT=$2; shift; shift
 mkdir -p $R/columba_amd/_variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-variable "$@" -c -o $R/columba_amd/_variants/${UNIT}_$NAME.o $R/columba_amd/csrc/$UNIT.hip 2>/dev/null
 OBJS=""
-for U in columba_amd move_backend pair_sam; do
+for U in columba_amd move_backend pair_sam pair_best; do
   if [ $U = $UNIT ]; then OBJS="$OBJS $R/columba_amd/_variants/${UNIT}_$NAME.o"; else OBJS="$OBJS $R/columba_amd/_build/$U.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/columba_amd/_variants/lib_$NAME.so $OBJS
