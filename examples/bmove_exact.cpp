@@ -1,7 +1,7 @@
 // Exact matching of a chunk of reads on the run-length compressed (b-move) index through the C++ adapter — the k = 0 branch of
 // SearchStrategy::matchApproxAllMap (reference src/searchstrategy.cpp:499-510) — followed by a walk that exercises the
 // extension and locate calls with the reference's method names.
-//   usage: bmove_exact <index base> <reads file: one sequence per line> [k [strategy [k-mer size [text file [best <x> <identity>]]]]]
+//   usage: bmove_exact <index base> <reads file: one sequence per line> [k [strategy [k-mer size [text file [best <x> <identity> | pairs <mates file> <x> <identity> <max fragment>]]]]]
 // with k > 0: the approximate search of SearchStrategy::matchApproxAllMap (searchstrategy.cpp:495-535, RLC flavour) instead
 // prints:  <read#> <begin> <end> <distance> <strand>      (stdout)
 //          nodes <NODE_COUNTER>; walk <depth> <width> <positions found>   (stderr)
@@ -33,6 +33,18 @@ int main(int argc, char** argv) {
             SearchStrategy strategy(index, argv[4], CMB_PARTITION_DYNAMIC, CMB_METRIC_EDIT, atoi(argv[5]));
             std::vector<std::string> ids, quals;
             for (size_t i = 0; i < chunk.size(); i++) ids.push_back("r" + std::to_string(i)), quals.push_back(std::string(chunk[i].size(), 'I'));
+            if (argc > 11 && std::string(argv[7]) == "pairs") { // ... pairs <mates file> <x> <min identity> <max fragment>: read pairs in BEST mode (FR)
+                std::vector<std::string> mates, ids2, quals2;
+                std::ifstream mf(argv[8]);
+                while (std::getline(mf, line)) mates.push_back(line);
+                for (size_t i = 0; i < mates.size(); i++) ids2.push_back("r" + std::to_string(i) + "/2"), quals2.push_back(std::string(mates[i].size(), 'I'));
+                for (size_t i = 0; i < ids.size(); i++) ids[i] += "/1";
+                size_t mapped = 0;
+                std::cout << strategy.samOfChunkPairedBest(ids, chunk, quals, ids2, mates, quals2, {"seq0"}, (uint32_t)atoi(argv[9]), (uint32_t)atoi(argv[10]),
+                                                           CMB_ORIENTATION_FR, (uint32_t)atoi(argv[11]), 0, true, true, mapped);
+                std::cerr << "mapped pairs " << mapped << "\n";
+                return 0;
+            }
             if (argc > 9 && std::string(argv[7]) == "best") { // ... best <x> <min identity>: BEST (+x strata) mode, the reference's default
                 size_t nMapped = 0;
                 std::cout << strategy.samOfChunkBest(ids, chunk, quals, {"seq0"}, (uint32_t)atoi(argv[8]), (uint32_t)atoi(argv[9]), true, false, nMapped);

@@ -28,6 +28,7 @@
 
 #include <cstdint>
 #include <fstream>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -291,6 +292,93 @@ class SearchStrategy {
         cmb_best* r = nullptr;
         check(cmb_move_match_best(index.handle(), h, x, minIdentity, kmerSize, buf.data(), off.data(), (uint32_t)reads.size(), &r));
         return samOfBest(r, buf, off, recs, seqNames, unmappedRecords, xaTag, nMapped);
+    }
+    // Read pairs in BEST (+x strata) mode on this flavour (matchApproxPairedEndBestPlusX, searchstrategy.cpp:1091-1179): the pairs walk through
+    // their strata together (cmb_pair_best_*); every round the lists the unfinished pairs wait for come from one b-move batch per (mate,
+    // distance) over the reads that ask — ALL mode, every strand filtered by itself, with alignments.  Needs BMove::attachText.
+    // orientation: CMB_ORIENTATION_*.
+    std::string samOfChunkPairedBest(const std::vector<std::string>& ids1, const std::vector<std::string>& reads1, const std::vector<std::string>& quals1,
+                                     const std::vector<std::string>& ids2, const std::vector<std::string>& reads2, const std::vector<std::string>& quals2,
+                                     const std::vector<std::string>& seqNames, uint32_t x, uint32_t minIdentity, uint32_t orientation,
+                                     uint32_t maxFragSize, uint32_t minFragSize, bool discordantAllowed, bool unmappedRecords, size_t& mappedPairs) {
+        if (reads1.size() != reads2.size()) throw std::runtime_error("the two read files do not hold the same number of reads");
+        const uint32_t n = (uint32_t)reads1.size();
+        uint32_t maxSupported = 0;
+        for (; maxSupported < 13; maxSupported++) {
+            uint32_t ns = 0, np = 0, crit[16];
+            if (cmb_strategy_describe(h, maxSupported + 1, &ns, &np, crit, 16) != CMB_OK || ns == 0) break;
+        }
+        const std::vector<std::string>* R[2] = {&reads1, &reads2};
+        const std::vector<std::string>* I[2] = {&ids1, &ids2};
+        const std::vector<std::string>* Q[2] = {&quals1, &quals2};
+        std::vector<std::vector<char>> store;
+        std::vector<cmb_pair_read> rd[2];
+        for (int m = 0; m < 2; m++)
+            for (uint32_t i = 0; i < n; i++) {
+                const std::string &id = (*I[m])[i], &seq = (*R[m])[i], &q = (*Q[m])[i];
+                const size_t at = store.size();
+                store.emplace_back(id.size() + 1), store.emplace_back(seq.size() + 1), store.emplace_back(seq.size() + 1), store.emplace_back(q.size() + 1);
+                check(cmb_read_prepare(id.c_str(), seq.c_str(), q.c_str(), store[at].data(), store[at + 1].data(), store[at + 2].data(), store[at + 3].data()));
+                rd[m].push_back(cmb_pair_read{store[at].data(), store[at + 1].data(), store[at + 2].data(), q.c_str(), store[at + 3].data(), nullptr, 0});
+            }
+        const cmb_pair_params prm = {orientation, maxFragSize, minFragSize, discordantAllowed ? 1 : 0, unmappedRecords ? 1 : 0};
+        cmb_pair_best* pb = nullptr;
+        check(cmb_pair_best_create(&prm, x, minIdentity, maxSupported, CMB_METRIC_EDIT, cmb_move_text_index(index.handle()), n, rd[0].data(), rd[1].data(), &pb));
+        struct Guard {
+            cmb_pair_best* p;
+            ~Guard() { cmb_pair_best_destroy(p); }
+        } guard{pb};
+        std::vector<cmb_pair_request> req(n ? n : 1);
+        for (;;) {
+            uint64_t nReq = 0;
+            check(cmb_pair_best_advance(pb, req.data(), req.size(), &nReq));
+            if (nReq == 0) break;
+            std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> groups; // (mate, distance) -> pairs
+            for (uint64_t j = 0; j < nReq; j++) groups[{req[j].mate, req[j].max_distance}].push_back(req[j].pair);
+            for (const auto& g : groups) {
+                const uint32_t mate = g.first.first, k = g.first.second;
+                std::string buf;
+                std::vector<uint64_t> off(g.second.size() + 1, 0), occOff(g.second.size() + 1, 0);
+                for (size_t j = 0; j < g.second.size(); j++) buf += (*R[mate])[g.second[j]], off[j + 1] = buf.size();
+                cmb_move_batch* b = nullptr;
+                check(cmb_move_batch_create(index.handle(), h, k, kmerSize, buf.data(), off.data(), (uint32_t)g.second.size(), &b));
+                struct BatchGuard {
+                    cmb_move_batch* b;
+                    ~BatchGuard() { cmb_move_batch_destroy(b); }
+                } bg{b};
+                check(cmb_move_batch_want_alignments(b, 1));
+                check(cmb_move_batch_filter_per_strand(b, 1));
+                check(cmb_move_batch_run(b));
+                uint64_t nOcc = 0, nOps = 0;
+                check(cmb_move_batch_result_size(b, &nOcc));
+                std::vector<cmb_move_occ> occ(nOcc ? nOcc : 1);
+                check(cmb_move_batch_results(b, occ.data(), occ.size(), occOff.data(), nullptr));
+                std::vector<cmb_aln> aln(nOcc ? nOcc : 1);
+                (void)cmb_move_batch_alignments(b, aln.data(), 0, nullptr, 0, &nOps); // (sizes first)
+                std::vector<uint16_t> ops(nOps ? nOps : 1);
+                check(cmb_move_batch_alignments(b, aln.data(), aln.size(), ops.data(), ops.size(), &nOps));
+                std::vector<cmb_occ> occ32(nOcc ? nOcc : 1);
+                for (uint64_t i = 0; i < nOcc; i++) occ32[i] = cmb_occ{(uint32_t)occ[i].begin, (uint32_t)occ[i].end, occ[i].distance, occ[i].strand};
+                for (size_t j = 0; j < g.second.size(); j++)
+                    for (uint32_t strand = 0; strand < 2; strand++)
+                        check(cmb_pair_best_supply(pb, g.second[j], mate, strand, k, occ32.data() + occOff[j], aln.data() + occOff[j], occOff[j + 1] - occOff[j],
+                                                   ops.data()));
+            }
+        }
+        std::vector<const char*> pn;
+        for (const auto& name : seqNames) pn.push_back(name.c_str());
+        std::string text;
+        std::vector<char> out;
+        for (uint32_t i = 0; i < n; i++) {
+            uint32_t nPairs = 0;
+            const int64_t len = cmb_pair_best_sam(pb, i, pn.data(), nullptr, 0, &nPairs);
+            if (len < 0) check((int)len);
+            out.resize((size_t)len + 1);
+            cmb_pair_best_sam(pb, i, pn.data(), out.data(), (uint64_t)len + 1, &nPairs);
+            text.append(out.data(), (size_t)len);
+            mappedPairs += nPairs > 0;
+        }
+        return text;
     }
     // matches[i] = the occurrences of reads[i] as filterPtr leaves them (searchstrategy.cpp:529); counters[CMB_CNT_*]
     void matchApproxBatch(const std::vector<std::string>& reads, length_t maxED, std::vector<uint64_t>& counters,

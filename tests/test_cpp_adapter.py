@@ -228,6 +228,26 @@ def test_bmove_adapter_example_matches_python_binding(tmp_path):
             cig = ca.cigar_string(b_ops[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigar_len"])])
             assert (f[2], int(f[3]), f[5], f[11]) == ("seq0", int(a["seq_begin"]) + 1, cig, f"AS:i:{int(b_best[i])}")
     assert (b_best != 0xFFFFFFFF).sum() > 100
+    # read pairs in BEST mode through the adapter (rlc::SearchStrategy::samOfChunkPairedBest: cmb_pair_best_* over b-move batches) = the
+    # Python host layer's records (ca.pair_chunk_sam_best on the same index)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    m1, m2 = [], []
+    for i in range(120):
+        p0 = int(rng.integers(0, len(t) - 700))
+        frag = int(rng.integers(220, 400))
+        a, b = bytearray(t[p0:p0 + 100]), bytearray(t[p0 + frag - 100:p0 + frag].translate(comp)[::-1])
+        if i % 4 == 0:
+            a[17] = b"ACGT"[(b"ACGT".index(bytes([a[17]])) + 1) % 4]
+        m1.append(bytes(a if i % 2 == 0 else b))
+        m2.append(bytes(b if i % 2 == 0 else a))
+    (tmp_path / "m1.txt").write_bytes(b"\n".join(m1) + b"\n")
+    (tmp_path / "m2.txt").write_bytes(b"\n".join(m2) + b"\n")
+    r = subprocess.run([exe, str(tmp_path / "idx"), str(tmp_path / "m1.txt"), "3", "columba", "6", str(tmp_path / "text.txt"), "pairs",
+                        str(tmp_path / "m2.txt"), "0", "95", "600"], capture_output=True, text=True, check=True)
+    want, mapped, _ = ca.pair_chunk_sam_best(dev, ca.SearchStrategy("columba", "edit", "dynamic"), m1, m2, [f"r{i}/1" for i in range(120)],
+                                             [f"r{i}/2" for i in range(120)], ["I" * 100] * 120, ["I" * 100] * 120, ["seq0"], x=0, min_identity=95,
+                                             orientation=ca.ORIENTATION_FR, max_frag=600, min_frag=0, kmer_size=6)
+    assert r.stdout == want and r.stderr.split("\n")[0] == f"mapped pairs {mapped}" and mapped > 100
 
 
 @pytest.mark.gpu
