@@ -4,7 +4,7 @@
 //                 [-I <min identity>] [-S <strategy>] [-m edit|hamming] [-p uniform|static|dynamic]
 //                 [-s <SA sparseness>] [-K <k-mer size>] [-b <reads per chunk>] [-XA] [-nU]
 //                 [-F <mates.fq> -O fr|rf|ff -X <max insert> -N <min insert> -nD -nI]  (read pairs)
-// Read pairs in BEST mode: unless -nI or one of -O / -X / -N is given, orientation and insert-size bounds are inferred from the first pairs of
+// Read pairs: unless -nI or one of -O / -X / -N is given, orientation and insert-size bounds are inferred from the first pairs of
 // the files as the reference does (parallel.cpp:468-655, :862-935: up to 10 000 reads matched single-end, the pairs whose mates both map
 // unambiguously are the sample) and that first chunk is paired from its single-end results.
 // FASTQ / FASTA in, SAM out (header of <base>.headerSN.bin, records in input order).
@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
         OutputWriter writer(outFile, base + ".headerSN.bin", cmdline);
         std::vector<SequenceRecord> chunk;
         size_t chunkID = 0, nReads = 0, nMapped = 0;
-        if (mateReader && mode != "all" && !noInfer && !pairParamsGiven) {
+        if (mateReader && !noInfer && !pairParamsGiven) {
             // PE_MAX_READS_FOR_INFERENCE = 10 000 reads (definitions.h:58): the first 5 000 pairs at most
             std::vector<SequenceRecord> mates;
             const size_t want = std::min<size_t>(chunkReads, 5000);
@@ -89,18 +89,27 @@ int main(int argc, char** argv) {
                     uint32_t v[2] = {0, 0};
                     if (fs.read(reinterpret_cast<char*>(v), sizeof(v))) seqsInFirstFile = v[1]; // (a second file starts at sequence v[1])
                 }
-                auto inf = strategy.inferPairedEndParameters(chunk, mates, (uint32_t)identity, seqsInFirstFile);
-                std::cerr << "Found " << inf.unambiguousPairs << " unambiguous pairs while processing " << inf.readsGiven
-                          << " reads for inferring paired-end parameters\n";
-                if (inf.inferred.inferred) {
-                    ori = inf.inferred.orientation, maxInsert = inf.inferred.max_insert, minInsert = inf.inferred.min_insert;
-                    std::cerr << "Inferred paired-end parameters: orientation " << (ori == CMB_ORIENTATION_FR ? "FR" : ori == CMB_ORIENTATION_RF ? "RF" : "FF")
-                              << ", insert size " << inf.inferred.mean_insert << " +- " << inf.inferred.stddev_insert << ", bounds [" << minInsert << ", "
-                              << maxInsert << "]\n";
-                } else
-                    std::cerr << "No pairs mapped unambiguously. Using default values!\n";
-                std::string text = strategy.samOfChunkPairedBest(chunk, mates, seqNamePtrs, 0, (uint32_t)identity, ori, maxInsert, minInsert, discordant, unmapped,
-                                                                 nMapped, nullptr, &inf);
+                auto report = [&](const cmb_pair_inferred& got, size_t unambiguousPairs, size_t readsGiven) {
+                    std::cerr << "Found " << unambiguousPairs << " unambiguous pairs while processing " << readsGiven
+                              << " reads for inferring paired-end parameters\n";
+                    if (got.inferred) {
+                        ori = got.orientation, maxInsert = got.max_insert, minInsert = got.min_insert;
+                        std::cerr << "Inferred paired-end parameters: orientation " << (ori == CMB_ORIENTATION_FR ? "FR" : ori == CMB_ORIENTATION_RF ? "RF" : "FF")
+                                  << ", insert size " << got.mean_insert << " +- " << got.stddev_insert << ", bounds [" << minInsert << ", " << maxInsert << "]\n";
+                    } else
+                        std::cerr << "No pairs mapped unambiguously. Using default values!\n";
+                };
+                std::string text;
+                if (mode == "all") {
+                    auto inf = strategy.inferPairedEndParametersAll(chunk, mates, (length_t)k, seqsInFirstFile);
+                    report(inf.inferred, inf.unambiguousPairs, inf.readsGiven);
+                    text = strategy.samOfChunkPairedAll(chunk, mates, seqNamePtrs, (length_t)k, ori, maxInsert, minInsert, discordant, unmapped, nMapped, &inf);
+                } else {
+                    auto inf = strategy.inferPairedEndParameters(chunk, mates, (uint32_t)identity, seqsInFirstFile);
+                    report(inf.inferred, inf.unambiguousPairs, inf.readsGiven);
+                    text = strategy.samOfChunkPairedBest(chunk, mates, seqNamePtrs, 0, (uint32_t)identity, ori, maxInsert, minInsert, discordant, unmapped, nMapped,
+                                                         nullptr, &inf);
+                }
                 nReads += chunk.size();
                 writer.commitChunk(chunkID++, std::move(text));
             }

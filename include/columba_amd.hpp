@@ -282,85 +282,91 @@ class SearchStrategy {
         text.resize((size_t)n);
         return text;
     }
-    // the SAM text of a chunk of read PAIRS in ALL mode: both mates matched single-ended (one batch each), then paired as
-    // SearchStrategy::pairSingleEndedMatchesAll does (searchstrategy.cpp:1345-1399) with the records of generateSAMPairedEnd.
-    // orientation: CMB_ORIENTATION_*.  Occurrences that run past the end of their sequence are trimmed as findSeqName does.
-    template <class Record>
-    std::string samOfChunkPairedAll(const std::vector<Record>& mates1, const std::vector<Record>& mates2,
-                                    const std::vector<const char*>& seqNames, length_t maxED, uint32_t orientation, uint32_t maxFragSize,
-                                    uint32_t minFragSize, bool discordantAllowed, bool unmappedRecords, size_t& mappedPairs) {
-        if (mates1.size() != mates2.size()) throw std::runtime_error("the two read files do not hold the same number of reads");
-        struct Mate {
-            std::vector<cmb_occ> occ;
-            std::vector<cmb_aln> aln;
-            std::vector<uint16_t> ops;
-            std::vector<uint64_t> oo;
-        } M[2];
-        const std::vector<Record>* in[2] = {&mates1, &mates2};
-        for (int m = 0; m < 2; m++) {
-            std::string seqs;
-            std::vector<uint64_t> offs(in[m]->size() + 1, 0);
-            for (size_t i = 0; i < in[m]->size(); i++) seqs += (*in[m])[i].read, offs[i + 1] = seqs.size();
-            cmb_batch* b = nullptr;
-            check(cmb_batch_create(index.handle(), h, maxED, seqs.data(), offs.data(), (uint32_t)in[m]->size(), &b));
-            struct Guard {
-                cmb_batch* b;
-                ~Guard() { cmb_batch_destroy(b); }
-            } guard{b};
-            check(cmb_batch_want_alignments(b, 1));
-            check(cmb_batch_filter_per_strand(b, 1)); // (mapRead filters every strand by itself: searchstrategy.cpp:746-776)
-            check(cmb_batch_run(b));
-            uint64_t n = 0, nOps = 0;
-            check(cmb_batch_result_size(b, &n));
-            M[m].occ.resize(n ? n : 1);
-            M[m].aln.resize(n ? n : 1);
-            M[m].oo.resize(in[m]->size() + 1);
-            std::vector<uint64_t> cnt(CMB_CNT_MAX);
-            check(cmb_batch_results(b, M[m].occ.data(), M[m].occ.size(), M[m].oo.data(), cnt.data()));
-            (void)cmb_batch_alignments(b, M[m].aln.data(), 0, nullptr, 0, &nOps); // sizes first
-            M[m].ops.resize(nOps ? nOps : 1);
-            check(cmb_batch_alignments(b, M[m].aln.data(), M[m].aln.size(), M[m].ops.data(), M[m].ops.size(), &nOps));
+    // ---- read pairs in ALL mode
+    // the occurrences of one read as cmb_pair_sam takes them: sequence assigned (trimmed where they ran over its end, findSeqName,
+    // indexinterface.cpp:833-899; those for which that fails are dropped), with their CIGAR operations
+    struct PairOccStore {
+        cmb_pair_occ p;
+        std::vector<uint16_t> ops;
+    };
+    typedef std::vector<std::vector<PairOccStore>> MateLists; // [read][occurrence]
+    // one batch over recs[ids]: ALL mode at maxED with alignments; perStrand: every strand filtered by itself (mapRead, searchstrategy.h:490-519)
+    // instead of the read's two strands together (matchApproxAllMap)
+    template <class Record> MateLists listsOfMate(const std::vector<Record>& recs, const std::vector<size_t>& ids, length_t maxED, bool perStrand) {
+        std::string seqs;
+        std::vector<uint64_t> offs(ids.size() + 1, 0);
+        for (size_t j = 0; j < ids.size(); j++) seqs += recs[ids[j]].read, offs[j + 1] = seqs.size();
+        cmb_batch* b = nullptr;
+        check(cmb_batch_create(index.handle(), h, maxED, seqs.data(), offs.data(), (uint32_t)ids.size(), &b));
+        struct Guard {
+            cmb_batch* b;
+            ~Guard() { cmb_batch_destroy(b); }
+        } guard{b};
+        check(cmb_batch_want_alignments(b, 1));
+        check(cmb_batch_filter_per_strand(b, perStrand ? 1 : 0));
+        check(cmb_batch_run(b));
+        uint64_t n = 0, nOps = 0;
+        check(cmb_batch_result_size(b, &n));
+        std::vector<cmb_occ> occ(n ? n : 1);
+        std::vector<cmb_aln> aln(n ? n : 1);
+        std::vector<uint64_t> oo(ids.size() + 1), cnt(CMB_CNT_MAX);
+        check(cmb_batch_results(b, occ.data(), occ.size(), oo.data(), cnt.data()));
+        (void)cmb_batch_alignments(b, aln.data(), 0, nullptr, 0, &nOps); // sizes first
+        std::vector<uint16_t> ops(nOps ? nOps : 1);
+        check(cmb_batch_alignments(b, aln.data(), aln.size(), ops.data(), ops.size(), &nOps));
+        MateLists out(ids.size());
+        std::vector<char> id, sq, rc, rq;
+        std::vector<uint16_t> trimmed(2 * (size_t)maxED + 8);
+        for (size_t j = 0; j < ids.size(); j++) {
+            const Record& r = recs[ids[j]];
+            bool prepared = false;
+            for (uint64_t q = oo[j]; q < oo[j + 1]; q++) {
+                cmb_occ o = occ[q];
+                cmb_aln a = aln[q];
+                const uint16_t* src = ops.data() + a.cigar_off;
+                uint32_t nOpsQ = a.cigar_len;
+                if (a.spans == 1) { // runs past the end of its sequence: assignSequence -> findSeqName trims it
+                    if (!prepared) {
+                        id.resize(r.seqID.size() + 1), sq.resize(r.read.size() + 1), rc.resize(r.read.size() + 1), rq.resize(r.qual.size() + 1);
+                        check(cmb_read_prepare(r.seqID.c_str(), r.read.c_str(), r.qual.c_str(), id.data(), sq.data(), rc.data(), rq.data()));
+                        prepared = true;
+                    }
+                    int found = 0;
+                    const char* pat = o.strand ? rc.data() : sq.data();
+                    check(cmb_trim_occurrence(index.handle(), pat, (uint32_t)strlen(pat), maxED, CMB_METRIC_EDIT, &o, &a, trimmed.data(), (uint32_t)trimmed.size(),
+                                              &nOpsQ, &found));
+                    if (!found) continue; // NOT_FOUND: takes no part in the pairing
+                    src = trimmed.data();
+                }
+                PairOccStore st;
+                st.ops.assign(src, src + nOpsQ);
+                st.p.seq_id = a.seq_id, st.p.begin = a.seq_begin, st.p.end = a.seq_begin + (o.end - o.begin), st.p.index_begin = o.begin;
+                st.p.distance = o.distance, st.p.strand = o.strand, st.p.cigar_ops = nullptr, st.p.n_ops = nOpsQ;
+                out[j].push_back(std::move(st));
+            }
         }
+        return out;
+    }
+    // cmb_pair_sam per pair over the mates' lists (pairSingleEndedMatchesAll + generateSAMPairedEnd)
+    template <class Record>
+    std::string pairListsAll(const std::vector<Record>& mates1, const std::vector<Record>& mates2, MateLists& L1, MateLists& L2, const std::vector<const char*>& seqNames,
+                             uint32_t orientation, uint32_t maxFragSize, uint32_t minFragSize, bool discordantAllowed, bool unmappedRecords, size_t& mappedPairs) {
         const cmb_pair_params prm = {orientation, maxFragSize, minFragSize, discordantAllowed ? 1 : 0, unmappedRecords ? 1 : 0};
+        const std::vector<Record>* in[2] = {&mates1, &mates2};
+        MateLists* L[2] = {&L1, &L2};
         std::string text;
         std::vector<char> buf;
         for (size_t i = 0; i < mates1.size(); i++) {
             std::vector<cmb_pair_occ> po[2];
-            std::vector<uint16_t> trimmedOps[2]; // (reserved up front: the records point into it)
             std::vector<char> id[2], sq[2], rc[2], rq[2];
             cmb_pair_read rd[2];
             for (int m = 0; m < 2; m++) {
                 const Record& r = (*in[m])[i];
                 id[m].resize(r.seqID.size() + 1), sq[m].resize(r.read.size() + 1), rc[m].resize(r.read.size() + 1), rq[m].resize(r.qual.size() + 1);
                 check(cmb_read_prepare(r.seqID.c_str(), r.read.c_str(), r.qual.c_str(), id[m].data(), sq[m].data(), rc[m].data(), rq[m].data()));
-                trimmedOps[m].clear();
-                trimmedOps[m].reserve((M[m].oo[i + 1] - M[m].oo[i]) * (2 * (size_t)maxED + 8));
-                for (uint64_t j = M[m].oo[i]; j < M[m].oo[i + 1]; j++) {
-                    cmb_occ o = M[m].occ[j];
-                    cmb_aln a = M[m].aln[j];
-                    const uint16_t* ops = M[m].ops.data() + a.cigar_off;
-                    uint32_t nOpsJ = a.cigar_len;
-                    if (a.spans == 1) { // runs past the end of its sequence: assignSequence -> findSeqName trims it (indexinterface.cpp:833-899)
-                        const size_t at = trimmedOps[m].size();
-                        trimmedOps[m].resize(at + 2 * (size_t)maxED + 8);
-                        int found = 0;
-                        const char* pat = o.strand ? rc[m].data() : sq[m].data();
-                        check(cmb_trim_occurrence(index.handle(), pat, (uint32_t)strlen(pat), maxED, CMB_METRIC_EDIT, &o, &a, trimmedOps[m].data() + at,
-                                                  (uint32_t)(2 * maxED + 8), &nOpsJ, &found));
-                        if (!found) continue; // NOT_FOUND: takes no part in the pairing
-                        ops = trimmedOps[m].data() + at;
-                    }
-                    const uint32_t width = o.end - o.begin;
-                    cmb_pair_occ p;
-                    p.seq_id = a.seq_id;
-                    p.begin = a.seq_begin;
-                    p.end = p.begin + width;
-                    p.index_begin = o.begin;
-                    p.distance = o.distance;
-                    p.strand = o.strand;
-                    p.cigar_ops = ops;
-                    p.n_ops = nOpsJ;
-                    po[m].push_back(p);
+                for (PairOccStore& st : (*L[m])[i]) {
+                    st.p.cigar_ops = st.ops.data();
+                    po[m].push_back(st.p);
                 }
                 rd[m] = cmb_pair_read{id[m].data(), sq[m].data(), rc[m].data(), r.qual.c_str(), rq[m].data(), po[m].data(), (uint32_t)po[m].size()};
             }
@@ -374,11 +380,79 @@ class SearchStrategy {
         }
         return text;
     }
-    // Read pairs in BEST (+x strata) mode: SearchStrategy::matchApproxPairedEndBestPlusX (searchstrategy.cpp:1091-1179) for a whole chunk.
-    // The pairs walk through their strata together (cmb_pair_best_*): every round, the lists the unfinished pairs wait for — mapRead of one
-    // mate at one distance — come from ONE device batch per (mate, distance) over the reads that ask (ALL mode, every strand filtered by
-    // itself, with alignments); both strands of a result are handed in.  maxSupported: getMaxSupportedDistanceForBestMapping of the
-    // strategy (the largest k such that 1 .. k all have schemes), 13 at most.
+    // The single-end phase that infers the paired-end parameters in ALL mode (parallel.cpp:236-312, :700-727; cmb_pair_infer for :329-466): read 1 of
+    // every pair matched as a single read (its two strands filtered together, matchApproxAllMap); read 2 where read 1 has exactly one match in
+    // the first reference file; the pairs whose mates both do are the sample.  The lists stay: the chunk is then paired from them
+    // (pairSingleEndedMatchesAll, searchstrategy.cpp:1345-1399 — a read 2 that was not matched yet is matched strand by strand there).
+    struct PairedEndInferenceAll {
+        cmb_pair_inferred inferred{};
+        size_t readsGiven = 0, unambiguousPairs = 0;
+        MateLists first, second;
+        std::vector<uint8_t> read2done;
+    };
+    template <class Record>
+    PairedEndInferenceAll inferPairedEndParametersAll(const std::vector<Record>& mates1, const std::vector<Record>& mates2, length_t maxED,
+                                                      uint32_t seqsInFirstFile) {
+        if (mates1.size() != mates2.size()) throw std::runtime_error("the two read files do not hold the same number of reads");
+        const size_t n = mates1.size();
+        PairedEndInferenceAll inf;
+        inf.read2done.assign(n, 0);
+        std::vector<size_t> all(n), second;
+        for (size_t i = 0; i < n; i++) all[i] = i;
+        inf.first = listsOfMate(mates1, all, maxED, false);
+        auto unambiguous = [&](std::vector<PairOccStore>& v) { // hasUnambiguousMatchInFirstFile: the one match of the first file moves to the front
+            size_t count = 0, at = 0;
+            for (size_t j = 0; j < v.size(); j++)
+                if (v[j].p.seq_id < seqsInFirstFile) {
+                    if (++count == 2) return false;
+                    at = j;
+                }
+            if (count == 1) std::swap(v[0], v[at]);
+            return count == 1;
+        };
+        for (size_t i = 0; i < n; i++)
+            if (unambiguous(inf.first[i])) second.push_back(i), inf.read2done[i] = 1;
+        MateLists done = listsOfMate(mates2, second, maxED, false);
+        inf.second.assign(n, {});
+        std::vector<cmb_pair_sample> samples;
+        for (size_t j = 0; j < second.size(); j++) {
+            const size_t i = second[j];
+            inf.second[i] = std::move(done[j]);
+            if (unambiguous(inf.second[i])) {
+                const cmb_pair_occ &a = inf.first[i][0].p, &b = inf.second[i][0].p;
+                samples.push_back(cmb_pair_sample{a.begin, a.end, a.strand, b.begin, b.end, b.strand});
+            }
+        }
+        inf.readsGiven = 2 * n, inf.unambiguousPairs = samples.size();
+        check(cmb_pair_infer(samples.data(), samples.size(), &inf.inferred));
+        return inf;
+    }
+    // the SAM text of a chunk of read PAIRS in ALL mode: both mates matched single-ended (one batch each, every strand filtered by itself as
+    // matchApproxPairedEndAll's mapRead does, searchstrategy.cpp:746-776), then paired as SearchStrategy::pairSingleEndedMatchesAll does
+    // (searchstrategy.cpp:1345-1399) with the records of generateSAMPairedEnd.  orientation: CMB_ORIENTATION_*.  startFrom: the lists of the
+    // inference phase (read 1, and read 2 where it was matched); the other reads 2 are matched here, strand by strand.
+    template <class Record>
+    std::string samOfChunkPairedAll(const std::vector<Record>& mates1, const std::vector<Record>& mates2,
+                                    const std::vector<const char*>& seqNames, length_t maxED, uint32_t orientation, uint32_t maxFragSize,
+                                    uint32_t minFragSize, bool discordantAllowed, bool unmappedRecords, size_t& mappedPairs,
+                                    PairedEndInferenceAll* startFrom = nullptr) {
+        if (mates1.size() != mates2.size()) throw std::runtime_error("the two read files do not hold the same number of reads");
+        const size_t n = mates1.size();
+        std::vector<size_t> all(n);
+        for (size_t i = 0; i < n; i++) all[i] = i;
+        if (!startFrom) {
+            MateLists L1 = listsOfMate(mates1, all, maxED, true), L2 = listsOfMate(mates2, all, maxED, true);
+            return pairListsAll(mates1, mates2, L1, L2, seqNames, orientation, maxFragSize, minFragSize, discordantAllowed, unmappedRecords, mappedPairs);
+        }
+        if (startFrom->read2done.size() != n) throw std::runtime_error("the single-end results are those of another chunk");
+        std::vector<size_t> rest;
+        for (size_t i = 0; i < n; i++)
+            if (!startFrom->read2done[i]) rest.push_back(i);
+        MateLists late = listsOfMate(mates2, rest, maxED, true);
+        for (size_t j = 0; j < rest.size(); j++) startFrom->second[rest[j]] = std::move(late[j]);
+        return pairListsAll(mates1, mates2, startFrom->first, startFrom->second, seqNames, orientation, maxFragSize, minFragSize, discordantAllowed,
+                            unmappedRecords, mappedPairs);
+    }
     // The single-end phase that infers the paired-end parameters (parallel.cpp:236-262 hasUnambiguousMatchInFirstFile, :276-312
     // processChunkSingleEndForPairInferring, :700-727 and cmb_pair_infer for :329-466): read 1 of every pair in BEST mode; read 2 where read 1 has
     // exactly one match in the first reference file; the pairs whose mates both do are the sample.  The single-end results stay here: the

@@ -331,3 +331,19 @@ def test_align_driver_paired_end(tmp_path):
     assert run.returncode == 0, run.stderr
     later = lambda path: [ln for ln in path.read_text().splitlines() if not ln.startswith("@") and int(ln.split("\t")[0][1:].split("/")[0]) >= 120]
     assert later(out3) == later(out4) and len(later(out3)) > 300
+    # the same in ALL mode: single-end phase with the strands of a read filtered together, the chunk paired from those lists
+    # (pairSingleEndedMatchesAll; a read 2 that was not matched yet is matched strand by strand), the later chunks as with the bounds given
+    out5, out6 = tmp_path / "o5.sam", tmp_path / "o6.sam"
+    run = subprocess.run([exe, "-r", str(tmp_path / "idx"), "-f", str(tmp_path / "r1.fq"), "-F", str(tmp_path / "r2.fq"), "-o", str(out5),
+                          "-a", "all", "-e", "2", "-S", "multiple_opt", "-b", "120"], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+    m = re.search(r"orientation FR, insert size ([0-9.]+) \+- ([0-9.]+), bounds \[(\d+), (\d+)\]", run.stderr)
+    assert m and 250 < float(m.group(1)) < 330 and "unambiguous pairs while processing 240 reads" in run.stderr, run.stderr
+    run = subprocess.run([exe, "-r", str(tmp_path / "idx"), "-f", str(tmp_path / "r1.fq"), "-F", str(tmp_path / "r2.fq"), "-o", str(out6),
+                          "-a", "all", "-e", "2", "-S", "multiple_opt", "-b", "120", "-X", m.group(4), "-N", m.group(3)], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+    assert later(out5) == later(out6) and len(later(out5)) > 300
+    first = lambda path: [ln.split("\t") for ln in path.read_text().splitlines() if not ln.startswith("@") and int(ln.split("\t")[0][1:].split("/")[0]) < 120]
+    proper5 = {(f[0], f[2], f[3]) for f in first(out5) if int(f[1]) & 2}
+    proper6 = {(f[0], f[2], f[3]) for f in first(out6) if int(f[1]) & 2}
+    assert len(proper5) > 100 and len(proper5 ^ proper6) <= 0.05 * len(proper6)   # (joint against per-strand filtering: the same proper pairs but for a few)
