@@ -74,8 +74,8 @@ class Occ:
 class RefWalk:
     """one pair, straight through"""
 
-    def __init__(self, table, reads, cutoffs, x, orientation, max_frag, min_frag, disc, unmapped, seeds=None):
-        self.table, self.R, self.cut = table, reads, cutoffs
+    def __init__(self, table, reads, cutoffs, x, orientation, max_frag, min_frag, disc, unmapped, seeds=None, hamming=False):
+        self.table, self.R, self.cut, self.hamming = table, reads, cutoffs, hamming
         self.x, self.ori, self.max_frag, self.min_frag, self.disc, self.unmapped = x, orientation, max_frag, min_frag, disc, unmapped
         self.ov = [[[[False, []] for _ in range(cutoffs[m] + 1)] for _s in (0, 1)] for m in (0, 1)]
         self.pairs = []     # [up, down, frag, distance, discordant]; up / down = Occ or ("unmapped", mate)
@@ -116,7 +116,7 @@ class RefWalk:
             if not o.spans:
                 o.state = FOUND
             else:
-                t = synthetic_trim(max_ed, o.ib, o.ib + o.w, o.d)
+                t = None if self.hamming else synthetic_trim(max_ed, o.ib, o.ib + o.w, o.d)  # (no trimming under Hamming distance, indexinterface.cpp:828-832)
                 if t is None:
                     o.state = NOT_FOUND
                 else:
@@ -516,13 +516,14 @@ def _as_arrays(lst):
     return occ, aln, np.asarray(ops, dtype=np.uint16)
 
 
-def _run_library(pairs, x, min_identity, max_supported, orientation, max_frag, min_frag, disc, unmapped, seeds=None):
+def _run_library(pairs, x, min_identity, max_supported, orientation, max_frag, min_frag, disc, unmapped, seeds=None, metric="edit"):
     """drive cmb_pair_best_* over a chunk: answer every request from the pair's table"""
     def trim(pair, mate, strand, stratum, occ):
+        assert metric == "edit", "an occurrence over a sequence end is never trimmed under Hamming distance"
         return synthetic_trim(stratum, *occ)
 
     pb = ca.PairBest([p[0][0] for p in pairs], [p[0][1] for p in pairs], x, min_identity, max_supported, orientation, max_frag, min_frag, disc,
-                     unmapped, trim=trim)
+                     unmapped, metric=metric, trim=trim)
     asked = [[] for _ in pairs]
     for i, sd in enumerate(seeds or []):
         if sd is not None:
@@ -601,6 +602,21 @@ def test_pairs_that_start_from_single_end_results(orientation):
     with pytest.raises(ca.CmbError, match="x = 0"):
         pb.seed(0, _as_arrays([]), _as_arrays([]), True)
     pb.close()
+
+
+def test_hamming_distance_never_trims():
+    rng = np.random.default_rng(9)
+    pairs = []
+    for i in range(150):
+        reads, cut, table, _ = _make_pair(rng, i, 100, 100, 95, 5, ["boundary", "sparse", "dense"][i % 3], ori=ca.ORIENTATION_FR)
+        pairs.append((reads, cut, table))
+    got, asked, _ = _run_library(pairs, 1, 95, 5, ca.ORIENTATION_FR, 600, 0, True, True, metric="hamming")
+    n = 0
+    for i, (reads, cut, table) in enumerate(pairs):
+        ref = RefWalk(table, reads, cut, 1, ca.ORIENTATION_FR, 600, 0, True, True, hamming=True).run()
+        assert got[i] == ref.sam() and asked[i] == list(dict.fromkeys(ref.asked)), i
+        n += got[i][1] > 0
+    assert n > 60
 
 
 def test_best_pairs_are_the_best_concordant_pairs():
