@@ -636,8 +636,13 @@ __global__ void k_mvs_prep(const uint8_t* __restrict__ reads, const uint64_t* __
 // ------------------------------------------------------------------ prologue: partitioning + scheme selection
 // SearchStrategy::partition (searchstrategy.cpp:141-419) and MultipleSchemes::createSearches (searchstrategy.h:2505-2537), one
 // lane per read x strand.  Partition state in LDS ([field][part][lane]).
+// (Register budget: the dynamic partitioning at 8 parts came out at 257 registers — one over the line for two wavefronts per SIMD — and ran one;
+// every lane is a chain of dependent table rows, so wavefronts are what hides them: CMB_MVS_PARTS_WAVES per SIMD for the narrow tables.)
+#ifndef CMB_MVS_PARTS_WAVES
+#define CMB_MVS_PARTS_WAVES 2
+#endif
 template <int PARTITION, int MP = MAXP>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, MP == MAXP ? CMB_MVS_PARTS_WAVES : 1)
 k_mvs_parts(MvSearchIndex sx, const DevStrategyKT<MP>* __restrict__ stp, uint32_t nReads, uint32_t maxLen, const uint8_t* __restrict__ seqAll,
             const uint64_t* __restrict__ offs, PartOutT<MP>* __restrict__ partsOut, MoveRangeRec* __restrict__ exr, uint8_t* __restrict__ psel, Queues q) {
     __shared__ uint32_t pbe[MP][64];
