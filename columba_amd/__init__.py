@@ -1183,13 +1183,17 @@ def pair_chunk_sam(index: "Index", strategy: "SearchStrategy", max_distance: int
 
 def pair_chunk_sam_best(index: "Index", strategy: "SearchStrategy", reads1, reads2, ids1, ids2, quals1, quals2, seq_names, x: int = 0,
                         min_identity: int = 95, orientation: int = ORIENTATION_FR, max_frag: int = 500, min_frag: int = 0,
-                        discordant_allowed: bool = True, unmapped_records: bool = True, max_supported: Optional[int] = None, kmer_size: int = 10):
+                        discordant_allowed: bool = True, unmapped_records: bool = True, max_supported: Optional[int] = None, kmer_size: int = 10,
+                        start_from=None):
     """A chunk of read pairs in BEST (+x strata) mode, end to end (SearchStrategy::matchApproxPairedEndBestPlusX,
     searchstrategy.cpp:1091-1179): the pairs walk through their strata together (PairBest); every round, the lists the unfinished pairs
     wait for — mapRead of one mate at one distance — are produced by ONE device batch per (mate, distance) over the reads that ask
     (ALL mode, every strand filtered by itself, with alignments), and both strands of a result are handed in.  `index`: an Index, or a
     MoveIndex with its text attached (the b-move backend: MoveBatch per (mate, distance); kmer_size is its seed table's).  Returns (SAM
-    text, number of properly or discordantly mapped pairs, number of device batches)."""
+    text, number of properly or discordantly mapped pairs, number of device batches).  start_from: the single-end results of
+    infer_paired_end_best for this chunk — the pairs start from them (pairSingleEndedMatchesBest; x = 0)."""
+    if start_from is not None:
+        x = 0
     is_move = isinstance(index, MoveIndex)
     if is_move:
         class _TextIndex:  # (the text beside the b-move index: what an occurrence over a sequence end is trimmed on)
@@ -1219,6 +1223,9 @@ def pair_chunk_sam_best(index: "Index", strategy: "SearchStrategy", reads1, read
     pb = PairBest(mates[0], mates[1], x, min_identity, max_supported, orientation, max_frag, min_frag, discordant_allowed, unmapped_records,
                   text_index=trim_index)
     raw = [[r if isinstance(r, bytes) else r.encode() for r in reads] for reads in (reads1, reads2)]
+    if start_from is not None:
+        for i in range(n):
+            pb.seed(i, start_from["single"][0][i], start_from["single"][1][i], bool(start_from["read2done"][i]))
     batches = 0
     while True:
         req = pb.advance()
@@ -1257,4 +1264,47 @@ def pair_chunk_sam_best(index: "Index", strategy: "SearchStrategy", reads1, read
         mapped += n_pairs > 0
     pb.close()
     return "".join(text), mapped, batches
+
+
+
+def infer_paired_end_best(index: "Index", strategy: "SearchStrategy", reads1, reads2, min_identity: int = 95, seqs_in_first_file: Optional[int] = None,
+                          kmer_size: int = 10):
+    """The single-end phase that infers the paired-end parameters (parallel.cpp:236-312, :700-727): read 1 of every pair in BEST mode
+    (match_best, x = 0); read 2 where read 1 has exactly one match in the first reference file (it moves to the front:
+    hasUnambiguousMatchInFirstFile); the pairs whose mates both do are the sample of cmb_pair_infer.  Returns a dict: "inferred"
+    (PairInferred), "unambiguous_pairs", "read2done", and "single" — per mate and pair (occ, aln, ops) for
+    pair_chunk_sam_best(..., start_from=...)."""
+    n = len(reads1)
+    lim = 0xFFFFFFFF if seqs_in_first_file is None else seqs_in_first_file
+    empty = (np.zeros(0, OCC_DTYPE), np.zeros(0, ALN_DTYPE), np.zeros(0, np.uint16))
+
+    def single(reads, ids):
+        out = {}
+        if not ids:
+            return out
+        occ, aln, ops, offs, _best, _hits, _cnt = match_best(index, strategy, [reads[i] for i in ids], x=0, min_identity=min_identity, kmer_size=kmer_size)
+        for j, i in enumerate(ids):
+            lo, hi = int(offs[j]), int(offs[j + 1])
+            o, a = occ[lo:hi].copy(), aln[lo:hi].copy()
+            a["spans"] = 0
+            first = [q for q in range(hi - lo) if int(a["seq_id"][q]) < lim]
+            unambiguous = len(first) == 1
+            if unambiguous and first[0] != 0:
+                o[[0, first[0]]] = o[[first[0], 0]]
+                a[[0, first[0]]] = a[[first[0], 0]]
+            out[i] = ((o, a, ops), unambiguous)
+        return out
+
+    r1 = single(reads1, list(range(n)))
+    second = [i for i in range(n) if r1[i][1]]
+    r2 = single(reads2, second)
+    samples = []
+    for i in second:
+        if r2[i][1]:
+            (o1, a1, _), (o2, a2, _) = r1[i][0], r2[i][0]
+            samples.append((int(a1["seq_begin"][0]), int(a1["seq_begin"][0]) + int(o1["end"][0]) - int(o1["begin"][0]), int(o1["strand"][0]),
+                            int(a2["seq_begin"][0]), int(a2["seq_begin"][0]) + int(o2["end"][0]) - int(o2["begin"][0]), int(o2["strand"][0])))
+    return {"inferred": pair_infer(samples if samples else np.zeros((0, 6), np.uint32)), "unambiguous_pairs": len(samples),
+            "read2done": [i in r2 for i in range(n)],
+            "single": ([r1[i][0] for i in range(n)], [r2[i][0] if i in r2 else empty for i in range(n)])}
 

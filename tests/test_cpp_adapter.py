@@ -323,6 +323,16 @@ def test_align_driver_paired_end(tmp_path):
         by.setdefault(ln.split("\t")[0].split("/")[0], []).append(int(ln.split("\t")[1]))
     assert len(by) == n
     assert sum(1 for fl in by.values() if any(f & 2 for f in fl)) > 0.6 * n
+    # the first chunk, record by record: the Python host layer's inference phase and seeded walk over the same C-ABI
+    inf = ca.infer_paired_end_best(dev, ca.SearchStrategy("columba", "edit", "dynamic"), r1[:120], r2[:120], min_identity=95)
+    got_inf = inf["inferred"]
+    assert (int(got_inf.min_insert), int(got_inf.max_insert)) == (int(m.group(3)), int(m.group(4))) and got_inf.orientation == ca.ORIENTATION_FR
+    want3, _, _ = ca.pair_chunk_sam_best(dev, ca.SearchStrategy("columba", "edit", "dynamic"), r1[:120], r2[:120], [f"@p{i}/1 x" for i in range(120)],
+                                         [f"@p{i}/2 x" for i in range(120)], [q] * 120, [q] * 120, names, x=0, min_identity=95,
+                                         orientation=int(got_inf.orientation), max_frag=int(got_inf.max_insert), min_frag=int(got_inf.min_insert),
+                                         start_from=inf)
+    first3 = "".join(ln + "\n" for ln in body3 if int(ln.split("\t")[0][1:].split("/")[0]) < 120)
+    assert first3 == want3 and f"Found {inf['unambiguous_pairs']} unambiguous pairs" in run.stderr
     # beyond the first chunk the records are those of the run with the same bounds given
     lo, hi = int(m.group(3)), int(m.group(4))
     out4 = tmp_path / "o4.sam"
