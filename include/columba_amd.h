@@ -578,14 +578,17 @@ int cmb_move_match_exact(const cmb_move_index* idx, const char* reads, const uin
  * RUN_LENGTH_COMPRESSION flavour compiles it — the same search schemes, partitioning and bit-parallel matrix over ranges that
  * carry run indices and a toehold (indexhelpers.h:137-255, :1040-1260), no in-text verification (switch point 0: bmove.cpp:195-197,
  * indexinterface.cpp:345-348, :516-524, :1306-1325, searchstrategy.cpp:461-477), in-index occurrences located by the phi / phi^-1
- * chains of their toehold (bmove.cpp:500-560), then getUniqueTextOccurrences (indexinterface.cpp:1373-1491).  Edit distance,
- * max_distance 1 .. 7 for the strategies that have schemes for it (0: the exact path above); kmer_size: word size of the k-mer
+ * chains of their toehold (bmove.cpp:500-560), then getUniqueTextOccurrences (indexinterface.cpp:1373-1491).  Edit and Hamming distance,
+ * max_distance 1 .. 13 (the reference's MAX_K) for the strategies that have schemes for it (0: the exact path above); kmer_size: word size of the k-mer
  * table used for seeding (populateTable, indexinterface.cpp:294-335; built on the device on first use).  Results: per read the list
  * cmb_match_batch would return on the same text, in 64-bit coordinates.  counters[CMB_CNT_MAX]: NODE_COUNTER, SEARCH_STARTED,
  * EXPANSIONS, MATRIX_ROWS as the reference counts them, TOTAL_REPORTED_POSITIONS / LOCATED_ROWS = located positions,
  * CMB_CNT_TABLE_ROWS = move-table rows fetched.  cmb_move_match_batch: host buffers in and out, CMB_ERR_OVERFLOW with *needed = the
- * number of records if out_cap is too small.  cmb_move_batch_*: reads resident on the device between runs (what bench.py times).
- * Reads not longer than the number of parts and Hamming distance: CMB_ERR_UNSUPPORTED (nothing is silently skipped). */
+ * number of records if out_cap is too small.  cmb_move_batch_*: reads resident on the device between runs (what bench.py times); a
+ * chunk of 2^19 reads or more is matched as two concurrent halves, each with pools, streams and a host thread of its own (results,
+ * offsets, counters and alignments are those of the one batch; CMB_MOVE_SUBBATCHES=n at creation overrides, 1 = one batch; fewer than 2^23
+ * reads per batch).
+ * Reads not longer than the number of parts are matched by naive backtracking, as the reference matches them (searchstrategy.cpp:148-152). */
 typedef struct cmb_move_batch cmb_move_batch;
 int cmb_move_match_batch(cmb_move_index* idx, const cmb_strategy* st, uint32_t max_distance, uint32_t kmer_size, const char* seqs,
                          const uint64_t* offs, uint32_t n_reads, cmb_move_occ* out, uint64_t out_cap, uint64_t* out_offs /* [n_reads + 1] */,
