@@ -60,7 +60,8 @@ int main(int argc, char** argv) {
     }
     if (base.empty() || readsFile.empty() || outFile.empty()) {
         std::cerr << "usage: " << argv[0] << " -r <index base> -f <reads> -o <out.sam> [-e k] [-a all|best] [-x strata] [-I identity] "
-                     "[-S strategy] [-m edit|hamming] [-p uniform|static|dynamic] [-s sparseness] [-K kmer] [-b chunk] [-XA] [-nU]\n";
+                     "[-S strategy] [-m edit|hamming] [-p uniform|static|dynamic] [-s sparseness] [-K kmer] [-b chunk] [-XA] [-nU] "
+                     "[-F mates -O fr|rf|ff -X max insert -N min insert -nD -nI]\n";
         return 2;
     }
     try {
