@@ -604,6 +604,27 @@ def test_pairs_that_start_from_single_end_results(orientation):
     pb.close()
 
 
+@pytest.mark.parametrize("x,orientation", [(0, ca.ORIENTATION_FR), (1, ca.ORIENTATION_RF), (3, ca.ORIENTATION_FF), (2, ca.ORIENTATION_FR)])
+def test_deep_strata_and_fragment_bounds(x, orientation):
+    """cut-offs up to 13 errors (90 % identity on 100 - 151 bp: the strata 1, 3, 5, 9, 13 of the walk and its steps of 4), a lower fragment
+    bound and a tight upper one, mates of different lengths"""
+    rng = np.random.default_rng(4000 + 10 * x + orientation)
+    pairs = []
+    for i in range(150):
+        reads, cut, table, _ = _make_pair(rng, i, int(rng.choice([100, 130, 151])), int(rng.choice([60, 100, 151])), 90, 13, KINDS[i % len(KINDS)],
+                                          ori=orientation if i % 3 else None)
+        pairs.append((reads, cut, table))
+    got, asked, cuts = _run_library(pairs, x, 90, 13, orientation, 420, 150, True, True)
+    deepest = 0
+    for i, (reads, cut, table) in enumerate(pairs):
+        assert cuts[i] == tuple(cut) and max(cut) >= 10
+        ref = RefWalk(table, reads, cut, x, orientation, 420, 150, True, True).run()
+        assert got[i] == ref.sam(), (i, KINDS[i % len(KINDS)])
+        assert asked[i] == list(dict.fromkeys(ref.asked)), (i, asked[i])
+        deepest = max([deepest] + [k for _m, _s, k in asked[i]])
+    assert deepest >= 9
+
+
 def test_hamming_distance_never_trims():
     rng = np.random.default_rng(9)
     pairs = []
