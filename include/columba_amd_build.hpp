@@ -310,7 +310,9 @@ inline std::ofstream openOut(const std::string& name) {
 }
 
 // FASTA files -> <base>.{meta, cct, txt.bin, bwt, brt, rev.brt, sa.<s>, sa.bv.<s>, pos, sna, fsid, headerSN.bin}
-inline void buildIndex(const std::vector<std::string>& fastaFiles, const std::string& base, uint32_t sparseness = 4, uint32_t seedLength = 0) {
+// allSparsenessFactors: the sparse suffix array for every factor 1, 2, 4 ... 128 (`-a`, buildindex.cpp:1914-1918) instead of the one given
+inline void buildIndex(const std::vector<std::string>& fastaFiles, const std::string& base, uint32_t sparseness = 4, uint32_t seedLength = 0,
+                       bool allSparsenessFactors = false) {
     if (sparseness == 0 || (sparseness & (sparseness - 1)) != 0) throw std::runtime_error("the sparseness factor must be a power of two");
     const Text tx = preprocessFastaFiles(fastaFiles, seedLength);
     const std::string& T = tx.T;
@@ -342,13 +344,13 @@ inline void buildIndex(const std::vector<std::string>& fastaFiles, const std::st
         const std::vector<uint32_t> SA = suffixArray(T);
         std::string bwt(n, '$');
         for (size_t i = 0; i < n; i++) bwt[i] = SA[i] > 0 ? T[SA[i] - 1] : T.back();
-        const SparseSA ssa = sparseSuffixArray(SA, sparseness);
-        {
-            std::ofstream f = openOut(base + ".sa.bv." + std::to_string(sparseness));
+        for (uint32_t sf = allSparsenessFactors ? 1u : sparseness; sf <= (allSparsenessFactors ? 128u : sparseness); sf *= 2) {
+            const SparseSA ssa = sparseSuffixArray(SA, sf);
+            std::ofstream f = openOut(base + ".sa.bv." + std::to_string(sf));
             put<uint64_t>(f, (uint64_t)n);
             putAll(f, ssa.bv);
             putAll(f, ssa.counts);
-            std::ofstream g = openOut(base + ".sa." + std::to_string(sparseness));
+            std::ofstream g = openOut(base + ".sa." + std::to_string(sf));
             putAll(g, ssa.samples);
         }
         const std::vector<uint64_t> words = encodeBwt(bwt);

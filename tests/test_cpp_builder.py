@@ -60,6 +60,19 @@ def test_index_files_equal_the_harness_builder(builder, n, sparseness, n_seqs):
     assert back.text.tobytes() == g.tobytes() + b"$" and np.array_equal(back.sa_samples, ix.sa_samples)
 
 
+def test_all_sparseness_factors(builder):
+    """-a: the sparse suffix array for every factor 1 ... 128 (buildindex.cpp:1914-1918), each equal to the build with that factor alone"""
+    exe, tmp = builder
+    g, _ = synth.genome_rep(seed=9, n=6_000, scale=2.0)
+    fa = os.path.join(tmp, "all.fa")
+    _write_fasta(fa, [("s", g[:6000].tobytes())])
+    subprocess.check_call([exe, "-a", "-r", os.path.join(tmp, "alls"), "-f", fa])
+    for sf in (1, 2, 4, 8, 16, 32, 64, 128):
+        subprocess.check_call([exe, "-s", str(sf), "-r", os.path.join(tmp, f"one{sf}"), "-f", fa])
+        for ext in (f"sa.{sf}", f"sa.bv.{sf}"):
+            assert open(os.path.join(tmp, f"alls.{ext}"), "rb").read() == open(os.path.join(tmp, f"one{sf}.{ext}"), "rb").read(), ext
+
+
 def test_text_preprocessing_follows_the_reference(builder):
     """several files, several sequences per file, lower case, a file without a header line, runs of N and other IUPAC codes: positions, names,
     first sequence per file; replaced characters are ACGT, identical between two runs, a seeded pattern with -l"""
