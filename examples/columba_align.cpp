@@ -2,7 +2,7 @@
 // accelerates: reference src/parallel.cpp main / threadEntrySingleEnd / processChunk):
 //   columba_align -r <index base> -f <reads.fq|fa> -o <out.sam> [-e <max distance>] [-a all|best] [-x <strata>]
 //                 [-I <min identity>] [-S <strategy>] [-m edit|hamming] [-p uniform|static|dynamic]
-//                 [-s <SA sparseness>] [-K <k-mer size>] [-b <reads per chunk>] [-XA] [-nU]
+//                 [-s <SA sparseness>] [-K <k-mer size>] [-i <in-text switch>] [-b <reads per chunk>] [-XA] [-nU]
 //                 [-F <mates.fq> -O fr|rf|ff -X <max insert> -N <min insert> -nD -nI]  (read pairs)
 // Read pairs: unless -nI or one of -O / -X / -N is given, orientation and insert-size bounds are inferred from the first pairs of
 // the files as the reference does (parallel.cpp:468-655, :862-935: up to 10 000 reads matched single-end, the pairs whose mates both map
@@ -19,7 +19,7 @@ using namespace columba_amd;
 
 int main(int argc, char** argv) {
     std::string base, readsFile, matesFile, orientation = "fr", outFile, strategyName = "columba", mode = "best", metric = "edit", part = "dynamic", cmdline;
-    int k = 0, x = 0, identity = 95, sparse = 4, kmer = 10;
+    int k = 0, x = 0, identity = 95, sparse = 4, kmer = 10, inTextSwitch = 4;
     size_t chunkReads = 1000000;
     bool xa = false, unmapped = true, discordant = true, noInfer = false, pairParamsGiven = false;
     unsigned maxInsert = 500, minInsert = 0;
@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
             else if (a == "-p") part = val();
             else if (a == "-s") sparse = std::stoi(val());
             else if (a == "-K") kmer = std::stoi(val());
+            else if (a == "-i") inTextSwitch = std::stoi(val()); // (in-text verification switch point, the reference's -i; default 4)
             else if (a == "-b") chunkReads = (size_t)std::stoul(val());
             else if (a == "-XA") xa = true;
             else if (a == "-nU") unmapped = false;
@@ -60,12 +61,12 @@ int main(int argc, char** argv) {
     }
     if (base.empty() || readsFile.empty() || outFile.empty()) {
         std::cerr << "usage: " << argv[0] << " -r <index base> -f <reads> -o <out.sam> [-e k] [-a all|best] [-x strata] [-I identity] "
-                     "[-S strategy] [-m edit|hamming] [-p uniform|static|dynamic] [-s sparseness] [-K kmer] [-b chunk] [-XA] [-nU] "
+                     "[-S strategy] [-m edit|hamming] [-p uniform|static|dynamic] [-s sparseness] [-K kmer] [-i in-text switch] [-b chunk] [-XA] [-nU] "
                      "[-F mates -O fr|rf|ff -X max insert -N min insert -nD -nI]\n";
         return 2;
     }
     try {
-        FMIndex index(base, 4, false, sparse, false, (length_t)kmer);
+        FMIndex index(base, (length_t)inTextSwitch, false, sparse, false, (length_t)kmer);
         const PartitionStrategy ps = part == "uniform" ? UNIFORM : part == "static" ? STATIC : DYNAMIC;
         const DistanceMetric dm = metric == "hamming" ? HAMMING : EDIT;
         NamedStrategy strategy(index, strategyName.c_str(), ps, dm);
