@@ -187,6 +187,14 @@ def test_bmove_adapter_example_matches_python_binding(tmp_path):
     exp = [(i, int(o["begin"]), int(o["end"]), int(o["distance"]), int(o["strand"]))
            for i in range(len(reads)) for o in occ[int(offs[i]):int(offs[i + 1])]]
     assert got == exp and len(exp) > 1000
+    # the same index built by the C++ tool from a FASTA file (columba_build --rlc: include/columba_amd_build.hpp) loads and answers alike
+    build_exe = str(tmp_path / "columba_build")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "columba_build.cpp"),
+                           "-o", build_exe, "-lz"])
+    (tmp_path / "ref.fa").write_bytes(b">seq0\n" + t[:-1] + b"\n")
+    subprocess.check_call([build_exe, "--rlc", "-r", str(tmp_path / "idx_cpp"), "-f", str(tmp_path / "ref.fa")])
+    r2 = subprocess.run([exe, str(tmp_path / "idx_cpp"), str(tmp_path / "reads.txt")], capture_output=True, text=True, check=True)
+    assert r2.stdout == r.stdout and r2.stderr == r.stderr
     err = r.stderr.split("\n")
     assert err[0] == f"nodes {cnt['NODE_COUNTER']}"
     walk = err[1].split()
